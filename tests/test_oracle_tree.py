@@ -1,0 +1,89 @@
+"""Oracle search (PUCT + Gumbel sequential halving) vs reference-generated fixtures.
+
+The evaluator is oracle.stubnet.StubNet on both sides, so every number must match
+bit-for-bit: visit counts, float32-accumulated value sums, chosen move, node count,
+batch sizes, a digest over the whole tree, and the position of the global RNG stream
+after the search."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle.halving import candidates_and_visit_pairs
+from oracle.stubnet import StubNet
+from oracle.tree import MCTSTree, TimeManager, TimeControl
+from tests.helpers import load_json, load_npz, oracle_replay, unhex
+
+
+def tree_digest(tree):
+    h = hashlib.sha256()
+    for i in range(tree.num_nodes):
+        nd = tree.node[i]
+        n = nd.num_children
+        h.update(np.array(nd.action[:n], dtype=np.int32).tobytes())
+        h.update(nd.children_index[:n].astype(np.int32).tobytes())
+        h.update(nd.children_visits[:n].astype(np.int32).tobytes())
+        h.update(nd.children_virtual_loss[:n].astype(np.int32).tobytes())
+        h.update(nd.children_value_sum[:n].astype(np.float64).tobytes())
+        h.update(nd.children_policy[:n].astype(np.float64).tobytes())
+        h.update(np.array([nd.node_visits, nd.virtual_loss], dtype=np.int64).tobytes())
+    return h.hexdigest()
+
+
+def check_root(tree, mv, rec):
+    root = tree.get_root()
+    n = root.num_children
+    assert n == rec["n"]
+    assert [int(a) for a in root.action[:n]] == rec["action"]
+    assert [int(v) for v in root.children_visits[:n]] == rec["child_visits"]
+    assert np.array_equal(root.children_value_sum[:n], unhex(rec["value_sum"]))
+    assert np.array_equal(root.children_policy[:n], unhex(rec["policy"]))
+    assert int(mv) == rec["move"]
+    assert tree.num_nodes == rec["num_nodes"]
+    assert int(root.node_visits) == rec["node_visits"]
+    assert float(root.node_value_sum) == float.fromhex(rec["node_value_sum"])
+    assert float(root.raw_value) == float.fromhex(rec["raw_value"])
+    assert tree_digest(tree) == rec["digest"]
+
+
+def cases(size, kind):
+    return [r for r in load_json(f"trees_s{size}.json") if r["kind"] == kind]
+
+
+def test_halving_schedule():
+    for key, pairs in load_json("tables.json")["halving"].items():
+        n0, v = (int(s) for s in key.split(","))
+        assert [[k, c] for k, c in candidates_and_visit_pairs(n0, v).items()] == pairs
+
+
+@pytest.mark.parametrize("size", [9, 19])
+def test_puct(size):
+    brd = load_npz(f"board_s{size}.npz")
+    for rec in cases(size, "puct"):
+        board = oracle_replay(size, brd["g0_move"], brd["g0_color"], rec["ply"], rec["superko"])
+        net = StubNet(salt=rec["seed"])
+        tree = MCTSTree(net, size, tree_size=2048, batch_size=rec["batch"], cgos_mode=rec["cgos"])
+        mode = TimeControl.STRICT_PLAYOUT if rec["mode"] == "STRICT" else TimeControl.CONSTANT_PLAYOUT
+        np.random.seed(rec["seed"])
+        mv = tree.search_best_move(board, rec["color"], TimeManager(mode, rec["visits"]))
+        assert net.calls == rec["batches"]
+        check_root(tree, mv, rec)
+        assert float(np.random.random_sample()) == float.fromhex(rec["rng_after"])
+
+
+@pytest.mark.parametrize("size", [9, 19])
+def test_gumbel(size):
+    brd = load_npz(f"board_s{size}.npz")
+    for rec in cases(size, "gumbel"):
+        board = oracle_replay(size, brd["g0_move"], brd["g0_color"], rec["ply"], rec["superko"])
+        net = StubNet(salt=100 + rec["seed"])
+        tree = MCTSTree(net, size, tree_size=160 if rec["visits"] <= 100 else 2048)
+        np.random.seed(rec["seed"])
+        mv = tree.generate_move_with_sequential_halving(
+            board, rec["color"], TimeManager(TimeControl.CONSTANT_PLAYOUT, rec["visits"]), True)
+        assert net.calls == rec["batches"]
+        check_root(tree, mv, rec)
+        root = tree.get_root()
+        assert np.array_equal(root.noise, unhex(rec["noise"]))
+        assert np.array_equal(root.improved_policy(), unhex(rec["improved"]))
+        assert float(np.random.random_sample()) == float.fromhex(rec["rng_after"])
