@@ -1,0 +1,161 @@
+/*
+ * tamago_hip.h - C ABI of libtamago_hip.so, the MI355X (gfx950) implementation of
+ * TamaGo's batched MCTS leaf-evaluation path.
+ *
+ * The reference (kobanium/TamaGo @ 2024-12-20) is 100 % Python and has no FFI of its
+ * own; each entry point below replaces the Python function(s) cited next to it, and is
+ * what a ctypes binding inside the reference would call (see INTEGRATION.md for the
+ * exact stubs).  Conventions:
+ *   - every function returns 0 on success, a negative tg_status on failure; the
+ *     message is available from tg_last_error() (thread-local);
+ *   - handles are opaque; a handle is bound to one HIP device and is NOT thread-safe;
+ *   - "host" pointers are caller-owned host memory, "dev" pointers are caller-owned
+ *     device memory on the handle's device (e.g. torch tensors' data_ptr());
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls that
+ *     take a stream only ENQUEUE work; the *_host convenience calls synchronise.
+ *   - board coordinates follow the reference: pos = x + y*(S+2) on the padded board,
+ *     PASS = 0, RESIGN = -1 (board/constant.py:4-31); colours EMPTY 0 / BLACK 1 /
+ *     WHITE 2 / OUT_OF_BOARD 3 (board/stone.py:5-11).
+ */
+#ifndef TAMAGO_HIP_H
+#define TAMAGO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum tg_status {
+    TG_OK = 0,
+    TG_ERR_ARG = -1,      /* bad argument                          */
+    TG_ERR_HIP = -2,      /* HIP runtime error (no GPU, OOM, ...)  */
+    TG_ERR_STATE = -3,    /* call sequence violated                */
+    TG_ERR_OVERFLOW = -4  /* node pool / RNG window exhausted      */
+} tg_status;
+
+/* ---- library ------------------------------------------------------------------------ */
+int tg_abi_version(void);                 /* increases on every incompatible change      */
+const char *tg_last_error(void);          /* message of the last failing call            */
+int tg_device_count(int *count);          /* replaces nn/utility.py:12-24 get_torch_device */
+
+/* ---- DualNet forward (nn/network/dual_net.py:41-106, res_block.py:8-38,
+ *      head/policy_head.py:7-39, head/value_head.py:7-39) ------------------------------- */
+typedef struct tg_net tg_net;
+
+/* Number of floats tg_net_create expects for a board size: the reference state_dict
+ * (nn/utility.py:139-159) flattened in this key order, num_batches_tracked skipped:
+ *   conv_layer.weight [64,6,3,3]; bn_layer.{weight,bias,running_mean,running_var} [64];
+ *   for b in 0..5: blocks.b.conv1.weight, blocks.b.conv2.weight [64,64,3,3],
+ *                  blocks.b.bn1.{w,b,mean,var}, blocks.b.bn2.{w,b,mean,var} [64];
+ *   policy_head.conv_layer.weight [2,64,1,1]; policy_head.bn_layer.{w,b,mean,var} [2];
+ *   policy_head.fc_layer.weight [A,2P]; policy_head.fc_layer.bias [A];
+ *   value_head.conv_layer.weight [1,64,1,1]; value_head.bn_layer.{w,b,mean,var} [1];
+ *   value_head.fc_layer.weight [3,P]; value_head.fc_layer.bias [3].       (P=S*S, A=P+1) */
+size_t tg_net_param_count(int board_size);
+
+/* Build a network on `device` from raw (un-folded) fp32 parameters; BatchNorm (eval
+ * mode, eps 1e-5 stem / 2e-5 elsewhere) is folded and the 3x3 weights are re-ordered
+ * into MFMA fragment order on the host.  Replaces load_network, nn/utility.py:139-159. */
+int tg_net_create(int board_size, int device, const float *params, size_t n_params,
+                  tg_net **out);
+int tg_net_destroy(tg_net *net);
+int tg_net_board_size(const tg_net *net);
+
+/* Forward pass on device-resident planes [B,6,S,S] fp32 -> policy [B,A], value [B,3].
+ * want_logits = 0: softmax(policy), softmax(value)     (DualNet.inference, :81-91)
+ * want_logits = 1: raw policy logits, softmax(value)   (inference_with_policy_logits, :94-106) */
+int tg_net_forward_dev(tg_net *net, const float *planes_dev, int batch, int want_logits,
+                       float *policy_dev, float *value_dev, void *stream);
+/* Same with host buffers (H2D, kernel, D2H, synchronise) - the reference's own boundary:
+ * host tensor in, host tensors out. */
+int tg_net_forward_host(tg_net *net, const float *planes_host, int batch, int want_logits,
+                        float *policy_host, float *value_host);
+/* Name (for rocprof) and algorithmic FLOPs per position of the dominant kernel. */
+const char *tg_net_kernel_name(const tg_net *net, int batch);
+double tg_net_flops_per_position(int board_size);
+
+/* ---- featurise (nn/feature.py:10-57 + go_board.py:468-478) -------------------------- */
+/* cells_dev: uint8 [B, P] on-board cell colours, row-major from the top-left point;
+ * to_move: int8 [B] (1 black / 2 white); prev_move: int32 [B] padded-board coordinate of
+ * the previous move (0 = PASS); moves: int32 [B] the board's move counter (starts at 1).
+ * Writes fp32 planes [B,6,S,S]. */
+int tg_featurize_dev(int board_size, const uint8_t *cells_dev, const int8_t *to_move_dev,
+                     const int32_t *prev_move_dev, const int32_t *moves_dev, int batch,
+                     float *planes_dev, void *stream);
+
+/* ---- batched tree search (mcts/tree.py, mcts/node.py, mcts/pucb/pucb.py,
+ *      mcts/batch_data.py, board/ as called from the search) --------------------------- */
+typedef struct tg_search tg_search;
+
+typedef struct tg_search_config {
+    int32_t board_size;      /* S: 9 or 19 (any 5..19)                                    */
+    int32_t num_trees;       /* T independent search trees ("boards") driven in lock-step */
+    int32_t tree_size;       /* nodes per tree (MCTSTree tree_size, tree.py:29)           */
+    int32_t batch_size;      /* leaves per tree per mini-batch (NN_BATCH_SIZE)            */
+    int32_t cgos_mode;       /* node.py:153-155                                           */
+    int32_t check_superko;   /* GoBoard(check_superko=...), go_board.py:285-301           */
+    int32_t device;
+    int32_t reserved;
+} tg_search_config;
+
+/* Root position of one tree, as the reference's GoBoard holds it. */
+typedef struct tg_root_position {
+    const uint8_t *cells;        /* [(S+2)^2] padded board, colours incl. OUT_OF_BOARD    */
+    const uint64_t *hash_history;/* [moves] positional hashes by move index (slot 0 = 0);
+                                    may be NULL when check_superko == 0                    */
+    uint64_t hash;               /* current positional hash                               */
+    int32_t moves;               /* GoBoard.moves (1 = empty game)                         */
+    int32_t ko_pos, ko_move;     /* go_board.py:173-177                                   */
+    int32_t prev_move;           /* record.pos[moves-1] (0 = PASS / none)                 */
+    int32_t prev_prev_move;      /* record.pos[moves-2]                                   */
+    int32_t to_move;             /* 1 black / 2 white                                     */
+} tg_root_position;
+
+int tg_search_create(const tg_search_config *cfg, tg_search **out);
+int tg_search_destroy(tg_search *s);
+
+/* Zobrist keys uint64 [4][(S+2)^2] used for positional superko (board/zobrist_hash.py);
+ * the caller owns the key table so that its own GoBoard hashes stay consistent. */
+int tg_search_set_zobrist(tg_search *s, const uint64_t *keys, size_t n);
+
+/* Reset tree `t` to a single un-evaluated root for `pos` (tree.py:49-54 / :330-336,
+ * first half: num_nodes = 0, expand_node(root)). */
+int tg_search_set_root(tg_search *s, int tree, const tg_root_position *pos);
+
+/* Feed the per-tree random streams.  The reference draws the Dirichlet "tentative"
+ * prior (tree.py:509-519) and Gumbel noise (node.py:275-278) from numpy's global
+ * legacy MT19937 stream; bit-exact parity needs the host's libm log(), so the host
+ * turns uniform doubles u_i into e_i = -log(1-u_i) and hands them over in stream
+ * order: tree t consumes exp_stream[t*stride + cursor ...].  `count` values per tree. */
+int tg_search_set_rng(tg_search *s, const double *exp_stream_host, size_t stride, size_t count);
+/* Doubles each tree consumed since the last tg_search_set_rng (host array [T]). */
+int tg_search_rng_consumed(tg_search *s, int64_t *consumed_host);
+
+/* PUCT: run up to `max_leaves` descents per tree (tree.py:199-244 search_mcts: select by
+ * PUCB, play, virtual loss, expand, featurise, queue).  Leaf planes go to planes_dev
+ * [T, batch_size, 6, S, S]; n_leaves_dev[T] receives the number queued per tree. */
+int tg_search_select_puct(tg_search *s, int max_leaves, float *planes_dev, int32_t *n_leaves_dev,
+                          void *stream);
+/* Evaluate the root of every tree: writes planes [T,1,6,S,S] (tree.py:52-53). */
+int tg_search_root_planes(tg_search *s, float *planes_dev, void *stream);
+/* Write NN outputs back and back up values (tree.py:273-315 process_mini_batch).
+ * policy_dev [T, batch_size, A], value_dev [T, batch_size, 3] in the slot order of the
+ * preceding select / root_planes call; use_logit as in tree.py:293-294. */
+int tg_search_backup(tg_search *s, const float *policy_dev, const float *value_dev,
+                     int use_logit, void *stream);
+
+/* Read-side of MCTSNode for node `node` of tree `t` (node.py:21-39); any pointer may be
+ * NULL.  Arrays have A entries. Synchronises the stream used by the last call. */
+int tg_search_read_node(tg_search *s, int tree, int node, int32_t *num_children,
+                        int32_t *node_visits, int32_t *action, int32_t *children_index,
+                        int32_t *children_visits, int32_t *children_virtual_loss,
+                        double *children_value_sum, double *children_policy,
+                        double *children_value, float *node_value_sum, float *raw_value);
+int tg_search_num_nodes(tg_search *s, int32_t *num_nodes_host /* [T] */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TAMAGO_HIP_H */

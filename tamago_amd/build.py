@@ -1,0 +1,63 @@
+"""In-tree build of libtamago_hip.so (hipcc, gfx950 only).
+
+``python -m tamago_amd.build`` or ``tamago_amd.build.build()``.  Objects are cached under
+``build/`` by source mtime; the shared library lands next to this file so that it ships
+with the repository snapshot to the GPU box.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libtamago_hip.so")
+OBJ_DIR = os.path.join(REPO, "build", "obj")
+
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+         "-ffp-contract=off"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found - the HIP extension cannot be built")
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)
+                  if f.endswith(".hip") or f.endswith(".cpp"))
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    hipcc = _hipcc()
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(REPO, "include", "tamago_hip.h"))
+    newest_header = max(os.path.getmtime(h) for h in headers)
+    objs = []
+    rebuilt = False
+    for src in sources():
+        obj = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
+        objs.append(obj)
+        stale = force or not os.path.exists(obj) or \
+            os.path.getmtime(obj) < max(os.path.getmtime(src), newest_header)
+        if stale:
+            cmd = [hipcc] + FLAGS + ["-x", "hip", "-c", src, "-o", obj]
+            if verbose:
+                print("[tamago_amd.build]", " ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            rebuilt = True
+    if rebuilt or not os.path.exists(LIB):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+        if verbose:
+            print("[tamago_amd.build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,41 @@
+// Library-level entry points of libtamago_hip.so: error reporting and device queries.
+#include "common.h"
+
+namespace tg {
+
+std::string &last_error() {
+    static thread_local std::string msg;
+    return msg;
+}
+
+int fail(int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    last_error() = buf;
+    return code;
+}
+
+}  // namespace tg
+
+extern "C" {
+
+int tg_abi_version(void) { return 1; }
+
+const char *tg_last_error(void) { return tg::last_error().c_str(); }
+
+int tg_device_count(int *count) {
+    if (!count) return tg::fail(TG_ERR_ARG, "tg_device_count: null argument");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return tg::fail(TG_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return TG_OK;
+}
+
+}  // extern "C"

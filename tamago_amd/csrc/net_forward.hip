@@ -1,0 +1,549 @@
+// DualNet forward for gfx950 (MI355X): one fused, persistent kernel for the whole network.
+//
+// Replaces nn/network/dual_net.py:41-106 (+ res_block.py:36-39, head/policy_head.py:33-39,
+// head/value_head.py:33-39) as run by mcts/tree.py:280-285.
+//
+// Design (see DESIGN.md "forward kernel"):
+//  * A workgroup (4 wavefronts) owns G boards and carries them through all 13 3x3
+//    convolutions + both heads.  Activations never leave the CU: one fp32 LDS buffer
+//    [G*P rows][64 ch] (row stride 72 floats = conflict-free ds_read_b128 A fragments), the
+//    layer result lives in MFMA accumulators until every wave has finished reading the
+//    layer input, then overwrites it in place; the residual-block input stays in VGPRs.
+//  * Each 3x3 conv is an implicit GEMM  M = G*P rows, N = 64, K = 9 taps x 64 ch  on
+//    v_mfma_f32_16x16x4_f32 (exact fp32, the only fp32 matrix path on gfx950).  Wave w owns
+//    output channels [16w,16w+16): B fragments (weights) are pre-shuffled on the host into
+//    fragment order, so one coalesced global_load_dwordx4 (1 KiB per wave, L2 resident)
+//    feeds four MFMAs per M-tile; A fragments are one ds_read_b128 per four MFMAs.
+//    Zero padding is an address select to a zero row (no branches).
+//  * BatchNorm is folded to a per-channel scale/shift applied in the epilogue together with
+//    the residual add and ReLU.
+//  * Heads (1x1 conv + BN + ReLU + FC + softmax) run on the VALU from the same LDS buffer.
+#include "common.h"
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kFilters = 64;
+constexpr int kBlocks = 6;
+constexpr int kConvLayers = 1 + 2 * kBlocks;  // 13
+constexpr int kRowFloats = 72;                // activation row stride in LDS (64 + 8 pad)
+constexpr int kRowBytes = kRowFloats * 4;     // 288
+
+struct NetDev {
+    const float *w0frag;  // [4 wave][9 tap][64 lane][2]         stem 6->64 (cin padded to 8)
+    const float *wfrag;   // [12 layer][4 wave][9 tap][4 s][64 lane][4]
+    const float *scale;   // [13][64] folded BN scale
+    const float *shift;   // [13][64] folded BN shift
+    const float *hp_w;    // [2][64]  policy 1x1 conv
+    const float *hv_w;    // [64]     value 1x1 conv
+    const float *head_ss; // [6]      policy scale0,shift0,scale1,shift1, value scale,shift
+    const float *pfc_wT;  // [2P][A]  policy FC, transposed
+    const float *pfc_b;   // [A]
+    const float *vfc_w;   // [3][P]
+    const float *vfc_b;   // [3]
+};
+
+template <int S, int G>
+struct FwdCfg {
+    static constexpr int P = S * S;
+    static constexpr int A = P + 1;
+    static constexpr int M = G * P;
+    static constexpr int MT = (M + 15) / 16;
+    static constexpr int ACT_BYTES = M * kRowBytes;
+    static constexpr int ZROW = ACT_BYTES;               // 288 B zero row
+    static constexpr int AUX = ACT_BYTES + kRowBytes;    // in8 [M][8] + zero8, later head scratch
+    static constexpr int ZERO8 = AUX + M * 32;
+    static constexpr int LDS_BYTES = ZERO8 + 32;
+    static constexpr int WAVES_PER_SIMD = (2 * LDS_BYTES <= 160 * 1024) ? 2 : 1;
+};
+
+__device__ __forceinline__ float lds_f32(const unsigned char *smem, int byte_off) {
+    return *reinterpret_cast<const float *>(smem + byte_off);
+}
+__device__ __forceinline__ f32x4 lds_f32x4(const unsigned char *smem, int byte_off) {
+    return *reinterpret_cast<const f32x4 *>(smem + byte_off);
+}
+
+template <int S, int G>
+__global__ __launch_bounds__(256, (FwdCfg<S, G>::WAVES_PER_SIMD)) void dualnet_fwd_kernel(
+    NetDev net, const float *__restrict__ planes, int batch, int want_logits,
+    float *__restrict__ policy, float *__restrict__ value) {
+    using C = FwdCfg<S, G>;
+    constexpr int P = C::P, A = C::A, M = C::M, MT = C::MT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6;   // output-channel tile
+    const int lane = tid & 63;
+    const int li = lane & 15;    // A row / B,C column within a tile
+    const int lg = lane >> 4;    // k index within an MFMA
+
+    // ---- per-lane constants ----------------------------------------------------------
+    // tap validity for row (mt*16 + li): bit t of mask[mt]
+    unsigned mask[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int r = mt * 16 + li;
+        const int bl = r / P;
+        const int p = r - bl * P;
+        const int y = p / S, x = p - y * S;
+        unsigned m = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            if (r < M && yy >= 0 && yy < S && xx >= 0 && xx < S) m |= 1u << t;
+        }
+        mask[mt] = m;
+    }
+    const int lane_act = li * kRowBytes + lg * 16;   // + mt*16*288 + tap offset + s*64
+    const int lane_zero = C::ZROW + lg * 16;
+    const int lane_in8 = C::AUX + li * 32 + lg * 4;  // + mt*16*32 + tap offset (+16 for k-step 1)
+    const int lane_zero8 = C::ZERO8 + lg * 4;
+
+    // zero rows (written once, never overwritten)
+    for (int e = tid; e < kRowFloats; e += 256) reinterpret_cast<float *>(smem + C::ZROW)[e] = 0.f;
+    if (tid < 8) reinterpret_cast<float *>(smem + C::ZERO8)[tid] = 0.f;
+
+    const int n_groups = (batch + G - 1) / G;
+    for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const int b0 = grp * G;
+
+        // ---- stage the input planes: global [b][6][P] -> LDS in8 [row][8] -----------------
+        {
+            float *in8 = reinterpret_cast<float *>(smem + C::AUX);
+            for (int e = tid; e < G * 6 * P; e += 256) {
+                const int bl = e / (6 * P);
+                const int rem = e - bl * 6 * P;
+                const int c = rem / P;
+                const int p = rem - c * P;
+                const int b = b0 + bl;
+                const float v = (b < batch) ? planes[(size_t)b * 6 * P + rem] : 0.f;
+                in8[(bl * P + p) * 8 + c] = v;
+            }
+            for (int e = tid; e < M * 2; e += 256) in8[(e >> 1) * 8 + 6 + (e & 1)] = 0.f;
+        }
+        __syncthreads();
+
+        f32x4 acc[MT];
+        f32x4 res[MT];
+
+        // ---- layer 0: 6(8) -> 64, K = 9 taps x 2 k-steps -----------------------------------
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        {
+            const float2 *w0 = reinterpret_cast<const float2 *>(net.w0frag) + wave * 9 * 64 + lane;
+            float2 bnext = w0[0];
+#pragma unroll 1
+            for (int tap = 0; tap < 9; ++tap) {
+                const float2 bcur = bnext;
+                bnext = w0[(tap < 8 ? tap + 1 : 8) * 64];
+                const int toff = ((tap / 3 - 1) * S + (tap % 3 - 1)) * 32;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const bool ok = (mask[mt] >> tap) & 1u;
+                    const int a = ok ? lane_in8 + mt * 16 * 32 + toff : lane_zero8;
+                    const float a0 = lds_f32(smem, a);
+                    const float a1 = lds_f32(smem, a + 16);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bcur.x, acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bcur.y, acc[mt], 0, 0, 0);
+                }
+            }
+        }
+
+        // ---- epilogue + layers 1..12 -----------------------------------------------------------
+#pragma unroll 1
+        for (int layer = 0; layer < kConvLayers; ++layer) {
+            if (layer > 0) {
+                // conv `layer` reads the activation buffer written by the previous epilogue
+                __syncthreads();
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const f32x4 *wl = reinterpret_cast<const f32x4 *>(net.wfrag) +
+                                  ((size_t)((layer - 1) * 4 + wave) * 9) * 4 * 64 + lane;
+                f32x4 bnext[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) bnext[s] = wl[s * 64];
+#pragma unroll 1
+                for (int tap = 0; tap < 9; ++tap) {
+                    f32x4 bcur[4];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) bcur[s] = bnext[s];
+                    const int tn = tap < 8 ? tap + 1 : 8;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) bnext[s] = wl[(tn * 4 + s) * 64];
+                    const int toff = ((tap / 3 - 1) * S + (tap % 3 - 1)) * kRowBytes;
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const bool ok = (mask[mt] >> tap) & 1u;
+                        const int a = ok ? lane_act + mt * 16 * kRowBytes + toff : lane_zero;
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) {
+                            const f32x4 av = lds_f32x4(smem, a + s * 64);
+                            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bcur[s].x, acc[mt], 0, 0, 0);
+                            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bcur[s].y, acc[mt], 0, 0, 0);
+                            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bcur[s].z, acc[mt], 0, 0, 0);
+                            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bcur[s].w, acc[mt], 0, 0, 0);
+                        }
+                    }
+                }
+                // every wave must be done reading before anyone overwrites the buffer
+                __syncthreads();
+            }
+            // epilogue: BN scale/shift (+ residual) + ReLU, C/D layout: col = lane&15, row = 4*(lane>>4)+j
+            const float sc = net.scale[layer * 64 + wave * 16 + li];
+            const float sh = net.shift[layer * 64 + wave * 16 + li];
+            const bool block_out = (layer & 1) == 0;       // stem (0) and every conv2 (2,4,..,12)
+            const bool add_res = block_out && layer > 0;
+            float *act = reinterpret_cast<float *>(smem);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = fmaf(acc[mt][j], sc, sh);
+                    if (add_res) v += res[mt][j];
+                    v = fmaxf(v, 0.f);
+                    if (block_out) res[mt][j] = v;
+                    const int r = mt * 16 + lg * 4 + j;
+                    if (r < M) act[r * kRowFloats + wave * 16 + li] = v;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- heads ------------------------------------------------------------------------------
+        float *hpol = reinterpret_cast<float *>(smem + C::AUX);   // [G][2P]
+        float *hval = hpol + G * 2 * P;                           // [G][P]
+        float *plog = hval + G * P;                               // [G][A]
+        float *vlog = plog + G * A;                               // [G][4]
+        {
+            const float ps0 = net.head_ss[0], pt0 = net.head_ss[1];
+            const float ps1 = net.head_ss[2], pt1 = net.head_ss[3];
+            const float vs = net.head_ss[4], vt = net.head_ss[5];
+            for (int r = tid; r < M; r += 256) {
+                float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+#pragma unroll
+                for (int k4 = 0; k4 < 16; ++k4) {
+                    const f32x4 xv = lds_f32x4(smem, r * kRowBytes + k4 * 16);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int k = k4 * 4 + j;
+                        d0 = fmaf(xv[j], net.hp_w[k], d0);
+                        d1 = fmaf(xv[j], net.hp_w[64 + k], d1);
+                        d2 = fmaf(xv[j], net.hv_w[k], d2);
+                    }
+                }
+                const int bl = r / P, p = r - bl * P;
+                hpol[bl * 2 * P + p] = fmaxf(fmaf(d0, ps0, pt0), 0.f);
+                hpol[bl * 2 * P + P + p] = fmaxf(fmaf(d1, ps1, pt1), 0.f);
+                hval[bl * P + p] = fmaxf(fmaf(d2, vs, vt), 0.f);
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < G * A + G * 3; e += 256) {
+            if (e < G * A) {
+                const int bl = e / A, a = e - bl * A;
+                const float *h = hpol + bl * 2 * P;
+                const float *wT = net.pfc_wT + a;
+                float s0 = net.pfc_b[a], s1 = 0.f, s2 = 0.f, s3 = 0.f;
+                int j = 0;
+                for (; j + 4 <= 2 * P; j += 4) {
+                    s0 = fmaf(h[j], wT[(size_t)j * A], s0);
+                    s1 = fmaf(h[j + 1], wT[(size_t)(j + 1) * A], s1);
+                    s2 = fmaf(h[j + 2], wT[(size_t)(j + 2) * A], s2);
+                    s3 = fmaf(h[j + 3], wT[(size_t)(j + 3) * A], s3);
+                }
+                for (; j < 2 * P; ++j) s0 = fmaf(h[j], wT[(size_t)j * A], s0);
+                plog[e] = (s0 + s1) + (s2 + s3);
+            } else {
+                const int q = e - G * A;
+                const int bl = q / 3, c = q - bl * 3;
+                const float *h = hval + bl * P;
+                const float *wv = net.vfc_w + c * P;
+                float s0 = net.vfc_b[c];
+                for (int j = 0; j < P; ++j) s0 = fmaf(h[j], wv[j], s0);
+                vlog[bl * 4 + c] = s0;
+            }
+        }
+        __syncthreads();
+        for (int bl = wave; bl < G; bl += 4) {
+            const int b = b0 + bl;
+            if (b >= batch) continue;
+            float m = -INFINITY;
+            for (int a = lane; a < A; a += 64) m = fmaxf(m, plog[bl * A + a]);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+            float sum = 0.f;
+            for (int a = lane; a < A; a += 64) sum += expf(plog[bl * A + a] - m);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+            const float inv = 1.f / sum;
+            for (int a = lane; a < A; a += 64) {
+                const float lg_ = plog[bl * A + a];
+                policy[(size_t)b * A + a] = want_logits ? lg_ : expf(lg_ - m) * inv;
+            }
+            if (lane < 3) {
+                const float v0 = vlog[bl * 4], v1 = vlog[bl * 4 + 1], v2 = vlog[bl * 4 + 2];
+                const float vm = fmaxf(v0, fmaxf(v1, v2));
+                const float e0 = expf(v0 - vm), e1 = expf(v1 - vm), e2 = expf(v2 - vm);
+                const float es = e0 + e1 + e2;
+                const float mine = lane == 0 ? e0 : (lane == 1 ? e1 : e2);
+                value[(size_t)b * 3 + lane] = mine / es;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+// ======================================================================================
+// host side
+// ======================================================================================
+struct tg_net {
+    int board_size = 0;
+    int device = 0;
+    int num_cus = 256;
+    NetDev dev{};
+    std::vector<void *> allocs;
+    // staging buffers for the host-pointer entry point
+    float *st_planes = nullptr, *st_policy = nullptr, *st_value = nullptr;
+    int st_cap = 0;
+};
+
+namespace {
+
+struct ParamReader {
+    const float *p;
+    size_t left;
+    const float *take(size_t n) {
+        const float *r = p;
+        p += n;
+        left -= n;
+        return r;
+    }
+    std::vector<float> vec(size_t n) {
+        const float *r = take(n);
+        return std::vector<float>(r, r + n);
+    }
+};
+
+void fold_bn(ParamReader &rd, int c, double eps, float *scale, float *shift) {
+    const float *w = rd.take(c), *b = rd.take(c), *mean = rd.take(c), *var = rd.take(c);
+    for (int i = 0; i < c; ++i) {
+        const double s = (double)w[i] / std::sqrt((double)var[i] + eps);
+        scale[i] = (float)s;
+        shift[i] = (float)((double)b[i] - (double)mean[i] * s);
+    }
+}
+
+int upload(tg_net *net, const std::vector<float> &h, const float **dst) {
+    void *d = nullptr;
+    TG_HIP(hipMalloc(&d, h.size() * sizeof(float)));
+    net->allocs.push_back(d);
+    TG_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    *dst = static_cast<const float *>(d);
+    return TG_OK;
+}
+
+template <int S, int G>
+int launch(tg_net *net, const float *planes, int batch, int want_logits, float *policy,
+           float *value, hipStream_t stream) {
+    using C = FwdCfg<S, G>;
+    auto kern = dualnet_fwd_kernel<S, G>;
+    static bool attr_set[16] = {};
+    if (!attr_set[net->device & 15]) {
+        TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+        attr_set[net->device & 15] = true;
+    }
+    const int groups = (batch + G - 1) / G;
+    const int max_blocks = net->num_cus * C::WAVES_PER_SIMD;
+    const int grid = groups < max_blocks ? groups : max_blocks;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), C::LDS_BYTES, stream, net->dev, planes, batch,
+                       want_logits, policy, value);
+    TG_HIP(hipGetLastError());
+    return TG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t tg_net_param_count(int board_size) {
+    const size_t p = (size_t)board_size * board_size, a = p + 1;
+    size_t n = 64 * 6 * 9 + 4 * 64;
+    n += (size_t)kBlocks * (2 * 64 * 64 * 9 + 8 * 64);
+    n += 2 * 64 + 4 * 2 + a * 2 * p + a;
+    n += 64 + 4 + 3 * p + 3;
+    return n;
+}
+
+double tg_net_flops_per_position(int board_size) {
+    const double p = (double)board_size * board_size, a = p + 1;
+    double macs = p * 64 * 6 * 9 + 12.0 * p * 64 * 64 * 9;   // padding taps counted
+    macs += p * 64 * 2 + 2 * p * a + p * 64 + p * 3;
+    return 2.0 * macs;
+}
+
+int tg_net_board_size(const tg_net *net) { return net ? net->board_size : 0; }
+
+int tg_net_create(int board_size, int device, const float *params, size_t n_params, tg_net **out) {
+    if (!out || !params) return tg::fail(TG_ERR_ARG, "tg_net_create: null argument");
+    if (board_size != 9 && board_size != 19)
+        return tg::fail(TG_ERR_ARG, "tg_net_create: board size %d not built (9 and 19 are)", board_size);
+    if (n_params != tg_net_param_count(board_size))
+        return tg::fail(TG_ERR_ARG, "tg_net_create: expected %zu parameters, got %zu",
+                        tg_net_param_count(board_size), n_params);
+    TG_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    TG_HIP(hipGetDeviceProperties(&prop, device));
+    tg_net *net = new tg_net;
+    net->board_size = board_size;
+    net->device = device;
+    net->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+
+    const int P = board_size * board_size, A = P + 1;
+    ParamReader rd{params, n_params};
+    std::vector<float> scale(13 * 64), shift(13 * 64);
+
+    // stem: conv_layer.weight [64][6][3][3] -> w0frag[w][tap][lane][2]
+    std::vector<float> w0(4 * 9 * 64 * 2, 0.f);
+    {
+        const float *w = rd.take(64 * 6 * 9);
+        for (int wv = 0; wv < 4; ++wv)
+            for (int tap = 0; tap < 9; ++tap)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 2; ++j) {
+                        const int n = lane & 15, g = lane >> 4, cin = 4 * j + g, cout = 16 * wv + n;
+                        const float v = cin < 6 ? w[(cout * 6 + cin) * 9 + tap] : 0.f;
+                        w0[((wv * 9 + tap) * 64 + lane) * 2 + j] = v;
+                    }
+        fold_bn(rd, 64, 1e-5, &scale[0], &shift[0]);
+    }
+    // residual blocks: layer index 1 + 2b (conv1), 2 + 2b (conv2)
+    std::vector<float> wf((size_t)12 * 4 * 9 * 4 * 64 * 4);
+    for (int b = 0; b < kBlocks; ++b) {
+        const float *wc[2] = {rd.take(64 * 64 * 9), nullptr};
+        wc[1] = rd.take(64 * 64 * 9);
+        for (int c = 0; c < 2; ++c) {
+            const int layer = 2 * b + c;  // 0..11
+            for (int wv = 0; wv < 4; ++wv)
+                for (int tap = 0; tap < 9; ++tap)
+                    for (int s = 0; s < 4; ++s)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 4; ++j) {
+                                const int n = lane & 15, g = lane >> 4;
+                                const int cin = 16 * s + 4 * g + j, cout = 16 * wv + n;
+                                wf[(((((size_t)layer * 4 + wv) * 9 + tap) * 4 + s) * 64 + lane) * 4 + j] =
+                                    wc[c][(cout * 64 + cin) * 9 + tap];
+                            }
+        }
+        fold_bn(rd, 64, 2e-5, &scale[(1 + 2 * b) * 64], &shift[(1 + 2 * b) * 64]);
+        fold_bn(rd, 64, 2e-5, &scale[(2 + 2 * b) * 64], &shift[(2 + 2 * b) * 64]);
+    }
+    // heads
+    std::vector<float> hp_w = rd.vec(2 * 64);
+    std::vector<float> head_ss(6);
+    {
+        float sc[2], sh[2];
+        fold_bn(rd, 2, 2e-5, sc, sh);
+        head_ss[0] = sc[0]; head_ss[1] = sh[0]; head_ss[2] = sc[1]; head_ss[3] = sh[1];
+    }
+    std::vector<float> pfc_wT((size_t)2 * P * A);
+    {
+        const float *w = rd.take((size_t)A * 2 * P);
+        for (int a = 0; a < A; ++a)
+            for (int j = 0; j < 2 * P; ++j) pfc_wT[(size_t)j * A + a] = w[(size_t)a * 2 * P + j];
+    }
+    std::vector<float> pfc_b = rd.vec(A);
+    std::vector<float> hv_w = rd.vec(64);
+    fold_bn(rd, 1, 2e-5, &head_ss[4], &head_ss[5]);
+    std::vector<float> vfc_w = rd.vec((size_t)3 * P);
+    std::vector<float> vfc_b = rd.vec(3);
+    if (rd.left != 0) {
+        delete net;
+        return tg::fail(TG_ERR_ARG, "tg_net_create: parameter blob not fully consumed");
+    }
+
+    int rc = TG_OK;
+    if ((rc = upload(net, w0, &net->dev.w0frag)) || (rc = upload(net, wf, &net->dev.wfrag)) ||
+        (rc = upload(net, scale, &net->dev.scale)) || (rc = upload(net, shift, &net->dev.shift)) ||
+        (rc = upload(net, hp_w, &net->dev.hp_w)) || (rc = upload(net, hv_w, &net->dev.hv_w)) ||
+        (rc = upload(net, head_ss, &net->dev.head_ss)) || (rc = upload(net, pfc_wT, &net->dev.pfc_wT)) ||
+        (rc = upload(net, pfc_b, &net->dev.pfc_b)) || (rc = upload(net, vfc_w, &net->dev.vfc_w)) ||
+        (rc = upload(net, vfc_b, &net->dev.vfc_b))) {
+        tg_net_destroy(net);
+        return rc;
+    }
+    *out = net;
+    return TG_OK;
+}
+
+int tg_net_destroy(tg_net *net) {
+    if (!net) return TG_OK;
+    (void)hipSetDevice(net->device);
+    for (void *p : net->allocs) (void)hipFree(p);
+    if (net->st_planes) (void)hipFree(net->st_planes);
+    if (net->st_policy) (void)hipFree(net->st_policy);
+    if (net->st_value) (void)hipFree(net->st_value);
+    delete net;
+    return TG_OK;
+}
+
+static int pick_group(int board_size, int batch, int num_cus) {
+    if (board_size != 9) return 1;
+    // small batches: one board per workgroup fills more CUs; large batches: 3 boards per
+    // workgroup (243 of 256 MFMA rows used instead of 81 of 96)
+    return batch > 2 * num_cus ? 3 : 1;
+}
+
+const char *tg_net_kernel_name(const tg_net *net, int batch) {
+    if (!net) return "";
+    if (net->board_size == 19) return "dualnet_fwd_kernel<19, 1>";
+    return pick_group(9, batch, net->num_cus) == 3 ? "dualnet_fwd_kernel<9, 3>" : "dualnet_fwd_kernel<9, 1>";
+}
+
+int tg_net_forward_dev(tg_net *net, const float *planes_dev, int batch, int want_logits,
+                       float *policy_dev, float *value_dev, void *stream) {
+    if (batch < 0) return tg::fail(TG_ERR_ARG, "tg_net_forward_dev: negative batch");
+    if (batch == 0) return TG_OK;
+    if (!net || !planes_dev || !policy_dev || !value_dev)
+        return tg::fail(TG_ERR_ARG, "tg_net_forward_dev: null argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (net->board_size == 19)
+        return launch<19, 1>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st);
+    if (pick_group(9, batch, net->num_cus) == 3)
+        return launch<9, 3>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st);
+    return launch<9, 1>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st);
+}
+
+int tg_net_forward_host(tg_net *net, const float *planes_host, int batch, int want_logits,
+                        float *policy_host, float *value_host) {
+    if (batch <= 0) return batch == 0 ? TG_OK : tg::fail(TG_ERR_ARG, "negative batch");
+    if (!net || !planes_host || !policy_host || !value_host)
+        return tg::fail(TG_ERR_ARG, "tg_net_forward_host: null argument");
+    TG_HIP(hipSetDevice(net->device));
+    const size_t P = (size_t)net->board_size * net->board_size, A = P + 1;
+    if (batch > net->st_cap) {
+        if (net->st_planes) { (void)hipFree(net->st_planes); (void)hipFree(net->st_policy); (void)hipFree(net->st_value); }
+        net->st_planes = net->st_policy = net->st_value = nullptr;
+        net->st_cap = 0;
+        TG_HIP(hipMalloc(reinterpret_cast<void **>(&net->st_planes), batch * 6 * P * sizeof(float)));
+        TG_HIP(hipMalloc(reinterpret_cast<void **>(&net->st_policy), batch * A * sizeof(float)));
+        TG_HIP(hipMalloc(reinterpret_cast<void **>(&net->st_value), batch * 3 * sizeof(float)));
+        net->st_cap = batch;
+    }
+    TG_HIP(hipMemcpy(net->st_planes, planes_host, batch * 6 * P * sizeof(float), hipMemcpyHostToDevice));
+    int rc = tg_net_forward_dev(net, net->st_planes, batch, want_logits, net->st_policy, net->st_value, nullptr);
+    if (rc) return rc;
+    TG_HIP(hipMemcpy(policy_host, net->st_policy, batch * A * sizeof(float), hipMemcpyDeviceToHost));
+    TG_HIP(hipMemcpy(value_host, net->st_value, batch * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    return TG_OK;
+}
+
+}  // extern "C"

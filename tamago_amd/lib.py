@@ -1,0 +1,86 @@
+"""ctypes binding of libtamago_hip.so (the C ABI declared in include/tamago_hip.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails, the product
+path raises.
+"""
+import ctypes
+import os
+from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64,
+                    c_size_t, c_uint64, c_void_p)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libtamago_hip.so")
+
+
+class TamagoHipError(RuntimeError):
+    pass
+
+
+class SearchConfig(Structure):
+    _fields_ = [("board_size", c_int32), ("num_trees", c_int32), ("tree_size", c_int32),
+                ("batch_size", c_int32), ("cgos_mode", c_int32), ("check_superko", c_int32),
+                ("device", c_int32), ("reserved", c_int32)]
+
+
+class RootPosition(Structure):
+    _fields_ = [("cells", c_void_p), ("hash_history", c_void_p), ("hash", c_uint64),
+                ("moves", c_int32), ("ko_pos", c_int32), ("ko_move", c_int32),
+                ("prev_move", c_int32), ("prev_prev_move", c_int32), ("to_move", c_int32)]
+
+
+_SIGNATURES = {
+    "tg_abi_version": (c_int, []),
+    "tg_last_error": (c_char_p, []),
+    "tg_device_count": (c_int, [POINTER(c_int)]),
+    "tg_net_param_count": (c_size_t, [c_int]),
+    "tg_net_create": (c_int, [c_int, c_int, c_void_p, c_size_t, POINTER(c_void_p)]),
+    "tg_net_destroy": (c_int, [c_void_p]),
+    "tg_net_board_size": (c_int, [c_void_p]),
+    "tg_net_forward_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "tg_net_forward_host": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "tg_net_kernel_name": (c_char_p, [c_void_p, c_int]),
+    "tg_net_flops_per_position": (c_double, [c_int]),
+    "tg_featurize_dev": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                 c_void_p]),
+    "tg_search_create": (c_int, [POINTER(SearchConfig), POINTER(c_void_p)]),
+    "tg_search_destroy": (c_int, [c_void_p]),
+    "tg_search_set_zobrist": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "tg_search_set_root": (c_int, [c_void_p, c_int, POINTER(RootPosition)]),
+    "tg_search_set_rng": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t]),
+    "tg_search_rng_consumed": (c_int, [c_void_p, c_void_p]),
+    "tg_search_select_puct": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "tg_search_root_planes": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "tg_search_backup": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "tg_search_read_node": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 11),
+    "tg_search_num_nodes": (c_int, [c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    """Names every build of the library must export (mirrors include/tamago_hip.h)."""
+    return sorted(_SIGNATURES)
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TamagoHipError(
+            f"{LIB_PATH} is missing - build it with `python -m tamago_amd.build` "
+            "(there is no CPU fallback for the product path)")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().tg_last_error()
+        raise TamagoHipError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")

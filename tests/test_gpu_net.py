@@ -1,0 +1,116 @@
+"""HIP DualNet forward + featurise kernels vs the oracle / reference goldens (needs a GPU).
+
+Tolerance (BASELINE.json north_star): policy / value within 1e-4 in fp32."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import load_npz
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def _net(size, sd):
+    from tamago_amd.nn.network.dual_net import DualNet
+    net = DualNet(torch.device("cuda:0"), size)
+    net.load_state_dict(sd)
+    return net
+
+
+@pytest.mark.parametrize("size", [9, 19])
+def test_forward_vs_reference_golden(size):
+    from oracle.net import make_state_dict
+    fix = load_npz(f"net_s{size}.npz")
+    for seed in (0, 7):
+        sd = make_state_dict(size, seed, float(fix[f"w{seed}_gain"]))
+        net = _net(size, sd)
+        x = torch.from_numpy(fix[f"w{seed}_planes"].astype(np.float32))
+        pol, val = net.inference(x)
+        assert np.abs(pol.numpy() - fix[f"w{seed}_policy"]).max() < TOL
+        assert np.abs(val.numpy() - fix[f"w{seed}_value"]).max() < TOL
+        lg, val2 = net.inference_with_policy_logits(x)
+        assert torch.equal(val, val2)
+        ref = fix[f"w{seed}_logits"]
+        assert np.abs(lg.numpy() - ref).max() < TOL * max(1.0, np.abs(ref).max())
+        # closeness to the fp64 forward of the reference: the HIP fp32 path should be as
+        # good as the reference's own fp32 path
+        err_hip = np.abs(lg.numpy() - fix[f"w{seed}_logits64"]).max()
+        err_ref = np.abs(ref - fix[f"w{seed}_logits64"]).max()
+        assert err_hip < 4 * err_ref + 1e-6
+
+
+@pytest.mark.parametrize("size,batches", [(9, [1, 2, 7, 256, 257, 770, 1539]), (19, [1, 3, 64])])
+def test_forward_vs_oracle_random_planes(size, batches):
+    from oracle.net import OracleNet, make_state_dict
+    sd = make_state_dict(size, 3, 1.4)
+    net = _net(size, sd)
+    ora = OracleNet(sd)
+    rs = np.random.RandomState(5)
+    for b in batches:
+        x = torch.from_numpy(rs.randint(-1, 2, size=(b, 6, size, size)).astype(np.float32))
+        pol, val = net.inference(x)
+        rp, rv = ora.inference(x)
+        assert np.abs(pol.numpy() - rp.numpy()).max() < TOL, b
+        assert np.abs(val.numpy() - rv.numpy()).max() < TOL, b
+        # device-resident entry point gives the same bits as the host one
+        pd, vd = net.forward_device(x.cuda())
+        torch.cuda.synchronize()
+        assert torch.equal(pd.cpu(), pol) and torch.equal(vd.cpu(), val)
+
+
+def test_forward_empty_and_errors():
+    from oracle.net import make_state_dict
+    from tamago_amd.lib import TamagoHipError
+    net = _net(9, make_state_dict(9, 0))
+    pol, val = net.inference(torch.zeros((0, 6, 9, 9)))
+    assert pol.shape == (0, 82) and val.shape == (0, 3)
+    with pytest.raises(ValueError):
+        net.inference(torch.zeros((1, 6, 19, 19)))
+    bad = make_state_dict(9, 0)
+    del bad["blocks.3.conv1.weight"]
+    with pytest.raises(KeyError):
+        net.load_state_dict(bad)
+    with pytest.raises(TamagoHipError):
+        from tamago_amd.nn.network.dual_net import DualNet
+        DualNet(torch.device("cpu"), 9)
+
+
+@pytest.mark.parametrize("size", [9, 19])
+def test_featurize_kernel_vs_reference_golden(size):
+    """tg_featurize_dev against planes recorded from nn/feature.py in the reference."""
+    from oracle.board import GoBoard
+    from tamago_amd import lib as tl
+    from tests.helpers import oracle_replay
+    lib = tl.load()
+    fix = load_npz(f"feat_s{size}.npz")
+    brd = load_npz(f"board_s{size}.npz")
+    specials = fix["special_seqs"]
+    cells, to_move, prev, moves, want = [], [], [], [], []
+    for i in range(len(fix["game"])):
+        g, ply, color = int(fix["game"][i]), int(fix["ply"][i]), int(fix["color"][i])
+        if g >= 0:
+            board = oracle_replay(size, brd[f"g{g}_move"], brd[f"g{g}_color"], ply)
+        else:
+            board = GoBoard(size)
+            c = 1
+            for mv in [int(v) for v in specials[-g - 1] if v != -9]:
+                board.put_stone(mv, c)
+                c = 3 - c
+        cells.append(board.get_board_data())
+        to_move.append(color)
+        prev.append(board.record_pos(board.moves - 1))
+        moves.append(board.moves)
+        want.append(fix["planes"][i].astype(np.float32))
+    n = len(cells)
+    d_cells = torch.tensor(np.array(cells, dtype=np.uint8)).cuda()
+    d_tm = torch.tensor(np.array(to_move, dtype=np.int8)).cuda()
+    d_prev = torch.tensor(np.array(prev, dtype=np.int32)).cuda()
+    d_moves = torch.tensor(np.array(moves, dtype=np.int32)).cuda()
+    out = torch.full((n, 6, size, size), 7.0, dtype=torch.float32, device="cuda")
+    tl.check(lib.tg_featurize_dev(size, d_cells.data_ptr(), d_tm.data_ptr(), d_prev.data_ptr(),
+                                  d_moves.data_ptr(), n, out.data_ptr(),
+                                  torch.cuda.current_stream().cuda_stream), "tg_featurize_dev")
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), np.array(want))
