@@ -133,23 +133,27 @@ int tg_search_set_rng(tg_search *s, const double *exp_stream_host, size_t stride
 /* Doubles each tree consumed since the last tg_search_set_rng (host array [T]). */
 int tg_search_rng_consumed(tg_search *s, int64_t *consumed_host);
 
-/* PUCT: run up to `max_leaves` descents per tree (tree.py:199-244 search_mcts: select by
- * PUCB, play, virtual loss, expand, featurise, queue).  Leaf planes go to planes_dev
- * [T, batch_size, 6, S, S]; n_leaves_dev[T] receives the number queued per tree. */
+/* PUCT: run `max_leaves` (<= batch_size) descents per tree (tree.py:199-244 search_mcts:
+ * select by PUCB, play, virtual loss, expand, featurise, queue).  Leaf planes go to
+ * planes_dev [T, max_leaves, 6, S, S]; n_leaves_dev[T] (may be NULL) receives the number
+ * queued per tree (== max_leaves unless the tree hit an error). */
 int tg_search_select_puct(tg_search *s, int max_leaves, float *planes_dev, int32_t *n_leaves_dev,
                           void *stream);
-/* Evaluate the root of every tree: writes planes [T,1,6,S,S] (tree.py:52-53). */
+/* Reset every tree to its root position, expand the root (consumes the root's Dirichlet
+ * draw) and write the root planes [T,6,S,S] (tree.py:49-53); one leaf per tree is queued. */
 int tg_search_root_planes(tg_search *s, float *planes_dev, void *stream);
 /* Write NN outputs back and back up values (tree.py:273-315 process_mini_batch).
- * policy_dev [T, batch_size, A], value_dev [T, batch_size, 3] in the slot order of the
- * preceding select / root_planes call; use_logit as in tree.py:293-294. */
+ * policy_dev [T, slots_per_tree, A], value_dev [T, slots_per_tree, 3] in the slot order
+ * of the preceding call (slots_per_tree = its max_leaves, or 1 after root_planes);
+ * use_logit as in tree.py:293-294. */
 int tg_search_backup(tg_search *s, const float *policy_dev, const float *value_dev,
-                     int use_logit, void *stream);
+                     int slots_per_tree, int use_logit, void *stream);
 
 /* Read-side of MCTSNode for node `node` of tree `t` (node.py:21-39); any pointer may be
  * NULL.  Arrays have A entries. Synchronises the stream used by the last call. */
 int tg_search_read_node(tg_search *s, int tree, int node, int32_t *num_children,
-                        int32_t *node_visits, int32_t *action, int32_t *children_index,
+                        int32_t *node_visits, int32_t *node_virtual_loss, int32_t *action,
+                        int32_t *children_index,
                         int32_t *children_visits, int32_t *children_virtual_loss,
                         double *children_value_sum, double *children_policy,
                         double *children_value, float *node_value_sum, float *raw_value);

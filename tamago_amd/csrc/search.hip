@@ -1,0 +1,945 @@
+// Device-resident batched MCTS for gfx950 (MI355X).
+//
+// Replaces, for T independent search trees driven in lock-step:
+//   mcts/tree.py:199-244   search_mcts        (PUCT descent, virtual loss, leaf queueing)
+//   mcts/tree.py:247-270   expand_node        (+ :509-519 Dirichlet tentative prior)
+//   mcts/tree.py:273-315   process_mini_batch (policy write-back, value backup)
+//   mcts/tree.py:387-422   search_sequential_halving (Gumbel descent)
+//   mcts/node.py:41-157, 275-361, mcts/pucb/pucb.py:8-29 (node math)
+//   mcts/batch_data.py:7-34 (the leaf queue)
+//   board/go_board.py:131-185, 237-304, 327-409 as called from the search (put_stone,
+//   legality incl. positional superko, self-atari, complete-eye filter)
+//   nn/feature.py:10-57 for the leaf boards.
+//
+// One wavefront (= one 64-thread workgroup) owns one tree.  The node pool is a
+// structure-of-arrays in HBM ([tree][node][child] per field); PUCB / Gumbel selection is
+// a 64-lane arg-max reduction with lowest-index tie-break, in float64 exactly as numpy
+// evaluates it; expansion tests all on-board points in parallel (one lane per point) on
+// a board held in LDS; backup walks parent links.  Boards use an O(1)-state
+// representation (cell colour + string id = smallest stone coordinate); liberties,
+// sizes and string hashes are recomputed with LDS atomics when a node is expanded, so
+// nothing has to be copied per descent except 3 bytes per cell.
+//
+// Bit-exactness notes (verified against the oracle in tests/test_gpu_search.py):
+//   * leaf values are float32; children_value_sum is accumulated in FLOAT32 and stored as
+//     float64, node_value_sum is float32, "1 - v" is float32 (what numpy/torch do in
+//     mcts/tree.py:297-313);
+//   * PUCB is float64 with IEEE division and sqrt; this file is compiled with
+//     -ffp-contract=off so no FMA is formed behind the source's back;
+//   * the random draws come from the host (libm log) through tg_search_set_rng.
+#include "common.h"
+
+#include <cstring>
+#include <vector>
+
+namespace {
+
+constexpr int kEmpty = 0, kBlack = 1, kWhite = 2, kOob = 3;
+constexpr int kNotExpanded = -1;
+
+struct RootMeta {
+    uint64_t hash;
+    int32_t moves, ko_pos, ko_move, prev, prevprev, to_move;
+    int32_t num_nodes;
+    int32_t hist_len;   // number of valid history slots (== moves, clamped)
+};
+
+struct SearchDev {
+    // node pool, [T][N][A]
+    int32_t *ch_index, *ch_visits, *ch_vl;
+    double *ch_vsum, *ch_policy, *ch_value;
+    int16_t *action;
+    // node scalars, [T][N]
+    int32_t *n_children, *n_visits, *n_vl, *n_parent, *n_pedge;
+    float *n_vsum, *n_raw;
+    double *noise;              // [T][A]   root Gumbel noise (0 for PUCT)
+    // root position, per tree
+    uint8_t *root_cells;        // [T][NC]
+    uint64_t *root_hist;        // [T][HMAX]
+    RootMeta *meta;             // [T]
+    // leaf queue, [T][K]
+    int32_t *q_node, *q_pnode, *q_pedge;
+    int32_t *n_leaves;          // [T]
+    // random stream
+    const double *rng;          // [T][rng_cap]  e_i = -log(1-u_i)
+    int64_t *rng_cursor;        // [T]
+    int64_t rng_cap;
+    const uint64_t *zob;        // [4][NC]
+    const uint8_t *eye;         // [65536]
+    int32_t *err;               // [T] sticky error flags
+    int32_t T, N, K, cgos, superko;
+};
+
+enum : int32_t { kErrPoolFull = 1, kErrRngEmpty = 2, kErrDepth = 4 };
+
+template <int S>
+struct Geo {
+    static constexpr int W = S + 2;
+    static constexpr int NC = W * W;
+    static constexpr int P = S * S;
+    static constexpr int A = P + 1;
+    static constexpr int HMAX = 3 * P;
+};
+
+// ---- wave helpers ----------------------------------------------------------------------
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ uint64_t wave_xor64(uint64_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t lo = __shfl_xor((int)(uint32_t)v, o);
+        const uint32_t hi = __shfl_xor((int)(uint32_t)(v >> 32), o);
+        v ^= ((uint64_t)hi << 32) | lo;
+    }
+    return v;
+}
+// arg-max with lowest-index tie-break (np.argmax); idx < 0 marks "no candidate"
+__device__ __forceinline__ void wave_argmax(double &val, int &idx) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_xor(val, o);
+        const int oi = __shfl_xor(idx, o);
+        const bool take = oi >= 0 && (idx < 0 || ov > val || (ov == val && oi < idx));
+        if (take) { val = ov; idx = oi; }
+    }
+}
+
+// ---- board in LDS ------------------------------------------------------------------------
+struct BoardScalars {
+    uint64_t hash;
+    int moves, ko_pos, ko_move, prev, prevprev;
+};
+
+template <int S>
+struct Lds {
+    using G = Geo<S>;
+    uint64_t hist[G::HMAX];
+    uint64_t strhash[G::NC];
+    uint32_t libcnt[G::NC];
+    uint32_t strsize[G::NC];
+    uint16_t root_sid[G::NC];
+    uint16_t sid[G::NC];
+    uint16_t cand[G::A + 3];
+    uint8_t root_color[G::NC + 7];
+    uint8_t color[G::NC + 7];
+    int32_t scratch[8];
+};
+
+template <int S>
+__device__ __forceinline__ bool touches(const Lds<S> &L, int p, int id) {
+    constexpr int W = Geo<S>::W;
+    return L.sid[p - W] == id || L.sid[p - 1] == id || L.sid[p + 1] == id || L.sid[p + W] == id;
+}
+
+// go_board.py:131-185 on the LDS board.  All 64 lanes call it with wave-uniform arguments.
+template <int S>
+__device__ void put_stone(Lds<S> &L, BoardScalars &b, int pos, int c, const uint64_t *zob, int lane) {
+    using G = Geo<S>;
+    constexpr int W = G::W, NC = G::NC;
+    if (pos == 0) {                                   // PASS: record only (go_board.py:138-141)
+        if (lane == 0 && b.moves < G::HMAX) L.hist[b.moves] = b.hash;
+        b.prevprev = b.prev;
+        b.prev = 0;
+        b.moves += 1;
+        __syncthreads();
+        return;
+    }
+    const int opp = 3 - c;
+    if (lane == 0) L.color[pos] = (uint8_t)c;
+    b.hash ^= zob[c * NC + pos];
+    __syncthreads();
+    const int nb[4] = {pos - W, pos - 1, pos + 1, pos + W};
+    int captured = 0;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const int n = nb[d];
+        if (L.color[n] != opp) continue;               // wave-uniform
+        const int id = L.sid[n];
+        int cnt = 0;
+        for (int p = lane; p < NC; p += 64)
+            if (L.color[p] == kEmpty && touches<S>(L, p, id)) ++cnt;
+        if (wave_sum(cnt) != 0) continue;
+        // capture string `id` (string.py:292-325): clear stones, XOR their keys out
+        uint64_t hx = 0;
+        int removed = 0;
+        for (int p = lane; p < NC; p += 64)
+            if (L.sid[p] == id) { hx ^= zob[opp * NC + p]; ++removed; }
+        __syncthreads();
+        for (int p = lane; p < NC; p += 64)
+            if (L.sid[p] == id) { L.color[p] = kEmpty; L.sid[p] = 0; }
+        b.hash ^= wave_xor64(hx);
+        captured += wave_sum(removed);
+        __syncthreads();
+    }
+    // connect with friendly neighbours: string id = smallest stone coordinate
+    int f[4];
+    int newid = pos;
+    bool any_friend = false;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        f[d] = (L.color[nb[d]] == c) ? L.sid[nb[d]] : 0;
+        if (f[d]) { any_friend = true; newid = f[d] < newid ? f[d] : newid; }
+    }
+    if (any_friend) {
+        for (int p = lane; p < NC; p += 64) {
+            const int s = L.sid[p];
+            if (s != 0 && (s == f[0] || s == f[1] || s == f[2] || s == f[3])) L.sid[p] = (uint16_t)newid;
+        }
+    } else if (captured == 1) {
+        // ko, go_board.py:173-177: lone stone, exactly one capture, exactly one liberty
+        int libs = 0, where = 0;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+            if (L.color[nb[d]] == kEmpty) { ++libs; if (!where) where = nb[d]; }
+        if (libs == 1) { b.ko_move = b.moves; b.ko_pos = where; }
+    }
+    __syncthreads();
+    if (lane == 0) {
+        L.sid[pos] = (uint16_t)newid;
+        if (b.moves < G::HMAX) L.hist[b.moves] = b.hash;
+    }
+    b.prevprev = b.prev;
+    b.prev = pos;
+    b.moves += 1;
+    __syncthreads();
+}
+
+// String ids from colours by min-label propagation (used once per root position).
+template <int S>
+__device__ void label_strings(uint8_t *color, uint16_t *sid, int lane) {
+    using G = Geo<S>;
+    constexpr int W = G::W, NC = G::NC;
+    for (int p = lane; p < NC; p += 64) {
+        const int c = color[p];
+        sid[p] = (c == kBlack || c == kWhite) ? (uint16_t)p : 0;
+    }
+    __syncthreads();
+    for (int iter = 0; iter < NC; ++iter) {
+        int changed = 0;
+        for (int p = lane; p < NC; p += 64) {
+            const int c = color[p];
+            if (c != kBlack && c != kWhite) continue;
+            int s = sid[p];
+            const int nn[4] = {p - W, p - 1, p + 1, p + W};
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+                if (color[nn[d]] == c && sid[nn[d]] < s) s = sid[nn[d]];
+            if (s != sid[p]) { sid[p] = (uint16_t)s; changed = 1; }
+        }
+        __syncthreads();
+        if (wave_sum(changed) == 0) break;
+    }
+}
+
+template <int S>
+__device__ __forceinline__ int pat3_at(const Lds<S> &L, int p) {
+    constexpr int W = Geo<S>::W;
+    return L.color[p - W - 1] | (L.color[p - W] << 2) | (L.color[p - W + 1] << 4) |
+           (L.color[p - 1] << 6) | (L.color[p + 1] << 8) | (L.color[p + W - 1] << 10) |
+           (L.color[p + W] << 12) | (L.color[p + W + 1] << 14);
+}
+
+// Candidate list of MCTSTree.expand_node (tree.py:260-264): legal (go_board.py:260-304),
+// check_self_atari_stone < 7 (:327-365), not a complete eye (:367-397); row-major, PASS last.
+// Returns the number of candidates (>= 1); L.cand[] holds their coordinates.
+template <int S>
+__device__ int gen_candidates(Lds<S> &L, const BoardScalars &b, int me, const SearchDev &D, int lane) {
+    using G = Geo<S>;
+    constexpr int W = G::W, NC = G::NC, P = G::P;
+    const int opp = 3 - me;
+    for (int p = lane; p < NC; p += 64) { L.libcnt[p] = 0; L.strsize[p] = 0; L.strhash[p] = 0; }
+    __syncthreads();
+    for (int p = lane; p < NC; p += 64) {
+        const int c = L.color[p];
+        if (c == kBlack || c == kWhite) {
+            atomicAdd(&L.strsize[L.sid[p]], 1u);
+            // superko quirk (go_board.py:292-296): keys of the mover's OPPONENT colour are
+            // used for every adjacent one-liberty string, whatever its colour
+            if (D.superko) atomicXor((unsigned long long *)&L.strhash[L.sid[p]],
+                                     (unsigned long long)D.zob[opp * NC + p]);
+        } else if (c == kEmpty) {
+            const int s0 = L.sid[p - W], s1 = L.sid[p - 1], s2 = L.sid[p + 1], s3 = L.sid[p + W];
+            if (s0) atomicAdd(&L.libcnt[s0], 1u);
+            if (s1 && s1 != s0) atomicAdd(&L.libcnt[s1], 1u);
+            if (s2 && s2 != s0 && s2 != s1) atomicAdd(&L.libcnt[s2], 1u);
+            if (s3 && s3 != s0 && s3 != s1 && s3 != s2) atomicAdd(&L.libcnt[s3], 1u);
+        }
+    }
+    __syncthreads();
+
+    int n = 0;
+    for (int q0 = 0; q0 < P; q0 += 64) {
+        const int q = q0 + lane;
+        const int p = (q < P) ? (q / S + 1) * W + (q % S) + 1 : 0;
+        bool keep = false;
+        bool slow = false;          // self-atari needs the exact liberty-union count
+        int fr[4] = {0, 0, 0, 0};
+        if (q < P && L.color[p] == kEmpty) {
+            const int nn[4] = {p - W, p - 1, p + 1, p + W};
+            int col[4], sid[4], lib[4];
+            int ne = 0;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                col[d] = L.color[nn[d]];
+                sid[d] = L.sid[nn[d]];
+                lib[d] = sid[d] ? (int)L.libcnt[sid[d]] : 0;
+                ne += col[d] == kEmpty;
+            }
+            // suicide (go_board.py:237-258), only consulted when there is no empty neighbour
+            bool suicide = true;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                if (col[d] == opp && lib[d] == 1) suicide = false;
+                if (col[d] == me && lib[d] > 1) suicide = false;
+            }
+            bool legal = !(ne == 0 && suicide);
+            if (b.ko_pos == p && b.ko_move == b.moves - 1) legal = false;
+            if (legal && D.superko) {
+                uint64_t h = b.hash ^ D.zob[me * NC + p];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    bool dup = false;
+#pragma unroll
+                    for (int e = 0; e < d; ++e) dup |= sid[e] == sid[d];
+                    if (sid[d] && !dup && lib[d] == 1) h ^= L.strhash[sid[d]];
+                }
+                // record.has_same_hash scans the whole fixed array; unused slots are 0 and
+                // slot 0 is never written, so comparing with slots [0, moves) is equivalent
+                const int hl = b.moves < G::HMAX ? b.moves : G::HMAX;
+                for (int i = 0; i < hl; ++i)
+                    if (L.hist[i] == h) { legal = false; break; }
+            }
+            if (legal) {
+                // self-atari size (go_board.py:327-365); only "< 7" matters
+                if (ne <= 1) {
+                    int size = 0;
+                    bool opp_atari = false, big_lib = false;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        if (col[d] == me) {
+                            bool dup = false;
+#pragma unroll
+                            for (int e = 0; e < d; ++e) dup |= (col[e] == me && sid[e] == sid[d]);
+                            if (!dup) { size += (int)L.strsize[sid[d]]; fr[d] = sid[d]; big_lib |= lib[d] >= 3; }
+                        } else if (col[d] == opp && lib[d] == 1) {
+                            opp_atari = true;
+                        }
+                    }
+                    if (size + 1 >= 7 && !opp_atari && !big_lib) { slow = true; }
+                }
+                // complete eye (go_board.py:367-397)
+                bool eye = false;
+                if (D.eye[pat3_at<S>(L, p)] == me) {
+                    const int cr[4] = {p - W - 1, p - W + 1, p + W - 1, p + W + 1};
+                    int count = 0;
+                    bool edge = false;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const int v = L.color[cr[d]];
+                        if (v == me || v == kOob) ++count;
+                        else if (v == kEmpty && D.eye[pat3_at<S>(L, cr[d])] == me) ++count;
+                        if (v == kOob) edge = true;
+                    }
+                    eye = (edge && count == 4) || (!edge && count >= 3);
+                }
+                keep = !eye;
+                if (eye) slow = false;
+            }
+        }
+        // rare slow path: |{empty nbrs of p} U liberties of the friendly neighbour strings| >= 3 ?
+        unsigned long long pending = __ballot(slow);
+        while (pending) {
+            const int src = __ffsll((long long)pending) - 1;
+            pending &= pending - 1;
+            const int sp = __shfl(p, src);
+            const int g0 = __shfl(fr[0], src), g1 = __shfl(fr[1], src), g2 = __shfl(fr[2], src),
+                      g3 = __shfl(fr[3], src);
+            int cnt = 0;
+            for (int e = lane; e < NC; e += 64) {
+                if (L.color[e] != kEmpty) continue;
+                bool in = (e == sp) || e == sp - W || e == sp - 1 || e == sp + 1 || e == sp + W;
+                if (!in) {
+                    const int t0 = L.sid[e - W], t1 = L.sid[e - 1], t2 = L.sid[e + 1], t3 = L.sid[e + W];
+                    const int ts[4] = {t0, t1, t2, t3};
+#pragma unroll
+                    for (int d = 0; d < 4; ++d)
+                        if (ts[d] && (ts[d] == g0 || ts[d] == g1 || ts[d] == g2 || ts[d] == g3)) in = true;
+                }
+                cnt += in;
+            }
+            const int total = wave_sum(cnt);
+            if (lane == src && total < 3) keep = false;   // self-atari of >= 7 stones: pruned
+        }
+        const unsigned long long kept = __ballot(keep);
+        if (keep) L.cand[n + __popcll(kept & ((1ull << lane) - 1))] = (uint16_t)p;
+        n += __popcll(kept);
+    }
+    if (lane == 0) L.cand[n] = 0;   // PASS
+    __syncthreads();
+    return n + 1;
+}
+
+// tree.py:247-270 expand_node + node.py:41-73: returns the new node index (or -1 on error).
+template <int S>
+__device__ int expand_node(Lds<S> &L, const BoardScalars &b, int to_move, const SearchDev &D, int t,
+                           int &num_nodes, int parent, int pedge, int lane) {
+    using G = Geo<S>;
+    constexpr int A = G::A;
+    if (num_nodes >= D.N) {
+        if (lane == 0) atomicOr(&D.err[t], kErrPoolFull);
+        return -1;
+    }
+    const int node = num_nodes;
+    const int n = gen_candidates<S>(L, b, to_move, D, lane);
+    // Dirichlet(1,..,1) prior from the host stream: p_i = e_i / (e_0 + e_1 + ... sequentially)
+    const int64_t cur = D.rng_cursor[t];
+    if (cur + n > D.rng_cap) {
+        if (lane == 0) atomicOr(&D.err[t], kErrRngEmpty);
+        return -1;
+    }
+    const double *e = D.rng + (size_t)t * D.rng_cap + cur;
+    double *stage = reinterpret_cast<double *>(L.strhash);     // free after gen_candidates
+    for (int i = lane; i < n; i += 64) stage[i] = e[i];
+    __syncthreads();
+    double acc = 0.0;
+    for (int i = 0; i < n; ++i) acc += stage[i];        // wave-uniform, sequential like numpy
+    const double inv = 1.0 / acc;
+    const size_t base = ((size_t)t * D.N + node) * A;
+    for (int i = lane; i < A; i += 64) {
+        D.ch_index[base + i] = kNotExpanded;
+        D.ch_visits[base + i] = 0;
+        D.ch_vl[base + i] = 0;
+        D.ch_vsum[base + i] = 0.0;
+        D.ch_value[base + i] = 0.0;
+        D.ch_policy[base + i] = i < n ? stage[i] * inv : 0.0;
+        D.action[base + i] = i < n ? (int16_t)L.cand[i] : (int16_t)0;
+    }
+    if (lane == 0) {
+        const size_t ns = (size_t)t * D.N + node;
+        D.n_children[ns] = n;
+        D.n_visits[ns] = 0;
+        D.n_vl[ns] = 0;
+        D.n_vsum[ns] = 0.f;
+        D.n_raw[ns] = 0.f;
+        D.n_parent[ns] = parent;
+        D.n_pedge[ns] = pedge;
+        D.rng_cursor[t] = cur + n;
+    }
+    num_nodes += 1;
+    __syncthreads();
+    return node;
+}
+
+// nn/feature.py:10-57 from the LDS board
+template <int S>
+__device__ void write_planes(const Lds<S> &L, const BoardScalars &b, int to_move, float *dst, int lane) {
+    using G = Geo<S>;
+    constexpr int W = G::W, P = G::P;
+    const bool pass_plane = b.moves > 1 && b.prev == 0;
+    const float side = to_move == kWhite ? -1.f : 1.f;
+    for (int q = lane; q < P; q += 64) {
+        const int p = (q / S + 1) * W + (q % S) + 1;
+        int c = L.color[p];
+        if (to_move == kWhite && c != 0) c = 3 - c;
+        dst[q] = c == 0 ? 1.f : 0.f;
+        dst[P + q] = c == 1 ? 1.f : 0.f;
+        dst[2 * P + q] = c == 2 ? 1.f : 0.f;
+        dst[3 * P + q] = (!pass_plane && p == b.prev) ? 1.f : 0.f;
+        dst[4 * P + q] = pass_plane ? 1.f : 0.f;
+        dst[5 * P + q] = side;
+    }
+}
+
+// node.py:141-157 + pucb.py:8-29
+template <int S>
+__device__ int select_puct(const SearchDev &D, int t, int node, int lane) {
+    constexpr int A = Geo<S>::A;
+    const size_t ns = (size_t)t * D.N + node;
+    const size_t base = ns * A;
+    const int nc = D.n_children[ns];
+    const int total = D.n_visits[ns] + D.n_vl[ns];
+    const double sq = __dsqrt_rn((double)(total + 1));
+    double best = 0.0;
+    int best_i = -1;
+    for (int i = lane; i < nc; i += 64) {
+        const int cnt = D.ch_visits[base + i] + D.ch_vl[base + i];
+        const double q = cnt != 0 ? D.ch_vsum[base + i] / (double)cnt : 0.0;
+        const double u = (D.ch_policy[base + i] * sq) / (double)(cnt + 1);
+        double sc = q + u;
+        if (D.cgos && i == nc - 1) sc -= 0.1;
+        if (best_i < 0 || sc > best) { best = sc; best_i = i; }
+    }
+    wave_argmax(best, best_i);
+    return best_i;
+}
+
+template <int S>
+__device__ void load_root(Lds<S> &L, BoardScalars &b, int &to_move, const SearchDev &D, int t, int lane) {
+    using G = Geo<S>;
+    for (int p = lane; p < G::NC; p += 64) L.root_color[p] = D.root_cells[(size_t)t * G::NC + p];
+    const RootMeta m = D.meta[t];
+    for (int i = lane; i < m.hist_len; i += 64) L.hist[i] = D.root_hist[(size_t)t * G::HMAX + i];
+    b.hash = m.hash;
+    b.moves = m.moves;
+    b.ko_pos = m.ko_pos;
+    b.ko_move = m.ko_move;
+    b.prev = m.prev;
+    b.prevprev = m.prevprev;
+    to_move = m.to_move;
+    __syncthreads();
+    label_strings<S>(L.root_color, L.root_sid, lane);
+}
+
+template <int S>
+__device__ void reset_work(Lds<S> &L, int lane) {
+    for (int p = lane; p < Geo<S>::NC; p += 64) { L.color[p] = L.root_color[p]; L.sid[p] = L.root_sid[p]; }
+    __syncthreads();
+}
+
+// tree.py:49-54 / :330-336 (first half): reset the tree, expand the root, featurise it.
+template <int S>
+__global__ __launch_bounds__(64) void root_kernel(SearchDev D, float *planes) {   // planes [T][6][P]
+    using G = Geo<S>;
+    __shared__ Lds<S> L;
+    const int t = blockIdx.x, lane = threadIdx.x;
+    BoardScalars b;
+    int to_move;
+    load_root<S>(L, b, to_move, D, t, lane);
+    reset_work<S>(L, lane);
+    int num_nodes = 0;
+    for (int i = lane; i < G::A; i += 64) D.noise[(size_t)t * G::A + i] = 0.0;
+    const int root = expand_node<S>(L, b, to_move, D, t, num_nodes, -1, -1, lane);
+    write_planes<S>(L, b, to_move, planes + (size_t)t * 6 * G::P, lane);
+    if (lane == 0) {
+        D.meta[t].num_nodes = num_nodes;
+        D.q_node[(size_t)t * D.K] = root;
+        D.q_pnode[(size_t)t * D.K] = -1;
+        D.q_pedge[(size_t)t * D.K] = -1;
+        D.n_leaves[t] = root >= 0 ? 1 : 0;
+    }
+}
+
+// tree.py:199-244 search_mcts, `max_leaves` descents per tree.
+template <int S>
+__global__ __launch_bounds__(64) void select_puct_kernel(SearchDev D, int max_leaves, float *planes) {
+    using G = Geo<S>;
+    constexpr int A = G::A;
+    __shared__ Lds<S> L;
+    const int t = blockIdx.x, lane = threadIdx.x;
+    BoardScalars rootb;
+    int root_to_move;
+    load_root<S>(L, rootb, root_to_move, D, t, lane);
+    int num_nodes = D.meta[t].num_nodes;
+    int queued = 0;
+    if (D.err[t] == 0 && num_nodes > 0) {
+        for (int k = 0; k < max_leaves; ++k) {
+            reset_work<S>(L, lane);
+            BoardScalars b = rootb;
+            int c = root_to_move;
+            int node = 0;
+            bool ok = true;
+            for (int depth = 0;; ++depth) {
+                const size_t ns = (size_t)t * D.N + node;
+                const size_t base = ns * A;
+                const int e = select_puct<S>(D, t, node, lane);
+                const int mv = D.action[base + e];
+                put_stone<S>(L, b, mv, c, D.zob, lane);
+                c = 3 - c;
+                const int edge_cnt = D.ch_visits[base + e] + D.ch_vl[base + e] + 1;   // after the VL
+                int child = D.ch_index[base + e];
+                __syncthreads();
+                if (lane == 0) {                                      // node.py:76-83
+                    D.n_vl[ns] += 1;
+                    D.ch_vl[base + e] += 1;
+                }
+                // two consecutive passes: never descend below (tree.py:224-229)
+                const bool two_pass = b.moves > 2 && b.prev == 0 && b.prevprev == 0;
+                const int threshold = two_pass ? 10000000 : 1;
+                if (edge_cnt < threshold + 1) {
+                    if (child == kNotExpanded) {
+                        child = expand_node<S>(L, b, c, D, t, num_nodes, node, e, lane);
+                        if (child < 0) { ok = false; break; }
+                        if (lane == 0) D.ch_index[base + e] = child;
+                    }
+                    write_planes<S>(L, b, c, planes + ((size_t)t * max_leaves + k) * 6 * G::P, lane);
+                    if (lane == 0) {
+                        D.q_node[(size_t)t * D.K + k] = child;
+                        D.q_pnode[(size_t)t * D.K + k] = node;
+                        D.q_pedge[(size_t)t * D.K + k] = e;
+                    }
+                    __syncthreads();
+                    break;
+                }
+                node = child;
+                __syncthreads();
+            }
+            if (!ok) break;
+            ++queued;
+        }
+    }
+    if (lane == 0) {
+        D.meta[t].num_nodes = num_nodes;
+        D.n_leaves[t] = queued;
+    }
+}
+
+// tree.py:273-315 process_mini_batch for the leaves queued by the preceding kernel.
+template <int S>
+__global__ __launch_bounds__(64) void backup_kernel(SearchDev D, const float *policy, const float *value,
+                                                    int stride, int use_logit) {
+    using G = Geo<S>;
+    constexpr int A = G::A, W = G::W, P = G::P;
+    const int t = blockIdx.x, lane = threadIdx.x;
+    const int n = D.n_leaves[t];
+    for (int k = 0; k < n; ++k) {
+        const size_t slot = (size_t)t * D.K + k;
+        int node = D.q_node[slot];
+        if (node < 0) node = D.N - 1;                 // node[-1]: Gumbel leaves (tree.py:412-416)
+        const size_t ns = (size_t)t * D.N + node;
+        const size_t base = ns * A;
+        const float *pol = policy + ((size_t)t * stride + k) * A;
+        const float *val = value + ((size_t)t * stride + k) * 3;
+        // node.py:86-93 update_policy via the {pos: policy} map of tree.py:287-295
+        const int nc = D.n_children[ns];
+        for (int i = lane; i < nc; i += 64) {
+            const int pos = D.action[base + i];
+            float pv;
+            if (pos == 0) {
+                pv = pol[P];
+                if (use_logit) pv = pv - 0.5f;
+            } else {
+                pv = pol[(pos / W - 1) * S + (pos % W) - 1];
+            }
+            D.ch_policy[base + i] = (double)pv;
+        }
+        const float v0 = val[0], v1 = val[1], v2 = val[2];
+        if (lane == 0) {
+            D.n_raw[ns] = v1 * 0.5f + v2;             // tree.py:299
+            int cur = D.q_pnode[slot];
+            int e = D.q_pedge[slot];
+            if (cur >= 0) {
+                float v = v0 + v1 * 0.5f;             // tree.py:302
+                D.ch_value[((size_t)t * D.N + cur) * A + e] = (double)v;   // set_leaf_value
+                while (cur >= 0) {
+                    const size_t cs = (size_t)t * D.N + cur;
+                    const size_t ce = cs * A + e;
+                    // float32 accumulation stored in float64 (see file header)
+                    D.ch_vsum[ce] = (double)((float)D.ch_vsum[ce] + v);
+                    D.ch_visits[ce] += 1;
+                    D.ch_vl[ce] -= 1;
+                    D.n_vsum[cs] += v;
+                    D.n_visits[cs] += 1;
+                    D.n_vl[cs] -= 1;
+                    v = 1.0f - v;
+                    e = D.n_pedge[cs];
+                    cur = D.n_parent[cs];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (lane == 0) D.n_leaves[t] = 0;
+}
+
+// Host-built eye table: same rule as board/pattern.py:52-98 produces.
+void build_eye_table(std::vector<uint8_t> &table) {
+    table.assign(65536, 0);
+    const int borders[9][5] = {{-1, -1, -1, -1, -1}, {0, 1, 2, -1, -1}, {5, 6, 7, -1, -1},
+                               {0, 3, 5, -1, -1},    {2, 4, 7, -1, -1}, {0, 1, 2, 3, 5},
+                               {0, 1, 2, 4, 7},      {0, 3, 5, 6, 7},   {2, 4, 5, 6, 7}};
+    const int orth[4] = {1, 3, 4, 6}, diag[4] = {0, 2, 5, 7};
+    for (const auto &bd : borders) {
+        bool is_border[8] = {};
+        for (int k = 0; k < 5; ++k)
+            if (bd[k] >= 0) is_border[bd[k]] = true;
+        int free_diag[4], n_free = 0;
+        for (int d : diag)
+            if (!is_border[d]) free_diag[n_free++] = d;
+        int combos = 1;
+        for (int i = 0; i < n_free; ++i) combos *= 3;
+        for (int combo = 0; combo < combos; ++combo) {
+            int cells[8] = {};
+            for (int k = 0; k < 8; ++k)
+                if (is_border[k]) cells[k] = kOob;
+            for (int o : orth)
+                if (!is_border[o]) cells[o] = kBlack;
+            int c = combo, n_own = 0, n_opp = 0;
+            for (int i = 0; i < n_free; ++i) {
+                const int v = c % 3;
+                c /= 3;
+                cells[free_diag[i]] = v;
+                n_own += v == kBlack;
+                n_opp += v == kWhite;
+            }
+            bool ok;
+            if (n_free == 4) ok = n_opp <= 1 || (n_opp == 2 && n_own == 2);
+            else if (n_free == 2) ok = n_own >= 1 || n_opp == 2;
+            else ok = true;
+            if (!ok) continue;
+            int code = 0, swapped = 0;
+            for (int k = 0; k < 8; ++k) {
+                const int v = cells[k];
+                const int sv = (v == kBlack || v == kWhite) ? 3 - v : v;
+                code |= v << (2 * k);
+                swapped |= sv << (2 * k);
+            }
+            table[code] = kBlack;
+            table[swapped] = kWhite;
+        }
+    }
+}
+
+}  // namespace
+
+// ======================================================================================
+// host side
+// ======================================================================================
+struct tg_search {
+    tg_search_config cfg{};
+    SearchDev dev{};
+    std::vector<void *> allocs;
+    int S = 0, W = 0, NC = 0, P = 0, A = 0, HMAX = 0;
+    hipStream_t last_stream = nullptr;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(tg_search *s, T **out, size_t count, bool zero = true) {
+    void *p = nullptr;
+    TG_HIP(hipMalloc(&p, count * sizeof(T)));
+    s->allocs.push_back(p);
+    if (zero) TG_HIP(hipMemset(p, 0, count * sizeof(T)));
+    *out = static_cast<T *>(p);
+    return TG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tg_search_create(const tg_search_config *cfg, tg_search **out) {
+    if (!cfg || !out) return tg::fail(TG_ERR_ARG, "tg_search_create: null argument");
+    if (cfg->board_size != 9 && cfg->board_size != 19)
+        return tg::fail(TG_ERR_ARG, "tg_search_create: board size %d not built (9 and 19 are)", cfg->board_size);
+    if (cfg->num_trees < 1 || cfg->tree_size < 2 || cfg->batch_size < 1)
+        return tg::fail(TG_ERR_ARG, "tg_search_create: num_trees/tree_size/batch_size out of range");
+    TG_HIP(hipSetDevice(cfg->device));
+    tg_search *s = new tg_search;
+    s->cfg = *cfg;
+    s->S = cfg->board_size;
+    s->W = s->S + 2;
+    s->NC = s->W * s->W;
+    s->P = s->S * s->S;
+    s->A = s->P + 1;
+    s->HMAX = 3 * s->P;
+    SearchDev &D = s->dev;
+    D.T = cfg->num_trees;
+    D.N = cfg->tree_size;
+    D.K = cfg->batch_size;
+    D.cgos = cfg->cgos_mode;
+    D.superko = cfg->check_superko;
+    const size_t T = D.T, N = D.N, A = s->A, K = D.K;
+    int rc = TG_OK;
+#define ALLOC(field, count) if ((rc = dev_alloc(s, &D.field, (count)))) { tg_search_destroy(s); return rc; }
+    ALLOC(ch_index, T * N * A) ALLOC(ch_visits, T * N * A) ALLOC(ch_vl, T * N * A)
+    ALLOC(ch_vsum, T * N * A) ALLOC(ch_policy, T * N * A) ALLOC(ch_value, T * N * A)
+    ALLOC(action, T * N * A)
+    ALLOC(n_children, T * N) ALLOC(n_visits, T * N) ALLOC(n_vl, T * N) ALLOC(n_parent, T * N)
+    ALLOC(n_pedge, T * N) ALLOC(n_vsum, T * N) ALLOC(n_raw, T * N)
+    ALLOC(noise, T * A)
+    ALLOC(root_cells, T * s->NC) ALLOC(root_hist, T * s->HMAX) ALLOC(meta, T)
+    ALLOC(q_node, T * K) ALLOC(q_pnode, T * K) ALLOC(q_pedge, T * K) ALLOC(n_leaves, T)
+    ALLOC(rng_cursor, T) ALLOC(err, T)
+#undef ALLOC
+    // default RNG window: one mini-batch worth of expansions (+ root, + Gumbel noise)
+    D.rng_cap = (int64_t)(K + 2) * A;
+    double *rng = nullptr;
+    if ((rc = dev_alloc(s, &rng, T * (size_t)D.rng_cap))) { tg_search_destroy(s); return rc; }
+    D.rng = rng;
+    uint64_t *zob = nullptr;
+    if ((rc = dev_alloc(s, &zob, (size_t)4 * s->NC))) { tg_search_destroy(s); return rc; }
+    D.zob = zob;
+    std::vector<uint8_t> eye;
+    build_eye_table(eye);
+    uint8_t *eye_dev = nullptr;
+    if ((rc = dev_alloc(s, &eye_dev, eye.size(), false))) { tg_search_destroy(s); return rc; }
+    hipError_t e = hipMemcpy(eye_dev, eye.data(), eye.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { tg_search_destroy(s); return tg::fail(TG_ERR_HIP, "eye upload: %s", hipGetErrorString(e)); }
+    D.eye = eye_dev;
+    *out = s;
+    return TG_OK;
+}
+
+int tg_search_destroy(tg_search *s) {
+    if (!s) return TG_OK;
+    (void)hipSetDevice(s->cfg.device);
+    for (void *p : s->allocs) (void)hipFree(p);
+    delete s;
+    return TG_OK;
+}
+
+int tg_search_set_zobrist(tg_search *s, const uint64_t *keys, size_t n) {
+    if (!s || !keys) return tg::fail(TG_ERR_ARG, "tg_search_set_zobrist: null argument");
+    if (n != (size_t)4 * s->NC) return tg::fail(TG_ERR_ARG, "tg_search_set_zobrist: expected %d keys", 4 * s->NC);
+    TG_HIP(hipMemcpy(const_cast<uint64_t *>(s->dev.zob), keys, n * sizeof(uint64_t), hipMemcpyHostToDevice));
+    return TG_OK;
+}
+
+int tg_search_set_root(tg_search *s, int tree, const tg_root_position *pos) {
+    if (!s || !pos || !pos->cells) return tg::fail(TG_ERR_ARG, "tg_search_set_root: null argument");
+    if (tree < 0 || tree >= s->dev.T) return tg::fail(TG_ERR_ARG, "tg_search_set_root: tree %d out of range", tree);
+    if (pos->moves < 1) return tg::fail(TG_ERR_ARG, "tg_search_set_root: moves must be >= 1");
+    if (pos->to_move != kBlack && pos->to_move != kWhite)
+        return tg::fail(TG_ERR_ARG, "tg_search_set_root: to_move must be 1 or 2");
+    if (s->dev.superko && !pos->hash_history && pos->moves > 1)
+        return tg::fail(TG_ERR_ARG, "tg_search_set_root: hash_history required with check_superko");
+    RootMeta m{};
+    m.hash = pos->hash;
+    m.moves = pos->moves;
+    m.ko_pos = pos->ko_pos;
+    m.ko_move = pos->ko_move;
+    m.prev = pos->prev_move;
+    m.prevprev = pos->prev_prev_move;
+    m.to_move = pos->to_move;
+    m.num_nodes = 0;
+    m.hist_len = pos->hash_history ? (pos->moves < s->HMAX ? pos->moves : s->HMAX) : 1;
+    TG_HIP(hipMemcpy(s->dev.root_cells + (size_t)tree * s->NC, pos->cells, s->NC, hipMemcpyHostToDevice));
+    if (pos->hash_history)
+        TG_HIP(hipMemcpy(s->dev.root_hist + (size_t)tree * s->HMAX, pos->hash_history,
+                         (size_t)m.hist_len * sizeof(uint64_t), hipMemcpyHostToDevice));
+    else
+        TG_HIP(hipMemset(s->dev.root_hist + (size_t)tree * s->HMAX, 0, sizeof(uint64_t)));
+    TG_HIP(hipMemcpy(s->dev.meta + tree, &m, sizeof(m), hipMemcpyHostToDevice));
+    TG_HIP(hipMemset(s->dev.err + tree, 0, sizeof(int32_t)));
+    return TG_OK;
+}
+
+int tg_search_set_rng(tg_search *s, const double *exp_stream_host, size_t stride, size_t count) {
+    if (!s || !exp_stream_host) return tg::fail(TG_ERR_ARG, "tg_search_set_rng: null argument");
+    if (count > stride) return tg::fail(TG_ERR_ARG, "tg_search_set_rng: count > stride");
+    if (s->last_stream) TG_HIP(hipStreamSynchronize(s->last_stream));
+    if ((int64_t)count > s->dev.rng_cap) {
+        double *rng = nullptr;
+        int rc = dev_alloc(s, &rng, (size_t)s->dev.T * count, false);
+        if (rc) return rc;
+        s->dev.rng = rng;          // the old window stays allocated until destroy
+        s->dev.rng_cap = (int64_t)count;
+    }
+    TG_HIP(hipMemcpy2D(const_cast<double *>(s->dev.rng), (size_t)s->dev.rng_cap * sizeof(double),
+                       exp_stream_host, stride * sizeof(double), count * sizeof(double), s->dev.T,
+                       hipMemcpyHostToDevice));
+    TG_HIP(hipMemset(s->dev.rng_cursor, 0, (size_t)s->dev.T * sizeof(int64_t)));
+    return TG_OK;
+}
+
+int tg_search_rng_consumed(tg_search *s, int64_t *consumed_host) {
+    if (!s || !consumed_host) return tg::fail(TG_ERR_ARG, "tg_search_rng_consumed: null argument");
+    if (s->last_stream) TG_HIP(hipStreamSynchronize(s->last_stream));
+    TG_HIP(hipMemcpy(consumed_host, s->dev.rng_cursor, (size_t)s->dev.T * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return TG_OK;
+}
+
+static int check_errors(tg_search *s) {
+    std::vector<int32_t> err(s->dev.T);
+    TG_HIP(hipMemcpy(err.data(), s->dev.err, err.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (int t = 0; t < s->dev.T; ++t)
+        if (err[t])
+            return tg::fail(TG_ERR_OVERFLOW, "tree %d: %s%s%s", t, (err[t] & kErrPoolFull) ? "node pool full " : "",
+                            (err[t] & kErrRngEmpty) ? "random window exhausted " : "",
+                            (err[t] & kErrDepth) ? "depth limit " : "");
+    return TG_OK;
+}
+
+int tg_search_root_planes(tg_search *s, float *planes_dev, void *stream) {
+    if (!s || !planes_dev) return tg::fail(TG_ERR_ARG, "tg_search_root_planes: null argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    s->last_stream = st;
+    if (s->S == 9) hipLaunchKernelGGL(root_kernel<9>, dim3(s->dev.T), dim3(64), 0, st, s->dev, planes_dev);
+    else hipLaunchKernelGGL(root_kernel<19>, dim3(s->dev.T), dim3(64), 0, st, s->dev, planes_dev);
+    TG_HIP(hipGetLastError());
+    return TG_OK;
+}
+
+int tg_search_select_puct(tg_search *s, int max_leaves, float *planes_dev, int32_t *n_leaves_dev, void *stream) {
+    if (!s || !planes_dev) return tg::fail(TG_ERR_ARG, "tg_search_select_puct: null argument");
+    if (max_leaves < 0 || max_leaves > s->dev.K)
+        return tg::fail(TG_ERR_ARG, "tg_search_select_puct: max_leaves %d outside [0, batch_size]", max_leaves);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    s->last_stream = st;
+    if (s->S == 9)
+        hipLaunchKernelGGL(select_puct_kernel<9>, dim3(s->dev.T), dim3(64), 0, st, s->dev, max_leaves, planes_dev);
+    else
+        hipLaunchKernelGGL(select_puct_kernel<19>, dim3(s->dev.T), dim3(64), 0, st, s->dev, max_leaves, planes_dev);
+    TG_HIP(hipGetLastError());
+    if (n_leaves_dev)
+        TG_HIP(hipMemcpyAsync(n_leaves_dev, s->dev.n_leaves, (size_t)s->dev.T * sizeof(int32_t),
+                              hipMemcpyDeviceToDevice, st));
+    return TG_OK;
+}
+
+int tg_search_backup(tg_search *s, const float *policy_dev, const float *value_dev, int slots_per_tree,
+                     int use_logit, void *stream) {
+    if (!s || !policy_dev || !value_dev) return tg::fail(TG_ERR_ARG, "tg_search_backup: null argument");
+    if (slots_per_tree < 1 || slots_per_tree > s->dev.K)
+        return tg::fail(TG_ERR_ARG, "tg_search_backup: slots_per_tree %d outside [1, batch_size]", slots_per_tree);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    s->last_stream = st;
+    if (s->S == 9)
+        hipLaunchKernelGGL(backup_kernel<9>, dim3(s->dev.T), dim3(64), 0, st, s->dev, policy_dev, value_dev, slots_per_tree, use_logit);
+    else
+        hipLaunchKernelGGL(backup_kernel<19>, dim3(s->dev.T), dim3(64), 0, st, s->dev, policy_dev, value_dev, slots_per_tree, use_logit);
+    TG_HIP(hipGetLastError());
+    return TG_OK;
+}
+
+int tg_search_num_nodes(tg_search *s, int32_t *num_nodes_host) {
+    if (!s || !num_nodes_host) return tg::fail(TG_ERR_ARG, "tg_search_num_nodes: null argument");
+    if (s->last_stream) TG_HIP(hipStreamSynchronize(s->last_stream));
+    else TG_HIP(hipDeviceSynchronize());
+    int rc = check_errors(s);
+    if (rc) return rc;
+    std::vector<RootMeta> meta(s->dev.T);
+    TG_HIP(hipMemcpy(meta.data(), s->dev.meta, meta.size() * sizeof(RootMeta), hipMemcpyDeviceToHost));
+    for (int t = 0; t < s->dev.T; ++t) num_nodes_host[t] = meta[t].num_nodes;
+    return TG_OK;
+}
+
+int tg_search_read_node(tg_search *s, int tree, int node, int32_t *num_children, int32_t *node_visits,
+                        int32_t *node_virtual_loss, int32_t *action, int32_t *children_index, int32_t *children_visits,
+                        int32_t *children_virtual_loss, double *children_value_sum, double *children_policy,
+                        double *children_value, float *node_value_sum, float *raw_value) {
+    if (!s) return tg::fail(TG_ERR_ARG, "tg_search_read_node: null argument");
+    if (tree < 0 || tree >= s->dev.T || node < 0 || node >= s->dev.N)
+        return tg::fail(TG_ERR_ARG, "tg_search_read_node: tree/node out of range");
+    if (s->last_stream) TG_HIP(hipStreamSynchronize(s->last_stream));
+    else TG_HIP(hipDeviceSynchronize());
+    int rc = check_errors(s);
+    if (rc) return rc;
+    const SearchDev &D = s->dev;
+    const size_t ns = (size_t)tree * D.N + node, base = ns * s->A, A = s->A;
+#define RD(dst, src, n, type) if (dst) TG_HIP(hipMemcpy(dst, src, (n) * sizeof(type), hipMemcpyDeviceToHost));
+    RD(num_children, D.n_children + ns, 1, int32_t)
+    RD(node_visits, D.n_visits + ns, 1, int32_t)
+    RD(node_virtual_loss, D.n_vl + ns, 1, int32_t)
+    RD(children_index, D.ch_index + base, A, int32_t)
+    RD(children_visits, D.ch_visits + base, A, int32_t)
+    RD(children_virtual_loss, D.ch_vl + base, A, int32_t)
+    RD(children_value_sum, D.ch_vsum + base, A, double)
+    RD(children_policy, D.ch_policy + base, A, double)
+    RD(children_value, D.ch_value + base, A, double)
+    RD(node_value_sum, D.n_vsum + ns, 1, float)
+    RD(raw_value, D.n_raw + ns, 1, float)
+#undef RD
+    if (action) {
+        std::vector<int16_t> a16(A);
+        TG_HIP(hipMemcpy(a16.data(), D.action + base, A * sizeof(int16_t), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < A; ++i) action[i] = a16[i];
+    }
+    return TG_OK;
+}
+
+}  // extern "C"

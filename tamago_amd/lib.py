@@ -50,8 +50,8 @@ _SIGNATURES = {
     "tg_search_rng_consumed": (c_int, [c_void_p, c_void_p]),
     "tg_search_select_puct": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "tg_search_root_planes": (c_int, [c_void_p, c_void_p, c_void_p]),
-    "tg_search_backup": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
-    "tg_search_read_node": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 11),
+    "tg_search_backup": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "tg_search_read_node": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 12),
     "tg_search_num_nodes": (c_int, [c_void_p, c_void_p]),
 }
 

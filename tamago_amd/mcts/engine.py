@@ -1,0 +1,226 @@
+"""Lock-step driver of T device-resident search trees (host side of the C ABI in
+include/tamago_hip.h).  MCTSTree (one tree, the reference's API) and the self-play worker
+(many boards per GPU) are thin layers over this class.
+
+Random streams: the reference consumes numpy's legacy MT19937 stream in program order -
+n doubles per node expansion (Dirichlet(1..1) prior, mcts/tree.py:509-519) and A doubles
+per Gumbel move (mcts/node.py:275-278).  ``ExpStream`` reproduces that stream position by
+position with ``RandomState.standard_exponential`` / ``gumbel`` (the very C functions
+numpy's dirichlet / gumbel use, so the doubles are bit-identical) and hands windows of it
+to the device, which consumes them with a cursor.
+"""
+import ctypes
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from tamago_amd import lib as _lib
+from tamago_amd.board.go_board import GoBoard, zobrist_keys
+from tamago_amd.board.stone import color_value
+from tamago_amd.mcts.node import MCTSNode
+
+
+class ExpStream:
+    """Position-addressable view of a legacy numpy stream as exponentials."""
+
+    def __init__(self, state):
+        self.origin = state                       # RandomState.get_state() tuple at position 0
+        self.gen = np.random.RandomState()
+        self.gen.set_state(state)
+        self.buf = np.empty(0, dtype=np.float64)  # exponentials for positions [buf0, buf0+len)
+        self.buf0 = 0
+        self.pos = 0                              # next unconsumed position
+
+    def window(self, need: int) -> np.ndarray:
+        have = self.buf0 + len(self.buf) - self.pos
+        if have < need:
+            extra = self.gen.standard_exponential(need - have)
+            self.buf = np.concatenate([self.buf[self.pos - self.buf0:], extra])
+            self.buf0 = self.pos
+        off = self.pos - self.buf0
+        return self.buf[off:off + need]
+
+    def consume(self, count: int):
+        self.pos += int(count)
+
+    def gumbel(self, size: int) -> np.ndarray:
+        """Next `size` positions as Gumbel(0,1) noise (node.py:278)."""
+        g = np.random.RandomState()
+        g.set_state(self.origin)
+        if self.pos:
+            g.random_sample(self.pos)             # one double per position
+        noise = g.gumbel(loc=0.0, scale=1.0, size=size)
+        self.pos += size
+        self.gen = g                              # continue after the noise
+        self.buf = np.empty(0, dtype=np.float64)
+        self.buf0 = self.pos
+        return noise
+
+    def final_state(self):
+        """Generator state after everything consumed so far."""
+        g = np.random.RandomState()
+        g.set_state(self.origin)
+        if self.pos:
+            g.random_sample(self.pos)
+        return g.get_state()
+
+
+class HostEvaluator:
+    """Adapter for any object with the DualNet host API (inference /
+    inference_with_policy_logits on CPU tensors): planes are copied to the host, results
+    back to the device.  Used for stand-in evaluators in the parity tests and for drop-in
+    compatibility with arbitrary networks."""
+
+    def __init__(self, network, device):
+        self.network = network
+        self.device = device
+        self.batches: List[int] = []
+
+    def __call__(self, planes: torch.Tensor, want_logits: bool):
+        x = planes.cpu()
+        self.batches.append(x.shape[0])
+        if want_logits:
+            policy, value = self.network.inference_with_policy_logits(x)
+        else:
+            policy, value = self.network.inference(x)
+        return (policy.to(self.device, torch.float32).contiguous(),
+                value.to(self.device, torch.float32).contiguous())
+
+
+class DeviceEvaluator:
+    """DualNet forward without a host hop (tg_net_forward_dev)."""
+
+    def __init__(self, network):
+        self.network = network
+        self.batches: List[int] = []
+
+    def __call__(self, planes: torch.Tensor, want_logits: bool):
+        self.batches.append(planes.shape[0])
+        return self.network.forward_device(planes, want_logits)
+
+
+class SearchEngine:
+    def __init__(self, board_size: int, num_trees: int, tree_size: int, batch_size: int,
+                 evaluator, cgos_mode: bool = False, check_superko: bool = False,
+                 device_index: int = 0):
+        self.lib = _lib.load()
+        self.S = board_size
+        self.P = board_size * board_size
+        self.A = self.P + 1
+        self.T = num_trees
+        self.N = tree_size
+        self.K = batch_size
+        self.device = torch.device("cuda", device_index)
+        self.evaluator = evaluator
+        cfg = _lib.SearchConfig(board_size, num_trees, tree_size, batch_size, int(cgos_mode),
+                                int(check_superko), device_index, 0)
+        handle = ctypes.c_void_p()
+        _lib.check(self.lib.tg_search_create(ctypes.byref(cfg), ctypes.byref(handle)),
+                   "tg_search_create")
+        self.handle = handle
+        keys = zobrist_keys(board_size)
+        _lib.check(self.lib.tg_search_set_zobrist(self.handle, keys.ctypes.data, keys.size),
+                   "tg_search_set_zobrist")
+        self.planes = torch.empty((num_trees * batch_size, 6, board_size, board_size),
+                                  dtype=torch.float32, device=self.device)
+        self.streams: List[Optional[ExpStream]] = [None] * num_trees
+
+    def close(self):
+        if self.handle is not None:
+            self.lib.tg_search_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    # ---------------------------------------------------------------------------------
+    def set_root(self, tree: int, board: GoBoard, color, rng_state=None):
+        """Position + (optionally) the legacy-RNG state this tree draws from."""
+        assert board.board_size == self.S
+        cells = np.ascontiguousarray(board.cells, dtype=np.uint8)
+        hist = np.ascontiguousarray(board.rec_hash[:min(board.moves, board.max_records)])
+        pos = _lib.RootPosition(cells.ctypes.data, hist.ctypes.data,
+                                ctypes.c_uint64(int(board.hash)), board.moves, board.ko_pos,
+                                board.ko_move, board.prev_move(1), board.prev_move(2),
+                                color_value(color))
+        _lib.check(self.lib.tg_search_set_root(self.handle, tree, ctypes.byref(pos)),
+                   "tg_search_set_root")
+        if rng_state is not None:
+            self.streams[tree] = ExpStream(rng_state)
+
+    def _feed_rng(self, need: int):
+        win = np.empty((self.T, need), dtype=np.float64)
+        for t, s in enumerate(self.streams):
+            win[t] = s.window(need)
+        _lib.check(self.lib.tg_search_set_rng(self.handle, win.ctypes.data, need, need),
+                   "tg_search_set_rng")
+
+    def _collect_rng(self):
+        used = np.zeros(self.T, dtype=np.int64)
+        _lib.check(self.lib.tg_search_rng_consumed(self.handle, used.ctypes.data),
+                   "tg_search_rng_consumed")
+        for s, c in zip(self.streams, used):
+            s.consume(int(c))
+        return used
+
+    def _evaluate_and_backup(self, n_slots: int, use_logit: bool):
+        planes = self.planes[:self.T * n_slots]
+        policy, value = self.evaluator(planes, use_logit)
+        _lib.check(self.lib.tg_search_backup(self.handle, policy.data_ptr(), value.data_ptr(),
+                                             n_slots, int(use_logit), self._stream()),
+                   "tg_search_backup")
+        self._keep = (policy, value)        # keep alive until the stream has consumed them
+
+    def root_eval(self, use_logit: bool = False):
+        """tree.py:49-54: expand + evaluate the root of every tree (one leaf each)."""
+        self._feed_rng(self.A)
+        _lib.check(self.lib.tg_search_root_planes(self.handle, self.planes.data_ptr(),
+                                                  self._stream()), "tg_search_root_planes")
+        self._evaluate_and_backup(1, use_logit)
+        self._collect_rng()
+
+    def puct_batch(self, leaves: int):
+        """`leaves` PUCT descents per tree + one evaluation + backup (tree.py:146-152 with
+        the flush of :240-241)."""
+        self._feed_rng(leaves * self.A)
+        _lib.check(self.lib.tg_search_select_puct(self.handle, leaves, self.planes.data_ptr(),
+                                                  None, self._stream()), "tg_search_select_puct")
+        self._evaluate_and_backup(leaves, False)
+        self._collect_rng()
+
+    # ---------------------------------------------------------------------------------
+    def num_nodes(self) -> np.ndarray:
+        out = np.zeros(self.T, dtype=np.int32)
+        _lib.check(self.lib.tg_search_num_nodes(self.handle, out.ctypes.data), "tg_search_num_nodes")
+        return out
+
+    def read_node(self, tree: int, node: int) -> MCTSNode:
+        a = self.A
+        view = MCTSNode(a)
+        nc = ctypes.c_int32()
+        nv = ctypes.c_int32()
+        nvl = ctypes.c_int32()
+        nvs = ctypes.c_float()
+        raw = ctypes.c_float()
+        action = np.zeros(a, dtype=np.int32)
+        _lib.check(self.lib.tg_search_read_node(
+            self.handle, tree, node, ctypes.byref(nc), ctypes.byref(nv), ctypes.byref(nvl),
+            action.ctypes.data,
+            view.children_index.ctypes.data, view.children_visits.ctypes.data,
+            view.children_virtual_loss.ctypes.data, view.children_value_sum.ctypes.data,
+            view.children_policy.ctypes.data, view.children_value.ctypes.data,
+            ctypes.byref(nvs), ctypes.byref(raw)), "tg_search_read_node")
+        view.num_children = nc.value
+        view.node_visits = nv.value
+        view.virtual_loss = nvl.value
+        view.node_value_sum = np.float32(nvs.value)
+        view.raw_value = np.float32(raw.value)
+        view.action = [int(v) for v in action]
+        return view

@@ -1,0 +1,70 @@
+"""Read-side view of one search-tree node (mirror of the MCTSNode fields and getters that
+callers read after a search, mcts/node.py:21-39,159-375).  The data lives in the GPU node
+pool; a view is a host snapshot fetched through ``tg_search_read_node``."""
+import numpy as np
+
+from tamago_amd.mcts.constant import C_VISIT, C_SCALE
+
+
+def apply_softmax(logits: np.ndarray) -> np.ndarray:
+    """nn/utility.py:125-136."""
+    shifted = np.exp(logits - np.max(logits))
+    return shifted / np.sum(shifted)
+
+
+class MCTSNode:
+    def __init__(self, num_actions: int):
+        self.node_visits = 0
+        self.virtual_loss = 0
+        self.node_value_sum = 0.0
+        self.raw_value = 0.0
+        self.action = [0] * num_actions
+        self.children_index = np.zeros(num_actions, dtype=np.int32)
+        self.children_value = np.zeros(num_actions, dtype=np.float64)
+        self.children_visits = np.zeros(num_actions, dtype=np.int32)
+        self.children_policy = np.zeros(num_actions, dtype=np.float64)
+        self.children_virtual_loss = np.zeros(num_actions, dtype=np.int32)
+        self.children_value_sum = np.zeros(num_actions, dtype=np.float64)
+        self.noise = np.zeros(num_actions, dtype=np.float64)
+        self.num_children = 0
+
+    def get_num_children(self) -> int:
+        return self.num_children
+
+    def get_best_move_index(self) -> int:
+        return int(np.argmax(self.children_visits[:self.num_children]))
+
+    def get_best_move(self) -> int:
+        return self.action[self.get_best_move_index()]
+
+    def get_child_move(self, index: int) -> int:
+        return self.action[index]
+
+    def get_child_index(self, index: int) -> int:
+        return int(self.children_index[index])
+
+    def calculate_value_evaluation(self, index: int) -> float:
+        if self.children_visits[index] == 0:
+            return 0.5
+        return self.children_value_sum[index] / self.children_visits[index]
+
+    def calculate_completed_q_value(self) -> np.ndarray:
+        """node.py:281-305."""
+        n = self.num_children
+        policy = apply_softmax(self.children_policy[:n])
+        q_value = np.divide(self.children_value_sum, self.children_visits,
+                            out=np.zeros_like(self.children_value_sum),
+                            where=(self.children_visits > 0))[:n]
+        sum_prob = np.sum(policy)
+        v_pi = np.sum(policy * q_value)
+        value = (float(self.raw_value) * np.ones(n) + self.node_visits * v_pi / sum_prob) \
+            / (self.node_visits + 1.0)
+        return np.where(self.children_visits[:n] > 0, q_value, value)
+
+    def calculate_improved_policy(self) -> np.ndarray:
+        """node.py:308-321 (used by the self-play record, sgf/selfplay_record.py:56)."""
+        max_visit = np.max(self.children_visits)
+        sigma_base = (C_VISIT + max_visit) * C_SCALE
+        logits = self.children_policy[:self.num_children] \
+            + sigma_base * self.calculate_completed_q_value()
+        return apply_softmax(logits)

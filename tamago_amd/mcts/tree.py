@@ -1,0 +1,128 @@
+"""MCTSTree on MI355X - the reference's search API (mcts/tree.py:26-105,318-356,424-430)
+over the device-resident search engine.
+
+``MCTSTree(network, tree_size, batch_size, cgos_mode)`` / ``search_best_move`` / ``search``
+/ ``get_root`` keep the reference's signatures and semantics: the caller's board is never
+modified, the tree is rebuilt on every call, the return value is a padded-board
+coordinate (PASS = 0, RESIGN = -1), and the Dirichlet / Gumbel draws come out of numpy's
+GLOBAL legacy generator, whose state is advanced exactly as the reference would advance it.
+"""
+from typing import Any, Dict
+
+import numpy as np
+
+from tamago_amd.board.constant import PASS, RESIGN
+from tamago_amd.board.go_board import GoBoard
+from tamago_amd.board.stone import Stone, color_value
+from tamago_amd.mcts.batch_data import BatchQueue
+from tamago_amd.mcts.constant import MCTS_TREE_SIZE, NN_BATCH_SIZE, RESIGN_THRESHOLD
+from tamago_amd.mcts.engine import SearchEngine, HostEvaluator, DeviceEvaluator
+from tamago_amd.mcts.node import MCTSNode
+from tamago_amd.mcts.time_manager import TimeManager
+
+
+class _NodeList:
+    """``tree.node[i]`` -> host snapshot of node i (negative indices as in a list)."""
+
+    def __init__(self, tree):
+        self._tree = tree
+
+    def __len__(self):
+        return self._tree.tree_size
+
+    def __getitem__(self, index: int) -> MCTSNode:
+        if index < 0:
+            index += self._tree.tree_size
+        return self._tree._engine_for(None).read_node(0, index)
+
+
+class MCTSTree:
+    def __init__(self, network, tree_size: int = MCTS_TREE_SIZE, batch_size: int = NN_BATCH_SIZE,
+                 cgos_mode: bool = False, device_index: int = 0):
+        self.network = network
+        self.tree_size = tree_size
+        self.batch_size = batch_size
+        self.cgos_mode = cgos_mode
+        self.device_index = device_index
+        self.num_nodes = 0
+        self.root = 0
+        self.current_root = 0
+        self.batch_queue = BatchQueue()
+        self.to_move = Stone.BLACK
+        self.node = _NodeList(self)
+        self._engine = None
+        self._engine_key = None
+
+    # ------------------------------------------------------------------------------------
+    def _evaluator(self):
+        from tamago_amd.nn.network.dual_net import DualNet
+        import torch
+        if isinstance(self.network, DualNet):
+            return DeviceEvaluator(self.network)
+        return HostEvaluator(self.network, torch.device("cuda", self.device_index))
+
+    def _engine_for(self, board):
+        if board is None:
+            if self._engine is None:
+                raise RuntimeError("no search has run yet")
+            return self._engine
+        key = (board.board_size, bool(board.check_superko), self.batch_size, self.cgos_mode,
+               self.tree_size)
+        if self._engine is None or key != self._engine_key:
+            if self._engine is not None:
+                self._engine.close()
+            self._engine = SearchEngine(board.board_size, 1, self.tree_size, self.batch_size,
+                                        self._evaluator(), self.cgos_mode, board.check_superko,
+                                        self.device_index)
+            self._engine_key = key
+        return self._engine
+
+    def _commit_rng(self, engine):
+        """Leave numpy's global generator where the reference would have left it."""
+        np.random.set_state(engine.streams[0].final_state())
+
+    def get_root(self) -> MCTSNode:
+        return self._engine_for(None).read_node(0, self.current_root)
+
+    # ------------------------------------------------------------------------------------
+    def search_best_move(self, board: GoBoard, color, time_manager: TimeManager,
+                         analysis_query: Dict[str, Any] = None) -> int:
+        """mcts/tree.py:57-105."""
+        engine = self._engine_for(board)
+        self.to_move = color if isinstance(color, Stone) else Stone(color_value(color))
+        engine.set_root(0, board, color, np.random.get_state())
+        engine.root_eval(use_logit=False)                              # _initialize_search
+        time_manager.start_timer()
+        root = engine.read_node(0, 0)
+        if root.get_num_children() == 1:
+            self.num_nodes = int(engine.num_nodes()[0])
+            self._commit_rng(engine)
+            return PASS
+        self.search(board, color, time_manager, analysis_query or {}, _engine=engine)
+        root = engine.read_node(0, 0)
+        self.num_nodes = int(engine.num_nodes()[0])
+        self._commit_rng(engine)
+        search_time = time_manager.calculate_consumption_time()
+        time_manager.set_search_speed(root.node_visits, max(search_time, 1e-9))
+        time_manager.substract_consumption_time(color, search_time)
+        next_index = root.get_best_move_index()
+        if root.calculate_value_evaluation(next_index) < RESIGN_THRESHOLD:
+            return RESIGN
+        return root.action[next_index]
+
+    def search(self, board: GoBoard, color, time_manager: TimeManager,
+               analysis_query: Dict[str, Any] = None, _engine=None):
+        """mcts/tree.py:130-152: `threshold` descents in mini-batches of batch_size; the
+        early-stop test (time_manager.py:135-163) runs after every mini-batch, which is
+        where its inputs change."""
+        engine = _engine or self._engine_for(board)
+        threshold = time_manager.get_num_visits_threshold(color)
+        done = 0
+        while done < threshold:
+            leaves = min(self.batch_size, threshold - done)
+            engine.puct_batch(leaves)
+            done += leaves
+            if leaves == self.batch_size and done < threshold:
+                root = engine.read_node(0, 0)
+                if time_manager.is_time_over() or time_manager.is_move_decided(root, threshold):
+                    break

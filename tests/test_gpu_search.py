@@ -1,0 +1,75 @@
+"""Device-resident MCTS (tamago_amd/csrc/search.hip through the MCTSTree API) vs the
+reference-generated tree fixtures and vs the oracle (needs a GPU).
+
+The evaluator is oracle.stubnet.StubNet on all sides (bit-identical outputs on every
+machine), so visit counts, float32-accumulated value sums, policies, chosen move, node
+count, mini-batch sizes, a digest over the WHOLE tree and the position of numpy's global
+RNG stream after the search must match exactly."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from tests.helpers import load_json, load_npz, unhex
+
+pytestmark = pytest.mark.gpu
+
+
+def product_replay(size, moves, colors, upto, superko):
+    from tamago_amd.board.go_board import GoBoard
+    board = GoBoard(size, 7.0, superko)
+    for mv, c in zip(moves[:upto], colors[:upto]):
+        board.put_stone(int(mv), int(c))
+    return board
+
+
+def product_digest(tree, num_nodes):
+    h = hashlib.sha256()
+    for i in range(num_nodes):
+        nd = tree.node[i]
+        n = nd.num_children
+        h.update(np.array(nd.action[:n], dtype=np.int32).tobytes())
+        h.update(nd.children_index[:n].astype(np.int32).tobytes())
+        h.update(nd.children_visits[:n].astype(np.int32).tobytes())
+        h.update(nd.children_virtual_loss[:n].astype(np.int32).tobytes())
+        h.update(nd.children_value_sum[:n].astype(np.float64).tobytes())
+        h.update(nd.children_policy[:n].astype(np.float64).tobytes())
+        h.update(np.array([nd.node_visits, nd.virtual_loss], dtype=np.int64).tobytes())
+    return h.hexdigest()
+
+
+def check_root(tree, mv, rec, digest=True):
+    root = tree.get_root()
+    n = root.num_children
+    assert n == rec["n"]
+    assert [int(a) for a in root.action[:n]] == rec["action"]
+    assert [int(v) for v in root.children_visits[:n]] == rec["child_visits"]
+    assert np.array_equal(root.children_value_sum[:n], unhex(rec["value_sum"]))
+    assert np.array_equal(root.children_policy[:n], unhex(rec["policy"]))
+    assert int(mv) == rec["move"]
+    assert tree.num_nodes == rec["num_nodes"]
+    assert int(root.node_visits) == rec["node_visits"]
+    assert float(root.node_value_sum) == float.fromhex(rec["node_value_sum"])
+    assert float(root.raw_value) == float.fromhex(rec["raw_value"])
+    if digest:
+        assert product_digest(tree, tree.num_nodes) == rec["digest"]
+
+
+@pytest.mark.parametrize("size", [9, 19])
+def test_puct_vs_reference_golden(size):
+    from oracle.stubnet import StubNet
+    from tamago_amd.mcts.tree import MCTSTree
+    from tamago_amd.mcts.time_manager import TimeManager, TimeControl
+    brd = load_npz(f"board_s{size}.npz")
+    for rec in [r for r in load_json(f"trees_s{size}.json") if r["kind"] == "puct"]:
+        board = product_replay(size, brd["g0_move"], brd["g0_color"], rec["ply"], rec["superko"])
+        cells_before = board.cells.copy()
+        net = StubNet(salt=rec["seed"])
+        tree = MCTSTree(net, tree_size=2048, batch_size=rec["batch"], cgos_mode=rec["cgos"])
+        mode = TimeControl.STRICT_PLAYOUT if rec["mode"] == "STRICT" else TimeControl.CONSTANT_PLAYOUT
+        np.random.seed(rec["seed"])
+        mv = tree.search_best_move(board, rec["color"], TimeManager(mode, rec["visits"]), {})
+        assert net.calls == rec["batches"], rec
+        check_root(tree, mv, rec)
+        assert float(np.random.random_sample()) == float.fromhex(rec["rng_after"])
+        assert np.array_equal(board.cells, cells_before) and board.moves == rec["ply"] + 1
