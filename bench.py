@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MCTS leaf-evaluations/s on 9x9, batch 256 (BASELINE.json).
+
+Workload (config[1] of BASELINE.json): PUCT search, random-init
+DualNet, 1000 strict visits per move, NN mini-batch 256 per tree -> per move and tree
+1 root evaluation + mini-batches of 256/256/256/232 = 1001 leaf evaluations.  One
+"step" = one such move search for every one of the `--trees` independent boards a GPU
+drives in lock-step (self-play boards shard across boards and GPUs without any exchange,
+SURVEY.md 8(e)); after each step every board plays its searched move, so tree shapes
+vary like in self-play.  Inputs (root positions, weights) are resident before the timed
+region; the timed region contains everything else, including the host side of the loop.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--trees T]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0) with the contract's keys plus `roofline` (fused forward
+kernel vs the fp32 MFMA peak, timed with HIP events on the launch stream) and
+`cpu_baseline` (the CPU oracle - a port of the reference's Python path - timed on this
+host on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--trees", type=int, default=64, help="boards searched in lock-step per GPU")
+    ap.add_argument("--visits", type=int, default=1000)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--size", type=int, default=9)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+class TimedEvaluator:
+    """DualNet forward on the launch stream, every launch bracketed by HIP events."""
+
+    def __init__(self, network):
+        self.network = network
+        self.events = []
+        self.batches = []
+        self.record = False
+
+    def __call__(self, planes, want_logits):
+        if self.record:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = self.network.forward_device(planes, want_logits)
+            e1.record()
+            self.events.append((e0, e1, planes.shape[0]))
+        else:
+            out = self.network.forward_device(planes, want_logits)
+        self.batches.append(planes.shape[0])
+        return out
+
+
+def opening_boards(size, count, seed):
+    """Synthetic root positions: seeded random legal openings of 0..11 plies."""
+    from tamago_amd.board.go_board import GoBoard
+    rs = np.random.RandomState(seed)
+    boards, colors = [], []
+    for i in range(count):
+        board = GoBoard(size, 7.0, False)
+        color = 1
+        for _ in range(i % 12):
+            legal = board.get_all_legal_pos(color)
+            board.put_stone(legal[rs.randint(len(legal))], color)
+            color = 3 - color
+        boards.append(board)
+        colors.append(color)
+    return boards, colors
+
+
+def run_step(engine, boards, colors, visits, batch):
+    """One move search for every tree; returns leaf evaluations done."""
+    for t, (b, c) in enumerate(zip(boards, colors)):
+        engine.set_root(t, b, c)
+    engine.root_eval(False)
+    done = 0
+    while done < visits:
+        k = min(batch, visits - done)
+        engine.puct_batch(k)
+        done += k
+    leaves = engine.T * (1 + visits)
+    # play the searched move (arg-max visits) on every board
+    nc, action, visits_arr = engine.read_roots()
+    for t in range(engine.T):
+        mv = int(action[t][int(np.argmax(visits_arr[t][:nc[t]]))])
+        if boards[t].moves > 2 * engine.P - 8:
+            boards[t].clear()
+            colors[t] = 1
+            continue
+        boards[t].put_stone(mv, colors[t])
+        colors[t] = 3 - colors[t]
+    return leaves
+
+
+def cpu_baseline(size, visits, batch, budget_s):
+    """The CPU oracle (port of the reference's Python/NumPy tree + PyTorch-CPU DualNet)
+    on the same workload, bounded to ~budget_s seconds."""
+    from oracle.board import GoBoard as OBoard, BLACK
+    from oracle.net import OracleNet
+    from oracle.tree import MCTSTree as OTree, TimeManager as OTM, TimeControl as OTC
+    from tamago_amd.nn.network.dual_net import random_state_dict
+    torch.manual_seed(0)
+    net = OracleNet(random_state_dict(size))
+    tree = OTree(net, size, tree_size=visits + 16, batch_size=batch)
+    board = OBoard(size)
+    np.random.seed(0)
+    color = BLACK
+    tm = OTM(OTC.STRICT_PLAYOUT, visits)
+    mv = tree.search_best_move(board, color, tm)            # warm-up move
+    board.put_stone(mv if mv > 0 else 0, color)
+    color = 3 - color
+    t0 = time.time()
+    leaves = 0
+    moves = 0
+    while time.time() - t0 < budget_s and moves < 30:
+        mv = tree.search_best_move(board, color, tm)
+        leaves += sum(tree.batch_log)
+        tree.batch_log.clear()
+        board.put_stone(mv if mv > 0 else 0, color)
+        color = 3 - color
+        moves += 1
+    dt = time.time() - t0
+    return {"value": leaves / dt, "unit": "leaf-evals/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"{moves} moves x {visits + 1} leaf-evals, 1 tree, batch {batch}, "
+                      f"oracle Python tree (1 thread) + PyTorch-CPU DualNet "
+                      f"({torch.get_num_threads()} threads) of {os.cpu_count()} host cores, "
+                      f"{dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from tamago_amd import lib as tl
+    from tamago_amd.mcts.engine import SearchEngine
+    from tamago_amd.nn.network.dual_net import DualNet
+    lib = tl.load()
+
+    torch.manual_seed(1234)
+    net = DualNet(dev, args.size)                      # random-init weights, resident
+    evaluator = TimedEvaluator(net)
+    engine = SearchEngine(args.size, args.trees, args.visits + 16, args.batch, evaluator,
+                          device_index=local_rank)
+    boards, colors = opening_boards(args.size, args.trees, 1000 + rank)
+    for t in range(args.trees):                         # one private legacy stream per board
+        rs = np.random.RandomState(10_000 * rank + t)
+        engine.set_root(t, boards[t], colors[t], rs.get_state())
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        run_step(engine, boards, colors, args.visits, args.batch)
+    evaluator.record = True
+    barrier()
+    t0 = time.perf_counter()
+    leaves = 0
+    for _ in range(args.steps):
+        leaves += run_step(engine, boards, colors, args.visits, args.batch)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    # forward-kernel time from the HIP events recorded around every launch
+    kern_ms = 0.0
+    kern_pos = 0
+    big = []
+    for e0, e1, b in evaluator.events:
+        ms = e0.elapsed_time(e1)
+        kern_ms += ms
+        kern_pos += b
+        if b == args.trees * args.batch:
+            big.append(ms)
+    flops_pos = lib.tg_net_flops_per_position(args.size)
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        tot = torch.tensor([leaves], device=dev, dtype=torch.float64)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        leaves = float(tot.item())
+
+    if rank == 0:
+        full_b = args.trees * args.batch
+        avg_ms = float(np.mean(big)) if big else float("nan")
+        achieved = full_b * flops_pos / (avg_ms * 1e-3) / 1e12 if big else float("nan")
+        result = {
+            "metric": "MCTS leaf-evals/sec (9x9, batch 256)" if args.size == 9
+            else f"MCTS leaf-evals/sec ({args.size}x{args.size}, batch {args.batch})",
+            "value": leaves / elapsed,
+            "unit": "leaf-evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"cfg-2 PUCT {args.size}x{args.size}, random-init DualNet, "
+                            f"{args.visits} strict visits/move, NN batch {args.batch} per tree",
+                "trees_per_gpu": args.trees,
+                "leaf_evals_per_step_per_gpu": args.trees * (args.visits + 1),
+                "parallelism": f"{world} x independent board shards (no collective)",
+            },
+            "roofline": {
+                "bound": "mfma",
+                "kernel": lib.tg_net_kernel_name(net.handle, full_b).decode(),
+                "achieved": achieved,
+                "peak": FP32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
+                "traffic": None,
+                "avg_launch_ms": avg_ms,
+                "launches": len(big),
+                "positions_per_launch": full_b,
+                "flops_per_position": flops_pos,
+                "forward_share_of_step": kern_ms * 1e-3 / (elapsed if world == 1 else elapsed),
+                "end_to_end_frac": leaves / elapsed / world * flops_pos / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+            },
+        }
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args.size, args.visits, args.batch,
+                                                  args.cpu_seconds)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -120,8 +120,8 @@ int tg_search_destroy(tg_search *s);
  * the caller owns the key table so that its own GoBoard hashes stay consistent. */
 int tg_search_set_zobrist(tg_search *s, const uint64_t *keys, size_t n);
 
-/* Reset tree `t` to a single un-evaluated root for `pos` (tree.py:49-54 / :330-336,
- * first half: num_nodes = 0, expand_node(root)). */
+/* Stage the root position of tree `t` (copied; uploaded in bulk by the next
+ * tg_search_root_planes, which resets the tree: tree.py:49-54 / :330-336). */
 int tg_search_set_root(tg_search *s, int tree, const tg_root_position *pos);
 
 /* Feed the per-tree random streams.  The reference draws the Dirichlet "tentative"
@@ -142,6 +142,16 @@ int tg_search_select_puct(tg_search *s, int max_leaves, float *planes_dev, int32
 /* Reset every tree to its root position, expand the root (consumes the root's Dirichlet
  * draw) and write the root planes [T,6,S,S] (tree.py:49-53); one leaf per tree is queued. */
 int tg_search_root_planes(tg_search *s, float *planes_dev, void *stream);
+/* Gumbel root noise, float64 [T][A] (node.py:275-278 set_gumbel_noise), to be set after the
+ * root evaluation of a Gumbel move. */
+int tg_search_set_noise(tg_search *s, const double *noise_host);
+/* One sequential-halving phase (tree.py:375-383): per tree, for count_threshold in
+ * 1..max_count[t], num_considered[t] descents (root: node.py:324-346, below: :349-361);
+ * every descent queues one leaf.  Planes [T, slots_per_tree, 6, S, S]; trees whose phase
+ * is (0, 0) idle.  Follow with the forward pass and tg_search_backup(use_logit = 1). */
+int tg_search_select_gumbel(tg_search *s, const int32_t *num_considered_host,
+                            const int32_t *max_count_host, int slots_per_tree,
+                            float *planes_dev, void *stream);
 /* Write NN outputs back and back up values (tree.py:273-315 process_mini_batch).
  * policy_dev [T, slots_per_tree, A], value_dev [T, slots_per_tree, 3] in the slot order
  * of the preceding call (slots_per_tree = its max_leaves, or 1 after root_planes);
@@ -158,6 +168,10 @@ int tg_search_read_node(tg_search *s, int tree, int node, int32_t *num_children,
                         double *children_value_sum, double *children_policy,
                         double *children_value, float *node_value_sum, float *raw_value);
 int tg_search_num_nodes(tg_search *s, int32_t *num_nodes_host /* [T] */);
+/* Root statistics of all trees in one call: num_children [T], action [T][A],
+ * children_visits [T][A] (what get_best_move reads, node.py:169-184). Synchronises. */
+int tg_search_read_roots(tg_search *s, int32_t *num_children_host, int32_t *action_host,
+                         int32_t *visits_host);
 
 #ifdef __cplusplus
 }

@@ -117,6 +117,8 @@ template <int S>
 struct Lds {
     using G = Geo<S>;
     uint64_t hist[G::HMAX];
+    double w1[G::A + 7];
+    double w2[G::A + 7];
     uint64_t strhash[G::NC];
     uint32_t libcnt[G::NC];
     uint32_t strsize[G::NC];
@@ -644,6 +646,228 @@ __global__ __launch_bounds__(64) void backup_kernel(SearchDev D, const float *po
     if (lane == 0) D.n_leaves[t] = 0;
 }
 
+
+// numpy's float64 add.reduce order (pairwise_sum in numpy/core/src/umath/loops_utils.h.src):
+// < 8 elements sequential; <= 128 elements eight interleaved accumulators combined as
+// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) then the tail; larger arrays split in halves (multiple
+// of 8).  Every lane runs it redundantly on an LDS vector (wave-uniform result).
+__device__ double np_sum_block(const double *a, int n) {
+    if (n < 8) {
+        double r = 0.;
+        for (int i = 0; i < n; ++i) r += a[i];
+        return r;
+    }
+    double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8) {
+        r0 += a[i]; r1 += a[i + 1]; r2 += a[i + 2]; r3 += a[i + 3];
+        r4 += a[i + 4]; r5 += a[i + 5]; r6 += a[i + 6]; r7 += a[i + 7];
+    }
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; ++i) res += a[i];
+    return res;
+}
+__device__ double np_sum(const double *a, int n) {
+    if (n <= 128) return np_sum_block(a, n);
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    const int nr = n - n2;
+    // one more level is enough for n <= 512 (A <= 362)
+    double left, right;
+    if (n2 <= 128) left = np_sum_block(a, n2);
+    else { int m = n2 / 2; m -= m % 8; left = np_sum_block(a, m) + np_sum_block(a + m, n2 - m); }
+    if (nr <= 128) right = np_sum_block(a + n2, nr);
+    else { int m = nr / 2; m -= m % 8; right = np_sum_block(a + n2, m) + np_sum_block(a + n2 + m, nr - m); }
+    return left + right;
+}
+__device__ __forceinline__ double wave_max_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const double ov = __shfl_xor(v, o); v = ov > v ? ov : v; }
+    return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int ov = __shfl_xor(v, o); v = ov > v ? ov : v; }
+    return v;
+}
+
+// node.py:324-346 select_move_by_sequential_halving_for_root
+template <int S>
+__device__ int select_root_halving(const SearchDev &D, int t, int node, int count_threshold, int lane) {
+    constexpr int A = Geo<S>::A;
+    const size_t ns = (size_t)t * D.N + node;
+    const size_t base = ns * A;
+    const int nc = D.n_children[ns];
+    int mx = 0;
+    for (int i = lane; i < nc; i += 64) mx = max(mx, D.ch_visits[base + i]);
+    mx = wave_max_i32(mx);
+    const double sigma = (double)(50 + mx) * 1.0;                   // (C_VISIT + max) * C_SCALE
+    double best = 0.0;
+    int best_i = -1;
+    for (int i = lane; i < nc; i += 64) {
+        const int v = D.ch_visits[base + i];
+        const int cnt = v + D.ch_vl[base + i];
+        const double q = v > 0 ? D.ch_vsum[base + i] / (double)v : 0.0;
+        const double logit = D.ch_policy[base + i] + D.noise[(size_t)t * A + i];
+        const double sc = cnt >= count_threshold ? -10000.0 : logit + sigma * q;
+        if (best_i < 0 || sc > best) { best = sc; best_i = i; }
+    }
+    wave_argmax(best, best_i);
+    return best_i;
+}
+
+// node.py:349-361 select_move_by_sequential_halving_for_node (+ :281-321 completed Q,
+// improved policy; nn/utility.py:125-136 softmax), float64 throughout
+template <int S>
+__device__ int select_node_halving(Lds<S> &L, const SearchDev &D, int t, int node, int lane) {
+    constexpr int A = Geo<S>::A;
+    constexpr int R = (A + 63) / 64;
+    const size_t ns = (size_t)t * D.N + node;
+    const size_t base = ns * A;
+    const int nc = D.n_children[ns];
+    const int nv = D.n_visits[ns];
+    const double raw = (double)D.n_raw[ns];
+    double logit[R], q[R];
+    int vis[R];
+    double mx = -INFINITY;
+    int maxv = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = lane + 64 * r;
+        logit[r] = 0.0; q[r] = 0.0; vis[r] = 0;
+        if (i < nc) {
+            logit[r] = D.ch_policy[base + i];
+            vis[r] = D.ch_visits[base + i];
+            q[r] = vis[r] > 0 ? D.ch_vsum[base + i] / (double)vis[r] : 0.0;
+            mx = logit[r] > mx ? logit[r] : mx;
+            maxv = max(maxv, vis[r]);
+        }
+    }
+    mx = wave_max_f64(mx);
+    maxv = wave_max_i32(maxv);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = lane + 64 * r;
+        if (i < nc) L.w1[i] = exp(logit[r] - mx);
+    }
+    __syncthreads();
+    const double s1 = np_sum(L.w1, nc);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = lane + 64 * r;
+        if (i < nc) {
+            const double pi = L.w1[i] / s1;
+            L.w1[i] = pi;
+            L.w2[i] = pi * q[r];
+        }
+    }
+    __syncthreads();
+    const double sum_prob = np_sum(L.w1, nc);
+    const double v_pi = np_sum(L.w2, nc);
+    const double mixed = (raw + ((double)nv * v_pi) / sum_prob) / ((double)nv + 1.0);
+    const double sigma = (double)(50 + maxv) * 1.0;
+    double il[R];
+    double mx2 = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = lane + 64 * r;
+        il[r] = 0.0;
+        if (i < nc) {
+            il[r] = logit[r] + sigma * (vis[r] > 0 ? q[r] : mixed);
+            mx2 = il[r] > mx2 ? il[r] : mx2;
+        }
+    }
+    mx2 = wave_max_f64(mx2);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = lane + 64 * r;
+        if (i < nc) L.w1[i] = exp(il[r] - mx2);
+    }
+    __syncthreads();
+    const double s2 = np_sum(L.w1, nc);
+    double best = 0.0;
+    int best_i = -1;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = lane + 64 * r;
+        if (i < nc) {
+            const double sc = L.w1[i] / s2 - ((double)vis[r] / (1.0 + (double)nv));
+            if (best_i < 0 || sc > best) { best = sc; best_i = i; }
+        }
+    }
+    __syncthreads();
+    wave_argmax(best, best_i);
+    return best_i;
+}
+
+// tree.py:359-422: one sequential-halving phase per launch: for threshold 1..max_count,
+// num_considered descents each; every descent ends in a queued leaf.
+template <int S>
+__global__ __launch_bounds__(64) void select_gumbel_kernel(SearchDev D, const int32_t *num_considered,
+                                                           const int32_t *max_count, int stride,
+                                                           float *planes) {
+    using G = Geo<S>;
+    constexpr int A = G::A;
+    __shared__ Lds<S> L;
+    const int t = blockIdx.x, lane = threadIdx.x;
+    BoardScalars rootb;
+    int root_to_move;
+    load_root<S>(L, rootb, root_to_move, D, t, lane);
+    int num_nodes = D.meta[t].num_nodes;
+    int queued = 0;
+    const int width = num_considered[t], levels = max_count[t];
+    bool ok = D.err[t] == 0 && num_nodes > 0 && width * levels <= stride;
+    for (int th = 1; ok && th <= levels; ++th) {
+        for (int j = 0; ok && j < width; ++j) {
+            reset_work<S>(L, lane);
+            BoardScalars b = rootb;
+            int c = root_to_move;
+            int node = 0;
+            for (;;) {
+                const size_t ns = (size_t)t * D.N + node;
+                const size_t base = ns * A;
+                const int e = node == 0 ? select_root_halving<S>(D, t, node, th, lane)
+                                        : select_node_halving<S>(L, D, t, node, lane);
+                const int mv = D.action[base + e];
+                put_stone<S>(L, b, mv, c, D.zob, lane);
+                c = 3 - c;
+                const int visits = D.ch_visits[base + e];
+                int child = D.ch_index[base + e];
+                __syncthreads();
+                if (lane == 0) {
+                    D.n_vl[ns] += 1;
+                    D.ch_vl[base + e] += 1;
+                }
+                if (visits < 1) {                                     // tree.py:412-416
+                    write_planes<S>(L, b, c, planes + ((size_t)t * stride + queued) * 6 * G::P, lane);
+                    if (lane == 0) {
+                        D.q_node[(size_t)t * D.K + queued] = child;   // still NOT_EXPANDED: node[-1]
+                        D.q_pnode[(size_t)t * D.K + queued] = node;
+                        D.q_pedge[(size_t)t * D.K + queued] = e;
+                    }
+                    __syncthreads();
+                    break;
+                }
+                if (child == kNotExpanded) {                          // tree.py:418-420
+                    child = expand_node<S>(L, b, c, D, t, num_nodes, node, e, lane);
+                    if (child < 0) { ok = false; break; }
+                    if (lane == 0) D.ch_index[base + e] = child;
+                }
+                node = child;
+                __syncthreads();
+            }
+            if (ok) ++queued;
+        }
+    }
+    if (lane == 0) {
+        D.meta[t].num_nodes = num_nodes;
+        D.n_leaves[t] = queued;
+    }
+}
+
 // Host-built eye table: same rule as board/pattern.py:52-98 produces.
 void build_eye_table(std::vector<uint8_t> &table) {
     table.assign(65536, 0);
@@ -703,6 +927,12 @@ struct tg_search {
     std::vector<void *> allocs;
     int S = 0, W = 0, NC = 0, P = 0, A = 0, HMAX = 0;
     hipStream_t last_stream = nullptr;
+    // root positions are staged on the host and uploaded in bulk by tg_search_root_planes
+    std::vector<uint8_t> st_cells;
+    std::vector<uint64_t> st_hist;
+    std::vector<RootMeta> st_meta;
+    bool st_dirty = false;
+    int32_t *phase_dev = nullptr;
 };
 
 namespace {
@@ -770,6 +1000,9 @@ int tg_search_create(const tg_search_config *cfg, tg_search **out) {
     hipError_t e = hipMemcpy(eye_dev, eye.data(), eye.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) { tg_search_destroy(s); return tg::fail(TG_ERR_HIP, "eye upload: %s", hipGetErrorString(e)); }
     D.eye = eye_dev;
+    s->st_cells.assign(T * s->NC, 0);
+    s->st_hist.assign(T * s->HMAX, 0);
+    s->st_meta.assign(T, RootMeta{});
     *out = s;
     return TG_OK;
 }
@@ -807,14 +1040,26 @@ int tg_search_set_root(tg_search *s, int tree, const tg_root_position *pos) {
     m.to_move = pos->to_move;
     m.num_nodes = 0;
     m.hist_len = pos->hash_history ? (pos->moves < s->HMAX ? pos->moves : s->HMAX) : 1;
-    TG_HIP(hipMemcpy(s->dev.root_cells + (size_t)tree * s->NC, pos->cells, s->NC, hipMemcpyHostToDevice));
-    if (pos->hash_history)
-        TG_HIP(hipMemcpy(s->dev.root_hist + (size_t)tree * s->HMAX, pos->hash_history,
-                         (size_t)m.hist_len * sizeof(uint64_t), hipMemcpyHostToDevice));
-    else
-        TG_HIP(hipMemset(s->dev.root_hist + (size_t)tree * s->HMAX, 0, sizeof(uint64_t)));
-    TG_HIP(hipMemcpy(s->dev.meta + tree, &m, sizeof(m), hipMemcpyHostToDevice));
-    TG_HIP(hipMemset(s->dev.err + tree, 0, sizeof(int32_t)));
+    std::memcpy(&s->st_cells[(size_t)tree * s->NC], pos->cells, s->NC);
+    uint64_t *hist = &s->st_hist[(size_t)tree * s->HMAX];
+    hist[0] = 0;
+    if (pos->hash_history) std::memcpy(hist, pos->hash_history, (size_t)m.hist_len * sizeof(uint64_t));
+    s->st_meta[tree] = m;
+    s->st_dirty = true;
+    return TG_OK;
+}
+
+static int flush_roots(tg_search *s, hipStream_t st) {
+    if (!s->st_dirty) return TG_OK;
+    const SearchDev &D = s->dev;
+    TG_HIP(hipMemcpyAsync(D.root_cells, s->st_cells.data(), s->st_cells.size(), hipMemcpyHostToDevice, st));
+    if (D.superko)
+        TG_HIP(hipMemcpyAsync(D.root_hist, s->st_hist.data(), s->st_hist.size() * sizeof(uint64_t),
+                              hipMemcpyHostToDevice, st));
+    TG_HIP(hipMemcpyAsync(D.meta, s->st_meta.data(), s->st_meta.size() * sizeof(RootMeta),
+                          hipMemcpyHostToDevice, st));
+    TG_HIP(hipMemsetAsync(D.err, 0, (size_t)D.T * sizeof(int32_t), st));
+    s->st_dirty = false;
     return TG_OK;
 }
 
@@ -858,6 +1103,10 @@ int tg_search_root_planes(tg_search *s, float *planes_dev, void *stream) {
     if (!s || !planes_dev) return tg::fail(TG_ERR_ARG, "tg_search_root_planes: null argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
     s->last_stream = st;
+    {
+        int rc = flush_roots(s, st);
+        if (rc) return rc;
+    }
     if (s->S == 9) hipLaunchKernelGGL(root_kernel<9>, dim3(s->dev.T), dim3(64), 0, st, s->dev, planes_dev);
     else hipLaunchKernelGGL(root_kernel<19>, dim3(s->dev.T), dim3(64), 0, st, s->dev, planes_dev);
     TG_HIP(hipGetLastError());
@@ -881,6 +1130,45 @@ int tg_search_select_puct(tg_search *s, int max_leaves, float *planes_dev, int32
     return TG_OK;
 }
 
+
+int tg_search_set_noise(tg_search *s, const double *noise_host) {
+    if (!s || !noise_host) return tg::fail(TG_ERR_ARG, "tg_search_set_noise: null argument");
+    if (s->last_stream) TG_HIP(hipStreamSynchronize(s->last_stream));
+    TG_HIP(hipMemcpy(s->dev.noise, noise_host, (size_t)s->dev.T * s->A * sizeof(double), hipMemcpyHostToDevice));
+    return TG_OK;
+}
+
+int tg_search_select_gumbel(tg_search *s, const int32_t *num_considered_host, const int32_t *max_count_host,
+                            int slots_per_tree, float *planes_dev, void *stream) {
+    if (!s || !num_considered_host || !max_count_host || !planes_dev)
+        return tg::fail(TG_ERR_ARG, "tg_search_select_gumbel: null argument");
+    if (slots_per_tree < 1 || slots_per_tree > s->dev.K)
+        return tg::fail(TG_ERR_ARG, "tg_search_select_gumbel: slots_per_tree %d outside [1, batch_size]", slots_per_tree);
+    for (int t = 0; t < s->dev.T; ++t)
+        if (num_considered_host[t] < 0 || max_count_host[t] < 0 ||
+            (int64_t)num_considered_host[t] * max_count_host[t] > slots_per_tree)
+            return tg::fail(TG_ERR_ARG, "tg_search_select_gumbel: tree %d phase does not fit slots_per_tree", t);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    s->last_stream = st;
+    if (!s->phase_dev) {
+        int rc = dev_alloc(s, &s->phase_dev, (size_t)2 * s->dev.T);
+        if (rc) return rc;
+    }
+    std::vector<int32_t> both(2 * (size_t)s->dev.T);
+    std::memcpy(both.data(), num_considered_host, s->dev.T * sizeof(int32_t));
+    std::memcpy(both.data() + s->dev.T, max_count_host, s->dev.T * sizeof(int32_t));
+    TG_HIP(hipMemcpyAsync(s->phase_dev, both.data(), both.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    TG_HIP(hipStreamSynchronize(st));     // `both` is a stack-lifetime staging buffer
+    if (s->S == 9)
+        hipLaunchKernelGGL(select_gumbel_kernel<9>, dim3(s->dev.T), dim3(64), 0, st, s->dev, s->phase_dev,
+                           s->phase_dev + s->dev.T, slots_per_tree, planes_dev);
+    else
+        hipLaunchKernelGGL(select_gumbel_kernel<19>, dim3(s->dev.T), dim3(64), 0, st, s->dev, s->phase_dev,
+                           s->phase_dev + s->dev.T, slots_per_tree, planes_dev);
+    TG_HIP(hipGetLastError());
+    return TG_OK;
+}
+
 int tg_search_backup(tg_search *s, const float *policy_dev, const float *value_dev, int slots_per_tree,
                      int use_logit, void *stream) {
     if (!s || !policy_dev || !value_dev) return tg::fail(TG_ERR_ARG, "tg_search_backup: null argument");
@@ -893,6 +1181,29 @@ int tg_search_backup(tg_search *s, const float *policy_dev, const float *value_d
     else
         hipLaunchKernelGGL(backup_kernel<19>, dim3(s->dev.T), dim3(64), 0, st, s->dev, policy_dev, value_dev, slots_per_tree, use_logit);
     TG_HIP(hipGetLastError());
+    return TG_OK;
+}
+
+int tg_search_read_roots(tg_search *s, int32_t *num_children_host, int32_t *action_host,
+                         int32_t *visits_host) {
+    if (!s || !num_children_host || !action_host || !visits_host)
+        return tg::fail(TG_ERR_ARG, "tg_search_read_roots: null argument");
+    if (s->last_stream) TG_HIP(hipStreamSynchronize(s->last_stream));
+    else TG_HIP(hipDeviceSynchronize());
+    int rc = check_errors(s);
+    if (rc) return rc;
+    const SearchDev &D = s->dev;
+    const size_t A = s->A, T = D.T, N = D.N;
+    std::vector<int16_t> a16(A);
+    // root = node 0 of every tree: rows are N*A apart
+    TG_HIP(hipMemcpy2D(visits_host, A * sizeof(int32_t), D.ch_visits, N * A * sizeof(int32_t),
+                       A * sizeof(int32_t), T, hipMemcpyDeviceToHost));
+    TG_HIP(hipMemcpy2D(num_children_host, sizeof(int32_t), D.n_children, N * sizeof(int32_t),
+                       sizeof(int32_t), T, hipMemcpyDeviceToHost));
+    std::vector<int16_t> act(T * A);
+    TG_HIP(hipMemcpy2D(act.data(), A * sizeof(int16_t), D.action, N * A * sizeof(int16_t),
+                       A * sizeof(int16_t), T, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < T * A; ++i) action_host[i] = act[i];
     return TG_OK;
 }
 

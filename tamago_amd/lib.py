@@ -49,10 +49,13 @@ _SIGNATURES = {
     "tg_search_set_rng": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t]),
     "tg_search_rng_consumed": (c_int, [c_void_p, c_void_p]),
     "tg_search_select_puct": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "tg_search_set_noise": (c_int, [c_void_p, c_void_p]),
+    "tg_search_select_gumbel": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "tg_search_root_planes": (c_int, [c_void_p, c_void_p, c_void_p]),
     "tg_search_backup": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "tg_search_read_node": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 12),
     "tg_search_num_nodes": (c_int, [c_void_p, c_void_p]),
+    "tg_search_read_roots": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 
 _lib = None
@@ -67,6 +70,9 @@ def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own HIP runtime; it must be the one already in the process when our
+    # library resolves libamdhip64, so that pointers, streams and events are shared
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise TamagoHipError(
             f"{LIB_PATH} is missing - build it with `python -m tamago_amd.build` "

@@ -10,6 +10,7 @@ numpy's dirichlet / gumbel use, so the doubles are bit-identical) and hands wind
 to the device, which consumes them with a cursor.
 """
 import ctypes
+import os
 from typing import List, Optional
 
 import numpy as np
@@ -125,6 +126,7 @@ class SearchEngine:
         self.planes = torch.empty((num_trees * batch_size, 6, board_size, board_size),
                                   dtype=torch.float32, device=self.device)
         self.streams: List[Optional[ExpStream]] = [None] * num_trees
+        self._pool = None
 
     def close(self):
         if self.handle is not None:
@@ -157,8 +159,19 @@ class SearchEngine:
 
     def _feed_rng(self, need: int):
         win = np.empty((self.T, need), dtype=np.float64)
-        for t, s in enumerate(self.streams):
-            win[t] = s.window(need)
+
+        def fill(t):
+            win[t] = self.streams[t].window(need)
+
+        if self.T >= 8:
+            # numpy's legacy generators release the GIL while filling, so threads scale
+            if self._pool is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._pool = ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1))
+            list(self._pool.map(fill, range(self.T)))
+        else:
+            for t in range(self.T):
+                fill(t)
         _lib.check(self.lib.tg_search_set_rng(self.handle, win.ctypes.data, need, need),
                    "tg_search_set_rng")
 
@@ -195,11 +208,45 @@ class SearchEngine:
         self._evaluate_and_backup(leaves, False)
         self._collect_rng()
 
+    def set_gumbel_noise(self):
+        """node.py:275-278 for every root: A doubles from each tree's stream, drawn after the
+        root's Dirichlet prior and NN evaluation (tree.py:332-336)."""
+        noise = np.empty((self.T, self.A), dtype=np.float64)
+        for t, s in enumerate(self.streams):
+            noise[t] = s.gumbel(self.A)
+        _lib.check(self.lib.tg_search_set_noise(self.handle, noise.ctypes.data), "tg_search_set_noise")
+        self.noise = noise
+        return noise
+
+    def gumbel_phase(self, num_considered, max_count):
+        """One sequential-halving phase for every tree (tree.py:375-384): per-tree
+        (num_considered, max_count), one evaluation of all queued leaves, backup."""
+        nc = np.ascontiguousarray(num_considered, dtype=np.int32)
+        mc = np.ascontiguousarray(max_count, dtype=np.int32)
+        slots = int(np.max(nc * mc))
+        if slots == 0:
+            return
+        self._feed_rng(slots * self.A)
+        _lib.check(self.lib.tg_search_select_gumbel(self.handle, nc.ctypes.data, mc.ctypes.data, slots,
+                                                    self.planes.data_ptr(), self._stream()),
+                   "tg_search_select_gumbel")
+        self._evaluate_and_backup(slots, True)
+        self._collect_rng()
+
     # ---------------------------------------------------------------------------------
     def num_nodes(self) -> np.ndarray:
         out = np.zeros(self.T, dtype=np.int32)
         _lib.check(self.lib.tg_search_num_nodes(self.handle, out.ctypes.data), "tg_search_num_nodes")
         return out
+
+    def read_roots(self):
+        """(num_children [T], action [T][A], children_visits [T][A]) of every root."""
+        nc = np.zeros(self.T, dtype=np.int32)
+        action = np.zeros((self.T, self.A), dtype=np.int32)
+        visits = np.zeros((self.T, self.A), dtype=np.int32)
+        _lib.check(self.lib.tg_search_read_roots(self.handle, nc.ctypes.data, action.ctypes.data,
+                                                 visits.ctypes.data), "tg_search_read_roots")
+        return nc, action, visits
 
     def read_node(self, tree: int, node: int) -> MCTSNode:
         a = self.A

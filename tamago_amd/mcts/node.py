@@ -68,3 +68,16 @@ class MCTSNode:
         logits = self.children_policy[:self.num_children] \
             + sigma_base * self.calculate_completed_q_value()
         return apply_softmax(logits)
+
+    def select_move_by_sequential_halving_for_root(self, count_threshold: int) -> int:
+        """node.py:324-346 (host copy, used for the final move choice, tree.py:344)."""
+        n = self.num_children
+        max_count = max(self.children_visits[:n])
+        sigma_base = (C_VISIT + max_count) * C_SCALE
+        counts = self.children_visits[:n] + self.children_virtual_loss[:n]
+        q_mean = np.divide(self.children_value_sum, self.children_visits,
+                           out=np.zeros_like(self.children_value_sum),
+                           where=(self.children_visits > 0))[:n]
+        evaluation = np.where(counts >= count_threshold, -10000.0,
+                              self.children_policy[:n] + self.noise[:n] + sigma_base * q_mean)
+        return int(np.argmax(evaluation))

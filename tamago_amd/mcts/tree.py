@@ -15,7 +15,9 @@ from tamago_amd.board.constant import PASS, RESIGN
 from tamago_amd.board.go_board import GoBoard
 from tamago_amd.board.stone import Stone, color_value
 from tamago_amd.mcts.batch_data import BatchQueue
-from tamago_amd.mcts.constant import MCTS_TREE_SIZE, NN_BATCH_SIZE, RESIGN_THRESHOLD
+from tamago_amd.mcts.constant import MCTS_TREE_SIZE, NN_BATCH_SIZE, RESIGN_THRESHOLD, \
+    PLAYOUTS, MAX_CONSIDERED_NODES
+from tamago_amd.mcts.sequential_halving import get_candidates_and_visit_pairs
 from tamago_amd.mcts.engine import SearchEngine, HostEvaluator, DeviceEvaluator
 from tamago_amd.mcts.node import MCTSNode
 from tamago_amd.mcts.time_manager import TimeManager
@@ -52,6 +54,7 @@ class MCTSTree:
         self.node = _NodeList(self)
         self._engine = None
         self._engine_key = None
+        self._gumbel_root = False
 
     # ------------------------------------------------------------------------------------
     def _evaluator(self):
@@ -61,17 +64,17 @@ class MCTSTree:
             return DeviceEvaluator(self.network)
         return HostEvaluator(self.network, torch.device("cuda", self.device_index))
 
-    def _engine_for(self, board):
+    def _engine_for(self, board, batch_size=None):
         if board is None:
             if self._engine is None:
                 raise RuntimeError("no search has run yet")
             return self._engine
-        key = (board.board_size, bool(board.check_superko), self.batch_size, self.cgos_mode,
-               self.tree_size)
+        batch = batch_size or self.batch_size
+        key = (board.board_size, bool(board.check_superko), batch, self.cgos_mode, self.tree_size)
         if self._engine is None or key != self._engine_key:
             if self._engine is not None:
                 self._engine.close()
-            self._engine = SearchEngine(board.board_size, 1, self.tree_size, self.batch_size,
+            self._engine = SearchEngine(board.board_size, 1, self.tree_size, batch,
                                         self._evaluator(), self.cgos_mode, board.check_superko,
                                         self.device_index)
             self._engine_key = key
@@ -82,13 +85,18 @@ class MCTSTree:
         np.random.set_state(engine.streams[0].final_state())
 
     def get_root(self) -> MCTSNode:
-        return self._engine_for(None).read_node(0, self.current_root)
+        root = self._engine_for(None).read_node(0, self.current_root)
+        noise = getattr(self._engine, "noise", None)
+        if noise is not None and self._gumbel_root:
+            root.noise = noise[0].copy()
+        return root
 
     # ------------------------------------------------------------------------------------
     def search_best_move(self, board: GoBoard, color, time_manager: TimeManager,
                          analysis_query: Dict[str, Any] = None) -> int:
         """mcts/tree.py:57-105."""
         engine = self._engine_for(board)
+        self._gumbel_root = False
         self.to_move = color if isinstance(color, Stone) else Stone(color_value(color))
         engine.set_root(0, board, color, np.random.get_state())
         engine.root_eval(use_logit=False)                              # _initialize_search
@@ -126,3 +134,30 @@ class MCTSTree:
                 root = engine.read_node(0, 0)
                 if time_manager.is_time_over() or time_manager.is_move_decided(root, threshold):
                     break
+
+    # ------------------------------------------------------------------------------------
+    def generate_move_with_sequential_halving(self, board: GoBoard, color, time_manager: TimeManager,
+                                              never_resign: bool) -> int:
+        """mcts/tree.py:318-356 (Gumbel AlphaZero root + sequential halving)."""
+        import time as _time
+        start = _time.time()
+        visits = time_manager.get_num_visits_threshold(color)
+        # every phase is one mini-batch of num_considered * max_count leaves (<= visits)
+        engine = self._engine_for(board, batch_size=max(visits, 1))
+        self._gumbel_root = True
+        engine.set_root(0, board, color, np.random.get_state())
+        engine.root_eval(use_logit=True)
+        engine.set_gumbel_noise()
+        nc, _, _ = engine.read_roots()
+        base = int(nc[0]) if nc[0] < MAX_CONSIDERED_NODES else MAX_CONSIDERED_NODES
+        for num_considered, max_count in get_candidates_and_visit_pairs(base, visits).items():
+            engine.gumbel_phase([num_considered], [max_count])
+        root = self.get_root()
+        self.num_nodes = int(engine.num_nodes()[0])
+        self._commit_rng(engine)
+        next_index = root.select_move_by_sequential_halving_for_root(PLAYOUTS)
+        value = root.calculate_value_evaluation(next_index)
+        time_manager.set_search_speed(root.node_visits, max(_time.time() - start, 1e-9))
+        if not never_resign and value < 0.05:
+            return RESIGN
+        return root.get_child_move(next_index)

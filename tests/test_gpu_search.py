@@ -73,3 +73,24 @@ def test_puct_vs_reference_golden(size):
         check_root(tree, mv, rec)
         assert float(np.random.random_sample()) == float.fromhex(rec["rng_after"])
         assert np.array_equal(board.cells, cells_before) and board.moves == rec["ply"] + 1
+
+
+@pytest.mark.parametrize("size", [9, 19])
+def test_gumbel_vs_reference_golden(size):
+    from oracle.stubnet import StubNet
+    from tamago_amd.mcts.tree import MCTSTree
+    from tamago_amd.mcts.time_manager import TimeManager, TimeControl
+    brd = load_npz(f"board_s{size}.npz")
+    for rec in [r for r in load_json(f"trees_s{size}.json") if r["kind"] == "gumbel"]:
+        board = product_replay(size, brd["g0_move"], brd["g0_color"], rec["ply"], rec["superko"])
+        net = StubNet(salt=100 + rec["seed"])
+        tree = MCTSTree(net, tree_size=160 if rec["visits"] <= 100 else 2048)
+        np.random.seed(rec["seed"])
+        mv = tree.generate_move_with_sequential_halving(
+            board, rec["color"], TimeManager(TimeControl.CONSTANT_PLAYOUT, rec["visits"]), True)
+        assert net.calls == rec["batches"], rec
+        check_root(tree, mv, rec)
+        root = tree.get_root()
+        assert np.array_equal(root.noise, unhex(rec["noise"]))
+        assert np.array_equal(root.calculate_improved_policy(), unhex(rec["improved"]))
+        assert float(np.random.random_sample()) == float.fromhex(rec["rng_after"])
