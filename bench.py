@@ -87,10 +87,9 @@ def opening_boards(size, count, seed):
     return boards, colors
 
 
-def run_step(engine, boards, colors, visits, batch):
-    """One move search for every tree; returns leaf evaluations done."""
-    for t, (b, c) in enumerate(zip(boards, colors)):
-        engine.set_root(t, b, c)
+def run_step(engine, plies, fresh_board, visits, batch):
+    """One move search for every tree; returns leaf evaluations done.  Boards live on the
+    device: the searched move (arg-max visits) is played there (tg_search_play)."""
     engine.root_eval(False)
     done = 0
     while done < visits:
@@ -98,16 +97,17 @@ def run_step(engine, boards, colors, visits, batch):
         engine.puct_batch(k)
         done += k
     leaves = engine.T * (1 + visits)
-    # play the searched move (arg-max visits) on every board
     nc, action, visits_arr = engine.read_roots()
-    for t in range(engine.T):
-        mv = int(action[t][int(np.argmax(visits_arr[t][:nc[t]]))])
-        if boards[t].moves > 2 * engine.P - 8:
-            boards[t].clear()
-            colors[t] = 1
-            continue
-        boards[t].put_stone(mv, colors[t])
-        colors[t] = 3 - colors[t]
+    cols = np.arange(engine.A)[None, :]
+    masked = np.where(cols < nc[:, None], visits_arr, -1)
+    moves = action[np.arange(engine.T), np.argmax(masked, axis=1)].astype(np.int32)
+    plies += 1
+    over = plies > 2 * engine.P - 8
+    moves[over] = -1
+    engine.play(moves)
+    for t in np.nonzero(over)[0]:                  # finished game: start a new one
+        engine.set_root(int(t), fresh_board, 1)
+        plies[t] = 0
     return leaves
 
 
@@ -181,14 +181,17 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    from tamago_amd.board.go_board import GoBoard
+    fresh_board = GoBoard(args.size, 7.0, False)
+    plies = np.array([b.moves - 1 for b in boards], dtype=np.int64)
     for _ in range(args.warmup):
-        run_step(engine, boards, colors, args.visits, args.batch)
+        run_step(engine, plies, fresh_board, args.visits, args.batch)
     evaluator.record = True
     barrier()
     t0 = time.perf_counter()
     leaves = 0
     for _ in range(args.steps):
-        leaves += run_step(engine, boards, colors, args.visits, args.batch)
+        leaves += run_step(engine, plies, fresh_board, args.visits, args.batch)
     barrier()
     elapsed = time.perf_counter() - t0
 

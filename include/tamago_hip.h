@@ -128,9 +128,13 @@ int tg_search_set_root(tg_search *s, int tree, const tg_root_position *pos);
  * prior (tree.py:509-519) and Gumbel noise (node.py:275-278) from numpy's global
  * legacy MT19937 stream; bit-exact parity needs the host's libm log(), so the host
  * turns uniform doubles u_i into e_i = -log(1-u_i) and hands them over in stream
- * order: tree t consumes exp_stream[t*stride + cursor ...].  `count` values per tree. */
+ * order: tree t consumes exp_stream[t*stride + cursor ...].  `count` values per tree.
+ * The window is uploaded on a private copy stream into the inactive one of two device
+ * windows and becomes active at the next root_planes / select call, so the host can
+ * prepare mini-batch j+1 while the forward pass of mini-batch j is still running. */
 int tg_search_set_rng(tg_search *s, const double *exp_stream_host, size_t stride, size_t count);
-/* Doubles each tree consumed since the last tg_search_set_rng (host array [T]). */
+/* Doubles each tree consumed from the active window (host array [T]); waits only for the
+ * last root_planes / select kernel, not for the forward or backup queued behind it. */
 int tg_search_rng_consumed(tg_search *s, int64_t *consumed_host);
 
 /* PUCT: run `max_leaves` (<= batch_size) descents per tree (tree.py:199-244 search_mcts:
@@ -142,6 +146,14 @@ int tg_search_select_puct(tg_search *s, int max_leaves, float *planes_dev, int32
 /* Reset every tree to its root position, expand the root (consumes the root's Dirichlet
  * draw) and write the root planes [T,6,S,S] (tree.py:49-53); one leaf per tree is queued. */
 int tg_search_root_planes(tg_search *s, float *planes_dev, void *stream);
+/* Play moves_host[t] (padded coordinate, 0 = PASS, < 0 = leave the tree alone) on the ROOT
+ * position of every tree on the device (GoBoard.put_stone, go_board.py:131-185) and flip the
+ * side to move: self-play boards stay resident between searches. */
+int tg_search_play(tg_search *s, const int32_t *moves_host, void *stream);
+/* Current root positions: cells uint8 [T][(S+2)^2], GoBoard.moves [T], side to move [T]
+ * (any pointer may be NULL). Synchronises. */
+int tg_search_read_positions(tg_search *s, uint8_t *cells_host, int32_t *moves_host,
+                             int32_t *to_move_host);
 /* Gumbel root noise, float64 [T][A] (node.py:275-278 set_gumbel_noise), to be set after the
  * root evaluation of a Gumbel move. */
 int tg_search_set_noise(tg_search *s, const double *noise_host);

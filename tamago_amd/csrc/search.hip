@@ -868,6 +868,39 @@ __global__ __launch_bounds__(64) void select_gumbel_kernel(SearchDev D, const in
     }
 }
 
+
+// Apply one move per tree to its ROOT position on the device (GoBoard.put_stone on the game
+// board, go_board.py:131-185) so that self-play boards never leave the GPU.
+template <int S>
+__global__ __launch_bounds__(64) void play_kernel(SearchDev D, const int32_t *moves) {
+    using G = Geo<S>;
+    __shared__ Lds<S> L;
+    const int t = blockIdx.x, lane = threadIdx.x;
+    const int mv = moves[t];
+    if (mv < 0) return;                                 // RESIGN / idle tree
+    BoardScalars b;
+    int to_move;
+    load_root<S>(L, b, to_move, D, t, lane);
+    reset_work<S>(L, lane);
+    const int at = b.moves;
+    put_stone<S>(L, b, mv, to_move, D.zob, lane);
+    for (int p = lane; p < G::NC; p += 64) D.root_cells[(size_t)t * G::NC + p] = L.color[p];
+    if (lane == 0) {
+        if (at < G::HMAX) D.root_hist[(size_t)t * G::HMAX + at] = b.hash;
+        RootMeta m = D.meta[t];
+        m.hash = b.hash;
+        m.moves = b.moves;
+        m.ko_pos = b.ko_pos;
+        m.ko_move = b.ko_move;
+        m.prev = b.prev;
+        m.prevprev = b.prevprev;
+        m.to_move = 3 - to_move;
+        m.hist_len = D.superko ? (b.moves < G::HMAX ? b.moves : G::HMAX) : 1;
+        m.num_nodes = 0;
+        D.meta[t] = m;
+    }
+}
+
 // Host-built eye table: same rule as board/pattern.py:52-98 produces.
 void build_eye_table(std::vector<uint8_t> &table) {
     table.assign(65536, 0);
@@ -931,8 +964,20 @@ struct tg_search {
     std::vector<uint8_t> st_cells;
     std::vector<uint64_t> st_hist;
     std::vector<RootMeta> st_meta;
+    std::vector<uint8_t> st_dirty_tree;
     bool st_dirty = false;
     int32_t *phase_dev = nullptr;
+    int32_t *moves_dev = nullptr;
+    // double-buffered random windows, uploaded on a private copy stream so that the host can
+    // prepare mini-batch j+1 while the forward pass of mini-batch j runs
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_rng[2] = {nullptr, nullptr};
+    hipEvent_t ev_sel = nullptr;
+    double *rng_buf[2] = {nullptr, nullptr};
+    int64_t rng_buf_cap[2] = {0, 0};
+    int rng_active = 0, rng_pending = -1;
+    int64_t rng_pending_cap = 0;
+    bool sel_recorded = false;
 };
 
 namespace {
@@ -985,11 +1030,21 @@ int tg_search_create(const tg_search_config *cfg, tg_search **out) {
     ALLOC(q_node, T * K) ALLOC(q_pnode, T * K) ALLOC(q_pedge, T * K) ALLOC(n_leaves, T)
     ALLOC(rng_cursor, T) ALLOC(err, T)
 #undef ALLOC
-    // default RNG window: one mini-batch worth of expansions (+ root, + Gumbel noise)
-    D.rng_cap = (int64_t)(K + 2) * A;
-    double *rng = nullptr;
-    if ((rc = dev_alloc(s, &rng, T * (size_t)D.rng_cap))) { tg_search_destroy(s); return rc; }
-    D.rng = rng;
+    // random windows: one mini-batch worth of expansions each (grown on demand)
+    for (int b = 0; b < 2; ++b) {
+        s->rng_buf_cap[b] = (int64_t)K * A;
+        hipError_t e2 = hipMalloc(reinterpret_cast<void **>(&s->rng_buf[b]), T * (size_t)s->rng_buf_cap[b] * sizeof(double));
+        if (e2 != hipSuccess) { tg_search_destroy(s); return tg::fail(TG_ERR_HIP, "rng window: %s", hipGetErrorString(e2)); }
+    }
+    D.rng = s->rng_buf[0];
+    D.rng_cap = 0;              // nothing installed yet
+    if (hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&s->ev_rng[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s->ev_rng[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s->ev_sel, hipEventDisableTiming) != hipSuccess) {
+        tg_search_destroy(s);
+        return tg::fail(TG_ERR_HIP, "tg_search_create: stream/event creation failed");
+    }
     uint64_t *zob = nullptr;
     if ((rc = dev_alloc(s, &zob, (size_t)4 * s->NC))) { tg_search_destroy(s); return rc; }
     D.zob = zob;
@@ -1003,6 +1058,7 @@ int tg_search_create(const tg_search_config *cfg, tg_search **out) {
     s->st_cells.assign(T * s->NC, 0);
     s->st_hist.assign(T * s->HMAX, 0);
     s->st_meta.assign(T, RootMeta{});
+    s->st_dirty_tree.assign(T, 0);
     *out = s;
     return TG_OK;
 }
@@ -1011,6 +1067,12 @@ int tg_search_destroy(tg_search *s) {
     if (!s) return TG_OK;
     (void)hipSetDevice(s->cfg.device);
     for (void *p : s->allocs) (void)hipFree(p);
+    for (int b = 0; b < 2; ++b) {
+        if (s->rng_buf[b]) (void)hipFree(s->rng_buf[b]);
+        if (s->ev_rng[b]) (void)hipEventDestroy(s->ev_rng[b]);
+    }
+    if (s->ev_sel) (void)hipEventDestroy(s->ev_sel);
+    if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
     delete s;
     return TG_OK;
 }
@@ -1045,6 +1107,7 @@ int tg_search_set_root(tg_search *s, int tree, const tg_root_position *pos) {
     hist[0] = 0;
     if (pos->hash_history) std::memcpy(hist, pos->hash_history, (size_t)m.hist_len * sizeof(uint64_t));
     s->st_meta[tree] = m;
+    s->st_dirty_tree[tree] = 1;
     s->st_dirty = true;
     return TG_OK;
 }
@@ -1052,39 +1115,78 @@ int tg_search_set_root(tg_search *s, int tree, const tg_root_position *pos) {
 static int flush_roots(tg_search *s, hipStream_t st) {
     if (!s->st_dirty) return TG_OK;
     const SearchDev &D = s->dev;
-    TG_HIP(hipMemcpyAsync(D.root_cells, s->st_cells.data(), s->st_cells.size(), hipMemcpyHostToDevice, st));
-    if (D.superko)
-        TG_HIP(hipMemcpyAsync(D.root_hist, s->st_hist.data(), s->st_hist.size() * sizeof(uint64_t),
+    size_t n_dirty = 0;
+    for (uint8_t d : s->st_dirty_tree) n_dirty += d;
+    if (n_dirty == (size_t)D.T) {
+        TG_HIP(hipMemcpyAsync(D.root_cells, s->st_cells.data(), s->st_cells.size(), hipMemcpyHostToDevice, st));
+        if (D.superko)
+            TG_HIP(hipMemcpyAsync(D.root_hist, s->st_hist.data(), s->st_hist.size() * sizeof(uint64_t),
+                                  hipMemcpyHostToDevice, st));
+        TG_HIP(hipMemcpyAsync(D.meta, s->st_meta.data(), s->st_meta.size() * sizeof(RootMeta),
                               hipMemcpyHostToDevice, st));
-    TG_HIP(hipMemcpyAsync(D.meta, s->st_meta.data(), s->st_meta.size() * sizeof(RootMeta),
-                          hipMemcpyHostToDevice, st));
+    } else {
+        for (int t = 0; t < D.T; ++t) {
+            if (!s->st_dirty_tree[t]) continue;
+            TG_HIP(hipMemcpyAsync(D.root_cells + (size_t)t * s->NC, &s->st_cells[(size_t)t * s->NC], s->NC,
+                                  hipMemcpyHostToDevice, st));
+            if (D.superko)
+                TG_HIP(hipMemcpyAsync(D.root_hist + (size_t)t * s->HMAX, &s->st_hist[(size_t)t * s->HMAX],
+                                      (size_t)s->st_meta[t].hist_len * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+            TG_HIP(hipMemcpyAsync(D.meta + t, &s->st_meta[t], sizeof(RootMeta), hipMemcpyHostToDevice, st));
+        }
+    }
     TG_HIP(hipMemsetAsync(D.err, 0, (size_t)D.T * sizeof(int32_t), st));
+    std::fill(s->st_dirty_tree.begin(), s->st_dirty_tree.end(), 0);
     s->st_dirty = false;
+    return TG_OK;
+}
+
+// make the most recently uploaded random window the active one (stream-ordered)
+static int install_rng(tg_search *s, hipStream_t st) {
+    if (s->rng_pending < 0) return TG_OK;
+    s->rng_active = s->rng_pending;
+    s->rng_pending = -1;
+    TG_HIP(hipStreamWaitEvent(st, s->ev_rng[s->rng_active], 0));
+    s->dev.rng = s->rng_buf[s->rng_active];
+    s->dev.rng_cap = s->rng_pending_cap;
+    TG_HIP(hipMemsetAsync(s->dev.rng_cursor, 0, (size_t)s->dev.T * sizeof(int64_t), st));
+    return TG_OK;
+}
+
+static int after_select(tg_search *s, hipStream_t st) {
+    TG_HIP(hipEventRecord(s->ev_sel, st));
+    s->sel_recorded = true;
     return TG_OK;
 }
 
 int tg_search_set_rng(tg_search *s, const double *exp_stream_host, size_t stride, size_t count) {
     if (!s || !exp_stream_host) return tg::fail(TG_ERR_ARG, "tg_search_set_rng: null argument");
     if (count > stride) return tg::fail(TG_ERR_ARG, "tg_search_set_rng: count > stride");
-    if (s->last_stream) TG_HIP(hipStreamSynchronize(s->last_stream));
-    if ((int64_t)count > s->dev.rng_cap) {
-        double *rng = nullptr;
-        int rc = dev_alloc(s, &rng, (size_t)s->dev.T * count, false);
-        if (rc) return rc;
-        s->dev.rng = rng;          // the old window stays allocated until destroy
-        s->dev.rng_cap = (int64_t)count;
+    const int idx = 1 - s->rng_active;          // never the window a running kernel may read
+    if ((int64_t)count > s->rng_buf_cap[idx]) {
+        (void)hipFree(s->rng_buf[idx]);          // implicit device synchronisation (rare)
+        s->rng_buf[idx] = nullptr;
+        s->rng_buf_cap[idx] = 0;
+        TG_HIP(hipMalloc(reinterpret_cast<void **>(&s->rng_buf[idx]), (size_t)s->dev.T * count * sizeof(double)));
+        s->rng_buf_cap[idx] = (int64_t)count;
     }
-    TG_HIP(hipMemcpy2D(const_cast<double *>(s->dev.rng), (size_t)s->dev.rng_cap * sizeof(double),
-                       exp_stream_host, stride * sizeof(double), count * sizeof(double), s->dev.T,
-                       hipMemcpyHostToDevice));
-    TG_HIP(hipMemset(s->dev.rng_cursor, 0, (size_t)s->dev.T * sizeof(int64_t)));
+    // rows are packed with pitch `count`; the kernels index with rng_cap = count
+    TG_HIP(hipMemcpy2DAsync(s->rng_buf[idx], count * sizeof(double), exp_stream_host, stride * sizeof(double),
+                            count * sizeof(double), s->dev.T, hipMemcpyHostToDevice, s->copy_stream));
+    TG_HIP(hipEventRecord(s->ev_rng[idx], s->copy_stream));
+    TG_HIP(hipStreamSynchronize(s->copy_stream));   // the host buffer may be released on return
+    s->rng_pending = idx;
+    s->rng_pending_cap = (int64_t)count;
     return TG_OK;
 }
 
 int tg_search_rng_consumed(tg_search *s, int64_t *consumed_host) {
     if (!s || !consumed_host) return tg::fail(TG_ERR_ARG, "tg_search_rng_consumed: null argument");
-    if (s->last_stream) TG_HIP(hipStreamSynchronize(s->last_stream));
-    TG_HIP(hipMemcpy(consumed_host, s->dev.rng_cursor, (size_t)s->dev.T * sizeof(int64_t), hipMemcpyDeviceToHost));
+    // wait for the last selection kernel only - the forward / backup behind it keep running
+    if (s->sel_recorded) TG_HIP(hipStreamWaitEvent(s->copy_stream, s->ev_sel, 0));
+    TG_HIP(hipMemcpyAsync(consumed_host, s->dev.rng_cursor, (size_t)s->dev.T * sizeof(int64_t),
+                          hipMemcpyDeviceToHost, s->copy_stream));
+    TG_HIP(hipStreamSynchronize(s->copy_stream));
     return TG_OK;
 }
 
@@ -1106,11 +1208,12 @@ int tg_search_root_planes(tg_search *s, float *planes_dev, void *stream) {
     {
         int rc = flush_roots(s, st);
         if (rc) return rc;
+        if ((rc = install_rng(s, st))) return rc;
     }
     if (s->S == 9) hipLaunchKernelGGL(root_kernel<9>, dim3(s->dev.T), dim3(64), 0, st, s->dev, planes_dev);
     else hipLaunchKernelGGL(root_kernel<19>, dim3(s->dev.T), dim3(64), 0, st, s->dev, planes_dev);
     TG_HIP(hipGetLastError());
-    return TG_OK;
+    return after_select(s, st);
 }
 
 int tg_search_select_puct(tg_search *s, int max_leaves, float *planes_dev, int32_t *n_leaves_dev, void *stream) {
@@ -1119,6 +1222,10 @@ int tg_search_select_puct(tg_search *s, int max_leaves, float *planes_dev, int32
         return tg::fail(TG_ERR_ARG, "tg_search_select_puct: max_leaves %d outside [0, batch_size]", max_leaves);
     hipStream_t st = static_cast<hipStream_t>(stream);
     s->last_stream = st;
+    {
+        int rc = install_rng(s, st);
+        if (rc) return rc;
+    }
     if (s->S == 9)
         hipLaunchKernelGGL(select_puct_kernel<9>, dim3(s->dev.T), dim3(64), 0, st, s->dev, max_leaves, planes_dev);
     else
@@ -1127,9 +1234,48 @@ int tg_search_select_puct(tg_search *s, int max_leaves, float *planes_dev, int32
     if (n_leaves_dev)
         TG_HIP(hipMemcpyAsync(n_leaves_dev, s->dev.n_leaves, (size_t)s->dev.T * sizeof(int32_t),
                               hipMemcpyDeviceToDevice, st));
+    return after_select(s, st);
+}
+
+
+
+int tg_search_play(tg_search *s, const int32_t *moves_host, void *stream) {
+    if (!s || !moves_host) return tg::fail(TG_ERR_ARG, "tg_search_play: null argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    s->last_stream = st;
+    int rc = flush_roots(s, st);
+    if (rc) return rc;
+    if (!s->moves_dev && (rc = dev_alloc(s, &s->moves_dev, (size_t)s->dev.T))) return rc;
+    TG_HIP(hipMemcpyAsync(s->moves_dev, moves_host, (size_t)s->dev.T * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    TG_HIP(hipStreamSynchronize(st));
+    if (s->S == 9) hipLaunchKernelGGL(play_kernel<9>, dim3(s->dev.T), dim3(64), 0, st, s->dev, s->moves_dev);
+    else hipLaunchKernelGGL(play_kernel<19>, dim3(s->dev.T), dim3(64), 0, st, s->dev, s->moves_dev);
+    TG_HIP(hipGetLastError());
     return TG_OK;
 }
 
+int tg_search_read_positions(tg_search *s, uint8_t *cells_host, int32_t *moves_host, int32_t *to_move_host) {
+    if (!s) return tg::fail(TG_ERR_ARG, "tg_search_read_positions: null argument");
+    if (s->last_stream) TG_HIP(hipStreamSynchronize(s->last_stream));
+    else TG_HIP(hipDeviceSynchronize());
+    {
+        int rc = flush_roots(s, s->last_stream);
+        if (rc) return rc;
+        if (s->last_stream) TG_HIP(hipStreamSynchronize(s->last_stream));
+        else TG_HIP(hipDeviceSynchronize());
+    }
+    if (cells_host)
+        TG_HIP(hipMemcpy(cells_host, s->dev.root_cells, (size_t)s->dev.T * s->NC, hipMemcpyDeviceToHost));
+    if (moves_host || to_move_host) {
+        std::vector<RootMeta> meta(s->dev.T);
+        TG_HIP(hipMemcpy(meta.data(), s->dev.meta, meta.size() * sizeof(RootMeta), hipMemcpyDeviceToHost));
+        for (int t = 0; t < s->dev.T; ++t) {
+            if (moves_host) moves_host[t] = meta[t].moves;
+            if (to_move_host) to_move_host[t] = meta[t].to_move;
+        }
+    }
+    return TG_OK;
+}
 
 int tg_search_set_noise(tg_search *s, const double *noise_host) {
     if (!s || !noise_host) return tg::fail(TG_ERR_ARG, "tg_search_set_noise: null argument");
@@ -1159,6 +1305,10 @@ int tg_search_select_gumbel(tg_search *s, const int32_t *num_considered_host, co
     std::memcpy(both.data() + s->dev.T, max_count_host, s->dev.T * sizeof(int32_t));
     TG_HIP(hipMemcpyAsync(s->phase_dev, both.data(), both.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     TG_HIP(hipStreamSynchronize(st));     // `both` is a stack-lifetime staging buffer
+    {
+        int rc = install_rng(s, st);
+        if (rc) return rc;
+    }
     if (s->S == 9)
         hipLaunchKernelGGL(select_gumbel_kernel<9>, dim3(s->dev.T), dim3(64), 0, st, s->dev, s->phase_dev,
                            s->phase_dev + s->dev.T, slots_per_tree, planes_dev);
@@ -1166,7 +1316,7 @@ int tg_search_select_gumbel(tg_search *s, const int32_t *num_considered_host, co
         hipLaunchKernelGGL(select_gumbel_kernel<19>, dim3(s->dev.T), dim3(64), 0, st, s->dev, s->phase_dev,
                            s->phase_dev + s->dev.T, slots_per_tree, planes_dev);
     TG_HIP(hipGetLastError());
-    return TG_OK;
+    return after_select(s, st);
 }
 
 int tg_search_backup(tg_search *s, const float *policy_dev, const float *value_dev, int slots_per_tree,

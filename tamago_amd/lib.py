@@ -49,6 +49,8 @@ _SIGNATURES = {
     "tg_search_set_rng": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t]),
     "tg_search_rng_consumed": (c_int, [c_void_p, c_void_p]),
     "tg_search_select_puct": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "tg_search_play": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "tg_search_read_positions": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "tg_search_set_noise": (c_int, [c_void_p, c_void_p]),
     "tg_search_select_gumbel": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "tg_search_root_planes": (c_int, [c_void_p, c_void_p, c_void_p]),

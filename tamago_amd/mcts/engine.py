@@ -196,17 +196,35 @@ class SearchEngine:
         self._feed_rng(self.A)
         _lib.check(self.lib.tg_search_root_planes(self.handle, self.planes.data_ptr(),
                                                   self._stream()), "tg_search_root_planes")
-        self._evaluate_and_backup(1, use_logit)
         self._collect_rng()
+        self._evaluate_and_backup(1, use_logit)
 
     def puct_batch(self, leaves: int):
         """`leaves` PUCT descents per tree + one evaluation + backup (tree.py:146-152 with
         the flush of :240-241)."""
+        # order matters for overlap: the random window of THIS batch is generated and
+        # uploaded (private copy stream) while the forward pass of the PREVIOUS batch is
+        # still running; the cursor read-back waits for the selection kernel only
         self._feed_rng(leaves * self.A)
         _lib.check(self.lib.tg_search_select_puct(self.handle, leaves, self.planes.data_ptr(),
                                                   None, self._stream()), "tg_search_select_puct")
-        self._evaluate_and_backup(leaves, False)
         self._collect_rng()
+        self._evaluate_and_backup(leaves, False)
+
+    def play(self, moves):
+        """Play one move per tree on the device-resident root positions (< 0 = skip)."""
+        mv = np.ascontiguousarray(moves, dtype=np.int32)
+        assert mv.shape == (self.T,)
+        _lib.check(self.lib.tg_search_play(self.handle, mv.ctypes.data, self._stream()), "tg_search_play")
+
+    def read_positions(self):
+        """(cells [T][(S+2)^2], moves [T], to_move [T]) of the current root positions."""
+        cells = np.zeros((self.T, (self.S + 2) ** 2), dtype=np.uint8)
+        moves = np.zeros(self.T, dtype=np.int32)
+        to_move = np.zeros(self.T, dtype=np.int32)
+        _lib.check(self.lib.tg_search_read_positions(self.handle, cells.ctypes.data, moves.ctypes.data,
+                                                     to_move.ctypes.data), "tg_search_read_positions")
+        return cells, moves, to_move
 
     def set_gumbel_noise(self):
         """node.py:275-278 for every root: A doubles from each tree's stream, drawn after the
@@ -230,8 +248,8 @@ class SearchEngine:
         _lib.check(self.lib.tg_search_select_gumbel(self.handle, nc.ctypes.data, mc.ctypes.data, slots,
                                                     self.planes.data_ptr(), self._stream()),
                    "tg_search_select_gumbel")
-        self._evaluate_and_backup(slots, True)
         self._collect_rng()
+        self._evaluate_and_backup(slots, True)
 
     # ---------------------------------------------------------------------------------
     def num_nodes(self) -> np.ndarray:

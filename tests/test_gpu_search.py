@@ -94,3 +94,44 @@ def test_gumbel_vs_reference_golden(size):
         assert np.array_equal(root.noise, unhex(rec["noise"]))
         assert np.array_equal(root.calculate_improved_policy(), unhex(rec["improved"]))
         assert float(np.random.random_sample()) == float.fromhex(rec["rng_after"])
+
+
+def test_device_play_matches_host_board():
+    """tg_search_play (root boards resident on the device) vs the reference play-outs."""
+    from oracle.stubnet import StubNet
+    from tamago_amd.board.go_board import GoBoard
+    from tamago_amd.mcts.engine import SearchEngine, HostEvaluator
+    import torch
+    size = 9
+    fix = load_npz(f"board_s{size}.npz")
+    games = [0, 1, 2, 3]
+    eng = SearchEngine(size, len(games), 64, 4, HostEvaluator(StubNet(0), torch.device("cuda:0")),
+                       check_superko=True)
+    for t in range(len(games)):
+        eng.set_root(t, GoBoard(size, 7.0, True), 1, np.random.RandomState(t).get_state())
+    eng.root_eval(False)
+    for ply in range(150):
+        moves = np.array([int(fix[f"g{g}_move"][ply]) for g in games], dtype=np.int32)
+        eng.play(moves)
+        if ply % 10 == 9 or ply == 149:
+            cells, mv, to_move = eng.read_positions()
+            for t, g in enumerate(games):
+                onboard = cells[t].reshape(size + 2, size + 2)[1:-1, 1:-1].reshape(-1)
+                assert np.array_equal(onboard, fix[f"g{g}_cells"][ply]), (g, ply)
+                assert mv[t] == ply + 2 and to_move[t] == 3 - int(fix[f"g{g}_color"][ply])
+    # a search from the device-resident position equals a search from the host position
+    ref_board = product_replay(size, fix["g0_move"], fix["g0_color"], 150, True)
+    eng2 = SearchEngine(size, 1, 256, 16, HostEvaluator(StubNet(9), torch.device("cuda:0")),
+                        check_superko=True)
+    eng2.set_root(0, ref_board, int(to_move[0]), np.random.RandomState(77).get_state())
+    eng2.root_eval(False)
+    eng2.puct_batch(16)
+    eng2.puct_batch(16)
+    want = eng2.read_node(0, 0)
+    eng.evaluator = HostEvaluator(StubNet(9), torch.device("cuda:0"))
+    for t in range(len(games)):
+        eng.streams[t] = type(eng.streams[t])(np.random.RandomState(77).get_state())
+    eng.root_eval(False)
+    eng.puct_batch(4)
+    got = eng.read_node(0, 0)
+    assert got.num_children == want.num_children and got.action == want.action
