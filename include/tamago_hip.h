@@ -72,6 +72,11 @@ int tg_net_forward_dev(tg_net *net, const float *planes_dev, int batch, int want
  * host tensor in, host tensors out. */
 int tg_net_forward_host(tg_net *net, const float *planes_host, int batch, int want_logits,
                         float *policy_host, float *value_host);
+/* Profiling aid: one forward pass with workgroup 0 writing s_memtime stamps at its phase
+ * boundaries (group start, stem, per layer: MFMAs issued / barrier passed, epilogues done,
+ * heads done) - up to 64 stamps of the first board group. Synchronises. */
+int tg_net_profile_phases(tg_net *net, const float *planes_dev, int batch, float *policy_dev,
+                          float *value_dev, long long *stamps_host, int n_stamps);
 /* Name (for rocprof) and algorithmic FLOPs per position of the dominant kernel. */
 const char *tg_net_kernel_name(const tg_net *net, int batch);
 double tg_net_flops_per_position(int board_size);

@@ -21,6 +21,7 @@
 #include "common.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -46,6 +47,7 @@ struct NetDev {
     const float *pfc_b;   // [A]
     const float *vfc_w;   // [3][P]
     const float *vfc_b;   // [3]
+    long long *timeline;  // optional [64] s_memtime stamps of workgroup 0 (tg_net_profile_phases)
 };
 
 template <int S, int G>
@@ -109,9 +111,15 @@ __global__ __launch_bounds__(256, (FwdCfg<S, G>::WAVES_PER_SIMD)) void dualnet_f
     for (int e = tid; e < kRowFloats; e += 256) reinterpret_cast<float *>(smem + C::ZROW)[e] = 0.f;
     if (tid < 8) reinterpret_cast<float *>(smem + C::ZERO8)[tid] = 0.f;
 
+    int stamp_i = 0;
+    auto stamp = [&]() {
+        if (net.timeline && blockIdx.x == 0 && tid == 0 && stamp_i < 64)
+            net.timeline[stamp_i++] = (long long)__builtin_amdgcn_s_memtime();
+    };
     const int n_groups = (batch + G - 1) / G;
     for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
         const int b0 = grp * G;
+        stamp();                                  // 0: group start
 
         // ---- stage the input planes: global [b][6][P] -> LDS in8 [row][8] -----------------
         {
@@ -155,6 +163,7 @@ __global__ __launch_bounds__(256, (FwdCfg<S, G>::WAVES_PER_SIMD)) void dualnet_f
             }
         }
 
+        stamp();                                  // 1: stem MFMAs issued
         // ---- epilogue + layers 1..12 -----------------------------------------------------------
 #pragma unroll 1
         for (int layer = 0; layer < kConvLayers; ++layer) {
@@ -168,6 +177,12 @@ __global__ __launch_bounds__(256, (FwdCfg<S, G>::WAVES_PER_SIMD)) void dualnet_f
                 f32x4 bnext[4];
 #pragma unroll
                 for (int s = 0; s < 4; ++s) bnext[s] = wl[s * 64];
+                // Software pipeline: M-tiles are processed in chunks of CH; the A fragments of
+                // chunk c+1 are in flight while the MFMAs of chunk c issue, and inside a chunk
+                // consecutive MFMAs hit different accumulators (the same accumulator comes
+                // back every CH MFMAs = CH*32 cycles, beyond the 40-cycle dependent latency).
+                constexpr int CH = 4;
+                constexpr int NCH = (MT + CH - 1) / CH;
 #pragma unroll 1
                 for (int tap = 0; tap < 9; ++tap) {
                     f32x4 bcur[4];
@@ -177,22 +192,54 @@ __global__ __launch_bounds__(256, (FwdCfg<S, G>::WAVES_PER_SIMD)) void dualnet_f
 #pragma unroll
                     for (int s = 0; s < 4; ++s) bnext[s] = wl[(tn * 4 + s) * 64];
                     const int toff = ((tap / 3 - 1) * S + (tap % 3 - 1)) * kRowBytes;
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
+                    const int tap_act = lane_act + toff;
+                    auto a_addr = [&](int mt) -> int {
                         const bool ok = (mask[mt] >> tap) & 1u;
-                        const int a = ok ? lane_act + mt * 16 * kRowBytes + toff : lane_zero;
+                        return ok ? tap_act + mt * 16 * kRowBytes : lane_zero;
+                    };
+                    f32x4 acur[CH], anext[CH];
 #pragma unroll
-                        for (int s = 0; s < 4; ++s) {
-                            const f32x4 av = lds_f32x4(smem, a + s * 64);
-                            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bcur[s].x, acc[mt], 0, 0, 0);
-                            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bcur[s].y, acc[mt], 0, 0, 0);
-                            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bcur[s].z, acc[mt], 0, 0, 0);
-                            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bcur[s].w, acc[mt], 0, 0, 0);
+                    for (int m = 0; m < CH; ++m)
+                        if (m < MT) acur[m] = lds_f32x4(smem, a_addr(m));
+#pragma unroll
+                    for (int it = 0; it < 4 * NCH; ++it) {
+                        const int s = it % 4, c = it / 4;      // all four 16-channel groups of a chunk
+                        if (it + 1 < 4 * NCH) {
+                            const int s2 = (it + 1) % 4, c2 = (it + 1) / 4;
+#pragma unroll
+                            for (int m = 0; m < CH; ++m)
+                                if (c2 * CH + m < MT) anext[m] = lds_f32x4(smem, a_addr(c2 * CH + m) + s2 * 64);
                         }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                            for (int m = 0; m < CH; ++m) {
+                                const int mt = c * CH + m;
+                                if (mt < MT)
+                                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[m][j], bcur[s][j], acc[mt], 0, 0, 0);
+                            }
+                        }
+                        // Issue order for this iteration: the next chunk's address arithmetic
+                        // and ds_reads ride in the shadow of the first MFMAs (one MFMA keeps
+                        // the matrix pipe busy for 32 cycles), the rest of the MFMAs follow
+                        // back to back.  Without this hipcc either sinks the loads to just
+                        // before their use or fences them into an MFMA-free block.
+#pragma unroll
+                        for (int m = 0; m < CH; ++m) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);   // <= 6 VALU
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+                        }
+                        __builtin_amdgcn_sched_group_barrier(0x008, 4 * CH - CH, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int m = 0; m < CH; ++m) acur[m] = anext[m];
                     }
                 }
+                stamp();                          // layer MFMAs issued (before the barrier)
                 // every wave must be done reading before anyone overwrites the buffer
                 __syncthreads();
+                stamp();                          // barrier passed
             }
             // epilogue: BN scale/shift (+ residual) + ReLU, C/D layout: col = lane&15, row = 4*(lane>>4)+j
             const float sc = net.scale[layer * 64 + wave * 16 + li];
@@ -214,6 +261,7 @@ __global__ __launch_bounds__(256, (FwdCfg<S, G>::WAVES_PER_SIMD)) void dualnet_f
             }
         }
         __syncthreads();
+        stamp();                                  // all epilogues done
 
         // ---- heads ------------------------------------------------------------------------------
         float *hpol = reinterpret_cast<float *>(smem + C::AUX);   // [G][2P]
@@ -296,6 +344,7 @@ __global__ __launch_bounds__(256, (FwdCfg<S, G>::WAVES_PER_SIMD)) void dualnet_f
             }
         }
         __syncthreads();
+        stamp();                                  // heads done
     }
 }
 
@@ -497,15 +546,21 @@ int tg_net_destroy(tg_net *net) {
 
 static int pick_group(int board_size, int batch, int num_cus) {
     if (board_size != 9) return 1;
-    // small batches: one board per workgroup fills more CUs; large batches: 3 boards per
-    // workgroup (243 of 256 MFMA rows used instead of 81 of 96)
+    if (const char *env = getenv("TG_FWD_GROUP")) {        // tuning knob: 1, 3 or 6
+        const int g = atoi(env);
+        if (g == 1 || g == 3 || g == 6) return g;
+    }
+    // small batches: one board per workgroup fills more CUs; large batches: 6 boards per
+    // workgroup (486 of 496 MFMA rows used instead of 81 of 96), one workgroup per CU
+    if (batch > 6 * num_cus) return 6;
     return batch > 2 * num_cus ? 3 : 1;
 }
 
 const char *tg_net_kernel_name(const tg_net *net, int batch) {
     if (!net) return "";
     if (net->board_size == 19) return "dualnet_fwd_kernel<19, 1>";
-    return pick_group(9, batch, net->num_cus) == 3 ? "dualnet_fwd_kernel<9, 3>" : "dualnet_fwd_kernel<9, 1>";
+    const int g = pick_group(9, batch, net->num_cus);
+    return g == 6 ? "dualnet_fwd_kernel<9, 6>" : (g == 3 ? "dualnet_fwd_kernel<9, 3>" : "dualnet_fwd_kernel<9, 1>");
 }
 
 int tg_net_forward_dev(tg_net *net, const float *planes_dev, int batch, int want_logits,
@@ -517,9 +572,30 @@ int tg_net_forward_dev(tg_net *net, const float *planes_dev, int batch, int want
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (net->board_size == 19)
         return launch<19, 1>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st);
-    if (pick_group(9, batch, net->num_cus) == 3)
-        return launch<9, 3>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st);
+    const int g = pick_group(9, batch, net->num_cus);
+    if (g == 6) return launch<9, 6>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st);
+    if (g == 3) return launch<9, 3>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st);
     return launch<9, 1>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st);
+}
+
+int tg_net_profile_phases(tg_net *net, const float *planes_dev, int batch, float *policy_dev, float *value_dev,
+                          long long *stamps_host, int n_stamps) {
+    if (!net || !planes_dev || !policy_dev || !value_dev || !stamps_host || n_stamps < 1 || n_stamps > 64)
+        return tg::fail(TG_ERR_ARG, "tg_net_profile_phases: bad argument");
+    TG_HIP(hipSetDevice(net->device));
+    long long *tl = nullptr;
+    TG_HIP(hipMalloc(reinterpret_cast<void **>(&tl), 64 * sizeof(long long)));
+    TG_HIP(hipMemset(tl, 0, 64 * sizeof(long long)));
+    net->dev.timeline = tl;
+    int rc = tg_net_forward_dev(net, planes_dev, batch, 0, policy_dev, value_dev, nullptr);
+    net->dev.timeline = nullptr;
+    if (rc == TG_OK) {
+        hipError_t e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = hipMemcpy(stamps_host, tl, n_stamps * sizeof(long long), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = tg::fail(TG_ERR_HIP, "tg_net_profile_phases: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(tl);
+    return rc;
 }
 
 int tg_net_forward_host(tg_net *net, const float *planes_host, int batch, int want_logits,

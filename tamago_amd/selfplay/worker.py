@@ -1,0 +1,185 @@
+"""Self-play on MI355X: many boards per GPU in lock-step, one process per GPU.
+
+``selfplay_worker`` keeps the reference signature (selfplay/worker.py:21-22) and - for
+``index_list = [k]`` - reproduces the reference game for ``np.random.seed(k)`` move for move
+(Gumbel search per move, resign rule, two-pass end, count_score, SGF text).
+``selfplay_shard`` is the MI355X form: ``boards`` games advance together so that every
+sequential-halving phase becomes ONE forward pass over all their leaves, and shards are
+independent across GPUs (selfplay_main.py:44-65: no communication but files).
+"""
+import os
+import random
+from typing import List, Sequence
+
+import numpy as np
+
+from tamago_amd.board.constant import PASS, RESIGN
+from tamago_amd.board.go_board import GoBoard
+from tamago_amd.board.stone import Stone
+from tamago_amd.mcts.constant import MAX_CONSIDERED_NODES, PLAYOUTS
+from tamago_amd.mcts.engine import SearchEngine, HostEvaluator, DeviceEvaluator
+from tamago_amd.mcts.sequential_halving import get_candidates_and_visit_pairs
+from tamago_amd.sgf.selfplay_record import SelfPlayRecord
+
+SELF_PLAY_VISITS = 16           # learning_param.py:40
+
+
+def shard_indices(index_list: Sequence[int], world_size: int, rank: int) -> List[int]:
+    """Contiguous split of the game indices over ranks (selfplay_main.py:44-57 does the same
+    over worker processes); shards differ in size by at most one game."""
+    n = len(index_list)
+    base, extra = divmod(n, world_size)
+    start = rank * base + min(rank, extra)
+    return list(index_list[start:start + base + (1 if rank < extra else 0)])
+
+
+class _Game:
+    def __init__(self, index: int, size: int, save_dir: str, never_resign: bool):
+        self.index = index
+        self.board = GoBoard(board_size=size, komi=7.0, check_superko=True)
+        self.record = SelfPlayRecord(save_dir, self.board.coordinate)
+        self.color = Stone.BLACK
+        self.pass_count = 0
+        self.never_resign = never_resign
+        self.moves_played = 0
+        self.done = False
+
+
+def _finish(game: _Game, winner, is_resign: bool, score: float):
+    game.record.set_index(game.index)
+    game.record.write_record(winner, game.board.get_komi(), is_resign, score)
+    game.done = True
+
+
+def selfplay_shard(save_dir: str, network, index_list: Sequence[int], size: int, visits: int,
+                   boards: int = 16, seeds: Sequence[int] = None, device_index: int = 0,
+                   never_resign_flags: Sequence[bool] = None) -> dict:
+    """Play the games of `index_list`, `boards` at a time.  Game i draws from its own legacy
+    stream seeded with seeds[i] (default: its index), so every game equals the reference
+    game a single-board worker would play with that seed."""
+    from tamago_amd.nn.network.dual_net import DualNet
+    import torch
+    todo = [i for i in index_list if not os.path.isfile(os.path.join(save_dir, f"{i}.sgf"))]
+    seeds = dict(zip(index_list, seeds if seeds is not None else index_list))
+    flags = dict(zip(index_list, never_resign_flags)) if never_resign_flags is not None else None
+    stats = {"games": 0, "moves": 0, "leaf_evals": 0}
+    if not todo:
+        return stats
+    boards = min(boards, len(todo))
+    evaluator = DeviceEvaluator(network) if isinstance(network, DualNet) \
+        else HostEvaluator(network, torch.device("cuda", device_index))
+    max_moves = size * size * 2                                    # worker.py:44
+    engine = SearchEngine(size, boards, max(SELF_PLAY_VISITS * 10, visits + 8), max(visits, 1),
+                          evaluator, check_superko=True, device_index=device_index)
+    slots: List[_Game] = [None] * boards
+    queue = list(todo)
+
+    def start(slot: int):
+        index = queue.pop(0)
+        nr = flags[index] if flags is not None else (random.randint(1, 10) == 1)   # worker.py:53
+        slots[slot] = _Game(index, size, save_dir, nr)
+        engine.streams[slot] = None
+        game = slots[slot]
+        engine.set_root(slot, game.board, game.color, np.random.RandomState(seeds[index]).get_state())
+
+    for s in range(boards):
+        start(s)
+
+    while any(g is not None and not g.done for g in slots):
+        active = [s for s, g in enumerate(slots) if g is not None and not g.done]
+        for s in active:
+            engine.set_root(s, slots[s].board, slots[s].color)
+        # idle slots keep their last root; their leaves are computed and ignored
+        engine.root_eval(use_logit=True)
+        engine.set_gumbel_noise()
+        nc, _, _ = engine.read_roots()
+        schedules = []
+        for s in range(boards):
+            base = int(nc[s]) if nc[s] < MAX_CONSIDERED_NODES else MAX_CONSIDERED_NODES
+            schedules.append(list(get_candidates_and_visit_pairs(base, visits).items())
+                             if s in active else [])
+        stats["leaf_evals"] += len(active)
+        for phase in range(max(len(sc) for sc in schedules)):
+            widths = [sc[phase][0] if phase < len(sc) else 0 for sc in schedules]
+            levels = [sc[phase][1] if phase < len(sc) else 0 for sc in schedules]
+            engine.gumbel_phase(widths, levels)
+            stats["leaf_evals"] += int(np.dot(widths, levels))
+        for s in active:
+            game = slots[s]
+            root = engine.read_node(s, 0)
+            root.noise = engine.noise[s].copy()
+            best = root.select_move_by_sequential_halving_for_root(PLAYOUTS)      # tree.py:344
+            value = root.calculate_value_evaluation(best)
+            pos = RESIGN if (not game.never_resign and value < 0.05) else root.get_child_move(best)
+            stats["moves"] += 1
+            if pos == RESIGN:                                                      # worker.py:59-62
+                _finish(game, Stone.get_opponent_color(game.color), True, 0.0)
+            else:
+                game.board.put_stone(pos, game.color)
+                game.pass_count = game.pass_count + 1 if pos == PASS else 0
+                game.record.save_record(root, pos, game.color)
+                game.color = Stone.get_opponent_color(game.color)
+                game.moves_played += 1
+                if game.pass_count == 2:                                           # worker.py:80-87
+                    score = game.board.count_score() - game.board.get_komi()
+                    winner = Stone.BLACK if score > 0.1 else (Stone.WHITE if score < -0.1
+                                                              else Stone.OUT_OF_BOARD)
+                    _finish(game, winner, False, score)
+                elif game.moves_played >= max_moves:
+                    # the reference reaches write_record with `winner` unset here (a NameError);
+                    # record the game as unfinished instead
+                    _finish(game, Stone.EMPTY, False, 0.0)
+            if game.done:
+                stats["games"] += 1
+                if queue:
+                    start(s)
+    engine.close()
+    return stats
+
+
+def selfplay_worker(save_dir: str, model_file_path: str, index_list: List[int], size: int,
+                    visits: int, use_gpu: bool) -> None:
+    """selfplay/worker.py:21-90.  One game at a time from ONE legacy stream seeded with
+    ``random.choice(index_list)``, exactly like the reference worker."""
+    from tamago_amd.nn.utility import load_network
+    network = load_network(model_file_path=model_file_path, use_gpu=use_gpu, board_size=size)
+    seed = random.choice(index_list)                                               # worker.py:39
+    state = np.random.RandomState(seed).get_state()
+    for index in index_list:
+        if os.path.isfile(os.path.join(save_dir, f"{index}.sgf")):
+            continue
+        never_resign = random.randint(1, 10) == 1
+        state = _play_one_game(save_dir, network, index, size, visits, state, never_resign)
+
+
+def _play_one_game(save_dir, network, index, size, visits, rng_state, never_resign):
+    """One game on a one-board engine, continuing `rng_state`; returns the stream state after
+    the game so that the next game continues it (the reference seeds once per worker)."""
+    from tamago_amd.mcts.time_manager import TimeManager, TimeControl
+    from tamago_amd.mcts.tree import MCTSTree
+    game = _Game(index, size, save_dir, never_resign)
+    tree = MCTSTree(network, tree_size=max(SELF_PLAY_VISITS * 10, visits + 8))
+    time_manager = TimeManager(TimeControl.CONSTANT_PLAYOUT, constant_visits=visits)
+    saved = np.random.get_state()
+    np.random.set_state(rng_state)
+    try:
+        winner, is_resign, score = Stone.EMPTY, False, 0.0
+        for _ in range(size * size * 2):
+            pos = tree.generate_move_with_sequential_halving(game.board, game.color, time_manager,
+                                                             never_resign)
+            if pos == RESIGN:
+                winner, is_resign = Stone.get_opponent_color(game.color), True
+                break
+            game.board.put_stone(pos, game.color)
+            game.pass_count = game.pass_count + 1 if pos == PASS else 0
+            game.record.save_record(tree.get_root(), pos, game.color)
+            game.color = Stone.get_opponent_color(game.color)
+            if game.pass_count == 2:
+                score = game.board.count_score() - game.board.get_komi()
+                winner = Stone.BLACK if score > 0.1 else (Stone.WHITE if score < -0.1
+                                                          else Stone.OUT_OF_BOARD)
+                break
+        _finish(game, winner, is_resign, score)
+        return np.random.get_state()
+    finally:
+        np.random.set_state(saved)

@@ -1,0 +1,58 @@
+"""Self-play worker (W1 row of SURVEY.md section 8) on the GPU vs complete games recorded from
+the reference's selfplay_worker (tests/golden/selfplay_games.json): byte-identical SGF text,
+i.e. identical moves, improved-policy strings (.3e) and results."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+from tests.helpers import load_json
+
+pytestmark = pytest.mark.gpu
+
+
+def _flags(k):
+    """never_resign as the reference worker draws it after random.seed(k) (worker.py:39,53)."""
+    random.seed(k)
+    random.choice([k])
+    return random.randint(1, 10) == 1
+
+
+@pytest.mark.parametrize("key", ["1,16", "2,16", "3,50"])
+def test_reference_signature_worker_reproduces_reference_game(key, tmp_path, monkeypatch):
+    from oracle.stubnet import StubNet
+    import tamago_amd.nn.utility as util
+    from tamago_amd.selfplay.worker import selfplay_worker
+    k, visits = (int(v) for v in key.split(","))
+    monkeypatch.setattr(util, "load_network", lambda **kw: StubNet(salt=200 + k))
+    random.seed(k)
+    selfplay_worker(str(tmp_path), "/nonexistent/model.bin", [k], 9, visits, True)
+    got = open(os.path.join(tmp_path, f"{k}.sgf"), encoding="utf-8").read()
+    assert got == load_json("selfplay_games.json")[key]
+
+
+def test_lockstep_shard_equals_single_board_games(tmp_path):
+    """Boards searched together (one forward pass per phase over all of them) play exactly
+    the games they play alone; finished slots are refilled from the queue."""
+    from oracle.stubnet import StubNet
+    from tamago_amd.selfplay.worker import selfplay_shard
+    golden = load_json("selfplay_games.json")
+    solo = tmp_path / "solo"
+    multi = tmp_path / "multi"
+    solo.mkdir()
+    multi.mkdir()
+    idx = [1, 5, 6]
+    flags = [_flags(1), True, False]
+    for i, f in zip(idx, flags):
+        selfplay_shard(str(solo), StubNet(salt=201), [i], 9, 16, boards=1, never_resign_flags=[f])
+    stats = selfplay_shard(str(multi), StubNet(salt=201), idx, 9, 16, boards=2, never_resign_flags=flags)
+    assert stats["games"] == 3 and stats["moves"] > 100
+    for i in idx:
+        a = open(solo / f"{i}.sgf", encoding="utf-8").read()
+        b = open(multi / f"{i}.sgf", encoding="utf-8").read()
+        assert a == b, i
+    assert open(solo / "1.sgf", encoding="utf-8").read() == golden["1,16"]
+    # resume-by-skip (worker.py:47-48): nothing left to do
+    again = selfplay_shard(str(multi), StubNet(salt=201), idx, 9, 16, boards=2, never_resign_flags=flags)
+    assert again["games"] == 0
