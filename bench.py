@@ -31,14 +31,26 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix
+PMC_SUMMARY = os.path.join(REPO, "profiles", "r01_pmc_forward_9x9_b65536.json")
+
+
+def pmc_traffic(size, positions):
+    """HBM bytes per launch of the forward kernel from the committed rocprofv3 --pmc passes
+    (tools/pmc_fwd.sh: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md section HBM prescribes), scaled per position.  None if not measured."""
+    if size != 9 or not os.path.exists(PMC_SUMMARY):
+        return None, None
+    with open(PMC_SUMMARY) as f:
+        d = json.load(f)["derived"]
+    return d["hbm_bytes_per_position"] * positions, d["mfma_busy_fraction_of_simd_cycles"]
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--trees", type=int, default=64, help="boards searched in lock-step per GPU")
+    ap.add_argument("--trees", type=int, default=2048, help="boards searched in lock-step per GPU")
     ap.add_argument("--visits", type=int, default=1000)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--size", type=int, default=9)
@@ -90,12 +102,15 @@ def opening_boards(size, count, seed):
 def run_step(engine, plies, fresh_board, visits, batch):
     """One move search for every tree; returns leaf evaluations done.  Boards live on the
     device: the searched move (arg-max visits) is played there (tg_search_play)."""
-    engine.root_eval(False)
+    first = min(batch, visits)
+    engine.root_eval(False, first_batch=first)
     done = 0
     while done < visits:
         k = min(batch, visits - done)
         engine.puct_batch(k)
         done += k
+    # window for the next search, generated while this search's last forward pass runs
+    engine.prefetch_rng(first)
     leaves = engine.T * (1 + visits)
     nc, action, visits_arr = engine.read_roots()
     cols = np.arange(engine.A)[None, :]
@@ -155,10 +170,17 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("TG_DIST_BACKEND", "nccl")      # nccl == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    if os.environ.get("TG_SINGLE_DEVICE"):                     # N ranks on one GPU (tests only)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    red_dev = dev if os.environ.get("TG_DIST_BACKEND", "nccl") == "nccl" else torch.device("cpu")
 
     from tamago_amd import lib as tl
     from tamago_amd.mcts.engine import SearchEngine
@@ -208,10 +230,10 @@ def main():
     flops_pos = lib.tg_net_flops_per_position(args.size)
 
     if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        tot = torch.tensor([leaves], device=dev, dtype=torch.float64)
+        tot = torch.tensor([leaves], device=red_dev, dtype=torch.float64)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         leaves = float(tot.item())
 
@@ -219,6 +241,7 @@ def main():
         full_b = args.trees * args.batch
         avg_ms = float(np.mean(big)) if big else float("nan")
         achieved = full_b * flops_pos / (avg_ms * 1e-3) / 1e12 if big else float("nan")
+        traffic, mfma_busy = pmc_traffic(args.size, full_b)
         result = {
             "metric": "MCTS leaf-evals/sec (9x9, batch 256)" if args.size == 9
             else f"MCTS leaf-evals/sec ({args.size}x{args.size}, batch {args.batch})",
@@ -247,7 +270,10 @@ def main():
                 "peak": FP32_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_unit": "bytes of HBM traffic per launch (rocprofv3 PMC, profiles/)",
+                "algorithmic_io_bytes": full_b * (6 * args.size ** 2 * 4 + (args.size ** 2 + 4) * 4),
+                "mfma_busy_frac_pmc": mfma_busy,
                 "avg_launch_ms": avg_ms,
                 "launches": len(big),
                 "positions_per_launch": full_b,

@@ -174,66 +174,58 @@ __global__ __launch_bounds__(256, (FwdCfg<S, G>::WAVES_PER_SIMD)) void dualnet_f
                 for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
                 const f32x4 *wl = reinterpret_cast<const f32x4 *>(net.wfrag) +
                                   ((size_t)((layer - 1) * 4 + wave) * 9) * 4 * 64 + lane;
-                f32x4 bnext[4];
-#pragma unroll
-                for (int s = 0; s < 4; ++s) bnext[s] = wl[s * 64];
-                // Software pipeline: M-tiles are processed in chunks of CH; the A fragments of
-                // chunk c+1 are in flight while the MFMAs of chunk c issue, and inside a chunk
-                // consecutive MFMAs hit different accumulators (the same accumulator comes
+                // Software pipeline.  K is walked as 36 groups of 16 input channels (9 taps x 4);
+                // the B fragment of group g+1 (one global_load_dwordx4, L2 resident) is in flight
+                // while group g computes.  Inside a group the M-tiles are processed in chunks
+                // of CH: the A fragments of chunk c+1 are loaded ahead of the MFMAs of chunk c,
+                // and consecutive MFMAs hit different accumulators (the same accumulator comes
                 // back every CH MFMAs = CH*32 cycles, beyond the 40-cycle dependent latency).
                 constexpr int CH = 4;
                 constexpr int NCH = (MT + CH - 1) / CH;
+                f32x4 bnext = wl[0];
 #pragma unroll 1
                 for (int tap = 0; tap < 9; ++tap) {
-                    f32x4 bcur[4];
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) bcur[s] = bnext[s];
-                    const int tn = tap < 8 ? tap + 1 : 8;
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) bnext[s] = wl[(tn * 4 + s) * 64];
                     const int toff = ((tap / 3 - 1) * S + (tap % 3 - 1)) * kRowBytes;
-                    const int tap_act = lane_act + toff;
-                    auto a_addr = [&](int mt) -> int {
+                    int addr[MT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
                         const bool ok = (mask[mt] >> tap) & 1u;
-                        return ok ? tap_act + mt * 16 * kRowBytes : lane_zero;
-                    };
+                        addr[mt] = ok ? lane_act + mt * 16 * kRowBytes + toff : lane_zero;
+                    }
                     f32x4 acur[CH], anext[CH];
 #pragma unroll
                     for (int m = 0; m < CH; ++m)
-                        if (m < MT) acur[m] = lds_f32x4(smem, a_addr(m));
+                        if (m < MT) acur[m] = lds_f32x4(smem, addr[m]);
 #pragma unroll
-                    for (int it = 0; it < 4 * NCH; ++it) {
-                        const int s = it % 4, c = it / 4;      // all four 16-channel groups of a chunk
-                        if (it + 1 < 4 * NCH) {
-                            const int s2 = (it + 1) % 4, c2 = (it + 1) / 4;
+                    for (int s = 0; s < 4; ++s) {
+                        const f32x4 bcur = bnext;
+                        const int gn = tap * 4 + s + 1;
+                        bnext = wl[(gn < 36 ? gn : 35) * 64];
 #pragma unroll
-                            for (int m = 0; m < CH; ++m)
-                                if (c2 * CH + m < MT) anext[m] = lds_f32x4(smem, a_addr(c2 * CH + m) + s2 * 64);
-                        }
+                        for (int c = 0; c < NCH; ++c) {
+                            const bool last = (s == 3 && c == NCH - 1);
+                            if (!last) {
+                                const int c2 = (c + 1) % NCH, s2 = s + (c + 1) / NCH;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                            for (int m = 0; m < CH; ++m) {
-                                const int mt = c * CH + m;
-                                if (mt < MT)
-                                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[m][j], bcur[s][j], acc[mt], 0, 0, 0);
+                                for (int m = 0; m < CH; ++m)
+                                    if (c2 * CH + m < MT) anext[m] = lds_f32x4(smem, addr[c2 * CH + m] + s2 * 64);
                             }
-                        }
-                        // Issue order for this iteration: the next chunk's address arithmetic
-                        // and ds_reads ride in the shadow of the first MFMAs (one MFMA keeps
-                        // the matrix pipe busy for 32 cycles), the rest of the MFMAs follow
-                        // back to back.  Without this hipcc either sinks the loads to just
-                        // before their use or fences them into an MFMA-free block.
+                            // keep the prefetch ahead of the MFMA block (hipcc otherwise sinks the
+                            // loads to just before their first use and exposes the LDS latency)
+                            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int m = 0; m < CH; ++m) {
-                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-                            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);   // <= 6 VALU
-                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
-                        }
-                        __builtin_amdgcn_sched_group_barrier(0x008, 4 * CH - CH, 0);
-                        __builtin_amdgcn_sched_barrier(0);
+                            for (int j = 0; j < 4; ++j) {
 #pragma unroll
-                        for (int m = 0; m < CH; ++m) acur[m] = anext[m];
+                                for (int m = 0; m < CH; ++m) {
+                                    const int mt = c * CH + m;
+                                    if (mt < MT)
+                                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[m][j], bcur[j], acc[mt], 0, 0, 0);
+                                }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int m = 0; m < CH; ++m) acur[m] = anext[m];
+                        }
                     }
                 }
                 stamp();                          // layer MFMAs issued (before the barrier)
@@ -550,10 +542,9 @@ static int pick_group(int board_size, int batch, int num_cus) {
         const int g = atoi(env);
         if (g == 1 || g == 3 || g == 6) return g;
     }
-    // small batches: one board per workgroup fills more CUs; large batches: 6 boards per
-    // workgroup (486 of 496 MFMA rows used instead of 81 of 96), one workgroup per CU
-    if (batch > 6 * num_cus) return 6;
-    return batch > 2 * num_cus ? 3 : 1;
+    // small batches: one board per workgroup fills more CUs; large batches: 3 boards per
+    // workgroup (243 of 256 MFMA rows used instead of 81 of 96), two workgroups per CU
+    return batch > 2 * num_cus ? 3 : 1;   // (6 is slower: 1 wave/SIMD, no cross-workgroup overlap)
 }
 
 const char *tg_net_kernel_name(const tg_net *net, int batch) {

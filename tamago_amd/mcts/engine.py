@@ -127,6 +127,9 @@ class SearchEngine:
                                   dtype=torch.float32, device=self.device)
         self.streams: List[Optional[ExpStream]] = [None] * num_trees
         self._pool = None
+        self._window_left = 0
+        self._window_cap = 0
+        self._window_used = np.zeros(num_trees, dtype=np.int64)
 
     def close(self):
         if self.handle is not None:
@@ -156,8 +159,17 @@ class SearchEngine:
                    "tg_search_set_root")
         if rng_state is not None:
             self.streams[tree] = ExpStream(rng_state)
+            self._window_left = 0
 
     def _feed_rng(self, need: int):
+        """Upload the next `need` stream positions of every tree (window becomes active at the
+        next root / select launch).  Skipped when an earlier (pre-fetched) window still covers
+        `need` positions for every tree."""
+        if self._window_left >= need:
+            return
+        self._window_left = need
+        self._window_cap = need
+        self._window_used = np.zeros(self.T, dtype=np.int64)
         win = np.empty((self.T, need), dtype=np.float64)
 
         def fill(t):
@@ -179,9 +191,13 @@ class SearchEngine:
         used = np.zeros(self.T, dtype=np.int64)
         _lib.check(self.lib.tg_search_rng_consumed(self.handle, used.ctypes.data),
                    "tg_search_rng_consumed")
-        for s, c in zip(self.streams, used):
+        # the device cursor is cumulative within the active window
+        delta = used - self._window_used
+        self._window_used = used
+        for s, c in zip(self.streams, delta):
             s.consume(int(c))
-        return used
+        self._window_left = self._window_cap - int(used.max()) if len(used) else 0
+        return delta
 
     def _evaluate_and_backup(self, n_slots: int, use_logit: bool):
         planes = self.planes[:self.T * n_slots]
@@ -191,13 +207,21 @@ class SearchEngine:
                    "tg_search_backup")
         self._keep = (policy, value)        # keep alive until the stream has consumed them
 
-    def root_eval(self, use_logit: bool = False):
-        """tree.py:49-54: expand + evaluate the root of every tree (one leaf each)."""
-        self._feed_rng(self.A)
+    def root_eval(self, use_logit: bool = False, first_batch: int = 0):
+        """tree.py:49-54: expand + evaluate the root of every tree (one leaf each).  With
+        `first_batch` the random window also covers the first mini-batch of that many leaves,
+        so no upload sits between the (tiny) root evaluation and the first selection."""
+        self._feed_rng(self.A * (1 + first_batch))
         _lib.check(self.lib.tg_search_root_planes(self.handle, self.planes.data_ptr(),
                                                   self._stream()), "tg_search_root_planes")
         self._collect_rng()
         self._evaluate_and_backup(1, use_logit)
+
+    def prefetch_rng(self, leaves: int):
+        """Generate + upload the window for the NEXT root evaluation and its first mini-batch
+        now (e.g. while the last forward pass of the current search is still running)."""
+        self._window_left = 0
+        self._feed_rng(self.A * (1 + leaves))
 
     def puct_batch(self, leaves: int):
         """`leaves` PUCT descents per tree + one evaluation + backup (tree.py:146-152 with
@@ -230,6 +254,7 @@ class SearchEngine:
         """node.py:275-278 for every root: A doubles from each tree's stream, drawn after the
         root's Dirichlet prior and NN evaluation (tree.py:332-336)."""
         noise = np.empty((self.T, self.A), dtype=np.float64)
+        self._window_left = 0                     # the noise sits between two windows
         for t, s in enumerate(self.streams):
             noise[t] = s.gumbel(self.A)
         _lib.check(self.lib.tg_search_set_noise(self.handle, noise.ctypes.data), "tg_search_set_noise")
