@@ -135,3 +135,38 @@ def test_device_play_matches_host_board():
     eng.puct_batch(4)
     got = eng.read_node(0, 0)
     assert got.num_children == want.num_children and got.action == want.action
+
+
+def test_edge_cases_pass_only_root_and_errors():
+    """Root with PASS as the only candidate returns PASS after the root evaluation
+    (tree.py:76-77); pool overflow and bad arguments are reported, not ignored."""
+    import torch
+    from oracle.stubnet import StubNet
+    from tamago_amd.board.go_board import GoBoard
+    from tamago_amd.lib import TamagoHipError
+    from tamago_amd.mcts.engine import SearchEngine, HostEvaluator
+    from tamago_amd.mcts.tree import MCTSTree
+    from tamago_amd.mcts.time_manager import TimeManager, TimeControl
+    # a full board of black stones with two eyes: white has no legal move, black only eye fills
+    board = GoBoard(9)
+    for pos in board.onboard_pos:
+        if pos not in (12, 14):                     # A9 and C9 stay empty (two black eyes)
+            board.cells[pos] = 1
+    board.moves = 5
+    tree = MCTSTree(StubNet(1), tree_size=64, batch_size=4)
+    np.random.seed(0)
+    assert tree.search_best_move(board, 2, TimeManager(TimeControl.STRICT_PLAYOUT, 20), {}) == 0
+    root = tree.get_root()
+    assert root.num_children == 1 and root.action[0] == 0 and tree.num_nodes == 1
+    np.random.seed(0)
+    assert tree.search_best_move(board, 1, TimeManager(TimeControl.STRICT_PLAYOUT, 20), {}) == 0
+    assert tree.get_root().num_children == 1        # both eyes are complete eyes: PASS only
+    # node pool too small for the visit budget -> TG_ERR_OVERFLOW surfaces at the next read
+    small = SearchEngine(9, 1, 8, 16, HostEvaluator(StubNet(0), torch.device("cuda:0")))
+    small.set_root(0, GoBoard(9), 1, np.random.RandomState(0).get_state())
+    small.root_eval(False)
+    small.puct_batch(16)
+    with pytest.raises(TamagoHipError, match="node pool full"):
+        small.read_node(0, 0)
+    with pytest.raises(TamagoHipError):
+        small.puct_batch(17)                         # more leaves than batch_size
