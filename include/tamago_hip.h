@@ -151,6 +151,12 @@ int tg_search_select_puct(tg_search *s, int max_leaves, float *planes_dev, int32
 /* Reset every tree to its root position, expand the root (consumes the root's Dirichlet
  * draw) and write the root planes [T,6,S,S] (tree.py:49-53); one leaf per tree is queued. */
 int tg_search_root_planes(tg_search *s, float *planes_dev, void *stream);
+/* Everything the Gumbel move choice and the improved policy need (node.py:281-346), for the
+ * roots of all trees in one call; arrays are [T] / [T][A]; any pointer may be NULL. */
+int tg_search_read_root_stats(tg_search *s, int32_t *num_children_host, int32_t *node_visits_host,
+                              float *raw_value_host, int32_t *action_host, int32_t *visits_host,
+                              int32_t *virtual_loss_host, double *value_sum_host,
+                              double *policy_host);
 /* Play moves_host[t] (padded coordinate, 0 = PASS, < 0 = leave the tree alone) on the ROOT
  * position of every tree on the device (GoBoard.put_stone, go_board.py:131-185) and flip the
  * side to move: self-play boards stay resident between searches. */

@@ -1357,6 +1357,36 @@ int tg_search_read_roots(tg_search *s, int32_t *num_children_host, int32_t *acti
     return TG_OK;
 }
 
+int tg_search_read_root_stats(tg_search *s, int32_t *num_children_host, int32_t *node_visits_host,
+                              float *raw_value_host, int32_t *action_host, int32_t *visits_host,
+                              int32_t *virtual_loss_host, double *value_sum_host, double *policy_host) {
+    if (!s) return tg::fail(TG_ERR_ARG, "tg_search_read_root_stats: null argument");
+    if (s->last_stream) TG_HIP(hipStreamSynchronize(s->last_stream));
+    else TG_HIP(hipDeviceSynchronize());
+    int rc = check_errors(s);
+    if (rc) return rc;
+    const SearchDev &D = s->dev;
+    const size_t A = s->A, T = D.T, N = D.N;
+    // root = node 0 of every tree: per-tree rows are N*A (arrays) or N (scalars) apart
+#define RD2(dst, src, type, width, pitch) \
+    if (dst) TG_HIP(hipMemcpy2D(dst, (width) * sizeof(type), src, (pitch) * sizeof(type), (width) * sizeof(type), T, hipMemcpyDeviceToHost));
+    RD2(num_children_host, D.n_children, int32_t, 1, N)
+    RD2(node_visits_host, D.n_visits, int32_t, 1, N)
+    RD2(raw_value_host, D.n_raw, float, 1, N)
+    RD2(visits_host, D.ch_visits, int32_t, A, N * A)
+    RD2(virtual_loss_host, D.ch_vl, int32_t, A, N * A)
+    RD2(value_sum_host, D.ch_vsum, double, A, N * A)
+    RD2(policy_host, D.ch_policy, double, A, N * A)
+#undef RD2
+    if (action_host) {
+        std::vector<int16_t> act(T * A);
+        TG_HIP(hipMemcpy2D(act.data(), A * sizeof(int16_t), D.action, N * A * sizeof(int16_t), A * sizeof(int16_t), T,
+                           hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < T * A; ++i) action_host[i] = act[i];
+    }
+    return TG_OK;
+}
+
 int tg_search_num_nodes(tg_search *s, int32_t *num_nodes_host) {
     if (!s || !num_nodes_host) return tg::fail(TG_ERR_ARG, "tg_search_num_nodes: null argument");
     if (s->last_stream) TG_HIP(hipStreamSynchronize(s->last_stream));

@@ -10,6 +10,7 @@ numpy's dirichlet / gumbel use, so the doubles are bit-identical) and hands wind
 to the device, which consumes them with a cursor.
 """
 import ctypes
+import math
 import os
 from typing import List, Optional
 
@@ -23,11 +24,15 @@ from tamago_amd.mcts.node import MCTSNode
 
 
 class ExpStream:
-    """Position-addressable view of a legacy numpy stream as exponentials."""
+    """Position-addressable view of a legacy numpy stream as exponentials e_i = -log(1-u_i).
+
+    Gumbel noise comes from the same values: numpy's legacy gumbel is
+    ``loc - scale*log(-log(1-u))`` = ``-log(e_i)`` with the same libm ``log`` (verified
+    bit-for-bit in tests/test_host_rng.py), so no second generator has to be positioned."""
 
     def __init__(self, state):
-        self.origin = state                       # RandomState.get_state() tuple at position 0
-        self.gen = np.random.RandomState()
+        self.origin = state                       # RandomState state at position 0
+        self.gen = np.random.RandomState()        # generator at position buf0 + len(buf)
         self.gen.set_state(state)
         self.buf = np.empty(0, dtype=np.float64)  # exponentials for positions [buf0, buf0+len)
         self.buf0 = 0
@@ -47,23 +52,16 @@ class ExpStream:
 
     def gumbel(self, size: int) -> np.ndarray:
         """Next `size` positions as Gumbel(0,1) noise (node.py:278)."""
+        noise = np.array([-math.log(v) for v in self.window(size)], dtype=np.float64)
+        self.pos += size
+        return noise
+
+    def final_state(self):
+        """Generator state after everything consumed so far (O(pos): per-move streams only)."""
         g = np.random.RandomState()
         g.set_state(self.origin)
         if self.pos:
             g.random_sample(self.pos)             # one double per position
-        noise = g.gumbel(loc=0.0, scale=1.0, size=size)
-        self.pos += size
-        self.gen = g                              # continue after the noise
-        self.buf = np.empty(0, dtype=np.float64)
-        self.buf0 = self.pos
-        return noise
-
-    def final_state(self):
-        """Generator state after everything consumed so far."""
-        g = np.random.RandomState()
-        g.set_state(self.origin)
-        if self.pos:
-            g.random_sample(self.pos)
         return g.get_state()
 
 
@@ -290,6 +288,39 @@ class SearchEngine:
         _lib.check(self.lib.tg_search_read_roots(self.handle, nc.ctypes.data, action.ctypes.data,
                                                  visits.ctypes.data), "tg_search_read_roots")
         return nc, action, visits
+
+    def read_root_stats(self):
+        """dict of root arrays for all trees ([T] / [T][A]) in one call."""
+        t, a = self.T, self.A
+        out = {"num_children": np.zeros(t, np.int32), "node_visits": np.zeros(t, np.int32),
+               "raw_value": np.zeros(t, np.float32), "action": np.zeros((t, a), np.int32),
+               "children_visits": np.zeros((t, a), np.int32),
+               "children_virtual_loss": np.zeros((t, a), np.int32),
+               "children_value_sum": np.zeros((t, a), np.float64),
+               "children_policy": np.zeros((t, a), np.float64)}
+        _lib.check(self.lib.tg_search_read_root_stats(
+            self.handle, out["num_children"].ctypes.data, out["node_visits"].ctypes.data,
+            out["raw_value"].ctypes.data, out["action"].ctypes.data,
+            out["children_visits"].ctypes.data, out["children_virtual_loss"].ctypes.data,
+            out["children_value_sum"].ctypes.data, out["children_policy"].ctypes.data),
+            "tg_search_read_root_stats")
+        return out
+
+    def root_view(self, stats, tree: int) -> MCTSNode:
+        """MCTSNode view of one root out of read_root_stats() (no further device access)."""
+        view = MCTSNode(self.A)
+        view.num_children = int(stats["num_children"][tree])
+        view.node_visits = int(stats["node_visits"][tree])
+        view.raw_value = np.float32(stats["raw_value"][tree])
+        view.action = [int(x) for x in stats["action"][tree]]
+        view.children_visits = stats["children_visits"][tree]
+        view.children_virtual_loss = stats["children_virtual_loss"][tree]
+        view.children_value_sum = stats["children_value_sum"][tree]
+        view.children_policy = stats["children_policy"][tree]
+        noise = getattr(self, "noise", None)
+        if noise is not None:
+            view.noise = noise[tree]
+        return view
 
     def read_node(self, tree: int, node: int) -> MCTSNode:
         a = self.A

@@ -94,7 +94,24 @@ class MCTSTree:
     # ------------------------------------------------------------------------------------
     def search_best_move(self, board: GoBoard, color, time_manager: TimeManager,
                          analysis_query: Dict[str, Any] = None) -> int:
-        """mcts/tree.py:57-105."""
+        """mcts/tree.py:57-105.  The reference doubles its node list when it fills up
+        (tree.py:254-258); the device pool is fixed, so on overflow the pool is doubled and
+        the (deterministic) search is repeated from the same RNG state - same result."""
+        from tamago_amd.lib import TamagoHipError
+        rng_state = np.random.get_state()
+        while True:
+            try:
+                return self._search_best_move(board, color, time_manager, analysis_query)
+            except TamagoHipError as err:
+                if "node pool full" not in str(err):
+                    raise
+                import sys
+                sys.stderr.write(f"Tree is full. Allocate new space {self.tree_size} -> "
+                                 f"{self.tree_size * 2}\n")
+                self.tree_size *= 2
+                np.random.set_state(rng_state)
+
+    def _search_best_move(self, board, color, time_manager, analysis_query):
         engine = self._engine_for(board)
         self._gumbel_root = False
         self.to_move = color if isinstance(color, Stone) else Stone(color_value(color))

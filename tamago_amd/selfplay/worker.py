@@ -36,7 +36,9 @@ def shard_indices(index_list: Sequence[int], world_size: int, rank: int) -> List
 class _Game:
     def __init__(self, index: int, size: int, save_dir: str, never_resign: bool):
         self.index = index
-        self.board = GoBoard(board_size=size, komi=7.0, check_superko=True)
+        self.size = size
+        self.board = GoBoard(board_size=size, komi=7.0, check_superko=True)   # start position
+        self.history = []                        # (pos, colour) - the game itself lives on the GPU
         self.record = SelfPlayRecord(save_dir, self.board.coordinate)
         self.color = Stone.BLACK
         self.pass_count = 0
@@ -87,9 +89,7 @@ def selfplay_shard(save_dir: str, network, index_list: Sequence[int], size: int,
 
     while any(g is not None and not g.done for g in slots):
         active = [s for s, g in enumerate(slots) if g is not None and not g.done]
-        for s in active:
-            engine.set_root(s, slots[s].board, slots[s].color)
-        # idle slots keep their last root; their leaves are computed and ignored
+        # boards are resident on the device (tg_search_play); idle slots keep their last root
         engine.root_eval(use_logit=True)
         engine.set_gumbel_noise()
         nc, _, _ = engine.read_roots()
@@ -104,10 +104,11 @@ def selfplay_shard(save_dir: str, network, index_list: Sequence[int], size: int,
             levels = [sc[phase][1] if phase < len(sc) else 0 for sc in schedules]
             engine.gumbel_phase(widths, levels)
             stats["leaf_evals"] += int(np.dot(widths, levels))
+        root_stats = engine.read_root_stats()
+        played = np.full(boards, -1, dtype=np.int32)
         for s in active:
             game = slots[s]
-            root = engine.read_node(s, 0)
-            root.noise = engine.noise[s].copy()
+            root = engine.root_view(root_stats, s)
             best = root.select_move_by_sequential_halving_for_root(PLAYOUTS)      # tree.py:344
             value = root.calculate_value_evaluation(best)
             pos = RESIGN if (not game.never_resign and value < 0.05) else root.get_child_move(best)
@@ -115,13 +116,17 @@ def selfplay_shard(save_dir: str, network, index_list: Sequence[int], size: int,
             if pos == RESIGN:                                                      # worker.py:59-62
                 _finish(game, Stone.get_opponent_color(game.color), True, 0.0)
             else:
-                game.board.put_stone(pos, game.color)
+                played[s] = pos
+                game.history.append((pos, game.color))
                 game.pass_count = game.pass_count + 1 if pos == PASS else 0
                 game.record.save_record(root, pos, game.color)
                 game.color = Stone.get_opponent_color(game.color)
                 game.moves_played += 1
                 if game.pass_count == 2:                                           # worker.py:80-87
-                    score = game.board.count_score() - game.board.get_komi()
+                    final = GoBoard(board_size=size, komi=7.0, check_superko=True)
+                    for mv, col in game.history:
+                        final.put_stone(mv, col)
+                    score = final.count_score() - final.get_komi()
                     winner = Stone.BLACK if score > 0.1 else (Stone.WHITE if score < -0.1
                                                               else Stone.OUT_OF_BOARD)
                     _finish(game, winner, False, score)
@@ -131,8 +136,11 @@ def selfplay_shard(save_dir: str, network, index_list: Sequence[int], size: int,
                     _finish(game, Stone.EMPTY, False, 0.0)
             if game.done:
                 stats["games"] += 1
-                if queue:
-                    start(s)
+                played[s] = -1
+        engine.play(played)
+        for s in active:
+            if slots[s].done and queue:
+                start(s)
     engine.close()
     return stats
 

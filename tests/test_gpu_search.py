@@ -170,3 +170,12 @@ def test_edge_cases_pass_only_root_and_errors():
         small.read_node(0, 0)
     with pytest.raises(TamagoHipError):
         small.puct_batch(17)                         # more leaves than batch_size
+    # MCTSTree grows the pool like the reference's "Tree is full" path and gives the same answer
+    grow = MCTSTree(StubNet(2), tree_size=16, batch_size=8)
+    ref = MCTSTree(StubNet(2), tree_size=256, batch_size=8)
+    np.random.seed(4)
+    a = grow.search_best_move(GoBoard(9), 1, TimeManager(TimeControl.STRICT_PLAYOUT, 100), {})
+    np.random.seed(4)
+    b = ref.search_best_move(GoBoard(9), 1, TimeManager(TimeControl.STRICT_PLAYOUT, 100), {})
+    assert a == b and grow.tree_size >= 128
+    assert np.array_equal(grow.get_root().children_visits, ref.get_root().children_visits)
