@@ -38,6 +38,7 @@ constexpr int kRowBytes = kRowFloats * 4;     // 288
 struct NetDev {
     const float *w0frag;  // [4 wave][9 tap][64 lane][2]         stem 6->64 (cin padded to 8)
     const float *wfrag;   // [12 layer][4 wave][9 tap][4 s][64 lane][4]
+    const float *wwino;   // [12 layer][4 wave][16 xi][4 s][64 lane][4]  Winograd G g G^T, fragment order
     const float *scale;   // [13][64] folded BN scale
     const float *shift;   // [13][64] folded BN shift
     const float *hp_w;    // [2][64]  policy 1x1 conv
@@ -69,6 +70,117 @@ __device__ __forceinline__ float lds_f32(const unsigned char *smem, int byte_off
 }
 __device__ __forceinline__ f32x4 lds_f32x4(const unsigned char *smem, int byte_off) {
     return *reinterpret_cast<const f32x4 *>(smem + byte_off);
+}
+
+
+// ---- pieces shared by the direct and the Winograd kernels -------------------------------------
+template <int S, int G>
+__device__ __forceinline__ void stage_planes(unsigned char *smem, const float *__restrict__ planes, int b0,
+                                             int batch, int tid) {
+    using C = FwdCfg<S, G>;
+    constexpr int P = C::P, M = C::M;
+    // global [b][6][P] -> LDS in8 [row][8]
+        {
+            float *in8 = reinterpret_cast<float *>(smem + C::AUX);
+            for (int e = tid; e < G * 6 * P; e += 256) {
+                const int bl = e / (6 * P);
+                const int rem = e - bl * 6 * P;
+                const int c = rem / P;
+                const int p = rem - c * P;
+                const int b = b0 + bl;
+                const float v = (b < batch) ? planes[(size_t)b * 6 * P + rem] : 0.f;
+                in8[(bl * P + p) * 8 + c] = v;
+            }
+            for (int e = tid; e < M * 2; e += 256) in8[(e >> 1) * 8 + 6 + (e & 1)] = 0.f;
+        }
+}
+
+template <int S, int G>
+__device__ __forceinline__ void run_heads(unsigned char *smem, const NetDev &net, int b0, int batch,
+                                          int want_logits, float *__restrict__ policy,
+                                          float *__restrict__ value, int tid) {
+    using C = FwdCfg<S, G>;
+    constexpr int P = C::P, A = C::A, M = C::M;
+    const int wave = tid >> 6, lane = tid & 63;
+        float *hpol = reinterpret_cast<float *>(smem + C::AUX);   // [G][2P]
+        float *hval = hpol + G * 2 * P;                           // [G][P]
+        float *plog = hval + G * P;                               // [G][A]
+        float *vlog = plog + G * A;                               // [G][4]
+        {
+            const float ps0 = net.head_ss[0], pt0 = net.head_ss[1];
+            const float ps1 = net.head_ss[2], pt1 = net.head_ss[3];
+            const float vs = net.head_ss[4], vt = net.head_ss[5];
+            for (int r = tid; r < M; r += 256) {
+                float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+#pragma unroll
+                for (int k4 = 0; k4 < 16; ++k4) {
+                    const f32x4 xv = lds_f32x4(smem, r * kRowBytes + k4 * 16);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int k = k4 * 4 + j;
+                        d0 = fmaf(xv[j], net.hp_w[k], d0);
+                        d1 = fmaf(xv[j], net.hp_w[64 + k], d1);
+                        d2 = fmaf(xv[j], net.hv_w[k], d2);
+                    }
+                }
+                const int bl = r / P, p = r - bl * P;
+                hpol[bl * 2 * P + p] = fmaxf(fmaf(d0, ps0, pt0), 0.f);
+                hpol[bl * 2 * P + P + p] = fmaxf(fmaf(d1, ps1, pt1), 0.f);
+                hval[bl * P + p] = fmaxf(fmaf(d2, vs, vt), 0.f);
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < G * A + G * 3; e += 256) {
+            if (e < G * A) {
+                const int bl = e / A, a = e - bl * A;
+                const float *h = hpol + bl * 2 * P;
+                const float *wT = net.pfc_wT + a;
+                float s0 = net.pfc_b[a], s1 = 0.f, s2 = 0.f, s3 = 0.f;
+                int j = 0;
+                for (; j + 4 <= 2 * P; j += 4) {
+                    s0 = fmaf(h[j], wT[(size_t)j * A], s0);
+                    s1 = fmaf(h[j + 1], wT[(size_t)(j + 1) * A], s1);
+                    s2 = fmaf(h[j + 2], wT[(size_t)(j + 2) * A], s2);
+                    s3 = fmaf(h[j + 3], wT[(size_t)(j + 3) * A], s3);
+                }
+                for (; j < 2 * P; ++j) s0 = fmaf(h[j], wT[(size_t)j * A], s0);
+                plog[e] = (s0 + s1) + (s2 + s3);
+            } else {
+                const int q = e - G * A;
+                const int bl = q / 3, c = q - bl * 3;
+                const float *h = hval + bl * P;
+                const float *wv = net.vfc_w + c * P;
+                float s0 = net.vfc_b[c];
+                for (int j = 0; j < P; ++j) s0 = fmaf(h[j], wv[j], s0);
+                vlog[bl * 4 + c] = s0;
+            }
+        }
+        __syncthreads();
+        for (int bl = wave; bl < G; bl += 4) {
+            const int b = b0 + bl;
+            if (b >= batch) continue;
+            float m = -INFINITY;
+            for (int a = lane; a < A; a += 64) m = fmaxf(m, plog[bl * A + a]);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+            float sum = 0.f;
+            for (int a = lane; a < A; a += 64) sum += expf(plog[bl * A + a] - m);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+            const float inv = 1.f / sum;
+            for (int a = lane; a < A; a += 64) {
+                const float lg_ = plog[bl * A + a];
+                policy[(size_t)b * A + a] = want_logits ? lg_ : expf(lg_ - m) * inv;
+            }
+            if (lane < 3) {
+                const float v0 = vlog[bl * 4], v1 = vlog[bl * 4 + 1], v2 = vlog[bl * 4 + 2];
+                const float vm = fmaxf(v0, fmaxf(v1, v2));
+                const float e0 = expf(v0 - vm), e1 = expf(v1 - vm), e2 = expf(v2 - vm);
+                const float es = e0 + e1 + e2;
+                const float mine = lane == 0 ? e0 : (lane == 1 ? e1 : e2);
+                value[(size_t)b * 3 + lane] = mine / es;
+            }
+        }
 }
 
 template <int S, int G>
@@ -121,20 +233,7 @@ __global__ __launch_bounds__(256, (FwdCfg<S, G>::WAVES_PER_SIMD)) void dualnet_f
         const int b0 = grp * G;
         stamp();                                  // 0: group start
 
-        // ---- stage the input planes: global [b][6][P] -> LDS in8 [row][8] -----------------
-        {
-            float *in8 = reinterpret_cast<float *>(smem + C::AUX);
-            for (int e = tid; e < G * 6 * P; e += 256) {
-                const int bl = e / (6 * P);
-                const int rem = e - bl * 6 * P;
-                const int c = rem / P;
-                const int p = rem - c * P;
-                const int b = b0 + bl;
-                const float v = (b < batch) ? planes[(size_t)b * 6 * P + rem] : 0.f;
-                in8[(bl * P + p) * 8 + c] = v;
-            }
-            for (int e = tid; e < M * 2; e += 256) in8[(e >> 1) * 8 + 6 + (e & 1)] = 0.f;
-        }
+        stage_planes<S, G>(smem, planes, b0, batch, tid);
         __syncthreads();
 
         f32x4 acc[MT];
@@ -255,88 +354,264 @@ __global__ __launch_bounds__(256, (FwdCfg<S, G>::WAVES_PER_SIMD)) void dualnet_f
         __syncthreads();
         stamp();                                  // all epilogues done
 
-        // ---- heads ------------------------------------------------------------------------------
-        float *hpol = reinterpret_cast<float *>(smem + C::AUX);   // [G][2P]
-        float *hval = hpol + G * 2 * P;                           // [G][P]
-        float *plog = hval + G * P;                               // [G][A]
-        float *vlog = plog + G * A;                               // [G][4]
-        {
-            const float ps0 = net.head_ss[0], pt0 = net.head_ss[1];
-            const float ps1 = net.head_ss[2], pt1 = net.head_ss[3];
-            const float vs = net.head_ss[4], vt = net.head_ss[5];
-            for (int r = tid; r < M; r += 256) {
-                float d0 = 0.f, d1 = 0.f, d2 = 0.f;
-#pragma unroll
-                for (int k4 = 0; k4 < 16; ++k4) {
-                    const f32x4 xv = lds_f32x4(smem, r * kRowBytes + k4 * 16);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int k = k4 * 4 + j;
-                        d0 = fmaf(xv[j], net.hp_w[k], d0);
-                        d1 = fmaf(xv[j], net.hp_w[64 + k], d1);
-                        d2 = fmaf(xv[j], net.hv_w[k], d2);
-                    }
-                }
-                const int bl = r / P, p = r - bl * P;
-                hpol[bl * 2 * P + p] = fmaxf(fmaf(d0, ps0, pt0), 0.f);
-                hpol[bl * 2 * P + P + p] = fmaxf(fmaf(d1, ps1, pt1), 0.f);
-                hval[bl * P + p] = fmaxf(fmaf(d2, vs, vt), 0.f);
-            }
-        }
-        __syncthreads();
-        for (int e = tid; e < G * A + G * 3; e += 256) {
-            if (e < G * A) {
-                const int bl = e / A, a = e - bl * A;
-                const float *h = hpol + bl * 2 * P;
-                const float *wT = net.pfc_wT + a;
-                float s0 = net.pfc_b[a], s1 = 0.f, s2 = 0.f, s3 = 0.f;
-                int j = 0;
-                for (; j + 4 <= 2 * P; j += 4) {
-                    s0 = fmaf(h[j], wT[(size_t)j * A], s0);
-                    s1 = fmaf(h[j + 1], wT[(size_t)(j + 1) * A], s1);
-                    s2 = fmaf(h[j + 2], wT[(size_t)(j + 2) * A], s2);
-                    s3 = fmaf(h[j + 3], wT[(size_t)(j + 3) * A], s3);
-                }
-                for (; j < 2 * P; ++j) s0 = fmaf(h[j], wT[(size_t)j * A], s0);
-                plog[e] = (s0 + s1) + (s2 + s3);
-            } else {
-                const int q = e - G * A;
-                const int bl = q / 3, c = q - bl * 3;
-                const float *h = hval + bl * P;
-                const float *wv = net.vfc_w + c * P;
-                float s0 = net.vfc_b[c];
-                for (int j = 0; j < P; ++j) s0 = fmaf(h[j], wv[j], s0);
-                vlog[bl * 4 + c] = s0;
-            }
-        }
-        __syncthreads();
-        for (int bl = wave; bl < G; bl += 4) {
-            const int b = b0 + bl;
-            if (b >= batch) continue;
-            float m = -INFINITY;
-            for (int a = lane; a < A; a += 64) m = fmaxf(m, plog[bl * A + a]);
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-            float sum = 0.f;
-            for (int a = lane; a < A; a += 64) sum += expf(plog[bl * A + a] - m);
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-            const float inv = 1.f / sum;
-            for (int a = lane; a < A; a += 64) {
-                const float lg_ = plog[bl * A + a];
-                policy[(size_t)b * A + a] = want_logits ? lg_ : expf(lg_ - m) * inv;
-            }
-            if (lane < 3) {
-                const float v0 = vlog[bl * 4], v1 = vlog[bl * 4 + 1], v2 = vlog[bl * 4 + 2];
-                const float vm = fmaxf(v0, fmaxf(v1, v2));
-                const float e0 = expf(v0 - vm), e1 = expf(v1 - vm), e2 = expf(v2 - vm);
-                const float es = e0 + e1 + e2;
-                const float mine = lane == 0 ? e0 : (lane == 1 ? e1 : e2);
-                value[(size_t)b * 3 + lane] = mine / es;
-            }
-        }
+        run_heads<S, G>(smem, net, b0, batch, want_logits, policy, value, tid);
         __syncthreads();
         stamp();                                  // heads done
+    }
+}
+
+
+// ======================================================================================
+// Winograd F(2x2,3x3) variant of the residual tower (same fusion, same LDS residency).
+//
+// For every 2x2 output tile the 3x3 correlation becomes 16 element-wise products in the
+// transform domain; summed over input channels these are 16 independent GEMMs
+//   M_xi[tile][cout] = sum_cin V_xi[tile][cin] * U_xi[cin][cout],  xi = 0..15,
+// with V = B^T d B (input transform, adds only), U = G g G^T (host) and Y = A^T M A (output
+// transform, adds only).  A 9x9 board has 25 tiles (the 10th row/column is discarded), so the
+// MFMA rows per board drop from 81 x 9 taps to 25 x 16 points: 1.8x fewer MFMAs in exact
+// fp32 (the transforms only add; the weights pick up factors 1/2 and 1/4).
+//
+// One workgroup (4 waves, 1 per SIMD, up to 512 VGPRs) owns G boards; wave w owns output
+// channels [16w,16w+16).  Work unit = (row-tile of 16 tiles, 16 input channels): 16
+// ds_read_b128 -> in-register input transform -> 64 MFMAs into 16 accumulators; after the
+// four channel groups the output transform folds them into the 2x2 outputs, which stay in
+// registers (with the residual) until the layer's barrier, exactly like the direct kernel.
+// The loads + transform of unit u+1 are issued while the MFMAs of unit u run.
+template <int S, int G>
+struct WinoCfg {
+    static constexpr int TY = (S + 1) / 2;          // tiles per side (5)
+    static constexpr int TPB = TY * TY;             // tiles per board (25)
+    static constexpr int NT = G * TPB;
+    static constexpr int RT = (NT + 15) / 16;       // row-tiles of 16 Winograd tiles
+};
+
+template <int S, int G>
+__global__ __launch_bounds__(256, 1) void dualnet_fwd_wino_kernel(
+    NetDev net, const float *__restrict__ planes, int batch, int want_logits,
+    float *__restrict__ policy, float *__restrict__ value) {
+    using C = FwdCfg<S, G>;
+    using Wc = WinoCfg<S, G>;
+    constexpr int P = C::P, M = C::M, MT = C::MT;
+    constexpr int TY = Wc::TY, TPB = Wc::TPB, NT = Wc::NT, RT = Wc::RT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6;
+    const int lane = tid & 63;
+    const int li = lane & 15;
+    const int lg = lane >> 4;
+
+    // per-lane A-side constants: tile (rt*16 + li) -> byte address of its 4x4 input patch origin
+    // (row 2ty-1, col 2tx-1; may lie off the board) and the validity of the 16 patch points
+    int base[RT];
+    unsigned vmask[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int t = rt * 16 + li;
+        const int bl = t / TPB;
+        const int tl = t - bl * TPB;
+        const int ty = tl / TY, tx = tl - ty * TY;
+        const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
+        base[rt] = (bl * P + y0 * S + x0) * kRowBytes + lg * 16;
+        unsigned m = 0;
+#pragma unroll
+        for (int pq = 0; pq < 16; ++pq) {
+            const int y = y0 + pq / 4, x = x0 + pq % 4;
+            if (t < NT && y >= 0 && y < S && x >= 0 && x < S) m |= 1u << pq;
+        }
+        vmask[rt] = m;
+    }
+    const int lane_zero = C::ZROW + lg * 16;
+    const int lane_in8 = C::AUX + li * 32 + lg * 4;
+    const int lane_zero8 = C::ZERO8 + lg * 4;
+
+    for (int e = tid; e < kRowFloats; e += 256) reinterpret_cast<float *>(smem + C::ZROW)[e] = 0.f;
+    if (tid < 8) reinterpret_cast<float *>(smem + C::ZERO8)[tid] = 0.f;
+
+    float *act = reinterpret_cast<float *>(smem);
+    const int n_groups = (batch + G - 1) / G;
+    for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const int b0 = grp * G;
+        stage_planes<S, G>(smem, planes, b0, batch, tid);
+        __syncthreads();
+
+        // ---- stem: direct 6(8) -> 64 conv, written straight to the activation buffer ------------
+        {
+            f32x4 acc[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float2 *w0 = reinterpret_cast<const float2 *>(net.w0frag) + wave * 9 * 64 + lane;
+#pragma unroll 1
+            for (int tap = 0; tap < 9; ++tap) {
+                const float2 bcur = w0[tap * 64];
+                const int toff = ((tap / 3 - 1) * S + (tap % 3 - 1)) * 32;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int r = mt * 16 + li;
+                    const int pb = r % P;
+                    const int yy = pb / S + tap / 3 - 1, xx = pb % S + tap % 3 - 1;
+                    const bool ok = r < M && yy >= 0 && yy < S && xx >= 0 && xx < S;
+                    const int a = ok ? lane_in8 + mt * 16 * 32 + toff : lane_zero8;
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(lds_f32(smem, a), bcur.x, acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(lds_f32(smem, a + 16), bcur.y, acc[mt], 0, 0, 0);
+                }
+            }
+            const float sc = net.scale[wave * 16 + li], sh = net.shift[wave * 16 + li];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = mt * 16 + lg * 4 + j;
+                    if (r < M) act[r * kRowFloats + wave * 16 + li] = fmaxf(fmaf(acc[mt][j], sc, sh), 0.f);
+                }
+        }
+        __syncthreads();
+
+        // output-side mapping (C/D layout): register j of row-tile rt <-> tile rt*16 + 4*lg + j,
+        // column li.  Outputs o = 2*oy + ox at board position (2ty+oy, 2tx+ox).
+        f32x4 yv[RT][4];       // this layer's outputs
+        f32x4 res[RT][4];      // residual-block input (same mapping)
+        auto out_pos = [&](int rt, int j, int o) -> int {   // flat activation row or -1
+            const int t = rt * 16 + lg * 4 + j;
+            const int bl = t / TPB;
+            const int tl = t - bl * TPB;
+            const int ty = tl / TY, tx = tl - ty * TY;
+            const int y = 2 * ty + (o >> 1), x = 2 * tx + (o & 1);
+            return (t < NT && y < S && x < S) ? bl * P + y * S + x : -1;
+        };
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = out_pos(rt, j, o);
+                    res[rt][o][j] = r >= 0 ? act[r * kRowFloats + wave * 16 + li] : 0.f;
+                }
+
+        // ---- residual tower ---------------------------------------------------------------------
+#pragma unroll 1
+        for (int layer = 1; layer < kConvLayers; ++layer) {
+            const f32x4 *wl = reinterpret_cast<const f32x4 *>(net.wwino) +
+                              ((size_t)((layer - 1) * 4 + wave) * 16) * 4 * 64 + lane;
+            // unit (rt, s): 4x4 patch (16 x float4 = 4 channels each) -> in-register transform ->
+            // 64 MFMAs.  Two patch buffers ping-pong (no copies): while the MFMAs of one unit
+            // issue, the other buffer is loaded and transformed for the next unit.
+            f32x4 va[16], vb[16];
+            int a16[16];                                   // patch point addresses of the row-tile being LOADED
+            auto set_addr = [&](int rt_base, unsigned rt_mask) {
+#pragma unroll
+                for (int pq = 0; pq < 16; ++pq) {
+                    const bool ok = (rt_mask >> pq) & 1u;
+                    a16[pq] = ok ? rt_base + ((pq / 4) * S + (pq % 4)) * kRowBytes : lane_zero;
+                }
+            };
+            auto load_patch = [&](f32x4 (&d)[16], int soff) {
+#pragma unroll
+                for (int pq = 0; pq < 16; ++pq) d[pq] = lds_f32x4(smem, a16[pq] + soff);
+            };
+            auto transform = [&](f32x4 (&d)[16]) {      // in place: d -> V = B^T d B
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {            // columns: t[a][q]
+                    const f32x4 d0 = d[q], d1 = d[4 + q], d2 = d[8 + q], d3 = d[12 + q];
+                    d[q] = d0 - d2;
+                    d[4 + q] = d1 + d2;
+                    d[8 + q] = d2 - d1;
+                    d[12 + q] = d1 - d3;
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {            // rows: V[a][b]
+                    const f32x4 t0 = d[4 * a], t1 = d[4 * a + 1], t2 = d[4 * a + 2], t3 = d[4 * a + 3];
+                    d[4 * a] = t0 - t2;
+                    d[4 * a + 1] = t1 + t2;
+                    d[4 * a + 2] = t2 - t1;
+                    d[4 * a + 3] = t1 - t3;
+                }
+            };
+            f32x4 bq[2];
+            bq[0] = wl[0];
+            bq[1] = wl[4 * 64];
+            // MFMAs of unit (cur, channel group s) + loads/transform of the next unit into nxt
+            auto unit = [&](f32x4 (&cur)[16], f32x4 (&nxt)[16], f32x4 (&macc)[16], int s, int next_soff) {
+                load_patch(nxt, next_soff);
+#pragma unroll
+                for (int xp = 0; xp < 16; xp += 2) {
+                    const f32x4 b0v = bq[0], b1v = bq[1];
+                    const int nx = xp + 2 < 16 ? xp + 2 : 0;          // next B pair (wraps to next unit)
+                    const int ns = xp + 2 < 16 ? s : (s + 1) & 3;
+                    bq[0] = wl[(nx * 4 + ns) * 64];
+                    bq[1] = wl[((nx + 1) * 4 + ns) * 64];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        macc[xp] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[xp][j], b0v[j], macc[xp], 0, 0, 0);
+                        macc[xp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[xp + 1][j], b1v[j], macc[xp + 1], 0, 0, 0);
+                    }
+                }
+                transform(nxt);
+                // issue order: loads first (one per MFMA), then the transform's VALU spread under
+                // the remaining MFMAs (each MFMA occupies the matrix pipe for 32 cycles)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+#pragma unroll
+                for (int k = 0; k < 48; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            set_addr(base[0], vmask[0]);
+            load_patch(va, 0);
+            transform(va);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                f32x4 macc[16];
+#pragma unroll
+                for (int xi = 0; xi < 16; ++xi) macc[xi] = f32x4{0.f, 0.f, 0.f, 0.f};
+                unit(va, vb, macc, 0, 64);
+                unit(vb, va, macc, 1, 128);
+                unit(va, vb, macc, 2, 192);
+                if (rt + 1 < RT) set_addr(base[rt + 1], vmask[rt + 1]);
+                unit(vb, va, macc, 3, 0);
+                // output transform Y = A^T M A
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const f32x4 m0 = macc[b] + macc[4 + b] + macc[8 + b];
+                    const f32x4 m1 = macc[4 + b] - macc[8 + b] - macc[12 + b];
+                    macc[b] = m0;
+                    macc[4 + b] = m1;
+                }
+                yv[rt][0] = macc[0] + macc[1] + macc[2];
+                yv[rt][1] = macc[1] - macc[2] - macc[3];
+                yv[rt][2] = macc[4] + macc[5] + macc[6];
+                yv[rt][3] = macc[5] - macc[6] - macc[7];
+            }
+            // every wave must be done reading before anyone overwrites the buffer
+            __syncthreads();
+            const float sc = net.scale[layer * 64 + wave * 16 + li];
+            const float sh = net.shift[layer * 64 + wave * 16 + li];
+            const bool block_out = (layer & 1) == 0;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int o = 0; o < 4; ++o)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float v = fmaf(yv[rt][o][j], sc, sh);
+                        if (block_out) v += res[rt][o][j];
+                        v = fmaxf(v, 0.f);
+                        if (block_out) res[rt][o][j] = v;
+                        const int r = out_pos(rt, j, o);
+                        if (r >= 0) act[r * kRowFloats + wave * 16 + li] = v;
+                    }
+            __syncthreads();
+        }
+        run_heads<S, G>(smem, net, b0, batch, want_logits, policy, value, tid);
+        __syncthreads();
     }
 }
 
@@ -411,6 +686,25 @@ int launch(tg_net *net, const float *planes, int batch, int want_logits, float *
     return TG_OK;
 }
 
+template <int S, int G>
+int launch_wino(tg_net *net, const float *planes, int batch, int want_logits, float *policy,
+                float *value, hipStream_t stream) {
+    using C = FwdCfg<S, G>;
+    auto kern = dualnet_fwd_wino_kernel<S, G>;
+    static bool attr_set[16] = {};
+    if (!attr_set[net->device & 15]) {
+        TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+        attr_set[net->device & 15] = true;
+    }
+    const int groups = (batch + G - 1) / G;
+    const int grid = groups < net->num_cus ? groups : net->num_cus;     // one workgroup per CU
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), C::LDS_BYTES, stream, net->dev, planes, batch,
+                       want_logits, policy, value);
+    TG_HIP(hipGetLastError());
+    return TG_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -468,6 +762,7 @@ int tg_net_create(int board_size, int device, const float *params, size_t n_para
     }
     // residual blocks: layer index 1 + 2b (conv1), 2 + 2b (conv2)
     std::vector<float> wf((size_t)12 * 4 * 9 * 4 * 64 * 4);
+    std::vector<float> ww((size_t)12 * 4 * 16 * 4 * 64 * 4);
     for (int b = 0; b < kBlocks; ++b) {
         const float *wc[2] = {rd.take(64 * 64 * 9), nullptr};
         wc[1] = rd.take(64 * 64 * 9);
@@ -483,6 +778,32 @@ int tg_net_create(int board_size, int device, const float *params, size_t n_para
                                 wf[(((((size_t)layer * 4 + wv) * 9 + tap) * 4 + s) * 64 + lane) * 4 + j] =
                                     wc[c][(cout * 64 + cin) * 9 + tap];
                             }
+        }
+        // Winograd F(2x2,3x3) weights U = G g G^T, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+        for (int c = 0; c < 2; ++c) {
+            const int layer = 2 * b + c;
+            for (int cout = 0; cout < 64; ++cout)
+                for (int cin = 0; cin < 64; ++cin) {
+                    const float *g = &wc[c][(cout * 64 + cin) * 9];
+                    double gg[4][3], u[4][4];
+                    for (int k = 0; k < 3; ++k) {
+                        gg[0][k] = g[k];
+                        gg[1][k] = 0.5 * ((double)g[k] + g[3 + k] + g[6 + k]);
+                        gg[2][k] = 0.5 * ((double)g[k] - g[3 + k] + g[6 + k]);
+                        gg[3][k] = g[6 + k];
+                    }
+                    for (int a = 0; a < 4; ++a) {
+                        u[a][0] = gg[a][0];
+                        u[a][1] = 0.5 * (gg[a][0] + gg[a][1] + gg[a][2]);
+                        u[a][2] = 0.5 * (gg[a][0] - gg[a][1] + gg[a][2]);
+                        u[a][3] = gg[a][2];
+                    }
+                    const int wv = cout / 16, n = cout % 16, sgrp = cin / 16, gq = (cin % 16) / 4, j = cin % 4;
+                    const int lane = gq * 16 + n;
+                    for (int xi = 0; xi < 16; ++xi)
+                        ww[(((((size_t)layer * 4 + wv) * 16 + xi) * 4 + sgrp) * 64 + lane) * 4 + j] =
+                            (float)u[xi / 4][xi % 4];
+                }
         }
         fold_bn(rd, 64, 2e-5, &scale[(1 + 2 * b) * 64], &shift[(1 + 2 * b) * 64]);
         fold_bn(rd, 64, 2e-5, &scale[(2 + 2 * b) * 64], &shift[(2 + 2 * b) * 64]);
@@ -512,7 +833,7 @@ int tg_net_create(int board_size, int device, const float *params, size_t n_para
     }
 
     int rc = TG_OK;
-    if ((rc = upload(net, w0, &net->dev.w0frag)) || (rc = upload(net, wf, &net->dev.wfrag)) ||
+    if ((rc = upload(net, w0, &net->dev.w0frag)) || (rc = upload(net, wf, &net->dev.wfrag)) || (rc = upload(net, ww, &net->dev.wwino)) ||
         (rc = upload(net, scale, &net->dev.scale)) || (rc = upload(net, shift, &net->dev.shift)) ||
         (rc = upload(net, hp_w, &net->dev.hp_w)) || (rc = upload(net, hv_w, &net->dev.hv_w)) ||
         (rc = upload(net, head_ss, &net->dev.head_ss)) || (rc = upload(net, pfc_wT, &net->dev.pfc_wT)) ||
@@ -554,6 +875,13 @@ const char *tg_net_kernel_name(const tg_net *net, int batch) {
     return g == 6 ? "dualnet_fwd_kernel<9, 6>" : (g == 3 ? "dualnet_fwd_kernel<9, 3>" : "dualnet_fwd_kernel<9, 1>");
 }
 
+static int pick_wino(int board_size, int batch, int num_cus) {
+    // Winograd tower: G boards per workgroup, one workgroup per CU; 0 = direct convolution
+    if (board_size != 9) return 0;
+    if (const char *env = getenv("TG_FWD_WINO")) return atoi(env);
+    return 0;
+}
+
 int tg_net_forward_dev(tg_net *net, const float *planes_dev, int batch, int want_logits,
                        float *policy_dev, float *value_dev, void *stream) {
     if (batch < 0) return tg::fail(TG_ERR_ARG, "tg_net_forward_dev: negative batch");
@@ -563,6 +891,12 @@ int tg_net_forward_dev(tg_net *net, const float *planes_dev, int batch, int want
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (net->board_size == 19)
         return launch<19, 1>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st);
+    if (net->board_size == 9) {
+        const int wg = pick_wino(9, batch, net->num_cus);
+        if (wg == 4) return launch_wino<9, 4>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st);
+        if (wg == 5) return launch_wino<9, 5>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st);
+        if (wg == 3) return launch_wino<9, 3>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st);
+    }
     const int g = pick_group(9, batch, net->num_cus);
     if (g == 6) return launch<9, 6>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st);
     if (g == 3) return launch<9, 3>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st);

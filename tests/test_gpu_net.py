@@ -114,3 +114,21 @@ def test_featurize_kernel_vs_reference_golden(size):
                                   torch.cuda.current_stream().cuda_stream), "tg_featurize_dev")
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy(), np.array(want))
+
+
+def test_experimental_winograd_tower_parity(monkeypatch):
+    """TG_FWD_WINO selects the experimental Winograd F(2x2,3x3) variant of the residual tower
+    (exact fp32, transforms only add).  Not the default - see DESIGN.md - but it must agree
+    with the oracle like the direct kernel."""
+    from oracle.net import OracleNet, make_state_dict
+    sd = make_state_dict(9, 7, 1.5)
+    net = _net(9, sd)
+    ora = OracleNet(sd)
+    rs = np.random.RandomState(11)
+    x = torch.from_numpy(rs.randint(-1, 2, size=(1301, 6, 9, 9)).astype(np.float32))
+    rp, rv = ora.inference(x)
+    for variant in ("3", "4"):
+        monkeypatch.setenv("TG_FWD_WINO", variant)
+        pol, val = net.inference(x)
+        assert np.abs(pol.numpy() - rp.numpy()).max() < TOL
+        assert np.abs(val.numpy() - rv.numpy()).max() < TOL
