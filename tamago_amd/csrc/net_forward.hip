@@ -256,8 +256,8 @@ __global__ __launch_bounds__(256, (FwdCfg<S, G>::WAVES_PER_SIMD)) void dualnet_f
                     const int a = ok ? lane_in8 + mt * 16 * 32 + toff : lane_zero8;
                     const float a0 = lds_f32(smem, a);
                     const float a1 = lds_f32(smem, a + 16);
-                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bcur.x, acc[mt], 0, 0, 0);
-                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bcur.y, acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur.x, a0, acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur.y, a1, acc[mt], 0, 0, 0);
                 }
             }
         }
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256, (FwdCfg<S, G>::WAVES_PER_SIMD)) void dualnet_f
                                 for (int m = 0; m < CH; ++m) {
                                     const int mt = c * CH + m;
                                     if (mt < MT)
-                                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[m][j], bcur[j], acc[mt], 0, 0, 0);
+                                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[j], acur[m][j], acc[mt], 0, 0, 0);
                                 }
                             }
                             __builtin_amdgcn_sched_barrier(0);
@@ -332,23 +332,27 @@ __global__ __launch_bounds__(256, (FwdCfg<S, G>::WAVES_PER_SIMD)) void dualnet_f
                 __syncthreads();
                 stamp();                          // barrier passed
             }
-            // epilogue: BN scale/shift (+ residual) + ReLU, C/D layout: col = lane&15, row = 4*(lane>>4)+j
-            const float sc = net.scale[layer * 64 + wave * 16 + li];
-            const float sh = net.shift[layer * 64 + wave * 16 + li];
+            // epilogue: BN scale/shift (+ residual) + ReLU.  The MFMAs are issued with the weights
+            // as the A operand and the activations as B, so D is [cout][position]: C/D column
+            // (lane & 15) = position within the M-tile, C/D rows 4*(lane>>4)+j = four CONSECUTIVE
+            // output channels -> one 16-byte LDS store per M-tile instead of four 4-byte ones.
+            const f32x4 sc = *reinterpret_cast<const f32x4 *>(net.scale + layer * 64 + wave * 16 + lg * 4);
+            const f32x4 sh = *reinterpret_cast<const f32x4 *>(net.shift + layer * 64 + wave * 16 + lg * 4);
             const bool block_out = (layer & 1) == 0;       // stem (0) and every conv2 (2,4,..,12)
             const bool add_res = block_out && layer > 0;
-            float *act = reinterpret_cast<float *>(smem);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
+                f32x4 v;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    float v = fmaf(acc[mt][j], sc, sh);
-                    if (add_res) v += res[mt][j];
-                    v = fmaxf(v, 0.f);
-                    if (block_out) res[mt][j] = v;
-                    const int r = mt * 16 + lg * 4 + j;
-                    if (r < M) act[r * kRowFloats + wave * 16 + li] = v;
+                    float t = fmaf(acc[mt][j], sc[j], sh[j]);
+                    if (add_res) t += res[mt][j];
+                    v[j] = fmaxf(t, 0.f);
                 }
+                if (block_out) res[mt] = v;
+                const int r = mt * 16 + li;
+                if (r < M)
+                    *reinterpret_cast<f32x4 *>(smem + r * kRowBytes + wave * 64 + lg * 16) = v;
             }
         }
         __syncthreads();
