@@ -157,6 +157,12 @@ int tg_search_read_root_stats(tg_search *s, int32_t *num_children_host, int32_t 
                               float *raw_value_host, int32_t *action_host, int32_t *visits_host,
                               int32_t *virtual_loss_host, double *value_sum_host,
                               double *policy_host);
+/* Profiling aid: with enable != 0 the PUCT selection kernel accumulates s_memtime cycles of
+ * tree 0 per phase into 16 counters (0 board reset, 1 PUCB select, 2 put_stone, 3 edge
+ * bookkeeping, 4 expansion, 5 planes + queue, 7 = number of tree levels walked, 8-10
+ * expansion detail: candidates / Dirichlet sum / node init); the call returns the counters
+ * accumulated so far (cycles_host [16], may be NULL) and clears them. */
+int tg_search_profile(tg_search *s, int enable, long long *cycles_host);
 /* Play moves_host[t] (padded coordinate, 0 = PASS, < 0 = leave the tree alone) on the ROOT
  * position of every tree on the device (GoBoard.put_stone, go_board.py:131-185) and flip the
  * side to move: self-play boards stay resident between searches. */

@@ -67,6 +67,7 @@ struct SearchDev {
     const uint64_t *zob;        // [4][NC]
     const uint8_t *eye;         // [65536]
     int32_t *err;               // [T] sticky error flags
+    long long *prof;            // optional [16] s_memtime cycle accumulators of tree 0 (tg_search_profile)
     int32_t T, N, K, cgos, superko;
 };
 
@@ -82,29 +83,68 @@ struct Geo {
 };
 
 // ---- wave helpers ----------------------------------------------------------------------
+// Cross-lane exchange for all-reduce butterflies.  Steps inside a row of 16 lanes use DPP
+// (quad_perm for xor 1 / 2, row_half_mirror / row_mirror for the 8- and 16-lane steps: mirrors
+// pair every lane with one from the other half, which is all an all-reduce needs); only the two
+// cross-row steps go through ds_bpermute.  ~3x fewer LDS-crossbar round trips than six
+// __shfl_xor rounds on a (double, int) pair.
+template <int STEP>
+__device__ __forceinline__ int lane_partner_i32(int v) {
+    if constexpr (STEP == 0) return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+    else if constexpr (STEP == 1) return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    else if constexpr (STEP == 2) return __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true);  // row_half_mirror
+    else if constexpr (STEP == 3) return __builtin_amdgcn_mov_dpp(v, 0x140, 0xF, 0xF, true);  // row_mirror
+    else if constexpr (STEP == 4) return __shfl_xor(v, 16);
+    else return __shfl_xor(v, 32);
+}
+template <int STEP>
+__device__ __forceinline__ double lane_partner_f64(double v) {
+    const long long bits = __double_as_longlong(v);
+    const int lo = lane_partner_i32<STEP>((int)(unsigned)bits);
+    const int hi = lane_partner_i32<STEP>((int)(unsigned)((unsigned long long)bits >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
 __device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    v += lane_partner_i32<0>(v);
+    v += lane_partner_i32<1>(v);
+    v += lane_partner_i32<2>(v);
+    v += lane_partner_i32<3>(v);
+    v += lane_partner_i32<4>(v);
+    v += lane_partner_i32<5>(v);
     return v;
 }
 __device__ __forceinline__ uint64_t wave_xor64(uint64_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const uint32_t lo = __shfl_xor((int)(uint32_t)v, o);
-        const uint32_t hi = __shfl_xor((int)(uint32_t)(v >> 32), o);
-        v ^= ((uint64_t)hi << 32) | lo;
-    }
-    return v;
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    lo ^= (unsigned)lane_partner_i32<0>((int)lo); hi ^= (unsigned)lane_partner_i32<0>((int)hi);
+    lo ^= (unsigned)lane_partner_i32<1>((int)lo); hi ^= (unsigned)lane_partner_i32<1>((int)hi);
+    lo ^= (unsigned)lane_partner_i32<2>((int)lo); hi ^= (unsigned)lane_partner_i32<2>((int)hi);
+    lo ^= (unsigned)lane_partner_i32<3>((int)lo); hi ^= (unsigned)lane_partner_i32<3>((int)hi);
+    lo ^= (unsigned)lane_partner_i32<4>((int)lo); hi ^= (unsigned)lane_partner_i32<4>((int)hi);
+    lo ^= (unsigned)lane_partner_i32<5>((int)lo); hi ^= (unsigned)lane_partner_i32<5>((int)hi);
+    return ((uint64_t)hi << 32) | lo;
 }
 // arg-max with lowest-index tie-break (np.argmax); idx < 0 marks "no candidate"
+template <int STEP>
+__device__ __forceinline__ void argmax_step(double &val, int &idx) {
+    const double ov = lane_partner_f64<STEP>(val);
+    const int oi = lane_partner_i32<STEP>(idx);
+    const bool take = oi >= 0 && (idx < 0 || ov > val || (ov == val && oi < idx));
+    if (take) { val = ov; idx = oi; }
+}
 __device__ __forceinline__ void wave_argmax(double &val, int &idx) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double ov = __shfl_xor(val, o);
-        const int oi = __shfl_xor(idx, o);
-        const bool take = oi >= 0 && (idx < 0 || ov > val || (ov == val && oi < idx));
-        if (take) { val = ov; idx = oi; }
-    }
+    argmax_step<0>(val, idx);
+    argmax_step<1>(val, idx);
+    argmax_step<2>(val, idx);
+    argmax_step<3>(val, idx);
+    argmax_step<4>(val, idx);
+    argmax_step<5>(val, idx);
+}
+// broadcast of a double from a wave-uniform lane (v_readlane: no LDS crossbar)
+__device__ __forceinline__ double read_lane_f64(double v, int src_lane) {
+    const long long bits = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)bits, src_lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)bits >> 32), src_lane);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
 // ---- board in LDS ------------------------------------------------------------------------
@@ -244,6 +284,25 @@ __device__ __forceinline__ int pat3_at(const Lds<S> &L, int p) {
            (L.color[p + W] << 12) | (L.color[p + W + 1] << 14);
 }
 
+// Eye colour of an empty point from its 3x3 neighbourhood (pattern.py:52-98,153-162) by the rule
+// the reference's table is exactly equal to on real boards (tests/test_oracle_board.py::
+// test_eye_table; the host-built copy of the table in D.eye is kept for cross-checking):
+// orthogonals own or border; 4 on-board diagonals: <= 1 opponent, or 2 opponent + 2 own;
+// 2 on-board diagonals (side): >= 1 own or both opponent; 1 on-board diagonal (corner): always.
+__device__ __forceinline__ bool is_eye_of(int code, int me) {
+    const int opp = 3 - me;
+    const int n = (code >> 2) & 3, w = (code >> 6) & 3, e = (code >> 8) & 3, s = (code >> 12) & 3;
+    if (!((n == me || n == kOob) && (w == me || w == kOob) && (e == me || e == kOob) && (s == me || s == kOob)))
+        return false;
+    const int d0 = code & 3, d1 = (code >> 4) & 3, d2 = (code >> 10) & 3, d3 = (code >> 14) & 3;
+    const int n_free = (d0 != kOob) + (d1 != kOob) + (d2 != kOob) + (d3 != kOob);
+    const int n_own = (d0 == me) + (d1 == me) + (d2 == me) + (d3 == me);
+    const int n_opp = (d0 == opp) + (d1 == opp) + (d2 == opp) + (d3 == opp);
+    if (n_free == 4) return n_opp <= 1 || (n_opp == 2 && n_own == 2);
+    if (n_free == 2) return n_own >= 1 || n_opp == 2;
+    return true;
+}
+
 // Candidate list of MCTSTree.expand_node (tree.py:260-264): legal (go_board.py:260-304),
 // check_self_atari_stone < 7 (:327-365), not a complete eye (:367-397); row-major, PASS last.
 // Returns the number of candidates (>= 1); L.cand[] holds their coordinates.
@@ -334,7 +393,7 @@ __device__ int gen_candidates(Lds<S> &L, const BoardScalars &b, int me, const Se
                 }
                 // complete eye (go_board.py:367-397)
                 bool eye = false;
-                if (D.eye[pat3_at<S>(L, p)] == me) {
+                if (is_eye_of(pat3_at<S>(L, p), me)) {
                     const int cr[4] = {p - W - 1, p - W + 1, p + W - 1, p + W + 1};
                     int count = 0;
                     bool edge = false;
@@ -342,7 +401,7 @@ __device__ int gen_candidates(Lds<S> &L, const BoardScalars &b, int me, const Se
                     for (int d = 0; d < 4; ++d) {
                         const int v = L.color[cr[d]];
                         if (v == me || v == kOob) ++count;
-                        else if (v == kEmpty && D.eye[pat3_at<S>(L, cr[d])] == me) ++count;
+                        else if (v == kEmpty && is_eye_of(pat3_at<S>(L, cr[d]), me)) ++count;
                         if (v == kOob) edge = true;
                     }
                     eye = (edge && count == 4) || (!edge && count >= 3);
@@ -395,29 +454,53 @@ __device__ int expand_node(Lds<S> &L, const BoardScalars &b, int to_move, const 
         return -1;
     }
     const int node = num_nodes;
-    const int n = gen_candidates<S>(L, b, to_move, D, lane);
-    // Dirichlet(1,..,1) prior from the host stream: p_i = e_i / (e_0 + e_1 + ... sequentially)
+    // Dirichlet(1,..,1) prior from the host stream: p_i = e_i / (e_0 + e_1 + ... sequentially).
+    // The stream values are requested BEFORE the candidate generation (n <= A is not known yet,
+    // every lane takes its ceil(A/64) slots) so that their latency hides behind the LDS work.
+    constexpr int R = (A + 63) / 64;
     const int64_t cur = D.rng_cursor[t];
+    const double *e = D.rng + (size_t)t * D.rng_cap;
+    double mine[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int64_t at = cur + lane + 64 * r;
+        if (at >= D.rng_cap) at = D.rng_cap - 1;
+        mine[r] = e[at];
+    }
+    const bool prof = D.prof && t == 0 && lane == 0;
+    long long tp = prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
+    auto lap = [&](int slot) {
+        if (prof) { const long long now = (long long)__builtin_amdgcn_s_memtime(); D.prof[slot] += now - tp; tp = now; }
+    };
+    const int n = gen_candidates<S>(L, b, to_move, D, lane);
+    lap(8);
     if (cur + n > D.rng_cap) {
         if (lane == 0) atomicOr(&D.err[t], kErrRngEmpty);
         return -1;
     }
-    const double *e = D.rng + (size_t)t * D.rng_cap + cur;
-    double *stage = reinterpret_cast<double *>(L.strhash);     // free after gen_candidates
-    for (int i = lane; i < n; i += 64) stage[i] = e[i];
-    __syncthreads();
+    // sequential sum e_0 + e_1 + ... exactly like numpy's dirichlet; the addends are broadcast
+    // from registers (lane i%64 holds e_i)
     double acc = 0.0;
-    for (int i = 0; i < n; ++i) acc += stage[i];        // wave-uniform, sequential like numpy
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int cnt = n - 64 * r < 64 ? n - 64 * r : 64;
+        for (int i = 0; i < cnt; ++i) acc += read_lane_f64(mine[r], i);
+    }
     const double inv = 1.0 / acc;
+    lap(9);
     const size_t base = ((size_t)t * D.N + node) * A;
-    for (int i = lane; i < A; i += 64) {
-        D.ch_index[base + i] = kNotExpanded;
-        D.ch_visits[base + i] = 0;
-        D.ch_vl[base + i] = 0;
-        D.ch_vsum[base + i] = 0.0;
-        D.ch_value[base + i] = 0.0;
-        D.ch_policy[base + i] = i < n ? stage[i] * inv : 0.0;
-        D.action[base + i] = i < n ? (int16_t)L.cand[i] : (int16_t)0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = lane + 64 * r;
+        if (i < A) {
+            D.ch_index[base + i] = kNotExpanded;
+            D.ch_visits[base + i] = 0;
+            D.ch_vl[base + i] = 0;
+            D.ch_vsum[base + i] = 0.0;
+            D.ch_value[base + i] = 0.0;
+            D.ch_policy[base + i] = i < n ? mine[r] * inv : 0.0;
+            D.action[base + i] = i < n ? (int16_t)L.cand[i] : (int16_t)0;
+        }
     }
     if (lane == 0) {
         const size_t ns = (size_t)t * D.N + node;
@@ -432,6 +515,7 @@ __device__ int expand_node(Lds<S> &L, const BoardScalars &b, int to_move, const 
     }
     num_nodes += 1;
     __syncthreads();
+    lap(10);
     return node;
 }
 
@@ -455,27 +539,67 @@ __device__ void write_planes(const Lds<S> &L, const BoardScalars &b, int to_move
     }
 }
 
-// node.py:141-157 + pucb.py:8-29
+// node.py:141-157 + pucb.py:8-29.  Everything the descent step needs from the node is loaded
+// in ONE round trip (the loads are independent): the three node scalars and, per lane, the
+// child arrays of its (up to ceil(A/64)) slots incl. action and child index; the winner's
+// fields travel with the arg-max.
+struct EdgePick {
+    int edge, move, child, count, edge_vl, node_vl;   // count = visits + virtual loss of the edge
+};
+
 template <int S>
-__device__ int select_puct(const SearchDev &D, int t, int node, int lane) {
+__device__ EdgePick select_puct(const SearchDev &D, int t, int node, int lane) {
     constexpr int A = Geo<S>::A;
+    constexpr int R = (A + 63) / 64;
     const size_t ns = (size_t)t * D.N + node;
     const size_t base = ns * A;
+    int vis[R], vl[R], idx[R], act[R];
+    double vsum[R], pol[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = lane + 64 * r;
+        const int ii = i < A ? i : A - 1;          // the arrays always hold A slots
+        vis[r] = D.ch_visits[base + ii];
+        vl[r] = D.ch_vl[base + ii];
+        vsum[r] = D.ch_vsum[base + ii];
+        pol[r] = D.ch_policy[base + ii];
+        idx[r] = D.ch_index[base + ii];
+        act[r] = D.action[base + ii];
+    }
     const int nc = D.n_children[ns];
-    const int total = D.n_visits[ns] + D.n_vl[ns];
+    const int node_vl = D.n_vl[ns];
+    const int total = D.n_visits[ns] + node_vl;
     const double sq = __dsqrt_rn((double)(total + 1));
     double best = 0.0;
-    int best_i = -1;
-    for (int i = lane; i < nc; i += 64) {
-        const int cnt = D.ch_visits[base + i] + D.ch_vl[base + i];
-        const double q = cnt != 0 ? D.ch_vsum[base + i] / (double)cnt : 0.0;
-        const double u = (D.ch_policy[base + i] * sq) / (double)(cnt + 1);
-        double sc = q + u;
-        if (D.cgos && i == nc - 1) sc -= 0.1;
-        if (best_i < 0 || sc > best) { best = sc; best_i = i; }
+    int best_i = -1, best_r = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = lane + 64 * r;
+        if (i < nc) {
+            const int cnt = vis[r] + vl[r];
+            const double q = cnt != 0 ? vsum[r] / (double)cnt : 0.0;
+            const double u = (pol[r] * sq) / (double)(cnt + 1);
+            double sc = q + u;
+            if (D.cgos && i == nc - 1) sc -= 0.1;
+            if (best_i < 0 || sc > best) { best = sc; best_i = i; best_r = r; }
+        }
     }
+    (void)best_r;
     wave_argmax(best, best_i);
-    return best_i;
+    const int owner = best_i & 63, slot = best_i >> 6;
+    int my_move = 0, my_child = 0, my_cnt = 0, my_vl = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (r == slot) { my_move = act[r]; my_child = idx[r]; my_cnt = vis[r] + vl[r]; my_vl = vl[r]; }
+    EdgePick pick;
+    pick.edge = best_i;
+    const int src = __builtin_amdgcn_readfirstlane(owner);        // wave-uniform after the arg-max
+    pick.move = __builtin_amdgcn_readlane(my_move, src);
+    pick.child = __builtin_amdgcn_readlane(my_child, src);
+    pick.count = __builtin_amdgcn_readlane(my_cnt, src);
+    pick.edge_vl = __builtin_amdgcn_readlane(my_vl, src);
+    pick.node_vl = node_vl;
+    return pick;
 }
 
 template <int S>
@@ -536,6 +660,12 @@ __global__ __launch_bounds__(64) void select_puct_kernel(SearchDev D, int max_le
     load_root<S>(L, rootb, root_to_move, D, t, lane);
     int num_nodes = D.meta[t].num_nodes;
     int queued = 0;
+    const bool prof = D.prof && t == 0;
+    long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tp = prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
+    auto lap = [&](int slot) {
+        if (prof) { const long long now = (long long)__builtin_amdgcn_s_memtime(); pc[slot] += now - tp; tp = now; }
+    };
     if (D.err[t] == 0 && num_nodes > 0) {
         for (int k = 0; k < max_leaves; ++k) {
             reset_work<S>(L, lane);
@@ -543,29 +673,35 @@ __global__ __launch_bounds__(64) void select_puct_kernel(SearchDev D, int max_le
             int c = root_to_move;
             int node = 0;
             bool ok = true;
+            lap(0);
             for (int depth = 0;; ++depth) {
                 const size_t ns = (size_t)t * D.N + node;
                 const size_t base = ns * A;
-                const int e = select_puct<S>(D, t, node, lane);
-                const int mv = D.action[base + e];
+                const EdgePick pick = select_puct<S>(D, t, node, lane);
+                const int e = pick.edge;
+                const int mv = pick.move;
+                lap(1);
                 put_stone<S>(L, b, mv, c, D.zob, lane);
+                lap(2);
+                if (prof) pc[7] += 1;
                 c = 3 - c;
-                const int edge_cnt = D.ch_visits[base + e] + D.ch_vl[base + e] + 1;   // after the VL
-                int child = D.ch_index[base + e];
-                __syncthreads();
+                const int edge_cnt = pick.count + 1;                  // after the virtual loss
+                int child = pick.child;
                 if (lane == 0) {                                      // node.py:76-83
-                    D.n_vl[ns] += 1;
-                    D.ch_vl[base + e] += 1;
+                    D.n_vl[ns] = pick.node_vl + 1;
+                    D.ch_vl[base + e] = pick.edge_vl + 1;
                 }
                 // two consecutive passes: never descend below (tree.py:224-229)
                 const bool two_pass = b.moves > 2 && b.prev == 0 && b.prevprev == 0;
                 const int threshold = two_pass ? 10000000 : 1;
+                lap(3);
                 if (edge_cnt < threshold + 1) {
                     if (child == kNotExpanded) {
                         child = expand_node<S>(L, b, c, D, t, num_nodes, node, e, lane);
                         if (child < 0) { ok = false; break; }
                         if (lane == 0) D.ch_index[base + e] = child;
                     }
+                    lap(4);
                     write_planes<S>(L, b, c, planes + ((size_t)t * max_leaves + k) * 6 * G::P, lane);
                     if (lane == 0) {
                         D.q_node[(size_t)t * D.K + k] = child;
@@ -573,10 +709,12 @@ __global__ __launch_bounds__(64) void select_puct_kernel(SearchDev D, int max_le
                         D.q_pedge[(size_t)t * D.K + k] = e;
                     }
                     __syncthreads();
+                    lap(5);
                     break;
                 }
                 node = child;
                 __syncthreads();
+                lap(3);
             }
             if (!ok) break;
             ++queued;
@@ -585,6 +723,8 @@ __global__ __launch_bounds__(64) void select_puct_kernel(SearchDev D, int max_le
     if (lane == 0) {
         D.meta[t].num_nodes = num_nodes;
         D.n_leaves[t] = queued;
+        if (prof)
+            for (int i = 0; i < 8; ++i) D.prof[i] += pc[i];
     }
 }
 
@@ -628,16 +768,22 @@ __global__ __launch_bounds__(64) void backup_kernel(SearchDev D, const float *po
                 while (cur >= 0) {
                     const size_t cs = (size_t)t * D.N + cur;
                     const size_t ce = cs * A + e;
+                    // all loads of a level first (independent, one round trip), then the stores
+                    const double vs = D.ch_vsum[ce];
+                    const int cv = D.ch_visits[ce], cl = D.ch_vl[ce];
+                    const float ns_ = D.n_vsum[cs];
+                    const int nv = D.n_visits[cs], nl = D.n_vl[cs];
+                    const int pe = D.n_pedge[cs], pn = D.n_parent[cs];
                     // float32 accumulation stored in float64 (see file header)
-                    D.ch_vsum[ce] = (double)((float)D.ch_vsum[ce] + v);
-                    D.ch_visits[ce] += 1;
-                    D.ch_vl[ce] -= 1;
-                    D.n_vsum[cs] += v;
-                    D.n_visits[cs] += 1;
-                    D.n_vl[cs] -= 1;
+                    D.ch_vsum[ce] = (double)((float)vs + v);
+                    D.ch_visits[ce] = cv + 1;
+                    D.ch_vl[ce] = cl - 1;
+                    D.n_vsum[cs] = ns_ + v;
+                    D.n_visits[cs] = nv + 1;
+                    D.n_vl[cs] = nl - 1;
                     v = 1.0f - v;
-                    e = D.n_pedge[cs];
-                    cur = D.n_parent[cs];
+                    e = pe;
+                    cur = pn;
                 }
             }
         }
@@ -1238,6 +1384,21 @@ int tg_search_select_puct(tg_search *s, int max_leaves, float *planes_dev, int32
 }
 
 
+
+int tg_search_profile(tg_search *s, int enable, long long *cycles_host) {
+    if (!s) return tg::fail(TG_ERR_ARG, "tg_search_profile: null argument");
+    if (s->last_stream) TG_HIP(hipStreamSynchronize(s->last_stream));
+    else TG_HIP(hipDeviceSynchronize());
+    if (enable && !s->dev.prof) {
+        int rc = dev_alloc(s, &s->dev.prof, (size_t)16);
+        if (rc) return rc;
+    }
+    if (cycles_host && s->dev.prof)
+        TG_HIP(hipMemcpy(cycles_host, s->dev.prof, 16 * sizeof(long long), hipMemcpyDeviceToHost));
+    if (s->dev.prof) TG_HIP(hipMemset(s->dev.prof, 0, 16 * sizeof(long long)));
+    if (!enable) s->dev.prof = nullptr;       // buffer stays allocated until destroy
+    return TG_OK;
+}
 
 int tg_search_play(tg_search *s, const int32_t *moves_host, void *stream) {
     if (!s || !moves_host) return tg::fail(TG_ERR_ARG, "tg_search_play: null argument");
