@@ -1,5 +1,6 @@
 """Sequential-halving schedule (host integer logic; mirror of the mctx schedule used by
 mcts/sequential_halving.py:7-60)."""
+import functools
 import math
 from typing import Dict, Tuple
 
@@ -24,6 +25,11 @@ def get_sequence_of_considered_visits(max_num_considered_actions: int,
 def get_candidates_and_visit_pairs(max_num_considered_actions: int,
                                    num_simulations: int) -> Dict[int, int]:
     """{number of considered actions: number of levels} in phase order."""
+    return dict(_pairs_cached(max_num_considered_actions, num_simulations))
+
+
+@functools.lru_cache(maxsize=256)
+def _pairs_cached(max_num_considered_actions: int, num_simulations: int):
     seq = get_sequence_of_considered_visits(max_num_considered_actions, num_simulations)
     width_at_level = [0] * (max(seq) + 1)
     for level in seq:
@@ -31,4 +37,4 @@ def get_candidates_and_visit_pairs(max_num_considered_actions: int,
     pairs: Dict[int, int] = {}
     for width in width_at_level:
         pairs[width] = pairs.get(width, 0) + 1
-    return pairs
+    return tuple(pairs.items())
