@@ -74,15 +74,14 @@ __device__ __forceinline__ f32x4 lds_f32x4(const unsigned char *smem, int byte_o
 
 
 // ---- pieces shared by the direct and the Winograd kernels -------------------------------------
-template <int S, int G>
+template <int S, int G, typename C = FwdCfg<S, G>, int NTHR = 256>
 __device__ __forceinline__ void stage_planes(unsigned char *smem, const float *__restrict__ planes, int b0,
                                              int batch, int tid) {
-    using C = FwdCfg<S, G>;
     constexpr int P = C::P, M = C::M;
     // global [b][6][P] -> LDS in8 [row][8]
         {
             float *in8 = reinterpret_cast<float *>(smem + C::AUX);
-            for (int e = tid; e < G * 6 * P; e += 256) {
+            for (int e = tid; e < G * 6 * P; e += NTHR) {
                 const int bl = e / (6 * P);
                 const int rem = e - bl * 6 * P;
                 const int c = rem / P;
@@ -91,15 +90,14 @@ __device__ __forceinline__ void stage_planes(unsigned char *smem, const float *_
                 const float v = (b < batch) ? planes[(size_t)b * 6 * P + rem] : 0.f;
                 in8[(bl * P + p) * 8 + c] = v;
             }
-            for (int e = tid; e < M * 2; e += 256) in8[(e >> 1) * 8 + 6 + (e & 1)] = 0.f;
+            for (int e = tid; e < M * 2; e += NTHR) in8[(e >> 1) * 8 + 6 + (e & 1)] = 0.f;
         }
 }
 
-template <int S, int G>
+template <int S, int G, typename C = FwdCfg<S, G>, int NTHR = 256>
 __device__ __forceinline__ void run_heads(unsigned char *smem, const NetDev &net, int b0, int batch,
                                           int want_logits, float *__restrict__ policy,
                                           float *__restrict__ value, int tid) {
-    using C = FwdCfg<S, G>;
     constexpr int P = C::P, A = C::A, M = C::M;
     const int wave = tid >> 6, lane = tid & 63;
         float *hpol = reinterpret_cast<float *>(smem + C::AUX);   // [G][2P]
@@ -110,7 +108,7 @@ __device__ __forceinline__ void run_heads(unsigned char *smem, const NetDev &net
             const float ps0 = net.head_ss[0], pt0 = net.head_ss[1];
             const float ps1 = net.head_ss[2], pt1 = net.head_ss[3];
             const float vs = net.head_ss[4], vt = net.head_ss[5];
-            for (int r = tid; r < M; r += 256) {
+            for (int r = tid; r < M; r += NTHR) {
                 float d0 = 0.f, d1 = 0.f, d2 = 0.f;
 #pragma unroll
                 for (int k4 = 0; k4 < 16; ++k4) {
@@ -130,7 +128,7 @@ __device__ __forceinline__ void run_heads(unsigned char *smem, const NetDev &net
             }
         }
         __syncthreads();
-        for (int e = tid; e < G * A + G * 3; e += 256) {
+        for (int e = tid; e < G * A + G * 3; e += NTHR) {
             if (e < G * A) {
                 const int bl = e / A, a = e - bl * A;
                 const float *h = hpol + bl * 2 * P;
@@ -156,7 +154,7 @@ __device__ __forceinline__ void run_heads(unsigned char *smem, const NetDev &net
             }
         }
         __syncthreads();
-        for (int bl = wave; bl < G; bl += 4) {
+        for (int bl = wave; bl < G; bl += NTHR / 64) {
             const int b = b0 + bl;
             if (b >= batch) continue;
             float m = -INFINITY;
@@ -366,255 +364,237 @@ __global__ __launch_bounds__(256, (FwdCfg<S, G>::WAVES_PER_SIMD)) void dualnet_f
 
 
 // ======================================================================================
-// Winograd F(2x2,3x3) variant of the residual tower (same fusion, same LDS residency).
+// Winograd F(2x2,3x3) residual tower (same fusion, same LDS residency as the direct kernel).
 //
 // For every 2x2 output tile the 3x3 correlation becomes 16 element-wise products in the
 // transform domain; summed over input channels these are 16 independent GEMMs
-//   M_xi[tile][cout] = sum_cin V_xi[tile][cin] * U_xi[cin][cout],  xi = 0..15,
+//   M_xi[cout][tile] = sum_cin U_xi[cout][cin] * V_xi[cin][tile],  xi = 0..15,
 // with V = B^T d B (input transform, adds only), U = G g G^T (host) and Y = A^T M A (output
 // transform, adds only).  A 9x9 board has 25 tiles (the 10th row/column is discarded), so the
 // MFMA rows per board drop from 81 x 9 taps to 25 x 16 points: 1.8x fewer MFMAs in exact
 // fp32 (the transforms only add; the weights pick up factors 1/2 and 1/4).
 //
-// One workgroup (4 waves, 1 per SIMD, up to 512 VGPRs) owns G boards; wave w owns output
-// channels [16w,16w+16).  Work unit = (row-tile of 16 tiles, 16 input channels): 16
-// ds_read_b128 -> in-register input transform -> 64 MFMAs into 16 accumulators; after the
-// four channel groups the output transform folds them into the 2x2 outputs, which stay in
-// registers (with the residual) until the layer's barrier, exactly like the direct kernel.
-// The loads + transform of unit u+1 are issued while the MFMAs of unit u run.
+// The workgroup keeps TWO activation buffers in LDS (block input X and intermediate H), so
+// neither the layer outputs nor the residual have to live in registers: every row-tile's
+// 2x2 outputs are finished (BN, residual, ReLU) and written to the other buffer as soon as
+// its 16 accumulators are complete, and a layer needs a single barrier.  Lane (li, lg) loads
+// the patch of tile rt*16+li (channels 16s+4lg..+3) and - because the weights are the MFMA A
+// operand - also receives that tile's outputs for channels 16w+4lg..+3.
+// Work unit = (row-tile, 16 input channels): 16 ds_read_b128 -> in-register input transform
+// -> 64 MFMAs into 16 accumulators.
 template <int S, int G>
 struct WinoCfg {
+    static constexpr int P = S * S;
+    static constexpr int A = P + 1;
+    static constexpr int M = G * P;
+    static constexpr int MT = (M + 15) / 16;
     static constexpr int TY = (S + 1) / 2;          // tiles per side (5)
     static constexpr int TPB = TY * TY;             // tiles per board (25)
     static constexpr int NT = G * TPB;
     static constexpr int RT = (NT + 15) / 16;       // row-tiles of 16 Winograd tiles
+    static constexpr int BUF_A = 0;
+    static constexpr int BUF_B = M * kRowBytes;
+    static constexpr int ZROW = 2 * M * kRowBytes;
+    static constexpr int AUX = ZROW + kRowBytes;          // in8 staging / head scratch / Y exchange
+    static constexpr int XCH_BYTES = 4 * 64 * 64;          // 4 waves x 64 lanes x 4 outputs x 16 B
+    static constexpr int AUX_BYTES = (M * 32 > XCH_BYTES) ? M * 32 : XCH_BYTES;
+    static constexpr int ZERO8 = AUX + AUX_BYTES;
+    static constexpr int LDS_BYTES = ZERO8 + 32;
 };
 
+// ---- Winograd tower, 8 waves per workgroup (2 per SIMD) --------------------------------------
+// Same algorithm and LDS layout as dualnet_fwd_wino_kernel, but the workgroup has two waves
+// per output-channel tile: half h = 0 takes row-tiles {0,1,2}, half h = 1 takes {3,4} (75 tiles).
+// Each wave keeps ONE patch buffer and simply alternates "16 loads + transform" with "64
+// MFMAs"; the two waves that share a SIMD fall out of phase, so one transforms while the
+// other feeds the matrix pipe - the overlap hipcc's scheduler does not produce inside a wave.
 template <int S, int G>
-__global__ __launch_bounds__(256, 1) void dualnet_fwd_wino_kernel(
+__global__ __launch_bounds__(512, 2) void dualnet_fwd_wino8_kernel(
     NetDev net, const float *__restrict__ planes, int batch, int want_logits,
     float *__restrict__ policy, float *__restrict__ value) {
-    using C = FwdCfg<S, G>;
-    using Wc = WinoCfg<S, G>;
+    using C = WinoCfg<S, G>;
     constexpr int P = C::P, M = C::M, MT = C::MT;
-    constexpr int TY = Wc::TY, TPB = Wc::TPB, NT = Wc::NT, RT = Wc::RT;
+    constexpr int TY = C::TY, TPB = C::TPB, NT = C::NT, RT = C::RT;
+    constexpr int MTH = (MT + 1) / 2;                 // stem M-tiles per half
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
-    const int wave = tid >> 6;
+    const int wid = tid >> 6;
+    const int wave = wid & 3;                         // output-channel tile
+    const int half = wid >> 2;
     const int lane = tid & 63;
     const int li = lane & 15;
     const int lg = lane >> 4;
 
-    // per-lane A-side constants: tile (rt*16 + li) -> byte address of its 4x4 input patch origin
-    // (row 2ty-1, col 2tx-1; may lie off the board) and the validity of the 16 patch points
-    int base[RT];
-    unsigned vmask[RT];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-        const int t = rt * 16 + li;
-        const int bl = t / TPB;
-        const int tl = t - bl * TPB;
-        const int ty = tl / TY, tx = tl - ty * TY;
-        const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
-        base[rt] = (bl * P + y0 * S + x0) * kRowBytes + lg * 16;
-        unsigned m = 0;
-#pragma unroll
-        for (int pq = 0; pq < 16; ++pq) {
-            const int y = y0 + pq / 4, x = x0 + pq % 4;
-            if (t < NT && y >= 0 && y < S && x >= 0 && x < S) m |= 1u << pq;
-        }
-        vmask[rt] = m;
-    }
     const int lane_zero = C::ZROW + lg * 16;
     const int lane_in8 = C::AUX + li * 32 + lg * 4;
     const int lane_zero8 = C::ZERO8 + lg * 4;
 
-    for (int e = tid; e < kRowFloats; e += 256) reinterpret_cast<float *>(smem + C::ZROW)[e] = 0.f;
+    for (int e = tid; e < kRowFloats; e += 512) reinterpret_cast<float *>(smem + C::ZROW)[e] = 0.f;
     if (tid < 8) reinterpret_cast<float *>(smem + C::ZERO8)[tid] = 0.f;
 
-    float *act = reinterpret_cast<float *>(smem);
     const int n_groups = (batch + G - 1) / G;
     for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
         const int b0 = grp * G;
-        stage_planes<S, G>(smem, planes, b0, batch, tid);
+        stage_planes<S, G, C, 512>(smem, planes, b0, batch, tid);
         __syncthreads();
 
-        // ---- stem: direct 6(8) -> 64 conv, written straight to the activation buffer ------------
+        // ---- stem: direct 6(8) -> 64 conv into buffer A; each half takes MTH M-tiles -------------
         {
-            f32x4 acc[MT];
+            f32x4 acc[MTH];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int m = 0; m < MTH; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
             const float2 *w0 = reinterpret_cast<const float2 *>(net.w0frag) + wave * 9 * 64 + lane;
 #pragma unroll 1
             for (int tap = 0; tap < 9; ++tap) {
                 const float2 bcur = w0[tap * 64];
                 const int toff = ((tap / 3 - 1) * S + (tap % 3 - 1)) * 32;
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
+                for (int m = 0; m < MTH; ++m) {
+                    const int mt = half * MTH + m;
                     const int r = mt * 16 + li;
                     const int pb = r % P;
                     const int yy = pb / S + tap / 3 - 1, xx = pb % S + tap % 3 - 1;
                     const bool ok = r < M && yy >= 0 && yy < S && xx >= 0 && xx < S;
                     const int a = ok ? lane_in8 + mt * 16 * 32 + toff : lane_zero8;
-                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(lds_f32(smem, a), bcur.x, acc[mt], 0, 0, 0);
-                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(lds_f32(smem, a + 16), bcur.y, acc[mt], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur.x, lds_f32(smem, a), acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur.y, lds_f32(smem, a + 16), acc[m], 0, 0, 0);
                 }
             }
-            const float sc = net.scale[wave * 16 + li], sh = net.shift[wave * 16 + li];
+            const f32x4 sc = *reinterpret_cast<const f32x4 *>(net.scale + wave * 16 + lg * 4);
+            const f32x4 sh = *reinterpret_cast<const f32x4 *>(net.shift + wave * 16 + lg * 4);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int m = 0; m < MTH; ++m) {
+                f32x4 v;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int r = mt * 16 + lg * 4 + j;
-                    if (r < M) act[r * kRowFloats + wave * 16 + li] = fmaxf(fmaf(acc[mt][j], sc, sh), 0.f);
-                }
+                for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(acc[m][j], sc[j], sh[j]), 0.f);
+                const int r = (half * MTH + m) * 16 + li;
+                if (r < M) *reinterpret_cast<f32x4 *>(smem + C::BUF_A + r * kRowBytes + wave * 64 + lg * 16) = v;
+            }
         }
         __syncthreads();
 
-        // output-side mapping (C/D layout): register j of row-tile rt <-> tile rt*16 + 4*lg + j,
-        // column li.  Outputs o = 2*oy + ox at board position (2ty+oy, 2tx+ox).
-        f32x4 yv[RT][4];       // this layer's outputs
-        f32x4 res[RT][4];      // residual-block input (same mapping)
-        auto out_pos = [&](int rt, int j, int o) -> int {   // flat activation row or -1
-            const int t = rt * 16 + lg * 4 + j;
-            const int bl = t / TPB;
-            const int tl = t - bl * TPB;
-            const int ty = tl / TY, tx = tl - ty * TY;
-            const int y = 2 * ty + (o >> 1), x = 2 * tx + (o & 1);
-            return (t < NT && y < S && x < S) ? bl * P + y * S + x : -1;
-        };
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int o = 0; o < 4; ++o)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int r = out_pos(rt, j, o);
-                    res[rt][o][j] = r >= 0 ? act[r * kRowFloats + wave * 16 + li] : 0.f;
-                }
-
-        // ---- residual tower ---------------------------------------------------------------------
 #pragma unroll 1
         for (int layer = 1; layer < kConvLayers; ++layer) {
+            const bool conv2 = (layer & 1) == 0;
+            const int in_off = conv2 ? C::BUF_B : C::BUF_A;
+            const int out_off = conv2 ? C::BUF_A : C::BUF_B;
             const f32x4 *wl = reinterpret_cast<const f32x4 *>(net.wwino) +
                               ((size_t)((layer - 1) * 4 + wave) * 16) * 4 * 64 + lane;
-            // unit (rt, s): 4x4 patch (16 x float4 = 4 channels each) -> in-register transform ->
-            // 64 MFMAs.  Two patch buffers ping-pong (no copies): while the MFMAs of one unit
-            // issue, the other buffer is loaded and transformed for the next unit.
-            f32x4 va[16], vb[16];
-            int a16[16];                                   // patch point addresses of the row-tile being LOADED
-            auto set_addr = [&](int rt_base, unsigned rt_mask) {
+            const f32x4 sc = *reinterpret_cast<const f32x4 *>(net.scale + layer * 64 + wave * 16 + lg * 4);
+            const f32x4 sh = *reinterpret_cast<const f32x4 *>(net.shift + layer * 64 + wave * 16 + lg * 4);
+            // Row-tile split between the two halves.  With an odd number of row-tiles the last one
+            // is SHARED: each half accumulates two of its four channel groups, the (linear) output
+            // transform is applied to both partial sums, half 1 hands its 2x2 outputs over through
+            // LDS and half 0 adds them and runs the epilogue - 2.5 : 2.5 instead of 3 : 2.
+            constexpr bool SHARE = false;   // (RT % 2 == 1) && RT > 1: measured slower (34.3 vs 30.7 ms / 65k positions)
+            constexpr int RTF = SHARE ? RT - 1 : RT;          // row-tiles that are not shared
+            const int rt_begin = half == 0 ? 0 : (RTF + 1) / 2;
+            const int rt_end = half == 0 ? (RTF + 1) / 2 : RTF;
+            const int n_own = rt_end - rt_begin;
+            const int n_iter = n_own + (SHARE ? 1 : 0);
+#pragma unroll 1
+            for (int it = 0; it < n_iter; ++it) {
+                const bool shared = SHARE && it == n_own;
+                const int rt = shared ? RT - 1 : rt_begin + it;
+                const int s_begin = shared ? 2 * half : 0;
+                const int s_end = shared ? 2 * half + 2 : 4;
+                const int t = rt * 16 + li;
+                const int bl = t / TPB;
+                const int tl = t - bl * TPB;
+                const int ty = tl / TY, tx = tl - ty * TY;
+                const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
+                const int base = in_off + (bl * P + y0 * S + x0) * kRowBytes + lg * 16;
+                int a16[16];
 #pragma unroll
                 for (int pq = 0; pq < 16; ++pq) {
-                    const bool ok = (rt_mask >> pq) & 1u;
-                    a16[pq] = ok ? rt_base + ((pq / 4) * S + (pq % 4)) * kRowBytes : lane_zero;
+                    const int y = y0 + pq / 4, x = x0 + pq % 4;
+                    const bool ok = t < NT && y >= 0 && y < S && x >= 0 && x < S;
+                    a16[pq] = ok ? base + ((pq / 4) * S + (pq % 4)) * kRowBytes : lane_zero;
                 }
-            };
-            auto load_patch = [&](f32x4 (&d)[16], int soff) {
-#pragma unroll
-                for (int pq = 0; pq < 16; ++pq) d[pq] = lds_f32x4(smem, a16[pq] + soff);
-            };
-            auto transform = [&](f32x4 (&d)[16]) {      // in place: d -> V = B^T d B
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {            // columns: t[a][q]
-                    const f32x4 d0 = d[q], d1 = d[4 + q], d2 = d[8 + q], d3 = d[12 + q];
-                    d[q] = d0 - d2;
-                    d[4 + q] = d1 + d2;
-                    d[8 + q] = d2 - d1;
-                    d[12 + q] = d1 - d3;
-                }
-#pragma unroll
-                for (int a = 0; a < 4; ++a) {            // rows: V[a][b]
-                    const f32x4 t0 = d[4 * a], t1 = d[4 * a + 1], t2 = d[4 * a + 2], t3 = d[4 * a + 3];
-                    d[4 * a] = t0 - t2;
-                    d[4 * a + 1] = t1 + t2;
-                    d[4 * a + 2] = t2 - t1;
-                    d[4 * a + 3] = t1 - t3;
-                }
-            };
-            f32x4 bq[2];
-            bq[0] = wl[0];
-            bq[1] = wl[4 * 64];
-            // MFMAs of unit (cur, channel group s) + loads/transform of the next unit into nxt
-            auto unit = [&](f32x4 (&cur)[16], f32x4 (&nxt)[16], f32x4 (&macc)[16], int s, int next_soff) {
-                load_patch(nxt, next_soff);
-#pragma unroll
-                for (int xp = 0; xp < 16; xp += 2) {
-                    const f32x4 b0v = bq[0], b1v = bq[1];
-                    const int nx = xp + 2 < 16 ? xp + 2 : 0;          // next B pair (wraps to next unit)
-                    const int ns = xp + 2 < 16 ? s : (s + 1) & 3;
-                    bq[0] = wl[(nx * 4 + ns) * 64];
-                    bq[1] = wl[((nx + 1) * 4 + ns) * 64];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        macc[xp] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[xp][j], b0v[j], macc[xp], 0, 0, 0);
-                        macc[xp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[xp + 1][j], b1v[j], macc[xp + 1], 0, 0, 0);
-                    }
-                }
-                transform(nxt);
-                // issue order: loads first (one per MFMA), then the transform's VALU spread under
-                // the remaining MFMAs (each MFMA occupies the matrix pipe for 32 cycles)
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                }
-#pragma unroll
-                for (int k = 0; k < 48; ++k) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            };
-            set_addr(base[0], vmask[0]);
-            load_patch(va, 0);
-            transform(va);
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
                 f32x4 macc[16];
 #pragma unroll
                 for (int xi = 0; xi < 16; ++xi) macc[xi] = f32x4{0.f, 0.f, 0.f, 0.f};
-                unit(va, vb, macc, 0, 64);
-                unit(vb, va, macc, 1, 128);
-                unit(va, vb, macc, 2, 192);
-                if (rt + 1 < RT) set_addr(base[rt + 1], vmask[rt + 1]);
-                unit(vb, va, macc, 3, 0);
-                // output transform Y = A^T M A
+                f32x4 bq[2];
+                bq[0] = wl[s_begin * 64];
+                bq[1] = wl[(4 + s_begin) * 64];
+#pragma unroll 1
+                for (int s = s_begin; s < s_end; ++s) {
+                    f32x4 d[16];
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
+                    for (int pq = 0; pq < 16; ++pq) d[pq] = lds_f32x4(smem, a16[pq] + s * 64);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {            // V = B^T d B, columns then rows
+                        const f32x4 d0 = d[q], d1 = d[4 + q], d2 = d[8 + q], d3 = d[12 + q];
+                        d[q] = d0 - d2;
+                        d[4 + q] = d1 + d2;
+                        d[8 + q] = d2 - d1;
+                        d[12 + q] = d1 - d3;
+                    }
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const f32x4 t0 = d[4 * a], t1 = d[4 * a + 1], t2 = d[4 * a + 2], t3 = d[4 * a + 3];
+                        d[4 * a] = t0 - t2;
+                        d[4 * a + 1] = t1 + t2;
+                        d[4 * a + 2] = t2 - t1;
+                        d[4 * a + 3] = t1 - t3;
+                    }
+#pragma unroll
+                    for (int xp = 0; xp < 16; xp += 2) {
+                        const f32x4 b0v = bq[0], b1v = bq[1];
+                        const int nx = xp + 2 < 16 ? xp + 2 : 0;              // next B pair
+                        const int ns = xp + 2 < 16 ? s : (s + 1 < s_end ? s + 1 : s);
+                        bq[0] = wl[(nx * 4 + ns) * 64];
+                        bq[1] = wl[((nx + 1) * 4 + ns) * 64];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            macc[xp] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0v[j], d[xp][j], macc[xp], 0, 0, 0);
+                            macc[xp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1v[j], d[xp + 1][j], macc[xp + 1], 0, 0, 0);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {                // Y = A^T M A
                     const f32x4 m0 = macc[b] + macc[4 + b] + macc[8 + b];
                     const f32x4 m1 = macc[4 + b] - macc[8 + b] - macc[12 + b];
                     macc[b] = m0;
                     macc[4 + b] = m1;
                 }
-                yv[rt][0] = macc[0] + macc[1] + macc[2];
-                yv[rt][1] = macc[1] - macc[2] - macc[3];
-                yv[rt][2] = macc[4] + macc[5] + macc[6];
-                yv[rt][3] = macc[5] - macc[6] - macc[7];
-            }
-            // every wave must be done reading before anyone overwrites the buffer
-            __syncthreads();
-            const float sc = net.scale[layer * 64 + wave * 16 + li];
-            const float sh = net.shift[layer * 64 + wave * 16 + li];
-            const bool block_out = (layer & 1) == 0;
+                f32x4 yv[4];
+                yv[0] = macc[0] + macc[1] + macc[2];
+                yv[1] = macc[1] - macc[2] - macc[3];
+                yv[2] = macc[4] + macc[5] + macc[6];
+                yv[3] = macc[5] - macc[6] - macc[7];
+                if (shared) {
+                    // exchange area: the in8 staging region (free between stem and heads), 4 KB per wave
+                    f32x4 *xch = reinterpret_cast<f32x4 *>(smem + C::AUX) + (wave * 64 + lane) * 4;
+                    if (half == 1) {
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                for (int o = 0; o < 4; ++o)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float v = fmaf(yv[rt][o][j], sc, sh);
-                        if (block_out) v += res[rt][o][j];
-                        v = fmaxf(v, 0.f);
-                        if (block_out) res[rt][o][j] = v;
-                        const int r = out_pos(rt, j, o);
-                        if (r >= 0) act[r * kRowFloats + wave * 16 + li] = v;
+                        for (int o = 0; o < 4; ++o) xch[o] = yv[o];
                     }
+                    __syncthreads();
+                    if (half == 1) continue;
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) yv[o] += xch[o];
+                }
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    const int y = 2 * ty + (o >> 1), x = 2 * tx + (o & 1);
+                    if (t < NT && y < S && x < S) {
+                        unsigned char *dst = smem + out_off + (bl * P + y * S + x) * kRowBytes + wave * 64 + lg * 16;
+                        f32x4 v;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = fmaf(yv[o][j], sc[j], sh[j]);
+                        if (conv2) v += *reinterpret_cast<const f32x4 *>(dst);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                        *reinterpret_cast<f32x4 *>(dst) = v;
+                    }
+                }
+            }
             __syncthreads();
         }
-        run_heads<S, G>(smem, net, b0, batch, want_logits, policy, value, tid);
+        run_heads<S, G, C, 512>(smem, net, b0, batch, want_logits, policy, value, tid);
         __syncthreads();
     }
 }
@@ -691,10 +671,10 @@ int launch(tg_net *net, const float *planes, int batch, int want_logits, float *
 }
 
 template <int S, int G>
-int launch_wino(tg_net *net, const float *planes, int batch, int want_logits, float *policy,
-                float *value, hipStream_t stream) {
-    using C = FwdCfg<S, G>;
-    auto kern = dualnet_fwd_wino_kernel<S, G>;
+int launch_wino8(tg_net *net, const float *planes, int batch, int want_logits, float *policy,
+                 float *value, hipStream_t stream) {
+    using C = WinoCfg<S, G>;
+    auto kern = dualnet_fwd_wino8_kernel<S, G>;
     static bool attr_set[16] = {};
     if (!attr_set[net->device & 15]) {
         TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -702,8 +682,8 @@ int launch_wino(tg_net *net, const float *planes, int batch, int want_logits, fl
         attr_set[net->device & 15] = true;
     }
     const int groups = (batch + G - 1) / G;
-    const int grid = groups < net->num_cus ? groups : net->num_cus;     // one workgroup per CU
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), C::LDS_BYTES, stream, net->dev, planes, batch,
+    const int grid = groups < net->num_cus ? groups : net->num_cus;     // one 8-wave workgroup per CU
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), C::LDS_BYTES, stream, net->dev, planes, batch,
                        want_logits, policy, value);
     TG_HIP(hipGetLastError());
     return TG_OK;
@@ -872,18 +852,36 @@ static int pick_group(int board_size, int batch, int num_cus) {
     return batch > 2 * num_cus ? 3 : 1;   // (6 is slower: 1 wave/SIMD, no cross-workgroup overlap)
 }
 
+static int pick_wino(int board_size, int batch, int num_cus);
+
 const char *tg_net_kernel_name(const tg_net *net, int batch) {
     if (!net) return "";
     if (net->board_size == 19) return "dualnet_fwd_kernel<19, 1>";
+    {
+        const int wg = pick_wino(9, batch, net->num_cus);
+        if (wg == 1) return "dualnet_fwd_wino8_kernel<9, 1>";
+        if (wg == 2) return "dualnet_fwd_wino8_kernel<9, 2>";
+        if (wg == 3) return "dualnet_fwd_wino8_kernel<9, 3>";
+    }
     const int g = pick_group(9, batch, net->num_cus);
     return g == 6 ? "dualnet_fwd_kernel<9, 6>" : (g == 3 ? "dualnet_fwd_kernel<9, 3>" : "dualnet_fwd_kernel<9, 1>");
 }
 
+// Winograd tower: boards per workgroup (1, 2 or 3), or 0 = direct convolution kernel.
+// Measured on MI355X (tools/bench_net.py): B <= 256: 173 us (direct 194); B = 512: 308 (347);
+// B >= 768: 98 % vs 83 % of the fp32 MFMA peak in algorithmic FLOPs.
 static int pick_wino(int board_size, int batch, int num_cus) {
-    // Winograd tower: G boards per workgroup, one workgroup per CU; 0 = direct convolution
-    if (board_size != 9) return 0;
-    if (const char *env = getenv("TG_FWD_WINO")) return atoi(env);
-    return 0;
+    if (board_size != 9) return 0;                    // 19x19: two 104 KB buffers do not fit in LDS
+    if (const char *env = getenv("TG_FWD_ALGO")) {
+        if (!strcmp(env, "direct")) return 0;
+    }
+    if (const char *env = getenv("TG_FWD_WINO")) {
+        const int g = atoi(env) % 10;                 // 81 / 82 / 83 (or 1 / 2 / 3)
+        if (g >= 1 && g <= 3) return g;
+    }
+    if (batch <= num_cus) return 1;
+    if (batch <= 2 * num_cus) return 2;
+    return 3;
 }
 
 int tg_net_forward_dev(tg_net *net, const float *planes_dev, int batch, int want_logits,
@@ -897,9 +895,9 @@ int tg_net_forward_dev(tg_net *net, const float *planes_dev, int batch, int want
         return launch<19, 1>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st);
     if (net->board_size == 9) {
         const int wg = pick_wino(9, batch, net->num_cus);
-        if (wg == 4) return launch_wino<9, 4>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st);
-        if (wg == 5) return launch_wino<9, 5>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st);
-        if (wg == 3) return launch_wino<9, 3>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st);
+        if (wg == 1) return launch_wino8<9, 1>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st);
+        if (wg == 2) return launch_wino8<9, 2>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st);
+        if (wg == 3) return launch_wino8<9, 3>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st);
     }
     const int g = pick_group(9, batch, net->num_cus);
     if (g == 6) return launch<9, 6>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st);

@@ -116,19 +116,21 @@ def test_featurize_kernel_vs_reference_golden(size):
     assert np.array_equal(out.cpu().numpy(), np.array(want))
 
 
-def test_experimental_winograd_tower_parity(monkeypatch):
-    """TG_FWD_WINO selects the experimental Winograd F(2x2,3x3) variant of the residual tower
-    (exact fp32, transforms only add).  Not the default - see DESIGN.md - but it must agree
-    with the oracle like the direct kernel."""
+@pytest.mark.parametrize("algo", ["direct", "winograd"])
+def test_both_tower_algorithms_match_the_oracle(algo, monkeypatch):
+    """9x9 has two implementations of the residual tower: the Winograd F(2x2,3x3) kernel
+    (default) and the direct implicit-GEMM kernel (TG_FWD_ALGO=direct; also the 19x19 path).
+    Both are exact fp32 and must agree with the oracle at every workgroup shape."""
     from oracle.net import OracleNet, make_state_dict
+    if algo == "direct":
+        monkeypatch.setenv("TG_FWD_ALGO", "direct")
     sd = make_state_dict(9, 7, 1.5)
     net = _net(9, sd)
     ora = OracleNet(sd)
     rs = np.random.RandomState(11)
-    x = torch.from_numpy(rs.randint(-1, 2, size=(1301, 6, 9, 9)).astype(np.float32))
-    rp, rv = ora.inference(x)
-    for variant in ("3", "4"):
-        monkeypatch.setenv("TG_FWD_WINO", variant)
+    for b in (1, 5, 256, 300, 512, 1301):          # G = 1 / 2 / 3 boards per workgroup, ragged tails
+        x = torch.from_numpy(rs.randint(-1, 2, size=(b, 6, 9, 9)).astype(np.float32))
+        rp, rv = ora.inference(x)
         pol, val = net.inference(x)
-        assert np.abs(pol.numpy() - rp.numpy()).max() < TOL
-        assert np.abs(val.numpy() - rv.numpy()).max() < TOL
+        assert np.abs(pol.numpy() - rp.numpy()).max() < TOL, (algo, b)
+        assert np.abs(val.numpy() - rv.numpy()).max() < TOL, (algo, b)

@@ -10,7 +10,7 @@ rs = np.random.RandomState(1)
 x = torch.from_numpy(rs.randint(-1, 2, size=(37, 6, 9, 9)).astype(np.float32))
 rp, rv = ora.inference(x)
 rl, _ = ora.inference_with_policy_logits(x)
-for w in ("0", "3", "4", "5"):
+for w in ("0", "81", "82", "83"):
     os.environ["TG_FWD_WINO"] = w
     p, v = net.inference(x)
     l, _ = net.inference_with_policy_logits(x)
