@@ -31,7 +31,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix
-PMC_SUMMARY = os.path.join(REPO, "profiles", "r01_pmc_forward_9x9_b65536.json")
+PMC_SUMMARY = os.path.join(REPO, "profiles", "r01_pmc_forward_wino_9x9_b65536.json")
 
 
 def pmc_traffic(size, positions):
@@ -266,6 +266,11 @@ def main():
             "roofline": {
                 "bound": "mfma",
                 "kernel": lib.tg_net_kernel_name(net.handle, full_b).decode(),
+                "note": "achieved = ALGORITHMIC FLOPs (direct 3x3 conv count, SURVEY 3.4: "
+                        "72.28 MFLOP/position at 9x9) / launch time.  The 9x9 kernel evaluates the "
+                        "residual tower with Winograd F(2x2,3x3) in exact fp32, which issues 1.8x "
+                        "fewer MFMAs than the direct form, so frac can approach / exceed the "
+                        "direct-conv MFMA bound; mfma_busy_frac_pmc is the matrix-pipe occupancy.",
                 "achieved": achieved,
                 "peak": FP32_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",

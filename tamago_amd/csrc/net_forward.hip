@@ -34,6 +34,10 @@ constexpr int kBlocks = 6;
 constexpr int kConvLayers = 1 + 2 * kBlocks;  // 13
 constexpr int kRowFloats = 72;                // activation row stride in LDS (64 + 8 pad)
 constexpr int kRowBytes = kRowFloats * 4;     // 288
+// Winograd kernel: lanes of a fragment read patches of CONSECUTIVE TILES (2 positions apart);
+// a row stride of 68 floats spreads 8 consecutive tiles over all 64 banks (72 would give 4)
+constexpr int kWinoRowFloats = 68;
+constexpr int kWinoRowBytes = kWinoRowFloats * 4;   // 272
 
 struct NetDev {
     const float *w0frag;  // [4 wave][9 tap][64 lane][2]         stem 6->64 (cin padded to 8)
@@ -57,6 +61,7 @@ struct FwdCfg {
     static constexpr int A = P + 1;
     static constexpr int M = G * P;
     static constexpr int MT = (M + 15) / 16;
+    static constexpr int ROW_BYTES = kRowBytes;
     static constexpr int ACT_BYTES = M * kRowBytes;
     static constexpr int ZROW = ACT_BYTES;               // 288 B zero row
     static constexpr int AUX = ACT_BYTES + kRowBytes;    // in8 [M][8] + zero8, later head scratch
@@ -112,7 +117,7 @@ __device__ __forceinline__ void run_heads(unsigned char *smem, const NetDev &net
                 float d0 = 0.f, d1 = 0.f, d2 = 0.f;
 #pragma unroll
                 for (int k4 = 0; k4 < 16; ++k4) {
-                    const f32x4 xv = lds_f32x4(smem, r * kRowBytes + k4 * 16);
+                    const f32x4 xv = lds_f32x4(smem, r * C::ROW_BYTES + k4 * 16);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int k = k4 * 4 + j;
@@ -392,10 +397,11 @@ struct WinoCfg {
     static constexpr int TPB = TY * TY;             // tiles per board (25)
     static constexpr int NT = G * TPB;
     static constexpr int RT = (NT + 15) / 16;       // row-tiles of 16 Winograd tiles
+    static constexpr int ROW_BYTES = kWinoRowBytes;
     static constexpr int BUF_A = 0;
-    static constexpr int BUF_B = M * kRowBytes;
-    static constexpr int ZROW = 2 * M * kRowBytes;
-    static constexpr int AUX = ZROW + kRowBytes;          // in8 staging / head scratch / Y exchange
+    static constexpr int BUF_B = M * kWinoRowBytes;
+    static constexpr int ZROW = 2 * M * kWinoRowBytes;
+    static constexpr int AUX = ZROW + kWinoRowBytes;          // in8 staging / head scratch / Y exchange
     static constexpr int XCH_BYTES = 4 * 64 * 64;          // 4 waves x 64 lanes x 4 outputs x 16 B
     static constexpr int AUX_BYTES = (M * 32 > XCH_BYTES) ? M * 32 : XCH_BYTES;
     static constexpr int ZERO8 = AUX + AUX_BYTES;
@@ -430,7 +436,7 @@ __global__ __launch_bounds__(512, 2) void dualnet_fwd_wino8_kernel(
     const int lane_in8 = C::AUX + li * 32 + lg * 4;
     const int lane_zero8 = C::ZERO8 + lg * 4;
 
-    for (int e = tid; e < kRowFloats; e += 512) reinterpret_cast<float *>(smem + C::ZROW)[e] = 0.f;
+    for (int e = tid; e < kWinoRowFloats; e += 512) reinterpret_cast<float *>(smem + C::ZROW)[e] = 0.f;
     if (tid < 8) reinterpret_cast<float *>(smem + C::ZERO8)[tid] = 0.f;
 
     const int n_groups = (batch + G - 1) / G;
@@ -469,7 +475,7 @@ __global__ __launch_bounds__(512, 2) void dualnet_fwd_wino8_kernel(
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(acc[m][j], sc[j], sh[j]), 0.f);
                 const int r = (half * MTH + m) * 16 + li;
-                if (r < M) *reinterpret_cast<f32x4 *>(smem + C::BUF_A + r * kRowBytes + wave * 64 + lg * 16) = v;
+                if (r < M) *reinterpret_cast<f32x4 *>(smem + C::BUF_A + r * kWinoRowBytes + wave * 64 + lg * 16) = v;
             }
         }
         __syncthreads();
@@ -504,13 +510,13 @@ __global__ __launch_bounds__(512, 2) void dualnet_fwd_wino8_kernel(
                 const int tl = t - bl * TPB;
                 const int ty = tl / TY, tx = tl - ty * TY;
                 const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
-                const int base = in_off + (bl * P + y0 * S + x0) * kRowBytes + lg * 16;
+                const int base = in_off + (bl * P + y0 * S + x0) * kWinoRowBytes + lg * 16;
                 int a16[16];
 #pragma unroll
                 for (int pq = 0; pq < 16; ++pq) {
                     const int y = y0 + pq / 4, x = x0 + pq % 4;
                     const bool ok = t < NT && y >= 0 && y < S && x >= 0 && x < S;
-                    a16[pq] = ok ? base + ((pq / 4) * S + (pq % 4)) * kRowBytes : lane_zero;
+                    a16[pq] = ok ? base + ((pq / 4) * S + (pq % 4)) * kWinoRowBytes : lane_zero;
                 }
                 f32x4 macc[16];
 #pragma unroll
@@ -581,7 +587,7 @@ __global__ __launch_bounds__(512, 2) void dualnet_fwd_wino8_kernel(
                 for (int o = 0; o < 4; ++o) {
                     const int y = 2 * ty + (o >> 1), x = 2 * tx + (o & 1);
                     if (t < NT && y < S && x < S) {
-                        unsigned char *dst = smem + out_off + (bl * P + y * S + x) * kRowBytes + wave * 64 + lg * 16;
+                        unsigned char *dst = smem + out_off + (bl * P + y * S + x) * kWinoRowBytes + wave * 64 + lg * 16;
                         f32x4 v;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] = fmaf(yv[o][j], sc[j], sh[j]);
