@@ -92,7 +92,8 @@ __device__ __forceinline__ void stage_planes(unsigned char *smem, const float *_
                 const int c = rem / P;
                 const int p = rem - c * P;
                 const int b = b0 + bl;
-                const float v = (b < batch) ? planes[(size_t)b * 6 * P + rem] : 0.f;
+                // streamed once: non-temporal, so the planes do not evict the L2-resident weights
+                const float v = (b < batch) ? __builtin_nontemporal_load(&planes[(size_t)b * 6 * P + rem]) : 0.f;
                 in8[(bl * P + p) * 8 + c] = v;
             }
             for (int e = tid; e < M * 2; e += NTHR) in8[(e >> 1) * 8 + 6 + (e & 1)] = 0.f;
@@ -173,7 +174,7 @@ __device__ __forceinline__ void run_heads(unsigned char *smem, const NetDev &net
             const float inv = 1.f / sum;
             for (int a = lane; a < A; a += 64) {
                 const float lg_ = plog[bl * A + a];
-                policy[(size_t)b * A + a] = want_logits ? lg_ : expf(lg_ - m) * inv;
+                __builtin_nontemporal_store(want_logits ? lg_ : expf(lg_ - m) * inv, &policy[(size_t)b * A + a]);
             }
             if (lane < 3) {
                 const float v0 = vlog[bl * 4], v1 = vlog[bl * 4 + 1], v2 = vlog[bl * 4 + 2];
