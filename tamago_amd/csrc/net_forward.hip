@@ -850,9 +850,9 @@ int tg_net_destroy(tg_net *net) {
 
 static int pick_group(int board_size, int batch, int num_cus) {
     if (board_size != 9) return 1;
-    if (const char *env = getenv("TG_FWD_GROUP")) {        // tuning knob: 1, 3 or 6
+    if (const char *env = getenv("TG_FWD_GROUP")) {        // tuning knob: 1 or 3
         const int g = atoi(env);
-        if (g == 1 || g == 3 || g == 6) return g;
+        if (g == 1 || g == 3) return g;
     }
     // small batches: one board per workgroup fills more CUs; large batches: 3 boards per
     // workgroup (243 of 256 MFMA rows used instead of 81 of 96), two workgroups per CU
@@ -871,7 +871,7 @@ const char *tg_net_kernel_name(const tg_net *net, int batch) {
         if (wg == 3) return "dualnet_fwd_wino8_kernel<9, 3>";
     }
     const int g = pick_group(9, batch, net->num_cus);
-    return g == 6 ? "dualnet_fwd_kernel<9, 6>" : (g == 3 ? "dualnet_fwd_kernel<9, 3>" : "dualnet_fwd_kernel<9, 1>");
+    return g == 3 ? "dualnet_fwd_kernel<9, 3>" : "dualnet_fwd_kernel<9, 1>";
 }
 
 // Winograd tower: boards per workgroup (1, 2 or 3), or 0 = direct convolution kernel.
@@ -907,7 +907,6 @@ int tg_net_forward_dev(tg_net *net, const float *planes_dev, int batch, int want
         if (wg == 3) return launch_wino8<9, 3>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st);
     }
     const int g = pick_group(9, batch, net->num_cus);
-    if (g == 6) return launch<9, 6>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st);
     if (g == 3) return launch<9, 3>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st);
     return launch<9, 1>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st);
 }
