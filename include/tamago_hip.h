@@ -90,6 +90,13 @@ int tg_featurize_dev(int board_size, const uint8_t *cells_dev, const int8_t *to_
                      const int32_t *prev_move_dev, const int32_t *moves_dev, int batch,
                      float *planes_dev, void *stream);
 
+/* Same with a board symmetry per position (sym_dev int8 [B], 0..7 as in go_board.py:80-104;
+ * NULL = identity): the training-side call generate_input_planes(board, color, sym) of
+ * nn/data_generator.py:108,125. */
+int tg_featurize_sym_dev(int board_size, const uint8_t *cells_dev, const int8_t *to_move_dev,
+                         const int32_t *prev_move_dev, const int32_t *moves_dev,
+                         const int8_t *sym_dev, int batch, float *planes_dev, void *stream);
+
 /* ---- batched tree search (mcts/tree.py, mcts/node.py, mcts/pucb/pucb.py,
  *      mcts/batch_data.py, board/ as called from the search) --------------------------- */
 typedef struct tg_search tg_search;

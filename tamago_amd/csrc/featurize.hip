@@ -13,6 +13,7 @@ __global__ __launch_bounds__(256) void featurize_kernel(const uint8_t *__restric
                                                         const int8_t *__restrict__ to_move,
                                                         const int32_t *__restrict__ prev_move,
                                                         const int32_t *__restrict__ moves,
+                                                        const int8_t *__restrict__ sym,
                                                         int batch, float *__restrict__ planes) {
     constexpr int P = S * S;
     constexpr int W = S + 2;
@@ -29,15 +30,30 @@ __global__ __launch_bounds__(256) void featurize_kernel(const uint8_t *__restric
         if (py >= 0 && py < S && px >= 0 && px < S) prev_idx = py * S + px;
     }
     const float side = color == 2 ? -1.f : 1.f;              // feature.py:50-52
+    const int sy_ = sym ? sym[b] : 0;                        // board symmetry 0..7 (go_board.py:80-104)
     const uint8_t *src = cells + (size_t)b * P;
     float *dst = planes + (size_t)b * 6 * P;
     for (int p = lane; p < P; p += 64) {
-        int c = src[p];
+        // output point p = (y, x) reads the cell the symmetry maps it to
+        const int y = p / S, x = p - y * S, n = S - 1;
+        int ry = y, rx = x;
+        switch (sy_) {
+            case 1: rx = n - x; break;
+            case 2: ry = n - y; break;
+            case 3: ry = n - y; rx = n - x; break;
+            case 4: ry = x; rx = y; break;
+            case 5: ry = n - x; rx = y; break;
+            case 6: ry = x; rx = n - y; break;
+            case 7: ry = n - x; rx = n - y; break;
+            default: break;
+        }
+        const int sp = ry * S + rx;
+        int c = src[sp];
         if (color == 2 && c != 0) c = 3 - c;                 // feature.py:24-25
         dst[p] = c == 0 ? 1.f : 0.f;
         dst[P + p] = c == 1 ? 1.f : 0.f;
         dst[2 * P + p] = c == 2 ? 1.f : 0.f;
-        dst[3 * P + p] = p == prev_idx ? 1.f : 0.f;
+        dst[3 * P + p] = sp == prev_idx ? 1.f : 0.f;
         dst[4 * P + p] = pass_plane ? 1.f : 0.f;
         dst[5 * P + p] = side;
     }
@@ -45,9 +61,20 @@ __global__ __launch_bounds__(256) void featurize_kernel(const uint8_t *__restric
 
 }  // namespace
 
+extern "C" int tg_featurize_sym_dev(int board_size, const uint8_t *cells_dev, const int8_t *to_move_dev,
+                                    const int32_t *prev_move_dev, const int32_t *moves_dev,
+                                    const int8_t *sym_dev, int batch, float *planes_dev, void *stream);
+
 extern "C" int tg_featurize_dev(int board_size, const uint8_t *cells_dev, const int8_t *to_move_dev,
                                 const int32_t *prev_move_dev, const int32_t *moves_dev, int batch,
                                 float *planes_dev, void *stream) {
+    return tg_featurize_sym_dev(board_size, cells_dev, to_move_dev, prev_move_dev, moves_dev, nullptr, batch,
+                                planes_dev, stream);
+}
+
+extern "C" int tg_featurize_sym_dev(int board_size, const uint8_t *cells_dev, const int8_t *to_move_dev,
+                                    const int32_t *prev_move_dev, const int32_t *moves_dev,
+                                    const int8_t *sym_dev, int batch, float *planes_dev, void *stream) {
     if (!cells_dev || !to_move_dev || !prev_move_dev || !moves_dev || !planes_dev)
         return tg::fail(TG_ERR_ARG, "tg_featurize_dev: null argument");
     if (batch <= 0) return batch == 0 ? TG_OK : tg::fail(TG_ERR_ARG, "tg_featurize_dev: negative batch");
@@ -55,10 +82,10 @@ extern "C" int tg_featurize_dev(int board_size, const uint8_t *cells_dev, const 
     const dim3 grid((batch + 3) / 4), block(256);
     if (board_size == 9)
         hipLaunchKernelGGL(featurize_kernel<9>, grid, block, 0, st, cells_dev, to_move_dev,
-                           prev_move_dev, moves_dev, batch, planes_dev);
+                           prev_move_dev, moves_dev, sym_dev, batch, planes_dev);
     else if (board_size == 19)
         hipLaunchKernelGGL(featurize_kernel<19>, grid, block, 0, st, cells_dev, to_move_dev,
-                           prev_move_dev, moves_dev, batch, planes_dev);
+                           prev_move_dev, moves_dev, sym_dev, batch, planes_dev);
     else
         return tg::fail(TG_ERR_ARG, "tg_featurize_dev: board size %d not built", board_size);
     TG_HIP(hipGetLastError());

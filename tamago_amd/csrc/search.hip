@@ -65,13 +65,12 @@ struct SearchDev {
     int64_t *rng_cursor;        // [T]
     int64_t rng_cap;
     const uint64_t *zob;        // [4][NC]
-    const uint8_t *eye;         // [65536]
     int32_t *err;               // [T] sticky error flags
     long long *prof;            // optional [16] s_memtime cycle accumulators of tree 0 (tg_search_profile)
     int32_t T, N, K, cgos, superko;
 };
 
-enum : int32_t { kErrPoolFull = 1, kErrRngEmpty = 2, kErrDepth = 4 };
+enum : int32_t { kErrPoolFull = 1, kErrRngEmpty = 2 };
 
 template <int S>
 struct Geo {
@@ -286,7 +285,7 @@ __device__ __forceinline__ int pat3_at(const Lds<S> &L, int p) {
 
 // Eye colour of an empty point from its 3x3 neighbourhood (pattern.py:52-98,153-162) by the rule
 // the reference's table is exactly equal to on real boards (tests/test_oracle_board.py::
-// test_eye_table; the host-built copy of the table in D.eye is kept for cross-checking):
+// test_eye_table pins the rule to the reference's table entry by entry):
 // orthogonals own or border; 4 on-board diagonals: <= 1 opponent, or 2 opponent + 2 own;
 // 2 on-board diagonals (side): >= 1 own or both opponent; 1 on-board diagonal (corner): always.
 __device__ __forceinline__ bool is_eye_of(int code, int me) {
@@ -1047,54 +1046,6 @@ __global__ __launch_bounds__(64) void play_kernel(SearchDev D, const int32_t *mo
     }
 }
 
-// Host-built eye table: same rule as board/pattern.py:52-98 produces.
-void build_eye_table(std::vector<uint8_t> &table) {
-    table.assign(65536, 0);
-    const int borders[9][5] = {{-1, -1, -1, -1, -1}, {0, 1, 2, -1, -1}, {5, 6, 7, -1, -1},
-                               {0, 3, 5, -1, -1},    {2, 4, 7, -1, -1}, {0, 1, 2, 3, 5},
-                               {0, 1, 2, 4, 7},      {0, 3, 5, 6, 7},   {2, 4, 5, 6, 7}};
-    const int orth[4] = {1, 3, 4, 6}, diag[4] = {0, 2, 5, 7};
-    for (const auto &bd : borders) {
-        bool is_border[8] = {};
-        for (int k = 0; k < 5; ++k)
-            if (bd[k] >= 0) is_border[bd[k]] = true;
-        int free_diag[4], n_free = 0;
-        for (int d : diag)
-            if (!is_border[d]) free_diag[n_free++] = d;
-        int combos = 1;
-        for (int i = 0; i < n_free; ++i) combos *= 3;
-        for (int combo = 0; combo < combos; ++combo) {
-            int cells[8] = {};
-            for (int k = 0; k < 8; ++k)
-                if (is_border[k]) cells[k] = kOob;
-            for (int o : orth)
-                if (!is_border[o]) cells[o] = kBlack;
-            int c = combo, n_own = 0, n_opp = 0;
-            for (int i = 0; i < n_free; ++i) {
-                const int v = c % 3;
-                c /= 3;
-                cells[free_diag[i]] = v;
-                n_own += v == kBlack;
-                n_opp += v == kWhite;
-            }
-            bool ok;
-            if (n_free == 4) ok = n_opp <= 1 || (n_opp == 2 && n_own == 2);
-            else if (n_free == 2) ok = n_own >= 1 || n_opp == 2;
-            else ok = true;
-            if (!ok) continue;
-            int code = 0, swapped = 0;
-            for (int k = 0; k < 8; ++k) {
-                const int v = cells[k];
-                const int sv = (v == kBlack || v == kWhite) ? 3 - v : v;
-                code |= v << (2 * k);
-                swapped |= sv << (2 * k);
-            }
-            table[code] = kBlack;
-            table[swapped] = kWhite;
-        }
-    }
-}
-
 }  // namespace
 
 // ======================================================================================
@@ -1194,13 +1145,6 @@ int tg_search_create(const tg_search_config *cfg, tg_search **out) {
     uint64_t *zob = nullptr;
     if ((rc = dev_alloc(s, &zob, (size_t)4 * s->NC))) { tg_search_destroy(s); return rc; }
     D.zob = zob;
-    std::vector<uint8_t> eye;
-    build_eye_table(eye);
-    uint8_t *eye_dev = nullptr;
-    if ((rc = dev_alloc(s, &eye_dev, eye.size(), false))) { tg_search_destroy(s); return rc; }
-    hipError_t e = hipMemcpy(eye_dev, eye.data(), eye.size(), hipMemcpyHostToDevice);
-    if (e != hipSuccess) { tg_search_destroy(s); return tg::fail(TG_ERR_HIP, "eye upload: %s", hipGetErrorString(e)); }
-    D.eye = eye_dev;
     s->st_cells.assign(T * s->NC, 0);
     s->st_hist.assign(T * s->HMAX, 0);
     s->st_meta.assign(T, RootMeta{});
@@ -1341,9 +1285,8 @@ static int check_errors(tg_search *s) {
     TG_HIP(hipMemcpy(err.data(), s->dev.err, err.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
     for (int t = 0; t < s->dev.T; ++t)
         if (err[t])
-            return tg::fail(TG_ERR_OVERFLOW, "tree %d: %s%s%s", t, (err[t] & kErrPoolFull) ? "node pool full " : "",
-                            (err[t] & kErrRngEmpty) ? "random window exhausted " : "",
-                            (err[t] & kErrDepth) ? "depth limit " : "");
+            return tg::fail(TG_ERR_OVERFLOW, "tree %d: %s%s", t, (err[t] & kErrPoolFull) ? "node pool full " : "",
+                            (err[t] & kErrRngEmpty) ? "random window exhausted " : "");
     return TG_OK;
 }
 

@@ -43,6 +43,8 @@ _SIGNATURES = {
     "tg_net_flops_per_position": (c_double, [c_int]),
     "tg_featurize_dev": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                  c_void_p]),
+    "tg_featurize_sym_dev": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                     c_void_p, c_void_p]),
     "tg_search_create": (c_int, [POINTER(SearchConfig), POINTER(c_void_p)]),
     "tg_search_destroy": (c_int, [c_void_p]),
     "tg_search_set_zobrist": (c_int, [c_void_p, c_void_p, c_size_t]),

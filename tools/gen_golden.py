@@ -189,7 +189,21 @@ def worker(size: int):
         feat["ply"].append(seq[0])
         feat["color"].append(c)
         feat["planes"].append(generate_input_planes(board, col(c), 0).astype(np.int8))
+    # all eight symmetries (training-side featurisation, nn/feature.py:10 sym argument)
+    sym_planes = []
+    sym_meta = []
+    for g in range(min(n_games, 2)):
+        moves = board_fix[f"g{g}_move"]
+        colors = board_fix[f"g{g}_color"]
+        for ply in ([7, 33, 77] if size == 9 else [41]):
+            board = replay(moves, colors, ply)
+            for c in (1, 2):
+                for sym in range(8):
+                    sym_meta.append([g, ply, c, sym])
+                    sym_planes.append(generate_input_planes(board, col(c), sym).astype(np.int8))
     feat_np = {k: np.array(v) for k, v in feat.items()}
+    feat_np["sym_meta"] = np.array(sym_meta)
+    feat_np["sym_planes"] = np.array(sym_planes)
     feat_np["special_seqs"] = np.array([[PASS, -9, -9], [PASS, PASS, -9], [size + 3, PASS, -9]])
     np.savez_compressed(os.path.join(GOLD, f"feat_{tag}.npz"), **feat_np)
 
@@ -344,6 +358,24 @@ def worker(size: int):
             shutil.rmtree(out, ignore_errors=True)
         with open(os.path.join(GOLD, "selfplay_games.json"), "w") as f:
             json.dump(games, f)
+        # RL policy targets (nn/feature.py:60-102) for a few plies of game 1, all symmetries
+        import re
+        from nn.feature import generate_rl_target_data, generate_target_data
+        sgf = games["1,16"]
+        plies = re.findall(r";([BW])\[([a-t]{2})\]C\[([^\]]*)\]", sgf)
+        board = GoBoard(board_size=size)
+        targets = []
+        for i, (c, mv, comment) in enumerate(plies[:40]):
+            color = Stone.BLACK if c == "B" else Stone.WHITE
+            pos = PASS if mv == "tt" else (ord(mv[0]) - 96) + (ord(mv[1]) - 96) * (size + 2)
+            if i in (0, 5, 17, 39):
+                for sym in range(8):
+                    targets.append({"ply": i, "sym": sym, "comment": comment, "move": pos,
+                                    "rl": [float(v).hex() for v in generate_rl_target_data(board, comment, sym)],
+                                    "sl": [int(v) for v in generate_target_data(board, pos, sym)]})
+            board.put_stone(pos, color)
+        with open(os.path.join(GOLD, "rl_targets.json"), "w") as f:
+            json.dump({"moves": [[c, mv] for c, mv, _ in plies[:40]], "targets": targets}, f)
     print("golden fixtures written for size", size)
 
 
