@@ -546,6 +546,9 @@ __global__ __launch_bounds__(512, 2) void dualnet_fwd_wino8_kernel(
                         d[4 * a + 2] = t2 - t1;
                         d[4 * a + 3] = t1 - t3;
                     }
+                    // the wave that is in its MFMA phase goes first on this SIMD; its partner is in
+                    // its load + transform phase and fills the issue slots the MFMAs leave
+                    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                     for (int xp = 0; xp < 16; xp += 2) {
                         const f32x4 b0v = bq[0], b1v = bq[1];
@@ -559,6 +562,7 @@ __global__ __launch_bounds__(512, 2) void dualnet_fwd_wino8_kernel(
                             macc[xp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1v[j], d[xp + 1][j], macc[xp + 1], 0, 0, 0);
                         }
                     }
+                    __builtin_amdgcn_s_setprio(0);
                 }
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {                // Y = A^T M A
