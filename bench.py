@@ -91,8 +91,11 @@ def opening_boards(size, count, seed):
         board = GoBoard(size, 7.0, False)
         color = 1
         for _ in range(i % 12):
-            legal = board.get_all_legal_pos(color)
-            board.put_stone(legal[rs.randint(len(legal))], color)
+            while True:                                   # random empty point that is legal
+                pos = board.onboard_pos[rs.randint(len(board.onboard_pos))]
+                if board.is_legal(pos, color):
+                    break
+            board.put_stone(pos, color)
             color = 3 - color
         boards.append(board)
         colors.append(color)

@@ -477,13 +477,23 @@ __device__ int expand_node(Lds<S> &L, const BoardScalars &b, int to_move, const 
         if (lane == 0) atomicOr(&D.err[t], kErrRngEmpty);
         return -1;
     }
-    // sequential sum e_0 + e_1 + ... exactly like numpy's dirichlet; the addends are broadcast
-    // from registers (lane i%64 holds e_i)
-    double acc = 0.0;
+    // sequential sum e_0 + e_1 + ... exactly like numpy's dirichlet.  The addends go through
+    // LDS: uniform-address ds_reads are independent of the running sum, so they pipeline and
+    // only the 82 (362) dependent float64 adds remain on the critical path.
+    double *stage = reinterpret_cast<double *>(L.strhash);     // free after gen_candidates
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int cnt = n - 64 * r < 64 ? n - 64 * r : 64;
-        for (int i = 0; i < cnt; ++i) acc += read_lane_f64(mine[r], i);
+    for (int r = 0; r < R; ++r)
+        if (lane + 64 * r < n) stage[lane + 64 * r] = mine[r];
+    __syncthreads();
+    double acc = 0.0;
+    {
+        int i = 0;
+        for (; i + 8 <= n; i += 8) {
+            const double v0 = stage[i], v1 = stage[i + 1], v2 = stage[i + 2], v3 = stage[i + 3];
+            const double v4 = stage[i + 4], v5 = stage[i + 5], v6 = stage[i + 6], v7 = stage[i + 7];
+            acc += v0; acc += v1; acc += v2; acc += v3; acc += v4; acc += v5; acc += v6; acc += v7;
+        }
+        for (; i < n; ++i) acc += stage[i];
     }
     const double inv = 1.0 / acc;
     lap(9);
