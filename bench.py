@@ -170,20 +170,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("TG_SINGLE_DEVICE"):                     # N ranks on one GPU (tests only)
+        local_rank = 0
+    torch.cuda.set_device(local_rank)                          # before any collective is set up
+    dev = torch.device("cuda", local_rank)
+    backend = os.environ.get("TG_DIST_BACKEND", "nccl")        # nccl == RCCL on ROCm
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("TG_DIST_BACKEND", "nccl")      # nccl == RCCL on ROCm
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    if os.environ.get("TG_SINGLE_DEVICE"):                     # N ranks on one GPU (tests only)
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    red_dev = dev if os.environ.get("TG_DIST_BACKEND", "nccl") == "nccl" else torch.device("cpu")
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
 
     from tamago_amd import lib as tl
     from tamago_amd.mcts.engine import SearchEngine
