@@ -289,6 +289,23 @@ def main():
                 "end_to_end_frac": leaves / elapsed / world * flops_pos / 1e12 / FP32_MFMA_PEAK_TFLOPS,
             },
         }
+        if world == 1 and args.trees > 1:
+            # strict single-tree reading of config[1]: ONE search tree, same budget (latency-bound:
+            # descent k+1 depends on the virtual loss of descent k) - reported beside the aggregate
+            torch.cuda.synchronize()
+            one = SearchEngine(args.size, 1, args.visits + 16, args.batch, TimedEvaluator(net),
+                               device_index=local_rank)
+            one.set_root(0, fresh_board, 1, np.random.RandomState(7).get_state())
+            p1 = np.zeros(1, dtype=np.int64)
+            run_step(one, p1, fresh_board, args.visits, args.batch)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n1 = sum(run_step(one, p1, fresh_board, args.visits, args.batch) for _ in range(5))
+            torch.cuda.synchronize()
+            dt1 = time.perf_counter() - t1
+            result["single_tree"] = {"value": n1 / dt1, "unit": "leaf-evals/s",
+                                     "ms_per_move": dt1 / 5 * 1e3, "moves": 5}
+            one.close()
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.size, args.visits, args.batch,
                                                   args.cpu_seconds)
