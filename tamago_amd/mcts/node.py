@@ -1,6 +1,8 @@
 """Read-side view of one search-tree node (mirror of the MCTSNode fields and getters that
 callers read after a search, mcts/node.py:21-39,159-375).  The data lives in the GPU node
 pool; a view is a host snapshot fetched through ``tg_search_read_node``."""
+import json
+
 import numpy as np
 
 from tamago_amd.mcts.constant import C_VISIT, C_SCALE
@@ -81,3 +83,37 @@ class MCTSNode:
         evaluation = np.where(counts >= count_threshold, -10000.0,
                               self.children_policy[:n] + self.noise[:n] + sigma_base * q_mean)
         return int(np.argmax(evaluation))
+
+    # ---- analysis strings for the GTP front end (next tier) --------------------
+    def get_analysis_status_list(self, board, pv_lists_func):
+        """node.py:414-450: children sorted by (visits, index) descending, unvisited ones dropped."""
+        order = sorted(((int(self.children_visits[i]), i) for i in range(self.num_children)),
+                       reverse=True)
+        coordinate = board.coordinate
+        pv_lists = pv_lists_func(self, coordinate)
+        out = []
+        for rank, (visits, i) in enumerate((v, i) for v, i in order if v != 0):
+            move = coordinate.convert_to_gtp_format(self.action[i])
+            winrate = self.children_value_sum[i] / visits
+            out.append({"move": move, "visits": int(visits), "winrate": float(winrate),
+                        "prior": float(self.children_policy[i]), "lcb": float(winrate),
+                        "order": rank, "pv": " ".join(str(p) for p in pv_lists[move])})
+        return out
+
+    def get_analysis_from_status_list(self, mode, children_status_list):
+        """node.py:453-482: "lz" = lz-analyze info lines, "cgos" = JSON."""
+        if mode == "cgos":
+            return json.dumps({"winrate": float(self.node_value_sum) / self.node_visits,
+                               "visits": self.node_visits, "moves": children_status_list},
+                              indent=None, separators=(',', ':')) + "\n"
+        parts = []
+        for st in children_status_list:
+            if mode == "lz":
+                parts.append(f"info move {st['move']} visits {st['visits']} "
+                             f"winrate {int(10000 * st['winrate'])} prior {int(10000 * st['prior'])} "
+                             f"lcb {int(10000 * st['lcb'])} order {st['order']} pv {st['pv']}")
+        return " ".join(parts) + "\n"
+
+    def get_analysis(self, board, mode, pv_lists_func):
+        """node.py:399-411."""
+        return self.get_analysis_from_status_list(mode, self.get_analysis_status_list(board, pv_lists_func))

@@ -151,6 +151,32 @@ class MCTSTree:
                 root = engine.read_node(0, 0)
                 if time_manager.is_time_over() or time_manager.is_move_decided(root, threshold):
                     break
+        if analysis_query and analysis_query.get("interval", 0) == 0:      # tree.py:170-174
+            import sys
+            sys.stdout.write(engine.read_node(0, 0).get_analysis(board, analysis_query.get("mode", "lz"),
+                                                                 self.get_pv_lists))
+            sys.stdout.flush()
+
+    # ---- principal variations (mcts/tree.py:432-473) -----------------------------------------
+    def get_pv_lists(self, root: MCTSNode, coord) -> Dict[str, Any]:
+        pv = {}
+        for i in range(root.num_children):
+            if root.children_visits[i] > 0:
+                seq = self.get_best_move_sequence([root.action[i]], int(root.children_index[i]))
+                pv[coord.convert_to_gtp_format(root.action[i])] = \
+                    [coord.convert_to_gtp_format(p) for p in seq]
+        return pv
+
+    def get_best_move_sequence(self, pv_list, index: int):
+        node = self.node[index]
+        if node.node_visits == 0:
+            return pv_list
+        best = node.get_best_move_index()
+        pv_list.append(node.action[best])
+        nxt = int(node.children_index[best])
+        if nxt == -1:
+            return pv_list
+        return self.get_best_move_sequence(pv_list, nxt)
 
     # ------------------------------------------------------------------------------------
     def generate_move_with_sequential_halving(self, board: GoBoard, color, time_manager: TimeManager,

@@ -73,6 +73,10 @@ def test_puct_vs_reference_golden(size):
         check_root(tree, mv, rec)
         assert float(np.random.random_sample()) == float.fromhex(rec["rng_after"])
         assert np.array_equal(board.cells, cells_before) and board.moves == rec["ply"] + 1
+        # analysis strings of the GTP front end (lz-analyze / cgos-analyze), incl. the PVs
+        root = tree.get_root()
+        assert root.get_analysis(board, "lz", tree.get_pv_lists) == rec["analysis_lz"]
+        assert root.get_analysis(board, "cgos", tree.get_pv_lists) == rec["analysis_cgos"]
 
 
 @pytest.mark.parametrize("size", [9, 19])

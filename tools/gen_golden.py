@@ -320,6 +320,8 @@ def worker(size: int):
         finally:
             sys.stderr = stderr
         rec = root_record(tree, mv)
+        rec["analysis_lz"] = tree.get_root().get_analysis(board, "lz", tree.get_pv_lists)
+        rec["analysis_cgos"] = tree.get_root().get_analysis(board, "cgos", tree.get_pv_lists)
         rec.update(kind="puct", seed=seed, batch=batch, visits=visits, mode=mode, cgos=cgos,
                    ply=ply, superko=superko, color=color, batches=list(net.calls),
                    rng_after=float(np.random.random_sample()).hex())
