@@ -73,8 +73,9 @@ int tg_net_forward_dev(tg_net *net, const float *planes_dev, int batch, int want
 int tg_net_forward_host(tg_net *net, const float *planes_host, int batch, int want_logits,
                         float *policy_host, float *value_host);
 /* Profiling aid: one forward pass with workgroup 0 writing s_memtime stamps at its phase
- * boundaries (group start, stem, per layer: MFMAs issued / barrier passed, epilogues done,
- * heads done) - up to 64 stamps of the first board group. Synchronises. */
+ * boundaries (group start, stem, per layer: work done / barrier passed, heads done).
+ * Direct kernel: wave 0 -> stamps [0,64).  Winograd kernel: wave 0 -> [0,64) and wave 4 (the
+ * other wave of the same SIMD) -> [64,128).  n_stamps <= 128.  Synchronises. */
 int tg_net_profile_phases(tg_net *net, const float *planes_dev, int batch, float *policy_dev,
                           float *value_dev, long long *stamps_host, int n_stamps);
 /* Name (for rocprof) and algorithmic FLOPs per position of the dominant kernel. */

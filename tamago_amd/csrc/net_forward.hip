@@ -29,7 +29,6 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kFilters = 64;
 constexpr int kBlocks = 6;
 constexpr int kConvLayers = 1 + 2 * kBlocks;  // 13
 constexpr int kRowFloats = 72;                // activation row stride in LDS (64 + 8 pad)
@@ -52,7 +51,7 @@ struct NetDev {
     const float *pfc_b;   // [A]
     const float *vfc_w;   // [3][P]
     const float *vfc_b;   // [3]
-    long long *timeline;  // optional [64] s_memtime stamps of workgroup 0 (tg_net_profile_phases)
+    long long *timeline;  // optional [128] s_memtime stamps of workgroup 0 (tg_net_profile_phases)
 };
 
 template <int S, int G>
@@ -192,7 +191,7 @@ __global__ __launch_bounds__(256, (FwdCfg<S, G>::WAVES_PER_SIMD)) void dualnet_f
     NetDev net, const float *__restrict__ planes, int batch, int want_logits,
     float *__restrict__ policy, float *__restrict__ value) {
     using C = FwdCfg<S, G>;
-    constexpr int P = C::P, A = C::A, M = C::M, MT = C::MT;
+    constexpr int P = C::P, M = C::M, MT = C::MT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
@@ -437,12 +436,20 @@ __global__ __launch_bounds__(512, 2) void dualnet_fwd_wino8_kernel(
     const int lane_in8 = C::AUX + li * 32 + lg * 4;
     const int lane_zero8 = C::ZERO8 + lg * 4;
 
+    // profiling stamps (tg_net_profile_phases), workgroup 0: first lane of wave 0 (half 0, three
+    // row-tiles) -> [0,64), first lane of wave 4 (half 1, two row-tiles, same SIMD) -> [64,128)
+    int stamp_i = 0;
+    auto stamp = [&]() {
+        if (net.timeline && blockIdx.x == 0 && (tid == 0 || tid == 256) && stamp_i < 64)
+            net.timeline[(tid == 0 ? 0 : 64) + stamp_i++] = (long long)__builtin_amdgcn_s_memtime();
+    };
     for (int e = tid; e < kWinoRowFloats; e += 512) reinterpret_cast<float *>(smem + C::ZROW)[e] = 0.f;
     if (tid < 8) reinterpret_cast<float *>(smem + C::ZERO8)[tid] = 0.f;
 
     const int n_groups = (batch + G - 1) / G;
     for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
         const int b0 = grp * G;
+        stamp();                                  // 0: group start
         stage_planes<S, G, C, 512>(smem, planes, b0, batch, tid);
         __syncthreads();
 
@@ -480,6 +487,7 @@ __global__ __launch_bounds__(512, 2) void dualnet_fwd_wino8_kernel(
             }
         }
         __syncthreads();
+        stamp();                                  // 1: stem done
 
 #pragma unroll 1
         for (int layer = 1; layer < kConvLayers; ++layer) {
@@ -522,9 +530,14 @@ __global__ __launch_bounds__(512, 2) void dualnet_fwd_wino8_kernel(
                 f32x4 macc[16];
 #pragma unroll
                 for (int xi = 0; xi < 16; ++xi) macc[xi] = f32x4{0.f, 0.f, 0.f, 0.f};
-                f32x4 bq[2];
-                bq[0] = wl[s_begin * 64];
-                bq[1] = wl[(4 + s_begin) * 64];
+                // weight fragments: ring of 4 steps (one step = a pair of Winograd points = 8 MFMAs),
+                // loaded three steps (~770 MFMA-pipe cycles) ahead of their use - an L2 hit takes ~500
+                f32x4 wq[4][2];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    wq[r][0] = wl[((2 * r) * 4 + s_begin) * 64];
+                    wq[r][1] = wl[((2 * r + 1) * 4 + s_begin) * 64];
+                }
 #pragma unroll 1
                 for (int s = s_begin; s < s_end; ++s) {
                     f32x4 d[16];
@@ -550,17 +563,23 @@ __global__ __launch_bounds__(512, 2) void dualnet_fwd_wino8_kernel(
                     // its load + transform phase and fills the issue slots the MFMAs leave
                     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                    for (int xp = 0; xp < 16; xp += 2) {
-                        const f32x4 b0v = bq[0], b1v = bq[1];
-                        const int nx = xp + 2 < 16 ? xp + 2 : 0;              // next B pair
-                        const int ns = xp + 2 < 16 ? s : (s + 1 < s_end ? s + 1 : s);
-                        bq[0] = wl[(nx * 4 + ns) * 64];
-                        bq[1] = wl[((nx + 1) * 4 + ns) * 64];
+                    for (int st = 0; st < 8; ++st) {
+                        const int xp = 2 * st;
+                        {   // fetch the pair used three steps from now (wraps into the next channel slice)
+                            const int f = st + 3;
+                            const int nx = 2 * (f & 7);
+                            const int ns = f < 8 ? s : (s + 1 < s_end ? s + 1 : s);
+                            wq[f & 3][0] = wl[(nx * 4 + ns) * 64];
+                            wq[f & 3][1] = wl[((nx + 1) * 4 + ns) * 64];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);       // keep the fetch at the head of its step
+                        const f32x4 b0v = wq[st & 3][0], b1v = wq[st & 3][1];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             macc[xp] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0v[j], d[xp][j], macc[xp], 0, 0, 0);
                             macc[xp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1v[j], d[xp + 1][j], macc[xp + 1], 0, 0, 0);
                         }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                     __builtin_amdgcn_s_setprio(0);
                 }
@@ -603,10 +622,13 @@ __global__ __launch_bounds__(512, 2) void dualnet_fwd_wino8_kernel(
                     }
                 }
             }
+            stamp();                              // 2 + 2k: layer work of this wave done
             __syncthreads();
+            stamp();                              // 3 + 2k: barrier passed
         }
         run_heads<S, G, C, 512>(smem, net, b0, batch, want_logits, policy, value, tid);
         __syncthreads();
+        stamp();                                  // 26: heads done
     }
 }
 
@@ -917,12 +939,12 @@ int tg_net_forward_dev(tg_net *net, const float *planes_dev, int batch, int want
 
 int tg_net_profile_phases(tg_net *net, const float *planes_dev, int batch, float *policy_dev, float *value_dev,
                           long long *stamps_host, int n_stamps) {
-    if (!net || !planes_dev || !policy_dev || !value_dev || !stamps_host || n_stamps < 1 || n_stamps > 64)
+    if (!net || !planes_dev || !policy_dev || !value_dev || !stamps_host || n_stamps < 1 || n_stamps > 128)
         return tg::fail(TG_ERR_ARG, "tg_net_profile_phases: bad argument");
     TG_HIP(hipSetDevice(net->device));
     long long *tl = nullptr;
-    TG_HIP(hipMalloc(reinterpret_cast<void **>(&tl), 64 * sizeof(long long)));
-    TG_HIP(hipMemset(tl, 0, 64 * sizeof(long long)));
+    TG_HIP(hipMalloc(reinterpret_cast<void **>(&tl), 128 * sizeof(long long)));
+    TG_HIP(hipMemset(tl, 0, 128 * sizeof(long long)));
     net->dev.timeline = tl;
     int rc = tg_net_forward_dev(net, planes_dev, batch, 0, policy_dev, value_dev, nullptr);
     net->dev.timeline = nullptr;

@@ -683,7 +683,7 @@ __global__ __launch_bounds__(64) void select_puct_kernel(SearchDev D, int max_le
             int node = 0;
             bool ok = true;
             lap(0);
-            for (int depth = 0;; ++depth) {
+            for (;;) {
                 const size_t ns = (size_t)t * D.N + node;
                 const size_t base = ns * A;
                 const EdgePick pick = select_puct<S>(D, t, node, lane);
