@@ -185,13 +185,18 @@ int tg_search_set_noise(tg_search *s, const double *noise_host);
 /* One sequential-halving phase (tree.py:375-383): per tree, for count_threshold in
  * 1..max_count[t], num_considered[t] descents (root: node.py:324-346, below: :349-361);
  * every descent queues one leaf.  Planes [T, slots_per_tree, 6, S, S]; trees whose phase
- * is (0, 0) idle.  Follow with the forward pass and tg_search_backup(use_logit = 1). */
+ * is (0, 0) idle.  slots_per_tree = 0 selects the PACKED layout: the leaves of tree t start at
+ * plane sum_{u<t} num_considered[u] * max_count[u], so the forward pass covers exactly the
+ * queued leaves (one tree with a single root candidate runs 1 x visits levels and would
+ * otherwise stretch every tree's slot range).  Follow with the forward pass and
+ * tg_search_backup(same slots_per_tree, use_logit = 1). */
 int tg_search_select_gumbel(tg_search *s, const int32_t *num_considered_host,
                             const int32_t *max_count_host, int slots_per_tree,
                             float *planes_dev, void *stream);
 /* Write NN outputs back and back up values (tree.py:273-315 process_mini_batch).
  * policy_dev [T, slots_per_tree, A], value_dev [T, slots_per_tree, 3] in the slot order
- * of the preceding call (slots_per_tree = its max_leaves, or 1 after root_planes);
+ * of the preceding call (slots_per_tree = its max_leaves, 1 after root_planes, 0 after a packed
+ * tg_search_select_gumbel: policy_dev [total, A], value_dev [total, 3]);
  * use_logit as in tree.py:293-294. */
 int tg_search_backup(tg_search *s, const float *policy_dev, const float *value_dev,
                      int slots_per_tree, int use_logit, void *stream);

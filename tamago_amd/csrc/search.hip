@@ -740,19 +740,20 @@ __global__ __launch_bounds__(64) void select_puct_kernel(SearchDev D, int max_le
 // tree.py:273-315 process_mini_batch for the leaves queued by the preceding kernel.
 template <int S>
 __global__ __launch_bounds__(64) void backup_kernel(SearchDev D, const float *policy, const float *value,
-                                                    int stride, int use_logit) {
+                                                    int stride, const int32_t *leaf_off, int use_logit) {
     using G = Geo<S>;
     constexpr int A = G::A, W = G::W, P = G::P;
     const int t = blockIdx.x, lane = threadIdx.x;
     const int n = D.n_leaves[t];
+    const size_t leaf_base = leaf_off ? (size_t)leaf_off[t] : (size_t)t * stride;
     for (int k = 0; k < n; ++k) {
         const size_t slot = (size_t)t * D.K + k;
         int node = D.q_node[slot];
         if (node < 0) node = D.N - 1;                 // node[-1]: Gumbel leaves (tree.py:412-416)
         const size_t ns = (size_t)t * D.N + node;
         const size_t base = ns * A;
-        const float *pol = policy + ((size_t)t * stride + k) * A;
-        const float *val = value + ((size_t)t * stride + k) * 3;
+        const float *pol = policy + (leaf_base + k) * A;
+        const float *val = value + (leaf_base + k) * 3;
         // node.py:86-93 update_policy via the {pos: policy} map of tree.py:287-295
         const int nc = D.n_children[ns];
         for (int i = lane; i < nc; i += 64) {
@@ -963,7 +964,7 @@ __device__ int select_node_halving(Lds<S> &L, const SearchDev &D, int t, int nod
 template <int S>
 __global__ __launch_bounds__(64) void select_gumbel_kernel(SearchDev D, const int32_t *num_considered,
                                                            const int32_t *max_count, int stride,
-                                                           float *planes) {
+                                                           const int32_t *leaf_off, float *planes) {
     using G = Geo<S>;
     constexpr int A = G::A;
     __shared__ Lds<S> L;
@@ -974,6 +975,8 @@ __global__ __launch_bounds__(64) void select_gumbel_kernel(SearchDev D, const in
     int num_nodes = D.meta[t].num_nodes;
     int queued = 0;
     const int width = num_considered[t], levels = max_count[t];
+    // packed layout (leaf_off != null): this tree's leaves follow those of the trees before it
+    const size_t leaf_base = leaf_off ? (size_t)leaf_off[t] : (size_t)t * stride;
     bool ok = D.err[t] == 0 && num_nodes > 0 && width * levels <= stride;
     for (int th = 1; ok && th <= levels; ++th) {
         for (int j = 0; ok && j < width; ++j) {
@@ -997,7 +1000,7 @@ __global__ __launch_bounds__(64) void select_gumbel_kernel(SearchDev D, const in
                     D.ch_vl[base + e] += 1;
                 }
                 if (visits < 1) {                                     // tree.py:412-416
-                    write_planes<S>(L, b, c, planes + ((size_t)t * stride + queued) * 6 * G::P, lane);
+                    write_planes<S>(L, b, c, planes + (leaf_base + queued) * 6 * G::P, lane);
                     if (lane == 0) {
                         D.q_node[(size_t)t * D.K + queued] = child;   // still NOT_EXPANDED: node[-1]
                         D.q_pnode[(size_t)t * D.K + queued] = node;
@@ -1073,7 +1076,9 @@ struct tg_search {
     std::vector<RootMeta> st_meta;
     std::vector<uint8_t> st_dirty_tree;
     bool st_dirty = false;
-    int32_t *phase_dev = nullptr;
+    int32_t *phase_dev = nullptr;          // [num_considered | max_count | packed leaf offsets], T each
+    std::vector<int32_t> phase_host;
+    bool packed_leaves = false;
     int32_t *moves_dev = nullptr;
     // double-buffered random windows, uploaded on a private copy stream so that the host can
     // prepare mini-batch j+1 while the forward pass of mini-batch j runs
@@ -1402,33 +1407,46 @@ int tg_search_select_gumbel(tg_search *s, const int32_t *num_considered_host, co
                             int slots_per_tree, float *planes_dev, void *stream) {
     if (!s || !num_considered_host || !max_count_host || !planes_dev)
         return tg::fail(TG_ERR_ARG, "tg_search_select_gumbel: null argument");
-    if (slots_per_tree < 1 || slots_per_tree > s->dev.K)
+    const bool packed = slots_per_tree == 0;
+    if (!packed && (slots_per_tree < 1 || slots_per_tree > s->dev.K))
         return tg::fail(TG_ERR_ARG, "tg_search_select_gumbel: slots_per_tree %d outside [1, batch_size]", slots_per_tree);
-    for (int t = 0; t < s->dev.T; ++t)
-        if (num_considered_host[t] < 0 || max_count_host[t] < 0 ||
-            (int64_t)num_considered_host[t] * max_count_host[t] > slots_per_tree)
-            return tg::fail(TG_ERR_ARG, "tg_search_select_gumbel: tree %d phase does not fit slots_per_tree", t);
+    const int T = s->dev.T;
+    const int limit = packed ? s->dev.K : slots_per_tree;
+    // staging: [num_considered | max_count | leaf offsets]; member storage, reused per call
+    s->phase_host.resize(3 * (size_t)T);
+    int64_t total = 0;
+    for (int t = 0; t < T; ++t) {
+        const int64_t n = (int64_t)num_considered_host[t] * max_count_host[t];
+        if (num_considered_host[t] < 0 || max_count_host[t] < 0 || n > limit)
+            return tg::fail(TG_ERR_ARG, "tg_search_select_gumbel: tree %d phase does not fit %d slots", t, limit);
+        s->phase_host[t] = num_considered_host[t];
+        s->phase_host[T + t] = max_count_host[t];
+        s->phase_host[2 * (size_t)T + t] = (int32_t)total;
+        total += n;
+    }
+    if (total > (int64_t)T * s->dev.K)
+        return tg::fail(TG_ERR_ARG, "tg_search_select_gumbel: %lld leaves exceed T * batch_size", (long long)total);
     hipStream_t st = static_cast<hipStream_t>(stream);
     s->last_stream = st;
     if (!s->phase_dev) {
-        int rc = dev_alloc(s, &s->phase_dev, (size_t)2 * s->dev.T);
+        int rc = dev_alloc(s, &s->phase_dev, (size_t)3 * T);
         if (rc) return rc;
     }
-    std::vector<int32_t> both(2 * (size_t)s->dev.T);
-    std::memcpy(both.data(), num_considered_host, s->dev.T * sizeof(int32_t));
-    std::memcpy(both.data() + s->dev.T, max_count_host, s->dev.T * sizeof(int32_t));
-    TG_HIP(hipMemcpyAsync(s->phase_dev, both.data(), both.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    TG_HIP(hipStreamSynchronize(st));     // `both` is a stack-lifetime staging buffer
+    TG_HIP(hipMemcpyAsync(s->phase_dev, s->phase_host.data(), s->phase_host.size() * sizeof(int32_t),
+                          hipMemcpyHostToDevice, st));
+    TG_HIP(hipStreamSynchronize(st));     // the staging vector is rewritten by the next call
     {
         int rc = install_rng(s, st);
         if (rc) return rc;
     }
+    s->packed_leaves = packed;
+    const int32_t *off = packed ? s->phase_dev + 2 * (size_t)T : nullptr;
     if (s->S == 9)
-        hipLaunchKernelGGL(select_gumbel_kernel<9>, dim3(s->dev.T), dim3(64), 0, st, s->dev, s->phase_dev,
-                           s->phase_dev + s->dev.T, slots_per_tree, planes_dev);
+        hipLaunchKernelGGL(select_gumbel_kernel<9>, dim3(T), dim3(64), 0, st, s->dev, s->phase_dev,
+                           s->phase_dev + T, limit, off, planes_dev);
     else
-        hipLaunchKernelGGL(select_gumbel_kernel<19>, dim3(s->dev.T), dim3(64), 0, st, s->dev, s->phase_dev,
-                           s->phase_dev + s->dev.T, slots_per_tree, planes_dev);
+        hipLaunchKernelGGL(select_gumbel_kernel<19>, dim3(T), dim3(64), 0, st, s->dev, s->phase_dev,
+                           s->phase_dev + T, limit, off, planes_dev);
     TG_HIP(hipGetLastError());
     return after_select(s, st);
 }
@@ -1436,14 +1454,18 @@ int tg_search_select_gumbel(tg_search *s, const int32_t *num_considered_host, co
 int tg_search_backup(tg_search *s, const float *policy_dev, const float *value_dev, int slots_per_tree,
                      int use_logit, void *stream) {
     if (!s || !policy_dev || !value_dev) return tg::fail(TG_ERR_ARG, "tg_search_backup: null argument");
-    if (slots_per_tree < 1 || slots_per_tree > s->dev.K)
+    const bool packed = slots_per_tree == 0;
+    if (packed && !s->packed_leaves)
+        return tg::fail(TG_ERR_ARG, "tg_search_backup: packed layout (slots_per_tree 0) needs a preceding packed tg_search_select_gumbel");
+    if (!packed && (slots_per_tree < 1 || slots_per_tree > s->dev.K))
         return tg::fail(TG_ERR_ARG, "tg_search_backup: slots_per_tree %d outside [1, batch_size]", slots_per_tree);
     hipStream_t st = static_cast<hipStream_t>(stream);
     s->last_stream = st;
+    const int32_t *off = packed ? s->phase_dev + 2 * (size_t)s->dev.T : nullptr;
     if (s->S == 9)
-        hipLaunchKernelGGL(backup_kernel<9>, dim3(s->dev.T), dim3(64), 0, st, s->dev, policy_dev, value_dev, slots_per_tree, use_logit);
+        hipLaunchKernelGGL(backup_kernel<9>, dim3(s->dev.T), dim3(64), 0, st, s->dev, policy_dev, value_dev, slots_per_tree, off, use_logit);
     else
-        hipLaunchKernelGGL(backup_kernel<19>, dim3(s->dev.T), dim3(64), 0, st, s->dev, policy_dev, value_dev, slots_per_tree, use_logit);
+        hipLaunchKernelGGL(backup_kernel<19>, dim3(s->dev.T), dim3(64), 0, st, s->dev, policy_dev, value_dev, slots_per_tree, off, use_logit);
     TG_HIP(hipGetLastError());
     return TG_OK;
 }

@@ -197,11 +197,13 @@ class SearchEngine:
         self._window_left = self._window_cap - int(used.max()) if len(used) else 0
         return delta
 
-    def _evaluate_and_backup(self, n_slots: int, use_logit: bool):
-        planes = self.planes[:self.T * n_slots]
+    def _evaluate_and_backup(self, n_slots: int, use_logit: bool, packed_total: int = 0):
+        """Forward pass over the queued leaves + write-back / backup.  `packed_total` > 0: the
+        leaves of the trees lie back to back (n_slots is ignored, 0 is passed to the library)."""
+        planes = self.planes[:packed_total] if packed_total else self.planes[:self.T * n_slots]
         policy, value = self.evaluator(planes, use_logit)
         _lib.check(self.lib.tg_search_backup(self.handle, policy.data_ptr(), value.data_ptr(),
-                                             n_slots, int(use_logit), self._stream()),
+                                             0 if packed_total else n_slots, int(use_logit), self._stream()),
                    "tg_search_backup")
         self._keep = (policy, value)        # keep alive until the stream has consumed them
 
@@ -259,20 +261,25 @@ class SearchEngine:
         self.noise = noise
         return noise
 
-    def gumbel_phase(self, num_considered, max_count):
+    def gumbel_phase(self, num_considered, max_count, packed: bool = True):
         """One sequential-halving phase for every tree (tree.py:375-384): per-tree
         (num_considered, max_count), one evaluation of all queued leaves, backup."""
         nc = np.ascontiguousarray(num_considered, dtype=np.int32)
         mc = np.ascontiguousarray(max_count, dtype=np.int32)
-        slots = int(np.max(nc * mc))
+        per_tree = nc.astype(np.int64) * mc
+        slots = int(per_tree.max())
         if slots == 0:
             return
+        # packed leaf layout (slots_per_tree = 0): the forward pass covers exactly the queued
+        # leaves - a tree whose root has one candidate runs 1 x `visits` levels and would
+        # otherwise stretch every tree's slot range to `visits`
         self._feed_rng(slots * self.A)
-        _lib.check(self.lib.tg_search_select_gumbel(self.handle, nc.ctypes.data, mc.ctypes.data, slots,
+        _lib.check(self.lib.tg_search_select_gumbel(self.handle, nc.ctypes.data, mc.ctypes.data,
+                                                    0 if packed else slots,
                                                     self.planes.data_ptr(), self._stream()),
                    "tg_search_select_gumbel")
         self._collect_rng()
-        self._evaluate_and_backup(slots, True)
+        self._evaluate_and_backup(slots, True, packed_total=int(per_tree.sum()) if packed else 0)
 
     # ---------------------------------------------------------------------------------
     def num_nodes(self) -> np.ndarray:

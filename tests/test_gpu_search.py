@@ -183,3 +183,36 @@ def test_edge_cases_pass_only_root_and_errors():
     b = ref.search_best_move(GoBoard(9), 1, TimeManager(TimeControl.STRICT_PLAYOUT, 100), {})
     assert a == b and grow.tree_size >= 128
     assert np.array_equal(grow.get_root().children_visits, ref.get_root().children_visits)
+
+
+def test_gumbel_packed_leaf_layout_equals_strided():
+    """slots_per_tree = 0 (leaves of the trees back to back) gives the same trees as the strided
+    layout, with ragged per-tree phases: an idle tree, a single-candidate tree (1 x 40 levels)
+    and ordinary (8 x 3), (4 x 5) phases."""
+    import torch
+    from oracle.stubnet import StubNet
+    from tamago_amd.board.go_board import GoBoard
+    from tamago_amd.mcts.engine import SearchEngine, HostEvaluator
+
+    def run(packed):
+        eng = SearchEngine(9, 4, 160, 48, HostEvaluator(StubNet(3), torch.device("cuda:0")))
+        boards = [GoBoard(9) for _ in range(4)]
+        boards[1].put_stone(boards[1].onboard_pos[40], 1)
+        boards[3].put_stone(boards[3].onboard_pos[10], 1)
+        for t, b in enumerate(boards):
+            eng.set_root(t, b, 1 if b.moves % 2 == 0 else 2, np.random.RandomState(10 + t).get_state())
+        eng.root_eval(use_logit=True)
+        eng.set_gumbel_noise()
+        eng.gumbel_phase([8, 0, 1, 4], [3, 0, 40, 5], packed=packed)
+        eng.gumbel_phase([4, 8, 0, 2], [5, 3, 0, 9], packed=packed)
+        stats = eng.read_root_stats()
+        nodes = eng.num_nodes()
+        eng.close()
+        return stats, nodes
+
+    a, na = run(True)
+    b, nb = run(False)
+    assert np.array_equal(na, nb)
+    for key in a:
+        assert np.array_equal(a[key], b[key]), key
+    assert a["children_visits"][0].sum() == 8 * 3 + 4 * 5 and a["children_visits"][2].sum() == 40
