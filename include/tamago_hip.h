@@ -179,6 +179,30 @@ int tg_search_play(tg_search *s, const int32_t *moves_host, void *stream);
  * (any pointer may be NULL). Synchronises. */
 int tg_search_read_positions(tg_search *s, uint8_t *cells_host, int32_t *moves_host,
                              int32_t *to_move_host);
+/* ---- library-owned random streams ---------------------------------------------------------
+ * Alternative to tg_search_set_rng / tg_search_rng_consumed / tg_search_set_noise for hosts that
+ * do not want to generate the draws themselves: the library continues numpy's legacy stream
+ * (RandomState: MT19937, random_sample, standard_exponential = -log(1-u), gumbel = -log(-log(1-u)))
+ * from a given generator state - what np.random.dirichlet(ones(n)) (mcts/tree.py:518) and
+ * np.random.gumbel(size=A) (mcts/node.py:278) consume - one stream per tree.
+ * seed_stream: mt_key = the 624 words, mt_pos = the index of np.random.get_state()[1:3].
+ * stream_state: generator state after everything the tree has consumed so far (hand it back with
+ *   np.random.set_state(('MT19937', key, pos, 0, 0.0))).
+ * feed_streams: make `need` draws per tree available to the next root / select launch (no-op
+ *   while the uploaded window still covers `need` for every tree, unless force != 0); staging is
+ *   pinned and the upload overlaps running kernels.
+ * advance_streams: after a root / select launch - wait for it, move every stream by what its tree
+ *   consumed (optionally reported in consumed_host [T]).
+ * draw_noise: set_gumbel_noise for every root from the next A draws of each stream (uploaded
+ *   like tg_search_set_noise; copy returned in noise_host [T][A] unless NULL). */
+int tg_search_seed_stream(tg_search *s, int tree, const uint32_t *mt_key, int mt_pos);
+int tg_search_stream_state(tg_search *s, int tree, uint32_t *mt_key_out, int *mt_pos_out);
+int tg_search_feed_streams(tg_search *s, size_t need, int force);
+int tg_search_advance_streams(tg_search *s, int64_t *consumed_host);
+int tg_search_draw_noise(tg_search *s, double *noise_host);
+/* Host-only helper (no device needed): the next n legacy standard_exponential draws of the
+ * generator (mt_key, *mt_pos), updated in place - the arithmetic the streams above use. */
+int tg_legacy_exponentials(uint32_t *mt_key, int *mt_pos, size_t n, double *out);
 /* Gumbel root noise, float64 [T][A] (node.py:275-278 set_gumbel_noise), to be set after the
  * root evaluation of a Gumbel move. */
 int tg_search_set_noise(tg_search *s, const double *noise_host);

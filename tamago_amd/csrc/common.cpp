@@ -39,3 +39,17 @@ int tg_device_count(int *count) {
 }
 
 }  // extern "C"
+
+#include "legacy_stream.h"
+
+extern "C" int tg_legacy_exponentials(uint32_t *mt_key, int *mt_pos, size_t n, double *out) {
+    if (!mt_key || !mt_pos || (!out && n)) return tg::fail(TG_ERR_ARG, "tg_legacy_exponentials: null argument");
+    if (*mt_pos < 0 || *mt_pos > 624) return tg::fail(TG_ERR_ARG, "tg_legacy_exponentials: MT19937 position outside [0, 624]");
+    tg::Mt19937 g;
+    std::memcpy(g.key, mt_key, sizeof(g.key));
+    g.pos = *mt_pos;
+    for (size_t i = 0; i < n; ++i) out[i] = -std::log(1.0 - g.next_double());
+    std::memcpy(mt_key, g.key, sizeof(g.key));
+    *mt_pos = g.pos;
+    return TG_OK;
+}

@@ -28,8 +28,11 @@
 //     -ffp-contract=off so no FMA is formed behind the source's back;
 //   * the random draws come from the host (libm log) through tg_search_set_rng.
 #include "common.h"
+#include "legacy_stream.h"
 
 #include <cstring>
+#include <algorithm>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -1090,6 +1093,14 @@ struct tg_search {
     int rng_active = 0, rng_pending = -1;
     int64_t rng_pending_cap = 0;
     bool sel_recorded = false;
+    // library-owned legacy streams (tg_search_seed_stream): one per tree, windows are generated,
+    // staged in pinned memory and uploaded without any host-language involvement
+    std::vector<tg::LegacyStream> streams;
+    double *stage[2] = {nullptr, nullptr};        // pinned, paired with rng_buf[]
+    size_t stage_cap[2] = {0, 0};
+    bool stage_busy[2] = {false, false};          // ev_rng[b] guards a copy out of stage[b]
+    int64_t win_cap = 0, win_left = 0;            // active / pending window: size, unread tail
+    std::vector<int64_t> win_used;                // device cursor per tree at the last advance
 };
 
 namespace {
@@ -1099,9 +1110,32 @@ int dev_alloc(tg_search *s, T **out, size_t count, bool zero = true) {
     void *p = nullptr;
     TG_HIP(hipMalloc(&p, count * sizeof(T)));
     s->allocs.push_back(p);
-    if (zero) TG_HIP(hipMemset(p, 0, count * sizeof(T)));
+    if (zero) {
+        // hipMemset on device memory is asynchronous (legacy null stream); callers go on to use the
+        // buffer from NON-BLOCKING streams (torch side streams), which the null stream does not order
+        TG_HIP(hipMemset(p, 0, count * sizeof(T)));
+        TG_HIP(hipStreamSynchronize(nullptr));
+    }
     *out = static_cast<T *>(p);
     return TG_OK;
+}
+
+template <typename F>
+void parallel_trees(int n, F &&fn) {
+    unsigned hw = std::thread::hardware_concurrency();
+    int nthr = (int)std::min<unsigned>(hw ? hw : 1u, 16u);
+    if (n < 32 || nthr < 2) {
+        for (int t = 0; t < n; ++t) fn(t);
+        return;
+    }
+    nthr = std::min(nthr, n / 8);
+    std::vector<std::thread> pool;
+    pool.reserve(nthr);
+    for (int w = 0; w < nthr; ++w)
+        pool.emplace_back([&, w]() {
+            for (int t = w; t < n; t += nthr) fn(t);
+        });
+    for (auto &th : pool) th.join();
 }
 
 }  // namespace
@@ -1178,6 +1212,8 @@ int tg_search_destroy(tg_search *s) {
     }
     if (s->ev_sel) (void)hipEventDestroy(s->ev_sel);
     if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
+    for (int b = 0; b < 2; ++b)
+        if (s->stage[b]) (void)hipHostFree(s->stage[b]);
     delete s;
     return TG_OK;
 }
@@ -1401,6 +1437,116 @@ int tg_search_set_noise(tg_search *s, const double *noise_host) {
     if (s->last_stream) TG_HIP(hipStreamSynchronize(s->last_stream));
     TG_HIP(hipMemcpy(s->dev.noise, noise_host, (size_t)s->dev.T * s->A * sizeof(double), hipMemcpyHostToDevice));
     return TG_OK;
+}
+
+// ---- library-owned legacy streams ---------------------------------------------------------
+
+int tg_search_seed_stream(tg_search *s, int tree, const uint32_t *mt_key, int mt_pos) {
+    if (!s || !mt_key) return tg::fail(TG_ERR_ARG, "tg_search_seed_stream: null argument");
+    if (tree < 0 || tree >= s->dev.T) return tg::fail(TG_ERR_ARG, "tg_search_seed_stream: tree %d out of range", tree);
+    if (mt_pos < 0 || mt_pos > 624) return tg::fail(TG_ERR_ARG, "tg_search_seed_stream: MT19937 position %d outside [0, 624]", mt_pos);
+    if (s->streams.empty()) s->streams.resize(s->dev.T);
+    s->streams[tree].seed(mt_key, mt_pos);
+    s->win_left = 0;                               // the uploaded window belongs to the old stream
+    return TG_OK;
+}
+
+int tg_search_stream_state(tg_search *s, int tree, uint32_t *mt_key_out, int *mt_pos_out) {
+    if (!s || !mt_key_out || !mt_pos_out) return tg::fail(TG_ERR_ARG, "tg_search_stream_state: null argument");
+    if (tree < 0 || tree >= s->dev.T || s->streams.empty() || !s->streams[tree].seeded)
+        return tg::fail(TG_ERR_ARG, "tg_search_stream_state: tree %d has no stream", tree);
+    const tg::Mt19937 &g = s->streams[tree].state_at_position();
+    std::memcpy(mt_key_out, g.key, 624 * sizeof(uint32_t));
+    *mt_pos_out = g.pos;
+    return TG_OK;
+}
+
+int tg_search_feed_streams(tg_search *s, size_t need, int force) {
+    if (!s) return tg::fail(TG_ERR_ARG, "tg_search_feed_streams: null argument");
+    const int T = s->dev.T;
+    if (s->streams.size() != (size_t)T) return tg::fail(TG_ERR_ARG, "tg_search_feed_streams: streams are not seeded");
+    for (int t = 0; t < T; ++t)
+        if (!s->streams[t].seeded) return tg::fail(TG_ERR_ARG, "tg_search_feed_streams: tree %d has no stream", t);
+    if (need == 0 || (!force && s->win_left >= (int64_t)need)) return TG_OK;
+    const int idx = 1 - s->rng_active;             // never the window a running kernel may read
+    if ((int64_t)need > s->rng_buf_cap[idx]) {
+        (void)hipFree(s->rng_buf[idx]);             // implicit device synchronisation (rare)
+        s->rng_buf[idx] = nullptr;
+        s->rng_buf_cap[idx] = 0;
+        TG_HIP(hipMalloc(reinterpret_cast<void **>(&s->rng_buf[idx]), (size_t)T * need * sizeof(double)));
+        s->rng_buf_cap[idx] = (int64_t)need;
+    }
+    if (s->stage_busy[idx]) {                       // an earlier upload may still read this staging buffer
+        TG_HIP(hipEventSynchronize(s->ev_rng[idx]));
+        s->stage_busy[idx] = false;
+    }
+    if ((size_t)T * need > s->stage_cap[idx]) {
+        if (s->stage[idx]) (void)hipHostFree(s->stage[idx]);
+        s->stage[idx] = nullptr;
+        s->stage_cap[idx] = 0;
+        TG_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->stage[idx]), (size_t)T * need * sizeof(double), hipHostMallocDefault));
+        s->stage_cap[idx] = (size_t)T * need;
+    }
+    double *stage = s->stage[idx];
+    parallel_trees(T, [&](int t) {
+        tg::LegacyStream &ls = s->streams[t];
+        ls.ensure(need);
+        std::memcpy(stage + (size_t)t * need, ls.data(), need * sizeof(double));
+    });
+    TG_HIP(hipMemcpyAsync(s->rng_buf[idx], stage, (size_t)T * need * sizeof(double), hipMemcpyHostToDevice, s->copy_stream));
+    TG_HIP(hipEventRecord(s->ev_rng[idx], s->copy_stream));
+    s->stage_busy[idx] = true;
+    s->rng_pending = idx;
+    s->rng_pending_cap = (int64_t)need;
+    s->win_cap = s->win_left = (int64_t)need;
+    s->win_used.assign(T, 0);
+    return TG_OK;
+}
+
+int tg_search_advance_streams(tg_search *s, int64_t *consumed_host) {
+    if (!s) return tg::fail(TG_ERR_ARG, "tg_search_advance_streams: null argument");
+    const int T = s->dev.T;
+    if (s->streams.size() != (size_t)T) return tg::fail(TG_ERR_ARG, "tg_search_advance_streams: streams are not seeded");
+    std::vector<int64_t> used(T);
+    {
+        int rc = tg_search_rng_consumed(s, used.data());
+        if (rc) return rc;
+    }
+    if (s->win_used.size() != (size_t)T) s->win_used.assign(T, 0);
+    int64_t most = 0;
+    for (int t = 0; t < T; ++t) {
+        const int64_t delta = used[t] - s->win_used[t];     // the device cursor is cumulative within a window
+        if (delta < 0 || (size_t)delta > s->streams[t].available())
+            return tg::fail(TG_ERR_ARG, "tg_search_advance_streams: tree %d consumed %lld of %zu staged draws", t,
+                            (long long)delta, s->streams[t].available());
+        s->streams[t].consume((size_t)delta);
+        if (consumed_host) consumed_host[t] = delta;
+        s->win_used[t] = used[t];
+        most = std::max(most, used[t]);
+    }
+    s->win_left = s->win_cap - most;
+    return TG_OK;
+}
+
+int tg_search_draw_noise(tg_search *s, double *noise_host) {
+    if (!s) return tg::fail(TG_ERR_ARG, "tg_search_draw_noise: null argument");
+    const int T = s->dev.T, A = s->A;
+    if (s->streams.size() != (size_t)T) return tg::fail(TG_ERR_ARG, "tg_search_draw_noise: streams are not seeded");
+    std::vector<double> local;
+    double *noise = noise_host;
+    if (!noise) {
+        local.resize((size_t)T * A);
+        noise = local.data();
+    }
+    parallel_trees(T, [&](int t) {
+        tg::LegacyStream &ls = s->streams[t];
+        ls.ensure((size_t)A);
+        const double *e = ls.data();
+        for (int i = 0; i < A; ++i) noise[(size_t)t * A + i] = -std::log(e[i]);   // gumbel(0,1) of the same uniforms
+        ls.consume((size_t)A);
+    });
+    s->win_left = 0;                               // the noise sits between two windows
+    return tg_search_set_noise(s, noise);
 }
 
 int tg_search_select_gumbel(tg_search *s, const int32_t *num_considered_host, const int32_t *max_count_host,

@@ -65,6 +65,27 @@ class ExpStream:
         return g.get_state()
 
 
+class LibStream:
+    """Handle on a library-owned legacy stream (tg_search_seed_stream): the C side generates,
+    stages and uploads the draws; Python only seeds it and reads the state back."""
+
+    def __init__(self, engine, tree: int, state):
+        self.engine = engine
+        self.tree = tree
+        key = np.ascontiguousarray(state[1], dtype=np.uint32)
+        assert state[0] == "MT19937" and key.shape == (624,)
+        _lib.check(engine.lib.tg_search_seed_stream(engine.handle, tree, key.ctypes.data, int(state[2])),
+                   "tg_search_seed_stream")
+
+    def final_state(self):
+        """numpy state after everything this tree has consumed so far."""
+        key = np.zeros(624, dtype=np.uint32)
+        pos = ctypes.c_int(0)
+        _lib.check(self.engine.lib.tg_search_stream_state(self.engine.handle, self.tree, key.ctypes.data,
+                                                          ctypes.byref(pos)), "tg_search_stream_state")
+        return ("MT19937", key, int(pos.value), 0, 0.0)
+
+
 class HostEvaluator:
     """Adapter for any object with the DualNet host API (inference /
     inference_with_policy_logits on CPU tensors): planes are copied to the host, results
@@ -102,7 +123,10 @@ class DeviceEvaluator:
 class SearchEngine:
     def __init__(self, board_size: int, num_trees: int, tree_size: int, batch_size: int,
                  evaluator, cgos_mode: bool = False, check_superko: bool = False,
-                 device_index: int = 0):
+                 device_index: int = 0, host_streams: bool = False):
+        """host_streams: generate the random draws in Python (ExpStream + tg_search_set_rng /
+        tg_search_rng_consumed / tg_search_set_noise - the calls a numpy-side host would make)
+        instead of the library-owned streams; same results, kept for that boundary's tests."""
         self.lib = _lib.load()
         self.S = board_size
         self.P = board_size * board_size
@@ -123,6 +147,7 @@ class SearchEngine:
                    "tg_search_set_zobrist")
         self.planes = torch.empty((num_trees * batch_size, 6, board_size, board_size),
                                   dtype=torch.float32, device=self.device)
+        self.host_streams = host_streams or bool(os.environ.get("TG_HOST_STREAMS"))
         self.streams: List[Optional[ExpStream]] = [None] * num_trees
         self._pool = None
         self._window_left = 0
@@ -156,13 +181,22 @@ class SearchEngine:
         _lib.check(self.lib.tg_search_set_root(self.handle, tree, ctypes.byref(pos)),
                    "tg_search_set_root")
         if rng_state is not None:
-            self.streams[tree] = ExpStream(rng_state)
-            self._window_left = 0
+            self.set_stream(tree, rng_state)
+
+    def set_stream(self, tree: int, rng_state):
+        """(Re)seed the legacy stream tree `tree` draws from (np.random.get_state() layout)."""
+        self.streams[tree] = ExpStream(rng_state) if self.host_streams else LibStream(self, tree, rng_state)
+        self._window_left = 0
 
     def _feed_rng(self, need: int):
         """Upload the next `need` stream positions of every tree (window becomes active at the
         next root / select launch).  Skipped when an earlier (pre-fetched) window still covers
         `need` positions for every tree."""
+        if not self.host_streams:
+            _lib.check(self.lib.tg_search_feed_streams(self.handle, need, int(self._window_left == 0)),
+                       "tg_search_feed_streams")
+            self._window_left = -1                   # the library tracks the window from here on
+            return
         if self._window_left >= need:
             return
         self._window_left = need
@@ -186,6 +220,11 @@ class SearchEngine:
                    "tg_search_set_rng")
 
     def _collect_rng(self):
+        if not self.host_streams:
+            delta = np.zeros(self.T, dtype=np.int64)
+            _lib.check(self.lib.tg_search_advance_streams(self.handle, delta.ctypes.data),
+                       "tg_search_advance_streams")
+            return delta
         used = np.zeros(self.T, dtype=np.int64)
         _lib.check(self.lib.tg_search_rng_consumed(self.handle, used.ctypes.data),
                    "tg_search_rng_consumed")
@@ -254,6 +293,10 @@ class SearchEngine:
         """node.py:275-278 for every root: A doubles from each tree's stream, drawn after the
         root's Dirichlet prior and NN evaluation (tree.py:332-336)."""
         noise = np.empty((self.T, self.A), dtype=np.float64)
+        if not self.host_streams:
+            _lib.check(self.lib.tg_search_draw_noise(self.handle, noise.ctypes.data), "tg_search_draw_noise")
+            self.noise = noise
+            return noise
         self._window_left = 0                     # the noise sits between two windows
         for t, s in enumerate(self.streams):
             noise[t] = s.gumbel(self.A)

@@ -55,12 +55,17 @@ def _finish(game: _Game, winner, is_resign: bool, score: float):
 
 def selfplay_shard(save_dir: str, network, index_list: Sequence[int], size: int, visits: int,
                    boards: int = 16, seeds: Sequence[int] = None, device_index: int = 0,
-                   never_resign_flags: Sequence[bool] = None) -> dict:
+                   never_resign_flags: Sequence[bool] = None, groups: int = 0) -> dict:
     """Play the games of `index_list`, `boards` at a time.  Game i draws from its own legacy
     stream seeded with seeds[i] (default: its index), so every game equals the reference
-    game a single-board worker would play with that seed."""
-    from tamago_amd.nn.network.dual_net import DualNet
-    import torch
+    game a single-board worker would play with that seed.
+
+    `groups` > 1 splits the boards into that many independent lock-step groups, each with its
+    own engine, HIP stream and host thread (default: 2 when boards >= 64): while one group's
+    host thread does the per-move bookkeeping (move choice, SGF comment, RNG windows) the GPU
+    runs the other group's phases, and one group's tree kernels overlap the other's forward
+    pass.  Games are independent, so the result does not depend on the grouping."""
+    import threading
     todo = [i for i in index_list if not os.path.isfile(os.path.join(save_dir, f"{i}.sgf"))]
     seeds = dict(zip(index_list, seeds if seeds is not None else index_list))
     flags = dict(zip(index_list, never_resign_flags)) if never_resign_flags is not None else None
@@ -68,81 +73,138 @@ def selfplay_shard(save_dir: str, network, index_list: Sequence[int], size: int,
     if not todo:
         return stats
     boards = min(boards, len(todo))
-    evaluator = DeviceEvaluator(network) if isinstance(network, DualNet) \
-        else HostEvaluator(network, torch.device("cuda", device_index))
-    max_moves = size * size * 2                                    # worker.py:44
-    engine = SearchEngine(size, boards, max(SELF_PLAY_VISITS * 10, visits + 8), max(visits, 1),
-                          evaluator, check_superko=True, device_index=device_index)
-    slots: List[_Game] = [None] * boards
+    if groups <= 0:
+        groups = 2 if boards >= 64 else 1
+    groups = max(1, min(groups, boards))
     queue = list(todo)
+    lock = threading.Lock()
 
-    def start(slot: int):
-        index = queue.pop(0)
-        nr = flags[index] if flags is not None else (random.randint(1, 10) == 1)   # worker.py:53
-        slots[slot] = _Game(index, size, save_dir, nr)
-        engine.streams[slot] = None
-        game = slots[slot]
-        engine.set_root(slot, game.board, game.color, np.random.RandomState(seeds[index]).get_state())
+    def next_game():
+        """(index, never_resign) of the next unplayed game, or None."""
+        with lock:
+            if not queue:
+                return None
+            index = queue.pop(0)
+            nr = flags[index] if flags is not None else (random.randint(1, 10) == 1)   # worker.py:53
+            return index, nr
 
-    for s in range(boards):
-        start(s)
+    if groups == 1:
+        _run_group(save_dir, network, size, visits, boards, seeds, device_index, next_game, stats, None)
+        return stats
 
-    while any(g is not None and not g.done for g in slots):
-        active = [s for s, g in enumerate(slots) if g is not None and not g.done]
-        # boards are resident on the device (tg_search_play); idle slots keep their last root
-        engine.root_eval(use_logit=True)
-        engine.set_gumbel_noise()
-        nc, _, _ = engine.read_roots()
-        schedules = []
-        for s in range(boards):
-            base = int(nc[s]) if nc[s] < MAX_CONSIDERED_NODES else MAX_CONSIDERED_NODES
-            schedules.append(list(get_candidates_and_visit_pairs(base, visits).items())
-                             if s in active else [])
-        stats["leaf_evals"] += len(active)
-        for phase in range(max(len(sc) for sc in schedules)):
-            widths = [sc[phase][0] if phase < len(sc) else 0 for sc in schedules]
-            levels = [sc[phase][1] if phase < len(sc) else 0 for sc in schedules]
-            engine.gumbel_phase(widths, levels)
-            stats["leaf_evals"] += int(np.dot(widths, levels))
-        root_stats = engine.read_root_stats()
-        played = np.full(boards, -1, dtype=np.int32)
-        for s in active:
-            game = slots[s]
-            root = engine.root_view(root_stats, s)
-            best = root.select_move_by_sequential_halving_for_root(PLAYOUTS)      # tree.py:344
-            value = root.calculate_value_evaluation(best)
-            pos = RESIGN if (not game.never_resign and value < 0.05) else root.get_child_move(best)
-            stats["moves"] += 1
-            if pos == RESIGN:                                                      # worker.py:59-62
-                _finish(game, Stone.get_opponent_color(game.color), True, 0.0)
-            else:
-                played[s] = pos
-                game.history.append((pos, game.color))
-                game.pass_count = game.pass_count + 1 if pos == PASS else 0
-                game.record.save_record(root, pos, game.color)
-                game.color = Stone.get_opponent_color(game.color)
-                game.moves_played += 1
-                if game.pass_count == 2:                                           # worker.py:80-87
-                    final = GoBoard(board_size=size, komi=7.0, check_superko=True)
-                    for mv, col in game.history:
-                        final.put_stone(mv, col)
-                    score = final.count_score() - final.get_komi()
-                    winner = Stone.BLACK if score > 0.1 else (Stone.WHITE if score < -0.1
-                                                              else Stone.OUT_OF_BOARD)
-                    _finish(game, winner, False, score)
-                elif game.moves_played >= max_moves:
-                    # the reference reaches write_record with `winner` unset here (a NameError);
-                    # record the game as unfinished instead
-                    _finish(game, Stone.EMPTY, False, 0.0)
-            if game.done:
-                stats["games"] += 1
-                played[s] = -1
-        engine.play(played)
-        for s in active:
-            if slots[s].done and queue:
-                start(s)
-    engine.close()
+    import torch
+    sizes = [boards // groups + (1 if g < boards % groups else 0) for g in range(groups)]
+    results = [dict(games=0, moves=0, leaf_evals=0) for _ in range(groups)]
+    errors = []
+
+    def work(g):
+        try:
+            stream = torch.cuda.Stream(device=torch.device("cuda", device_index))
+            _run_group(save_dir, network, size, visits, sizes[g], seeds, device_index, next_game,
+                       results[g], stream)
+        except BaseException as exc:          # surfaced in the caller's thread
+            errors.append(exc)
+
+    threads = [threading.Thread(target=work, args=(g,), name=f"selfplay-group-{g}") for g in range(groups)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    if errors:
+        raise errors[0]
+    for r in results:
+        for k in stats:
+            stats[k] += r[k]
     return stats
+
+
+def _run_group(save_dir, network, size, visits, boards, seeds, device_index, next_game, stats, stream):
+    """One lock-step group of `boards` games on its own engine (and HIP stream, if given)."""
+    from tamago_amd.nn.network.dual_net import DualNet
+    import contextlib
+    import torch
+    ctx = torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
+    with ctx:
+        evaluator = DeviceEvaluator(network) if isinstance(network, DualNet) \
+            else HostEvaluator(network, torch.device("cuda", device_index))
+        max_moves = size * size * 2                                    # worker.py:44
+        engine = SearchEngine(size, boards, max(SELF_PLAY_VISITS * 10, visits + 8), max(visits, 1),
+                              evaluator, check_superko=True, device_index=device_index)
+        slots: List[_Game] = [None] * boards
+
+        def start(slot: int) -> bool:
+            nxt = next_game()
+            if nxt is None:
+                return False
+            index, nr = nxt
+            slots[slot] = _Game(index, size, save_dir, nr)
+            engine.streams[slot] = None
+            game = slots[slot]
+            engine.set_root(slot, game.board, game.color, np.random.RandomState(seeds[index]).get_state())
+            return True
+
+        for s in range(boards):
+            if not start(s):
+                # fewer games than slots: park an empty board with a private stream
+                slots[s] = None
+                engine.set_root(s, GoBoard(board_size=size, komi=7.0, check_superko=True), Stone.BLACK,
+                                np.random.RandomState(0).get_state())
+
+        while any(g is not None and not g.done for g in slots):
+            active = [s for s, g in enumerate(slots) if g is not None and not g.done]
+            # boards are resident on the device (tg_search_play); idle slots keep their last root
+            engine.root_eval(use_logit=True)
+            engine.set_gumbel_noise()
+            nc, _, _ = engine.read_roots()
+            schedules = []
+            for s in range(boards):
+                base = int(nc[s]) if nc[s] < MAX_CONSIDERED_NODES else MAX_CONSIDERED_NODES
+                schedules.append(list(get_candidates_and_visit_pairs(base, visits).items())
+                                 if s in active else [])
+            stats["leaf_evals"] += len(active)
+            for phase in range(max(len(sc) for sc in schedules)):
+                widths = [sc[phase][0] if phase < len(sc) else 0 for sc in schedules]
+                levels = [sc[phase][1] if phase < len(sc) else 0 for sc in schedules]
+                engine.gumbel_phase(widths, levels)
+                stats["leaf_evals"] += int(np.dot(widths, levels))
+            root_stats = engine.read_root_stats()
+            played = np.full(boards, -1, dtype=np.int32)
+            for s in active:
+                game = slots[s]
+                root = engine.root_view(root_stats, s)
+                best = root.select_move_by_sequential_halving_for_root(PLAYOUTS)      # tree.py:344
+                value = root.calculate_value_evaluation(best)
+                pos = RESIGN if (not game.never_resign and value < 0.05) else root.get_child_move(best)
+                stats["moves"] += 1
+                if pos == RESIGN:                                                      # worker.py:59-62
+                    _finish(game, Stone.get_opponent_color(game.color), True, 0.0)
+                else:
+                    played[s] = pos
+                    game.history.append((pos, game.color))
+                    game.pass_count = game.pass_count + 1 if pos == PASS else 0
+                    game.record.save_record(root, pos, game.color)
+                    game.color = Stone.get_opponent_color(game.color)
+                    game.moves_played += 1
+                    if game.pass_count == 2:                                           # worker.py:80-87
+                        final = GoBoard(board_size=size, komi=7.0, check_superko=True)
+                        for mv, col in game.history:
+                            final.put_stone(mv, col)
+                        score = final.count_score() - final.get_komi()
+                        winner = Stone.BLACK if score > 0.1 else (Stone.WHITE if score < -0.1
+                                                                  else Stone.OUT_OF_BOARD)
+                        _finish(game, winner, False, score)
+                    elif game.moves_played >= max_moves:
+                        # the reference reaches write_record with `winner` unset here (a NameError);
+                        # record the game as unfinished instead
+                        _finish(game, Stone.EMPTY, False, 0.0)
+                if game.done:
+                    stats["games"] += 1
+                    played[s] = -1
+            engine.play(played)
+            for s in active:
+                if slots[s].done:
+                    start(s)
+        engine.close()
 
 
 def selfplay_worker(save_dir: str, model_file_path: str, index_list: List[int], size: int,

@@ -134,7 +134,7 @@ def test_device_play_matches_host_board():
     want = eng2.read_node(0, 0)
     eng.evaluator = HostEvaluator(StubNet(9), torch.device("cuda:0"))
     for t in range(len(games)):
-        eng.streams[t] = type(eng.streams[t])(np.random.RandomState(77).get_state())
+        eng.set_stream(t, np.random.RandomState(77).get_state())
     eng.root_eval(False)
     eng.puct_batch(4)
     got = eng.read_node(0, 0)
@@ -216,3 +216,47 @@ def test_gumbel_packed_leaf_layout_equals_strided():
     for key in a:
         assert np.array_equal(a[key], b[key]), key
     assert a["children_visits"][0].sum() == 8 * 3 + 4 * 5 and a["children_visits"][2].sum() == 40
+
+
+def test_library_streams_equal_host_streams():
+    """The library-owned legacy streams (tg_search_seed_stream / feed / advance / draw_noise) and
+    the numpy-side feed (ExpStream + tg_search_set_rng / rng_consumed / set_noise) give the same
+    trees, the same Gumbel noise and the same generator state afterwards."""
+    import torch
+    from oracle.stubnet import StubNet
+    from tamago_amd.board.go_board import GoBoard
+    from tamago_amd.mcts.engine import SearchEngine, HostEvaluator
+
+    def run(host_streams):
+        eng = SearchEngine(9, 3, 200, 32, HostEvaluator(StubNet(5), torch.device("cuda:0")),
+                           host_streams=host_streams)
+        for t in range(3):
+            eng.set_root(t, GoBoard(9), 1, np.random.RandomState(40 + t).get_state())
+        eng.root_eval(False, first_batch=7)
+        eng.puct_batch(7)
+        eng.prefetch_rng(32)
+        eng.puct_batch(32)
+        eng.puct_batch(5)
+        puct = eng.read_root_stats()
+        for t in range(3):
+            eng.set_root(t, GoBoard(9), 1)                 # new search, streams continue
+        eng.root_eval(use_logit=True)
+        noise = eng.set_gumbel_noise().copy()
+        eng.gumbel_phase([16, 8, 4], [2, 4, 8])
+        eng.gumbel_phase([8, 4, 2], [4, 8, 16])
+        gum = eng.read_root_stats()
+        states = [eng.streams[t].final_state() for t in range(3)]
+        eng.close()
+        return puct, noise, gum, states
+
+    a = run(False)
+    b = run(True)
+    for key in a[0]:
+        assert np.array_equal(a[0][key], b[0][key]), key
+        assert np.array_equal(a[2][key], b[2][key]), key
+    assert np.array_equal(a[1], b[1])
+    for sa, sb in zip(a[3], b[3]):
+        ga, gb = np.random.RandomState(), np.random.RandomState()
+        ga.set_state(sa)
+        gb.set_state(sb)
+        assert np.array_equal(ga.random_sample(8), gb.random_sample(8))

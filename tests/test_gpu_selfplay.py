@@ -53,6 +53,14 @@ def test_lockstep_shard_equals_single_board_games(tmp_path):
         b = open(multi / f"{i}.sgf", encoding="utf-8").read()
         assert a == b, i
     assert open(solo / "1.sgf", encoding="utf-8").read() == golden["1,16"]
+    # two pipelined groups (own engine, HIP stream and host thread each) play the same games
+    piped = tmp_path / "piped"
+    piped.mkdir()
+    stats = selfplay_shard(str(piped), StubNet(salt=201), idx, 9, 16, boards=3, never_resign_flags=flags,
+                           groups=2)
+    assert stats["games"] == 3
+    for i in idx:
+        assert open(solo / f"{i}.sgf", encoding="utf-8").read() == open(piped / f"{i}.sgf", encoding="utf-8").read(), i
     # resume-by-skip (worker.py:47-48): nothing left to do
     again = selfplay_shard(str(multi), StubNet(salt=201), idx, 9, 16, boards=2, never_resign_flags=flags)
     assert again["games"] == 0

@@ -27,3 +27,40 @@ def test_expstream_reproduces_dirichlet_and_gumbel_draws():
         g = np.random.RandomState()
         g.set_state(s.final_state())
         assert np.array_equal(g.random_sample(4), fix[f"seed{seed}_uni"])
+
+
+def test_library_legacy_stream_equals_numpy():
+    """tg_legacy_exponentials (the arithmetic of the library-owned streams: MT19937, legacy
+    random_sample, standard_exponential) vs numpy.random.RandomState, across state refills and
+    from mid-state positions; the updated state continues numpy's stream."""
+    from tamago_amd import lib as tl
+    lib = tl.load()
+    fix = load_npz("rng.npz")
+    for seed in (0, 1, 12345, 2**31 - 5):
+        ref = np.random.RandomState(seed)
+        state = ref.get_state()
+        key = np.ascontiguousarray(state[1], dtype=np.uint32).copy()
+        pos = tl.ctypes.c_int(int(state[2]))
+        for n in (1, 5, 311, 313, 1000, 2):              # 311 + 313 doubles = 2 x 624 words: refill boundary
+            out = np.empty(n, dtype=np.float64)
+            tl.check(lib.tg_legacy_exponentials(key.ctypes.data, tl.ctypes.byref(pos), n, out.ctypes.data))
+            assert np.array_equal(out, ref.standard_exponential(n)), (seed, n)
+        cont = np.random.RandomState()
+        cont.set_state(("MT19937", key, int(pos.value), 0, 0.0))
+        assert np.array_equal(cont.random_sample(7), ref.random_sample(7))
+    # the recorded reference draws: dirichlet(ones(n)) = normalised exponentials, gumbel = -log(e)
+    for seed in (0, 1, 12345):
+        state = np.random.RandomState(seed).get_state()
+        key = np.ascontiguousarray(state[1], dtype=np.uint32).copy()
+        pos = tl.ctypes.c_int(int(state[2]))
+        for n in (1, 2, 37, 82, 362):
+            e = np.empty(n)
+            tl.check(lib.tg_legacy_exponentials(key.ctypes.data, tl.ctypes.byref(pos), n, e.ctypes.data))
+            acc = 0.0
+            for v in e:
+                acc += v
+            assert np.array_equal(e * (1.0 / acc), fix[f"seed{seed}_dir{n}"]), (seed, n)
+        e = np.empty(82)
+        tl.check(lib.tg_legacy_exponentials(key.ctypes.data, tl.ctypes.byref(pos), 82, e.ctypes.data))
+        import math
+        assert np.array_equal(np.array([-math.log(v) for v in e]), fix[f"seed{seed}_gum82"])   # libm log, not numpy's SIMD log
