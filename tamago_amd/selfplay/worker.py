@@ -61,7 +61,7 @@ def selfplay_shard(save_dir: str, network, index_list: Sequence[int], size: int,
     game a single-board worker would play with that seed.
 
     `groups` > 1 splits the boards into that many independent lock-step groups, each with its
-    own engine, HIP stream and host thread (default: 2 when boards >= 64): while one group's
+    own engine, HIP stream and host thread (default: 4 when boards >= 256, 2 when >= 64): while one group's
     host thread does the per-move bookkeeping (move choice, SGF comment, RNG windows) the GPU
     runs the other group's phases, and one group's tree kernels overlap the other's forward
     pass.  Games are independent, so the result does not depend on the grouping."""
@@ -74,7 +74,7 @@ def selfplay_shard(save_dir: str, network, index_list: Sequence[int], size: int,
         return stats
     boards = min(boards, len(todo))
     if groups <= 0:
-        groups = 2 if boards >= 64 else 1
+        groups = 4 if boards >= 256 else (2 if boards >= 64 else 1)
     groups = max(1, min(groups, boards))
     queue = list(todo)
     lock = threading.Lock()
@@ -106,10 +106,18 @@ def selfplay_shard(save_dir: str, network, index_list: Sequence[int], size: int,
             errors.append(exc)
 
     threads = [threading.Thread(target=work, args=(g,), name=f"selfplay-group-{g}") for g in range(groups)]
-    for th in threads:
-        th.start()
-    for th in threads:
-        th.join()
+    # a group thread coming back from a (GIL-free) library call must not wait a whole default
+    # switch interval (5 ms) for the interpreter while its GPU work queue runs dry
+    import sys
+    interval = sys.getswitchinterval()
+    sys.setswitchinterval(2e-4)
+    try:
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+    finally:
+        sys.setswitchinterval(interval)
     if errors:
         raise errors[0]
     for r in results:

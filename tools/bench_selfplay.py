@@ -9,6 +9,7 @@ from tamago_amd.selfplay.worker import selfplay_shard
 boards = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 visits = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 games = int(sys.argv[3]) if len(sys.argv) > 3 else boards
+groups = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 torch.manual_seed(0)
 net = DualNet(torch.device("cuda:0"), 9)
 out = tempfile.mkdtemp(prefix="sp_")
@@ -17,9 +18,9 @@ selfplay_shard(out, net, list(range(1000, 1000 + min(boards, 4))), 9, 16, boards
                never_resign_flags=[False] * min(boards, 4))
 t0 = time.time()
 stats = selfplay_shard(out, net, list(range(1, games + 1)), 9, visits, boards=boards,
-                       never_resign_flags=[True] * games)
+                       never_resign_flags=[True] * games, groups=groups)
 dt = time.time() - t0
 shutil.rmtree(out, ignore_errors=True)
-print(f"selfplay boards={boards} visits={visits}: {stats['games']} games, {stats['moves']} moves, "
+print(f"selfplay boards={boards} groups={groups or 'auto'} visits={visits}: {stats['games']} games, {stats['moves']} moves, "
       f"{stats['leaf_evals']} leaf-evals in {dt:.1f} s -> {stats['leaf_evals']/dt:.0f} leaf-evals/s, "
       f"{stats['games']/dt*3600:.0f} games/hour")
