@@ -31,7 +31,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix
-PMC_SUMMARY = os.path.join(REPO, "profiles", "r01_pmc_forward_wino_9x9_b65536.json")
+PMC_SUMMARY = os.path.join(REPO, "profiles", "r01c_pmc_forward_wino_9x9_b65536.json")
 
 
 def pmc_traffic(size, positions):
@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--size", type=int, default=9)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--selfplay-boards", type=int, default=256,
+                    help="boards of the Gumbel self-play leg reported in `selfplay` (0 = skip; N = 1 only)")
     return ap.parse_args()
 
 
@@ -306,6 +308,29 @@ def main():
             result["single_tree"] = {"value": n1 / dt1, "unit": "leaf-evals/s",
                                      "ms_per_move": dt1 / 5 * 1e3, "moves": 5}
             one.close()
+        if world == 1 and args.selfplay_boards > 0 and args.size == 9:
+            # cfg-3/4 style leg (Gumbel self-play, 400 simulations per move, games to completion):
+            # reported beside the headline, never part of `value`
+            try:
+                import shutil
+                import tempfile
+                from tamago_amd.selfplay.worker import selfplay_shard
+                engine.close()
+                torch.cuda.synchronize()
+                out_dir = tempfile.mkdtemp(prefix="tg_sp_")
+                nb = args.selfplay_boards
+                ts = time.perf_counter()
+                st = selfplay_shard(out_dir, net, list(range(1, nb + nb // 2 + 1)), args.size, 400, boards=nb,
+                                    never_resign_flags=[True] * (nb + nb // 2))
+                dts = time.perf_counter() - ts
+                shutil.rmtree(out_dir, ignore_errors=True)
+                result["selfplay"] = {"value": st["leaf_evals"] / dts, "unit": "leaf-evals/s",
+                                      "games_per_hour": st["games"] / dts * 3600, "boards": nb,
+                                      "games": st["games"], "moves": st["moves"], "seconds": dts,
+                                      "workload": "Gumbel sequential halving, 400 simulations/move, "
+                                                  "lock-step boards, SGF records written"}
+            except Exception as exc:                      # the headline must not depend on this leg
+                result["selfplay"] = {"error": repr(exc)}
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.size, args.visits, args.batch,
                                                   args.cpu_seconds)
