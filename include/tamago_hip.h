@@ -225,6 +225,12 @@ int tg_search_select_gumbel(tg_search *s, const int32_t *num_considered_host,
 int tg_search_backup(tg_search *s, const float *policy_dev, const float *value_dev,
                      int slots_per_tree, int use_logit, void *stream);
 
+/* Path of queued leaf `slot` of tree `tree` after a selection launch, root first:
+ * (node index, child index) per level - the `path` list of search_mcts (tree.py:199-244) that
+ * search_with_callback (tree.py:177-196) hands to its callback.  Valid for the slots the last
+ * selection launch queued, until the next one.  Synchronises. */
+int tg_search_read_path(tg_search *s, int tree, int slot, int32_t *nodes_host, int32_t *edges_host,
+                        int capacity, int32_t *length_host);
 /* Read-side of MCTSNode for node `node` of tree `t` (node.py:21-39); any pointer may be
  * NULL.  Arrays have A entries. Synchronises the stream used by the last call. */
 int tg_search_read_node(tg_search *s, int tree, int node, int32_t *num_children,

@@ -1669,6 +1669,40 @@ int tg_search_read_root_stats(tg_search *s, int32_t *num_children_host, int32_t 
     return TG_OK;
 }
 
+int tg_search_read_path(tg_search *s, int tree, int slot, int32_t *nodes_host, int32_t *edges_host, int capacity,
+                        int32_t *length_host) {
+    if (!s || !nodes_host || !edges_host || !length_host)
+        return tg::fail(TG_ERR_ARG, "tg_search_read_path: null argument");
+    if (tree < 0 || tree >= s->dev.T || slot < 0 || slot >= s->dev.K)
+        return tg::fail(TG_ERR_ARG, "tg_search_read_path: tree %d / slot %d out of range", tree, slot);
+    if (s->last_stream) TG_HIP(hipStreamSynchronize(s->last_stream));
+    else TG_HIP(hipDeviceSynchronize());
+    const SearchDev &D = s->dev;
+    // (the queue entries stay valid until the next selection launch, also after tg_search_backup)
+    // leaf -> root over the parent pointers, then reversed into the reference's root -> leaf order
+    std::vector<int32_t> nodes, edges;
+    int32_t cur = -1, e = -1;
+    const size_t q = (size_t)tree * D.K + slot;
+    TG_HIP(hipMemcpy(&cur, D.q_pnode + q, sizeof(int32_t), hipMemcpyDeviceToHost));
+    TG_HIP(hipMemcpy(&e, D.q_pedge + q, sizeof(int32_t), hipMemcpyDeviceToHost));
+    while (cur >= 0) {
+        nodes.push_back(cur);
+        edges.push_back(e);
+        const size_t cs = (size_t)tree * D.N + cur;
+        TG_HIP(hipMemcpy(&e, D.n_pedge + cs, sizeof(int32_t), hipMemcpyDeviceToHost));
+        TG_HIP(hipMemcpy(&cur, D.n_parent + cs, sizeof(int32_t), hipMemcpyDeviceToHost));
+        if ((int)nodes.size() > D.N) return tg::fail(TG_ERR_HIP, "tg_search_read_path: parent chain does not end");
+    }
+    *length_host = (int32_t)nodes.size();
+    if ((int)nodes.size() > capacity)
+        return tg::fail(TG_ERR_ARG, "tg_search_read_path: path of %zu steps exceeds capacity %d", nodes.size(), capacity);
+    for (size_t i = 0; i < nodes.size(); ++i) {
+        nodes_host[i] = nodes[nodes.size() - 1 - i];
+        edges_host[i] = edges[nodes.size() - 1 - i];
+    }
+    return TG_OK;
+}
+
 int tg_search_num_nodes(tg_search *s, int32_t *num_nodes_host) {
     if (!s || !num_nodes_host) return tg::fail(TG_ERR_ARG, "tg_search_num_nodes: null argument");
     if (s->last_stream) TG_HIP(hipStreamSynchronize(s->last_stream));

@@ -330,6 +330,16 @@ class SearchEngine:
         _lib.check(self.lib.tg_search_num_nodes(self.handle, out.ctypes.data), "tg_search_num_nodes")
         return out
 
+    def read_path(self, tree: int, slot: int):
+        """[(node index, child index), ...] root first for queued leaf `slot` (tree.py:199-244 path)."""
+        cap = 4 * self.P + 8
+        nodes = np.zeros(cap, dtype=np.int32)
+        edges = np.zeros(cap, dtype=np.int32)
+        n = ctypes.c_int32(0)
+        _lib.check(self.lib.tg_search_read_path(self.handle, tree, slot, nodes.ctypes.data, edges.ctypes.data,
+                                                cap, ctypes.byref(n)), "tg_search_read_path")
+        return [(int(nodes[i]), int(edges[i])) for i in range(n.value)]
+
     def read_roots(self):
         """(num_children [T], action [T][A], children_visits [T][A]) of every root."""
         nc = np.zeros(self.T, dtype=np.int32)

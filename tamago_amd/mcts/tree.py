@@ -157,6 +157,67 @@ class MCTSTree:
                                                                  self.get_pv_lists))
             sys.stdout.flush()
 
+    def ponder(self, board: GoBoard, color, analysis_query: Dict[str, Any]):
+        """mcts/tree.py:108-127: search without a visit limit until input arrives on stdin
+        (``analysis_query["ponder"]``), printing analysis every ``interval`` seconds.  The
+        reference polls stdin after every descent; here the poll sits between mini-batches (a
+        batch in flight is finished), input that is already waiting stops after one descent.
+        The node pool is fixed: pondering also stops when the next mini-batch might not fit."""
+        import select
+        import sys
+        import time
+        engine = self._engine_for(board)
+        self._gumbel_root = False
+        self.to_move = color if isinstance(color, Stone) else Stone(color_value(color))
+        engine.set_root(0, board, color, np.random.get_state())
+        engine.root_eval(use_logit=False)                              # _initialize_search
+        query = analysis_query or {}
+        interval = query.get("interval", 0)
+        mode = query.get("mode", "lz")
+        clock = time.time()
+
+        def stdin_ready():
+            if not query.get("ponder", False):
+                return False
+            ready, _, _ = select.select([sys.stdin], [], [], 0)
+            return bool(ready)
+
+        if engine.read_node(0, 0).get_num_children() > 1:
+            while True:
+                used = int(engine.num_nodes()[0])
+                if used + self.batch_size + 1 > self.tree_size:
+                    break
+                waiting = stdin_ready()
+                engine.puct_batch(1 if waiting else self.batch_size)
+                if waiting or stdin_ready():
+                    break
+                if query and interval > 0 and time.time() - clock > interval:
+                    clock = time.time()
+                    sys.stdout.write(engine.read_node(0, 0).get_analysis(board, mode, self.get_pv_lists))
+                    sys.stdout.flush()
+        if query and interval == 0:                                    # tree.py:170-174
+            sys.stdout.write(engine.read_node(0, 0).get_analysis(board, mode, self.get_pv_lists))
+            sys.stdout.flush()
+        self.num_nodes = int(engine.num_nodes()[0])
+        self._commit_rng(engine)
+
+    def search_with_callback(self, board: GoBoard, color, callback):
+        """mcts/tree.py:177-196: one descent at a time (mini-batches of one leaf); the callback
+        gets the descent's [(node index, child index), ...] and ends the search by returning True."""
+        engine = self._engine_for(board, batch_size=1)
+        self._gumbel_root = False
+        self.to_move = color if isinstance(color, Stone) else Stone(color_value(color))
+        engine.set_root(0, board, color, np.random.get_state())
+        engine.root_eval(use_logit=False)
+        while True:
+            if int(engine.num_nodes()[0]) + 2 > self.tree_size:
+                raise RuntimeError("search_with_callback: node pool exhausted; create the tree with a larger tree_size")
+            engine.puct_batch(1)
+            if callback(engine.read_path(0, 0)):
+                break
+        self.num_nodes = int(engine.num_nodes()[0])
+        self._commit_rng(engine)
+
     # ---- principal variations (mcts/tree.py:432-473) -----------------------------------------
     def get_pv_lists(self, root: MCTSNode, coord) -> Dict[str, Any]:
         pv = {}
