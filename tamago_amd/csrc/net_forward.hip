@@ -76,6 +76,18 @@ __device__ __forceinline__ f32x4 lds_f32x4(const unsigned char *smem, int byte_o
     return *reinterpret_cast<const f32x4 *>(smem + byte_off);
 }
 
+// a - b as two v_pk_add_f32 with negated second operand (hipcc emits four scalar v_sub_f32 for a
+// float4 subtraction; a + (-b) is the same IEEE operation)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 sub4(f32x4 a, f32x4 b) {
+    f32x2 lo, hi;
+    const f32x2 alo = __builtin_shufflevector(a, a, 0, 1), ahi = __builtin_shufflevector(a, a, 2, 3);
+    const f32x2 blo = __builtin_shufflevector(b, b, 0, 1), bhi = __builtin_shufflevector(b, b, 2, 3);
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(lo) : "v"(alo), "v"(blo));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(hi) : "v"(ahi), "v"(bhi));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
+
 
 // ---- pieces shared by the direct and the Winograd kernels -------------------------------------
 template <int S, int G, typename C = FwdCfg<S, G>, int NTHR = 256>
@@ -401,19 +413,20 @@ struct WinoCfg {
     static constexpr int BUF_A = 0;
     static constexpr int BUF_B = M * kWinoRowBytes;
     static constexpr int ZROW = 2 * M * kWinoRowBytes;
-    static constexpr int AUX = ZROW + kWinoRowBytes;          // in8 staging / head scratch / Y exchange
-    static constexpr int XCH_BYTES = 4 * 64 * 64;          // 4 waves x 64 lanes x 4 outputs x 16 B
-    static constexpr int AUX_BYTES = (M * 32 > XCH_BYTES) ? M * 32 : XCH_BYTES;
+    static constexpr int AUX = ZROW + kWinoRowBytes;          // in8 staging / head scratch
+    static constexpr int AUX_BYTES = M * 32;
     static constexpr int ZERO8 = AUX + AUX_BYTES;
     static constexpr int LDS_BYTES = ZERO8 + 32;
 };
 
 // ---- Winograd tower, 8 waves per workgroup (2 per SIMD) --------------------------------------
-// Same algorithm and LDS layout as dualnet_fwd_wino_kernel, but the workgroup has two waves
-// per output-channel tile: half h = 0 takes row-tiles {0,1,2}, half h = 1 takes {3,4} (75 tiles).
-// Each wave keeps ONE patch buffer and simply alternates "16 loads + transform" with "64
-// MFMAs"; the two waves that share a SIMD fall out of phase, so one transforms while the
-// other feeds the matrix pipe - the overlap hipcc's scheduler does not produce inside a wave.
+// Wave (w, h): output channels [16w, 16w+16), half h = 0 takes row-tiles {0,1,2}, h = 1 takes
+// {3,4} (75 tiles).  A wave alternates "16 patch reads + input transform" with "64 MFMAs".
+// What costs time here is instruction ISSUE: a wave is held for the 8 passes of each MFMA it
+// issues and everything else it issues comes on top (tools/microbench/mfma_coissue.hip), so
+// the loop is trimmed for instruction count: packed subtractions (sub4), patch addresses from
+// per-lane geometry computed once (3 VALU each per row-tile, one add per slice), a weight
+// ring that runs on across row-tiles.
 template <int S, int G>
 __global__ __launch_bounds__(512, 2) void dualnet_fwd_wino8_kernel(
     NetDev net, const float *__restrict__ planes, int batch, int want_logits,
@@ -446,6 +459,31 @@ __global__ __launch_bounds__(512, 2) void dualnet_fwd_wino8_kernel(
     for (int e = tid; e < kWinoRowFloats; e += 512) reinterpret_cast<float *>(smem + C::ZROW)[e] = 0.f;
     if (tid < 8) reinterpret_cast<float *>(smem + C::ZERO8)[tid] = 0.f;
 
+    // row-tile split between the two halves: half 0 takes the first (RT+1)/2 row-tiles.  Per-lane
+    // geometry of this wave's row-tiles, computed once: buffer-relative address of the patch origin
+    // (with the lane's channel sub-slice) and the 16 "inside the board" bits of the 4x4 patch
+    constexpr int RTH = (RT + 1) / 2;
+    const int rt_begin = half == 0 ? 0 : RTH;
+    const int n_own = half == 0 ? RTH : RT - RTH;
+    int base_rel[3];
+    unsigned valid[3];
+    static_assert(RTH <= 3, "geometry registers are sized for three row-tiles per wave");
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int t = (rt_begin + r) * 16 + li;
+        const int bl = t / TPB;
+        const int tl = t - bl * TPB;
+        const int ty = tl / TY, tx = tl - ty * TY;
+        const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
+        unsigned m = 0;
+#pragma unroll
+        for (int pq = 0; pq < 16; ++pq) {
+            const int y = y0 + pq / 4, x = x0 + pq % 4;
+            if (r < n_own && t < NT && y >= 0 && y < S && x >= 0 && x < S) m |= 1u << pq;
+        }
+        valid[r] = m;
+        base_rel[r] = (r < n_own && t < NT) ? (bl * P + y0 * S + x0) * kWinoRowBytes + lg * 16 : 0;
+    }
     const int n_groups = (batch + G - 1) / G;
     for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
         const int b0 = grp * G;
@@ -498,66 +536,55 @@ __global__ __launch_bounds__(512, 2) void dualnet_fwd_wino8_kernel(
                               ((size_t)((layer - 1) * 4 + wave) * 16) * 4 * 64 + lane;
             const f32x4 sc = *reinterpret_cast<const f32x4 *>(net.scale + layer * 64 + wave * 16 + lg * 4);
             const f32x4 sh = *reinterpret_cast<const f32x4 *>(net.shift + layer * 64 + wave * 16 + lg * 4);
-            // Row-tile split between the two halves.  With an odd number of row-tiles the last one
-            // is SHARED: each half accumulates two of its four channel groups, the (linear) output
-            // transform is applied to both partial sums, half 1 hands its 2x2 outputs over through
-            // LDS and half 0 adds them and runs the epilogue - 2.5 : 2.5 instead of 3 : 2.
-            constexpr bool SHARE = false;   // (RT % 2 == 1) && RT > 1: measured slower (34.3 vs 30.7 ms / 65k positions)
-            constexpr int RTF = SHARE ? RT - 1 : RT;          // row-tiles that are not shared
-            const int rt_begin = half == 0 ? 0 : (RTF + 1) / 2;
-            const int rt_end = half == 0 ? (RTF + 1) / 2 : RTF;
-            const int n_own = rt_end - rt_begin;
-            const int n_iter = n_own + (SHARE ? 1 : 0);
+            // weight fragments: ring of 4 steps (one step = a pair of Winograd points = 8 MFMAs),
+            // fetched three steps (~770 MFMA-pipe cycles) ahead of their use - an L2 hit takes ~500.
+            // The (slice, step) sequence of a row-tile is the same for every row-tile, so the ring
+            // simply wraps from the last step of one row-tile to the first of the next.
+            f32x4 wq[4][2];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                wq[r][0] = wl[((2 * r) * 4) * 64];
+                wq[r][1] = wl[((2 * r + 1) * 4) * 64];
+            }
 #pragma unroll 1
-            for (int it = 0; it < n_iter; ++it) {
-                const bool shared = SHARE && it == n_own;
-                const int rt = shared ? RT - 1 : rt_begin + it;
-                const int s_begin = shared ? 2 * half : 0;
-                const int s_end = shared ? 2 * half + 2 : 4;
-                const int t = rt * 16 + li;
-                const int bl = t / TPB;
-                const int tl = t - bl * TPB;
-                const int ty = tl / TY, tx = tl - ty * TY;
-                const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
-                const int base = in_off + (bl * P + y0 * S + x0) * kWinoRowBytes + lg * 16;
+            for (int it = 0; it < n_own; ++it) {
+                // patch addresses of this row-tile: 3 VALU each from the per-lane geometry
+                const int brel = it == 0 ? base_rel[0] : (it == 1 ? base_rel[1] : base_rel[2]);
+                const unsigned vm = it == 0 ? valid[0] : (it == 1 ? valid[1] : valid[2]);
+                const int base = in_off + brel;
                 int a16[16];
 #pragma unroll
                 for (int pq = 0; pq < 16; ++pq) {
-                    const int y = y0 + pq / 4, x = x0 + pq % 4;
-                    const bool ok = t < NT && y >= 0 && y < S && x >= 0 && x < S;
-                    a16[pq] = ok ? base + ((pq / 4) * S + (pq % 4)) * kWinoRowBytes : lane_zero;
+                    const int ok = ((int)(vm << (31 - pq))) >> 31;                  // -1 inside the board
+                    const int addr = base + ((pq / 4) * S + (pq % 4)) * kWinoRowBytes;
+                    a16[pq] = (addr & ok) | (lane_zero & ~ok);
                 }
                 f32x4 macc[16];
 #pragma unroll
                 for (int xi = 0; xi < 16; ++xi) macc[xi] = f32x4{0.f, 0.f, 0.f, 0.f};
-                // weight fragments: ring of 4 steps (one step = a pair of Winograd points = 8 MFMAs),
-                // loaded three steps (~770 MFMA-pipe cycles) ahead of their use - an L2 hit takes ~500
-                f32x4 wq[4][2];
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    wq[r][0] = wl[((2 * r) * 4 + s_begin) * 64];
-                    wq[r][1] = wl[((2 * r + 1) * 4 + s_begin) * 64];
-                }
 #pragma unroll 1
-                for (int s = s_begin; s < s_end; ++s) {
+                for (int s = 0; s < 4; ++s) {
                     f32x4 d[16];
 #pragma unroll
-                    for (int pq = 0; pq < 16; ++pq) d[pq] = lds_f32x4(smem, a16[pq] + s * 64);
+                    for (int pq = 0; pq < 16; ++pq) {
+                        d[pq] = lds_f32x4(smem, a16[pq]);
+                        a16[pq] += 64;                       // next 16-channel slice (the zero row is 272 B wide)
+                    }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {            // V = B^T d B, columns then rows
                         const f32x4 d0 = d[q], d1 = d[4 + q], d2 = d[8 + q], d3 = d[12 + q];
-                        d[q] = d0 - d2;
+                        d[q] = sub4(d0, d2);
                         d[4 + q] = d1 + d2;
-                        d[8 + q] = d2 - d1;
-                        d[12 + q] = d1 - d3;
+                        d[8 + q] = sub4(d2, d1);
+                        d[12 + q] = sub4(d1, d3);
                     }
 #pragma unroll
                     for (int a = 0; a < 4; ++a) {
                         const f32x4 t0 = d[4 * a], t1 = d[4 * a + 1], t2 = d[4 * a + 2], t3 = d[4 * a + 3];
-                        d[4 * a] = t0 - t2;
+                        d[4 * a] = sub4(t0, t2);
                         d[4 * a + 1] = t1 + t2;
-                        d[4 * a + 2] = t2 - t1;
-                        d[4 * a + 3] = t1 - t3;
+                        d[4 * a + 2] = sub4(t2, t1);
+                        d[4 * a + 3] = sub4(t1, t3);
                     }
                     // the wave that is in its MFMA phase goes first on this SIMD; its partner is in
                     // its load + transform phase and fills the issue slots the MFMAs leave
@@ -565,10 +592,10 @@ __global__ __launch_bounds__(512, 2) void dualnet_fwd_wino8_kernel(
 #pragma unroll
                     for (int st = 0; st < 8; ++st) {
                         const int xp = 2 * st;
-                        {   // fetch the pair used three steps from now (wraps into the next channel slice)
+                        {   // fetch the pair used three steps from now (wraps into the next slice / row-tile)
                             const int f = st + 3;
                             const int nx = 2 * (f & 7);
-                            const int ns = f < 8 ? s : (s + 1 < s_end ? s + 1 : s);
+                            const int ns = f < 8 ? s : ((s + 1) & 3);
                             wq[f & 3][0] = wl[(nx * 4 + ns) * 64];
                             wq[f & 3][1] = wl[((nx + 1) * 4 + ns) * 64];
                         }
@@ -586,32 +613,20 @@ __global__ __launch_bounds__(512, 2) void dualnet_fwd_wino8_kernel(
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {                // Y = A^T M A
                     const f32x4 m0 = macc[b] + macc[4 + b] + macc[8 + b];
-                    const f32x4 m1 = macc[4 + b] - macc[8 + b] - macc[12 + b];
+                    const f32x4 m1 = sub4(sub4(macc[4 + b], macc[8 + b]), macc[12 + b]);
                     macc[b] = m0;
                     macc[4 + b] = m1;
                 }
                 f32x4 yv[4];
                 yv[0] = macc[0] + macc[1] + macc[2];
-                yv[1] = macc[1] - macc[2] - macc[3];
+                yv[1] = sub4(sub4(macc[1], macc[2]), macc[3]);
                 yv[2] = macc[4] + macc[5] + macc[6];
-                yv[3] = macc[5] - macc[6] - macc[7];
-                if (shared) {
-                    // exchange area: the in8 staging region (free between stem and heads), 4 KB per wave
-                    f32x4 *xch = reinterpret_cast<f32x4 *>(smem + C::AUX) + (wave * 64 + lane) * 4;
-                    if (half == 1) {
-#pragma unroll
-                        for (int o = 0; o < 4; ++o) xch[o] = yv[o];
-                    }
-                    __syncthreads();
-                    if (half == 1) continue;
-#pragma unroll
-                    for (int o = 0; o < 4; ++o) yv[o] += xch[o];
-                }
+                yv[3] = sub4(sub4(macc[5], macc[6]), macc[7]);
 #pragma unroll
                 for (int o = 0; o < 4; ++o) {
-                    const int y = 2 * ty + (o >> 1), x = 2 * tx + (o & 1);
-                    if (t < NT && y < S && x < S) {
-                        unsigned char *dst = smem + out_off + (bl * P + y * S + x) * kWinoRowBytes + wave * 64 + lg * 16;
+                    const int py = 1 + (o >> 1), px = 1 + (o & 1);     // output o sits on patch cell (py, px)
+                    if ((vm >> (py * 4 + px)) & 1u) {
+                        unsigned char *dst = smem + out_off + brel + (py * S + px) * kWinoRowBytes + wave * 64;
                         f32x4 v;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] = fmaf(yv[o][j], sc[j], sh[j]);
