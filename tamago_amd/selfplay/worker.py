@@ -61,7 +61,7 @@ def selfplay_shard(save_dir: str, network, index_list: Sequence[int], size: int,
     game a single-board worker would play with that seed.
 
     `groups` > 1 splits the boards into that many independent lock-step groups, each with its
-    own engine, HIP stream and host thread (default: 4 when boards >= 256, 2 when >= 64): while one group's
+    own engine, HIP stream and host thread (default: one group per 128 boards, 2..8; 1 below 64 boards): while one group's
     host thread does the per-move bookkeeping (move choice, SGF comment, RNG windows) the GPU
     runs the other group's phases, and one group's tree kernels overlap the other's forward
     pass.  Games are independent, so the result does not depend on the grouping."""
@@ -74,7 +74,7 @@ def selfplay_shard(save_dir: str, network, index_list: Sequence[int], size: int,
         return stats
     boards = min(boards, len(todo))
     if groups <= 0:
-        groups = 4 if boards >= 256 else (2 if boards >= 64 else 1)
+        groups = 1 if boards < 64 else (2 if boards < 256 else min(8, boards // 128))
     groups = max(1, min(groups, boards))
     queue = list(todo)
     lock = threading.Lock()
