@@ -51,6 +51,11 @@ def parse():
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--trees", type=int, default=2048, help="boards searched in lock-step per GPU")
+    ap.add_argument("--groups", type=int, default=1,
+                    help="run the boards of a GPU as this many lock-step groups on their own HIP streams "
+                         "(measured: no gain - the forward kernel's two 256-VGPR waves per SIMD leave no "
+                         "registers for another kernel's waves, so nothing overlaps: 2.25 / 2.20 / 2.08 M "
+                         "leaf-evals/s at 1 / 2 / 4 groups)")
     ap.add_argument("--visits", type=int, default=1000)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--size", type=int, default=9)
@@ -104,30 +109,39 @@ def opening_boards(size, count, seed):
     return boards, colors
 
 
-def run_step(engine, plies, fresh_board, visits, batch):
-    """One move search for every tree; returns leaf evaluations done.  Boards live on the
-    device: the searched move (arg-max visits) is played there (tg_search_play)."""
+def run_step(engines, plies_list, fresh_board, visits, batch):
+    """One move search for every tree of every group; returns leaf evaluations done.  Boards live
+    on the device: the searched move (arg-max visits) is played there (tg_search_play).  The
+    groups are driven round-robin from this one host thread, each on its own stream: launches are
+    asynchronous, only a group's own selection kernel is waited for (random-stream cursor)."""
     first = min(batch, visits)
-    engine.root_eval(False, first_batch=first)
+    for engine, stream in engines:
+        with torch.cuda.stream(stream):
+            engine.root_eval(False, first_batch=first)
     done = 0
     while done < visits:
         k = min(batch, visits - done)
-        engine.puct_batch(k)
+        for engine, stream in engines:
+            with torch.cuda.stream(stream):
+                engine.puct_batch(k)
         done += k
-    # window for the next search, generated while this search's last forward pass runs
-    engine.prefetch_rng(first)
-    leaves = engine.T * (1 + visits)
-    nc, action, visits_arr = engine.read_roots()
-    cols = np.arange(engine.A)[None, :]
-    masked = np.where(cols < nc[:, None], visits_arr, -1)
-    moves = action[np.arange(engine.T), np.argmax(masked, axis=1)].astype(np.int32)
-    plies += 1
-    over = plies > 2 * engine.P - 8
-    moves[over] = -1
-    engine.play(moves)
-    for t in np.nonzero(over)[0]:                  # finished game: start a new one
-        engine.set_root(int(t), fresh_board, 1)
-        plies[t] = 0
+    leaves = 0
+    for (engine, stream), plies in zip(engines, plies_list):
+        with torch.cuda.stream(stream):
+            # window for the next search, generated while this search's last forward pass runs
+            engine.prefetch_rng(first)
+            leaves += engine.T * (1 + visits)
+            nc, action, visits_arr = engine.read_roots()
+            cols = np.arange(engine.A)[None, :]
+            masked = np.where(cols < nc[:, None], visits_arr, -1)
+            moves = action[np.arange(engine.T), np.argmax(masked, axis=1)].astype(np.int32)
+            plies += 1
+            over = plies > 2 * engine.P - 8
+            moves[over] = -1
+            engine.play(moves)
+            for t in np.nonzero(over)[0]:                  # finished game: start a new one
+                engine.set_root(int(t), fresh_board, 1)
+                plies[t] = 0
     return leaves
 
 
@@ -194,12 +208,22 @@ def main():
     torch.manual_seed(1234)
     net = DualNet(dev, args.size)                      # random-init weights, resident
     evaluator = TimedEvaluator(net)
-    engine = SearchEngine(args.size, args.trees, args.visits + 16, args.batch, evaluator,
-                          device_index=local_rank)
+    n_groups = max(1, min(args.groups, args.trees))
+    sizes = [args.trees // n_groups + (1 if g < args.trees % n_groups else 0) for g in range(n_groups)]
     boards, colors = opening_boards(args.size, args.trees, 1000 + rank)
-    for t in range(args.trees):                         # one private legacy stream per board
-        rs = np.random.RandomState(10_000 * rank + t)
-        engine.set_root(t, boards[t], colors[t], rs.get_state())
+    engines, plies_list = [], []
+    t0 = 0
+    for g, n in enumerate(sizes):
+        stream = torch.cuda.Stream(device=dev) if n_groups > 1 else torch.cuda.current_stream(dev)
+        with torch.cuda.stream(stream):
+            engine = SearchEngine(args.size, n, args.visits + 16, args.batch, evaluator,
+                                  device_index=local_rank)
+            for t in range(n):                          # one private legacy stream per board
+                rs = np.random.RandomState(10_000 * rank + t0 + t)
+                engine.set_root(t, boards[t0 + t], colors[t0 + t], rs.get_state())
+        engines.append((engine, stream))
+        plies_list.append(np.array([b.moves - 1 for b in boards[t0:t0 + n]], dtype=np.int64))
+        t0 += n
 
     def barrier():
         torch.cuda.synchronize()
@@ -209,15 +233,14 @@ def main():
 
     from tamago_amd.board.go_board import GoBoard
     fresh_board = GoBoard(args.size, 7.0, False)
-    plies = np.array([b.moves - 1 for b in boards], dtype=np.int64)
     for _ in range(args.warmup):
-        run_step(engine, plies, fresh_board, args.visits, args.batch)
+        run_step(engines, plies_list, fresh_board, args.visits, args.batch)
     evaluator.record = True
     barrier()
     t0 = time.perf_counter()
     leaves = 0
     for _ in range(args.steps):
-        leaves += run_step(engine, plies, fresh_board, args.visits, args.batch)
+        leaves += run_step(engines, plies_list, fresh_board, args.visits, args.batch)
     barrier()
     elapsed = time.perf_counter() - t0
 
@@ -229,7 +252,7 @@ def main():
         ms = e0.elapsed_time(e1)
         kern_ms += ms
         kern_pos += b
-        if b == args.trees * args.batch:
+        if b == sizes[0] * args.batch:
             big.append(ms)
     flops_pos = lib.tg_net_flops_per_position(args.size)
 
@@ -242,7 +265,7 @@ def main():
         leaves = float(tot.item())
 
     if rank == 0:
-        full_b = args.trees * args.batch
+        full_b = sizes[0] * args.batch
         avg_ms = float(np.mean(big)) if big else float("nan")
         achieved = full_b * flops_pos / (avg_ms * 1e-3) / 1e12 if big else float("nan")
         traffic, mfma_busy = pmc_traffic(args.size, full_b)
@@ -264,6 +287,7 @@ def main():
                 "workload": f"cfg-2 PUCT {args.size}x{args.size}, random-init DualNet, "
                             f"{args.visits} strict visits/move, NN batch {args.batch} per tree",
                 "trees_per_gpu": args.trees,
+                "lockstep_groups_per_gpu": n_groups,
                 "leaf_evals_per_step_per_gpu": args.trees * (args.visits + 1),
                 "parallelism": f"{world} x independent board shards (no collective)",
             },
@@ -299,10 +323,11 @@ def main():
                                device_index=local_rank)
             one.set_root(0, fresh_board, 1, np.random.RandomState(7).get_state())
             p1 = np.zeros(1, dtype=np.int64)
-            run_step(one, p1, fresh_board, args.visits, args.batch)
+            cur = torch.cuda.current_stream(dev)
+            run_step([(one, cur)], [p1], fresh_board, args.visits, args.batch)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            n1 = sum(run_step(one, p1, fresh_board, args.visits, args.batch) for _ in range(5))
+            n1 = sum(run_step([(one, cur)], [p1], fresh_board, args.visits, args.batch) for _ in range(5))
             torch.cuda.synchronize()
             dt1 = time.perf_counter() - t1
             result["single_tree"] = {"value": n1 / dt1, "unit": "leaf-evals/s",
@@ -315,7 +340,8 @@ def main():
                 import shutil
                 import tempfile
                 from tamago_amd.selfplay.worker import selfplay_shard
-                engine.close()
+                for eng, _ in engines:
+                    eng.close()
                 torch.cuda.synchronize()
                 out_dir = tempfile.mkdtemp(prefix="tg_sp_")
                 nb = args.selfplay_boards
