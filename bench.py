@@ -357,7 +357,7 @@ def main():
                                                   "lock-step boards, SGF records written"}
             except Exception as exc:                      # the headline must not depend on this leg
                 result["selfplay"] = {"error": repr(exc)}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # rank 0 at N = 1 only
             result["cpu_baseline"] = cpu_baseline(args.size, args.visits, args.batch,
                                                   args.cpu_seconds)
         print(json.dumps(result), flush=True)
