@@ -23,6 +23,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -41,7 +42,9 @@ constexpr int kWinoRowBytes = kWinoRowFloats * 4;   // 272
 struct NetDev {
     const float *w0frag;  // [4 wave][9 tap][64 lane][2]         stem 6->64 (cin padded to 8)
     const float *wfrag;   // [12 layer][4 wave][9 tap][4 s][64 lane][4]
-    const float *wwino;   // [12 layer][4 wave][16 xi][4 s][64 lane][4]  Winograd G g G^T, fragment order
+    const float *wwino;   // [12 layer][4 wave][4 s][16 xi][64 lane][4]  Winograd G g G^T, fragment order
+                          // (the 16 fragments of a work unit are 16 contiguous KB: two address bases reach them
+                          //  all through the +-4 KB immediate of global_load)
     const float *scale;   // [13][64] folded BN scale
     const float *shift;   // [13][64] folded BN shift
     const float *hp_w;    // [2][64]  policy 1x1 conv
@@ -543,8 +546,8 @@ __global__ __launch_bounds__(512, 2) void dualnet_fwd_wino8_kernel(
             f32x4 wq[4][2];
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                wq[r][0] = wl[((2 * r) * 4) * 64];
-                wq[r][1] = wl[((2 * r + 1) * 4) * 64];
+                wq[r][0] = wl[(2 * r) * 64];
+                wq[r][1] = wl[(2 * r + 1) * 64];
             }
 #pragma unroll 1
             for (int it = 0; it < n_own; ++it) {
@@ -560,10 +563,10 @@ __global__ __launch_bounds__(512, 2) void dualnet_fwd_wino8_kernel(
                     a16[pq] = (addr & ok) | (lane_zero & ~ok);
                 }
                 f32x4 macc[16];
-#pragma unroll
-                for (int xi = 0; xi < 16; ++xi) macc[xi] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-                for (int s = 0; s < 4; ++s) {
+                // one work unit = (row-tile, 16-channel slice s).  The first slice is a second copy
+                // of the body whose MFMAs start from a zero literal (no 64-register clearing sweep).
+                auto unit = [&](const int s, auto first_tag) {
+                    constexpr bool FIRST = decltype(first_tag)::value;
                     f32x4 d[16];
 #pragma unroll
                     for (int pq = 0; pq < 16; ++pq) {
@@ -596,20 +599,25 @@ __global__ __launch_bounds__(512, 2) void dualnet_fwd_wino8_kernel(
                             const int f = st + 3;
                             const int nx = 2 * (f & 7);
                             const int ns = f < 8 ? s : ((s + 1) & 3);
-                            wq[f & 3][0] = wl[(nx * 4 + ns) * 64];
-                            wq[f & 3][1] = wl[((nx + 1) * 4 + ns) * 64];
+                            wq[f & 3][0] = wl[(ns * 16 + nx) * 64];
+                            wq[f & 3][1] = wl[(ns * 16 + nx + 1) * 64];
                         }
                         __builtin_amdgcn_sched_barrier(0);       // keep the fetch at the head of its step
                         const f32x4 b0v = wq[st & 3][0], b1v = wq[st & 3][1];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            macc[xp] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0v[j], d[xp][j], macc[xp], 0, 0, 0);
-                            macc[xp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1v[j], d[xp + 1][j], macc[xp + 1], 0, 0, 0);
+                            const f32x4 c0 = (FIRST && j == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : macc[xp];
+                            const f32x4 c1 = (FIRST && j == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : macc[xp + 1];
+                            macc[xp] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0v[j], d[xp][j], c0, 0, 0, 0);
+                            macc[xp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1v[j], d[xp + 1][j], c1, 0, 0, 0);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     __builtin_amdgcn_s_setprio(0);
-                }
+                };
+                unit(0, std::true_type{});
+#pragma unroll 1
+                for (int s = 1; s < 4; ++s) unit(s, std::false_type{});
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {                // Y = A^T M A
                     const f32x4 m0 = macc[b] + macc[4 + b] + macc[8 + b];
@@ -833,7 +841,7 @@ int tg_net_create(int board_size, int device, const float *params, size_t n_para
                     const int wv = cout / 16, n = cout % 16, sgrp = cin / 16, gq = (cin % 16) / 4, j = cin % 4;
                     const int lane = gq * 16 + n;
                     for (int xi = 0; xi < 16; ++xi)
-                        ww[(((((size_t)layer * 4 + wv) * 16 + xi) * 4 + sgrp) * 64 + lane) * 4 + j] =
+                        ww[(((((size_t)layer * 4 + wv) * 4 + sgrp) * 16 + xi) * 64 + lane) * 4 + j] =
                             (float)u[xi / 4][xi % 4];
                 }
         }
