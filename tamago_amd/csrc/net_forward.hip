@@ -54,6 +54,7 @@ struct NetDev {
     const float *pfc_b;   // [A]
     const float *vfc_w;   // [3][P]
     const float *vfc_b;   // [3]
+    float *scratch;       // 19x19 Winograd: per workgroup two [P][64] activation images (L2-resident)
     long long *timeline;  // optional [128] s_memtime stamps of workgroup 0 (tg_net_profile_phases)
 };
 
@@ -402,7 +403,7 @@ __global__ __launch_bounds__(256, (FwdCfg<S, G>::WAVES_PER_SIMD)) void dualnet_f
 // operand - also receives that tile's outputs for channels 16w+4lg..+3.
 // Work unit = (row-tile, 16 input channels): 16 ds_read_b128 -> in-register input transform
 // -> 64 MFMAs into 16 accumulators.
-template <int S, int G>
+template <int S, int G, bool GS = false>
 struct WinoCfg {
     static constexpr int P = S * S;
     static constexpr int A = P + 1;
@@ -413,9 +414,13 @@ struct WinoCfg {
     static constexpr int NT = G * TPB;
     static constexpr int RT = (NT + 15) / 16;       // row-tiles of 16 Winograd tiles
     static constexpr int ROW_BYTES = kWinoRowBytes;
+    // GS ("global scratch", 19x19): two 98 KB buffers do not fit into 160 KB of LDS, so LDS holds
+    // only the input of the current layer; layer outputs go to a per-workgroup scratch image in
+    // global memory (L2-resident) and are copied back into LDS behind the layer barrier
+    static constexpr int NBUF = GS ? 1 : 2;
     static constexpr int BUF_A = 0;
-    static constexpr int BUF_B = M * kWinoRowBytes;
-    static constexpr int ZROW = 2 * M * kWinoRowBytes;
+    static constexpr int BUF_B = GS ? 0 : M * kWinoRowBytes;
+    static constexpr int ZROW = NBUF * M * kWinoRowBytes;
     static constexpr int AUX = ZROW + kWinoRowBytes;          // in8 staging / head scratch
     static constexpr int AUX_BYTES = M * 32;
     static constexpr int ZERO8 = AUX + AUX_BYTES;
@@ -430,11 +435,11 @@ struct WinoCfg {
 // the loop is trimmed for instruction count: packed subtractions (sub4), patch addresses from
 // per-lane geometry computed once (3 VALU each per row-tile, one add per slice), a weight
 // ring that runs on across row-tiles.
-template <int S, int G>
+template <int S, int G, bool GS = false>
 __global__ __launch_bounds__(512, 2) void dualnet_fwd_wino8_kernel(
     NetDev net, const float *__restrict__ planes, int batch, int want_logits,
     float *__restrict__ policy, float *__restrict__ value) {
-    using C = WinoCfg<S, G>;
+    using C = WinoCfg<S, G, GS>;
     constexpr int P = C::P, M = C::M, MT = C::MT;
     constexpr int TY = C::TY, TPB = C::TPB, NT = C::NT, RT = C::RT;
     constexpr int MTH = (MT + 1) / 2;                 // stem M-tiles per half
@@ -468,11 +473,11 @@ __global__ __launch_bounds__(512, 2) void dualnet_fwd_wino8_kernel(
     constexpr int RTH = (RT + 1) / 2;
     const int rt_begin = half == 0 ? 0 : RTH;
     const int n_own = half == 0 ? RTH : RT - RTH;
-    int base_rel[3];
-    unsigned valid[3];
-    static_assert(RTH <= 3, "geometry registers are sized for three row-tiles per wave");
+    int base_rel[RTH];
+    int base_row[RTH];                                // row index of the patch origin (global scratch addressing)
+    unsigned valid[RTH];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
+    for (int r = 0; r < RTH; ++r) {
         const int t = (rt_begin + r) * 16 + li;
         const int bl = t / TPB;
         const int tl = t - bl * TPB;
@@ -485,8 +490,12 @@ __global__ __launch_bounds__(512, 2) void dualnet_fwd_wino8_kernel(
             if (r < n_own && t < NT && y >= 0 && y < S && x >= 0 && x < S) m |= 1u << pq;
         }
         valid[r] = m;
-        base_rel[r] = (r < n_own && t < NT) ? (bl * P + y0 * S + x0) * kWinoRowBytes + lg * 16 : 0;
+        base_row[r] = (r < n_own && t < NT) ? bl * P + y0 * S + x0 : 0;
+        base_rel[r] = base_row[r] * kWinoRowBytes + lg * 16;
     }
+    // global scratch images of this workgroup: X (block input / output) and H (intermediate)
+    float *gx = GS ? net.scratch + (size_t)blockIdx.x * 2 * M * 64 : nullptr;
+    float *gh = GS ? gx + (size_t)M * 64 : nullptr;
     const int n_groups = (batch + G - 1) / G;
     for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
         const int b0 = grp * G;
@@ -525,6 +534,7 @@ __global__ __launch_bounds__(512, 2) void dualnet_fwd_wino8_kernel(
                 for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(acc[m][j], sc[j], sh[j]), 0.f);
                 const int r = (half * MTH + m) * 16 + li;
                 if (r < M) *reinterpret_cast<f32x4 *>(smem + C::BUF_A + r * kWinoRowBytes + wave * 64 + lg * 16) = v;
+                if (GS && r < M) *reinterpret_cast<f32x4 *>(gx + (size_t)r * 64 + wave * 16 + lg * 4) = v;
             }
         }
         __syncthreads();
@@ -533,8 +543,9 @@ __global__ __launch_bounds__(512, 2) void dualnet_fwd_wino8_kernel(
 #pragma unroll 1
         for (int layer = 1; layer < kConvLayers; ++layer) {
             const bool conv2 = (layer & 1) == 0;
-            const int in_off = conv2 ? C::BUF_B : C::BUF_A;
+            const int in_off = GS ? C::BUF_A : (conv2 ? C::BUF_B : C::BUF_A);
             const int out_off = conv2 ? C::BUF_A : C::BUF_B;
+            float *gout = conv2 ? gx : gh;            // (GS) conv1 writes H, conv2 adds X and overwrites it
             const f32x4 *wl = reinterpret_cast<const f32x4 *>(net.wwino) +
                               ((size_t)((layer - 1) * 4 + wave) * 16) * 4 * 64 + lane;
             const f32x4 sc = *reinterpret_cast<const f32x4 *>(net.scale + layer * 64 + wave * 16 + lg * 4);
@@ -552,8 +563,14 @@ __global__ __launch_bounds__(512, 2) void dualnet_fwd_wino8_kernel(
 #pragma unroll 1
             for (int it = 0; it < n_own; ++it) {
                 // patch addresses of this row-tile: 3 VALU each from the per-lane geometry
-                const int brel = it == 0 ? base_rel[0] : (it == 1 ? base_rel[1] : base_rel[2]);
-                const unsigned vm = it == 0 ? valid[0] : (it == 1 ? valid[1] : valid[2]);
+                int brel = base_rel[0], brow = base_row[0];
+                unsigned vm = valid[0];
+#pragma unroll
+                for (int r = 1; r < RTH; ++r) {
+                    brel = it == r ? base_rel[r] : brel;
+                    brow = it == r ? base_row[r] : brow;
+                    vm = it == r ? valid[r] : vm;
+                }
                 const int base = in_off + brel;
                 int a16[16];
 #pragma unroll
@@ -634,18 +651,39 @@ __global__ __launch_bounds__(512, 2) void dualnet_fwd_wino8_kernel(
                 for (int o = 0; o < 4; ++o) {
                     const int py = 1 + (o >> 1), px = 1 + (o & 1);     // output o sits on patch cell (py, px)
                     if ((vm >> (py * 4 + px)) & 1u) {
-                        unsigned char *dst = smem + out_off + brel + (py * S + px) * kWinoRowBytes + wave * 64;
                         f32x4 v;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] = fmaf(yv[o][j], sc[j], sh[j]);
-                        if (conv2) v += *reinterpret_cast<const f32x4 *>(dst);
+                        if (GS) {
+                            f32x4 *dst = reinterpret_cast<f32x4 *>(gout + (size_t)(brow + py * S + px) * 64 + wave * 16 + lg * 4);
+                            if (conv2) v += *dst;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-                        *reinterpret_cast<f32x4 *>(dst) = v;
+                            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                            *dst = v;
+                        } else {
+                            unsigned char *dst = smem + out_off + brel + (py * S + px) * kWinoRowBytes + wave * 64;
+                            if (conv2) v += *reinterpret_cast<const f32x4 *>(dst);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                            *reinterpret_cast<f32x4 *>(dst) = v;
+                        }
                     }
                 }
             }
             stamp();                              // 2 + 2k: layer work of this wave done
+            if (GS) {
+                // outputs are in the scratch image: make them visible, wait until every wave has
+                // finished reading the LDS input, then load them as the next layer's input
+                // workgroup scope is enough (all waves share this CU's write-through L1); an agent-scope
+                // fence writes back / invalidates L2 state and cost 3x the whole layer
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __syncthreads();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                const f32x4 *src = reinterpret_cast<const f32x4 *>(gout);
+                for (int e = tid; e < M * 16; e += 512)
+                    *reinterpret_cast<f32x4 *>(smem + C::BUF_A + (e >> 4) * kWinoRowBytes + (e & 15) * 16) =
+                        __builtin_nontemporal_load(src + e);
+            }
             __syncthreads();
             stamp();                              // 3 + 2k: barrier passed
         }
@@ -726,11 +764,11 @@ int launch(tg_net *net, const float *planes, int batch, int want_logits, float *
     return TG_OK;
 }
 
-template <int S, int G>
+template <int S, int G, bool GS = false>
 int launch_wino8(tg_net *net, const float *planes, int batch, int want_logits, float *policy,
                  float *value, hipStream_t stream) {
-    using C = WinoCfg<S, G>;
-    auto kern = dualnet_fwd_wino8_kernel<S, G>;
+    using C = WinoCfg<S, G, GS>;
+    auto kern = dualnet_fwd_wino8_kernel<S, G, GS>;
     static bool attr_set[16] = {};
     if (!attr_set[net->device & 15]) {
         TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -872,6 +910,16 @@ int tg_net_create(int board_size, int device, const float *params, size_t n_para
         return tg::fail(TG_ERR_ARG, "tg_net_create: parameter blob not fully consumed");
     }
 
+    if (board_size == 19) {       // scratch images of the Winograd kernel: 2 x [P][64] floats per workgroup
+        void *d = nullptr;
+        hipError_t e = hipMalloc(&d, (size_t)net->num_cus * 2 * P * 64 * sizeof(float));
+        if (e != hipSuccess) {
+            delete net;
+            return tg::fail(TG_ERR_HIP, "tg_net_create: scratch: %s", hipGetErrorString(e));
+        }
+        net->allocs.push_back(d);
+        net->dev.scratch = static_cast<float *>(d);
+    }
     int rc = TG_OK;
     if ((rc = upload(net, w0, &net->dev.w0frag)) || (rc = upload(net, wf, &net->dev.wfrag)) || (rc = upload(net, ww, &net->dev.wwino)) ||
         (rc = upload(net, scale, &net->dev.scale)) || (rc = upload(net, shift, &net->dev.shift)) ||
@@ -912,7 +960,8 @@ static int pick_wino(int board_size, int batch, int num_cus);
 
 const char *tg_net_kernel_name(const tg_net *net, int batch) {
     if (!net) return "";
-    if (net->board_size == 19) return "dualnet_fwd_kernel<19, 1>";
+    if (net->board_size == 19)
+        return pick_wino(19, batch, net->num_cus) ? "dualnet_fwd_wino8_kernel<19, 1, global scratch>" : "dualnet_fwd_kernel<19, 1>";
     {
         const int wg = pick_wino(9, batch, net->num_cus);
         if (wg == 1) return "dualnet_fwd_wino8_kernel<9, 1>";
@@ -927,10 +976,13 @@ const char *tg_net_kernel_name(const tg_net *net, int batch) {
 // Measured on MI355X (tools/bench_net.py): B <= 256: 173 us (direct 194); B = 512: 308 (347);
 // B >= 768: 98 % vs 83 % of the fp32 MFMA peak in algorithmic FLOPs.
 static int pick_wino(int board_size, int batch, int num_cus) {
-    if (board_size != 9) return 0;                    // 19x19: two 104 KB buffers do not fit in LDS
     if (const char *env = getenv("TG_FWD_ALGO")) {
         if (!strcmp(env, "direct")) return 0;
     }
+    // 19x19: two 98 KB activation buffers do not fit in LDS; the Winograd kernel keeps one and
+    // passes layer outputs through a per-workgroup scratch image in global memory
+    if (board_size == 19) return 1;    // measured: 553 vs 648 us at B <= 256, 92 % vs 80 % of peak at B >= 1024
+    if (board_size != 9) return 0;
     if (const char *env = getenv("TG_FWD_WINO")) {
         const int g = atoi(env) % 10;                 // 81 / 82 / 83 (or 1 / 2 / 3)
         if (g >= 1 && g <= 3) return g;
@@ -947,8 +999,11 @@ int tg_net_forward_dev(tg_net *net, const float *planes_dev, int batch, int want
     if (!net || !planes_dev || !policy_dev || !value_dev)
         return tg::fail(TG_ERR_ARG, "tg_net_forward_dev: null argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (net->board_size == 19)
+    if (net->board_size == 19) {
+        if (pick_wino(19, batch, net->num_cus))
+            return launch_wino8<19, 1, true>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st);
         return launch<19, 1>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st);
+    }
     if (net->board_size == 9) {
         const int wg = pick_wino(9, batch, net->num_cus);
         if (wg == 1) return launch_wino8<9, 1>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st);

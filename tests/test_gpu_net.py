@@ -116,20 +116,23 @@ def test_featurize_kernel_vs_reference_golden(size):
     assert np.array_equal(out.cpu().numpy(), np.array(want))
 
 
+@pytest.mark.parametrize("size", [9, 19])
 @pytest.mark.parametrize("algo", ["direct", "winograd"])
-def test_both_tower_algorithms_match_the_oracle(algo, monkeypatch):
-    """9x9 has two implementations of the residual tower: the Winograd F(2x2,3x3) kernel
-    (default) and the direct implicit-GEMM kernel (TG_FWD_ALGO=direct; also the 19x19 path).
-    Both are exact fp32 and must agree with the oracle at every workgroup shape."""
+def test_both_tower_algorithms_match_the_oracle(algo, size, monkeypatch):
+    """Two implementations of the residual tower per board size: the Winograd F(2x2,3x3) kernel
+    (default; at 19x19 with the layer outputs passing through a global scratch image) and the
+    direct implicit-GEMM kernel (TG_FWD_ALGO=direct).  Both are exact fp32 and must agree with the
+    oracle at every workgroup shape."""
     from oracle.net import OracleNet, make_state_dict
     if algo == "direct":
         monkeypatch.setenv("TG_FWD_ALGO", "direct")
-    sd = make_state_dict(9, 7, 1.5)
-    net = _net(9, sd)
+    sd = make_state_dict(size, 7, 1.5)
+    net = _net(size, sd)
     ora = OracleNet(sd)
     rs = np.random.RandomState(11)
-    for b in (1, 5, 256, 300, 512, 1301):          # G = 1 / 2 / 3 boards per workgroup, ragged tails
-        x = torch.from_numpy(rs.randint(-1, 2, size=(b, 6, 9, 9)).astype(np.float32))
+    # 9x9: G = 1 / 2 / 3 boards per workgroup, ragged tails; 19x19: fewer / more boards than CUs
+    for b in ((1, 5, 256, 300, 512, 1301) if size == 9 else (1, 3, 300)):
+        x = torch.from_numpy(rs.randint(-1, 2, size=(b, 6, size, size)).astype(np.float32))
         rp, rv = ora.inference(x)
         pol, val = net.inference(x)
         assert np.abs(pol.numpy() - rp.numpy()).max() < TOL, (algo, b)
