@@ -635,6 +635,18 @@ __global__ __launch_bounds__(512, 2) void dualnet_fwd_wino8_kernel(
                 unit(0, std::true_type{});
 #pragma unroll 1
                 for (int s = 1; s < 4; ++s) unit(s, std::false_type{});
+                // (GS) the block input of the four output cells comes from the scratch image: request it
+                // before the output transform so that its latency overlaps the transform
+                f32x4 resid[4];
+                if (GS && conv2) {
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) {
+                        const int py = 1 + (o >> 1), px = 1 + (o & 1);
+                        const bool ok = (vm >> (py * 4 + px)) & 1u;
+                        resid[o] = ok ? *reinterpret_cast<const f32x4 *>(gout + (size_t)(brow + py * S + px) * 64 + wave * 16 + lg * 4)
+                                      : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {                // Y = A^T M A
                     const f32x4 m0 = macc[b] + macc[4 + b] + macc[8 + b];
@@ -656,7 +668,7 @@ __global__ __launch_bounds__(512, 2) void dualnet_fwd_wino8_kernel(
                         for (int j = 0; j < 4; ++j) v[j] = fmaf(yv[o][j], sc[j], sh[j]);
                         if (GS) {
                             f32x4 *dst = reinterpret_cast<f32x4 *>(gout + (size_t)(brow + py * S + px) * 64 + wave * 16 + lg * 4);
-                            if (conv2) v += *dst;
+                            if (conv2) v += resid[o];
 #pragma unroll
                             for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
                             *dst = v;
