@@ -31,7 +31,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix
-PMC_SUMMARY = os.path.join(REPO, "profiles", "r01d_pmc_forward_wino_9x9_b65536.json")
+PMC_SUMMARY = os.path.join(REPO, "profiles", "r01e_pmc_forward_wino_9x9_b65536.json")
 
 
 def pmc_traffic(size, positions):
