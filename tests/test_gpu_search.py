@@ -318,3 +318,24 @@ def test_search_with_callback_and_ponder():
     root = pond.get_root()
     assert root.node_visits == 1 and pond.num_nodes == 2                # root + the one descent that expanded a child
     assert text.startswith("info move ") and text.endswith("\n")
+
+
+@pytest.mark.parametrize("cfg", ["9 24 64 4", "9 1 256 4", "19 6 32 4"])
+def test_pipelined_selection_equals_serial(cfg):
+    """select_puct_pipe_kernel (selector + two worker wavefronts per tree, the default) builds
+    exactly the trees of the one-wavefront kernel (TG_SELECT_SERIAL=1): ragged roots, superko,
+    several mini-batches with a short last one."""
+    import os
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_select_digest.py")
+    outs = []
+    for serial in (True, False, False):
+        env = dict(os.environ)
+        env.pop("TG_SELECT_SERIAL", None)
+        if serial:
+            env["TG_SELECT_SERIAL"] = "1"
+        res = subprocess.run([sys.executable, script] + cfg.split(), env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        outs.append(res.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1] == outs[2], outs
