@@ -1018,40 +1018,55 @@ __global__ __launch_bounds__(192) void select_puct_pipe_kernel(SearchDev D, int 
 }
 
 // tree.py:273-315 process_mini_batch for the leaves queued by the preceding kernel.
+// Two wavefronts per tree on disjoint data: wave 1 writes the policies back (lane-parallel,
+// independent per leaf), wave 0 walks the values leaf -> root in leaf order (the float32
+// accumulation order is part of the contract) with the next leaf's scalars already requested.
 template <int S>
-__global__ __launch_bounds__(64) void backup_kernel(SearchDev D, const float *policy, const float *value,
-                                                    int stride, const int32_t *leaf_off, int use_logit) {
+__global__ __launch_bounds__(128) void backup_kernel(SearchDev D, const float *policy, const float *value,
+                                                     int stride, const int32_t *leaf_off, int use_logit) {
     using G = Geo<S>;
     constexpr int A = G::A, W = G::W, P = G::P;
-    const int t = blockIdx.x, lane = threadIdx.x;
+    const int t = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int n = D.n_leaves[t];
     const size_t leaf_base = leaf_off ? (size_t)leaf_off[t] : (size_t)t * stride;
-    for (int k = 0; k < n; ++k) {
-        const size_t slot = (size_t)t * D.K + k;
-        int node = D.q_node[slot];
-        if (node < 0) node = D.N - 1;                 // node[-1]: Gumbel leaves (tree.py:412-416)
-        const size_t ns = (size_t)t * D.N + node;
-        const size_t base = ns * A;
-        const float *pol = policy + (leaf_base + k) * A;
-        const float *val = value + (leaf_base + k) * 3;
+    __syncthreads();          // both waves have read the leaf count before wave 0 may reset it
+    if (wid == 1) {
         // node.py:86-93 update_policy via the {pos: policy} map of tree.py:287-295
-        const int nc = D.n_children[ns];
-        for (int i = lane; i < nc; i += 64) {
-            const int pos = D.action[base + i];
-            float pv;
-            if (pos == 0) {
-                pv = pol[P];
-                if (use_logit) pv = pv - 0.5f;
-            } else {
-                pv = pol[(pos / W - 1) * S + (pos % W) - 1];
+        for (int k = 0; k < n; ++k) {
+            int node = D.q_node[(size_t)t * D.K + k];
+            if (node < 0) node = D.N - 1;             // node[-1]: Gumbel leaves (tree.py:412-416)
+            const size_t ns = (size_t)t * D.N + node;
+            const size_t base = ns * A;
+            const float *pol = policy + (leaf_base + k) * A;
+            const int nc = D.n_children[ns];
+            for (int i = lane; i < nc; i += 64) {
+                const int pos = D.action[base + i];
+                float pv;
+                if (pos == 0) {
+                    pv = pol[P];
+                    if (use_logit) pv = pv - 0.5f;
+                } else {
+                    pv = pol[(pos / W - 1) * S + (pos % W) - 1];
+                }
+                D.ch_policy[base + i] = (double)pv;
             }
-            D.ch_policy[base + i] = (double)pv;
         }
-        const float v0 = val[0], v1 = val[1], v2 = val[2];
-        if (lane == 0) {
-            D.n_raw[ns] = v1 * 0.5f + v2;             // tree.py:299
-            int cur = D.q_pnode[slot];
-            int e = D.q_pedge[slot];
+        return;
+    }
+    if (lane == 0 && n > 0) {
+        size_t slot = (size_t)t * D.K;
+        int node = D.q_node[slot], cur = D.q_pnode[slot], e = D.q_pedge[slot];
+        const float *val = value + leaf_base * 3;
+        float v0 = val[0], v1 = val[1], v2 = val[2];
+        for (int k = 0; k < n; ++k) {
+            // request the next leaf's scalars before walking this one
+            const int kn = k + 1 < n ? k + 1 : k;
+            const size_t slot_n = (size_t)t * D.K + kn;
+            const int node_n = D.q_node[slot_n], cur_n = D.q_pnode[slot_n], e_n = D.q_pedge[slot_n];
+            const float *val_n = value + (leaf_base + kn) * 3;
+            const float v0_n = val_n[0], v1_n = val_n[1], v2_n = val_n[2];
+            if (node < 0) node = D.N - 1;
+            D.n_raw[(size_t)t * D.N + node] = v1 * 0.5f + v2;             // tree.py:299
             if (cur >= 0) {
                 float v = v0 + v1 * 0.5f;             // tree.py:302
                 D.ch_value[((size_t)t * D.N + cur) * A + e] = (double)v;   // set_leaf_value
@@ -1076,10 +1091,11 @@ __global__ __launch_bounds__(64) void backup_kernel(SearchDev D, const float *po
                     cur = pn;
                 }
             }
+            node = node_n; cur = cur_n; e = e_n;
+            v0 = v0_n; v1 = v1_n; v2 = v2_n;
         }
-        wave_sync();
     }
-    if (lane == 0) D.n_leaves[t] = 0;
+    if (threadIdx.x == 0) D.n_leaves[t] = 0;
 }
 
 
@@ -1896,9 +1912,9 @@ int tg_search_backup(tg_search *s, const float *policy_dev, const float *value_d
     s->last_stream = st;
     const int32_t *off = packed ? s->phase_dev + 2 * (size_t)s->dev.T : nullptr;
     if (s->S == 9)
-        hipLaunchKernelGGL(backup_kernel<9>, dim3(s->dev.T), dim3(64), 0, st, s->dev, policy_dev, value_dev, slots_per_tree, off, use_logit);
+        hipLaunchKernelGGL(backup_kernel<9>, dim3(s->dev.T), dim3(128), 0, st, s->dev, policy_dev, value_dev, slots_per_tree, off, use_logit);
     else
-        hipLaunchKernelGGL(backup_kernel<19>, dim3(s->dev.T), dim3(64), 0, st, s->dev, policy_dev, value_dev, slots_per_tree, off, use_logit);
+        hipLaunchKernelGGL(backup_kernel<19>, dim3(s->dev.T), dim3(128), 0, st, s->dev, policy_dev, value_dev, slots_per_tree, off, use_logit);
     TG_HIP(hipGetLastError());
     return TG_OK;
 }
