@@ -1170,8 +1170,8 @@ __device__ int select_root_halving(const SearchDev &D, int t, int node, int coun
 
 // node.py:349-361 select_move_by_sequential_halving_for_node (+ :281-321 completed Q,
 // improved policy; nn/utility.py:125-136 softmax), float64 throughout
-template <int S>
-__device__ int select_node_halving(Lds<S> &L, const SearchDev &D, int t, int node, int lane) {
+template <int S, typename Scratch>
+__device__ int select_node_halving(Scratch &L, const SearchDev &D, int t, int node, int lane) {   // uses L.w1, L.w2
     constexpr int A = Geo<S>::A;
     constexpr int R = (A + 63) / 64;
     const size_t ns = (size_t)t * D.N + node;
@@ -1253,6 +1253,170 @@ __device__ int select_node_halving(Lds<S> &L, const SearchDev &D, int t, int nod
     wave_sync();
     wave_argmax(best, best_i);
     return best_i;
+}
+
+// ---- Gumbel / sequential-halving selection, pipelined like select_puct_pipe_kernel -----------
+// The selector walks (root: node.py:324-346, below: :349-361) and queues two kinds of jobs for
+// the workers: LEAF (replay the path, write the planes of leaf `plane_slot`) and EXPAND (replay,
+// expand the child it is about to enter - the selector then waits for exactly that job, because
+// it continues INTO the new node).  9x9 only (three LDS boards of 19x19 exceed the static limit).
+template <int S>
+struct HalvingScratch {
+    double w1[Geo<S>::A + 7];
+    double w2[Geo<S>::A + 7];
+};
+
+template <int S>
+__global__ __launch_bounds__(192) void select_gumbel_pipe_kernel(SearchDev D, const int32_t *num_considered,
+                                                                 const int32_t *max_count, int stride,
+                                                                 const int32_t *leaf_off, float *planes) {
+    using G = Geo<S>;
+    constexpr int A = G::A;
+    __shared__ PipeShared<S> sh;
+    __shared__ HalvingScratch<S> hs;
+    __shared__ int16_t sel_moves[kPipeMaxDepth];
+    const int t = blockIdx.x;
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const RootMeta meta = D.meta[t];
+    const int n0 = meta.num_nodes;
+    if (threadIdx.x < kPipeSlots) {
+        sh.job_seq[threadIdx.x] = 0;
+        sh.slot_done[threadIdx.x] = 0;
+    }
+    for (int i = threadIdx.x; i < kPipeMaxK; i += 192) sh.done[i] = 0;
+    if (threadIdx.x == 0) {
+        sh.cursor_seq = 0;
+        sh.cursor_val = D.rng_cursor[t];
+        sh.final_count = -1;
+        sh.err = 0;
+    }
+    __syncthreads();
+    const int width = num_considered[t], levels = max_count[t];
+    const size_t leaf_base = leaf_off ? (size_t)leaf_off[t] : (size_t)t * stride;
+    const bool active = D.err[t] == 0 && n0 > 0 && width * levels <= stride;
+    int num_nodes = n0;
+    int queued = 0;
+
+    if (wid == 0) {
+        // ---- selector -------------------------------------------------------------------
+        int jid = 0, nexp = 0;
+        bool ok = active;
+        auto publish = [&](int plane_slot, int parent, int edge, int child, int expand, int xseq, int depth) -> bool {
+            if (jid >= kPipeMaxK) return false;
+            const int slot = jid % kPipeSlots;
+            if (!pipe_wait_ge(&sh.slot_done[slot], jid / kPipeSlots)) return false;
+            for (int i = lane; i < depth; i += 64) sh.moves[slot][i] = sel_moves[i];
+            wave_sync();
+            if (lane == 0) {
+                PipeJob &j = sh.job[slot];
+                j.k = plane_slot; j.parent = parent; j.edge = edge; j.child = child;
+                j.expand = expand; j.xseq = xseq; j.depth = depth;
+                pipe_store(&sh.job_seq[slot], jid + 1);
+            }
+            wave_sync();
+            ++jid;
+            return true;
+        };
+        for (int th = 1; ok && th <= levels; ++th) {
+            for (int j = 0; ok && j < width; ++j) {
+                if (pipe_load(&sh.err)) { ok = false; break; }
+                int node = 0, depth = 0;
+                while (ok) {
+                    if (node >= n0) ok = pipe_wait_ge(&sh.done[sh.jobof[node - n0]], 1);
+                    if (!ok) break;
+                    const size_t ns = (size_t)t * D.N + node;
+                    const size_t base = ns * A;
+                    const int e = node == 0 ? select_root_halving<S>(D, t, node, th, lane)
+                                            : select_node_halving<S>(hs, D, t, node, lane);
+                    const int mv = D.action[base + e];
+                    const int visits = D.ch_visits[base + e];
+                    int child = D.ch_index[base + e];
+                    if (depth >= kPipeMaxDepth) { ok = false; break; }
+                    wave_sync();
+                    if (lane == 0) {
+                        sel_moves[depth] = (int16_t)mv;
+                        D.n_vl[ns] += 1;
+                        D.ch_vl[base + e] += 1;
+                    }
+                    ++depth;
+                    wave_sync();
+                    if (visits < 1) {                                     // tree.py:412-416
+                        if (lane == 0) {
+                            D.q_node[(size_t)t * D.K + queued] = child;   // still NOT_EXPANDED: node[-1]
+                            D.q_pnode[(size_t)t * D.K + queued] = node;
+                            D.q_pedge[(size_t)t * D.K + queued] = e;
+                        }
+                        ok = publish(queued, node, e, child, 0, 0, depth);
+                        if (ok) ++queued;
+                        break;
+                    }
+                    if (child == kNotExpanded) {                          // tree.py:418-420
+                        if (num_nodes >= D.N || num_nodes - n0 >= kPipeMaxK) {
+                            if (lane == 0) atomicOr(&D.err[t], kErrPoolFull);
+                            ok = false;
+                            break;
+                        }
+                        child = num_nodes++;
+                        if (lane == 0) {
+                            D.ch_index[base + e] = child;
+                            sh.jobof[child - n0] = (int16_t)jid;
+                        }
+                        wave_sync();
+                        ok = publish(-1, node, e, child, 1, nexp++, depth);
+                        if (!ok) break;
+                    }
+                    node = child;
+                }
+            }
+        }
+        if (active && !ok && lane == 0) {
+            if (!(D.err[t] & (kErrPoolFull | kErrRngEmpty))) atomicOr(&D.err[t], kErrPipeline);
+            pipe_store(&sh.err, 1);
+        }
+        if (lane == 0) pipe_store(&sh.final_count, jid);
+    } else {
+        // ---- workers ---------------------------------------------------------------------
+        Lds<S> &L = sh.board[wid - 1];
+        BoardScalars rootb;
+        int root_to_move;
+        load_root<S>(L, rootb, root_to_move, D, t, lane);
+        for (int k = wid - 1; active; k += 2) {
+            const int slot = k % kPipeSlots;
+            bool have = false, stalled = true;
+            for (int spin = 0; spin < kPipeSpinLimit; ++spin) {
+                if (pipe_load(&sh.job_seq[slot]) == k + 1) { have = true; stalled = false; break; }
+                const int fc = pipe_load(&sh.final_count);
+                if (fc >= 0 && k >= fc) { stalled = false; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (stalled && lane == 0) {
+                atomicOr(&D.err[t], kErrPipeline);
+                pipe_store(&sh.err, 1);
+            }
+            if (!have) break;
+            const PipeJob j = sh.job[slot];
+            reset_work<S>(L, lane);
+            BoardScalars b = rootb;
+            int c = root_to_move;
+            for (int i = 0; i < j.depth; ++i) {
+                put_stone<S>(L, b, sh.moves[slot][i], c, D.zob, lane);
+                c = 3 - c;
+            }
+            if (j.expand) expand_node_pipe<S>(L, b, c, D, t, j.child, j.parent, j.edge, j.xseq, sh, lane);
+            if (j.k >= 0) write_planes<S>(L, b, c, planes + (leaf_base + j.k) * 6 * G::P, lane);
+            wave_sync();
+            if (lane == 0) {
+                pipe_store(&sh.done[k], 1);
+                pipe_store(&sh.slot_done[slot], k / kPipeSlots + 1);
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        D.meta[t].num_nodes = num_nodes;
+        D.n_leaves[t] = queued;
+        D.rng_cursor[t] = sh.cursor_val;
+    }
 }
 
 // tree.py:359-422: one sequential-halving phase per launch: for threshold 1..max_count,
@@ -1890,7 +2054,11 @@ int tg_search_select_gumbel(tg_search *s, const int32_t *num_considered_host, co
     }
     s->packed_leaves = packed;
     const int32_t *off = packed ? s->phase_dev + 2 * (size_t)T : nullptr;
-    if (s->S == 9)
+    static const bool force_serial = getenv("TG_SELECT_SERIAL") != nullptr;
+    if (s->S == 9 && !force_serial && limit <= kPipeMaxK / 2)
+        hipLaunchKernelGGL(select_gumbel_pipe_kernel<9>, dim3(T), dim3(192), 0, st, s->dev, s->phase_dev,
+                           s->phase_dev + T, limit, off, planes_dev);
+    else if (s->S == 9)
         hipLaunchKernelGGL(select_gumbel_kernel<9>, dim3(T), dim3(64), 0, st, s->dev, s->phase_dev,
                            s->phase_dev + T, limit, off, planes_dev);
     else
