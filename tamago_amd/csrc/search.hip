@@ -73,6 +73,9 @@ struct SearchDev {
     RootMeta *meta;             // [T]
     // leaf queue, [T][K]
     int32_t *q_node, *q_pnode, *q_pedge;
+    // optional root->leaf path of a queued leaf, (node << 10 | edge) per level, kPathCap entries per slot;
+    // q_depth = number of levels (0: not recorded - the backup then follows the parent pointers)
+    int32_t *q_depth, *q_path;
     int32_t *n_leaves;          // [T]
     // random stream
     const double *rng;          // [T][rng_cap]  e_i = -log(1-u_i)
@@ -84,6 +87,7 @@ struct SearchDev {
     int32_t T, N, K, cgos, superko;
 };
 
+constexpr int kPathCap = 24;
 enum : int32_t { kErrPoolFull = 1, kErrRngEmpty = 2, kErrPipeline = 4 };
 
 template <int S>
@@ -667,6 +671,7 @@ __global__ __launch_bounds__(64) void root_kernel(SearchDev D, float *planes) { 
         D.q_node[(size_t)t * D.K] = root;
         D.q_pnode[(size_t)t * D.K] = -1;
         D.q_pedge[(size_t)t * D.K] = -1;
+        D.q_depth[(size_t)t * D.K] = 0;
         D.n_leaves[t] = root >= 0 ? 1 : 0;
     }
 }
@@ -730,6 +735,7 @@ __global__ __launch_bounds__(64) void select_puct_kernel(SearchDev D, int max_le
                         D.q_node[(size_t)t * D.K + k] = child;
                         D.q_pnode[(size_t)t * D.K + k] = node;
                         D.q_pedge[(size_t)t * D.K + k] = e;
+                        D.q_depth[(size_t)t * D.K + k] = 0;
                     }
                     wave_sync();
                     lap(5);
@@ -923,6 +929,7 @@ __global__ __launch_bounds__(192) void select_puct_pipe_kernel(SearchDev D, int 
                     sh.moves[slot][depth] = (int16_t)mv;
                     D.n_vl[ns] = pick.node_vl + 1;                             // node.py:76-83
                     D.ch_vl[base + e] = pick.edge_vl + 1;
+                    if (depth < kPathCap) D.q_path[((size_t)t * D.K + k) * kPathCap + depth] = (node << 10) | e;
                 }
                 ++depth;
                 prevprev = prev;
@@ -955,6 +962,7 @@ __global__ __launch_bounds__(192) void select_puct_pipe_kernel(SearchDev D, int 
                         D.q_node[(size_t)t * D.K + k] = child;
                         D.q_pnode[(size_t)t * D.K + k] = node;
                         D.q_pedge[(size_t)t * D.K + k] = e;
+                        D.q_depth[(size_t)t * D.K + k] = (depth <= kPathCap && D.N <= (1 << 21)) ? depth : 0;
                         pipe_store(&sh.job_seq[slot], k + 1);
                     }
                     wave_sync();
@@ -1018,11 +1026,13 @@ __global__ __launch_bounds__(192) void select_puct_pipe_kernel(SearchDev D, int 
 }
 
 // tree.py:273-315 process_mini_batch for the leaves queued by the preceding kernel.
-// Two wavefronts per tree on disjoint data: wave 1 writes the policies back (lane-parallel,
+// Wavefronts of a tree work on disjoint data: waves 1.. write the policies back (lane-parallel,
 // independent per leaf), wave 0 walks the values leaf -> root in leaf order (the float32
 // accumulation order is part of the contract) with the next leaf's scalars already requested.
+constexpr int kPolicyWaves = 7;
+
 template <int S>
-__global__ __launch_bounds__(128) void backup_kernel(SearchDev D, const float *policy, const float *value,
+__global__ __launch_bounds__(64 * (1 + kPolicyWaves)) void backup_kernel(SearchDev D, const float *policy, const float *value,
                                                      int stride, const int32_t *leaf_off, int use_logit) {
     using G = Geo<S>;
     constexpr int A = G::A, W = G::W, P = G::P;
@@ -1030,11 +1040,21 @@ __global__ __launch_bounds__(128) void backup_kernel(SearchDev D, const float *p
     const int n = D.n_leaves[t];
     const size_t leaf_base = leaf_off ? (size_t)leaf_off[t] : (size_t)t * stride;
     __syncthreads();          // both waves have read the leaf count before wave 0 may reset it
-    if (wid == 1) {
-        // node.py:86-93 update_policy via the {pos: policy} map of tree.py:287-295
-        for (int k = 0; k < n; ++k) {
+    // the root's statistics are touched by every leaf: wave 0 keeps them in LDS for the whole launch
+    // (256 dependent read-modify-writes through L2 otherwise) and writes them back at the end
+    __shared__ double r_vsum[A];
+    __shared__ int r_vis[A], r_vl[A];
+    __shared__ float r_nvsum;
+    __shared__ int r_nvis, r_nvl;
+    if (wid >= 1) {
+        // node.py:86-93 update_policy via the {pos: policy} map of tree.py:287-295.  Each leaf is a
+        // chain of four dependent loads (queue entry, child count, actions, policy values), and the
+        // leaves are independent: kPolicyWaves waves take them round-robin.  (Gumbel leaves all name
+        // the reference's node[-1], tree.py:412-416: the last pool slot, which has no children unless
+        // the pool is full - an error - so nothing is written for them and their order is immaterial.)
+        for (int k = wid - 1; k < n; k += kPolicyWaves) {
             int node = D.q_node[(size_t)t * D.K + k];
-            if (node < 0) node = D.N - 1;             // node[-1]: Gumbel leaves (tree.py:412-416)
+            if (node < 0) node = D.N - 1;
             const size_t ns = (size_t)t * D.N + node;
             const size_t base = ns * A;
             const float *pol = policy + (leaf_base + k) * A;
@@ -1053,46 +1073,117 @@ __global__ __launch_bounds__(128) void backup_kernel(SearchDev D, const float *p
         }
         return;
     }
-    if (lane == 0 && n > 0) {
-        size_t slot = (size_t)t * D.K;
-        int node = D.q_node[slot], cur = D.q_pnode[slot], e = D.q_pedge[slot];
+    // wave 0.  A leaf whose root->leaf path was recorded by the selector (q_depth > 0) is backed up
+    // with ONE memory round trip: lane i handles level i of the path (all loads of all levels are
+    // independent); a node always sits at the same level, i.e. in the same lane, so updates of a
+    // node shared by consecutive leaves stay in program order.  The value at level j above the
+    // leaf edge is the reference's iterated float32 `value = 1.0 - value`.  Other leaves follow
+    // the parent pointers in lane 0.
+    if (n > 0) {
+        const size_t rbase = (size_t)t * D.N * A;                 // root = node 0
+        for (int i = lane; i < A; i += 64) {
+            r_vsum[i] = D.ch_vsum[rbase + i];
+            r_vis[i] = D.ch_visits[rbase + i];
+            r_vl[i] = D.ch_vl[rbase + i];
+        }
+        if (lane == 0) {
+            r_nvsum = D.n_vsum[(size_t)t * D.N];
+            r_nvis = D.n_visits[(size_t)t * D.N];
+            r_nvl = D.n_vl[(size_t)t * D.N];
+        }
+        wave_sync();
+        const size_t slot0 = (size_t)t * D.K;
+        int node = D.q_node[slot0], cur = D.q_pnode[slot0], e = D.q_pedge[slot0], depth = D.q_depth[slot0];
+        int entry = lane < kPathCap ? D.q_path[slot0 * kPathCap + lane] : 0;
         const float *val = value + leaf_base * 3;
         float v0 = val[0], v1 = val[1], v2 = val[2];
         for (int k = 0; k < n; ++k) {
-            // request the next leaf's scalars before walking this one
+            // request the next leaf's scalars before backing this one up
             const int kn = k + 1 < n ? k + 1 : k;
             const size_t slot_n = (size_t)t * D.K + kn;
             const int node_n = D.q_node[slot_n], cur_n = D.q_pnode[slot_n], e_n = D.q_pedge[slot_n];
+            const int depth_n = D.q_depth[slot_n];
+            const int entry_n = lane < kPathCap ? D.q_path[slot_n * kPathCap + lane] : 0;
             const float *val_n = value + (leaf_base + kn) * 3;
             const float v0_n = val_n[0], v1_n = val_n[1], v2_n = val_n[2];
             if (node < 0) node = D.N - 1;
-            D.n_raw[(size_t)t * D.N + node] = v1 * 0.5f + v2;             // tree.py:299
+            if (lane == 0) D.n_raw[(size_t)t * D.N + node] = v1 * 0.5f + v2;   // tree.py:299
             if (cur >= 0) {
-                float v = v0 + v1 * 0.5f;             // tree.py:302
-                D.ch_value[((size_t)t * D.N + cur) * A + e] = (double)v;   // set_leaf_value
-                while (cur >= 0) {
-                    const size_t cs = (size_t)t * D.N + cur;
-                    const size_t ce = cs * A + e;
-                    // all loads of a level first (independent, one round trip), then the stores
-                    const double vs = D.ch_vsum[ce];
-                    const int cv = D.ch_visits[ce], cl = D.ch_vl[ce];
-                    const float ns_ = D.n_vsum[cs];
-                    const int nv = D.n_visits[cs], nl = D.n_vl[cs];
-                    const int pe = D.n_pedge[cs], pn = D.n_parent[cs];
-                    // float32 accumulation stored in float64 (see file header)
-                    D.ch_vsum[ce] = (double)((float)vs + v);
-                    D.ch_visits[ce] = cv + 1;
-                    D.ch_vl[ce] = cl - 1;
-                    D.n_vsum[cs] = ns_ + v;
-                    D.n_visits[cs] = nv + 1;
-                    D.n_vl[cs] = nl - 1;
-                    v = 1.0f - v;
-                    e = pe;
-                    cur = pn;
+                const float vleaf = v0 + v1 * 0.5f;   // tree.py:302
+                if (depth > 0) {
+                    if (lane < depth) {
+                        const int pn = entry >> 10, pe = entry & 1023;
+                        float v = vleaf;
+                        for (int q = depth - 1 - lane; q > 0; --q) v = 1.0f - v;
+                        const size_t cs = (size_t)t * D.N + pn;
+                        const size_t ce = cs * A + pe;
+                        if (lane == depth - 1) D.ch_value[ce] = (double)vleaf;   // set_leaf_value
+                        if (pn == 0) {                                           // root: LDS copy
+                            r_vsum[pe] = (double)((float)r_vsum[pe] + v);
+                            r_vis[pe] += 1;
+                            r_vl[pe] -= 1;
+                            r_nvsum += v;
+                            r_nvis += 1;
+                            r_nvl -= 1;
+                        } else {
+                            const double vs = D.ch_vsum[ce];
+                            const int cv = D.ch_visits[ce], cl = D.ch_vl[ce];
+                            const float ns_ = D.n_vsum[cs];
+                            const int nv = D.n_visits[cs], nl = D.n_vl[cs];
+                            D.ch_vsum[ce] = (double)((float)vs + v);         // float32 accumulation (file header)
+                            D.ch_visits[ce] = cv + 1;
+                            D.ch_vl[ce] = cl - 1;
+                            D.n_vsum[cs] = ns_ + v;
+                            D.n_visits[cs] = nv + 1;
+                            D.n_vl[cs] = nl - 1;
+                        }
+                    }
+                } else if (lane == 0) {
+                    float v = vleaf;
+                    D.ch_value[((size_t)t * D.N + cur) * A + e] = (double)v;   // set_leaf_value
+                    while (cur > 0) {
+                        const size_t cs = (size_t)t * D.N + cur;
+                        const size_t ce = cs * A + e;
+                        // all loads of a level first (independent, one round trip), then the stores
+                        const double vs = D.ch_vsum[ce];
+                        const int cv = D.ch_visits[ce], cl = D.ch_vl[ce];
+                        const float ns_ = D.n_vsum[cs];
+                        const int nv = D.n_visits[cs], nl = D.n_vl[cs];
+                        const int pe = D.n_pedge[cs], pn = D.n_parent[cs];
+                        D.ch_vsum[ce] = (double)((float)vs + v);
+                        D.ch_visits[ce] = cv + 1;
+                        D.ch_vl[ce] = cl - 1;
+                        D.n_vsum[cs] = ns_ + v;
+                        D.n_visits[cs] = nv + 1;
+                        D.n_vl[cs] = nl - 1;
+                        v = 1.0f - v;
+                        e = pe;
+                        cur = pn;
+                    }
+                    if (cur == 0) {                                          // root: LDS copy
+                        r_vsum[e] = (double)((float)r_vsum[e] + v);
+                        r_vis[e] += 1;
+                        r_vl[e] -= 1;
+                        r_nvsum += v;
+                        r_nvis += 1;
+                        r_nvl -= 1;
+                    }
                 }
+                wave_sync();
             }
-            node = node_n; cur = cur_n; e = e_n;
+            node = node_n; cur = cur_n; e = e_n; depth = depth_n; entry = entry_n;
             v0 = v0_n; v1 = v1_n; v2 = v2_n;
+        }
+        wave_sync();
+        for (int i = lane; i < A; i += 64) {
+            D.ch_vsum[rbase + i] = r_vsum[i];
+            D.ch_visits[rbase + i] = r_vis[i];
+            D.ch_vl[rbase + i] = r_vl[i];
+        }
+        if (lane == 0) {
+            D.n_vsum[(size_t)t * D.N] = r_nvsum;
+            D.n_visits[(size_t)t * D.N] = r_nvis;
+            D.n_vl[(size_t)t * D.N] = r_nvl;
         }
     }
     if (threadIdx.x == 0) D.n_leaves[t] = 0;
@@ -1345,6 +1436,7 @@ __global__ __launch_bounds__(192) void select_gumbel_pipe_kernel(SearchDev D, co
                             D.q_node[(size_t)t * D.K + queued] = child;   // still NOT_EXPANDED: node[-1]
                             D.q_pnode[(size_t)t * D.K + queued] = node;
                             D.q_pedge[(size_t)t * D.K + queued] = e;
+                            D.q_depth[(size_t)t * D.K + queued] = 0;
                         }
                         ok = publish(queued, node, e, child, 0, 0, depth);
                         if (ok) ++queued;
@@ -1465,6 +1557,7 @@ __global__ __launch_bounds__(64) void select_gumbel_kernel(SearchDev D, const in
                         D.q_node[(size_t)t * D.K + queued] = child;   // still NOT_EXPANDED: node[-1]
                         D.q_pnode[(size_t)t * D.K + queued] = node;
                         D.q_pedge[(size_t)t * D.K + queued] = e;
+                        D.q_depth[(size_t)t * D.K + queued] = 0;
                     }
                     wave_sync();
                     break;
@@ -1631,6 +1724,7 @@ int tg_search_create(const tg_search_config *cfg, tg_search **out) {
     ALLOC(noise, T * A)
     ALLOC(root_cells, T * s->NC) ALLOC(root_hist, T * s->HMAX) ALLOC(meta, T)
     ALLOC(q_node, T * K) ALLOC(q_pnode, T * K) ALLOC(q_pedge, T * K) ALLOC(n_leaves, T)
+    ALLOC(q_depth, T * K) ALLOC(q_path, T * K * kPathCap)
     ALLOC(rng_cursor, T) ALLOC(err, T)
 #undef ALLOC
     // random windows: one mini-batch worth of expansions each (grown on demand)
@@ -2080,9 +2174,9 @@ int tg_search_backup(tg_search *s, const float *policy_dev, const float *value_d
     s->last_stream = st;
     const int32_t *off = packed ? s->phase_dev + 2 * (size_t)s->dev.T : nullptr;
     if (s->S == 9)
-        hipLaunchKernelGGL(backup_kernel<9>, dim3(s->dev.T), dim3(128), 0, st, s->dev, policy_dev, value_dev, slots_per_tree, off, use_logit);
+        hipLaunchKernelGGL(backup_kernel<9>, dim3(s->dev.T), dim3(64 * (1 + kPolicyWaves)), 0, st, s->dev, policy_dev, value_dev, slots_per_tree, off, use_logit);
     else
-        hipLaunchKernelGGL(backup_kernel<19>, dim3(s->dev.T), dim3(128), 0, st, s->dev, policy_dev, value_dev, slots_per_tree, off, use_logit);
+        hipLaunchKernelGGL(backup_kernel<19>, dim3(s->dev.T), dim3(64 * (1 + kPolicyWaves)), 0, st, s->dev, policy_dev, value_dev, slots_per_tree, off, use_logit);
     TG_HIP(hipGetLastError());
     return TG_OK;
 }
