@@ -20,7 +20,7 @@ from tamago_amd.mcts.constant import MCTS_TREE_SIZE, NN_BATCH_SIZE, RESIGN_THRES
 from tamago_amd.mcts.sequential_halving import get_candidates_and_visit_pairs
 from tamago_amd.mcts.engine import SearchEngine, HostEvaluator, DeviceEvaluator
 from tamago_amd.mcts.node import MCTSNode
-from tamago_amd.mcts.time_manager import TimeManager
+from tamago_amd.mcts.time_manager import TimeControl, TimeManager
 
 
 class _NodeList:
@@ -118,8 +118,7 @@ class MCTSTree:
         engine.set_root(0, board, color, np.random.get_state())
         engine.root_eval(use_logit=False)                              # _initialize_search
         time_manager.start_timer()
-        root = engine.read_node(0, 0)
-        if root.get_num_children() == 1:
+        if int(engine.read_roots()[0][0]) == 1:                            # tree.py:76-77
             self.num_nodes = int(engine.num_nodes()[0])
             self._commit_rng(engine)
             return PASS
@@ -148,8 +147,11 @@ class MCTSTree:
             engine.puct_batch(leaves)
             done += leaves
             if leaves == self.batch_size and done < threshold:
-                root = engine.read_node(0, 0)
-                if time_manager.is_time_over() or time_manager.is_move_decided(root, threshold):
+                if time_manager.is_time_over():
+                    break
+                # STRICT_PLAYOUT never decides early (time_manager.py:160-161): no root read-back
+                if time_manager.mode != TimeControl.STRICT_PLAYOUT and \
+                        time_manager.is_move_decided(engine.read_node(0, 0), threshold):
                     break
         if analysis_query and analysis_query.get("interval", 0) == 0:      # tree.py:170-174
             import sys
