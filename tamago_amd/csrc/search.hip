@@ -1238,29 +1238,45 @@ __device__ __forceinline__ int wave_max_i32(int v) {
 template <int S>
 __device__ int select_root_halving(const SearchDev &D, int t, int node, int count_threshold, int lane) {
     constexpr int A = Geo<S>::A;
+    constexpr int R = (A + 63) / 64;
     const size_t ns = (size_t)t * D.N + node;
     const size_t base = ns * A;
+    // one memory round trip: every lane requests its slots of all five arrays up front
+    int vis[R], vl[R];
+    double vsum[R], logit[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = lane + 64 * r;
+        const int ii = i < A ? i : A - 1;
+        vis[r] = D.ch_visits[base + ii];
+        vl[r] = D.ch_vl[base + ii];
+        vsum[r] = D.ch_vsum[base + ii];
+        logit[r] = D.ch_policy[base + ii] + D.noise[(size_t)t * A + ii];
+    }
     const int nc = D.n_children[ns];
     int mx = 0;
-    for (int i = lane; i < nc; i += 64) mx = max(mx, D.ch_visits[base + i]);
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (lane + 64 * r < nc) mx = max(mx, vis[r]);
     mx = wave_max_i32(mx);
     const double sigma = (double)(50 + mx) * 1.0;                   // (C_VISIT + max) * C_SCALE
     double best = 0.0;
     int best_i = -1;
-    for (int i = lane; i < nc; i += 64) {
-        const int v = D.ch_visits[base + i];
-        const int cnt = v + D.ch_vl[base + i];
-        const double q = v > 0 ? D.ch_vsum[base + i] / (double)v : 0.0;
-        const double logit = D.ch_policy[base + i] + D.noise[(size_t)t * A + i];
-        const double sc = cnt >= count_threshold ? -10000.0 : logit + sigma * q;
-        if (best_i < 0 || sc > best) { best = sc; best_i = i; }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = lane + 64 * r;
+        if (i < nc) {
+            const int v = vis[r];
+            const int cnt = v + vl[r];
+            const double q = v > 0 ? vsum[r] / (double)v : 0.0;
+            const double sc = cnt >= count_threshold ? -10000.0 : logit[r] + sigma * q;
+            if (best_i < 0 || sc > best) { best = sc; best_i = i; }
+        }
     }
     wave_argmax(best, best_i);
     return best_i;
 }
 
-// node.py:349-361 select_move_by_sequential_halving_for_node (+ :281-321 completed Q,
-// improved policy; nn/utility.py:125-136 softmax), float64 throughout
 template <int S, typename Scratch>
 __device__ int select_node_halving(Scratch &L, const SearchDev &D, int t, int node, int lane) {   // uses L.w1, L.w2
     constexpr int A = Geo<S>::A;
