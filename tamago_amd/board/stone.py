@@ -1,20 +1,18 @@
-"""Cell colours (mirror of board/stone.py:5-27)."""
+"""Cell colours with the values of board/stone.py:5-27 (the device code uses the same numbers:
+0 empty, 1 black, 2 white, 3 border)."""
 from enum import Enum
 
 
 class Stone(Enum):
-    EMPTY = 0
-    BLACK = 1
-    WHITE = 2
-    OUT_OF_BOARD = 3
+    EMPTY, BLACK, WHITE, OUT_OF_BOARD = range(4)
 
     @classmethod
     def get_opponent_color(cls, color):
-        if color == Stone.BLACK:
-            return Stone.WHITE
-        if color == Stone.WHITE:
-            return Stone.BLACK
-        return color
+        """BLACK <-> WHITE; anything else comes back unchanged."""
+        return _OTHER_SIDE.get(color, color)
+
+
+_OTHER_SIDE = {Stone.BLACK: Stone.WHITE, Stone.WHITE: Stone.BLACK}
 
 
 def color_value(color) -> int:

@@ -32,17 +32,16 @@ class TimeManager:
         self.search_speed = visits / consumption_time if visits > 0 else VISITS_PER_SEC
 
     def get_num_visits_threshold(self, color) -> int:
-        if self.mode in (TimeControl.CONSTANT_PLAYOUT, TimeControl.STRICT_PLAYOUT):
+        """Visit budget of the coming search; also arms `time_limit` (time_manager.py:61-83)."""
+        fixed_visits = self.mode in (TimeControl.CONSTANT_PLAYOUT, TimeControl.STRICT_PLAYOUT)
+        if fixed_visits:
             self.time_limit = 10000.0
             return int(self.constant_visits)
         if self.mode == TimeControl.CONSTANT_TIME:
             self.time_limit = self.constant_time
-            threshold = int(self.search_speed * self.constant_time)
-            return threshold if threshold > 0 else 1
-        remaining = self.remaining_time[0] if color_value(color) == 1 else self.remaining_time[1]
-        self.time_limit = remaining / 10.0
-        threshold = int(self.search_speed * self.time_limit)
-        return threshold if threshold > 0 else 1
+        else:                                                   # a tenth of the player's clock
+            self.time_limit = self.remaining_time[color_value(color) - 1] / 10.0
+        return max(int(self.search_speed * self.time_limit), 1)
 
     def set_remaining_time(self, color, remaining_time: float):
         self.remaining_time[color_value(color) - 1] = remaining_time
