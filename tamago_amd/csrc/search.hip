@@ -1444,6 +1444,7 @@ __global__ __launch_bounds__(192) void select_gumbel_pipe_kernel(SearchDev D, co
                         sel_moves[depth] = (int16_t)mv;
                         D.n_vl[ns] += 1;
                         D.ch_vl[base + e] += 1;
+                        if (depth < kPathCap) D.q_path[((size_t)t * D.K + queued) * kPathCap + depth] = (node << 10) | e;
                     }
                     ++depth;
                     wave_sync();
@@ -1452,7 +1453,7 @@ __global__ __launch_bounds__(192) void select_gumbel_pipe_kernel(SearchDev D, co
                             D.q_node[(size_t)t * D.K + queued] = child;   // still NOT_EXPANDED: node[-1]
                             D.q_pnode[(size_t)t * D.K + queued] = node;
                             D.q_pedge[(size_t)t * D.K + queued] = e;
-                            D.q_depth[(size_t)t * D.K + queued] = 0;
+                            D.q_depth[(size_t)t * D.K + queued] = (depth <= kPathCap && D.N <= (1 << 21)) ? depth : 0;
                         }
                         ok = publish(queued, node, e, child, 0, 0, depth);
                         if (ok) ++queued;
