@@ -1,0 +1,245 @@
+"""Training step for the DualNet the search evaluates (nn/learn.py:318-403,
+nn/loss.py:33-55).
+
+State of this row: the loop, the losses, the optimiser and the file formats are here and
+interchange with the reference (``model/rl-model.bin`` is the same ``state_dict``,
+``model/rl-state.ckpt`` holds a ``torch.optim.SGD`` state over the parameters in the same
+order).  The differentiation itself is torch autograd over ATen / MIOpen ops on the ROCm
+device - it is NOT yet one of this repo's HIP kernels; the hand-written backward for the fused
+tower is the open item in DESIGN.md §8.  The arithmetic is fp32 throughout (the reference runs
+this step under fp16 autocast with a GradScaler, learn.py:342,371 - fp32 is the stricter of
+the two, and what its CPU trainer does).
+
+The network is held as a flat table of tensors keyed like the state_dict (no module tree):
+the same table feeds ``DualNet.load_state_dict`` of the inference side after a step.
+"""
+import glob
+import os
+import sys
+import time
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from tamago_amd.nn.network.dual_net import BLOCKS, random_state_dict, state_dict_keys
+
+SL_LEARNING_RATE = 0.01      # learning_param.py
+RL_LEARNING_RATE = 0.01
+MOMENTUM = 0.9
+WEIGHT_DECAY = 1e-4
+SL_VALUE_WEIGHT = 0.02
+RL_VALUE_WEIGHT = 1.0
+
+_STEM_BN = (1e-5, 0.1)       # nn.BatchNorm2d defaults (dual_net.py:32)
+_BODY_BN = (2e-5, 0.01)      # res_block.py:21-22, head/*.py:21
+
+
+# ---------------------------------------------------------------------------------- losses
+def calculate_policy_kld_loss(output: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """loss.py:33-43: KL(target || softmax(output)), summed, divided by the batch size."""
+    logp = F.log_softmax(output, dim=-1)
+    return F.kl_div(logp, target, reduction="batchmean")
+
+
+def calculate_policy_loss(output: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """loss.py:9-19: cross entropy of a probability output against a distribution."""
+    return -(target * torch.log(output.float() + 1e-8)).sum(dim=1)
+
+
+def calculate_sl_policy_loss(output: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """loss.py:21-31: per-sample cross entropy against a move class."""
+    return F.cross_entropy(output, target, reduction="none")
+
+
+def calculate_value_loss(output: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """loss.py:45-55: per-sample cross entropy over (loss, draw, win)."""
+    return F.cross_entropy(output, target, reduction="none")
+
+
+# -------------------------------------------------------------------------------- the table
+class TrainableDualNet:
+    """Parameters and batch-norm statistics of one DualNet on the device, as leaves of an
+    autograd graph.  ``parameters()`` yields them in the reference module's order, so an
+    optimiser state written by either side loads into the other."""
+
+    def __init__(self, device: torch.device, board_size: int = 9,
+                 state: Dict[str, torch.Tensor] = None):
+        self.device = torch.device(device)
+        self.board_size = board_size
+        self.training = True
+        self.t: Dict[str, torch.Tensor] = {}
+        self.load_state_dict(state if state is not None else random_state_dict(board_size))
+
+    def load_state_dict(self, state: Dict[str, torch.Tensor]):
+        table = {}
+        for key, shape in state_dict_keys(self.board_size):
+            v = torch.as_tensor(state[key]).detach().to(self.device, torch.float32).clone()
+            if tuple(v.shape) != tuple(shape):
+                raise ValueError(f"shape mismatch for {key}: {tuple(v.shape)} vs {shape}")
+            if not key.endswith(("running_mean", "running_var")):
+                v.requires_grad_(True)
+            table[key] = v
+        self.t = table
+        tracked = state.get("bn_layer.num_batches_tracked")
+        self.batches_tracked = int(tracked) if tracked is not None else 0
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        """CPU copy with the reference's keys, plus the ``num_batches_tracked`` counters a
+        torch module writes (one per batch norm, all equal to the number of training
+        forwards; no computation reads them - every batch norm has a fixed momentum)."""
+        out = {}
+        for key, _ in state_dict_keys(self.board_size):
+            out[key] = self.t[key].detach().to("cpu").clone()
+            if key.endswith("running_var"):
+                out[key[:-len("running_var")] + "num_batches_tracked"] = \
+                    torch.tensor(self.batches_tracked)
+        return out
+
+    def parameters(self):
+        return [v for v in self.t.values() if v.requires_grad]
+
+    def train(self):
+        self.training = True
+        return self
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def zero_grad(self):
+        for p in self.parameters():
+            p.grad = None
+
+    # ---- forward (dual_net.py:41-52, res_block.py:27-40, head/*.py) -------------------------
+    def _bn(self, x, prefix, cfg):
+        eps, momentum = cfg
+        t = self.t
+        return F.batch_norm(x, t[prefix + ".running_mean"], t[prefix + ".running_var"],
+                            t[prefix + ".weight"], t[prefix + ".bias"],
+                            training=self.training, momentum=momentum, eps=eps)
+
+    def forward(self, planes: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Policy logits [B, S*S+1] and value logits [B, 3]."""
+        t = self.t
+        self.batches_tracked += int(self.training)
+        x = F.relu(self._bn(F.conv2d(planes, t["conv_layer.weight"], padding=1),
+                            "bn_layer", _STEM_BN))
+        for b in range(BLOCKS):
+            pre = f"blocks.{b}"
+            h = F.relu(self._bn(F.conv2d(x, t[pre + ".conv1.weight"], padding=1),
+                                pre + ".bn1", _BODY_BN))
+            h = self._bn(F.conv2d(h, t[pre + ".conv2.weight"], padding=1), pre + ".bn2", _BODY_BN)
+            x = F.relu(x + h)
+        heads = []
+        for name in ("policy_head", "value_head"):
+            h = F.relu(self._bn(F.conv2d(x, t[name + ".conv_layer.weight"]),
+                                name + ".bn_layer", _BODY_BN))
+            heads.append(F.linear(h.flatten(1), t[name + ".fc_layer.weight"],
+                                  t[name + ".fc_layer.bias"]))
+        return heads[0], heads[1]
+
+
+def make_optimizer(net: TrainableDualNet, lr: float) -> torch.optim.SGD:
+    """learn.py:333-337: SGD, Nesterov momentum 0.9, weight decay 1e-4 on every parameter."""
+    return torch.optim.SGD(net.parameters(), lr=lr, momentum=MOMENTUM,
+                           weight_decay=WEIGHT_DECAY, nesterov=True)
+
+
+def rl_train_step(net: TrainableDualNet, optimizer, plane, policy, value) -> Dict[str, float]:
+    """One mini-batch of learn.py:360-376 (KLD policy loss + value cross entropy)."""
+    with torch.enable_grad():
+        policy_predict, value_predict = net.forward(plane)
+        net.zero_grad()
+        policy_loss = calculate_policy_kld_loss(policy_predict, policy)
+        value_loss = calculate_value_loss(value_predict, value)
+        loss = (policy_loss + RL_VALUE_WEIGHT * value_loss).mean()
+        loss.backward()
+    optimizer.step()
+    return {"loss": loss.item(), "policy": policy_loss.mean().item(),
+            "value": value_loss.mean().item()}
+
+
+def sl_train_step(net: TrainableDualNet, optimizer, plane, policy, value) -> Dict[str, float]:
+    """One mini-batch of the supervised trainer (learn.py:150-180): the policy target is a
+    distribution scored against the softmax output, value weight 0.02."""
+    with torch.enable_grad():
+        policy_predict, value_predict = net.forward(plane)
+        net.zero_grad()
+        policy_loss = calculate_policy_loss(F.softmax(policy_predict, dim=1), policy)
+        value_loss = calculate_value_loss(value_predict, value)
+        loss = (policy_loss + SL_VALUE_WEIGHT * value_loss).mean()
+        loss.backward()
+    optimizer.step()
+    return {"loss": loss.item(), "policy": policy_loss.mean().item(),
+            "value": value_loss.mean().item()}
+
+
+# ------------------------------------------------------------------------------ file formats
+def load_data_set(path: str):
+    """nn/utility.py:90-102 - one shuffle of the chunk from numpy's global generator."""
+    data = np.load(path)
+    perm = np.random.permutation(len(data["value"]))
+    return (data["input"][perm], data["policy"][perm].astype(np.float32),
+            data["value"][perm].astype(np.int64))
+
+
+def print_learning_process(loss_data, epoch, index, iteration, start_time):
+    """nn/utility.py:43-59 (stderr, same three lines)."""
+    n = max(iteration, 1)
+    spent = time.time() - start_time
+    print(f"epoch {epoch}, data-{index} : loss = {loss_data['loss'] / n:6f}, "
+          f"time = {spent:3f} seconds.", file=sys.stderr)
+    print(f"\tpolicy loss : {loss_data['policy'] / n:6f}", file=sys.stderr)
+    print(f"\tvalue loss  : {loss_data['value'] / n:6f}", file=sys.stderr)
+
+
+def train_with_gumbel_alphazero_on_gpu(program_dir: str, board_size: int, batch_size: int,
+                                       device_index: int = 0) -> Dict[str, float]:
+    """learn.py:318-403: one pass over ``data/rl_data_*.npz``, resuming from and writing
+    ``model/rl-model.bin`` / ``model/rl-state.ckpt``.  Returns the summed losses of the
+    last chunk (the reference returns nothing)."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("tamago_amd trains on the GPU only")
+    device = torch.device("cuda", device_index)
+    data_set = sorted(glob.glob(os.path.join(program_dir, "data", "rl_data_*.npz")))
+    net = TrainableDualNet(device, board_size)
+    model_file_path = os.path.join(program_dir, "model", "rl-model.bin")
+    if os.path.exists(model_file_path):
+        print(f"load {model_file_path}")
+        net.load_state_dict(torch.load(model_file_path, map_location="cpu"))
+    optimizer = make_optimizer(net, RL_LEARNING_RATE)
+    num_trained_batches = 0
+    state_file_path = os.path.join(program_dir, "model", "rl-state.ckpt")
+    if os.path.exists(state_file_path):
+        print(f"load {state_file_path}")
+        checkpoint = torch.load(state_file_path, map_location=device)
+        optimizer.load_state_dict(checkpoint["optimizer_state_dict"])
+        num_trained_batches = checkpoint["num_trained_batches"]
+        print(f"num_trained_batches : {num_trained_batches}")
+
+    train_loss = {"loss": 0.0, "policy": 0.0, "value": 0.0}
+    for data_index, path in enumerate(data_set):
+        plane_data, policy_data, value_data = load_data_set(path)
+        planes = torch.from_numpy(plane_data).to(device, torch.float32)   # chunk resident in HBM
+        policies = torch.from_numpy(policy_data).to(device)
+        values = torch.from_numpy(value_data).to(device)
+        train_loss = {"loss": 0.0, "policy": 0.0, "value": 0.0}
+        iteration = 0
+        net.train()
+        started = time.time()
+        for i in range(0, len(value_data) - batch_size + 1, batch_size):
+            part = rl_train_step(net, optimizer, planes[i:i + batch_size],
+                                 policies[i:i + batch_size], values[i:i + batch_size])
+            for k in train_loss:
+                train_loss[k] += part[k]
+            num_trained_batches += 1
+            iteration += 1
+        print_learning_process(train_loss, 0, data_index, iteration, started)
+
+    os.makedirs(os.path.dirname(model_file_path), exist_ok=True)
+    torch.save(net.state_dict(), model_file_path)
+    torch.save({"num_trained_batches": num_trained_batches,
+                "optimizer_state_dict": optimizer.state_dict()}, state_file_path)
+    return train_loss

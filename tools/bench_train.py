@@ -1,0 +1,31 @@
+"""Positions/s of the fp32 RL training step (tamago_amd/nn/learn.py) at the reference's batch
+size (learning_param.py BATCH_SIZE = 256) and at larger batches, synthetic data in HBM."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+from tamago_amd.nn import learn  # noqa: E402
+
+dev = torch.device("cuda", 0)
+size = int(sys.argv[1]) if len(sys.argv) > 1 else 9
+for batch in (256, 1024, 4096):
+    net = learn.TrainableDualNet(dev, size)
+    opt = learn.make_optimizer(net, 0.01)
+    rng = np.random.RandomState(1)
+    planes = torch.from_numpy((rng.uniform(size=(batch, 6, size, size)) < 0.3).astype(np.float32)).to(dev)
+    pol = torch.softmax(torch.randn(batch, size * size + 1, device=dev), 1)
+    val = torch.randint(0, 3, (batch,), device=dev)
+    for _ in range(5):
+        learn.rl_train_step(net, opt, planes, pol, val)
+    torch.cuda.synchronize()
+    n = 30
+    t0 = time.time()
+    for _ in range(n):
+        learn.rl_train_step(net, opt, planes, pol, val)
+    torch.cuda.synchronize()
+    dt = (time.time() - t0) / n
+    print(f"train step {size}x{size} batch {batch}: {dt * 1e3:.2f} ms -> {batch / dt:,.0f} positions/s")
