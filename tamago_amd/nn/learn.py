@@ -176,6 +176,87 @@ def sl_train_step(net: TrainableDualNet, optimizer, plane, policy, value) -> Dic
             "value": value_loss.mean().item()}
 
 
+class GraphedStep:
+    """One mini-batch step captured in a hipGraph (torch.cuda.CUDAGraph) and replayed: the
+    eager step is launch-bound (a few hundred small kernels for 2.7 ms of a 256-position
+    batch), a replay is one submission.  Inputs are copied into static buffers, the three
+    loss values are accumulated on the device (no host read per step).  The operator sequence
+    is the eager step's; results agree with it to summation-order noise."""
+
+    def __init__(self, net: TrainableDualNet, optimizer, batch_size: int, mode: str = "rl"):
+        dev, s = net.device, net.board_size
+        self.net, self.optimizer = net, optimizer
+        self.plane = torch.zeros((batch_size, 6, s, s), device=dev)
+        self.policy = torch.full((batch_size, s * s + 1), 1.0 / (s * s + 1), device=dev)
+        self.value = torch.zeros((batch_size,), dtype=torch.int64, device=dev)
+        self.sums = torch.zeros(3, dtype=torch.float64, device=dev)
+        self.steps = 0
+        body = self._rl if mode == "rl" else self._sl
+        # warm-up on a side stream (library workspaces, algorithm choice), then put every
+        # tensor the warm-up touched back: parameters, statistics, momentum buffers
+        params = [p.detach().clone() for p in net.parameters()]
+        stats = {k: v.clone() for k, v in net.t.items() if not v.requires_grad}
+        had = {id(p): optimizer.state[p]["momentum_buffer"].clone()
+               for p in net.parameters() if "momentum_buffer" in optimizer.state.get(p, {})}
+        tracked = net.batches_tracked
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side), torch.enable_grad():
+            for _ in range(3):
+                optimizer.zero_grad(set_to_none=True)
+                body()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self._restore(params, stats, had)
+        self.graph = torch.cuda.CUDAGraph()
+        optimizer.zero_grad(set_to_none=True)
+        with torch.enable_grad(), torch.cuda.graph(self.graph):
+            body()
+        self._restore(params, stats, had)     # the capture pass does not execute, but be exact
+        self.sums.zero_()
+        net.batches_tracked = tracked
+
+    def _restore(self, params, stats, had):
+        with torch.no_grad():
+            for p, saved in zip(self.net.parameters(), params):
+                p.copy_(saved)
+                buf = self.optimizer.state[p].get("momentum_buffer")
+                if buf is not None:           # zeros == "no buffer yet": first step sets buf = grad
+                    buf.copy_(had[id(p)]) if id(p) in had else buf.zero_()
+            for k, saved in stats.items():
+                self.net.t[k].copy_(saved)
+
+    def _losses(self, policy_loss, value_loss, weight):
+        loss = (policy_loss + weight * value_loss).mean()
+        loss.backward()
+        self.optimizer.step()
+        self.sums += torch.stack([loss.detach(), policy_loss.detach().mean(),
+                                  value_loss.detach().mean()]).double()
+
+    def _rl(self):
+        p, v = self.net.forward(self.plane)
+        self._losses(calculate_policy_kld_loss(p, self.policy),
+                     calculate_value_loss(v, self.value), RL_VALUE_WEIGHT)
+
+    def _sl(self):
+        p, v = self.net.forward(self.plane)
+        self._losses(calculate_policy_loss(F.softmax(p, dim=1), self.policy),
+                     calculate_value_loss(v, self.value), SL_VALUE_WEIGHT)
+
+    def __call__(self, plane, policy, value):
+        self.plane.copy_(plane, non_blocking=True)
+        self.policy.copy_(policy, non_blocking=True)
+        self.value.copy_(value, non_blocking=True)
+        self.graph.replay()
+        self.steps += 1
+        self.net.batches_tracked += 1
+
+    def take_losses(self) -> Dict[str, float]:
+        """Summed losses since the last call (one host read)."""
+        total = self.sums.tolist()
+        self.sums.zero_()
+        return {"loss": total[0], "policy": total[1], "value": total[2]}
+
+
 # ------------------------------------------------------------------------------ file formats
 def load_data_set(path: str):
     """nn/utility.py:90-102 - one shuffle of the chunk from numpy's global generator."""
@@ -220,6 +301,9 @@ def train_with_gumbel_alphazero_on_gpu(program_dir: str, board_size: int, batch_
         print(f"num_trained_batches : {num_trained_batches}")
 
     train_loss = {"loss": 0.0, "policy": 0.0, "value": 0.0}
+    graphed = None
+    if os.environ.get("TG_TRAIN_EAGER", "0") != "1":
+        graphed = GraphedStep(net.train(), optimizer, batch_size, "rl")
     for data_index, path in enumerate(data_set):
         plane_data, policy_data, value_data = load_data_set(path)
         planes = torch.from_numpy(plane_data).to(device, torch.float32)   # chunk resident in HBM
@@ -230,12 +314,17 @@ def train_with_gumbel_alphazero_on_gpu(program_dir: str, board_size: int, batch_
         net.train()
         started = time.time()
         for i in range(0, len(value_data) - batch_size + 1, batch_size):
-            part = rl_train_step(net, optimizer, planes[i:i + batch_size],
-                                 policies[i:i + batch_size], values[i:i + batch_size])
-            for k in train_loss:
-                train_loss[k] += part[k]
+            batch = (planes[i:i + batch_size], policies[i:i + batch_size], values[i:i + batch_size])
+            if graphed is not None:
+                graphed(*batch)
+            else:
+                part = rl_train_step(net, optimizer, *batch)
+                for k in train_loss:
+                    train_loss[k] += part[k]
             num_trained_batches += 1
             iteration += 1
+        if graphed is not None:
+            train_loss = graphed.take_losses()
         print_learning_process(train_loss, 0, data_index, iteration, started)
 
     os.makedirs(os.path.dirname(model_file_path), exist_ok=True)

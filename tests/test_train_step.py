@@ -96,6 +96,40 @@ def test_train_steps_match_reference_gpu(mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["rl", "sl"])
+def test_graphed_step_equals_eager(mode):
+    """The hipGraph replay runs the eager step's operator sequence: parameters, statistics and
+    loss sums after three steps agree with eager steps to summation-order noise (wgrad
+    reductions are not order-deterministic; measured 1.4e-6 after three steps), also when the
+    optimiser already holds momentum at capture time."""
+    dev = torch.device("cuda", 0)
+    state, batches = make_case()
+    dev_batches = [tuple(torch.from_numpy(a).to(dev) for a in b) for b in batches]
+    eager = learn.TrainableDualNet(dev, 9, state).train()
+    opt_e = learn.make_optimizer(eager, 0.01)
+    step = learn.rl_train_step if mode == "rl" else learn.sl_train_step
+    sums = np.zeros(3)
+    for b in dev_batches:
+        part = step(eager, opt_e, *b)
+        sums += [part["loss"], part["policy"], part["value"]]
+    graphed_net = learn.TrainableDualNet(dev, 9, state).train()
+    opt_g = learn.make_optimizer(graphed_net, 0.01)
+    step(graphed_net, opt_g, *dev_batches[0])                 # momentum buffers exist before capture
+    run = learn.GraphedStep(graphed_net, opt_g, 32, mode)
+    for b in dev_batches[1:]:
+        run(*b)
+    got = run.take_losses()
+    fresh = learn.TrainableDualNet(dev, 9, state).train()
+    first = step(fresh, learn.make_optimizer(fresh, 0.01), *dev_batches[0])
+    np.testing.assert_allclose([got["loss"] + first["loss"], got["policy"] + first["policy"],
+                                got["value"] + first["value"]], sums, rtol=0, atol=1e-4)
+    a, b = eager.state_dict(), graphed_net.state_dict()
+    for key, _ in state_dict_keys(9):
+        np.testing.assert_allclose(b[key].numpy(), a[key].numpy(), rtol=0, atol=2e-5, err_msg=key)
+    assert int(b["bn_layer.num_batches_tracked"]) == 3
+
+
+@pytest.mark.gpu
 def test_rl_training_loop_files(tmp_path):
     """data/rl_data_*.npz -> model/rl-model.bin + rl-state.ckpt, then a resumed second pass."""
     state, batches = make_case()

@@ -28,4 +28,14 @@ for batch in (256, 1024, 4096):
         learn.rl_train_step(net, opt, planes, pol, val)
     torch.cuda.synchronize()
     dt = (time.time() - t0) / n
-    print(f"train step {size}x{size} batch {batch}: {dt * 1e3:.2f} ms -> {batch / dt:,.0f} positions/s")
+    run = learn.GraphedStep(net, opt, batch, "rl")
+    for _ in range(3):
+        run(planes, pol, val)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(n):
+        run(planes, pol, val)
+    torch.cuda.synchronize()
+    dg = (time.time() - t0) / n
+    print(f"train step {size}x{size} batch {batch}: eager {dt * 1e3:.2f} ms -> {batch / dt:,.0f} positions/s; "
+          f"hipGraph {dg * 1e3:.2f} ms -> {batch / dg:,.0f} positions/s")
