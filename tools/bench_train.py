@@ -12,7 +12,8 @@ from tamago_amd.nn import learn  # noqa: E402
 
 dev = torch.device("cuda", 0)
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 9
-for batch in (256, 1024, 4096):
+batches = [int(b) for b in sys.argv[2].split(",")] if len(sys.argv) > 2 else [256, 1024, 4096]
+for batch in batches:
     net = learn.TrainableDualNet(dev, size)
     opt = learn.make_optimizer(net, 0.01)
     rng = np.random.RandomState(1)
