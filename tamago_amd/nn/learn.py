@@ -31,6 +31,8 @@ MOMENTUM = 0.9
 WEIGHT_DECAY = 1e-4
 SL_VALUE_WEIGHT = 0.02
 RL_VALUE_WEIGHT = 1.0
+EPOCHS = 15
+LEARNING_SCHEDULE = {"learning_rate": {5: 0.001, 8: 0.0001, 10: 0.00001}}
 
 _STEM_BN = (1e-5, 0.1)       # nn.BatchNorm2d defaults (dual_net.py:32)
 _BODY_BN = (2e-5, 0.01)      # res_block.py:21-22, head/*.py:21
@@ -332,3 +334,91 @@ def train_with_gumbel_alphazero_on_gpu(program_dir: str, board_size: int, batch_
     torch.save({"num_trained_batches": num_trained_batches,
                 "optimizer_state_dict": optimizer.state_dict()}, state_file_path)
     return train_loss
+
+
+def split_train_test_set(file_list, train_data_ratio: float):
+    """nn/utility.py:105-122: the first 80 % of the chunk files train, the rest test."""
+    cut = int(len(file_list) * train_data_ratio)
+    train_files, test_files = file_list[:cut], file_list[cut:]
+    print(f"Training data set : {train_files}")
+    print(f"Testing data set  : {test_files}")
+    return train_files, test_files
+
+
+def _chunk_on_device(path: str, device):
+    plane_data, policy_data, value_data = load_data_set(path)
+    return (torch.from_numpy(plane_data).to(device, torch.float32),
+            torch.from_numpy(policy_data).to(device), torch.from_numpy(value_data).to(device))
+
+
+def train_on_gpu(program_dir: str, board_size: int, batch_size: int, epochs: int,
+                 device_index: int = 0) -> Dict[str, float]:
+    """Supervised trainer, learn.py:126-232: `epochs` passes over the training chunks of
+    ``data/sl_data_*.npz``, after each one the test chunks in eval mode, then the learning
+    rate schedule; writes ``model/sl-model.bin`` relative to the working directory, as the
+    reference does (learn.py:232).  Returns the last test-loss sums."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("tamago_amd trains on the GPU only")
+    device = torch.device("cuda", device_index)
+    data_set = sorted(glob.glob(os.path.join(program_dir, "data", "sl_data_*.npz")))
+    train_files, test_files = split_train_test_set(data_set, 0.8)
+    net = TrainableDualNet(device, board_size)
+    optimizer = make_optimizer(net, SL_LEARNING_RATE)
+    current_lr = SL_LEARNING_RATE
+    eager = os.environ.get("TG_TRAIN_EAGER", "0") == "1"
+    graphed = None
+    test_loss = {"loss": 0.0, "policy": 0.0, "value": 0.0}
+    for epoch in range(epochs):
+        for data_index, path in enumerate(train_files):
+            planes, policies, values = _chunk_on_device(path, device)
+            net.train()
+            if graphed is None and not eager:     # (re)captured after a learning-rate change:
+                graphed = GraphedStep(net, optimizer, batch_size, "sl")   # lr is baked into the graph
+            train_loss = {"loss": 0.0, "policy": 0.0, "value": 0.0}
+            iteration = 0
+            started = time.time()
+            for i in range(0, len(values) - batch_size + 1, batch_size):
+                batch = (planes[i:i + batch_size], policies[i:i + batch_size], values[i:i + batch_size])
+                if eager:
+                    part = sl_train_step(net, optimizer, *batch)
+                    for k in train_loss:
+                        train_loss[k] += part[k]
+                else:
+                    graphed(*batch)
+                iteration += 1
+            if not eager:
+                train_loss = graphed.take_losses()
+            print_learning_process(train_loss, epoch, data_index, iteration, started)
+
+        sums = torch.zeros(3, dtype=torch.float64, device=device)
+        test_iteration = 0
+        started = time.time()
+        net.eval()
+        for path in test_files:
+            planes, policies, values = _chunk_on_device(path, device)
+            with torch.no_grad():
+                for i in range(0, len(values) - batch_size + 1, batch_size):
+                    p, v = net.forward(planes[i:i + batch_size])
+                    policy_loss = calculate_policy_loss(F.softmax(p, dim=1), policies[i:i + batch_size])
+                    value_loss = calculate_value_loss(v, values[i:i + batch_size])
+                    loss = (policy_loss + SL_VALUE_WEIGHT * value_loss).mean()
+                    sums += torch.stack([loss, policy_loss.mean(), value_loss.mean()]).double()
+                    test_iteration += 1
+        total = sums.tolist()
+        test_loss = {"loss": total[0], "policy": total[1], "value": total[2]}
+        n = max(test_iteration, 1)
+        print(f"Test {epoch} : loss = {total[0] / n:6f}, time = {time.time() - started:3f} seconds.",
+              file=sys.stderr)
+        print(f"\tpolicy loss : {total[1] / n:6f}", file=sys.stderr)
+        print(f"\tvalue loss  : {total[2] / n:6f}", file=sys.stderr)
+
+        if epoch in LEARNING_SCHEDULE["learning_rate"]:
+            previous_lr, current_lr = current_lr, LEARNING_SCHEDULE["learning_rate"][epoch]
+            for group in optimizer.param_groups:
+                group["lr"] = current_lr
+            graphed = None
+            print(f"Epoch {epoch}, learning rate has changed {previous_lr} -> {current_lr}")
+
+    os.makedirs("model", exist_ok=True)
+    torch.save(net.state_dict(), os.path.join("model", "sl-model.bin"))
+    return test_loss
