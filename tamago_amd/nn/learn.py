@@ -294,12 +294,17 @@ def train_with_gumbel_alphazero_on_gpu(program_dir: str, board_size: int, batch_
         net.load_state_dict(torch.load(model_file_path, map_location="cpu"))
     optimizer = make_optimizer(net, RL_LEARNING_RATE)
     num_trained_batches = 0
+    # fp32 needs no loss scaling; the entry exists because the reference's GPU trainer reads it
+    # on resume (learn.py:356) - a fresh GradScaler's state, or the one a loaded checkpoint had
+    scaler_state = {"scale": 65536.0, "growth_factor": 2.0, "backoff_factor": 0.5,
+                    "growth_interval": 2000, "_growth_tracker": 0}
     state_file_path = os.path.join(program_dir, "model", "rl-state.ckpt")
     if os.path.exists(state_file_path):
         print(f"load {state_file_path}")
         checkpoint = torch.load(state_file_path, map_location=device)
         optimizer.load_state_dict(checkpoint["optimizer_state_dict"])
         num_trained_batches = checkpoint["num_trained_batches"]
+        scaler_state = checkpoint.get("scaler_state_dict", scaler_state)
         print(f"num_trained_batches : {num_trained_batches}")
 
     train_loss = {"loss": 0.0, "policy": 0.0, "value": 0.0}
@@ -332,7 +337,8 @@ def train_with_gumbel_alphazero_on_gpu(program_dir: str, board_size: int, batch_
     os.makedirs(os.path.dirname(model_file_path), exist_ok=True)
     torch.save(net.state_dict(), model_file_path)
     torch.save({"num_trained_batches": num_trained_batches,
-                "optimizer_state_dict": optimizer.state_dict()}, state_file_path)
+                "optimizer_state_dict": optimizer.state_dict(),
+                "scaler_state_dict": scaler_state}, state_file_path)
     return train_loss
 
 

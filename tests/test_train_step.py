@@ -142,6 +142,8 @@ def test_rl_training_loop_files(tmp_path):
     first = learn.train_with_gumbel_alphazero_on_gpu(str(tmp_path), 9, 32)
     ck = torch.load(tmp_path / "model" / "rl-state.ckpt", map_location="cpu")
     assert ck["num_trained_batches"] == 3
+    fresh_scaler = torch.amp.GradScaler("cpu", enabled=True)
+    fresh_scaler.load_state_dict(ck["scaler_state_dict"])      # what learn.py:356 does on resume
     assert len(ck["optimizer_state_dict"]["state"]) == len(
         [k for k, _ in state_dict_keys(9) if not k.endswith(("running_mean", "running_var"))])
     saved = torch.load(tmp_path / "model" / "rl-model.bin", map_location="cpu")
