@@ -231,6 +231,17 @@ int tg_search_backup(tg_search *s, const float *policy_dev, const float *value_d
  * selection launch queued, until the next one.  Synchronises. */
 int tg_search_read_path(tg_search *s, int tree, int slot, int32_t *nodes_host, int32_t *edges_host,
                         int capacity, int32_t *length_host);
+/* Leaf queue of tree `tree` as the last selection launch left it (mcts/batch_data.py:7-34, the
+ * `node_index` list of BatchQueue): count_host = leaves queued, node_index_host[i] = node that
+ * receives leaf i's policy (-1 = the reference's node[-1] slot, tree.py:222-233 when the leaf was
+ * already expanded).  The matching `input_plane` entries are the planes the selection wrote, the
+ * `path` entries come from tg_search_read_path.  Valid until the next selection launch.  Synchronises. */
+int tg_search_read_queue(tg_search *s, int tree, int32_t *node_index_host, int capacity,
+                         int32_t *count_host);
+/* Grow the node pool of every tree to new_tree_size nodes, keeping the trees (the reference doubles
+ * its node list in place when it fills up, mcts/tree.py:254-258).  No-op if the pool is already that
+ * large.  Synchronises the device. */
+int tg_search_grow(tg_search *s, int new_tree_size);
 /* Read-side of MCTSNode for node `node` of tree `t` (node.py:21-39); any pointer may be
  * NULL.  Arrays have A entries. Synchronises the stream used by the last call. */
 int tg_search_read_node(tg_search *s, int tree, int node, int32_t *num_children,

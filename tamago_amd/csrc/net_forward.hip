@@ -23,6 +23,8 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <type_traits>
 #include <vector>
 
@@ -716,9 +718,16 @@ struct tg_net {
     int num_cus = 256;
     NetDev dev{};
     std::vector<void *> allocs;
-    // staging buffers for the host-pointer entry point
+    // staging buffers for the host-pointer entry point (guarded by host_mu: the host API of one
+    // handle may be called from several threads, e.g. self-play group threads sharing a network)
     float *st_planes = nullptr, *st_policy = nullptr, *st_value = nullptr;
     int st_cap = 0;
+    std::mutex host_mu;
+    // 19x19 Winograd kernel: one scratch image set PER STREAM.  Launches on one stream run in order,
+    // launches on different streams may overlap on the device and must not share activation images.
+    std::mutex scratch_mu;
+    std::map<hipStream_t, float *> scratch_by_stream;
+    size_t scratch_floats = 0;
 };
 
 namespace {
@@ -789,7 +798,18 @@ int launch_wino8(tg_net *net, const float *planes, int batch, int want_logits, f
     }
     const int groups = (batch + G - 1) / G;
     const int grid = groups < net->num_cus ? groups : net->num_cus;     // one 8-wave workgroup per CU
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), C::LDS_BYTES, stream, net->dev, planes, batch,
+    NetDev dev = net->dev;
+    if (GS) {
+        std::lock_guard<std::mutex> lock(net->scratch_mu);
+        float *&slot = net->scratch_by_stream[stream];
+        if (!slot) {
+            void *d = nullptr;
+            TG_HIP(hipMalloc(&d, net->scratch_floats * sizeof(float)));
+            slot = static_cast<float *>(d);
+        }
+        dev.scratch = slot;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), C::LDS_BYTES, stream, dev, planes, batch,
                        want_logits, policy, value);
     TG_HIP(hipGetLastError());
     return TG_OK;
@@ -922,16 +942,9 @@ int tg_net_create(int board_size, int device, const float *params, size_t n_para
         return tg::fail(TG_ERR_ARG, "tg_net_create: parameter blob not fully consumed");
     }
 
-    if (board_size == 19) {       // scratch images of the Winograd kernel: 2 x [P][64] floats per workgroup
-        void *d = nullptr;
-        hipError_t e = hipMalloc(&d, (size_t)net->num_cus * 2 * P * 64 * sizeof(float));
-        if (e != hipSuccess) {
-            delete net;
-            return tg::fail(TG_ERR_HIP, "tg_net_create: scratch: %s", hipGetErrorString(e));
-        }
-        net->allocs.push_back(d);
-        net->dev.scratch = static_cast<float *>(d);
-    }
+    // scratch images of the 19x19 Winograd kernel: 2 x [P][64] floats per workgroup, allocated per
+    // launch stream on first use (launch_wino8)
+    if (board_size == 19) net->scratch_floats = (size_t)net->num_cus * 2 * P * 64;
     int rc = TG_OK;
     if ((rc = upload(net, w0, &net->dev.w0frag)) || (rc = upload(net, wf, &net->dev.wfrag)) || (rc = upload(net, ww, &net->dev.wwino)) ||
         (rc = upload(net, scale, &net->dev.scale)) || (rc = upload(net, shift, &net->dev.shift)) ||
@@ -950,6 +963,7 @@ int tg_net_destroy(tg_net *net) {
     if (!net) return TG_OK;
     (void)hipSetDevice(net->device);
     for (void *p : net->allocs) (void)hipFree(p);
+    for (auto &kv : net->scratch_by_stream) (void)hipFree(kv.second);
     if (net->st_planes) (void)hipFree(net->st_planes);
     if (net->st_policy) (void)hipFree(net->st_policy);
     if (net->st_value) (void)hipFree(net->st_value);
@@ -1052,6 +1066,7 @@ int tg_net_forward_host(tg_net *net, const float *planes_host, int batch, int wa
     if (batch <= 0) return batch == 0 ? TG_OK : tg::fail(TG_ERR_ARG, "negative batch");
     if (!net || !planes_host || !policy_host || !value_host)
         return tg::fail(TG_ERR_ARG, "tg_net_forward_host: null argument");
+    std::lock_guard<std::mutex> lock(net->host_mu);
     TG_HIP(hipSetDevice(net->device));
     const size_t P = (size_t)net->board_size * net->board_size, A = P + 1;
     if (batch > net->st_cap) {

@@ -30,6 +30,8 @@
 #include "common.h"
 #include "legacy_stream.h"
 
+#include <sched.h>
+
 #include <cstring>
 #include <algorithm>
 #include <thread>
@@ -1689,8 +1691,23 @@ int dev_alloc(tg_search *s, T **out, size_t count, bool zero = true) {
 
 template <typename F>
 void parallel_trees(int n, F &&fn) {
-    unsigned hw = std::thread::hardware_concurrency();
-    int nthr = (int)std::min<unsigned>(hw ? hw : 1u, 16u);
+    // host threads this process may use: its affinity mask (a shard launcher pins every rank to a
+    // private slice of the cores), capped by TG_HOST_THREADS and 16
+    static const int host_threads = [] {
+        unsigned hw = std::thread::hardware_concurrency();
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) {
+            const int n = CPU_COUNT(&set);
+            if (n > 0) hw = (unsigned)n;
+        }
+        int n = (int)std::min<unsigned>(hw ? hw : 1u, 16u);
+        if (const char *env = getenv("TG_HOST_THREADS")) {
+            const int cap = atoi(env);
+            if (cap >= 1 && cap < n) n = cap;
+        }
+        return n;
+    }();
+    int nthr = host_threads;
     if (n < 32 || nthr < 2) {
         for (int t = 0; t < n; ++t) fn(t);
         return;
@@ -1705,6 +1722,23 @@ void parallel_trees(int n, F &&fn) {
     for (auto &th : pool) th.join();
 }
 
+}  // namespace
+
+namespace {
+// Re-allocate one [T][n_old * per_node] pool array as [T][n_new * per_node], keeping every tree's rows.
+template <typename T>
+int grow_array(tg_search *s, T **field, size_t trees, size_t n_old, size_t n_new, size_t per_node) {
+    void *p = nullptr;
+    TG_HIP(hipMalloc(&p, trees * n_new * per_node * sizeof(T)));
+    TG_HIP(hipMemset(p, 0, trees * n_new * per_node * sizeof(T)));
+    TG_HIP(hipMemcpy2D(p, n_new * per_node * sizeof(T), *field, n_old * per_node * sizeof(T),
+                       n_old * per_node * sizeof(T), trees, hipMemcpyDeviceToDevice));
+    for (void *&a : s->allocs)
+        if (a == static_cast<void *>(*field)) a = p;
+    (void)hipFree(*field);
+    *field = static_cast<T *>(p);
+    return TG_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -1783,6 +1817,26 @@ int tg_search_destroy(tg_search *s) {
     for (int b = 0; b < 2; ++b)
         if (s->stage[b]) (void)hipHostFree(s->stage[b]);
     delete s;
+    return TG_OK;
+}
+
+int tg_search_grow(tg_search *s, int new_tree_size) {
+    if (!s) return tg::fail(TG_ERR_ARG, "tg_search_grow: null argument");
+    SearchDev &D = s->dev;
+    if (new_tree_size <= D.N) return TG_OK;
+    TG_HIP(hipSetDevice(s->cfg.device));
+    TG_HIP(hipDeviceSynchronize());           // nothing may still be running on the old arrays
+    const size_t T = D.T, n0 = D.N, n1 = (size_t)new_tree_size, A = s->A;
+    int rc = TG_OK;
+#define GROW(field, per) if ((rc = grow_array(s, &D.field, T, n0, n1, (per)))) return rc;
+    GROW(ch_index, A) GROW(ch_visits, A) GROW(ch_vl, A) GROW(ch_vsum, A) GROW(ch_policy, A) GROW(ch_value, A)
+    GROW(action, A)
+    GROW(n_children, 1) GROW(n_visits, 1) GROW(n_vl, 1) GROW(n_parent, 1) GROW(n_pedge, 1) GROW(n_vsum, 1)
+    GROW(n_raw, 1)
+#undef GROW
+    TG_HIP(hipDeviceSynchronize());
+    D.N = new_tree_size;
+    s->cfg.tree_size = new_tree_size;
     return TG_OK;
 }
 
@@ -2282,6 +2336,21 @@ int tg_search_read_path(tg_search *s, int tree, int slot, int32_t *nodes_host, i
         nodes_host[i] = nodes[nodes.size() - 1 - i];
         edges_host[i] = edges[nodes.size() - 1 - i];
     }
+    return TG_OK;
+}
+
+int tg_search_read_queue(tg_search *s, int tree, int32_t *node_index_host, int capacity, int32_t *count_host) {
+    if (!s || !node_index_host || !count_host) return tg::fail(TG_ERR_ARG, "tg_search_read_queue: null argument");
+    if (tree < 0 || tree >= s->dev.T) return tg::fail(TG_ERR_ARG, "tg_search_read_queue: tree %d out of range", tree);
+    if (s->last_stream) TG_HIP(hipStreamSynchronize(s->last_stream));
+    else TG_HIP(hipDeviceSynchronize());
+    const SearchDev &D = s->dev;
+    int32_t n = 0;
+    TG_HIP(hipMemcpy(&n, D.n_leaves + tree, sizeof(int32_t), hipMemcpyDeviceToHost));
+    *count_host = n;
+    if (n > capacity) return tg::fail(TG_ERR_ARG, "tg_search_read_queue: %d leaves exceed capacity %d", n, capacity);
+    if (n > 0)
+        TG_HIP(hipMemcpy(node_index_host, D.q_node + (size_t)tree * D.K, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
     return TG_OK;
 }
 

@@ -62,6 +62,8 @@ _SIGNATURES = {
     "tg_search_backup": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "tg_search_read_node": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 12),
     "tg_search_num_nodes": (c_int, [c_void_p, c_void_p]),
+    "tg_search_read_queue": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "tg_search_grow": (c_int, [c_void_p, c_int]),
     "tg_search_read_roots": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "tg_search_read_path": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "tg_search_seed_stream": (c_int, [c_void_p, c_int, c_void_p, c_int]),

@@ -150,6 +150,7 @@ class SearchEngine:
         self.host_streams = host_streams or bool(os.environ.get("TG_HOST_STREAMS"))
         self.streams: List[Optional[ExpStream]] = [None] * num_trees
         self._pool = None
+        self.node_bound = 0                       # upper bound of nodes in use in any tree
         self._window_left = 0
         self._window_cap = 0
         self._window_used = np.zeros(num_trees, dtype=np.int64)
@@ -250,6 +251,8 @@ class SearchEngine:
         """tree.py:49-54: expand + evaluate the root of every tree (one leaf each).  With
         `first_batch` the random window also covers the first mini-batch of that many leaves,
         so no upload sits between the (tiny) root evaluation and the first selection."""
+        self.node_bound = 1
+        self._queue_stride = 1
         self._feed_rng(self.A * (1 + first_batch))
         _lib.check(self.lib.tg_search_root_planes(self.handle, self.planes.data_ptr(),
                                                   self._stream()), "tg_search_root_planes")
@@ -268,11 +271,57 @@ class SearchEngine:
         # order matters for overlap: the random window of THIS batch is generated and
         # uploaded (private copy stream) while the forward pass of the PREVIOUS batch is
         # still running; the cursor read-back waits for the selection kernel only
+        self.puct_select(leaves)
+        self._evaluate_and_backup(leaves, False)
+
+    def puct_select(self, leaves: int):
+        """The selection half of puct_batch: afterwards the device queue holds `leaves` leaves per
+        tree (read_queue) until puct_flush() evaluates and backs them up."""
+        self.node_bound += leaves
+        self._queue_stride = leaves
         self._feed_rng(leaves * self.A)
         _lib.check(self.lib.tg_search_select_puct(self.handle, leaves, self.planes.data_ptr(),
                                                   None, self._stream()), "tg_search_select_puct")
         self._collect_rng()
-        self._evaluate_and_backup(leaves, False)
+
+    def puct_flush(self):
+        """process_mini_batch (tree.py:273-315) for the leaves queued by puct_select."""
+        self._evaluate_and_backup(self._queue_stride, False)
+
+    def ensure_capacity(self, leaves: int) -> bool:
+        """Make room for `leaves` more descents (each allocates at most one node) in every tree:
+        the reference doubles its node list when it fills up (mcts/tree.py:254-258), the device
+        pool is grown in place the same way (tg_search_grow keeps the trees).  The host-side
+        bound makes this free while the pool is far from full.  Returns True if the pool grew."""
+        if self.node_bound + leaves <= self.N:
+            return False
+        self.node_bound = int(self.num_nodes().max())
+        if self.node_bound + leaves <= self.N:
+            return False
+        new_size = self.N
+        while self.node_bound + leaves > new_size:
+            import sys
+            sys.stderr.write(f"Tree is full. Allocate new space {new_size} -> {new_size * 2}\n")
+            new_size *= 2
+        _lib.check(self.lib.tg_search_grow(self.handle, new_size), "tg_search_grow")
+        self.N = new_size
+        return True
+
+    def read_queue(self, tree: int = 0):
+        """The device leaf queue of `tree` as a BatchQueue (mcts/batch_data.py:7-34): input planes,
+        root-first paths and node indices of the leaves the last selection launch queued.  Empty
+        once the mini-batch has been backed up (the reference clears its queue there, tree.py:315)."""
+        from tamago_amd.mcts.batch_data import BatchQueue
+        idx = np.zeros(self.K, dtype=np.int32)
+        n = ctypes.c_int32(0)
+        _lib.check(self.lib.tg_search_read_queue(self.handle, tree, idx.ctypes.data, self.K, ctypes.byref(n)),
+                   "tg_search_read_queue")
+        queue = BatchQueue()
+        if n.value:
+            planes = self.planes[tree * self._queue_stride:tree * self._queue_stride + n.value].cpu().numpy()
+            for k in range(n.value):
+                queue.push(planes[k], self.read_path(tree, k), int(idx[k]))
+        return queue
 
     def play(self, moves):
         """Play one move per tree on the device-resident root positions (< 0 = skip)."""
@@ -316,6 +365,7 @@ class SearchEngine:
         # packed leaf layout (slots_per_tree = 0): the forward pass covers exactly the queued
         # leaves - a tree whose root has one candidate runs 1 x `visits` levels and would
         # otherwise stretch every tree's slot range to `visits`
+        self.node_bound += slots
         self._feed_rng(slots * self.A)
         _lib.check(self.lib.tg_search_select_gumbel(self.handle, nc.ctypes.data, mc.ctypes.data,
                                                     0 if packed else slots,

@@ -49,12 +49,21 @@ class MCTSTree:
         self.num_nodes = 0
         self.root = 0
         self.current_root = 0
-        self.batch_queue = BatchQueue()
         self.to_move = Stone.BLACK
         self.node = _NodeList(self)
+        self.ponder_max_nodes = 1 << 22            # 4 M nodes = 13 GB of 9x9 pool: cap of ponder's growth
         self._engine = None
         self._engine_key = None
         self._gumbel_root = False
+
+    @property
+    def batch_queue(self) -> BatchQueue:
+        """mcts/batch_data.py:7-34 view of the DEVICE leaf queue (input planes, paths, node indices
+        of the leaves waiting for the network).  Like the reference's, it is empty whenever a
+        search call has returned (every mini-batch is flushed before, tree.py:150-152,315)."""
+        if self._engine is None:
+            return BatchQueue()
+        return self._engine.read_queue(0)
 
     # ------------------------------------------------------------------------------------
     def _evaluator(self):
@@ -70,6 +79,10 @@ class MCTSTree:
                 raise RuntimeError("no search has run yet")
             return self._engine
         batch = batch_size or self.batch_size
+        net_size = getattr(self.network, "board_size", None)
+        if net_size is not None and net_size != board.board_size:
+            raise ValueError(f"network is built for {net_size}x{net_size}, board is "
+                             f"{board.board_size}x{board.board_size}")
         key = (board.board_size, bool(board.check_superko), batch, self.cgos_mode, self.tree_size)
         if self._engine is None or key != self._engine_key:
             if self._engine is not None:
@@ -95,21 +108,17 @@ class MCTSTree:
     def search_best_move(self, board: GoBoard, color, time_manager: TimeManager,
                          analysis_query: Dict[str, Any] = None) -> int:
         """mcts/tree.py:57-105.  The reference doubles its node list when it fills up
-        (tree.py:254-258); the device pool is fixed, so on overflow the pool is doubled and
-        the (deterministic) search is repeated from the same RNG state - same result."""
-        from tamago_amd.lib import TamagoHipError
-        rng_state = np.random.get_state()
-        while True:
-            try:
-                return self._search_best_move(board, color, time_manager, analysis_query)
-            except TamagoHipError as err:
-                if "node pool full" not in str(err):
-                    raise
-                import sys
-                sys.stderr.write(f"Tree is full. Allocate new space {self.tree_size} -> "
-                                 f"{self.tree_size * 2}\n")
-                self.tree_size *= 2
-                np.random.set_state(rng_state)
+        (tree.py:254-258); the device pool is grown in place the same way between mini-batches
+        (SearchEngine.ensure_capacity -> tg_search_grow), so a search is never repeated and the
+        clock keeps running over a growth."""
+        return self._search_best_move(board, color, time_manager, analysis_query)
+
+    def _sync_size(self, engine):
+        """tree_size follows the pool (len(tree.node) after the reference's doubling)."""
+        if engine.N != self.tree_size:
+            self.tree_size = engine.N
+            key = self._engine_key
+            self._engine_key = key[:4] + (engine.N,)
 
     def _search_best_move(self, board, color, time_manager, analysis_query):
         engine = self._engine_for(board)
@@ -125,6 +134,7 @@ class MCTSTree:
         self.search(board, color, time_manager, analysis_query or {}, _engine=engine)
         root = engine.read_node(0, 0)
         self.num_nodes = int(engine.num_nodes()[0])
+        self._sync_size(engine)
         self._commit_rng(engine)
         search_time = time_manager.calculate_consumption_time()
         time_manager.set_search_speed(root.node_visits, max(search_time, 1e-9))
@@ -144,6 +154,7 @@ class MCTSTree:
         done = 0
         while done < threshold:
             leaves = min(self.batch_size, threshold - done)
+            engine.ensure_capacity(leaves)
             engine.puct_batch(leaves)
             done += leaves
             if leaves == self.batch_size and done < threshold:
@@ -164,7 +175,8 @@ class MCTSTree:
         (``analysis_query["ponder"]``), printing analysis every ``interval`` seconds.  The
         reference polls stdin after every descent; here the poll sits between mini-batches (a
         batch in flight is finished), input that is already waiting stops after one descent.
-        The node pool is fixed: pondering also stops when the next mini-batch might not fit."""
+        The node pool doubles when the next mini-batch might not fit (tree.py:254-258), up to
+        `ponder_max_nodes` nodes (the reference is bounded by host memory only)."""
         import select
         import sys
         import time
@@ -186,9 +198,12 @@ class MCTSTree:
 
         if engine.read_node(0, 0).get_num_children() > 1:
             while True:
-                used = int(engine.num_nodes()[0])
-                if used + self.batch_size + 1 > self.tree_size:
-                    break
+                if engine.node_bound + self.batch_size > engine.N:
+                    engine.node_bound = int(engine.num_nodes()[0])
+                    if engine.node_bound + self.batch_size > engine.N and \
+                            engine.N * 2 > self.ponder_max_nodes:
+                        break
+                engine.ensure_capacity(self.batch_size)
                 waiting = stdin_ready()
                 engine.puct_batch(1 if waiting else self.batch_size)
                 if waiting or stdin_ready():
@@ -201,6 +216,7 @@ class MCTSTree:
             sys.stdout.write(engine.read_node(0, 0).get_analysis(board, mode, self.get_pv_lists))
             sys.stdout.flush()
         self.num_nodes = int(engine.num_nodes()[0])
+        self._sync_size(engine)
         self._commit_rng(engine)
 
     def search_with_callback(self, board: GoBoard, color, callback):
@@ -212,12 +228,12 @@ class MCTSTree:
         engine.set_root(0, board, color, np.random.get_state())
         engine.root_eval(use_logit=False)
         while True:
-            if int(engine.num_nodes()[0]) + 2 > self.tree_size:
-                raise RuntimeError("search_with_callback: node pool exhausted; create the tree with a larger tree_size")
+            engine.ensure_capacity(1)
             engine.puct_batch(1)
             if callback(engine.read_path(0, 0)):
                 break
         self.num_nodes = int(engine.num_nodes()[0])
+        self._sync_size(engine)
         self._commit_rng(engine)
 
     # ---- principal variations (mcts/tree.py:432-473) -----------------------------------------
@@ -257,6 +273,7 @@ class MCTSTree:
         nc, _, _ = engine.read_roots()
         base = int(nc[0]) if nc[0] < MAX_CONSIDERED_NODES else MAX_CONSIDERED_NODES
         for num_considered, max_count in get_candidates_and_visit_pairs(base, visits).items():
+            engine.ensure_capacity(num_considered * max_count)
             engine.gumbel_phase([num_considered], [max_count])
         root = self.get_root()
         self.num_nodes = int(engine.num_nodes()[0])

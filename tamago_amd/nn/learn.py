@@ -286,6 +286,7 @@ def train_with_gumbel_alphazero_on_gpu(program_dir: str, board_size: int, batch_
     if not torch.cuda.is_available():
         raise RuntimeError("tamago_amd trains on the GPU only")
     device = torch.device("cuda", device_index)
+    torch.cuda.set_device(device)             # graph capture and side streams run on the CURRENT device
     data_set = sorted(glob.glob(os.path.join(program_dir, "data", "rl_data_*.npz")))
     net = TrainableDualNet(device, board_size)
     model_file_path = os.path.join(program_dir, "model", "rl-model.bin")
@@ -366,6 +367,7 @@ def train_on_gpu(program_dir: str, board_size: int, batch_size: int, epochs: int
     if not torch.cuda.is_available():
         raise RuntimeError("tamago_amd trains on the GPU only")
     device = torch.device("cuda", device_index)
+    torch.cuda.set_device(device)             # graph capture and side streams run on the CURRENT device
     data_set = sorted(glob.glob(os.path.join(program_dir, "data", "sl_data_*.npz")))
     train_files, test_files = split_train_test_set(data_set, 0.8)
     net = TrainableDualNet(device, board_size)

@@ -151,7 +151,11 @@ class DualNet:
         """Device-resident variant: planes is a CUDA fp32 tensor [B,6,S,S]; enqueues on the
         current torch stream and returns CUDA tensors (no host hop)."""
         assert planes.is_cuda and planes.dtype == torch.float32 and planes.is_contiguous()
-        b = planes.shape[0]
+        b, s = planes.shape[0], self.board_size
+        if tuple(planes.shape[1:]) != (6, s, s):
+            # the reference's conv / fc layers raise a shape error here; the device kernels would
+            # index a [B, S*S+1] policy with another board's stride
+            raise ValueError(f"expected [B,6,{s},{s}], got {tuple(planes.shape)}")
         if out is None:
             policy = torch.empty((b, self.board_size ** 2 + 1), dtype=torch.float32,
                                  device=planes.device)

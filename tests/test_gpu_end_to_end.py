@@ -118,10 +118,86 @@ def test_cfg2_puct_9x9_batch256_1000_visits():
     assert int(np.abs(root.children_virtual_loss).sum()) == 0
 
 
-def test_cfg5_puct_19x19_batch64():
-    tree, root, _ = _run(19, 320, 64, 60, seed=4)
-    assert [b[0].shape[0] for b in tree.recorder.log] == [1] + [64] * 5
-    assert root.node_visits == 320 and 280 < tree.num_nodes <= 321
+def test_cfg5_puct_19x19_batch64_1600_visits():
+    """BASELINE.json config 5 at its full size: 19x19, 1600 strict visits, NN batch 64."""
+    tree, root, _ = _run(19, 1600, 64, 60, seed=4)
+    assert [b[0].shape[0] for b in tree.recorder.log] == [1] + [64] * 25
+    assert root.node_visits == 1600 and 1400 < tree.num_nodes <= 1601
+    assert int(root.children_visits.sum()) == 1600 and root.virtual_loss == 0
+
+
+def test_multi_tree_lockstep_device_evaluator_replay():
+    """64 trees in lock-step on the DeviceEvaluator path (what bench.py and the self-play shards
+    run): every tree's slice of every recorded mini-batch is replayed into its own CPU oracle
+    tree - identical leaf planes in order, identical visit counts / value sums / node counts."""
+    from oracle.board import GoBoard as OBoard
+    from oracle.net import OracleNet, make_state_dict
+    from oracle.tree import MCTSTree as OTree, TimeManager as OTM, TimeControl as OTC
+    from tamago_amd.board.go_board import GoBoard
+    from tamago_amd.mcts.engine import SearchEngine, DeviceEvaluator
+    from tamago_amd.nn.network.dual_net import DualNet
+    from tests.helpers import load_npz
+
+    size, T, K, visits = 9, 64, 64, 200
+    sd = make_state_dict(size, 7, 1.5)
+    net = DualNet(torch.device("cuda:0"), size)
+    net.load_state_dict(sd)
+    rec = Recorder(DeviceEvaluator(net))
+    engine = SearchEngine(size, T, visits + 16, K, rec)
+    brd = load_npz("board_s9.npz")
+    roots = []
+    for t in range(T):
+        game, plies = t % 4, 2 + (t * 5) % 40
+        board, oboard = GoBoard(size, 7.0, False), OBoard(size, 7.0, False)
+        mv, col = brd[f"g{game}_move"], brd[f"g{game}_color"]
+        plies = min(plies, len(mv) - 1)
+        for m, c in zip(mv[:plies], col[:plies]):
+            board.put_stone(int(m), int(c))
+            oboard.put_stone(int(m), int(c))
+        color = 3 - int(col[plies - 1])
+        engine.set_root(t, board, color, np.random.RandomState(900 + t).get_state())
+        roots.append((oboard, color))
+    engine.root_eval(False)
+    done = 0
+    while done < visits:
+        k = min(K, visits - done)
+        engine.puct_batch(k)
+        done += k
+    stats = engine.read_root_stats()
+    nodes = engine.num_nodes()
+    assert [b[0].shape[0] for b in rec.log] == [T, T * 64, T * 64, T * 64, T * 8]
+    # CPU parity of the recorded device outputs, whole mini-batches at once
+    cpu = OracleNet(sd)
+    for planes, policy, value, _ in rec.log:
+        ref_p, ref_v = cpu.inference(planes)
+        assert float((ref_p - policy).abs().max()) < 1e-4 and float((ref_v - value).abs().max()) < 1e-4
+
+    class Slice:
+        """the recorded outputs of tree t, mini-batch by mini-batch"""
+        def __init__(self, t):
+            self.t, self.i = t, 0
+
+        def inference(self, planes):
+            rp, pol, val, _ = rec.log[self.i]
+            per = rp.shape[0] // T
+            self.i += 1
+            lo = self.t * per
+            assert torch.equal(planes, rp[lo:lo + planes.shape[0]]), (self.t, self.i - 1)
+            return pol[lo:lo + planes.shape[0]], val[lo:lo + planes.shape[0]]
+
+    for t in range(0, T, 3):                       # every third tree: 22 oracle searches
+        oboard, color = roots[t]
+        sl = Slice(t)
+        otree = OTree(sl, size, tree_size=visits + 16, batch_size=K)
+        np.random.set_state(np.random.RandomState(900 + t).get_state())
+        otree.search_best_move(oboard, color, OTM(OTC.STRICT_PLAYOUT, visits))
+        oroot = otree.get_root()
+        n = oroot.num_children
+        assert sl.i == len(rec.log) and int(stats["num_children"][t]) == n and int(nodes[t]) == otree.num_nodes
+        assert np.array_equal(stats["children_visits"][t][:n], oroot.children_visits[:n]), t
+        assert np.array_equal(stats["children_value_sum"][t][:n], oroot.children_value_sum[:n]), t
+        assert np.array_equal(stats["children_policy"][t][:n], oroot.children_policy[:n]), t
+    engine.close()
 
 
 def test_gumbel_400_sims_with_real_network():

@@ -1,0 +1,161 @@
+// Main loop of a direct 3x3 convolution layer evaluated with 3-way bf16 operand splitting
+// (a = ah + am + al exactly, 8 mantissa bits each; a*b ~ ah*bh + ah*bm + am*bh + ah*bl + al*bh + am*bm)
+// on v_mfma_f32_16x16x32_bf16: what does the loop sustain with LDS-resident activations (three bf16
+// images, [piece][k-chunk][row][4 x 16 B, xor-swizzled]) and weights streamed tap by tap through LDS
+// with global_load_lds?  One workgroup = 8 waves = 256 rows x 64 output channels x K = 9 taps x 64.
+// Prints cycles per layer per workgroup (MFMA floor: 6912 MFMAs x 16 cycles / 4 SIMDs = 27.6 k).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int ROWS = 243, S = 9;
+constexpr int ACT_PIECE = 2 * ROWS * 64;            // bytes per piece: [kc][row][64 B]
+constexpr int ACT_BYTES = 3 * ACT_PIECE;            // 93312
+constexpr int ZERO_OFF = ACT_BYTES;                 // 16 B of zeros
+constexpr int W_OFF = ACT_BYTES + 64;
+constexpr int W_TAP = 2 * 3 * 4 * 1024;             // [kc][piece][ct][lane][16 B] = 24576
+constexpr int LDS_BYTES = W_OFF + 2 * W_TAP;
+
+template <bool DMA, bool BAR, bool LDSREAD>
+__global__ __launch_bounds__(512, 2) void k(const unsigned char *__restrict__ wglob, float *out, int layers) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+    for (int e = tid; e < LDS_BYTES / 4; e += 512) reinterpret_cast<unsigned *>(smem)[e] = ((e * 2654435761u) ^ (blockIdx.x * 40503u)) & 0xBF7FBF7Fu;   // random finite bf16 pairs
+    __syncthreads();
+    // geometry of this wave's two row-tiles
+    int base_row[2];
+    unsigned mask[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int row = (wid * 2 + r) * 16 + li;
+        const int p = row % 81, y = p / S, x = p % S;
+        unsigned m = 0;
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            if (row < ROWS && yy >= 0 && yy < S && xx >= 0 && xx < S) m |= 1u << t;
+        }
+        mask[r] = m;
+        base_row[r] = row;
+    }
+    f32x4 acc[4][2];
+    f32x4 total = {0.f, 0.f, 0.f, 0.f};
+    const unsigned char *wsrc = wglob + lane * 16;
+    for (int layer = 0; layer < layers; ++layer) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) acc[c][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto dma = [&](int tap, int buf) {
+            if (!DMA) return;
+            // 24 pieces of 1 KB per tap, 3 per wave
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int piece = wid * 3 + q;
+                const unsigned char *src = wsrc + ((size_t)(layer * 9 + tap) * 24 + piece) * 1024;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(smem + W_OFF + buf * W_TAP + piece * 1024),
+                                                 16, 0, 0);
+            }
+        };
+        dma(0, 0);
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            if (BAR) __syncthreads();
+            if (tap + 1 < 9) dma(tap + 1, (tap + 1) & 1);
+            const int toff = (tap / 3 - 1) * S + (tap % 3 - 1);
+            int aaddr[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int row = base_row[r] + toff;
+                const bool ok = (mask[r] >> tap) & 1u;
+                aaddr[r] = ok ? row * 64 + ((lg ^ ((row >> 1) & 3)) << 4) : ZERO_OFF;
+            }
+            const int wbase = W_OFF + (tap & 1) * W_TAP + lane * 16;
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) {
+                bf16x8 b[2][3];
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        const int ad = aaddr[r] == ZERO_OFF ? ZERO_OFF : aaddr[r] + p * ACT_PIECE + kc * ROWS * 64;
+                        b[r][p] = LDSREAD ? *reinterpret_cast<const bf16x8 *>(smem + ad) : bf16x8{};
+                    }
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) {
+                    bf16x8 a[2][3];
+#pragma unroll
+                    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                        for (int p = 0; p < 3; ++p)
+                            a[cc][p] = LDSREAD ? *reinterpret_cast<const bf16x8 *>(smem + wbase + ((kc * 3 + p) * 4 + c2 * 2 + cc) * 1024) : bf16x8{};
+                    // six products, four accumulators in rotation
+                    constexpr int PA[6] = {0, 0, 1, 0, 2, 1};
+                    constexpr int PB[6] = {0, 1, 0, 2, 0, 1};
+#pragma unroll
+                    for (int q = 0; q < 6; ++q)
+#pragma unroll
+                        for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                            for (int r = 0; r < 2; ++r)
+                                acc[c2 * 2 + cc][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[cc][PA[q]], b[r][PB[q]], acc[c2 * 2 + cc][r], 0, 0, 0);
+                }
+            }
+        }
+        if (BAR) __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) total += acc[c][r];
+        if (BAR) __syncthreads();
+    }
+    out[blockIdx.x * 512 + tid] = total[0] + total[1] + total[2] + total[3];
+}
+
+template <bool DMA, bool BAR, bool LDSREAD>
+void run(const char *name, const unsigned char *w, float *out) {
+    const int layers = 48;
+    auto kern = k<DMA, BAR, LDSREAD>;
+    hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL(kern, dim3(256), dim3(512), LDS_BYTES, 0, w, out, layers);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(kern, dim3(256), dim3(512), LDS_BYTES, 0, w, out, layers);
+    hipEventRecord(e1);
+    hipDeviceSynchronize();
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    ms /= 5;
+    const double us_layer = ms * 1e3 / layers;
+    const double flop = 256.0 * layers * 6912.0 * 16384.0;
+    printf("%-34s %.3f ms: %.2f us per layer per workgroup = %.0f cycles at 2.4 GHz (floor 27648), %.0f TFLOP/s bf16, "
+           "fp32-equivalent %.1f TFLOP/s (direct-conv count)\n",
+           name, ms, us_layer, us_layer * 2400.0, flop / ms / 1e9, flop / 6.0 / ms / 1e9);
+    if (hipGetLastError() != hipSuccess) printf("  (error)\n");
+}
+
+int main() {
+    unsigned char *w;
+    float *out;
+    const size_t wbytes = (size_t)48 * 9 * 24 * 1024;
+    hipMalloc(&w, wbytes);
+    {
+        unsigned *h = static_cast<unsigned *>(malloc(wbytes));       // random finite bf16 pairs: realistic switching power
+        unsigned x = 12345u;
+        for (size_t i = 0; i < wbytes / 4; ++i) { x = x * 1664525u + 1013904223u; h[i] = x & 0x3F7F3F7Fu; }
+        hipMemcpy(w, h, wbytes, hipMemcpyHostToDevice);
+        free(h);
+    }
+    hipMalloc(&out, 256 * 512 * 4);
+    run<false, false, false>("mfma only", w, out);
+    run<false, false, true>("mfma + lds reads", w, out);
+    run<false, true, true>("mfma + lds reads + barriers", w, out);
+    run<true, true, true>("mfma + lds reads + barriers + dma", w, out);
+    return 0;
+}
