@@ -18,191 +18,20 @@
 //  * BatchNorm is folded to a per-channel scale/shift applied in the epilogue together with
 //    the residual add and ReLU.
 //  * Heads (1x1 conv + BN + ReLU + FC + softmax) run on the VALU from the same LDS buffer.
-#include "common.h"
+#include "net_device.h"
 
-#include <cmath>
 #include <cstdlib>
 #include <cstring>
-#include <map>
-#include <mutex>
 #include <type_traits>
-#include <vector>
+
+namespace tg {
+// net_forward_split.hip
+int split_prepare(tg_net *net, const float *conv0, const float *const *tower, const float *scale);
+int split_forward(tg_net *net, int group, const float *planes, int batch, int want_logits, float *policy,
+                  float *value, int *overflow, hipStream_t stream);
+}  // namespace tg
 
 namespace {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int kBlocks = 6;
-constexpr int kConvLayers = 1 + 2 * kBlocks;  // 13
-constexpr int kRowFloats = 72;                // activation row stride in LDS (64 + 8 pad)
-constexpr int kRowBytes = kRowFloats * 4;     // 288
-// Winograd kernel: lanes of a fragment read patches of CONSECUTIVE TILES (2 positions apart);
-// a row stride of 68 floats spreads 8 consecutive tiles over all 64 banks (72 would give 4)
-constexpr int kWinoRowFloats = 68;
-constexpr int kWinoRowBytes = kWinoRowFloats * 4;   // 272
-
-struct NetDev {
-    const float *w0frag;  // [4 wave][9 tap][64 lane][2]         stem 6->64 (cin padded to 8)
-    const float *wfrag;   // [12 layer][4 wave][9 tap][4 s][64 lane][4]
-    const float *wwino;   // [12 layer][4 wave][4 s][16 xi][64 lane][4]  Winograd G g G^T, fragment order
-                          // (the 16 fragments of a work unit are 16 contiguous KB: two address bases reach them
-                          //  all through the +-4 KB immediate of global_load)
-    const float *scale;   // [13][64] folded BN scale
-    const float *shift;   // [13][64] folded BN shift
-    const float *hp_w;    // [2][64]  policy 1x1 conv
-    const float *hv_w;    // [64]     value 1x1 conv
-    const float *head_ss; // [6]      policy scale0,shift0,scale1,shift1, value scale,shift
-    const float *pfc_wT;  // [2P][A]  policy FC, transposed
-    const float *pfc_b;   // [A]
-    const float *vfc_w;   // [3][P]
-    const float *vfc_b;   // [3]
-    float *scratch;       // 19x19 Winograd: per workgroup two [P][64] activation images (L2-resident)
-    long long *timeline;  // optional [128] s_memtime stamps of workgroup 0 (tg_net_profile_phases)
-};
-
-template <int S, int G>
-struct FwdCfg {
-    static constexpr int P = S * S;
-    static constexpr int A = P + 1;
-    static constexpr int M = G * P;
-    static constexpr int MT = (M + 15) / 16;
-    static constexpr int ROW_BYTES = kRowBytes;
-    static constexpr int ACT_BYTES = M * kRowBytes;
-    static constexpr int ZROW = ACT_BYTES;               // 288 B zero row
-    static constexpr int AUX = ACT_BYTES + kRowBytes;    // in8 [M][8] + zero8, later head scratch
-    static constexpr int ZERO8 = AUX + M * 32;
-    static constexpr int LDS_BYTES = ZERO8 + 32;
-    static constexpr int WAVES_PER_SIMD = (2 * LDS_BYTES <= 160 * 1024) ? 2 : 1;
-};
-
-__device__ __forceinline__ float lds_f32(const unsigned char *smem, int byte_off) {
-    return *reinterpret_cast<const float *>(smem + byte_off);
-}
-__device__ __forceinline__ f32x4 lds_f32x4(const unsigned char *smem, int byte_off) {
-    return *reinterpret_cast<const f32x4 *>(smem + byte_off);
-}
-
-// a - b as two v_pk_add_f32 with negated second operand (hipcc emits four scalar v_sub_f32 for a
-// float4 subtraction; a + (-b) is the same IEEE operation)
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x4 sub4(f32x4 a, f32x4 b) {
-    f32x2 lo, hi;
-    const f32x2 alo = __builtin_shufflevector(a, a, 0, 1), ahi = __builtin_shufflevector(a, a, 2, 3);
-    const f32x2 blo = __builtin_shufflevector(b, b, 0, 1), bhi = __builtin_shufflevector(b, b, 2, 3);
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(lo) : "v"(alo), "v"(blo));
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(hi) : "v"(ahi), "v"(bhi));
-    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
-}
-
-
-// ---- pieces shared by the direct and the Winograd kernels -------------------------------------
-template <int S, int G, typename C = FwdCfg<S, G>, int NTHR = 256>
-__device__ __forceinline__ void stage_planes(unsigned char *smem, const float *__restrict__ planes, int b0,
-                                             int batch, int tid) {
-    constexpr int P = C::P, M = C::M;
-    // global [b][6][P] -> LDS in8 [row][8]
-        {
-            float *in8 = reinterpret_cast<float *>(smem + C::AUX);
-            for (int e = tid; e < G * 6 * P; e += NTHR) {
-                const int bl = e / (6 * P);
-                const int rem = e - bl * 6 * P;
-                const int c = rem / P;
-                const int p = rem - c * P;
-                const int b = b0 + bl;
-                // streamed once: non-temporal, so the planes do not evict the L2-resident weights
-                const float v = (b < batch) ? __builtin_nontemporal_load(&planes[(size_t)b * 6 * P + rem]) : 0.f;
-                in8[(bl * P + p) * 8 + c] = v;
-            }
-            for (int e = tid; e < M * 2; e += NTHR) in8[(e >> 1) * 8 + 6 + (e & 1)] = 0.f;
-        }
-}
-
-template <int S, int G, typename C = FwdCfg<S, G>, int NTHR = 256>
-__device__ __forceinline__ void run_heads(unsigned char *smem, const NetDev &net, int b0, int batch,
-                                          int want_logits, float *__restrict__ policy,
-                                          float *__restrict__ value, int tid) {
-    constexpr int P = C::P, A = C::A, M = C::M;
-    const int wave = tid >> 6, lane = tid & 63;
-        float *hpol = reinterpret_cast<float *>(smem + C::AUX);   // [G][2P]
-        float *hval = hpol + G * 2 * P;                           // [G][P]
-        float *plog = hval + G * P;                               // [G][A]
-        float *vlog = plog + G * A;                               // [G][4]
-        {
-            const float ps0 = net.head_ss[0], pt0 = net.head_ss[1];
-            const float ps1 = net.head_ss[2], pt1 = net.head_ss[3];
-            const float vs = net.head_ss[4], vt = net.head_ss[5];
-            for (int r = tid; r < M; r += NTHR) {
-                float d0 = 0.f, d1 = 0.f, d2 = 0.f;
-#pragma unroll
-                for (int k4 = 0; k4 < 16; ++k4) {
-                    const f32x4 xv = lds_f32x4(smem, r * C::ROW_BYTES + k4 * 16);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int k = k4 * 4 + j;
-                        d0 = fmaf(xv[j], net.hp_w[k], d0);
-                        d1 = fmaf(xv[j], net.hp_w[64 + k], d1);
-                        d2 = fmaf(xv[j], net.hv_w[k], d2);
-                    }
-                }
-                const int bl = r / P, p = r - bl * P;
-                hpol[bl * 2 * P + p] = fmaxf(fmaf(d0, ps0, pt0), 0.f);
-                hpol[bl * 2 * P + P + p] = fmaxf(fmaf(d1, ps1, pt1), 0.f);
-                hval[bl * P + p] = fmaxf(fmaf(d2, vs, vt), 0.f);
-            }
-        }
-        __syncthreads();
-        for (int e = tid; e < G * A + G * 3; e += NTHR) {
-            if (e < G * A) {
-                const int bl = e / A, a = e - bl * A;
-                const float *h = hpol + bl * 2 * P;
-                const float *wT = net.pfc_wT + a;
-                float s0 = net.pfc_b[a], s1 = 0.f, s2 = 0.f, s3 = 0.f;
-                int j = 0;
-                for (; j + 4 <= 2 * P; j += 4) {
-                    s0 = fmaf(h[j], wT[(size_t)j * A], s0);
-                    s1 = fmaf(h[j + 1], wT[(size_t)(j + 1) * A], s1);
-                    s2 = fmaf(h[j + 2], wT[(size_t)(j + 2) * A], s2);
-                    s3 = fmaf(h[j + 3], wT[(size_t)(j + 3) * A], s3);
-                }
-                for (; j < 2 * P; ++j) s0 = fmaf(h[j], wT[(size_t)j * A], s0);
-                plog[e] = (s0 + s1) + (s2 + s3);
-            } else {
-                const int q = e - G * A;
-                const int bl = q / 3, c = q - bl * 3;
-                const float *h = hval + bl * P;
-                const float *wv = net.vfc_w + c * P;
-                float s0 = net.vfc_b[c];
-                for (int j = 0; j < P; ++j) s0 = fmaf(h[j], wv[j], s0);
-                vlog[bl * 4 + c] = s0;
-            }
-        }
-        __syncthreads();
-        for (int bl = wave; bl < G; bl += NTHR / 64) {
-            const int b = b0 + bl;
-            if (b >= batch) continue;
-            float m = -INFINITY;
-            for (int a = lane; a < A; a += 64) m = fmaxf(m, plog[bl * A + a]);
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-            float sum = 0.f;
-            for (int a = lane; a < A; a += 64) sum += expf(plog[bl * A + a] - m);
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-            const float inv = 1.f / sum;
-            for (int a = lane; a < A; a += 64) {
-                const float lg_ = plog[bl * A + a];
-                __builtin_nontemporal_store(want_logits ? lg_ : expf(lg_ - m) * inv, &policy[(size_t)b * A + a]);
-            }
-            if (lane < 3) {
-                const float v0 = vlog[bl * 4], v1 = vlog[bl * 4 + 1], v2 = vlog[bl * 4 + 2];
-                const float vm = fmaxf(v0, fmaxf(v1, v2));
-                const float e0 = expf(v0 - vm), e1 = expf(v1 - vm), e2 = expf(v2 - vm);
-                const float es = e0 + e1 + e2;
-                const float mine = lane == 0 ? e0 : (lane == 1 ? e1 : e2);
-                value[(size_t)b * 3 + lane] = mine / es;
-            }
-        }
-}
 
 template <int S, int G>
 __global__ __launch_bounds__(256, (FwdCfg<S, G>::WAVES_PER_SIMD)) void dualnet_fwd_kernel(
@@ -440,8 +269,10 @@ struct WinoCfg {
 template <int S, int G, bool GS = false>
 __global__ __launch_bounds__(512, 2) void dualnet_fwd_wino8_kernel(
     NetDev net, const float *__restrict__ planes, int batch, int want_logits,
-    float *__restrict__ policy, float *__restrict__ value) {
+    float *__restrict__ policy, float *__restrict__ value, const int *__restrict__ guard) {
     using C = WinoCfg<S, G, GS>;
+    // fallback launch behind the split-operand kernel: runs only if that kernel raised its range flag
+    if (guard != nullptr && __builtin_nontemporal_load(guard) == 0) return;
     constexpr int P = C::P, M = C::M, MT = C::MT;
     constexpr int TY = C::TY, TPB = C::TPB, NT = C::NT, RT = C::RT;
     constexpr int MTH = (MT + 1) / 2;                 // stem M-tiles per half
@@ -712,24 +543,6 @@ __global__ __launch_bounds__(512, 2) void dualnet_fwd_wino8_kernel(
 // ======================================================================================
 // host side
 // ======================================================================================
-struct tg_net {
-    int board_size = 0;
-    int device = 0;
-    int num_cus = 256;
-    NetDev dev{};
-    std::vector<void *> allocs;
-    // staging buffers for the host-pointer entry point (guarded by host_mu: the host API of one
-    // handle may be called from several threads, e.g. self-play group threads sharing a network)
-    float *st_planes = nullptr, *st_policy = nullptr, *st_value = nullptr;
-    int st_cap = 0;
-    std::mutex host_mu;
-    // 19x19 Winograd kernel: one scratch image set PER STREAM.  Launches on one stream run in order,
-    // launches on different streams may overlap on the device and must not share activation images.
-    std::mutex scratch_mu;
-    std::map<hipStream_t, float *> scratch_by_stream;
-    size_t scratch_floats = 0;
-};
-
 namespace {
 
 struct ParamReader {
@@ -787,7 +600,7 @@ int launch(tg_net *net, const float *planes, int batch, int want_logits, float *
 
 template <int S, int G, bool GS = false>
 int launch_wino8(tg_net *net, const float *planes, int batch, int want_logits, float *policy,
-                 float *value, hipStream_t stream) {
+                 float *value, hipStream_t stream, const int *guard = nullptr) {
     using C = WinoCfg<S, G, GS>;
     auto kern = dualnet_fwd_wino8_kernel<S, G, GS>;
     static bool attr_set[16] = {};
@@ -810,7 +623,7 @@ int launch_wino8(tg_net *net, const float *planes, int batch, int want_logits, f
         dev.scratch = slot;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), C::LDS_BYTES, stream, dev, planes, batch,
-                       want_logits, policy, value);
+                       want_logits, policy, value, guard);
     TG_HIP(hipGetLastError());
     return TG_OK;
 }
@@ -858,8 +671,11 @@ int tg_net_create(int board_size, int device, const float *params, size_t n_para
 
     // stem: conv_layer.weight [64][6][3][3] -> w0frag[w][tap][lane][2]
     std::vector<float> w0(4 * 9 * 64 * 2, 0.f);
+    const float *conv0_raw = nullptr;
+    const float *tower_raw[12] = {};
     {
         const float *w = rd.take(64 * 6 * 9);
+        conv0_raw = w;
         for (int wv = 0; wv < 4; ++wv)
             for (int tap = 0; tap < 9; ++tap)
                 for (int lane = 0; lane < 64; ++lane)
@@ -876,6 +692,8 @@ int tg_net_create(int board_size, int device, const float *params, size_t n_para
     for (int b = 0; b < kBlocks; ++b) {
         const float *wc[2] = {rd.take(64 * 64 * 9), nullptr};
         wc[1] = rd.take(64 * 64 * 9);
+        tower_raw[2 * b] = wc[0];
+        tower_raw[2 * b + 1] = wc[1];
         for (int c = 0; c < 2; ++c) {
             const int layer = 2 * b + c;  // 0..11
             for (int wv = 0; wv < 4; ++wv)
@@ -955,6 +773,10 @@ int tg_net_create(int board_size, int device, const float *params, size_t n_para
         tg_net_destroy(net);
         return rc;
     }
+    if (board_size == 9 && (rc = tg::split_prepare(net, conv0_raw, tower_raw, scale.data()))) {
+        tg_net_destroy(net);
+        return rc;
+    }
     *out = net;
     return TG_OK;
 }
@@ -964,6 +786,7 @@ int tg_net_destroy(tg_net *net) {
     (void)hipSetDevice(net->device);
     for (void *p : net->allocs) (void)hipFree(p);
     for (auto &kv : net->scratch_by_stream) (void)hipFree(kv.second);
+    for (auto &kv : net->flag_by_stream) (void)hipFree(kv.second);
     if (net->st_planes) (void)hipFree(net->st_planes);
     if (net->st_policy) (void)hipFree(net->st_policy);
     if (net->st_value) (void)hipFree(net->st_value);
@@ -984,10 +807,18 @@ static int pick_group(int board_size, int batch, int num_cus) {
 
 static int pick_wino(int board_size, int batch, int num_cus);
 
+// 9x9 forward algorithm: TG_FWD_ALGO = split16 (f16 x 2 operand pieces on the 16-bit matrix pipe, 3 MFMAs
+// per product-sum; default) | wino (exact fp32 Winograd tower) | direct (exact fp32 direct convolution).
+static bool pick_split() {
+    const char *env = getenv("TG_FWD_ALGO");
+    return !env || !strcmp(env, "split16");
+}
+
 const char *tg_net_kernel_name(const tg_net *net, int batch) {
     if (!net) return "";
     if (net->board_size == 19)
         return pick_wino(19, batch, net->num_cus) ? "dualnet_fwd_wino8_kernel<19, 1, global scratch>" : "dualnet_fwd_kernel<19, 1>";
+    if (pick_split()) return batch > net->num_cus ? "dualnet_fwd_split_kernel<9, 3, f16x2>" : "dualnet_fwd_split_kernel<9, 1, f16x2>";
     {
         const int wg = pick_wino(9, batch, net->num_cus);
         if (wg == 1) return "dualnet_fwd_wino8_kernel<9, 1>";
@@ -1031,6 +862,24 @@ int tg_net_forward_dev(tg_net *net, const float *planes_dev, int batch, int want
         return launch<19, 1>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st);
     }
     if (net->board_size == 9) {
+        if (pick_split()) {
+            // split-operand kernel on the 16-bit matrix pipe.  f16 pieces: a range flag (per launch stream)
+            // makes the exact-fp32 Winograd kernel, queued right behind, redo the batch if a layer output
+            // left the f16 range; with the flag clear that launch exits at once.
+            const int group = batch > net->num_cus ? 3 : 1;
+            int *flag = nullptr;
+            {
+                std::lock_guard<std::mutex> lock(net->scratch_mu);
+                int *&slot = net->flag_by_stream[st];
+                if (!slot) TG_HIP(hipMalloc(reinterpret_cast<void **>(&slot), sizeof(int)));
+                flag = slot;
+            }
+            TG_HIP(hipMemsetAsync(flag, 0, sizeof(int), st));
+            int rc = tg::split_forward(net, group, planes_dev, batch, want_logits, policy_dev, value_dev, flag, st);
+            if (rc) return rc;
+            if (group == 3) return launch_wino8<9, 3>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st, flag);
+            return launch_wino8<9, 1>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st, flag);
+        }
         const int wg = pick_wino(9, batch, net->num_cus);
         if (wg == 1) return launch_wino8<9, 1>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st);
         if (wg == 2) return launch_wino8<9, 2>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st);

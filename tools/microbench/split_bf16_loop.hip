@@ -115,6 +115,325 @@ __global__ __launch_bounds__(512, 2) void k(const unsigned char *__restrict__ wg
     out[blockIdx.x * 512 + tid] = total[0] + total[1] + total[2] + total[3];
 }
 
+
+// Software-pipelined form: the flattened step sequence (tap, k-chunk, cout pair) keeps the fragments of
+// step s+1 in flight while the 24 MFMAs of step s issue; ONE barrier per tap, placed before the tap's last
+// step: by then every wave has read all of this tap's weights (the last step's fragments are in registers),
+// so the buffer can be refilled for tap+2, and every wave's DMA pieces of tap+1 have landed.
+template <int PRIO, int NA = 6, int NB = 6, bool MF = true>
+__global__ __launch_bounds__(512, 2) void kpipe(const unsigned char *__restrict__ wglob, float *out, int layers) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+    for (int e = tid; e < LDS_BYTES / 4; e += 512) reinterpret_cast<unsigned *>(smem)[e] = ((e * 2654435761u) ^ (blockIdx.x * 40503u)) & 0xBF7FBF7Fu;
+    __syncthreads();
+    int base_row[2];
+    unsigned mask[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int row = (wid * 2 + r) * 16 + li;
+        const int p = row % 81, y = p / S, x = p % S;
+        unsigned m = 0;
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            if (row < ROWS && yy >= 0 && yy < S && xx >= 0 && xx < S) m |= 1u << t;
+        }
+        mask[r] = m;
+        base_row[r] = row;
+    }
+    f32x4 acc[4][2];
+    f32x4 total = {0.f, 0.f, 0.f, 0.f};
+    const unsigned char *wsrc = wglob + lane * 16;
+    const int ntaps = layers * 9;
+    auto dma = [&](int g) {                         // global tap index -> buffer g & 1
+        if (g >= ntaps) return;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int piece = wid * 3 + q;
+            const unsigned char *src = wsrc + ((size_t)g * 24 + piece) * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(smem + W_OFF + (g & 1) * W_TAP + piece * 1024),
+                                             16, 0, 0);
+        }
+    };
+    auto act_addr = [&](int tap, int r) {
+        const int toff = (tap / 3 - 1) * S + (tap % 3 - 1);
+        const int row = base_row[r] + toff;
+        const bool ok = (mask[r] >> tap) & 1u;
+        return ok ? row * 64 + ((lg ^ ((row >> 1) & 3)) << 4) : -1;
+    };
+    auto load_b = [&](bf16x8 (&b)[2][3], int tap, int kc) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int a0 = act_addr(tap, r);
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                if (r * 3 + p < NB) b[r][p] = *reinterpret_cast<const bf16x8 *>(smem + (a0 < 0 ? ZERO_OFF : a0 + p * ACT_PIECE + kc * ROWS * 64));
+        }
+    };
+    auto load_a = [&](bf16x8 (&a)[2][3], int g, int kc, int c2) {
+        const int wbase = W_OFF + (g & 1) * W_TAP + lane * 16;
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                if (cc * 3 + p < NA) a[cc][p] = *reinterpret_cast<const bf16x8 *>(smem + wbase + ((kc * 3 + p) * 4 + c2 * 2 + cc) * 1024);
+    };
+    dma(0);
+    dma(1);
+    __syncthreads();                                 // (vmcnt(0) + barrier: taps 0 and 1 landed)
+    bf16x8 a_cur[2][3] = {}, a_nxt[2][3] = {}, b_cur[2][3] = {}, b_nxt[2][3] = {};
+    int g = 0;
+    for (int layer = 0; layer < layers; ++layer) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) acc[c][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        load_b(b_cur, 0, 0);
+        load_a(a_cur, g, 0, 0);
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap, ++g) {
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const int kc = st >> 1, c2 = st & 1;
+                if (st == 3) {
+                    // all reads of this tap's weights are issued and (below) consumed from registers
+                    __syncthreads();
+                    dma(g + 2);
+                }
+                // prefetch the next step's fragments
+                if (st < 3) {
+                    load_a(a_nxt, g, (st + 1) >> 1, (st + 1) & 1);
+                    if (st == 1) load_b(b_nxt, tap, 1);
+                } else if (tap < 8) {
+                    load_a(a_nxt, g + 1, 0, 0);
+                    load_b(b_nxt, tap + 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (PRIO) __builtin_amdgcn_s_setprio(1);
+                constexpr int PA[6] = {0, 0, 1, 0, 2, 1};
+                constexpr int PB[6] = {0, 1, 0, 2, 0, 1};
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+#pragma unroll
+                    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                        for (int r = 0; r < 2; ++r)
+                            if (MF) acc[c2 * 2 + cc][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur[cc][PA[q]], b_cur[r][PB[q]], acc[c2 * 2 + cc][r], 0, 0, 0);
+                            else if (q == 0) acc[c2 * 2 + cc][r][0] += (float)a_cur[cc][0][0] + (float)a_cur[cc][1][1] + (float)a_cur[cc][2][2] + (float)b_cur[r][0][3] + (float)b_cur[r][1][4] + (float)b_cur[r][2][5];
+                if (PRIO) __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) a_cur[cc][p] = a_nxt[cc][p];
+                if (st == 1 || st == 3) {
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) b_cur[r][p] = b_nxt[r][p];
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) total += acc[c][r];
+        __syncthreads();
+    }
+    out[blockIdx.x * 512 + tid] = total[0] + total[1] + total[2] + total[3];
+}
+
+template <int PRIO, int NA = 6, int NB = 6, bool MF = true>
+void run_pipe(const char *name, const unsigned char *w, float *out) {
+    const int layers = 48;
+    auto kern = kpipe<PRIO, NA, NB, MF>;
+    hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL(kern, dim3(256), dim3(512), LDS_BYTES, 0, w, out, layers);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(kern, dim3(256), dim3(512), LDS_BYTES, 0, w, out, layers);
+    hipEventRecord(e1);
+    hipDeviceSynchronize();
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    ms /= 5;
+    const double us_layer = ms * 1e3 / layers;
+    const double flop = 256.0 * layers * 6912.0 * 16384.0;
+    printf("%-34s %.3f ms: %.2f us per layer per workgroup = %.0f cycles at 2.4 GHz (floor 27648), %.0f TFLOP/s bf16, "
+           "fp32-equivalent %.1f TFLOP/s (direct-conv count)\n",
+           name, ms, us_layer, us_layer * 2400.0, flop / ms / 1e9, flop / 6.0 / ms / 1e9);
+    if (hipGetLastError() != hipSuccess) printf("  (error)\n");
+}
+
+
+// Hand-placed form: LDS fragment loads are inline-asm ds_read_b128 (the compiler does not track them, so
+// it inserts no lgkmcnt(0) of its own); the loads of step s+1 go out one after each of the first MFMAs of
+// step s; one manual s_waitcnt per step, tied to the fragment registers so that no MFMA can move above it.
+typedef int i32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void lds_load(i32x4v &dst, int addr) {
+    asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
+}
+__device__ __forceinline__ void wait_frags(i32x4v (&a)[2][3], i32x4v (&b)[2][3]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]),
+                   "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][2]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[1][2]));
+}
+template <int PRIO, int GAP>
+__global__ __launch_bounds__(512, 2) void kasm(const unsigned char *__restrict__ wglob, float *out, int layers) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+    for (int e = tid; e < LDS_BYTES / 4; e += 512) reinterpret_cast<unsigned *>(smem)[e] = ((e * 2654435761u) ^ (blockIdx.x * 40503u)) & 0xBF7FBF7Fu;
+    __syncthreads();
+    int base_row[2];
+    unsigned mask[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int row = (wid * 2 + r) * 16 + li;
+        const int p = row % 81, y = p / S, x = p % S;
+        unsigned m = 0;
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            if (row < ROWS && yy >= 0 && yy < S && xx >= 0 && xx < S) m |= 1u << t;
+        }
+        mask[r] = m;
+        base_row[r] = row;
+    }
+    f32x4 acc[4][2];
+    f32x4 total = {0.f, 0.f, 0.f, 0.f};
+    const unsigned char *wsrc = wglob + lane * 16;
+    const int ntaps = layers * 9;
+    const int lds0 = (int)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;   // LDS byte address of smem
+    auto dma = [&](int g) {
+        if (g >= ntaps) return;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int piece = wid * 3 + q;
+            const unsigned char *src = wsrc + ((size_t)g * 24 + piece) * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(smem + W_OFF + (g & 1) * W_TAP + piece * 1024),
+                                             16, 0, 0);
+        }
+    };
+    auto act_addr = [&](int tap, int r) {
+        const int toff = (tap / 3 - 1) * S + (tap % 3 - 1);
+        const int row = base_row[r] + toff;
+        const bool ok = (mask[r] >> tap) & 1u;
+        return ok ? row * 64 + ((lg ^ ((row >> 1) & 3)) << 4) : -1;
+    };
+    // address of load number i (0..5 weights, 6..11 activations) of a step
+    auto a_addr = [&](int g, int kc, int c2, int i) {
+        const int cc = i / 3, p = i % 3;
+        return lds0 + W_OFF + (g & 1) * W_TAP + lane * 16 + ((kc * 3 + p) * 4 + c2 * 2 + cc) * 1024;
+    };
+    auto b_addr = [&](int a0, int kc, int p) { return lds0 + (a0 < 0 ? ZERO_OFF : a0 + p * ACT_PIECE + kc * ROWS * 64); };
+    dma(0);
+    dma(1);
+    __syncthreads();
+    i32x4v a_cur[2][3], a_nxt[2][3], b_cur[2][3], b_nxt[2][3];
+    int g = 0;
+    for (int layer = 0; layer < layers; ++layer) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) acc[c][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        {
+            const int a0 = act_addr(0, 0), a1 = act_addr(0, 1);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) lds_load(a_cur[i / 3][i % 3], a_addr(g, 0, 0, i));
+#pragma unroll
+            for (int p = 0; p < 3; ++p) { lds_load(b_cur[0][p], b_addr(a0, 0, p)); lds_load(b_cur[1][p], b_addr(a1, 0, p)); }
+        }
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap, ++g) {
+            const int nb0 = act_addr(tap, 0), nb1 = act_addr(tap, 1);
+            const int nt0 = tap < 8 ? act_addr(tap + 1, 0) : -1, nt1 = tap < 8 ? act_addr(tap + 1, 1) : -1;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const int kc = st >> 1, c2 = st & 1;
+                if (st == 3) {
+                    __syncthreads();
+                    dma(g + 2);
+                }
+                wait_frags(a_cur, b_cur);
+                if (PRIO) __builtin_amdgcn_s_setprio(1);
+                constexpr int PA[6] = {0, 0, 1, 0, 2, 1};
+                constexpr int PB[6] = {0, 1, 0, 2, 0, 1};
+                int issued = 0;
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+#pragma unroll
+                    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                        for (int r = 0; r < 2; ++r) {
+                            acc[c2 * 2 + cc][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                __builtin_bit_cast(bf16x8, a_cur[cc][PA[q]]), __builtin_bit_cast(bf16x8, b_cur[r][PB[q]]), acc[c2 * 2 + cc][r], 0, 0, 0);
+                            const int m = q * 4 + cc * 2 + r;            // MFMA number within the step
+                            if (m % GAP == GAP - 1) {
+                                const int i = m / GAP;                   // load number: 0..5 weights, 6..11 acts
+                                if (i < 6) {
+                                    if (st < 3) lds_load(a_nxt[i / 3][i % 3], a_addr(g, (st + 1) >> 1, (st + 1) & 1, i));
+                                    else lds_load(a_nxt[i / 3][i % 3], a_addr(g + 1, 0, 0, i));
+                                } else if (i < 12 && (st == 1 || st == 3)) {
+                                    const int r2 = (i - 6) / 3, p2 = (i - 6) % 3;
+                                    if (st == 1) lds_load(b_nxt[r2][p2], b_addr(r2 ? nb1 : nb0, 1, p2));
+                                    else lds_load(b_nxt[r2][p2], b_addr(r2 ? nt1 : nt0, 0, p2));
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                if (PRIO) __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) a_cur[cc][p] = a_nxt[cc][p];
+                if (st == 1 || st == 3) {
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) b_cur[r][p] = b_nxt[r][p];
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) total += acc[c][r];
+        __syncthreads();
+    }
+    out[blockIdx.x * 512 + tid] = total[0] + total[1] + total[2] + total[3];
+}
+
+template <int PRIO, int GAP>
+void run_asm(const char *name, const unsigned char *w, float *out) {
+    const int layers = 48;
+    auto kern = kasm<PRIO, GAP>;
+    hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL(kern, dim3(256), dim3(512), LDS_BYTES, 0, w, out, layers);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(kern, dim3(256), dim3(512), LDS_BYTES, 0, w, out, layers);
+    hipEventRecord(e1);
+    hipDeviceSynchronize();
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    ms /= 5;
+    const double us_layer = ms * 1e3 / layers;
+    const double flop = 256.0 * layers * 6912.0 * 16384.0;
+    printf("%-34s %.3f ms: %.2f us per layer per workgroup = %.0f cycles at 2.4 GHz (floor 27648), %.0f TFLOP/s bf16\n",
+           name, ms, us_layer, us_layer * 2400.0, flop / ms / 1e9);
+    if (hipGetLastError() != hipSuccess) printf("  (error)\n");
+}
+
 template <bool DMA, bool BAR, bool LDSREAD>
 void run(const char *name, const unsigned char *w, float *out) {
     const int layers = 48;
@@ -157,5 +476,16 @@ int main() {
     run<false, false, true>("mfma + lds reads", w, out);
     run<false, true, true>("mfma + lds reads + barriers", w, out);
     run<true, true, true>("mfma + lds reads + barriers + dma", w, out);
+    run_pipe<0>("pipelined, all of it", w, out);
+    run_pipe<1>("pipelined, setprio around MFMAs", w, out);
+    run_asm<0, 1>("asm loads, one after each MFMA", w, out);
+    run_asm<0, 2>("asm loads, one per 2 MFMAs", w, out);
+    run_asm<1, 1>("asm loads, gap 1, setprio", w, out);
+    run_asm<1, 2>("asm loads, gap 2, setprio", w, out);
+    run_pipe<0, 6, 6, false>("pipelined, LDS reads only (18/chunk)", w, out);
+    run_pipe<0, 3, 6, true>("pipelined, 12 reads/chunk (w 6, a 6)", w, out);
+    run_pipe<0, 3, 3, true>("pipelined, 9 reads/chunk (w 6, a 3)", w, out);
+    run_pipe<0, 1, 1, true>("pipelined, 3 reads/chunk (w 2, a 1)", w, out);
+    run_pipe<0, 0, 0, true>("pipelined, 0 reads/chunk", w, out);
     return 0;
 }
