@@ -32,10 +32,12 @@
 //   * weights stream tap by tap (16 / 24 KB) from L2 into a two-slot LDS ring with global_load_lds_dwordx4 in
 //     MFMA A-fragment order: one copy per workgroup instead of one per wave, conflict-free reads, ONE barrier
 //     per tap;
-//   * fragment loads are inline-asm ds_read_b128, issued between the MFMAs of the previous k-chunk, with one
-//     hand-placed s_waitcnt per chunk (hipcc puts lgkmcnt(0) right behind loads it knows about).
+//   * fragment loads are issued between the MFMAs of earlier k-chunks (activations one chunk ahead, weights
+//     two), their program positions pinned with sched_barrier; the chunk sequence of a layer is straight-line
+//     code, so hipcc's counted waits land exactly where the fragments are first used.
 #include "net_device.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <type_traits>
 #include <utility>
@@ -65,10 +67,16 @@ struct SplitCfg {
     static constexpr int NTHR = NW * 64;
     static constexpr int IMG = (M + 1) * 64;                      // one [row][64 B] image + its zero row
     static constexpr int ACT_BYTES = F::NP * 2 * IMG;             // image index = piece * 2 + kc
-    static constexpr int W_OFF = (ACT_BYTES + 255) & ~255;
-    static constexpr int W_TAP = 2 * F::NP * 4 * 1024;            // [kc][piece][ct][lane][16 B]
-    static constexpr int STAGE = W_OFF + 2 * W_TAP;               // input planes [G][6][P] fp32
-    static constexpr int PIPE_BYTES = STAGE + ((G * 6 * P * 4 + 255) & ~255);
+    static constexpr int CHUNK = F::NP * 4 * 1024;                // weight image per k-chunk: [piece][ct][lane][16 B]
+    static constexpr int STAGE = (ACT_BYTES + 255) & ~255;        // input planes [G][6][P] fp32 (group start only)
+    // residual-block input X as fp32 [row][16 x 16 B], slot ^= row & 15 (conflict-free 16-byte accesses);
+    // written by the stem / conv2 epilogues, added back two layers later.  Keeping it out of the register
+    // file (64 registers) is what lets accumulators + five fragment sets stay put.
+    // (behind the fp32 image the LAST epilogue writes for the heads, which must not run into residuals that
+    // other waves have yet to read)
+    static constexpr int RES_OFF = STAGE + ((G * 6 * P * 4 + 255) & ~255) > ((M * kRowBytes + 255) & ~255)
+                                       ? STAGE + ((G * 6 * P * 4 + 255) & ~255) : ((M * kRowBytes + 255) & ~255);
+    static constexpr int PIPE_BYTES = RES_OFF + M * 256;
     // head phase (after the last layer): fp32 activations [M][72 floats] from offset 0 + run_heads scratch
     static constexpr int ROW_BYTES = kRowBytes;
     static constexpr int AUX = ((M * kRowBytes + 255) & ~255);
@@ -76,10 +84,18 @@ struct SplitCfg {
     static constexpr int LDS_BYTES = PIPE_BYTES > HEAD_BYTES ? PIPE_BYTES : HEAD_BYTES;
 };
 
+// Fragment loads are PLAIN loads: hipcc tracks lgkmcnt / vmcnt for them exactly in straight-line code (counted
+// waits at the first use, one / two k-chunks later) and knows which registers are still in flight.  (A first
+// version issued them as inline asm with hand-placed s_waitcnt: hipcc then treats the destination as written at
+// once, and under register pressure it copied or re-used such registers before the data had landed.)
 template <int OFFSET>
-__device__ __forceinline__ void lds_load_frag(i32x4v &dst, int addr) {
-    static_assert(OFFSET >= 0 && OFFSET < 65536 && OFFSET % 16 == 0, "ds_read_b128 offset field");
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFFSET));
+__device__ __forceinline__ void lds_load_frag(i32x4v &dst, const unsigned char *smem, int addr) {
+    dst = *reinterpret_cast<const i32x4v *>(smem + addr + OFFSET);
+}
+
+// weight fragment straight from the L2-resident image (1 KB per wave, coalesced)
+__device__ __forceinline__ void gmem_load_frag(i32x4v &dst, const unsigned char *base, int byte_off) {
+    dst = *reinterpret_cast<const i32x4v *>(base + byte_off);
 }
 
 // compile-time loop: fn(std::integral_constant<int, 0>{}), ..., fn(std::integral_constant<int, N - 1>{})
@@ -111,7 +127,7 @@ __device__ __forceinline__ void split4(const f32x4 v, uint2 (&out)[F::NP]) {
     }
 }
 
-template <int S, int G, typename F>
+template <int S, int G, typename F, int SPANQ = 6>
 __global__ __launch_bounds__((SplitCfg<S, G, F>::NTHR), 1) void dualnet_fwd_split_kernel(
     NetDev net, const float *__restrict__ planes, int batch, int want_logits,
     float *__restrict__ policy, float *__restrict__ value, int *__restrict__ overflow) {
@@ -120,8 +136,8 @@ __global__ __launch_bounds__((SplitCfg<S, G, F>::NTHR), 1) void dualnet_fwd_spli
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
-    const int lds0 = (int)(size_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: scalar branches around the DMA
+    const int lane = tid & 63, li = lane & 15, lg = lane >> 4;
 
     // ---- per-lane geometry of this wave's row-tiles ------------------------------------------------
     int base_row[RTW];
@@ -143,28 +159,24 @@ __global__ __launch_bounds__((SplitCfg<S, G, F>::NTHR), 1) void dualnet_fwd_spli
     for (int e = tid; e < NP * 2 * 16; e += NTHR)
         reinterpret_cast<unsigned *>(smem + (e >> 4) * IMG + M * 64)[e & 15] = 0u;
 
-    const unsigned char *wimg = net.wsplit + lane * 16;
     const float *bn_scale = net.sscale;
-    // weight ring: global tap g -> slot g & 1; every wave copies its share of the 2 * NP * 4 one-KB pieces
-    auto dma = [&](int g) {
-        if (g >= kSplitTaps) return;
-        constexpr int PIECES = 2 * NP * 4;
-#pragma unroll
-        for (int q = 0; q < (PIECES + C::NW - 1) / C::NW; ++q) {
-            const int piece = q * C::NW + wave;
-            if (piece < PIECES)
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void *)(wimg + ((size_t)g * PIECES + piece) * 1024),
-                    (__attribute__((address_space(3))) void *)(smem + C::W_OFF + (g & 1) * C::W_TAP + piece * 1024), 16, 0, 0);
-        }
-    };
+    // weight stream: k-chunk gc = 2 * tap + kc of the whole network lies at wsplit + gc * CHUNK; a chunk's eight
+    // fragments are at lane * 16 + (piece * 4 + ct) * 1024 (two lane offsets cover the 4 KB offset field)
+    const int wv0 = lane * 16;
+    constexpr int kChunks = 2 * kSplitTaps;
 
+    // profiling stamps (tg_net_profile_phases): workgroup 0, wave 0: 0 group start, 1 input staged + split,
+    // then per layer (stem first) "MFMA loop done" / "epilogue done", last: heads done
+    int stamp_i = 0;
+    auto stamp = [&]() {
+        if (net.timeline && blockIdx.x == 0 && tid == 0 && stamp_i < 64)
+            net.timeline[stamp_i++] = (long long)__builtin_amdgcn_s_memtime();
+    };
     int ovf = 0;
     const int n_groups = (batch + G - 1) / G;
     for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
         const int b0 = grp * G;
-        dma(0);
-        dma(1);
+        stamp();
         // ---- input planes -> LDS -> im2col'ed, split "layer -1" activations (K = 9 taps x 6 planes, padded to 64) ----
         {
             float *st = reinterpret_cast<float *>(smem + C::STAGE);
@@ -195,119 +207,120 @@ __global__ __launch_bounds__((SplitCfg<S, G, F>::NTHR), 1) void dualnet_fwd_spli
                         uint4{plo[q].x, plo[q].y, phi[q].x, phi[q].y};
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of taps 0 and 1 have landed
-        __syncthreads();                                  // activations written; everybody's pieces have landed
+        __syncthreads();                                  // activations written
+        stamp();
 
         f32x4 acc[F::NACC][4][RTW];
-        f32x4 res[4][RTW];
-        i32x4v fa[2][4][NP], fb[2][RTW][NP];              // two fragment sets: weights (A operand), activations (B)
+        // fragment sets: weights (A operand) three deep - requested TWO k-chunks ahead from L2 -, activations
+        // (B operand) two deep - requested one chunk ahead from LDS
+        i32x4v fa[3][4][NP], fb[2][RTW][NP];
 
         // B-fragment base address of row-tile r for tap `tap` of layer kind `stem`
-        auto row_addr = [&](int r, int tap, bool stem) {
+        auto row_addr = [&](int r, int tap, bool stem) __attribute__((always_inline)) {
             const int toff = stem ? 0 : (tap / 3 - 1) * S + (tap % 3 - 1);
             const bool ok = stem ? base_row[r] < M : ((mask[r] >> tap) & 1u) != 0;
             const int row = ok ? base_row[r] + toff : M;
-            return lds0 + row * 64 + ((lg ^ ((row >> 1) & 3)) << 4);
+            return row * 64 + ((lg ^ ((row >> 1) & 3)) << 4);
         };
-        auto load_b = [&](i32x4v &dst, auto P_, auto KC_, int addr) {
-            // image (p, kc) at (p * 2 + kc) * IMG; the 16-bit offset field reaches 64 KB
-            constexpr int off = (decltype(P_)::value * 2 + decltype(KC_)::value) * IMG;
-            lds_load_frag<off>(dst, addr);
+        auto load_b = [&](i32x4v &dst, auto P_, auto KC_, int addr) __attribute__((always_inline)) {
+            constexpr int off = (decltype(P_)::value * 2 + decltype(KC_)::value) * IMG;   // image (p, kc)
+            lds_load_frag<off>(dst, smem, addr);
         };
+        // all eight weight fragments of chunk gc into set SET
+        auto load_a_all = [&](auto SET_, int gc) __attribute__((always_inline)) {
+            constexpr int set = decltype(SET_)::value;
+            const unsigned char *base = net.wsplit + (size_t)(gc < kChunks ? gc : kChunks - 1) * C::CHUNK;
+            static_for<4 * NP>([&](auto J) {
+                constexpr int j = decltype(J)::value, c = j % 4, p = j / 4;
+                gmem_load_frag(fa[set][c][p], base, wv0 + (p * 4 + c) * 1024);
+            });
+        };
+        // chunk gc uses weight set (gc + 1) % 3: the stem's two chunks take sets 1 and 2, every tower layer
+        // (18 chunks) starts at set 0
+        load_a_all(std::integral_constant<int, 1>{}, 0);
+        load_a_all(std::integral_constant<int, 2>{}, 1);
 
-        int g = 0;                                        // global tap index
+        // One k-chunk: wait for its fragments, 4 * RTW * NPROD MFMAs; in between, the activation fragments of the
+        // next chunk (LDS, set 1 - BSET) and the weight fragments of the chunk after next (L2, the set this
+        // chunk's predecessor used).  ba: this tap's row addresses (for a KC = 0 chunk's successor), bn: the
+        // next tap's.
+        auto chunk = [&](auto KC_, auto ASET_, int gc, const int (&ba)[RTW], const int (&bn)[RTW]) __attribute__((always_inline)) {
+            constexpr int kc = decltype(KC_)::value, aset = decltype(ASET_)::value, anext = (aset + 2) % 3;
+            // (this chunk's fragments went out one / two chunks ago; hipcc places the counted waits)
+            const unsigned char *wnext = net.wsplit + (size_t)(gc + 2 < kChunks ? gc + 2 : kChunks - 1) * C::CHUNK;
+            constexpr int NMFMA = 4 * RTW * F::NPROD;
+            constexpr int NB = RTW * NP, NA = 4 * NP;
+            constexpr int BSPAN = NMFMA * SPANQ / 16;      // activation loads: during the first SPANQ/16 of the chunk
+            static_for<NMFMA>([&](auto M_) {
+                constexpr int m = decltype(M_)::value;
+                constexpr int q = m / (4 * RTW), c = (m / RTW) % 4, r = m % RTW;
+                acc[F::PC[q]][c][r] = mfma16<F>(fa[aset][c][F::PA[q]], fb[kc][r][F::PB[q]], acc[F::PC[q]][c][r]);
+                // activation fragment j of the next chunk (uniformly spread over the first BSPAN MFMAs)
+                constexpr int jb0 = m * NB / BSPAN, jb1 = (m + 1) * NB / BSPAN;
+                if constexpr (jb1 > jb0 && jb0 < NB) {
+                    constexpr int r2 = jb0 % RTW, p2 = jb0 / RTW;
+                    if constexpr (kc == 0) load_b(fb[1][r2][p2], std::integral_constant<int, p2>{}, std::integral_constant<int, 1>{}, ba[r2]);
+                    else load_b(fb[0][r2][p2], std::integral_constant<int, p2>{}, std::integral_constant<int, 0>{}, bn[r2]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // weight fragment j of the chunk after next (spread over the whole chunk)
+                constexpr int ja0 = m * NA / NMFMA, ja1 = (m + 1) * NA / NMFMA;
+                if constexpr (ja1 > ja0) {
+                    constexpr int c2 = ja0 % 4, p2 = ja0 / 4;
+                    gmem_load_frag(fa[anext][c2][p2], wnext, wv0 + (p2 * 4 + c2) * 1024);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+
+        int gc = 0;                                       // k-chunk index over the whole network
 #pragma unroll 1
         for (int layer = 0; layer <= kTowerLayers; ++layer) {
             const bool stem = layer == 0;
-            const int ntaps = stem ? 1 : 9;
 #pragma unroll
             for (int s = 0; s < F::NACC; ++s)
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
 #pragma unroll
                     for (int r = 0; r < RTW; ++r) acc[s][c][r] = f32x4{0.f, 0.f, 0.f, 0.f};
-            // first chunk of the layer: activation fragments now (the epilogue just wrote them); the weight
-            // fragments of (g, kc 0) were requested by the previous layer's last chunk, except for the stem
-            {
-                int ba[RTW];
+            // activation fragments of the layer's first chunk: the previous epilogue just wrote them
+            int ba[RTW], bn[RTW];
 #pragma unroll
-                for (int r = 0; r < RTW; ++r) ba[r] = row_addr(r, 0, stem);
-                if (stem) {
-                    const int wa = lds0 + C::W_OFF + (g & 1) * C::W_TAP + lane * 16;
-                    static_for<4 * NP>([&](auto J) {
-                        constexpr int c = decltype(J)::value % 4, p = decltype(J)::value / 4;
-                        lds_load_frag<(p * 4 + c) * 1024>(fa[0][c][p], wa);
-                    });
-                }
-                static_for<RTW * NP>([&](auto J) {
-                    constexpr int r = decltype(J)::value % RTW, p = decltype(J)::value / RTW;
-                    load_b(fb[0][r][p], std::integral_constant<int, p>{}, std::integral_constant<int, 0>{}, ba[r]);
-                });
-            }
+            for (int r = 0; r < RTW; ++r) ba[r] = row_addr(r, 0, stem);
+            static_for<RTW * NP>([&](auto J) {
+                constexpr int r = decltype(J)::value % RTW, p = decltype(J)::value / RTW;
+                load_b(fb[0][r][p], std::integral_constant<int, p>{}, I0{}, ba[r]);
+            });
+            if (stem) {
+                chunk(I0{}, I1{}, gc, ba, ba);
+                chunk(I1{}, I2{}, gc + 1, ba, ba);
+                gc += 2;
+            } else {
 #pragma unroll 1
-            for (int tap = 0; tap < ntaps; ++tap, ++g) {
-                int ba[RTW], bn[RTW];
+                for (int t3 = 0; t3 < 9; t3 += 3) {        // three taps = six chunks = two turns of the weight sets
 #pragma unroll
-                for (int r = 0; r < RTW; ++r) {
-                    ba[r] = row_addr(r, tap, stem);
-                    bn[r] = row_addr(r, tap + 1 < ntaps ? tap + 1 : tap, stem);
+                    for (int r = 0; r < RTW; ++r) bn[r] = row_addr(r, t3 + 1, false);
+                    chunk(I0{}, I0{}, gc, ba, bn);
+                    chunk(I1{}, I1{}, gc + 1, ba, bn);
+#pragma unroll
+                    for (int r = 0; r < RTW; ++r) { ba[r] = bn[r]; bn[r] = row_addr(r, t3 + 2, false); }
+                    chunk(I0{}, I2{}, gc + 2, ba, bn);
+                    chunk(I1{}, I0{}, gc + 3, ba, bn);
+#pragma unroll
+                    for (int r = 0; r < RTW; ++r) { ba[r] = bn[r]; bn[r] = row_addr(r, t3 + 3 < 9 ? t3 + 3 : 8, false); }
+                    chunk(I0{}, I1{}, gc + 4, ba, bn);
+                    chunk(I1{}, I2{}, gc + 5, ba, bn);
+#pragma unroll
+                    for (int r = 0; r < RTW; ++r) ba[r] = bn[r];
+                    gc += 6;
                 }
-                const int wa_cur = lds0 + C::W_OFF + (g & 1) * C::W_TAP + lane * 16;
-                const int wa_nxt = lds0 + C::W_OFF + ((g + 1) & 1) * C::W_TAP + lane * 16;
-                auto chunk = [&](auto KC_) {
-                    constexpr int kc = decltype(KC_)::value;
-                    // ---- wait for this chunk's fragments (set kc); the loads were issued a chunk ago ----
-                    static_assert(NP == 2, "the wait below names every weight fragment register");
-                    asm volatile("s_waitcnt lgkmcnt(0)"
-                                 : "+v"(fa[kc][0][0]), "+v"(fa[kc][1][0]), "+v"(fa[kc][2][0]), "+v"(fa[kc][3][0]),
-                                   "+v"(fa[kc][0][1]), "+v"(fa[kc][1][1]), "+v"(fa[kc][2][1]), "+v"(fa[kc][3][1]));
-#pragma unroll
-                    for (int r = 0; r < RTW; ++r)
-#pragma unroll
-                        for (int p = 0; p < NP; ++p) asm volatile("" : "+v"(fb[kc][r][p]));
-                    if constexpr (kc == 1) {
-                        // every wave now holds all it needs of slot g & 1 in registers, and its own pieces of
-                        // tap g + 1 have landed (vmcnt(0) inside __syncthreads): refill the slot with tap g + 2
-                        // (hipcc does not wait for LDS-DMA traffic at a barrier by itself)
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        __syncthreads();
-                        dma(g + 2);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    // ---- MFMAs of this chunk, with the next chunk's fragment loads in between ----
-                    constexpr int NLOAD = (4 + RTW) * NP;
-                    constexpr int NMFMA = 4 * RTW * F::NPROD;
-                    constexpr int SPAN = NMFMA * 3 / 4;                    // loads go out during the first 3/4
-                    const bool next_b = kc == 0 || tap + 1 < ntaps;         // no activations beyond the layer yet
-                    const bool next_a = kc == 0 || g + 1 < kSplitTaps;
-                    static_for<NMFMA>([&](auto M_) {
-                        constexpr int m = decltype(M_)::value;
-                        constexpr int q = m / (4 * RTW), c = (m / RTW) % 4, r = m % RTW;
-                        acc[F::PC[q]][c][r] = mfma16<F>(fa[kc][c][F::PA[q]], fb[kc][r][F::PB[q]], acc[F::PC[q]][c][r]);
-                        constexpr int j0 = m * NLOAD / SPAN, j1 = (m + 1) * NLOAD / SPAN;
-                        if constexpr (j1 > j0 && j0 < NLOAD) {
-                            constexpr int j = j0;                          // load j of the next chunk
-                            if constexpr (j < 4 * NP) {                    // weight fragment (ct = j % 4, piece = j / 4)
-                                constexpr int c2 = j % 4, p2 = j / 4;
-                                if constexpr (kc == 0) lds_load_frag<((NP + p2) * 4 + c2) * 1024>(fa[1][c2][p2], wa_cur);
-                                else if (next_a) lds_load_frag<(p2 * 4 + c2) * 1024>(fa[0][c2][p2], wa_nxt);
-                            } else {                                       // activation fragment
-                                constexpr int r2 = (j - 4 * NP) % RTW, p2 = (j - 4 * NP) / RTW;
-                                if constexpr (kc == 0)
-                                    load_b(fb[1][r2][p2], std::integral_constant<int, p2>{}, std::integral_constant<int, 1>{}, ba[r2]);
-                                else if (next_b)
-                                    load_b(fb[0][r2][p2], std::integral_constant<int, p2>{}, std::integral_constant<int, 0>{}, bn[r2]);
-                            }
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    });
-                    __builtin_amdgcn_sched_barrier(0);
-                };
-                chunk(std::integral_constant<int, 0>{});
-                chunk(std::integral_constant<int, 1>{});
             }
             // ---- epilogue: BN scale/shift (+ residual) + ReLU, split, overwrite the activation images ----
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            stamp();
             __syncthreads();                              // every wave is done reading the layer input
             const bool block_out = (layer & 1) == 0;       // stem (0) and every conv2 (2, 4, .., 12)
             const bool add_res = block_out && layer > 0;
@@ -319,19 +332,22 @@ __global__ __launch_bounds__((SplitCfg<S, G, F>::NTHR), 1) void dualnet_fwd_spli
                 const f32x4 sh = *reinterpret_cast<const f32x4 *>(net.shift + layer * 64 + c * 16 + lg * 4);
 #pragma unroll
                 for (int r = 0; r < RTW; ++r) {
+                    const int row = base_row[r];
+                    unsigned char *rp = smem + C::RES_OFF + row * 256 + (((c * 4 + lg) ^ (row & 15)) << 4);
+                    f32x4 x = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (add_res && row < M) x = *reinterpret_cast<const f32x4 *>(rp);
                     f32x4 v;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         float t = acc[0][c][r][j];
                         if constexpr (F::NACC == 2) t = fmaf(acc[1][c][r][j], 1.f / 2048.f, t);
                         t = fmaf(t, sc[j], sh[j]);
-                        if (add_res) t += res[c][r][j];
+                        if (add_res) t += x[j];
                         v[j] = fmaxf(t, 0.f);
                         amax = fmaxf(amax, v[j]);
                     }
-                    if (block_out) res[c][r] = v;
-                    const int row = base_row[r];
                     if (row < M) {
+                        if (block_out && !last) *reinterpret_cast<f32x4 *>(rp) = v;
                         if (last) {
                             *reinterpret_cast<f32x4 *>(smem + row * kRowBytes + (c * 16 + lg * 4) * 4) = v;
                         } else {
@@ -348,9 +364,11 @@ __global__ __launch_bounds__((SplitCfg<S, G, F>::NTHR), 1) void dualnet_fwd_spli
             }
             if (!(amax < 60000.f)) ovf = 1;                // f16 range guard (also catches NaN)
             __syncthreads();
+            stamp();
         }
         run_heads<S, G, C, NTHR>(smem, net, b0, batch, want_logits, policy, value, tid);
         __syncthreads();
+        stamp();
         // the head scratch overlapped the activation images' zero rows
         for (int e = tid; e < NP * 2 * 16; e += NTHR)
             reinterpret_cast<unsigned *>(smem + (e >> 4) * IMG + M * 64)[e & 15] = 0u;
@@ -405,11 +423,11 @@ inline void split_weight(float w, uint16_t *out) {
     out[1] = f32_to_f16_rn((w - f16_to_f32(h)) * 2048.f);
 }
 
-template <int S, int G, typename F>
+template <int S, int G, typename F, int SPANQ = 6>
 int launch_split(tg_net *net, const float *planes, int batch, int want_logits, float *policy, float *value,
                  int *overflow, hipStream_t stream) {
     using C = SplitCfg<S, G, F>;
-    auto kern = dualnet_fwd_split_kernel<S, G, F>;
+    auto kern = dualnet_fwd_split_kernel<S, G, F, SPANQ>;
     static bool attr_set[16] = {};
     if (!attr_set[net->device & 15]) {
         TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
@@ -489,7 +507,16 @@ int split_prepare(tg_net *net, const float *conv0, const float *const *tower, co
 int split_forward(tg_net *net, int group, const float *planes, int batch, int want_logits, float *policy,
                   float *value, int *overflow, hipStream_t stream) {
     if (net->board_size != 9) return tg::fail(TG_ERR_ARG, "split forward: 9x9 only");
-    if (group == 3) return launch_split<9, 3, FmtF16>(net, planes, batch, want_logits, policy, value, overflow, stream);
+    if (group == 3) {
+        if (const char *env = getenv("TG_SPLIT_SPAN")) {              // tuning knob
+            const int q = atoi(env);
+            if (q == 2) return launch_split<9, 3, FmtF16, 2>(net, planes, batch, want_logits, policy, value, overflow, stream);
+            if (q == 3) return launch_split<9, 3, FmtF16, 3>(net, planes, batch, want_logits, policy, value, overflow, stream);
+            if (q == 4) return launch_split<9, 3, FmtF16, 4>(net, planes, batch, want_logits, policy, value, overflow, stream);
+            if (q == 8) return launch_split<9, 3, FmtF16, 8>(net, planes, batch, want_logits, policy, value, overflow, stream);
+        }
+        return launch_split<9, 3, FmtF16>(net, planes, batch, want_logits, policy, value, overflow, stream);
+    }
     return launch_split<9, 1, FmtF16>(net, planes, batch, want_logits, policy, value, overflow, stream);
 }
 

@@ -25,7 +25,13 @@ for _ in range(2):
                                        st.ctypes.data, 128))
 name = lib.tg_net_kernel_name(net.handle, b).decode()
 print("kernel:", name)
-if "wino" in name:
+if "split" in name:
+    s = st[:29] - st[0]
+    print(f"group total {s[28]} ticks; staging + im2col + split of the input {s[1]}")
+    print("  MFMA loop (stem, then 12 layers):", [int(s[2 + 2 * i] - s[1 + 2 * i]) for i in range(13)])
+    print("  barrier + epilogue + barrier    :", [int(s[3 + 2 * i] - s[2 + 2 * i]) for i in range(13)])
+    print("  heads                           :", int(s[28] - s[27]))
+elif "wino" in name:
     for label, s in (("half 0 (wave 0)", st[:64]), ("half 1 (wave 4)", st[64:])):
         s = s - st[0]
         print(f"{label}: group total {s[26]} ticks; staging + stem {s[1]}")
