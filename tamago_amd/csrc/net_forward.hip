@@ -744,7 +744,8 @@ int tg_net_create(int board_size, int device, const float *params, size_t n_para
         fold_bn(rd, 2, 2e-5, sc, sh);
         head_ss[0] = sc[0]; head_ss[1] = sh[0]; head_ss[2] = sc[1]; head_ss[3] = sh[1];
     }
-    std::vector<float> pfc_wT((size_t)2 * P * A);
+    // (padded to whole 4 KB: the split-operand kernel copies it into LDS in 1 KB pieces)
+    std::vector<float> pfc_wT((((size_t)2 * P * A * 4 + 4095) / 4096) * 1024, 0.f);
     {
         const float *w = rd.take((size_t)A * 2 * P);
         for (int a = 0; a < A; ++a)

@@ -65,7 +65,8 @@ struct SplitCfg {
     static constexpr int RTW = G == 3 ? 4 : 2;                    // row-tiles per wave
     static constexpr int NW = (MT + RTW - 1) / RTW;               // waves per workgroup
     static constexpr int NTHR = NW * 64;
-    static constexpr int IMG = (M + 1) * 64;                      // one [row][64 B] image + its zero row
+    static constexpr int IMG = (M + 2) * 64;                      // one [row][64 B] image + zero row M + dump row M + 1
+                                                                  // (rows >= M of the last row-tile store there: no branches)
     static constexpr int ACT_BYTES = F::NP * 2 * IMG;             // image index = piece * 2 + kc
     static constexpr int CHUNK = F::NP * 4 * 1024;                // weight image per k-chunk: [piece][ct][lane][16 B]
     static constexpr int STAGE = (ACT_BYTES + 255) & ~255;        // input planes [G][6][P] fp32 (group start only)
@@ -73,15 +74,18 @@ struct SplitCfg {
     // written by the stem / conv2 epilogues, added back two layers later.  Keeping it out of the register
     // file (64 registers) is what lets accumulators + five fragment sets stay put.
     // (behind the fp32 image the LAST epilogue writes for the heads, which must not run into residuals that
-    // other waves have yet to read)
-    static constexpr int RES_OFF = STAGE + ((G * 6 * P * 4 + 255) & ~255) > ((M * kRowBytes + 255) & ~255)
-                                       ? STAGE + ((G * 6 * P * 4 + 255) & ~255) : ((M * kRowBytes + 255) & ~255);
-    static constexpr int PIPE_BYTES = RES_OFF + M * 256;
-    // head phase (after the last layer): fp32 activations [M][72 floats] from offset 0 + run_heads scratch
+    // other waves have yet to read).  During the head phase the same region receives the policy FC weights.
+    static constexpr int STAGE_END = STAGE + ((G * 6 * P * 4 + 255) & ~255);
+    static constexpr int HEAD_IMG = ((M + 1) * kRowBytes + 255) & ~255;
+    static constexpr int RES_OFF = STAGE_END > HEAD_IMG ? STAGE_END : HEAD_IMG;
+    static constexpr int FC_BYTES = ((2 * P * A * 4 + 4095) / 4096) * 4096;          // policy FC, [2P][A] fp32, padded
+    static constexpr int RES_BYTES = (M + 1) * 256 > FC_BYTES ? (M + 1) * 256 : FC_BYTES;
+    static constexpr int SS_OFF = RES_OFF + RES_BYTES;           // folded BN scale [13][64] + shift [13][64]
+    static constexpr int PIPE_BYTES = SS_OFF + 2 * 13 * 64 * 4;
+    // head phase (after the last layer): fp32 activations [M][72 floats] from offset 0, scratch behind the BN table
     static constexpr int ROW_BYTES = kRowBytes;
-    static constexpr int AUX = ((M * kRowBytes + 255) & ~255);
-    static constexpr int HEAD_BYTES = AUX + G * (3 * P + A + 4) * 4 + 256;
-    static constexpr int LDS_BYTES = PIPE_BYTES > HEAD_BYTES ? PIPE_BYTES : HEAD_BYTES;
+    static constexpr int AUX = PIPE_BYTES;
+    static constexpr int LDS_BYTES = AUX + G * (3 * P + A + 4) * 4 + 256;
 };
 
 // Fragment loads are PLAIN loads: hipcc tracks lgkmcnt / vmcnt for them exactly in straight-line code (counted
@@ -127,6 +131,123 @@ __device__ __forceinline__ void split4(const f32x4 v, uint2 (&out)[F::NP]) {
     }
 }
 
+
+// Heads (1x1 convolutions + BN + ReLU on the fp32 image the last epilogue left at offset 0, the two fully
+// connected layers, softmax) - run_heads of net_device.h with the policy FC weights (53 KB, the one large
+// operand: 162 dependent L2 round trips per output when read from global memory) served from LDS: they are
+// copied with global_load_lds into the residual region, which is idle by now, while the 1x1 convolutions run.
+template <int S, int G, typename C, int NTHR>
+__device__ __forceinline__ void run_heads_split(unsigned char *smem, const NetDev &net, int b0, int batch, int want_logits,
+                                                float *__restrict__ policy, float *__restrict__ value, int tid, int wave,
+                                                long long *tl) {
+    constexpr int P = C::P, A = C::A, M = C::M;
+    const int lane = tid & 63;
+    auto stamp = [&](int i) { if (tl && tid == 0) tl[i] = (long long)__builtin_amdgcn_s_memtime(); };
+    {
+        constexpr int PIECES = C::FC_BYTES / 1024;
+        const unsigned char *src = reinterpret_cast<const unsigned char *>(net.pfc_wT) + lane * 16;
+#pragma unroll 1
+        for (int piece = wave; piece < PIECES; piece += NTHR / 64)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + piece * 1024),
+                                             (__attribute__((address_space(3))) void *)(smem + C::RES_OFF + piece * 1024), 16, 0, 0);
+    }
+    float *hpol = reinterpret_cast<float *>(smem + C::AUX);   // [G][2P]
+    float *hval = hpol + G * 2 * P;                           // [G][P]
+    float *plog = hval + G * P;                               // [G][A]
+    float *vlog = plog + G * A;                               // [G][4]
+    {
+        const float ps0 = net.head_ss[0], pt0 = net.head_ss[1];
+        const float ps1 = net.head_ss[2], pt1 = net.head_ss[3];
+        const float vs = net.head_ss[4], vt = net.head_ss[5];
+        for (int r = tid; r < M; r += NTHR) {
+            float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+#pragma unroll
+            for (int k4 = 0; k4 < 16; ++k4) {
+                const f32x4 xv = lds_f32x4(smem, r * C::ROW_BYTES + k4 * 16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = k4 * 4 + j;
+                    d0 = fmaf(xv[j], net.hp_w[k], d0);
+                    d1 = fmaf(xv[j], net.hp_w[64 + k], d1);
+                    d2 = fmaf(xv[j], net.hv_w[k], d2);
+                }
+            }
+            const int bl = r / P, p = r - bl * P;
+            hpol[bl * 2 * P + p] = fmaxf(fmaf(d0, ps0, pt0), 0.f);
+            hpol[bl * 2 * P + P + p] = fmaxf(fmaf(d1, ps1, pt1), 0.f);
+            hval[bl * P + p] = fmaxf(fmaf(d2, vs, vt), 0.f);
+        }
+    }
+    stamp(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's pieces of the FC weights have landed
+    __syncthreads();
+    stamp(1);
+    const float *fcw = reinterpret_cast<const float *>(smem + C::RES_OFF);
+    // policy FC: one output per thread, six independent partial sums (LDS latency, not bandwidth, is the cost)
+    for (int e = tid; e < G * A; e += NTHR) {
+        const int bl = e / A, a = e - bl * A;
+        const float *h = hpol + bl * 2 * P;
+        const float *wT = fcw + a;
+        float s0 = net.pfc_b[a], s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f;
+        int j = 0;
+#pragma unroll 3
+        for (; j + 6 <= 2 * P; j += 6) {
+            s0 = fmaf(h[j], wT[j * A], s0);
+            s1 = fmaf(h[j + 1], wT[(j + 1) * A], s1);
+            s2 = fmaf(h[j + 2], wT[(j + 2) * A], s2);
+            s3 = fmaf(h[j + 3], wT[(j + 3) * A], s3);
+            s4 = fmaf(h[j + 4], wT[(j + 4) * A], s4);
+            s5 = fmaf(h[j + 5], wT[(j + 5) * A], s5);
+        }
+        for (; j < 2 * P; ++j) s0 = fmaf(h[j], wT[j * A], s0);
+        plog[e] = ((s0 + s1) + (s2 + s3)) + (s4 + s5);
+    }
+    // value FC: sixteen lanes per output, strided partial sums, butterfly over the 16 lanes
+    for (int o = tid >> 4; o < G * 3; o += NTHR / 16) {
+        const int part = tid & 15, bl = o / 3, c = o - bl * 3;
+        const float *h = hval + bl * P;
+        const float *wv = net.vfc_w + c * P;
+        float sv = 0.f;
+#pragma unroll
+        for (int i = 0; i < (P + 15) / 16; ++i) {
+            const int j = part + i * 16;
+            if (j < P) sv = fmaf(h[j], wv[j], sv);
+        }
+        sv += __shfl_xor(sv, 8);
+        sv += __shfl_xor(sv, 4);
+        sv += __shfl_xor(sv, 2);
+        sv += __shfl_xor(sv, 1);
+        if (part == 0) vlog[bl * 4 + c] = sv + net.vfc_b[c];
+    }
+    stamp(2);
+    __syncthreads();
+    for (int bl = wave; bl < G; bl += NTHR / 64) {
+        const int b = b0 + bl;
+        if (b >= batch) continue;
+        float m = -INFINITY;
+        for (int a = lane; a < A; a += 64) m = fmaxf(m, plog[bl * A + a]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float sum = 0.f;
+        for (int a = lane; a < A; a += 64) sum += expf(plog[bl * A + a] - m);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        const float inv = 1.f / sum;
+        for (int a = lane; a < A; a += 64) {
+            const float lg_ = plog[bl * A + a];
+            __builtin_nontemporal_store(want_logits ? lg_ : expf(lg_ - m) * inv, &policy[(size_t)b * A + a]);
+        }
+        if (lane < 3) {
+            const float v0 = vlog[bl * 4], v1 = vlog[bl * 4 + 1], v2 = vlog[bl * 4 + 2];
+            const float vm = fmaxf(v0, fmaxf(v1, v2));
+            const float e0 = expf(v0 - vm), e1 = expf(v1 - vm), e2 = expf(v2 - vm);
+            const float es = e0 + e1 + e2;
+            const float mine = lane == 0 ? e0 : (lane == 1 ? e1 : e2);
+            value[(size_t)b * 3 + lane] = mine / es;
+        }
+    }
+}
+
 template <int S, int G, typename F, int SPANQ = 6>
 __global__ __launch_bounds__((SplitCfg<S, G, F>::NTHR), 1) void dualnet_fwd_split_kernel(
     NetDev net, const float *__restrict__ planes, int batch, int want_logits,
@@ -159,7 +280,11 @@ __global__ __launch_bounds__((SplitCfg<S, G, F>::NTHR), 1) void dualnet_fwd_spli
     for (int e = tid; e < NP * 2 * 16; e += NTHR)
         reinterpret_cast<unsigned *>(smem + (e >> 4) * IMG + M * 64)[e & 15] = 0u;
 
-    const float *bn_scale = net.sscale;
+    // folded BN scale / shift of all 13 layers -> LDS, once (the epilogues would otherwise wait for L2 every layer)
+    for (int e = tid; e < 13 * 64; e += NTHR) {
+        reinterpret_cast<float *>(smem + C::SS_OFF)[e] = net.sscale[e];
+        reinterpret_cast<float *>(smem + C::SS_OFF)[13 * 64 + e] = net.shift[e];
+    }
     // weight stream: k-chunk gc = 2 * tap + kc of the whole network lies at wsplit + gc * CHUNK; a chunk's eight
     // fragments are at lane * 16 + (piece * 4 + ct) * 1024 (two lane offsets cover the 4 KB offset field)
     const int wv0 = lane * 16;
@@ -174,37 +299,53 @@ __global__ __launch_bounds__((SplitCfg<S, G, F>::NTHR), 1) void dualnet_fwd_spli
     };
     int ovf = 0;
     const int n_groups = (batch + G - 1) / G;
+    constexpr int NPL = (G * 6 * P + NTHR - 1) / NTHR;
+    float pre[NPL];
+    auto fetch_planes = [&](int grp2) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            const int e = tid + i * NTHR;
+            const int b = grp2 * G + e / (6 * P);
+            pre[i] = (e < G * 6 * P && grp2 < n_groups && b < batch)
+                         ? __builtin_nontemporal_load(&planes[(size_t)grp2 * G * 6 * P + e]) : 0.f;
+        }
+    };
+    fetch_planes(blockIdx.x);
     for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
         const int b0 = grp * G;
         stamp();
-        // ---- input planes -> LDS -> im2col'ed, split "layer -1" activations (K = 9 taps x 6 planes, padded to 64) ----
+        // ---- input planes (fetched into registers during the previous group's head phase) -> LDS -> im2col'ed, split "layer -1"
+        //      activations: K = 9 taps x 6 planes (k = 6 tap + plane), padded to 64 ----
         {
             float *st = reinterpret_cast<float *>(smem + C::STAGE);
-            for (int e = tid; e < G * 6 * P; e += NTHR) {
-                const int b = b0 + e / (6 * P);
-                st[e] = b < batch ? __builtin_nontemporal_load(&planes[(size_t)b0 * 6 * P + e]) : 0.f;
-            }
+#pragma unroll
+            for (int i = 0; i < NPL; ++i)
+                if (tid + i * NTHR < G * 6 * P) st[tid + i * NTHR] = pre[i];
             __syncthreads();
-            for (int e = tid; e < M * 8; e += NTHR) {
-                const int row = e >> 3, sl = e & 7;                // slot sl holds k = 8 sl .. 8 sl + 7
-                const int bl = row / P, p = row - bl * P, y = p / S, x = p - y * S;
-                f32x4 lo, hi;
+            if (tid < M) {                                  // one thread per position
+                const int row = tid, bl = row / P, p = row - bl * P, y = p / S, x = p - y * S;
+                const float *src = st + bl * 6 * P + p;
+                const int swz = (row >> 1) & 3;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int k = sl * 8 + j, t = k / 6, c = k - t * 6;
-                    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-                    const bool ok = k < 54 && yy >= 0 && yy < S && xx >= 0 && xx < S;
-                    const float v = ok ? st[(bl * 6 + c) * P + yy * S + xx] : 0.f;
-                    if (j < 4) lo[j] = v; else hi[j - 4] = v;
+                for (int sl = 0; sl < 8; ++sl) {            // slot sl holds k = 8 sl .. 8 sl + 7
+                    f32x4 lo, hi;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int k = sl * 8 + j, t = k / 6, c = k - t * 6;
+                        const int dy = t / 3 - 1, dx = t % 3 - 1;
+                        const bool ok = k < 54 && (unsigned)(y + dy) < (unsigned)S && (unsigned)(x + dx) < (unsigned)S;
+                        const float v = ok ? src[c * P + dy * S + dx] : 0.f;
+                        if (j < 4) lo[j] = v; else hi[j - 4] = v;
+                    }
+                    uint2 plo[NP], phi[NP];
+                    split4<F>(lo, plo);
+                    split4<F>(hi, phi);
+                    const int kc = sl >> 2, slot = (sl & 3) ^ swz;
+#pragma unroll
+                    for (int q = 0; q < NP; ++q)
+                        *reinterpret_cast<uint4 *>(smem + (q * 2 + kc) * IMG + row * 64 + slot * 16) =
+                            uint4{plo[q].x, plo[q].y, phi[q].x, phi[q].y};
                 }
-                uint2 plo[NP], phi[NP];
-                split4<F>(lo, plo);
-                split4<F>(hi, phi);
-                const int kc = sl >> 2, slot = (sl & 3) ^ ((row >> 1) & 3);
-#pragma unroll
-                for (int q = 0; q < NP; ++q)
-                    *reinterpret_cast<uint4 *>(smem + (q * 2 + kc) * IMG + row * 64 + slot * 16) =
-                        uint4{plo[q].x, plo[q].y, phi[q].x, phi[q].y};
             }
         }
         __syncthreads();                                  // activations written
@@ -255,12 +396,14 @@ __global__ __launch_bounds__((SplitCfg<S, G, F>::NTHR), 1) void dualnet_fwd_spli
                 constexpr int m = decltype(M_)::value;
                 constexpr int q = m / (4 * RTW), c = (m / RTW) % 4, r = m % RTW;
                 acc[F::PC[q]][c][r] = mfma16<F>(fa[aset][c][F::PA[q]], fb[kc][r][F::PB[q]], acc[F::PC[q]][c][r]);
-                // activation fragment j of the next chunk (uniformly spread over the first BSPAN MFMAs)
-                constexpr int jb0 = m * NB / BSPAN, jb1 = (m + 1) * NB / BSPAN;
-                if constexpr (jb1 > jb0 && jb0 < NB) {
-                    constexpr int r2 = jb0 % RTW, p2 = jb0 / RTW;
-                    if constexpr (kc == 0) load_b(fb[1][r2][p2], std::integral_constant<int, p2>{}, std::integral_constant<int, 1>{}, ba[r2]);
-                    else load_b(fb[0][r2][p2], std::integral_constant<int, p2>{}, std::integral_constant<int, 0>{}, bn[r2]);
+                // activation fragments of the next chunk (uniformly spread over the first BSPAN MFMAs)
+                constexpr int jb0 = m * NB / BSPAN, jb1 = (m + 1) * NB / BSPAN < NB ? (m + 1) * NB / BSPAN : NB;
+                if constexpr (jb1 > jb0) {
+                    static_for<jb1 - jb0>([&](auto D_) {
+                        constexpr int jb = jb0 + decltype(D_)::value, r2 = jb % RTW, p2 = jb / RTW;
+                        if constexpr (kc == 0) load_b(fb[1][r2][p2], std::integral_constant<int, p2>{}, std::integral_constant<int, 1>{}, ba[r2]);
+                        else load_b(fb[0][r2][p2], std::integral_constant<int, p2>{}, std::integral_constant<int, 0>{}, bn[r2]);
+                    });
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 // weight fragment j of the chunk after next (spread over the whole chunk)
@@ -322,35 +465,51 @@ __global__ __launch_bounds__((SplitCfg<S, G, F>::NTHR), 1) void dualnet_fwd_spli
             // ---- epilogue: BN scale/shift (+ residual) + ReLU, split, overwrite the activation images ----
             stamp();
             __syncthreads();                              // every wave is done reading the layer input
-            const bool block_out = (layer & 1) == 0;       // stem (0) and every conv2 (2, 4, .., 12)
-            const bool add_res = block_out && layer > 0;
-            const bool last = layer == kTowerLayers;
             float amax = 0.f;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const f32x4 sc = *reinterpret_cast<const f32x4 *>(bn_scale + layer * 64 + c * 16 + lg * 4);
-                const f32x4 sh = *reinterpret_cast<const f32x4 *>(net.shift + layer * 64 + c * 16 + lg * 4);
+            // three shapes, chosen once per layer (no per-tile branches): conv1 (plain), stem / conv2 (keep the
+            // result as the next block's residual; conv2 adds the current one), last conv2 (fp32 image for the heads)
+            auto epilogue = [&](auto KEEP_, auto ADD_, auto LAST_) __attribute__((always_inline)) {
+                constexpr bool keep = decltype(KEEP_)::value, add_res = decltype(ADD_)::value, last = decltype(LAST_)::value;
+                // every LDS operand first (one wave per SIMD: nothing else hides their latency)
+                f32x4 xres[4][RTW], sc[4], sh[4];
+                int rrow[RTW], wrow[RTW];
 #pragma unroll
                 for (int r = 0; r < RTW; ++r) {
-                    const int row = base_row[r];
-                    unsigned char *rp = smem + C::RES_OFF + row * 256 + (((c * 4 + lg) ^ (row & 15)) << 4);
-                    f32x4 x = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (add_res && row < M) x = *reinterpret_cast<const f32x4 *>(rp);
-                    f32x4 v;
+                    rrow[r] = base_row[r] < M ? base_row[r] : 0;          // rows >= M: read anything valid,
+                    wrow[r] = base_row[r] < M ? base_row[r] : M + 1;      // store into the dump row
+                }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float t = acc[0][c][r][j];
-                        if constexpr (F::NACC == 2) t = fmaf(acc[1][c][r][j], 1.f / 2048.f, t);
-                        t = fmaf(t, sc[j], sh[j]);
-                        if (add_res) t += x[j];
-                        v[j] = fmaxf(t, 0.f);
-                        amax = fmaxf(amax, v[j]);
+                for (int c = 0; c < 4; ++c) {
+                    sc[c] = *reinterpret_cast<const f32x4 *>(smem + C::SS_OFF + (layer * 64 + c * 16 + lg * 4) * 4);
+                    sh[c] = *reinterpret_cast<const f32x4 *>(smem + C::SS_OFF + (13 * 64 + layer * 64 + c * 16 + lg * 4) * 4);
+                    if constexpr (add_res) {
+#pragma unroll
+                        for (int r = 0; r < RTW; ++r)
+                            xres[c][r] = *reinterpret_cast<const f32x4 *>(smem + C::RES_OFF + rrow[r] * 256 + (((c * 4 + lg) ^ (rrow[r] & 15)) << 4));
                     }
-                    if (row < M) {
-                        if (block_out && !last) *reinterpret_cast<f32x4 *>(rp) = v;
-                        if (last) {
-                            *reinterpret_cast<f32x4 *>(smem + row * kRowBytes + (c * 16 + lg * 4) * 4) = v;
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                    for (int r = 0; r < RTW; ++r) {
+                        f32x4 v;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float t = acc[0][c][r][j];
+                            if constexpr (F::NACC == 2) t = fmaf(acc[1][c][r][j], 1.f / 2048.f, t);
+                            t = fmaf(t, sc[c][j], sh[c][j]);
+                            if constexpr (add_res) t += xres[c][r][j];
+                            v[j] = fmaxf(t, 0.f);
+                        }
+                        amax = fmaxf(fmaxf(amax, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+                        const int row = wrow[r];
+                        if constexpr (last) {
+                            const int hrow = base_row[r] < M ? base_row[r] : M;
+                            *reinterpret_cast<f32x4 *>(smem + hrow * kRowBytes + (c * 16 + lg * 4) * 4) = v;
                         } else {
+                            if constexpr (keep)
+                                *reinterpret_cast<f32x4 *>(smem + C::RES_OFF + (base_row[r] < M ? base_row[r] : M) * 256 +
+                                                           (((c * 4 + lg) ^ (base_row[r] & 15)) << 4)) = v;
                             uint2 pc[NP];
                             split4<F>(v, pc);
                             const int slot = (((c & 1) << 1) | (lg >> 1)) ^ ((row >> 1) & 3);
@@ -361,12 +520,22 @@ __global__ __launch_bounds__((SplitCfg<S, G, F>::NTHR), 1) void dualnet_fwd_spli
                         }
                     }
                 }
-            }
+            };
+            using T = std::true_type;
+            using N = std::false_type;
+            if (layer == kTowerLayers) epilogue(N{}, T{}, T{});
+            else if (layer == 0) epilogue(T{}, N{}, N{});
+            else if (layer & 1) epilogue(N{}, N{}, N{});
+            else epilogue(T{}, T{}, N{});
             if (!(amax < 60000.f)) ovf = 1;                // f16 range guard (also catches NaN)
             __syncthreads();
             stamp();
         }
-        run_heads<S, G, C, NTHR>(smem, net, b0, batch, want_logits, policy, value, tid);
+        // next group's input planes: HBM latency, and vmcnt retires in order - requested here, where the only
+        // wait behind them is the heads' own (the FC weight copy), not one of the tower's weight fragments
+        fetch_planes(grp + gridDim.x);
+        run_heads_split<S, G, C, NTHR>(smem, net, b0, batch, want_logits, policy, value, tid, wave,
+                                       (net.timeline && blockIdx.x == 0 && grp == blockIdx.x) ? net.timeline + 40 : nullptr);
         __syncthreads();
         stamp();
         // the head scratch overlapped the activation images' zero rows

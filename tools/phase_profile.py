@@ -30,7 +30,9 @@ if "split" in name:
     print(f"group total {s[28]} ticks; staging + im2col + split of the input {s[1]}")
     print("  MFMA loop (stem, then 12 layers):", [int(s[2 + 2 * i] - s[1 + 2 * i]) for i in range(13)])
     print("  barrier + epilogue + barrier    :", [int(s[3 + 2 * i] - s[2 + 2 * i]) for i in range(13)])
-    print("  heads                           :", int(s[28] - s[27]))
+    print("  heads                           :", int(s[28] - s[27]), " (1x1 convs", int(st[40] - st[27]),
+          "| FC weights landed + barrier", int(st[41] - st[40]), "| FCs", int(st[42] - st[41]), "| softmax + stores",
+          int(st[28] - st[42]), ")")
 elif "wino" in name:
     for label, s in (("half 0 (wave 0)", st[:64]), ("half 1 (wave 4)", st[64:])):
         s = s - st[0]
