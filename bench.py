@@ -14,9 +14,12 @@ region; the timed region contains everything else, including the host side of th
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line (rank 0) with the contract's keys plus `roofline` (fused forward
-kernel vs the fp32 MFMA peak, timed with HIP events on the launch stream) and
-`cpu_baseline` (the CPU oracle - a port of the reference's Python path - timed on this
-host on a bounded sample of the same workload).
+kernel: FLOPs of the MFMA instructions it executes / HIP-event launch time on the launch
+stream, against the dense matrix peak of the precision they run in; HBM traffic from the
+rocprofv3 PMC summary measured on these kernel sources), `cpu_baseline` (the CPU oracle - a
+port of the reference's Python path - timed on this host on a bounded sample of the same
+workload) and, at N = 1, legs for the other BASELINE.json configs (single tree, cfg-3,
+one cfg-4 shard, cfg-5).
 """
 import argparse
 import json
@@ -30,19 +33,28 @@ import torch
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix
-PMC_SUMMARY = os.path.join(REPO, "profiles", "r01e_pmc_forward_wino_9x9_b65536.json")
+FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix (= fp32 vector) peak
+PROFILES = os.path.join(REPO, "profiles")
 
 
-def pmc_traffic(size, positions):
-    """HBM bytes per launch of the forward kernel from the committed rocprofv3 --pmc passes
-    (tools/pmc_fwd.sh: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as
-    MI355X_MICROARCH.md section HBM prescribes), scaled per position.  None if not measured."""
-    if size != 9 or not os.path.exists(PMC_SUMMARY):
-        return None, None
-    with open(PMC_SUMMARY) as f:
-        d = json.load(f)["derived"]
-    return d["hbm_bytes_per_position"] * positions, d["mfma_busy_fraction_of_simd_cycles"]
+def pmc_summary(kernel_name):
+    """The rocprofv3 PMC summary (tools/pmc_r02.sh -> profiles/r02_pmc_forward_*.json) measured on THESE
+    kernel sources for THIS kernel: HBM-side bytes per position (FETCH_SIZE doubled + WRITE_SIZE, separate
+    passes, as MI355X_MICROARCH.md section HBM prescribes), matrix-pipe busy fraction, L2 request bytes.
+    A summary taken on other sources (csrc digest differs) or another kernel is NOT quoted: returns None and
+    says so on stderr."""
+    from tamago_amd.build import source_digest
+    digest = source_digest()
+    import glob
+    for path in sorted(glob.glob(os.path.join(PROFILES, "r02_pmc_forward_*.json")), reverse=True):
+        with open(path) as f:
+            d = json.load(f)
+        if d.get("csrc_digest") == digest and kernel_name.split("<")[0] in d.get("kernel", ""):
+            d["file"] = os.path.relpath(path, REPO)
+            return d
+    sys.stderr.write(f"bench.py: no PMC summary in profiles/ for kernel {kernel_name!r} at csrc digest {digest} - "
+                     "roofline.traffic is null (run tools/pmc_r02.sh on the GPU box and commit the summary)\n")
+    return None
 
 
 def parse():
@@ -61,8 +73,8 @@ def parse():
     ap.add_argument("--size", type=int, default=9)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--selfplay-boards", type=int, default=256,
-                    help="boards of the Gumbel self-play leg reported in `selfplay` (0 = skip; N = 1 only)")
+    ap.add_argument("--no-legs", action="store_true",
+                    help="skip the extra legs (single tree, cfg-3 / cfg-4-shard self-play, cfg-5 19x19); N = 1 only")
     return ap.parse_args()
 
 
@@ -143,6 +155,66 @@ def run_step(engines, plies_list, fresh_board, visits, batch):
                 engine.set_root(int(t), fresh_board, 1)
                 plies[t] = 0
     return leaves
+
+
+def extra_legs(args, net, dev, local_rank, fresh_board):
+    """Driver-visible numbers for the other BASELINE.json configs (never part of `value`): the literal one-tree
+    cfg-2, cfg-3 (Gumbel self-play, 16 boards x 400 simulations), one cfg-4 shard (64 boards x 400 simulations;
+    8 of them = cfg-4, one per GPU), a large self-play shard, and cfg-5 (19x19, 1600 visits, batch 64)."""
+    import shutil
+    import tempfile
+    from tamago_amd.mcts.engine import SearchEngine
+    from tamago_amd.nn.network.dual_net import DualNet
+    from tamago_amd.selfplay.worker import selfplay_shard
+    out = {}
+    cur = torch.cuda.current_stream(dev)
+
+    def one_tree(size, network, visits, batch, moves):
+        board = type(fresh_board)(size, 7.0, False)
+        one = SearchEngine(size, 1, visits + 16, batch, TimedEvaluator(network), device_index=local_rank)
+        one.set_root(0, board, 1, np.random.RandomState(7).get_state())
+        plies = np.zeros(1, dtype=np.int64)
+        run_step([(one, cur)], [plies], board, visits, batch)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n1 = sum(run_step([(one, cur)], [plies], board, visits, batch) for _ in range(moves))
+        torch.cuda.synchronize()
+        dt1 = time.perf_counter() - t1
+        one.close()
+        return {"value": n1 / dt1, "unit": "leaf-evals/s", "ms_per_move": dt1 / moves * 1e3, "moves": moves,
+                "workload": f"ONE search tree, {size}x{size}, {visits} strict visits/move, NN batch {batch}"}
+
+    # strict single-tree reading of config[1] (latency-bound: descent k+1 depends on the virtual loss of k)
+    out["single_tree"] = one_tree(args.size, net, args.visits, args.batch, 8)
+
+    def selfplay(boards, games):
+        tmp = tempfile.mkdtemp(prefix="tg_sp_")
+        try:
+            ts = time.perf_counter()
+            st = selfplay_shard(tmp, net, list(range(1, games + 1)), 9, 400, boards=boards,
+                                never_resign_flags=[True] * games, device_index=local_rank)
+            torch.cuda.synchronize()
+            dts = time.perf_counter() - ts
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+        return {"value": st["leaf_evals"] / dts, "unit": "leaf-evals/s", "games_per_hour": st["games"] / dts * 3600,
+                "boards": boards, "games": st["games"], "moves": st["moves"], "seconds": dts,
+                "workload": f"Gumbel sequential halving, 400 simulations/move, {boards} lock-step boards, "
+                            "games to completion, SGF records written"}
+
+    for key, boards, games in (("cfg3_selfplay_16_boards", 16, 32), ("cfg4_shard_64_boards", 64, 128),
+                               ("selfplay_1024_boards", 1024, 1024)):
+        try:
+            out[key] = selfplay(boards, games)
+        except Exception as exc:                          # the headline must not depend on a leg
+            out[key] = {"error": repr(exc)}
+    try:
+        torch.manual_seed(4321)
+        net19 = DualNet(dev, 19)
+        out["cfg5_19x19"] = one_tree(19, net19, 1600, 64, 4)
+    except Exception as exc:
+        out["cfg5_19x19"] = {"error": repr(exc)}
+    return out
 
 
 def cpu_baseline(size, visits, batch, budget_s):
@@ -265,10 +337,17 @@ def main():
         leaves = float(tot.item())
 
     if rank == 0:
+        import ctypes
         full_b = sizes[0] * args.batch
         avg_ms = float(np.mean(big)) if big else float("nan")
-        achieved = full_b * flops_pos / (avg_ms * 1e-3) / 1e12 if big else float("nan")
-        traffic, mfma_busy = pmc_traffic(args.size, full_b)
+        kname = lib.tg_net_kernel_name(net.handle, full_b).decode()
+        peak = ctypes.c_double(0.0)
+        dtype_name = ctypes.c_char_p()
+        exec_flops = lib.tg_net_executed_flops_per_position(net.handle, full_b, ctypes.byref(peak), ctypes.byref(dtype_name))
+        algorithmic = full_b * flops_pos / (avg_ms * 1e-3) / 1e12 if big else float("nan")
+        executed = full_b * exec_flops / (avg_ms * 1e-3) / 1e12 if big else float("nan")
+        pmc = pmc_summary(kname) if args.size == 9 else None
+        io_bytes = 6 * args.size ** 2 * 4 + (args.size ** 2 + 4) * 4
         result = {
             "metric": "MCTS leaf-evals/sec (9x9, batch 256)" if args.size == 9
             else f"MCTS leaf-evals/sec ({args.size}x{args.size}, batch {args.batch})",
@@ -281,7 +360,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if peak.value < 200 else "f32 results from f16 x 2 split operands, fp32 accumulate",
             "data": "synthetic",
             "config": {
                 "workload": f"cfg-2 PUCT {args.size}x{args.size}, random-init DualNet, "
@@ -293,70 +372,39 @@ def main():
             },
             "roofline": {
                 "bound": "mfma",
-                "kernel": lib.tg_net_kernel_name(net.handle, full_b).decode(),
-                "note": "achieved = ALGORITHMIC FLOPs (direct 3x3 conv count, SURVEY 3.4: "
-                        "72.28 MFLOP/position at 9x9) / launch time.  The 9x9 kernel evaluates the "
-                        "residual tower with Winograd F(2x2,3x3) in exact fp32, which issues 1.8x "
-                        "fewer MFMAs than the direct form, so frac can approach / exceed the "
-                        "direct-conv MFMA bound; mfma_busy_frac_pmc is the matrix-pipe occupancy.",
-                "achieved": achieved,
-                "peak": FP32_MFMA_PEAK_TFLOPS,
+                "kernel": kname,
+                "note": "achieved / peak / frac = FLOPs of the MFMA instructions the kernel EXECUTES (operand splitting "
+                        "and tile padding included, tg_net_executed_flops_per_position) per launch / HIP-event launch "
+                        "time, against the dense matrix peak of the precision they run in.  algorithmic_tflops = "
+                        "direct-3x3-convolution count of SURVEY 3.4 (72.28 MFLOP/position at 9x9), the fp32-equivalent "
+                        "work delivered; it may exceed the fp32 matrix peak because the products run on the f16 pipe.",
+                "achieved": executed,
+                "peak": peak.value,
                 "unit": "TFLOP/s",
-                "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                "traffic": traffic,
-                "traffic_unit": "bytes of HBM traffic per launch (rocprofv3 PMC, profiles/)",
-                "algorithmic_io_bytes": full_b * (6 * args.size ** 2 * 4 + (args.size ** 2 + 4) * 4),
-                "mfma_busy_frac_pmc": mfma_busy,
+                "frac": executed / peak.value,
+                "executed_dtype": dtype_name.value.decode() if dtype_name.value else "",
+                "executed_flops_per_position": exec_flops,
+                "algorithmic_tflops": algorithmic,
+                "algorithmic_flops_per_position": flops_pos,
+                "algorithmic_over_fp32_matrix_peak": algorithmic / FP32_MFMA_PEAK_TFLOPS,
+                "traffic": pmc["derived"]["hbm_bytes_per_position"] * full_b if pmc else None,
+                "traffic_unit": "HBM-side bytes per launch: rocprofv3 PMC FETCH_SIZE x 2 + WRITE_SIZE (separate passes) "
+                                "per position x positions of this launch",
+                "traffic_source": pmc["file"] if pmc else None,
+                "algorithmic_io_bytes": full_b * io_bytes,
+                "mfma_busy_frac_pmc": pmc["derived"]["mfma_busy_fraction_of_simd_cycles"] if pmc else None,
                 "avg_launch_ms": avg_ms,
                 "launches": len(big),
                 "positions_per_launch": full_b,
-                "flops_per_position": flops_pos,
-                "forward_share_of_step": kern_ms * 1e-3 / (elapsed if world == 1 else elapsed),
-                "end_to_end_frac": leaves / elapsed / world * flops_pos / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                "forward_share_of_step": kern_ms * 1e-3 / elapsed,
+                "end_to_end_frac": leaves / elapsed / world * exec_flops / 1e12 / peak.value,
             },
         }
-        if world == 1 and args.trees > 1:
-            # strict single-tree reading of config[1]: ONE search tree, same budget (latency-bound:
-            # descent k+1 depends on the virtual loss of descent k) - reported beside the aggregate
+        if world == 1 and not args.no_legs and args.size == 9:
+            for eng, _ in engines:
+                eng.close()
             torch.cuda.synchronize()
-            one = SearchEngine(args.size, 1, args.visits + 16, args.batch, TimedEvaluator(net),
-                               device_index=local_rank)
-            one.set_root(0, fresh_board, 1, np.random.RandomState(7).get_state())
-            p1 = np.zeros(1, dtype=np.int64)
-            cur = torch.cuda.current_stream(dev)
-            run_step([(one, cur)], [p1], fresh_board, args.visits, args.batch)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            n1 = sum(run_step([(one, cur)], [p1], fresh_board, args.visits, args.batch) for _ in range(5))
-            torch.cuda.synchronize()
-            dt1 = time.perf_counter() - t1
-            result["single_tree"] = {"value": n1 / dt1, "unit": "leaf-evals/s",
-                                     "ms_per_move": dt1 / 5 * 1e3, "moves": 5}
-            one.close()
-        if world == 1 and args.selfplay_boards > 0 and args.size == 9:
-            # cfg-3/4 style leg (Gumbel self-play, 400 simulations per move, games to completion):
-            # reported beside the headline, never part of `value`
-            try:
-                import shutil
-                import tempfile
-                from tamago_amd.selfplay.worker import selfplay_shard
-                for eng, _ in engines:
-                    eng.close()
-                torch.cuda.synchronize()
-                out_dir = tempfile.mkdtemp(prefix="tg_sp_")
-                nb = args.selfplay_boards
-                ts = time.perf_counter()
-                st = selfplay_shard(out_dir, net, list(range(1, nb + nb // 2 + 1)), args.size, 400, boards=nb,
-                                    never_resign_flags=[True] * (nb + nb // 2))
-                dts = time.perf_counter() - ts
-                shutil.rmtree(out_dir, ignore_errors=True)
-                result["selfplay"] = {"value": st["leaf_evals"] / dts, "unit": "leaf-evals/s",
-                                      "games_per_hour": st["games"] / dts * 3600, "boards": nb,
-                                      "games": st["games"], "moves": st["moves"], "seconds": dts,
-                                      "workload": "Gumbel sequential halving, 400 simulations/move, "
-                                                  "lock-step boards, SGF records written"}
-            except Exception as exc:                      # the headline must not depend on this leg
-                result["selfplay"] = {"error": repr(exc)}
+            result.update(extra_legs(args, net, dev, local_rank, fresh_board))
         if not args.no_cpu_baseline and world == 1:          # rank 0 at N = 1 only
             result["cpu_baseline"] = cpu_baseline(args.size, args.visits, args.batch,
                                                   args.cpu_seconds)

@@ -81,6 +81,14 @@ int tg_net_profile_phases(tg_net *net, const float *planes_dev, int batch, float
 /* Name (for rocprof) and algorithmic FLOPs per position of the dominant kernel. */
 const char *tg_net_kernel_name(const tg_net *net, int batch);
 double tg_net_flops_per_position(int board_size);
+/* What the kernel tg_net_forward_dev picks for `batch` actually EXECUTES on the matrix pipe, per position:
+ * FLOPs of the issued MFMA instructions including tile padding and operand splitting (split-operand f16
+ * kernel: 3 MFMAs per product-sum over the direct 3x3 convolution, 243 of 256 rows used; Winograd fp32
+ * kernel: 25 tiles x 16 points, 75 of 80 tiles used; direct fp32 kernel: 9 taps).  *peak_tflops receives
+ * the dense matrix peak of the precision those instructions run in (MI355X: 2500 f16, 157.3 fp32),
+ * *dtype its name.  The roofline fraction of the forward kernel is executed FLOP/s over that peak. */
+double tg_net_executed_flops_per_position(const tg_net *net, int batch, double *peak_tflops,
+                                          const char **dtype);
 
 /* ---- featurise (nn/feature.py:10-57 + go_board.py:468-478) -------------------------- */
 /* cells_dev: uint8 [B, P] on-board cell colours, row-major from the top-left point;

@@ -32,6 +32,20 @@ def sources():
                   if f.endswith(".hip") or f.endswith(".cpp"))
 
 
+def source_digest() -> str:
+    """sha256 (16 hex digits) over the kernel sources and the ABI header: profiles/ summaries carry it,
+    bench.py only quotes a PMC summary that was measured on the kernels it is running."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sources() + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
+    files.append(os.path.join(REPO, "include", "tamago_hip.h"))
+    for path in files:
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = _hipcc()
     os.makedirs(OBJ_DIR, exist_ok=True)

@@ -2,11 +2,16 @@
 // sym = 0) + GoBoard.get_board_data (board/go_board.py:468-478).
 //
 // HBM-bound byte kernel: P bytes in, 6*P fp32 out per position (2 025 B at 9x9, 9 025 B at
-// 19x19).  One wavefront per position; every plane is written as one coalesced run of
-// fp32, the uint8 cells are read once and kept in registers.
+// 19x19).  A workgroup takes NPOS consecutive positions: their planes are ONE contiguous run of
+// NPOS*6*P floats, which the 256 threads write as 16-byte non-temporal stores (1 KB per wave
+// instruction, no partial waves: a wave per position with 4-byte stores left the 82nd..128th lane
+// idle and reached 44 % of the HBM peak); the uint8 cells are read once, coalesced, into LDS with
+// the board symmetry and the colour swap already applied.
 #include "common.h"
 
 namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int S>
 __global__ __launch_bounds__(256) void featurize_kernel(const uint8_t *__restrict__ cells,
@@ -17,27 +22,30 @@ __global__ __launch_bounds__(256) void featurize_kernel(const uint8_t *__restric
                                                         int batch, float *__restrict__ planes) {
     constexpr int P = S * S;
     constexpr int W = S + 2;
-    const int lane = threadIdx.x & 63;
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= batch) return;
-    const int color = to_move[b];
-    const int prev = prev_move[b];
-    const bool pass_plane = moves[b] > 1 && prev == 0;       // feature.py:39
-    // previous move as an on-board index (or -1): pos = x + y*W with a one-cell border
-    int prev_idx = -1;
-    if (!pass_plane && prev > 0) {
-        const int py = prev / W - 1, px = prev % W - 1;
-        if (py >= 0 && py < S && px >= 0 && px < S) prev_idx = py * S + px;
-    }
-    const float side = color == 2 ? -1.f : 1.f;              // feature.py:50-52
-    const int sy_ = sym ? sym[b] : 0;                        // board symmetry 0..7 (go_board.py:80-104)
-    const uint8_t *src = cells + (size_t)b * P;
-    float *dst = planes + (size_t)b * 6 * P;
-    for (int p = lane; p < P; p += 64) {
-        // output point p = (y, x) reads the cell the symmetry maps it to
+    constexpr int NPOS = S == 9 ? 16 : 4;              // positions per workgroup
+    constexpr int RUN = NPOS * 6 * P;                  // floats written by a workgroup (multiple of 4)
+    static_assert(RUN % 4 == 0 && (6 * P * NPOS * 4) % 16 == 0, "16-byte stores");
+    __shared__ uint8_t cls[NPOS][P];                   // 0 empty / 1 own / 2 opponent, bit 2: previous move
+    __shared__ float meta[NPOS][2];                    // pass plane value, side-to-move value
+    const int tid = threadIdx.x;
+    const int b0 = blockIdx.x * NPOS;
+    const int nvalid = batch - b0 < NPOS ? batch - b0 : NPOS;
+
+    for (int e = tid; e < nvalid * P; e += 256) {
+        const int bl = e / P, p = e - bl * P, b = b0 + bl;
+        const int color = to_move[b];
+        const int prev = prev_move[b];
+        const bool pass_plane = moves[b] > 1 && prev == 0;   // feature.py:39
+        // previous move as an on-board index (or -1): pos = x + y*W with a one-cell border
+        int prev_idx = -1;
+        if (!pass_plane && prev > 0) {
+            const int py = prev / W - 1, px = prev % W - 1;
+            if (py >= 0 && py < S && px >= 0 && px < S) prev_idx = py * S + px;
+        }
+        // output point p = (y, x) reads the cell the symmetry maps it to (go_board.py:80-104)
         const int y = p / S, x = p - y * S, n = S - 1;
         int ry = y, rx = x;
-        switch (sy_) {
+        switch (sym ? sym[b] : 0) {
             case 1: rx = n - x; break;
             case 2: ry = n - y; break;
             case 3: ry = n - y; rx = n - x; break;
@@ -48,14 +56,37 @@ __global__ __launch_bounds__(256) void featurize_kernel(const uint8_t *__restric
             default: break;
         }
         const int sp = ry * S + rx;
-        int c = src[sp];
+        int c = cells[(size_t)b * P + sp];
         if (color == 2 && c != 0) c = 3 - c;                 // feature.py:24-25
-        dst[p] = c == 0 ? 1.f : 0.f;
-        dst[P + p] = c == 1 ? 1.f : 0.f;
-        dst[2 * P + p] = c == 2 ? 1.f : 0.f;
-        dst[3 * P + p] = sp == prev_idx ? 1.f : 0.f;
-        dst[4 * P + p] = pass_plane ? 1.f : 0.f;
-        dst[5 * P + p] = side;
+        cls[bl][p] = (uint8_t)(c | (sp == prev_idx ? 4 : 0));
+        if (p == 0) {
+            meta[bl][0] = pass_plane ? 1.f : 0.f;
+            meta[bl][1] = color == 2 ? -1.f : 1.f;           // feature.py:50-52
+        }
+    }
+    __syncthreads();
+    auto element = [&](int e) -> float {
+        const int bl = e / (6 * P), r = e - bl * 6 * P, plane = r / P, p = r - plane * P;
+        const int c = cls[bl][p];
+        switch (plane) {
+            case 0: return (c & 3) == 0 ? 1.f : 0.f;
+            case 1: return (c & 3) == 1 ? 1.f : 0.f;
+            case 2: return (c & 3) == 2 ? 1.f : 0.f;
+            case 3: return (c & 4) ? 1.f : 0.f;
+            case 4: return meta[bl][0];
+            default: return meta[bl][1];
+        }
+    };
+    float *dst = planes + (size_t)b0 * 6 * P;
+    const int nfloat = nvalid * 6 * P;
+    for (int i = tid; i * 4 < nfloat; i += 256) {
+        const int e0 = i * 4;
+        if (e0 + 4 <= nfloat) {
+            const f32x4 v = {element(e0), element(e0 + 1), element(e0 + 2), element(e0 + 3)};
+            __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(dst + e0));
+        } else {
+            for (int e = e0; e < nfloat; ++e) dst[e] = element(e);
+        }
     }
 }
 
@@ -79,7 +110,8 @@ extern "C" int tg_featurize_sym_dev(int board_size, const uint8_t *cells_dev, co
         return tg::fail(TG_ERR_ARG, "tg_featurize_dev: null argument");
     if (batch <= 0) return batch == 0 ? TG_OK : tg::fail(TG_ERR_ARG, "tg_featurize_dev: negative batch");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const dim3 grid((batch + 3) / 4), block(256);
+    const int npos = board_size == 9 ? 16 : 4;            // positions per workgroup (featurize_kernel NPOS)
+    const dim3 grid((batch + npos - 1) / npos), block(256);
     if (board_size == 9)
         hipLaunchKernelGGL(featurize_kernel<9>, grid, block, 0, st, cells_dev, to_move_dev,
                            prev_move_dev, moves_dev, sym_dev, batch, planes_dev);

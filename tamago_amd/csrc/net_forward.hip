@@ -830,6 +830,34 @@ const char *tg_net_kernel_name(const tg_net *net, int batch) {
     return g == 3 ? "dualnet_fwd_kernel<9, 3>" : "dualnet_fwd_kernel<9, 1>";
 }
 
+double tg_net_executed_flops_per_position(const tg_net *net, int batch, double *peak_tflops, const char **dtype) {
+    if (!net) return 0.0;
+    const int S = net->board_size, P = S * S;
+    double peak = 157.3;
+    const char *name = "f32";
+    double flops = 0.0;
+    if (S == 9 && pick_split()) {
+        // per workgroup pass: (2 stem + 12 * 18) k-chunks x (4 cout tiles x row tiles) x 3 products of
+        // v_mfma_f32_16x16x32_f16 (16 384 FLOP each)
+        const int g = batch > net->num_cus ? 3 : 1;
+        const int row_tiles = g == 3 ? 16 : 6;              // 4 waves x 4, 3 waves x 2
+        flops = (2.0 + 12.0 * 18.0) * 4.0 * row_tiles * 3.0 * 16384.0 / g;
+        peak = 2500.0;
+        name = "f16 (2 operand pieces, fp32 accumulate)";
+    } else if (pick_wino(S, batch, net->num_cus)) {
+        // v_mfma_f32_16x16x4_f32 (2048 FLOP): per layer 16 points x 4 cout tiles x row tiles x 16 k-steps; stem direct
+        const int g = S == 9 ? pick_wino(9, batch, net->num_cus) : 1;
+        const int tiles = g * ((S + 1) / 2) * ((S + 1) / 2), rt = (tiles + 15) / 16, mt = (g * P + 15) / 16;
+        flops = (12.0 * 16 * 4 * rt * 16 + 9.0 * 2 * 4 * mt) * 2048.0 / g;
+    } else {
+        const int g = pick_group(S, batch, net->num_cus), mt = (g * P + 15) / 16;
+        flops = (12.0 * 9 * 16 * 4 * mt + 9.0 * 2 * 4 * mt) * 2048.0 / g;
+    }
+    if (peak_tflops) *peak_tflops = peak;
+    if (dtype) *dtype = name;
+    return flops;
+}
+
 // Winograd tower: boards per workgroup (1, 2 or 3), or 0 = direct convolution kernel.
 // Measured on MI355X (tools/bench_net.py): B <= 256: 173 us (direct 194); B = 512: 308 (347);
 // B >= 768: 98 % vs 83 % of the fp32 MFMA peak in algorithmic FLOPs.

@@ -4,6 +4,6 @@ cd /tmp && export TMPDIR=/tmp
 TREES=${1:-256}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_t$TREES
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --stats -d $OUT -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --trees $TREES --no-cpu-baseline --selfplay-boards 0 > $OUT/bench.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --trees $TREES --no-cpu-baseline --no-legs > $OUT/bench.log 2>&1
 tail -1 $OUT/bench.log | cut -c1-400
 ls $OUT
