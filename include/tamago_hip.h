@@ -264,6 +264,33 @@ int tg_search_num_nodes(tg_search *s, int32_t *num_nodes_host /* [T] */);
 int tg_search_read_roots(tg_search *s, int32_t *num_children_host, int32_t *action_host,
                          int32_t *visits_host);
 
+/* ---- self-play shard bookkeeping (selfplay/worker.py:50-90, sgf/selfplay_record.py:45-110) -----------
+ * Everything the reference's worker does per move and per board AROUND the search, for all T boards of a
+ * search handle in one host call per move (C++, host threads): sequential-halving schedule
+ * (mcts/sequential_halving.py), final root choice (tree.py:344, node.py:324-346), resign rule
+ * (tree.py:351-354), improved-policy comment with ".3e" values (node.py:281-321, selfplay_record.py:45-65),
+ * two-pass end with count_score (go_board.py:561-608), maximum length (worker.py:44), the SGF file
+ * <save_dir>/<index>.sgf byte for byte as selfplay_record.py:67-110 writes it.
+ * Per move the caller does: tg_search_root_planes / forward / tg_search_backup, tg_search_draw_noise,
+ * tg_selfplay_schedule, one tg_search_select_gumbel / forward / tg_search_backup per phase,
+ * tg_selfplay_finish_move, tg_search_play(moves); slots whose game finished get tg_search_set_root +
+ * tg_search_seed_stream + tg_selfplay_start_game (or index -1 to park them). */
+typedef struct tg_selfplay tg_selfplay;
+/* komi_text: the komi as the SGF shall spell it (the reference prints Python's repr, e.g. "7.0"). */
+int tg_selfplay_create(tg_search *s, const char *save_dir, int visits, double komi, const char *komi_text,
+                       tg_selfplay **out);
+int tg_selfplay_destroy(tg_selfplay *sp);
+int tg_selfplay_start_game(tg_selfplay *sp, int slot, int index, int never_resign);
+/* Phases of the coming move for every board: num_considered / max_count host arrays [max_phases][T] (zero
+ * where a board has no such phase or is parked), *n_phases_host = phases of the longest schedule. */
+int tg_selfplay_schedule(tg_selfplay *sp, int32_t *num_considered_host, int32_t *max_count_host,
+                         int max_phases, int32_t *n_phases_host);
+/* After the last phase: moves_host[T] = move to play on each board (-1 = none: parked, resigned or game
+ * over), finished_host[T] = 1 where the game ended (its file is written), stats_host[2] = {games finished,
+ * moves decided} by this call (may be NULL). */
+int tg_selfplay_finish_move(tg_selfplay *sp, int32_t *moves_host, int32_t *finished_host,
+                            int64_t *stats_host);
+
 #ifdef __cplusplus
 }
 #endif

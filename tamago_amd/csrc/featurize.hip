@@ -3,10 +3,11 @@
 //
 // HBM-bound byte kernel: P bytes in, 6*P fp32 out per position (2 025 B at 9x9, 9 025 B at
 // 19x19).  A workgroup takes NPOS consecutive positions: their planes are ONE contiguous run of
-// NPOS*6*P floats, which the 256 threads write as 16-byte non-temporal stores (1 KB per wave
-// instruction, no partial waves: a wave per position with 4-byte stores left the 82nd..128th lane
-// idle and reached 44 % of the HBM peak); the uint8 cells are read once, coalesced, into LDS with
-// the board symmetry and the colour swap already applied.
+// NPOS*6*P floats.  Phase 1 (one thread per cell): read the uint8 cell through the board symmetry,
+// swap colours, write the cell's six plane values into an LDS image of that run.  Phase 2: the
+// image goes out as 16-byte non-temporal stores (1 KB per wave instruction, every lane busy, no index
+// arithmetic in the store loop).  (A wave per position with 4-byte stores left lanes 82..127 idle:
+// 44 % of the HBM peak; computing plane / point from the flat index in the store loop was VALU-bound.)
 #include "common.h"
 
 namespace {
@@ -25,8 +26,7 @@ __global__ __launch_bounds__(256) void featurize_kernel(const uint8_t *__restric
     constexpr int NPOS = S == 9 ? 16 : 4;              // positions per workgroup
     constexpr int RUN = NPOS * 6 * P;                  // floats written by a workgroup (multiple of 4)
     static_assert(RUN % 4 == 0 && (6 * P * NPOS * 4) % 16 == 0, "16-byte stores");
-    __shared__ uint8_t cls[NPOS][P];                   // 0 empty / 1 own / 2 opponent, bit 2: previous move
-    __shared__ float meta[NPOS][2];                    // pass plane value, side-to-move value
+    __shared__ __attribute__((aligned(16))) float img[RUN];   // [position][plane][point]
     const int tid = threadIdx.x;
     const int b0 = blockIdx.x * NPOS;
     const int nvalid = batch - b0 < NPOS ? batch - b0 : NPOS;
@@ -58,34 +58,22 @@ __global__ __launch_bounds__(256) void featurize_kernel(const uint8_t *__restric
         const int sp = ry * S + rx;
         int c = cells[(size_t)b * P + sp];
         if (color == 2 && c != 0) c = 3 - c;                 // feature.py:24-25
-        cls[bl][p] = (uint8_t)(c | (sp == prev_idx ? 4 : 0));
-        if (p == 0) {
-            meta[bl][0] = pass_plane ? 1.f : 0.f;
-            meta[bl][1] = color == 2 ? -1.f : 1.f;           // feature.py:50-52
-        }
+        float *o = img + bl * 6 * P + p;
+        o[0] = c == 0 ? 1.f : 0.f;
+        o[P] = c == 1 ? 1.f : 0.f;
+        o[2 * P] = c == 2 ? 1.f : 0.f;
+        o[3 * P] = sp == prev_idx ? 1.f : 0.f;
+        o[4 * P] = pass_plane ? 1.f : 0.f;
+        o[5 * P] = color == 2 ? -1.f : 1.f;                  // feature.py:50-52
     }
     __syncthreads();
-    auto element = [&](int e) -> float {
-        const int bl = e / (6 * P), r = e - bl * 6 * P, plane = r / P, p = r - plane * P;
-        const int c = cls[bl][p];
-        switch (plane) {
-            case 0: return (c & 3) == 0 ? 1.f : 0.f;
-            case 1: return (c & 3) == 1 ? 1.f : 0.f;
-            case 2: return (c & 3) == 2 ? 1.f : 0.f;
-            case 3: return (c & 4) ? 1.f : 0.f;
-            case 4: return meta[bl][0];
-            default: return meta[bl][1];
-        }
-    };
     float *dst = planes + (size_t)b0 * 6 * P;
     const int nfloat = nvalid * 6 * P;
-    for (int i = tid; i * 4 < nfloat; i += 256) {
-        const int e0 = i * 4;
+    for (int e0 = tid * 4; e0 < nfloat; e0 += 1024) {
         if (e0 + 4 <= nfloat) {
-            const f32x4 v = {element(e0), element(e0 + 1), element(e0 + 2), element(e0 + 3)};
-            __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(dst + e0));
+            __builtin_nontemporal_store(*reinterpret_cast<const f32x4 *>(img + e0), reinterpret_cast<f32x4 *>(dst + e0));
         } else {
-            for (int e = e0; e < nfloat; ++e) dst[e] = element(e);
+            for (int e = e0; e < nfloat; ++e) dst[e] = img[e];
         }
     }
 }

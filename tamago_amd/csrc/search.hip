@@ -32,8 +32,11 @@
 
 #include <sched.h>
 
+#include <cmath>
 #include <cstring>
 #include <algorithm>
+#include <map>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -1670,6 +1673,7 @@ struct tg_search {
     bool stage_busy[2] = {false, false};          // ev_rng[b] guards a copy out of stage[b]
     int64_t win_cap = 0, win_left = 0;            // active / pending window: size, unread tail
     std::vector<int64_t> win_used;                // device cursor per tree at the last advance
+    std::vector<double> noise_host;               // last root Gumbel noise [T][A] (tg_search_set_noise)
 };
 
 namespace {
@@ -2068,6 +2072,7 @@ int tg_search_set_noise(tg_search *s, const double *noise_host) {
     if (!s || !noise_host) return tg::fail(TG_ERR_ARG, "tg_search_set_noise: null argument");
     if (s->last_stream) TG_HIP(hipStreamSynchronize(s->last_stream));
     TG_HIP(hipMemcpy(s->dev.noise, noise_host, (size_t)s->dev.T * s->A * sizeof(double), hipMemcpyHostToDevice));
+    s->noise_host.assign(noise_host, noise_host + (size_t)s->dev.T * s->A);
     return TG_OK;
 }
 
@@ -2396,6 +2401,353 @@ int tg_search_read_node(tg_search *s, int tree, int node, int32_t *num_children,
         std::vector<int16_t> a16(A);
         TG_HIP(hipMemcpy(a16.data(), D.action + base, A * sizeof(int16_t), hipMemcpyDeviceToHost));
         for (size_t i = 0; i < A; ++i) action[i] = a16[i];
+    }
+    return TG_OK;
+}
+
+}  // extern "C"
+
+// ======================================================================================
+// Self-play shard bookkeeping (host, C++): everything selfplay/worker.py:50-90 does per move and per board
+// around the search - sequential-halving schedule (mcts/sequential_halving.py:7-60), final root choice
+// (node.py:324-346), resign rule (tree.py:351-354), improved policy (node.py:281-321) and its ".3e" comment
+// (sgf/selfplay_record.py:45-65), two-pass end + count_score (go_board.py:561-608), the SGF file
+// (selfplay_record.py:67-110) - for all T boards of a search handle in ONE call per move, on host threads.
+// Double arithmetic in the reference's evaluation order (np.sum's pairwise order, libm exp).
+// ======================================================================================
+namespace {
+
+double host_np_sum_block(const double *a, int n) {
+    if (n < 8) {
+        double r = 0.;
+        for (int i = 0; i < n; ++i) r += a[i];
+        return r;
+    }
+    double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8) {
+        r0 += a[i]; r1 += a[i + 1]; r2 += a[i + 2]; r3 += a[i + 3];
+        r4 += a[i + 4]; r5 += a[i + 5]; r6 += a[i + 6]; r7 += a[i + 7];
+    }
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; ++i) res += a[i];
+    return res;
+}
+double host_np_sum(const double *a, int n) {        // numpy's pairwise summation (blocks of <= 128)
+    if (n <= 128) return host_np_sum_block(a, n);
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return host_np_sum(a, n2) + host_np_sum(a + n2, n - n2);
+}
+
+struct SpGame {
+    int index = -1;                 // -1: slot parked
+    bool never_resign = false, done = true;
+    int to_move = kBlack, pass_count = 0, moves_played = 0;
+    std::string body;               // ";B[ee]C[...]" ...
+};
+
+// {considered actions: levels} in phase order (mcts/sequential_halving.py)
+std::vector<std::pair<int, int>> halving_pairs(int max_considered, int sims) {
+    std::vector<int> seq;
+    if (max_considered <= 1) {
+        for (int i = 0; i < sims; ++i) seq.push_back(i);
+    } else {
+        const int log2max = (int)std::ceil(std::log2((double)max_considered));
+        std::vector<int> visits(max_considered, 0);
+        int width = max_considered;
+        while ((int)seq.size() < sims) {
+            const int rounds = std::max(1, (int)((double)sims / (double)(log2max * width)));
+            for (int r = 0; r < rounds; ++r)
+                for (int i = 0; i < width; ++i) seq.push_back(visits[i]++);
+            width = std::max(2, width / 2);
+        }
+        seq.resize(sims);
+    }
+    int mx = 0;
+    for (int v : seq) mx = std::max(mx, v);
+    std::vector<int> width_at_level(mx + 1, 0);
+    for (int v : seq) ++width_at_level[v];
+    std::vector<std::pair<int, int>> pairs;
+    for (int w : width_at_level) {
+        bool found = false;
+        for (auto &pr : pairs)
+            if (pr.first == w) { ++pr.second; found = true; break; }
+        if (!found) pairs.emplace_back(w, 1);
+    }
+    return pairs;
+}
+
+}  // namespace
+
+struct tg_selfplay {
+    tg_search *s = nullptr;
+    std::string save_dir, komi_text;
+    double komi = 7.0;
+    int visits = 16;
+    std::vector<SpGame> games;                                   // [T]
+    std::map<int, std::vector<std::pair<int, int>>> schedule_cache;   // root candidates -> phases
+    // per-move scratch (root statistics of all trees)
+    std::vector<int32_t> nc, nv, visits_a, vl_a;
+    std::vector<float> raw;
+    std::vector<double> vsum_a, pol_a;
+    std::vector<int16_t> act_a;
+    std::vector<uint8_t> cells;
+};
+
+namespace {
+
+std::string gtp_name(int pos, int S) {                           // board/coordinate.py:38-43
+    if (pos == 0) return "pass";
+    static const char *letters = "IABCDEFGHJKLMNOPQRSTUVWXYZ";
+    const int W = S + 2, col = pos % W - 1, row = pos / W - 1;
+    return std::string(1, letters[col + 1]) + std::to_string(S - row);
+}
+std::string sgf_name(int pos, int S) {                           // board/coordinate.py:45-49
+    if (pos == 0) return "tt";
+    const int W = S + 2, col = pos % W - 1, row = pos / W - 1;
+    return std::string(1, (char)('a' + col)) + std::string(1, (char)('a' + row));
+}
+
+// go_board.py:561-608: stones in atari count as dead; an empty point takes the colour of its direct
+// neighbours only (both colours -> neutral), in row-major order, earlier colourings feeding later points
+int count_score_cells(const uint8_t *cells, int S) {
+    const int W = S + 2, NC = W * W;
+    std::vector<uint8_t> work(cells, cells + NC);
+    std::vector<int> stack;
+    std::vector<uint8_t> seen(NC), lib_seen(NC);
+    for (int y = 1; y <= S; ++y)
+        for (int x = 1; x <= S; ++x) {
+            const int pos = y * W + x, c = cells[pos];
+            if (c != kBlack && c != kWhite) continue;
+            std::fill(seen.begin(), seen.end(), 0);
+            std::fill(lib_seen.begin(), lib_seen.end(), 0);
+            int libs = 0;
+            stack.assign(1, pos);
+            seen[pos] = 1;
+            while (!stack.empty() && libs < 2) {
+                const int p = stack.back();
+                stack.pop_back();
+                const int nb[4] = {p - W, p - 1, p + 1, p + W};
+                for (int n : nb) {
+                    if (cells[n] == kEmpty) { if (!lib_seen[n]) { lib_seen[n] = 1; ++libs; } }
+                    else if (cells[n] == c && !seen[n]) { seen[n] = 1; stack.push_back(n); }
+                }
+            }
+            if (libs == 1) work[pos] = kEmpty;
+        }
+    for (int y = 1; y <= S; ++y)
+        for (int x = 1; x <= S; ++x) {
+            const int pos = y * W + x;
+            if (work[pos] != kEmpty) continue;
+            int color = kEmpty;
+            const int nb[4] = {pos - W, pos - 1, pos + 1, pos + W};
+            for (int n : nb) {
+                const int v = work[n];
+                if (v == kBlack || v == kWhite) {
+                    if (color == kEmpty) color = v;
+                    else if (color != v) color = kOob;
+                }
+            }
+            work[pos] = (uint8_t)color;
+        }
+    int score = 0;
+    for (int i = 0; i < NC; ++i) score += (work[i] == kBlack) - (work[i] == kWhite);
+    return score;
+}
+
+int write_sgf(const tg_selfplay *sp, const SpGame &g, int winner, bool is_resign, double score) {
+    char buf[96];
+    std::string text = "(;FF[4]GM[1]SZ[" + std::to_string(sp->s->S) + "]\n";
+    text += "AP[TamaGo]PB[TamaGo-Black]PW[TamaGo-White]";
+    if (winner == kBlack) {
+        if (is_resign) text += "RE[B+R]";
+        else { snprintf(buf, sizeof(buf), "RE[B+%.1f]", score); text += buf; }
+    } else if (winner == kWhite) {
+        if (is_resign) text += "RE[W+R]";
+        else { snprintf(buf, sizeof(buf), "RE[W+%.1f]", -score); text += buf; }
+    } else {
+        text += "RE[0]";
+    }
+    text += "KM[" + sp->komi_text + "]";
+    text += g.body;
+    text += "\n)";
+    const std::string path = sp->save_dir + "/" + std::to_string(g.index) + ".sgf";
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) return tg::fail(TG_ERR_ARG, "tg_selfplay: cannot write %s", path.c_str());
+    const bool ok = fwrite(text.data(), 1, text.size(), f) == text.size();
+    fclose(f);
+    return ok ? TG_OK : tg::fail(TG_ERR_ARG, "tg_selfplay: short write to %s", path.c_str());
+}
+
+}  // namespace
+
+extern "C" {
+
+int tg_selfplay_create(tg_search *s, const char *save_dir, int visits, double komi, const char *komi_text,
+                       tg_selfplay **out) {
+    if (!s || !save_dir || !komi_text || !out) return tg::fail(TG_ERR_ARG, "tg_selfplay_create: null argument");
+    if (visits < 1) return tg::fail(TG_ERR_ARG, "tg_selfplay_create: visits must be >= 1");
+    tg_selfplay *sp = new tg_selfplay;
+    sp->s = s;
+    sp->save_dir = save_dir;
+    sp->komi = komi;
+    sp->komi_text = komi_text;
+    sp->visits = visits;
+    sp->games.assign(s->dev.T, SpGame{});
+    *out = sp;
+    return TG_OK;
+}
+
+int tg_selfplay_destroy(tg_selfplay *sp) {
+    delete sp;
+    return TG_OK;
+}
+
+int tg_selfplay_start_game(tg_selfplay *sp, int slot, int index, int never_resign) {
+    if (!sp) return tg::fail(TG_ERR_ARG, "tg_selfplay_start_game: null argument");
+    if (slot < 0 || slot >= sp->s->dev.T) return tg::fail(TG_ERR_ARG, "tg_selfplay_start_game: slot %d out of range", slot);
+    SpGame g;
+    g.index = index;
+    g.never_resign = never_resign != 0;
+    g.done = index < 0;
+    sp->games[slot] = g;
+    return TG_OK;
+}
+
+int tg_selfplay_schedule(tg_selfplay *sp, int32_t *num_considered_host, int32_t *max_count_host, int max_phases,
+                         int32_t *n_phases_host) {
+    if (!sp || !num_considered_host || !max_count_host || !n_phases_host)
+        return tg::fail(TG_ERR_ARG, "tg_selfplay_schedule: null argument");
+    tg_search *s = sp->s;
+    const int T = s->dev.T;
+    sp->nc.resize(T);
+    int rc = tg_search_read_root_stats(s, sp->nc.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    std::fill(num_considered_host, num_considered_host + (size_t)max_phases * T, 0);
+    std::fill(max_count_host, max_count_host + (size_t)max_phases * T, 0);
+    int n_phases = 0;
+    for (int t = 0; t < T; ++t) {
+        if (sp->games[t].done) continue;
+        const int base = sp->nc[t] < 16 ? sp->nc[t] : 16;            // MAX_CONSIDERED_NODES (mcts/constant.py)
+        auto it = sp->schedule_cache.find(base);
+        if (it == sp->schedule_cache.end())
+            it = sp->schedule_cache.emplace(base, halving_pairs(base, sp->visits)).first;
+        const auto &pairs = it->second;
+        if ((int)pairs.size() > max_phases) return tg::fail(TG_ERR_ARG, "tg_selfplay_schedule: %zu phases exceed max_phases", pairs.size());
+        for (size_t ph = 0; ph < pairs.size(); ++ph) {
+            num_considered_host[ph * T + t] = pairs[ph].first;
+            max_count_host[ph * T + t] = pairs[ph].second;
+        }
+        n_phases = std::max(n_phases, (int)pairs.size());
+    }
+    *n_phases_host = n_phases;
+    return TG_OK;
+}
+
+int tg_selfplay_finish_move(tg_selfplay *sp, int32_t *moves_host, int32_t *finished_host, int64_t *stats_host) {
+    if (!sp || !moves_host || !finished_host) return tg::fail(TG_ERR_ARG, "tg_selfplay_finish_move: null argument");
+    tg_search *s = sp->s;
+    const SearchDev &D = s->dev;
+    const int T = D.T, A = s->A, S = s->S;
+    sp->nc.resize(T); sp->nv.resize(T); sp->raw.resize(T);
+    sp->visits_a.resize((size_t)T * A); sp->vl_a.resize((size_t)T * A);
+    sp->vsum_a.resize((size_t)T * A); sp->pol_a.resize((size_t)T * A);
+    std::vector<int32_t> act32((size_t)T * A);
+    int rc = tg_search_read_root_stats(s, sp->nc.data(), sp->nv.data(), sp->raw.data(), act32.data(), sp->visits_a.data(),
+                                       sp->vl_a.data(), sp->vsum_a.data(), sp->pol_a.data());
+    if (rc) return rc;
+    if (s->noise_host.size() != (size_t)T * A) return tg::fail(TG_ERR_STATE, "tg_selfplay_finish_move: no root noise was set");
+    sp->cells.resize((size_t)T * s->NC);
+    TG_HIP(hipMemcpy(sp->cells.data(), D.root_cells, sp->cells.size(), hipMemcpyDeviceToHost));
+    const int max_moves = S * S * 2;                                  // worker.py:44
+    std::vector<int> status(T, TG_OK);
+    std::vector<int64_t> n_moves(T, 0), n_games(T, 0);
+    parallel_trees(T, [&](int t) {
+        SpGame &g = sp->games[t];
+        moves_host[t] = -1;
+        finished_host[t] = 0;
+        if (g.done) return;
+        const size_t o = (size_t)t * A;
+        const int n = sp->nc[t];
+        const int32_t *vis = &sp->visits_a[o], *vl = &sp->vl_a[o], *act = &act32[o];
+        const double *vsum = &sp->vsum_a[o], *pol = &sp->pol_a[o], *noise = &s->noise_host[o];
+        // ---- final root choice (tree.py:344, node.py:324-346 with count_threshold = PLAYOUTS = 100) ----
+        int max_count = 0;
+        for (int i = 0; i < n; ++i) max_count = std::max(max_count, vis[i]);
+        const double sigma_sel = (double)(50 + max_count) * 1.0;
+        std::vector<double> q(n), w1(n), w2(n);
+        int best = 0;
+        double best_v = 0.0;
+        for (int i = 0; i < n; ++i) {
+            q[i] = vis[i] > 0 ? vsum[i] / (double)vis[i] : 0.0;
+            const double ev = (vis[i] + vl[i] >= 100) ? -10000.0 : (pol[i] + noise[i]) + sigma_sel * q[i];
+            if (i == 0 || ev > best_v) { best_v = ev; best = i; }
+        }
+        const double value = vis[best] == 0 ? 0.5 : vsum[best] / (double)vis[best];
+        n_moves[t] = 1;
+        if (!g.never_resign && value < 0.05) {                          // worker.py:59-62
+            status[t] = write_sgf(sp, g, 3 - g.to_move, true, 0.0);
+            g.done = true;
+            finished_host[t] = 1;
+            n_games[t] = 1;
+            return;
+        }
+        const int pos = act[best];
+        // ---- improved policy (node.py:281-321) -> comment "<n> <gtp>:<p:.3e> ..." ----
+        double mx = -INFINITY;
+        for (int i = 0; i < n; ++i) mx = pol[i] > mx ? pol[i] : mx;
+        for (int i = 0; i < n; ++i) w1[i] = std::exp(pol[i] - mx);
+        const double s1 = host_np_sum(w1.data(), n);
+        for (int i = 0; i < n; ++i) { w1[i] = w1[i] / s1; w2[i] = w1[i] * q[i]; }
+        const double sum_prob = host_np_sum(w1.data(), n), v_pi = host_np_sum(w2.data(), n);
+        const double nvd = (double)sp->nv[t];
+        const double mixed = ((double)sp->raw[t] * 1.0 + nvd * v_pi / sum_prob) / (nvd + 1.0);
+        // np.max(self.children_visits) runs over the whole array (zeros beyond n): same value
+        double mx2 = -INFINITY;
+        for (int i = 0; i < n; ++i) {
+            w2[i] = pol[i] + sigma_sel * (vis[i] > 0 ? q[i] : mixed);
+            mx2 = w2[i] > mx2 ? w2[i] : mx2;
+        }
+        for (int i = 0; i < n; ++i) w1[i] = std::exp(w2[i] - mx2);
+        const double s2 = host_np_sum(w1.data(), n);
+        char buf[64];
+        g.body += g.to_move == kBlack ? ";B[" : ";W[";
+        g.body += sgf_name(pos, S);
+        g.body += "]C[";
+        g.body += std::to_string(n);
+        for (int i = 0; i < n; ++i) {
+            snprintf(buf, sizeof(buf), ":%.3e", w1[i] / s2);
+            g.body += ' ';
+            g.body += gtp_name(act[i], S);
+            g.body += buf;
+        }
+        g.body += ']';
+        moves_host[t] = pos;
+        g.pass_count = pos == 0 ? g.pass_count + 1 : 0;
+        g.to_move = 3 - g.to_move;
+        g.moves_played += 1;
+        if (g.pass_count == 2) {                                        // worker.py:80-87 (a pass leaves the cells as they are)
+            const double score = (double)count_score_cells(&sp->cells[(size_t)t * s->NC], S) - sp->komi;
+            const int winner = score > 0.1 ? kBlack : (score < -0.1 ? kWhite : kOob);
+            status[t] = write_sgf(sp, g, winner, false, score);
+            g.done = true;
+        } else if (g.moves_played >= max_moves) {
+            status[t] = write_sgf(sp, g, kEmpty, false, 0.0);
+            g.done = true;
+        }
+        if (g.done) {
+            finished_host[t] = 1;
+            n_games[t] = 1;
+            moves_host[t] = -1;                                         // the slot gets a new root anyway
+        }
+    });
+    for (int t = 0; t < T; ++t)
+        if (status[t] != TG_OK) return status[t];
+    if (stats_host) {
+        stats_host[0] = 0;
+        stats_host[1] = 0;
+        for (int t = 0; t < T; ++t) { stats_host[0] += n_games[t]; stats_host[1] += n_moves[t]; }
     }
     return TG_OK;
 }

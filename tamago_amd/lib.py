@@ -73,6 +73,11 @@ _SIGNATURES = {
     "tg_search_advance_streams": (c_int, [c_void_p, c_void_p]),
     "tg_search_draw_noise": (c_int, [c_void_p, c_void_p]),
     "tg_legacy_exponentials": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "tg_selfplay_create": (c_int, [c_void_p, c_char_p, c_int, c_double, c_char_p, POINTER(c_void_p)]),
+    "tg_selfplay_destroy": (c_int, [c_void_p]),
+    "tg_selfplay_start_game": (c_int, [c_void_p, c_int, c_int, c_int]),
+    "tg_selfplay_schedule": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "tg_selfplay_finish_move": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -16,9 +16,7 @@ import numpy as np
 from tamago_amd.board.constant import PASS, RESIGN
 from tamago_amd.board.go_board import GoBoard
 from tamago_amd.board.stone import Stone
-from tamago_amd.mcts.constant import MAX_CONSIDERED_NODES, PLAYOUTS
 from tamago_amd.mcts.engine import SearchEngine, HostEvaluator, DeviceEvaluator
-from tamago_amd.mcts.sequential_halving import get_candidates_and_visit_pairs
 from tamago_amd.sgf.selfplay_record import SelfPlayRecord
 
 SELF_PLAY_VISITS = 16           # learning_param.py:40
@@ -127,92 +125,77 @@ def selfplay_shard(save_dir: str, network, index_list: Sequence[int], size: int,
 
 
 def _run_group(save_dir, network, size, visits, boards, seeds, device_index, next_game, stats, stream):
-    """One lock-step group of `boards` games on its own engine (and HIP stream, if given)."""
-    from tamago_amd.nn.network.dual_net import DualNet
+    """One lock-step group of `boards` games on its own engine (and HIP stream, if given).
+
+    Per move the host issues a constant number of library calls, whatever the number of boards: root
+    evaluation, Gumbel noise, tg_selfplay_schedule, one selection + forward + backup per halving
+    phase, tg_selfplay_finish_move (final root choice, resign rule, improved-policy comment, two-pass
+    end + scoring, SGF file - in C++ on host threads), tg_search_play.  Python only starts games."""
     import contextlib
+    import ctypes
     import torch
+    from tamago_amd import lib as _lib
+    from tamago_amd.nn.network.dual_net import DualNet
     ctx = torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
     with ctx:
         evaluator = DeviceEvaluator(network) if isinstance(network, DualNet) \
             else HostEvaluator(network, torch.device("cuda", device_index))
-        max_moves = size * size * 2                                    # worker.py:44
         engine = SearchEngine(size, boards, max(SELF_PLAY_VISITS * 10, visits + 8), max(visits, 1),
                               evaluator, check_superko=True, device_index=device_index)
-        slots: List[_Game] = [None] * boards
+        lib = engine.lib
+        start_board = GoBoard(board_size=size, komi=7.0, check_superko=True)
+        handle = ctypes.c_void_p()
+        _lib.check(lib.tg_selfplay_create(engine.handle, os.fsencode(save_dir), visits, float(start_board.get_komi()),
+                                          repr(float(start_board.get_komi())).encode(), ctypes.byref(handle)),
+                   "tg_selfplay_create")
+        live = 0
 
         def start(slot: int) -> bool:
             nxt = next_game()
             if nxt is None:
+                _lib.check(lib.tg_selfplay_start_game(handle, slot, -1, 0), "tg_selfplay_start_game")
                 return False
-            index, nr = nxt
-            slots[slot] = _Game(index, size, save_dir, nr)
+            index, never_resign = nxt
             engine.streams[slot] = None
-            game = slots[slot]
-            engine.set_root(slot, game.board, game.color, np.random.RandomState(seeds[index]).get_state())
+            engine.set_root(slot, start_board, Stone.BLACK, np.random.RandomState(seeds[index]).get_state())
+            _lib.check(lib.tg_selfplay_start_game(handle, slot, index, int(never_resign)), "tg_selfplay_start_game")
             return True
 
-        for s in range(boards):
-            if not start(s):
-                # fewer games than slots: park an empty board with a private stream
-                slots[s] = None
-                engine.set_root(s, GoBoard(board_size=size, komi=7.0, check_superko=True), Stone.BLACK,
-                                np.random.RandomState(0).get_state())
-
-        while any(g is not None and not g.done for g in slots):
-            active = [s for s, g in enumerate(slots) if g is not None and not g.done]
-            # boards are resident on the device (tg_search_play); idle slots keep their last root
-            engine.root_eval(use_logit=True)
-            engine.set_gumbel_noise()
-            nc, _, _ = engine.read_roots()
-            schedules = []
+        try:
             for s in range(boards):
-                base = int(nc[s]) if nc[s] < MAX_CONSIDERED_NODES else MAX_CONSIDERED_NODES
-                schedules.append(list(get_candidates_and_visit_pairs(base, visits).items())
-                                 if s in active else [])
-            stats["leaf_evals"] += len(active)
-            for phase in range(max(len(sc) for sc in schedules)):
-                widths = [sc[phase][0] if phase < len(sc) else 0 for sc in schedules]
-                levels = [sc[phase][1] if phase < len(sc) else 0 for sc in schedules]
-                engine.gumbel_phase(widths, levels)
-                stats["leaf_evals"] += int(np.dot(widths, levels))
-            root_stats = engine.read_root_stats()
-            played = np.full(boards, -1, dtype=np.int32)
-            for s in active:
-                game = slots[s]
-                root = engine.root_view(root_stats, s)
-                best = root.select_move_by_sequential_halving_for_root(PLAYOUTS)      # tree.py:344
-                value = root.calculate_value_evaluation(best)
-                pos = RESIGN if (not game.never_resign and value < 0.05) else root.get_child_move(best)
-                stats["moves"] += 1
-                if pos == RESIGN:                                                      # worker.py:59-62
-                    _finish(game, Stone.get_opponent_color(game.color), True, 0.0)
+                if start(s):
+                    live += 1
                 else:
-                    played[s] = pos
-                    game.history.append((pos, game.color))
-                    game.pass_count = game.pass_count + 1 if pos == PASS else 0
-                    game.record.save_record(root, pos, game.color)
-                    game.color = Stone.get_opponent_color(game.color)
-                    game.moves_played += 1
-                    if game.pass_count == 2:                                           # worker.py:80-87
-                        final = GoBoard(board_size=size, komi=7.0, check_superko=True)
-                        for mv, col in game.history:
-                            final.put_stone(mv, col)
-                        score = final.count_score() - final.get_komi()
-                        winner = Stone.BLACK if score > 0.1 else (Stone.WHITE if score < -0.1
-                                                                  else Stone.OUT_OF_BOARD)
-                        _finish(game, winner, False, score)
-                    elif game.moves_played >= max_moves:
-                        # the reference reaches write_record with `winner` unset here (a NameError);
-                        # record the game as unfinished instead
-                        _finish(game, Stone.EMPTY, False, 0.0)
-                if game.done:
-                    stats["games"] += 1
-                    played[s] = -1
-            engine.play(played)
-            for s in active:
-                if slots[s].done:
-                    start(s)
-        engine.close()
+                    # fewer games than slots: park an empty board with a private stream
+                    engine.set_root(s, start_board, Stone.BLACK, np.random.RandomState(0).get_state())
+            max_phases = 16
+            widths = np.zeros((max_phases, boards), dtype=np.int32)
+            levels = np.zeros((max_phases, boards), dtype=np.int32)
+            n_phases = ctypes.c_int32(0)
+            played = np.zeros(boards, dtype=np.int32)
+            finished = np.zeros(boards, dtype=np.int32)
+            counts = np.zeros(2, dtype=np.int64)
+            while live > 0:
+                # boards are resident on the device (tg_search_play); parked slots keep their last root
+                engine.root_eval(use_logit=True)
+                engine.set_gumbel_noise()
+                _lib.check(lib.tg_selfplay_schedule(handle, widths.ctypes.data, levels.ctypes.data, max_phases,
+                                                    ctypes.byref(n_phases)), "tg_selfplay_schedule")
+                stats["leaf_evals"] += live
+                for phase in range(n_phases.value):
+                    engine.gumbel_phase(widths[phase], levels[phase])
+                stats["leaf_evals"] += int((widths[:n_phases.value].astype(np.int64) * levels[:n_phases.value]).sum())
+                _lib.check(lib.tg_selfplay_finish_move(handle, played.ctypes.data, finished.ctypes.data,
+                                                       counts.ctypes.data), "tg_selfplay_finish_move")
+                stats["games"] += int(counts[0])
+                stats["moves"] += int(counts[1])
+                engine.play(played)
+                for s in np.nonzero(finished)[0]:
+                    if not start(int(s)):
+                        live -= 1
+        finally:
+            lib.tg_selfplay_destroy(handle)
+            engine.close()
 
 
 def selfplay_worker(save_dir: str, model_file_path: str, index_list: List[int], size: int,

@@ -55,7 +55,7 @@ def main(out):
     # ---- 1. forward kernel ----------------------------------------------------------------------
     per, times = counters(out, ["fwd_a", "fwd_b", "fwd_c", "fwd_d", "fwd_e", "fwd_f"], ["dualnet_fwd"])
     for kname, c in per.items():
-        if "GRBM_GUI_ACTIVE" not in c:
+        if "GRBM_GUI_ACTIVE" not in c or times[kname][1] < 1e5:      # (the guarded fp32 fallback launch exits in microseconds)
             continue
         positions = 65536
         launches, dur_ns = times[kname]
