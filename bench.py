@@ -43,8 +43,8 @@ def pmc_summary(kernel_name):
     passes, as MI355X_MICROARCH.md section HBM prescribes), matrix-pipe busy fraction, L2 request bytes.
     A summary taken on other sources (csrc digest differs) or another kernel is NOT quoted: returns None and
     says so on stderr."""
-    from tamago_amd.build import source_digest
-    digest = source_digest()
+    from tamago_amd.build import FORWARD_SOURCES, source_digest
+    digest = source_digest(FORWARD_SOURCES)
     import glob
     for path in sorted(glob.glob(os.path.join(PROFILES, "r02_pmc_forward_*.json")), reverse=True):
         with open(path) as f:

@@ -291,6 +291,32 @@ int tg_selfplay_schedule(tg_selfplay *sp, int32_t *num_considered_host, int32_t 
 int tg_selfplay_finish_move(tg_selfplay *sp, int32_t *moves_host, int32_t *finished_host,
                             int64_t *stats_host);
 
+/* ---- training step (nn/learn.py:318-403, nn/loss.py:9-55; modules of nn/network/) ---------------------------
+ * One mini-batch of the reference's GPU trainers as hand-written HIP kernels (forward with batch statistics,
+ * backward, torch.optim.SGD(momentum 0.9, weight_decay 1e-4, nesterov=True) update, batch-norm running
+ * statistics), fp32.  The trainer owns a device copy of the parameters in the tg_net_create blob order
+ * (running_mean / running_var included; num_batches_tracked is the caller's counter) and a momentum blob of
+ * the same layout.  9x9; batch = positions per step (>= 2).
+ *   tg_trainer_step: planes [B,6,9,9] fp32, policy targets [B,82] fp32, value classes [B] int64, all device
+ *     memory; sl_mode 0 = RL objective (KL(target || softmax) batch mean + value_weight * cross entropy,
+ *     learn.py:360-376), 1 = supervised (-sum t log(softmax + 1e-8), learn.py:150-180); ENQUEUES the step.
+ *   tg_trainer_read_losses: device-accumulated sums of (total, policy, value) loss over the steps since the
+ *     last reset, one read for many steps. */
+typedef struct tg_trainer tg_trainer;
+int tg_trainer_create(int board_size, int device, int batch, const float *params_host, size_t n_params,
+                      tg_trainer **out);
+int tg_trainer_destroy(tg_trainer *t);
+int tg_trainer_step(tg_trainer *t, const float *planes_dev, const float *policy_dev,
+                    const long long *value_dev, int sl_mode, float value_weight, float lr, void *stream);
+int tg_trainer_read_losses(tg_trainer *t, double *sums_host /* [3] */, int reset);
+/* parameters (and, unless NULL, the momentum buffers) back to the host; n = tg_net_param_count(9) */
+int tg_trainer_get_params(tg_trainer *t, float *params_host, float *momentum_host, size_t n);
+/* test aid: one saved tensor of the last step, NHWC fp32 [B][81][64]: which 0 = Z_index (convolution output
+ * before its batch norm, index 0..12), 1 = Y_index (block output, 0..6), 2 = D_index (dL/d batch-norm output) */
+int tg_trainer_debug_read(tg_trainer *t, int which, int index, float *out_host);
+/* resume: momentum buffers of a loaded optimiser state (the next step is then not a "first" step) */
+int tg_trainer_set_momentum(tg_trainer *t, const float *momentum_host, size_t n);
+
 #ifdef __cplusplus
 }
 #endif

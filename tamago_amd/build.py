@@ -32,13 +32,20 @@ def sources():
                   if f.endswith(".hip") or f.endswith(".cpp"))
 
 
-def source_digest() -> str:
-    """sha256 (16 hex digits) over the kernel sources and the ABI header: profiles/ summaries carry it,
-    bench.py only quotes a PMC summary that was measured on the kernels it is running."""
+FORWARD_SOURCES = ("net_forward.hip", "net_forward_split.hip", "net_device.h", "common.h")
+
+
+def source_digest(names=None) -> str:
+    """sha256 (16 hex digits) over kernel sources: profiles/ summaries carry it, bench.py only quotes a PMC
+    summary that was measured on the kernels it is running.  `names`: basenames under csrc/ (default: all
+    sources + headers + the ABI header); FORWARD_SOURCES = what the DualNet forward kernels are built from."""
     import hashlib
     h = hashlib.sha256()
-    files = sources() + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
-    files.append(os.path.join(REPO, "include", "tamago_hip.h"))
+    if names is None:
+        files = sources() + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
+        files.append(os.path.join(REPO, "include", "tamago_hip.h"))
+    else:
+        files = [os.path.join(CSRC, f) for f in names]
     for path in files:
         h.update(os.path.basename(path).encode())
         with open(path, "rb") as f:

@@ -294,7 +294,7 @@ __global__ __launch_bounds__((SplitCfg<S, G, F>::NTHR), 1) void dualnet_fwd_spli
     // then per layer (stem first) "MFMA loop done" / "epilogue done", last: heads done
     int stamp_i = 0;
     auto stamp = [&]() {
-        if (net.timeline && blockIdx.x == 0 && tid == 0 && stamp_i < 64)
+        if (net.timeline && blockIdx.x == 0 && tid == 0 && stamp_i < 40)      // (40..42: head sub-phases)
             net.timeline[stamp_i++] = (long long)__builtin_amdgcn_s_memtime();
     };
     int ovf = 0;

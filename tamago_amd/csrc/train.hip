@@ -1,0 +1,935 @@
+// Training step of the DualNet on gfx950 (MI355X): forward with batch statistics, backward, SGD-Nesterov -
+// hand-written HIP kernels, no library call.  Replaces one mini-batch of nn/learn.py:360-376 (RL: KLD policy
+// loss + value cross entropy, nn/loss.py:33-55) and of the supervised trainer (learn.py:150-180) as executed
+// by torch autograd over the modules of nn/network/dual_net.py:16-52, res_block.py:8-40, head/*.py, with
+// torch.optim.SGD(momentum 0.9, weight decay 1e-4, nesterov) - in fp32 (the reference runs it under fp16
+// autocast; fp32 is what its CPU trainer does and the stricter of the two).
+//
+// Data layout (HBM): activations are NHWC fp32 [B][81][64].  Kept per step: Z_l = convolution output before
+// its batch norm (13 layers), Y_b = block outputs after ReLU (stem + 6 blocks), D_l = dL/d(batch-norm output
+// of layer l, ReLU mask applied).  Nothing else is materialised: every kernel rebuilds the tensor it needs
+// while staging a board into LDS (batch norm + ReLU of the producer's Z, batch-norm backward of D), so a
+// step is ~45 launches instead of the ~230 of the operator-by-operator library path.
+//
+// Kernels (one workgroup = one board at a time, 4 waves; wave w owns output channels [16w, 16w+16)):
+//   conv_kernel<FWD>   implicit GEMM 81(96) x 64 x 576 on v_mfma_f32_16x16x4_f32, epilogue: Z + per-channel
+//                      sum / sum of squares (the batch statistics) by atomics
+//   conv_kernel<DGRAD> the same loop on rotated / transposed weights over dZ; epilogue: + skip gradient,
+//                      ReLU mask, D of the layer below + its two batch-norm-backward sums
+//   wgrad_kernel       dW[co][tap][ci] = sum_rows dZ[row][co] * A[row + tap][ci] per board, accumulated over a
+//                      workgroup's boards in registers, one partial image per workgroup
+//   head_* kernels     1x1 convolutions, their batch norms, both fully connected layers, the losses and all
+//                      of their gradients
+//   sgd_kernel         reduces the partial images, adds weight decay, momentum / Nesterov, updates; batch-norm
+//                      running statistics in the same launch
+#include "common.h"
+
+#include <cmath>
+#include <cstring>
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int S = 9, P = 81, A = 82, C = 64;
+constexpr int kLayers = 13;                       // conv layers: stem + 12
+constexpr int kRow = 72;                          // LDS row stride in floats (conflict-free ds_read_b128)
+constexpr int kMT = 6;                            // 16-row tiles per board (96 >= 81)
+constexpr int kConvW = 64 * 64 * 9;
+constexpr int kRep = 16;                          // replicas of every atomically accumulated statistic
+
+// ---- parameter blob (tg_net_param_count order, include/tamago_hip.h) -----------------------------------
+struct Layout {
+    size_t conv[kLayers], bn_w[kLayers], bn_b[kLayers], bn_m[kLayers], bn_v[kLayers];
+    size_t p_conv, p_bn_w, p_bn_b, p_bn_m, p_bn_v, p_fc_w, p_fc_b;
+    size_t v_conv, v_bn_w, v_bn_b, v_bn_m, v_bn_v, v_fc_w, v_fc_b;
+    size_t total;
+};
+Layout make_layout() {
+    Layout L{};
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t r = o; o += n; return r; };
+    L.conv[0] = take(64 * 6 * 9);
+    L.bn_w[0] = take(64); L.bn_b[0] = take(64); L.bn_m[0] = take(64); L.bn_v[0] = take(64);
+    for (int b = 0; b < 6; ++b) {
+        L.conv[1 + 2 * b] = take(kConvW);
+        L.conv[2 + 2 * b] = take(kConvW);
+        for (int k = 0; k < 2; ++k) {
+            const int l = 1 + 2 * b + k;
+            L.bn_w[l] = take(64); L.bn_b[l] = take(64); L.bn_m[l] = take(64); L.bn_v[l] = take(64);
+        }
+    }
+    L.p_conv = take(2 * 64); L.p_bn_w = take(2); L.p_bn_b = take(2); L.p_bn_m = take(2); L.p_bn_v = take(2);
+    L.p_fc_w = take((size_t)A * 2 * P); L.p_fc_b = take(A);
+    L.v_conv = take(64); L.v_bn_w = take(1); L.v_bn_b = take(1); L.v_bn_m = take(1); L.v_bn_v = take(1);
+    L.v_fc_w = take(3 * P); L.v_fc_b = take(3);
+    L.total = o;
+    return L;
+}
+
+struct TrainDev {
+    float *param, *grad, *mom;      // flat blobs (grad / mom: running statistics slots unused)
+    float *wf, *wb;                 // [13][4 wave][9 tap][4 s][64 lane][4]: forward / transposed-rotated fragments
+    float *Z, *Y, *D;               // [13][B][81][64], [7][B][81][64], [13][B][81][64]
+    double *stat;                   // per layer [kRep][4][64]: sum z, sum z^2 (forward), S1 = sum D, S2 = sum D*xhat (backward);
+                                    // double: var = E[z^2] - mean^2 cancels, and the stem's gradient sees 13 layers of it.
+                                    // kRep replicas (workgroup w adds to replica w % kRep): 256 same-address atomics
+                                    // per channel serialise in L2 and cost more than the convolution itself
+    float *partial;                 // [13][NWG][9][64][64] weight-gradient partial images
+    float *hz, *hD;                 // head conv outputs / their D: [B][81][4] (2 policy, 1 value, 1 pad)
+    double *hstat;                  // [kRep][4][4]: sum, sumsq, S1, S2 for the 3 head channels
+    float *hact;                    // [B][3*81] ReLU(BN(hz)) flattened: policy c*81+p (162), value (81)
+    float *dlog;                    // [B][A + 3] dL/dlogits
+    double *loss;                   // [kRep][4] accumulated: total, policy, value
+    Layout L;
+    int B, NWG;
+};
+
+struct TrainDev;
+__device__ __forceinline__ double stat_sum(const double *base, int stride) {   // sum over the replicas
+    double v = 0.0;
+#pragma unroll
+    for (int r = 0; r < kRep; ++r) v += base[(size_t)r * stride];
+    return v;
+}
+__device__ __forceinline__ f32x4 lds4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+
+// compile-time loop: fn(std::integral_constant<int, 0>{}), ..., fn(std::integral_constant<int, N - 1>{})
+template <typename Fn, int... Is>
+__device__ __forceinline__ void static_for_impl(Fn &&fn, std::integer_sequence<int, Is...>) {
+    (fn(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename Fn>
+__device__ __forceinline__ void static_for(Fn &&fn) {
+    static_for_impl(fn, std::make_integer_sequence<int, N>{});
+}
+
+// batch-norm constants of layer `l` from its statistics: scale = gamma * rstd, shift = beta - mean * scale
+__device__ __forceinline__ void bn_consts(const TrainDev &T, int l, int c, float eps, float &mean, float &rstd) {
+    const double n = (double)(T.B * P);
+    const double m = stat_sum(T.stat + (size_t)l * kRep * 256 + c, 256) / n;
+    const double var = fmax(stat_sum(T.stat + (size_t)l * kRep * 256 + 64 + c, 256) / n - m * m, 0.0);
+    mean = (float)m;
+    rstd = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+enum ConvMode { FWD = 0, DGRAD = 1 };
+
+// ---- 3x3 convolution, forward and data gradient ----------------------------------------------------------
+// layer l (0 = stem).  FWD: input = activation feeding conv l, output Z_l + statistics.
+// DGRAD (l >= 1): input dZ_l (batch-norm backward of D_l, rebuilt on load), output D_{l-1} + its sums.
+// 4 waves: wave w owns output channels [16w, 16w+16) of all six row tiles.  A 256-position batch is one board per CU
+// = one wave per SIMD, so the loop hides its own latencies: weight fragments (L2) are requested two (tap, channel
+// group) steps ahead, activation fragments (LDS) one step ahead, positions pinned with sched_barrier.
+template <int MODE>
+__global__ __launch_bounds__(256) void conv_kernel(TrainDev T, const float *__restrict__ planes, int l) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *act = smem;                       // [81][72] + zero row
+    float *zrow = smem + P * kRow;
+    float *tab = zrow + kRow;                // per-channel constants [4][64]
+    constexpr int NT = 256, HMT = kMT;                     // row tiles per wave
+    const int tid = threadIdx.x, wave = tid >> 6, half = 0, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+    const float eps_l = 2e-5f;
+    for (int e = tid; e < kRow; e += NT) zrow[e] = 0.f;
+    // tap validity of row (half * HMT + mt) * 16 + li
+    unsigned mask[HMT];
+#pragma unroll
+    for (int mt = 0; mt < HMT; ++mt) {
+        const int r = (half * HMT + mt) * 16 + li, y = r / S, x = r - y * S;
+        unsigned m = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            if (r < P && yy >= 0 && yy < S && xx >= 0 && xx < S) m |= 1u << t;
+        }
+        mask[mt] = m;
+    }
+    // ---- per-channel tables -------------------------------------------------------------------------
+    // FWD: tab[0] = scale, tab[1] = shift of the PRODUCER's batch norm (layer l - 1)
+    // DGRAD: tab[0] = gamma*rstd of layer l, tab[1] = mean, tab[2] = rstd, tab[3] unused; m1/m2 in tab[4..5]
+    if (tid < 64) {
+        if (MODE == FWD) {
+            if (l >= 1) {
+                float mean, rstd;
+                bn_consts(T, l - 1, tid, l - 1 == 0 ? 1e-5f : eps_l, mean, rstd);
+                const float sc = T.param[T.L.bn_w[l - 1] + tid] * rstd;
+                tab[tid] = sc;
+                tab[64 + tid] = T.param[T.L.bn_b[l - 1] + tid] - mean * sc;
+            }
+        } else {
+            float mean, rstd;
+            bn_consts(T, l, tid, eps_l, mean, rstd);
+            const double n = (double)(T.B * P);
+            tab[tid] = T.param[T.L.bn_w[l] + tid] * rstd;
+            tab[64 + tid] = mean;
+            tab[128 + tid] = rstd;
+            tab[192 + tid] = (float)(stat_sum(T.stat + (size_t)l * kRep * 256 + 128 + tid, 256) / n);      // m1 = mean(D)
+            tab[256 + tid] = (float)(stat_sum(T.stat + (size_t)l * kRep * 256 + 192 + tid, 256) / n);      // m2 = mean(D * xhat)
+            // constants of the layer BELOW (mask / xhat of D_{l-1})
+            float mean2, rstd2;
+            bn_consts(T, l - 1, tid, l - 1 == 0 ? 1e-5f : eps_l, mean2, rstd2);
+            const float sc2 = T.param[T.L.bn_w[l - 1] + tid] * rstd2;
+            tab[320 + tid] = sc2;
+            tab[384 + tid] = T.param[T.L.bn_b[l - 1] + tid] - mean2 * sc2;
+            tab[448 + tid] = mean2;
+            tab[512 + tid] = rstd2;
+        }
+    }
+    __syncthreads();
+    const float *wfrag = (MODE == FWD ? T.wf : T.wb) + (size_t)l * 4 * 9 * 4 * 64 * 4;
+    const f32x4 *wl = reinterpret_cast<const f32x4 *>(wfrag) + (size_t)wave * 9 * 4 * 64 + lane;
+    const size_t bstride = (size_t)P * C;
+    float s_sum[4] = {0.f, 0.f, 0.f, 0.f}, s_sq[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int b = blockIdx.x; b < T.B; b += gridDim.x) {
+        // ---- stage the board: LDS act[row][c].  All global loads of a thread first, then the arithmetic: the board
+        //      is 1296 float4 = 5.06 per thread, and a load-use-store loop would pay the memory latency five times ----
+        constexpr int NV = (P * C / 4 + NT - 1) / NT;          // float4 per thread
+        if (MODE == FWD && l == 0) {
+            for (int e = tid; e < P * C; e += NT) {
+                const int row = e >> 6, c = e & 63;
+                act[row * kRow + c] = c < 6 ? planes[((size_t)b * 6 + c) * P + row] : 0.f;
+            }
+        } else {
+            const bool fwd = MODE == FWD;
+            const bool conv1 = (l & 1) != 0;
+            // FWD: z = Z_{l-1}; conv1 also adds the previous block output and materialises Y.  DGRAD: d = D_l, z = Z_l.
+            const float *zsrc = T.Z + ((size_t)(fwd ? l - 1 : l) * T.B + b) * bstride;
+            const int yb = (l - 1) / 2;
+            const float *second = fwd ? (conv1 && yb >= 1 ? T.Y + ((size_t)(yb - 1) * T.B + b) * bstride : nullptr)
+                                      : T.D + ((size_t)l * T.B + b) * bstride;
+            float *yout = fwd && conv1 ? T.Y + ((size_t)yb * T.B + b) * bstride : nullptr;
+            f32x4 zv[NV], sv[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int e = tid + i * NT;
+                if (e < P * C / 4) {
+                    zv[i] = *reinterpret_cast<const f32x4 *>(zsrc + e * 4);
+                    if (second) sv[i] = *reinterpret_cast<const f32x4 *>(second + e * 4);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int e = tid + i * NT;
+                if (e < P * C / 4) {
+                    const int row = e >> 4, c = (e & 15) * 4;
+                    f32x4 v;
+                    if (fwd) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = fmaf(zv[i][j], tab[c + j], tab[64 + c + j]);
+                        if (second) v += sv[i];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                        if (yout) *reinterpret_cast<f32x4 *>(yout + e * 4) = v;
+                    } else {
+                        // dZ_l = gamma*rstd * (D - m1 - xhat * m2), xhat = (Z - mean) * rstd
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float xh = (zv[i][j] - tab[64 + c + j]) * tab[128 + c + j];
+                            v[j] = tab[c + j] * (sv[i][j] - tab[192 + c + j] - xh * tab[256 + c + j]);
+                        }
+                    }
+                    *reinterpret_cast<f32x4 *>(act + row * kRow + c) = v;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- implicit GEMM: acc[mt] (16 couts x 16 rows) over 9 taps x 16 k-groups of 4 channels ----
+        f32x4 acc[HMT];
+#pragma unroll
+        for (int mt = 0; mt < HMT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // DGRAD: the epilogue's operands (Z, Y of the layer below, the skip gradient) are requested now, behind the loop
+        const bool ep_conv1 = MODE == DGRAD && (l & 1) != 0;   // input of conv1 = block output Y_{(l-1)/2}; the skip carries D_{l+1}
+        f32x4 ep_z[HMT], ep_y[HMT], ep_s[HMT];
+        if (MODE == DGRAD) {
+            const float *zb = T.Z + ((size_t)(l - 1) * T.B + b) * bstride;
+            const float *yb2 = T.Y + ((size_t)((l - 1) / 2) * T.B + b) * bstride;
+            const float *dskip = T.D + ((size_t)(l + 1 < kLayers ? l + 1 : l) * T.B + b) * bstride;
+            const int cc = wave * 16 + lg * 4;
+#pragma unroll
+            for (int mt = 0; mt < HMT; ++mt) {
+                const int row = (half * HMT + mt) * 16 + li, r2 = row < P ? row : 0;
+                ep_z[mt] = *reinterpret_cast<const f32x4 *>(zb + r2 * C + cc);
+                if (ep_conv1) {
+                    ep_y[mt] = *reinterpret_cast<const f32x4 *>(yb2 + r2 * C + cc);
+                    ep_s[mt] = *reinterpret_cast<const f32x4 *>(dskip + r2 * C + cc);
+                }
+            }
+        }
+        // per row tile: base pointer of the lane's row (channel sub-group lg), per tap: shifted or the zero row
+        const float *rowp[HMT];
+#pragma unroll
+        for (int mt = 0; mt < HMT; ++mt) rowp[mt] = act + ((half * HMT + mt) * 16 + li) * kRow + lg * 4;
+        const float *zp = zrow + lg * 4;
+        f32x4 wq[3], av[2][HMT];
+        wq[0] = wl[0];
+        wq[1] = wl[64];
+#pragma unroll
+        for (int mt = 0; mt < HMT; ++mt)
+            av[0][mt] = lds4((((mask[mt] >> 0) & 1u) ? rowp[mt] + (-S - 1) * kRow : zp));
+        static_for<36>([&](auto ST_) {
+            constexpr int st = decltype(ST_)::value, nx = st + 1, tapn = nx / 4, sn = nx % 4;
+            constexpr int toffn = ((tapn / 3 - 1) * S + (tapn % 3 - 1)) * kRow;
+            wq[(st + 2) % 3] = wl[(st + 2 < 36 ? st + 2 : 35) * 64];
+            if constexpr (nx < 36) {
+#pragma unroll
+                for (int mt = 0; mt < HMT; ++mt)
+                    av[nx & 1][mt] = lds4((((mask[mt] >> tapn) & 1u) ? rowp[mt] + toffn : zp) + sn * 16);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mt = 0; mt < HMT; ++mt)
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[st % 3][j], av[st & 1][mt][j], acc[mt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        // ---- epilogue ----
+        const int c0 = wave * 16 + lg * 4;
+        if (MODE == FWD) {
+            float *z = T.Z + ((size_t)l * T.B + b) * bstride;
+#pragma unroll
+            for (int mt = 0; mt < HMT; ++mt) {
+                const int row = (half * HMT + mt) * 16 + li;
+                if (row < P) {
+                    *reinterpret_cast<f32x4 *>(z + row * C + c0) = acc[mt];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { s_sum[j] += acc[mt][j]; s_sq[j] = fmaf(acc[mt][j], acc[mt][j], s_sq[j]); }
+                }
+            }
+        } else {
+            // D_{l-1} = (dA + skip) * [A_{l-1} > 0]; sums S1 = sum D, S2 = sum D * xhat_{l-1}
+            float *dout = T.D + ((size_t)(l - 1) * T.B + b) * bstride;
+#pragma unroll
+            for (int mt = 0; mt < HMT; ++mt) {
+                const int row = (half * HMT + mt) * 16 + li;
+                if (row < P) {
+                    f32x4 g = acc[mt];
+                    if (ep_conv1) g += ep_s[mt];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float pre = ep_conv1 ? ep_y[mt][j] : fmaf(ep_z[mt][j], tab[320 + c0 + j], tab[384 + c0 + j]);
+                        g[j] = pre > 0.f ? g[j] : 0.f;
+                        const float xh = (ep_z[mt][j] - tab[448 + c0 + j]) * tab[512 + c0 + j];
+                        s_sum[j] += g[j];
+                        s_sq[j] = fmaf(g[j], xh, s_sq[j]);
+                    }
+                    *reinterpret_cast<f32x4 *>(dout + row * C + c0) = g;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // per-channel sums: reduce over the 16 lanes that share lg, one atomic per channel and workgroup-wave
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { s_sum[j] += __shfl_xor(s_sum[j], o); s_sq[j] += __shfl_xor(s_sq[j], o); }
+    }
+    if (li == 0) {
+        const int sl = MODE == FWD ? l : l - 1;
+        const int base = (sl * kRep + (int)(blockIdx.x % kRep)) * 256 + (MODE == FWD ? 0 : 128) + wave * 16 + lg * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            atomicAdd(&T.stat[base + j], (double)s_sum[j]);
+            atomicAdd(&T.stat[base + 64 + j], (double)s_sq[j]);
+        }
+    }
+}
+
+// ---- weight gradient: partial[wg][tap][co][ci] = sum over the workgroup's boards and rows of dZ[row][co] * A[row+tap][ci] ----
+__global__ __launch_bounds__(512) void wgrad_kernel(TrainDev T, const float *__restrict__ planes, int l) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *act = smem;                         // A_{l-1}: [81][72] + zero row
+    float *zrow = smem + P * kRow;
+    float *dzt = zrow + kRow;                  // dZ_l: [84 rows][72]
+    float *tab = dzt + 84 * kRow;
+    // 8 waves: wave (w, half) owns output channels [16w, 16w+16) for taps {0..4} (half 0) / {5..8} (half 1)
+    constexpr int NT = 512;
+    const int tid = threadIdx.x, wave = (tid >> 6) & 3, half = tid >> 8, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+    const int tap0 = half ? 5 : 0, ntap = half ? 4 : 5;
+    const float eps_l = 2e-5f;
+    for (int e = tid; e < kRow; e += NT) zrow[e] = 0.f;
+    for (int e = tid; e < 3 * kRow; e += NT) dzt[P * kRow + e] = 0.f;     // rows 81..83: zero
+    if (tid < 64) {
+        float mean, rstd;
+        bn_consts(T, l, tid, l == 0 ? 1e-5f : eps_l, mean, rstd);
+        const double n = (double)(T.B * P);
+        tab[tid] = T.param[T.L.bn_w[l] + tid] * rstd;
+        tab[64 + tid] = mean;
+        tab[128 + tid] = rstd;
+        tab[192 + tid] = (float)(stat_sum(T.stat + (size_t)l * kRep * 256 + 128 + tid, 256) / n);
+        tab[256 + tid] = (float)(stat_sum(T.stat + (size_t)l * kRep * 256 + 192 + tid, 256) / n);
+        if (l >= 1 && (l & 1) == 0) {          // conv2: its input h = relu(bn(Z_{l-1})) is rebuilt
+            float mean2, rstd2;
+            bn_consts(T, l - 1, tid, eps_l, mean2, rstd2);
+            const float sc2 = T.param[T.L.bn_w[l - 1] + tid] * rstd2;
+            tab[320 + tid] = sc2;
+            tab[384 + tid] = T.param[T.L.bn_b[l - 1] + tid] - mean2 * sc2;
+        }
+    }
+    __syncthreads();
+    const size_t bstride = (size_t)P * C;
+    f32x4 acc[20];                              // [tap - tap0][ci tile]
+#pragma unroll
+    for (int i = 0; i < 20; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = blockIdx.x; b < T.B; b += gridDim.x) {
+        const float *d = T.D + ((size_t)l * T.B + b) * bstride;
+        const float *z = T.Z + ((size_t)l * T.B + b) * bstride;
+        for (int e = tid; e < P * C / 4; e += NT) {
+            const int row = e >> 4, c = (e & 15) * 4;
+            const f32x4 dv = *reinterpret_cast<const f32x4 *>(d + row * C + c);
+            const f32x4 zv = *reinterpret_cast<const f32x4 *>(z + row * C + c);
+            f32x4 v, a;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xh = (zv[j] - tab[64 + c + j]) * tab[128 + c + j];
+                v[j] = tab[c + j] * (dv[j] - tab[192 + c + j] - xh * tab[256 + c + j]);
+            }
+            *reinterpret_cast<f32x4 *>(dzt + row * kRow + c) = v;
+            if (l == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[j] = c + j < 6 ? planes[((size_t)b * 6 + c + j) * P + row] : 0.f;
+            } else if (l & 1) {
+                a = *reinterpret_cast<const f32x4 *>(T.Y + ((size_t)((l - 1) / 2) * T.B + b) * bstride + row * C + c);
+            } else {
+                const f32x4 zp = *reinterpret_cast<const f32x4 *>(T.Z + ((size_t)(l - 1) * T.B + b) * bstride + row * C + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[j] = fmaxf(fmaf(zp[j], tab[320 + c + j], tab[384 + c + j]), 0.f);
+            }
+            *reinterpret_cast<f32x4 *>(act + row * kRow + c) = a;
+        }
+        __syncthreads();
+        // D[co][ci] += sum_k dZ^T[co][k = row] * A[row + tap][ci]: MFMA A operand = dZ^T (lane: co = li, k = lg),
+        // B operand = shifted activations (lane: ci = li, k = lg)
+#pragma unroll 1
+        for (int ks = 0; ks < 21; ++ks) {
+            const int row = ks * 4 + lg;
+            const float dzv = dzt[row * kRow + wave * 16 + li];
+            const int y = row / S, x = row - y * S;
+#pragma unroll
+            for (int tt = 0; tt < 5; ++tt) {
+                const int tap = tap0 + tt;
+                const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+                const bool ok = tt < ntap && row < P && (unsigned)(y + dy) < (unsigned)S && (unsigned)(x + dx) < (unsigned)S;
+                const float *ap = ok ? act + (row + dy * S + dx) * kRow + li : zrow + li;
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+                    acc[tt * 4 + ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(dzv, ap[ct * 16], acc[tt * 4 + ct], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // partial image: [wg][tap][co][ci]; lane holds co = 16 wave + 4 lg + j, ci = 16 ct + li
+    float *out = T.partial + ((size_t)l * T.NWG + blockIdx.x) * 9 * 64 * 64;
+#pragma unroll
+    for (int tt = 0; tt < 5; ++tt)
+        if (tt < ntap)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    out[((tap0 + tt) * 64 + wave * 16 + lg * 4 + j) * 64 + ct * 16 + li] = acc[tt * 4 + ct][j];
+}
+
+// ---- weight fragments from the master weights (they change every step) ---------------------------------
+__global__ void repack_kernel(TrainDev T) {
+    const int l = blockIdx.y;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;          // fragment element index
+    if (e >= 4 * 9 * 4 * 64 * 4) return;
+    const int j = e & 3, lane = (e >> 2) & 63, s = (e >> 8) & 3, tap = (e >> 10) % 9, wv = e / (9 * 1024);
+    const int n = lane & 15, g = lane >> 4;
+    const int k = 16 * s + 4 * g + j, o = 16 * wv + n;             // k: reduction channel, o: output channel of the pass
+    float f, bwd = 0.f;
+    if (l == 0) {
+        f = k < 6 ? T.param[T.L.conv[0] + (o * 6 + k) * 9 + tap] : 0.f;
+    } else {
+        const float *w = T.param + T.L.conv[l];
+        f = w[(o * 64 + k) * 9 + tap];                             // forward: out = cout, k = cin
+        bwd = w[(k * 64 + o) * 9 + (8 - tap)];                     // data gradient: out = cin, k = cout, taps mirrored
+    }
+    T.wf[(size_t)l * 36864 + e] = f;
+    T.wb[(size_t)l * 36864 + e] = bwd;
+}
+
+// ---- heads -----------------------------------------------------------------------------------------------
+// 1. per board: Y_6 = relu(Y_5 + bn(Z_12)) (materialised), head 1x1 convolutions -> hz[b][p][3], statistics
+__global__ __launch_bounds__(128) void head_conv_kernel(TrainDev T) {
+    __shared__ float tab[128];
+    __shared__ float red[6];
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        float mean, rstd;
+        bn_consts(T, 12, tid, 2e-5f, mean, rstd);
+        const float sc = T.param[T.L.bn_w[12] + tid] * rstd;
+        tab[tid] = sc;
+        tab[64 + tid] = T.param[T.L.bn_b[12] + tid] - mean * sc;
+    }
+    if (tid < 6) red[tid] = 0.f;
+    __syncthreads();
+    const size_t bstride = (size_t)P * C;
+    float s[3] = {0.f, 0.f, 0.f}, q[3] = {0.f, 0.f, 0.f};
+    for (int b = blockIdx.x; b < T.B; b += gridDim.x) {
+        const float *z = T.Z + ((size_t)12 * T.B + b) * bstride;
+        const float *yp = T.Y + ((size_t)5 * T.B + b) * bstride;
+        float *yo = T.Y + ((size_t)6 * T.B + b) * bstride;
+        for (int row = tid; row < P; row += 128) {
+            float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+            for (int c = 0; c < C; c += 4) {
+                const f32x4 zv = *reinterpret_cast<const f32x4 *>(z + row * C + c);
+                f32x4 v = *reinterpret_cast<const f32x4 *>(yp + row * C + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[j] = fmaxf(v[j] + fmaf(zv[j], tab[c + j], tab[64 + c + j]), 0.f);
+                    d0 = fmaf(v[j], T.param[T.L.p_conv + c + j], d0);
+                    d1 = fmaf(v[j], T.param[T.L.p_conv + 64 + c + j], d1);
+                    d2 = fmaf(v[j], T.param[T.L.v_conv + c + j], d2);
+                }
+                *reinterpret_cast<f32x4 *>(yo + row * C + c) = v;
+            }
+            *reinterpret_cast<f32x4 *>(T.hz + ((size_t)b * P + row) * 4) = f32x4{d0, d1, d2, 0.f};
+            s[0] += d0; s[1] += d1; s[2] += d2;
+            q[0] = fmaf(d0, d0, q[0]); q[1] = fmaf(d1, d1, q[1]); q[2] = fmaf(d2, d2, q[2]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { atomicAdd(&red[k], s[k]); atomicAdd(&red[3 + k], q[k]); }
+    __syncthreads();
+    double *hs = T.hstat + (blockIdx.x % kRep) * 16;
+    if (tid < 3) { atomicAdd(&hs[tid], (double)red[tid]); atomicAdd(&hs[4 + tid], (double)red[3 + tid]); }
+}
+
+// 2. per board: batch norm + ReLU of the head convolutions, both FC layers, losses, dL/dlogits, gradient back to the
+//    head activations (hD = dL/d(bn output), ReLU mask applied) and its batch-norm-backward sums
+__global__ __launch_bounds__(256) void head_loss_kernel(TrainDev T, const float *__restrict__ target_policy,
+                                                         const long long *__restrict__ target_value, int sl_mode,
+                                                         float value_weight) {
+    __shared__ float h[3 * P];            // [162 policy | 81 value]
+    __shared__ float logit[A + 3], dl[A + 3];
+    __shared__ float hc[12];              // head bn: scale[3], shift[3], mean[3], rstd[3]
+    __shared__ float red[8];
+    const int tid = threadIdx.x;
+    if (tid < 3) {
+        const double n = (double)(T.B * P);
+        const double dmean = stat_sum(T.hstat + tid, 16) / n;
+        const float mean = (float)dmean;
+        const float rstd = (float)(1.0 / sqrt(fmax(stat_sum(T.hstat + 4 + tid, 16) / n - dmean * dmean, 0.0) + 2e-5));
+        const float gamma = tid < 2 ? T.param[T.L.p_bn_w + tid] : T.param[T.L.v_bn_w];
+        const float beta = tid < 2 ? T.param[T.L.p_bn_b + tid] : T.param[T.L.v_bn_b];
+        hc[tid] = gamma * rstd;
+        hc[3 + tid] = beta - mean * gamma * rstd;
+        hc[6 + tid] = mean;
+        hc[9 + tid] = rstd;
+    }
+    if (tid < 8) red[tid] = 0.f;
+    __syncthreads();
+    float lp = 0.f, lv = 0.f, s1[3] = {0.f, 0.f, 0.f}, s2[3] = {0.f, 0.f, 0.f};
+    for (int b = blockIdx.x; b < T.B; b += gridDim.x) {
+        for (int e = tid; e < 3 * P; e += 256) {
+            const int k = e / P, p = e - k * P;
+            const float v = fmaxf(fmaf(T.hz[((size_t)b * P + p) * 4 + k], hc[k], hc[3 + k]), 0.f);
+            h[e] = v;
+            T.hact[(size_t)b * 3 * P + e] = v;
+        }
+        __syncthreads();
+        if (tid < A) {
+            const float *w = T.param + T.L.p_fc_w + (size_t)tid * 2 * P;
+            float acc = T.param[T.L.p_fc_b + tid];
+            for (int j = 0; j < 2 * P; ++j) acc = fmaf(h[j], w[j], acc);
+            logit[tid] = acc;
+        } else if (tid < A + 3) {
+            const float *w = T.param + T.L.v_fc_w + (size_t)(tid - A) * P;
+            float acc = T.param[T.L.v_fc_b + tid - A];
+            for (int j = 0; j < P; ++j) acc = fmaf(h[2 * P + j], w[j], acc);
+            logit[tid] = acc;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            // policy: log-softmax, loss, dL/dlogit
+            float m = -INFINITY;
+            for (int a = 0; a < A; ++a) m = fmaxf(m, logit[a]);
+            float se = 0.f;
+            for (int a = 0; a < A; ++a) se += expf(logit[a] - m);
+            const float lse = m + logf(se);
+            const float *tp = target_policy + (size_t)b * A;
+            const float invb = 1.f / (float)T.B;
+            float loss = 0.f;
+            if (!sl_mode) {
+                // kl_div(logp, t, batchmean): sum t * (log t - logp) / B (0 where t == 0); gradient (p * sum t - t) / B
+                float st = 0.f;
+                for (int a = 0; a < A; ++a) st += tp[a];
+                for (int a = 0; a < A; ++a) {
+                    const float logp = logit[a] - lse, t = tp[a];
+                    if (t > 0.f) loss += t * (logf(t) - logp);
+                    dl[a] = (expf(logp) * st - t) * invb;
+                }
+            } else {
+                // -sum t * log(softmax + 1e-8) per sample, mean over the batch
+                float dot = 0.f;
+                for (int a = 0; a < A; ++a) {
+                    const float p = expf(logit[a] - lse), t = tp[a];
+                    loss -= t * logf(p + 1e-8f);
+                    dot += t * p / (p + 1e-8f);
+                }
+                for (int a = 0; a < A; ++a) {
+                    const float p = expf(logit[a] - lse), t = tp[a];
+                    dl[a] = (p * dot - t * p / (p + 1e-8f)) * invb;
+                }
+            }
+            lp += loss;
+            // value: cross entropy against the class
+            float vm = fmaxf(logit[A], fmaxf(logit[A + 1], logit[A + 2]));
+            float ve = expf(logit[A] - vm) + expf(logit[A + 1] - vm) + expf(logit[A + 2] - vm);
+            const float vlse = vm + logf(ve);
+            const int cls = (int)target_value[b];
+            lv += vlse - logit[A + cls];
+            for (int k = 0; k < 3; ++k)
+                dl[A + k] = value_weight * (expf(logit[A + k] - vlse) - (k == cls ? 1.f : 0.f)) * invb;
+        }
+        __syncthreads();
+        if (tid < A + 3) T.dlog[(size_t)b * (A + 3) + tid] = dl[tid];
+        // back through the FC layers to the head activations, ReLU mask, D + sums
+        for (int e = tid; e < 3 * P; e += 256) {
+            const int k = e / P, p = e - k * P;
+            float g = 0.f;
+            if (k < 2) {
+                for (int a = 0; a < A; ++a) g = fmaf(dl[a], T.param[T.L.p_fc_w + (size_t)a * 2 * P + e], g);
+            } else {
+                for (int c = 0; c < 3; ++c) g = fmaf(dl[A + c], T.param[T.L.v_fc_w + (size_t)c * P + p], g);
+            }
+            g = h[e] > 0.f ? g : 0.f;
+            T.hD[((size_t)b * P + p) * 4 + k] = g;
+            const float xh = (T.hz[((size_t)b * P + p) * 4 + k] - hc[6 + k]) * hc[9 + k];
+            s1[k] += g;
+            s2[k] = fmaf(g, xh, s2[k]);
+        }
+        __syncthreads();
+    }
+    // every thread contributes to every k (its elements may span channels)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { atomicAdd(&red[k], s1[k]); atomicAdd(&red[3 + k], s2[k]); }
+    __syncthreads();
+    double *hs = T.hstat + (blockIdx.x % kRep) * 16;
+    if (tid < 3) { atomicAdd(&hs[8 + tid], (double)red[tid]); atomicAdd(&hs[12 + tid], (double)red[3 + tid]); }
+    if (tid == 0) {
+        const double pol = (double)lp / T.B, val = (double)lv / T.B;      // this workgroup's share of the batch means
+        double *ls = T.loss + (blockIdx.x % kRep) * 4;
+        atomicAdd(&ls[1], pol);
+        atomicAdd(&ls[2], val);
+        atomicAdd(&ls[0], pol + (double)value_weight * val);
+    }
+}
+
+// 3. FC weight / bias gradients: dW[a][j] = sum_b dlog[b][a] * hact[b][j] (policy: j < 162; value rows a >= A: the last
+//    81 of hact).  One workgroup per output a, thread j: hact reads coalesced over j, dlog[b][a] a broadcast.
+__global__ __launch_bounds__(192) void head_fc_grad_kernel(TrainDev T) {
+    const int a = blockIdx.x, j = threadIdx.x;
+    const bool pol = a < A;
+    const int nj = pol ? 2 * P : P;
+    float g = 0.f, gb = 0.f;
+    if (j < nj) {
+        const float *h = T.hact + (pol ? j : 2 * P + j);
+        const float *d = T.dlog + a;
+#pragma unroll 4
+        for (int b = 0; b < T.B; ++b) {
+            const float dv = d[(size_t)b * (A + 3)];
+            g = fmaf(dv, h[(size_t)b * 3 * P], g);
+            gb += dv;
+        }
+        T.grad[(pol ? T.L.p_fc_w + (size_t)a * 2 * P : T.L.v_fc_w + (size_t)(a - A) * P) + j] = g;
+        if (j == 0) T.grad[pol ? T.L.p_fc_b + a : T.L.v_fc_b + a - A] = gb;
+    }
+}
+
+// 4. per board: batch-norm backward of the head convolutions, their weight gradients, gradient into Y_6,
+//    ReLU mask -> D_12 and its sums.  Thread (row group g, channel c): coalesced over c, sums in registers.
+__global__ __launch_bounds__(256) void head_back_kernel(TrainDev T) {
+    __shared__ float hc[15];              // gamma*rstd[3], mean[3], rstd[3], m1[3], m2[3]
+    __shared__ float dzs[P * 4];          // dZ of the three head channels, per row
+    __shared__ float red[4][5][64];       // per row group: S1, S2, three weight-gradient rows
+    const int tid = threadIdx.x, c = tid & 63, g = tid >> 6;
+    if (tid < 3) {
+        const double n = (double)(T.B * P);
+        const double dmean = stat_sum(T.hstat + tid, 16) / n;
+        const float mean = (float)dmean;
+        const float rstd = (float)(1.0 / sqrt(fmax(stat_sum(T.hstat + 4 + tid, 16) / n - dmean * dmean, 0.0) + 2e-5));
+        const float gamma = tid < 2 ? T.param[T.L.p_bn_w + tid] : T.param[T.L.v_bn_w];
+        hc[tid] = gamma * rstd;
+        hc[3 + tid] = mean;
+        hc[6 + tid] = rstd;
+        hc[9 + tid] = (float)(stat_sum(T.hstat + 8 + tid, 16) / n);
+        hc[12 + tid] = (float)(stat_sum(T.hstat + 12 + tid, 16) / n);
+    }
+    float mean12, rstd12;
+    bn_consts(T, 12, c, 2e-5f, mean12, rstd12);
+    const float w0 = T.param[T.L.p_conv + c], w1 = T.param[T.L.p_conv + 64 + c], w2 = T.param[T.L.v_conv + c];
+    __syncthreads();
+    const size_t bstride = (size_t)P * C;
+    float s1 = 0.f, s2 = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    for (int b = blockIdx.x; b < T.B; b += gridDim.x) {
+        for (int e = tid; e < P * 3; e += 256) {
+            const int row = e / 3, k = e - row * 3;
+            const float z = T.hz[((size_t)b * P + row) * 4 + k], d = T.hD[((size_t)b * P + row) * 4 + k];
+            const float xh = (z - hc[3 + k]) * hc[6 + k];
+            dzs[row * 4 + k] = hc[k] * (d - hc[9 + k] - xh * hc[12 + k]);
+        }
+        __syncthreads();
+        const float *y6 = T.Y + ((size_t)6 * T.B + b) * bstride;
+        const float *z12 = T.Z + ((size_t)12 * T.B + b) * bstride;
+        float *d12 = T.D + ((size_t)12 * T.B + b) * bstride;
+        for (int row = g; row < P; row += 4) {
+            const float yv = y6[row * C + c], zv = z12[row * C + c];
+            const float d0 = dzs[row * 4], d1 = dzs[row * 4 + 1], d2 = dzs[row * 4 + 2];
+            float v = d0 * w0 + d1 * w1 + d2 * w2;
+            v = yv > 0.f ? v : 0.f;
+            d12[row * C + c] = v;
+            s1 += v;
+            s2 = fmaf(v, (zv - mean12) * rstd12, s2);
+            g0 = fmaf(d0, yv, g0);
+            g1 = fmaf(d1, yv, g1);
+            g2 = fmaf(d2, yv, g2);
+        }
+        __syncthreads();
+    }
+    red[g][0][c] = s1; red[g][1][c] = s2; red[g][2][c] = g0; red[g][3][c] = g1; red[g][4][c] = g2;
+    __syncthreads();
+    if (tid < 64) {
+        float r[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) r[q] = (red[0][q][c] + red[1][q][c]) + (red[2][q][c] + red[3][q][c]);
+        double *st12 = T.stat + ((size_t)12 * kRep + blockIdx.x % kRep) * 256;
+        atomicAdd(&st12[128 + c], (double)r[0]);
+        atomicAdd(&st12[192 + c], (double)r[1]);
+        atomicAdd(&T.grad[T.L.p_conv + c], r[2]);
+        atomicAdd(&T.grad[T.L.p_conv + 64 + c], r[3]);
+        atomicAdd(&T.grad[T.L.v_conv + c], r[4]);
+    }
+}
+
+// ---- optimiser: torch.optim.SGD(momentum, weight_decay, nesterov) over every parameter, running statistics ------
+struct SgdArgs { float lr, momentum, weight_decay; int first_step; };
+
+__global__ void sgd_kernel(TrainDev T, SgdArgs a) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T.L.total) return;
+    const Layout &L = T.L;
+    // which tensor is element i in?
+    float g;
+    bool is_stat = false;
+    int l = -1, kind = -1;       // kind 0 conv weight, 1 bn weight, 2 bn bias, 3 running mean, 4 running var
+    for (int k = 0; k < kLayers; ++k) {
+        const size_t wn = k == 0 ? 64 * 6 * 9 : kConvW;
+        if (i >= L.conv[k] && i < L.conv[k] + wn) { l = k; kind = 0; break; }
+        if (i >= L.bn_w[k] && i < L.bn_w[k] + 64) { l = k; kind = 1; break; }
+        if (i >= L.bn_b[k] && i < L.bn_b[k] + 64) { l = k; kind = 2; break; }
+        if (i >= L.bn_m[k] && i < L.bn_m[k] + 64) { l = k; kind = 3; break; }
+        if (i >= L.bn_v[k] && i < L.bn_v[k] + 64) { l = k; kind = 4; break; }
+    }
+    const double n = (double)(T.B * P);
+    if (kind == 0) {
+        return;                                                       // convolution weights: sgd_conv_kernel
+    } else if (kind == 1) {
+        g = (float)stat_sum(T.stat + (size_t)l * kRep * 256 + 192 + (i - L.bn_w[l]), 256);   // d gamma = S2
+    } else if (kind == 2) {
+        g = (float)stat_sum(T.stat + (size_t)l * kRep * 256 + 128 + (i - L.bn_b[l]), 256);   // d beta = S1
+    } else if (kind == 3 || kind == 4) {
+        const int c = (int)(i - (kind == 3 ? L.bn_m[l] : L.bn_v[l]));
+        const float m = l == 0 ? 0.1f : 0.01f;
+        const double mean = stat_sum(T.stat + (size_t)l * kRep * 256 + c, 256) / n;
+        const double var = fmax(stat_sum(T.stat + (size_t)l * kRep * 256 + 64 + c, 256) / n - mean * mean, 0.0);
+        T.param[i] = kind == 3 ? (1.f - m) * T.param[i] + m * (float)mean
+                               : (1.f - m) * T.param[i] + m * (float)(var * (n / (n - 1.0)));
+        is_stat = true;
+        g = 0.f;
+    } else {
+        // heads
+        auto in = [&](size_t off, size_t cnt) { return i >= off && i < off + cnt; };
+        if (in(L.p_bn_w, 2)) g = (float)stat_sum(T.hstat + 12 + (i - L.p_bn_w), 16);
+        else if (in(L.p_bn_b, 2)) g = (float)stat_sum(T.hstat + 8 + (i - L.p_bn_b), 16);
+        else if (in(L.v_bn_w, 1)) g = (float)stat_sum(T.hstat + 12 + 2, 16);
+        else if (in(L.v_bn_b, 1)) g = (float)stat_sum(T.hstat + 8 + 2, 16);
+        else if (in(L.p_bn_m, 2) || in(L.p_bn_v, 2) || in(L.v_bn_m, 1) || in(L.v_bn_v, 1)) {
+            const bool is_mean = in(L.p_bn_m, 2) || in(L.v_bn_m, 1);
+            const int k = in(L.p_bn_m, 2) ? (int)(i - L.p_bn_m) : in(L.p_bn_v, 2) ? (int)(i - L.p_bn_v) : 2;
+            const double mean = stat_sum(T.hstat + k, 16) / n;
+            const double var = fmax(stat_sum(T.hstat + 4 + k, 16) / n - mean * mean, 0.0);
+            T.param[i] = is_mean ? 0.99f * T.param[i] + 0.01f * (float)mean
+                                 : 0.99f * T.param[i] + 0.01f * (float)(var * (n / (n - 1.0)));
+            is_stat = true;
+            g = 0.f;
+        } else {
+            g = T.grad[i];                                             // FC layers, head convolutions
+        }
+    }
+    if (is_stat) return;
+    const float p = T.param[i];
+    g = fmaf(a.weight_decay, p, g);
+    float buf = a.first_step ? g : fmaf(a.momentum, T.mom[i], g);
+    T.mom[i] = buf;
+    T.param[i] = p - a.lr * fmaf(a.momentum, buf, g);
+}
+
+// convolution weights: thread e walks the partial images [wg][tap][co][ci] in their own order (coalesced), sums
+// them over the workgroups and updates the parameter it belongs to
+__global__ void sgd_conv_kernel(TrainDev T, SgdArgs a) {
+    const int l = blockIdx.y;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 36864) return;
+    const int ci = e & 63, co = (e >> 6) & 63, tap = e >> 12;
+    if (l == 0 && ci >= 6) return;
+    const float *p = T.partial + (size_t)l * T.NWG * 36864 + e;
+    float g = 0.f;
+    for (int w = 0; w < T.NWG; ++w) g += p[(size_t)w * 36864];
+    const size_t i = T.L.conv[l] + (l == 0 ? (size_t)(co * 6 + ci) * 9 + tap : (size_t)(co * 64 + ci) * 9 + tap);
+    const float w0 = T.param[i];
+    g = fmaf(a.weight_decay, w0, g);
+    const float buf = a.first_step ? g : fmaf(a.momentum, T.mom[i], g);
+    T.mom[i] = buf;
+    T.param[i] = w0 - a.lr * fmaf(a.momentum, buf, g);
+}
+
+}  // namespace
+
+struct tg_trainer {
+    int device = 0, batch = 0;
+    TrainDev dev{};
+    std::vector<void *> allocs;
+    bool first_step = true;
+};
+
+namespace {
+template <typename T>
+int talloc(tg_trainer *t, T **out, size_t count) {
+    void *p = nullptr;
+    TG_HIP(hipMalloc(&p, count * sizeof(T)));
+    TG_HIP(hipMemset(p, 0, count * sizeof(T)));
+    t->allocs.push_back(p);
+    *out = static_cast<T *>(p);
+    return TG_OK;
+}
+constexpr int kConvLds = (P * kRow + kRow + 9 * 64) * 4;
+constexpr int kWgradLds = (P * kRow + kRow + 84 * kRow + 7 * 64) * 4;
+}  // namespace
+
+extern "C" {
+
+int tg_trainer_create(int board_size, int device, int batch, const float *params_host, size_t n_params, tg_trainer **out) {
+    if (!params_host || !out) return tg::fail(TG_ERR_ARG, "tg_trainer_create: null argument");
+    if (board_size != 9) return tg::fail(TG_ERR_ARG, "tg_trainer_create: the HIP training step is built for 9x9");
+    if (batch < 2) return tg::fail(TG_ERR_ARG, "tg_trainer_create: batch must be >= 2 (batch statistics)");
+    const Layout L = make_layout();
+    if (n_params != L.total) return tg::fail(TG_ERR_ARG, "tg_trainer_create: expected %zu parameters, got %zu", L.total, n_params);
+    TG_HIP(hipSetDevice(device));
+    tg_trainer *t = new tg_trainer;
+    t->device = device;
+    t->batch = batch;
+    TrainDev &D = t->dev;
+    D.L = L;
+    D.B = batch;
+    D.NWG = batch < 256 ? batch : 256;
+    const size_t act = (size_t)batch * P * C;
+    int rc = TG_OK;
+    if ((rc = talloc(t, &D.param, L.total)) || (rc = talloc(t, &D.grad, L.total)) || (rc = talloc(t, &D.mom, L.total)) ||
+        (rc = talloc(t, &D.wf, (size_t)kLayers * 36864)) || (rc = talloc(t, &D.wb, (size_t)kLayers * 36864)) ||
+        (rc = talloc(t, &D.Z, kLayers * act)) || (rc = talloc(t, &D.Y, 7 * act)) || (rc = talloc(t, &D.D, kLayers * act)) ||
+        (rc = talloc(t, &D.stat, (size_t)kLayers * kRep * 256)) || (rc = talloc(t, &D.partial, (size_t)kLayers * D.NWG * 36864)) ||
+        (rc = talloc(t, &D.hz, (size_t)batch * P * 4)) || (rc = talloc(t, &D.hD, (size_t)batch * P * 4)) ||
+        (rc = talloc(t, &D.hstat, (size_t)kRep * 16)) || (rc = talloc(t, &D.hact, (size_t)batch * 3 * P)) ||
+        (rc = talloc(t, &D.dlog, (size_t)batch * (A + 3))) || (rc = talloc(t, &D.loss, (size_t)kRep * 4))) {
+        for (void *p : t->allocs) (void)hipFree(p);
+        delete t;
+        return rc;
+    }
+    TG_HIP(hipMemcpy(D.param, params_host, L.total * sizeof(float), hipMemcpyHostToDevice));
+    TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_kernel<FWD>), hipFuncAttributeMaxDynamicSharedMemorySize, kConvLds));
+    TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_kernel<DGRAD>), hipFuncAttributeMaxDynamicSharedMemorySize, kConvLds));
+    TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kWgradLds));
+    *out = t;
+    return TG_OK;
+}
+
+int tg_trainer_destroy(tg_trainer *t) {
+    if (!t) return TG_OK;
+    (void)hipSetDevice(t->device);
+    for (void *p : t->allocs) (void)hipFree(p);
+    delete t;
+    return TG_OK;
+}
+
+int tg_trainer_step(tg_trainer *t, const float *planes_dev, const float *policy_dev, const long long *value_dev,
+                    int sl_mode, float value_weight, float lr, void *stream) {
+    if (!t || !planes_dev || !policy_dev || !value_dev) return tg::fail(TG_ERR_ARG, "tg_trainer_step: null argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    TrainDev &D = t->dev;
+    const int grid = D.NWG;
+    TG_HIP(hipMemsetAsync(D.stat, 0, (size_t)kLayers * kRep * 256 * sizeof(double), st));
+    TG_HIP(hipMemsetAsync(D.hstat, 0, (size_t)kRep * 16 * sizeof(double), st));
+    TG_HIP(hipMemsetAsync(D.grad + D.L.p_conv, 0, 128 * sizeof(float), st));
+    TG_HIP(hipMemsetAsync(D.grad + D.L.v_conv, 0, 64 * sizeof(float), st));
+    hipLaunchKernelGGL(repack_kernel, dim3(36864 / 256, kLayers), dim3(256), 0, st, D);
+    for (int l = 0; l < kLayers; ++l)
+        hipLaunchKernelGGL(conv_kernel<FWD>, dim3(grid), dim3(256), kConvLds, st, D, planes_dev, l);
+    hipLaunchKernelGGL(head_conv_kernel, dim3(grid), dim3(128), 0, st, D);
+    hipLaunchKernelGGL(head_loss_kernel, dim3(grid), dim3(256), 0, st, D, policy_dev, value_dev, sl_mode, value_weight);
+    hipLaunchKernelGGL(head_fc_grad_kernel, dim3(A + 3), dim3(192), 0, st, D);
+    hipLaunchKernelGGL(head_back_kernel, dim3(grid), dim3(256), 0, st, D);
+    for (int l = kLayers - 1; l >= 0; --l) {
+        hipLaunchKernelGGL(wgrad_kernel, dim3(grid), dim3(512), kWgradLds, st, D, planes_dev, l);
+        if (l >= 1) hipLaunchKernelGGL(conv_kernel<DGRAD>, dim3(grid), dim3(256), kConvLds, st, D, planes_dev, l);
+    }
+    SgdArgs a{lr, 0.9f, 1e-4f, t->first_step ? 1 : 0};
+    hipLaunchKernelGGL(sgd_conv_kernel, dim3(36864 / 256, kLayers), dim3(256), 0, st, D, a);
+    hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)((D.L.total + 255) / 256)), dim3(256), 0, st, D, a);
+    TG_HIP(hipGetLastError());
+    t->first_step = false;
+    return TG_OK;
+}
+
+int tg_trainer_read_losses(tg_trainer *t, double *sums_host, int reset) {
+    if (!t || !sums_host) return tg::fail(TG_ERR_ARG, "tg_trainer_read_losses: null argument");
+    TG_HIP(hipSetDevice(t->device));
+    TG_HIP(hipDeviceSynchronize());
+    double rep[kRep * 4];
+    TG_HIP(hipMemcpy(rep, t->dev.loss, sizeof(rep), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 3; ++k) {
+        sums_host[k] = 0.0;
+        for (int r = 0; r < kRep; ++r) sums_host[k] += rep[r * 4 + k];
+    }
+    if (reset) TG_HIP(hipMemset(t->dev.loss, 0, sizeof(rep)));
+    return TG_OK;
+}
+
+int tg_trainer_get_params(tg_trainer *t, float *params_host, float *momentum_host, size_t n) {
+    if (!t || !params_host) return tg::fail(TG_ERR_ARG, "tg_trainer_get_params: null argument");
+    if (n != t->dev.L.total) return tg::fail(TG_ERR_ARG, "tg_trainer_get_params: expected %zu floats", t->dev.L.total);
+    TG_HIP(hipSetDevice(t->device));
+    TG_HIP(hipDeviceSynchronize());
+    TG_HIP(hipMemcpy(params_host, t->dev.param, n * sizeof(float), hipMemcpyDeviceToHost));
+    if (momentum_host) TG_HIP(hipMemcpy(momentum_host, t->dev.mom, n * sizeof(float), hipMemcpyDeviceToHost));
+    return TG_OK;
+}
+
+int tg_trainer_debug_read(tg_trainer *t, int which, int index, float *out_host) {
+    if (!t || !out_host) return tg::fail(TG_ERR_ARG, "tg_trainer_debug_read: null argument");
+    TG_HIP(hipSetDevice(t->device));
+    TG_HIP(hipDeviceSynchronize());
+    const TrainDev &D = t->dev;
+    const size_t act = (size_t)D.B * P * C;
+    const float *src = which == 0 ? D.Z + index * act : which == 1 ? D.Y + index * act : which == 2 ? D.D + index * act : nullptr;
+    if (!src) return tg::fail(TG_ERR_ARG, "tg_trainer_debug_read: which must be 0 (Z), 1 (Y) or 2 (D)");
+    TG_HIP(hipMemcpy(out_host, src, act * sizeof(float), hipMemcpyDeviceToHost));
+    return TG_OK;
+}
+
+int tg_trainer_set_momentum(tg_trainer *t, const float *momentum_host, size_t n) {
+    if (!t || !momentum_host) return tg::fail(TG_ERR_ARG, "tg_trainer_set_momentum: null argument");
+    if (n != t->dev.L.total) return tg::fail(TG_ERR_ARG, "tg_trainer_set_momentum: expected %zu floats", t->dev.L.total);
+    TG_HIP(hipSetDevice(t->device));
+    TG_HIP(hipMemcpy(t->dev.mom, momentum_host, n * sizeof(float), hipMemcpyHostToDevice));
+    t->first_step = false;
+    return TG_OK;
+}
+
+}  // extern "C"

@@ -73,6 +73,13 @@ _SIGNATURES = {
     "tg_search_advance_streams": (c_int, [c_void_p, c_void_p]),
     "tg_search_draw_noise": (c_int, [c_void_p, c_void_p]),
     "tg_legacy_exponentials": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "tg_trainer_create": (c_int, [c_int, c_int, c_int, c_void_p, c_size_t, POINTER(c_void_p)]),
+    "tg_trainer_destroy": (c_int, [c_void_p]),
+    "tg_trainer_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p]),
+    "tg_trainer_read_losses": (c_int, [c_void_p, c_void_p, c_int]),
+    "tg_trainer_get_params": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    "tg_trainer_debug_read": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "tg_trainer_set_momentum": (c_int, [c_void_p, c_void_p, c_size_t]),
     "tg_selfplay_create": (c_int, [c_void_p, c_char_p, c_int, c_double, c_char_p, POINTER(c_void_p)]),
     "tg_selfplay_destroy": (c_int, [c_void_p]),
     "tg_selfplay_start_game": (c_int, [c_void_p, c_int, c_int, c_int]),

@@ -1,14 +1,16 @@
 """Training step for the DualNet the search evaluates (nn/learn.py:318-403,
 nn/loss.py:33-55).
 
-State of this row: the loop, the losses, the optimiser and the file formats are here and
-interchange with the reference (``model/rl-model.bin`` is the same ``state_dict``,
-``model/rl-state.ckpt`` holds a ``torch.optim.SGD`` state over the parameters in the same
-order).  The differentiation itself is torch autograd over ATen / MIOpen ops on the ROCm
-device - it is NOT yet one of this repo's HIP kernels; the hand-written backward for the fused
-tower is the open item in DESIGN.md §8.  The arithmetic is fp32 throughout (the reference runs
-this step under fp16 autocast with a GradScaler, learn.py:342,371 - fp32 is the stricter of
-the two, and what its CPU trainer does).
+The loop, the losses, the optimiser and the file formats interchange with the reference
+(``model/rl-model.bin`` is the same ``state_dict``, ``model/rl-state.ckpt`` holds a
+``torch.optim.SGD`` state over the parameters in the same order).  The mini-batch step itself
+exists twice: ``HipTrainer`` = this repo's HIP kernels (tamago_amd/csrc/train.hip behind
+``tg_trainer_*``: forward with batch statistics, backward, SGD-Nesterov, running statistics;
+the default for 9x9), and ``rl_train_step`` / ``sl_train_step`` / ``GraphedStep`` = torch autograd
+over ATen / MIOpen ops, kept as the fp32 reference the kernels are tested against and for other
+board sizes.  The arithmetic is fp32 throughout (the reference runs this step under fp16
+autocast with a GradScaler, learn.py:342,371 - fp32 is the stricter of the two, and what its
+CPU trainer does).
 
 The network is held as a flat table of tensors keyed like the state_dict (no module tree):
 the same table feeds ``DualNet.load_state_dict`` of the inference side after a step.
@@ -259,6 +261,109 @@ class GraphedStep:
         return {"loss": total[0], "policy": total[1], "value": total[2]}
 
 
+class HipTrainer:
+    """The training step as this repo's HIP kernels (tamago_amd/csrc/train.hip behind tg_trainer_*): forward with
+    batch statistics, backward, SGD-Nesterov + weight decay, batch-norm running statistics - no autograd, no
+    library kernel.  Same table / state_dict / optimiser-state layout as TrainableDualNet + make_optimizer, so
+    the two interchange (and with the reference's modules).  9x9, fp32."""
+
+    def __init__(self, device: torch.device, board_size: int = 9, batch_size: int = 256,
+                 state: Dict[str, torch.Tensor] = None):
+        import ctypes
+        from tamago_amd import lib as _lib
+        self._lib_mod = _lib
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        self.board_size = board_size
+        self.batch_size = batch_size
+        self.keys = state_dict_keys(board_size)
+        state = state if state is not None else random_state_dict(board_size)
+        flat = np.concatenate([torch.as_tensor(state[k]).detach().to("cpu", torch.float32).numpy().reshape(-1)
+                               for k, _ in self.keys]).astype(np.float32)
+        self.n_params = flat.size
+        tracked = state.get("bn_layer.num_batches_tracked")
+        self.batches_tracked = int(tracked) if tracked is not None else 0
+        handle = ctypes.c_void_p()
+        index = self.device.index if self.device.index is not None else 0
+        _lib.check(self.lib.tg_trainer_create(board_size, index, batch_size, flat.ctypes.data, flat.size,
+                                              ctypes.byref(handle)), "tg_trainer_create")
+        self.handle = handle
+        self.steps = 0
+
+    def close(self):
+        if getattr(self, "handle", None) is not None:
+            self.lib.tg_trainer_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def step(self, plane: torch.Tensor, policy: torch.Tensor, value: torch.Tensor, mode: str = "rl",
+             lr: float = RL_LEARNING_RATE):
+        """Enqueue one mini-batch on the current stream (device tensors, batch = batch_size)."""
+        assert plane.is_cuda and plane.shape == (self.batch_size, 6, self.board_size, self.board_size)
+        plane = plane.contiguous().float()
+        policy = policy.contiguous().float()
+        value = value.contiguous().long()
+        weight = RL_VALUE_WEIGHT if mode == "rl" else SL_VALUE_WEIGHT
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._lib_mod.check(self.lib.tg_trainer_step(self.handle, plane.data_ptr(), policy.data_ptr(), value.data_ptr(),
+                                                     int(mode != "rl"), float(weight), float(lr), stream),
+                            "tg_trainer_step")
+        self._keep = (plane, policy, value)
+        self.steps += 1
+        self.batches_tracked += 1
+
+    def take_losses(self) -> Dict[str, float]:
+        """Summed losses since the last call (one host read)."""
+        sums = np.zeros(3, dtype=np.float64)
+        self._lib_mod.check(self.lib.tg_trainer_read_losses(self.handle, sums.ctypes.data, 1), "tg_trainer_read_losses")
+        return {"loss": float(sums[0]), "policy": float(sums[1]), "value": float(sums[2])}
+
+    def _blobs(self):
+        params = np.zeros(self.n_params, dtype=np.float32)
+        mom = np.zeros(self.n_params, dtype=np.float32)
+        self._lib_mod.check(self.lib.tg_trainer_get_params(self.handle, params.ctypes.data, mom.ctypes.data,
+                                                           self.n_params), "tg_trainer_get_params")
+        return params, mom
+
+    def _unflatten(self, flat):
+        out, o = {}, 0
+        for key, shape in self.keys:
+            n = int(np.prod(shape))
+            out[key] = torch.from_numpy(flat[o:o + n].reshape(shape).copy())
+            o += n
+        return out
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        table = self._unflatten(self._blobs()[0])
+        out = {}
+        for key, _ in self.keys:
+            out[key] = table[key]
+            if key.endswith("running_var"):
+                out[key[:-len("running_var")] + "num_batches_tracked"] = torch.tensor(self.batches_tracked)
+        return out
+
+    def momentum_buffers(self):
+        """Momentum buffers of the trainable tensors in parameters() order (torch.optim.SGD state layout)."""
+        table = self._unflatten(self._blobs()[1])
+        return [table[k] for k, _ in self.keys if not k.endswith(("running_mean", "running_var"))]
+
+    def load_momentum_buffers(self, buffers):
+        flat, it = [], iter(buffers)
+        for key, shape in self.keys:
+            if key.endswith(("running_mean", "running_var")):
+                flat.append(np.zeros(int(np.prod(shape)), dtype=np.float32))
+            else:
+                flat.append(torch.as_tensor(next(it)).detach().to("cpu", torch.float32).numpy().reshape(-1))
+        blob = np.concatenate(flat).astype(np.float32)
+        self._lib_mod.check(self.lib.tg_trainer_set_momentum(self.handle, blob.ctypes.data, blob.size),
+                            "tg_trainer_set_momentum")
+
+
 # ------------------------------------------------------------------------------ file formats
 def load_data_set(path: str):
     """nn/utility.py:90-102 - one shuffle of the chunk from numpy's global generator."""
@@ -309,8 +414,19 @@ def train_with_gumbel_alphazero_on_gpu(program_dir: str, board_size: int, batch_
         print(f"num_trained_batches : {num_trained_batches}")
 
     train_loss = {"loss": 0.0, "policy": 0.0, "value": 0.0}
-    graphed = None
-    if os.environ.get("TG_TRAIN_EAGER", "0") != "1":
+    # Step implementation: this repo's HIP kernels (tg_trainer_*, 9x9) unless TG_TRAIN_BACKEND says otherwise
+    # ("autograd" = torch autograd replayed as a hipGraph, "eager" = the same, launch by launch; other board sizes
+    # use autograd).  All three read and write the same model / optimiser-state files.
+    backend = os.environ.get("TG_TRAIN_BACKEND", "hip" if board_size == 9 else "autograd")
+    if os.environ.get("TG_TRAIN_EAGER", "0") == "1":
+        backend = "eager"
+    graphed = hip = None
+    if backend == "hip":
+        hip = HipTrainer(device, board_size, batch_size, net.state_dict())
+        buffers = [optimizer.state[p].get("momentum_buffer") for p in net.parameters()]
+        if all(b is not None for b in buffers):
+            hip.load_momentum_buffers(buffers)
+    elif backend == "autograd":
         graphed = GraphedStep(net.train(), optimizer, batch_size, "rl")
     for data_index, path in enumerate(data_set):
         plane_data, policy_data, value_data = load_data_set(path)
@@ -323,7 +439,9 @@ def train_with_gumbel_alphazero_on_gpu(program_dir: str, board_size: int, batch_
         started = time.time()
         for i in range(0, len(value_data) - batch_size + 1, batch_size):
             batch = (planes[i:i + batch_size], policies[i:i + batch_size], values[i:i + batch_size])
-            if graphed is not None:
+            if hip is not None:
+                hip.step(*batch, mode="rl", lr=RL_LEARNING_RATE)
+            elif graphed is not None:
                 graphed(*batch)
             else:
                 part = rl_train_step(net, optimizer, *batch)
@@ -331,10 +449,19 @@ def train_with_gumbel_alphazero_on_gpu(program_dir: str, board_size: int, batch_
                     train_loss[k] += part[k]
             num_trained_batches += 1
             iteration += 1
-        if graphed is not None:
+        if hip is not None:
+            train_loss = hip.take_losses()
+        elif graphed is not None:
             train_loss = graphed.take_losses()
         print_learning_process(train_loss, 0, data_index, iteration, started)
 
+    if hip is not None:
+        # back into the table / torch.optim.SGD layout the files are written from
+        net.load_state_dict(hip.state_dict())
+        if hip.steps:
+            for p, buf in zip(net.parameters(), hip.momentum_buffers()):
+                optimizer.state[p]["momentum_buffer"] = buf.to(device)
+        hip.close()
     os.makedirs(os.path.dirname(model_file_path), exist_ok=True)
     torch.save(net.state_dict(), model_file_path)
     torch.save({"num_trained_batches": num_trained_batches,

@@ -13,7 +13,24 @@ from tamago_amd.nn import learn  # noqa: E402
 dev = torch.device("cuda", 0)
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 9
 batches = [int(b) for b in sys.argv[2].split(",")] if len(sys.argv) > 2 else [256, 1024, 4096]
+hip_only = len(sys.argv) > 3 and sys.argv[3] == "hip"     # profile runs: only this repo's kernels
 for batch in batches:
+    if hip_only:
+        rng = np.random.RandomState(1)
+        planes = torch.from_numpy((rng.uniform(size=(batch, 6, size, size)) < 0.3).astype(np.float32)).to(dev)
+        pol = torch.softmax(torch.randn(batch, size * size + 1, device=dev), 1)
+        val = torch.randint(0, 3, (batch,), device=dev)
+        hip = learn.HipTrainer(dev, 9, batch)
+        for _ in range(3):
+            hip.step(planes, pol, val)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(30):
+            hip.step(planes, pol, val)
+        torch.cuda.synchronize()
+        dh = (time.time() - t0) / 30
+        print(f"train step 9x9 batch {batch}: HIP kernels (tg_trainer_step) {dh * 1e3:.2f} ms -> {batch / dh:,.0f} positions/s")
+        continue
     net = learn.TrainableDualNet(dev, size)
     opt = learn.make_optimizer(net, 0.01)
     rng = np.random.RandomState(1)
@@ -38,5 +55,18 @@ for batch in batches:
         run(planes, pol, val)
     torch.cuda.synchronize()
     dg = (time.time() - t0) / n
-    print(f"train step {size}x{size} batch {batch}: eager {dt * 1e3:.2f} ms -> {batch / dt:,.0f} positions/s; "
-          f"hipGraph {dg * 1e3:.2f} ms -> {batch / dg:,.0f} positions/s")
+    line = (f"train step {size}x{size} batch {batch}: autograd eager {dt * 1e3:.2f} ms -> {batch / dt:,.0f} positions/s; "
+            f"autograd hipGraph {dg * 1e3:.2f} ms -> {batch / dg:,.0f} positions/s")
+    if size == 9:
+        hip = learn.HipTrainer(dev, 9, batch)
+        for _ in range(3):
+            hip.step(planes, pol, val)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(n):
+            hip.step(planes, pol, val)
+        torch.cuda.synchronize()
+        dh = (time.time() - t0) / n
+        line += f"; HIP kernels (tg_trainer_step) {dh * 1e3:.2f} ms -> {batch / dh:,.0f} positions/s"
+        hip.close()
+    print(line, flush=True)

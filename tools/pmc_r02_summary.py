@@ -50,8 +50,9 @@ def short(name):
 
 
 def main(out):
-    from tamago_amd.build import source_digest
-    digest = source_digest()
+    from tamago_amd.build import FORWARD_SOURCES, source_digest
+    digest = source_digest(FORWARD_SOURCES)          # forward summaries: the forward kernels' sources only
+    digest_all = source_digest()
     # ---- 1. forward kernel ----------------------------------------------------------------------
     per, times = counters(out, ["fwd_a", "fwd_b", "fwd_c", "fwd_d", "fwd_e", "fwd_f"], ["dualnet_fwd"])
     for kname, c in per.items():
@@ -89,7 +90,7 @@ def main(out):
         print(path, json.dumps(summary["derived"], indent=1))
     # ---- 2. tree kernels + 3. featurise -------------------------------------------------------------
     leaves = 3 * 2048 * 1001                              # bench.py --steps 2 --warmup 1 --trees 2048: leaf evaluations
-    tree = {"csrc_digest": digest, "run": "bench.py --steps 2 --warmup 1 --trees 2048 (3 move searches x 2048 trees x 1001 leaf evaluations)",
+    tree = {"csrc_digest": digest_all, "run": "bench.py --steps 2 --warmup 1 --trees 2048 (3 move searches x 2048 trees x 1001 leaf evaluations)",
             "leaf_evals_in_run": leaves, "kernels": {},
             "algorithmic_bytes_per_leaf_SURVEY_8d": {
                 "select (PUCB walk 24 B x children x ~3.5 levels + node init 38 B x A + planes 1944 B)": 3.5 * 82 * 24 + 38 * 82 + 1944,
