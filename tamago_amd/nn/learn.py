@@ -458,9 +458,12 @@ def train_with_gumbel_alphazero_on_gpu(program_dir: str, board_size: int, batch_
     if hip is not None:
         # back into the table / torch.optim.SGD layout the files are written from
         net.load_state_dict(hip.state_dict())
-        if hip.steps:
+        fresh = make_optimizer(net, RL_LEARNING_RATE)        # (load_state_dict made new parameter tensors)
+        had_momentum = any("momentum_buffer" in st for st in optimizer.state.values())
+        if hip.steps or had_momentum:
             for p, buf in zip(net.parameters(), hip.momentum_buffers()):
-                optimizer.state[p]["momentum_buffer"] = buf.to(device)
+                fresh.state[p]["momentum_buffer"] = buf.to(device)
+        optimizer = fresh
         hip.close()
     os.makedirs(os.path.dirname(model_file_path), exist_ok=True)
     torch.save(net.state_dict(), model_file_path)
