@@ -290,6 +290,13 @@ int tg_selfplay_schedule(tg_selfplay *sp, int32_t *num_considered_host, int32_t 
  * moves decided} by this call (may be NULL). */
 int tg_selfplay_finish_move(tg_selfplay *sp, int32_t *moves_host, int32_t *finished_host,
                             int64_t *stats_host);
+/* The whole move above in ONE call when the evaluator is a tg_net (root evaluation, noise, schedule, every
+ * phase with its forward pass, tg_selfplay_finish_move, tg_search_play): nothing but library code runs
+ * between the launches.  Caller's device buffers: planes [T*batch_size,6,S,S], policy [T*batch_size,A],
+ * value [T*batch_size,3].  finished_host[T] as above; stats_host[3] = {games finished, moves decided, leaf
+ * evaluations} of this move (may be NULL). */
+int tg_selfplay_play_move(tg_selfplay *sp, tg_net *net, float *planes_dev, float *policy_dev,
+                          float *value_dev, void *stream, int32_t *finished_host, int64_t *stats_host);
 
 /* ---- training step (nn/learn.py:318-403, nn/loss.py:9-55; modules of nn/network/) ---------------------------
  * One mini-batch of the reference's GPU trainers as hand-written HIP kernels (forward with batch statistics,

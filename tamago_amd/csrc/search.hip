@@ -2493,6 +2493,8 @@ struct tg_selfplay {
     std::vector<double> vsum_a, pol_a;
     std::vector<int16_t> act_a;
     std::vector<uint8_t> cells;
+    std::vector<int32_t> ph_nc, ph_mc, mv, fin;       // tg_selfplay_play_move scratch
+    bool force_feed = true;                          // a stream was (re)seeded: the next random window is regenerated
 };
 
 namespace {
@@ -2612,6 +2614,7 @@ int tg_selfplay_start_game(tg_selfplay *sp, int slot, int index, int never_resig
     g.never_resign = never_resign != 0;
     g.done = index < 0;
     sp->games[slot] = g;
+    sp->force_feed = true;
     return TG_OK;
 }
 
@@ -2749,6 +2752,60 @@ int tg_selfplay_finish_move(tg_selfplay *sp, int32_t *moves_host, int32_t *finis
         stats_host[1] = 0;
         for (int t = 0; t < T; ++t) { stats_host[0] += n_games[t]; stats_host[1] += n_moves[t]; }
     }
+    return TG_OK;
+}
+
+// One whole self-play move of every board, driven from here (no host-language code between the launches):
+// root expansion + evaluation, Gumbel noise, halving schedule, every phase (selection, forward pass of the
+// library's own network handle, backup), final choice / records / finished games, the moves played on the
+// device-resident boards.  Buffers are the caller's (device): planes [T * batch_size][6][S][S],
+// policy [T * batch_size][A], value [T * batch_size][3].
+int tg_selfplay_play_move(tg_selfplay *sp, tg_net *net, float *planes_dev, float *policy_dev, float *value_dev,
+                          void *stream, int32_t *finished_host, int64_t *stats_host) {
+    if (!sp || !net || !planes_dev || !policy_dev || !value_dev || !finished_host)
+        return tg::fail(TG_ERR_ARG, "tg_selfplay_play_move: null argument");
+    tg_search *s = sp->s;
+    const int T = s->dev.T, A = s->A;
+    int rc;
+    int live = 0;
+    for (int t = 0; t < T; ++t) live += sp->games[t].done ? 0 : 1;
+    // ---- root: expand, evaluate (tree.py:330-336) ----
+    if ((rc = tg_search_feed_streams(s, (size_t)A, sp->force_feed ? 1 : 0))) return rc;
+    sp->force_feed = false;
+    if ((rc = tg_search_root_planes(s, planes_dev, stream))) return rc;
+    if ((rc = tg_search_advance_streams(s, nullptr))) return rc;
+    if ((rc = tg_net_forward_dev(net, planes_dev, T, 1, policy_dev, value_dev, stream))) return rc;
+    if ((rc = tg_search_backup(s, policy_dev, value_dev, 1, 1, stream))) return rc;
+    if ((rc = tg_search_draw_noise(s, nullptr))) return rc;
+    // ---- sequential halving (tree.py:375-384) ----
+    constexpr int kMaxPhases = 16;
+    sp->ph_nc.resize((size_t)kMaxPhases * T);
+    sp->ph_mc.resize((size_t)kMaxPhases * T);
+    int32_t n_phases = 0;
+    if ((rc = tg_selfplay_schedule(sp, sp->ph_nc.data(), sp->ph_mc.data(), kMaxPhases, &n_phases))) return rc;
+    int64_t leaves = live;
+    for (int ph = 0; ph < n_phases; ++ph) {
+        const int32_t *nc = &sp->ph_nc[(size_t)ph * T], *mc = &sp->ph_mc[(size_t)ph * T];
+        int64_t total = 0, slots = 0;
+        for (int t = 0; t < T; ++t) {
+            const int64_t n = (int64_t)nc[t] * mc[t];
+            total += n;
+            slots = n > slots ? n : slots;
+        }
+        if (slots == 0) continue;
+        if ((rc = tg_search_feed_streams(s, (size_t)slots * A, 0))) return rc;
+        if ((rc = tg_search_select_gumbel(s, nc, mc, 0, planes_dev, stream))) return rc;
+        if ((rc = tg_search_advance_streams(s, nullptr))) return rc;
+        if ((rc = tg_net_forward_dev(net, planes_dev, (int)total, 1, policy_dev, value_dev, stream))) return rc;
+        if ((rc = tg_search_backup(s, policy_dev, value_dev, 0, 1, stream))) return rc;
+        leaves += total;
+    }
+    // ---- move choice, records, finished games; play ----
+    sp->mv.resize(T);
+    int64_t counts[2] = {0, 0};
+    if ((rc = tg_selfplay_finish_move(sp, sp->mv.data(), finished_host, counts))) return rc;
+    if ((rc = tg_search_play(s, sp->mv.data(), stream))) return rc;
+    if (stats_host) { stats_host[0] = counts[0]; stats_host[1] = counts[1]; stats_host[2] = leaves; }
     return TG_OK;
 }
 

@@ -85,6 +85,7 @@ _SIGNATURES = {
     "tg_selfplay_start_game": (c_int, [c_void_p, c_int, c_int, c_int]),
     "tg_selfplay_schedule": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "tg_selfplay_finish_move": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "tg_selfplay_play_move": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -168,31 +168,50 @@ def _run_group(save_dir, network, size, visits, boards, seeds, device_index, nex
                 else:
                     # fewer games than slots: park an empty board with a private stream
                     engine.set_root(s, start_board, Stone.BLACK, np.random.RandomState(0).get_state())
-            max_phases = 16
-            widths = np.zeros((max_phases, boards), dtype=np.int32)
-            levels = np.zeros((max_phases, boards), dtype=np.int32)
-            n_phases = ctypes.c_int32(0)
-            played = np.zeros(boards, dtype=np.int32)
             finished = np.zeros(boards, dtype=np.int32)
-            counts = np.zeros(2, dtype=np.int64)
-            while live > 0:
-                # boards are resident on the device (tg_search_play); parked slots keep their last root
-                engine.root_eval(use_logit=True)
-                engine.set_gumbel_noise()
-                _lib.check(lib.tg_selfplay_schedule(handle, widths.ctypes.data, levels.ctypes.data, max_phases,
-                                                    ctypes.byref(n_phases)), "tg_selfplay_schedule")
-                stats["leaf_evals"] += live
-                for phase in range(n_phases.value):
-                    engine.gumbel_phase(widths[phase], levels[phase])
-                stats["leaf_evals"] += int((widths[:n_phases.value].astype(np.int64) * levels[:n_phases.value]).sum())
-                _lib.check(lib.tg_selfplay_finish_move(handle, played.ctypes.data, finished.ctypes.data,
-                                                       counts.ctypes.data), "tg_selfplay_finish_move")
-                stats["games"] += int(counts[0])
-                stats["moves"] += int(counts[1])
-                engine.play(played)
-                for s in np.nonzero(finished)[0]:
-                    if not start(int(s)):
-                        live -= 1
+            if isinstance(evaluator, DeviceEvaluator):
+                # the library's own network: the whole move is one call (tg_selfplay_play_move)
+                a = size * size + 1
+                policy = torch.empty((boards * engine.K, a), dtype=torch.float32, device=engine.device)
+                value = torch.empty((boards * engine.K, 3), dtype=torch.float32, device=engine.device)
+                counts = np.zeros(3, dtype=np.int64)
+                while live > 0:
+                    _lib.check(lib.tg_selfplay_play_move(handle, network.handle, engine.planes.data_ptr(),
+                                                         policy.data_ptr(), value.data_ptr(), engine._stream(),
+                                                         finished.ctypes.data, counts.ctypes.data),
+                               "tg_selfplay_play_move")
+                    stats["games"] += int(counts[0])
+                    stats["moves"] += int(counts[1])
+                    stats["leaf_evals"] += int(counts[2])
+                    for s in np.nonzero(finished)[0]:
+                        if not start(int(s)):
+                            live -= 1
+            else:
+                # any other evaluator (host API): the phases are driven from here, the bookkeeping stays in C++
+                max_phases = 16
+                widths = np.zeros((max_phases, boards), dtype=np.int32)
+                levels = np.zeros((max_phases, boards), dtype=np.int32)
+                n_phases = ctypes.c_int32(0)
+                played = np.zeros(boards, dtype=np.int32)
+                counts = np.zeros(2, dtype=np.int64)
+                while live > 0:
+                    # boards are resident on the device (tg_search_play); parked slots keep their last root
+                    engine.root_eval(use_logit=True)
+                    engine.set_gumbel_noise()
+                    _lib.check(lib.tg_selfplay_schedule(handle, widths.ctypes.data, levels.ctypes.data, max_phases,
+                                                        ctypes.byref(n_phases)), "tg_selfplay_schedule")
+                    stats["leaf_evals"] += live
+                    for phase in range(n_phases.value):
+                        engine.gumbel_phase(widths[phase], levels[phase])
+                    stats["leaf_evals"] += int((widths[:n_phases.value].astype(np.int64) * levels[:n_phases.value]).sum())
+                    _lib.check(lib.tg_selfplay_finish_move(handle, played.ctypes.data, finished.ctypes.data,
+                                                           counts.ctypes.data), "tg_selfplay_finish_move")
+                    stats["games"] += int(counts[0])
+                    stats["moves"] += int(counts[1])
+                    engine.play(played)
+                    for s in np.nonzero(finished)[0]:
+                        if not start(int(s)):
+                            live -= 1
         finally:
             lib.tg_selfplay_destroy(handle)
             engine.close()

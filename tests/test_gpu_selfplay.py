@@ -64,3 +64,35 @@ def test_lockstep_shard_equals_single_board_games(tmp_path):
     # resume-by-skip (worker.py:47-48): nothing left to do
     again = selfplay_shard(str(multi), StubNet(salt=201), idx, 9, 16, boards=2, never_resign_flags=flags)
     assert again["games"] == 0
+
+
+def test_one_call_per_move_path_equals_the_phase_by_phase_path(tmp_path):
+    """With a DualNet the shard plays each move through ONE library call (tg_selfplay_play_move: root
+    evaluation, noise, schedule, every phase with its forward pass, records, play).  Wrapped so that it is
+    not recognised as a DualNet, the same network goes through the phase-by-phase path (host evaluator API).
+    Same forward kernel, same bits: the games must be byte-identical."""
+    import torch
+    from tamago_amd.nn.network.dual_net import DualNet
+    from tamago_amd.selfplay.worker import selfplay_shard
+
+    class HostOnly:
+        def __init__(self, net):
+            self.net = net
+
+        def inference(self, planes):
+            return self.net.inference(planes)
+
+        def inference_with_policy_logits(self, planes):
+            return self.net.inference_with_policy_logits(planes)
+
+    torch.manual_seed(21)
+    net = DualNet(torch.device("cuda:0"), 9)
+    idx = list(range(1, 11))
+    flags = [i % 3 == 0 for i in idx]
+    fast, slow = tmp_path / "fast", tmp_path / "slow"
+    fast.mkdir(), slow.mkdir()
+    a = selfplay_shard(str(fast), net, idx, 9, 48, boards=4, never_resign_flags=flags)
+    b = selfplay_shard(str(slow), HostOnly(net), idx, 9, 48, boards=4, never_resign_flags=flags)
+    assert a == b and a["games"] == 10
+    for i in idx:
+        assert open(fast / f"{i}.sgf").read() == open(slow / f"{i}.sgf").read(), i
