@@ -1411,8 +1411,50 @@ __global__ __launch_bounds__(192) void select_gumbel_pipe_kernel(SearchDev D, co
 
     if (wid == 0) {
         // ---- selector -------------------------------------------------------------------
+        // Within a phase nothing backs values up, so (a) the root's score "logit + noise + sigma q" of every child
+        // is a constant - only "visits + virtual loss >= threshold" moves, and the virtual loss is added by this
+        // wave: the root lives in registers for the whole launch (loaded once, written back once); (b) below the
+        // root the choice (node.py:349-361: completed Q, two softmaxes - the costly part) is a pure function of
+        // statistics that do not change: it is computed at a node's first visit and remembered (LDS, by node).
+        // Virtual losses below the root are fire-and-forget atomics (nobody reads them before the backup).
+        constexpr int R = (A + 63) / 64;
         int jid = 0, nexp = 0;
         bool ok = active;
+        double r_score[R];
+        int r_cnt[R], r_vis[R], r_idx[R], r_act[R], r_vl0[R];
+        int r_nc = 0, r_added = 0;
+        if (active) {
+            const size_t base = (size_t)t * D.N * A;
+            double vsum[R];
+            r_nc = D.n_children[(size_t)t * D.N];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int i = lane + 64 * r, ii = i < A ? i : A - 1;
+                r_vis[r] = D.ch_visits[base + ii];
+                r_vl0[r] = D.ch_vl[base + ii];
+                vsum[r] = D.ch_vsum[base + ii];
+                r_score[r] = D.ch_policy[base + ii] + D.noise[(size_t)t * A + ii];
+                r_idx[r] = D.ch_index[base + ii];
+                r_act[r] = D.action[base + ii];
+            }
+            int mx = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (lane + 64 * r < r_nc) mx = max(mx, r_vis[r]);
+            mx = wave_max_i32(mx);
+            const double sigma = (double)(50 + mx) * 1.0;                   // (C_VISIT + max) * C_SCALE
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const double q = r_vis[r] > 0 ? vsum[r] / (double)r_vis[r] : 0.0;
+                r_score[r] = r_score[r] + sigma * q;
+                r_cnt[r] = r_vis[r] + r_vl0[r];
+            }
+        }
+        // remembered choices below the root: tag = node, value = (edge, move, visits of the edge, child)
+        constexpr int kMemo = 64;
+        __shared__ int memo_tag[kMemo], memo_edge[kMemo], memo_move[kMemo], memo_vis[kMemo], memo_child[kMemo];
+        for (int i = lane; i < kMemo; i += 64) memo_tag[i] = -1;
+        wave_sync();
         auto publish = [&](int plane_slot, int parent, int edge, int child, int expand, int xseq, int depth) -> bool {
             if (jid >= kPipeMaxK) return false;
             const int slot = jid % kPipeSlots;
@@ -1434,21 +1476,58 @@ __global__ __launch_bounds__(192) void select_gumbel_pipe_kernel(SearchDev D, co
                 if (pipe_load(&sh.err)) { ok = false; break; }
                 int node = 0, depth = 0;
                 while (ok) {
-                    if (node >= n0) ok = pipe_wait_ge(&sh.done[sh.jobof[node - n0]], 1);
-                    if (!ok) break;
                     const size_t ns = (size_t)t * D.N + node;
                     const size_t base = ns * A;
-                    const int e = node == 0 ? select_root_halving<S>(D, t, node, th, lane)
-                                            : select_node_halving<S>(hs, D, t, node, lane);
-                    const int mv = D.action[base + e];
-                    const int visits = D.ch_visits[base + e];
-                    int child = D.ch_index[base + e];
+                    int e, mv, visits, child;
+                    if (node == 0) {
+                        // node.py:324-346 on the register copy
+                        double best = 0.0;
+                        int best_i = -1;
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            const int i = lane + 64 * r;
+                            if (i < r_nc) {
+                                const double sc = r_cnt[r] >= th ? -10000.0 : r_score[r];
+                                if (best_i < 0 || sc > best) { best = sc; best_i = i; }
+                            }
+                        }
+                        wave_argmax(best, best_i);
+                        e = best_i;
+                        const int owner = __builtin_amdgcn_readfirstlane(e & 63), rr = e >> 6;
+                        int m_mv = 0, m_vis = 0, m_idx = 0;
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+                            if (r == rr) { m_mv = r_act[r]; m_vis = r_vis[r]; m_idx = r_idx[r]; if (lane == owner) r_cnt[r] += 1; }
+                        mv = __builtin_amdgcn_readlane(m_mv, owner);
+                        visits = __builtin_amdgcn_readlane(m_vis, owner);
+                        child = __builtin_amdgcn_readlane(m_idx, owner);
+                        ++r_added;
+                    } else {
+                        const int slot = node & (kMemo - 1);
+                        if (memo_tag[slot] == node) {
+                            e = memo_edge[slot]; mv = memo_move[slot]; visits = memo_vis[slot]; child = memo_child[slot];
+                        } else {
+                            if (node >= n0) ok = pipe_wait_ge(&sh.done[sh.jobof[node - n0]], 1);   // expansion in flight?
+                            if (!ok) break;
+                            e = select_node_halving<S>(hs, D, t, node, lane);
+                            mv = D.action[base + e];
+                            visits = D.ch_visits[base + e];
+                            child = D.ch_index[base + e];
+                            wave_sync();
+                            if (lane == 0) {
+                                memo_tag[slot] = node; memo_edge[slot] = e; memo_move[slot] = mv;
+                                memo_vis[slot] = visits; memo_child[slot] = child;
+                            }
+                            wave_sync();
+                        }
+                        if (lane == 0) {                                  // node.py:76-83, nobody reads these before the backup
+                            atomicAdd(&D.n_vl[ns], 1);
+                            atomicAdd(&D.ch_vl[base + e], 1);
+                        }
+                    }
                     if (depth >= kPipeMaxDepth) { ok = false; break; }
-                    wave_sync();
                     if (lane == 0) {
                         sel_moves[depth] = (int16_t)mv;
-                        D.n_vl[ns] += 1;
-                        D.ch_vl[base + e] += 1;
                         if (depth < kPathCap) D.q_path[((size_t)t * D.K + queued) * kPathCap + depth] = (node << 10) | e;
                     }
                     ++depth;
@@ -1471,6 +1550,14 @@ __global__ __launch_bounds__(192) void select_gumbel_pipe_kernel(SearchDev D, co
                             break;
                         }
                         child = num_nodes++;
+                        if (node == 0) {
+                            const int owner = e & 63, rr = e >> 6;
+#pragma unroll
+                            for (int r = 0; r < R; ++r)
+                                if (r == rr && lane == owner) r_idx[r] = child;
+                        } else if (lane == 0) {
+                            memo_child[node & (kMemo - 1)] = child;
+                        }
                         if (lane == 0) {
                             D.ch_index[base + e] = child;
                             sh.jobof[child - n0] = (int16_t)jid;
@@ -1482,6 +1569,16 @@ __global__ __launch_bounds__(192) void select_gumbel_pipe_kernel(SearchDev D, co
                     node = child;
                 }
             }
+        }
+        if (active) {
+            // the root's virtual losses back to the pool
+            const size_t base = (size_t)t * D.N * A;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int i = lane + 64 * r;
+                if (i < r_nc) D.ch_vl[base + i] = r_cnt[r] - r_vis[r];
+            }
+            if (lane == 0) D.n_vl[(size_t)t * D.N] += r_added;
         }
         if (active && !ok && lane == 0) {
             if (!(D.err[t] & (kErrPoolFull | kErrRngEmpty))) atomicOr(&D.err[t], kErrPipeline);
