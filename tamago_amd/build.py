@@ -36,7 +36,7 @@ FORWARD_SOURCES = ("net_forward.hip", "net_forward_split.hip", "net_device.h", "
 
 
 def source_digest(names=None) -> str:
-    """sha256 (16 hex digits) over kernel sources: profiles/ summaries carry it, bench.py only quotes a PMC
+    """sha256 (16 hex digits) over the code lines (// comments and blank lines dropped) of kernel sources: profiles/ summaries carry it, bench.py only quotes a PMC
     summary that was measured on the kernels it is running.  `names`: basenames under csrc/ (default: all
     sources + headers + the ABI header); FORWARD_SOURCES = what the DualNet forward kernels are built from."""
     import hashlib
@@ -48,8 +48,11 @@ def source_digest(names=None) -> str:
         files = [os.path.join(CSRC, f) for f in names]
     for path in files:
         h.update(os.path.basename(path).encode())
-        with open(path, "rb") as f:
-            h.update(f.read())
+        with open(path, "r") as f:
+            for line in f:
+                code = line.split("//", 1)[0].strip()     # comment edits do not invalidate a measurement
+                if code:
+                    h.update(code.encode() + b"\n")
     return h.hexdigest()[:16]
 
 

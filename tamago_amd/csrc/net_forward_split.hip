@@ -29,9 +29,11 @@
 //   * activations are stored as NP 16-bit images [piece][k-chunk][row][4 x 16 B], slot = lg ^ ((row >> 1) & 3):
 //     conflict-free ds_read_b128 B-fragments for every tap shift (brute-forced against the hardware's lane
 //     groups); an all-zero row per image serves the padding taps (uniform offsets, no branches);
-//   * weights stream tap by tap (16 / 24 KB) from L2 into a two-slot LDS ring with global_load_lds_dwordx4 in
-//     MFMA A-fragment order: one copy per workgroup instead of one per wave, conflict-free reads, ONE barrier
-//     per tap;
+//   * weights do not pass through LDS at all: the host lays them out in MFMA A-fragment order
+//     [tap][k-chunk][piece][channel tile][lane][16 B] and every wave fetches its fragments with plain
+//     coalesced 16-byte global loads (1 KB per wave instruction) from the L2-resident image (1.8 MB) - the
+//     vector-memory path is idle otherwise, and LDS bandwidth is the scarce resource of this loop (a first
+//     version streamed them through an LDS ring with global_load_lds: 15 % slower, one barrier per tap);
 //   * fragment loads are issued between the MFMAs of earlier k-chunks (activations one chunk ahead, weights
 //     two), their program positions pinned with sched_barrier; the chunk sequence of a layer is straight-line
 //     code, so hipcc's counted waits land exactly where the fragments are first used.

@@ -813,9 +813,9 @@ __device__ __forceinline__ bool pipe_wait_ge(const int *p, int want) {
 }
 
 // expand_node for a worker: node index given by the selector, draws reserved through the chain
-template <int S>
+template <int S, typename Sh>
 __device__ bool expand_node_pipe(Lds<S> &L, const BoardScalars &b, int to_move, const SearchDev &D, int t,
-                                 int node, int parent, int pedge, int xseq, PipeShared<S> &sh, int lane) {
+                                 int node, int parent, int pedge, int xseq, Sh &sh, int lane) {
     using G = Geo<S>;
     constexpr int A = G::A;
     constexpr int R = (A + 63) / 64;
@@ -1028,6 +1028,384 @@ __global__ __launch_bounds__(192) void select_puct_pipe_kernel(SearchDev D, int 
         D.n_leaves[t] = queued;
         D.rng_cursor[t] = sh.cursor_val;
     }
+}
+
+// ---- PUCT selection with the descents themselves pipelined ----------------------------------
+// With few trees per GPU the selector wave above is the critical path: ~3.5 levels per descent, each an L2
+// round trip plus ~2 k cycles of fp64 PUCB arithmetic, and descent k + 1 may not start before descent k has
+// left its virtual loss behind.  But a descent only needs the virtual losses on the nodes it visits itself.
+// So NSEL selector waves take the descents round-robin and a descent scores node n (at level L) once every
+// earlier descent still in flight has either chosen a different level-L node or finished with n - a node is
+// then always scored with exactly the statistics the serial order gives it:
+//   * level_done[k] = levels descent k has left behind; lvl_node[k][L] = its level-L node, published with
+//     level_done[k] = L.  Only the NSEL - 1 predecessors of k can still be in flight.
+//   * the ROOT is visited by every descent, so its step is the chain that bounds the launch.  Its statistics
+//     cannot change inside a launch (the backup runs between launches) except for the virtual losses, so every
+//     selector keeps visits / value sums / priors of the root's children in registers and only the virtual
+//     losses and child indices live in LDS.  sqrt(N + 1) and the prior products of descent k depend on k alone
+//     and are computed BEFORE waiting for descent k - 1; after the wait only children whose virtual loss
+//     changed since this wave's last visit get new quotients.  The root's virtual losses reach global memory
+//     once, at the end of the launch.
+//   * new node indices and the random draws stay in descent order: a descent allocates only after its
+//     predecessor is completely done.  Board work goes to NWRK worker waves as before.
+// Same trees bit for bit (tests/test_gpu_search.py).
+constexpr int kMpDone = 1 << 30;        // level_done value of a finished descent
+constexpr int kMpTrackDepth = 64;       // levels with a published node (deeper: wait for the predecessors outright)
+
+template <int S, int NSEL, int NWRK>
+struct MPipeShared {
+    static constexpr int kMpSlots = 2 * NWRK;      // job ring; a multiple of the worker count
+    static constexpr int kRing = 2 * NSEL;         // rows of lvl_node: a row is reused only after its reader is done
+    Lds<S> board[NWRK];
+    PipeJob job[kMpSlots];
+    int16_t moves[kMpSlots][kPipeMaxDepth];
+    int job_seq[kMpSlots];            // k + 1 once job k sits in its slot
+    int slot_done[kMpSlots];          // jobs finished in this slot so far
+    int done[kPipeMaxK];              // job k finished (node initialised, planes written)
+    int level_done[kPipeMaxK];        // levels descent k has left behind (kMpDone: leaf queued)
+    int lvl_node[kRing][kMpTrackDepth];
+    int16_t jobof[kPipeMaxK];         // node (n0 + i) is being created by job jobof[i]
+    int root_vl[Geo<S>::A];           // virtual losses / child indices of the root's children
+    int root_idx[Geo<S>::A];
+    int num_nodes, nexp;              // owned by the descent whose predecessor is done
+    int cursor_seq;
+    long long cursor_val;
+    int err;
+};
+
+// wave-uniform wait for *p >= want: the value read, or -1 on a stall or once another wave has reported an error
+template <typename Sh>
+__device__ __forceinline__ int mp_wait_val(const Sh &sh, const int *p, int want) {
+    for (int spin = 0; spin < kPipeSpinLimit; ++spin) {
+        const int v = pipe_load(p);
+        if (v >= want) return v;
+        if (spin >= 32) {
+            if (pipe_load(&sh.err)) return -1;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    return -1;
+}
+template <typename Sh>
+__device__ __forceinline__ bool mp_wait_ge(const Sh &sh, const int *p, int want) {
+    return mp_wait_val(sh, p, want) >= 0;
+}
+
+// flag store behind plain LDS stores of the same lane: LDS operations of a wave complete in order, the fence
+// only keeps the compiler from reordering them
+__device__ __forceinline__ void mp_publish(int *p, int v) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <int S, int NSEL, int NWRK>
+__global__ __launch_bounds__(64 * (NSEL + NWRK)) void select_puct_mpipe_kernel(SearchDev D, int max_leaves, float *planes) {
+    using G = Geo<S>;
+    using Shared = MPipeShared<S, NSEL, NWRK>;
+    constexpr int A = G::A;
+    constexpr int R = (A + 63) / 64;
+    constexpr int NTHR = 64 * (NSEL + NWRK);
+    constexpr int kMpSlots = Shared::kMpSlots, kRing = Shared::kRing;
+    static_assert(kMpSlots % NWRK == 0 && kMpSlots >= NSEL, "job ring");
+    extern __shared__ __attribute__((aligned(16))) unsigned char mp_smem[];
+    Shared &sh = *reinterpret_cast<Shared *>(mp_smem);
+    const int t = blockIdx.x;
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const RootMeta meta = D.meta[t];
+    const int n0 = meta.num_nodes;
+    const size_t root_ns = (size_t)t * D.N, root_base = root_ns * A;
+    const bool active = D.err[t] == 0 && n0 > 0;
+    if (threadIdx.x < kMpSlots) {
+        sh.job_seq[threadIdx.x] = 0;
+        sh.slot_done[threadIdx.x] = 0;
+    }
+    for (int i = threadIdx.x; i < kPipeMaxK; i += NTHR) { sh.done[i] = 0; sh.level_done[i] = 0; }
+    if (active)
+        for (int i = threadIdx.x; i < A; i += NTHR) {
+            sh.root_vl[i] = D.ch_vl[root_base + i];
+            sh.root_idx[i] = D.ch_index[root_base + i];
+        }
+    if (threadIdx.x == 0) {
+        sh.cursor_seq = 0;
+        sh.cursor_val = D.rng_cursor[t];
+        sh.num_nodes = n0;
+        sh.nexp = 0;
+        sh.err = 0;
+    }
+    __syncthreads();
+    // per-phase s_memtime accumulators of tree 0 (tg_search_profile with TG_MPIPE_PROF=1; tools/profile_select.py)
+    const bool prof = D.prof && t == 0;
+    long long pc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long tp = prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
+    auto lap = [&](int i) {
+        if (prof) { const long long now = (long long)__builtin_amdgcn_s_memtime(); pc[i] += now - tp; tp = now; }
+    };
+
+    if (wid < NSEL) {
+        // ---- selectors: descent k on wave k % NSEL ------------------------------------------
+        __builtin_amdgcn_s_setprio(3);          // the critical path: ahead of the workers that share the SIMD
+        // the root's children, constant for the launch; c_vl / c_q: virtual loss this wave last saw and its quotient
+        int r_vis[R], r_act[R], c_vl[R];
+        double r_vsum[R], r_pol[R], c_q[R];
+        int root_nc = 0, root_total0 = 0;
+        if (active) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int i = lane + 64 * r, ii = i < A ? i : A - 1;
+                r_vis[r] = D.ch_visits[root_base + ii];
+                r_act[r] = D.action[root_base + ii];
+                r_vsum[r] = D.ch_vsum[root_base + ii];
+                r_pol[r] = D.ch_policy[root_base + ii];
+                c_vl[r] = D.ch_vl[root_base + ii];
+                const int cnt = r_vis[r] + c_vl[r];
+                c_q[r] = cnt != 0 ? r_vsum[r] / (double)cnt : 0.0;
+            }
+            root_nc = D.n_children[root_ns];
+            root_total0 = D.n_visits[root_ns] + D.n_vl[root_ns];
+        }
+        for (int k = wid; active && k < max_leaves; k += NSEL) {
+            if (pipe_load(&sh.err)) break;
+            const int slot = k % kMpSlots;
+            int *my_nodes = sh.lvl_node[k % kRing];
+            lap(8);
+            bool ok = mp_wait_ge(sh, &sh.slot_done[slot], k / kMpSlots);          // ring slot free again
+            lap(0);
+            int node = 0, depth = 0;
+            int moves = meta.moves, prev = meta.prev, prevprev = meta.prevprev;
+            bool pool_full = false;
+            while (ok) {
+                EdgePick pick;
+                size_t ns = root_ns, base = root_base;
+                if (depth == 0) {
+                    // every descent before this one has added one virtual loss to the root (node.py:76-83)
+                    const double sq = __dsqrt_rn((double)(root_total0 + k + 1));
+                    double psq[R], sc[R];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        psq[r] = r_pol[r] * sq;
+                        sc[r] = c_q[r] + psq[r] / (double)(r_vis[r] + c_vl[r] + 1);
+                    }
+                    lap(1);
+                    if (k > 0) ok = mp_wait_ge(sh, &sh.level_done[k - 1], 1);      // predecessor has left the root
+                    lap(2);
+                    if (!ok) break;
+                    int idx[R];
+                    bool changed = false;
+                    int vl[R];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const int i = lane + 64 * r, ii = i < A ? i : A - 1;
+                        vl[r] = sh.root_vl[ii];
+                        idx[r] = sh.root_idx[ii];
+                        changed |= vl[r] != c_vl[r];
+                    }
+                    if (__any(changed)) {
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+                            if (vl[r] != c_vl[r]) {
+                                c_vl[r] = vl[r];
+                                const int cnt = r_vis[r] + vl[r];
+                                c_q[r] = cnt != 0 ? r_vsum[r] / (double)cnt : 0.0;
+                                sc[r] = c_q[r] + psq[r] / (double)(cnt + 1);
+                            }
+                    }
+                    double best = 0.0;
+                    int best_i = -1;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const int i = lane + 64 * r;
+                        if (i < root_nc) {
+                            double v = sc[r];
+                            if (D.cgos && i == root_nc - 1) v -= 0.1;
+                            if (best_i < 0 || v > best) { best = v; best_i = i; }
+                        }
+                    }
+                    wave_argmax(best, best_i);
+                    const int owner = best_i & 63, oslot = best_i >> 6;
+                    int my_move = 0, my_child = 0, my_cnt = 0, my_vl = 0;
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        if (r == oslot) { my_move = r_act[r]; my_child = idx[r]; my_cnt = r_vis[r] + vl[r]; my_vl = vl[r]; }
+                    const int src = __builtin_amdgcn_readfirstlane(owner);
+                    pick.edge = best_i;
+                    pick.move = __builtin_amdgcn_readlane(my_move, src);
+                    pick.child = __builtin_amdgcn_readlane(my_child, src);
+                    pick.count = __builtin_amdgcn_readlane(my_cnt, src);
+                    pick.edge_vl = __builtin_amdgcn_readlane(my_vl, src);
+                    pick.node_vl = 0;
+                    lap(3);
+                } else {
+                    lap(8);
+                    // predecessors still in flight: wait until each has chosen its node of this level, and until
+                    // it has left that node if it is this one
+                    for (int j = k - 1; ok && j > k - NSEL && j >= 0; --j) {
+                        const bool tracked = depth < kMpTrackDepth;
+                        const int v = mp_wait_val(sh, &sh.level_done[j], tracked ? depth : depth + 1);
+                        ok = v >= 0;
+                        if (ok && v == depth && sh.lvl_node[j % kRing][depth] == node)
+                            ok = mp_wait_ge(sh, &sh.level_done[j], depth + 1);
+                    }
+                    lap(4);
+                    if (ok && node >= n0) ok = mp_wait_ge(sh, &sh.done[sh.jobof[node - n0]], 1);   // expansion in flight?
+                    lap(5);
+                    if (!ok) break;
+                    ns = (size_t)t * D.N + node;
+                    base = ns * A;
+                    pick = select_puct<S>(D, t, node, lane);
+                    lap(6);
+                }
+                const int e = pick.edge;
+                const int mv = pick.move;
+                if (depth >= kPipeMaxDepth) { ok = false; break; }
+                if (lane == 0) {
+                    sh.moves[slot][depth] = (int16_t)mv;
+                    if (depth == 0) {
+                        sh.root_vl[e] = pick.edge_vl + 1;
+                    } else {
+                        D.n_vl[ns] = pick.node_vl + 1;                             // node.py:76-83
+                        D.ch_vl[base + e] = pick.edge_vl + 1;
+                    }
+                    if (depth < kPathCap) D.q_path[((size_t)t * D.K + k) * kPathCap + depth] = (node << 10) | e;
+                }
+                ++depth;
+                prevprev = prev;
+                prev = mv;
+                ++moves;
+                // two consecutive passes: never descend below (tree.py:224-229)
+                const bool two_pass = moves > 2 && prev == 0 && prevprev == 0;
+                const int threshold = two_pass ? 10000000 : 1;
+                if (prof) pc[13] += 1;
+                if (pick.count + 1 < threshold + 1) {
+                    lap(8);
+                    if (k > 0) ok = mp_wait_ge(sh, &sh.level_done[k - 1], kMpDone); // node numbers in descent order
+                    lap(7);
+                    if (!ok) break;
+                    int num_nodes = sh.num_nodes, nexp = sh.nexp;
+                    int child = pick.child;
+                    const int expand = child == kNotExpanded;
+                    int xseq = 0;
+                    if (expand) {
+                        if (num_nodes >= D.N || num_nodes - n0 >= kPipeMaxK) { pool_full = true; ok = false; break; }
+                        child = num_nodes++;
+                        xseq = nexp++;
+                    }
+                    if (lane == 0) {
+                        if (expand) {
+                            D.ch_index[base + e] = child;
+                            if (node == 0) sh.root_idx[e] = child;
+                            sh.jobof[child - n0] = (int16_t)k;
+                            sh.num_nodes = num_nodes;
+                            sh.nexp = nexp;
+                        }
+                        PipeJob &j = sh.job[slot];
+                        j.k = k; j.parent = node; j.edge = e; j.child = child;
+                        j.expand = expand; j.xseq = xseq; j.depth = depth;
+                        D.q_node[(size_t)t * D.K + k] = child;
+                        D.q_pnode[(size_t)t * D.K + k] = node;
+                        D.q_pedge[(size_t)t * D.K + k] = e;
+                        D.q_depth[(size_t)t * D.K + k] = (depth <= kPathCap && D.N <= (1 << 21)) ? depth : 0;
+                        pipe_store(&sh.job_seq[slot], k + 1);
+                        pipe_store(&sh.level_done[k], kMpDone);
+                    }
+                    break;
+                }
+                node = pick.child;
+                if (lane == 0) {
+                    if (depth < kMpTrackDepth) my_nodes[depth] = node;
+                    if (depth == 1) mp_publish(&sh.level_done[k], depth);         // only LDS was written at the root
+                    else pipe_store(&sh.level_done[k], depth);
+                }
+            }
+            if (!ok) {
+                if (lane == 0 && !pipe_load(&sh.err)) {
+                    atomicOr(&D.err[t], pool_full ? kErrPoolFull : kErrPipeline);
+                    pipe_store(&sh.err, 1);
+                }
+                break;
+            }
+        }
+    } else {
+        // ---- workers: job k on wave k % NWRK --------------------------------------------------
+        const int w = wid - NSEL;
+        Lds<S> &L = sh.board[w];
+        BoardScalars rootb;
+        int root_to_move;
+        load_root<S>(L, rootb, root_to_move, D, t, lane);
+        for (int k = w; active && k < max_leaves; k += NWRK) {
+            const int slot = k % kMpSlots;
+            lap(12);
+            const bool have = mp_wait_ge(sh, &sh.job_seq[slot], k + 1);
+            lap(9);
+            if (!have) {
+                if (lane == 0 && !pipe_load(&sh.err)) {
+                    atomicOr(&D.err[t], kErrPipeline);
+                    pipe_store(&sh.err, 1);
+                }
+                break;
+            }
+            const PipeJob j = sh.job[slot];
+            reset_work<S>(L, lane);
+            BoardScalars b = rootb;
+            int c = root_to_move;
+            for (int i = 0; i < j.depth; ++i) {
+                put_stone<S>(L, b, sh.moves[slot][i], c, D.zob, lane);
+                c = 3 - c;
+            }
+            lap(10);
+            if (j.expand) expand_node_pipe<S>(L, b, c, D, t, j.child, j.parent, j.edge, j.xseq, sh, lane);
+            lap(11);
+            write_planes<S>(L, b, c, planes + ((size_t)t * max_leaves + k) * 6 * G::P, lane);
+            wave_sync();
+            if (lane == 0) {
+                pipe_store(&sh.done[k], 1);                                        // releases the node arrays
+                pipe_store(&sh.slot_done[slot], k / kMpSlots + 1);
+            }
+        }
+    }
+    if (prof && lane == 0)
+        for (int i = 0; i < 14; ++i) atomicAdd(reinterpret_cast<unsigned long long *>(D.prof + i), (unsigned long long)pc[i]);
+    __syncthreads();
+    const bool good = active && !sh.err;
+    if (good) {
+        // the root's virtual losses (max_leaves descents, one each) reach the pool here
+        for (int i = threadIdx.x; i < A; i += NTHR) D.ch_vl[root_base + i] = sh.root_vl[i];
+        if (threadIdx.x == 0) D.n_vl[root_ns] += max_leaves;
+    }
+    if (threadIdx.x == 0) {
+        D.meta[t].num_nodes = sh.num_nodes;
+        D.n_leaves[t] = good ? max_leaves : 0;
+        D.rng_cursor[t] = sh.cursor_val;
+    }
+}
+
+template <int S, int NSEL, int NWRK>
+int launch_mpipe_cfg(const SearchDev &dev, int max_leaves, float *planes, hipStream_t st) {
+    constexpr size_t lds = sizeof(MPipeShared<S, NSEL, NWRK>);
+    static_assert(lds <= 160 * 1024, "LDS");
+    static bool configured = false;
+    if (!configured) {
+        TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&select_puct_mpipe_kernel<S, NSEL, NWRK>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = true;
+    }
+    hipLaunchKernelGGL((select_puct_mpipe_kernel<S, NSEL, NWRK>), dim3(dev.T), dim3(64 * (NSEL + NWRK)), lds, st, dev,
+                       max_leaves, planes);
+    return TG_OK;
+}
+
+template <int S>
+int launch_mpipe(const SearchDev &dev, int max_leaves, float *planes, hipStream_t st) {
+    static const int cfg = getenv("TG_MPIPE_CFG") ? atoi(getenv("TG_MPIPE_CFG")) : 0;    // tuning knob: selectors * 100 + workers
+    if constexpr (S == 9) {
+        if (cfg == 404) return launch_mpipe_cfg<S, 4, 4>(dev, max_leaves, planes, st);
+        if (cfg == 208) return launch_mpipe_cfg<S, 2, 8>(dev, max_leaves, planes, st);
+        if (cfg == 412) return launch_mpipe_cfg<S, 4, 12>(dev, max_leaves, planes, st);
+        if (cfg == 608) return launch_mpipe_cfg<S, 6, 8>(dev, max_leaves, planes, st);
+        if (cfg == 610) return launch_mpipe_cfg<S, 6, 10>(dev, max_leaves, planes, st);
+        if (cfg == 808) return launch_mpipe_cfg<S, 8, 8>(dev, max_leaves, planes, st);
+        return launch_mpipe_cfg<S, 4, 8>(dev, max_leaves, planes, st);
+    }
+    return launch_mpipe_cfg<S, 4, 4>(dev, max_leaves, planes, st);
 }
 
 // tree.py:273-315 process_mini_batch for the leaves queued by the preceding kernel.
@@ -2093,8 +2471,15 @@ int tg_search_select_puct(tg_search *s, int max_leaves, float *planes_dev, int32
     // 1.8x for one tree, still +0.4 % with 2048 trees per GPU (measured); TG_SELECT_SERIAL=1 keeps
     // the one-wavefront kernel (also used while the per-phase profile counters are on)
     static const bool force_serial = getenv("TG_SELECT_SERIAL") != nullptr;
-    const bool pipelined = !force_serial && !s->dev.prof && max_leaves <= kPipeMaxK;
-    if (pipelined) {
+    static const bool mpipe_prof = getenv("TG_MPIPE_PROF") != nullptr;     // phase counters of the multi-selector kernel
+    const bool pipelined = !force_serial && (!s->dev.prof || mpipe_prof) && max_leaves <= kPipeMaxK;
+    // few trees: the descents themselves are pipelined over four selector waves (+ four workers); with many
+    // trees per CU the three-wave kernel keeps more trees resident
+    static const int mpipe_max_trees = getenv("TG_SELECT_MPIPE_TREES") ? atoi(getenv("TG_SELECT_MPIPE_TREES")) : 256;
+    if (pipelined && s->dev.T <= mpipe_max_trees) {
+        int rc = s->S == 9 ? launch_mpipe<9>(s->dev, max_leaves, planes_dev, st) : launch_mpipe<19>(s->dev, max_leaves, planes_dev, st);
+        if (rc) return rc;
+    } else if (pipelined) {
         if (s->S == 9)
             hipLaunchKernelGGL(select_puct_pipe_kernel<9>, dim3(s->dev.T), dim3(192), 0, st, s->dev, max_leaves, planes_dev);
         else
