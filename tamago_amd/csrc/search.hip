@@ -169,6 +169,28 @@ __device__ __forceinline__ double read_lane_f64(double v, int src_lane) {
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+// np.argmax over per-lane candidates (idx < 0: none): the maximum by a max butterfly inside each row of 16 lanes
+// (DPP) and a v_readlane of the four row results, then the lowest index among the lanes that hold it the same
+// way.  ~40 instructions and no branches; the compare-and-swap butterfly above costs ~150 with its exec-mask
+// juggling.  Returns the wave-uniform winner (-1: no candidate).  All 64 lanes must be active.
+__device__ __forceinline__ int wave_argmax_first(double val, int idx) {
+    double m = idx >= 0 ? val : -__builtin_inf();
+    m = __builtin_fmax(m, lane_partner_f64<0>(m));
+    m = __builtin_fmax(m, lane_partner_f64<1>(m));
+    m = __builtin_fmax(m, lane_partner_f64<2>(m));
+    m = __builtin_fmax(m, lane_partner_f64<3>(m));
+    const double mx = __builtin_fmax(__builtin_fmax(read_lane_f64(m, 0), read_lane_f64(m, 16)),
+                                     __builtin_fmax(read_lane_f64(m, 32), read_lane_f64(m, 48)));
+    int c = (idx >= 0 && val == mx) ? idx : 0x7fffffff;
+    c = min(c, lane_partner_i32<0>(c));
+    c = min(c, lane_partner_i32<1>(c));
+    c = min(c, lane_partner_i32<2>(c));
+    c = min(c, lane_partner_i32<3>(c));
+    const int w = min(min(__builtin_amdgcn_readlane(c, 0), __builtin_amdgcn_readlane(c, 16)),
+                      min(__builtin_amdgcn_readlane(c, 32), __builtin_amdgcn_readlane(c, 48)));
+    return w == 0x7fffffff ? -1 : w;
+}
+
 // ---- board in LDS ------------------------------------------------------------------------
 struct BoardScalars {
     uint64_t hash;
@@ -360,10 +382,12 @@ __device__ int gen_candidates(Lds<S> &L, const BoardScalars &b, int me, const Se
         bool keep = false;
         bool slow = false;          // self-atari needs the exact liberty-union count
         int fr[4] = {0, 0, 0, 0};
+        int col[4] = {0, 0, 0, 0}, sid[4] = {0, 0, 0, 0}, lib[4] = {0, 0, 0, 0};
+        int ne = 0;
+        bool legal = false;
+        uint64_t h = 0;
         if (q < P && L.color[p] == kEmpty) {
             const int nn[4] = {p - W, p - 1, p + 1, p + W};
-            int col[4], sid[4], lib[4];
-            int ne = 0;
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
                 col[d] = L.color[nn[d]];
@@ -378,10 +402,10 @@ __device__ int gen_candidates(Lds<S> &L, const BoardScalars &b, int me, const Se
                 if (col[d] == opp && lib[d] == 1) suicide = false;
                 if (col[d] == me && lib[d] > 1) suicide = false;
             }
-            bool legal = !(ne == 0 && suicide);
+            legal = !(ne == 0 && suicide);
             if (b.ko_pos == p && b.ko_move == b.moves - 1) legal = false;
             if (legal && D.superko) {
-                uint64_t h = b.hash ^ D.zob[me * NC + p];
+                h = b.hash ^ D.zob[me * NC + p];
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
                     bool dup = false;
@@ -389,13 +413,29 @@ __device__ int gen_candidates(Lds<S> &L, const BoardScalars &b, int me, const Se
                     for (int e = 0; e < d; ++e) dup |= sid[e] == sid[d];
                     if (sid[d] && !dup && lib[d] == 1) h ^= L.strhash[sid[d]];
                 }
-                // record.has_same_hash scans the whole fixed array; unused slots are 0 and
-                // slot 0 is never written, so comparing with slots [0, moves) is equivalent
-                const int hl = b.moves < G::HMAX ? b.moves : G::HMAX;
-                for (int i = 0; i < hl; ++i)
-                    if (L.hist[i] == h) { legal = false; break; }
             }
-            if (legal) {
+        }
+        if (D.superko) {
+            // record.has_same_hash scans the whole fixed array; unused slots are 0 and slot 0 is never
+            // written, so comparing with slots [0, moves) is equivalent.  Wave-uniform loop, four
+            // uniform-address reads per round and no early exit: the reads pipeline (a per-lane loop
+            // with a break paid one LDS round trip per history entry - 10 k cycles at move 100).
+            const int hl = b.moves < G::HMAX ? b.moves : G::HMAX;
+            bool seen = false;
+            for (int i = 0; i < hl; i += 4) {
+                const uint64_t a0 = L.hist[i];
+                const uint64_t a1 = L.hist[i + 1 < G::HMAX ? i + 1 : i];
+                const uint64_t a2 = L.hist[i + 2 < G::HMAX ? i + 2 : i];
+                const uint64_t a3 = L.hist[i + 3 < G::HMAX ? i + 3 : i];
+                seen |= a0 == h;
+                seen |= i + 1 < hl && a1 == h;
+                seen |= i + 2 < hl && a2 == h;
+                seen |= i + 3 < hl && a3 == h;
+            }
+            if (seen) legal = false;
+        }
+        if (legal) {
+            {
                 // self-atari size (go_board.py:327-365); only "< 7" matters
                 if (ne <= 1) {
                     int size = 0;
@@ -465,6 +505,34 @@ __device__ int gen_candidates(Lds<S> &L, const BoardScalars &b, int me, const Se
     return n + 1;
 }
 
+// e_0 + e_1 + ... + e_{n-1} in exactly that order (numpy's dirichlet), addend i held by lane i % 64 in v[i / 64].
+// v_readlane moves the addends into scalar registers independently of the running sum, so only the n dependent
+// float64 adds are on the critical path and nothing goes through LDS (staging the addends there and reading
+// them back eight at a time cost 5.8 k cycles for 82 addends).  Blocks of eight; a block past n is skipped, the
+// tail of the last block adds +0.0, which leaves a positive sum unchanged.
+template <int R>
+__device__ __forceinline__ double sequential_sum(const double (&v)[R], int n) {
+    const int lane = threadIdx.x & 63;
+    double z[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) z[r] = lane + 64 * r < n ? v[r] : 0.0;
+    double acc = 0.0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int l0 = 0; l0 < 64; l0 += 8) {
+            if (64 * r + l0 < n) {                                  // wave-uniform
+                double x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x[u] = read_lane_f64(z[r], l0 + u);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += x[u];
+            }
+        }
+    }
+    return acc;
+}
+
 // tree.py:247-270 expand_node + node.py:41-73: returns the new node index (or -1 on error).
 template <int S>
 __device__ int expand_node(Lds<S> &L, const BoardScalars &b, int to_move, const SearchDev &D, int t,
@@ -500,24 +568,8 @@ __device__ int expand_node(Lds<S> &L, const BoardScalars &b, int to_move, const 
         if (lane == 0) atomicOr(&D.err[t], kErrRngEmpty);
         return -1;
     }
-    // sequential sum e_0 + e_1 + ... exactly like numpy's dirichlet.  The addends go through
-    // LDS: uniform-address ds_reads are independent of the running sum, so they pipeline and
-    // only the 82 (362) dependent float64 adds remain on the critical path.
-    double *stage = reinterpret_cast<double *>(L.strhash);     // free after gen_candidates
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-        if (lane + 64 * r < n) stage[lane + 64 * r] = mine[r];
-    wave_sync();
-    double acc = 0.0;
-    {
-        int i = 0;
-        for (; i + 8 <= n; i += 8) {
-            const double v0 = stage[i], v1 = stage[i + 1], v2 = stage[i + 2], v3 = stage[i + 3];
-            const double v4 = stage[i + 4], v5 = stage[i + 5], v6 = stage[i + 6], v7 = stage[i + 7];
-            acc += v0; acc += v1; acc += v2; acc += v3; acc += v4; acc += v5; acc += v6; acc += v7;
-        }
-        for (; i < n; ++i) acc += stage[i];
-    }
+    // sequential sum e_0 + e_1 + ... exactly like numpy's dirichlet
+    const double acc = sequential_sum<R>(mine, n);
     const double inv = 1.0 / acc;
     lap(9);
     const size_t base = ((size_t)t * D.N + node) * A;
@@ -617,7 +669,7 @@ __device__ EdgePick select_puct(const SearchDev &D, int t, int node, int lane) {
         }
     }
     (void)best_r;
-    wave_argmax(best, best_i);
+    best_i = wave_argmax_first(best, best_i);
     const int owner = best_i & 63, slot = best_i >> 6;
     int my_move = 0, my_child = 0, my_cnt = 0, my_vl = 0;
 #pragma unroll
@@ -843,21 +895,7 @@ __device__ bool expand_node_pipe(Lds<S> &L, const BoardScalars &b, int to_move, 
         mine[r] = e[at];
     }
     // sequential sum e_0 + e_1 + ... exactly like numpy's dirichlet (see expand_node)
-    double *stage = reinterpret_cast<double *>(L.strhash);
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-        if (lane + 64 * r < n) stage[lane + 64 * r] = mine[r];
-    wave_sync();
-    double acc = 0.0;
-    {
-        int i = 0;
-        for (; i + 8 <= n; i += 8) {
-            const double v0 = stage[i], v1 = stage[i + 1], v2 = stage[i + 2], v3 = stage[i + 3];
-            const double v4 = stage[i + 4], v5 = stage[i + 5], v6 = stage[i + 6], v7 = stage[i + 7];
-            acc += v0; acc += v1; acc += v2; acc += v3; acc += v4; acc += v5; acc += v6; acc += v7;
-        }
-        for (; i < n; ++i) acc += stage[i];
-    }
+    const double acc = sequential_sum<R>(mine, n);
     const double inv = 1.0 / acc;
     const size_t base = ((size_t)t * D.N + node) * A;
 #pragma unroll
@@ -1111,6 +1149,7 @@ __global__ __launch_bounds__(64 * (NSEL + NWRK)) void select_puct_mpipe_kernel(S
     Shared &sh = *reinterpret_cast<Shared *>(mp_smem);
     const int t = blockIdx.x;
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long t_begin = (D.prof && t == 0) ? (long long)__builtin_amdgcn_s_memtime() : 0;
     const RootMeta meta = D.meta[t];
     const int n0 = meta.num_nodes;
     const size_t root_ns = (size_t)t * D.N, root_base = root_ns * A;
@@ -1135,7 +1174,7 @@ __global__ __launch_bounds__(64 * (NSEL + NWRK)) void select_puct_mpipe_kernel(S
     __syncthreads();
     // per-phase s_memtime accumulators of tree 0 (tg_search_profile with TG_MPIPE_PROF=1; tools/profile_select.py)
     const bool prof = D.prof && t == 0;
-    long long pc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long pc[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long tp = prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
     auto lap = [&](int i) {
         if (prof) { const long long now = (long long)__builtin_amdgcn_s_memtime(); pc[i] += now - tp; tp = now; }
@@ -1171,7 +1210,7 @@ __global__ __launch_bounds__(64 * (NSEL + NWRK)) void select_puct_mpipe_kernel(S
             bool ok = mp_wait_ge(sh, &sh.slot_done[slot], k / kMpSlots);          // ring slot free again
             lap(0);
             int node = 0, depth = 0;
-            int moves = meta.moves, prev = meta.prev, prevprev = meta.prevprev;
+            int moves = meta.moves, prev = meta.prev;
             bool pool_full = false;
             while (ok) {
                 EdgePick pick;
@@ -1179,27 +1218,36 @@ __global__ __launch_bounds__(64 * (NSEL + NWRK)) void select_puct_mpipe_kernel(S
                 if (depth == 0) {
                     // every descent before this one has added one virtual loss to the root (node.py:76-83)
                     const double sq = __dsqrt_rn((double)(root_total0 + k + 1));
-                    double psq[R], sc[R];
+                    // scores for "virtual loss as this wave last saw it" and for "one more" (what one intervening
+                    // descent leaves behind) - all the divisions happen before the wait
+                    double psq[R], sc[R], sc1[R], q1[R];
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
+                        const int cnt = r_vis[r] + c_vl[r];
                         psq[r] = r_pol[r] * sq;
-                        sc[r] = c_q[r] + psq[r] / (double)(r_vis[r] + c_vl[r] + 1);
+                        sc[r] = c_q[r] + psq[r] / (double)(cnt + 1);
+                        q1[r] = r_vsum[r] / (double)(cnt + 1);
+                        sc1[r] = q1[r] + psq[r] / (double)(cnt + 2);
+                        // keep the arithmetic on this side of the wait (hipcc would sink it to its first use)
+                        asm volatile("" : "+v"(sc[r]), "+v"(sc1[r]), "+v"(q1[r]), "+v"(psq[r]));
                     }
                     lap(1);
                     if (k > 0) ok = mp_wait_ge(sh, &sh.level_done[k - 1], 1);      // predecessor has left the root
                     lap(2);
                     if (!ok) break;
                     int idx[R];
-                    bool changed = false;
+                    bool slow = false;
                     int vl[R];
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         const int i = lane + 64 * r, ii = i < A ? i : A - 1;
                         vl[r] = sh.root_vl[ii];
                         idx[r] = sh.root_idx[ii];
-                        changed |= vl[r] != c_vl[r];
+                        const int d = vl[r] - c_vl[r];
+                        if (d == 1) { sc[r] = sc1[r]; c_q[r] = q1[r]; c_vl[r] = vl[r]; }
+                        slow |= d != 0 && d != 1;
                     }
-                    if (__any(changed)) {
+                    if (__any(slow)) {                                         // several descents through one child
 #pragma unroll
                         for (int r = 0; r < R; ++r)
                             if (vl[r] != c_vl[r]) {
@@ -1220,7 +1268,7 @@ __global__ __launch_bounds__(64 * (NSEL + NWRK)) void select_puct_mpipe_kernel(S
                             if (best_i < 0 || v > best) { best = v; best_i = i; }
                         }
                     }
-                    wave_argmax(best, best_i);
+                    best_i = wave_argmax_first(best, best_i);
                     const int owner = best_i & 63, oslot = best_i >> 6;
                     int my_move = 0, my_child = 0, my_cnt = 0, my_vl = 0;
 #pragma unroll
@@ -1257,25 +1305,32 @@ __global__ __launch_bounds__(64 * (NSEL + NWRK)) void select_puct_mpipe_kernel(S
                 const int e = pick.edge;
                 const int mv = pick.move;
                 if (depth >= kPipeMaxDepth) { ok = false; break; }
+                // two consecutive passes: never descend below (tree.py:224-229)
+                const bool two_pass = moves + 1 > 2 && mv == 0 && prev == 0;
+                const int threshold = two_pass ? 10000000 : 1;
+                const bool leaf = pick.count + 1 < threshold + 1;
                 if (lane == 0) {
-                    sh.moves[slot][depth] = (int16_t)mv;
                     if (depth == 0) {
                         sh.root_vl[e] = pick.edge_vl + 1;
                     } else {
                         D.n_vl[ns] = pick.node_vl + 1;                             // node.py:76-83
                         D.ch_vl[base + e] = pick.edge_vl + 1;
                     }
+                    // the successors may have this node as soon as the virtual loss is in place (a descent that ends
+                    // here publishes when its leaf is queued: the child index has to be there first)
+                    if (!leaf) {
+                        if (depth + 1 < kMpTrackDepth) my_nodes[depth + 1] = pick.child;
+                        if (depth == 0) mp_publish(&sh.level_done[k], 1);         // only LDS was written at the root
+                        else pipe_store(&sh.level_done[k], depth + 1);
+                    }
+                    sh.moves[slot][depth] = (int16_t)mv;
                     if (depth < kPathCap) D.q_path[((size_t)t * D.K + k) * kPathCap + depth] = (node << 10) | e;
                 }
                 ++depth;
-                prevprev = prev;
                 prev = mv;
                 ++moves;
-                // two consecutive passes: never descend below (tree.py:224-229)
-                const bool two_pass = moves > 2 && prev == 0 && prevprev == 0;
-                const int threshold = two_pass ? 10000000 : 1;
                 if (prof) pc[13] += 1;
-                if (pick.count + 1 < threshold + 1) {
+                if (leaf) {
                     lap(8);
                     if (k > 0) ok = mp_wait_ge(sh, &sh.level_done[k - 1], kMpDone); // node numbers in descent order
                     lap(7);
@@ -1310,11 +1365,6 @@ __global__ __launch_bounds__(64 * (NSEL + NWRK)) void select_puct_mpipe_kernel(S
                     break;
                 }
                 node = pick.child;
-                if (lane == 0) {
-                    if (depth < kMpTrackDepth) my_nodes[depth] = node;
-                    if (depth == 1) mp_publish(&sh.level_done[k], depth);         // only LDS was written at the root
-                    else pipe_store(&sh.level_done[k], depth);
-                }
             }
             if (!ok) {
                 if (lane == 0 && !pipe_load(&sh.err)) {
@@ -1331,6 +1381,7 @@ __global__ __launch_bounds__(64 * (NSEL + NWRK)) void select_puct_mpipe_kernel(S
         BoardScalars rootb;
         int root_to_move;
         load_root<S>(L, rootb, root_to_move, D, t, lane);
+        lap(14);
         for (int k = w; active && k < max_leaves; k += NWRK) {
             const int slot = k % kMpSlots;
             lap(12);
@@ -1363,7 +1414,7 @@ __global__ __launch_bounds__(64 * (NSEL + NWRK)) void select_puct_mpipe_kernel(S
         }
     }
     if (prof && lane == 0)
-        for (int i = 0; i < 14; ++i) atomicAdd(reinterpret_cast<unsigned long long *>(D.prof + i), (unsigned long long)pc[i]);
+        for (int i = 0; i < 15; ++i) atomicAdd(reinterpret_cast<unsigned long long *>(D.prof + i), (unsigned long long)pc[i]);
     __syncthreads();
     const bool good = active && !sh.err;
     if (good) {
@@ -1371,6 +1422,7 @@ __global__ __launch_bounds__(64 * (NSEL + NWRK)) void select_puct_mpipe_kernel(S
         for (int i = threadIdx.x; i < A; i += NTHR) D.ch_vl[root_base + i] = sh.root_vl[i];
         if (threadIdx.x == 0) D.n_vl[root_ns] += max_leaves;
     }
+    if (prof && threadIdx.x == 0) D.prof[15] += (long long)__builtin_amdgcn_s_memtime() - t_begin;
     if (threadIdx.x == 0) {
         D.meta[t].num_nodes = sh.num_nodes;
         D.n_leaves[t] = good ? max_leaves : 0;
@@ -1395,17 +1447,21 @@ int launch_mpipe_cfg(const SearchDev &dev, int max_leaves, float *planes, hipStr
 
 template <int S>
 int launch_mpipe(const SearchDev &dev, int max_leaves, float *planes, hipStream_t st) {
-    static const int cfg = getenv("TG_MPIPE_CFG") ? atoi(getenv("TG_MPIPE_CFG")) : 0;    // tuning knob: selectors * 100 + workers
+    // selectors * 100 + workers (TG_MPIPE_CFG: tuning knob).  9x9: 16 wavefronts; 19x19: a worker's board is 25 KB of LDS
+    static const int cfg = getenv("TG_MPIPE_CFG") ? atoi(getenv("TG_MPIPE_CFG")) : 0;
     if constexpr (S == 9) {
         if (cfg == 404) return launch_mpipe_cfg<S, 4, 4>(dev, max_leaves, planes, st);
-        if (cfg == 208) return launch_mpipe_cfg<S, 2, 8>(dev, max_leaves, planes, st);
+        if (cfg == 408) return launch_mpipe_cfg<S, 4, 8>(dev, max_leaves, planes, st);
         if (cfg == 412) return launch_mpipe_cfg<S, 4, 12>(dev, max_leaves, planes, st);
-        if (cfg == 608) return launch_mpipe_cfg<S, 6, 8>(dev, max_leaves, planes, st);
-        if (cfg == 610) return launch_mpipe_cfg<S, 6, 10>(dev, max_leaves, planes, st);
         if (cfg == 808) return launch_mpipe_cfg<S, 8, 8>(dev, max_leaves, planes, st);
-        return launch_mpipe_cfg<S, 4, 8>(dev, max_leaves, planes, st);
+        return launch_mpipe_cfg<S, 6, 10>(dev, max_leaves, planes, st);
+    } else {
+        if (cfg == 404) return launch_mpipe_cfg<S, 4, 4>(dev, max_leaves, planes, st);
+        if (cfg == 405) return launch_mpipe_cfg<S, 4, 5>(dev, max_leaves, planes, st);
+        if (cfg == 605) return launch_mpipe_cfg<S, 6, 5>(dev, max_leaves, planes, st);
+        if (cfg == 805) return launch_mpipe_cfg<S, 8, 5>(dev, max_leaves, planes, st);
+        return launch_mpipe_cfg<S, 4, 4>(dev, max_leaves, planes, st);
     }
-    return launch_mpipe_cfg<S, 4, 4>(dev, max_leaves, planes, st);
 }
 
 // tree.py:273-315 process_mini_batch for the leaves queued by the preceding kernel.
@@ -1656,7 +1712,7 @@ __device__ int select_root_halving(const SearchDev &D, int t, int node, int coun
             if (best_i < 0 || sc > best) { best = sc; best_i = i; }
         }
     }
-    wave_argmax(best, best_i);
+    best_i = wave_argmax_first(best, best_i);
     return best_i;
 }
 
@@ -1741,7 +1797,7 @@ __device__ int select_node_halving(Scratch &L, const SearchDev &D, int t, int no
         }
     }
     wave_sync();
-    wave_argmax(best, best_i);
+    best_i = wave_argmax_first(best, best_i);
     return best_i;
 }
 
@@ -1869,7 +1925,7 @@ __global__ __launch_bounds__(192) void select_gumbel_pipe_kernel(SearchDev D, co
                                 if (best_i < 0 || sc > best) { best = sc; best_i = i; }
                             }
                         }
-                        wave_argmax(best, best_i);
+                        best_i = wave_argmax_first(best, best_i);
                         e = best_i;
                         const int owner = __builtin_amdgcn_readfirstlane(e & 63), rr = e >> 6;
                         int m_mv = 0, m_vis = 0, m_idx = 0;

@@ -36,3 +36,4 @@ print(f"  selector  total {tot/d:.0f} per descent over all selector waves")
 wt = sum(cyc[i] for i in wrk)
 for i, nme in wrk.items():
     print(f"  worker    {nme:58s} {cyc[i]/d:8.0f}  {100*cyc[i]/wt:5.1f} %")
+print(f"per launch: kernel {cyc[15]/n:.0f} ticks = {cyc[15]/n/d*n:.0f} per descent; workers' root set-up (sum over workers) {cyc[14]/n:.0f}")
