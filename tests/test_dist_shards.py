@@ -56,3 +56,49 @@ def test_shard_indices_properties():
             assert [g for p in parts for g in p] == list(range(n))
             sizes = [len(p) for p in parts]
             assert max(sizes) - min(sizes) <= 1
+
+
+LAUNCHER = r'''
+import json, os, sys
+sys.path.insert(0, os.environ["TG_REPO"])
+from tamago_amd.selfplay import main as launcher
+from tamago_amd.selfplay.worker import shard_indices
+
+def fake_shard(args, rank, world, local_rank, record_dir):
+    # what run_shard reports, without a GPU: this rank's block of game indices
+    assert os.path.isdir(record_dir)
+    mine = shard_indices(list(range(1, args.num_data + 1)), world, rank)
+    open(os.path.join(record_dir, f"rank{rank}.txt"), "w").write(" ".join(map(str, mine)))
+    return {"games": len(mine), "moves": 10 * len(mine), "leaf_evals": 401 * 10 * len(mine), "seconds": 0.5 + rank,
+            "rank": rank, "device": local_rank, "host_cores": launcher.pin_host_threads(local_rank, world),
+            "first": mine[0], "last": mine[-1]}
+
+launcher.run_shard = fake_shard
+result = launcher.main(["--save-dir", os.environ["TG_SAVE"], "--num-data", "11", "--visits", "400", "--boards", "64",
+                        "--size", "9", "--json"])
+if int(os.environ["RANK"]) == 0:
+    assert result["shards"] == 2 and result["games"] == 11 and result["leaf_evals"] == 401 * 110
+    assert result["seconds"] >= 1.5                      # slowest rank
+    assert sorted(s["rank"] for s in result["per_shard"]) == [0, 1]
+    print("LAUNCH-OK")
+'''
+
+
+def test_selfplay_launcher_two_ranks_gloo(tmp_path):
+    """The config[3] launcher under torch.distributed.run, world size 2, gloo: record directory chosen by rank 0
+    and broadcast, disjoint game blocks, aggregate over ranks, slowest rank's clock (the shard itself is stubbed -
+    the GPU run of the same launch is tests/test_gpu_fullsize.py)."""
+    script = tmp_path / "launch.py"
+    script.write_text(LAUNCHER)
+    save = tmp_path / "archive"
+    save.mkdir()
+    (save / "3").mkdir()                                   # existing record directories: next is 4
+    env = dict(os.environ, TG_REPO=REPO, TG_SAVE=str(save), MASTER_ADDR="127.0.0.1", MASTER_PORT="29573")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29573", str(script)],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "LAUNCH-OK" in out.stdout
+    r0 = (save / "4" / "rank0.txt").read_text().split()
+    r1 = (save / "4" / "rank1.txt").read_text().split()
+    assert [int(g) for g in r0 + r1] == list(range(1, 12))
