@@ -1632,21 +1632,34 @@ __global__ __launch_bounds__(64 * (1 + kPolicyWaves)) void backup_kernel(SearchD
 // numpy's float64 add.reduce order (pairwise_sum in numpy/core/src/umath/loops_utils.h.src):
 // < 8 elements sequential; <= 128 elements eight interleaved accumulators combined as
 // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) then the tail; larger arrays split in halves (multiple
-// of 8).  Every lane runs it redundantly on an LDS vector (wave-uniform result).
+// of 8).  The vector sits in LDS; the result is wave-uniform.  All 64 lanes call it with uniform arguments.
+// Accumulator j only ever sees a[j], a[8 + j], a[16 + j], ... in that order, so lane j (< 8) owns it: its up to
+// 15 LDS reads are independent and issued together, eight chains of dependent adds run side by side, the combine
+// is three DPP steps (fp addition commutes exactly, so the mirrored partners give the same sums).
 __device__ double np_sum_block(const double *a, int n) {
     if (n < 8) {
         double r = 0.;
         for (int i = 0; i < n; ++i) r += a[i];
         return r;
     }
-    double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
-    int i = 8;
-    for (; i < n - (n % 8); i += 8) {
-        r0 += a[i]; r1 += a[i + 1]; r2 += a[i + 2]; r3 += a[i + 3];
-        r4 += a[i + 4]; r5 += a[i + 5]; r6 += a[i + 6]; r7 += a[i + 7];
+    const int lane = threadIdx.x & 63;
+    const int n8 = n - (n % 8);
+    const int j = lane & 7;
+    double v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int i = 8 * k + j;
+        v[k] = a[i < n8 ? i : j];                     // clamped: never past the vector
     }
-    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
-    for (; i < n; ++i) res += a[i];
+    double r = v[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k)
+        if (8 * k < n8) r += v[k];                    // wave-uniform
+    r = r + lane_partner_f64<0>(r);                   // r0 + r1 | r2 + r3 | r4 + r5 | r6 + r7
+    r = r + lane_partner_f64<1>(r);                   // (r0 + r1) + (r2 + r3) | (r4 + r5) + (r6 + r7)
+    r = r + lane_partner_f64<2>(r);                   // lane i <-> 7 - i inside every group of eight
+    double res = read_lane_f64(r, 0);
+    for (int i = n8; i < n; ++i) res += a[i];
     return res;
 }
 __device__ double np_sum(const double *a, int n) {
@@ -1888,6 +1901,13 @@ __global__ __launch_bounds__(192) void select_gumbel_pipe_kernel(SearchDev D, co
         constexpr int kMemo = 64;
         __shared__ int memo_tag[kMemo], memo_edge[kMemo], memo_move[kMemo], memo_vis[kMemo], memo_child[kMemo];
         for (int i = lane; i < kMemo; i += 64) memo_tag[i] = -1;
+        // leaves already queued in this phase, by (parent node, edge): a sequential-halving phase sends max_count
+        // descents down every considered root child and they all end on the same leaf (the statistics do not move
+        // within a phase), i.e. on the same board - later ones are COPY jobs (planes of the first one's slot)
+        // instead of another replay of the path.  The network still evaluates every queued leaf.
+        constexpr int kLeafKeys = 64;
+        __shared__ int leaf_key[kLeafKeys], leaf_slot[kLeafKeys], leaf_job[kLeafKeys];
+        int n_keys = 0;
         wave_sync();
         auto publish = [&](int plane_slot, int parent, int edge, int child, int expand, int xseq, int depth) -> bool {
             if (jid >= kPipeMaxK) return false;
@@ -1973,7 +1993,19 @@ __global__ __launch_bounds__(192) void select_gumbel_pipe_kernel(SearchDev D, co
                             D.q_pedge[(size_t)t * D.K + queued] = e;
                             D.q_depth[(size_t)t * D.K + queued] = (depth <= kPathCap && D.N <= (1 << 21)) ? depth : 0;
                         }
-                        ok = publish(queued, node, e, child, 0, 0, depth);
+                        const int key = (node << 10) | e;
+                        const unsigned long long hit = __ballot(lane < n_keys && leaf_key[lane] == key);
+                        if (hit && D.N <= (1 << 21)) {
+                            const int f = __ffsll((long long)hit) - 1;
+                            ok = publish(queued, leaf_slot[f], e, leaf_job[f], 2, 0, 0);
+                        } else {
+                            if (n_keys < kLeafKeys) {
+                                if (lane == 0) { leaf_key[n_keys] = key; leaf_slot[n_keys] = queued; leaf_job[n_keys] = jid; }
+                                ++n_keys;
+                                wave_sync();
+                            }
+                            ok = publish(queued, node, e, child, 0, 0, depth);
+                        }
                         if (ok) ++queued;
                         break;
                     }
@@ -2040,15 +2072,27 @@ __global__ __launch_bounds__(192) void select_gumbel_pipe_kernel(SearchDev D, co
             }
             if (!have) break;
             const PipeJob j = sh.job[slot];
-            reset_work<S>(L, lane);
-            BoardScalars b = rootb;
-            int c = root_to_move;
-            for (int i = 0; i < j.depth; ++i) {
-                put_stone<S>(L, b, sh.moves[slot][i], c, D.zob, lane);
-                c = 3 - c;
+            if (j.expand == 2) {
+                // COPY: the planes of leaf slot j.parent (written by job j.child) are this leaf's planes
+                if (!pipe_wait_ge(&sh.done[j.child], 1)) {
+                    if (lane == 0) { atomicOr(&D.err[t], kErrPipeline); pipe_store(&sh.err, 1); }
+                    break;
+                }
+                static_assert((6 * G::P) % 2 == 0, "8-byte copies");
+                const float2 *src = reinterpret_cast<const float2 *>(planes + (leaf_base + j.parent) * 6 * G::P);
+                float2 *dst = reinterpret_cast<float2 *>(planes + (leaf_base + j.k) * 6 * G::P);
+                for (int i = lane; i < 3 * G::P; i += 64) dst[i] = src[i];
+            } else {
+                reset_work<S>(L, lane);
+                BoardScalars b = rootb;
+                int c = root_to_move;
+                for (int i = 0; i < j.depth; ++i) {
+                    put_stone<S>(L, b, sh.moves[slot][i], c, D.zob, lane);
+                    c = 3 - c;
+                }
+                if (j.expand) expand_node_pipe<S>(L, b, c, D, t, j.child, j.parent, j.edge, j.xseq, sh, lane);
+                if (j.k >= 0) write_planes<S>(L, b, c, planes + (leaf_base + j.k) * 6 * G::P, lane);
             }
-            if (j.expand) expand_node_pipe<S>(L, b, c, D, t, j.child, j.parent, j.edge, j.xseq, sh, lane);
-            if (j.k >= 0) write_planes<S>(L, b, c, planes + (leaf_base + j.k) * 6 * G::P, lane);
             wave_sync();
             if (lane == 0) {
                 pipe_store(&sh.done[k], 1);
@@ -2183,7 +2227,13 @@ struct tg_search {
     std::vector<uint8_t> st_dirty_tree;
     bool st_dirty = false;
     int32_t *phase_dev = nullptr;          // [num_considered | max_count | packed leaf offsets], T each
-    std::vector<int32_t> phase_host;
+    // pinned staging ring for the phase description: the host never waits for the copy of the current call, only
+    // (practically never) for the one kPhaseRing calls ago
+    static constexpr int kPhaseRing = 8;
+    int32_t *phase_pin = nullptr;
+    hipEvent_t phase_ev[kPhaseRing] = {};
+    bool phase_ev_used[kPhaseRing] = {};
+    unsigned phase_seq = 0;
     bool packed_leaves = false;
     int32_t *moves_dev = nullptr;
     // double-buffered random windows, uploaded on a private copy stream so that the host can
@@ -2343,6 +2393,10 @@ int tg_search_destroy(tg_search *s) {
     if (!s) return TG_OK;
     (void)hipSetDevice(s->cfg.device);
     for (void *p : s->allocs) (void)hipFree(p);
+    if (s->phase_pin) {
+        (void)hipHostFree(s->phase_pin);
+        for (int i = 0; i < tg_search::kPhaseRing; ++i) (void)hipEventDestroy(s->phase_ev[i]);
+    }
     for (int b = 0; b < 2; ++b) {
         if (s->rng_buf[b]) (void)hipFree(s->rng_buf[b]);
         if (s->ev_rng[b]) (void)hipEventDestroy(s->ev_rng[b]);
@@ -2733,16 +2787,23 @@ int tg_search_select_gumbel(tg_search *s, const int32_t *num_considered_host, co
         return tg::fail(TG_ERR_ARG, "tg_search_select_gumbel: slots_per_tree %d outside [1, batch_size]", slots_per_tree);
     const int T = s->dev.T;
     const int limit = packed ? s->dev.K : slots_per_tree;
-    // staging: [num_considered | max_count | leaf offsets]; member storage, reused per call
-    s->phase_host.resize(3 * (size_t)T);
+    // staging: [num_considered | max_count | leaf offsets] in a ring of pinned buffers (a pageable staging vector
+    // needed a stream synchronisation per phase: the host then waited for the previous phase's forward and backup)
+    if (!s->phase_pin) {
+        TG_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->phase_pin), (size_t)tg_search::kPhaseRing * 3 * T * sizeof(int32_t)));
+        for (int i = 0; i < tg_search::kPhaseRing; ++i) TG_HIP(hipEventCreateWithFlags(&s->phase_ev[i], hipEventDisableTiming));
+    }
+    const int ring = (int)(s->phase_seq % tg_search::kPhaseRing);
+    if (s->phase_ev_used[ring]) TG_HIP(hipEventSynchronize(s->phase_ev[ring]));
+    int32_t *phase_host = s->phase_pin + (size_t)ring * 3 * T;
     int64_t total = 0;
     for (int t = 0; t < T; ++t) {
         const int64_t n = (int64_t)num_considered_host[t] * max_count_host[t];
         if (num_considered_host[t] < 0 || max_count_host[t] < 0 || n > limit)
             return tg::fail(TG_ERR_ARG, "tg_search_select_gumbel: tree %d phase does not fit %d slots", t, limit);
-        s->phase_host[t] = num_considered_host[t];
-        s->phase_host[T + t] = max_count_host[t];
-        s->phase_host[2 * (size_t)T + t] = (int32_t)total;
+        phase_host[t] = num_considered_host[t];
+        phase_host[T + t] = max_count_host[t];
+        phase_host[2 * (size_t)T + t] = (int32_t)total;
         total += n;
     }
     if (total > (int64_t)T * s->dev.K)
@@ -2753,9 +2814,10 @@ int tg_search_select_gumbel(tg_search *s, const int32_t *num_considered_host, co
         int rc = dev_alloc(s, &s->phase_dev, (size_t)3 * T);
         if (rc) return rc;
     }
-    TG_HIP(hipMemcpyAsync(s->phase_dev, s->phase_host.data(), s->phase_host.size() * sizeof(int32_t),
-                          hipMemcpyHostToDevice, st));
-    TG_HIP(hipStreamSynchronize(st));     // the staging vector is rewritten by the next call
+    TG_HIP(hipMemcpyAsync(s->phase_dev, phase_host, (size_t)3 * T * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    TG_HIP(hipEventRecord(s->phase_ev[ring], st));
+    s->phase_ev_used[ring] = true;
+    s->phase_seq += 1;
     {
         int rc = install_rng(s, st);
         if (rc) return rc;
