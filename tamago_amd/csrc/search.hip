@@ -197,12 +197,13 @@ struct BoardScalars {
     int moves, ko_pos, ko_move, prev, prevprev;
 };
 
-template <int S>
+// HALVING = false drops the two softmax scratch vectors that only the one-wave Gumbel kernel keeps in its board
+template <int S, bool HALVING = true>
 struct Lds {
     using G = Geo<S>;
     uint64_t hist[G::HMAX];
-    double w1[G::A + 7];
-    double w2[G::A + 7];
+    double w1[HALVING ? G::A + 7 : 1];
+    double w2[HALVING ? G::A + 7 : 1];
     uint64_t strhash[G::NC];
     uint32_t libcnt[G::NC];
     uint32_t strsize[G::NC];
@@ -214,15 +215,15 @@ struct Lds {
     int32_t scratch[8];
 };
 
-template <int S>
-__device__ __forceinline__ bool touches(const Lds<S> &L, int p, int id) {
+template <int S, typename LT>
+__device__ __forceinline__ bool touches(const LT &L, int p, int id) {
     constexpr int W = Geo<S>::W;
     return L.sid[p - W] == id || L.sid[p - 1] == id || L.sid[p + 1] == id || L.sid[p + W] == id;
 }
 
 // go_board.py:131-185 on the LDS board.  All 64 lanes call it with wave-uniform arguments.
-template <int S>
-__device__ void put_stone(Lds<S> &L, BoardScalars &b, int pos, int c, const uint64_t *zob, int lane) {
+template <int S, typename LT>
+__device__ void put_stone(LT &L, BoardScalars &b, int pos, int c, const uint64_t *zob, int lane) {
     using G = Geo<S>;
     constexpr int W = G::W, NC = G::NC;
     if (pos == 0) {                                   // PASS: record only (go_board.py:138-141)
@@ -320,8 +321,8 @@ __device__ void label_strings(uint8_t *color, uint16_t *sid, int lane) {
     }
 }
 
-template <int S>
-__device__ __forceinline__ int pat3_at(const Lds<S> &L, int p) {
+template <int S, typename LT>
+__device__ __forceinline__ int pat3_at(const LT &L, int p) {
     constexpr int W = Geo<S>::W;
     return L.color[p - W - 1] | (L.color[p - W] << 2) | (L.color[p - W + 1] << 4) |
            (L.color[p - 1] << 6) | (L.color[p + 1] << 8) | (L.color[p + W - 1] << 10) |
@@ -350,8 +351,8 @@ __device__ __forceinline__ bool is_eye_of(int code, int me) {
 // Candidate list of MCTSTree.expand_node (tree.py:260-264): legal (go_board.py:260-304),
 // check_self_atari_stone < 7 (:327-365), not a complete eye (:367-397); row-major, PASS last.
 // Returns the number of candidates (>= 1); L.cand[] holds their coordinates.
-template <int S>
-__device__ int gen_candidates(Lds<S> &L, const BoardScalars &b, int me, const SearchDev &D, int lane) {
+template <int S, typename LT>
+__device__ int gen_candidates(LT &L, const BoardScalars &b, int me, const SearchDev &D, int lane) {
     using G = Geo<S>;
     constexpr int W = G::W, NC = G::NC, P = G::P;
     const int opp = 3 - me;
@@ -534,8 +535,8 @@ __device__ __forceinline__ double sequential_sum(const double (&v)[R], int n) {
 }
 
 // tree.py:247-270 expand_node + node.py:41-73: returns the new node index (or -1 on error).
-template <int S>
-__device__ int expand_node(Lds<S> &L, const BoardScalars &b, int to_move, const SearchDev &D, int t,
+template <int S, typename LT>
+__device__ int expand_node(LT &L, const BoardScalars &b, int to_move, const SearchDev &D, int t,
                            int &num_nodes, int parent, int pedge, int lane) {
     using G = Geo<S>;
     constexpr int A = G::A;
@@ -604,8 +605,8 @@ __device__ int expand_node(Lds<S> &L, const BoardScalars &b, int to_move, const 
 }
 
 // nn/feature.py:10-57 from the LDS board
-template <int S>
-__device__ void write_planes(const Lds<S> &L, const BoardScalars &b, int to_move, float *dst, int lane) {
+template <int S, typename LT>
+__device__ void write_planes(const LT &L, const BoardScalars &b, int to_move, float *dst, int lane) {
     using G = Geo<S>;
     constexpr int W = G::W, P = G::P;
     const bool pass_plane = b.moves > 1 && b.prev == 0;
@@ -686,8 +687,8 @@ __device__ EdgePick select_puct(const SearchDev &D, int t, int node, int lane) {
     return pick;
 }
 
-template <int S>
-__device__ void load_root(Lds<S> &L, BoardScalars &b, int &to_move, const SearchDev &D, int t, int lane) {
+template <int S, typename LT>
+__device__ void load_root(LT &L, BoardScalars &b, int &to_move, const SearchDev &D, int t, int lane) {
     using G = Geo<S>;
     for (int p = lane; p < G::NC; p += 64) L.root_color[p] = D.root_cells[(size_t)t * G::NC + p];
     const RootMeta m = D.meta[t];
@@ -703,8 +704,8 @@ __device__ void load_root(Lds<S> &L, BoardScalars &b, int &to_move, const Search
     label_strings<S>(L.root_color, L.root_sid, lane);
 }
 
-template <int S>
-__device__ void reset_work(Lds<S> &L, int lane) {
+template <int S, typename LT>
+__device__ void reset_work(LT &L, int lane) {
     for (int p = lane; p < Geo<S>::NC; p += 64) { L.color[p] = L.root_color[p]; L.sid[p] = L.root_sid[p]; }
     wave_sync();
 }
@@ -834,14 +835,23 @@ struct PipeJob {
     int k, parent, edge, child, expand, xseq, depth;
 };
 
+// Longest path a pipelined kernel follows (deeper: reported as an error, never silent).  A 9x9 game has at most
+// 243 recorded moves (MAX_RECORDS = 3 P), so 256 covers every path there.
+template <int S>
+constexpr int kPathMax = S == 9 ? 256 : kPipeMaxDepth;
+
+// The three-wave kernels are sized to sit NEXT TO a forward workgroup on a CU (the split-operand forward kernel
+// leaves 19.6 KB of the 160 KB): boards without the softmax scratch, path buffers of kPathMax<S>, "job done"
+// flags as a bit set.  Otherwise a selection launch of one board group waits for the forward pass of the other
+// group to drain instead of overlapping it.
 template <int S>
 struct PipeShared {
-    Lds<S> board[2];
+    Lds<S, false> board[2];
     PipeJob job[kPipeSlots];
-    int16_t moves[kPipeSlots][kPipeMaxDepth];
+    int16_t moves[kPipeSlots][kPathMax<S>];
     int job_seq[kPipeSlots];          // k + 1 once job k sits in its slot
     int slot_done[kPipeSlots];        // jobs finished in this slot so far
-    int done[kPipeMaxK];              // job k finished (node initialised, planes written)
+    unsigned done_bits[kPipeMaxK / 32];   // bit k: job k finished (node initialised, planes written)
     int16_t jobof[kPipeMaxK];         // node (n0 + i) is being created by job jobof[i]
     int cursor_seq;                   // expansions that have reserved their draws
     long long cursor_val;             // stream position after those reservations
@@ -855,6 +865,14 @@ __device__ __forceinline__ int pipe_load(const int *p) {
 __device__ __forceinline__ void pipe_store(int *p, int v) {
     __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+// job-done bits of PipeShared
+template <typename Sh>
+__device__ __forceinline__ void pipe_set_done(Sh &sh, int k) {
+    __hip_atomic_fetch_or(&sh.done_bits[k >> 5], 1u << (k & 31), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+template <typename Sh>
+__device__ __forceinline__ bool pipe_wait_done(const Sh &sh, int k);
+
 // wave-uniform wait for *p >= want; false on a stall (reported, never a hang)
 __device__ __forceinline__ bool pipe_wait_ge(const int *p, int want) {
     for (int spin = 0; spin < kPipeSpinLimit; ++spin) {
@@ -864,9 +882,20 @@ __device__ __forceinline__ bool pipe_wait_ge(const int *p, int want) {
     return false;
 }
 
+template <typename Sh>
+__device__ __forceinline__ bool pipe_wait_done(const Sh &sh, int k) {
+    const unsigned *p = &sh.done_bits[k >> 5];
+    const unsigned bit = 1u << (k & 31);
+    for (int spin = 0; spin < kPipeSpinLimit; ++spin) {
+        if (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & bit) return true;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return false;
+}
+
 // expand_node for a worker: node index given by the selector, draws reserved through the chain
-template <int S, typename Sh>
-__device__ bool expand_node_pipe(Lds<S> &L, const BoardScalars &b, int to_move, const SearchDev &D, int t,
+template <int S, typename LT, typename Sh>
+__device__ bool expand_node_pipe(LT &L, const BoardScalars &b, int to_move, const SearchDev &D, int t,
                                  int node, int parent, int pedge, int xseq, Sh &sh, int lane) {
     using G = Geo<S>;
     constexpr int A = G::A;
@@ -938,7 +967,7 @@ __global__ __launch_bounds__(192) void select_puct_pipe_kernel(SearchDev D, int 
         sh.job_seq[threadIdx.x] = 0;
         sh.slot_done[threadIdx.x] = 0;
     }
-    for (int i = threadIdx.x; i < kPipeMaxK; i += 192) sh.done[i] = 0;
+    for (int i = threadIdx.x; i < kPipeMaxK / 32; i += 192) sh.done_bits[i] = 0u;
     if (threadIdx.x == 0) {
         sh.cursor_seq = 0;
         sh.cursor_val = D.rng_cursor[t];
@@ -960,14 +989,14 @@ __global__ __launch_bounds__(192) void select_puct_pipe_kernel(SearchDev D, int 
             int node = 0, depth = 0;
             int moves = meta.moves, prev = meta.prev, prevprev = meta.prevprev;
             while (ok) {
-                if (node >= n0) ok = pipe_wait_ge(&sh.done[sh.jobof[node - n0]], 1);   // expansion still in flight?
+                if (node >= n0) ok = pipe_wait_done(sh, sh.jobof[node - n0]);   // expansion still in flight?
                 if (!ok) break;
                 const size_t ns = (size_t)t * D.N + node;
                 const size_t base = ns * A;
                 const EdgePick pick = select_puct<S>(D, t, node, lane);
                 const int e = pick.edge;
                 const int mv = pick.move;
-                if (depth >= kPipeMaxDepth) { ok = false; break; }
+                if (depth >= kPathMax<S>) { ok = false; break; }
                 if (lane == 0) {
                     sh.moves[slot][depth] = (int16_t)mv;
                     D.n_vl[ns] = pick.node_vl + 1;                             // node.py:76-83
@@ -1025,7 +1054,7 @@ __global__ __launch_bounds__(192) void select_puct_pipe_kernel(SearchDev D, int 
         if (lane == 0) pipe_store(&sh.final_count, queued);
     } else {
         // ---- workers ---------------------------------------------------------------------
-        Lds<S> &L = sh.board[wid - 1];
+        Lds<S, false> &L = sh.board[wid - 1];
         BoardScalars rootb;
         int root_to_move;
         load_root<S>(L, rootb, root_to_move, D, t, lane);
@@ -1055,7 +1084,7 @@ __global__ __launch_bounds__(192) void select_puct_pipe_kernel(SearchDev D, int 
             write_planes<S>(L, b, c, planes + ((size_t)t * max_leaves + k) * 6 * G::P, lane);
             wave_sync();
             if (lane == 0) {
-                pipe_store(&sh.done[k], 1);                                    // releases the node arrays
+                pipe_set_done(sh, k);                                          // releases the node arrays
                 pipe_store(&sh.slot_done[slot], k / kPipeSlots + 1);
             }
         }
@@ -1833,7 +1862,7 @@ __global__ __launch_bounds__(192) void select_gumbel_pipe_kernel(SearchDev D, co
     constexpr int A = G::A;
     __shared__ PipeShared<S> sh;
     __shared__ HalvingScratch<S> hs;
-    __shared__ int16_t sel_moves[kPipeMaxDepth];
+    __shared__ int16_t sel_moves[kPathMax<S>];
     const int t = blockIdx.x;
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const RootMeta meta = D.meta[t];
@@ -1842,7 +1871,7 @@ __global__ __launch_bounds__(192) void select_gumbel_pipe_kernel(SearchDev D, co
         sh.job_seq[threadIdx.x] = 0;
         sh.slot_done[threadIdx.x] = 0;
     }
-    for (int i = threadIdx.x; i < kPipeMaxK; i += 192) sh.done[i] = 0;
+    for (int i = threadIdx.x; i < kPipeMaxK / 32; i += 192) sh.done_bits[i] = 0u;
     if (threadIdx.x == 0) {
         sh.cursor_seq = 0;
         sh.cursor_val = D.rng_cursor[t];
@@ -1961,7 +1990,7 @@ __global__ __launch_bounds__(192) void select_gumbel_pipe_kernel(SearchDev D, co
                         if (memo_tag[slot] == node) {
                             e = memo_edge[slot]; mv = memo_move[slot]; visits = memo_vis[slot]; child = memo_child[slot];
                         } else {
-                            if (node >= n0) ok = pipe_wait_ge(&sh.done[sh.jobof[node - n0]], 1);   // expansion in flight?
+                            if (node >= n0) ok = pipe_wait_done(sh, sh.jobof[node - n0]);   // expansion in flight?
                             if (!ok) break;
                             e = select_node_halving<S>(hs, D, t, node, lane);
                             mv = D.action[base + e];
@@ -1979,7 +2008,7 @@ __global__ __launch_bounds__(192) void select_gumbel_pipe_kernel(SearchDev D, co
                             atomicAdd(&D.ch_vl[base + e], 1);
                         }
                     }
-                    if (depth >= kPipeMaxDepth) { ok = false; break; }
+                    if (depth >= kPathMax<S>) { ok = false; break; }
                     if (lane == 0) {
                         sel_moves[depth] = (int16_t)mv;
                         if (depth < kPathCap) D.q_path[((size_t)t * D.K + queued) * kPathCap + depth] = (node << 10) | e;
@@ -2053,7 +2082,7 @@ __global__ __launch_bounds__(192) void select_gumbel_pipe_kernel(SearchDev D, co
         if (lane == 0) pipe_store(&sh.final_count, jid);
     } else {
         // ---- workers ---------------------------------------------------------------------
-        Lds<S> &L = sh.board[wid - 1];
+        Lds<S, false> &L = sh.board[wid - 1];
         BoardScalars rootb;
         int root_to_move;
         load_root<S>(L, rootb, root_to_move, D, t, lane);
@@ -2074,7 +2103,7 @@ __global__ __launch_bounds__(192) void select_gumbel_pipe_kernel(SearchDev D, co
             const PipeJob j = sh.job[slot];
             if (j.expand == 2) {
                 // COPY: the planes of leaf slot j.parent (written by job j.child) are this leaf's planes
-                if (!pipe_wait_ge(&sh.done[j.child], 1)) {
+                if (!pipe_wait_done(sh, j.child)) {
                     if (lane == 0) { atomicOr(&D.err[t], kErrPipeline); pipe_store(&sh.err, 1); }
                     break;
                 }
@@ -2095,7 +2124,7 @@ __global__ __launch_bounds__(192) void select_gumbel_pipe_kernel(SearchDev D, co
             }
             wave_sync();
             if (lane == 0) {
-                pipe_store(&sh.done[k], 1);
+                pipe_set_done(sh, k);
                 pipe_store(&sh.slot_done[slot], k / kPipeSlots + 1);
             }
         }

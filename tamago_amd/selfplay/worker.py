@@ -59,7 +59,7 @@ def selfplay_shard(save_dir: str, network, index_list: Sequence[int], size: int,
     game a single-board worker would play with that seed.
 
     `groups` > 1 splits the boards into that many independent lock-step groups, each with its
-    own engine, HIP stream and host thread (default: one group per 128 boards, 2..8; 1 below 64 boards): while one group's
+    own engine, HIP stream and host thread (default: 1 below 192 boards, 2 below 512, else 4): while one group's
     host thread does the per-move bookkeeping (move choice, SGF comment, RNG windows) the GPU
     runs the other group's phases, and one group's tree kernels overlap the other's forward
     pass.  Games are independent, so the result does not depend on the grouping."""
@@ -72,7 +72,10 @@ def selfplay_shard(save_dir: str, network, index_list: Sequence[int], size: int,
         return stats
     boards = min(boards, len(todo))
     if groups <= 0:
-        groups = 1 if boards < 64 else (2 if boards < 256 else min(8, boards // 128))
+        # measured on MI355X (tools/bench_selfplay.py, 400 simulations): with the per-move bookkeeping inside the
+        # library one group is best up to 128 boards (64 boards: 2.43 M leaf-evals/s vs 2.08 M with two groups);
+        # 256 boards: two groups 3.67 M vs 3.36 M; 1024 boards: four groups 4.18 M vs 3.99 M (two) / 3.84 M (eight)
+        groups = 1 if boards < 192 else (2 if boards < 512 else 4)
     groups = max(1, min(groups, boards))
     queue = list(todo)
     lock = threading.Lock()
