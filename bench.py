@@ -202,8 +202,10 @@ def extra_legs(args, net, dev, local_rank, fresh_board):
                 "workload": f"Gumbel sequential halving, 400 simulations/move, {boards} lock-step boards, "
                             "games to completion, SGF records written"}
 
-    for key, boards, games in (("cfg3_selfplay_16_boards", 16, 32), ("cfg4_shard_64_boards", 64, 128),
-                               ("selfplay_1024_boards", 1024, 1024)):
+    # games >> boards: a shard refills a slot when its game ends, but the run ends with the last game, and with
+    # only two games per slot half of the lock-step moves ran on half-empty shards (9x9 games last 60..162 moves)
+    for key, boards, games in (("cfg3_selfplay_16_boards", 16, 256), ("cfg4_shard_64_boards", 64, 640),
+                               ("selfplay_1024_boards", 1024, 2048)):
         try:
             out[key] = selfplay(boards, games)
         except Exception as exc:                          # the headline must not depend on a leg

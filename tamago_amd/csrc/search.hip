@@ -37,6 +37,7 @@
 #include <algorithm>
 #include <map>
 #include <string>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -3396,16 +3397,27 @@ int tg_selfplay_play_move(tg_selfplay *sp, tg_net *net, float *planes_dev, float
     tg_search *s = sp->s;
     const int T = s->dev.T, A = s->A;
     int rc;
+    // host-side wall clock per section (TG_SP_TIMING=1: printed every 200 moves) - where a move's time goes when
+    // the GPU is not the bound
+    static const bool timing = getenv("TG_SP_TIMING") != nullptr;
+    static double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    static long moves_timed = 0;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_last = timing ? now() : 0.0;
+    auto lap = [&](int i) { if (timing) { const double t = now(); acc[i] += t - t_last; t_last = t; } };
     int live = 0;
     for (int t = 0; t < T; ++t) live += sp->games[t].done ? 0 : 1;
     // ---- root: expand, evaluate (tree.py:330-336) ----
     if ((rc = tg_search_feed_streams(s, (size_t)A, sp->force_feed ? 1 : 0))) return rc;
     sp->force_feed = false;
+    lap(0);
     if ((rc = tg_search_root_planes(s, planes_dev, stream))) return rc;
     if ((rc = tg_search_advance_streams(s, nullptr))) return rc;
+    lap(1);
     if ((rc = tg_net_forward_dev(net, planes_dev, T, 1, policy_dev, value_dev, stream))) return rc;
     if ((rc = tg_search_backup(s, policy_dev, value_dev, 1, 1, stream))) return rc;
     if ((rc = tg_search_draw_noise(s, nullptr))) return rc;
+    lap(2);
     // ---- sequential halving (tree.py:375-384) ----
     constexpr int kMaxPhases = 16;
     sp->ph_nc.resize((size_t)kMaxPhases * T);
@@ -3422,9 +3434,12 @@ int tg_selfplay_play_move(tg_selfplay *sp, tg_net *net, float *planes_dev, float
             slots = n > slots ? n : slots;
         }
         if (slots == 0) continue;
+        lap(3);
         if ((rc = tg_search_feed_streams(s, (size_t)slots * A, 0))) return rc;
+        lap(4);
         if ((rc = tg_search_select_gumbel(s, nc, mc, 0, planes_dev, stream))) return rc;
         if ((rc = tg_search_advance_streams(s, nullptr))) return rc;
+        lap(5);
         if ((rc = tg_net_forward_dev(net, planes_dev, (int)total, 1, policy_dev, value_dev, stream))) return rc;
         if ((rc = tg_search_backup(s, policy_dev, value_dev, 0, 1, stream))) return rc;
         leaves += total;
@@ -3432,8 +3447,16 @@ int tg_selfplay_play_move(tg_selfplay *sp, tg_net *net, float *planes_dev, float
     // ---- move choice, records, finished games; play ----
     sp->mv.resize(T);
     int64_t counts[2] = {0, 0};
+    lap(3);
     if ((rc = tg_selfplay_finish_move(sp, sp->mv.data(), finished_host, counts))) return rc;
+    lap(6);
     if ((rc = tg_search_play(s, sp->mv.data(), stream))) return rc;
+    lap(7);
+    if (timing && ++moves_timed % 200 == 0)
+        fprintf(stderr, "[selfplay timing, ms per move over %ld moves] feed(root) %.3f | root planes + sync %.3f | root forward/backup/noise %.3f | "
+                "launches %.3f | feed(phases) %.3f | select + sync %.3f | finish_move %.3f | play %.3f\n", moves_timed,
+                1e3 * acc[0] / moves_timed, 1e3 * acc[1] / moves_timed, 1e3 * acc[2] / moves_timed, 1e3 * acc[3] / moves_timed,
+                1e3 * acc[4] / moves_timed, 1e3 * acc[5] / moves_timed, 1e3 * acc[6] / moves_timed, 1e3 * acc[7] / moves_timed);
     if (stats_host) { stats_host[0] = counts[0]; stats_host[1] = counts[1]; stats_host[2] = leaves; }
     return TG_OK;
 }

@@ -178,17 +178,30 @@ def _run_group(save_dir, network, size, visits, boards, seeds, device_index, nex
                 policy = torch.empty((boards * engine.K, a), dtype=torch.float32, device=engine.device)
                 value = torch.empty((boards * engine.K, 3), dtype=torch.float32, device=engine.device)
                 counts = np.zeros(3, dtype=np.int64)
+                timing = os.environ.get("TG_SP_TIMING") is not None
+                t_call = t_start = 0.0
+                n_calls = 0
+                import time as _time
                 while live > 0:
+                    t0 = _time.perf_counter()
                     _lib.check(lib.tg_selfplay_play_move(handle, network.handle, engine.planes.data_ptr(),
                                                          policy.data_ptr(), value.data_ptr(), engine._stream(),
                                                          finished.ctypes.data, counts.ctypes.data),
                                "tg_selfplay_play_move")
+                    t1 = _time.perf_counter()
                     stats["games"] += int(counts[0])
                     stats["moves"] += int(counts[1])
                     stats["leaf_evals"] += int(counts[2])
                     for s in np.nonzero(finished)[0]:
                         if not start(int(s)):
                             live -= 1
+                    t_call += t1 - t0
+                    t_start += _time.perf_counter() - t1
+                    n_calls += 1
+                if timing:
+                    import sys
+                    sys.stderr.write(f"[selfplay timing] {n_calls} lock-step moves: play_move {1e3 * t_call / max(n_calls, 1):.3f} ms, "
+                                     f"slot refill {1e3 * t_start / max(n_calls, 1):.3f} ms per move\n")
             else:
                 # any other evaluator (host API): the phases are driven from here, the bookkeeping stays in C++
                 max_phases = 16
