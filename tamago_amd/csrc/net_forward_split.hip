@@ -83,7 +83,13 @@ struct SplitCfg {
     static constexpr int FC_BYTES = ((2 * P * A * 4 + 4095) / 4096) * 4096;          // policy FC, [2P][A] fp32, padded
     static constexpr int RES_BYTES = (M + 1) * 256 > FC_BYTES ? (M + 1) * 256 : FC_BYTES;
     static constexpr int SS_OFF = RES_OFF + RES_BYTES;           // folded BN scale [13][64] + shift [13][64]
-    static constexpr int PIPE_BYTES = SS_OFF + 2 * 13 * 64 * 4;
+    // head tables, staged once per workgroup: 1x1 weights [64][4] (policy 0, policy 1, value, 0), policy FC bias [A]
+    // (padded), BN scale / shift of the three head channels [8].  (In the heads every use of a kernel-argument
+    // pointer was a reload from scratch followed by a dependent global load.)
+    static constexpr int HW_OFF = SS_OFF + 2 * 13 * 64 * 4;
+    static constexpr int HB_OFF = HW_OFF + 64 * 4 * 4;
+    static constexpr int HS_OFF = HB_OFF + ((A + 3) & ~3) * 4;
+    static constexpr int PIPE_BYTES = HS_OFF + 8 * 4;
     // head phase (after the last layer): fp32 activations [M][72 floats] from offset 0, scratch behind the BN table
     static constexpr int ROW_BYTES = kRowBytes;
     static constexpr int AUX = PIPE_BYTES;
@@ -157,27 +163,41 @@ __device__ __forceinline__ void run_heads_split(unsigned char *smem, const NetDe
     float *hval = hpol + G * 2 * P;                           // [G][P]
     float *plog = hval + G * P;                               // [G][A]
     float *vlog = plog + G * A;                               // [G][4]
+    const int li = lane & 15, lg = lane >> 4;
+    constexpr int NW = NTHR / 64;
     {
-        const float ps0 = net.head_ss[0], pt0 = net.head_ss[1];
-        const float ps1 = net.head_ss[2], pt1 = net.head_ss[3];
-        const float vs = net.head_ss[4], vt = net.head_ss[5];
-        for (int r = tid; r < M; r += NTHR) {
-            float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+        // 1x1 convolutions (64 -> 2 policy + 1 value channels) on the fp32 matrix pipe: rows = positions, columns =
+        // the three head channels (13 of 16 columns idle - still 5x faster than one row per thread on the VALU, whose
+        // 16-byte reads of consecutive rows collide in LDS).  k-step ks of lane group lg covers channel 16 lg + ks:
+        // a lane reads its 16 channels as four 16-byte loads (rows 16 apart in the [row][72] image: conflict-free).
+        const float *hw = reinterpret_cast<const float *>(smem + C::HW_OFF);
+        const float *hs = reinterpret_cast<const float *>(smem + C::HS_OFF);
+        const int col = li < 3 ? li : 3;                   // column 3 of the table is zero
+        float wB[16];
 #pragma unroll
-            for (int k4 = 0; k4 < 16; ++k4) {
-                const f32x4 xv = lds_f32x4(smem, r * C::ROW_BYTES + k4 * 16);
+        for (int ks = 0; ks < 16; ++ks) wB[ks] = hw[(lg * 16 + ks) * 4 + col];
+        const float sc = hs[2 * (li < 3 ? li : 0)], sh = hs[2 * (li < 3 ? li : 0) + 1];
+        for (int t = wave; t < C::MT; t += NW) {
+            const int row = t * 16 + li;
+            f32x4 xa[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int k = k4 * 4 + j;
-                    d0 = fmaf(xv[j], net.hp_w[k], d0);
-                    d1 = fmaf(xv[j], net.hp_w[64 + k], d1);
-                    d2 = fmaf(xv[j], net.hv_w[k], d2);
+            for (int j = 0; j < 4; ++j) xa[j] = lds_f32x4(smem, row * C::ROW_BYTES + lg * 64 + j * 16);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks >> 2][ks & 3], wB[ks], acc, 0, 0, 0);
+            if (li < 3) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int r = t * 16 + lg * 4 + v;
+                    if (r < M) {
+                        const int bl = r / P, pp = r - bl * P;
+                        const float o = fmaxf(fmaf(acc[v], sc, sh), 0.f);
+                        if (li == 2) hval[bl * P + pp] = o;
+                        else hpol[bl * 2 * P + li * P + pp] = o;
+                    }
                 }
             }
-            const int bl = r / P, p = r - bl * P;
-            hpol[bl * 2 * P + p] = fmaxf(fmaf(d0, ps0, pt0), 0.f);
-            hpol[bl * 2 * P + P + p] = fmaxf(fmaf(d1, ps1, pt1), 0.f);
-            hval[bl * P + p] = fmaxf(fmaf(d2, vs, vt), 0.f);
         }
     }
     stamp(0);
@@ -185,24 +205,32 @@ __device__ __forceinline__ void run_heads_split(unsigned char *smem, const NetDe
     __syncthreads();
     stamp(1);
     const float *fcw = reinterpret_cast<const float *>(smem + C::RES_OFF);
-    // policy FC: one output per thread, six independent partial sums (LDS latency, not bandwidth, is the cost)
-    for (int e = tid; e < G * A; e += NTHR) {
-        const int bl = e / A, a = e - bl * A;
-        const float *h = hpol + bl * 2 * P;
-        const float *wT = fcw + a;
-        float s0 = net.pfc_b[a], s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f;
-        int j = 0;
-#pragma unroll 3
-        for (; j + 6 <= 2 * P; j += 6) {
-            s0 = fmaf(h[j], wT[j * A], s0);
-            s1 = fmaf(h[j + 1], wT[(j + 1) * A], s1);
-            s2 = fmaf(h[j + 2], wT[(j + 2) * A], s2);
-            s3 = fmaf(h[j + 3], wT[(j + 3) * A], s3);
-            s4 = fmaf(h[j + 4], wT[(j + 4) * A], s4);
-            s5 = fmaf(h[j + 5], wT[(j + 5) * A], s5);
+    {
+        // policy FC on the fp32 matrix pipe: rows = the G boards (13+ of 16 rows idle), columns = 16 of the A
+        // outputs per tile, K = 2P inputs in 41 steps of 4 with k = 41 lg + ks (contiguous per lane group; k >= 2P
+        // masked).  One thread per output on the VALU needed 2 x 162 LDS reads per output: 13 k cycles.
+        constexpr int KS = (2 * P + 3) / 4;                 // 41
+        constexpr int CT = (A + 15) / 16;                   // 6 column tiles
+        for (int ct = wave; ct < CT; ct += NW) {
+            const int a = ct * 16 + li;
+            const int ac = a < A ? a : A - 1;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+            for (int ks = 0; ks < KS; ++ks) {
+                const int k = lg * KS + ks;
+                const bool kin = k < 2 * P;
+                const int kc = kin ? k : 0;
+                const float hv = (li < G && kin) ? hpol[li * 2 * P + kc] : 0.f;
+                const float wv = kin ? fcw[kc * A + ac] : 0.f;
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hv, wv, acc, 0, 0, 0);
+            }
+            if (lg == 0 && a < A) {
+                const float bias = reinterpret_cast<const float *>(smem + C::HB_OFF)[a];
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    if (v < G) plog[v * A + a] = acc[v] + bias;
+            }
         }
-        for (; j < 2 * P; ++j) s0 = fmaf(h[j], wT[j * A], s0);
-        plog[e] = ((s0 + s1) + (s2 + s3)) + (s4 + s5);
     }
     // value FC: sixteen lanes per output, strided partial sums, butterfly over the 16 lanes
     for (int o = tid >> 4; o < G * 3; o += NTHR / 16) {
@@ -287,6 +315,12 @@ __global__ __launch_bounds__((SplitCfg<S, G, F>::NTHR), 1) void dualnet_fwd_spli
         reinterpret_cast<float *>(smem + C::SS_OFF)[e] = net.sscale[e];
         reinterpret_cast<float *>(smem + C::SS_OFF)[13 * 64 + e] = net.shift[e];
     }
+    for (int e = tid; e < 64 * 4; e += NTHR) {
+        const int k = e >> 2, c = e & 3;
+        reinterpret_cast<float *>(smem + C::HW_OFF)[e] = c == 0 ? net.hp_w[k] : (c == 1 ? net.hp_w[64 + k] : (c == 2 ? net.hv_w[k] : 0.f));
+    }
+    for (int e = tid; e < C::A; e += NTHR) reinterpret_cast<float *>(smem + C::HB_OFF)[e] = net.pfc_b[e];
+    if (tid < 6) reinterpret_cast<float *>(smem + C::HS_OFF)[tid] = net.head_ss[tid];
     // weight stream: k-chunk gc = 2 * tap + kc of the whole network lies at wsplit + gc * CHUNK; a chunk's eight
     // fragments are at lane * 16 + (piece * 4 + ct) * 1024 (two lane offsets cover the 4 KB offset field)
     const int wv0 = lane * 16;
@@ -474,11 +508,17 @@ __global__ __launch_bounds__((SplitCfg<S, G, F>::NTHR), 1) void dualnet_fwd_spli
                 constexpr bool keep = decltype(KEEP_)::value, add_res = decltype(ADD_)::value, last = decltype(LAST_)::value;
                 // every LDS operand first (one wave per SIMD: nothing else hides their latency)
                 f32x4 xres[4][RTW], sc[4], sh[4];
-                int rrow[RTW], wrow[RTW];
+                int brow[RTW], rrow[RTW], wrow[RTW];
 #pragma unroll
                 for (int r = 0; r < RTW; ++r) {
-                    rrow[r] = base_row[r] < M ? base_row[r] : 0;          // rows >= M: read anything valid,
-                    wrow[r] = base_row[r] < M ? base_row[r] : M + 1;      // store into the dump row
+                    // opaque copy: the ~50 LDS addresses below are loop-invariant across the layers, hipcc hoisted
+                    // them out of the layer loop, found no registers there and reloaded every one of them from
+                    // scratch in every epilogue (the conv2 epilogue waited on ~30 scratch loads); recomputing them
+                    // from the row costs a few VALU instructions
+                    brow[r] = base_row[r];
+                    asm volatile("" : "+v"(brow[r]));
+                    rrow[r] = brow[r] < M ? brow[r] : 0;                  // rows >= M: read anything valid,
+                    wrow[r] = brow[r] < M ? brow[r] : M + 1;              // store into the dump row
                 }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -506,12 +546,12 @@ __global__ __launch_bounds__((SplitCfg<S, G, F>::NTHR), 1) void dualnet_fwd_spli
                         amax = fmaxf(fmaxf(amax, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
                         const int row = wrow[r];
                         if constexpr (last) {
-                            const int hrow = base_row[r] < M ? base_row[r] : M;
+                            const int hrow = brow[r] < M ? brow[r] : M;
                             *reinterpret_cast<f32x4 *>(smem + hrow * kRowBytes + (c * 16 + lg * 4) * 4) = v;
                         } else {
                             if constexpr (keep)
-                                *reinterpret_cast<f32x4 *>(smem + C::RES_OFF + (base_row[r] < M ? base_row[r] : M) * 256 +
-                                                           (((c * 4 + lg) ^ (base_row[r] & 15)) << 4)) = v;
+                                *reinterpret_cast<f32x4 *>(smem + C::RES_OFF + (brow[r] < M ? brow[r] : M) * 256 +
+                                                           (((c * 4 + lg) ^ (brow[r] & 15)) << 4)) = v;
                             uint2 pc[NP];
                             split4<F>(v, pc);
                             const int slot = (((c & 1) << 1) | (lg >> 1)) ^ ((row >> 1) & 3);
