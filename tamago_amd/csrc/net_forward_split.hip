@@ -149,7 +149,8 @@ __device__ __forceinline__ void run_heads_split(unsigned char *smem, const NetDe
                                                 float *__restrict__ policy, float *__restrict__ value, int tid, int wave,
                                                 long long *tl) {
     constexpr int P = C::P, A = C::A, M = C::M;
-    const int lane = tid & 63;
+    asm volatile("" : "+v"(tid));                          // opaque: nothing derived from it below is hoisted out of
+    const int lane = tid & 63;                             // the caller's group loop (and spilled there)
     auto stamp = [&](int i) { if (tl && tid == 0) tl[i] = (long long)__builtin_amdgcn_s_memtime(); };
     {
         constexpr int PIECES = C::FC_BYTES / 1024;
@@ -338,9 +339,11 @@ __global__ __launch_bounds__((SplitCfg<S, G, F>::NTHR), 1) void dualnet_fwd_spli
     constexpr int NPL = (G * 6 * P + NTHR - 1) / NTHR;
     float pre[NPL];
     auto fetch_planes = [&](int grp2) __attribute__((always_inline)) {
+        int ft = tid;                                      // opaque: keeps the per-lane offsets and predicates from
+        asm volatile("" : "+v"(ft));                       // being hoisted out of the group loop and spilled
 #pragma unroll
         for (int i = 0; i < NPL; ++i) {
-            const int e = tid + i * NTHR;
+            const int e = ft + i * NTHR;
             const int b = grp2 * G + e / (6 * P);
             pre[i] = (e < G * 6 * P && grp2 < n_groups && b < batch)
                          ? __builtin_nontemporal_load(&planes[(size_t)grp2 * G * 6 * P + e]) : 0.f;
@@ -354,12 +357,14 @@ __global__ __launch_bounds__((SplitCfg<S, G, F>::NTHR), 1) void dualnet_fwd_spli
         //      activations: K = 9 taps x 6 planes (k = 6 tap + plane), padded to 64 ----
         {
             float *st = reinterpret_cast<float *>(smem + C::STAGE);
+            int stid = tid;                                 // opaque, as above
+            asm volatile("" : "+v"(stid));
 #pragma unroll
             for (int i = 0; i < NPL; ++i)
-                if (tid + i * NTHR < G * 6 * P) st[tid + i * NTHR] = pre[i];
+                if (stid + i * NTHR < G * 6 * P) st[stid + i * NTHR] = pre[i];
             __syncthreads();
-            if (tid < M) {                                  // one thread per position
-                const int row = tid, bl = row / P, p = row - bl * P, y = p / S, x = p - y * S;
+            if (stid < M) {                                 // one thread per position
+                const int row = stid, bl = row / P, p = row - bl * P, y = p / S, x = p - y * S;
                 const float *src = st + bl * 6 * P + p;
                 const int swz = (row >> 1) & 3;
 #pragma unroll
@@ -404,12 +409,17 @@ __global__ __launch_bounds__((SplitCfg<S, G, F>::NTHR), 1) void dualnet_fwd_spli
             lds_load_frag<off>(dst, smem, addr);
         };
         // all eight weight fragments of chunk gc into set SET
+        // (opaque lane offset: with a constant chunk index these sixteen addresses are invariant across the groups,
+        // were hoisted out of the group loop as 64-bit pointers, spilled, and each load then waited for its own
+        // pointer to come back from scratch)
+        int wvg = wv0;
+        asm volatile("" : "+v"(wvg));
         auto load_a_all = [&](auto SET_, int gc) __attribute__((always_inline)) {
             constexpr int set = decltype(SET_)::value;
             const unsigned char *base = net.wsplit + (size_t)(gc < kChunks ? gc : kChunks - 1) * C::CHUNK;
             static_for<4 * NP>([&](auto J) {
                 constexpr int j = decltype(J)::value, c = j % 4, p = j / 4;
-                gmem_load_frag(fa[set][c][p], base, wv0 + (p * 4 + c) * 1024);
+                gmem_load_frag(fa[set][c][p], base, wvg + (p * 4 + c) * 1024);
             });
         };
         // chunk gc uses weight set (gc + 1) % 3: the stem's two chunks take sets 1 and 2, every tower layer
