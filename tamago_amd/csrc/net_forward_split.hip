@@ -89,7 +89,8 @@ struct SplitCfg {
     static constexpr int HW_OFF = SS_OFF + 2 * 13 * 64 * 4;
     static constexpr int HB_OFF = HW_OFF + 64 * 4 * 4;
     static constexpr int HS_OFF = HB_OFF + ((A + 3) & ~3) * 4;
-    static constexpr int PIPE_BYTES = HS_OFF + 8 * 4;
+    static constexpr int VW_OFF = HS_OFF + 8 * 4;                 // value FC weights [3][P] + bias [3]
+    static constexpr int PIPE_BYTES = VW_OFF + ((3 * P + 3 + 3) & ~3) * 4;
     // head phase (after the last layer): fp32 activations [M][72 floats] from offset 0, scratch behind the BN table
     static constexpr int ROW_BYTES = kRowBytes;
     static constexpr int AUX = PIPE_BYTES;
@@ -164,6 +165,8 @@ __device__ __forceinline__ void run_heads_split(unsigned char *smem, const NetDe
     float *hval = hpol + G * 2 * P;                           // [G][P]
     float *plog = hval + G * P;                               // [G][A]
     float *vlog = plog + G * A;                               // [G][4]
+    float *plog_part = reinterpret_cast<float *>(smem);       // [waves][G][A] partial FC sums: over the fp32 feature
+                                                              // image, which nobody reads after the 1x1 convolutions
     const int li = lane & 15, lg = lane >> 4;
     constexpr int NW = NTHR / 64;
     {
@@ -178,22 +181,33 @@ __device__ __forceinline__ void run_heads_split(unsigned char *smem, const NetDe
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) wB[ks] = hw[(lg * 16 + ks) * 4 + col];
         const float sc = hs[2 * (li < 3 ? li : 0)], sh = hs[2 * (li < 3 ? li : 0) + 1];
-        for (int t = wave; t < C::MT; t += NW) {
-            const int row = t * 16 + li;
-            f32x4 xa[4];
+        // a wave's tiles (t = wave, wave + NW, ...) together: their accumulator chains are independent, so the
+        // dependent-issue latency of one hides behind the others
+        constexpr int TPW = (C::MT + NW - 1) / NW;
+        f32x4 xa[TPW][4], acc[TPW];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) xa[j] = lds_f32x4(smem, row * C::ROW_BYTES + lg * 64 + j * 16);
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < TPW; ++q) {
+            const int t = wave + q * NW;
+            const int row = (t < C::MT ? t : wave) * 16 + li;
 #pragma unroll
-            for (int ks = 0; ks < 16; ++ks)
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks >> 2][ks & 3], wB[ks], acc, 0, 0, 0);
-            if (li < 3) {
+            for (int j = 0; j < 4; ++j) xa[q][j] = lds_f32x4(smem, row * C::ROW_BYTES + lg * 64 + j * 16);
+            acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+            for (int q = 0; q < TPW; ++q)
+                acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[q][ks >> 2][ks & 3], wB[ks], acc[q], 0, 0, 0);
+        if (li < 3) {
+#pragma unroll
+            for (int q = 0; q < TPW; ++q) {
+                const int t = wave + q * NW;
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const int r = t * 16 + lg * 4 + v;
-                    if (r < M) {
+                    if (t < C::MT && r < M) {
                         const int bl = r / P, pp = r - bl * P;
-                        const float o = fmaxf(fmaf(acc[v], sc, sh), 0.f);
+                        const float o = fmaxf(fmaf(acc[q][v], sc, sh), 0.f);
                         if (li == 2) hval[bl * P + pp] = o;
                         else hpol[bl * 2 * P + li * P + pp] = o;
                     }
@@ -210,26 +224,35 @@ __device__ __forceinline__ void run_heads_split(unsigned char *smem, const NetDe
         // policy FC on the fp32 matrix pipe: rows = the G boards (13+ of 16 rows idle), columns = 16 of the A
         // outputs per tile, K = 2P inputs in 41 steps of 4 with k = 41 lg + ks (contiguous per lane group; k >= 2P
         // masked).  One thread per output on the VALU needed 2 x 162 LDS reads per output: 13 k cycles.
-        constexpr int KS = (2 * P + 3) / 4;                 // 41
+        constexpr int KS = (2 * P + 3) / 4;                 // 41 k-steps
         constexpr int CT = (A + 15) / 16;                   // 6 column tiles
-        for (int ct = wave; ct < CT; ct += NW) {
-            const int a = ct * 16 + li;
-            const int ac = a < A ? a : A - 1;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-            for (int ks = 0; ks < KS; ++ks) {
-                const int k = lg * KS + ks;
-                const bool kin = k < 2 * P;
-                const int kc = kin ? k : 0;
-                const float hv = (li < G && kin) ? hpol[li * 2 * P + kc] : 0.f;
-                const float wv = kin ? fcw[kc * A + ac] : 0.f;
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hv, wv, acc, 0, 0, 0);
-            }
-            if (lg == 0 && a < A) {
-                const float bias = reinterpret_cast<const float *>(smem + C::HB_OFF)[a];
+        constexpr int KW = (KS + NW - 1) / NW;              // k-steps per wave: every wave takes a slice of K for ALL
+        f32x4 acc[CT];                                      // column tiles (six independent accumulators, equal work);
+#pragma unroll                                              // the partial sums meet in LDS (plog_part) below
+        for (int ct = 0; ct < CT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int v = 0; v < 4; ++v)
-                    if (v < G) plog[v * A + a] = acc[v] + bias;
+        for (int kk = 0; kk < KW; ++kk) {
+            const int ks = wave * KW + kk;
+            const int k = lg * KS + ks;
+            const bool kin = ks < KS && k < 2 * P;
+            const int kc = kin ? k : 0;
+            const float hv = (li < G && kin) ? hpol[li * 2 * P + kc] : 0.f;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const int a = ct * 16 + li;
+                const float wv = kin ? fcw[kc * A + (a < A ? a : A - 1)] : 0.f;
+                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv, wv, acc[ct], 0, 0, 0);
+            }
+        }
+        if (lg == 0) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const int a = ct * 16 + li;
+                if (a < A) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+                        if (v < G) plog_part[(wave * G + v) * A + a] = acc[ct][v];
+                }
             }
         }
     }
@@ -237,7 +260,7 @@ __device__ __forceinline__ void run_heads_split(unsigned char *smem, const NetDe
     for (int o = tid >> 4; o < G * 3; o += NTHR / 16) {
         const int part = tid & 15, bl = o / 3, c = o - bl * 3;
         const float *h = hval + bl * P;
-        const float *wv = net.vfc_w + c * P;
+        const float *wv = reinterpret_cast<const float *>(smem + C::VW_OFF) + c * P;
         float sv = 0.f;
 #pragma unroll
         for (int i = 0; i < (P + 15) / 16; ++i) {
@@ -248,7 +271,7 @@ __device__ __forceinline__ void run_heads_split(unsigned char *smem, const NetDe
         sv += __shfl_xor(sv, 4);
         sv += __shfl_xor(sv, 2);
         sv += __shfl_xor(sv, 1);
-        if (part == 0) vlog[bl * 4 + c] = sv + net.vfc_b[c];
+        if (part == 0) vlog[bl * 4 + c] = sv + reinterpret_cast<const float *>(smem + C::VW_OFF)[3 * P + c];
     }
     stamp(2);
     __syncthreads();
@@ -256,7 +279,13 @@ __device__ __forceinline__ void run_heads_split(unsigned char *smem, const NetDe
         const int b = b0 + bl;
         if (b >= batch) continue;
         float m = -INFINITY;
-        for (int a = lane; a < A; a += 64) m = fmaxf(m, plog[bl * A + a]);
+        for (int a = lane; a < A; a += 64) {               // partial FC sums of the waves + bias (a lane re-reads only
+            float lgt = reinterpret_cast<const float *>(smem + C::HB_OFF)[a];     // the entries it writes here)
+#pragma unroll
+            for (int w = 0; w < NTHR / 64; ++w) lgt += plog_part[(w * G + bl) * A + a];
+            plog[bl * A + a] = lgt;
+            m = fmaxf(m, lgt);
+        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
         float sum = 0.f;
@@ -322,6 +351,8 @@ __global__ __launch_bounds__((SplitCfg<S, G, F>::NTHR), 1) void dualnet_fwd_spli
     }
     for (int e = tid; e < C::A; e += NTHR) reinterpret_cast<float *>(smem + C::HB_OFF)[e] = net.pfc_b[e];
     if (tid < 6) reinterpret_cast<float *>(smem + C::HS_OFF)[tid] = net.head_ss[tid];
+    for (int e = tid; e < 3 * P + 3; e += NTHR)
+        reinterpret_cast<float *>(smem + C::VW_OFF)[e] = e < 3 * P ? net.vfc_w[e] : net.vfc_b[e - 3 * P];
     // weight stream: k-chunk gc = 2 * tap + kc of the whole network lies at wsplit + gc * CHUNK; a chunk's eight
     // fragments are at lane * 16 + (piece * 4 + ct) * 1024 (two lane offsets cover the 4 KB offset field)
     const int wv0 = lane * 16;
