@@ -3412,10 +3412,10 @@ int tg_selfplay_play_move(tg_selfplay *sp, tg_net *net, float *planes_dev, float
     sp->force_feed = false;
     lap(0);
     if ((rc = tg_search_root_planes(s, planes_dev, stream))) return rc;
-    if ((rc = tg_search_advance_streams(s, nullptr))) return rc;
-    lap(1);
     if ((rc = tg_net_forward_dev(net, planes_dev, T, 1, policy_dev, value_dev, stream))) return rc;
     if ((rc = tg_search_backup(s, policy_dev, value_dev, 1, 1, stream))) return rc;
+    if ((rc = tg_search_advance_streams(s, nullptr))) return rc;
+    lap(1);
     if ((rc = tg_search_draw_noise(s, nullptr))) return rc;
     lap(2);
     // ---- sequential halving (tree.py:375-384) ----
@@ -3438,10 +3438,11 @@ int tg_selfplay_play_move(tg_selfplay *sp, tg_net *net, float *planes_dev, float
         if ((rc = tg_search_feed_streams(s, (size_t)slots * A, 0))) return rc;
         lap(4);
         if ((rc = tg_search_select_gumbel(s, nc, mc, 0, planes_dev, stream))) return rc;
-        if ((rc = tg_search_advance_streams(s, nullptr))) return rc;
-        lap(5);
+        // forward + backup go out before the cursor read-back (which waits for the selection kernel only)
         if ((rc = tg_net_forward_dev(net, planes_dev, (int)total, 1, policy_dev, value_dev, stream))) return rc;
         if ((rc = tg_search_backup(s, policy_dev, value_dev, 0, 1, stream))) return rc;
+        if ((rc = tg_search_advance_streams(s, nullptr))) return rc;
+        lap(5);
         leaves += total;
     }
     // ---- move choice, records, finished games; play ----

@@ -271,8 +271,15 @@ class SearchEngine:
         # order matters for overlap: the random window of THIS batch is generated and
         # uploaded (private copy stream) while the forward pass of the PREVIOUS batch is
         # still running; the cursor read-back waits for the selection kernel only
-        self.puct_select(leaves)
+        self.node_bound += leaves
+        self._queue_stride = leaves
+        self._feed_rng(leaves * self.A)
+        _lib.check(self.lib.tg_search_select_puct(self.handle, leaves, self.planes.data_ptr(),
+                                                  None, self._stream()), "tg_search_select_puct")
+        # forward + backup are queued BEFORE the cursor read-back: that read waits for the selection kernel only
+        # (its own event on the copy stream), so the host is back while the forward pass runs
         self._evaluate_and_backup(leaves, False)
+        self._collect_rng()
 
     def puct_select(self, leaves: int):
         """The selection half of puct_batch: afterwards the device queue holds `leaves` leaves per
