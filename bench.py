@@ -273,6 +273,14 @@ def main():
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
     red_dev = dev if backend == "nccl" else torch.device("cpu")
+    if world > 1:
+        # one rank per GPU shares the host with the others: give each its own slice of the cores (the library's
+        # random-stream threads of eight ranks must not pile onto the same cores)
+        try:
+            from tamago_amd.selfplay.main import pin_host_threads
+            pin_host_threads(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+        except Exception as exc:                                  # pinning is an optimisation, never fatal
+            sys.stderr.write(f"bench.py: host-thread pinning skipped ({exc})\n")
 
     from tamago_amd import lib as tl
     from tamago_amd.mcts.engine import SearchEngine

@@ -120,3 +120,24 @@ def test_eight_shards_share_one_gpu_without_collisions(tmp_path):
     assert sorted(int(f[:-4]) for f in os.listdir(tmp_path / "1")) == list(range(1, 17))
     assert [s["rank"] for s in result["per_shard"]] == list(range(8))
     assert all(s["games"] == 2 for s in result["per_shard"])
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, one rank per GPU), with both
+    ranks on cuda:0 (TG_SINGLE_DEVICE) and gloo for the barrier / reductions (RCCL cannot put two ranks on one
+    device): ONE JSON line from rank 0, whole-job aggregate over both ranks, weak scaling, max-over-ranks time."""
+    env = dict(os.environ, TG_SINGLE_DEVICE="1", TG_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT="29583",
+               PYTHONPATH=REPO + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", "29583", os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1",
+           "--warmup", "1", "--trees", "64", "--no-cpu-baseline", "--no-legs"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 1 and res["scaling"] == "weak" and res["higher_is_better"] is True
+    assert res["metric"].startswith("MCTS leaf-evals") and res["unit"] == "leaf-evals/s"
+    # two ranks x 64 trees x 1001 leaf evaluations in the timed step
+    assert abs(res["value"] * res["ms_per_step"] / 1e3 - 2 * 64 * 1001) < 1.0
+    assert 0.0 < res["roofline"]["frac"] <= 1.0 and res["roofline"]["bound"] == "mfma"
