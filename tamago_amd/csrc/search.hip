@@ -833,7 +833,7 @@ constexpr int kPipeMaxK = 1024;
 constexpr int kPipeSpinLimit = 1 << 24;
 
 struct PipeJob {
-    int k, parent, edge, child, expand, xseq, depth;
+    int k, parent, edge, child, expand, xseq, depth, src;
 };
 
 // Longest path a pipelined kernel follows (deeper: reported as an error, never silent).  A 9x9 game has at most
@@ -850,6 +850,7 @@ struct PipeShared {
     Lds<S, false> board[2];
     PipeJob job[kPipeSlots];
     int16_t moves[kPipeSlots][kPathMax<S>];
+    int paths[kPipeSlots][kPathMax<S>];   // Gumbel jobs: (node << 10 | edge) per level, for the worker's bookkeeping
     int job_seq[kPipeSlots];          // k + 1 once job k sits in its slot
     int slot_done[kPipeSlots];        // jobs finished in this slot so far
     unsigned done_bits[kPipeMaxK / 32];   // bit k: job k finished (node initialised, planes written)
@@ -1864,6 +1865,7 @@ __global__ __launch_bounds__(192) void select_gumbel_pipe_kernel(SearchDev D, co
     __shared__ PipeShared<S> sh;
     __shared__ HalvingScratch<S> hs;
     __shared__ int16_t sel_moves[kPathMax<S>];
+    __shared__ int sel_path[kPathMax<S>];
     const int t = blockIdx.x;
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const RootMeta meta = D.meta[t];
@@ -1927,6 +1929,54 @@ __global__ __launch_bounds__(192) void select_gumbel_pipe_kernel(SearchDev D, co
                 r_cnt[r] = r_vis[r] + r_vl0[r];
             }
         }
+        // The scores are constants of the launch, so "arg-max over the children still under the threshold" is "the
+        // first such child in score order": the children are ranked once (score descending, index ascending - the
+        // order np.argmax resolves ties in) and every per-child register array is permuted into rank order.  A root
+        // choice is then a compare, a ballot and a find-first-bit instead of a float64 arg-max over the wave
+        // (1.4 k cycles of the 6.6 k a descent cost the selector).  When no child is under the threshold every
+        // score is -10000 and np.argmax returns child 0: pos0 is where that child sits.
+        int r_edge[R];
+        int pos0 = 0;
+        if (active) {
+            wave_sync();
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (lane + 64 * r < A) hs.w1[lane + 64 * r] = r_score[r];
+            wave_sync();
+            int rank[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) rank[r] = 0;
+            for (int j = 0; j < r_nc; ++j) {
+                const double sj = hs.w1[j];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int i = lane + 64 * r;
+                    rank[r] += (sj > r_score[r] || (sj == r_score[r] && j < i)) ? 1 : 0;
+                }
+            }
+            __shared__ int ptmp[A + 1];
+            auto permute = [&](int (&v)[R]) {
+                wave_sync();
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if (lane + 64 * r < r_nc) ptmp[rank[r]] = v[r];
+                wave_sync();
+#pragma unroll
+                for (int r = 0; r < R; ++r) v[r] = lane + 64 * r < r_nc ? ptmp[lane + 64 * r] : 0;
+            };
+#pragma unroll
+            for (int r = 0; r < R; ++r) r_edge[r] = lane + 64 * r;
+            permute(r_edge);
+            permute(r_cnt);
+            permute(r_vis);
+            permute(r_idx);
+            permute(r_act);
+            // rank of child 0
+            wave_sync();
+            if (lane == 0) ptmp[A] = rank[0];
+            wave_sync();
+            pos0 = ptmp[A];
+        }
         // remembered choices below the root: tag = node, value = (edge, move, visits of the edge, child)
         constexpr int kMemo = 64;
         __shared__ int memo_tag[kMemo], memo_edge[kMemo], memo_move[kMemo], memo_vis[kMemo], memo_child[kMemo];
@@ -1939,16 +1989,16 @@ __global__ __launch_bounds__(192) void select_gumbel_pipe_kernel(SearchDev D, co
         __shared__ int leaf_key[kLeafKeys], leaf_slot[kLeafKeys], leaf_job[kLeafKeys];
         int n_keys = 0;
         wave_sync();
-        auto publish = [&](int plane_slot, int parent, int edge, int child, int expand, int xseq, int depth) -> bool {
+        auto publish = [&](int plane_slot, int parent, int edge, int child, int expand, int xseq, int depth, int src) -> bool {
             if (jid >= kPipeMaxK) return false;
             const int slot = jid % kPipeSlots;
             if (!pipe_wait_ge(&sh.slot_done[slot], jid / kPipeSlots)) return false;
-            for (int i = lane; i < depth; i += 64) sh.moves[slot][i] = sel_moves[i];
+            for (int i = lane; i < depth; i += 64) { sh.moves[slot][i] = sel_moves[i]; sh.paths[slot][i] = sel_path[i]; }
             wave_sync();
             if (lane == 0) {
                 PipeJob &j = sh.job[slot];
                 j.k = plane_slot; j.parent = parent; j.edge = edge; j.child = child;
-                j.expand = expand; j.xseq = xseq; j.depth = depth;
+                j.expand = expand; j.xseq = xseq; j.depth = depth; j.src = src;
                 pipe_store(&sh.job_seq[slot], jid + 1);
             }
             wave_sync();
@@ -1958,33 +2008,30 @@ __global__ __launch_bounds__(192) void select_gumbel_pipe_kernel(SearchDev D, co
         for (int th = 1; ok && th <= levels; ++th) {
             for (int j = 0; ok && j < width; ++j) {
                 if (pipe_load(&sh.err)) { ok = false; break; }
-                int node = 0, depth = 0;
+                int node = 0, depth = 0, root_pos = 0;
                 while (ok) {
                     const size_t ns = (size_t)t * D.N + node;
                     const size_t base = ns * A;
                     int e, mv, visits, child;
                     if (node == 0) {
-                        // node.py:324-346 on the register copy
-                        double best = 0.0;
-                        int best_i = -1;
+                        // node.py:324-346 on the rank-ordered register copy: first child under the threshold
+                        int pos = -1;
 #pragma unroll
                         for (int r = 0; r < R; ++r) {
-                            const int i = lane + 64 * r;
-                            if (i < r_nc) {
-                                const double sc = r_cnt[r] >= th ? -10000.0 : r_score[r];
-                                if (best_i < 0 || sc > best) { best = sc; best_i = i; }
-                            }
+                            const unsigned long long under = __ballot(lane + 64 * r < r_nc && r_cnt[r] < th);
+                            if (pos < 0 && under) pos = 64 * r + __ffsll((long long)under) - 1;
                         }
-                        best_i = wave_argmax_first(best, best_i);
-                        e = best_i;
-                        const int owner = __builtin_amdgcn_readfirstlane(e & 63), rr = e >> 6;
-                        int m_mv = 0, m_vis = 0, m_idx = 0;
+                        if (pos < 0) pos = pos0;
+                        const int owner = pos & 63, rr = pos >> 6;
+                        int m_mv = 0, m_vis = 0, m_idx = 0, m_e = 0;
 #pragma unroll
                         for (int r = 0; r < R; ++r)
-                            if (r == rr) { m_mv = r_act[r]; m_vis = r_vis[r]; m_idx = r_idx[r]; if (lane == owner) r_cnt[r] += 1; }
+                            if (r == rr) { m_mv = r_act[r]; m_vis = r_vis[r]; m_idx = r_idx[r]; m_e = r_edge[r]; if (lane == owner) r_cnt[r] += 1; }
                         mv = __builtin_amdgcn_readlane(m_mv, owner);
                         visits = __builtin_amdgcn_readlane(m_vis, owner);
                         child = __builtin_amdgcn_readlane(m_idx, owner);
+                        e = __builtin_amdgcn_readlane(m_e, owner);
+                        root_pos = pos;
                         ++r_added;
                     } else {
                         const int slot = node & (kMemo - 1);
@@ -2004,37 +2051,31 @@ __global__ __launch_bounds__(192) void select_gumbel_pipe_kernel(SearchDev D, co
                             }
                             wave_sync();
                         }
-                        if (lane == 0) {                                  // node.py:76-83, nobody reads these before the backup
-                            atomicAdd(&D.n_vl[ns], 1);
-                            atomicAdd(&D.ch_vl[base + e], 1);
-                        }
+                        // (node.py:76-83: the virtual losses below the root are added by the worker that takes the leaf
+                        // job - nobody reads them before the backup)
                     }
                     if (depth >= kPathMax<S>) { ok = false; break; }
                     if (lane == 0) {
                         sel_moves[depth] = (int16_t)mv;
-                        if (depth < kPathCap) D.q_path[((size_t)t * D.K + queued) * kPathCap + depth] = (node << 10) | e;
+                        sel_path[depth] = (node << 10) | e;
                     }
                     ++depth;
                     wave_sync();
                     if (visits < 1) {                                     // tree.py:412-416
-                        if (lane == 0) {
-                            D.q_node[(size_t)t * D.K + queued] = child;   // still NOT_EXPANDED: node[-1]
-                            D.q_pnode[(size_t)t * D.K + queued] = node;
-                            D.q_pedge[(size_t)t * D.K + queued] = e;
-                            D.q_depth[(size_t)t * D.K + queued] = (depth <= kPathCap && D.N <= (1 << 21)) ? depth : 0;
-                        }
+                        // the queue entry of this leaf (node to evaluate - still NOT_EXPANDED: node[-1] -, parent, edge,
+                        // path) is written by the worker that takes the job
                         const int key = (node << 10) | e;
                         const unsigned long long hit = __ballot(lane < n_keys && leaf_key[lane] == key);
                         if (hit && D.N <= (1 << 21)) {
                             const int f = __ffsll((long long)hit) - 1;
-                            ok = publish(queued, leaf_slot[f], e, leaf_job[f], 2, 0, 0);
+                            ok = publish(queued, node, e, child, 2, leaf_job[f], depth, leaf_slot[f]);
                         } else {
                             if (n_keys < kLeafKeys) {
                                 if (lane == 0) { leaf_key[n_keys] = key; leaf_slot[n_keys] = queued; leaf_job[n_keys] = jid; }
                                 ++n_keys;
                                 wave_sync();
                             }
-                            ok = publish(queued, node, e, child, 0, 0, depth);
+                            ok = publish(queued, node, e, child, 0, 0, depth, -1);
                         }
                         if (ok) ++queued;
                         break;
@@ -2047,7 +2088,7 @@ __global__ __launch_bounds__(192) void select_gumbel_pipe_kernel(SearchDev D, co
                         }
                         child = num_nodes++;
                         if (node == 0) {
-                            const int owner = e & 63, rr = e >> 6;
+                            const int owner = root_pos & 63, rr = root_pos >> 6;
 #pragma unroll
                             for (int r = 0; r < R; ++r)
                                 if (r == rr && lane == owner) r_idx[r] = child;
@@ -2059,7 +2100,7 @@ __global__ __launch_bounds__(192) void select_gumbel_pipe_kernel(SearchDev D, co
                             sh.jobof[child - n0] = (int16_t)jid;
                         }
                         wave_sync();
-                        ok = publish(-1, node, e, child, 1, nexp++, depth);
+                        ok = publish(-1, node, e, child, 1, nexp++, depth, -1);
                         if (!ok) break;
                     }
                     node = child;
@@ -2072,7 +2113,7 @@ __global__ __launch_bounds__(192) void select_gumbel_pipe_kernel(SearchDev D, co
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int i = lane + 64 * r;
-                if (i < r_nc) D.ch_vl[base + i] = r_cnt[r] - r_vis[r];
+                if (i < r_nc) D.ch_vl[base + r_edge[r]] = r_cnt[r] - r_vis[r];       // rank order -> child index
             }
             if (lane == 0) D.n_vl[(size_t)t * D.N] += r_added;
         }
@@ -2102,14 +2143,34 @@ __global__ __launch_bounds__(192) void select_gumbel_pipe_kernel(SearchDev D, co
             }
             if (!have) break;
             const PipeJob j = sh.job[slot];
+            if (j.k >= 0) {
+                // the leaf's queue entry and the virtual losses of its path below the root (node.py:76-83) - what the
+                // selector would otherwise spend ~2 k cycles per descent on (64-bit addressing of seven arrays)
+                const size_t qs = (size_t)t * D.K + j.k;
+                if (lane == 0) {
+                    D.q_node[qs] = j.child;
+                    D.q_pnode[qs] = j.parent;
+                    D.q_pedge[qs] = j.edge;
+                    D.q_depth[qs] = (j.depth <= kPathCap && D.N <= (1 << 21)) ? j.depth : 0;
+                }
+                for (int i = lane; i < j.depth; i += 64) {
+                    const int entry = sh.paths[slot][i];
+                    if (i < kPathCap) D.q_path[qs * kPathCap + i] = entry;
+                    if (i >= 1) {
+                        const size_t ns = (size_t)t * D.N + (entry >> 10);
+                        atomicAdd(&D.n_vl[ns], 1);
+                        atomicAdd(&D.ch_vl[ns * A + (entry & 1023)], 1);
+                    }
+                }
+            }
             if (j.expand == 2) {
-                // COPY: the planes of leaf slot j.parent (written by job j.child) are this leaf's planes
-                if (!pipe_wait_done(sh, j.child)) {
+                // COPY: the planes of leaf slot j.src (written by job j.xseq) are this leaf's planes
+                if (!pipe_wait_done(sh, j.xseq)) {
                     if (lane == 0) { atomicOr(&D.err[t], kErrPipeline); pipe_store(&sh.err, 1); }
                     break;
                 }
                 static_assert((6 * G::P) % 2 == 0, "8-byte copies");
-                const float2 *src = reinterpret_cast<const float2 *>(planes + (leaf_base + j.parent) * 6 * G::P);
+                const float2 *src = reinterpret_cast<const float2 *>(planes + (leaf_base + j.src) * 6 * G::P);
                 float2 *dst = reinterpret_cast<float2 *>(planes + (leaf_base + j.k) * 6 * G::P);
                 for (int i = lane; i < 3 * G::P; i += 64) dst[i] = src[i];
             } else {
