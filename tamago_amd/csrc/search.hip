@@ -2005,6 +2005,92 @@ __global__ __launch_bounds__(192) void select_gumbel_pipe_kernel(SearchDev D, co
             ++jid;
             return true;
         };
+        // Expansions first.  Every root child is entered several times in a phase, and only its FIRST descent can meet
+        // a node that has to be expanded (the later ones find it there; the new node's children are unvisited, so
+        // the descent ends right below it).  Waiting for each of those expansions in turn (replay + candidates +
+        // prior: ~5 us) was a third of a launch.  So the root choices of the phase are simulated on a copy of the
+        // counters (ballots: cheap), and each root child, at its first appearance, is walked down WITHOUT side
+        // effects to the point of expansion: the node is allocated and its EXPAND job queued - node numbers and
+        // draws in descent order, exactly as before - and nobody waits.  The descents proper then find the children
+        // allocated and wait, if at all, for a job that is about to finish.  Subtrees of different root children are
+        // disjoint and statistics are constant within a phase, so every choice is what the one-by-one order makes.
+        if (ok) {
+            int s_cnt[R];
+            unsigned long long seen[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) { s_cnt[r] = r_cnt[r]; seen[r] = 0ull; }
+            for (int th = 1; ok && th <= levels; ++th) {
+                for (int j = 0; ok && j < width; ++j) {
+                    int pos = -1;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const unsigned long long under = __ballot(lane + 64 * r < r_nc && s_cnt[r] < th);
+                        if (pos < 0 && under) pos = 64 * r + __ffsll((long long)under) - 1;
+                    }
+                    if (pos < 0) pos = pos0;
+                    const int owner = pos & 63, rr = pos >> 6;
+                    int m_mv = 0, m_vis = 0, m_idx = 0, m_e = 0;
+                    bool first = false;
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        if (r == rr) {
+                            m_mv = r_act[r]; m_vis = r_vis[r]; m_idx = r_idx[r]; m_e = r_edge[r];
+                            first = !((seen[r] >> owner) & 1ull);            // wave-uniform bookkeeping
+                            seen[r] |= 1ull << owner;
+                            if (lane == owner) s_cnt[r] += 1;
+                        }
+                    if (!first) continue;
+                    int node = 0, depth = 0;
+                    int mv = __builtin_amdgcn_readlane(m_mv, owner);
+                    int visits = __builtin_amdgcn_readlane(m_vis, owner);
+                    int child = __builtin_amdgcn_readlane(m_idx, owner);
+                    int e = __builtin_amdgcn_readlane(m_e, owner);
+                    while (ok) {
+                        if (depth >= kPathMax<S>) break;                  // the descent proper reports it
+                        if (lane == 0) { sel_moves[depth] = (int16_t)mv; sel_path[depth] = (node << 10) | e; }
+                        ++depth;
+                        wave_sync();
+                        if (visits < 1) break;                            // ends on a leaf: nothing to expand
+                        if (child == kNotExpanded) {
+                            if (num_nodes >= D.N || num_nodes - n0 >= kPipeMaxK) break;   // reported by the descent proper
+                            child = num_nodes++;
+                            if (node == 0) {
+#pragma unroll
+                                for (int r = 0; r < R; ++r)
+                                    if (r == rr && lane == owner) r_idx[r] = child;
+                            } else if (lane == 0) {
+                                memo_child[node & (kMemo - 1)] = child;
+                            }
+                            if (lane == 0) {
+                                D.ch_index[((size_t)t * D.N + node) * A + e] = child;
+                                sh.jobof[child - n0] = (int16_t)jid;
+                            }
+                            wave_sync();
+                            ok = publish(-1, node, e, child, 1, nexp++, depth, -1);
+                            break;                                        // its children are unvisited: a leaf follows
+                        }
+                        node = child;
+                        if (node >= n0) break;                            // (created in this launch: cannot happen, subtrees are disjoint)
+                        const int slot = node & (kMemo - 1);
+                        if (memo_tag[slot] != node) {
+                            e = select_node_halving<S>(hs, D, t, node, lane);
+                            const size_t nb = ((size_t)t * D.N + node) * A;
+                            mv = D.action[nb + e];
+                            visits = D.ch_visits[nb + e];
+                            child = D.ch_index[nb + e];
+                            wave_sync();
+                            if (lane == 0) {
+                                memo_tag[slot] = node; memo_edge[slot] = e; memo_move[slot] = mv;
+                                memo_vis[slot] = visits; memo_child[slot] = child;
+                            }
+                            wave_sync();
+                        } else {
+                            e = memo_edge[slot]; mv = memo_move[slot]; visits = memo_vis[slot]; child = memo_child[slot];
+                        }
+                    }
+                }
+            }
+        }
         for (int th = 1; ok && th <= levels; ++th) {
             for (int j = 0; ok && j < width; ++j) {
                 if (pipe_load(&sh.err)) { ok = false; break; }
