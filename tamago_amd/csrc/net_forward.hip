@@ -774,7 +774,7 @@ int tg_net_create(int board_size, int device, const float *params, size_t n_para
         tg_net_destroy(net);
         return rc;
     }
-    if (board_size == 9 && (rc = tg::split_prepare(net, conv0_raw, tower_raw, scale.data()))) {
+    if ((rc = tg::split_prepare(net, conv0_raw, tower_raw, scale.data()))) {
         tg_net_destroy(net);
         return rc;
     }
@@ -817,8 +817,10 @@ static bool pick_split() {
 
 const char *tg_net_kernel_name(const tg_net *net, int batch) {
     if (!net) return "";
-    if (net->board_size == 19)
+    if (net->board_size == 19) {
+        if (pick_split()) return "dualnet_fwd_split_kernel<19, 1, f16x2>";
         return pick_wino(19, batch, net->num_cus) ? "dualnet_fwd_wino8_kernel<19, 1, global scratch>" : "dualnet_fwd_kernel<19, 1>";
+    }
     if (pick_split()) return batch > net->num_cus ? "dualnet_fwd_split_kernel<9, 3, f16x2>" : "dualnet_fwd_split_kernel<9, 1, f16x2>";
     {
         const int wg = pick_wino(9, batch, net->num_cus);
@@ -836,11 +838,11 @@ double tg_net_executed_flops_per_position(const tg_net *net, int batch, double *
     double peak = 157.3;
     const char *name = "f32";
     double flops = 0.0;
-    if (S == 9 && pick_split()) {
+    if ((S == 9 || S == 19) && pick_split()) {
         // per workgroup pass: (2 stem + 12 * 18) k-chunks x (4 cout tiles x row tiles) x 3 products of
         // v_mfma_f32_16x16x32_f16 (16 384 FLOP each)
-        const int g = batch > net->num_cus ? 3 : 1;
-        const int row_tiles = g == 3 ? 16 : 6;              // 4 waves x 4, 3 waves x 2
+        const int g = S == 19 ? 1 : (batch > net->num_cus ? 3 : 1);
+        const int row_tiles = S == 19 ? 24 : (g == 3 ? 16 : 6);   // 4 waves x 6 | 4 waves x 4 | 3 waves x 2
         flops = (2.0 + 12.0 * 18.0) * 4.0 * row_tiles * 3.0 * 16384.0 / g;
         peak = 2500.0;
         name = "f16 (2 operand pieces, fp32 accumulate)";
@@ -886,6 +888,21 @@ int tg_net_forward_dev(tg_net *net, const float *planes_dev, int batch, int want
         return tg::fail(TG_ERR_ARG, "tg_net_forward_dev: null argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (net->board_size == 19) {
+        if (pick_split()) {
+            // split-operand kernel (one board per workgroup, residual image in the per-stream scratch), the exact
+            // fp32 Winograd kernel behind it as the range-guard fallback - as at 9x9 below
+            int *flag = nullptr;
+            {
+                std::lock_guard<std::mutex> lock(net->scratch_mu);
+                int *&slot = net->flag_by_stream[st];
+                if (!slot) TG_HIP(hipMalloc(reinterpret_cast<void **>(&slot), sizeof(int)));
+                flag = slot;
+            }
+            TG_HIP(hipMemsetAsync(flag, 0, sizeof(int), st));
+            int rc = tg::split_forward(net, 1, planes_dev, batch, want_logits, policy_dev, value_dev, flag, st);
+            if (rc) return rc;
+            return launch_wino8<19, 1, true>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st, flag);
+        }
         if (pick_wino(19, batch, net->num_cus))
             return launch_wino8<19, 1, true>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st);
         return launch<19, 1>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st);

@@ -64,7 +64,11 @@ template <int S, int G, typename F>
 struct SplitCfg {
     static constexpr int P = S * S, A = P + 1, M = G * P;
     static constexpr int MT = (M + 15) / 16;
-    static constexpr int RTW = G == 3 ? 4 : 2;                    // row-tiles per wave
+    // 19x19 (one board per workgroup, 23 row-tiles): four waves of six row-tiles; the residual image (93 KB)
+    // does not fit into LDS next to the activation images and lives in an L2-resident scratch image per workgroup;
+    // the policy FC weights (1 MB) are read from L2 by the generic head code
+    static constexpr bool BIG = S > 9;
+    static constexpr int RTW = BIG ? 6 : (G == 3 ? 4 : 2);        // row-tiles per wave
     static constexpr int NW = (MT + RTW - 1) / RTW;               // waves per workgroup
     static constexpr int NTHR = NW * 64;
     static constexpr int IMG = (M + 2) * 64;                      // one [row][64 B] image + zero row M + dump row M + 1
@@ -81,7 +85,8 @@ struct SplitCfg {
     static constexpr int HEAD_IMG = ((M + 1) * kRowBytes + 255) & ~255;
     static constexpr int RES_OFF = STAGE_END > HEAD_IMG ? STAGE_END : HEAD_IMG;
     static constexpr int FC_BYTES = ((2 * P * A * 4 + 4095) / 4096) * 4096;          // policy FC, [2P][A] fp32, padded
-    static constexpr int RES_BYTES = (M + 1) * 256 > FC_BYTES ? (M + 1) * 256 : FC_BYTES;
+    static constexpr int RES_BYTES = BIG ? 0 : ((M + 1) * 256 > FC_BYTES ? (M + 1) * 256 : FC_BYTES);
+    static constexpr int RES_ROWS = M + 2;                        // rows of the global residual image (BIG)
     static constexpr int SS_OFF = RES_OFF + RES_BYTES;           // folded BN scale [13][64] + shift [13][64]
     // head tables, staged once per workgroup: 1x1 weights [64][4] (policy 0, policy 1, value, 0), policy FC bias [A]
     // (padded), BN scale / shift of the three head channels [8].  (In the heads every use of a kernel-argument
@@ -153,7 +158,7 @@ __device__ __forceinline__ void run_heads_split(unsigned char *smem, const NetDe
     asm volatile("" : "+v"(tid));                          // opaque: nothing derived from it below is hoisted out of
     const int lane = tid & 63;                             // the caller's group loop (and spilled there)
     auto stamp = [&](int i) { if (tl && tid == 0) tl[i] = (long long)__builtin_amdgcn_s_memtime(); };
-    {
+    if constexpr (!C::BIG) {
         constexpr int PIECES = C::FC_BYTES / 1024;
         const unsigned char *src = reinterpret_cast<const unsigned char *>(net.pfc_wT) + lane * 16;
 #pragma unroll 1
@@ -220,7 +225,42 @@ __device__ __forceinline__ void run_heads_split(unsigned char *smem, const NetDe
     __syncthreads();
     stamp(1);
     const float *fcw = reinterpret_cast<const float *>(smem + C::RES_OFF);
-    {
+    if constexpr (C::BIG) {
+        // 19x19 policy FC: 2P x A = 1 MB of weights per board, streamed from L2 exactly once - every wave takes a quarter
+        // of K for ALL outputs (six per lane, coalesced rows of the transposed weight matrix), eight k-rows = 48
+        // independent loads in flight; the partial sums meet in LDS like the small boards'.  (One output per thread
+        // with four partial sums kept four loads in flight: 130 us per board, 40 % of the kernel.)
+        static_assert(G == 1, "one board per workgroup");
+        constexpr int K = 2 * P, KQ = (K + NW - 1) / NW;
+        constexpr int OPL = (A + 63) / 64;                 // outputs per lane
+        const int k0 = wave * KQ, k1 = k0 + KQ < K ? k0 + KQ : K;
+        float accf[OPL];
+#pragma unroll
+        for (int i = 0; i < OPL; ++i) accf[i] = 0.f;
+        const float *wrow = net.pfc_wT + lane;
+        for (int k = k0; k < k1; k += 8) {
+            float w[8][OPL], h[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int kk = k + u < k1 ? k + u : k1 - 1;
+                h[u] = k + u < k1 ? hpol[kk] : 0.f;
+#pragma unroll
+                for (int i = 0; i < OPL; ++i) {
+                    const int a = lane + 64 * i;
+                    w[u][i] = wrow[(size_t)kk * A + (a < A ? 64 * i : 0)];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int i = 0; i < OPL; ++i) accf[i] = fmaf(h[u], w[u][i], accf[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < OPL; ++i) {
+            const int a = lane + 64 * i;
+            if (a < A) plog_part[wave * A + a] = accf[i];
+        }
+    } else {
         // policy FC on the fp32 matrix pipe: rows = the G boards (13+ of 16 rows idle), columns = 16 of the A
         // outputs per tile, K = 2P inputs in 41 steps of 4 with k = 41 lg + ks (contiguous per lane group; k >= 2P
         // masked).  One thread per output on the VALU needed 2 x 162 LDS reads per output: 13 k cycles.
@@ -313,6 +353,9 @@ __global__ __launch_bounds__((SplitCfg<S, G, F>::NTHR), 1) void dualnet_fwd_spli
     NetDev net, const float *__restrict__ planes, int batch, int want_logits,
     float *__restrict__ policy, float *__restrict__ value, int *__restrict__ overflow) {
     using C = SplitCfg<S, G, F>;
+    // 19x19: this workgroup's residual image [row][64] fp32 in the per-stream scratch (every lane re-reads only what
+    // it wrote itself two layers earlier: no fence needed)
+    float *const resg = C::BIG ? net.scratch + (size_t)blockIdx.x * C::RES_ROWS * 64 : nullptr;
     constexpr int P = C::P, M = C::M, RTW = C::RTW, NTHR = C::NTHR, NP = F::NP, IMG = C::IMG;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -394,8 +437,8 @@ __global__ __launch_bounds__((SplitCfg<S, G, F>::NTHR), 1) void dualnet_fwd_spli
             for (int i = 0; i < NPL; ++i)
                 if (stid + i * NTHR < G * 6 * P) st[stid + i * NTHR] = pre[i];
             __syncthreads();
-            if (stid < M) {                                 // one thread per position
-                const int row = stid, bl = row / P, p = row - bl * P, y = p / S, x = p - y * S;
+            for (int row = stid; row < M; row += NTHR) {     // one thread per position (19x19: two passes)
+                const int bl = row / P, p = row - bl * P, y = p / S, x = p - y * S;
                 const float *src = st + bl * 6 * P + p;
                 const int swz = (row >> 1) & 3;
 #pragma unroll
@@ -426,7 +469,10 @@ __global__ __launch_bounds__((SplitCfg<S, G, F>::NTHR), 1) void dualnet_fwd_spli
         f32x4 acc[F::NACC][4][RTW];
         // fragment sets: weights (A operand) three deep - requested TWO k-chunks ahead from L2 -, activations
         // (B operand) two deep - requested one chunk ahead from LDS
-        i32x4v fa[3][4][NP], fb[2][RTW][NP];
+        // (19x19, six row-tiles per wave: two weight sets, one chunk ahead - a third set does not fit the register file
+        // next to 192 accumulators and 96 activation-fragment registers, and a chunk is 1.5x as long there)
+        constexpr int NASET = C::BIG ? 2 : 3, ADIST = NASET - 1;
+        i32x4v fa[NASET][4][NP], fb[2][RTW][NP];
 
         // B-fragment base address of row-tile r for tap `tap` of layer kind `stem`
         auto row_addr = [&](int r, int tap, bool stem) __attribute__((always_inline)) {
@@ -453,19 +499,23 @@ __global__ __launch_bounds__((SplitCfg<S, G, F>::NTHR), 1) void dualnet_fwd_spli
                 gmem_load_frag(fa[set][c][p], base, wvg + (p * 4 + c) * 1024);
             });
         };
-        // chunk gc uses weight set (gc + 1) % 3: the stem's two chunks take sets 1 and 2, every tower layer
-        // (18 chunks) starts at set 0
-        load_a_all(std::integral_constant<int, 1>{}, 0);
-        load_a_all(std::integral_constant<int, 2>{}, 1);
+        // three sets: chunk gc uses weight set (gc + 1) % 3 - the stem's two chunks take sets 1 and 2, every tower
+        // layer (18 chunks) starts at set 0; two sets: chunk gc uses set gc % 2
+        if constexpr (NASET == 3) {
+            load_a_all(std::integral_constant<int, 1>{}, 0);
+            load_a_all(std::integral_constant<int, 2>{}, 1);
+        } else {
+            load_a_all(std::integral_constant<int, 0>{}, 0);
+        }
 
         // One k-chunk: wait for its fragments, 4 * RTW * NPROD MFMAs; in between, the activation fragments of the
         // next chunk (LDS, set 1 - BSET) and the weight fragments of the chunk after next (L2, the set this
         // chunk's predecessor used).  ba: this tap's row addresses (for a KC = 0 chunk's successor), bn: the
         // next tap's.
         auto chunk = [&](auto KC_, auto ASET_, int gc, const int (&ba)[RTW], const int (&bn)[RTW]) __attribute__((always_inline)) {
-            constexpr int kc = decltype(KC_)::value, aset = decltype(ASET_)::value, anext = (aset + 2) % 3;
+            constexpr int kc = decltype(KC_)::value, aset = decltype(ASET_)::value % NASET, anext = (aset + ADIST) % NASET;
             // (this chunk's fragments went out one / two chunks ago; hipcc places the counted waits)
-            const unsigned char *wnext = net.wsplit + (size_t)(gc + 2 < kChunks ? gc + 2 : kChunks - 1) * C::CHUNK;
+            const unsigned char *wnext = net.wsplit + (size_t)(gc + ADIST < kChunks ? gc + ADIST : kChunks - 1) * C::CHUNK;
             constexpr int NMFMA = 4 * RTW * F::NPROD;
             constexpr int NB = RTW * NP, NA = 4 * NP;
             constexpr int BSPAN = NMFMA * SPANQ / 16;      // activation loads: during the first SPANQ/16 of the chunk
@@ -516,8 +566,8 @@ __global__ __launch_bounds__((SplitCfg<S, G, F>::NTHR), 1) void dualnet_fwd_spli
                 load_b(fb[0][r][p], std::integral_constant<int, p>{}, I0{}, ba[r]);
             });
             if (stem) {
-                chunk(I0{}, I1{}, gc, ba, ba);
-                chunk(I1{}, I2{}, gc + 1, ba, ba);
+                chunk(I0{}, std::integral_constant<int, NASET == 3 ? 1 : 0>{}, gc, ba, ba);
+                chunk(I1{}, std::integral_constant<int, NASET == 3 ? 2 : 1>{}, gc + 1, ba, ba);
                 gc += 2;
             } else {
 #pragma unroll 1
@@ -528,12 +578,12 @@ __global__ __launch_bounds__((SplitCfg<S, G, F>::NTHR), 1) void dualnet_fwd_spli
                     chunk(I1{}, I1{}, gc + 1, ba, bn);
 #pragma unroll
                     for (int r = 0; r < RTW; ++r) { ba[r] = bn[r]; bn[r] = row_addr(r, t3 + 2, false); }
-                    chunk(I0{}, I2{}, gc + 2, ba, bn);
-                    chunk(I1{}, I0{}, gc + 3, ba, bn);
+                    chunk(I0{}, I2{}, gc + 2, ba, bn);                      // (sets taken modulo the number of sets)
+                    chunk(I1{}, std::integral_constant<int, 3>{}, gc + 3, ba, bn);
 #pragma unroll
                     for (int r = 0; r < RTW; ++r) { ba[r] = bn[r]; bn[r] = row_addr(r, t3 + 3 < 9 ? t3 + 3 : 8, false); }
-                    chunk(I0{}, I1{}, gc + 4, ba, bn);
-                    chunk(I1{}, I2{}, gc + 5, ba, bn);
+                    chunk(I0{}, std::integral_constant<int, 4>{}, gc + 4, ba, bn);
+                    chunk(I1{}, std::integral_constant<int, 5>{}, gc + 5, ba, bn);
 #pragma unroll
                     for (int r = 0; r < RTW; ++r) ba[r] = bn[r];
                     gc += 6;
@@ -568,7 +618,10 @@ __global__ __launch_bounds__((SplitCfg<S, G, F>::NTHR), 1) void dualnet_fwd_spli
                     if constexpr (add_res) {
 #pragma unroll
                         for (int r = 0; r < RTW; ++r)
-                            xres[c][r] = *reinterpret_cast<const f32x4 *>(smem + C::RES_OFF + rrow[r] * 256 + (((c * 4 + lg) ^ (rrow[r] & 15)) << 4));
+                            if constexpr (C::BIG)
+                                xres[c][r] = *reinterpret_cast<const f32x4 *>(resg + rrow[r] * 64 + c * 16 + lg * 4);
+                            else
+                                xres[c][r] = *reinterpret_cast<const f32x4 *>(smem + C::RES_OFF + rrow[r] * 256 + (((c * 4 + lg) ^ (rrow[r] & 15)) << 4));
                     }
                 }
 #pragma unroll
@@ -590,9 +643,13 @@ __global__ __launch_bounds__((SplitCfg<S, G, F>::NTHR), 1) void dualnet_fwd_spli
                             const int hrow = brow[r] < M ? brow[r] : M;
                             *reinterpret_cast<f32x4 *>(smem + hrow * kRowBytes + (c * 16 + lg * 4) * 4) = v;
                         } else {
-                            if constexpr (keep)
-                                *reinterpret_cast<f32x4 *>(smem + C::RES_OFF + (brow[r] < M ? brow[r] : M) * 256 +
-                                                           (((c * 4 + lg) ^ (brow[r] & 15)) << 4)) = v;
+                            if constexpr (keep) {
+                                if constexpr (C::BIG)
+                                    *reinterpret_cast<f32x4 *>(resg + (brow[r] < M ? brow[r] : M) * 64 + c * 16 + lg * 4) = v;
+                                else
+                                    *reinterpret_cast<f32x4 *>(smem + C::RES_OFF + (brow[r] < M ? brow[r] : M) * 256 +
+                                                               (((c * 4 + lg) ^ (brow[r] & 15)) << 4)) = v;
+                            }
                             uint2 pc[NP];
                             split4<F>(v, pc);
                             const int slot = (((c & 1) << 1) | (lg >> 1)) ^ ((row >> 1) & 3);
@@ -687,7 +744,21 @@ int launch_split(tg_net *net, const float *planes, int batch, int want_logits, f
     }
     const int groups = (batch + G - 1) / G;
     const int grid = groups < net->num_cus ? groups : net->num_cus;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTHR), C::LDS_BYTES, stream, net->dev, planes, batch, want_logits,
+    NetDev dev = net->dev;
+    if (C::BIG) {
+        // residual images: the per-stream scratch the 19x19 Winograd kernel uses (two [P][64] images per workgroup -
+        // more than the [P + 2][64] needed here); launches on one stream run in order
+        static_assert(!C::BIG || C::RES_ROWS * 64 <= 2 * C::P * 64, "scratch image");
+        std::lock_guard<std::mutex> lock(net->scratch_mu);
+        float *&slot = net->scratch_by_stream[stream];
+        if (!slot) {
+            void *d = nullptr;
+            TG_HIP(hipMalloc(&d, net->scratch_floats * sizeof(float)));
+            slot = static_cast<float *>(d);
+        }
+        dev.scratch = slot;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTHR), C::LDS_BYTES, stream, dev, planes, batch, want_logits,
                        policy, value, overflow);
     TG_HIP(hipGetLastError());
     return TG_OK;
@@ -758,7 +829,8 @@ int split_prepare(tg_net *net, const float *conv0, const float *const *tower, co
 // group = boards per workgroup (1 or 3); 9x9 only.
 int split_forward(tg_net *net, int group, const float *planes, int batch, int want_logits, float *policy,
                   float *value, int *overflow, hipStream_t stream) {
-    if (net->board_size != 9) return tg::fail(TG_ERR_ARG, "split forward: 9x9 only");
+    if (net->board_size == 19) return launch_split<19, 1, FmtF16>(net, planes, batch, want_logits, policy, value, overflow, stream);
+    if (net->board_size != 9) return tg::fail(TG_ERR_ARG, "split forward: 9x9 and 19x19 only");
     if (group == 3) {
         if (const char *env = getenv("TG_SPLIT_SPAN")) {              // tuning knob
             const int q = atoi(env);

@@ -117,12 +117,13 @@ def test_featurize_kernel_vs_reference_golden(size):
 
 
 @pytest.mark.parametrize("size,algo", [(9, "direct"), (9, "wino"), (9, "split16"),
-                                       (19, "direct"), (19, "wino")])
+                                       (19, "direct"), (19, "wino"), (19, "split16")])
 def test_every_tower_algorithm_matches_the_oracle(algo, size, monkeypatch):
     """Implementations of the residual tower: exact-fp32 Winograd F(2x2,3x3) kernel (TG_FWD_ALGO=wino; the
-    19x19 default, layer outputs passing through a global scratch image), exact-fp32 direct implicit GEMM
-    (direct), and for 9x9 the split-operand kernel on the 16-bit matrix pipe (split16 = f16 x 2 pieces, the
-    9x9 default).  All must agree with the oracle at every workgroup shape."""
+    layer outputs of a 19x19 board passing through a global scratch image), exact-fp32 direct implicit GEMM
+    (direct), and the split-operand kernel on the 16-bit matrix pipe (split16 = f16 x 2 pieces, the default at
+    both sizes; 19x19: one board per workgroup, residual image in an L2-resident scratch).  All must agree with
+    the oracle at every workgroup shape."""
     from oracle.net import OracleNet, make_state_dict
     monkeypatch.setenv("TG_FWD_ALGO", algo)
     sd = make_state_dict(size, 7, 1.5)

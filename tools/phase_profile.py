@@ -14,10 +14,11 @@ from tamago_amd.nn.network.dual_net import DualNet
 from tamago_amd import lib as tl
 
 lib = tl.load()
-net = DualNet(torch.device("cuda:0"), 9)
+size = int(sys.argv[2]) if len(sys.argv) > 2 else 9
+net = DualNet(torch.device("cuda:0"), size)
 b = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-x = torch.randint(-1, 2, (b, 6, 9, 9), device="cuda").float()
-pol = torch.empty((b, 82), device="cuda")
+x = torch.randint(-1, 2, (b, 6, size, size), device="cuda").float()
+pol = torch.empty((b, size * size + 1), device="cuda")
 val = torch.empty((b, 3), device="cuda")
 st = np.zeros(128, dtype=np.int64)
 for _ in range(2):
@@ -30,9 +31,12 @@ if "split" in name:
     print(f"group total {s[28]} ticks; staging + im2col + split of the input {s[1]}")
     print("  MFMA loop (stem, then 12 layers):", [int(s[2 + 2 * i] - s[1 + 2 * i]) for i in range(13)])
     print("  barrier + epilogue + barrier    :", [int(s[3 + 2 * i] - s[2 + 2 * i]) for i in range(13)])
-    print("  heads                           :", int(s[28] - s[27]), " (1x1 convs", int(st[40] - st[27]),
-          "| FC weights landed + barrier", int(st[41] - st[40]), "| FCs", int(st[42] - st[41]), "| softmax + stores",
-          int(st[28] - st[42]), ")")
+    if size == 9:
+        print("  heads                           :", int(s[28] - s[27]), " (1x1 convs", int(st[40] - st[27]),
+              "| FC weights landed + barrier", int(st[41] - st[40]), "| FCs", int(st[42] - st[41]), "| softmax + stores",
+              int(st[28] - st[42]), ")")
+    else:
+        print("  heads                           :", int(s[28] - s[27]))
 elif "wino" in name:
     for label, s in (("half 0 (wave 0)", st[:64]), ("half 1 (wave 4)", st[64:])):
         s = s - st[0]
