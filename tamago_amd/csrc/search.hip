@@ -1125,7 +1125,7 @@ template <int S, int NSEL, int NWRK>
 struct MPipeShared {
     static constexpr int kMpSlots = 2 * NWRK;      // job ring; a multiple of the worker count
     static constexpr int kRing = 2 * NSEL;         // rows of lvl_node: a row is reused only after its reader is done
-    Lds<S> board[NWRK];
+    Lds<S, false> board[NWRK];
     PipeJob job[kMpSlots];
     int16_t moves[kMpSlots][kPipeMaxDepth];
     int job_seq[kMpSlots];            // k + 1 once job k sits in its slot
@@ -1408,7 +1408,7 @@ __global__ __launch_bounds__(64 * (NSEL + NWRK)) void select_puct_mpipe_kernel(S
     } else {
         // ---- workers: job k on wave k % NWRK --------------------------------------------------
         const int w = wid - NSEL;
-        Lds<S> &L = sh.board[w];
+        Lds<S, false> &L = sh.board[w];
         BoardScalars rootb;
         int root_to_move;
         load_root<S>(L, rootb, root_to_move, D, t, lane);
@@ -1488,10 +1488,9 @@ int launch_mpipe(const SearchDev &dev, int max_leaves, float *planes, hipStream_
         return launch_mpipe_cfg<S, 6, 10>(dev, max_leaves, planes, st);
     } else {
         if (cfg == 404) return launch_mpipe_cfg<S, 4, 4>(dev, max_leaves, planes, st);
-        if (cfg == 405) return launch_mpipe_cfg<S, 4, 5>(dev, max_leaves, planes, st);
         if (cfg == 605) return launch_mpipe_cfg<S, 6, 5>(dev, max_leaves, planes, st);
-        if (cfg == 805) return launch_mpipe_cfg<S, 8, 5>(dev, max_leaves, planes, st);
-        return launch_mpipe_cfg<S, 4, 4>(dev, max_leaves, planes, st);
+        if (cfg == 806) return launch_mpipe_cfg<S, 8, 6>(dev, max_leaves, planes, st);
+        return launch_mpipe_cfg<S, 6, 6>(dev, max_leaves, planes, st);
     }
 }
 
