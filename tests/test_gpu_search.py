@@ -322,20 +322,24 @@ def test_search_with_callback_and_ponder():
 
 @pytest.mark.parametrize("cfg", ["9 24 64 4", "9 1 256 4", "19 6 32 4"])
 def test_pipelined_selection_equals_serial(cfg):
-    """select_puct_pipe_kernel (selector + two worker wavefronts per tree, the default) builds
-    exactly the trees of the one-wavefront kernel (TG_SELECT_SERIAL=1): ragged roots, superko,
-    several mini-batches with a short last one."""
+    """The pipelined PUCT selection kernels - select_puct_mpipe_kernel (descents pipelined over several selector
+    waves + board workers, the default up to 256 trees) and select_puct_pipe_kernel (selector + two workers per
+    tree, for more trees; forced here with TG_SELECT_MPIPE_TREES=0) - build exactly the trees of the one-wavefront
+    kernel (TG_SELECT_SERIAL=1): ragged roots, superko, several mini-batches with a short last one."""
     import os
     import subprocess
     import sys
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_select_digest.py")
     outs = []
-    for serial in (True, False, False):
+    for variant in ("serial", "mpipe", "mpipe", "pipe"):
         env = dict(os.environ)
         env.pop("TG_SELECT_SERIAL", None)
-        if serial:
+        env.pop("TG_SELECT_MPIPE_TREES", None)
+        if variant == "serial":
             env["TG_SELECT_SERIAL"] = "1"
+        elif variant == "pipe":
+            env["TG_SELECT_MPIPE_TREES"] = "0"
         res = subprocess.run([sys.executable, script] + cfg.split(), env=env, capture_output=True, text=True, timeout=600)
         assert res.returncode == 0, res.stderr[-2000:]
         outs.append(res.stdout.strip().splitlines()[-1])
-    assert outs[0] == outs[1] == outs[2], outs
+    assert outs[0] == outs[1] == outs[2] == outs[3], outs
