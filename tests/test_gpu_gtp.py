@@ -1,5 +1,9 @@
 """GTP front end (next row 8(f).2) on the device search: a command script end to end; genmove
-equals MCTSTree.search_best_move on the same position and random state."""
+equals MCTSTree.search_best_move on the same position and random state.
+
+This file compares the product WITH ITSELF (command loop vs direct search).  What pins the GTP row to the
+reference are the lz- / cgos-analysis strings and PV lines (byte-identical to reference-recorded goldens,
+tests/test_gpu_search.py) and the search itself (tree fixtures); the command loop has no reference recording."""
 import io
 import sys
 
