@@ -11,11 +11,13 @@
 //   legality incl. positional superko, self-atari, complete-eye filter)
 //   nn/feature.py:10-57 for the leaf boards.
 //
-// One wavefront (= one 64-thread workgroup) owns one tree.  The node pool is a
+// One workgroup owns one tree; inside it every WAVEFRONT has a role of its own (selector, board worker, value or
+// policy backup) and works alone on its data - the one-wavefront kernels are the reference forms of the pipelined
+// ones (select_puct_pipe / select_puct_mpipe / select_gumbel_pipe).  The node pool is a
 // structure-of-arrays in HBM ([tree][node][child] per field); PUCB / Gumbel selection is
 // a 64-lane arg-max reduction with lowest-index tie-break, in float64 exactly as numpy
 // evaluates it; expansion tests all on-board points in parallel (one lane per point) on
-// a board held in LDS; backup walks parent links.  Boards use an O(1)-state
+// a board held in LDS; backup walks the recorded path (or parent links).  Boards use an O(1)-state
 // representation (cell colour + string id = smallest stone coordinate); liberties,
 // sizes and string hashes are recomputed with LDS atomics when a node is expanded, so
 // nothing has to be copied per descent except 3 bytes per cell.
@@ -26,7 +28,8 @@
 //     mcts/tree.py:297-313);
 //   * PUCB is float64 with IEEE division and sqrt; this file is compiled with
 //     -ffp-contract=off so no FMA is formed behind the source's back;
-//   * the random draws come from the host (libm log) through tg_search_set_rng.
+//   * the random draws come from the host side of the library (libm log; csrc/legacy_stream.h) or from the
+//     caller through tg_search_set_rng.
 #include "common.h"
 #include "legacy_stream.h"
 
@@ -43,10 +46,11 @@
 
 namespace {
 
-// Every kernel of this file runs ONE wavefront per workgroup.  LDS and vector-memory operations
-// of a wavefront execute in order, so cross-lane hand-offs need no s_barrier (and no drain of the
-// outstanding global loads / stores that the compiler puts in front of one): wavefront-scope
-// fences order the accesses for the compiler and cost no instruction.
+// Hand-offs between the LANES of one wavefront (every role in this file is one wavefront).  LDS and vector-memory
+// operations of a wavefront execute in order, so they need no s_barrier (and no drain of the outstanding global
+// loads / stores that the compiler puts in front of one): wavefront-scope fences order the accesses for the
+// compiler and cost no instruction.  Hand-offs BETWEEN wavefronts go through LDS flags with workgroup-scope
+// release / acquire (pipe_store / pipe_load below).
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
