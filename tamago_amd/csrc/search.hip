@@ -3273,7 +3273,8 @@ struct tg_selfplay {
     std::vector<double> vsum_a, pol_a;
     std::vector<int16_t> act_a;
     std::vector<uint8_t> cells;
-    std::vector<int32_t> ph_nc, ph_mc, mv, fin;       // tg_selfplay_play_move scratch
+    std::vector<int32_t> ph_nc, ph_mc, mv, fin;
+    std::vector<int32_t> ph_seen;          // per tree: root children entered so far in this move (upper bound)       // tg_selfplay_play_move scratch
     bool force_feed = true;                          // a stream was (re)seeded: the next random window is regenerated
 };
 
@@ -3575,17 +3576,26 @@ int tg_selfplay_play_move(tg_selfplay *sp, tg_net *net, float *planes_dev, float
     int32_t n_phases = 0;
     if ((rc = tg_selfplay_schedule(sp, sp->ph_nc.data(), sp->ph_mc.data(), kMaxPhases, &n_phases))) return rc;
     int64_t leaves = live;
+    // Random draws a phase can consume: one Dirichlet prior (<= A draws) per EXPANSION, and only the first descent
+    // through a root child can expand a node.  Root children entered in a phase: at most its width
+    // (new ones: the picks among the unvisited children are nested prefixes of their score order, the first round's
+    // being the largest) plus the children visited before the phase.  Provisioning slots * A draws per tree, as if
+    // every descent expanded, generated and uploaded 2.4x more random numbers than this bound.
+    sp->ph_seen.assign(T, 0);
     for (int ph = 0; ph < n_phases; ++ph) {
         const int32_t *nc = &sp->ph_nc[(size_t)ph * T], *mc = &sp->ph_mc[(size_t)ph * T];
-        int64_t total = 0, slots = 0;
+        int64_t total = 0, slots = 0, expansions = 0;
         for (int t = 0; t < T; ++t) {
             const int64_t n = (int64_t)nc[t] * mc[t];
             total += n;
             slots = n > slots ? n : slots;
+            const int64_t entered = std::min<int64_t>(n, std::min<int64_t>(A, (int64_t)nc[t] + sp->ph_seen[t]));
+            expansions = entered > expansions ? entered : expansions;
+            sp->ph_seen[t] = (int32_t)std::min<int64_t>(A, sp->ph_seen[t] + entered);
         }
         if (slots == 0) continue;
         lap(3);
-        if ((rc = tg_search_feed_streams(s, (size_t)slots * A, 0))) return rc;
+        if ((rc = tg_search_feed_streams(s, (size_t)expansions * A, 0))) return rc;
         lap(4);
         if ((rc = tg_search_select_gumbel(s, nc, mc, 0, planes_dev, stream))) return rc;
         // forward + backup go out before the cursor read-back (which waits for the selection kernel only)
