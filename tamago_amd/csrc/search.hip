@@ -2394,6 +2394,32 @@ __global__ __launch_bounds__(64) void play_kernel(SearchDev D, const int32_t *mo
 // ======================================================================================
 // host side
 // ======================================================================================
+// Root statistics of every tree packed into one record per tree (one launch + ONE device-to-host copy instead of
+// nine strided copies, each a host round trip): [num_children, node_visits, raw_value bits, error flags] then
+// visits[A], virtual_loss[A], action[A] (int32), value_sum[A], policy[A] (float64).
+__global__ __launch_bounds__(64) void gather_roots_kernel(SearchDev D, int A, unsigned char *out, size_t rec_bytes) {
+    const int t = blockIdx.x, lane = threadIdx.x;
+    const size_t ns = (size_t)t * D.N, base = ns * A;
+    unsigned char *rec = out + (size_t)t * rec_bytes;
+    int32_t *head = reinterpret_cast<int32_t *>(rec);
+    if (lane == 0) {
+        head[0] = D.n_children[ns];
+        head[1] = D.n_visits[ns];
+        head[2] = __float_as_int(D.n_raw[ns]);
+        head[3] = D.err[t];
+    }
+    int32_t *vis = head + 4, *vl = vis + A, *act = vl + A;
+    double *vsum = reinterpret_cast<double *>(rec + 16 + (size_t)3 * A * 4 + (((size_t)3 * A * 4) % 8 ? 4 : 0));
+    double *pol = vsum + A;
+    for (int i = lane; i < A; i += 64) {
+        vis[i] = D.ch_visits[base + i];
+        vl[i] = D.ch_vl[base + i];
+        act[i] = D.action[base + i];
+        vsum[i] = D.ch_vsum[base + i];
+        pol[i] = D.ch_policy[base + i];
+    }
+}
+
 struct tg_search {
     tg_search_config cfg{};
     SearchDev dev{};
@@ -2407,6 +2433,7 @@ struct tg_search {
     std::vector<uint8_t> st_dirty_tree;
     bool st_dirty = false;
     int32_t *phase_dev = nullptr;          // [num_considered | max_count | packed leaf offsets], T each
+    unsigned char *roots_dev = nullptr, *roots_host = nullptr;   // gather_roots_kernel records (device / pinned host)
     // pinned staging ring for the phase description: the host never waits for the copy of the current call, only
     // (practically never) for the one kPhaseRing calls ago
     static constexpr int kPhaseRing = 8;
@@ -2573,6 +2600,7 @@ int tg_search_destroy(tg_search *s) {
     if (!s) return TG_OK;
     (void)hipSetDevice(s->cfg.device);
     for (void *p : s->allocs) (void)hipFree(p);
+    if (s->roots_dev) { (void)hipFree(s->roots_dev); (void)hipHostFree(s->roots_host); }
     if (s->phase_pin) {
         (void)hipHostFree(s->phase_pin);
         for (int i = 0; i < tg_search::kPhaseRing; ++i) (void)hipEventDestroy(s->phase_ev[i]);
@@ -3037,55 +3065,64 @@ int tg_search_backup(tg_search *s, const float *policy_dev, const float *value_d
     return TG_OK;
 }
 
+}  // extern "C"
+
+// root records of all trees -> s->roots_host (pinned); also surfaces the sticky error flags
+static size_t root_rec_bytes(int A) {
+    size_t ints = 16 + (size_t)3 * A * 4;
+    if (ints % 8) ints += 4;
+    return ints + (size_t)2 * A * 8;
+}
+static int gather_roots(tg_search *s) {
+    const int T = s->dev.T, A = s->A;
+    const size_t rec = root_rec_bytes(A);
+    if (!s->roots_dev) {
+        TG_HIP(hipMalloc(reinterpret_cast<void **>(&s->roots_dev), rec * T));
+        TG_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->roots_host), rec * T));
+    }
+    hipStream_t st = s->last_stream;
+    hipLaunchKernelGGL(gather_roots_kernel, dim3(T), dim3(64), 0, st, s->dev, A, s->roots_dev, rec);
+    TG_HIP(hipGetLastError());
+    TG_HIP(hipMemcpyAsync(s->roots_host, s->roots_dev, rec * T, hipMemcpyDeviceToHost, st));
+    TG_HIP(hipStreamSynchronize(st));
+    for (int t = 0; t < T; ++t) {
+        const int32_t err = reinterpret_cast<const int32_t *>(s->roots_host + rec * t)[3];
+        if (err)
+            return tg::fail(TG_ERR_OVERFLOW, "tree %d: %s%s", t, (err & kErrPoolFull) ? "node pool full " : "",
+                            (err & kErrRngEmpty) ? "random window exhausted " : (err & kErrPipeline) ? "selection pipeline stalled or path too deep " : "");
+    }
+    return TG_OK;
+}
+
+extern "C" {
+
 int tg_search_read_roots(tg_search *s, int32_t *num_children_host, int32_t *action_host,
                          int32_t *visits_host) {
     if (!s || !num_children_host || !action_host || !visits_host)
         return tg::fail(TG_ERR_ARG, "tg_search_read_roots: null argument");
-    if (s->last_stream) TG_HIP(hipStreamSynchronize(s->last_stream));
-    else TG_HIP(hipDeviceSynchronize());
-    int rc = check_errors(s);
-    if (rc) return rc;
-    const SearchDev &D = s->dev;
-    const size_t A = s->A, T = D.T, N = D.N;
-    std::vector<int16_t> a16(A);
-    // root = node 0 of every tree: rows are N*A apart
-    TG_HIP(hipMemcpy2D(visits_host, A * sizeof(int32_t), D.ch_visits, N * A * sizeof(int32_t),
-                       A * sizeof(int32_t), T, hipMemcpyDeviceToHost));
-    TG_HIP(hipMemcpy2D(num_children_host, sizeof(int32_t), D.n_children, N * sizeof(int32_t),
-                       sizeof(int32_t), T, hipMemcpyDeviceToHost));
-    std::vector<int16_t> act(T * A);
-    TG_HIP(hipMemcpy2D(act.data(), A * sizeof(int16_t), D.action, N * A * sizeof(int16_t),
-                       A * sizeof(int16_t), T, hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < T * A; ++i) action_host[i] = act[i];
-    return TG_OK;
+    return tg_search_read_root_stats(s, num_children_host, nullptr, nullptr, action_host, visits_host, nullptr, nullptr, nullptr);
 }
 
 int tg_search_read_root_stats(tg_search *s, int32_t *num_children_host, int32_t *node_visits_host,
                               float *raw_value_host, int32_t *action_host, int32_t *visits_host,
                               int32_t *virtual_loss_host, double *value_sum_host, double *policy_host) {
     if (!s) return tg::fail(TG_ERR_ARG, "tg_search_read_root_stats: null argument");
-    if (s->last_stream) TG_HIP(hipStreamSynchronize(s->last_stream));
-    else TG_HIP(hipDeviceSynchronize());
-    int rc = check_errors(s);
+    int rc = gather_roots(s);
     if (rc) return rc;
-    const SearchDev &D = s->dev;
-    const size_t A = s->A, T = D.T, N = D.N;
-    // root = node 0 of every tree: per-tree rows are N*A (arrays) or N (scalars) apart
-#define RD2(dst, src, type, width, pitch) \
-    if (dst) TG_HIP(hipMemcpy2D(dst, (width) * sizeof(type), src, (pitch) * sizeof(type), (width) * sizeof(type), T, hipMemcpyDeviceToHost));
-    RD2(num_children_host, D.n_children, int32_t, 1, N)
-    RD2(node_visits_host, D.n_visits, int32_t, 1, N)
-    RD2(raw_value_host, D.n_raw, float, 1, N)
-    RD2(visits_host, D.ch_visits, int32_t, A, N * A)
-    RD2(virtual_loss_host, D.ch_vl, int32_t, A, N * A)
-    RD2(value_sum_host, D.ch_vsum, double, A, N * A)
-    RD2(policy_host, D.ch_policy, double, A, N * A)
-#undef RD2
-    if (action_host) {
-        std::vector<int16_t> act(T * A);
-        TG_HIP(hipMemcpy2D(act.data(), A * sizeof(int16_t), D.action, N * A * sizeof(int16_t), A * sizeof(int16_t), T,
-                           hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < T * A; ++i) action_host[i] = act[i];
+    const size_t A = s->A, T = s->dev.T, rec = root_rec_bytes((int)A);
+    for (size_t t = 0; t < T; ++t) {
+        const unsigned char *r = s->roots_host + rec * t;
+        const int32_t *head = reinterpret_cast<const int32_t *>(r);
+        const int32_t *vis = head + 4, *vl = vis + A, *act = vl + A;
+        const double *vsum = reinterpret_cast<const double *>(r + rec - 2 * A * 8), *pol = vsum + A;
+        if (num_children_host) num_children_host[t] = head[0];
+        if (node_visits_host) node_visits_host[t] = head[1];
+        if (raw_value_host) std::memcpy(&raw_value_host[t], &head[2], 4);
+        if (visits_host) std::memcpy(visits_host + t * A, vis, A * 4);
+        if (virtual_loss_host) std::memcpy(virtual_loss_host + t * A, vl, A * 4);
+        if (action_host) std::memcpy(action_host + t * A, act, A * 4);
+        if (value_sum_host) std::memcpy(value_sum_host + t * A, vsum, A * 8);
+        if (policy_host) std::memcpy(policy_host + t * A, pol, A * 8);
     }
     return TG_OK;
 }
