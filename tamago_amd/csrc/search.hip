@@ -3311,6 +3311,8 @@ struct tg_selfplay {
     std::vector<int16_t> act_a;
     std::vector<uint8_t> cells;
     std::vector<int32_t> ph_nc, ph_mc, mv, fin;
+    std::vector<int64_t> consumed;
+    bool nc_known = false;                 // nc holds the roots' child counts of the move in progress
     std::vector<int32_t> ph_seen;          // per tree: root children entered so far in this move (upper bound)       // tg_selfplay_play_move scratch
     bool force_feed = true;                          // a stream was (re)seeded: the next random window is regenerated
 };
@@ -3442,9 +3444,12 @@ int tg_selfplay_schedule(tg_selfplay *sp, int32_t *num_considered_host, int32_t 
         return tg::fail(TG_ERR_ARG, "tg_selfplay_schedule: null argument");
     tg_search *s = sp->s;
     const int T = s->dev.T;
-    sp->nc.resize(T);
-    int rc = tg_search_read_root_stats(s, sp->nc.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-    if (rc) return rc;
+    if (!sp->nc_known) {
+        sp->nc.resize(T);
+        int rc = tg_search_read_root_stats(s, sp->nc.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+        if (rc) return rc;
+    }
+    sp->nc_known = false;
     std::fill(num_considered_host, num_considered_host + (size_t)max_phases * T, 0);
     std::fill(max_count_host, max_count_host + (size_t)max_phases * T, 0);
     int n_phases = 0;
@@ -3479,8 +3484,11 @@ int tg_selfplay_finish_move(tg_selfplay *sp, int32_t *moves_host, int32_t *finis
                                        sp->vl_a.data(), sp->vsum_a.data(), sp->pol_a.data());
     if (rc) return rc;
     if (s->noise_host.size() != (size_t)T * A) return tg::fail(TG_ERR_STATE, "tg_selfplay_finish_move: no root noise was set");
+    // the boards are only needed to score a game that ends with this move, i.e. with a second pass in a row
+    bool may_end = false;
+    for (int t = 0; t < T; ++t) may_end |= !sp->games[t].done && sp->games[t].pass_count == 1;
     sp->cells.resize((size_t)T * s->NC);
-    TG_HIP(hipMemcpy(sp->cells.data(), D.root_cells, sp->cells.size(), hipMemcpyDeviceToHost));
+    if (may_end) TG_HIP(hipMemcpy(sp->cells.data(), D.root_cells, sp->cells.size(), hipMemcpyDeviceToHost));
     const int max_moves = S * S * 2;                                  // worker.py:44
     std::vector<int> status(T, TG_OK);
     std::vector<int64_t> n_moves(T, 0), n_games(T, 0);
@@ -3602,7 +3610,13 @@ int tg_selfplay_play_move(tg_selfplay *sp, tg_net *net, float *planes_dev, float
     if ((rc = tg_search_root_planes(s, planes_dev, stream))) return rc;
     if ((rc = tg_net_forward_dev(net, planes_dev, T, 1, policy_dev, value_dev, stream))) return rc;
     if ((rc = tg_search_backup(s, policy_dev, value_dev, 1, 1, stream))) return rc;
-    if ((rc = tg_search_advance_streams(s, nullptr))) return rc;
+    // the root expansion is the only consumer of draws in this launch, and a Dirichlet prior takes one draw per
+    // child: the cursor read-back IS the roots' child counts (saves the schedule's own device read)
+    sp->consumed.resize(T);
+    if ((rc = tg_search_advance_streams(s, sp->consumed.data()))) return rc;
+    sp->nc.resize(T);
+    for (int t = 0; t < T; ++t) sp->nc[t] = (int32_t)sp->consumed[t];
+    sp->nc_known = true;
     lap(1);
     if ((rc = tg_search_draw_noise(s, nullptr))) return rc;
     lap(2);
