@@ -3627,35 +3627,48 @@ int tg_selfplay_play_move(tg_selfplay *sp, tg_net *net, float *planes_dev, float
     int32_t n_phases = 0;
     if ((rc = tg_selfplay_schedule(sp, sp->ph_nc.data(), sp->ph_mc.data(), kMaxPhases, &n_phases))) return rc;
     int64_t leaves = live;
-    // Random draws a phase can consume: one Dirichlet prior (<= A draws) per EXPANSION, and only the first descent
+    // Random draws the phases can consume: one Dirichlet prior (<= A draws) per EXPANSION, and only the first descent
     // through a root child can expand a node.  Root children entered in a phase: at most its width
     // (new ones: the picks among the unvisited children are nested prefixes of their score order, the first round's
-    // being the largest) plus the children visited before the phase.  Provisioning slots * A draws per tree, as if
-    // every descent expanded, generated and uploaded 2.4x more random numbers than this bound.
+    // being the largest) plus the children visited before the phase.  ONE window for all phases of the move is
+    // generated and uploaded up front (the device cursor runs on from launch to launch) and the consumption is
+    // read back once, behind the last phase - not a window, an upload and a host synchronisation per phase, each
+    // sized as if every descent expanded (2.4x more draws).
     sp->ph_seen.assign(T, 0);
+    int64_t window = 0;
     for (int ph = 0; ph < n_phases; ++ph) {
         const int32_t *nc = &sp->ph_nc[(size_t)ph * T], *mc = &sp->ph_mc[(size_t)ph * T];
-        int64_t total = 0, slots = 0, expansions = 0;
+        int64_t expansions = 0;
         for (int t = 0; t < T; ++t) {
             const int64_t n = (int64_t)nc[t] * mc[t];
-            total += n;
-            slots = n > slots ? n : slots;
             const int64_t entered = std::min<int64_t>(n, std::min<int64_t>(A, (int64_t)nc[t] + sp->ph_seen[t]));
             expansions = entered > expansions ? entered : expansions;
             sp->ph_seen[t] = (int32_t)std::min<int64_t>(A, sp->ph_seen[t] + entered);
         }
+        window += expansions * A;
+    }
+    lap(3);
+    if (window > 0 && (rc = tg_search_feed_streams(s, (size_t)window, 0))) return rc;
+    lap(4);
+    bool any_phase = false;
+    for (int ph = 0; ph < n_phases; ++ph) {
+        const int32_t *nc = &sp->ph_nc[(size_t)ph * T], *mc = &sp->ph_mc[(size_t)ph * T];
+        int64_t total = 0, slots = 0;
+        for (int t = 0; t < T; ++t) {
+            const int64_t n = (int64_t)nc[t] * mc[t];
+            total += n;
+            slots = n > slots ? n : slots;
+        }
         if (slots == 0) continue;
-        lap(3);
-        if ((rc = tg_search_feed_streams(s, (size_t)expansions * A, 0))) return rc;
-        lap(4);
         if ((rc = tg_search_select_gumbel(s, nc, mc, 0, planes_dev, stream))) return rc;
-        // forward + backup go out before the cursor read-back (which waits for the selection kernel only)
         if ((rc = tg_net_forward_dev(net, planes_dev, (int)total, 1, policy_dev, value_dev, stream))) return rc;
         if ((rc = tg_search_backup(s, policy_dev, value_dev, 0, 1, stream))) return rc;
-        if ((rc = tg_search_advance_streams(s, nullptr))) return rc;
-        lap(5);
         leaves += total;
+        any_phase = true;
     }
+    lap(3);
+    if (any_phase && (rc = tg_search_advance_streams(s, nullptr))) return rc;
+    lap(5);
     // ---- move choice, records, finished games; play ----
     sp->mv.resize(T);
     int64_t counts[2] = {0, 0};
