@@ -185,7 +185,10 @@ def extra_legs(args, net, dev, local_rank, fresh_board):
                 "workload": f"ONE search tree, {size}x{size}, {visits} strict visits/move, NN batch {batch}"}
 
     # strict single-tree reading of config[1] (latency-bound: descent k+1 depends on the virtual loss of k)
-    out["single_tree"] = one_tree(args.size, net, args.visits, args.batch, 8)
+    try:
+        out["single_tree"] = one_tree(args.size, net, args.visits, args.batch, 8)
+    except Exception as exc:                              # the headline must not depend on a leg
+        out["single_tree"] = {"error": repr(exc)}
 
     def selfplay(boards, games):
         tmp = tempfile.mkdtemp(prefix="tg_sp_")
