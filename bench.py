@@ -419,8 +419,10 @@ def main():
             torch.cuda.synchronize()
             result.update(extra_legs(args, net, dev, local_rank, fresh_board))
         if not args.no_cpu_baseline and world == 1:          # rank 0 at N = 1 only
-            result["cpu_baseline"] = cpu_baseline(args.size, args.visits, args.batch,
-                                                  args.cpu_seconds)
+            try:
+                result["cpu_baseline"] = cpu_baseline(args.size, args.visits, args.batch, args.cpu_seconds)
+            except Exception as exc:                          # a broken baseline leg must not lose the measured line
+                result["cpu_baseline"] = {"error": repr(exc)}
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
