@@ -87,3 +87,53 @@ def test_gumbel(size):
         assert np.array_equal(root.noise, unhex(rec["noise"]))
         assert np.array_equal(root.improved_policy(), unhex(rec["improved"]))
         assert float(np.random.random_sample()) == float.fromhex(rec["rng_after"])
+
+
+@pytest.mark.parametrize("visits", [16, 100, 400])
+def test_random_draws_of_a_gumbel_phase_stay_inside_the_provisioned_window(visits):
+    """What tg_selfplay_play_move relies on when it uploads ONE random window for all phases of a move
+    (csrc/search.hip): in a sequential-halving phase only the first descent through a root child can expand a
+    node, and a phase enters at most `width` root children it has not entered before in this move - so the
+    expansions (one Dirichlet prior of <= A draws each) of phase p are bounded by
+    min(slots_p, A, width_p + entered_before).  Checked on the oracle (= the reference's algorithm) over seeded
+    mid-game positions; the device consumes draws exactly as the oracle does (tree fixtures, RNG position)."""
+    from oracle.board import GoBoard, BLACK, WHITE
+    from oracle.halving import candidates_and_visit_pairs as pairs_of
+
+    class Counting(MCTSTree):
+        def search_by_sequential_halving(self, board, color, threshold):
+            search_board = board.clone()
+            n_root = self.node[self.current_root].num_children
+            base = n_root if n_root < 16 else 16
+            seen = 0
+            A = board.board_size ** 2 + 1
+            root = self.node[self.current_root]
+            for num_considered, max_count in pairs_of(base, threshold).items():
+                before_nodes = self.num_nodes
+                visited_before = {e for e in range(root.num_children) if root.children_visits[e] + root.children_virtual_loss[e] > 0}
+                for count_threshold in range(max_count):
+                    for _ in range(num_considered):
+                        search_board.copy_from(board)
+                        self.search_sequential_halving(search_board, color, self.current_root, [], count_threshold + 1)
+                entered = {e for e in range(root.num_children) if root.children_virtual_loss[e] > 0}
+                expansions = self.num_nodes - before_nodes
+                slots = num_considered * max_count
+                bound = min(slots, A, num_considered + seen)            # the window the library provisions (x A draws)
+                assert expansions <= len(entered) <= bound, (num_considered, max_count, expansions, len(entered), bound)
+                assert len(entered - visited_before) <= num_considered
+                seen = min(A, seen + bound)
+                self.process_mini_batch(search_board, use_logit=True)
+
+    rs = np.random.RandomState(1234 + visits)
+    for game in range(4):
+        board = GoBoard(9, check_superko=True)
+        color = BLACK
+        for _ in range(rs.randint(0, 40)):                              # a seeded random opening
+            legal = [p for p in board.onboard_pos if board.is_legal(p, color)]
+            if not legal:
+                break
+            board.put_stone(legal[rs.randint(len(legal))], color)
+            color = WHITE if color == BLACK else BLACK
+        np.random.seed(77 + game)
+        tree = Counting(StubNet(3 + game), 9, tree_size=visits * 10 + 16, batch_size=max(visits, 1))
+        tree.generate_move_with_sequential_halving(board, color, TimeManager(TimeControl.CONSTANT_PLAYOUT, visits), True)
