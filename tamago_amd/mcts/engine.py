@@ -378,8 +378,9 @@ class SearchEngine:
                                                     0 if packed else slots,
                                                     self.planes.data_ptr(), self._stream()),
                    "tg_search_select_gumbel")
-        self._collect_rng()
+        # forward + backup are queued before the cursor read-back (which waits for the selection kernel only)
         self._evaluate_and_backup(slots, True, packed_total=int(per_tree.sum()) if packed else 0)
+        self._collect_rng()
 
     # ---------------------------------------------------------------------------------
     def num_nodes(self) -> np.ndarray:
