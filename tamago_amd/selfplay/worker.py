@@ -59,7 +59,7 @@ def selfplay_shard(save_dir: str, network, index_list: Sequence[int], size: int,
     game a single-board worker would play with that seed.
 
     `groups` > 1 splits the boards into that many independent lock-step groups, each with its
-    own engine, HIP stream and host thread (default: 1 below 192 boards, 2 below 512, else 4): while one group's
+    own engine, HIP stream and host thread (default: 1 below 2048 boards, else 2): while one group's
     host thread does the per-move bookkeeping (move choice, SGF comment, RNG windows) the GPU
     runs the other group's phases, and one group's tree kernels overlap the other's forward
     pass.  Games are independent, so the result does not depend on the grouping."""
@@ -73,9 +73,10 @@ def selfplay_shard(save_dir: str, network, index_list: Sequence[int], size: int,
     boards = min(boards, len(todo))
     if groups <= 0:
         # measured on MI355X (tools/bench_selfplay.py, 400 simulations): with the per-move bookkeeping inside the
-        # library one group is best up to 128 boards (64 boards: 2.43 M leaf-evals/s vs 2.08 M with two groups);
-        # 256 boards: two groups 3.67 M vs 3.36 M; 1024 boards: four groups 4.18 M vs 3.99 M (two) / 3.84 M (eight)
-        groups = 1 if boards < 192 else (2 if boards < 512 else 4)
+        # library and three host round trips per move, ONE group is best up to 1024 boards (16 boards: 1.71 M
+        # leaf-evals/s vs 1.17 M with two groups; 64: 3.00 vs 2.45 M; 256: 4.04 vs 3.59 M; 1024: 4.67 vs 4.54 M);
+        # at 2048 boards two groups are level (4.75 vs 4.70 M)
+        groups = 1 if boards < 2048 else 2
     groups = max(1, min(groups, boards))
     queue = list(todo)
     lock = threading.Lock()
