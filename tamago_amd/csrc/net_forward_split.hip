@@ -85,7 +85,10 @@ struct SplitCfg {
     static constexpr int HEAD_IMG = ((M + 1) * kRowBytes + 255) & ~255;
     static constexpr int RES_OFF = STAGE_END > HEAD_IMG ? STAGE_END : HEAD_IMG;
     static constexpr int FC_BYTES = ((2 * P * A * 4 + 4095) / 4096) * 4096;          // policy FC, [2P][A] fp32, padded
-    static constexpr int RES_BYTES = BIG ? 0 : ((M + 1) * 256 > FC_BYTES ? (M + 1) * 256 : FC_BYTES);
+    // (19x19: the residual of the first RES_LDS_TILES row-tiles of every wave stays in LDS - what the 160 KB still
+    // hold -, the rest goes through the global scratch image)
+    static constexpr int RES_LDS_TILES = BIG ? 2 : 0;
+    static constexpr int RES_BYTES = BIG ? NW * RES_LDS_TILES * 16 * 256 : ((M + 1) * 256 > FC_BYTES ? (M + 1) * 256 : FC_BYTES);
     static constexpr int RES_ROWS = M + 2;                        // rows of the global residual image (BIG)
     static constexpr int SS_OFF = RES_OFF + RES_BYTES;           // folded BN scale [13][64] + shift [13][64]
     // head tables, staged once per workgroup: 1x1 weights [64][4] (policy 0, policy 1, value, 0), policy FC bias [A]
@@ -618,9 +621,14 @@ __global__ __launch_bounds__((SplitCfg<S, G, F>::NTHR), 1) void dualnet_fwd_spli
                     if constexpr (add_res) {
 #pragma unroll
                         for (int r = 0; r < RTW; ++r)
-                            if constexpr (C::BIG)
-                                xres[c][r] = *reinterpret_cast<const f32x4 *>(resg + rrow[r] * 64 + c * 16 + lg * 4);
-                            else
+                            if constexpr (C::BIG) {
+                                if (r < C::RES_LDS_TILES) {            // (r is a compile-time constant after unrolling)
+                                    const int lrow = (wave * C::RES_LDS_TILES + r) * 16 + li;
+                                    xres[c][r] = *reinterpret_cast<const f32x4 *>(smem + C::RES_OFF + lrow * 256 + (((c * 4 + lg) ^ (lrow & 15)) << 4));
+                                } else {
+                                    xres[c][r] = *reinterpret_cast<const f32x4 *>(resg + rrow[r] * 64 + c * 16 + lg * 4);
+                                }
+                            } else
                                 xres[c][r] = *reinterpret_cast<const f32x4 *>(smem + C::RES_OFF + rrow[r] * 256 + (((c * 4 + lg) ^ (rrow[r] & 15)) << 4));
                     }
                 }
@@ -644,9 +652,14 @@ __global__ __launch_bounds__((SplitCfg<S, G, F>::NTHR), 1) void dualnet_fwd_spli
                             *reinterpret_cast<f32x4 *>(smem + hrow * kRowBytes + (c * 16 + lg * 4) * 4) = v;
                         } else {
                             if constexpr (keep) {
-                                if constexpr (C::BIG)
-                                    *reinterpret_cast<f32x4 *>(resg + (brow[r] < M ? brow[r] : M) * 64 + c * 16 + lg * 4) = v;
-                                else
+                                if constexpr (C::BIG) {
+                                    if (r < C::RES_LDS_TILES) {
+                                        const int lrow = (wave * C::RES_LDS_TILES + r) * 16 + li;
+                                        *reinterpret_cast<f32x4 *>(smem + C::RES_OFF + lrow * 256 + (((c * 4 + lg) ^ (lrow & 15)) << 4)) = v;
+                                    } else {
+                                        *reinterpret_cast<f32x4 *>(resg + (brow[r] < M ? brow[r] : M) * 64 + c * 16 + lg * 4) = v;
+                                    }
+                                } else
                                     *reinterpret_cast<f32x4 *>(smem + C::RES_OFF + (brow[r] < M ? brow[r] : M) * 256 +
                                                                (((c * 4 + lg) ^ (brow[r] & 15)) << 4)) = v;
                             }

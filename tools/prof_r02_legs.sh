@@ -38,9 +38,9 @@ if fetch is not None and write is not None:
     hbm = (2 * fetch + write) * 1024
     res["hbm_side_bytes_per_position"] = hbm / 4096
     res["algorithmic_io_bytes_per_position"] = 6 * 361 * 4 + 362 * 4 + 12
-    res["note"] = ("the residual image of a board (93 KB, written 7x and read 6x per position) lives in a per-workgroup "
-                   "scratch in global memory; with the 1.9 MB weight stream it exceeds the 4 MB L2 of an XCD (32 "
-                   "workgroups), so most of it travels to the Infinity Cache and back")
+    res["note"] = ("two thirds of a board's residual image (93 KB, written 7x and read 6x per position) live in a "
+                   "per-workgroup scratch in global memory (the rest in LDS); with the 1.9 MB weight stream they exceed the "
+                   "4 MB L2 of an XCD (32 workgroups), so part of them travels to the Infinity Cache and back")
 json.dump(res, open(f"{out}/r02_pmc_forward_split_19x19_b4096.json", "w"), indent=1)
 print(res)
 PY
