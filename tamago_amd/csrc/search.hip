@@ -1132,6 +1132,7 @@ struct MPipeShared {
     Lds<S, false> board[NWRK];
     PipeJob job[kMpSlots];
     int16_t moves[kMpSlots][kPipeMaxDepth];
+    int qpath[kMpSlots][kPathCap];    // (node << 10 | edge) of the first kPathCap levels: the worker writes the queue entry
     int job_seq[kMpSlots];            // k + 1 once job k sits in its slot
     int slot_done[kMpSlots];          // jobs finished in this slot so far
     int done[kPipeMaxK];              // job k finished (node initialised, planes written)
@@ -1359,7 +1360,7 @@ __global__ __launch_bounds__(64 * (NSEL + NWRK)) void select_puct_mpipe_kernel(S
                         else pipe_store(&sh.level_done[k], depth + 1);
                     }
                     sh.moves[slot][depth] = (int16_t)mv;
-                    if (depth < kPathCap) D.q_path[((size_t)t * D.K + k) * kPathCap + depth] = (node << 10) | e;
+                    if (depth < kPathCap) sh.qpath[slot][depth] = (node << 10) | e;
                 }
                 ++depth;
                 prev = mv;
@@ -1390,10 +1391,7 @@ __global__ __launch_bounds__(64 * (NSEL + NWRK)) void select_puct_mpipe_kernel(S
                         PipeJob &j = sh.job[slot];
                         j.k = k; j.parent = node; j.edge = e; j.child = child;
                         j.expand = expand; j.xseq = xseq; j.depth = depth;
-                        D.q_node[(size_t)t * D.K + k] = child;
-                        D.q_pnode[(size_t)t * D.K + k] = node;
-                        D.q_pedge[(size_t)t * D.K + k] = e;
-                        D.q_depth[(size_t)t * D.K + k] = (depth <= kPathCap && D.N <= (1 << 21)) ? depth : 0;
+                        // (the leaf's queue entry - node, parent, edge, recorded path - is written by the worker)
                         pipe_store(&sh.job_seq[slot], k + 1);
                         pipe_store(&sh.level_done[k], kMpDone);
                     }
@@ -1430,6 +1428,18 @@ __global__ __launch_bounds__(64 * (NSEL + NWRK)) void select_puct_mpipe_kernel(S
                 break;
             }
             const PipeJob j = sh.job[slot];
+            {
+                // queue entry of leaf k (what the backup reads): off the selectors' critical path
+                const size_t qs = (size_t)t * D.K + k;
+                const int npath = j.depth < kPathCap ? j.depth : kPathCap;
+                if (lane < npath) D.q_path[qs * kPathCap + lane] = sh.qpath[slot][lane];
+                if (lane == 0) {
+                    D.q_node[qs] = j.child;
+                    D.q_pnode[qs] = j.parent;
+                    D.q_pedge[qs] = j.edge;
+                    D.q_depth[qs] = (j.depth <= kPathCap && D.N <= (1 << 21)) ? j.depth : 0;
+                }
+            }
             reset_work<S>(L, lane);
             BoardScalars b = rootb;
             int c = root_to_move;
