@@ -2404,6 +2404,37 @@ __global__ __launch_bounds__(64) void play_kernel(SearchDev D, const int32_t *mo
 // ======================================================================================
 // host side
 // ======================================================================================
+// One node of one tree packed into one record (tg_search_read_node: one launch + one copy instead of thirteen
+// copies): [num_children, node_visits, node_virtual_loss, node_value_sum bits, raw_value bits, error flags, 0, 0],
+// children_index[A], children_visits[A], children_virtual_loss[A], action[A] (int32), then value_sum[A], policy[A],
+// value[A] (float64, 8-byte aligned).
+__global__ __launch_bounds__(64) void gather_node_kernel(SearchDev D, int A, int tree, int node, unsigned char *out) {
+    const int lane = threadIdx.x;
+    const size_t ns = (size_t)tree * D.N + node, base = ns * A;
+    int32_t *head = reinterpret_cast<int32_t *>(out);
+    if (lane == 0) {
+        head[0] = D.n_children[ns];
+        head[1] = D.n_visits[ns];
+        head[2] = D.n_vl[ns];
+        head[3] = __float_as_int(D.n_vsum[ns]);
+        head[4] = __float_as_int(D.n_raw[ns]);
+        head[5] = D.err[tree];
+        head[6] = head[7] = 0;
+    }
+    int32_t *idx = head + 8, *vis = idx + A, *vl = vis + A, *act = vl + A;
+    double *vsum = reinterpret_cast<double *>(out + 32 + (((size_t)4 * A * 4 + 7) & ~(size_t)7));
+    double *pol = vsum + A, *val = pol + A;
+    for (int i = lane; i < A; i += 64) {
+        idx[i] = D.ch_index[base + i];
+        vis[i] = D.ch_visits[base + i];
+        vl[i] = D.ch_vl[base + i];
+        act[i] = D.action[base + i];
+        vsum[i] = D.ch_vsum[base + i];
+        pol[i] = D.ch_policy[base + i];
+        val[i] = D.ch_value[base + i];
+    }
+}
+
 // Root statistics of every tree packed into one record per tree (one launch + ONE device-to-host copy instead of
 // nine strided copies, each a host round trip): [num_children, node_visits, raw_value bits, error flags] then
 // visits[A], virtual_loss[A], action[A] (int32), value_sum[A], policy[A] (float64).
@@ -2444,6 +2475,7 @@ struct tg_search {
     bool st_dirty = false;
     int32_t *phase_dev = nullptr;          // [num_considered | max_count | packed leaf offsets], T each
     unsigned char *roots_dev = nullptr, *roots_host = nullptr;   // gather_roots_kernel records (device / pinned host)
+    unsigned char *node_dev = nullptr, *node_host = nullptr;     // gather_node_kernel record
     // pinned staging ring for the phase description: the host never waits for the copy of the current call, only
     // (practically never) for the one kPhaseRing calls ago
     static constexpr int kPhaseRing = 8;
@@ -2611,6 +2643,7 @@ int tg_search_destroy(tg_search *s) {
     (void)hipSetDevice(s->cfg.device);
     for (void *p : s->allocs) (void)hipFree(p);
     if (s->roots_dev) { (void)hipFree(s->roots_dev); (void)hipHostFree(s->roots_host); }
+    if (s->node_dev) { (void)hipFree(s->node_dev); (void)hipHostFree(s->node_host); }
     if (s->phase_pin) {
         (void)hipHostFree(s->phase_pin);
         for (int i = 0; i < tg_search::kPhaseRing; ++i) (void)hipEventDestroy(s->phase_ev[i]);
@@ -3205,30 +3238,38 @@ int tg_search_read_node(tg_search *s, int tree, int node, int32_t *num_children,
     if (!s) return tg::fail(TG_ERR_ARG, "tg_search_read_node: null argument");
     if (tree < 0 || tree >= s->dev.T || node < 0 || node >= s->dev.N)
         return tg::fail(TG_ERR_ARG, "tg_search_read_node: tree/node out of range");
-    if (s->last_stream) TG_HIP(hipStreamSynchronize(s->last_stream));
-    else TG_HIP(hipDeviceSynchronize());
-    int rc = check_errors(s);
-    if (rc) return rc;
-    const SearchDev &D = s->dev;
-    const size_t ns = (size_t)tree * D.N + node, base = ns * s->A, A = s->A;
-#define RD(dst, src, n, type) if (dst) TG_HIP(hipMemcpy(dst, src, (n) * sizeof(type), hipMemcpyDeviceToHost));
-    RD(num_children, D.n_children + ns, 1, int32_t)
-    RD(node_visits, D.n_visits + ns, 1, int32_t)
-    RD(node_virtual_loss, D.n_vl + ns, 1, int32_t)
-    RD(children_index, D.ch_index + base, A, int32_t)
-    RD(children_visits, D.ch_visits + base, A, int32_t)
-    RD(children_virtual_loss, D.ch_vl + base, A, int32_t)
-    RD(children_value_sum, D.ch_vsum + base, A, double)
-    RD(children_policy, D.ch_policy + base, A, double)
-    RD(children_value, D.ch_value + base, A, double)
-    RD(node_value_sum, D.n_vsum + ns, 1, float)
-    RD(raw_value, D.n_raw + ns, 1, float)
-#undef RD
-    if (action) {
-        std::vector<int16_t> a16(A);
-        TG_HIP(hipMemcpy(a16.data(), D.action + base, A * sizeof(int16_t), hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < A; ++i) action[i] = a16[i];
+    const size_t A = s->A;
+    const size_t ints = 32 + (((size_t)4 * A * 4 + 7) & ~(size_t)7), rec = ints + (size_t)3 * A * 8;
+    if (!s->node_dev) {
+        TG_HIP(hipMalloc(reinterpret_cast<void **>(&s->node_dev), rec));
+        TG_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->node_host), rec));
     }
+    hipStream_t st = s->last_stream;
+    hipLaunchKernelGGL(gather_node_kernel, dim3(1), dim3(64), 0, st, s->dev, (int)A, tree, node, s->node_dev);
+    TG_HIP(hipGetLastError());
+    TG_HIP(hipMemcpyAsync(s->node_host, s->node_dev, rec, hipMemcpyDeviceToHost, st));
+    TG_HIP(hipStreamSynchronize(st));
+    const int32_t *head = reinterpret_cast<const int32_t *>(s->node_host);
+    if (head[5]) {
+        // another tree's sticky error is reported by the calls that read all trees; this one checks its own
+        const int err = head[5];
+        return tg::fail(TG_ERR_OVERFLOW, "tree %d: %s%s", tree, (err & kErrPoolFull) ? "node pool full " : "",
+                        (err & kErrRngEmpty) ? "random window exhausted " : (err & kErrPipeline) ? "selection pipeline stalled or path too deep " : "");
+    }
+    const int32_t *idx = head + 8, *vis = idx + A, *vl = vis + A, *act = vl + A;
+    const double *vsum = reinterpret_cast<const double *>(s->node_host + ints), *pol = vsum + A, *val = pol + A;
+    if (num_children) *num_children = head[0];
+    if (node_visits) *node_visits = head[1];
+    if (node_virtual_loss) *node_virtual_loss = head[2];
+    if (node_value_sum) std::memcpy(node_value_sum, &head[3], 4);
+    if (raw_value) std::memcpy(raw_value, &head[4], 4);
+    if (children_index) std::memcpy(children_index, idx, A * 4);
+    if (children_visits) std::memcpy(children_visits, vis, A * 4);
+    if (children_virtual_loss) std::memcpy(children_virtual_loss, vl, A * 4);
+    if (action) std::memcpy(action, act, A * 4);
+    if (children_value_sum) std::memcpy(children_value_sum, vsum, A * 8);
+    if (children_policy) std::memcpy(children_policy, pol, A * 8);
+    if (children_value) std::memcpy(children_value, val, A * 8);
     return TG_OK;
 }
 

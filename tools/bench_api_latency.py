@@ -26,3 +26,11 @@ for i in range(n):
     mv = tree.generate_move_with_sequential_halving(board, color, tm2, True); board.put_stone(max(mv, 0), color); color = 3 - color
 dt = (time.perf_counter() - t0) / n
 print(f"MCTSTree.generate_move_with_sequential_halving (400 sims): {dt*1e3:.2f} ms per move = {401/dt:.0f} leaf-evals/s")
+tm3 = TimeManager(TimeControl.CONSTANT_PLAYOUT, 1000)
+board = GoBoard(9, 7.0, True); color = 1
+t0 = time.perf_counter(); done = 0
+for i in range(n):
+    mv = tree.search_best_move(board, color, tm3, {}); board.put_stone(max(mv, 0), color); color = 3 - color
+    done += int(tree.get_root().node_visits)
+dt = (time.perf_counter() - t0) / n
+print(f"MCTSTree.search_best_move (CONSTANT_PLAYOUT 1000: early stop tested after every mini-batch): {dt*1e3:.2f} ms per move, {done/n:.0f} visits per move")
