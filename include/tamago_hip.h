@@ -297,6 +297,29 @@ int tg_selfplay_finish_move(tg_selfplay *sp, int32_t *moves_host, int32_t *finis
  * evaluations} of this move (may be NULL). */
 int tg_selfplay_play_move(tg_selfplay *sp, tg_net *net, float *planes_dev, float *policy_dev,
                           float *value_dev, void *stream, int32_t *finished_host, int64_t *stats_host);
+/* Audit hook of tg_selfplay_play_move (parity tests replay what the one-call path evaluated into the CPU oracle,
+ * mini-batch by mini-batch: mcts/tree.py:273-315 process_mini_batch is where the reference would be tapped).
+ * The observer is called on the calling thread
+ *   kind 0: after a mini-batch's forward pass and backup were ENQUEUED on `stream` and before the next selection
+ *           overwrites the buffers - synchronise `stream`, then planes_dev [positions,6,S,S], policy_dev
+ *           [positions,A], value_dev [positions,3] hold that mini-batch.  phase = -1: root evaluation, one leaf
+ *           per board in board order; phase >= 0: sequential-halving phase, PACKED layout - the leaves of board t
+ *           start at sum_{u<t} num_considered[u] * max_count[u] (host arrays [trees]);
+ *   kind 1: after the moves of all boards were decided (tg_selfplay_finish_move) and before they are played: root
+ *           statistics of every board as host arrays num_children [trees], action / children_visits [trees][A],
+ *           children_value_sum [trees][A], moves [trees] (-1 = none), finished [trees].
+ * Pointers are valid until the observer returns.  fn = NULL removes the observer.  Results do not depend on it. */
+typedef struct tg_selfplay_event {
+    int32_t kind, phase, trees, positions;
+    const int32_t *num_considered, *max_count;                 /* kind 0, phase >= 0 */
+    const float *planes_dev, *policy_dev, *value_dev;          /* kind 0 */
+    void *stream;
+    const int32_t *num_children, *action, *children_visits;    /* kind 1 */
+    const double *children_value_sum;
+    const int32_t *moves, *finished;
+} tg_selfplay_event;
+typedef void (*tg_selfplay_observer)(void *user, const tg_selfplay_event *event);
+int tg_selfplay_set_observer(tg_selfplay *sp, tg_selfplay_observer fn, void *user);
 
 /* ---- training step (nn/learn.py:318-403, nn/loss.py:9-55; modules of nn/network/) ---------------------------
  * One mini-batch of the reference's GPU trainers as hand-written HIP kernels (forward with batch statistics,

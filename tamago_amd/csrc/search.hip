@@ -3366,6 +3366,12 @@ struct tg_selfplay {
     bool nc_known = false;                 // nc holds the roots' child counts of the move in progress
     std::vector<int32_t> ph_seen;          // per tree: root children entered so far in this move (upper bound)       // tg_selfplay_play_move scratch
     bool force_feed = true;                          // a stream was (re)seeded: the next random window is regenerated
+    tg_selfplay_observer observer = nullptr;         // audit hook (tg_selfplay_set_observer)
+    void *observer_user = nullptr;
+    std::vector<int32_t> nc_cursor;                  // root child counts as read off the draw cursor (cross-checked after the move)
+    std::vector<int32_t> act32;                      // root actions of the move in progress (finish_move scratch)
+    double t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // TG_SP_TIMING: host wall clock per section, per HANDLE (groups run on their own threads)
+    long moves_timed = 0;
 };
 
 namespace {
@@ -3530,7 +3536,8 @@ int tg_selfplay_finish_move(tg_selfplay *sp, int32_t *moves_host, int32_t *finis
     sp->nc.resize(T); sp->nv.resize(T); sp->raw.resize(T);
     sp->visits_a.resize((size_t)T * A); sp->vl_a.resize((size_t)T * A);
     sp->vsum_a.resize((size_t)T * A); sp->pol_a.resize((size_t)T * A);
-    std::vector<int32_t> act32((size_t)T * A);
+    std::vector<int32_t> &act32 = sp->act32;
+    act32.resize((size_t)T * A);
     int rc = tg_search_read_root_stats(s, sp->nc.data(), sp->nv.data(), sp->raw.data(), act32.data(), sp->visits_a.data(),
                                        sp->vl_a.data(), sp->vsum_a.data(), sp->pol_a.data());
     if (rc) return rc;
@@ -3632,6 +3639,13 @@ int tg_selfplay_finish_move(tg_selfplay *sp, int32_t *moves_host, int32_t *finis
     return TG_OK;
 }
 
+int tg_selfplay_set_observer(tg_selfplay *sp, tg_selfplay_observer fn, void *user) {
+    if (!sp) return tg::fail(TG_ERR_ARG, "tg_selfplay_set_observer: null argument");
+    sp->observer = fn;
+    sp->observer_user = user;
+    return TG_OK;
+}
+
 // One whole self-play move of every board, driven from here (no host-language code between the launches):
 // root expansion + evaluation, Gumbel noise, halving schedule, every phase (selection, forward pass of the
 // library's own network handle, backup), final choice / records / finished games, the moves played on the
@@ -3647,8 +3661,8 @@ int tg_selfplay_play_move(tg_selfplay *sp, tg_net *net, float *planes_dev, float
     // host-side wall clock per section (TG_SP_TIMING=1: printed every 200 moves) - where a move's time goes when
     // the GPU is not the bound
     static const bool timing = getenv("TG_SP_TIMING") != nullptr;
-    static double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    static long moves_timed = 0;
+    double *acc = sp->t_acc;
+    long &moves_timed = sp->moves_timed;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_last = timing ? now() : 0.0;
     auto lap = [&](int i) { if (timing) { const double t = now(); acc[i] += t - t_last; t_last = t; } };
@@ -3665,9 +3679,24 @@ int tg_selfplay_play_move(tg_selfplay *sp, tg_net *net, float *planes_dev, float
     // child: the cursor read-back IS the roots' child counts (saves the schedule's own device read)
     sp->consumed.resize(T);
     if ((rc = tg_search_advance_streams(s, sp->consumed.data()))) return rc;
+    // ... but only if nothing went wrong in that launch: a sticky device error (pool full, window exhausted) would
+    // leave a cursor that is not a child count, and the halving schedule would be built from a wrong width
+    if ((rc = check_errors(s))) return rc;
     sp->nc.resize(T);
-    for (int t = 0; t < T; ++t) sp->nc[t] = (int32_t)sp->consumed[t];
+    for (int t = 0; t < T; ++t) {
+        if (sp->consumed[t] < 1 || sp->consumed[t] > A)
+            return tg::fail(TG_ERR_STATE, "tg_selfplay_play_move: board %d consumed %lld draws at its root (expected 1..%d)",
+                            t, (long long)sp->consumed[t], A);
+        sp->nc[t] = (int32_t)sp->consumed[t];
+    }
     sp->nc_known = true;
+    sp->nc_cursor = sp->nc;
+    if (sp->observer) {
+        tg_selfplay_event ev{};
+        ev.kind = 0; ev.phase = -1; ev.trees = T; ev.positions = T;
+        ev.planes_dev = planes_dev; ev.policy_dev = policy_dev; ev.value_dev = value_dev; ev.stream = stream;
+        sp->observer(sp->observer_user, &ev);
+    }
     lap(1);
     if ((rc = tg_search_draw_noise(s, nullptr))) return rc;
     lap(2);
@@ -3714,6 +3743,13 @@ int tg_selfplay_play_move(tg_selfplay *sp, tg_net *net, float *planes_dev, float
         if ((rc = tg_search_select_gumbel(s, nc, mc, 0, planes_dev, stream))) return rc;
         if ((rc = tg_net_forward_dev(net, planes_dev, (int)total, 1, policy_dev, value_dev, stream))) return rc;
         if ((rc = tg_search_backup(s, policy_dev, value_dev, 0, 1, stream))) return rc;
+        if (sp->observer) {
+            tg_selfplay_event ev{};
+            ev.kind = 0; ev.phase = ph; ev.trees = T; ev.positions = (int32_t)total;
+            ev.num_considered = nc; ev.max_count = mc;
+            ev.planes_dev = planes_dev; ev.policy_dev = policy_dev; ev.value_dev = value_dev; ev.stream = stream;
+            sp->observer(sp->observer_user, &ev);
+        }
         leaves += total;
         any_phase = true;
     }
@@ -3725,6 +3761,18 @@ int tg_selfplay_play_move(tg_selfplay *sp, tg_net *net, float *planes_dev, float
     int64_t counts[2] = {0, 0};
     lap(3);
     if ((rc = tg_selfplay_finish_move(sp, sp->mv.data(), finished_host, counts))) return rc;
+    // the roots' child counts as the statistics read-back reports them must be what the draw cursor said
+    for (int t = 0; t < T; ++t)
+        if (sp->nc[t] != sp->nc_cursor[t])
+            return tg::fail(TG_ERR_STATE, "tg_selfplay_play_move: board %d has %d root children but its root expansion "
+                            "consumed %d draws - the halving schedule was built from a wrong width", t, sp->nc[t], sp->nc_cursor[t]);
+    if (sp->observer) {
+        tg_selfplay_event ev{};
+        ev.kind = 1; ev.phase = n_phases; ev.trees = T;
+        ev.num_children = sp->nc.data(); ev.action = sp->act32.data(); ev.children_visits = sp->visits_a.data();
+        ev.children_value_sum = sp->vsum_a.data(); ev.moves = sp->mv.data(); ev.finished = finished_host;
+        sp->observer(sp->observer_user, &ev);
+    }
     lap(6);
     if ((rc = tg_search_play(s, sp->mv.data(), stream))) return rc;
     lap(7);

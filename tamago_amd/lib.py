@@ -28,6 +28,19 @@ class RootPosition(Structure):
                 ("prev_move", c_int32), ("prev_prev_move", c_int32), ("to_move", c_int32)]
 
 
+class SelfplayEvent(Structure):
+    """tg_selfplay_event (include/tamago_hip.h): what tg_selfplay_play_move shows its observer."""
+    _fields_ = [("kind", c_int32), ("phase", c_int32), ("trees", c_int32), ("positions", c_int32),
+                ("num_considered", POINTER(c_int32)), ("max_count", POINTER(c_int32)),
+                ("planes_dev", c_void_p), ("policy_dev", c_void_p), ("value_dev", c_void_p),
+                ("stream", c_void_p),
+                ("num_children", POINTER(c_int32)), ("action", POINTER(c_int32)),
+                ("children_visits", POINTER(c_int32)), ("children_value_sum", POINTER(c_double)),
+                ("moves", POINTER(c_int32)), ("finished", POINTER(c_int32))]
+
+
+SELFPLAY_OBSERVER = ctypes.CFUNCTYPE(None, c_void_p, POINTER(SelfplayEvent))
+
 _SIGNATURES = {
     "tg_abi_version": (c_int, []),
     "tg_last_error": (c_char_p, []),
@@ -85,6 +98,7 @@ _SIGNATURES = {
     "tg_selfplay_start_game": (c_int, [c_void_p, c_int, c_int, c_int]),
     "tg_selfplay_schedule": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "tg_selfplay_finish_move": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "tg_selfplay_set_observer": (c_int, [c_void_p, SELFPLAY_OBSERVER, c_void_p]),
     "tg_selfplay_play_move": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 

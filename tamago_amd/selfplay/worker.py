@@ -53,7 +53,7 @@ def _finish(game: _Game, winner, is_resign: bool, score: float):
 
 def selfplay_shard(save_dir: str, network, index_list: Sequence[int], size: int, visits: int,
                    boards: int = 16, seeds: Sequence[int] = None, device_index: int = 0,
-                   never_resign_flags: Sequence[bool] = None, groups: int = 0) -> dict:
+                   never_resign_flags: Sequence[bool] = None, groups: int = 0, observer=None) -> dict:
     """Play the games of `index_list`, `boards` at a time.  Game i draws from its own legacy
     stream seeded with seeds[i] (default: its index), so every game equals the reference
     game a single-board worker would play with that seed.
@@ -62,7 +62,11 @@ def selfplay_shard(save_dir: str, network, index_list: Sequence[int], size: int,
     own engine, HIP stream and host thread (default: 1 below 2048 boards, else 2): while one group's
     host thread does the per-move bookkeeping (move choice, SGF comment, RNG windows) the GPU
     runs the other group's phases, and one group's tree kernels overlap the other's forward
-    pass.  Games are independent, so the result does not depend on the grouping."""
+    pass.  Games are independent, so the result does not depend on the grouping.
+
+    `observer` (audit hook, one group only): called as observer(engine, event) from inside
+    tg_selfplay_play_move for every evaluated mini-batch and every decided move
+    (tg_selfplay_set_observer in include/tamago_hip.h; event = lib.SelfplayEvent)."""
     import threading
     todo = [i for i in index_list if not os.path.isfile(os.path.join(save_dir, f"{i}.sgf"))]
     seeds = dict(zip(index_list, seeds if seeds is not None else index_list))
@@ -78,6 +82,8 @@ def selfplay_shard(save_dir: str, network, index_list: Sequence[int], size: int,
         # at 2048 boards two groups are level (4.75 vs 4.70 M)
         groups = 1 if boards < 2048 else 2
     groups = max(1, min(groups, boards))
+    if observer is not None and groups != 1:
+        raise ValueError("selfplay_shard: an observer needs groups = 1")
     queue = list(todo)
     lock = threading.Lock()
 
@@ -91,7 +97,7 @@ def selfplay_shard(save_dir: str, network, index_list: Sequence[int], size: int,
             return index, nr
 
     if groups == 1:
-        _run_group(save_dir, network, size, visits, boards, seeds, device_index, next_game, stats, None)
+        _run_group(save_dir, network, size, visits, boards, seeds, device_index, next_game, stats, None, observer)
         return stats
 
     import torch
@@ -128,7 +134,8 @@ def selfplay_shard(save_dir: str, network, index_list: Sequence[int], size: int,
     return stats
 
 
-def _run_group(save_dir, network, size, visits, boards, seeds, device_index, next_game, stats, stream):
+def _run_group(save_dir, network, size, visits, boards, seeds, device_index, next_game, stats, stream,
+               observer=None):
     """One lock-step group of `boards` games on its own engine (and HIP stream, if given).
 
     Per move the host issues a constant number of library calls, whatever the number of boards: root
@@ -153,6 +160,12 @@ def _run_group(save_dir, network, size, visits, boards, seeds, device_index, nex
                                           repr(float(start_board.get_komi())).encode(), ctypes.byref(handle)),
                    "tg_selfplay_create")
         live = 0
+        hook = None
+        if observer is not None:
+            if not isinstance(evaluator, DeviceEvaluator):
+                raise ValueError("selfplay_shard: the observer taps tg_selfplay_play_move (DualNet evaluator only)")
+            hook = _lib.SELFPLAY_OBSERVER(lambda _user, ev: observer(engine, ev.contents))
+            _lib.check(lib.tg_selfplay_set_observer(handle, hook, None), "tg_selfplay_set_observer")
 
         def start(slot: int) -> bool:
             nxt = next_game()
@@ -178,6 +191,7 @@ def _run_group(save_dir, network, size, visits, boards, seeds, device_index, nex
                 a = size * size + 1
                 policy = torch.empty((boards * engine.K, a), dtype=torch.float32, device=engine.device)
                 value = torch.empty((boards * engine.K, 3), dtype=torch.float32, device=engine.device)
+                engine.sp_outputs = (policy, value)          # what an observer's device pointers refer to
                 counts = np.zeros(3, dtype=np.int64)
                 timing = os.environ.get("TG_SP_TIMING") is not None
                 t_call = t_start = 0.0

@@ -1,0 +1,285 @@
+"""The code paths bench.py TIMES, at BASELINE.json's full sizes, against the CPU oracle.
+
+1. cfg-3 / cfg-4-shard self-play through ``tg_selfplay_play_move`` (DualNet evaluator: ONE library
+   call per lock-step move, one random window for all phases of a move) - 16 and 64 boards x 400
+   simulations, games to completion:
+   * byte-identical SGF files to the phase-by-phase host-driven path on the same network;
+   * every mini-batch the one-call path evaluated is tapped (tg_selfplay_set_observer) and the
+     slices of four boards are replayed, in order, into the CPU oracle's Gumbel tree
+     (mcts/tree.py:318-422, selfplay/worker.py:46-90 restated in oracle/): the oracle must ask for
+     bit-identical leaf planes in the same order, its own CPU network must agree with the recorded
+     GPU outputs within 1e-4, and after every move the root's actions, visit vector, value sums
+     and the move played must equal what the library decided.
+2. ``select_puct_pipe_kernel`` (the selector above 256 trees, i.e. of the 2 048-tree headline):
+   a 512-tree lock-step PUCT search on the DeviceEvaluator path, every 16th tree replayed into its
+   own oracle tree.
+"""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+VISITS = 400
+TOL = 1e-4          # north_star tolerance on policy / value outputs (fp32)
+
+
+class HostOnly:
+    """The same network, not recognisable as a DualNet: selfplay_shard then drives every phase
+    from Python through the host evaluator API (worker.py's phase-by-phase branch)."""
+
+    def __init__(self, net):
+        self.net = net
+
+    def inference(self, planes):
+        return self.net.inference(planes)
+
+    def inference_with_policy_logits(self, planes):
+        return self.net.inference_with_policy_logits(planes)
+
+
+class Tap:
+    """Observer of tg_selfplay_play_move: keeps, for the watched slots only, the leaf planes (int8:
+    plane values are -1 / 0 / 1), logits and value rows of every mini-batch and the root statistics
+    behind every decided move."""
+
+    def __init__(self, watch, size):
+        self.watch = list(watch)
+        self.P = size * size
+        self.A = self.P + 1
+        self.batches = {t: [] for t in self.watch}       # per slot: (planes i8, policy, value)
+        self.moves = {t: [] for t in self.watch}         # per slot: dict per decided move
+        self.closed = set()
+        self.errors = []
+        self.phase_sizes = []
+
+    def __call__(self, engine, ev):
+        try:
+            self._on(engine, ev)
+        except BaseException as exc:      # an exception cannot cross the C frame: keep it for the test
+            self.errors.append(repr(exc))
+
+    def _on(self, engine, ev):
+        T = ev.trees
+        if ev.kind == 0:
+            torch.cuda.synchronize()
+            policy, value = engine.sp_outputs
+            if ev.phase < 0:
+                offs = np.arange(T + 1)
+            else:
+                nc = np.ctypeslib.as_array(ev.num_considered, shape=(T,)).astype(np.int64)
+                mc = np.ctypeslib.as_array(ev.max_count, shape=(T,)).astype(np.int64)
+                offs = np.concatenate([[0], np.cumsum(nc * mc)])
+            assert offs[-1] == ev.positions
+            self.phase_sizes.append(int(ev.positions))
+            for t in self.watch:
+                lo, hi = int(offs[t]), int(offs[t + 1])
+                if t in self.closed or hi == lo:
+                    continue
+                pl = engine.planes[lo:hi].cpu()
+                assert float((pl - pl.round()).abs().max()) == 0.0 and float(pl.abs().max()) <= 1.0
+                self.batches[t].append((pl.to(torch.int8), policy[lo:hi].cpu().clone(), value[lo:hi].cpu().clone()))
+        else:
+            A = self.A
+            nch = np.ctypeslib.as_array(ev.num_children, shape=(T,))
+            act = np.ctypeslib.as_array(ev.action, shape=(T, A))
+            vis = np.ctypeslib.as_array(ev.children_visits, shape=(T, A))
+            vsum = np.ctypeslib.as_array(ev.children_value_sum, shape=(T, A))
+            mv = np.ctypeslib.as_array(ev.moves, shape=(T,))
+            fin = np.ctypeslib.as_array(ev.finished, shape=(T,))
+            for t in self.watch:
+                if t in self.closed:
+                    continue
+                n = int(nch[t])
+                self.moves[t].append(dict(n=n, action=act[t, :n].copy(), visits=vis[t, :n].copy(),
+                                          vsum=vsum[t, :n].copy(), move=int(mv[t]), finished=int(fin[t])))
+                if fin[t]:
+                    self.closed.add(t)
+
+
+class SliceNet:
+    """Oracle-side network of ONE board: hands out that board's recorded GPU outputs mini-batch by
+    mini-batch, checks the oracle's planes against the recorded ones and the CPU network against
+    the GPU outputs."""
+
+    def __init__(self, batches, cpu_net):
+        self.batches = batches
+        self.cpu_net = cpu_net
+        self.i = 0
+        self.max_err = 0.0
+
+    def inference_with_policy_logits(self, planes):
+        rec_planes, policy, value = self.batches[self.i]
+        self.i += 1
+        assert planes.shape[0] == rec_planes.shape[0], f"mini-batch {self.i - 1}: {planes.shape[0]} leaves vs {rec_planes.shape[0]} recorded"
+        assert torch.equal(planes, rec_planes.to(torch.float32)), f"leaf planes differ in mini-batch {self.i - 1}"
+        ref_p, ref_v = self.cpu_net.inference_with_policy_logits(planes)
+        self.max_err = max(self.max_err, float(((ref_p - policy).abs() / (1.0 + ref_p.abs())).max()),
+                           float((ref_v - value).abs().max()))
+        return policy, value
+
+    def inference(self, planes):
+        raise AssertionError("Gumbel search evaluates logits only (tree.py:283)")
+
+
+def _sgf_moves(text):
+    return re.findall(r";([BW])\[([a-z]{2})\]", text)
+
+
+def _replay_game(tap, slot, seed, never_resign, state_dict, sgf_text):
+    """selfplay/worker.py:46-90 on the oracle with the recorded outputs of `slot`."""
+    from oracle.board import GoBoard as OBoard, BLACK, PASS, RESIGN
+    from oracle.net import OracleNet
+    from oracle.tree import MCTSTree as OTree, TimeManager as OTM, TimeControl as OTC
+    net = SliceNet(tap.batches[slot], OracleNet(state_dict))
+    otree = OTree(net, 9, tree_size=max(160, VISITS + 8))
+    tm = OTM(OTC.CONSTANT_PLAYOUT, VISITS)
+    oboard = OBoard(9, 7.0, True)
+    color = BLACK
+    saved = np.random.get_state()
+    np.random.set_state(np.random.RandomState(seed).get_state())
+    try:
+        for k, rec in enumerate(tap.moves[slot]):
+            omv = otree.generate_move_with_sequential_halving(oboard, color, tm, never_resign)
+            root = otree.get_root()
+            n = root.num_children
+            assert n == rec["n"], (slot, k)
+            assert list(root.action[:n]) == list(rec["action"]), (slot, k)
+            assert np.array_equal(root.children_visits[:n], rec["visits"]), (slot, k)
+            assert np.array_equal(root.children_value_sum[:n], rec["vsum"]), (slot, k)
+            if rec["finished"]:
+                assert k == len(tap.moves[slot]) - 1
+                if omv != RESIGN:                      # two passes / move limit: the SGF holds the move
+                    assert omv == PASS or len(_sgf_moves(sgf_text)) == 2 * 81
+                else:
+                    assert "+R]" in sgf_text
+                break
+            assert omv == rec["move"], (slot, k, omv, rec["move"])
+            oboard.put_stone(omv, color)
+            color = 3 - color
+    finally:
+        np.random.set_state(saved)
+    assert net.i == len(net.batches), "the oracle evaluated fewer mini-batches than the library"
+    assert tap.moves[slot][-1]["finished"] == 1
+    return len(tap.moves[slot]), net.max_err
+
+
+def _fast_vs_slow(tmp_path, boards, first_index, watch, replay_moves_at_least):
+    from oracle.net import make_state_dict
+    from tamago_amd.nn.network.dual_net import DualNet
+    from tamago_amd.selfplay.worker import selfplay_shard
+    sd = make_state_dict(9, 23, 1.5)                      # seeded synthetic weights, non-trivial BN statistics
+    net = DualNet(torch.device("cuda:0"), 9)
+    net.load_state_dict(sd)
+    idx = list(range(first_index, first_index + boards))
+    flags = [i % 5 != 0 for i in idx]                     # most games never resign (worker.py:53 draws 1 in 10)
+    fast, slow = tmp_path / "fast", tmp_path / "slow"
+    fast.mkdir(), slow.mkdir()
+    tap = Tap(watch, 9)
+    a = selfplay_shard(str(fast), net, idx, 9, VISITS, boards=boards, never_resign_flags=flags, observer=tap)
+    assert not tap.errors, tap.errors[:3]
+    b = selfplay_shard(str(slow), HostOnly(net), idx, 9, VISITS, boards=boards, never_resign_flags=flags)
+    assert a == b and a["games"] == boards
+    assert a["leaf_evals"] == a["moves"] * (VISITS + 1)
+    texts = {}
+    for i in idx:
+        texts[i] = open(fast / f"{i}.sgf").read()
+        assert texts[i] == open(slow / f"{i}.sgf").read(), i
+    # the first lock-step move: every board has the full 1 + 96 + 96 + 100 + 108 schedule
+    assert tap.phase_sizes[:5] == [boards, 96 * boards, 96 * boards, 100 * boards, 108 * boards]
+    total_moves = 0
+    worst = 0.0
+    for t in watch:
+        n_moves, err = _replay_game(tap, t, idx[t], flags[t], sd, texts[idx[t]])
+        total_moves += n_moves
+        worst = max(worst, err)
+    assert worst < TOL, worst
+    assert total_moves >= replay_moves_at_least
+    return a
+
+
+def test_cfg3_one_call_path_16_boards_400_sims_vs_phase_path_and_oracle(tmp_path):
+    _fast_vs_slow(tmp_path, 16, 101, watch=(0, 5, 10, 15), replay_moves_at_least=120)
+
+
+def test_cfg4_shard_one_call_path_64_boards_400_sims_vs_phase_path_and_oracle(tmp_path):
+    _fast_vs_slow(tmp_path, 64, 201, watch=(1, 22, 43, 63), replay_moves_at_least=120)
+
+
+def test_512_tree_puct_pipe_kernel_device_evaluator_replay():
+    """512 trees > 256: tg_search_select_puct launches select_puct_pipe_kernel (1 selector + 2 worker
+    waves per tree), the selector of bench.py's 2 048-tree headline.  Every 16th tree's slice of every
+    recorded mini-batch is replayed into its own CPU oracle tree: identical leaf planes in order,
+    identical visit counts / value sums / policies / node counts."""
+    from oracle.board import GoBoard as OBoard
+    from oracle.net import OracleNet, make_state_dict
+    from oracle.tree import MCTSTree as OTree, TimeManager as OTM, TimeControl as OTC
+    from tamago_amd.board.go_board import GoBoard
+    from tamago_amd.mcts.engine import SearchEngine, DeviceEvaluator
+    from tamago_amd.nn.network.dual_net import DualNet
+    from tests.helpers import load_npz
+    from tests.test_gpu_end_to_end import Recorder
+
+    for knob in ("TG_SELECT_SERIAL", "TG_SELECT_MPIPE_TREES", "TG_MPIPE_PROF"):
+        assert not os.environ.get(knob), "the kernel choice must be the library's default"
+    size, T, K, visits = 9, 512, 64, 200
+    sd = make_state_dict(size, 7, 1.5)
+    net = DualNet(torch.device("cuda:0"), size)
+    net.load_state_dict(sd)
+    rec = Recorder(DeviceEvaluator(net))
+    engine = SearchEngine(size, T, visits + 16, K, rec)
+    brd = load_npz("board_s9.npz")
+    roots = []
+    for t in range(T):
+        game, plies = t % 4, 2 + (t * 5) % 40
+        board, oboard = GoBoard(size, 7.0, False), OBoard(size, 7.0, False)
+        mv, col = brd[f"g{game}_move"], brd[f"g{game}_color"]
+        plies = min(plies, len(mv) - 1)
+        for m, c in zip(mv[:plies], col[:plies]):
+            board.put_stone(int(m), int(c))
+            oboard.put_stone(int(m), int(c))
+        color = 3 - int(col[plies - 1])
+        engine.set_root(t, board, color, np.random.RandomState(5000 + t).get_state())
+        roots.append((oboard, color))
+    engine.root_eval(False)
+    done = 0
+    while done < visits:
+        k = min(K, visits - done)
+        engine.puct_batch(k)
+        done += k
+    stats = engine.read_root_stats()
+    nodes = engine.num_nodes()
+    assert [b[0].shape[0] for b in rec.log] == [T, T * 64, T * 64, T * 64, T * 8]
+    cpu = OracleNet(sd)
+    for planes, policy, value, _ in rec.log[:2]:
+        ref_p, ref_v = cpu.inference(planes[:4096])
+        assert float((ref_p - policy[:4096]).abs().max()) < TOL and float((ref_v - value[:4096]).abs().max()) < TOL
+
+    class Slice:
+        def __init__(self, t):
+            self.t, self.i = t, 0
+
+        def inference(self, planes):
+            rp, pol, val, _ = rec.log[self.i]
+            per = rp.shape[0] // T
+            self.i += 1
+            lo = self.t * per
+            assert torch.equal(planes, rp[lo:lo + planes.shape[0]]), (self.t, self.i - 1)
+            return pol[lo:lo + planes.shape[0]], val[lo:lo + planes.shape[0]]
+
+    for t in range(0, T, 16):
+        oboard, color = roots[t]
+        sl = Slice(t)
+        otree = OTree(sl, size, tree_size=visits + 16, batch_size=K)
+        np.random.set_state(np.random.RandomState(5000 + t).get_state())
+        otree.search_best_move(oboard, color, OTM(OTC.STRICT_PLAYOUT, visits))
+        oroot = otree.get_root()
+        n = oroot.num_children
+        assert sl.i == len(rec.log) and int(stats["num_children"][t]) == n and int(nodes[t]) == otree.num_nodes
+        assert np.array_equal(stats["children_visits"][t][:n], oroot.children_visits[:n]), t
+        assert np.array_equal(stats["children_value_sum"][t][:n], oroot.children_value_sum[:n]), t
+        assert np.array_equal(stats["children_policy"][t][:n], oroot.children_policy[:n]), t
+    engine.close()
