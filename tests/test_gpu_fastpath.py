@@ -129,8 +129,9 @@ def _sgf_moves(text):
     return re.findall(r";([BW])\[([a-z]{2})\]", text)
 
 
-def _replay_game(tap, slot, seed, never_resign, state_dict, sgf_text):
-    """selfplay/worker.py:46-90 on the oracle with the recorded outputs of `slot`."""
+def _replay_game(tap, slot, seed, never_resign, state_dict, sgf_text, max_moves=None):
+    """selfplay/worker.py:46-90 on the oracle with the recorded outputs of `slot` (the whole game, or its
+    first `max_moves` moves: the oracle runs at ~0.3 s per move)."""
     from oracle.board import GoBoard as OBoard, BLACK, PASS, RESIGN
     from oracle.net import OracleNet
     from oracle.tree import MCTSTree as OTree, TimeManager as OTM, TimeControl as OTC
@@ -143,6 +144,8 @@ def _replay_game(tap, slot, seed, never_resign, state_dict, sgf_text):
     np.random.set_state(np.random.RandomState(seed).get_state())
     try:
         for k, rec in enumerate(tap.moves[slot]):
+            if max_moves is not None and k >= max_moves:
+                return k, net.max_err
             omv = otree.generate_move_with_sequential_halving(oboard, color, tm, never_resign)
             root = otree.get_root()
             n = root.num_children
@@ -167,7 +170,7 @@ def _replay_game(tap, slot, seed, never_resign, state_dict, sgf_text):
     return len(tap.moves[slot]), net.max_err
 
 
-def _fast_vs_slow(tmp_path, boards, first_index, watch, replay_moves_at_least):
+def _fast_vs_slow(tmp_path, boards, first_index, watch, replay_moves_at_least, caps):
     from oracle.net import make_state_dict
     from tamago_amd.nn.network.dual_net import DualNet
     from tamago_amd.selfplay.worker import selfplay_shard
@@ -192,8 +195,8 @@ def _fast_vs_slow(tmp_path, boards, first_index, watch, replay_moves_at_least):
     assert tap.phase_sizes[:5] == [boards, 96 * boards, 96 * boards, 100 * boards, 108 * boards]
     total_moves = 0
     worst = 0.0
-    for t in watch:
-        n_moves, err = _replay_game(tap, t, idx[t], flags[t], sd, texts[idx[t]])
+    for t, cap in zip(watch, caps):
+        n_moves, err = _replay_game(tap, t, idx[t], flags[t], sd, texts[idx[t]], cap)
         total_moves += n_moves
         worst = max(worst, err)
     assert worst < TOL, worst
@@ -202,11 +205,12 @@ def _fast_vs_slow(tmp_path, boards, first_index, watch, replay_moves_at_least):
 
 
 def test_cfg3_one_call_path_16_boards_400_sims_vs_phase_path_and_oracle(tmp_path):
-    _fast_vs_slow(tmp_path, 16, 101, watch=(0, 5, 10, 15), replay_moves_at_least=120)
+    # two games replayed move for move to their end, two for their first 50 moves
+    _fast_vs_slow(tmp_path, 16, 101, watch=(0, 5, 10, 15), replay_moves_at_least=160, caps=(None, 50, None, 50))
 
 
 def test_cfg4_shard_one_call_path_64_boards_400_sims_vs_phase_path_and_oracle(tmp_path):
-    _fast_vs_slow(tmp_path, 64, 201, watch=(1, 22, 43, 63), replay_moves_at_least=120)
+    _fast_vs_slow(tmp_path, 64, 201, watch=(1, 22, 43, 63), replay_moves_at_least=160, caps=(40, 40, 40, 40))
 
 
 def test_512_tree_puct_pipe_kernel_device_evaluator_replay():
