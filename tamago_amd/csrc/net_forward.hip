@@ -29,6 +29,9 @@ namespace tg {
 int split_prepare(tg_net *net, const float *conv0, const float *const *tower, const float *scale);
 int split_forward(tg_net *net, int group, const float *planes, int batch, int want_logits, float *policy,
                   float *value, int *overflow, hipStream_t stream);
+int s32_prepare(tg_net *net, const float *conv0, const float *const *tower, const float *scale, const float *shift);
+int s32_forward(tg_net *net, const float *planes, int batch, int want_logits, float *policy, float *value,
+                int *overflow, hipStream_t stream);
 }  // namespace tg
 
 namespace {
@@ -774,7 +777,8 @@ int tg_net_create(int board_size, int device, const float *params, size_t n_para
         tg_net_destroy(net);
         return rc;
     }
-    if ((rc = tg::split_prepare(net, conv0_raw, tower_raw, scale.data()))) {
+    if ((rc = tg::split_prepare(net, conv0_raw, tower_raw, scale.data())) ||
+        (board_size == 9 && (rc = tg::s32_prepare(net, conv0_raw, tower_raw, scale.data(), shift.data())))) {
         tg_net_destroy(net);
         return rc;
     }
@@ -812,7 +816,14 @@ static int pick_wino(int board_size, int batch, int num_cus);
 // per product-sum; default) | wino (exact fp32 Winograd tower) | direct (exact fp32 direct convolution).
 static bool pick_split() {
     const char *env = getenv("TG_FWD_ALGO");
-    return !env || !strcmp(env, "split16");
+    return !env || !strcmp(env, "split16") || !strcmp(env, "s32");
+}
+// large 9x9 batches (three boards per workgroup): the 32x32x16 kernel with two waves per SIMD (net_forward_s32.hip)
+// unless TG_FWD_ALGO=split16 asks for the one-wave-per-SIMD 16x16x32 kernel (net_forward_split.hip)
+static bool pick_s32(int board_size, int batch, int num_cus) {
+    if (board_size != 9 || batch <= num_cus) return false;
+    const char *env = getenv("TG_FWD_ALGO");
+    return !env || !strcmp(env, "s32");
 }
 
 const char *tg_net_kernel_name(const tg_net *net, int batch) {
@@ -821,6 +832,7 @@ const char *tg_net_kernel_name(const tg_net *net, int batch) {
         if (pick_split()) return "dualnet_fwd_split_kernel<19, 1, f16x2>";
         return pick_wino(19, batch, net->num_cus) ? "dualnet_fwd_wino8_kernel<19, 1, global scratch>" : "dualnet_fwd_kernel<19, 1>";
     }
+    if (pick_s32(9, batch, net->num_cus)) return "dualnet_fwd_s32_kernel<9, 3>";
     if (pick_split()) return batch > net->num_cus ? "dualnet_fwd_split_kernel<9, 3, f16x2>" : "dualnet_fwd_split_kernel<9, 1, f16x2>";
     {
         const int wg = pick_wino(9, batch, net->num_cus);
@@ -841,6 +853,7 @@ double tg_net_executed_flops_per_position(const tg_net *net, int batch, double *
     if ((S == 9 || S == 19) && pick_split()) {
         // per workgroup pass: (2 stem + 12 * 18) k-chunks x (4 cout tiles x row tiles) x 3 products of
         // v_mfma_f32_16x16x32_f16 (16 384 FLOP each)
+        // (the 32x32x16 kernel issues the same FLOPs: 8 waves x 12 MFMAs of 32 768 FLOP per chunk = 16 row tiles x 4 x 3 x 16 384)
         const int g = S == 19 ? 1 : (batch > net->num_cus ? 3 : 1);
         const int row_tiles = S == 19 ? 24 : (g == 3 ? 16 : 6);   // 4 waves x 6 | 4 waves x 4 | 3 waves x 2
         flops = (2.0 + 12.0 * 18.0) * 4.0 * row_tiles * 3.0 * 16384.0 / g;
@@ -921,7 +934,9 @@ int tg_net_forward_dev(tg_net *net, const float *planes_dev, int batch, int want
                 flag = slot;
             }
             TG_HIP(hipMemsetAsync(flag, 0, sizeof(int), st));
-            int rc = tg::split_forward(net, group, planes_dev, batch, want_logits, policy_dev, value_dev, flag, st);
+            int rc = pick_s32(9, batch, net->num_cus)
+                         ? tg::s32_forward(net, planes_dev, batch, want_logits, policy_dev, value_dev, flag, st)
+                         : tg::split_forward(net, group, planes_dev, batch, want_logits, policy_dev, value_dev, flag, st);
             if (rc) return rc;
             if (group == 3) return launch_wino8<9, 3>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st, flag);
             return launch_wino8<9, 1>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st, flag);

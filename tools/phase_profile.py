@@ -26,7 +26,7 @@ for _ in range(2):
                                        st.ctypes.data, 128))
 name = lib.tg_net_kernel_name(net.handle, b).decode()
 print("kernel:", name)
-if "split" in name:
+if "split" in name or "s32" in name:
     s = st[:29] - st[0]
     print(f"group total {s[28]} ticks; staging + im2col + split of the input {s[1]}")
     print("  MFMA loop (stem, then 12 layers):", [int(s[2 + 2 * i] - s[1 + 2 * i]) for i in range(13)])
