@@ -32,7 +32,7 @@ def sources():
                   if f.endswith(".hip") or f.endswith(".cpp"))
 
 
-FORWARD_SOURCES = ("net_forward.hip", "net_forward_split.hip", "net_forward_s32.hip", "split_common.h", "net_device.h",
+FORWARD_SOURCES = ("net_forward.hip", "net_forward_split.hip", "net_forward_w2.hip", "split_common.h", "net_device.h",
                    "common.h")
 
 

@@ -29,8 +29,8 @@ namespace tg {
 int split_prepare(tg_net *net, const float *conv0, const float *const *tower, const float *scale);
 int split_forward(tg_net *net, int group, const float *planes, int batch, int want_logits, float *policy,
                   float *value, int *overflow, hipStream_t stream);
-int s32_prepare(tg_net *net, const float *conv0, const float *const *tower, const float *scale, const float *shift);
-int s32_forward(tg_net *net, const float *planes, int batch, int want_logits, float *policy, float *value,
+int w2_prepare(tg_net *net, const float *conv0, const float *const *tower, const float *scale, const float *shift);
+int w2_forward(tg_net *net, const float *planes, int batch, int want_logits, float *policy, float *value,
                 int *overflow, hipStream_t stream);
 }  // namespace tg
 
@@ -778,7 +778,7 @@ int tg_net_create(int board_size, int device, const float *params, size_t n_para
         return rc;
     }
     if ((rc = tg::split_prepare(net, conv0_raw, tower_raw, scale.data())) ||
-        (board_size == 9 && (rc = tg::s32_prepare(net, conv0_raw, tower_raw, scale.data(), shift.data())))) {
+        (board_size == 9 && (rc = tg::w2_prepare(net, conv0_raw, tower_raw, scale.data(), shift.data())))) {
         tg_net_destroy(net);
         return rc;
     }
@@ -816,14 +816,14 @@ static int pick_wino(int board_size, int batch, int num_cus);
 // per product-sum; default) | wino (exact fp32 Winograd tower) | direct (exact fp32 direct convolution).
 static bool pick_split() {
     const char *env = getenv("TG_FWD_ALGO");
-    return !env || !strcmp(env, "split16") || !strcmp(env, "s32");
+    return !env || !strcmp(env, "split16") || !strcmp(env, "w2");
 }
-// large 9x9 batches (three boards per workgroup): the 32x32x16 kernel with two waves per SIMD (net_forward_s32.hip)
+// large 9x9 batches (three boards per workgroup): the 32x32x16 kernel with two waves per SIMD (net_forward_w2.hip)
 // unless TG_FWD_ALGO=split16 asks for the one-wave-per-SIMD 16x16x32 kernel (net_forward_split.hip)
-static bool pick_s32(int board_size, int batch, int num_cus) {
+static bool pick_w2(int board_size, int batch, int num_cus) {
     if (board_size != 9 || batch <= num_cus) return false;
     const char *env = getenv("TG_FWD_ALGO");
-    return !env || !strcmp(env, "s32");
+    return !env || !strcmp(env, "w2");
 }
 
 const char *tg_net_kernel_name(const tg_net *net, int batch) {
@@ -832,7 +832,7 @@ const char *tg_net_kernel_name(const tg_net *net, int batch) {
         if (pick_split()) return "dualnet_fwd_split_kernel<19, 1, f16x2>";
         return pick_wino(19, batch, net->num_cus) ? "dualnet_fwd_wino8_kernel<19, 1, global scratch>" : "dualnet_fwd_kernel<19, 1>";
     }
-    if (pick_s32(9, batch, net->num_cus)) return "dualnet_fwd_s32_kernel<9, 3>";
+    if (pick_w2(9, batch, net->num_cus)) return "dualnet_fwd_w2_kernel<9, 3>";
     if (pick_split()) return batch > net->num_cus ? "dualnet_fwd_split_kernel<9, 3, f16x2>" : "dualnet_fwd_split_kernel<9, 1, f16x2>";
     {
         const int wg = pick_wino(9, batch, net->num_cus);
@@ -934,8 +934,8 @@ int tg_net_forward_dev(tg_net *net, const float *planes_dev, int batch, int want
                 flag = slot;
             }
             TG_HIP(hipMemsetAsync(flag, 0, sizeof(int), st));
-            int rc = pick_s32(9, batch, net->num_cus)
-                         ? tg::s32_forward(net, planes_dev, batch, want_logits, policy_dev, value_dev, flag, st)
+            int rc = pick_w2(9, batch, net->num_cus)
+                         ? tg::w2_forward(net, planes_dev, batch, want_logits, policy_dev, value_dev, flag, st)
                          : tg::split_forward(net, group, planes_dev, batch, want_logits, policy_dev, value_dev, flag, st);
             if (rc) return rc;
             if (group == 3) return launch_wino8<9, 3>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st, flag);

@@ -1,49 +1,46 @@
 // DualNet forward for gfx950, split operands (f16 x 2 pieces, three MFMAs per fp32 product - the scheme of
-// net_forward_split.hip, same accuracy class) on v_mfma_f32_32x32x16_f16 with TWO waves per SIMD.
+// net_forward_split.hip, same accuracy class) with TWO waves per SIMD.
 //
 // Why a second kernel (profiles/r02_pmc_forward_split_9x9_b65536.json, r02_phase_timeline_forward_split_9x9.txt):
 // the one-wave-per-SIMD kernel keeps the matrix pipe 56 % busy.  Its loop loses 25 % to fragment reads a lone
 // wave cannot overlap with its own MFMAs (in-order issue), its epilogues run on a VALU that one wave can feed
 // one instruction every ~4 cycles, and a quarter of their instructions only move accumulators out of AGPRs.
 // Here:
-//   * eight waves per workgroup = two per SIMD, <= 256 registers each: while one wave waits for a fragment or
-//     issues VALU / LDS work, its partner's MFMAs keep the pipe busy; the epilogue's VALU and LDS-store rates
-//     double (two instruction streams per SIMD);
-//   * wave tile = 32 output channels x 64 positions (RT = 2 tiles of v_mfma_f32_32x32x16_f16): half the MFMA
-//     instructions of the 16x16x32 form for the same FLOPs, 64 accumulator registers per wave;
-//     wave w: row quarter rq = w % 4, channel half chh = w / 4 (waves w and w + 4 share a SIMD);
-//   * fragment bytes per MFMA FLOP as before: per k-chunk (K = 32) and wave 8 ds_read_b128 (activations, two
-//     pieces x two k-steps x two row tiles) and 4 coalesced 1 KB global loads (weights, L2-resident image in
-//     fragment order), 12 MFMAs;
+//   * eight waves per workgroup = two per SIMD, <= 256 registers each (accumulators in VGPRs: no v_accvgpr moves):
+//     while one wave waits for a fragment or issues VALU / LDS work, its partner's MFMAs keep the pipe busy;
+//   * wave tile = 32 output channels x 64 positions (2 x 4 tiles of v_mfma_f32_16x16x32_f16), 64 accumulator
+//     registers; wave w: row quarter rq = w % 4, channel half chh = w / 4 (waves w and w + 4 share a SIMD);
+//   * per k-chunk (K = 32) and wave: 8 ds_read_b128 (activations: four row tiles x two pieces), 4 coalesced 1 KB
+//     global loads (weights, L2-resident image in fragment order), 24 MFMAs;
 //   * batch norm is folded away on the host: the scale goes INTO the weights (in fp64, before the f16 split),
 //     the shift becomes the accumulators' initial value, so an epilogue is: combine the two accumulator sets,
 //     one power-of-two factor, (+ residual), ReLU, split, store.
 //
-// Layouts.  32x32x16 fragments: A (weights) lane l holds cout = l & 31, k = 8 (l >> 5) + 0..7 of a k-step;
-// B (activations) lane l holds position = l & 31, same k; D register r of lane l is cout = (r & 3) + 8 (r >> 2)
-// + 4 (l >> 5), position = l & 31.
-// Activation images [piece 2][k-chunk 2][row][64 B]: row = position, the 64 B are the k-chunk's 32 channels in
-// order, 16-byte slot s XOR ((row >> 2) & 3): conflict-free ds_read_b128 for every tap shift (brute-forced
-// against the hardware's lane groups {0-3,12-15,20-27} ...).  Row M is all zero (padding taps), row M + 1 takes
-// the stores of rows >= M.  Residual image fp32 [row][16 x 16 B], slot XOR (row & 15).
+// MFMA shape: the board is POWER-capped (rocm-smi: 1.31-1.37 kW of 1.4 kW while this kernel runs; the shader clock
+// follows the work's energy, profiles/r03_power_and_pmc_s32_vs_split16.txt).  On random f16 data, MFMAs back to back
+// from registers sustain 1.93 PFLOP/s as 16x16x32 but only 1.72 PFLOP/s as 32x32x16 (tools/microbench/mfma_power.hip,
+// profiles/r03_microbench_mfma_power.txt).  A first version of this kernel on 32x32x16 tiles (git: "s32") had its
+// loop at 90-97 % of the MFMA time and still ran 10 % slower in wall time than the 16x16x32 kernel: 1.91 vs 2.22 GHz.
+//
+// Layouts as in net_forward_split.hip: activation images [piece 2][k-chunk 2][row][4 x 16 B], slot = (k / 8) XOR
+// ((row >> 1) & 3) - conflict-free ds_read_b128 B-fragments for every tap shift; row M all zero (padding taps),
+// row M + 1 takes the stores of rows >= M.  Residual image fp32 [row][16 x 16 B], slot XOR (row & 15).
 #include "split_common.h"
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
 template <int S, int G>
-struct S32Cfg {
+struct W2Cfg {
     static constexpr int P = S * S, A = P + 1, M = G * P;
-    static constexpr int MT32 = (M + 31) / 32;                    // 32-row tiles
-    static constexpr int RT = (MT32 % 2 == 0) ? 2 : 1;            // row tiles per wave
-    static constexpr int NRQ = MT32 / RT;                         // row groups
+    static constexpr int MT = (M + 15) / 16;                      // 16-row tiles
+    static constexpr int RTW = G >= 2 ? 4 : 2;                    // row tiles per wave
+    static constexpr int NRQ = (MT + RTW - 1) / RTW;              // row groups
+    static constexpr int CT = 2;                                  // 16-channel tiles per wave (one channel half)
     static constexpr int NW = 2 * NRQ, NTHR = NW * 64;
-    static constexpr int MT = (M + 15) / 16;                      // 16-row tiles (head phase)
     static constexpr bool BIG = false;
     static constexpr int IMG = (M + 2) * 64;
     static constexpr int ACT_BYTES = 4 * IMG;                     // image index = piece * 2 + kc
-    static constexpr int CHUNK = 8192;                            // weights per k-chunk: [chh 2][piece 2][ks 2][lane][16 B]
+    static constexpr int CHUNK = 8192;                            // weights per k-chunk: [chh 2][piece 2][ct 2][lane][16 B]
     static constexpr int STAGE = (ACT_BYTES + 255) & ~255;        // input planes [G][6][P] fp32
     static constexpr int STAGE_END = STAGE + ((G * 6 * P * 4 + 255) & ~255);
     static constexpr int HEAD_IMG = ((M + 1) * kRowBytes + 255) & ~255;     // fp32 image of the last layer (heads)
@@ -61,36 +58,28 @@ struct S32Cfg {
     static constexpr int LDS_BYTES = AUX + G * (3 * P + A + 4) * 4 + 256;
 };
 
-__device__ __forceinline__ f32x16 mfma32(const i32x4v &w, const i32x4v &a, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, a), c, 0, 0, 0);
-}
-
-// MFMA order inside a k-step for RT row tiles: (product q, row tile r) such that an accumulator is not touched by
-// two MFMAs in a row.  Products: q0 = wh x ah -> set 0, q1 = wl x ah -> set 1, q2 = wh x al -> set 1.
-template <int RT> struct MOrder;
-template <> struct MOrder<2> { static constexpr int Q[6] = {1, 1, 0, 2, 2, 0}, R[6] = {0, 1, 0, 0, 1, 1}; };
-template <> struct MOrder<1> { static constexpr int Q[3] = {1, 0, 2}, R[3] = {0, 0, 0}; };
-
-template <int S, int G>
-__global__ __launch_bounds__((S32Cfg<S, G>::NTHR), 2) void dualnet_fwd_s32_kernel(
+// ABL: timing-only ablations for tools/phase_profile.py (results are wrong): bit 0 = no activation-fragment reads in
+// the loop, bit 1 = no weight-fragment loads in the loop, bit 2 = no MFMAs
+template <int S, int G, int ABL = 0>
+__global__ __launch_bounds__((W2Cfg<S, G>::NTHR), 2) void dualnet_fwd_w2_kernel(
     NetDev net, const float *__restrict__ planes, int batch, int want_logits,
     float *__restrict__ policy, float *__restrict__ value, int *__restrict__ overflow) {
-    using C = S32Cfg<S, G>;
+    using C = W2Cfg<S, G>;
     using F = FmtF16;
-    constexpr int P = C::P, M = C::M, RT = C::RT, NTHR = C::NTHR, IMG = C::IMG, NRQ = C::NRQ;
+    constexpr int P = C::P, M = C::M, RTW = C::RTW, CT = C::CT, NTHR = C::NTHR, IMG = C::IMG, NRQ = C::NRQ;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int lane = tid & 63, li = lane & 15, lg = lane >> 4;
     const int rq = wave % NRQ, chh = wave / NRQ;
 
     // ---- per-lane geometry of this wave's row tiles ----
-    int base_row[RT];
-    unsigned mask[RT];                                    // bit t: tap t of this row is inside its board
+    int base_row[RTW];
+    unsigned mask[RTW];                                   // bit t: tap t of this row is inside its board
 #pragma unroll
-    for (int r = 0; r < RT; ++r) {
-        const int row = (rq * RT + r) * 32 + l31;
+    for (int r = 0; r < RTW; ++r) {
+        const int row = (rq * RTW + r) * 16 + li;
         const int p = row % P, y = p / S, x = p - y * S;
         unsigned m = 0;
 #pragma unroll
@@ -105,7 +94,7 @@ __global__ __launch_bounds__((S32Cfg<S, G>::NTHR), 2) void dualnet_fwd_s32_kerne
     for (int e = tid; e < 4 * 16; e += NTHR)
         reinterpret_cast<unsigned *>(smem + (e >> 4) * IMG + M * 64)[e & 15] = 0u;
     // tables -> LDS, once per workgroup
-    for (int e = tid; e < 13 * 64; e += NTHR) reinterpret_cast<float *>(smem + C::SS_OFF)[e] = net.s32_init[e];
+    for (int e = tid; e < 13 * 64; e += NTHR) reinterpret_cast<float *>(smem + C::SS_OFF)[e] = net.w2_init[e];
     for (int e = tid; e < 64 * 4; e += NTHR) {
         const int k = e >> 2, c = e & 3;
         reinterpret_cast<float *>(smem + C::HW_OFF)[e] = c == 0 ? net.hp_w[k] : (c == 1 ? net.hp_w[64 + k] : (c == 2 ? net.hv_w[k] : 0.f));
@@ -115,15 +104,19 @@ __global__ __launch_bounds__((S32Cfg<S, G>::NTHR), 2) void dualnet_fwd_s32_kerne
     for (int e = tid; e < 3 * P + 3; e += NTHR)
         reinterpret_cast<float *>(smem + C::VW_OFF)[e] = e < 3 * P ? net.vfc_w[e] : net.vfc_b[e - 3 * P];
 
-    // weight stream: k-chunk gc of the whole network at ws32 + gc * CHUNK; this wave's four fragments (piece p,
-    // k-step ks) at chh * 4096 + (p * 2 + ks) * 1024 + lane * 16
+    // weight stream: k-chunk gc of the whole network at ww2 + gc * CHUNK; this wave's four fragments (piece p,
+    // channel tile c) at chh * 4096 + (p * 2 + c) * 1024 + lane * 16
     const int wv0 = chh * 4096 + lane * 16;
     constexpr int kChunks = 2 * kSplitTaps;
 
+    // profiling stamps (tg_net_profile_phases), workgroup 0: wave 0 -> timeline[0..], the last wave -> timeline[64..]:
+    // 0 group start, 1 input staged + split, per layer L (stem first) 2 + 3 L "MFMA loop done", 3 + 3 L "all waves
+    // done" (barrier passed), 4 + 3 L "epilogue stored, barrier passed"; 41 heads done (44..46: head sub-phases)
     int stamp_i = 0;
+    const bool stamper = net.timeline && blockIdx.x == 0 && (tid == 0 || tid == NTHR - 64);
+    long long *const tl = net.timeline ? net.timeline + (tid == 0 ? 0 : 64) : nullptr;
     auto stamp = [&]() {
-        if (net.timeline && blockIdx.x == 0 && tid == 0 && stamp_i < 40)
-            net.timeline[stamp_i++] = (long long)__builtin_amdgcn_s_memtime();
+        if (stamper && stamp_i < 42) tl[stamp_i++] = (long long)__builtin_amdgcn_s_memtime();
     };
     int ovf = 0;
     const int n_groups = (batch + G - 1) / G;
@@ -158,7 +151,7 @@ __global__ __launch_bounds__((S32Cfg<S, G>::NTHR), 2) void dualnet_fwd_s32_kerne
                 const int row = e >> 1, kc = e & 1;
                 const int bl = row / P, p = row - bl * P, y = p / S, x = p - y * S;
                 const float *src = st + bl * 6 * P + p;
-                const int swz = (row >> 2) & 3;
+                const int swz = (row >> 1) & 3;
 #pragma unroll
                 for (int sl = 0; sl < 4; ++sl) {            // slot sl holds k = 32 kc + 8 sl .. + 7
                     f32x4 lo, hi;
@@ -183,68 +176,61 @@ __global__ __launch_bounds__((S32Cfg<S, G>::NTHR), 2) void dualnet_fwd_s32_kerne
         __syncthreads();
         stamp();
 
-        f32x16 acc[2][RT];
+        f32x4 acc[2][CT][RTW];
         constexpr int NASET = 3, ADIST = 2;
-        i32x4v fa[NASET][2][2];                            // [set][k-step][piece]
-        i32x4v fb[2][RT][2][2];                            // [k-chunk parity][row tile][k-step][piece]
+        i32x4v fa[NASET][CT][2];                           // [set][channel tile][piece]
+        i32x4v fb[2][RTW][2];                              // [k-chunk parity][row tile][piece]
 
-        // B-fragment address (k-step 0) of row tile r for tap `tap`; k-step 1 is the same address with bit 5 flipped
+        // B-fragment address of row tile r for tap `tap`
         auto row_addr = [&](int r, int tap, bool stem) __attribute__((always_inline)) {
             const int toff = stem ? 0 : (tap / 3 - 1) * S + (tap % 3 - 1);
             const bool ok = stem ? base_row[r] < M : ((mask[r] >> tap) & 1u) != 0;
             const int row = ok ? base_row[r] + toff : M;
-            return row * 64 + ((h ^ ((row >> 2) & 3)) << 4);
+            return row * 64 + ((lg ^ ((row >> 1) & 3)) << 4);
         };
-        auto load_b = [&](i32x4v &dst, auto P_, auto KC_, auto KS_, int addr) __attribute__((always_inline)) {
+        auto load_b = [&](i32x4v &dst, auto P_, auto KC_, int addr) __attribute__((always_inline)) {
             constexpr int off = (decltype(P_)::value * 2 + decltype(KC_)::value) * IMG;
-            if constexpr (decltype(KS_)::value == 0) lds_load_frag<off>(dst, smem, addr);
-            else lds_load_frag<off>(dst, smem, addr ^ 32);
+            lds_load_frag<off>(dst, smem, addr);
         };
         int wvg = wv0;
         asm volatile("" : "+v"(wvg));
         auto load_a_all = [&](auto SET_, int gc) __attribute__((always_inline)) {
             constexpr int set = decltype(SET_)::value;
-            const unsigned char *base = net.ws32 + (size_t)(gc < kChunks ? gc : kChunks - 1) * C::CHUNK;
-            static_for<4>([&](auto J) {
-                constexpr int j = decltype(J)::value, ks = j & 1, p = j >> 1;
-                gmem_load_frag(fa[set][ks][p], base, wvg + j * 1024);
+            const unsigned char *base = net.ww2 + (size_t)(gc < kChunks ? gc : kChunks - 1) * C::CHUNK;
+            static_for<2 * CT>([&](auto J) {
+                constexpr int j = decltype(J)::value, c = j % CT, p = j / CT;
+                gmem_load_frag(fa[set][c][p], base, wvg + j * 1024);
             });
         };
         load_a_all(std::integral_constant<int, 1>{}, 0);
         load_a_all(std::integral_constant<int, 2>{}, 1);
 
-        // One k-chunk: 6 RT MFMAs; in between, the activation fragments of the next chunk (LDS) and the weight
-        // fragments of the chunk after next (L2, into the set this chunk's predecessor used).
-        auto chunk = [&](auto KC_, auto ASET_, int gc, const int (&ba)[RT], const int (&bn)[RT]) __attribute__((always_inline)) {
+        // One k-chunk: CT x RTW x 3 MFMAs; in between, the activation fragments of the next chunk (LDS) and the
+        // weight fragments of the chunk after next (L2, into the set this chunk's predecessor used).
+        auto chunk = [&](auto KC_, auto ASET_, int gc, const int (&ba)[RTW], const int (&bn)[RTW]) __attribute__((always_inline)) {
             constexpr int kc = decltype(KC_)::value, aset = decltype(ASET_)::value % NASET, anext = (aset + ADIST) % NASET;
-            const unsigned char *wnext = net.ws32 + (size_t)(gc + ADIST < kChunks ? gc + ADIST : kChunks - 1) * C::CHUNK;
-            constexpr int NPK = 3 * RT;                    // MFMAs per k-step
-            constexpr int NMFMA = 2 * NPK;
-            constexpr int NB = RT * 4, NA = 4;
-            using O = MOrder<RT>;
+            const unsigned char *wnext = net.ww2 + (size_t)(gc + ADIST < kChunks ? gc + ADIST : kChunks - 1) * C::CHUNK;
+            constexpr int NMFMA = CT * RTW * F::NPROD;
+            constexpr int NB = RTW * 2, NA = CT * 2;
+            constexpr int BSPAN = NMFMA * 10 / 16;         // activation loads: during the first 10/16 of the chunk
             static_for<NMFMA>([&](auto M_) {
                 constexpr int m = decltype(M_)::value;
-                constexpr int ks = m / NPK, q = O::Q[m % NPK], r = O::R[m % NPK];
-                acc[F::PC[q]][r] = mfma32(fa[aset][ks][F::PA[q]], fb[kc][r][ks][F::PB[q]], acc[F::PC[q]][r]);
-                // activation fragments of the next chunk
-                constexpr int jb0 = m * NB / NMFMA, jb1 = (m + 1) * NB / NMFMA;
-                if constexpr (jb1 > jb0) {
+                constexpr int q = m / (CT * RTW), c = (m / RTW) % CT, r = m % RTW;
+                if constexpr (!(ABL & 4))
+                    acc[F::PC[q]][c][r] = mfma16<F>(fa[aset][c][F::PA[q]], fb[kc][r][F::PB[q]], acc[F::PC[q]][c][r]);
+                constexpr int jb0 = m * NB / BSPAN, jb1 = (m + 1) * NB / BSPAN < NB ? (m + 1) * NB / BSPAN : NB;
+                if constexpr (jb1 > jb0 && !(ABL & 1)) {
                     static_for<jb1 - jb0>([&](auto D_) {
-                        constexpr int jb = jb0 + decltype(D_)::value, r2 = jb % RT, ks2 = (jb / RT) & 1, p2 = jb / (2 * RT);
-                        if constexpr (kc == 0)
-                            load_b(fb[1][r2][ks2][p2], std::integral_constant<int, p2>{}, std::integral_constant<int, 1>{},
-                                   std::integral_constant<int, ks2>{}, ba[r2]);
-                        else
-                            load_b(fb[0][r2][ks2][p2], std::integral_constant<int, p2>{}, std::integral_constant<int, 0>{},
-                                   std::integral_constant<int, ks2>{}, bn[r2]);
+                        constexpr int jb = jb0 + decltype(D_)::value, r2 = jb % RTW, p2 = jb / RTW;
+                        if constexpr (kc == 0) load_b(fb[1][r2][p2], std::integral_constant<int, p2>{}, std::integral_constant<int, 1>{}, ba[r2]);
+                        else load_b(fb[0][r2][p2], std::integral_constant<int, p2>{}, std::integral_constant<int, 0>{}, bn[r2]);
                     });
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                // weight fragment of the chunk after next
                 constexpr int ja0 = m * NA / NMFMA, ja1 = (m + 1) * NA / NMFMA;
-                if constexpr (ja1 > ja0) {
-                    constexpr int ks2 = ja0 & 1, p2 = ja0 >> 1;
-                    gmem_load_frag(fa[anext][ks2][p2], wnext, wv0 + ja0 * 1024);
+                if constexpr (ja1 > ja0 && !(ABL & 2)) {
+                    constexpr int c2 = ja0 % CT, p2 = ja0 / CT;
+                    gmem_load_frag(fa[anext][c2][p2], wnext, wv0 + ja0 * 1024);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             });
@@ -262,24 +248,23 @@ __global__ __launch_bounds__((S32Cfg<S, G>::NTHR), 2) void dualnet_fwd_s32_kerne
             {
                 int lz = lane;
                 asm volatile("" : "+v"(lz));                // opaque: the table addresses are not hoisted out of the layer loop
-                const int cb = C::SS_OFF + (layer * 64 + chh * 32 + (lz >> 5) * 4) * 4;
-                f32x4 ini[4];
+                const int cb = C::SS_OFF + (layer * 64 + chh * 32 + (lz >> 4) * 4) * 4;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) ini[g] = *reinterpret_cast<const f32x4 *>(smem + cb + g * 32);
+                for (int c = 0; c < CT; ++c) {
+                    const f32x4 ini = *reinterpret_cast<const f32x4 *>(smem + cb + c * 64);
 #pragma unroll
-                for (int r = 0; r < RT; ++r)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        acc[0][r][e] = ini[e >> 2][e & 3];
-                        acc[1][r][e] = 0.f;
+                    for (int r = 0; r < RTW; ++r) {
+                        acc[0][c][r] = ini;
+                        acc[1][c][r] = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
+                }
             }
-            int ba[RT], bn[RT];
+            int ba[RTW], bn[RTW];
 #pragma unroll
-            for (int r = 0; r < RT; ++r) ba[r] = row_addr(r, 0, stem);
-            static_for<RT * 4>([&](auto J) {
-                constexpr int jb = decltype(J)::value, r = jb % RT, ks = (jb / RT) & 1, p = jb / (2 * RT);
-                load_b(fb[0][r][ks][p], std::integral_constant<int, p>{}, I0{}, std::integral_constant<int, ks>{}, ba[r]);
+            for (int r = 0; r < RTW; ++r) ba[r] = row_addr(r, 0, stem);
+            static_for<RTW * 2>([&](auto J) {
+                constexpr int r = decltype(J)::value % RTW, p = decltype(J)::value / RTW;
+                load_b(fb[0][r][p], std::integral_constant<int, p>{}, I0{}, ba[r]);
             });
             if (stem) {
                 chunk(I0{}, I1{}, gc, ba, ba);
@@ -289,73 +274,74 @@ __global__ __launch_bounds__((S32Cfg<S, G>::NTHR), 2) void dualnet_fwd_s32_kerne
 #pragma unroll 1
                 for (int t3 = 0; t3 < 9; t3 += 3) {        // three taps = six chunks = two turns of the weight sets
 #pragma unroll
-                    for (int r = 0; r < RT; ++r) bn[r] = row_addr(r, t3 + 1, false);
+                    for (int r = 0; r < RTW; ++r) bn[r] = row_addr(r, t3 + 1, false);
                     chunk(I0{}, I0{}, gc, ba, bn);
                     chunk(I1{}, I1{}, gc + 1, ba, bn);
 #pragma unroll
-                    for (int r = 0; r < RT; ++r) { ba[r] = bn[r]; bn[r] = row_addr(r, t3 + 2, false); }
+                    for (int r = 0; r < RTW; ++r) { ba[r] = bn[r]; bn[r] = row_addr(r, t3 + 2, false); }
                     chunk(I0{}, I2{}, gc + 2, ba, bn);
                     chunk(I1{}, std::integral_constant<int, 3>{}, gc + 3, ba, bn);
 #pragma unroll
-                    for (int r = 0; r < RT; ++r) { ba[r] = bn[r]; bn[r] = row_addr(r, t3 + 3 < 9 ? t3 + 3 : 8, false); }
+                    for (int r = 0; r < RTW; ++r) { ba[r] = bn[r]; bn[r] = row_addr(r, t3 + 3 < 9 ? t3 + 3 : 8, false); }
                     chunk(I0{}, std::integral_constant<int, 4>{}, gc + 4, ba, bn);
                     chunk(I1{}, std::integral_constant<int, 5>{}, gc + 5, ba, bn);
 #pragma unroll
-                    for (int r = 0; r < RT; ++r) ba[r] = bn[r];
+                    for (int r = 0; r < RTW; ++r) ba[r] = bn[r];
                     gc += 6;
                 }
             }
             // ---- epilogue: combine the accumulator sets, undo the weight scaling, (+ residual), ReLU, split, store ----
             stamp();
+            const float down = net.w2_down[layer];        // 2^-e of this layer's weights (uniform: scalar load, in flight
+            const float down_x = down * (1.f / 2048.f);    // across the barrier)
             __syncthreads();                              // every wave is done reading the layer input
+            stamp();
             float amax = 0.f;
-            const float down = net.s32_down[layer];       // 2^-e of this layer's weights (uniform: scalar load)
-            const float down_x = down * (1.f / 2048.f);
             auto epilogue = [&](auto KEEP_, auto ADD_, auto LAST_) __attribute__((always_inline)) {
                 constexpr bool keep = decltype(KEEP_)::value, add_res = decltype(ADD_)::value, last = decltype(LAST_)::value;
-                int brow[RT], rrow[RT], wrow[RT];
-                f32x4 xres[RT][4];
+                int brow[RTW], rrow[RTW], wrow[RTW];
+                f32x4 xres[CT][RTW];
 #pragma unroll
-                for (int r = 0; r < RT; ++r) {
+                for (int r = 0; r < RTW; ++r) {
                     brow[r] = base_row[r];
                     asm volatile("" : "+v"(brow[r]));     // opaque: LDS addresses are recomputed, not hoisted + spilled
                     rrow[r] = brow[r] < M ? brow[r] : 0;
                     wrow[r] = brow[r] < M ? brow[r] : M + 1;
                 }
-                const int c16 = chh * 8 + h;                // 16-byte slot (4 channels) of register group g: c16 + 2 g
+                const int c16 = chh * 8 + lg;               // 16-byte slot (4 channels) of channel tile c: c16 + 4 c
                 if constexpr (add_res) {
 #pragma unroll
-                    for (int r = 0; r < RT; ++r)
+                    for (int c = 0; c < CT; ++c)
 #pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            xres[r][g] = *reinterpret_cast<const f32x4 *>(smem + C::RES_OFF + rrow[r] * 256 +
-                                                                          (((c16 + 2 * g) ^ (rrow[r] & 15)) << 4));
+                        for (int r = 0; r < RTW; ++r)
+                            xres[c][r] = *reinterpret_cast<const f32x4 *>(smem + C::RES_OFF + rrow[r] * 256 +
+                                                                          (((c16 + 4 * c) ^ (rrow[r] & 15)) << 4));
                 }
 #pragma unroll
-                for (int r = 0; r < RT; ++r) {
-                    const int row = wrow[r];
-                    const int swz = (row >> 2) & 3;
+                for (int c = 0; c < CT; ++c) {
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
+                    for (int r = 0; r < RTW; ++r) {
+                        const int row = wrow[r];
                         f32x4 v;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            float t = fmaf(acc[1][r][g * 4 + j], down_x, acc[0][r][g * 4 + j] * down);
-                            if constexpr (add_res) t += xres[r][g][j];
+                            float t = fmaf(acc[1][c][r][j], down_x, acc[0][c][r][j] * down);
+                            if constexpr (add_res) t += xres[c][r][j];
                             v[j] = fmaxf(t, 0.f);
                         }
                         amax = fmaxf(fmaxf(amax, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
                         if constexpr (last) {
                             const int hrow = brow[r] < M ? brow[r] : M;
-                            *reinterpret_cast<f32x4 *>(smem + hrow * kRowBytes + (chh * 32 + g * 8 + h * 4) * 4) = v;
+                            *reinterpret_cast<f32x4 *>(smem + hrow * kRowBytes + (chh * 32 + c * 16 + lg * 4) * 4) = v;
                         } else {
                             if constexpr (keep) {
                                 const int krow = brow[r] < M ? brow[r] : M;
-                                *reinterpret_cast<f32x4 *>(smem + C::RES_OFF + krow * 256 + (((c16 + 2 * g) ^ (krow & 15)) << 4)) = v;
+                                *reinterpret_cast<f32x4 *>(smem + C::RES_OFF + krow * 256 + (((c16 + 4 * c) ^ (krow & 15)) << 4)) = v;
                             }
                             uint2 pc[2];
                             split4<F>(v, pc);
-                            const int off = row * 64 + ((g ^ swz) << 4) + h * 8;
+                            const int slot = ((c << 1) | (lg >> 1)) ^ ((row >> 1) & 3);
+                            const int off = row * 64 + slot * 16 + (lg & 1) * 8;
 #pragma unroll
                             for (int q = 0; q < 2; ++q)
                                 *reinterpret_cast<uint2 *>(smem + (q * 2 + chh) * IMG + off) = pc[q];
@@ -375,7 +361,7 @@ __global__ __launch_bounds__((S32Cfg<S, G>::NTHR), 2) void dualnet_fwd_s32_kerne
         }
         fetch_planes(grp + gridDim.x);
         run_heads_split<S, G, C, NTHR>(smem, net, b0, batch, want_logits, policy, value, tid, wave,
-                                       (net.timeline && blockIdx.x == 0 && grp == blockIdx.x) ? net.timeline + 40 : nullptr);
+                                       (net.timeline && blockIdx.x == 0 && grp == blockIdx.x) ? net.timeline + 44 : nullptr);
         __syncthreads();
         stamp();
         // the head scratch overlapped the activation images' zero rows
@@ -385,12 +371,13 @@ __global__ __launch_bounds__((S32Cfg<S, G>::NTHR), 2) void dualnet_fwd_s32_kerne
     if (ovf && overflow) atomicOr(overflow, 1);
 }
 
-template <int S, int G>
-int launch_s32(tg_net *net, const float *planes, int batch, int want_logits, float *policy, float *value,
-               int *overflow, hipStream_t stream) {
-    using C = S32Cfg<S, G>;
+template <int S, int G, int ABL = 0>
+int launch_w2(tg_net *net, const float *planes, int batch, int want_logits, float *policy, float *value,
+              int *overflow, hipStream_t stream) {
+    using C = W2Cfg<S, G>;
     static_assert(C::LDS_BYTES <= 160 * 1024, "LDS budget");
-    auto kern = dualnet_fwd_s32_kernel<S, G>;
+    static_assert(C::NRQ * C::RTW * 16 >= C::M, "row coverage");
+    auto kern = dualnet_fwd_w2_kernel<S, G, ABL>;
     static bool attr_set[16] = {};
     if (!attr_set[net->device & 15]) {
         TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
@@ -408,11 +395,12 @@ int launch_s32(tg_net *net, const float *planes, int batch, int want_logits, flo
 
 namespace tg {
 
-// Weight image of the s32 kernel.  conv0: [64][6][3][3]; tower[l]: [64][64][3][3]; scale / shift: folded batch norm
-// [13][64].  Per layer: w' = w * scale[cout] (fp64), scaled by a power of two 2^e so that the largest |w'| lies in
-// [2^9, 2^10) (f16 pieces stay normal), split into two f16 pieces; accumulator start = shift * 2^e; 2^-e is applied in
-// the epilogue.  Image: [k-chunk gc][chh 2][piece 2][k-step 2][lane 64][8 x f16], gc = 2 * tap_g + kc.
-int s32_prepare(tg_net *net, const float *conv0, const float *const *tower, const float *scale, const float *shift) {
+// Weight image of the two-waves-per-SIMD kernel.  conv0: [64][6][3][3]; tower[l]: [64][64][3][3]; scale / shift: folded
+// batch norm [13][64].  Per layer: w' = w * scale[cout] (fp64), scaled by a power of two 2^e so that the largest |w'|
+// lies in [2^9, 2^10) (f16 pieces stay normal), split into two f16 pieces; accumulator start = shift * 2^e; 2^-e is
+// applied in the epilogue.  Image: [k-chunk gc][chh 2][piece 2][ct 2][lane 64][8 x f16], gc = 2 * tap_g + kc; lane l of
+// a fragment holds cout = 32 chh + 16 ct + (l & 15), k = 32 kc + 8 (l >> 4) + 0..7.
+int w2_prepare(tg_net *net, const float *conv0, const float *const *tower, const float *scale, const float *shift) {
     std::vector<uint16_t> img((size_t)2 * kSplitTaps * 4096, 0);
     std::vector<float> init(13 * 64), down(16, 1.f);
     for (int layer = 0; layer <= kTowerLayers; ++layer) {
@@ -438,10 +426,10 @@ int s32_prepare(tg_net *net, const float *conv0, const float *const *tower, cons
             const int g = layer == 0 ? 0 : 1 + (layer - 1) * 9 + tap;
             for (int kc = 0; kc < 2; ++kc)
                 for (int chh = 0; chh < 2; ++chh)
-                    for (int ks = 0; ks < 2; ++ks)
+                    for (int ct = 0; ct < 2; ++ct)
                         for (int lane = 0; lane < 64; ++lane)
                             for (int el = 0; el < 8; ++el) {
-                                const int cout = chh * 32 + (lane & 31), k = kc * 32 + ks * 16 + (lane >> 5) * 8 + el;
+                                const int cout = chh * 32 + ct * 16 + (lane & 15), k = kc * 32 + (lane >> 4) * 8 + el;
                                 double v;
                                 if (layer == 0) {                  // k = tap' * 6 + plane
                                     const int t2 = k / 6, c2 = k % 6;
@@ -450,12 +438,12 @@ int s32_prepare(tg_net *net, const float *conv0, const float *const *tower, cons
                                     v = (double)w[((size_t)cout * 64 + k) * 9 + tap];
                                 }
                                 v *= (double)scale[layer * 64 + cout] * up;
-                                uint16_t pc[2];
-                                split_weight((float)v, pc);
                                 // pieces of the fp64 product: the second piece takes what the first left of the exact value
+                                uint16_t pc[2];
+                                pc[0] = f32_to_f16_rn((float)v);
                                 pc[1] = f32_to_f16_rn((float)((v - (double)f16_to_f32(pc[0])) * 2048.0));
                                 for (int p = 0; p < 2; ++p)
-                                    img[(((((size_t)g * 2 + kc) * 2 + chh) * 2 + p) * 2 + ks) * 512 + lane * 8 + el] = pc[p];
+                                    img[(((((size_t)g * 2 + kc) * 2 + chh) * 2 + p) * 2 + ct) * 512 + lane * 8 + el] = pc[p];
                             }
         }
     }
@@ -463,24 +451,33 @@ int s32_prepare(tg_net *net, const float *conv0, const float *const *tower, cons
     TG_HIP(hipMalloc(&d, img.size() * 2));
     net->allocs.push_back(d);
     TG_HIP(hipMemcpy(d, img.data(), img.size() * 2, hipMemcpyHostToDevice));
-    net->dev.ws32 = static_cast<const unsigned char *>(d);
+    net->dev.ww2 = static_cast<const unsigned char *>(d);
     void *di = nullptr;
     TG_HIP(hipMalloc(&di, init.size() * 4));
     net->allocs.push_back(di);
     TG_HIP(hipMemcpy(di, init.data(), init.size() * 4, hipMemcpyHostToDevice));
-    net->dev.s32_init = static_cast<const float *>(di);
+    net->dev.w2_init = static_cast<const float *>(di);
     void *dd = nullptr;
     TG_HIP(hipMalloc(&dd, down.size() * 4));
     net->allocs.push_back(dd);
     TG_HIP(hipMemcpy(dd, down.data(), down.size() * 4, hipMemcpyHostToDevice));
-    net->dev.s32_down = static_cast<const float *>(dd);
+    net->dev.w2_down = static_cast<const float *>(dd);
     return TG_OK;
 }
 
-int s32_forward(tg_net *net, const float *planes, int batch, int want_logits, float *policy, float *value,
-                int *overflow, hipStream_t stream) {
-    if (net->board_size != 9) return tg::fail(TG_ERR_ARG, "s32 forward: 9x9 only");
-    return launch_s32<9, 3>(net, planes, batch, want_logits, policy, value, overflow, stream);
+int w2_forward(tg_net *net, const float *planes, int batch, int want_logits, float *policy, float *value,
+               int *overflow, hipStream_t stream) {
+    if (net->board_size != 9) return tg::fail(TG_ERR_ARG, "w2 forward: 9x9 only");
+    if (const char *env = getenv("TG_W2_ABL")) {            // timing-only ablations (wrong results): see the kernel
+        switch (atoi(env)) {
+        case 1: return launch_w2<9, 3, 1>(net, planes, batch, want_logits, policy, value, overflow, stream);
+        case 2: return launch_w2<9, 3, 2>(net, planes, batch, want_logits, policy, value, overflow, stream);
+        case 3: return launch_w2<9, 3, 3>(net, planes, batch, want_logits, policy, value, overflow, stream);
+        case 4: return launch_w2<9, 3, 4>(net, planes, batch, want_logits, policy, value, overflow, stream);
+        default: break;
+        }
+    }
+    return launch_w2<9, 3>(net, planes, batch, want_logits, policy, value, overflow, stream);
 }
 
 }  // namespace tg

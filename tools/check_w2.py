@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Bring-up / regression check of the two-waves-per-SIMD forward kernel (net_forward_s32.hip) on the GPU box:
+"""Bring-up / regression check of the two-waves-per-SIMD forward kernel (net_forward_w2.hip) on the GPU box:
 structured networks that localise an indexing mistake (centre-tap identity, single shifted taps, one channel
 pair), the seeded synthetic networks against the CPU oracle and the reference-recorded fp64 logits, and the
-forward-only rate of every 9x9 kernel.   python tools/check_s32.py [quick]"""
+forward-only rate of every 9x9 kernel.   python tools/check_w2.py [quick]"""
 import os
 import sys
 import time
@@ -51,11 +51,11 @@ def structured(kind):
 
 rs = np.random.RandomState(5)
 x300 = torch.from_numpy(rs.randint(-1, 2, size=(300, 6, 9, 9)).astype(np.float32))
-print("== structured networks, B = 300 (s32 kernel vs CPU oracle; split16 for comparison) ==")
+print("== structured networks, B = 300 (w2 kernel vs CPU oracle; split16 for comparison) ==")
 for kind in ["identity", "perm", "tap0", "tap5", "tap7", "random"]:
     sd = make_state_dict(9, 3, 1.4) if kind == "random" else structured(kind)
     ref = OracleNet(sd).inference_with_policy_logits(x300)
-    for algo in ("s32", "split16"):
+    for algo in ("w2", "split16"):
         (lg, val), name = run(algo, sd, x300)
         bad_boards = int(((lg - ref[0]).abs().amax(dim=1) > 1e-4).sum())
         print(f"{kind:9s} {algo:8s} {name:40s} logit err {float((lg - ref[0]).abs().max()):.3e}  value err "
@@ -63,7 +63,7 @@ for kind in ["identity", "perm", "tap0", "tap5", "tap7", "random"]:
 
 print("== accuracy against the reference-recorded fp64 forward (planes tiled to B > 256) ==")
 fix = load_npz("net_s9.npz")
-for algo in ("s32", "split16", "wino"):
+for algo in ("w2", "split16", "wino"):
     for seed in (0, 7):
         sd = make_state_dict(9, seed, float(fix[f"w{seed}_gain"]))
         x = torch.from_numpy(fix[f"w{seed}_planes"].astype(np.float32))
@@ -82,13 +82,13 @@ ora = OracleNet(sd)
 for b in (257, 770, 1539, 4099):
     x = torch.from_numpy(rs.randint(-1, 2, size=(b, 6, 9, 9)).astype(np.float32))
     rp, rv = ora.inference(x)
-    (pol, val), name = run("s32", sd, x, logits=False)
+    (pol, val), name = run("w2", sd, x, logits=False)
     print(f"B={b:5d} {name}: policy err {float((pol - rp).abs().max()):.3e} value err {float((val - rv).abs().max()):.3e}", flush=True)
 
 if not quick:
     print("== forward-only rate, planes resident ==")
     flops = lib.tg_net_flops_per_position(9)
-    for algo in ("s32", "split16"):
+    for algo in ("w2", "split16"):
         os.environ["TG_FWD_ALGO"] = algo
         torch.manual_seed(0)
         net = DualNet(dev, 9)

@@ -26,7 +26,20 @@ for _ in range(2):
                                        st.ctypes.data, 128))
 name = lib.tg_net_kernel_name(net.handle, b).decode()
 print("kernel:", name)
-if "split" in name or "s32" in name:
+if "w2" in name:
+    # two stamping waves (wave 0 and the last wave of workgroup 0); per layer: MFMA loop done, barrier passed (= every
+    # wave's loop done), epilogue stored + barrier passed
+    for label, base in (("wave 0", 0), ("last wave", 64)):
+        s = st[base:base + 42] - st[base]
+        print(f"{label}: group total {s[41]} ticks; staging + im2col + split of the input {s[1]}")
+        print("  MFMA loop (stem, then 12 layers)   :", [int(s[2 + 3 * i] - s[1 + 3 * i]) for i in range(13)])
+        print("  wait for the other waves (barrier) :", [int(s[3 + 3 * i] - s[2 + 3 * i]) for i in range(13)])
+        print("  epilogue + barrier                 :", [int(s[4 + 3 * i] - s[3 + 3 * i]) for i in range(13)])
+        print("  heads                              :", int(s[41] - s[40]))
+    print("  heads detail (wave 0): 1x1 convs", int(st[44] - st[40]), "| FC weights landed + barrier", int(st[45] - st[44]),
+          "| FCs", int(st[46] - st[45]), "| softmax + stores", int(st[41] - st[46]))
+    print("  start skew of the last wave vs wave 0:", int(st[64] - st[0]))
+elif "split" in name:
     s = st[:29] - st[0]
     print(f"group total {s[28]} ticks; staging + im2col + split of the input {s[1]}")
     print("  MFMA loop (stem, then 12 layers):", [int(s[2 + 2 * i] - s[1 + 2 * i]) for i in range(13)])
