@@ -10,8 +10,13 @@
 //     while one wave waits for a fragment or issues VALU / LDS work, its partner's MFMAs keep the pipe busy;
 //   * wave tile = 32 output channels x 64 positions (2 x 4 tiles of v_mfma_f32_16x16x32_f16), 64 accumulator
 //     registers; wave w: row quarter rq = w % 4, channel half chh = w / 4 (waves w and w + 4 share a SIMD);
-//   * per k-chunk (K = 32) and wave: 8 ds_read_b128 (activations: four row tiles x two pieces), 4 coalesced 1 KB
-//     global loads (weights, L2-resident image in fragment order), 24 MFMAs;
+//   * weights reach the CU ONCE per k-chunk: every wave copies 1 KB of the chunk's 8 KB (L2-resident image in
+//     fragment order) into a two-slot LDS ring with global_load_lds, two chunks ahead; one s_barrier per chunk
+//     publishes the slot that has landed and frees the one that was read.  (With every wave fetching its own
+//     fragments from L2 - 32 KB per chunk and CU through the vector-memory path - the loop lost 4.8 k of 21 k cycles
+//     per layer: profiles/r03_w2_direct_weights_ablation_phase_timeline.txt.)
+//   * per k-chunk (K = 32) and wave: 8 + 4 ds_read_b128 (activations: four row tiles x two pieces; weights: two
+//     channel tiles x two pieces), 24 MFMAs;
 //   * batch norm is folded away on the host: the scale goes INTO the weights (in fp64, before the f16 split),
 //     the shift becomes the accumulators' initial value, so an epilogue is: combine the two accumulator sets,
 //     one power-of-two factor, (+ residual), ReLU, split, store.
@@ -55,7 +60,8 @@ struct W2Cfg {
     static constexpr int PIPE_BYTES = VW_OFF + ((3 * P + 3 + 3) & ~3) * 4;
     static constexpr int ROW_BYTES = kRowBytes;
     static constexpr int AUX = PIPE_BYTES;
-    static constexpr int LDS_BYTES = AUX + G * (3 * P + A + 4) * 4 + 256;
+    static constexpr int RING_OFF = (AUX + G * (3 * P + A + 4) * 4 + 255) & ~255;     // weight ring: two k-chunks
+    static constexpr int LDS_BYTES = RING_OFF + 2 * CHUNK;
 };
 
 // ABL: timing-only ablations for tools/phase_profile.py (results are wrong): bit 0 = no activation-fragment reads in
@@ -104,10 +110,28 @@ __global__ __launch_bounds__((W2Cfg<S, G>::NTHR), 2) void dualnet_fwd_w2_kernel(
     for (int e = tid; e < 3 * P + 3; e += NTHR)
         reinterpret_cast<float *>(smem + C::VW_OFF)[e] = e < 3 * P ? net.vfc_w[e] : net.vfc_b[e - 3 * P];
 
-    // weight stream: k-chunk gc of the whole network at ww2 + gc * CHUNK; this wave's four fragments (piece p,
-    // channel tile c) at chh * 4096 + (p * 2 + c) * 1024 + lane * 16
-    const int wv0 = chh * 4096 + lane * 16;
+    // weight stream: k-chunk gc of the whole network at ww2 + gc * CHUNK -> ring slot gc & 1; this wave's four
+    // fragments (piece p, channel tile c) at chh * 4096 + (p * 2 + c) * 1024 + lane * 16 of the slot; its share of the
+    // copy: bytes [wave * 1024, + 1024) of the chunk
+    const int wv0 = C::RING_OFF + chh * 4096 + lane * 16;
     constexpr int kChunks = 2 * kSplitTaps;
+    const unsigned dma_off = (unsigned)(wave * 1024 + lane * 16);
+    auto dma_chunk = [&](int gc) __attribute__((always_inline)) {       // gc taken modulo the network: the ring runs on
+        const int g2 = gc < kChunks ? gc : gc - kChunks;                 // into the next board group
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(net.ww2 + (size_t)g2 * C::CHUNK + dma_off),
+                                         (__attribute__((address_space(3))) void *)(smem + C::RING_OFF + (gc & 1) * C::CHUNK + wave * 1024),
+                                         16, 0, 0);
+    };
+    // publish: my share of every copy issued so far has landed, my fragment reads of the slot about to be refilled
+    // are done; behind the barrier the other waves' shares have landed too
+    auto ring_barrier = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_s_waitcnt(0x0070);                 // vmcnt(0) lgkmcnt(0) - the builtin, so that hipcc's own counters
+        asm volatile("" ::: "memory");                      // know (behind an asm wait it re-waited lgkmcnt(0) on the next
+        __builtin_amdgcn_s_barrier();                       // chunk's first, freshly issued read)
+        asm volatile("" ::: "memory");
+    };
+    dma_chunk(0);
+    dma_chunk(1);
 
     // profiling stamps (tg_net_profile_phases), workgroup 0: wave 0 -> timeline[0..], the last wave -> timeline[64..]:
     // 0 group start, 1 input staged + split, per layer L (stem first) 2 + 3 L "MFMA loop done", 3 + 3 L "all waves
@@ -133,6 +157,7 @@ __global__ __launch_bounds__((W2Cfg<S, G>::NTHR), 2) void dualnet_fwd_w2_kernel(
                          ? __builtin_nontemporal_load(&planes[(size_t)grp2 * G * 6 * P + e]) : 0.f;
         }
     };
+    ring_barrier();                                       // chunks 0 and 1 of the weight stream are in the ring (and the tables above in LDS)
     fetch_planes(blockIdx.x);
     for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
         const int b0 = grp * G;
@@ -177,8 +202,7 @@ __global__ __launch_bounds__((W2Cfg<S, G>::NTHR), 2) void dualnet_fwd_w2_kernel(
         stamp();
 
         f32x4 acc[2][CT][RTW];
-        constexpr int NASET = 3, ADIST = 2;
-        i32x4v fa[NASET][CT][2];                           // [set][channel tile][piece]
+        i32x4v fa[2][CT][2];                               // [k-chunk parity][channel tile][piece]
         i32x4v fb[2][RTW][2];                              // [k-chunk parity][row tile][piece]
 
         // B-fragment address of row tile r for tap `tap`
@@ -193,31 +217,35 @@ __global__ __launch_bounds__((W2Cfg<S, G>::NTHR), 2) void dualnet_fwd_w2_kernel(
             lds_load_frag<off>(dst, smem, addr);
         };
         int wvg = wv0;
-        asm volatile("" : "+v"(wvg));
-        auto load_a_all = [&](auto SET_, int gc) __attribute__((always_inline)) {
-            constexpr int set = decltype(SET_)::value;
-            const unsigned char *base = net.ww2 + (size_t)(gc < kChunks ? gc : kChunks - 1) * C::CHUNK;
-            static_for<2 * CT>([&](auto J) {
-                constexpr int j = decltype(J)::value, c = j % CT, p = j / CT;
-                gmem_load_frag(fa[set][c][p], base, wvg + j * 1024);
-            });
+        asm volatile("" : "+v"(wvg));                      // opaque: one address register, slot and fragment in the immediate
+        // weight fragments of a chunk with parity KC from its ring slot
+        auto load_a = [&](i32x4v &dst, auto KC_, auto J_) __attribute__((always_inline)) {
+            constexpr int off = decltype(KC_)::value * C::CHUNK + decltype(J_)::value * 1024;
+            lds_load_frag<off>(dst, smem, wvg);
         };
-        load_a_all(std::integral_constant<int, 1>{}, 0);
-        load_a_all(std::integral_constant<int, 2>{}, 1);
+        // chunk 0 of the network lies in slot 0 (first group: copied above; later groups: the previous group's last
+        // chunks copied chunks 0 and 1 of the next pass), published by a ring barrier
+        static_for<2 * CT>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            load_a(fa[0][j % CT][j / CT], std::integral_constant<int, 0>{}, J);
+        });
 
-        // One k-chunk: CT x RTW x 3 MFMAs; in between, the activation fragments of the next chunk (LDS) and the
-        // weight fragments of the chunk after next (L2, into the set this chunk's predecessor used).
-        auto chunk = [&](auto KC_, auto ASET_, int gc, const int (&ba)[RTW], const int (&bn)[RTW]) __attribute__((always_inline)) {
-            constexpr int kc = decltype(KC_)::value, aset = decltype(ASET_)::value % NASET, anext = (aset + ADIST) % NASET;
-            const unsigned char *wnext = net.ww2 + (size_t)(gc + ADIST < kChunks ? gc + ADIST : kChunks - 1) * C::CHUNK;
+        // One k-chunk gc (parity KC): copy of chunk gc + 2 into this chunk's slot (its fragments are in registers, every
+        // wave's - ring barrier of the previous chunk), CT x RTW x 3 MFMAs with the weight fragments of chunk gc + 1
+        // (other slot) and - unless this is a layer's last chunk - the activation fragments of the next chunk in
+        // between, ring barrier.  ba: this tap's row addresses (for a KC = 0 chunk's successor), bn: the next tap's.
+        auto chunk = [&](auto KC_, auto LASTC_, int gc, const int (&ba)[RTW], const int (&bn)[RTW]) __attribute__((always_inline)) {
+            constexpr int kc = decltype(KC_)::value;
+            constexpr bool lastc = decltype(LASTC_)::value;
+            if constexpr (!(ABL & 2)) dma_chunk(gc + 2);
             constexpr int NMFMA = CT * RTW * F::NPROD;
-            constexpr int NB = RTW * 2, NA = CT * 2;
+            constexpr int NB = lastc ? 0 : RTW * 2, NA = CT * 2;
             constexpr int BSPAN = NMFMA * 10 / 16;         // activation loads: during the first 10/16 of the chunk
             static_for<NMFMA>([&](auto M_) {
                 constexpr int m = decltype(M_)::value;
                 constexpr int q = m / (CT * RTW), c = (m / RTW) % CT, r = m % RTW;
                 if constexpr (!(ABL & 4))
-                    acc[F::PC[q]][c][r] = mfma16<F>(fa[aset][c][F::PA[q]], fb[kc][r][F::PB[q]], acc[F::PC[q]][c][r]);
+                    acc[F::PC[q]][c][r] = mfma16<F>(fa[kc][c][F::PA[q]], fb[kc][r][F::PB[q]], acc[F::PC[q]][c][r]);
                 constexpr int jb0 = m * NB / BSPAN, jb1 = (m + 1) * NB / BSPAN < NB ? (m + 1) * NB / BSPAN : NB;
                 if constexpr (jb1 > jb0 && !(ABL & 1)) {
                     static_for<jb1 - jb0>([&](auto D_) {
@@ -227,18 +255,22 @@ __global__ __launch_bounds__((W2Cfg<S, G>::NTHR), 2) void dualnet_fwd_w2_kernel(
                     });
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                constexpr int ja0 = m * NA / NMFMA, ja1 = (m + 1) * NA / NMFMA;
+                // weight fragments of the next chunk: spread over the second half of the chunk (the first half's LDS
+                // slots go to the activation fragments)
+                constexpr int ja0 = m >= NMFMA / 2 ? (m - NMFMA / 2) * NA / (NMFMA / 2) : 0;
+                constexpr int ja1 = m >= NMFMA / 2 ? (m + 1 - NMFMA / 2) * NA / (NMFMA / 2) : 0;
                 if constexpr (ja1 > ja0 && !(ABL & 2)) {
-                    constexpr int c2 = ja0 % CT, p2 = ja0 / CT;
-                    gmem_load_frag(fa[anext][c2][p2], wnext, wv0 + ja0 * 1024);
+                    load_a(fa[1 - kc][ja0 % CT][ja0 / CT], std::integral_constant<int, 1 - kc>{}, std::integral_constant<int, ja0>{});
                     __builtin_amdgcn_sched_barrier(0);
                 }
             });
             __builtin_amdgcn_sched_barrier(0);
+            ring_barrier();
         };
         using I0 = std::integral_constant<int, 0>;
         using I1 = std::integral_constant<int, 1>;
-        using I2 = std::integral_constant<int, 2>;
+        using T = std::true_type;
+        using N = std::false_type;
 
         int gc = 0;
 #pragma unroll 1
@@ -267,34 +299,28 @@ __global__ __launch_bounds__((W2Cfg<S, G>::NTHR), 2) void dualnet_fwd_w2_kernel(
                 load_b(fb[0][r][p], std::integral_constant<int, p>{}, I0{}, ba[r]);
             });
             if (stem) {
-                chunk(I0{}, I1{}, gc, ba, ba);
-                chunk(I1{}, I2{}, gc + 1, ba, ba);
+                chunk(I0{}, N{}, gc, ba, ba);
+                chunk(I1{}, T{}, gc + 1, ba, ba);
                 gc += 2;
             } else {
 #pragma unroll 1
-                for (int t3 = 0; t3 < 9; t3 += 3) {        // three taps = six chunks = two turns of the weight sets
+                for (int t = 0; t < 8; ++t) {              // taps 0..7: two chunks each, activation fragments of the next tap
 #pragma unroll
-                    for (int r = 0; r < RTW; ++r) bn[r] = row_addr(r, t3 + 1, false);
-                    chunk(I0{}, I0{}, gc, ba, bn);
-                    chunk(I1{}, I1{}, gc + 1, ba, bn);
-#pragma unroll
-                    for (int r = 0; r < RTW; ++r) { ba[r] = bn[r]; bn[r] = row_addr(r, t3 + 2, false); }
-                    chunk(I0{}, I2{}, gc + 2, ba, bn);
-                    chunk(I1{}, std::integral_constant<int, 3>{}, gc + 3, ba, bn);
-#pragma unroll
-                    for (int r = 0; r < RTW; ++r) { ba[r] = bn[r]; bn[r] = row_addr(r, t3 + 3 < 9 ? t3 + 3 : 8, false); }
-                    chunk(I0{}, std::integral_constant<int, 4>{}, gc + 4, ba, bn);
-                    chunk(I1{}, std::integral_constant<int, 5>{}, gc + 5, ba, bn);
+                    for (int r = 0; r < RTW; ++r) bn[r] = row_addr(r, t + 1, false);
+                    chunk(I0{}, N{}, gc, ba, bn);
+                    chunk(I1{}, N{}, gc + 1, ba, bn);
 #pragma unroll
                     for (int r = 0; r < RTW; ++r) ba[r] = bn[r];
-                    gc += 6;
+                    gc += 2;
                 }
+                chunk(I0{}, N{}, gc, ba, ba);              // tap 8
+                chunk(I1{}, T{}, gc + 1, ba, ba);
+                gc += 2;
             }
             // ---- epilogue: combine the accumulator sets, undo the weight scaling, (+ residual), ReLU, split, store ----
-            stamp();
-            const float down = net.w2_down[layer];        // 2^-e of this layer's weights (uniform: scalar load, in flight
-            const float down_x = down * (1.f / 2048.f);    // across the barrier)
-            __syncthreads();                              // every wave is done reading the layer input
+            stamp();                                      // (the last chunk's ring barrier: every wave is done reading the
+            const float down = net.w2_down[layer];        // layer input)   2^-e of this layer's weights (uniform: scalar load)
+            const float down_x = down * (1.f / 2048.f);
             stamp();
             float amax = 0.f;
             auto epilogue = [&](auto KEEP_, auto ADD_, auto LAST_) __attribute__((always_inline)) {
@@ -349,8 +375,6 @@ __global__ __launch_bounds__((W2Cfg<S, G>::NTHR), 2) void dualnet_fwd_w2_kernel(
                     }
                 }
             };
-            using T = std::true_type;
-            using N = std::false_type;
             if (layer == kTowerLayers) epilogue(N{}, T{}, T{});
             else if (layer == 0) epilogue(T{}, N{}, N{});
             else if (layer & 1) epilogue(N{}, N{}, N{});
