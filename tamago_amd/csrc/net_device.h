@@ -40,7 +40,7 @@ struct NetDev {
     // 1 + 9*layer + tap for the tower) an LDS-ready image [k-chunk 2][piece][cout tile 4][lane 64][8 x 16 bit]
     const unsigned char *wsplit;      // f16 x 2 pieces
     const float *sscale;              // [13][64] folded BN scale incl. the per-layer weight scaling 2^-e
-    // 32x32x16 two-waves-per-SIMD kernel (net_forward_w2.hip): [k-chunk][chh 2][piece 2][k-step 2][lane 64][8 x f16],
+    // two-waves-per-SIMD kernel (net_forward_w2.hip): [k-chunk][chh 2][piece 2][ct 2][lane 64][8 x f16],
     // batch-norm scale folded into the weights; accumulator start values [13][64] (folded shift x weight scaling);
     // per-layer factor 2^-e [13]
     const unsigned char *ww2;

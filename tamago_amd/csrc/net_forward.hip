@@ -818,12 +818,13 @@ static bool pick_split() {
     const char *env = getenv("TG_FWD_ALGO");
     return !env || !strcmp(env, "split16") || !strcmp(env, "w2");
 }
-// large 9x9 batches (three boards per workgroup): the 32x32x16 kernel with two waves per SIMD (net_forward_w2.hip)
-// unless TG_FWD_ALGO=split16 asks for the one-wave-per-SIMD 16x16x32 kernel (net_forward_split.hip)
+// TG_FWD_ALGO=w2: large 9x9 batches (three boards per workgroup) on the two-waves-per-SIMD kernel (net_forward_w2.hip:
+// weights through an LDS ring, batch norm folded into the weights); measured level with the one-wave-per-SIMD kernel
+// (net_forward_split.hip, the default), DESIGN.md 4.1d
 static bool pick_w2(int board_size, int batch, int num_cus) {
     if (board_size != 9 || batch <= num_cus) return false;
     const char *env = getenv("TG_FWD_ALGO");
-    return !env || !strcmp(env, "w2");
+    return env && !strcmp(env, "w2");
 }
 
 const char *tg_net_kernel_name(const tg_net *net, int batch) {
@@ -853,7 +854,7 @@ double tg_net_executed_flops_per_position(const tg_net *net, int batch, double *
     if ((S == 9 || S == 19) && pick_split()) {
         // per workgroup pass: (2 stem + 12 * 18) k-chunks x (4 cout tiles x row tiles) x 3 products of
         // v_mfma_f32_16x16x32_f16 (16 384 FLOP each)
-        // (the 32x32x16 kernel issues the same FLOPs: 8 waves x 12 MFMAs of 32 768 FLOP per chunk = 16 row tiles x 4 x 3 x 16 384)
+        // (the two-waves-per-SIMD kernel issues the same MFMAs: 8 waves x 24 per chunk = 16 row tiles x 4 x 3)
         const int g = S == 19 ? 1 : (batch > net->num_cus ? 3 : 1);
         const int row_tiles = S == 19 ? 24 : (g == 3 ? 16 : 6);   // 4 waves x 6 | 4 waves x 4 | 3 waves x 2
         flops = (2.0 + 12.0 * 18.0) * 4.0 * row_tiles * 3.0 * 16384.0 / g;

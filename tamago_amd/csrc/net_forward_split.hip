@@ -52,8 +52,13 @@ struct SplitCfg {
     static constexpr int RTW = BIG ? 6 : (G == 3 ? 4 : 2);        // row-tiles per wave
     static constexpr int NW = (MT + RTW - 1) / RTW;               // waves per workgroup
     static constexpr int NTHR = NW * 64;
-    static constexpr int IMG = (M + 2) * 64;                      // one [row][64 B] image + zero row M + dump row M + 1
-                                                                  // (rows >= M of the last row-tile store there: no branches)
+    // one [row][64 B] image + dump row M (rows >= M of the last row-tile store there: no branches) + a 256-byte,
+    // 256-byte-aligned block of zeros: a padding tap reads zero block + (address of the row it would have read) mod 256,
+    // i.e. zeros from the banks its own row would have used - conflict-free like the real rows.  (One shared zero row
+    // cost 8 instead of 4 LDS cycles on 94 of the 144 (row tile, tap) fragments of a 3-board group:
+    // tools/microbench/lds_read_patterns.hip, profiles/r03_microbench_lds_read_patterns.txt.)
+    static constexpr int ZOFF = ((M + 1) * 64 + 255) & ~255;
+    static constexpr int IMG = ZOFF + 256;
     static constexpr int ACT_BYTES = F::NP * 2 * IMG;             // image index = piece * 2 + kc
     static constexpr int CHUNK = F::NP * 4 * 1024;                // weight image per k-chunk: [piece][ct][lane][16 B]
     static constexpr int STAGE = (ACT_BYTES + 255) & ~255;        // input planes [G][6][P] fp32 (group start only)
@@ -119,8 +124,8 @@ __global__ __launch_bounds__((SplitCfg<S, G, F>::NTHR), 1) void dualnet_fwd_spli
         base_row[r] = row;
     }
     // zero rows of the activation images (written once; the epilogues never touch row M)
-    for (int e = tid; e < NP * 2 * 16; e += NTHR)
-        reinterpret_cast<unsigned *>(smem + (e >> 4) * IMG + M * 64)[e & 15] = 0u;
+    for (int e = tid; e < NP * 2 * 64; e += NTHR)
+        reinterpret_cast<unsigned *>(smem + (e >> 6) * IMG + C::ZOFF)[e & 63] = 0u;
 
     // folded BN scale / shift of all 13 layers -> LDS, once (the epilogues would otherwise wait for L2 every layer)
     for (int e = tid; e < 13 * 64; e += NTHR) {
@@ -217,8 +222,9 @@ __global__ __launch_bounds__((SplitCfg<S, G, F>::NTHR), 1) void dualnet_fwd_spli
         auto row_addr = [&](int r, int tap, bool stem) __attribute__((always_inline)) {
             const int toff = stem ? 0 : (tap / 3 - 1) * S + (tap % 3 - 1);
             const bool ok = stem ? base_row[r] < M : ((mask[r] >> tap) & 1u) != 0;
-            const int row = ok ? base_row[r] + toff : M;
-            return row * 64 + ((lg ^ ((row >> 1) & 3)) << 4);
+            const int row = base_row[r] + toff;             // (may lie outside the image when !ok: only its banks matter)
+            const int nat = row * 64 + ((lg ^ ((row >> 1) & 3)) << 4);
+            return ok ? nat : C::ZOFF + (nat & 255);
         };
         auto load_b = [&](i32x4v &dst, auto P_, auto KC_, int addr) __attribute__((always_inline)) {
             constexpr int off = (decltype(P_)::value * 2 + decltype(KC_)::value) * IMG;   // image (p, kc)
@@ -348,7 +354,7 @@ __global__ __launch_bounds__((SplitCfg<S, G, F>::NTHR), 1) void dualnet_fwd_spli
                     brow[r] = base_row[r];
                     asm volatile("" : "+v"(brow[r]));
                     rrow[r] = brow[r] < M ? brow[r] : 0;                  // rows >= M: read anything valid,
-                    wrow[r] = brow[r] < M ? brow[r] : M + 1;              // store into the dump row
+                    wrow[r] = brow[r] < M ? brow[r] : M;                  // store into the dump row
                 }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -428,8 +434,8 @@ __global__ __launch_bounds__((SplitCfg<S, G, F>::NTHR), 1) void dualnet_fwd_spli
         __syncthreads();
         stamp();
         // the head scratch overlapped the activation images' zero rows
-        for (int e = tid; e < NP * 2 * 16; e += NTHR)
-            reinterpret_cast<unsigned *>(smem + (e >> 4) * IMG + M * 64)[e & 15] = 0u;
+        for (int e = tid; e < NP * 2 * 64; e += NTHR)
+            reinterpret_cast<unsigned *>(smem + (e >> 6) * IMG + C::ZOFF)[e & 63] = 0u;
     }
     if (ovf && overflow) atomicOr(overflow, 1);
 }

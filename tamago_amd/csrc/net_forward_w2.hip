@@ -28,8 +28,12 @@
 // loop at 90-97 % of the MFMA time and still ran 10 % slower in wall time than the 16x16x32 kernel: 1.91 vs 2.22 GHz.
 //
 // Layouts as in net_forward_split.hip: activation images [piece 2][k-chunk 2][row][4 x 16 B], slot = (k / 8) XOR
-// ((row >> 1) & 3) - conflict-free ds_read_b128 B-fragments for every tap shift; row M all zero (padding taps),
-// row M + 1 takes the stores of rows >= M.  Residual image fp32 [row][16 x 16 B], slot XOR (row & 15).
+// ((row >> 1) & 3) - conflict-free ds_read_b128 B-fragments for every tap shift.  Padding taps read ZEROS FROM THE BANKS
+// THEIR OWN ROW WOULD HAVE USED: every image ends in a 256-byte (one full bank row) block of zeros, and a lane whose tap
+// falls outside its board reads zero block + (address of the row it would have read) mod 256.  (With ONE zero row
+// shared by all padding lanes 94 of the 144 (row tile, tap) fragments of a 3-board group took 8 LDS cycles instead of
+// 4: brute force over the hardware's lane groups; PMC: 37 % of the LDS-active cycles were bank conflicts.)  Row M takes
+// the stores of rows >= M.  Residual image fp32 [row][16 x 16 B], slot XOR (row & 15).
 #include "split_common.h"
 
 namespace {
@@ -43,7 +47,8 @@ struct W2Cfg {
     static constexpr int CT = 2;                                  // 16-channel tiles per wave (one channel half)
     static constexpr int NW = 2 * NRQ, NTHR = NW * 64;
     static constexpr bool BIG = false;
-    static constexpr int IMG = (M + 2) * 64;
+    static constexpr int ZOFF = ((M + 1) * 64 + 255) & ~255;      // zero block of an image: 256 B, 256-byte aligned (row M: dump)
+    static constexpr int IMG = ZOFF + 256;                        // (a multiple of 256: every image sees the same banks)
     static constexpr int ACT_BYTES = 4 * IMG;                     // image index = piece * 2 + kc
     static constexpr int CHUNK = 8192;                            // weights per k-chunk: [chh 2][piece 2][ct 2][lane][16 B]
     static constexpr int STAGE = (ACT_BYTES + 255) & ~255;        // input planes [G][6][P] fp32
@@ -97,8 +102,8 @@ __global__ __launch_bounds__((W2Cfg<S, G>::NTHR), 2) void dualnet_fwd_w2_kernel(
         base_row[r] = row;
     }
     // zero rows of the four activation images (the epilogues never touch row M)
-    for (int e = tid; e < 4 * 16; e += NTHR)
-        reinterpret_cast<unsigned *>(smem + (e >> 4) * IMG + M * 64)[e & 15] = 0u;
+    for (int e = tid; e < 4 * 64; e += NTHR)
+        reinterpret_cast<unsigned *>(smem + (e >> 6) * IMG + C::ZOFF)[e & 63] = 0u;
     // tables -> LDS, once per workgroup
     for (int e = tid; e < 13 * 64; e += NTHR) reinterpret_cast<float *>(smem + C::SS_OFF)[e] = net.w2_init[e];
     for (int e = tid; e < 64 * 4; e += NTHR) {
@@ -204,13 +209,15 @@ __global__ __launch_bounds__((W2Cfg<S, G>::NTHR), 2) void dualnet_fwd_w2_kernel(
         f32x4 acc[2][CT][RTW];
         i32x4v fa[2][CT][2];                               // [k-chunk parity][channel tile][piece]
         i32x4v fb[2][RTW][2];                              // [k-chunk parity][row tile][piece]
+        i32x4v fbd[RTW][2];                                // (ablation 16 only)
 
         // B-fragment address of row tile r for tap `tap`
         auto row_addr = [&](int r, int tap, bool stem) __attribute__((always_inline)) {
             const int toff = stem ? 0 : (tap / 3 - 1) * S + (tap % 3 - 1);
             const bool ok = stem ? base_row[r] < M : ((mask[r] >> tap) & 1u) != 0;
-            const int row = ok ? base_row[r] + toff : M;
-            return row * 64 + ((lg ^ ((row >> 1) & 3)) << 4);
+            const int row = base_row[r] + toff;             // (may lie outside the image when !ok: only its banks matter)
+            const int nat = row * 64 + ((lg ^ ((row >> 1) & 3)) << 4);
+            return ok ? nat : C::ZOFF + (nat & 255);
         };
         auto load_b = [&](i32x4v &dst, auto P_, auto KC_, int addr) __attribute__((always_inline)) {
             constexpr int off = (decltype(P_)::value * 2 + decltype(KC_)::value) * IMG;
@@ -240,31 +247,36 @@ __global__ __launch_bounds__((W2Cfg<S, G>::NTHR), 2) void dualnet_fwd_w2_kernel(
             if constexpr (!(ABL & 2)) dma_chunk(gc + 2);
             constexpr int NMFMA = CT * RTW * F::NPROD;
             constexpr int NB = lastc ? 0 : RTW * 2, NA = CT * 2;
-            constexpr int BSPAN = NMFMA * 10 / 16;         // activation loads: during the first 10/16 of the chunk
+            // fragment reads: one behind each of the first NA + NB MFMAs (weights of the next chunk first - their slot was
+            // published by the last barrier -, then the activations): nothing is still in flight at the ring barrier
             static_for<NMFMA>([&](auto M_) {
                 constexpr int m = decltype(M_)::value;
                 constexpr int q = m / (CT * RTW), c = (m / RTW) % CT, r = m % RTW;
                 if constexpr (!(ABL & 4))
                     acc[F::PC[q]][c][r] = mfma16<F>(fa[kc][c][F::PA[q]], fb[kc][r][F::PB[q]], acc[F::PC[q]][c][r]);
-                constexpr int jb0 = m * NB / BSPAN, jb1 = (m + 1) * NB / BSPAN < NB ? (m + 1) * NB / BSPAN : NB;
+                constexpr int jb0 = m < NA ? 0 : (m - NA < NB ? m - NA : NB), jb1 = m < NA ? 0 : (m + 1 - NA < NB ? m + 1 - NA : NB);
                 if constexpr (jb1 > jb0 && !(ABL & 1)) {
                     static_for<jb1 - jb0>([&](auto D_) {
                         constexpr int jb = jb0 + decltype(D_)::value, r2 = jb % RTW, p2 = jb / RTW;
-                        if constexpr (kc == 0) load_b(fb[1][r2][p2], std::integral_constant<int, p2>{}, std::integral_constant<int, 1>{}, ba[r2]);
+                        if constexpr (ABL & 16) {             // reads issued into a set no MFMA reads (no data dependence)
+                            if constexpr (kc == 0) load_b(fbd[r2][p2], std::integral_constant<int, p2>{}, std::integral_constant<int, 1>{}, ba[r2]);
+                            else load_b(fbd[r2][p2], std::integral_constant<int, p2>{}, std::integral_constant<int, 0>{}, bn[r2]);
+                        } else if constexpr (kc == 0) load_b(fb[1][r2][p2], std::integral_constant<int, p2>{}, std::integral_constant<int, 1>{}, ba[r2]);
                         else load_b(fb[0][r2][p2], std::integral_constant<int, p2>{}, std::integral_constant<int, 0>{}, bn[r2]);
                     });
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                // weight fragments of the next chunk: spread over the second half of the chunk (the first half's LDS
-                // slots go to the activation fragments)
-                constexpr int ja0 = m >= NMFMA / 2 ? (m - NMFMA / 2) * NA / (NMFMA / 2) : 0;
-                constexpr int ja1 = m >= NMFMA / 2 ? (m + 1 - NMFMA / 2) * NA / (NMFMA / 2) : 0;
+                constexpr int ja0 = m < NA ? m : NA, ja1 = m < NA ? m + 1 : NA;
                 if constexpr (ja1 > ja0 && !(ABL & 2)) {
                     load_a(fa[1 - kc][ja0 % CT][ja0 / CT], std::integral_constant<int, 1 - kc>{}, std::integral_constant<int, ja0>{});
                     __builtin_amdgcn_sched_barrier(0);
                 }
             });
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (ABL & 16) {
+#pragma unroll
+                for (int r = 0; r < RTW; ++r) { asm volatile("" :: "v"(fbd[r][0])); asm volatile("" :: "v"(fbd[r][1])); }
+            }
             ring_barrier();
         };
         using I0 = std::integral_constant<int, 0>;
@@ -332,7 +344,7 @@ __global__ __launch_bounds__((W2Cfg<S, G>::NTHR), 2) void dualnet_fwd_w2_kernel(
                     brow[r] = base_row[r];
                     asm volatile("" : "+v"(brow[r]));     // opaque: LDS addresses are recomputed, not hoisted + spilled
                     rrow[r] = brow[r] < M ? brow[r] : 0;
-                    wrow[r] = brow[r] < M ? brow[r] : M + 1;
+                    wrow[r] = brow[r] < M ? brow[r] : M;
                 }
                 const int c16 = chh * 8 + lg;               // 16-byte slot (4 channels) of channel tile c: c16 + 4 c
                 if constexpr (add_res) {
@@ -389,8 +401,8 @@ __global__ __launch_bounds__((W2Cfg<S, G>::NTHR), 2) void dualnet_fwd_w2_kernel(
         __syncthreads();
         stamp();
         // the head scratch overlapped the activation images' zero rows
-        for (int e = tid; e < 4 * 16; e += NTHR)
-            reinterpret_cast<unsigned *>(smem + (e >> 4) * IMG + M * 64)[e & 15] = 0u;
+        for (int e = tid; e < 4 * 64; e += NTHR)
+            reinterpret_cast<unsigned *>(smem + (e >> 6) * IMG + C::ZOFF)[e & 63] = 0u;
     }
     if (ovf && overflow) atomicOr(overflow, 1);
 }
@@ -498,6 +510,7 @@ int w2_forward(tg_net *net, const float *planes, int batch, int want_logits, flo
         case 2: return launch_w2<9, 3, 2>(net, planes, batch, want_logits, policy, value, overflow, stream);
         case 3: return launch_w2<9, 3, 3>(net, planes, batch, want_logits, policy, value, overflow, stream);
         case 4: return launch_w2<9, 3, 4>(net, planes, batch, want_logits, policy, value, overflow, stream);
+        case 18: return launch_w2<9, 3, 18>(net, planes, batch, want_logits, policy, value, overflow, stream);
         default: break;
         }
     }

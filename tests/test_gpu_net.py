@@ -116,14 +116,15 @@ def test_featurize_kernel_vs_reference_golden(size):
     assert np.array_equal(out.cpu().numpy(), np.array(want))
 
 
-@pytest.mark.parametrize("size,algo", [(9, "direct"), (9, "wino"), (9, "split16"),
+@pytest.mark.parametrize("size,algo", [(9, "direct"), (9, "wino"), (9, "split16"), (9, "w2"),
                                        (19, "direct"), (19, "wino"), (19, "split16")])
 def test_every_tower_algorithm_matches_the_oracle(algo, size, monkeypatch):
     """Implementations of the residual tower: exact-fp32 Winograd F(2x2,3x3) kernel (TG_FWD_ALGO=wino; the
     layer outputs of a 19x19 board passing through a global scratch image), exact-fp32 direct implicit GEMM
-    (direct), and the split-operand kernel on the 16-bit matrix pipe (split16 = f16 x 2 pieces, the default at
-    both sizes; 19x19: one board per workgroup, residual image in an L2-resident scratch).  All must agree with
-    the oracle at every workgroup shape."""
+    (direct), and the split-operand kernels on the 16-bit matrix pipe (split16 = f16 x 2 pieces, one wave per SIMD,
+    at both sizes; 19x19: one board per workgroup, residual image in an L2-resident scratch; w2 = the same arithmetic
+    with two waves per SIMD, weights through an LDS ring and batch norm folded into the weights, for 9x9 batches
+    above the CU count).  All must agree with the oracle at every workgroup shape."""
     from oracle.net import OracleNet, make_state_dict
     monkeypatch.setenv("TG_FWD_ALGO", algo)
     sd = make_state_dict(size, 7, 1.5)
@@ -148,14 +149,17 @@ def test_split_kernels_are_fp32_class_and_fall_back_on_f16_overflow(monkeypatch)
     from oracle.net import OracleNet, make_state_dict
     fix = load_npz("net_s9.npz")
     errs = {}
-    for algo in ("wino", "direct", "split16"):
+    for algo in ("wino", "direct", "split16", "w2"):
         monkeypatch.setenv("TG_FWD_ALGO", algo)
         worst = 0.0
         for seed in (0, 7):
             sd = make_state_dict(9, seed, float(fix[f"w{seed}_gain"]))
             net = _net(9, sd)
             x = torch.from_numpy(fix[f"w{seed}_planes"].astype(np.float32))
-            lg, _ = net.inference_with_policy_logits(x)
+            n = x.shape[0]
+            reps = (300 + n - 1) // n                  # above the CU count: the three-boards-per-workgroup kernels
+            lg, _ = net.inference_with_policy_logits(x.repeat(reps, 1, 1, 1))
+            lg = lg[:n]
             err_hip = np.abs(lg.numpy() - fix[f"w{seed}_logits64"]).max()
             err_ref = np.abs(fix[f"w{seed}_logits"] - fix[f"w{seed}_logits64"]).max()
             assert err_hip < 4 * err_ref + 1e-6, (algo, seed, err_hip, err_ref)
@@ -168,6 +172,7 @@ def test_split_kernels_are_fp32_class_and_fall_back_on_f16_overflow(monkeypatch)
     x = torch.from_numpy(np.random.RandomState(2).randint(-1, 2, size=(300, 6, 9, 9)).astype(np.float32))
     monkeypatch.setenv("TG_FWD_ALGO", "wino")
     want = _net(9, sd).inference_with_policy_logits(x)
-    monkeypatch.setenv("TG_FWD_ALGO", "split16")
-    got = _net(9, sd).inference_with_policy_logits(x)
-    assert torch.isfinite(got[0]).all() and torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    for algo in ("split16", "w2"):
+        monkeypatch.setenv("TG_FWD_ALGO", algo)
+        got = _net(9, sd).inference_with_policy_logits(x)
+        assert torch.isfinite(got[0]).all() and torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), algo
