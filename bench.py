@@ -14,12 +14,16 @@ region; the timed region contains everything else, including the host side of th
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line (rank 0) with the contract's keys plus `roofline` (fused forward
-kernel: FLOPs of the MFMA instructions it executes / HIP-event launch time on the launch
-stream, against the dense matrix peak of the precision they run in; HBM traffic from the
-rocprofv3 PMC summary measured on these kernel sources), `cpu_baseline` (the CPU oracle - a
-port of the reference's Python path - timed on this host on a bounded sample of the same
-workload) and, at N = 1, legs for the other BASELINE.json configs (single tree, cfg-3,
-one cfg-4 shard, cfg-5).
+kernel: ALGORITHMIC FLOPs per launch / HIP-event launch time on the launch stream, against
+the dense matrix peak of the precision the kernel executes in - SURVEY 8(d) -, the
+issue-slot utilisation of the matrix pipe under its own name `mfma_issue_frac`, HBM traffic
+from the rocprofv3 PMC summary measured on these kernel sources), `tree_kernels` (HBM traffic
+of selection / backup, same rule), `cpu_baseline` (the CPU oracle - a port of the reference's
+Python path - timed on this host on a bounded sample of the same workload) and legs for the
+other BASELINE.json configs: at N = 1 `fp32_exact` (the same workload on the exact-fp32
+Winograd kernel), `single_tree`, `cfg3_selfplay_16_boards`, `cfg4_shard_64_boards`,
+`selfplay_1024_boards`, `cfg5_19x19`, `cfg1_cpu`; at N > 1 `cfg4_selfplay_shards` (one
+64-board Gumbel shard per rank, aggregate + per-rank rates + host cores per rank).
 """
 import argparse
 import json
@@ -46,14 +50,36 @@ def pmc_summary(kernel_name):
     from tamago_amd.build import FORWARD_SOURCES, source_digest
     digest = source_digest(FORWARD_SOURCES)
     import glob
-    for path in sorted(glob.glob(os.path.join(PROFILES, "r02_pmc_forward_*.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(PROFILES, "r0[0-9]_pmc_forward_*.json")), reverse=True):
         with open(path) as f:
             d = json.load(f)
         if d.get("csrc_digest") == digest and kernel_name.split("<")[0] in d.get("kernel", ""):
             d["file"] = os.path.relpath(path, REPO)
             return d
     sys.stderr.write(f"bench.py: no PMC summary in profiles/ for kernel {kernel_name!r} at csrc digest {digest} - "
-                     "roofline.traffic is null (run tools/pmc_r02.sh on the GPU box and commit the summary)\n")
+                     "roofline.traffic is null (run tools/pmc_r03.sh on the GPU box and commit the summary)\n")
+    return None
+
+
+def tree_pmc_summary():
+    """HBM-side traffic of the tree kernels (selection, backup; rocprofv3 PMC, tools/pmc_r03.sh) - quoted only when the
+    summary was measured on THESE sources (digest over all of csrc/ + the ABI header), else None + a warning."""
+    import glob
+    from tamago_amd.build import source_digest
+    digest = source_digest()
+    for path in sorted(glob.glob(os.path.join(PROFILES, "r0[0-9]_pmc_tree_and_featurize_kernels.json")), reverse=True):
+        with open(path) as f:
+            d = json.load(f)
+        if d.get("csrc_digest") == digest:
+            out = {"source": os.path.relpath(path, REPO)}
+            for name, k in d.get("kernels", {}).items():
+                if "hbm_bytes_per_leaf_eval" in k:
+                    out[name] = {"hbm_bytes_per_leaf_eval": k["hbm_bytes_per_leaf_eval"], "hbm_GBps": k["hbm_GBps"],
+                                 "fraction_of_8TBps_HBM_peak": k["fraction_of_8TBps_HBM_peak"],
+                                 "avg_duration_us": k["avg_duration_us"]}
+            return out
+    sys.stderr.write(f"bench.py: no tree-kernel PMC summary in profiles/ at csrc digest {digest} - tree_kernels is null "
+                     "(run tools/pmc_r03.sh on the GPU box and commit the summary)\n")
     return None
 
 
@@ -74,7 +100,11 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true",
-                    help="skip the extra legs (single tree, cfg-3 / cfg-4-shard self-play, cfg-5 19x19); N = 1 only")
+                    help="skip the extra legs (N = 1: exact-fp32 kernel, single tree, cfg-3 / cfg-4-shard self-play, cfg-5 "
+                         "19x19, cfg-1 on the CPU; N > 1: the cfg-4 shard per rank)")
+    ap.add_argument("--cfg4-boards", type=int, default=64, help="boards per cfg-4 shard (BASELINE.json: 64)")
+    ap.add_argument("--cfg4-games", type=int, default=192, help="games each rank's cfg-4 shard plays to completion")
+    ap.add_argument("--cfg4-visits", type=int, default=400)
     return ap.parse_args()
 
 
@@ -258,6 +288,80 @@ def cpu_baseline(size, visits, batch, budget_s):
                       f"{dt:.1f} s"}
 
 
+def cfg1_cpu(budget_s):
+    """BASELINE.json config[0]: 9x9, random-init DualNet, 100 visits/move, NN batch 1, CPU path only (the reference's
+    plumbing: main.py --visits 100 --batch-size 1 --use-gpu false): the CPU oracle, STRICT_PLAYOUT (exactly 100 visits)
+    and CONSTANT_PLAYOUT (the reference's --visits: early stop once the runner-up cannot catch up)."""
+    from oracle.board import GoBoard as OBoard, BLACK
+    from oracle.net import OracleNet
+    from oracle.tree import MCTSTree as OTree, TimeManager as OTM, TimeControl as OTC
+    from tamago_amd.nn.network.dual_net import random_state_dict
+    torch.manual_seed(0)
+    net = OracleNet(random_state_dict(9))
+    out = {"kind": "port", "cores": torch.get_num_threads(),
+           "workload": "cfg-1: 9x9, 100 visits/move, NN batch 1, CPU oracle (Python tree, 1 thread + PyTorch-CPU DualNet)"}
+    for label, mode in (("strict", OTC.STRICT_PLAYOUT), ("constant", OTC.CONSTANT_PLAYOUT)):
+        tree = OTree(net, 9, tree_size=256, batch_size=1)
+        board = OBoard(9)
+        np.random.seed(0)
+        color = BLACK
+        tm = OTM(mode, 100)
+        t0 = time.time()
+        leaves = moves = 0
+        while time.time() - t0 < budget_s / 2 and moves < 12:
+            mv = tree.search_best_move(board, color, tm)
+            leaves += sum(tree.batch_log)
+            tree.batch_log.clear()
+            board.put_stone(mv if mv > 0 else 0, color)
+            color = 3 - color
+            moves += 1
+        dt = time.time() - t0
+        out[label] = {"value": leaves / dt, "unit": "leaf-evals/s", "moves": moves, "leaf_evals": leaves,
+                      "ms_per_move": dt / max(moves, 1) * 1e3}
+    return out
+
+
+def cfg4_leg(args, net, local_rank, rank, world, dist, red_dev):
+    """BASELINE.json config[3] as the driver's N-rank launch runs it: every rank = one GPU = ONE Gumbel self-play shard of
+    `--cfg4-boards` lock-step boards at 400 simulations (selfplay/worker.py via selfplay_shard, the launcher's code path,
+    selfplay_main.py:44-65), no collective in the data path; rank 0 reports the aggregate over the ranks (leaf evaluations
+    of all shards / the slowest shard's time), the per-rank rates and the host cores each rank was pinned to."""
+    import shutil
+    import tempfile
+    from tamago_amd.selfplay.worker import selfplay_shard
+    games = args.cfg4_games
+    first = 1 + rank * games
+    tmp = tempfile.mkdtemp(prefix=f"tg_cfg4_r{rank}_")
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    try:
+        st = selfplay_shard(tmp, net, list(range(first, first + games)), 9, args.cfg4_visits, boards=args.cfg4_boards,
+                            never_resign_flags=[True] * games, device_index=local_rank)
+        torch.cuda.synchronize()
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    dt = time.perf_counter() - t0
+    mine = torch.tensor([st["leaf_evals"], dt, st["games"], st["moves"], len(os.sched_getaffinity(0))],
+                        dtype=torch.float64, device=red_dev)
+    if world > 1:
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+    else:
+        allr = [mine]
+    rows = [[float(v) for v in t.cpu()] for t in allr]
+    total = sum(r[0] for r in rows)
+    slowest = max(r[1] for r in rows)
+    return {"value": total / slowest, "unit": "leaf-evals/s", "shards": world, "boards_per_shard": args.cfg4_boards,
+            "games_per_shard": games, "simulations_per_move": args.cfg4_visits, "seconds": slowest,
+            "games_per_hour": sum(r[2] for r in rows) / slowest * 3600,
+            "per_rank": [{"rank": i, "leaf_evals_per_s": r[0] / r[1], "seconds": r[1], "games": int(r[2]), "moves": int(r[3]),
+                          "host_cores": int(r[4])} for i, r in enumerate(rows)],
+            "workload": f"cfg-4: {world} shard(s) x {args.cfg4_boards} lock-step boards, Gumbel sequential halving, "
+                        f"{args.cfg4_visits} simulations/move, games to completion, SGF records written, one shard per rank / GPU"}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -317,50 +421,95 @@ def main():
             torch.cuda.synchronize()
 
     from tamago_amd.board.go_board import GoBoard
+    import ctypes
     fresh_board = GoBoard(args.size, 7.0, False)
-    for _ in range(args.warmup):
-        run_step(engines, plies_list, fresh_board, args.visits, args.batch)
-    evaluator.record = True
-    barrier()
-    t0 = time.perf_counter()
-    leaves = 0
-    for _ in range(args.steps):
-        leaves += run_step(engines, plies_list, fresh_board, args.visits, args.batch)
-    barrier()
-    elapsed = time.perf_counter() - t0
-
-    # forward-kernel time from the HIP events recorded around every launch
-    kern_ms = 0.0
-    kern_pos = 0
-    big = []
-    for e0, e1, b in evaluator.events:
-        ms = e0.elapsed_time(e1)
-        kern_ms += ms
-        kern_pos += b
-        if b == sizes[0] * args.batch:
-            big.append(ms)
+    full_b = sizes[0] * args.batch
     flops_pos = lib.tg_net_flops_per_position(args.size)
 
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        tot = torch.tensor([leaves], device=red_dev, dtype=torch.float64)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        leaves = float(tot.item())
+    def timed_region(steps, warmup):
+        """W untimed + K timed steps (barrier + synchronise on both sides); returns leaf evaluations, seconds (max over
+        ranks), and the forward launches' HIP-event times (all: ms sum; full-size launches: list)."""
+        evaluator.record = False
+        for _ in range(warmup):
+            run_step(engines, plies_list, fresh_board, args.visits, args.batch)
+        evaluator.events.clear()
+        evaluator.record = True
+        barrier()
+        t0 = time.perf_counter()
+        leaves = 0
+        for _ in range(steps):
+            leaves += run_step(engines, plies_list, fresh_board, args.visits, args.batch)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        evaluator.record = False
+        kern_ms, big = 0.0, []
+        for e0, e1, b in evaluator.events:
+            ms = e0.elapsed_time(e1)
+            kern_ms += ms
+            if b == full_b:
+                big.append(ms)
+        if world > 1:
+            tmax = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+            tot = torch.tensor([leaves], device=red_dev, dtype=torch.float64)
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            leaves = float(tot.item())
+        return leaves, elapsed, kern_ms, big
 
-    if rank == 0:
-        import ctypes
-        full_b = sizes[0] * args.batch
+    def roofline(leaves, elapsed, kern_ms, big):
+        """achieved = ALGORITHMIC FLOPs per launch (72.28 MFLOP per 9x9 position x positions) / the
+        kernel's average launch time (HIP events on the launch stream), against the dense matrix peak of the precision
+        the kernel executes in.  mfma_issue_frac = the FLOPs of the MFMA instructions it issues (operand splitting, tile
+        padding) over the same peak: the issue-slot utilisation of the matrix pipe."""
         avg_ms = float(np.mean(big)) if big else float("nan")
         kname = lib.tg_net_kernel_name(net.handle, full_b).decode()
         peak = ctypes.c_double(0.0)
         dtype_name = ctypes.c_char_p()
         exec_flops = lib.tg_net_executed_flops_per_position(net.handle, full_b, ctypes.byref(peak), ctypes.byref(dtype_name))
-        algorithmic = full_b * flops_pos / (avg_ms * 1e-3) / 1e12 if big else float("nan")
-        executed = full_b * exec_flops / (avg_ms * 1e-3) / 1e12 if big else float("nan")
+        algorithmic = full_b * flops_pos / (avg_ms * 1e-3) / 1e12
+        executed = full_b * exec_flops / (avg_ms * 1e-3) / 1e12
         pmc = pmc_summary(kname) if args.size == 9 else None
         io_bytes = 6 * args.size ** 2 * 4 + (args.size ** 2 + 4) * 4
+        return peak.value, {
+            "bound": "mfma",
+            "kernel": kname,
+            "note": "achieved = algorithmic FLOPs (direct 3x3 convolution count of SURVEY 3.4: 72.28 MFLOP per 9x9 position) "
+                    "per launch / HIP-event launch time; peak = dense matrix peak of the precision the kernel EXECUTES in "
+                    "(f16 pipe: 2 500, fp32 pipe: 157.3 TFLOP/s); frac = achieved / peak.  mfma_issue_* = FLOPs of the MFMA "
+                    "instructions actually issued (three f16 products per fp32 product, tile padding) over the same peak = "
+                    "issue-slot utilisation of the matrix pipe.  The board is power-capped: see power_cap.",
+            "achieved": algorithmic,
+            "peak": peak.value,
+            "unit": "TFLOP/s",
+            "frac": algorithmic / peak.value,
+            "algorithmic_flops_per_position": flops_pos,
+            "algorithmic_over_fp32_matrix_peak": algorithmic / FP32_MFMA_PEAK_TFLOPS,
+            "mfma_issue_tflops": executed,
+            "mfma_issue_frac": executed / peak.value,
+            "executed_dtype": dtype_name.value.decode() if dtype_name.value else "",
+            "executed_flops_per_position": exec_flops,
+            "power_cap": "MI355X throttles the shader clock to its 1.4 kW budget: back-to-back v_mfma_f32_16x16x32_f16 on random "
+                         "data from registers sustain 1 930 TFLOP/s at 1.88 GHz, not 2 500 (profiles/r03_microbench_mfma_power.txt)",
+            "mfma_issue_frac_of_power_capped_rate": executed / 1930.0 if peak.value > 200 else None,
+            "traffic": pmc["derived"]["hbm_bytes_per_position"] * full_b if pmc else None,
+            "traffic_unit": "HBM-side bytes per launch: rocprofv3 PMC FETCH_SIZE x 2 + WRITE_SIZE (separate passes) "
+                            "per position x positions of this launch",
+            "traffic_source": pmc["file"] if pmc else None,
+            "algorithmic_io_bytes": full_b * io_bytes,
+            "mfma_busy_frac_pmc": pmc["derived"]["mfma_busy_fraction_of_simd_cycles"] if pmc else None,
+            "avg_launch_ms": avg_ms,
+            "launches": len(big),
+            "positions_per_launch": full_b,
+            "forward_share_of_step": kern_ms * 1e-3 / elapsed,
+            "end_to_end_frac": leaves / elapsed / world * flops_pos / 1e12 / peak.value,
+        }
+
+    leaves, elapsed, kern_ms, big = timed_region(args.steps, args.warmup)
+
+    result = None
+    if rank == 0:
+        peak_value, roof = roofline(leaves, elapsed, kern_ms, big)
         result = {
             "metric": "MCTS leaf-evals/sec (9x9, batch 256)" if args.size == 9
             else f"MCTS leaf-evals/sec ({args.size}x{args.size}, batch {args.batch})",
@@ -373,7 +522,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if peak.value < 200 else "f32 results from f16 x 2 split operands, fp32 accumulate",
+            "dtype": "f32" if peak_value < 200 else "f32 results from f16 x 2 split operands, fp32 accumulate",
             "data": "synthetic",
             "config": {
                 "workload": f"cfg-2 PUCT {args.size}x{args.size}, random-init DualNet, "
@@ -383,36 +532,41 @@ def main():
                 "leaf_evals_per_step_per_gpu": args.trees * (args.visits + 1),
                 "parallelism": f"{world} x independent board shards (no collective)",
             },
-            "roofline": {
-                "bound": "mfma",
-                "kernel": kname,
-                "note": "achieved / peak / frac = FLOPs of the MFMA instructions the kernel EXECUTES (operand splitting "
-                        "and tile padding included, tg_net_executed_flops_per_position) per launch / HIP-event launch "
-                        "time, against the dense matrix peak of the precision they run in.  algorithmic_tflops = "
-                        "direct-3x3-convolution count of SURVEY 3.4 (72.28 MFLOP/position at 9x9), the fp32-equivalent "
-                        "work delivered; it may exceed the fp32 matrix peak because the products run on the f16 pipe.",
-                "achieved": executed,
-                "peak": peak.value,
-                "unit": "TFLOP/s",
-                "frac": executed / peak.value,
-                "executed_dtype": dtype_name.value.decode() if dtype_name.value else "",
-                "executed_flops_per_position": exec_flops,
-                "algorithmic_tflops": algorithmic,
-                "algorithmic_flops_per_position": flops_pos,
-                "algorithmic_over_fp32_matrix_peak": algorithmic / FP32_MFMA_PEAK_TFLOPS,
-                "traffic": pmc["derived"]["hbm_bytes_per_position"] * full_b if pmc else None,
-                "traffic_unit": "HBM-side bytes per launch: rocprofv3 PMC FETCH_SIZE x 2 + WRITE_SIZE (separate passes) "
-                                "per position x positions of this launch",
-                "traffic_source": pmc["file"] if pmc else None,
-                "algorithmic_io_bytes": full_b * io_bytes,
-                "mfma_busy_frac_pmc": pmc["derived"]["mfma_busy_fraction_of_simd_cycles"] if pmc else None,
-                "avg_launch_ms": avg_ms,
-                "launches": len(big),
-                "positions_per_launch": full_b,
-                "forward_share_of_step": kern_ms * 1e-3 / elapsed,
-                "end_to_end_frac": leaves / elapsed / world * exec_flops / 1e12 / peak.value,
-            },
+            "roofline": roof,
+            "tree_kernels": tree_pmc_summary() if args.size == 9 else None,
         }
+    # ---- exact-fp32 arithmetic on the same workload (N = 1): the Winograd fp32-MFMA kernel ----
+    if world == 1 and not args.no_legs and args.size == 9:
+        saved = os.environ.get("TG_FWD_ALGO")
+        os.environ["TG_FWD_ALGO"] = "wino"
+        try:
+            l2, e2, k2, b2 = timed_region(2, 1)
+            _, roof2 = roofline(l2, e2, k2, b2)
+            result["fp32_exact"] = {"value": l2 / e2, "unit": "leaf-evals/s", "dtype": "f32", "steps": 2, "warmup": 1,
+                                    "ms_per_step": e2 / 2 * 1e3, "workload": result["config"]["workload"] +
+                                    f", {args.trees} trees, TG_FWD_ALGO=wino (exact fp32 operands on the fp32 MFMA)",
+                                    "roofline": roof2}
+        except Exception as exc:                          # the headline must not depend on a leg
+            result["fp32_exact"] = {"error": repr(exc)}
+        finally:
+            if saved is None:
+                os.environ.pop("TG_FWD_ALGO", None)
+            else:
+                os.environ["TG_FWD_ALGO"] = saved
+    # ---- BASELINE.json config[3]: one Gumbel self-play shard per rank (N > 1: what the driver's scaling run adds) ----
+    if world > 1 and not args.no_legs and args.size == 9:
+        for eng, _ in engines:
+            eng.close()
+        engines = []
+        try:
+            leg = cfg4_leg(args, net, local_rank, rank, world, dist, red_dev)
+        except Exception as exc:
+            # every rank must reach the collectives below whatever happened here
+            leg = {"error": repr(exc)}
+            sys.stderr.write(f"bench.py rank {rank}: cfg-4 leg failed: {exc!r}\n")
+        if rank == 0:
+            result["cfg4_selfplay_shards"] = leg
+    if rank == 0:
         if world == 1 and not args.no_legs and args.size == 9:
             for eng, _ in engines:
                 eng.close()
@@ -423,6 +577,11 @@ def main():
                 result["cpu_baseline"] = cpu_baseline(args.size, args.visits, args.batch, args.cpu_seconds)
             except Exception as exc:                          # a broken baseline leg must not lose the measured line
                 result["cpu_baseline"] = {"error": repr(exc)}
+            if not args.no_legs and args.size == 9:
+                try:
+                    result["cfg1_cpu"] = cfg1_cpu(8.0)
+                except Exception as exc:
+                    result["cfg1_cpu"] = {"error": repr(exc)}
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

@@ -2559,18 +2559,28 @@ void parallel_trees(int n, F &&fn) {
 }  // namespace
 
 namespace {
-// Re-allocate one [T][n_old * per_node] pool array as [T][n_new * per_node], keeping every tree's rows.
-template <typename T>
-int grow_array(tg_search *s, T **field, size_t trees, size_t n_old, size_t n_new, size_t per_node) {
-    void *p = nullptr;
-    TG_HIP(hipMalloc(&p, trees * n_new * per_node * sizeof(T)));
-    TG_HIP(hipMemset(p, 0, trees * n_new * per_node * sizeof(T)));
-    TG_HIP(hipMemcpy2D(p, n_new * per_node * sizeof(T), *field, n_old * per_node * sizeof(T),
-                       n_old * per_node * sizeof(T), trees, hipMemcpyDeviceToDevice));
-    for (void *&a : s->allocs)
-        if (a == static_cast<void *>(*field)) a = p;
-    (void)hipFree(*field);
-    *field = static_cast<T *>(p);
+// One pool array [T][n_old * per_node] to be re-allocated as [T][n_new * per_node], keeping every tree's rows.  The
+// growth is transactional: every new array is allocated and filled FIRST; only when all of that has
+// succeeded are the pointers swapped and the old arrays freed - a failing hipMalloc (old and new pools are resident
+// together: up to 2 x 13 GB at the 4 M-node cap) leaves the handle exactly as it was.
+struct GrowItem {
+    void **field;          // address of the SearchDev pointer
+    size_t elem;           // bytes per element
+    size_t per_node;       // elements per node
+    void *fresh = nullptr;
+};
+
+int grow_fill(const GrowItem &g, size_t trees, size_t n_old, size_t n_new) {
+    const size_t row_old = n_old * g.per_node * g.elem, row_new = n_new * g.per_node * g.elem;
+    TG_HIP(hipMemset(g.fresh, 0, trees * row_new));
+    if (row_old < ((size_t)1 << 30)) {
+        TG_HIP(hipMemcpy2D(g.fresh, row_new, *g.field, row_old, row_old, trees, hipMemcpyDeviceToDevice));
+    } else {
+        // rows beyond 1 GB (millions of nodes per tree): one linear copy per tree, no 2D pitch limits involved
+        for (size_t t = 0; t < trees; ++t)
+            TG_HIP(hipMemcpy(static_cast<char *>(g.fresh) + t * row_new, static_cast<const char *>(*g.field) + t * row_old,
+                             row_old, hipMemcpyDeviceToDevice));
+    }
     return TG_OK;
 }
 }  // namespace
@@ -2667,14 +2677,39 @@ int tg_search_grow(tg_search *s, int new_tree_size) {
     TG_HIP(hipSetDevice(s->cfg.device));
     TG_HIP(hipDeviceSynchronize());           // nothing may still be running on the old arrays
     const size_t T = D.T, n0 = D.N, n1 = (size_t)new_tree_size, A = s->A;
-    int rc = TG_OK;
-#define GROW(field, per) if ((rc = grow_array(s, &D.field, T, n0, n1, (per)))) return rc;
+    std::vector<GrowItem> items;
+#define GROW(field, per) items.push_back(GrowItem{reinterpret_cast<void **>(&D.field), sizeof(*D.field), (size_t)(per)});
     GROW(ch_index, A) GROW(ch_visits, A) GROW(ch_vl, A) GROW(ch_vsum, A) GROW(ch_policy, A) GROW(ch_value, A)
     GROW(action, A)
     GROW(n_children, 1) GROW(n_visits, 1) GROW(n_vl, 1) GROW(n_parent, 1) GROW(n_pedge, 1) GROW(n_vsum, 1)
     GROW(n_raw, 1)
 #undef GROW
-    TG_HIP(hipDeviceSynchronize());
+    // phase 1: every new array allocated and filled; on any failure the new arrays are released and nothing changed
+    int rc = TG_OK;
+    for (GrowItem &g : items) {
+        const hipError_t e = hipMalloc(&g.fresh, T * n1 * g.per_node * g.elem);
+        if (e != hipSuccess) {
+            g.fresh = nullptr;
+            rc = tg::fail(TG_ERR_HIP, "tg_search_grow: %s allocating %zu bytes - the pool keeps its %zu nodes per tree",
+                          hipGetErrorString(e), T * n1 * g.per_node * g.elem, n0);
+            break;
+        }
+        if ((rc = grow_fill(g, T, n0, n1))) break;
+    }
+    if (rc == TG_OK && hipDeviceSynchronize() != hipSuccess) rc = tg::fail(TG_ERR_HIP, "tg_search_grow: copy failed");
+    if (rc != TG_OK) {
+        for (GrowItem &g : items)
+            if (g.fresh) (void)hipFree(g.fresh);
+        (void)hipGetLastError();
+        return rc;
+    }
+    // phase 2: swap (cannot fail)
+    for (GrowItem &g : items) {
+        for (void *&a : s->allocs)
+            if (a == *g.field) a = g.fresh;
+        (void)hipFree(*g.field);
+        *g.field = g.fresh;
+    }
     D.N = new_tree_size;
     s->cfg.tree_size = new_tree_size;
     return TG_OK;

@@ -861,6 +861,7 @@ int tg_trainer_destroy(tg_trainer *t) {
 int tg_trainer_step(tg_trainer *t, const float *planes_dev, const float *policy_dev, const long long *value_dev,
                     int sl_mode, float value_weight, float lr, void *stream) {
     if (!t || !planes_dev || !policy_dev || !value_dev) return tg::fail(TG_ERR_ARG, "tg_trainer_step: null argument");
+    TG_HIP(hipSetDevice(t->device));          // the launches below belong to the trainer's device whatever the caller's is
     hipStream_t st = static_cast<hipStream_t>(stream);
     TrainDev &D = t->dev;
     const int grid = D.NWG;

@@ -274,6 +274,8 @@ class HipTrainer:
         self._lib_mod = _lib
         self.lib = _lib.load()
         self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", 0)           # (tg_trainer_create below uses index 0 as well)
         self.board_size = board_size
         self.batch_size = batch_size
         self.keys = state_dict_keys(board_size)
@@ -305,14 +307,19 @@ class HipTrainer:
              lr: float = RL_LEARNING_RATE):
         """Enqueue one mini-batch on the current stream (device tensors, batch = batch_size)."""
         assert plane.is_cuda and plane.shape == (self.batch_size, 6, self.board_size, self.board_size)
+        if plane.device != self.device or policy.device != self.device or value.device != self.device:
+            raise ValueError(f"HipTrainer on {self.device}: step() got tensors on {plane.device} / {policy.device} / {value.device}")
         plane = plane.contiguous().float()
         policy = policy.contiguous().float()
         value = value.contiguous().long()
         weight = RL_VALUE_WEIGHT if mode == "rl" else SL_VALUE_WEIGHT
-        stream = torch.cuda.current_stream(self.device).cuda_stream
-        self._lib_mod.check(self.lib.tg_trainer_step(self.handle, plane.data_ptr(), policy.data_ptr(), value.data_ptr(),
-                                                     int(mode != "rl"), float(weight), float(lr), stream),
-                            "tg_trainer_step")
+        # the trainer's own device is made current for the launch (a caller on cuda:0 driving a trainer on cuda:1 would
+        # otherwise enqueue onto the wrong device's stream)
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            self._lib_mod.check(self.lib.tg_trainer_step(self.handle, plane.data_ptr(), policy.data_ptr(), value.data_ptr(),
+                                                         int(mode != "rl"), float(weight), float(lr), stream),
+                                "tg_trainer_step")
         self._keep = (plane, policy, value)
         self.steps += 1
         self.batches_tracked += 1
@@ -420,6 +427,9 @@ def train_with_gumbel_alphazero_on_gpu(program_dir: str, board_size: int, batch_
     backend = os.environ.get("TG_TRAIN_BACKEND", "hip" if board_size == 9 else "autograd")
     if os.environ.get("TG_TRAIN_EAGER", "0") == "1":
         backend = "eager"
+    if backend not in ("hip", "autograd", "eager"):
+        # (a typo used to fall through to the eager loop silently)
+        raise ValueError(f"TG_TRAIN_BACKEND={backend!r}: expected 'hip', 'autograd' or 'eager'")
     graphed = hip = None
     if backend == "hip":
         hip = HipTrainer(device, board_size, batch_size, net.state_dict())

@@ -78,7 +78,10 @@ def run_shard(args, rank: int, world: int, local_rank: int, record_dir: str) -> 
     import torch
     from tamago_amd.nn.utility import load_network
     from tamago_amd.selfplay.worker import selfplay_shard, shard_indices
-    device_index = 0 if os.environ.get("TG_SINGLE_DEVICE") else local_rank
+    n_dev = max(1, torch.cuda.device_count())
+    # more worker processes than GPUs (the reference's --process N puts N workers on ONE device, nn/utility.py:22):
+    # the shards share the devices round-robin
+    device_index = 0 if os.environ.get("TG_SINGLE_DEVICE") else local_rank % n_dev
     cores = pin_host_threads(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     torch.cuda.set_device(device_index)
     network = load_network(model_file_path=args.model, use_gpu=args.use_gpu, board_size=args.size,
@@ -141,28 +144,47 @@ def main(argv=None) -> dict:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if world > 1:
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        # Every rank reaches every collective whatever happens to it: a failure (record directory, shard) travels as an
+        # {"error": ...} object, so that no rank is left waiting in a gloo collective and partial results are reported.
         box = [None]
         if rank == 0:
-            n = args.resume_dir or next_record_dir(args.save_dir)
-            os.makedirs(os.path.join(args.save_dir, str(n)), exist_ok=True)
-            print(f"Self play visits : {args.visits}")
-            box = [n]
+            try:
+                n = args.resume_dir or next_record_dir(args.save_dir)
+                os.makedirs(os.path.join(args.save_dir, str(n)), exist_ok=True)
+                box = [n]
+            except Exception as exc:
+                box = [{"error": f"record directory: {exc!r}"}]
         if world > 1:
             dist.broadcast_object_list(box, src=0)
+        if isinstance(box[0], dict):
+            if world > 1:
+                dist.destroy_process_group()
+            raise SystemExit(f"self-play launcher: {box[0]['error']}")
+        if rank == 0:
+            print(f"Self play visits : {args.visits}")
         record_dir = os.path.join(args.save_dir, str(box[0]))
         t0 = time.perf_counter()
-        mine = run_shard(args, rank, world, local_rank, record_dir)
+        try:
+            mine = run_shard(args, rank, world, local_rank, record_dir)
+        except BaseException as exc:
+            mine = {"error": repr(exc), "rank": rank}
         gathered = [mine]
         if world > 1:
             gathered = [None] * world
             dist.all_gather_object(gathered, mine)
-        elapsed = max(time.perf_counter() - t0, max(s["seconds"] for s in gathered))
-        result = aggregate(gathered, elapsed, args.visits, args.boards)
-        if rank == 0:
-            report(result, args.json)
+        failed = [s for s in gathered if "error" in s]
+        good = [s for s in gathered if "error" not in s]
+        result = None
+        if good:
+            elapsed = max(time.perf_counter() - t0, max(s["seconds"] for s in good))
+            result = aggregate(good, elapsed, args.visits, args.boards)
+            if rank == 0:
+                report(result, args.json)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
+        if failed:
+            raise SystemExit(f"self-play shard(s) failed: {failed}")
         return result
 
     # stand-alone: this process is the launcher (selfplay_main.py:56-66), one child per GPU

@@ -102,3 +102,35 @@ def test_selfplay_launcher_two_ranks_gloo(tmp_path):
     r0 = (save / "4" / "rank0.txt").read_text().split()
     r1 = (save / "4" / "rank1.txt").read_text().split()
     assert [int(g) for g in r0 + r1] == list(range(1, 12))
+
+
+FAILING = r'''
+import os, sys
+sys.path.insert(0, os.environ["TG_REPO"])
+from tamago_amd.selfplay import main as launcher
+
+def fake_shard(args, rank, world, local_rank, record_dir):
+    if rank == 1:
+        raise RuntimeError("GPU fell off the bus")
+    return {"games": 3, "moves": 30, "leaf_evals": 401 * 30, "seconds": 0.25, "rank": rank, "device": local_rank,
+            "host_cores": 1, "first": 1, "last": 3}
+
+launcher.run_shard = fake_shard
+launcher.main(["--save-dir", os.environ["TG_SAVE"], "--num-data", "6", "--visits", "400", "--boards", "4", "--json"])
+'''
+
+
+def test_launcher_rank_failure_reaches_every_rank(tmp_path):
+    """A shard that raises must not strand the other ranks in a collective (ADVICE round 2): its error travels through
+    the all-gather, the surviving shards are still reported, every rank exits non-zero."""
+    script = tmp_path / "failing.py"
+    script.write_text(FAILING)
+    save = tmp_path / "archive"
+    save.mkdir()
+    env = dict(os.environ, TG_REPO=REPO, TG_SAVE=str(save), MASTER_ADDR="127.0.0.1", MASTER_PORT="29575")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29575", str(script)],
+                         env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0
+    assert "GPU fell off the bus" in out.stderr + out.stdout
+    assert "shard 0" in out.stdout and "games/hour" in out.stdout          # the surviving shard's report

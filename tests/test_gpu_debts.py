@@ -140,6 +140,54 @@ def test_pool_grows_in_place_like_the_reference(capsys):
     assert np.array_equal(pond.get_root().children_visits, same.get_root().children_visits)
 
 
+def test_multi_tree_pool_growth_is_transactional_and_keeps_every_tree():
+    """tg_search_grow on a 6-tree engine: every tree's rows survive the re-strided copy - a digest over
+    root statistics and sampled nodes of all trees equals that of an engine created at the final size -, and a growth
+    whose allocation fails (absurd size) returns an error and leaves the handle exactly as it was."""
+    import hashlib
+    import torch
+    from oracle.stubnet import StubNet
+    from tamago_amd import lib as tl
+    from tamago_amd.board.go_board import GoBoard
+    from tamago_amd.mcts.engine import SearchEngine, HostEvaluator
+
+    def run(tree_size, grow_to=None, fail=False):
+        eng = SearchEngine(9, 6, tree_size, 8, HostEvaluator(StubNet(5), torch.device("cuda:0")), check_superko=True)
+        for t in range(6):
+            b = GoBoard(9, 7.0, True)
+            for k in range(t):
+                b.put_stone(b.onboard_pos[10 * k + t], 1 + k % 2)
+            eng.set_root(t, b, 1 + t % 2, np.random.RandomState(40 + t).get_state())
+        eng.root_eval(False)
+        for i in range(6):
+            if grow_to and i == 3:
+                if fail:
+                    rc = eng.lib.tg_search_grow(eng.handle, 1 << 30)          # ~ 6 x 2^30 x 3 KB: cannot be allocated
+                    assert rc != 0 and b"tg_search_grow" in eng.lib.tg_last_error()
+                tl.check(eng.lib.tg_search_grow(eng.handle, grow_to), "tg_search_grow")
+                eng.N = grow_to
+            eng.puct_batch(8)
+        h = hashlib.sha256()
+        st = eng.read_root_stats()
+        for k in sorted(st):
+            h.update(np.ascontiguousarray(st[k]).tobytes())
+        nn = eng.num_nodes()
+        h.update(nn.tobytes())
+        for t in range(6):
+            for node in range(0, int(nn[t]), 5):
+                nd = eng.read_node(t, node)
+                n = nd.num_children
+                for arr in (nd.children_index[:n], nd.children_visits[:n], nd.children_value_sum[:n], nd.children_policy[:n]):
+                    h.update(np.ascontiguousarray(arr).tobytes())
+        eng.close()
+        return h.hexdigest(), int(nn.sum())
+
+    want = run(128)
+    assert want[1] > 6 * 40
+    assert run(32, grow_to=128) == want                       # (24 nodes per tree in use when the pool grows)
+    assert run(32, grow_to=128, fail=True) == want
+
+
 def test_batch_queue_is_the_device_leaf_queue():
     """mcts/batch_data.py:7-34: between selection and process_mini_batch the queue holds the
     leaves' planes, root-first paths and node indices - the same entries the oracle's queue holds -

@@ -125,12 +125,14 @@ def test_eight_shards_share_one_gpu_without_collisions(tmp_path):
 def test_bench_two_ranks_on_one_gpu():
     """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, one rank per GPU), with both
     ranks on cuda:0 (TG_SINGLE_DEVICE) and gloo for the barrier / reductions (RCCL cannot put two ranks on one
-    device): ONE JSON line from rank 0, whole-job aggregate over both ranks, weak scaling, max-over-ranks time."""
+    device): ONE JSON line from rank 0, whole-job aggregate over both ranks, weak scaling, max-over-ranks time;
+    the cfg-4 leg (shrunk: 4 boards x 32 simulations) runs one self-play shard per rank."""
     env = dict(os.environ, TG_SINGLE_DEVICE="1", TG_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT="29583",
                PYTHONPATH=REPO + os.pathsep + os.environ.get("PYTHONPATH", ""))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
            "127.0.0.1", "--master-port", "29583", os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1",
-           "--warmup", "1", "--trees", "64", "--no-cpu-baseline", "--no-legs"]
+           "--warmup", "1", "--trees", "64", "--no-cpu-baseline", "--cfg4-boards", "4", "--cfg4-games", "6",
+           "--cfg4-visits", "32"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=REPO)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -140,4 +142,12 @@ def test_bench_two_ranks_on_one_gpu():
     assert res["metric"].startswith("MCTS leaf-evals") and res["unit"] == "leaf-evals/s"
     # two ranks x 64 trees x 1001 leaf evaluations in the timed step
     assert abs(res["value"] * res["ms_per_step"] / 1e3 - 2 * 64 * 1001) < 1.0
-    assert 0.0 < res["roofline"]["frac"] <= 1.0 and res["roofline"]["bound"] == "mfma"
+    roof = res["roofline"]
+    assert roof["bound"] == "mfma" and 0.0 < roof["frac"] < roof["mfma_issue_frac"] <= 1.0
+    # frac = algorithmic FLOPs per launch / launch time / peak of the executed precision
+    assert abs(roof["frac"] - roof["positions_per_launch"] * 2 * 36140823 / (roof["avg_launch_ms"] * 1e-3) / 1e12 / roof["peak"]) < 1e-9
+    # BASELINE.json config[3] rides on the N > 1 launch: one Gumbel self-play shard per rank, aggregate on rank 0
+    leg = res["cfg4_selfplay_shards"]
+    assert leg["shards"] == 2 and [r["rank"] for r in leg["per_rank"]] == [0, 1]
+    assert all(r["games"] == 6 and r["host_cores"] >= 1 for r in leg["per_rank"])
+    assert abs(leg["value"] * leg["seconds"] - sum(r["moves"] for r in leg["per_rank"]) * 33) < 1.0
