@@ -298,6 +298,10 @@ def cfg1_cpu(budget_s):
     from tamago_amd.nn.network.dual_net import random_state_dict
     torch.manual_seed(0)
     net = OracleNet(random_state_dict(9))
+    # batch-1 convolutions do not scale over a big host's cores (128 torch threads: 30 leaf-evals/s on the GPU box, 8
+    # threads: the survey container's 150-200): the leg runs at 8 torch threads and says so
+    all_threads = torch.get_num_threads()
+    torch.set_num_threads(min(8, all_threads))
     out = {"kind": "port", "cores": torch.get_num_threads(),
            "workload": "cfg-1: 9x9, 100 visits/move, NN batch 1, CPU oracle (Python tree, 1 thread + PyTorch-CPU DualNet)"}
     for label, mode in (("strict", OTC.STRICT_PLAYOUT), ("constant", OTC.CONSTANT_PLAYOUT)):
@@ -318,6 +322,7 @@ def cfg1_cpu(budget_s):
         dt = time.time() - t0
         out[label] = {"value": leaves / dt, "unit": "leaf-evals/s", "moves": moves, "leaf_evals": leaves,
                       "ms_per_move": dt / max(moves, 1) * 1e3}
+    torch.set_num_threads(all_threads)
     return out
 
 
