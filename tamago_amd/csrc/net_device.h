@@ -46,6 +46,14 @@ struct NetDev {
     const unsigned char *ww2;
     const float *w2_init;
     const float *w2_down;
+    // head phase on the 16-bit matrix pipe (split_common.h run_heads_mfma): the three 1x1-convolution channels
+    // (policy 0, policy 1, value; batch norm folded) as A fragments [k-chunk 2][piece 2][lane 64][8 x f16], their
+    // accumulator start values [16] + 2^-e at [16]; the policy FC as A fragments
+    // [column tile 6][k-step 6][piece 2][lane 64][8 x f16] (K = 2P padded to 192), 2^-e at pfc_tab[0]
+    const unsigned char *hd1_img;
+    const float *hd1_tab;
+    const unsigned char *pfc_img;
+    const float *pfc_tab;
     int *overflow;                    // f16 range guard: set when a layer output leaves the f16 range
     float *scratch;       // 19x19 Winograd: per workgroup two [P][64] activation images (L2-resident)
     long long *timeline;  // optional [128] s_memtime stamps of workgroup 0 (tg_net_profile_phases)

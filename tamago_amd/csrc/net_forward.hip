@@ -29,6 +29,7 @@ namespace tg {
 int split_prepare(tg_net *net, const float *conv0, const float *const *tower, const float *scale);
 int split_forward(tg_net *net, int group, const float *planes, int batch, int want_logits, float *policy,
                   float *value, int *overflow, hipStream_t stream);
+int heads_prepare(tg_net *net, const float *hp_w, const float *hv_w, const float *head_ss, const float *pfc_w, int P);
 int w2_prepare(tg_net *net, const float *conv0, const float *const *tower, const float *scale, const float *shift);
 int w2_forward(tg_net *net, const float *planes, int batch, int want_logits, float *policy, float *value,
                 int *overflow, hipStream_t stream);
@@ -749,11 +750,9 @@ int tg_net_create(int board_size, int device, const float *params, size_t n_para
     }
     // (padded to whole 4 KB: the split-operand kernel copies it into LDS in 1 KB pieces)
     std::vector<float> pfc_wT((((size_t)2 * P * A * 4 + 4095) / 4096) * 1024, 0.f);
-    {
-        const float *w = rd.take((size_t)A * 2 * P);
-        for (int a = 0; a < A; ++a)
-            for (int j = 0; j < 2 * P; ++j) pfc_wT[(size_t)j * A + a] = w[(size_t)a * 2 * P + j];
-    }
+    const float *pfc_raw = rd.take((size_t)A * 2 * P);      // [A][2P] as the state_dict holds it
+    for (int a = 0; a < A; ++a)
+        for (int j = 0; j < 2 * P; ++j) pfc_wT[(size_t)j * A + a] = pfc_raw[(size_t)a * 2 * P + j];
     std::vector<float> pfc_b = rd.vec(A);
     std::vector<float> hv_w = rd.vec(64);
     fold_bn(rd, 1, 2e-5, &head_ss[4], &head_ss[5]);
@@ -777,7 +776,8 @@ int tg_net_create(int board_size, int device, const float *params, size_t n_para
         tg_net_destroy(net);
         return rc;
     }
-    if ((rc = tg::split_prepare(net, conv0_raw, tower_raw, scale.data())) ||
+    if ((board_size == 9 && (rc = tg::heads_prepare(net, hp_w.data(), hv_w.data(), head_ss.data(), pfc_raw, P))) ||
+        (rc = tg::split_prepare(net, conv0_raw, tower_raw, scale.data())) ||
         (board_size == 9 && (rc = tg::w2_prepare(net, conv0_raw, tower_raw, scale.data(), shift.data())))) {
         tg_net_destroy(net);
         return rc;

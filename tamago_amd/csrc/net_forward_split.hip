@@ -76,6 +76,7 @@ struct SplitCfg {
     static constexpr int RES_LDS_TILES = BIG ? 2 : 0;
     static constexpr int RES_BYTES = BIG ? NW * RES_LDS_TILES * 16 * 256 : ((M + 1) * 256 > FC_BYTES ? (M + 1) * 256 : FC_BYTES);
     static constexpr int RES_ROWS = M + 2;                        // rows of the global residual image (BIG)
+    static constexpr int HQ_OFF = RES_OFF;                       // head phase (9x9): policy features as f16 pairs (12 KB)
     static constexpr int SS_OFF = RES_OFF + RES_BYTES;           // folded BN scale [13][64] + shift [13][64]
     // head tables, staged once per workgroup: 1x1 weights [64][4] (policy 0, policy 1, value, 0), policy FC bias [A]
     // (padded), BN scale / shift of the three head channels [8].  (In the heads every use of a kernel-argument
@@ -84,7 +85,8 @@ struct SplitCfg {
     static constexpr int HB_OFF = HW_OFF + 64 * 4 * 4;
     static constexpr int HS_OFF = HB_OFF + ((A + 3) & ~3) * 4;
     static constexpr int VW_OFF = HS_OFF + 8 * 4;                 // value FC weights [3][P] + bias [3]
-    static constexpr int PIPE_BYTES = VW_OFF + ((3 * P + 3 + 3) & ~3) * 4;
+    static constexpr int HD1_OFF = (VW_OFF + ((3 * P + 3 + 3) & ~3) * 4 + 15) & ~15;   // 9x9: 1x1 fragment image 4 KB + table
+    static constexpr int PIPE_BYTES = HD1_OFF + (BIG ? 0 : 4096 + 128);
     // head phase (after the last layer): fp32 activations [M][72 floats] from offset 0, scratch behind the BN table
     static constexpr int ROW_BYTES = kRowBytes;
     static constexpr int AUX = PIPE_BYTES;
@@ -140,6 +142,7 @@ __global__ __launch_bounds__((SplitCfg<S, G, F>::NTHR), 1) void dualnet_fwd_spli
     if (tid < 6) reinterpret_cast<float *>(smem + C::HS_OFF)[tid] = net.head_ss[tid];
     for (int e = tid; e < 3 * P + 3; e += NTHR)
         reinterpret_cast<float *>(smem + C::VW_OFF)[e] = e < 3 * P ? net.vfc_w[e] : net.vfc_b[e - 3 * P];
+    if constexpr (!C::BIG) stage_head_tables<C, NTHR>(smem, net, tid);
     // weight stream: k-chunk gc = 2 * tap + kc of the whole network lies at wsplit + gc * CHUNK; a chunk's eight
     // fragments are at lane * 16 + (piece * 4 + ct) * 1024 (two lane offsets cover the 4 KB offset field)
     const int wv0 = lane * 16;
@@ -418,7 +421,10 @@ __global__ __launch_bounds__((SplitCfg<S, G, F>::NTHR), 1) void dualnet_fwd_spli
             };
             using T = std::true_type;
             using N = std::false_type;
-            if (layer == kTowerLayers) epilogue(N{}, T{}, T{});
+            if (layer == kTowerLayers) {
+                if constexpr (C::BIG) epilogue(N{}, T{}, T{});          // 19x19: fp32 image for the generic head code
+                else epilogue(N{}, T{}, N{});                           // 9x9: the heads read the activation images
+            }
             else if (layer == 0) epilogue(T{}, N{}, N{});
             else if (layer & 1) epilogue(N{}, N{}, N{});
             else epilogue(T{}, T{}, N{});
@@ -429,8 +435,12 @@ __global__ __launch_bounds__((SplitCfg<S, G, F>::NTHR), 1) void dualnet_fwd_spli
         // next group's input planes: HBM latency, and vmcnt retires in order - requested here, where the only
         // wait behind them is the heads' own (the FC weight copy), not one of the tower's weight fragments
         fetch_planes(grp + gridDim.x);
-        run_heads_split<S, G, C, NTHR>(smem, net, b0, batch, want_logits, policy, value, tid, wave,
-                                       (net.timeline && blockIdx.x == 0 && grp == blockIdx.x) ? net.timeline + 40 : nullptr);
+        if constexpr (C::BIG)
+            run_heads_split<S, G, C, NTHR>(smem, net, b0, batch, want_logits, policy, value, tid, wave,
+                                           (net.timeline && blockIdx.x == 0 && grp == blockIdx.x) ? net.timeline + 40 : nullptr);
+        else
+            run_heads_mfma<S, G, C, NTHR>(smem, net, b0, batch, want_logits, policy, value, tid, wave,
+                                          (net.timeline && blockIdx.x == 0 && grp == blockIdx.x) ? net.timeline + 40 : nullptr);
         __syncthreads();
         stamp();
         // the head scratch overlapped the activation images' zero rows
@@ -532,6 +542,81 @@ int split_prepare(tg_net *net, const float *conv0, const float *const *tower, co
         TG_HIP(hipMemcpy(ds, sscale.data(), sscale.size() * 4, hipMemcpyHostToDevice));
         net->dev.sscale = static_cast<const float *>(ds);
     }
+    return TG_OK;
+}
+
+// Head phase on the 16-bit matrix pipe (9x9): fragment images of the 1x1 convolutions (batch norm folded: scale into
+// the weights in fp64, shift -> accumulator start) and of the policy FC, both as f16 x 2 pieces with a power-of-two
+// scaling per image.  hp_w [2][64], hv_w [64], head_ss = (scale0, shift0, scale1, shift1, value scale, value shift),
+// pfc_w [A][2P].
+int heads_prepare(tg_net *net, const float *hp_w, const float *hv_w, const float *head_ss, const float *pfc_w, int P) {
+    const int A = P + 1, K = 2 * P;
+    auto scale_exp = [](double mx) {
+        int e = 0;
+        if (mx > 0.0 && std::isfinite(mx)) {
+            int ex;
+            std::frexp(mx, &ex);
+            e = 10 - ex;
+        }
+        return e > 40 ? 40 : (e < -40 ? -40 : e);
+    };
+    auto put = [](std::vector<uint16_t> &img, size_t base, double v) {       // two pieces of v at img[base], img[base + 512]
+        const uint16_t h = f32_to_f16_rn((float)v);
+        img[base] = h;
+        img[base + 512] = f32_to_f16_rn((float)((v - (double)f16_to_f32(h)) * 2048.0));
+    };
+    // ---- 1x1 convolutions: channel 0 / 1 = policy, 2 = value, 3..15 = 0 ----
+    auto w1 = [&](int ch, int k) -> double {
+        if (ch == 0) return (double)hp_w[k] * head_ss[0];
+        if (ch == 1) return (double)hp_w[64 + k] * head_ss[2];
+        if (ch == 2) return (double)hv_w[k] * head_ss[4];
+        return 0.0;
+    };
+    double mx = 0.0;
+    for (int ch = 0; ch < 3; ++ch)
+        for (int k = 0; k < 64; ++k) mx = std::fmax(mx, std::fabs(w1(ch, k)));
+    const int e1 = scale_exp(mx);
+    std::vector<uint16_t> img1((size_t)2 * 2 * 512, 0);      // [kc][piece][lane][8]
+    for (int kc = 0; kc < 2; ++kc)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int el = 0; el < 8; ++el)
+                put(img1, ((size_t)kc * 2) * 512 + lane * 8 + el, w1(lane & 15, kc * 32 + (lane >> 4) * 8 + el) * std::ldexp(1.0, e1));
+    std::vector<float> tab1(20, 0.f);
+    tab1[0] = (float)((double)head_ss[1] * std::ldexp(1.0, e1));
+    tab1[1] = (float)((double)head_ss[3] * std::ldexp(1.0, e1));
+    tab1[2] = (float)((double)head_ss[5] * std::ldexp(1.0, e1));
+    tab1[16] = std::ldexp(1.f, -e1);
+    // ---- policy FC: logits[a] = sum_k W[a][k] h[k] + bias[a], k = channel * P + position ----
+    constexpr int NT = 6, KS = 6;
+    if (A > NT * 16 || K > KS * 32) return tg::fail(TG_ERR_ARG, "heads_prepare: board too large for the fragment image");
+    mx = 0.0;
+    for (size_t i = 0; i < (size_t)A * K; ++i) mx = std::fmax(mx, std::fabs((double)pfc_w[i]));
+    const int e2 = scale_exp(mx);
+    std::vector<uint16_t> img2((size_t)NT * KS * 2 * 512, 0);  // [nt][ks][piece][lane][8]
+    for (int nt = 0; nt < NT; ++nt)
+        for (int ks = 0; ks < KS; ++ks)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int el = 0; el < 8; ++el) {
+                    const int a = nt * 16 + (lane & 15), k = ks * 32 + (lane >> 4) * 8 + el;
+                    const double v = (a < A && k < K) ? (double)pfc_w[(size_t)a * K + k] * std::ldexp(1.0, e2) : 0.0;
+                    put(img2, ((size_t)(nt * KS + ks) * 2) * 512 + lane * 8 + el, v);
+                }
+    std::vector<float> tab2(4, 0.f);
+    tab2[0] = std::ldexp(1.f, -e2);
+    auto up = [&](const void *src, size_t bytes, const void **dst) {
+        void *d = nullptr;
+        TG_HIP(hipMalloc(&d, bytes));
+        net->allocs.push_back(d);
+        TG_HIP(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
+        *dst = d;
+        return (int)TG_OK;
+    };
+    int rc;
+    if ((rc = up(img1.data(), img1.size() * 2, reinterpret_cast<const void **>(&net->dev.hd1_img))) ||
+        (rc = up(tab1.data(), tab1.size() * 4, reinterpret_cast<const void **>(&net->dev.hd1_tab))) ||
+        (rc = up(img2.data(), img2.size() * 2, reinterpret_cast<const void **>(&net->dev.pfc_img))) ||
+        (rc = up(tab2.data(), tab2.size() * 4, reinterpret_cast<const void **>(&net->dev.pfc_tab))))
+        return rc;
     return TG_OK;
 }
 

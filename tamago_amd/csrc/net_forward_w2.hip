@@ -51,18 +51,17 @@ struct W2Cfg {
     static constexpr int IMG = ZOFF + 256;                        // (a multiple of 256: every image sees the same banks)
     static constexpr int ACT_BYTES = 4 * IMG;                     // image index = piece * 2 + kc
     static constexpr int CHUNK = 8192;                            // weights per k-chunk: [chh 2][piece 2][ct 2][lane][16 B]
-    static constexpr int STAGE = (ACT_BYTES + 255) & ~255;        // input planes [G][6][P] fp32
-    static constexpr int STAGE_END = STAGE + ((G * 6 * P * 4 + 255) & ~255);
-    static constexpr int HEAD_IMG = ((M + 1) * kRowBytes + 255) & ~255;     // fp32 image of the last layer (heads)
-    static constexpr int RES_OFF = STAGE_END > HEAD_IMG ? STAGE_END : HEAD_IMG;
-    static constexpr int FC_BYTES = ((2 * P * A * 4 + 4095) / 4096) * 4096;
-    static constexpr int RES_BYTES = (M + 1) * 256 > FC_BYTES ? (M + 1) * 256 : FC_BYTES;
+    // the residual region serves three masters in turn: the input planes [G][6][P] fp32 while a group is staged, the
+    // residual image during the tower, the policy features of the head phase (HQ)
+    static constexpr int RES_OFF = (ACT_BYTES + 255) & ~255;
+    static constexpr int STAGE = RES_OFF;
+    static constexpr int RES_BYTES = (M + 1) * 256;
+    static constexpr int HQ_OFF = RES_OFF;
     static constexpr int SS_OFF = RES_OFF + RES_BYTES;            // accumulator initial values [13][64] fp32
-    static constexpr int HW_OFF = SS_OFF + 13 * 64 * 4;
-    static constexpr int HB_OFF = HW_OFF + 64 * 4 * 4;
-    static constexpr int HS_OFF = HB_OFF + ((A + 3) & ~3) * 4;
-    static constexpr int VW_OFF = HS_OFF + 8 * 4;
-    static constexpr int PIPE_BYTES = VW_OFF + ((3 * P + 3 + 3) & ~3) * 4;
+    static constexpr int HB_OFF = SS_OFF + 13 * 64 * 4;           // policy FC bias [A]
+    static constexpr int VW_OFF = HB_OFF + ((A + 3) & ~3) * 4;    // value FC weights [3][P] + bias [3]
+    static constexpr int HD1_OFF = (VW_OFF + ((3 * P + 3 + 3) & ~3) * 4 + 15) & ~15;   // 1x1 fragment image + table
+    static constexpr int PIPE_BYTES = HD1_OFF + 4096 + 128;
     static constexpr int ROW_BYTES = kRowBytes;
     static constexpr int AUX = PIPE_BYTES;
     static constexpr int RING_OFF = (AUX + G * (3 * P + A + 4) * 4 + 255) & ~255;     // weight ring: two k-chunks
@@ -106,12 +105,8 @@ __global__ __launch_bounds__((W2Cfg<S, G>::NTHR), 2) void dualnet_fwd_w2_kernel(
         reinterpret_cast<unsigned *>(smem + (e >> 6) * IMG + C::ZOFF)[e & 63] = 0u;
     // tables -> LDS, once per workgroup
     for (int e = tid; e < 13 * 64; e += NTHR) reinterpret_cast<float *>(smem + C::SS_OFF)[e] = net.w2_init[e];
-    for (int e = tid; e < 64 * 4; e += NTHR) {
-        const int k = e >> 2, c = e & 3;
-        reinterpret_cast<float *>(smem + C::HW_OFF)[e] = c == 0 ? net.hp_w[k] : (c == 1 ? net.hp_w[64 + k] : (c == 2 ? net.hv_w[k] : 0.f));
-    }
     for (int e = tid; e < C::A; e += NTHR) reinterpret_cast<float *>(smem + C::HB_OFF)[e] = net.pfc_b[e];
-    if (tid < 6) reinterpret_cast<float *>(smem + C::HS_OFF)[tid] = net.head_ss[tid];
+    stage_head_tables<C, NTHR>(smem, net, tid);
     for (int e = tid; e < 3 * P + 3; e += NTHR)
         reinterpret_cast<float *>(smem + C::VW_OFF)[e] = e < 3 * P ? net.vfc_w[e] : net.vfc_b[e - 3 * P];
 
@@ -387,7 +382,7 @@ __global__ __launch_bounds__((W2Cfg<S, G>::NTHR), 2) void dualnet_fwd_w2_kernel(
                     }
                 }
             };
-            if (layer == kTowerLayers) epilogue(N{}, T{}, T{});
+            if (layer == kTowerLayers) epilogue(N{}, T{}, N{});        // (the heads read the block output as activation images)
             else if (layer == 0) epilogue(T{}, N{}, N{});
             else if (layer & 1) epilogue(N{}, N{}, N{});
             else epilogue(T{}, T{}, N{});
@@ -396,7 +391,7 @@ __global__ __launch_bounds__((W2Cfg<S, G>::NTHR), 2) void dualnet_fwd_w2_kernel(
             stamp();
         }
         fetch_planes(grp + gridDim.x);
-        run_heads_split<S, G, C, NTHR>(smem, net, b0, batch, want_logits, policy, value, tid, wave,
+        run_heads_mfma<S, G, C, NTHR>(smem, net, b0, batch, want_logits, policy, value, tid, wave,
                                        (net.timeline && blockIdx.x == 0 && grp == blockIdx.x) ? net.timeline + 44 : nullptr);
         __syncthreads();
         stamp();

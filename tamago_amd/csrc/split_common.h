@@ -271,6 +271,183 @@ __device__ __forceinline__ void run_heads_split(unsigned char *smem, const NetDe
     }
 }
 
+// Head phase on the 16-bit matrix pipe (9x9; round 3).  The last tower epilogue writes the block output as the usual
+// f16-pair activation images; from there:
+//   1. the three 1x1-convolution channels are one more split-operand product per 16-row tile (K = 64: 6 MFMAs, four
+//      B-fragment reads - the tower's own fragments at the centre tap), batch norm folded into the fragment image
+//      (heads_prepare); channels 0..2 of a position land in lane group 0.  ReLU; the policy features go to LDS as f16
+//      pairs in B-fragment order [piece][board 16][k 192] (k = channel * P + position), the value features as fp32;
+//   2. the policy FC is a split-operand product too: column tile (16 outputs) x board (16, G used) x K = 192 in 6 k-steps
+//      = 18 MFMAs per column tile; the 72 KB of weight fragments never touch LDS - every wave requests the 12 KB of its
+//      column tile straight from L2 BEFORE step 1, so their latency is covered; the value FC (81 -> 3) stays on the VALU;
+//   3. softmax, stores.
+// (Before: fp32 MFMAs with most rows idle on an fp32 image of the last layer, the FC weights copied to LDS per group:
+// 14.5 - 18.7 k cycles per group, profiles/r03_check_w2_ring_zero_block.txt.)
+// C must provide: P, A, M, MT, IMG, ZOFF, HQ_OFF (12 KB, free during the head phase), HD1_OFF (the 1x1 fragment image
+// 4 KB + its table 80 B, staged once per workgroup: stage_head_tables), AUX, HB_OFF, VW_OFF.
+// once per workgroup: the 1x1-convolution fragment image (4 KB) and its table (accumulator start values [16], 2^-e) -> LDS
+template <typename C, int NTHR>
+__device__ __forceinline__ void stage_head_tables(unsigned char *smem, const NetDev &net, int tid) {
+    for (int e = tid; e < 4096 / 16; e += NTHR)
+        reinterpret_cast<uint4 *>(smem + C::HD1_OFF)[e] = reinterpret_cast<const uint4 *>(net.hd1_img)[e];
+    if (tid < 20) reinterpret_cast<float *>(smem + C::HD1_OFF + 4096)[tid] = net.hd1_tab[tid];
+}
+
+template <int S, int G, typename C, int NTHR>
+__device__ __forceinline__ void run_heads_mfma(unsigned char *smem, const NetDev &net, int b0, int batch, int want_logits,
+                                               float *__restrict__ policy, float *__restrict__ value, int tid, int wave,
+                                               long long *tl) {
+    constexpr int P = C::P, A = C::A, M = C::M, IMG = C::IMG;
+    constexpr int NW = NTHR / 64, NT = 6, KS = 6, NTW = (NT + NW - 1) / NW;
+    using F = FmtF16;
+    asm volatile("" : "+v"(tid));                          // opaque: nothing derived from it is hoisted out of the group loop
+    const int lane = tid & 63, li = lane & 15, lg = lane >> 4;
+    auto stamp = [&](int i) { if (tl && tid == 0) tl[i] = (long long)__builtin_amdgcn_s_memtime(); };
+    float *hval = reinterpret_cast<float *>(smem + C::AUX);   // [G][P]
+    float *plog = hval + G * P;                               // [G][NT * 16]
+    float *vlog = plog + G * NT * 16;                         // [G][4]
+    // ---- policy FC weight fragments of this wave's column tiles: requested now, used in step 2 ----
+    i32x4v fw[NTW][KS][2];
+#pragma unroll
+    for (int u = 0; u < NTW; ++u) {
+        const int nt = wave + u * NW;
+        const unsigned char *base = net.pfc_img + (size_t)(nt < NT ? nt : 0) * KS * 2048 + lane * 16;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) gmem_load_frag(fw[u][s][p], base, (s * 2 + p) * 1024);
+    }
+    // the feature image [piece][board 16][k 192]: boards < G get their 2P features below and zeros in the K padding here
+    // (the FC weights are zero there, but 0 x Inf would not be - the region held other data); boards >= G are never
+    // written: whatever they hold only reaches output columns that are discarded
+    for (int e = tid; e < 2 * G * (192 - 2 * P); e += NTHR) {
+        const int pc = e / (G * (192 - 2 * P)), r2 = e - pc * G * (192 - 2 * P), bl = r2 / (192 - 2 * P), kk = r2 - bl * (192 - 2 * P);
+        reinterpret_cast<_Float16 *>(smem + C::HQ_OFF)[(pc * 16 + bl) * 192 + 2 * P + kk] = (_Float16)0.f;
+    }
+    // ---- 1. 1x1 convolutions: fragments of all of this wave's row tiles first, then the products ----
+    i32x4v ha[2][2];
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) lds_load_frag<0>(ha[kc][p], smem, C::HD1_OFF + (kc * 2 + p) * 1024 + lane * 16);
+    const f32x4 ini = *reinterpret_cast<const f32x4 *>(smem + C::HD1_OFF + 4096 + lg * 16);
+    const float down1 = *reinterpret_cast<const float *>(smem + C::HD1_OFF + 4096 + 64), down1x = down1 * (1.f / 2048.f);
+    constexpr int TPW = (C::MT + NW - 1) / NW;
+    i32x4v fb[TPW][2][2];                                  // [tile][piece][kc]
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+        const int t = wave + q * NW;
+        const int row = (t < C::MT ? t : wave) * 16 + li;
+        const int nat = row * 64 + ((lg ^ ((row >> 1) & 3)) << 4);
+        const int addr = row < M ? nat : C::ZOFF + (nat & 255);
+        lds_load_frag<0 * IMG>(fb[q][0][0], smem, addr);
+        lds_load_frag<1 * IMG>(fb[q][0][1], smem, addr);
+        lds_load_frag<2 * IMG>(fb[q][1][0], smem, addr);
+        lds_load_frag<3 * IMG>(fb[q][1][1], smem, addr);
+    }
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+        const int t = wave + q * NW;
+        const int row = t * 16 + li;
+        f32x4 a0 = ini, a1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            a0 = mfma16<F>(ha[kc][0], fb[q][0][kc], a0);
+            a1 = mfma16<F>(ha[kc][1], fb[q][0][kc], a1);
+            a1 = mfma16<F>(ha[kc][0], fb[q][1][kc], a1);
+        }
+        if (lg == 0 && t < C::MT && row < M) {
+            const int bl = row / P, pp = row - bl * P;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float v = fmaxf(fmaf(a1[j], down1x, a0[j] * down1), 0.f);
+                if (j == 2) {
+                    hval[bl * P + pp] = v;
+                } else {
+                    const _Float16 h = (_Float16)v;
+                    const _Float16 l = (_Float16)((v - (float)h) * 2048.f);
+                    _Float16 *hq = reinterpret_cast<_Float16 *>(smem + C::HQ_OFF);
+                    hq[(0 * 16 + bl) * 192 + j * P + pp] = h;
+                    hq[(1 * 16 + bl) * 192 + j * P + pp] = l;
+                }
+            }
+        }
+    }
+    stamp(0);
+    __syncthreads();
+    stamp(1);
+    // ---- 2. policy FC (waves take column tiles), value FC (all threads) ----
+    const float down2 = net.pfc_tab[0], down2x = down2 * (1.f / 2048.f);
+#pragma unroll
+    for (int u = 0; u < NTW; ++u) {
+        const int nt = wave + u * NW;
+        if (nt < NT) {
+            f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                i32x4v fh, fl;
+                const int off = C::HQ_OFF + (li * 192 + s * 32 + lg * 8) * 2;
+                lds_load_frag<0>(fh, smem, off);
+                lds_load_frag<16 * 192 * 2>(fl, smem, off);
+                a0 = mfma16<F>(fw[u][s][0], fh, a0);
+                a1 = mfma16<F>(fw[u][s][1], fh, a1);
+                a1 = mfma16<F>(fw[u][s][0], fl, a1);
+            }
+            if (li < G) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int a = nt * 16 + lg * 4 + j;
+                    if (a < A)
+                        plog[li * NT * 16 + a] = fmaf(a1[j], down2x, a0[j] * down2) + reinterpret_cast<const float *>(smem + C::HB_OFF)[a];
+                }
+            }
+        }
+    }
+    for (int o = tid >> 4; o < G * 3; o += NTHR / 16) {
+        const int part = tid & 15, bl = o / 3, c = o - bl * 3;
+        const float *h = hval + bl * P;
+        const float *wv = reinterpret_cast<const float *>(smem + C::VW_OFF) + c * P;
+        float sv = 0.f;
+#pragma unroll
+        for (int i = 0; i < (P + 15) / 16; ++i) {
+            const int j = part + i * 16;
+            if (j < P) sv = fmaf(h[j], wv[j], sv);
+        }
+        sv += __shfl_xor(sv, 8);
+        sv += __shfl_xor(sv, 4);
+        sv += __shfl_xor(sv, 2);
+        sv += __shfl_xor(sv, 1);
+        if (part == 0) vlog[bl * 4 + c] = sv + reinterpret_cast<const float *>(smem + C::VW_OFF)[3 * P + c];
+    }
+    stamp(2);
+    __syncthreads();
+    // ---- 3. softmax, stores ----
+    for (int bl = wave; bl < G; bl += NW) {
+        const int b = b0 + bl;
+        if (b >= batch) continue;
+        const float l0 = plog[bl * NT * 16 + lane];
+        const float l1 = lane + 64 < A ? plog[bl * NT * 16 + lane + 64] : -INFINITY;
+        float m = fmaxf(l0, l1);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        const float e0 = expf(l0 - m), e1 = lane + 64 < A ? expf(l1 - m) : 0.f;
+        float sum = e0 + e1;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        const float inv = 1.f / sum;
+        __builtin_nontemporal_store(want_logits ? l0 : e0 * inv, &policy[(size_t)b * A + lane]);
+        if (lane + 64 < A) __builtin_nontemporal_store(want_logits ? l1 : e1 * inv, &policy[(size_t)b * A + lane + 64]);
+        if (lane < 3) {
+            const float v0 = vlog[bl * 4], v1 = vlog[bl * 4 + 1], v2 = vlog[bl * 4 + 2];
+            const float vm = fmaxf(v0, fmaxf(v1, v2));
+            const float x0 = expf(v0 - vm), x1 = expf(v1 - vm), x2 = expf(v2 - vm);
+            const float es = x0 + x1 + x2;
+            const float mine = lane == 0 ? x0 : (lane == 1 ? x1 : x2);
+            value[(size_t)b * 3 + lane] = mine / es;
+        }
+    }
+}
+
 // ---- host: operand splitting of the weights -----------------------------------------------------
 inline uint16_t f32_to_f16_rn(float f) {
     uint32_t x;
