@@ -415,7 +415,11 @@ int launch_w2(tg_net *net, const float *planes, int batch, int want_logits, floa
         attr_set[net->device & 15] = true;
     }
     const int groups = (batch + G - 1) / G;
-    const int grid = groups < net->num_cus ? groups : net->num_cus;
+    // TG_FWD_CUS=n: at most n workgroups (CUs) for the forward pass - leaves CUs to the tree kernels of another lock-step
+    // group running on a second stream (the persistent workgroups of a full-width launch own every CU's LDS and registers)
+    static const int cu_cap = getenv("TG_FWD_CUS") ? atoi(getenv("TG_FWD_CUS")) : 0;
+    const int cus = cu_cap > 0 && cu_cap < net->num_cus ? cu_cap : net->num_cus;
+    const int grid = groups < cus ? groups : cus;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTHR), C::LDS_BYTES, stream, net->dev, planes, batch, want_logits,
                        policy, value, overflow);
     TG_HIP(hipGetLastError());

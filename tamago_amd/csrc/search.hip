@@ -3714,9 +3714,9 @@ int tg_selfplay_play_move(tg_selfplay *sp, tg_net *net, float *planes_dev, float
     // child: the cursor read-back IS the roots' child counts (saves the schedule's own device read)
     sp->consumed.resize(T);
     if ((rc = tg_search_advance_streams(s, sp->consumed.data()))) return rc;
-    // ... but only if nothing went wrong in that launch: a sticky device error (pool full, window exhausted) would
-    // leave a cursor that is not a child count, and the halving schedule would be built from a wrong width
-    if ((rc = check_errors(s))) return rc;
+    // ... provided nothing went wrong in that launch (a sticky device error - pool full, window exhausted - would leave a
+    // cursor that is not a child count): the count must be plausible here, and it is compared with the root statistics
+    // read back behind the last phase, where the device error words are checked as well (no extra synchronisation here)
     sp->nc.resize(T);
     for (int t = 0; t < T; ++t) {
         if (sp->consumed[t] < 1 || sp->consumed[t] > A)
@@ -3796,6 +3796,7 @@ int tg_selfplay_play_move(tg_selfplay *sp, tg_net *net, float *planes_dev, float
     int64_t counts[2] = {0, 0};
     lap(3);
     if ((rc = tg_selfplay_finish_move(sp, sp->mv.data(), finished_host, counts))) return rc;
+    if ((rc = check_errors(s))) return rc;          // (the stream is drained here: finish_move has read the roots back)
     // the roots' child counts as the statistics read-back reports them must be what the draw cursor said
     for (int t = 0; t < T; ++t)
         if (sp->nc[t] != sp->nc_cursor[t])
