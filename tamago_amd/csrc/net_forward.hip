@@ -923,6 +923,23 @@ int tg_net_forward_dev(tg_net *net, const float *planes_dev, int batch, int want
     }
     if (net->board_size == 9) {
         if (pick_split()) {
+            // Tail of a batch that is not a whole number of rounds: a round = one 3-board workgroup on each of the CUs
+            // (142 us); up to num_cus leftover positions are cheaper as ONE round of 1-board workgroups (80 us) than as
+            // one more, mostly empty round of 3-board workgroups - the two launches follow each other on the stream.
+            // (Self-play phases: 16 boards x 100 / 108 leaves = 2 rounds + 64 / 192 positions.)
+            {
+                const int round = 3 * net->num_cus;
+                const int rem = batch % round;
+                static const bool no_tail = getenv("TG_FWD_NO_TAIL") != nullptr;
+                if (!no_tail && batch > round && rem > 0 && rem <= net->num_cus) {
+                    const int head = batch - rem;
+                    const size_t P = 81, A = 82;
+                    int rc = tg_net_forward_dev(net, planes_dev, head, want_logits, policy_dev, value_dev, stream);
+                    if (rc) return rc;
+                    return tg_net_forward_dev(net, planes_dev + (size_t)head * 6 * P, rem, want_logits,
+                                              policy_dev + (size_t)head * A, value_dev + (size_t)head * 3, stream);
+                }
+            }
             // split-operand kernel on the 16-bit matrix pipe.  f16 pieces: a range flag (per launch stream)
             // makes the exact-fp32 Winograd kernel, queued right behind, redo the batch if a layer output
             // left the f16 range; with the flag clear that launch exits at once.

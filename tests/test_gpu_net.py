@@ -41,7 +41,7 @@ def test_forward_vs_reference_golden(size):
         assert err_hip < 4 * err_ref + 1e-6
 
 
-@pytest.mark.parametrize("size,batches", [(9, [1, 2, 7, 256, 257, 770, 1539]), (19, [1, 3, 64])])
+@pytest.mark.parametrize("size,batches", [(9, [1, 2, 7, 256, 257, 770, 1539, 1600]), (19, [1, 3, 64])])
 def test_forward_vs_oracle_random_planes(size, batches):
     from oracle.net import OracleNet, make_state_dict
     sd = make_state_dict(size, 3, 1.4)
