@@ -3467,6 +3467,19 @@ struct tg_selfplay {
     std::vector<int32_t> act32;                      // root actions of the move in progress (finish_move scratch)
     double t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // TG_SP_TIMING: host wall clock per section, per HANDLE (groups run on their own threads)
     long moves_timed = 0;
+    // The improved-policy comment of a move (two softmaxes + up to 82 "%.3e" fields per board: most of finish_move's
+    // host time) is not needed to go on - only the chosen move is.  finish_move saves what the comment is made of and
+    // the text is appended to the game record later, while the NEXT move's kernels run (tg_selfplay_play_move, before
+    // it waits for them), at the latest at the start of the next finish_move.
+    struct PendingComment {
+        bool valid = false;
+        int n = 0, pos = 0, color = 0, nv = 0, max_count = 0;
+        float raw = 0.f;
+        std::vector<int32_t> act, vis;
+        std::vector<double> pol, vsum;
+    };
+    std::vector<PendingComment> pending;             // [T]
+    int64_t last_window = 0;                         // phase random window of the last move (draws per tree): pre-generation hint
 };
 
 namespace {
@@ -3554,6 +3567,58 @@ int write_sgf(const tg_selfplay *sp, const SpGame &g, int winner, bool is_resign
     return ok ? TG_OK : tg::fail(TG_ERR_ARG, "tg_selfplay: short write to %s", path.c_str());
 }
 
+// improved policy (node.py:281-321) -> ";B[ee]C[<n> <gtp>:<p:.3e> ...]" appended to the game record
+void append_comment(tg_selfplay *sp, SpGame &g, const tg_selfplay::PendingComment &pc) {
+    const int n = pc.n, S = sp->s->S;
+    const double sigma_sel = (double)(50 + pc.max_count) * 1.0;
+    std::vector<double> q(n), w1(n), w2(n);
+    const double *pol = pc.pol.data(), *vsum = pc.vsum.data();
+    const int32_t *vis = pc.vis.data(), *act = pc.act.data();
+    for (int i = 0; i < n; ++i) q[i] = vis[i] > 0 ? vsum[i] / (double)vis[i] : 0.0;
+    double mx = -INFINITY;
+    for (int i = 0; i < n; ++i) mx = pol[i] > mx ? pol[i] : mx;
+    for (int i = 0; i < n; ++i) w1[i] = std::exp(pol[i] - mx);
+    const double s1 = host_np_sum(w1.data(), n);
+    for (int i = 0; i < n; ++i) { w1[i] = w1[i] / s1; w2[i] = w1[i] * q[i]; }
+    const double sum_prob = host_np_sum(w1.data(), n), v_pi = host_np_sum(w2.data(), n);
+    const double nvd = (double)pc.nv;
+    const double mixed = ((double)pc.raw * 1.0 + nvd * v_pi / sum_prob) / (nvd + 1.0);
+    // np.max(self.children_visits) runs over the whole array (zeros beyond n): same value
+    double mx2 = -INFINITY;
+    for (int i = 0; i < n; ++i) {
+        w2[i] = pol[i] + sigma_sel * (vis[i] > 0 ? q[i] : mixed);
+        mx2 = w2[i] > mx2 ? w2[i] : mx2;
+    }
+    for (int i = 0; i < n; ++i) w1[i] = std::exp(w2[i] - mx2);
+    const double s2 = host_np_sum(w1.data(), n);
+    char buf[64];
+    g.body += pc.color == kBlack ? ";B[" : ";W[";
+    g.body += sgf_name(pc.pos, S);
+    g.body += "]C[";
+    g.body += std::to_string(n);
+    for (int i = 0; i < n; ++i) {
+        snprintf(buf, sizeof(buf), ":%.3e", w1[i] / s2);
+        g.body += ' ';
+        g.body += gtp_name(act[i], S);
+        g.body += buf;
+    }
+    g.body += ']';
+}
+
+void flush_comments(tg_selfplay *sp) {
+    const int T = sp->s->dev.T;
+    if ((int)sp->pending.size() != T) return;
+    bool any = false;
+    for (int t = 0; t < T; ++t) any |= sp->pending[t].valid;
+    if (!any) return;
+    parallel_trees(T, [&](int t) {
+        tg_selfplay::PendingComment &pc = sp->pending[t];
+        if (!pc.valid) return;
+        append_comment(sp, sp->games[t], pc);
+        pc.valid = false;
+    });
+}
+
 }  // namespace
 
 extern "C" {
@@ -3586,6 +3651,7 @@ int tg_selfplay_start_game(tg_selfplay *sp, int slot, int index, int never_resig
     g.never_resign = never_resign != 0;
     g.done = index < 0;
     sp->games[slot] = g;
+    if ((size_t)slot < sp->pending.size()) sp->pending[slot].valid = false;
     sp->force_feed = true;
     return TG_OK;
 }
@@ -3628,6 +3694,8 @@ int tg_selfplay_finish_move(tg_selfplay *sp, int32_t *moves_host, int32_t *finis
     tg_search *s = sp->s;
     const SearchDev &D = s->dev;
     const int T = D.T, A = s->A, S = s->S;
+    flush_comments(sp);                                               // the previous move's comments, if still waiting
+    sp->pending.resize(T);
     sp->nc.resize(T); sp->nv.resize(T); sp->raw.resize(T);
     sp->visits_a.resize((size_t)T * A); sp->vl_a.resize((size_t)T * A);
     sp->vsum_a.resize((size_t)T * A); sp->pol_a.resize((size_t)T * A);
@@ -3658,12 +3726,11 @@ int tg_selfplay_finish_move(tg_selfplay *sp, int32_t *moves_host, int32_t *finis
         int max_count = 0;
         for (int i = 0; i < n; ++i) max_count = std::max(max_count, vis[i]);
         const double sigma_sel = (double)(50 + max_count) * 1.0;
-        std::vector<double> q(n), w1(n), w2(n);
         int best = 0;
         double best_v = 0.0;
         for (int i = 0; i < n; ++i) {
-            q[i] = vis[i] > 0 ? vsum[i] / (double)vis[i] : 0.0;
-            const double ev = (vis[i] + vl[i] >= 100) ? -10000.0 : (pol[i] + noise[i]) + sigma_sel * q[i];
+            const double qi = vis[i] > 0 ? vsum[i] / (double)vis[i] : 0.0;
+            const double ev = (vis[i] + vl[i] >= 100) ? -10000.0 : (pol[i] + noise[i]) + sigma_sel * qi;
             if (i == 0 || ev > best_v) { best_v = ev; best = i; }
         }
         const double value = vis[best] == 0 ? 0.5 : vsum[best] / (double)vis[best];
@@ -3676,39 +3743,22 @@ int tg_selfplay_finish_move(tg_selfplay *sp, int32_t *moves_host, int32_t *finis
             return;
         }
         const int pos = act[best];
-        // ---- improved policy (node.py:281-321) -> comment "<n> <gtp>:<p:.3e> ..." ----
-        double mx = -INFINITY;
-        for (int i = 0; i < n; ++i) mx = pol[i] > mx ? pol[i] : mx;
-        for (int i = 0; i < n; ++i) w1[i] = std::exp(pol[i] - mx);
-        const double s1 = host_np_sum(w1.data(), n);
-        for (int i = 0; i < n; ++i) { w1[i] = w1[i] / s1; w2[i] = w1[i] * q[i]; }
-        const double sum_prob = host_np_sum(w1.data(), n), v_pi = host_np_sum(w2.data(), n);
-        const double nvd = (double)sp->nv[t];
-        const double mixed = ((double)sp->raw[t] * 1.0 + nvd * v_pi / sum_prob) / (nvd + 1.0);
-        // np.max(self.children_visits) runs over the whole array (zeros beyond n): same value
-        double mx2 = -INFINITY;
-        for (int i = 0; i < n; ++i) {
-            w2[i] = pol[i] + sigma_sel * (vis[i] > 0 ? q[i] : mixed);
-            mx2 = w2[i] > mx2 ? w2[i] : mx2;
-        }
-        for (int i = 0; i < n; ++i) w1[i] = std::exp(w2[i] - mx2);
-        const double s2 = host_np_sum(w1.data(), n);
-        char buf[64];
-        g.body += g.to_move == kBlack ? ";B[" : ";W[";
-        g.body += sgf_name(pos, S);
-        g.body += "]C[";
-        g.body += std::to_string(n);
-        for (int i = 0; i < n; ++i) {
-            snprintf(buf, sizeof(buf), ":%.3e", w1[i] / s2);
-            g.body += ' ';
-            g.body += gtp_name(act[i], S);
-            g.body += buf;
-        }
-        g.body += ']';
+        // ---- improved policy (node.py:281-321) -> comment "<n> <gtp>:<p:.3e> ...": saved, formatted later ----
+        tg_selfplay::PendingComment &pc = sp->pending[t];
+        pc.valid = true;
+        pc.n = n; pc.pos = pos; pc.color = g.to_move; pc.nv = sp->nv[t]; pc.raw = sp->raw[t]; pc.max_count = max_count;
+        pc.act.assign(act, act + n);
+        pc.vis.assign(vis, vis + n);
+        pc.pol.assign(pol, pol + n);
+        pc.vsum.assign(vsum, vsum + n);
         moves_host[t] = pos;
         g.pass_count = pos == 0 ? g.pass_count + 1 : 0;
         g.to_move = 3 - g.to_move;
         g.moves_played += 1;
+        if (g.pass_count == 2 || g.moves_played >= max_moves) {         // the game ends here: its record is written now
+            append_comment(sp, g, pc);
+            pc.valid = false;
+        }
         if (g.pass_count == 2) {                                        // worker.py:80-87 (a pass leaves the cells as they are)
             const double score = (double)count_score_cells(&sp->cells[(size_t)t * s->NC], S) - sp->komi;
             const int winner = score > 0.1 ? kBlack : (score < -0.1 ? kWhite : kOob);
@@ -3849,6 +3899,17 @@ int tg_selfplay_play_move(tg_selfplay *sp, tg_net *net, float *planes_dev, float
         any_phase = true;
     }
     lap(3);
+    // ---- host work that nobody is waiting for, while the phase kernels run: the previous move's record comments, and
+    //      the draws the next move will ask for (root prior, noise, a window like this move's) generated ahead ----
+    flush_comments(sp);
+    {
+        const size_t ahead = (size_t)2 * A + (size_t)sp->last_window + (size_t)8 * A;
+        parallel_trees(T, [&](int t) {
+            if (!sp->games[t].done && s->streams[t].seeded) s->streams[t].ensure(s->streams[t].available() < ahead ? ahead : 0);
+        });
+        sp->last_window = window;
+    }
+    lap(4);
     if (any_phase && (rc = tg_search_advance_streams(s, nullptr))) return rc;
     lap(5);
     // ---- move choice, records, finished games; play ----
