@@ -8,14 +8,19 @@ from tests.helpers import load_npz
 from oracle.net import OracleNet, make_state_dict
 from tamago_amd.nn.network.dual_net import DualNet
 fix = load_npz("net_s9.npz")
-for algo in ("wino", "direct", "split16"):
+for algo in ("wino", "direct", "split16", "w2"):
     os.environ["TG_FWD_ALGO"] = algo
     for seed in (0, 7):
         sd = make_state_dict(9, seed, float(fix[f"w{seed}_gain"]))
         net = DualNet(torch.device("cuda:0"), 9); net.load_state_dict(sd)
         x = torch.from_numpy(fix[f"w{seed}_planes"].astype(np.float32))
-        lg, val = net.inference_with_policy_logits(x)
-        pol, _ = net.inference(x)
+        for reps in (1, (300 + x.shape[0] - 1) // x.shape[0]):       # as recorded (one board per workgroup) and tiled
+            xx = x.repeat(reps, 1, 1, 1)                              # beyond the CU count (three boards per workgroup)
+            lg, val = net.inference_with_policy_logits(xx)
+            pol, _ = net.inference(xx)
+            lg, val, pol = lg[:x.shape[0]], val[:x.shape[0]], pol[:x.shape[0]]
+            if reps > 1:
+                print(f"{algo:10s} seed {seed} B={xx.shape[0]}: |logit-fp64| {np.abs(lg.numpy() - fix[f'w{seed}_logits64']).max():.3e}")
         e64 = np.abs(lg.numpy() - fix[f"w{seed}_logits64"]).max()
         eref = np.abs(fix[f"w{seed}_logits"] - fix[f"w{seed}_logits64"]).max()
         ep = np.abs(pol.numpy() - fix[f"w{seed}_policy"]).max()
