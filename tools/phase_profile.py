@@ -17,6 +17,9 @@ lib = tl.load()
 size = int(sys.argv[2]) if len(sys.argv) > 2 else 9
 net = DualNet(torch.device("cuda:0"), size)
 b = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+if size == 9 and b > 768:
+    b -= b % 768        # whole rounds of 3-board workgroups: a ragged tail would be a second launch (1-board workgroups)
+                        # whose stamps overwrite the first one's
 x = torch.randint(-1, 2, (b, 6, size, size), device="cuda").float()
 pol = torch.empty((b, size * size + 1), device="cuda")
 val = torch.empty((b, 3), device="cuda")
