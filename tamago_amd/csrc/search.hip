@@ -640,6 +640,54 @@ struct EdgePick {
     int edge, move, child, count, edge_vl, node_vl;   // count = visits + virtual loss of the edge
 };
 
+// pucb.py:8-29 on a node's statistics held in registers (lane i + 64 r: child i + 64 r); `total` = visits + virtual
+// losses of the node.  The arithmetic of select_puct, shared with the kernels that load the statistics themselves.
+template <int S>
+__device__ __forceinline__ EdgePick score_puct(const SearchDev &D, const int (&vis)[(Geo<S>::A + 63) / 64],
+                                               const int (&vl)[(Geo<S>::A + 63) / 64], const int (&idx)[(Geo<S>::A + 63) / 64],
+                                               const int (&act)[(Geo<S>::A + 63) / 64], const double (&vsum)[(Geo<S>::A + 63) / 64],
+                                               const double (&pol)[(Geo<S>::A + 63) / 64], int nc, int total, int node_vl, int lane) {
+    constexpr int R = (Geo<S>::A + 63) / 64;
+    const double sq = __dsqrt_rn((double)(total + 1));
+    double best = 0.0;
+    int best_i = -1;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = lane + 64 * r;
+        const int cnt = vis[r] + vl[r];
+        // A group of 64 children none of which has been tried needs no division: q = 0 and u = (p sqrt) / 1, and
+        // 0.0 + x / 1.0 is x bit for bit.  Most groups of most nodes are like that.
+        if (__any(i < nc && cnt != 0)) {
+            if (i < nc) {
+                const double q = cnt != 0 ? vsum[r] / (double)cnt : 0.0;
+                const double u = (pol[r] * sq) / (double)(cnt + 1);
+                double sc = q + u;
+                if (D.cgos && i == nc - 1) sc -= 0.1;
+                if (best_i < 0 || sc > best) { best = sc; best_i = i; }
+            }
+        } else if (i < nc) {
+            double sc = pol[r] * sq;
+            if (D.cgos && i == nc - 1) sc -= 0.1;
+            if (best_i < 0 || sc > best) { best = sc; best_i = i; }
+        }
+    }
+    best_i = wave_argmax_first(best, best_i);
+    const int owner = best_i & 63, slot = best_i >> 6;
+    int my_move = 0, my_child = 0, my_cnt = 0, my_vl = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (r == slot) { my_move = act[r]; my_child = idx[r]; my_cnt = vis[r] + vl[r]; my_vl = vl[r]; }
+    EdgePick pick;
+    pick.edge = best_i;
+    const int src = __builtin_amdgcn_readfirstlane(owner);        // wave-uniform after the arg-max
+    pick.move = __builtin_amdgcn_readlane(my_move, src);
+    pick.child = __builtin_amdgcn_readlane(my_child, src);
+    pick.count = __builtin_amdgcn_readlane(my_cnt, src);
+    pick.edge_vl = __builtin_amdgcn_readlane(my_vl, src);
+    pick.node_vl = node_vl;
+    return pick;
+}
+
 template <int S>
 __device__ EdgePick select_puct(const SearchDev &D, int t, int node, int lane) {
     constexpr int A = Geo<S>::A;
@@ -662,37 +710,7 @@ __device__ EdgePick select_puct(const SearchDev &D, int t, int node, int lane) {
     const int nc = D.n_children[ns];
     const int node_vl = D.n_vl[ns];
     const int total = D.n_visits[ns] + node_vl;
-    const double sq = __dsqrt_rn((double)(total + 1));
-    double best = 0.0;
-    int best_i = -1, best_r = 0;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int i = lane + 64 * r;
-        if (i < nc) {
-            const int cnt = vis[r] + vl[r];
-            const double q = cnt != 0 ? vsum[r] / (double)cnt : 0.0;
-            const double u = (pol[r] * sq) / (double)(cnt + 1);
-            double sc = q + u;
-            if (D.cgos && i == nc - 1) sc -= 0.1;
-            if (best_i < 0 || sc > best) { best = sc; best_i = i; best_r = r; }
-        }
-    }
-    (void)best_r;
-    best_i = wave_argmax_first(best, best_i);
-    const int owner = best_i & 63, slot = best_i >> 6;
-    int my_move = 0, my_child = 0, my_cnt = 0, my_vl = 0;
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-        if (r == slot) { my_move = act[r]; my_child = idx[r]; my_cnt = vis[r] + vl[r]; my_vl = vl[r]; }
-    EdgePick pick;
-    pick.edge = best_i;
-    const int src = __builtin_amdgcn_readfirstlane(owner);        // wave-uniform after the arg-max
-    pick.move = __builtin_amdgcn_readlane(my_move, src);
-    pick.child = __builtin_amdgcn_readlane(my_child, src);
-    pick.count = __builtin_amdgcn_readlane(my_cnt, src);
-    pick.edge_vl = __builtin_amdgcn_readlane(my_vl, src);
-    pick.node_vl = node_vl;
-    return pick;
+    return score_puct<S>(D, vis, vl, idx, act, vsum, pol, nc, total, node_vl, lane);
 }
 
 template <int S, typename LT>
@@ -852,14 +870,17 @@ constexpr int kPathMax = S == 9 ? 256 : kPipeMaxDepth;
 // leaves 19.6 KB of the 160 KB): boards without the softmax scratch, path buffers of kPathMax<S>, "job done"
 // flags as a bit set.  Otherwise a selection launch of one board group waits for the forward pass of the other
 // group to drain instead of overlapping it.
-template <int S>
+// (NW workers, 2 NW ring slots: with few trees per GPU the Gumbel kernel takes more workers per tree - the CUs are
+// idle anyway and its jobs - expansions, leaves, ~100 plane copies per phase - are what a phase waits for.)
+template <int S, int NW = 2>
 struct PipeShared {
-    Lds<S, false> board[2];
-    PipeJob job[kPipeSlots];
-    int16_t moves[kPipeSlots][kPathMax<S>];
-    int paths[kPipeSlots][kPathMax<S>];   // Gumbel jobs: (node << 10 | edge) per level, for the worker's bookkeeping
-    int job_seq[kPipeSlots];          // k + 1 once job k sits in its slot
-    int slot_done[kPipeSlots];        // jobs finished in this slot so far
+    static constexpr int kSlots = 2 * NW;
+    Lds<S, false> board[NW];
+    PipeJob job[kSlots];
+    int16_t moves[kSlots][kPathMax<S>];
+    int paths[kSlots][kPathMax<S>];       // Gumbel jobs: (node << 10 | edge) per level, for the worker's bookkeeping
+    int job_seq[kSlots];              // k + 1 once job k sits in its slot
+    int slot_done[kSlots];            // jobs finished in this slot so far
     unsigned done_bits[kPipeMaxK / 32];   // bit k: job k finished (node initialised, planes written)
     int16_t jobof[kPipeMaxK];         // node (n0 + i) is being created by job jobof[i]
     int cursor_seq;                   // expansions that have reserved their draws
@@ -1511,6 +1532,433 @@ int launch_mpipe(const SearchDev &dev, int max_leaves, float *planes, hipStream_
     }
 }
 
+// ---- PUCT selection with every NODE owned by one wavefront -----------------------------------------------------
+// The multi-selector kernel above gives each DESCENT to a wavefront; a descent then has to wait at every node for the
+// earlier descents still inside it, and to make its virtual loss visible to the others (global stores, a wait for
+// them to land, a flag) before it moves on: 24 k cycles of wavefront time per descent, 40 % of it waiting.  Here
+// the NODES have owners instead.  A descent is a token that travels from wavefront to wavefront:
+//   * wave 0 owns the ROOT: it takes the root steps of all descents one after the other out of registers (statistics,
+//     virtual losses, quotient cache) - the chain every launch is bounded by, now without a single wait for another
+//     wavefront inside it;
+//   * waves 1..NNODE own the nodes below: a node at depth d under root edge e belongs to wave 1 + (d + e) % NNODE.
+//     Wide trees spread over the root edges, deep narrow ones over the levels.  All visits to a node are made by one
+//     wavefront in descent order (a node's visitors all come from its parent's owner, which hands them on in the
+//     order it made them - by induction from the root), so the owner reads and writes the node's virtual losses with
+//     plain loads and stores: nobody else looks at them before the launch ends;
+//   * one wave is the ALLOCATOR: every descent ends in exactly one leaf; leaves report to it and it takes them in
+//     descent order - node numbers, random draws (xseq) and job slots are handed out exactly as by the serial loop;
+//   * NWRK workers replay paths, expand and featurise as before.
+// A descent's state sits in an LDS slot (slot = k mod kSlots; at most kSlots descents are in flight: the root waits
+// for the worker of descent k - kSlots), the hand-over is one LDS word per slot (`mail`: descent, addressee) that every
+// owner polls with one load per lane.  An owner takes the LOWEST descent addressed to it whose node is ready (child
+// index assigned by the allocator, arrays initialised by the worker): never blocking on a descent keeps the allocator
+// - which needs ALL earlier leaves - from waiting for a descent queued behind one that waits for the allocator.
+// An edge expanded earlier in the same launch is recognised by its owner (child index still "not expanded" although
+// the edge has been visited) and resolved through the expanding descent (exp_key / alloc_child).
+// Same trees bit for bit (tests/test_gpu_search.py, test_gpu_end_to_end.py).
+template <int S, int NNODE, int NWRK>
+struct OwnerShared {
+    static constexpr int kSlots = (S == 9 ? 5 : 4) * NWRK;       // descents in flight; a multiple of the worker count
+    static_assert(kSlots <= 64, "one mail word per lane");
+    Lds<S, false> board[NWRK];
+    PipeJob job[kSlots];
+    int16_t moves[kSlots][kPathMax<S>];
+    int qpath[kSlots][kPathCap];      // (node << 10 | edge) of the first kPathCap levels
+    int job_seq[kSlots];              // k + 1 once job k sits in its slot
+    int slot_done[kSlots];            // jobs finished in this slot so far
+    int mail[64];                     // (k + 1) << 8 | wave that takes descent k next; 0: nobody
+    int st_node[kSlots];              // its node; <= -2: the child that descent (-2 - v) is having allocated
+    int st_depth[kSlots], st_prev[kSlots], st_redge[kSlots];
+    int lm_parent[kSlots], lm_edge[kSlots], lm_child[kSlots], lm_depth[kSlots];   // leaf report to the allocator
+    int leaf_ready[kSlots];           // k + 1
+    int done[kPipeMaxK];              // job k finished (node initialised, planes written)
+    int alloc_child[kPipeMaxK];       // node of descent k's leaf once the allocator has taken it (kOwnNotYet before)
+    int exp_key[kPipeMaxK];           // (parent << 10 | edge) if descent k's leaf needs a new node, else -1
+    int16_t jobof[kPipeMaxK];         // node (n0 + i) is being created by job jobof[i]
+    int num_nodes;
+    int cursor_seq;
+    long long cursor_val;
+    int all_done;                     // the allocator has handed out the last leaf
+    int err;
+};
+constexpr int kOwnNotYet = -3;
+
+__device__ __forceinline__ int wave_min_i32(int v) {
+    v = min(v, lane_partner_i32<0>(v));
+    v = min(v, lane_partner_i32<1>(v));
+    v = min(v, lane_partner_i32<2>(v));
+    v = min(v, lane_partner_i32<3>(v));
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
+template <int S, int NNODE, int NWRK>
+__global__ __launch_bounds__(64 * (NNODE + NWRK + 2)) void select_puct_owner_kernel(SearchDev D, int max_leaves, float *planes) {
+    using G = Geo<S>;
+    using Shared = OwnerShared<S, NNODE, NWRK>;
+    constexpr int A = G::A;
+    constexpr int R = (A + 63) / 64;
+    constexpr int NTHR = 64 * (NNODE + NWRK + 2);
+    constexpr int kSlots = Shared::kSlots;
+    extern __shared__ __attribute__((aligned(16))) unsigned char own_smem[];
+    Shared &sh = *reinterpret_cast<Shared *>(own_smem);
+    const int t = blockIdx.x;
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const RootMeta meta = D.meta[t];
+    const int n0 = meta.num_nodes;
+    const size_t root_ns = (size_t)t * D.N, root_base = root_ns * A;
+    const bool active = D.err[t] == 0 && n0 > 0;
+    if (threadIdx.x < kSlots) {
+        sh.job_seq[threadIdx.x] = 0;
+        sh.slot_done[threadIdx.x] = 0;
+        sh.leaf_ready[threadIdx.x] = 0;
+    }
+    if (threadIdx.x < 64) sh.mail[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < kPipeMaxK; i += NTHR) { sh.done[i] = 0; sh.alloc_child[i] = kOwnNotYet; sh.exp_key[i] = -1; }
+    if (threadIdx.x == 0) {
+        sh.cursor_seq = 0;
+        sh.cursor_val = D.rng_cursor[t];
+        sh.num_nodes = n0;
+        sh.all_done = 0;
+        sh.err = 0;
+    }
+    __syncthreads();
+    // s_memtime accumulators of tree 0 (tg_search_profile with TG_MPIPE_PROF=1; tools/profile_owner.py)
+    const bool prof = D.prof && t == 0;
+    const long long t_begin = prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
+    long long tp = t_begin, pc_busy = 0, pc_wait = 0, pc_items = 0;
+    auto lap = [&](long long &acc) {
+        if (prof) { const long long now = (long long)__builtin_amdgcn_s_memtime(); acc += now - tp; tp = now; }
+    };
+    auto fail = [&](int code, int site = 0) {                       // wave-uniform call; reported once
+        if (lane == 0 && !pipe_load(&sh.err)) {
+            atomicOr(&D.err[t], code | (site << 8));
+            pipe_store(&sh.err, 1);
+        }
+    };
+
+    if (wid == 0) {
+        // ---- the root's owner ------------------------------------------------------------------------
+        __builtin_amdgcn_s_setprio(3);
+        if (active) {
+            int r_vis[R], r_act[R], r_idx[R], r_kref[R], c_vl[R];
+            double r_vsum[R], r_pol[R], c_q[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int i = lane + 64 * r, ii = i < A ? i : A - 1;
+                r_vis[r] = D.ch_visits[root_base + ii];
+                r_act[r] = D.action[root_base + ii];
+                r_idx[r] = D.ch_index[root_base + ii];
+                r_vsum[r] = D.ch_vsum[root_base + ii];
+                r_pol[r] = D.ch_policy[root_base + ii];
+                c_vl[r] = D.ch_vl[root_base + ii];
+                r_kref[r] = -1;
+                const int cnt = r_vis[r] + c_vl[r];
+                c_q[r] = cnt != 0 ? r_vsum[r] / (double)cnt : 0.0;
+            }
+            const int root_nc = D.n_children[root_ns];
+            const int root_total0 = D.n_visits[root_ns] + D.n_vl[root_ns];
+            bool ok = true;
+            int k = 0;
+            for (; k < max_leaves; ++k) {
+                const int slot = k % kSlots;
+                lap(pc_busy);
+                ok = mp_wait_ge(sh, &sh.slot_done[slot], k / kSlots);                 // the slot's last descent is through
+                lap(pc_wait);
+                if (!ok) break;
+                // pucb.py:8-29 with the quotients of the unchanged children remembered (node.py:141-157); every
+                // descent before this one has added one virtual loss to the root (node.py:76-83)
+                const double sq = __dsqrt_rn((double)(root_total0 + k + 1));
+                double best = 0.0;
+                int best_i = -1;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int i = lane + 64 * r;
+                    if (i < root_nc) {
+                        double v = c_q[r] + (r_pol[r] * sq) / (double)(r_vis[r] + c_vl[r] + 1);
+                        if (D.cgos && i == root_nc - 1) v -= 0.1;
+                        if (best_i < 0 || v > best) { best = v; best_i = i; }
+                    }
+                }
+                best_i = wave_argmax_first(best, best_i);
+                const int owner = best_i & 63, oslot = best_i >> 6;
+                int my_move = 0, my_child = 0, my_cnt = 0, my_kref = -1;
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if (r == oslot) { my_move = r_act[r]; my_child = r_idx[r]; my_cnt = r_vis[r] + c_vl[r]; my_kref = r_kref[r]; }
+                const int src = __builtin_amdgcn_readfirstlane(owner);
+                const int e = best_i;
+                const int mv = __builtin_amdgcn_readlane(my_move, src);
+                int child = __builtin_amdgcn_readlane(my_child, src);
+                const int count = __builtin_amdgcn_readlane(my_cnt, src);
+                const int kref = __builtin_amdgcn_readlane(my_kref, src);
+                // two consecutive passes: never descend below (tree.py:224-229)
+                const bool two_pass = meta.moves + 1 > 2 && mv == 0 && meta.prev == 0;
+                const int threshold = two_pass ? 10000000 : 1;
+                const bool leaf = count + 1 < threshold + 1;
+                if (child == kNotExpanded && kref >= 0) child = -2 - kref;           // being allocated by descent kref
+                const bool expands = leaf && child == kNotExpanded;
+                if (!leaf && child == kNotExpanded) { ok = false; break; }           // visited but without a node: never
+                // the virtual loss of this descent, and the quotient it changes
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if (r == oslot) {
+                        if (lane == owner) {
+                            c_vl[r] += 1;
+                            if (expands) r_kref[r] = k;
+                        }
+                        const int cnt = r_vis[r] + c_vl[r];
+                        const double q = cnt != 0 ? r_vsum[r] / (double)cnt : 0.0;
+                        if (lane == owner) c_q[r] = q;
+                    }
+                if (lane == 0) {
+                    sh.moves[slot][0] = (int16_t)mv;
+                    sh.qpath[slot][0] = e;                                           // node 0
+                    if (leaf) {
+                        sh.lm_parent[slot] = 0; sh.lm_edge[slot] = e; sh.lm_child[slot] = child; sh.lm_depth[slot] = 1;
+                        mp_publish(&sh.leaf_ready[slot], k + 1);
+                    } else {
+                        sh.st_node[slot] = child; sh.st_depth[slot] = 1; sh.st_prev[slot] = mv; sh.st_redge[slot] = e;
+                        mp_publish(&sh.mail[slot], ((k + 1) << 8) | (1 + (1 + e) % NNODE));
+                    }
+                }
+            }
+            lap(pc_busy);
+            if (prof && lane == 0) { atomicAdd((unsigned long long *)D.prof + 0, (unsigned long long)pc_busy); atomicAdd((unsigned long long *)D.prof + 1, (unsigned long long)pc_wait); }
+            if (!ok) fail(kErrPipeline, 1);
+            if (ok) {
+                // the root's virtual losses (max_leaves descents, one each) reach the pool here
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int i = lane + 64 * r;
+                    if (i < A) D.ch_vl[root_base + i] = c_vl[r];
+                }
+                if (lane == 0) D.n_vl[root_ns] += max_leaves;
+            }
+        }
+    } else if (wid <= NNODE) {
+        // ---- owners of the nodes below the root --------------------------------------------------------
+        __builtin_amdgcn_s_setprio(2);
+        const int me = wid;
+        int idle = 0;
+        int unf0 = -1, unf1 = -1, unf2 = -1, unf3 = -1, n_unf = 0;   // nodes with stores of this wave possibly still in flight
+        while (active) {
+            // the lowest descent addressed to this wave whose node is ready
+            lap(pc_busy);
+            // Readiness (child index assigned by the allocator, arrays initialised by the worker) is evaluated by all
+            // lanes at once, lane = slot: two descents waiting for the same node read the same flags with the same
+            // instructions - one after the other, the later descent could find ready what the earlier one had just
+            // found pending, and overtake it.
+            const int w = lane < kSlots ? pipe_load(&sh.mail[lane]) : 0;
+            const bool mine = (w & 255) == me;
+            int nd = mine ? sh.st_node[lane] : 0;
+            bool ready = mine;
+            {
+                const bool pending = mine && nd <= -2;
+                const int c = pipe_load(&sh.alloc_child[pending ? -2 - nd : 0]);
+                if (pending) {
+                    if (c == kOwnNotYet) ready = false;
+                    else nd = c;
+                }
+                const bool fresh = ready && nd >= n0;                                 // created in this launch
+                const int dn = pipe_load(&sh.done[fresh ? (int)sh.jobof[nd - n0] : 0]);
+                if (fresh && dn == 0) ready = false;                                  // expansion in flight
+            }
+            const int kmin = wave_min_i32(ready ? (w >> 8) - 1 : 0x7fffffff);
+            const int k = kmin == 0x7fffffff ? -1 : kmin;
+            const int slot = k >= 0 ? k % kSlots : 0;
+            const int node = __builtin_amdgcn_readlane(nd, slot);
+            if (k < 0) {
+                if (pipe_load(&sh.all_done) || pipe_load(&sh.err)) break;
+                if (++idle > kPipeSpinLimit) { fail(kErrPipeline, 2); break; }
+                __builtin_amdgcn_s_sleep(1);
+                continue;
+            }
+            idle = 0;
+            lap(pc_wait);
+            pc_items += 1;
+            const int depth = sh.st_depth[slot], prev = sh.st_prev[slot], redge = sh.st_redge[slot];
+            if (depth >= kPathMax<S>) { fail(kErrPipeline, 3); break; }
+            // This wave's earlier virtual-loss stores have to have landed if they concern this very node (and none of
+            // the loads below may be issued before they have): the nodes written since the last such wait are
+            // remembered - a wait on every visit cost ~1 k cycles of the ~6 k a visit took.
+            if (node == unf0 || node == unf1 || node == unf2 || node == unf3 || n_unf >= 4) {
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                unf0 = unf1 = unf2 = unf3 = -1;
+                n_unf = 0;
+            } else {
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            }
+            if (n_unf == 0) unf0 = node;
+            else if (n_unf == 1) unf1 = node;
+            else if (n_unf == 2) unf2 = node;
+            else unf3 = node;
+            ++n_unf;
+            const EdgePick pick = select_puct<S>(D, t, node, lane);
+            const int e = pick.edge, mv = pick.move;
+            const size_t ns = (size_t)t * D.N + node, base = ns * A;
+            const bool two_pass = meta.moves + depth + 1 > 2 && mv == 0 && prev == 0;   // tree.py:224-229
+            const int threshold = two_pass ? 10000000 : 1;
+            const bool leaf = pick.count + 1 < threshold + 1;
+            int child = pick.child;
+            const int key = (node << 10) | e;
+            if (child == kNotExpanded && pick.count >= 1) {
+                // visited, yet without a node: an earlier descent of this launch is having it allocated
+                int kref = -1;
+                for (int b0 = 0; b0 < k && kref < 0; b0 += 64) {
+                    const unsigned long long hit = __ballot(b0 + lane < k && sh.exp_key[b0 + lane] == key);
+                    if (hit) kref = b0 + __ffsll((long long)hit) - 1;
+                }
+                if (kref < 0) { fail(kErrPipeline, 4); break; }
+                child = -2 - kref;
+            }
+            if (lane == 0) {
+                D.n_vl[ns] = pick.node_vl + 1;                                       // node.py:76-83
+                D.ch_vl[base + e] = pick.edge_vl + 1;
+                sh.moves[slot][depth] = (int16_t)mv;
+                if (depth < kPathCap) sh.qpath[slot][depth] = key;
+                if (leaf) {
+                    if (child == kNotExpanded) sh.exp_key[k] = key;
+                    sh.lm_parent[slot] = node; sh.lm_edge[slot] = e; sh.lm_child[slot] = child; sh.lm_depth[slot] = depth + 1;
+                    sh.mail[slot] = 0;
+                    mp_publish(&sh.leaf_ready[slot], k + 1);
+                } else {
+                    sh.st_node[slot] = child; sh.st_depth[slot] = depth + 1; sh.st_prev[slot] = mv;
+                    mp_publish(&sh.mail[slot], ((k + 1) << 8) | (1 + (depth + 1 + redge) % NNODE));
+                }
+            }
+            wave_sync();
+        }
+        if (prof && lane == 0) {
+            atomicAdd((unsigned long long *)D.prof + 2, (unsigned long long)pc_busy);
+            atomicAdd((unsigned long long *)D.prof + 3, (unsigned long long)pc_wait);
+            atomicAdd((unsigned long long *)D.prof + 4, (unsigned long long)pc_items);
+        }
+    } else if (wid == NNODE + 1) {
+        // ---- the allocator: leaves in descent order ----------------------------------------------------
+        int num_nodes = n0, nexp = 0;
+        bool ok = active;
+        for (int k = 0; ok && k < max_leaves; ++k) {
+            const int slot = k % kSlots;
+            lap(pc_busy);
+            ok = mp_wait_ge(sh, &sh.leaf_ready[slot], k + 1);
+            lap(pc_wait);
+            if (!ok) { fail(kErrPipeline, 5); break; }
+            const int parent = sh.lm_parent[slot], e = sh.lm_edge[slot], depth = sh.lm_depth[slot];
+            int child = sh.lm_child[slot];
+            if (child <= -2) child = sh.alloc_child[-2 - child];                     // an earlier leaf: taken already
+            const int expand = child == kNotExpanded;
+            int xseq = 0;
+            if (expand) {
+                if (num_nodes >= D.N || num_nodes - n0 >= kPipeMaxK) { fail(kErrPoolFull, 6); ok = false; break; }
+                child = num_nodes++;
+                xseq = nexp++;
+            }
+            if (lane == 0) {
+                if (expand) sh.jobof[child - n0] = (int16_t)k;
+                PipeJob &j = sh.job[slot];
+                j.k = k; j.parent = parent; j.edge = e; j.child = child;
+                j.expand = expand; j.xseq = xseq; j.depth = depth;
+                mp_publish(&sh.alloc_child[k], child);
+                mp_publish(&sh.job_seq[slot], k + 1);
+                if (expand) {
+                    __builtin_amdgcn_s_waitcnt(0xC07F);                              // lgkmcnt(0): jobof is in LDS before ...
+                    D.ch_index[((size_t)t * D.N + parent) * A + e] = child;          // ... anybody can find the node here
+                }
+            }
+        }
+        lap(pc_busy);
+        if (lane == 0) {
+            sh.num_nodes = num_nodes;
+            if (ok) mp_publish(&sh.all_done, 1);
+            if (prof) { atomicAdd((unsigned long long *)D.prof + 5, (unsigned long long)pc_busy); atomicAdd((unsigned long long *)D.prof + 6, (unsigned long long)pc_wait); }
+        }
+    } else {
+        // ---- workers: job k on wave k % NWRK ------------------------------------------------------------
+        const int w = wid - NNODE - 2;
+        Lds<S, false> &L = sh.board[w];
+        BoardScalars rootb;
+        int root_to_move;
+        load_root<S>(L, rootb, root_to_move, D, t, lane);
+        for (int k = w; active && k < max_leaves; k += NWRK) {
+            const int slot = k % kSlots;
+            lap(pc_busy);
+            const bool have = mp_wait_ge(sh, &sh.job_seq[slot], k + 1);
+            lap(pc_wait);
+            if (!have) { fail(kErrPipeline, 7); break; }
+            const PipeJob j = sh.job[slot];
+            {
+                // queue entry of leaf k (what the backup reads)
+                const size_t qs = (size_t)t * D.K + k;
+                const int npath = j.depth < kPathCap ? j.depth : kPathCap;
+                if (lane < npath) D.q_path[qs * kPathCap + lane] = sh.qpath[slot][lane];
+                if (lane == 0) {
+                    D.q_node[qs] = j.child;
+                    D.q_pnode[qs] = j.parent;
+                    D.q_pedge[qs] = j.edge;
+                    D.q_depth[qs] = (j.depth <= kPathCap && D.N <= (1 << 21)) ? j.depth : 0;
+                }
+            }
+            reset_work<S>(L, lane);
+            BoardScalars b = rootb;
+            int c = root_to_move;
+            for (int i = 0; i < j.depth; ++i) {
+                put_stone<S>(L, b, sh.moves[slot][i], c, D.zob, lane);
+                c = 3 - c;
+            }
+            if (j.expand) expand_node_pipe<S>(L, b, c, D, t, j.child, j.parent, j.edge, j.xseq, sh, lane);
+            write_planes<S>(L, b, c, planes + ((size_t)t * max_leaves + k) * 6 * G::P, lane);
+            wave_sync();
+            if (lane == 0) {
+                pipe_store(&sh.done[k], 1);                                          // releases the node arrays
+                pipe_store(&sh.slot_done[slot], k / kSlots + 1);
+            }
+        }
+        lap(pc_busy);
+        if (prof && lane == 0) { atomicAdd((unsigned long long *)D.prof + 7, (unsigned long long)pc_busy); atomicAdd((unsigned long long *)D.prof + 8, (unsigned long long)pc_wait); }
+    }
+    __syncthreads();
+    if (prof && threadIdx.x == 0) D.prof[15] += (long long)__builtin_amdgcn_s_memtime() - t_begin;
+    const bool good = active && !sh.err;
+    if (threadIdx.x == 0) {
+        D.meta[t].num_nodes = sh.num_nodes;
+        D.n_leaves[t] = good ? max_leaves : 0;
+        D.rng_cursor[t] = sh.cursor_val;
+    }
+}
+
+template <int S, int NNODE, int NWRK>
+int launch_owner_cfg(const SearchDev &dev, int max_leaves, float *planes, hipStream_t st) {
+    constexpr size_t lds = sizeof(OwnerShared<S, NNODE, NWRK>);
+    static_assert(lds <= 160 * 1024, "LDS");
+    static_assert(NNODE + NWRK + 2 <= 16, "wavefronts per workgroup");
+    static bool configured = false;
+    if (!configured) {
+        TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&select_puct_owner_kernel<S, NNODE, NWRK>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = true;
+    }
+    hipLaunchKernelGGL((select_puct_owner_kernel<S, NNODE, NWRK>), dim3(dev.T), dim3(64 * (NNODE + NWRK + 2)), lds, st, dev,
+                       max_leaves, planes);
+    return TG_OK;
+}
+
+template <int S>
+int launch_owner(const SearchDev &dev, int max_leaves, float *planes, hipStream_t st) {
+    // node owners * 100 + workers (TG_OWNER_CFG: tuning knob)
+    static const int cfg = getenv("TG_OWNER_CFG") ? atoi(getenv("TG_OWNER_CFG")) : 0;
+    if constexpr (S == 9) {
+        if (cfg == 608) return launch_owner_cfg<S, 6, 8>(dev, max_leaves, planes, st);
+        if (cfg == 410) return launch_owner_cfg<S, 4, 10>(dev, max_leaves, planes, st);
+        if (cfg == 311) return launch_owner_cfg<S, 3, 11>(dev, max_leaves, planes, st);
+        return launch_owner_cfg<S, 5, 9>(dev, max_leaves, planes, st);
+    } else {
+        if (cfg == 406) return launch_owner_cfg<S, 4, 6>(dev, max_leaves, planes, st);
+        if (cfg == 704) return launch_owner_cfg<S, 7, 4>(dev, max_leaves, planes, st);
+        return launch_owner_cfg<S, 5, 5>(dev, max_leaves, planes, st);
+    }
+}
+
 // tree.py:273-315 process_mini_batch for the leaves queued by the preceding kernel.
 // Wavefronts of a tree work on disjoint data: waves 1.. write the policies back (lane-parallel,
 // independent per leaf), wave 0 walks the values leaf -> root in leaf order (the float32
@@ -1872,13 +2320,15 @@ struct HalvingScratch {
     double w2[Geo<S>::A + 7];
 };
 
-template <int S>
-__global__ __launch_bounds__(192) void select_gumbel_pipe_kernel(SearchDev D, const int32_t *num_considered,
+template <int S, int NW>
+__global__ __launch_bounds__(64 * (1 + NW)) void select_gumbel_pipe_kernel(SearchDev D, const int32_t *num_considered,
                                                                  const int32_t *max_count, int stride,
                                                                  const int32_t *leaf_off, float *planes) {
     using G = Geo<S>;
     constexpr int A = G::A;
-    __shared__ PipeShared<S> sh;
+    constexpr int kPipeSlots = PipeShared<S, NW>::kSlots;      // (shadows the three-wave kernels' ring size)
+    constexpr int NTHR = 64 * (1 + NW);
+    __shared__ PipeShared<S, NW> sh;
     __shared__ HalvingScratch<S> hs;
     __shared__ int16_t sel_moves[kPathMax<S>];
     __shared__ int sel_path[kPathMax<S>];
@@ -1890,7 +2340,7 @@ __global__ __launch_bounds__(192) void select_gumbel_pipe_kernel(SearchDev D, co
         sh.job_seq[threadIdx.x] = 0;
         sh.slot_done[threadIdx.x] = 0;
     }
-    for (int i = threadIdx.x; i < kPipeMaxK / 32; i += 192) sh.done_bits[i] = 0u;
+    for (int i = threadIdx.x; i < kPipeMaxK / 32; i += NTHR) sh.done_bits[i] = 0u;
     if (threadIdx.x == 0) {
         sh.cursor_seq = 0;
         sh.cursor_val = D.rng_cursor[t];
@@ -2004,12 +2454,26 @@ __global__ __launch_bounds__(192) void select_gumbel_pipe_kernel(SearchDev D, co
         constexpr int kLeafKeys = 64;
         __shared__ int leaf_key[kLeafKeys], leaf_slot[kLeafKeys], leaf_job[kLeafKeys];
         int n_keys = 0;
+        // ... and by root child: the FIRST descent of a phase through a considered root child walks down (memo above)
+        // and queues the leaf; every later one is recognised right after the root choice and becomes a COPY job
+        // without walking: its path is kept here (paths of up to kRootPath levels).  ~100 descents of a phase go
+        // to 2..16 root children, so this is what most of them take: the selector was the slowest wave of a phase.
+        constexpr int kRootMemo = 16, kRootPath = 32;
+        __shared__ int rm_pos[kRootMemo], rm_parent[kRootMemo], rm_edge[kRootMemo], rm_child[kRootMemo], rm_job[kRootMemo],
+            rm_slot[kRootMemo], rm_depth[kRootMemo];
+        __shared__ int rm_path[kRootMemo][kRootPath];
+        int n_rm = 0;
         wave_sync();
-        auto publish = [&](int plane_slot, int parent, int edge, int child, int expand, int xseq, int depth, int src) -> bool {
+        auto publish = [&](int plane_slot, int parent, int edge, int child, int expand, int xseq, int depth, int src,
+                           const int *path_src = nullptr) -> bool {
             if (jid >= kPipeMaxK) return false;
             const int slot = jid % kPipeSlots;
             if (!pipe_wait_ge(&sh.slot_done[slot], jid / kPipeSlots)) return false;
-            for (int i = lane; i < depth; i += 64) { sh.moves[slot][i] = sel_moves[i]; sh.paths[slot][i] = sel_path[i]; }
+            if (path_src) {                                      // COPY job: the worker needs the path only
+                for (int i = lane; i < depth; i += 64) sh.paths[slot][i] = path_src[i];
+            } else {
+                for (int i = lane; i < depth; i += 64) { sh.moves[slot][i] = sel_moves[i]; sh.paths[slot][i] = sel_path[i]; }
+            }
             wave_sync();
             if (lane == 0) {
                 PipeJob &j = sh.job[slot];
@@ -2135,6 +2599,14 @@ __global__ __launch_bounds__(192) void select_gumbel_pipe_kernel(SearchDev D, co
                         e = __builtin_amdgcn_readlane(m_e, owner);
                         root_pos = pos;
                         ++r_added;
+                        const unsigned long long rh = __ballot(lane < n_rm && rm_pos[lane] == pos);
+                        if (rh) {                                         // this root child's leaf is queued already
+                            const int f = __ffsll((long long)rh) - 1;
+                            ok = publish(queued, rm_parent[f], rm_edge[f], rm_child[f], 2, rm_job[f], rm_depth[f], rm_slot[f],
+                                         rm_path[f]);
+                            if (ok) ++queued;
+                            break;
+                        }
                     } else {
                         const int slot = node & (kMemo - 1);
                         if (memo_tag[slot] == node) {
@@ -2175,6 +2647,15 @@ __global__ __launch_bounds__(192) void select_gumbel_pipe_kernel(SearchDev D, co
                             if (n_keys < kLeafKeys) {
                                 if (lane == 0) { leaf_key[n_keys] = key; leaf_slot[n_keys] = queued; leaf_job[n_keys] = jid; }
                                 ++n_keys;
+                                wave_sync();
+                            }
+                            if (n_rm < kRootMemo && depth <= kRootPath && D.N <= (1 << 21)) {
+                                if (lane == 0) {
+                                    rm_pos[n_rm] = root_pos; rm_parent[n_rm] = node; rm_edge[n_rm] = e; rm_child[n_rm] = child;
+                                    rm_job[n_rm] = jid; rm_slot[n_rm] = queued; rm_depth[n_rm] = depth;
+                                }
+                                if (lane < depth) rm_path[n_rm][lane] = sel_path[lane];
+                                ++n_rm;
                                 wave_sync();
                             }
                             ok = publish(queued, node, e, child, 0, 0, depth, -1);
@@ -2230,7 +2711,7 @@ __global__ __launch_bounds__(192) void select_gumbel_pipe_kernel(SearchDev D, co
         BoardScalars rootb;
         int root_to_move;
         load_root<S>(L, rootb, root_to_move, D, t, lane);
-        for (int k = wid - 1; active; k += 2) {
+        for (int k = wid - 1; active; k += NW) {
             const int slot = k % kPipeSlots;
             bool have = false, stalled = true;
             for (int spin = 0; spin < kPipeSpinLimit; ++spin) {
@@ -2932,7 +3413,12 @@ int tg_search_select_puct(tg_search *s, int max_leaves, float *planes_dev, int32
     // few trees: the descents themselves are pipelined over four selector waves (+ four workers); with many
     // trees per CU the three-wave kernel keeps more trees resident
     static const int mpipe_max_trees = getenv("TG_SELECT_MPIPE_TREES") ? atoi(getenv("TG_SELECT_MPIPE_TREES")) : 256;
-    if (pipelined && s->dev.T <= mpipe_max_trees) {
+    // ... or, TG_SELECT_OWNER=1, nodes owned by wavefronts and descents travelling between them
+    const bool owner = getenv("TG_SELECT_OWNER") && atoi(getenv("TG_SELECT_OWNER")) != 0;     // (read per call: tests toggle it)
+    if (pipelined && s->dev.T <= mpipe_max_trees && owner && s->dev.N <= (1 << 21)) {
+        int rc = s->S == 9 ? launch_owner<9>(s->dev, max_leaves, planes_dev, st) : launch_owner<19>(s->dev, max_leaves, planes_dev, st);
+        if (rc) return rc;
+    } else if (pipelined && s->dev.T <= mpipe_max_trees) {
         int rc = s->S == 9 ? launch_mpipe<9>(s->dev, max_leaves, planes_dev, st) : launch_mpipe<19>(s->dev, max_leaves, planes_dev, st);
         if (rc) return rc;
     } else if (pipelined) {
@@ -3171,8 +3657,18 @@ int tg_search_select_gumbel(tg_search *s, const int32_t *num_considered_host, co
     s->packed_leaves = packed;
     const int32_t *off = packed ? s->phase_dev + 2 * (size_t)T : nullptr;
     static const bool force_serial = getenv("TG_SELECT_SERIAL") != nullptr;
-    if (s->S == 9 && !force_serial && limit <= kPipeMaxK / 2)
-        hipLaunchKernelGGL(select_gumbel_pipe_kernel<9>, dim3(T), dim3(192), 0, st, s->dev, s->phase_dev,
+    // workers per tree: two when the trees crowd the CUs (the three-wave workgroup fits next to a forward workgroup),
+    // six when there are CUs to spare (TG_GUMBEL_WORKERS overrides)
+    static const int workers_env = getenv("TG_GUMBEL_WORKERS") ? atoi(getenv("TG_GUMBEL_WORKERS")) : 0;
+    const int workers = workers_env ? workers_env : (T <= 128 ? 6 : 2);
+    if (s->S == 9 && !force_serial && limit <= kPipeMaxK / 2 && workers == 6)
+        hipLaunchKernelGGL((select_gumbel_pipe_kernel<9, 6>), dim3(T), dim3(64 * 7), 0, st, s->dev, s->phase_dev,
+                           s->phase_dev + T, limit, off, planes_dev);
+    else if (s->S == 9 && !force_serial && limit <= kPipeMaxK / 2 && workers == 4)
+        hipLaunchKernelGGL((select_gumbel_pipe_kernel<9, 4>), dim3(T), dim3(64 * 5), 0, st, s->dev, s->phase_dev,
+                           s->phase_dev + T, limit, off, planes_dev);
+    else if (s->S == 9 && !force_serial && limit <= kPipeMaxK / 2)
+        hipLaunchKernelGGL((select_gumbel_pipe_kernel<9, 2>), dim3(T), dim3(192), 0, st, s->dev, s->phase_dev,
                            s->phase_dev + T, limit, off, planes_dev);
     else if (s->S == 9)
         hipLaunchKernelGGL(select_gumbel_kernel<9>, dim3(T), dim3(64), 0, st, s->dev, s->phase_dev,
@@ -3348,8 +3844,8 @@ int tg_search_read_node(tg_search *s, int tree, int node, int32_t *num_children,
     if (head[5]) {
         // another tree's sticky error is reported by the calls that read all trees; this one checks its own
         const int err = head[5];
-        return tg::fail(TG_ERR_OVERFLOW, "tree %d: %s%s", tree, (err & kErrPoolFull) ? "node pool full " : "",
-                        (err & kErrRngEmpty) ? "random window exhausted " : (err & kErrPipeline) ? "selection pipeline stalled or path too deep " : "");
+        return tg::fail(TG_ERR_OVERFLOW, "tree %d: %s%s(err 0x%x)", tree, (err & kErrPoolFull) ? "node pool full " : "",
+                        (err & kErrRngEmpty) ? "random window exhausted " : (err & kErrPipeline) ? "selection pipeline stalled or path too deep " : "", err);
     }
     const int32_t *idx = head + 8, *vis = idx + A, *vl = vis + A, *act = vl + A;
     const double *vsum = reinterpret_cast<const double *>(s->node_host + ints), *pol = vsum + A, *val = pol + A;
