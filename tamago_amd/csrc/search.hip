@@ -2332,6 +2332,20 @@ __global__ __launch_bounds__(64 * (1 + NW)) void select_gumbel_pipe_kernel(Searc
     __shared__ HalvingScratch<S> hs;
     __shared__ int16_t sel_moves[kPathMax<S>];
     __shared__ int sel_path[kPathMax<S>];
+    // Leaves by root child.  ~100 descents of a phase go to 2..16 root children and all descents through one root
+    // child end on the same leaf (nothing moves within a phase).  The root choices of the whole phase are simulated up
+    // front (ballots on a copy of the counters): a root child's FIRST descent gets an entry f (rm_pos = its root child,
+    // rm_slot = its leaf slot), every later descent only `sched[leaf slot] = f`.  The selector then walks the first
+    // descents alone (LEAF jobs; rm_* completed: leaf, path, job).  When the ring has drained, the workers share
+    // the scheduled leaves out among themselves: queue entry, virtual losses of the path, planes copied from the
+    // first leaf's slot - no per-leaf work of the selector, which was the slowest wave of a phase (2.2 k cycles
+    // per repeated descent, 87 of 100).
+    constexpr int kRootMemo = 24, kRootPath = 32;        // (a phase enters at most 16 + 1 root children)
+    __shared__ int rm_pos[kRootMemo], rm_parent[kRootMemo], rm_edge[kRootMemo], rm_child[kRootMemo], rm_job[kRootMemo],
+        rm_slot[kRootMemo], rm_depth[kRootMemo];
+    __shared__ int rm_path[kRootMemo][kRootPath];
+    __shared__ int8_t sched[kPipeMaxK / 2];
+    __shared__ int bulk_n;
     const int t = blockIdx.x;
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const RootMeta meta = D.meta[t];
@@ -2354,6 +2368,15 @@ __global__ __launch_bounds__(64 * (1 + NW)) void select_gumbel_pipe_kernel(Searc
     int num_nodes = n0;
     int queued = 0;
 
+    // s_memtime accumulators of tree 0's selector (tg_search_profile; tools/profile_gumbel.py): 0 set-up (root into
+    // registers, ranking), 1 look-ahead for expansions, 2 descents that walk, 3 descents answered by the root memo,
+    // 4 waiting for a free job slot (inside 1..3), 5 write-back, 6 / 7 descents that walked / did not
+    const bool prof = D.prof && t == 0;
+    const long long t_begin = prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
+    long long tp = t_begin, pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto lap = [&](int i) {
+        if (prof) { const long long now = (long long)__builtin_amdgcn_s_memtime(); pc[i] += now - tp; tp = now; }
+    };
     if (wid == 0) {
         // ---- selector -------------------------------------------------------------------
         // Within a phase nothing backs values up, so (a) the root's score "logit + noise + sigma q" of every child
@@ -2447,28 +2470,16 @@ __global__ __launch_bounds__(64 * (1 + NW)) void select_gumbel_pipe_kernel(Searc
         constexpr int kMemo = 64;
         __shared__ int memo_tag[kMemo], memo_edge[kMemo], memo_move[kMemo], memo_vis[kMemo], memo_child[kMemo];
         for (int i = lane; i < kMemo; i += 64) memo_tag[i] = -1;
-        // leaves already queued in this phase, by (parent node, edge): a sequential-halving phase sends max_count
-        // descents down every considered root child and they all end on the same leaf (the statistics do not move
-        // within a phase), i.e. on the same board - later ones are COPY jobs (planes of the first one's slot)
-        // instead of another replay of the path.  The network still evaluates every queued leaf.
-        constexpr int kLeafKeys = 64;
-        __shared__ int leaf_key[kLeafKeys], leaf_slot[kLeafKeys], leaf_job[kLeafKeys];
-        int n_keys = 0;
-        // ... and by root child: the FIRST descent of a phase through a considered root child walks down (memo above)
-        // and queues the leaf; every later one is recognised right after the root choice and becomes a COPY job
-        // without walking: its path is kept here (paths of up to kRootPath levels).  ~100 descents of a phase go
-        // to 2..16 root children, so this is what most of them take: the selector was the slowest wave of a phase.
-        constexpr int kRootMemo = 16, kRootPath = 32;
-        __shared__ int rm_pos[kRootMemo], rm_parent[kRootMemo], rm_edge[kRootMemo], rm_child[kRootMemo], rm_job[kRootMemo],
-            rm_slot[kRootMemo], rm_depth[kRootMemo];
-        __shared__ int rm_path[kRootMemo][kRootPath];
-        int n_rm = 0;
+        // (leaves by root child: rm_* / sched above.  The network still evaluates every queued leaf.)
+        int n_first = 0, my_first_pos = -1, n_desc = 0;      // entries so far; lane f: entry f's root child; descents so far
         wave_sync();
         auto publish = [&](int plane_slot, int parent, int edge, int child, int expand, int xseq, int depth, int src,
                            const int *path_src = nullptr) -> bool {
             if (jid >= kPipeMaxK) return false;
             const int slot = jid % kPipeSlots;
+            const long long w0 = prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
             if (!pipe_wait_ge(&sh.slot_done[slot], jid / kPipeSlots)) return false;
+            if (prof) pc[4] += (long long)__builtin_amdgcn_s_memtime() - w0;
             if (path_src) {                                      // COPY job: the worker needs the path only
                 for (int i = lane; i < depth; i += 64) sh.paths[slot][i] = path_src[i];
             } else {
@@ -2494,6 +2505,7 @@ __global__ __launch_bounds__(64 * (1 + NW)) void select_gumbel_pipe_kernel(Searc
         // draws in descent order, exactly as before - and nobody waits.  The descents proper then find the children
         // allocated and wait, if at all, for a job that is about to finish.  Subtrees of different root children are
         // disjoint and statistics are constant within a phase, so every choice is what the one-by-one order makes.
+        lap(0);
         if (ok) {
             int s_cnt[R];
             unsigned long long seen[R];
@@ -2519,7 +2531,16 @@ __global__ __launch_bounds__(64 * (1 + NW)) void select_gumbel_pipe_kernel(Searc
                             seen[r] |= 1ull << owner;
                             if (lane == owner) s_cnt[r] += 1;
                         }
-                    if (!first) continue;
+                    const int q = n_desc++;                               // this descent's leaf slot
+                    if (!first) {
+                        const unsigned long long rh = __ballot(lane < n_first && my_first_pos == pos);
+                        if (lane == 0) sched[q] = (int8_t)(__ffsll((long long)rh) - 1);
+                        continue;
+                    }
+                    if (n_first >= kRootMemo) { ok = false; break; }      // (never: <= 17 root children per phase)
+                    if (lane == n_first) my_first_pos = pos;
+                    if (lane == 0) { rm_pos[n_first] = pos; rm_slot[n_first] = q; sched[q] = (int8_t)-1; }
+                    ++n_first;
                     int node = 0, depth = 0;
                     int mv = __builtin_amdgcn_readlane(m_mv, owner);
                     int visits = __builtin_amdgcn_readlane(m_vis, owner);
@@ -2570,43 +2591,36 @@ __global__ __launch_bounds__(64 * (1 + NW)) void select_gumbel_pipe_kernel(Searc
                     }
                 }
             }
+            // every descent adds one virtual loss to its root child (node.py:76-83): the simulated counters are the final ones
+#pragma unroll
+            for (int r = 0; r < R; ++r) r_cnt[r] = s_cnt[r];
+            r_added = n_desc;
         }
-        for (int th = 1; ok && th <= levels; ++th) {
-            for (int j = 0; ok && j < width; ++j) {
+        wave_sync();
+        lap(1);
+        // the first descents proper, in descent order
+        for (int f = 0; ok && f < n_first; ++f) {
+            {
                 if (pipe_load(&sh.err)) { ok = false; break; }
+                const int my_q = rm_slot[f];
                 int node = 0, depth = 0, root_pos = 0;
                 while (ok) {
                     const size_t ns = (size_t)t * D.N + node;
                     const size_t base = ns * A;
                     int e, mv, visits, child;
                     if (node == 0) {
-                        // node.py:324-346 on the rank-ordered register copy: first child under the threshold
-                        int pos = -1;
-#pragma unroll
-                        for (int r = 0; r < R; ++r) {
-                            const unsigned long long under = __ballot(lane + 64 * r < r_nc && r_cnt[r] < th);
-                            if (pos < 0 && under) pos = 64 * r + __ffsll((long long)under) - 1;
-                        }
-                        if (pos < 0) pos = pos0;
+                        // node.py:324-346: the root child this entry was made for (rank-ordered register copy)
+                        const int pos = rm_pos[f];
                         const int owner = pos & 63, rr = pos >> 6;
                         int m_mv = 0, m_vis = 0, m_idx = 0, m_e = 0;
 #pragma unroll
                         for (int r = 0; r < R; ++r)
-                            if (r == rr) { m_mv = r_act[r]; m_vis = r_vis[r]; m_idx = r_idx[r]; m_e = r_edge[r]; if (lane == owner) r_cnt[r] += 1; }
+                            if (r == rr) { m_mv = r_act[r]; m_vis = r_vis[r]; m_idx = r_idx[r]; m_e = r_edge[r]; }
                         mv = __builtin_amdgcn_readlane(m_mv, owner);
                         visits = __builtin_amdgcn_readlane(m_vis, owner);
                         child = __builtin_amdgcn_readlane(m_idx, owner);
                         e = __builtin_amdgcn_readlane(m_e, owner);
                         root_pos = pos;
-                        ++r_added;
-                        const unsigned long long rh = __ballot(lane < n_rm && rm_pos[lane] == pos);
-                        if (rh) {                                         // this root child's leaf is queued already
-                            const int f = __ffsll((long long)rh) - 1;
-                            ok = publish(queued, rm_parent[f], rm_edge[f], rm_child[f], 2, rm_job[f], rm_depth[f], rm_slot[f],
-                                         rm_path[f]);
-                            if (ok) ++queued;
-                            break;
-                        }
                     } else {
                         const int slot = node & (kMemo - 1);
                         if (memo_tag[slot] == node) {
@@ -2638,29 +2652,25 @@ __global__ __launch_bounds__(64 * (1 + NW)) void select_gumbel_pipe_kernel(Searc
                     if (visits < 1) {                                     // tree.py:412-416
                         // the queue entry of this leaf (node to evaluate - still NOT_EXPANDED: node[-1] -, parent, edge,
                         // path) is written by the worker that takes the job
-                        const int key = (node << 10) | e;
-                        const unsigned long long hit = __ballot(lane < n_keys && leaf_key[lane] == key);
-                        if (hit && D.N <= (1 << 21)) {
-                            const int f = __ffsll((long long)hit) - 1;
-                            ok = publish(queued, node, e, child, 2, leaf_job[f], depth, leaf_slot[f]);
+                        const int leaf_jid = jid;
+                        if (depth <= kRootPath) {
+                            // the later descents through this root child: left to the workers (sched)
+                            if (lane == 0) { rm_parent[f] = node; rm_edge[f] = e; rm_child[f] = child; rm_job[f] = leaf_jid; rm_depth[f] = depth; }
+                            if (lane < depth) rm_path[f][lane] = sel_path[lane];
+                            wave_sync();
+                            ok = publish(my_q, node, e, child, 0, 0, depth, -1);
                         } else {
-                            if (n_keys < kLeafKeys) {
-                                if (lane == 0) { leaf_key[n_keys] = key; leaf_slot[n_keys] = queued; leaf_job[n_keys] = jid; }
-                                ++n_keys;
-                                wave_sync();
-                            }
-                            if (n_rm < kRootMemo && depth <= kRootPath && D.N <= (1 << 21)) {
-                                if (lane == 0) {
-                                    rm_pos[n_rm] = root_pos; rm_parent[n_rm] = node; rm_edge[n_rm] = e; rm_child[n_rm] = child;
-                                    rm_job[n_rm] = jid; rm_slot[n_rm] = queued; rm_depth[n_rm] = depth;
+                            // a path too long for rm_path: the later descents become COPY jobs here (planes of this leaf's slot)
+                            ok = publish(my_q, node, e, child, 0, 0, depth, -1);
+                            for (int qq = 0; ok && qq < n_desc; ++qq)
+                                if (sched[qq] == f) {
+                                    ok = publish(qq, node, e, child, 2, leaf_jid, depth, my_q);
+                                    if (lane == 0) sched[qq] = (int8_t)-1;
                                 }
-                                if (lane < depth) rm_path[n_rm][lane] = sel_path[lane];
-                                ++n_rm;
-                                wave_sync();
-                            }
-                            ok = publish(queued, node, e, child, 0, 0, depth, -1);
+                            wave_sync();
                         }
-                        if (ok) ++queued;
+                        lap(2);
+                        if (prof) pc[6] += 1;
                         break;
                     }
                     if (child == kNotExpanded) {                          // tree.py:418-420
@@ -2704,7 +2714,16 @@ __global__ __launch_bounds__(64 * (1 + NW)) void select_gumbel_pipe_kernel(Searc
             if (!(D.err[t] & (kErrPoolFull | kErrRngEmpty))) atomicOr(&D.err[t], kErrPipeline);
             pipe_store(&sh.err, 1);
         }
-        if (lane == 0) pipe_store(&sh.final_count, jid);
+        if (ok) queued = n_desc;                           // every descent has queued one leaf
+        if (lane == 0) {
+            bulk_n = ok ? queued : 0;
+            pipe_store(&sh.final_count, jid);
+        }
+        lap(5);
+        if (prof && lane == 0) {
+            for (int i = 0; i < 8; ++i) D.prof[i] += pc[i];
+            D.prof[15] += (long long)__builtin_amdgcn_s_memtime() - t_begin;
+        }
     } else {
         // ---- workers ---------------------------------------------------------------------
         Lds<S, false> &L = sh.board[wid - 1];
@@ -2772,6 +2791,36 @@ __global__ __launch_bounds__(64 * (1 + NW)) void select_gumbel_pipe_kernel(Searc
                 pipe_set_done(sh, k);
                 pipe_store(&sh.slot_done[slot], k / kPipeSlots + 1);
             }
+        }
+        // the scheduled leaves (see `sched`): leaf slot q of this tree repeats the leaf of root-child entry f
+        const int nq = (active && pipe_load(&sh.final_count) >= 0 && !pipe_load(&sh.err)) ? bulk_n : 0;
+        for (int q = wid - 1; q < nq; q += NW) {
+            const int f = sched[q];
+            if (f < 0) continue;
+            const int depth = rm_depth[f];
+            const size_t qs = (size_t)t * D.K + q;
+            if (lane == 0) {
+                D.q_node[qs] = rm_child[f];
+                D.q_pnode[qs] = rm_parent[f];
+                D.q_pedge[qs] = rm_edge[f];
+                D.q_depth[qs] = depth <= kPathCap ? depth : 0;                     // (entries exist only if N <= 2^21)
+            }
+            if (lane < depth) {
+                const int entry = rm_path[f][lane];
+                if (lane < kPathCap) D.q_path[qs * kPathCap + lane] = entry;
+                if (lane >= 1) {                                                   // node.py:76-83 below the root
+                    const size_t ns = (size_t)t * D.N + (entry >> 10);
+                    atomicAdd(&D.n_vl[ns], 1);
+                    atomicAdd(&D.ch_vl[ns * A + (entry & 1023)], 1);
+                }
+            }
+            if (!pipe_wait_done(sh, rm_job[f])) {                                  // the first leaf's planes are there
+                if (lane == 0) { atomicOr(&D.err[t], kErrPipeline); pipe_store(&sh.err, 1); }
+                break;
+            }
+            const float2 *src = reinterpret_cast<const float2 *>(planes + (leaf_base + rm_slot[f]) * 6 * G::P);
+            float2 *dst = reinterpret_cast<float2 *>(planes + (leaf_base + q) * 6 * G::P);
+            for (int i = lane; i < 3 * G::P; i += 64) dst[i] = src[i];
         }
     }
     __syncthreads();
@@ -3661,13 +3710,14 @@ int tg_search_select_gumbel(tg_search *s, const int32_t *num_considered_host, co
     // six when there are CUs to spare (TG_GUMBEL_WORKERS overrides)
     static const int workers_env = getenv("TG_GUMBEL_WORKERS") ? atoi(getenv("TG_GUMBEL_WORKERS")) : 0;
     const int workers = workers_env ? workers_env : (T <= 128 ? 6 : 2);
-    if (s->S == 9 && !force_serial && limit <= kPipeMaxK / 2 && workers == 6)
+    const bool gpipe = s->S == 9 && !force_serial && limit <= kPipeMaxK / 2 && s->dev.N <= (1 << 21);   // (paths as node << 10 | edge)
+    if (gpipe && workers == 6)
         hipLaunchKernelGGL((select_gumbel_pipe_kernel<9, 6>), dim3(T), dim3(64 * 7), 0, st, s->dev, s->phase_dev,
                            s->phase_dev + T, limit, off, planes_dev);
-    else if (s->S == 9 && !force_serial && limit <= kPipeMaxK / 2 && workers == 4)
+    else if (gpipe && workers == 4)
         hipLaunchKernelGGL((select_gumbel_pipe_kernel<9, 4>), dim3(T), dim3(64 * 5), 0, st, s->dev, s->phase_dev,
                            s->phase_dev + T, limit, off, planes_dev);
-    else if (s->S == 9 && !force_serial && limit <= kPipeMaxK / 2)
+    else if (gpipe)
         hipLaunchKernelGGL((select_gumbel_pipe_kernel<9, 2>), dim3(T), dim3(192), 0, st, s->dev, s->phase_dev,
                            s->phase_dev + T, limit, off, planes_dev);
     else if (s->S == 9)
