@@ -2249,30 +2249,38 @@ __device__ int select_node_halving(Scratch &L, const SearchDev &D, int t, int no
             maxv = max(maxv, vis[r]);
         }
     }
-    mx = wave_max_f64(mx);
     maxv = wave_max_i32(maxv);
-    wave_sync();
+    double mixed;
+    if (nv == 0 && maxv == 0) {
+        // A node nobody has been below (every node a phase creates, when its first descent arrives): all q are 0, so
+        // v_pi is a sum of zeros and mixed = (raw + (0 * 0) / sum_prob) / (0 + 1) = raw bit for bit - the prior's softmax
+        // (an exp pass, three pairwise sums, a division pass) is not needed to know that.
+        mixed = raw;
+    } else {
+        mx = wave_max_f64(mx);
+        wave_sync();
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int i = lane + 64 * r;
-        if (i < nc) L.w1[i] = exp(logit[r] - mx);
-    }
-    wave_sync();
-    const double s1 = np_sum(L.w1, nc);
-    wave_sync();
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int i = lane + 64 * r;
-        if (i < nc) {
-            const double pi = L.w1[i] / s1;
-            L.w1[i] = pi;
-            L.w2[i] = pi * q[r];
+        for (int r = 0; r < R; ++r) {
+            const int i = lane + 64 * r;
+            if (i < nc) L.w1[i] = exp(logit[r] - mx);
         }
+        wave_sync();
+        const double s1 = np_sum(L.w1, nc);
+        wave_sync();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = lane + 64 * r;
+            if (i < nc) {
+                const double pi = L.w1[i] / s1;
+                L.w1[i] = pi;
+                L.w2[i] = pi * q[r];
+            }
+        }
+        wave_sync();
+        const double sum_prob = np_sum(L.w1, nc);
+        const double v_pi = np_sum(L.w2, nc);
+        mixed = (raw + ((double)nv * v_pi) / sum_prob) / ((double)nv + 1.0);
     }
-    wave_sync();
-    const double sum_prob = np_sum(L.w1, nc);
-    const double v_pi = np_sum(L.w2, nc);
-    const double mixed = (raw + ((double)nv * v_pi) / sum_prob) / ((double)nv + 1.0);
     const double sigma = (double)(50 + maxv) * 1.0;
     double il[R];
     double mx2 = -INFINITY;
