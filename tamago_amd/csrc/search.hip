@@ -1960,33 +1960,61 @@ int launch_owner(const SearchDev &dev, int max_leaves, float *planes, hipStream_
 }
 
 // tree.py:273-315 process_mini_batch for the leaves queued by the preceding kernel.
-// Wavefronts of a tree work on disjoint data: waves 1.. write the policies back (lane-parallel,
-// independent per leaf), wave 0 walks the values leaf -> root in leaf order (the float32
-// accumulation order is part of the contract) with the next leaf's scalars already requested.
+// Policies (node.py:86-93 update_policy via the {pos: policy} map of tree.py:287-295) are independent per leaf: the
+// eight waves of a tree take the leaves round-robin.  Values walk leaf -> root in leaf order, and the float32
+// accumulation order is part of the contract - per NODE.  Leaves below different root children touch disjoint nodes,
+// so when every leaf carries its recorded path (q_depth > 0: the pipelined selectors) the leaves are shared out by
+// root edge: wave w backs up, in leaf order, the leaves whose root edge is w mod 8 - every (node, edge) still sees
+// its additions in leaf order.  What all leaves share is the root NODE's float32 value sum: each wave leaves its
+// leaves' root-level values in LDS and one lane adds them up in leaf order at the end.  (One wave doing all leaves one
+// after the other was 0.12-0.19 ms per 256-leaf mini-batch of a single tree and 0.13 ms per Gumbel phase.)
+// Leaves without a recorded path (serial selectors, paths deeper than kPathCap) keep the one-wave walk.
 constexpr int kPolicyWaves = 7;
+constexpr int kBackupCap = 1024;        // leaves per tree the partitioned walk has LDS for
 
 template <int S>
 __global__ __launch_bounds__(64 * (1 + kPolicyWaves)) void backup_kernel(SearchDev D, const float *policy, const float *value,
                                                      int stride, const int32_t *leaf_off, int use_logit) {
     using G = Geo<S>;
     constexpr int A = G::A, W = G::W, P = G::P;
+    constexpr int NWAVE = 1 + kPolicyWaves, NTHR = 64 * NWAVE;
     const int t = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int n = D.n_leaves[t];
     const size_t leaf_base = leaf_off ? (size_t)leaf_off[t] : (size_t)t * stride;
-    __syncthreads();          // both waves have read the leaf count before wave 0 may reset it
-    // the root's statistics are touched by every leaf: wave 0 keeps them in LDS for the whole launch
-    // (256 dependent read-modify-writes through L2 otherwise) and writes them back at the end
+    // the root's statistics are touched by every leaf: they live in LDS for the whole launch
+    // (256 dependent read-modify-writes through L2 otherwise) and are written back at the end
     __shared__ double r_vsum[A];
     __shared__ int r_vis[A], r_vl[A];
     __shared__ float r_nvsum;
     __shared__ int r_nvis, r_nvl;
-    if (wid >= 1) {
-        // node.py:86-93 update_policy via the {pos: policy} map of tree.py:287-295.  Each leaf is a
-        // chain of four dependent loads (queue entry, child count, actions, policy values), and the
-        // leaves are independent: kPolicyWaves waves take them round-robin.  (Gumbel leaves all name
-        // the reference's node[-1], tree.py:412-416: the last pool slot, which has no children unless
-        // the pool is full - an error - so nothing is written for them and their order is immaterial.)
-        for (int k = wid - 1; k < n; k += kPolicyWaves) {
+    __shared__ uint16_t leaf_edge[kBackupCap];     // root edge of leaf k; | 0x8000 once backed up WITHOUT a parent (nothing for the root)
+    __shared__ float rootv[kBackupCap];            // its value at the root's level
+    const size_t rbase = (size_t)t * D.N * A;                     // root = node 0
+    bool part = n > 0 && n <= kBackupCap;
+    if (n > 0) {
+        for (int i = threadIdx.x; i < A; i += NTHR) {
+            r_vsum[i] = D.ch_vsum[rbase + i];
+            r_vis[i] = D.ch_visits[rbase + i];
+            r_vl[i] = D.ch_vl[rbase + i];
+        }
+        if (threadIdx.x == 0) {
+            r_nvsum = D.n_vsum[(size_t)t * D.N];
+            r_nvis = D.n_visits[(size_t)t * D.N];
+            r_nvl = D.n_vl[(size_t)t * D.N];
+        }
+        if (part)
+            for (int k = threadIdx.x; k < n; k += NTHR) {
+                const size_t slot = (size_t)t * D.K + k;
+                if (D.q_depth[slot] > 0 && D.q_pnode[slot] >= 0) leaf_edge[k] = (uint16_t)(D.q_path[slot * kPathCap] & 1023);
+                else part = false;
+            }
+    }
+    part = __syncthreads_and(part) != 0;      // (also: every wave has read the leaf count before anybody resets it)
+    {
+        // policies.  Each leaf is a chain of four dependent loads (queue entry, child count, actions, policy values).
+        // (Gumbel leaves all name the reference's node[-1], tree.py:412-416: the last pool slot, which has no children
+        // unless the pool is full - an error - so nothing is written for them and their order is immaterial.)
+        for (int k = wid; k < n; k += NWAVE) {
             int node = D.q_node[(size_t)t * D.K + k];
             if (node < 0) node = D.N - 1;
             const size_t ns = (size_t)t * D.N + node;
@@ -2005,27 +2033,77 @@ __global__ __launch_bounds__(64 * (1 + kPolicyWaves)) void backup_kernel(SearchD
                 D.ch_policy[base + i] = (double)pv;
             }
         }
-        return;
     }
-    // wave 0.  A leaf whose root->leaf path was recorded by the selector (q_depth > 0) is backed up
-    // with ONE memory round trip: lane i handles level i of the path (all loads of all levels are
-    // independent); a node always sits at the same level, i.e. in the same lane, so updates of a
-    // node shared by consecutive leaves stay in program order.  The value at level j above the
-    // leaf edge is the reference's iterated float32 `value = 1.0 - value`.  Other leaves follow
-    // the parent pointers in lane 0.
-    if (n > 0) {
-        const size_t rbase = (size_t)t * D.N * A;                 // root = node 0
-        for (int i = lane; i < A; i += 64) {
-            r_vsum[i] = D.ch_vsum[rbase + i];
-            r_vis[i] = D.ch_visits[rbase + i];
-            r_vl[i] = D.ch_vl[rbase + i];
+    if (part) {
+        // values, leaves shared out by root edge.  Lane i handles level i of a leaf's recorded path (all loads of all
+        // levels are independent: one memory round trip per leaf); the value at level j above the leaf edge is the
+        // reference's iterated float32 `value = 1.0 - value`.
+        for (int k0 = 0; k0 < n; k0 += 64) {
+            const int kk = k0 + lane;
+            unsigned long long todo = __ballot(kk < n && (int)(leaf_edge[kk < n ? kk : 0] % NWAVE) == wid);
+            while (todo) {
+                const int k = k0 + __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const size_t slot = (size_t)t * D.K + k;
+                int node = D.q_node[slot];
+                const int depth = D.q_depth[slot];
+                const int entry = lane < kPathCap ? D.q_path[slot * kPathCap + lane] : 0;
+                const float *val = value + (leaf_base + k) * 3;
+                const float v0 = val[0], v1 = val[1], v2 = val[2];
+                if (node < 0) node = D.N - 1;
+                if (lane == 0) D.n_raw[(size_t)t * D.N + node] = v1 * 0.5f + v2;   // tree.py:299
+                const float vleaf = v0 + v1 * 0.5f;   // tree.py:302
+                if (lane < depth) {
+                    const int pn = entry >> 10, pe = entry & 1023;
+                    float v = vleaf;
+                    for (int q = depth - 1 - lane; q > 0; --q) v = 1.0f - v;
+                    const size_t cs = (size_t)t * D.N + pn;
+                    const size_t ce = cs * A + pe;
+                    if (lane == depth - 1) D.ch_value[ce] = (double)vleaf;   // set_leaf_value
+                    if (lane == 0) {                                         // level 0 is the root: LDS copy
+                        r_vsum[pe] = (double)((float)r_vsum[pe] + v);
+                        r_vis[pe] += 1;
+                        r_vl[pe] -= 1;
+                        rootv[k] = v;
+                    } else {
+                        const double vs = D.ch_vsum[ce];
+                        const int cv = D.ch_visits[ce], cl = D.ch_vl[ce];
+                        const float ns_ = D.n_vsum[cs];
+                        const int nv = D.n_visits[cs], nl = D.n_vl[cs];
+                        D.ch_vsum[ce] = (double)((float)vs + v);         // float32 accumulation (file header)
+                        D.ch_visits[ce] = cv + 1;
+                        D.ch_vl[ce] = cl - 1;
+                        D.n_vsum[cs] = ns_ + v;
+                        D.n_visits[cs] = nv + 1;
+                        D.n_vl[cs] = nl - 1;
+                    }
+                }
+                // (the next leaf of this wave may pass through the same nodes: a node always sits at the same level, i.e.
+                // in the same lane, so its loads follow these stores in that lane's program order)
+                wave_sync();
+            }
         }
-        if (lane == 0) {
-            r_nvsum = D.n_vsum[(size_t)t * D.N];
-            r_nvis = D.n_visits[(size_t)t * D.N];
-            r_nvl = D.n_vl[(size_t)t * D.N];
+        __syncthreads();
+        if (wid == 0) {
+            // the root node's float32 value sum: every leaf's root-level value, in leaf order
+            float acc = r_nvsum;
+            for (int k0 = 0; k0 < n; k0 += 64) {
+                const float mine = k0 + lane < n ? rootv[k0 + lane] : 0.f;
+                const int cnt = min(64, n - k0);
+                for (int j = 0; j < cnt; ++j)
+                    acc += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), j));
+            }
+            if (lane == 0) {
+                r_nvsum = acc;
+                r_nvis += n;
+                r_nvl -= n;
+            }
         }
-        wave_sync();
+    } else if (wid == 0 && n > 0) {
+        // one wave, all leaves in order.  A leaf whose root->leaf path was recorded by the selector (q_depth > 0) is
+        // backed up with ONE memory round trip: lane i handles level i of the path; a node always sits at the same
+        // level, i.e. in the same lane, so updates of a node shared by consecutive leaves stay in program order.
+        // Other leaves follow the parent pointers in lane 0.  The next leaf's scalars are requested ahead.
         const size_t slot0 = (size_t)t * D.K;
         int node = D.q_node[slot0], cur = D.q_pnode[slot0], e = D.q_pedge[slot0], depth = D.q_depth[slot0];
         int entry = lane < kPathCap ? D.q_path[slot0 * kPathCap + lane] : 0;
@@ -2108,13 +2186,15 @@ __global__ __launch_bounds__(64 * (1 + kPolicyWaves)) void backup_kernel(SearchD
             node = node_n; cur = cur_n; e = e_n; depth = depth_n; entry = entry_n;
             v0 = v0_n; v1 = v1_n; v2 = v2_n;
         }
-        wave_sync();
-        for (int i = lane; i < A; i += 64) {
+    }
+    __syncthreads();
+    if (n > 0) {
+        for (int i = threadIdx.x; i < A; i += NTHR) {
             D.ch_vsum[rbase + i] = r_vsum[i];
             D.ch_visits[rbase + i] = r_vis[i];
             D.ch_vl[rbase + i] = r_vl[i];
         }
-        if (lane == 0) {
+        if (threadIdx.x == 0) {
             D.n_vsum[(size_t)t * D.N] = r_nvsum;
             D.n_visits[(size_t)t * D.N] = r_nvis;
             D.n_vl[(size_t)t * D.N] = r_nvl;
