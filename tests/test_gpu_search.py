@@ -331,15 +331,18 @@ def test_pipelined_selection_equals_serial(cfg):
     import sys
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_select_digest.py")
     outs = []
-    for variant in ("serial", "mpipe", "mpipe", "pipe"):
+    for variant in ("serial", "mpipe", "mpipe", "pipe", "owner", "owner"):
         env = dict(os.environ)
         env.pop("TG_SELECT_SERIAL", None)
         env.pop("TG_SELECT_MPIPE_TREES", None)
+        env.pop("TG_SELECT_OWNER", None)
         if variant == "serial":
             env["TG_SELECT_SERIAL"] = "1"
         elif variant == "pipe":
             env["TG_SELECT_MPIPE_TREES"] = "0"
+        elif variant == "owner":          # select_puct_owner_kernel: nodes owned by wavefronts (opt-in)
+            env["TG_SELECT_OWNER"] = "1"
         res = subprocess.run([sys.executable, script] + cfg.split(), env=env, capture_output=True, text=True, timeout=600)
         assert res.returncode == 0, res.stderr[-2000:]
         outs.append(res.stdout.strip().splitlines()[-1])
-    assert outs[0] == outs[1] == outs[2] == outs[3], outs
+    assert len(set(outs)) == 1, outs
