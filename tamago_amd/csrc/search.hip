@@ -1959,6 +1959,414 @@ int launch_owner(const SearchDev &dev, int max_leaves, float *planes, hipStream_
     }
 }
 
+// ---- PUCT selection of one tree on TWO compute units ------------------------------------------------------------
+// Both kernels above keep ~40 k wave-cycles of work per descent on the 16 waves a workgroup can have - on ONE CU -
+// and 25 k of it is the workers' board work (path replay, candidates, priors, planes), which needs nothing from the
+// selectors but the job.  Here a tree gets two workgroups: blockIdx 2t is the owner kernel's selecting half (root
+// owner, node owners, allocator: now up to 14 node owners), blockIdx 2t + 1 is nothing but workers, on another CU
+// (consecutive workgroups go to different XCDs).  What crosses between them goes through memory with agent-coherent
+// accesses (relaxed agent-scope atomics: sc1 loads and stores, served at the coherence point, no cache maintenance):
+//   * allocator -> workers: the job (header, recorded path, moves) in a per-launch array of entries, one store
+//     instruction per 64 words, `s_waitcnt vmcnt(0)`, then the entry's tag word.  Tags carry the launch number, so
+//     nothing has to be cleared between launches.  All jobs of a launch have their own entry: the selecting half
+//     never waits for the workers to free anything;
+//   * workers -> node owners: "node initialised" (only consulted when a descent steps into a node created in the same
+//     launch): the node's arrays are ordinary stores, so the worker releases at agent scope (L2 write-back) before
+//     it stores the tag, and the owner acquires (invalidate) before it loads the node;
+//   * the random-draw cursor chain stays inside the workers' workgroup (LDS).
+// Bounded spins everywhere (a stall is an error, never a hang).  Same trees bit for bit.
+constexpr int kXwHeader = 8;                                   // words: tag, parent, edge, child, expand, xseq, depth, k
+template <int S>
+constexpr int kXwEntryWords = kXwHeader + kPathCap + kPathMax<S> / 2;
+constexpr int kXwMaxTrees = 16;
+
+__device__ __forceinline__ int xw_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void xw_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <int S, int NNODE>
+struct SplitSelShared {
+    static constexpr int kSlots = 64;                 // descents inside the selecting half: one mail word per lane
+    int16_t moves[kSlots][kPathMax<S>];
+    int qpath[kSlots][kPathCap];
+    int slot_free[kSlots];            // descents this slot has seen through (shipped to the workers)
+    int mail[64];
+    int st_node[kSlots], st_depth[kSlots], st_prev[kSlots], st_redge[kSlots];
+    int lm_parent[kSlots], lm_edge[kSlots], lm_child[kSlots], lm_depth[kSlots];
+    int leaf_ready[kSlots];
+    int sp_child[kSlots], sp_expand[kSlots], sp_xseq[kSlots];   // the allocator's part of the job, for the shipper
+    int ship_ready[kSlots];           // k + 1 once descent k's job can be shipped
+    int alloc_child[kPipeMaxK];
+    int exp_key[kPipeMaxK];
+    int16_t jobof[kPipeMaxK];
+    int num_nodes;
+    int all_done;
+    int err;
+};
+template <int S, int NWRK>
+struct SplitWrkShared {
+    Lds<S, false> board[NWRK];
+    int16_t moves[NWRK][kPathMax<S>];
+    int cursor_seq;
+    long long cursor_val;
+    int err;
+};
+
+template <int S, int NNODE, int NWRK, int NSHIP>
+__global__ __launch_bounds__(1024) void select_puct_split_kernel(SearchDev D, int max_leaves, float *planes, int *xw_job,
+                                                                   int *xw_done, int tag_base, int cap) {
+    using G = Geo<S>;
+    constexpr int A = G::A;
+    constexpr int R = (A + 63) / 64;
+    constexpr int EW = kXwEntryWords<S>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char xw_smem[];
+    const int t = blockIdx.x >> 1;
+    const bool selecting = (blockIdx.x & 1) == 0;
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const RootMeta meta = D.meta[t];
+    const int n0 = meta.num_nodes;
+    const size_t root_ns = (size_t)t * D.N, root_base = root_ns * A;
+    const bool active = D.err[t] == 0 && n0 > 0;
+    int *const jobs = xw_job + (size_t)t * cap * EW;
+    int *const done = xw_done + (size_t)t * cap;
+
+    if (selecting) {
+        using Shared = SplitSelShared<S, NNODE>;
+        constexpr int kSlots = Shared::kSlots;
+        Shared &sh = *reinterpret_cast<Shared *>(xw_smem);
+        if (threadIdx.x < kSlots) {
+            sh.slot_free[threadIdx.x] = 0; sh.leaf_ready[threadIdx.x] = 0; sh.ship_ready[threadIdx.x] = 0; sh.mail[threadIdx.x] = 0;
+        }
+        for (int i = threadIdx.x; i < kPipeMaxK; i += 1024) { sh.alloc_child[i] = kOwnNotYet; sh.exp_key[i] = -1; }
+        if (threadIdx.x == 0) { sh.num_nodes = n0; sh.all_done = 0; sh.err = 0; }
+        __syncthreads();
+        auto fail = [&](int code, int site) {
+            if (lane == 0 && !pipe_load(&sh.err)) {
+                atomicOr(&D.err[t], code | (site << 8));
+                pipe_store(&sh.err, 1);
+            }
+        };
+        if (wid == 0) {
+            // ---- the root's owner (as in select_puct_owner_kernel) ---------------------------------------
+            __builtin_amdgcn_s_setprio(3);
+            if (active) {
+                int r_vis[R], r_act[R], r_idx[R], r_kref[R], c_vl[R];
+                double r_vsum[R], r_pol[R], c_q[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int i = lane + 64 * r, ii = i < A ? i : A - 1;
+                    r_vis[r] = D.ch_visits[root_base + ii];
+                    r_act[r] = D.action[root_base + ii];
+                    r_idx[r] = D.ch_index[root_base + ii];
+                    r_vsum[r] = D.ch_vsum[root_base + ii];
+                    r_pol[r] = D.ch_policy[root_base + ii];
+                    c_vl[r] = D.ch_vl[root_base + ii];
+                    r_kref[r] = -1;
+                    const int cnt = r_vis[r] + c_vl[r];
+                    c_q[r] = cnt != 0 ? r_vsum[r] / (double)cnt : 0.0;
+                }
+                const int root_nc = D.n_children[root_ns];
+                const int root_total0 = D.n_visits[root_ns] + D.n_vl[root_ns];
+                bool ok = true;
+                for (int k = 0; k < max_leaves; ++k) {
+                    const int slot = k % kSlots;
+                    ok = mp_wait_ge(sh, &sh.slot_free[slot], k / kSlots);
+                    if (!ok) break;
+                    const double sq = __dsqrt_rn((double)(root_total0 + k + 1));
+                    double best = 0.0;
+                    int best_i = -1;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const int i = lane + 64 * r;
+                        if (i < root_nc) {
+                            double v = c_q[r] + (r_pol[r] * sq) / (double)(r_vis[r] + c_vl[r] + 1);
+                            if (D.cgos && i == root_nc - 1) v -= 0.1;
+                            if (best_i < 0 || v > best) { best = v; best_i = i; }
+                        }
+                    }
+                    best_i = wave_argmax_first(best, best_i);
+                    const int owner = best_i & 63, oslot = best_i >> 6;
+                    int my_move = 0, my_child = 0, my_cnt = 0, my_kref = -1;
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        if (r == oslot) { my_move = r_act[r]; my_child = r_idx[r]; my_cnt = r_vis[r] + c_vl[r]; my_kref = r_kref[r]; }
+                    const int src = __builtin_amdgcn_readfirstlane(owner);
+                    const int e = best_i;
+                    const int mv = __builtin_amdgcn_readlane(my_move, src);
+                    int child = __builtin_amdgcn_readlane(my_child, src);
+                    const int count = __builtin_amdgcn_readlane(my_cnt, src);
+                    const int kref = __builtin_amdgcn_readlane(my_kref, src);
+                    const bool two_pass = meta.moves + 1 > 2 && mv == 0 && meta.prev == 0;   // tree.py:224-229
+                    const int threshold = two_pass ? 10000000 : 1;
+                    const bool leaf = count + 1 < threshold + 1;
+                    if (child == kNotExpanded && kref >= 0) child = -2 - kref;
+                    const bool expands = leaf && child == kNotExpanded;
+                    if (!leaf && child == kNotExpanded) { ok = false; break; }
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        if (r == oslot) {
+                            if (lane == owner) {
+                                c_vl[r] += 1;
+                                if (expands) r_kref[r] = k;
+                            }
+                            const int cnt = r_vis[r] + c_vl[r];
+                            const double q = cnt != 0 ? r_vsum[r] / (double)cnt : 0.0;
+                            if (lane == owner) c_q[r] = q;
+                        }
+                    if (lane == 0) {
+                        sh.moves[slot][0] = (int16_t)mv;
+                        sh.qpath[slot][0] = e;
+                        if (leaf) {
+                            sh.lm_parent[slot] = 0; sh.lm_edge[slot] = e; sh.lm_child[slot] = child; sh.lm_depth[slot] = 1;
+                            mp_publish(&sh.leaf_ready[slot], k + 1);
+                        } else {
+                            sh.st_node[slot] = child; sh.st_depth[slot] = 1; sh.st_prev[slot] = mv; sh.st_redge[slot] = e;
+                            mp_publish(&sh.mail[slot], ((k + 1) << 8) | (1 + (1 + e) % NNODE));
+                        }
+                    }
+                }
+                if (!ok) fail(kErrPipeline, 1);
+                if (ok) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const int i = lane + 64 * r;
+                        if (i < A) D.ch_vl[root_base + i] = c_vl[r];
+                    }
+                    if (lane == 0) D.n_vl[root_ns] += max_leaves;
+                }
+            }
+        } else if (wid <= NNODE) {
+            // ---- owners of the nodes below the root ----------------------------------------------------
+            __builtin_amdgcn_s_setprio(2);
+            const int me = wid;
+            int idle = 0;
+            int unf0 = -1, unf1 = -1, unf2 = -1, unf3 = -1, n_unf = 0;
+            while (active) {
+                const int w = lane < kSlots ? pipe_load(&sh.mail[lane]) : 0;
+                const bool mine = (w & 255) == me;
+                int nd = mine ? sh.st_node[lane] : 0;
+                bool ready = mine;
+                bool fresh;
+                {
+                    const bool pending = mine && nd <= -2;
+                    const int c = pipe_load(&sh.alloc_child[pending ? -2 - nd : 0]);
+                    if (pending) {
+                        if (c == kOwnNotYet) ready = false;
+                        else nd = c;
+                    }
+                    fresh = ready && nd >= n0;                                    // created in this launch
+                    if (__any(fresh)) {
+                        // initialised by its worker?  (the other workgroup: an agent-coherent load)
+                        const int jk = fresh ? (int)sh.jobof[nd - n0] : 0;
+                        const int dn = xw_load(&done[jk]);
+                        if (fresh && dn != (tag_base | (jk + 1))) ready = false;
+                    }
+                }
+                const int kmin = wave_min_i32(ready ? (w >> 8) - 1 : 0x7fffffff);
+                const int k = kmin == 0x7fffffff ? -1 : kmin;
+                const int slot = k >= 0 ? k % kSlots : 0;
+                const int node = __builtin_amdgcn_readlane(nd, slot);
+                const bool was_fresh = __builtin_amdgcn_readlane((int)fresh, slot) != 0;
+                if (k < 0) {
+                    if (pipe_load(&sh.all_done) || pipe_load(&sh.err)) break;
+                    if (++idle > kPipeSpinLimit / 16) { fail(kErrPipeline, 2); break; }
+                    __builtin_amdgcn_s_sleep(1);
+                    continue;
+                }
+                idle = 0;
+                const int depth = sh.st_depth[slot], prev = sh.st_prev[slot], redge = sh.st_redge[slot];
+                if (depth >= kPathMax<S>) { fail(kErrPipeline, 3); break; }
+                if (was_fresh) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");              // the worker's stores, not a stale line
+                    unf0 = unf1 = unf2 = unf3 = -1;
+                    n_unf = 0;
+                } else if (node == unf0 || node == unf1 || node == unf2 || node == unf3 || n_unf >= 4) {
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                    unf0 = unf1 = unf2 = unf3 = -1;
+                    n_unf = 0;
+                } else {
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                }
+                if (n_unf == 0) unf0 = node;
+                else if (n_unf == 1) unf1 = node;
+                else if (n_unf == 2) unf2 = node;
+                else unf3 = node;
+                ++n_unf;
+                const EdgePick pick = select_puct<S>(D, t, node, lane);
+                const int e = pick.edge, mv = pick.move;
+                const size_t ns = (size_t)t * D.N + node, base = ns * A;
+                const bool two_pass = meta.moves + depth + 1 > 2 && mv == 0 && prev == 0;   // tree.py:224-229
+                const int threshold = two_pass ? 10000000 : 1;
+                const bool leaf = pick.count + 1 < threshold + 1;
+                int child = pick.child;
+                const int key = (node << 10) | e;
+                if (child == kNotExpanded && pick.count >= 1) {
+                    int kref = -1;
+                    for (int b0 = 0; b0 < k && kref < 0; b0 += 64) {
+                        const unsigned long long hit = __ballot(b0 + lane < k && sh.exp_key[b0 + lane] == key);
+                        if (hit) kref = b0 + __ffsll((long long)hit) - 1;
+                    }
+                    if (kref < 0) { fail(kErrPipeline, 4); break; }
+                    child = -2 - kref;
+                }
+                if (lane == 0) {
+                    D.n_vl[ns] = pick.node_vl + 1;                                   // node.py:76-83
+                    D.ch_vl[base + e] = pick.edge_vl + 1;
+                    sh.moves[slot][depth] = (int16_t)mv;
+                    if (depth < kPathCap) sh.qpath[slot][depth] = key;
+                    if (leaf) {
+                        if (child == kNotExpanded) sh.exp_key[k] = key;
+                        sh.lm_parent[slot] = node; sh.lm_edge[slot] = e; sh.lm_child[slot] = child; sh.lm_depth[slot] = depth + 1;
+                        sh.mail[slot] = 0;
+                        mp_publish(&sh.leaf_ready[slot], k + 1);
+                    } else {
+                        sh.st_node[slot] = child; sh.st_depth[slot] = depth + 1; sh.st_prev[slot] = mv;
+                        mp_publish(&sh.mail[slot], ((k + 1) << 8) | (1 + (depth + 1 + redge) % NNODE));
+                    }
+                }
+                wave_sync();
+            }
+        } else if (wid == NNODE + 1) {
+            // ---- the allocator: leaves in descent order (LDS only: what later descents may be waiting for) ----
+            int num_nodes = n0, nexp = 0;
+            bool ok = active;
+            for (int k = 0; ok && k < max_leaves; ++k) {
+                const int slot = k % kSlots;
+                ok = mp_wait_ge(sh, &sh.leaf_ready[slot], k + 1);
+                if (!ok) { fail(kErrPipeline, 5); break; }
+                const int parent = sh.lm_parent[slot], e = sh.lm_edge[slot];
+                int child = sh.lm_child[slot];
+                if (child <= -2) child = sh.alloc_child[-2 - child];
+                const int expand = child == kNotExpanded;
+                int xseq = 0;
+                if (expand) {
+                    if (num_nodes >= D.N || num_nodes - n0 >= kPipeMaxK) { fail(kErrPoolFull, 6); ok = false; break; }
+                    child = num_nodes++;
+                    xseq = nexp++;
+                }
+                if (lane == 0) {
+                    if (expand) sh.jobof[child - n0] = (int16_t)k;
+                    sh.sp_child[slot] = child; sh.sp_expand[slot] = expand; sh.sp_xseq[slot] = xseq;
+                    mp_publish(&sh.alloc_child[k], child);
+                    mp_publish(&sh.ship_ready[slot], k + 1);
+                    if (expand) {
+                        __builtin_amdgcn_s_waitcnt(0xC07F);                          // lgkmcnt(0): jobof is in LDS before ...
+                        D.ch_index[((size_t)t * D.N + parent) * A + e] = child;      // ... anybody can find the node here
+                    }
+                }
+            }
+            if (lane == 0) {
+                sh.num_nodes = num_nodes;
+                if (ok) mp_publish(&sh.all_done, 1);
+            }
+        } else if (wid < NNODE + 2 + NSHIP) {
+            // ---- shippers: job k to the workers' workgroup, on wave k % NSHIP (a store to the coherence point takes
+            //      longer than the root takes for a descent: several jobs are under way at a time) ----
+            const int j = wid - (NNODE + 2);
+            for (int k = j; active && k < max_leaves; k += NSHIP) {
+                const int slot = k % kSlots;
+                if (!mp_wait_ge(sh, &sh.ship_ready[slot], k + 1)) { fail(kErrPipeline, 8); break; }
+                const int depth = sh.lm_depth[slot];
+                int *const entry = jobs + (size_t)k * EW;
+                {
+                    // header (words 1..7), recorded path, moves (two per word): one store per 64 words
+                    int word = 0;
+                    if (lane == 1) word = sh.lm_parent[slot];
+                    else if (lane == 2) word = sh.lm_edge[slot];
+                    else if (lane == 3) word = sh.sp_child[slot];
+                    else if (lane == 4) word = sh.sp_expand[slot];
+                    else if (lane == 5) word = sh.sp_xseq[slot];
+                    else if (lane == 6) word = depth;
+                    else if (lane == 7) word = k;
+                    else if (lane >= kXwHeader && lane < kXwHeader + kPathCap) word = sh.qpath[slot][lane - kXwHeader];
+                    if (lane >= 1 && lane < kXwHeader + kPathCap) xw_store(&entry[lane], word);
+                    for (int jj = lane; 2 * jj < depth; jj += 64) {
+                        const int lo = (unsigned short)sh.moves[slot][2 * jj];
+                        const int hi = 2 * jj + 1 < depth ? (unsigned short)sh.moves[slot][2 * jj + 1] : 0;
+                        xw_store(&entry[kXwHeader + kPathCap + jj], lo | (hi << 16));
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0x0F70);                                  // vmcnt(0): the entry is written ...
+                if (lane == 0) {
+                    xw_store(&entry[0], tag_base | (k + 1));                         // ... before its tag
+                    mp_publish(&sh.slot_free[slot], k / kSlots + 1);
+                }
+            }
+        }
+        __syncthreads();
+        const bool good = active && !sh.err;
+        if (threadIdx.x == 0) {
+            D.meta[t].num_nodes = sh.num_nodes;
+            D.n_leaves[t] = good ? max_leaves : 0;
+        }
+    } else {
+        // ---- the workers' workgroup: job k on wave k % NWRK ----------------------------------------------------
+        using Shared = SplitWrkShared<S, NWRK>;
+        Shared &sh = *reinterpret_cast<Shared *>(xw_smem);
+        if (threadIdx.x == 0) { sh.cursor_seq = 0; sh.cursor_val = D.rng_cursor[t]; sh.err = 0; }
+        __syncthreads();
+        if (wid < NWRK) {
+            const int w = wid;
+            Lds<S, false> &L = sh.board[w];
+            BoardScalars rootb;
+            int root_to_move;
+            load_root<S>(L, rootb, root_to_move, D, t, lane);
+            for (int k = w; active && k < max_leaves; k += NWRK) {
+                const int *const entry = jobs + (size_t)k * EW;
+                bool have = false;
+                for (int spin = 0; spin < kPipeSpinLimit / 16; ++spin) {
+                    if (xw_load(&entry[0]) == (tag_base | (k + 1))) { have = true; break; }
+                    if ((spin & 63) == 63 && (xw_load(&D.err[t]) || pipe_load(&sh.err))) break;   // the other half gave up
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                if (!have) {
+                    if (lane == 0 && !xw_load(&D.err[t])) atomicOr(&D.err[t], kErrPipeline | (7 << 8));
+                    if (lane == 0) pipe_store(&sh.err, 1);
+                    break;
+                }
+                const int hw = lane < kXwHeader + kPathCap ? xw_load(&entry[lane]) : 0;
+                const int parent = __builtin_amdgcn_readlane(hw, 1), edge = __builtin_amdgcn_readlane(hw, 2);
+                const int child = __builtin_amdgcn_readlane(hw, 3), expand = __builtin_amdgcn_readlane(hw, 4);
+                const int xseq = __builtin_amdgcn_readlane(hw, 5), depth = __builtin_amdgcn_readlane(hw, 6);
+                for (int j = lane; 2 * j < depth; j += 64) {
+                    const int mw = xw_load(&entry[kXwHeader + kPathCap + j]);
+                    sh.moves[w][2 * j] = (int16_t)(mw & 0xffff);
+                    if (2 * j + 1 < depth) sh.moves[w][2 * j + 1] = (int16_t)((unsigned)mw >> 16);
+                }
+                {
+                    // queue entry of leaf k (what the backup reads)
+                    const size_t qs = (size_t)t * D.K + k;
+                    const int npath = depth < kPathCap ? depth : kPathCap;
+                    if (lane >= kXwHeader && lane < kXwHeader + npath) D.q_path[qs * kPathCap + lane - kXwHeader] = hw;
+                    if (lane == 0) {
+                        D.q_node[qs] = child;
+                        D.q_pnode[qs] = parent;
+                        D.q_pedge[qs] = edge;
+                        D.q_depth[qs] = (depth <= kPathCap && D.N <= (1 << 21)) ? depth : 0;
+                    }
+                }
+                wave_sync();
+                reset_work<S>(L, lane);
+                BoardScalars b = rootb;
+                int c = root_to_move;
+                for (int i = 0; i < depth; ++i) {
+                    put_stone<S>(L, b, sh.moves[w][i], c, D.zob, lane);
+                    c = 3 - c;
+                }
+                if (expand) expand_node_pipe<S>(L, b, c, D, t, child, parent, edge, xseq, sh, lane);
+                write_planes<S>(L, b, c, planes + ((size_t)t * max_leaves + k) * 6 * G::P, lane);
+                wave_sync();
+                if (expand) {
+                    // the node's arrays reach memory before its "initialised" tag does (a descent of this launch may enter it)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    if (lane == 0) xw_store(&done[k], tag_base | (k + 1));
+                }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) D.rng_cursor[t] = sh.cursor_val;
+    }
+}
+
 // tree.py:273-315 process_mini_batch for the leaves queued by the preceding kernel.
 // Policies (node.py:86-93 update_policy via the {pos: policy} map of tree.py:287-295) are independent per leaf: the
 // eight waves of a tree take the leaves round-robin.  Values walk leaf -> root in leaf order, and the float32
@@ -3106,6 +3514,10 @@ struct tg_search {
     unsigned phase_seq = 0;
     bool packed_leaves = false;
     int32_t *moves_dev = nullptr;
+    // select_puct_split_kernel: job entries and "node initialised" tags that cross between a tree's two workgroups
+    int *xw_job = nullptr, *xw_done = nullptr;
+    int xw_cap = 0;
+    unsigned xw_seq = 0;
     // double-buffered random windows, uploaded on a private copy stream so that the host can
     // prepare mini-batch j+1 while the forward pass of mini-batch j runs
     hipStream_t copy_stream = nullptr;
@@ -3260,6 +3672,54 @@ int grow_fill(const GrowItem &g, size_t trees, size_t n_old, size_t n_new) {
                              row_old, hipMemcpyDeviceToDevice));
     }
     return TG_OK;
+}
+}  // namespace
+
+namespace {
+template <int S, int NNODE, int NWRK, int NSHIP = 3>
+int launch_split_cfg(tg_search *s, int max_leaves, float *planes, hipStream_t st) {
+    constexpr size_t lds_a = sizeof(SplitSelShared<S, NNODE>), lds_b = sizeof(SplitWrkShared<S, NWRK>);
+    constexpr size_t lds = lds_a > lds_b ? lds_a : lds_b;
+    static_assert(lds <= 160 * 1024, "LDS");
+    static_assert(NNODE + 2 + NSHIP <= 16 && NWRK <= 16, "wavefronts per workgroup");
+    const int T = s->dev.T;
+    if (!s->xw_job) {
+        s->xw_cap = s->dev.K < kPipeMaxK ? s->dev.K : kPipeMaxK;
+        int rc = dev_alloc(s, &s->xw_job, (size_t)T * s->xw_cap * kXwEntryWords<S>);
+        if (rc) return rc;
+        if ((rc = dev_alloc(s, &s->xw_done, (size_t)T * s->xw_cap))) return rc;
+    }
+    if ((++s->xw_seq & 0xFFFFFu) == 0) {                 // the launch number in the tags wraps: start from clean buffers
+        TG_HIP(hipMemsetAsync(s->xw_job, 0, (size_t)T * s->xw_cap * kXwEntryWords<S> * sizeof(int), st));
+        TG_HIP(hipMemsetAsync(s->xw_done, 0, (size_t)T * s->xw_cap * sizeof(int), st));
+        s->xw_seq = 1;
+    }
+    static bool configured = false;
+    if (!configured) {
+        TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&select_puct_split_kernel<S, NNODE, NWRK, NSHIP>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = true;
+    }
+    hipLaunchKernelGGL((select_puct_split_kernel<S, NNODE, NWRK, NSHIP>), dim3(2 * T), dim3(1024), lds, st, s->dev, max_leaves, planes,
+                       s->xw_job, s->xw_done, (int)((s->xw_seq & 0xFFFFFu) << 11), s->xw_cap);
+    return TG_OK;
+}
+
+template <int S>
+int launch_split(tg_search *s, int max_leaves, float *planes, hipStream_t st) {
+    // node owners * 100 + workers (TG_SPLIT_CFG: tuning knob)
+    static const int cfg = getenv("TG_SPLIT_CFG") ? atoi(getenv("TG_SPLIT_CFG")) : 0;
+    if constexpr (S == 9) {
+        if (cfg == 616) return launch_split_cfg<S, 6, 16>(s, max_leaves, planes, st);
+        if (cfg == 816) return launch_split_cfg<S, 8, 16>(s, max_leaves, planes, st);
+        if (cfg == 1216) return launch_split_cfg<S, 12, 16, 2>(s, max_leaves, planes, st);
+        if (cfg == 1012) return launch_split_cfg<S, 10, 12>(s, max_leaves, planes, st);
+        return launch_split_cfg<S, 10, 16>(s, max_leaves, planes, st);
+    } else {
+        if (cfg == 607) return launch_split_cfg<S, 6, 7>(s, max_leaves, planes, st);
+        if (cfg == 1207) return launch_split_cfg<S, 12, 7, 2>(s, max_leaves, planes, st);
+        return launch_split_cfg<S, 10, 7>(s, max_leaves, planes, st);
+    }
 }
 }  // namespace
 
@@ -3552,7 +4012,12 @@ int tg_search_select_puct(tg_search *s, int max_leaves, float *planes_dev, int32
     static const int mpipe_max_trees = getenv("TG_SELECT_MPIPE_TREES") ? atoi(getenv("TG_SELECT_MPIPE_TREES")) : 256;
     // ... or, TG_SELECT_OWNER=1, nodes owned by wavefronts and descents travelling between them
     const bool owner = getenv("TG_SELECT_OWNER") && atoi(getenv("TG_SELECT_OWNER")) != 0;     // (read per call: tests toggle it)
-    if (pipelined && s->dev.T <= mpipe_max_trees && owner && s->dev.N <= (1 << 21)) {
+    // ... or, TG_SELECT_SPLIT=1, a second workgroup (on another CU) for the board work of every tree
+    const bool split = getenv("TG_SELECT_SPLIT") && atoi(getenv("TG_SELECT_SPLIT")) != 0;
+    if (pipelined && split && !s->dev.prof && s->dev.T <= kXwMaxTrees && s->dev.N <= (1 << 21)) {
+        int rc = s->S == 9 ? launch_split<9>(s, max_leaves, planes_dev, st) : launch_split<19>(s, max_leaves, planes_dev, st);
+        if (rc) return rc;
+    } else if (pipelined && s->dev.T <= mpipe_max_trees && owner && s->dev.N <= (1 << 21)) {
         int rc = s->S == 9 ? launch_owner<9>(s->dev, max_leaves, planes_dev, st) : launch_owner<19>(s->dev, max_leaves, planes_dev, st);
         if (rc) return rc;
     } else if (pipelined && s->dev.T <= mpipe_max_trees) {

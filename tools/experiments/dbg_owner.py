@@ -8,7 +8,7 @@ size = int(sys.argv[1]) if len(sys.argv) > 1 else 9
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 nb = int(sys.argv[3]) if len(sys.argv) > 3 else 6
 def run(owner):
-    os.environ["TG_SELECT_OWNER"] = "1" if owner else "0"
+    os.environ[os.environ.get("DBG_VAR", "TG_SELECT_OWNER")] = "1" if owner else "0"
     eng = SearchEngine(size, 1, batch * nb + 16, batch, HostEvaluator(StubNet(3), torch.device("cuda:0")), check_superko=True)
     eng.set_root(0, GoBoard(size, 7.0, True), 1, np.random.RandomState(100).get_state())
     eng.root_eval(False)

@@ -9,7 +9,7 @@ size = 9
 brd = load_npz(f"board_s{size}.npz")
 recs = [r for r in load_json(f"trees_s{size}.json") if r["kind"] == "puct"]
 def run(rec, owner):
-    os.environ["TG_SELECT_OWNER"] = "1" if owner else "0"
+    os.environ[os.environ.get("DBG_VAR", "TG_SELECT_OWNER")] = "1" if owner else "0"
     board = product_replay(size, brd["g0_move"], brd["g0_color"], rec["ply"], rec["superko"])
     net = StubNet(salt=rec["seed"])
     tree = MCTSTree(net, tree_size=2048, batch_size=rec["batch"], cgos_mode=rec["cgos"])
