@@ -4012,8 +4012,8 @@ int tg_search_select_puct(tg_search *s, int max_leaves, float *planes_dev, int32
     static const int mpipe_max_trees = getenv("TG_SELECT_MPIPE_TREES") ? atoi(getenv("TG_SELECT_MPIPE_TREES")) : 256;
     // ... or, TG_SELECT_OWNER=1, nodes owned by wavefronts and descents travelling between them
     const bool owner = getenv("TG_SELECT_OWNER") && atoi(getenv("TG_SELECT_OWNER")) != 0;     // (read per call: tests toggle it)
-    // ... or, TG_SELECT_SPLIT=1, a second workgroup (on another CU) for the board work of every tree
-    const bool split = getenv("TG_SELECT_SPLIT") && atoi(getenv("TG_SELECT_SPLIT")) != 0;
+    // up to kXwMaxTrees trees: a second workgroup (on another CU) for the board work of every tree (TG_SELECT_SPLIT=0: off)
+    const bool split = !getenv("TG_SELECT_SPLIT") || atoi(getenv("TG_SELECT_SPLIT")) != 0;
     if (pipelined && split && !s->dev.prof && s->dev.T <= kXwMaxTrees && s->dev.N <= (1 << 21)) {
         int rc = s->S == 9 ? launch_split<9>(s, max_leaves, planes_dev, st) : launch_split<19>(s, max_leaves, planes_dev, st);
         if (rc) return rc;

@@ -320,7 +320,7 @@ def test_search_with_callback_and_ponder():
     assert text.startswith("info move ") and text.endswith("\n")
 
 
-@pytest.mark.parametrize("cfg", ["9 24 64 4", "9 1 256 4", "19 6 32 4"])
+@pytest.mark.parametrize("cfg", ["9 24 64 4", "9 1 256 4", "19 6 32 4", "9 16 64 5"])
 def test_pipelined_selection_equals_serial(cfg):
     """The pipelined PUCT selection kernels - select_puct_mpipe_kernel (descents pipelined over several selector
     waves + board workers, the default up to 256 trees) and select_puct_pipe_kernel (selector + two workers per
@@ -331,11 +331,12 @@ def test_pipelined_selection_equals_serial(cfg):
     import sys
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_select_digest.py")
     outs = []
-    for variant in ("serial", "mpipe", "mpipe", "pipe", "owner", "owner"):
+    for variant in ("serial", "mpipe", "mpipe", "pipe", "owner", "owner", "split", "split"):
         env = dict(os.environ)
         env.pop("TG_SELECT_SERIAL", None)
         env.pop("TG_SELECT_MPIPE_TREES", None)
         env.pop("TG_SELECT_OWNER", None)
+        env["TG_SELECT_SPLIT"] = "1" if variant == "split" else "0"   # select_puct_split_kernel: two workgroups per tree (<= 16 trees)
         if variant == "serial":
             env["TG_SELECT_SERIAL"] = "1"
         elif variant == "pipe":
