@@ -223,8 +223,7 @@ struct tg_net {
     // launches on different streams may overlap on the device and must not share activation images.
     std::mutex scratch_mu;
     std::map<hipStream_t, float *> scratch_by_stream;
-    std::map<hipStream_t, int *> flag_by_stream;      // f16 split kernel: ring of range flags per launch stream
-    std::map<hipStream_t, unsigned> flag_seq_by_stream;   // launches that have taken a flag of that ring
+    std::map<hipStream_t, int *> flag_by_stream;      // f16 split kernel: range flag per launch stream
     size_t scratch_floats = 0;
 };
 

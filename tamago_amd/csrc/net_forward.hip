@@ -632,24 +632,6 @@ int launch_wino8(tg_net *net, const float *planes, int batch, int want_logits, f
     return TG_OK;
 }
 
-// The range flag of a split-operand launch: a clear word of a per-stream ring.  A launch and the fallback queued behind
-// it share a word nobody has touched since the ring was last cleared - one memset per kFlagRing launches instead of one
-// (a 5 us fill kernel and a launch gap) in front of every forward pass.
-constexpr unsigned kFlagRing = 256;
-int range_flag(tg_net *net, hipStream_t st, int **flag) {
-    std::lock_guard<std::mutex> lock(net->scratch_mu);
-    int *&ring = net->flag_by_stream[st];
-    unsigned &seq = net->flag_seq_by_stream[st];
-    if (!ring) {
-        TG_HIP(hipMalloc(reinterpret_cast<void **>(&ring), kFlagRing * sizeof(int)));
-        seq = 0;
-    }
-    if (seq % kFlagRing == 0) TG_HIP(hipMemsetAsync(ring, 0, kFlagRing * sizeof(int), st));   // (earlier users: earlier in this stream)
-    *flag = ring + seq % kFlagRing;
-    ++seq;
-    return TG_OK;
-}
-
 }  // namespace
 
 extern "C" {
@@ -925,9 +907,12 @@ int tg_net_forward_dev(tg_net *net, const float *planes_dev, int batch, int want
             // fp32 Winograd kernel behind it as the range-guard fallback - as at 9x9 below
             int *flag = nullptr;
             {
-                int rc = range_flag(net, st, &flag);
-                if (rc) return rc;
+                std::lock_guard<std::mutex> lock(net->scratch_mu);
+                int *&slot = net->flag_by_stream[st];
+                if (!slot) TG_HIP(hipMalloc(reinterpret_cast<void **>(&slot), sizeof(int)));
+                flag = slot;
             }
+            TG_HIP(hipMemsetAsync(flag, 0, sizeof(int), st));
             int rc = tg::split_forward(net, 1, planes_dev, batch, want_logits, policy_dev, value_dev, flag, st);
             if (rc) return rc;
             return launch_wino8<19, 1, true>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st, flag);
@@ -961,9 +946,12 @@ int tg_net_forward_dev(tg_net *net, const float *planes_dev, int batch, int want
             const int group = batch > net->num_cus ? 3 : 1;
             int *flag = nullptr;
             {
-                int rc = range_flag(net, st, &flag);
-                if (rc) return rc;
+                std::lock_guard<std::mutex> lock(net->scratch_mu);
+                int *&slot = net->flag_by_stream[st];
+                if (!slot) TG_HIP(hipMalloc(reinterpret_cast<void **>(&slot), sizeof(int)));
+                flag = slot;
             }
+            TG_HIP(hipMemsetAsync(flag, 0, sizeof(int), st));
             int rc = pick_w2(9, batch, net->num_cus)
                          ? tg::w2_forward(net, planes_dev, batch, want_logits, policy_dev, value_dev, flag, st)
                          : tg::split_forward(net, group, planes_dev, batch, want_logits, policy_dev, value_dev, flag, st);
