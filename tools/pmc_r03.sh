@@ -11,6 +11,8 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/pmc_r03
 rm -rf $OUT; mkdir -p $OUT
 pass() { dir=$1; shift; cmd=$1; shift; timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$dir -o p -- $cmd > $OUT/$dir.log 2>&1; echo "$dir: rc=$? $(tail -1 $OUT/$dir.log | cut -c1-160)"; }
+# PMC_ONLY=tree: only the tree / featurise passes and the kernel trace (forward sources unchanged: their summaries stay valid)
+if [ "$PMC_ONLY" != "tree" ]; then
 FWD="python $R/tools/bench_net.py 9 65536"
 pass fwd_a "$FWD" SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE
 pass fwd_b "$FWD" SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
@@ -33,6 +35,7 @@ pass f19_a "$F19" SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES GRBM
 pass f19_c "$F19" FETCH_SIZE
 pass f19_d "$F19" WRITE_SIZE
 pass f19_e "$F19" TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_READ_sum
+fi
 TREE="python $R/bench.py --steps 2 --warmup 1 --trees 2048 --no-cpu-baseline --no-legs"
 pass tree_c "$TREE" FETCH_SIZE
 pass tree_d "$TREE" WRITE_SIZE
