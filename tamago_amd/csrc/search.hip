@@ -2422,24 +2422,52 @@ __global__ __launch_bounds__(64 * (1 + kPolicyWaves)) void backup_kernel(SearchD
         // policies.  Each leaf is a chain of four dependent loads (queue entry, child count, actions, policy values).
         // (Gumbel leaves all name the reference's node[-1], tree.py:412-416: the last pool slot, which has no children
         // unless the pool is full - an error - so nothing is written for them and their order is immaterial.)
-        for (int k = wid; k < n; k += NWAVE) {
-            int node = D.q_node[(size_t)t * D.K + k];
-            if (node < 0) node = D.N - 1;
-            const size_t ns = (size_t)t * D.N + node;
-            const size_t base = ns * A;
-            const float *pol = policy + (leaf_base + k) * A;
-            const int nc = D.n_children[ns];
-            for (int i = lane; i < nc; i += 64) {
-                const int pos = D.action[base + i];
-                float pv;
-                if (pos == 0) {
-                    pv = pol[P];
-                    if (use_logit) pv = pv - 0.5f;
-                } else {
-                    pv = pol[(pos / W - 1) * S + (pos % W) - 1];
-                }
-                D.ch_policy[base + i] = (double)pv;
+        // Four leaves of a wave at a time, every stage of the chain for all four before the next stage: the round
+        // trips of the four overlap (one leaf after the other: 32 leaves x 4 round trips = 80 us of a 256-leaf launch).
+        constexpr int U = 4, RP = (A + 63) / 64;
+        for (int k0 = wid; k0 < n; k0 += U * NWAVE) {
+            int node[U], nc[U];
+            bool live[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = k0 + u * NWAVE;
+                live[u] = k < n;
+                node[u] = live[u] ? D.q_node[(size_t)t * D.K + k] : 0;
             }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (node[u] < 0) node[u] = D.N - 1;
+                nc[u] = live[u] ? D.n_children[(size_t)t * D.N + node[u]] : 0;
+            }
+            int pos[U][RP];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int r = 0; r < RP; ++r) {
+                    const int i = lane + 64 * r;
+                    pos[u][r] = i < nc[u] ? (int)D.action[((size_t)t * D.N + node[u]) * A + i] : -1;
+                }
+            float pv[U][RP];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float *pol = policy + (leaf_base + k0 + u * NWAVE) * A;
+#pragma unroll
+                for (int r = 0; r < RP; ++r) {
+                    const int ps = pos[u][r];
+                    pv[u][r] = 0.f;
+                    if (ps == 0) {
+                        pv[u][r] = pol[P];
+                        if (use_logit) pv[u][r] = pv[u][r] - 0.5f;
+                    } else if (ps > 0) {
+                        pv[u][r] = pol[(ps / W - 1) * S + (ps % W) - 1];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int r = 0; r < RP; ++r)
+                    if (pos[u][r] >= 0) D.ch_policy[((size_t)t * D.N + node[u]) * A + lane + 64 * r] = (double)pv[u][r];
         }
     }
     if (part) {
