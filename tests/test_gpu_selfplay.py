@@ -96,3 +96,25 @@ def test_one_call_per_move_path_equals_the_phase_by_phase_path(tmp_path):
     assert a == b and a["games"] == 10
     for i in idx:
         assert open(fast / f"{i}.sgf").read() == open(slow / f"{i}.sgf").read(), i
+
+
+def test_gumbel_kernel_variants_write_the_same_games():
+    """select_gumbel_pipe_kernel with two, four and six workers per tree (six is the default up to 128 trees; the
+    repeated descents of a phase are shared out among the workers) and the one-wavefront kernel
+    (TG_SELECT_SERIAL=1) play byte-identical games: 8 lock-step boards, 64 simulations per move."""
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_gumbel_games.py")
+    outs = []
+    for variant in ("serial", "2", "4", "6"):
+        env = dict(os.environ)
+        env.pop("TG_SELECT_SERIAL", None)
+        env.pop("TG_GUMBEL_WORKERS", None)
+        if variant == "serial":
+            env["TG_SELECT_SERIAL"] = "1"
+        else:
+            env["TG_GUMBEL_WORKERS"] = variant
+        res = subprocess.run([sys.executable, script, "8", "12", "64"], env=env, capture_output=True, text=True, timeout=900)
+        assert res.returncode == 0, res.stderr[-2000:]
+        outs.append(res.stdout.strip().splitlines()[-1])
+    assert len(set(outs)) == 1, outs
