@@ -12,8 +12,8 @@ OUT=$R/gpurun_out/pmc_r03
 rm -rf $OUT; mkdir -p $OUT
 pass() { dir=$1; shift; cmd=$1; shift; timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$dir -o p -- $cmd > $OUT/$dir.log 2>&1; echo "$dir: rc=$? $(tail -1 $OUT/$dir.log | cut -c1-160)"; }
 # PMC_ONLY=tree: only the tree / featurise passes and the kernel trace (forward sources unchanged: their summaries stay valid)
-if [ "$PMC_ONLY" != "tree" ]; then
 FWD="python $R/tools/bench_net.py 9 65536"
+if [ "$PMC_ONLY" != "tree" ]; then
 pass fwd_a "$FWD" SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE
 pass fwd_b "$FWD" SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
 pass fwd_c "$FWD" FETCH_SIZE
@@ -29,6 +29,19 @@ pass w2_d "$FWD" WRITE_SIZE
 pass w2_e "$FWD" TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_READ_sum
 pass w2_f "$FWD" TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_BUSY_avr
 unset TG_FWD_ALGO
+fi
+# the exact-fp32 Winograd kernel (TG_FWD_ALGO=wino: bench.py's fp32_exact leg) on the same batch
+if [ "$PMC_ONLY" != "tree" ] || [ "$PMC_WINO" = "1" ]; then
+export TG_FWD_ALGO=wino
+pass wn_a "$FWD" SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE
+pass wn_b "$FWD" SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
+pass wn_c "$FWD" FETCH_SIZE
+pass wn_d "$FWD" WRITE_SIZE
+pass wn_e "$FWD" TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_READ_sum
+pass wn_f "$FWD" TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_BUSY_avr
+unset TG_FWD_ALGO
+fi
+if [ "$PMC_ONLY" != "tree" ]; then
 # 19x19 split kernel
 F19="python $R/tools/bench_net.py 19 4096"
 pass f19_a "$F19" SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE

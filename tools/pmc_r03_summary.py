@@ -58,6 +58,9 @@ def main(out):
     per2, times2 = counters(out, ["w2_a", "w2_b", "w2_c", "w2_d", "w2_e", "w2_f"], ["dualnet_fwd_w2"])
     per.update(per2)
     times.update(times2)
+    per3, times3 = counters(out, ["wn_a", "wn_b", "wn_c", "wn_d", "wn_e", "wn_f"], ["dualnet_fwd_wino8"])
+    per.update(per3)
+    times.update(times3)
     per19, times19 = counters(out, ["f19_a", "f19_c", "f19_d", "f19_e"], ["dualnet_fwd_split_kernel<19"])
     for kname, c in per19.items():
         if "GRBM_GUI_ACTIVE" not in c:
