@@ -923,13 +923,13 @@ __device__ __forceinline__ bool pipe_wait_done(const Sh &sh, int k) {
     return false;
 }
 
+template <int S, typename LT>
+__device__ void expand_fill(LT &L, const SearchDev &D, int t, int node, int parent, int pedge, int n, long long cur, int lane);
+
 // expand_node for a worker: node index given by the selector, draws reserved through the chain
 template <int S, typename LT, typename Sh>
 __device__ bool expand_node_pipe(LT &L, const BoardScalars &b, int to_move, const SearchDev &D, int t,
                                  int node, int parent, int pedge, int xseq, Sh &sh, int lane) {
-    using G = Geo<S>;
-    constexpr int A = G::A;
-    constexpr int R = (A + 63) / 64;
     const int n = gen_candidates<S>(L, b, to_move, D, lane);
     bool ok = pipe_wait_ge(&sh.cursor_seq, xseq);
     const long long cur = sh.cursor_val;
@@ -945,6 +945,16 @@ __device__ bool expand_node_pipe(LT &L, const BoardScalars &b, int to_move, cons
         sh.cursor_val = cur + n;
         pipe_store(&sh.cursor_seq, xseq + 1);
     }
+    expand_fill<S>(L, D, t, node, parent, pedge, n, cur, lane);
+    return true;
+}
+
+// the second half of an expansion: prior from the n draws at stream position `cur`, the node's arrays
+template <int S, typename LT>
+__device__ void expand_fill(LT &L, const SearchDev &D, int t, int node, int parent, int pedge, int n, long long cur, int lane) {
+    using G = Geo<S>;
+    constexpr int A = G::A;
+    constexpr int R = (A + 63) / 64;
     const double *e = D.rng + (size_t)t * D.rng_cap;
     double mine[R];
 #pragma unroll
@@ -981,7 +991,6 @@ __device__ bool expand_node_pipe(LT &L, const BoardScalars &b, int to_move, cons
         D.n_pedge[ns] = pedge;
     }
     wave_sync();
-    return true;
 }
 
 template <int S>
@@ -1999,6 +2008,7 @@ struct SplitSelShared {
     int exp_key[kPipeMaxK];
     int16_t jobof[kPipeMaxK];
     int num_nodes;
+    int nexp_total;                   // expansions of the launch (once all_done)
     int all_done;
     int err;
 };
@@ -2011,16 +2021,22 @@ struct SplitWrkShared {
     int err;
 };
 
-template <int S, int NNODE, int NWRK, int NSHIP>
+// NWG workgroups of workers.  With more than one, the draw cursor (expansion x takes the n_x draws behind those of
+// expansions 0 .. x - 1) cannot be chained through one workgroup's LDS: a worker reports n_x once its candidates are
+// counted, a wave of the selecting half adds the counts up in expansion order and hands out the offsets, and the worker
+// - which has written its planes meanwhile - fills in the prior when its offset is there.
+template <int S, int NNODE, int NWRK, int NSHIP, int NWG>
 __global__ __launch_bounds__(1024) void select_puct_split_kernel(SearchDev D, int max_leaves, float *planes, int *xw_job,
-                                                                   int *xw_done, int tag_base, int cap) {
+                                                                   int *xw_done, int *xw_n, unsigned long long *xw_off,
+                                                                   int tag_base, int cap) {
     using G = Geo<S>;
     constexpr int A = G::A;
     constexpr int R = (A + 63) / 64;
     constexpr int EW = kXwEntryWords<S>;
     extern __shared__ __attribute__((aligned(16))) unsigned char xw_smem[];
-    const int t = blockIdx.x >> 1;
-    const bool selecting = (blockIdx.x & 1) == 0;
+    const int t = blockIdx.x / (1 + NWG);
+    const int role = blockIdx.x % (1 + NWG);          // 0: selecting half, 1 .. NWG: workers
+    const bool selecting = role == 0;
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const RootMeta meta = D.meta[t];
     const int n0 = meta.num_nodes;
@@ -2028,6 +2044,9 @@ __global__ __launch_bounds__(1024) void select_puct_split_kernel(SearchDev D, in
     const bool active = D.err[t] == 0 && n0 > 0;
     int *const jobs = xw_job + (size_t)t * cap * EW;
     int *const done = xw_done + (size_t)t * cap;
+    int *const xn = xw_n + (size_t)t * cap;                                   // candidates of expansion x (tagged)
+    unsigned long long *const xoff = xw_off + (size_t)t * (cap + 1);          // draws before expansion x (tagged)
+    const long long cursor0 = D.rng_cursor[t];
 
     if (selecting) {
         using Shared = SplitSelShared<S, NNODE>;
@@ -2256,6 +2275,7 @@ __global__ __launch_bounds__(1024) void select_puct_split_kernel(SearchDev D, in
             }
             if (lane == 0) {
                 sh.num_nodes = num_nodes;
+                sh.nexp_total = nexp;
                 if (ok) mp_publish(&sh.all_done, 1);
             }
         } else if (wid < NNODE + 2 + NSHIP) {
@@ -2292,6 +2312,33 @@ __global__ __launch_bounds__(1024) void select_puct_split_kernel(SearchDev D, in
                 }
             }
         }
+        if (NWG > 1 && wid == NNODE + 2 + NSHIP && active) {
+            // ---- the draw cursor: counts in, offsets out, in expansion order ----
+            unsigned off = 0;
+            bool ok = true;
+            if (lane == 0) __hip_atomic_store(&xoff[0], ((unsigned long long)(unsigned)tag_base << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int x = 0; ok; ++x) {
+                int v = 0;
+                bool have = false;
+                for (int spin = 0; spin < kPipeSpinLimit / 16; ++spin) {
+                    if (x < cap) {
+                        v = xw_load(&xn[x]);
+                        if ((v & ~2047) == tag_base && (v & 2047) != 0) { have = true; break; }
+                    }
+                    if (pipe_load(&sh.all_done) && x >= sh.nexp_total) break;   // every expansion has been through
+                    if (pipe_load(&sh.err) || ((spin & 63) == 63 && xw_load(&D.err[t]))) { ok = false; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (!have) {
+                    if (ok && !(pipe_load(&sh.all_done) && x >= sh.nexp_total)) { fail(kErrPipeline, 9); ok = false; }
+                    break;
+                }
+                off += (unsigned)((v & 2047) - 1);
+                if (lane == 0 && x + 1 <= cap)
+                    __hip_atomic_store(&xoff[x + 1], ((unsigned long long)(unsigned)tag_base << 32) | off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (ok && lane == 0) D.rng_cursor[t] = cursor0 + (long long)off;
+        }
         __syncthreads();
         const bool good = active && !sh.err;
         if (threadIdx.x == 0) {
@@ -2310,7 +2357,7 @@ __global__ __launch_bounds__(1024) void select_puct_split_kernel(SearchDev D, in
             BoardScalars rootb;
             int root_to_move;
             load_root<S>(L, rootb, root_to_move, D, t, lane);
-            for (int k = w; active && k < max_leaves; k += NWRK) {
+            for (int k = (role - 1) * NWRK + w; active && k < max_leaves; k += NWG * NWRK) {
                 const int *const entry = jobs + (size_t)k * EW;
                 bool have = false;
                 for (int spin = 0; spin < kPipeSpinLimit / 16; ++spin) {
@@ -2352,8 +2399,37 @@ __global__ __launch_bounds__(1024) void select_puct_split_kernel(SearchDev D, in
                     put_stone<S>(L, b, sh.moves[w][i], c, D.zob, lane);
                     c = 3 - c;
                 }
-                if (expand) expand_node_pipe<S>(L, b, c, D, t, child, parent, edge, xseq, sh, lane);
-                write_planes<S>(L, b, c, planes + ((size_t)t * max_leaves + k) * 6 * G::P, lane);
+                if constexpr (NWG == 1) {
+                    if (expand) expand_node_pipe<S>(L, b, c, D, t, child, parent, edge, xseq, sh, lane);
+                    write_planes<S>(L, b, c, planes + ((size_t)t * max_leaves + k) * 6 * G::P, lane);
+                } else {
+                    int n = 0;
+                    if (expand) {
+                        n = gen_candidates<S>(L, b, c, D, lane);
+                        if (lane == 0) xw_store(&xn[xseq], tag_base | (n + 1));
+                    }
+                    write_planes<S>(L, b, c, planes + ((size_t)t * max_leaves + k) * 6 * G::P, lane);
+                    if (expand) {
+                        unsigned long long ov = 0;
+                        bool got = false;
+                        for (int spin = 0; spin < kPipeSpinLimit / 16; ++spin) {
+                            ov = __hip_atomic_load(&xoff[xseq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if ((unsigned)(ov >> 32) == (unsigned)tag_base) { got = true; break; }
+                            if ((spin & 63) == 63 && (xw_load(&D.err[t]) || pipe_load(&sh.err))) break;
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                        const long long cur = cursor0 + (long long)(unsigned)ov;
+                        if (!got || cur + n > D.rng_cap) {
+                            if (lane == 0) {
+                                if (!got) { if (!xw_load(&D.err[t])) atomicOr(&D.err[t], kErrPipeline | (10 << 8)); }
+                                else atomicOr(&D.err[t], kErrRngEmpty);
+                                pipe_store(&sh.err, 1);
+                            }
+                            break;
+                        }
+                        expand_fill<S>(L, D, t, child, parent, edge, n, cur, lane);
+                    }
+                }
                 wave_sync();
                 if (expand) {
                     // the node's arrays reach memory before its "initialised" tag does (a descent of this launch may enter it)
@@ -2363,7 +2439,7 @@ __global__ __launch_bounds__(1024) void select_puct_split_kernel(SearchDev D, in
             }
         }
         __syncthreads();
-        if (threadIdx.x == 0) D.rng_cursor[t] = sh.cursor_val;
+        if (NWG == 1 && threadIdx.x == 0) D.rng_cursor[t] = sh.cursor_val;
     }
 }
 
@@ -3543,7 +3619,8 @@ struct tg_search {
     bool packed_leaves = false;
     int32_t *moves_dev = nullptr;
     // select_puct_split_kernel: job entries and "node initialised" tags that cross between a tree's two workgroups
-    int *xw_job = nullptr, *xw_done = nullptr;
+    int *xw_job = nullptr, *xw_done = nullptr, *xw_n = nullptr;
+    unsigned long long *xw_off = nullptr;
     int xw_cap = 0;
     unsigned xw_seq = 0;
     // double-buffered random windows, uploaded on a private copy stream so that the host can
@@ -3704,32 +3781,36 @@ int grow_fill(const GrowItem &g, size_t trees, size_t n_old, size_t n_new) {
 }  // namespace
 
 namespace {
-template <int S, int NNODE, int NWRK, int NSHIP = 3>
+template <int S, int NNODE, int NWRK, int NSHIP = 3, int NWG = 1>
 int launch_split_cfg(tg_search *s, int max_leaves, float *planes, hipStream_t st) {
     constexpr size_t lds_a = sizeof(SplitSelShared<S, NNODE>), lds_b = sizeof(SplitWrkShared<S, NWRK>);
     constexpr size_t lds = lds_a > lds_b ? lds_a : lds_b;
     static_assert(lds <= 160 * 1024, "LDS");
-    static_assert(NNODE + 2 + NSHIP <= 16 && NWRK <= 16, "wavefronts per workgroup");
+    static_assert(NNODE + 2 + NSHIP + (NWG > 1 ? 1 : 0) <= 16 && NWRK <= 16, "wavefronts per workgroup");
     const int T = s->dev.T;
     if (!s->xw_job) {
         s->xw_cap = s->dev.K < kPipeMaxK ? s->dev.K : kPipeMaxK;
         int rc = dev_alloc(s, &s->xw_job, (size_t)T * s->xw_cap * kXwEntryWords<S>);
         if (rc) return rc;
         if ((rc = dev_alloc(s, &s->xw_done, (size_t)T * s->xw_cap))) return rc;
+        if ((rc = dev_alloc(s, &s->xw_n, (size_t)T * s->xw_cap))) return rc;
+        if ((rc = dev_alloc(s, &s->xw_off, (size_t)T * (s->xw_cap + 1)))) return rc;
     }
     if ((++s->xw_seq & 0xFFFFFu) == 0) {                 // the launch number in the tags wraps: start from clean buffers
         TG_HIP(hipMemsetAsync(s->xw_job, 0, (size_t)T * s->xw_cap * kXwEntryWords<S> * sizeof(int), st));
         TG_HIP(hipMemsetAsync(s->xw_done, 0, (size_t)T * s->xw_cap * sizeof(int), st));
+        TG_HIP(hipMemsetAsync(s->xw_n, 0, (size_t)T * s->xw_cap * sizeof(int), st));
+        TG_HIP(hipMemsetAsync(s->xw_off, 0, (size_t)T * (s->xw_cap + 1) * sizeof(unsigned long long), st));
         s->xw_seq = 1;
     }
     static bool configured = false;
     if (!configured) {
-        TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&select_puct_split_kernel<S, NNODE, NWRK, NSHIP>),
+        TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&select_puct_split_kernel<S, NNODE, NWRK, NSHIP, NWG>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = true;
     }
-    hipLaunchKernelGGL((select_puct_split_kernel<S, NNODE, NWRK, NSHIP>), dim3(2 * T), dim3(1024), lds, st, s->dev, max_leaves, planes,
-                       s->xw_job, s->xw_done, (int)((s->xw_seq & 0xFFFFFu) << 11), s->xw_cap);
+    hipLaunchKernelGGL((select_puct_split_kernel<S, NNODE, NWRK, NSHIP, NWG>), dim3((1 + NWG) * T), dim3(1024), lds, st, s->dev,
+                       max_leaves, planes, s->xw_job, s->xw_done, s->xw_n, s->xw_off, (int)((s->xw_seq & 0xFFFFFu) << 11), s->xw_cap);
     return TG_OK;
 }
 
@@ -3742,11 +3823,15 @@ int launch_split(tg_search *s, int max_leaves, float *planes, hipStream_t st) {
         if (cfg == 816) return launch_split_cfg<S, 8, 16>(s, max_leaves, planes, st);
         if (cfg == 1216) return launch_split_cfg<S, 12, 16, 2>(s, max_leaves, planes, st);
         if (cfg == 1012) return launch_split_cfg<S, 10, 12>(s, max_leaves, planes, st);
-        return launch_split_cfg<S, 10, 16>(s, max_leaves, planes, st);
+        if (cfg == 11016) return launch_split_cfg<S, 10, 16, 3, 1>(s, max_leaves, planes, st);    // one workgroup of workers
+        if (cfg == 31016) return launch_split_cfg<S, 10, 16, 3, 3>(s, max_leaves, planes, st);
+        return launch_split_cfg<S, 10, 16, 3, 2>(s, max_leaves, planes, st);
     } else {
         if (cfg == 607) return launch_split_cfg<S, 6, 7>(s, max_leaves, planes, st);
         if (cfg == 1207) return launch_split_cfg<S, 12, 7, 2>(s, max_leaves, planes, st);
-        return launch_split_cfg<S, 10, 7>(s, max_leaves, planes, st);
+        if (cfg == 11007) return launch_split_cfg<S, 10, 7, 3, 1>(s, max_leaves, planes, st);
+        if (cfg == 31007) return launch_split_cfg<S, 10, 7, 3, 3>(s, max_leaves, planes, st);
+        return launch_split_cfg<S, 10, 7, 3, 2>(s, max_leaves, planes, st);
     }
 }
 }  // namespace
