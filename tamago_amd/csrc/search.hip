@@ -1968,21 +1968,23 @@ int launch_owner(const SearchDev &dev, int max_leaves, float *planes, hipStream_
     }
 }
 
-// ---- PUCT selection of one tree on TWO compute units ------------------------------------------------------------
+// ---- PUCT selection of one tree on SEVERAL compute units -----------------------------------------------------------
 // Both kernels above keep ~40 k wave-cycles of work per descent on the 16 waves a workgroup can have - on ONE CU -
 // and 25 k of it is the workers' board work (path replay, candidates, priors, planes), which needs nothing from the
-// selectors but the job.  Here a tree gets two workgroups: blockIdx 2t is the owner kernel's selecting half (root
-// owner, node owners, allocator: now up to 14 node owners), blockIdx 2t + 1 is nothing but workers, on another CU
-// (consecutive workgroups go to different XCDs).  What crosses between them goes through memory with agent-coherent
+// selectors but the job.  Here a tree gets 1 + NWG workgroups: the first is the owner kernel's selecting half (root
+// owner, node owners, allocator, plus "shippers" and the draw cursor), the others are nothing but workers, on other
+// CUs (consecutive workgroups go to different XCDs).  What crosses between them goes through memory with agent-coherent
 // accesses (relaxed agent-scope atomics: sc1 loads and stores, served at the coherence point, no cache maintenance):
-//   * allocator -> workers: the job (header, recorded path, moves) in a per-launch array of entries, one store
+//   * shippers -> workers: the job (header, recorded path, moves) in a per-launch array of entries, one store
 //     instruction per 64 words, `s_waitcnt vmcnt(0)`, then the entry's tag word.  Tags carry the launch number, so
 //     nothing has to be cleared between launches.  All jobs of a launch have their own entry: the selecting half
-//     never waits for the workers to free anything;
+//     never waits for the workers to free anything.  A store to the coherence point takes longer than the root takes for
+//     a descent: NSHIP waves ship, job k on wave k % NSHIP;
 //   * workers -> node owners: "node initialised" (only consulted when a descent steps into a node created in the same
 //     launch): the node's arrays are ordinary stores, so the worker releases at agent scope (L2 write-back) before
 //     it stores the tag, and the owner acquires (invalidate) before it loads the node;
-//   * the random-draw cursor chain stays inside the workers' workgroup (LDS).
+//   * the random-draw cursor: inside ONE workgroup of workers a chain through LDS (NWG = 1); with more, counts in and
+//     offsets out through a wave of the selecting half (see the kernel).
 // Bounded spins everywhere (a stall is an error, never a hang).  Same trees bit for bit.
 constexpr int kXwHeader = 8;                                   // words: tag, parent, edge, child, expand, xseq, depth, k
 template <int S>
