@@ -331,12 +331,16 @@ def test_pipelined_selection_equals_serial(cfg):
     import sys
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_select_digest.py")
     outs = []
-    for variant in ("serial", "mpipe", "mpipe", "pipe", "owner", "owner", "split", "split"):
+    for variant in ("serial", "mpipe", "mpipe", "pipe", "owner", "owner", "split", "split", "split1"):
         env = dict(os.environ)
         env.pop("TG_SELECT_SERIAL", None)
         env.pop("TG_SELECT_MPIPE_TREES", None)
         env.pop("TG_SELECT_OWNER", None)
-        env["TG_SELECT_SPLIT"] = "1" if variant == "split" else "0"   # select_puct_split_kernel: two workgroups per tree (<= 16 trees)
+        env.pop("TG_SPLIT_CFG", None)
+        # select_puct_split_kernel (<= 16 trees): one selecting workgroup + two of workers per tree; "split1": one of workers
+        env["TG_SELECT_SPLIT"] = "1" if variant.startswith("split") else "0"
+        if variant == "split1":
+            env["TG_SPLIT_CFG"] = "11016" if cfg.startswith("9 ") else "11007"
         if variant == "serial":
             env["TG_SELECT_SERIAL"] = "1"
         elif variant == "pipe":
