@@ -2455,15 +2455,15 @@ __global__ __launch_bounds__(1024) void select_puct_split_kernel(SearchDev D, in
 // leaves' root-level values in LDS and one lane adds them up in leaf order at the end.  (One wave doing all leaves one
 // after the other was 0.12-0.19 ms per 256-leaf mini-batch of a single tree and 0.13 ms per Gumbel phase.)
 // Leaves without a recorded path (serial selectors, paths deeper than kPathCap) keep the one-wave walk.
-constexpr int kPolicyWaves = 7;
 constexpr int kBackupCap = 1024;        // leaves per tree the partitioned walk has LDS for
 
-template <int S>
-__global__ __launch_bounds__(64 * (1 + kPolicyWaves)) void backup_kernel(SearchDev D, const float *policy, const float *value,
+// NWAVE waves per tree: 8 when the trees crowd the CUs, 16 for a few trees (the leaves per wave are what a launch takes)
+template <int S, int NWAVE>
+__global__ __launch_bounds__(64 * NWAVE) void backup_kernel(SearchDev D, const float *policy, const float *value,
                                                      int stride, const int32_t *leaf_off, int use_logit) {
     using G = Geo<S>;
     constexpr int A = G::A, W = G::W, P = G::P;
-    constexpr int NWAVE = 1 + kPolicyWaves, NTHR = 64 * NWAVE;
+    constexpr int NTHR = 64 * NWAVE;
     const int t = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int n = D.n_leaves[t];
     const size_t leaf_base = leaf_off ? (size_t)leaf_off[t] : (size_t)t * stride;
@@ -4409,10 +4409,17 @@ int tg_search_backup(tg_search *s, const float *policy_dev, const float *value_d
     hipStream_t st = static_cast<hipStream_t>(stream);
     s->last_stream = st;
     const int32_t *off = packed ? s->phase_dev + 2 * (size_t)s->dev.T : nullptr;
-    if (s->S == 9)
-        hipLaunchKernelGGL(backup_kernel<9>, dim3(s->dev.T), dim3(64 * (1 + kPolicyWaves)), 0, st, s->dev, policy_dev, value_dev, slots_per_tree, off, use_logit);
-    else
-        hipLaunchKernelGGL(backup_kernel<19>, dim3(s->dev.T), dim3(64 * (1 + kPolicyWaves)), 0, st, s->dev, policy_dev, value_dev, slots_per_tree, off, use_logit);
+    const bool few = s->dev.T <= 64;          // few trees: 16 waves per tree
+    const dim3 grid(s->dev.T), block(64 * (few ? 16 : 8));
+    if (s->S == 9 && few) {
+        hipLaunchKernelGGL((backup_kernel<9, 16>), grid, block, 0, st, s->dev, policy_dev, value_dev, slots_per_tree, off, use_logit);
+    } else if (s->S == 9) {
+        hipLaunchKernelGGL((backup_kernel<9, 8>), grid, block, 0, st, s->dev, policy_dev, value_dev, slots_per_tree, off, use_logit);
+    } else if (few) {
+        hipLaunchKernelGGL((backup_kernel<19, 16>), grid, block, 0, st, s->dev, policy_dev, value_dev, slots_per_tree, off, use_logit);
+    } else {
+        hipLaunchKernelGGL((backup_kernel<19, 8>), grid, block, 0, st, s->dev, policy_dev, value_dev, slots_per_tree, off, use_logit);
+    }
     TG_HIP(hipGetLastError());
     return TG_OK;
 }
