@@ -341,14 +341,23 @@ def cfg4_leg(args, net, local_rank, rank, world, dist, red_dev):
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
+    # A rank whose shard fails still takes part in every collective below: it contributes an error row (the other
+    # ranks would otherwise wait in all_gather until the RCCL timeout).  TG_BENCH_FAIL_RANK=r injects such a failure (tests).
+    err = None
+    st = {"leaf_evals": 0, "games": 0, "moves": 0}
     try:
+        if os.environ.get("TG_BENCH_FAIL_RANK") == str(rank):
+            raise RuntimeError(f"injected failure on rank {rank} (TG_BENCH_FAIL_RANK)")
         st = selfplay_shard(tmp, net, list(range(first, first + games)), 9, args.cfg4_visits, boards=args.cfg4_boards,
                             never_resign_flags=[True] * games, device_index=local_rank)
         torch.cuda.synchronize()
+    except Exception as exc:                                # (KeyboardInterrupt / SystemExit end the process: torchrun
+        err = repr(exc)                                     #  then tears the other ranks down)
+        sys.stderr.write(f"bench.py rank {rank}: cfg-4 shard failed: {err}\n")
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     dt = time.perf_counter() - t0
-    mine = torch.tensor([st["leaf_evals"], dt, st["games"], st["moves"], len(os.sched_getaffinity(0))],
+    mine = torch.tensor([st["leaf_evals"], dt, st["games"], st["moves"], len(os.sched_getaffinity(0)), 1.0 if err else 0.0],
                         dtype=torch.float64, device=red_dev)
     if world > 1:
         allr = [torch.zeros_like(mine) for _ in range(world)]
@@ -356,6 +365,16 @@ def cfg4_leg(args, net, local_rank, rank, world, dist, red_dev):
     else:
         allr = [mine]
     rows = [[float(v) for v in t.cpu()] for t in allr]
+    failed = [i for i, r in enumerate(rows) if r[5] != 0.0]
+    if failed:
+        # every rank sees the same flags, so every rank enters this second collective
+        msgs = [None] * world
+        if world > 1:
+            dist.all_gather_object(msgs, err)
+        else:
+            msgs = [err]
+        return {"error": f"cfg-4 shard failed on rank(s) {failed}", "failed_ranks": failed,
+                "messages": {str(i): msgs[i] for i in failed}, "shards": world}
     total = sum(r[0] for r in rows)
     slowest = max(r[1] for r in rows)
     return {"value": total / slowest, "unit": "leaf-evals/s", "shards": world, "boards_per_shard": args.cfg4_boards,
@@ -390,7 +409,7 @@ def main():
         # random-stream threads of eight ranks must not pile onto the same cores)
         try:
             from tamago_amd.selfplay.main import pin_host_threads
-            pin_host_threads(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+            pin_host_threads(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), local_rank)
         except Exception as exc:                                  # pinning is an optimisation, never fatal
             sys.stderr.write(f"bench.py: host-thread pinning skipped ({exc})\n")
 

@@ -20,6 +20,12 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-
          "-ffp-contract=off"]
 
 
+# per-source flags.  net_forward_wsplit.hip: MFMA results in VGPRs (the accumulation half of the register file holds the
+# layer's weight fragments), and no SLP vectorisation (v_pk_add_f32 / v_pk_fma_f32 beside an MFMA stream cost ~12 cycles
+# each against ~3.4 for two plain instructions: profiles/r04_microbench_wino_issue_model.txt)
+EXTRA_FLAGS = {"net_forward_wsplit.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+
+
 def _hipcc() -> str:
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
@@ -32,7 +38,7 @@ def sources():
                   if f.endswith(".hip") or f.endswith(".cpp"))
 
 
-FORWARD_SOURCES = ("net_forward.hip", "net_forward_split.hip", "net_forward_w2.hip", "split_common.h", "net_device.h",
+FORWARD_SOURCES = ("net_forward.hip", "net_forward_split.hip", "net_forward_w2.hip", "net_forward_wsplit.hip", "split_common.h", "net_device.h",
                    "common.h")
 
 
@@ -71,7 +77,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         stale = force or not os.path.exists(obj) or \
             os.path.getmtime(obj) < max(os.path.getmtime(src), newest_header)
         if stale:
-            cmd = [hipcc] + FLAGS + ["-x", "hip", "-c", src, "-o", obj]
+            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-x", "hip", "-c", src, "-o", obj]
             if verbose:
                 print("[tamago_amd.build]", " ".join(cmd), flush=True)
             subprocess.check_call(cmd)

@@ -54,6 +54,15 @@ struct NetDev {
     const float *hd1_tab;
     const unsigned char *pfc_img;
     const float *pfc_tab;
+    // Winograd tower on split operands (net_forward_wsplit.hip): weight image [layer 12][point row 4][j 4][kc 2][piece 2]
+    // [ct 4][lane 64][8 x f16] (batch-norm scale folded in, x 2^e, low pieces unscaled), folded shift [12][64], 2^-e [12];
+    // LDS address tables of the workgroup shapes G = 1 / G = 3: patch cells [wave 4][row tile][lane 64][8], epilogue
+    // (store [0..3] / residual [4..7]) [wave 4][row tile][lane 64][8]
+    const unsigned char *ws_w;
+    const float *ws_shift;
+    const float *ws_down;
+    const int *ws_tin[2];
+    const int *ws_tout[2];
     int *overflow;                    // f16 range guard: set when a layer output leaves the f16 range
     float *scratch;       // 19x19 Winograd: per workgroup two [P][64] activation images (L2-resident)
     long long *timeline;  // optional [128] s_memtime stamps of workgroup 0 (tg_net_profile_phases)

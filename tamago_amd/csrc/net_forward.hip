@@ -30,6 +30,9 @@ int split_prepare(tg_net *net, const float *conv0, const float *const *tower, co
 int split_forward(tg_net *net, int group, const float *planes, int batch, int want_logits, float *policy,
                   float *value, int *overflow, hipStream_t stream);
 int heads_prepare(tg_net *net, const float *hp_w, const float *hv_w, const float *head_ss, const float *pfc_w, int P);
+int wsplit_prepare(tg_net *net, const float *const *tower, const float *scale, const float *shift);
+int wsplit_forward(tg_net *net, int group, const float *planes, int batch, int want_logits, float *policy,
+                   float *value, int *overflow, hipStream_t stream);
 int w2_prepare(tg_net *net, const float *conv0, const float *const *tower, const float *scale, const float *shift);
 int w2_forward(tg_net *net, const float *planes, int batch, int want_logits, float *policy, float *value,
                 int *overflow, hipStream_t stream);
@@ -778,7 +781,8 @@ int tg_net_create(int board_size, int device, const float *params, size_t n_para
     }
     if ((board_size == 9 && (rc = tg::heads_prepare(net, hp_w.data(), hv_w.data(), head_ss.data(), pfc_raw, P))) ||
         (rc = tg::split_prepare(net, conv0_raw, tower_raw, scale.data())) ||
-        (board_size == 9 && (rc = tg::w2_prepare(net, conv0_raw, tower_raw, scale.data(), shift.data())))) {
+        (board_size == 9 && (rc = tg::w2_prepare(net, conv0_raw, tower_raw, scale.data(), shift.data()))) ||
+        (board_size == 9 && (rc = tg::wsplit_prepare(net, tower_raw, scale.data(), shift.data())))) {
         tg_net_destroy(net);
         return rc;
     }
@@ -816,7 +820,13 @@ static int pick_wino(int board_size, int batch, int num_cus);
 // per product-sum; default) | wino (exact fp32 Winograd tower) | direct (exact fp32 direct convolution).
 static bool pick_split() {
     const char *env = getenv("TG_FWD_ALGO");
-    return !env || !strcmp(env, "split16") || !strcmp(env, "w2");
+    return !env || !strcmp(env, "split16") || !strcmp(env, "w2") || !strcmp(env, "wsplit");
+}
+// TG_FWD_ALGO=wsplit: the 9x9 tower as Winograd F(2x2,3x3) on split operands (net_forward_wsplit.hip)
+static bool pick_wsplit(int board_size) {
+    if (board_size != 9) return false;
+    const char *env = getenv("TG_FWD_ALGO");
+    return env && !strcmp(env, "wsplit");
 }
 // TG_FWD_ALGO=w2: large 9x9 batches (three boards per workgroup) on the two-waves-per-SIMD kernel (net_forward_w2.hip:
 // weights through an LDS ring, batch norm folded into the weights); measured level with the one-wave-per-SIMD kernel
@@ -834,6 +844,7 @@ const char *tg_net_kernel_name(const tg_net *net, int batch) {
         return pick_wino(19, batch, net->num_cus) ? "dualnet_fwd_wino8_kernel<19, 1, global scratch>" : "dualnet_fwd_kernel<19, 1>";
     }
     if (pick_w2(9, batch, net->num_cus)) return "dualnet_fwd_w2_kernel<9, 3>";
+    if (pick_wsplit(9)) return batch > net->num_cus ? "dualnet_fwd_wsplit_kernel<3>" : "dualnet_fwd_wsplit_kernel<1>";
     if (pick_split()) return batch > net->num_cus ? "dualnet_fwd_split_kernel<9, 3, f16x2>" : "dualnet_fwd_split_kernel<9, 1, f16x2>";
     {
         const int wg = pick_wino(9, batch, net->num_cus);
@@ -851,7 +862,15 @@ double tg_net_executed_flops_per_position(const tg_net *net, int batch, double *
     double peak = 157.3;
     const char *name = "f32";
     double flops = 0.0;
-    if ((S == 9 || S == 19) && pick_split()) {
+    if (pick_wsplit(S)) {
+        // per workgroup pass: stem (2 k-chunks x 4 channel tiles x 4 waves x RTW row tiles x 3 products) + 12 layers x
+        // (16 points x NRT row tiles x 4 channel tiles x 2 k-chunks x 3 products) of v_mfma_f32_16x16x32_f16
+        const int g = batch > net->num_cus ? 3 : 1;
+        const int nrt = (g * 25 + 15) / 16, rtw = ((g * P + 15) / 16 + 3) / 4;
+        flops = (2.0 * 4 * 4 * rtw * 3 + 12.0 * 16 * nrt * 4 * 2 * 3) * 16384.0 / g;
+        peak = 2500.0;
+        name = "f16 (2 operand pieces, Winograd F(2x2,3x3), fp32 accumulate)";
+    } else if ((S == 9 || S == 19) && pick_split()) {
         // per workgroup pass: (2 stem + 12 * 18) k-chunks x (4 cout tiles x row tiles) x 3 products of
         // v_mfma_f32_16x16x32_f16 (16 384 FLOP each)
         // (the two-waves-per-SIMD kernel issues the same MFMAs: 8 waves x 24 per chunk = 16 row tiles x 4 x 3)
@@ -952,9 +971,11 @@ int tg_net_forward_dev(tg_net *net, const float *planes_dev, int batch, int want
                 flag = slot;
             }
             TG_HIP(hipMemsetAsync(flag, 0, sizeof(int), st));
-            int rc = pick_w2(9, batch, net->num_cus)
-                         ? tg::w2_forward(net, planes_dev, batch, want_logits, policy_dev, value_dev, flag, st)
-                         : tg::split_forward(net, group, planes_dev, batch, want_logits, policy_dev, value_dev, flag, st);
+            int rc = pick_wsplit(9)
+                         ? tg::wsplit_forward(net, group, planes_dev, batch, want_logits, policy_dev, value_dev, flag, st)
+                         : (pick_w2(9, batch, net->num_cus)
+                                ? tg::w2_forward(net, planes_dev, batch, want_logits, policy_dev, value_dev, flag, st)
+                                : tg::split_forward(net, group, planes_dev, batch, want_logits, policy_dev, value_dev, flag, st));
             if (rc) return rc;
             if (group == 3) return launch_wino8<9, 3>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st, flag);
             return launch_wino8<9, 1>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st, flag);

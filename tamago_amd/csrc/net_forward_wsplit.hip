@@ -1,0 +1,782 @@
+// DualNet forward for gfx950, 9x9: Winograd F(2x2,3x3) residual tower ON SPLIT OPERANDS (round 4).
+//
+// net_forward_split.hip runs the fp32 3x3 convolutions on the 16-bit matrix pipe as three f16 products per fp32
+// product (a = ah + al, w = wh + wl:  a w ~ ah wh + ah wl + al wh) - and is bound by the MFMA count: the pipe is
+// power- and issue-capped, and 228.6 MFLOP of MFMAs are issued per position for 72.3 MFLOP of
+// algorithm.  This kernel cuts the count: per 2x2 output tile Y = A^T [ (G g G^T) . (B^T d B) ] A, i.e. 16
+// transform points x (25 tiles per board) instead of 9 taps x 81 positions = 1.82x fewer MFMA rows; 127.9 MFLOP
+// issued per position.  What makes it work (measured first: tools/microbench/wino_issue_model.hip,
+// profiles/r04_microbench_wino_issue_model.txt; tools/experiments/winograd_split_accuracy.py):
+//   * V = B^T d B is computed in fp32 (adds only, exact inputs) and split AFTERWARDS into two f16 pieces; the weights
+//     U = G g G^T are computed in fp64 on the host with the batch-norm scale folded in, scaled by a power of two per
+//     layer and split there.  Logit error against the reference's fp64 forward: the same class as the direct split
+//     kernel and the reference's own fp32 path.
+//   * the LOW pieces are kept UNSCALED (al = rn16(a - ah), no 2^11): v_mfma_f32_16x16x32_f16 keeps f16 subnormals
+//     (probe in the micro-benchmark), so the cross terms have the right magnitude by themselves and ONE accumulator
+//     set takes all three products (K = 64 per Winograd point: six MFMAs per accumulator).
+//   * a Winograd point's GEMM is tiny (tiles x 64 x 64), so the operands decide the structure: wave w of the four
+//     owns POINT ROW w (four points, all 64 output channels, all tiles).  Its 64 weight fragments (64 KB) are
+//     loaded once per layer and stay in registers; it computes only its own row of the input transform (no wave
+//     repeats another's VALU work - the loop is VALU-bound: beside an MFMA stream every VALU instruction beyond
+//     two per MFMA costs ~3.4 cycles); the transform along the point row's own axis is done in registers, and the
+//     sum over the four point rows goes through a 32 KB LDS exchange: Z = M A (two values per row instead of
+//     four), then wave w' finishes output channels [16 w', 16 w' + 16): folded shift, residual, ReLU, store.
+//   * activations stay in LDS as fp32 [position][64 channels] (two buffers: block input X - also the residual -
+//     and the intermediate H), 16-byte chunk index XOR-swizzled by a function of the position under which the
+//     4 x 4 patch reads of sixteen tiles are conflict-free for every patch cell; the tiles are assigned to lanes
+//     so that this holds (host: ws_geometry).  All per-lane LDS addresses of a row tile come from two small
+//     tables in global memory (the geometry is the same for every layer and workgroup): no address arithmetic in
+//     the loop.
+// Stem (6 -> 64 channels) and heads are the direct split kernel's (im2col'ed K = 64 product; 1x1 convolutions and
+// policy FC on the 16-bit pipe), reading / writing the fp32 images.  f16 range guard as there: |V| <= 4 |d| must stay
+// below 65504, so a layer output beyond 16000 raises the flag and the exact-fp32 kernel redoes the batch.
+// Reference: nn/network/res_block.py:8-38, nn/network/dual_net.py:41-52.
+#include "split_common.h"
+
+namespace {
+
+constexpr int kWsRangeLimit = 16000;
+
+template <int G>
+struct WsCfg {
+    static constexpr int S = 9, P = 81, A = 82, M = G * P;
+    static constexpr int MT = (M + 15) / 16;              // row tiles of 16 positions (stem, heads)
+    static constexpr int NT = G * 25;                     // Winograd tiles (5 x 5 per board)
+    static constexpr int NRT = (NT + 15) / 16;            // row tiles of 16 Winograd tiles
+    static constexpr int NTHR = 256, NW = 4;
+    // activation buffers: fp32 [row][16 x 16 B]; row M = dump row (stores of positions outside the board), row M + 1 =
+    // zero row (patch cells outside the board, 256-byte aligned: a read keeps the bank of its natural address)
+    static constexpr int ROWS = M + 2;
+    static constexpr int BUF = ROWS * 256;
+    static constexpr int DUMP_REL = M * 256, ZERO_REL = (M + 1) * 256;
+    static constexpr int X_OFF = 0, H_OFF = BUF;
+    static constexpr int EX_OFF = 2 * BUF;                // exchange: [wave 4][z 2][ct 4][lane 64][16 B]
+    static constexpr int EX_BYTES = 32768;
+    // head tables, staged once per workgroup
+    static constexpr int HD1_OFF = EX_OFF + EX_BYTES;     // 1x1 fragment image 4 KB + table 128 B
+    static constexpr int HB_OFF = HD1_OFF + 4096 + 128;   // policy FC bias [A] (padded to 84)
+    static constexpr int VW_OFF = HB_OFF + 84 * 4;        // value FC weights [3][P] + bias [3] (padded)
+    static constexpr int LDS_BYTES = VW_OFF + ((3 * P + 3 + 3) & ~3) * 4;
+    // stem overlay (over H and the exchange): im2col'ed input as f16-pair images [piece 2][kc 2][row][64 B] + planes
+    static constexpr int ZOFF = ((M + 1) * 64 + 255) & ~255;
+    static constexpr int IMG = ZOFF + 256;
+    static constexpr int SI_OFF = H_OFF;
+    static constexpr int STAGE = SI_OFF + 4 * IMG;
+    static constexpr int RTW = (MT + NW - 1) / NW;        // stem: row tiles per wave
+    // head overlay (over H): policy features as f16 pairs 12 KB, scratch
+    static constexpr int HQ_OFF = H_OFF;
+    static constexpr int AUX = H_OFF + 12288;
+    static_assert(STAGE + G * 6 * P * 4 <= EX_OFF + EX_BYTES, "stem overlay");
+    static_assert(AUX + G * (P + 96 + 4) * 4 <= H_OFF + M * 256, "head overlay");
+    static_assert(LDS_BYTES <= 163840, "LDS");
+};
+
+// 16-byte chunk XOR of activation row R (position 81 b + 9 y + x): g = ((y + 1) / 2 + 5 ((x + 1) / 2) + b) mod 8, spread
+// over chunk-index bits 0, 2, 3 (bit 1 is the one in which the two lane groups of a ds_read_b128 cycle differ)
+__host__ __device__ inline int ws_swz(int R) {
+    const int b = R >= 162 ? 2 : (R >= 81 ? 1 : 0);
+    const int p = R - 81 * b, y = (p * 57) >> 9, x = p - 9 * y;
+    const int g = (((y + 1) >> 1) + 5 * ((x + 1) >> 1) + b) & 7;
+    return (g & 1) | ((g & 6) << 1);
+}
+
+// LDS accesses by ABSOLUTE LDS byte address (the kernel has no static LDS: the dynamic array starts at 0, checked at
+// kernel start).  Through `smem + addr` every access costs a v_add_u32 with the array's (relocatable) base.
+typedef __attribute__((address_space(3))) f32x4 lds_f32x4_t;
+template <int OFF>
+__device__ __forceinline__ f32x4 lds_f32x4_at(int addr) {
+    return *reinterpret_cast<const lds_f32x4_t *>(static_cast<unsigned>(addr + OFF));
+}
+template <int OFF>
+__device__ __forceinline__ void lds_f32x4_put(int addr, f32x4 v) {
+    *reinterpret_cast<lds_f32x4_t *>(static_cast<unsigned>(addr + OFF)) = v;
+}
+
+// v_fma_mix_f32: v - (f16 half of h), exact.  hipcc does not form it from C (it emits v_cvt_f32_f16 + v_sub_f32).
+__device__ __forceinline__ float sub_f16_lo(float v, unsigned h) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(v));
+    return r;
+}
+__device__ __forceinline__ float sub_f16_hi(float v, unsigned h) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(v));
+    return r;
+}
+// four fp32 values -> two packed registers of high pieces, two of UNSCALED low pieces (8 VALU instructions)
+__device__ __forceinline__ void split4_unscaled(const f32x4 v, unsigned (&hi)[2], unsigned (&lo)[2]) {
+    const f16x2 h01 = __builtin_convertvector(f32x2v{v[0], v[1]}, f16x2);
+    const f16x2 h23 = __builtin_convertvector(f32x2v{v[2], v[3]}, f16x2);
+    hi[0] = __builtin_bit_cast(unsigned, h01);
+    hi[1] = __builtin_bit_cast(unsigned, h23);
+    const float r0 = sub_f16_lo(v[0], hi[0]), r1 = sub_f16_hi(v[1], hi[0]);
+    const float r2 = sub_f16_lo(v[2], hi[1]), r3 = sub_f16_hi(v[3], hi[1]);
+    lo[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{r0, r1}, f16x2));
+    lo[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{r2, r3}, f16x2));
+}
+
+// Request the 32 weight fragments of k-chunk KC of a wave's layer block wb ([j 4][kc 2][piece 2][ct 4][lane][16 B]) into
+// AGPRs.  (A free function: clang rejects asm operands that name captured variables inside a generic lambda.)
+template <int KC>
+__device__ __forceinline__ void ws_load_w(i32x4v (&ua)[4][2][2][4], const unsigned char *wb, int wlane) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const unsigned char *base = wb + ((j * 2 + KC) * 2 + p) * 4096;
+            asm volatile("global_load_dwordx4 %0, %4, %5\n\t"
+                         "global_load_dwordx4 %1, %4, %5 offset:1024\n\t"
+                         "global_load_dwordx4 %2, %4, %5 offset:2048\n\t"
+                         "global_load_dwordx4 %3, %4, %5 offset:3072"
+                         : "=a"(ua[j][KC][p][0]), "=a"(ua[j][KC][p][1]), "=a"(ua[j][KC][p][2]), "=a"(ua[j][KC][p][3])
+                         : "v"(wlane), "s"(base)
+                         : "memory");
+        }
+}
+
+// Heads on the 16-bit matrix pipe (split_common.h: run_heads_mfma), reading the block output from the fp32 image X:
+// a B fragment (position li of a 16-row tile, channels 32 kc + 8 lg ..) is two 16-byte reads + the operand split.
+template <int G, typename C>
+__device__ __forceinline__ void run_heads_x32(unsigned char *smem, const NetDev &net, int b0, int batch, int want_logits,
+                                              float *__restrict__ policy, float *__restrict__ value, int tid, int wave,
+                                              long long *tl) {
+    constexpr int P = C::P, A = C::A, M = C::M, NTHR = C::NTHR;
+    constexpr int NW = NTHR / 64, NT = 6, KS = 6, NTW = (NT + NW - 1) / NW;
+    using F = FmtF16;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, li = lane & 15, lg = lane >> 4;
+    auto stamp = [&](int i) { if (tl && tid == 0) tl[i] = (long long)__builtin_amdgcn_s_memtime(); };
+    float *hval = reinterpret_cast<float *>(smem + C::AUX);   // [G][P]
+    float *plog = hval + G * P;                               // [G][NT * 16]
+    float *vlog = plog + G * NT * 16;                         // [G][4]
+    i32x4v fw[NTW][KS][2];
+#pragma unroll
+    for (int u = 0; u < NTW; ++u) {
+        const int nt = wave + u * NW;
+        const unsigned char *base = net.pfc_img + (size_t)(nt < NT ? nt : 0) * KS * 2048 + lane * 16;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) gmem_load_frag(fw[u][s][p], base, (s * 2 + p) * 1024);
+    }
+    for (int e = tid; e < 2 * G * (192 - 2 * P); e += NTHR) {
+        const int pc = e / (G * (192 - 2 * P)), r2 = e - pc * G * (192 - 2 * P), bl = r2 / (192 - 2 * P), kk = r2 - bl * (192 - 2 * P);
+        reinterpret_cast<_Float16 *>(smem + C::HQ_OFF)[(pc * 16 + bl) * 192 + 2 * P + kk] = (_Float16)0.f;
+    }
+    i32x4v ha[2][2];
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) lds_load_frag<0>(ha[kc][p], smem, C::HD1_OFF + (kc * 2 + p) * 1024 + lane * 16);
+    const f32x4 ini = *reinterpret_cast<const f32x4 *>(smem + C::HD1_OFF + 4096 + lg * 16);
+    const float down1 = *reinterpret_cast<const float *>(smem + C::HD1_OFF + 4096 + 64), down1x = down1 * (1.f / 2048.f);
+    constexpr int TPW = (C::MT + NW - 1) / NW;
+    i32x4v fb[TPW][2][2];                                  // [tile][piece][kc]
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+        const int t = wave + q * NW;
+        const int row = (t < C::MT ? t : wave) * 16 + li;
+        const int rr = row < M ? row : M + 1;              // zero row
+        const int sw = row < M ? ws_swz(row) : 0;
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            const int a0 = C::X_OFF + rr * 256 + (((kc * 8 + lg * 2) ^ sw) << 4);
+            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(smem + a0);
+            const f32x4 v1 = *reinterpret_cast<const f32x4 *>(smem + (a0 ^ 16));
+            uint2 p0[2], p1[2];
+            split4<F>(v0, p0);
+            split4<F>(v1, p1);
+            fb[q][0][kc] = i32x4v{(int)p0[0].x, (int)p0[0].y, (int)p1[0].x, (int)p1[0].y};
+            fb[q][1][kc] = i32x4v{(int)p0[1].x, (int)p0[1].y, (int)p1[1].x, (int)p1[1].y};
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+        const int t = wave + q * NW;
+        const int row = t * 16 + li;
+        f32x4 a0 = ini, a1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            a0 = mfma16<F>(ha[kc][0], fb[q][0][kc], a0);
+            a1 = mfma16<F>(ha[kc][1], fb[q][0][kc], a1);
+            a1 = mfma16<F>(ha[kc][0], fb[q][1][kc], a1);
+        }
+        if (lg == 0 && t < C::MT && row < M) {
+            const int bl = row / P, pp = row - bl * P;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float v = fmaxf(fmaf(a1[j], down1x, a0[j] * down1), 0.f);
+                if (j == 2) {
+                    hval[bl * P + pp] = v;
+                } else {
+                    const _Float16 h = (_Float16)v;
+                    const _Float16 l = (_Float16)((v - (float)h) * 2048.f);
+                    _Float16 *hq = reinterpret_cast<_Float16 *>(smem + C::HQ_OFF);
+                    hq[(0 * 16 + bl) * 192 + j * P + pp] = h;
+                    hq[(1 * 16 + bl) * 192 + j * P + pp] = l;
+                }
+            }
+        }
+    }
+    stamp(0);
+    __syncthreads();
+    stamp(1);
+    const float down2 = net.pfc_tab[0], down2x = down2 * (1.f / 2048.f);
+#pragma unroll
+    for (int u = 0; u < NTW; ++u) {
+        const int nt = wave + u * NW;
+        if (nt < NT) {
+            f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                i32x4v fh, fl;
+                const int off = C::HQ_OFF + (li * 192 + s * 32 + lg * 8) * 2;
+                lds_load_frag<0>(fh, smem, off);
+                lds_load_frag<16 * 192 * 2>(fl, smem, off);
+                a0 = mfma16<F>(fw[u][s][0], fh, a0);
+                a1 = mfma16<F>(fw[u][s][1], fh, a1);
+                a1 = mfma16<F>(fw[u][s][0], fl, a1);
+            }
+            if (li < G) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int a = nt * 16 + lg * 4 + j;
+                    if (a < A)
+                        plog[li * NT * 16 + a] = fmaf(a1[j], down2x, a0[j] * down2) + reinterpret_cast<const float *>(smem + C::HB_OFF)[a];
+                }
+            }
+        }
+    }
+    for (int o = tid >> 4; o < G * 3; o += NTHR / 16) {
+        const int part = tid & 15, bl = o / 3, c = o - bl * 3;
+        const float *h = hval + bl * P;
+        const float *wv = reinterpret_cast<const float *>(smem + C::VW_OFF) + c * P;
+        float sv = 0.f;
+#pragma unroll
+        for (int i = 0; i < (P + 15) / 16; ++i) {
+            const int j = part + i * 16;
+            if (j < P) sv = fmaf(h[j], wv[j], sv);
+        }
+        sv += __shfl_xor(sv, 8);
+        sv += __shfl_xor(sv, 4);
+        sv += __shfl_xor(sv, 2);
+        sv += __shfl_xor(sv, 1);
+        if (part == 0) vlog[bl * 4 + c] = sv + reinterpret_cast<const float *>(smem + C::VW_OFF)[3 * P + c];
+    }
+    stamp(2);
+    __syncthreads();
+    for (int bl = wave; bl < G; bl += NW) {
+        const int b = b0 + bl;
+        if (b >= batch) continue;
+        const float l0 = plog[bl * NT * 16 + lane];
+        const float l1 = lane + 64 < A ? plog[bl * NT * 16 + lane + 64] : -INFINITY;
+        float m = fmaxf(l0, l1);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        const float e0 = expf(l0 - m), e1 = lane + 64 < A ? expf(l1 - m) : 0.f;
+        float sum = e0 + e1;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        const float inv = 1.f / sum;
+        __builtin_nontemporal_store(want_logits ? l0 : e0 * inv, &policy[(size_t)b * A + lane]);
+        if (lane + 64 < A) __builtin_nontemporal_store(want_logits ? l1 : e1 * inv, &policy[(size_t)b * A + lane + 64]);
+        if (lane < 3) {
+            const float v0 = vlog[bl * 4], v1 = vlog[bl * 4 + 1], v2 = vlog[bl * 4 + 2];
+            const float vm = fmaxf(v0, fmaxf(v1, v2));
+            const float x0 = expf(v0 - vm), x1 = expf(v1 - vm), x2 = expf(v2 - vm);
+            const float es = x0 + x1 + x2;
+            const float mine = lane == 0 ? x0 : (lane == 1 ? x1 : x2);
+            value[(size_t)b * 3 + lane] = mine / es;
+        }
+    }
+}
+
+template <int G>
+__global__ __launch_bounds__(256, 1) void dualnet_fwd_wsplit_kernel(
+    NetDev net, const float *__restrict__ planes, int batch, int want_logits,
+    float *__restrict__ policy, float *__restrict__ value, int *__restrict__ overflow) {
+    using C = WsCfg<G>;
+    using F = FmtF16;
+    constexpr int P = C::P, M = C::M, NTHR = C::NTHR, NRT = C::NRT, RTW = C::RTW, IMG = C::IMG;
+    constexpr int GI = G == 3 ? 1 : 0;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, li = lane & 15, lg = lane >> 4;
+
+    if (static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) unsigned char *)smem)) != 0u)
+        __builtin_trap();                                      // absolute LDS addressing below
+    // ---- once per workgroup: zero + dump rows, head tables ----
+    for (int e = tid; e < 2 * 2 * 64; e += NTHR) {             // rows M, M + 1 of X and H
+        const int buf = e >> 7, r = (e >> 6) & 1, c = e & 63;
+        reinterpret_cast<float *>(smem + buf * C::BUF + (M + r) * 256)[c] = 0.f;
+    }
+    for (int e = tid; e < C::A; e += NTHR) reinterpret_cast<float *>(smem + C::HB_OFF)[e] = net.pfc_b[e];
+    for (int e = tid; e < 3 * P + 3; e += NTHR)
+        reinterpret_cast<float *>(smem + C::VW_OFF)[e] = e < 3 * P ? net.vfc_w[e] : net.vfc_b[e - 3 * P];
+    stage_head_tables<C, NTHR>(smem, net, tid);
+
+    int stamp_i = 0;
+    auto stamp = [&]() {
+        if (net.timeline && blockIdx.x == 0 && tid == 0 && stamp_i < 40)
+            net.timeline[stamp_i++] = (long long)__builtin_amdgcn_s_memtime();
+    };
+    int ovf = 0;
+    const int n_groups = (batch + G - 1) / G;
+    constexpr int NPL = (G * 6 * P + NTHR - 1) / NTHR;
+    float pre[NPL];
+    auto fetch_planes = [&](int grp2) __attribute__((always_inline)) {
+        int ft = tid;
+        asm volatile("" : "+v"(ft));
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            const int e = ft + i * NTHR;
+            const int b = grp2 * G + e / (6 * P);
+            pre[i] = (e < G * 6 * P && grp2 < n_groups && b < batch)
+                         ? __builtin_nontemporal_load(&planes[(size_t)grp2 * G * 6 * P + e]) : 0.f;
+        }
+    };
+    fetch_planes(blockIdx.x);
+    const float sgn = wave == 1 ? 1.f : -1.f;                  // row pass of point row w: d[ra] + sgn d[rb]
+    const int *const tin_w = net.ws_tin[GI] + (size_t)wave * NRT * 64 * 8;
+    const int *const tout_w = net.ws_tout[GI] + (size_t)wave * NRT * 64 * 8;
+    // LDS address tables of the row tile about to be processed (carried across layers: the geometry repeats)
+    i32x4v ta = *reinterpret_cast<const i32x4v *>(tin_w + (size_t)lane * 8);
+    i32x4v tb = *reinterpret_cast<const i32x4v *>(tin_w + (size_t)lane * 8 + 4);
+    i32x4v to = *reinterpret_cast<const i32x4v *>(tout_w + (size_t)lane * 8);
+    i32x4v tr = *reinterpret_cast<const i32x4v *>(tout_w + (size_t)lane * 8 + 4);
+    asm volatile("" :: "v"(ta), "v"(tb), "v"(to), "v"(tr));   // waited for here, before the weight requests below
+    // This wave's 64 weight fragments of a layer, [j 4][kc 2][piece 2][ct 4]: resident in the accumulation half of the
+    // register file for the whole layer (MFMA A operands are read from there directly).  They are requested by inline
+    // asm with AGPR destinations - left to the register allocator they end up in VGPRs, spilled to AGPRs and copied back
+    // before every use - so hipcc does not track them: the waits are explicit (body) and nothing may copy these registers
+    // between a request and its wait (checked in the ISA).  All requests of a k-chunk go out in the layer BEFORE, in its
+    // last row tile, as soon as the chunk's own MFMAs are done; layer 0's at kernel start and in layer 11's last row tile.
+    i32x4v ua[4][2][2][4];
+    const int wlane = lane * 16;
+    auto load_w = [&](auto KC_, int layer) __attribute__((always_inline)) {
+        ws_load_w<decltype(KC_)::value>(ua, net.ws_w + ((size_t)layer * 4 + wave) * 65536, wlane);
+    };
+    load_w(std::integral_constant<int, 0>{}, 0);
+    load_w(std::integral_constant<int, 1>{}, 0);
+
+    for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const int b0 = grp * G;
+        stamp();
+        // ================= stem: planes -> im2col'ed f16-pair images (K = 9 taps x 6 planes, padded to 64) =================
+        {
+            float *st = reinterpret_cast<float *>(smem + C::STAGE);
+            int stid = tid;
+            asm volatile("" : "+v"(stid));
+#pragma unroll
+            for (int i = 0; i < NPL; ++i)
+                if (stid + i * NTHR < G * 6 * P) st[stid + i * NTHR] = pre[i];
+            for (int e = stid; e < 4 * 64; e += NTHR)           // zero blocks of the four images
+                reinterpret_cast<unsigned *>(smem + C::SI_OFF + (e >> 6) * IMG + C::ZOFF)[e & 63] = 0u;
+            __syncthreads();
+            for (int row = stid; row < M; row += NTHR) {
+                const int bl = row / P, p = row - bl * P, y = p / 9, x = p - y * 9;
+                const float *src = st + bl * 6 * P + p;
+                const int swz = (row >> 1) & 3;
+#pragma unroll
+                for (int sl = 0; sl < 8; ++sl) {
+                    f32x4 lo, hi;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int k = sl * 8 + j, t = k / 6, c = k - t * 6;
+                        const int dy = t / 3 - 1, dx = t % 3 - 1;
+                        const bool ok = k < 54 && (unsigned)(y + dy) < 9u && (unsigned)(x + dx) < 9u;
+                        const float v = ok ? src[c * P + dy * 9 + dx] : 0.f;
+                        if (j < 4) lo[j] = v; else hi[j - 4] = v;
+                    }
+                    uint2 plo[2], phi[2];
+                    split4<F>(lo, plo);
+                    split4<F>(hi, phi);
+                    const int kc = sl >> 2, slot = (sl & 3) ^ swz;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        *reinterpret_cast<uint4 *>(smem + C::SI_OFF + (q * 2 + kc) * IMG + row * 64 + slot * 16) =
+                            uint4{plo[q].x, plo[q].y, phi[q].x, phi[q].y};
+                }
+            }
+        }
+        __syncthreads();
+        stamp();
+        float amax = 0.f;
+        {
+            // stem product: 2 k-chunks x 4 channel tiles x RTW row tiles x 3 f16 products (two accumulator sets, scaled
+            // low pieces: the direct split kernel's image and weights), batch norm, ReLU -> X (fp32, swizzled)
+            i32x4v fa[2][2][4];                                  // [kc][piece][ct]
+            int wvg = lane * 16;
+            asm volatile("" : "+v"(wvg));
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        gmem_load_frag(fa[kc][p][c], net.wsplit + (size_t)kc * 8192, wvg + (p * 4 + c) * 1024);
+#pragma unroll
+            for (int r = 0; r < RTW; ++r) {
+                int row = (wave * RTW + r) * 16 + li;
+                asm volatile("" : "+v"(row));
+                const int nat = row * 64 + ((lg ^ ((row >> 1) & 3)) << 4);
+                const int addr = C::SI_OFF + (row < M ? nat : C::ZOFF + (nat & 255));
+                i32x4v fb[2][2];                                 // [piece][kc]
+                lds_load_frag<0 * IMG>(fb[0][0], smem, addr);
+                lds_load_frag<1 * IMG>(fb[0][1], smem, addr);
+                lds_load_frag<2 * IMG>(fb[1][0], smem, addr);
+                lds_load_frag<3 * IMG>(fb[1][1], smem, addr);
+                const int orow = row < M ? row : M;
+                const int osw = row < M ? ws_swz(row) : 0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+#pragma unroll
+                    for (int kc = 0; kc < 2; ++kc) {
+                        a0 = mfma16<F>(fa[kc][0][c], fb[0][kc], a0);
+                        a1 = mfma16<F>(fa[kc][1][c], fb[0][kc], a1);
+                        a1 = mfma16<F>(fa[kc][0][c], fb[1][kc], a1);
+                    }
+                    const f32x4 sc = *reinterpret_cast<const f32x4 *>(net.sscale + c * 16 + lg * 4);
+                    const f32x4 sh = *reinterpret_cast<const f32x4 *>(net.shift + c * 16 + lg * 4);
+                    f32x4 v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float t = fmaf(a1[j], 1.f / 2048.f, a0[j]);
+                        t = fmaf(t, sc[j], sh[j]);
+                        v[j] = fmaxf(t, 0.f);
+                    }
+                    amax = fmaxf(fmaxf(amax, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+                    *reinterpret_cast<f32x4 *>(smem + C::X_OFF + orow * 256 + (((c * 4 + lg) ^ osw) << 4)) = v;
+                }
+            }
+        }
+        __syncthreads();                                        // X complete; the overlay is free again
+        if (tid < 64) reinterpret_cast<float *>(smem + C::H_OFF + (M + 1) * 256)[tid] = 0.f;   // H's zero row was under it
+        stamp();
+
+        // ================= tower: 12 Winograd layers =================
+        // one row tile of one layer: IN / OUT = byte offsets of the input / output buffer, RES: add the residual from OUT
+        // (in place), LAST: the layer's last row tile - the weight registers of a k-chunk are dead after its MFMAs, and the
+        // next layer's fragments are requested into them right there (see load_w)
+        auto body = [&](auto IN_, auto OUT_, auto RES_, auto LAST_, int rt, int next_layer, const f32x4 shf, const float down)
+                        __attribute__((always_inline)) {
+            constexpr int IN = decltype(IN_)::value, OUT = decltype(OUT_)::value;
+            constexpr bool RES = decltype(RES_)::value, LAST = decltype(LAST_)::value;
+            // address tables of the NEXT row tile (cyclic: the last row tile fetches row tile 0's for the next layer)
+            const int rn = rt + 1 < NRT ? rt + 1 : 0;
+            const i32x4v na = *reinterpret_cast<const i32x4v *>(tin_w + ((size_t)rn * 64 + lane) * 8);
+            const i32x4v nb = *reinterpret_cast<const i32x4v *>(tin_w + ((size_t)rn * 64 + lane) * 8 + 4);
+            const i32x4v no = *reinterpret_cast<const i32x4v *>(tout_w + ((size_t)rn * 64 + lane) * 8);
+            const i32x4v nr = *reinterpret_cast<const i32x4v *>(tout_w + ((size_t)rn * 64 + lane) * 8 + 4);
+            f32x4 acc[4][4];
+            static_for<2>([&](auto KC_) {
+                constexpr int kc = decltype(KC_)::value;
+                // ---- patch rows ra, rb of this wave's point row: 8 cells x 8 channels ----
+                f32x4 d[2][4][2];
+#pragma unroll
+                for (int c8 = 0; c8 < 8; ++c8) {
+                    const int a0 = (c8 < 4 ? ta[c8] : tb[c8 - 4]) ^ (kc << 7);
+                    d[c8 >> 2][c8 & 3][0] = lds_f32x4_at<IN>(a0);
+                    d[c8 >> 2][c8 & 3][1] = lds_f32x4_at<IN>(a0 ^ 16);
+                }
+                // ---- input transform: row pass t = d[ra] + sgn d[rb]; column pass; operand split ----
+                i32x4v bh[4], bl[4];
+                {
+                    f32x4 t[4][2];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) t[s][h][e] = fmaf(d[1][s][h][e], sgn, d[0][s][h][e]);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        f32x4 v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[0][e] = t[0][h][e] - t[2][h][e];
+                            v[1][e] = t[1][h][e] + t[2][h][e];
+                            v[2][e] = t[2][h][e] - t[1][h][e];
+                            v[3][e] = t[1][h][e] - t[3][h][e];
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            unsigned hi[2], lo[2];
+                            split4_unscaled(v[j], hi, lo);
+                            bh[j][2 * h] = (int)hi[0];
+                            bh[j][2 * h + 1] = (int)hi[1];
+                            bl[j][2 * h] = (int)lo[0];
+                            bl[j][2 * h + 1] = (int)lo[1];
+                        }
+                    }
+                }
+                // the fragments of this k-chunk were requested a layer ago (kc = 0: 32 younger requests - the other k-chunk's -
+                // may still be in flight).  Only a layer's first row tile can actually wait here.
+                if constexpr (!LAST) {
+                    if constexpr (kc == 0) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                // ---- 48 MFMAs: cross terms first, one accumulator set ----
+                // (the three MFMAs of an accumulator four apart: a dependent MFMA issued back to back stalls)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        acc[j][c] = mfma16<F>(ua[j][kc][1][c], bh[j], kc == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[j][c]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[j][c] = mfma16<F>(ua[j][kc][0][c], bl[j], acc[j][c]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[j][c] = mfma16<F>(ua[j][kc][0][c], bh[j], acc[j][c]);
+                }
+                if constexpr (LAST) {
+                    if constexpr (kc == 0) asm volatile("" :: "v"(na), "v"(nb), "v"(no), "v"(nr));   // (their wait goes here)
+                    load_w(std::integral_constant<int, kc>{}, next_layer);
+                }
+            });
+            // ---- output transform along the point row: Z0 = m0 + m1 + m2, Z1 = m1 - m2 - m3 -> exchange ----
+            int exw = wave * 8192 + lane * 16, exr = wave * 1024 + lane * 16;     // this wave's block / its channel tile
+            asm volatile("" : "+v"(exw), "+v"(exr));
+            __syncthreads();                                // the previous row tile's exchange has been read
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                f32x4 z0, z1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    z0[e] = (acc[0][c][e] + acc[1][c][e]) + acc[2][c][e];
+                    z1[e] = (acc[1][c][e] - acc[2][c][e]) - acc[3][c][e];
+                }
+                lds_f32x4_put<C::EX_OFF>(exw + c * 1024, z0);
+                lds_f32x4_put<C::EX_OFF + 4096>(exw + c * 1024, z1);
+            }
+            __syncthreads();
+            // ---- sum over the point rows for output channels 16 wave + 4 lg .., shift, residual, ReLU, store ----
+            {
+                f32x4 z[4][2];
+#pragma unroll
+                for (int w2 = 0; w2 < 4; ++w2)
+#pragma unroll
+                    for (int zz = 0; zz < 2; ++zz)
+                        z[w2][zz] = lds_f32x4_at<C::EX_OFF>(exr + (w2 * 2 + zz) * 4096);
+                f32x4 res[4];
+                if constexpr (RES) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) res[q] = lds_f32x4_at<OUT>(tr[q]);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {               // q = 2 r + c: output (2 ty + r, 2 tx + c)
+                    const int r = q >> 1, cc = q & 1;
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float y = r == 0 ? (z[0][cc][e] + z[1][cc][e]) + z[2][cc][e]
+                                               : (z[1][cc][e] - z[2][cc][e]) - z[3][cc][e];
+                        float tt = fmaf(y, down, shf[e]);
+                        if constexpr (RES) tt += res[q][e];
+                        v[e] = fmaxf(tt, 0.f);
+                    }
+                    amax = fmaxf(fmaxf(amax, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+                    lds_f32x4_put<OUT>(to[q], v);
+                }
+            }
+            ta = na; tb = nb; to = no; tr = nr;
+        };
+        auto conv = [&](auto IN_, auto OUT_, auto RES_, int layer) __attribute__((always_inline)) {
+            // epilogue constants of the output channels this wave finishes: 16 wave + 4 lg ..
+            const f32x4 shf = *reinterpret_cast<const f32x4 *>(net.ws_shift + layer * 64 + wave * 16 + lg * 4);
+            const float down = net.ws_down[layer];
+            const int next_layer = layer + 1 < kTowerLayers ? layer + 1 : 0;
+#pragma unroll 1
+            for (int rt = 0; rt < NRT - 1; ++rt) body(IN_, OUT_, RES_, std::false_type{}, rt, next_layer, shf, down);
+            body(IN_, OUT_, RES_, std::true_type{}, NRT - 1, next_layer, shf, down);
+            if (!(amax < (float)kWsRangeLimit)) ovf = 1;        // f16 range guard (also catches NaN)
+            __syncthreads();                                    // OUT complete before the next layer reads it
+            stamp();
+        };
+        using IX = std::integral_constant<int, C::X_OFF>;
+        using IH = std::integral_constant<int, C::H_OFF>;
+        if (!(amax < (float)kWsRangeLimit)) ovf = 1;
+#pragma unroll 1
+        for (int blk = 0; blk < kBlocks; ++blk) {
+            conv(IX{}, IH{}, std::false_type{}, 2 * blk);
+            conv(IH{}, IX{}, std::true_type{}, 2 * blk + 1);
+        }
+        // next group's input planes: requested here, consumed after the heads
+        fetch_planes(grp + gridDim.x);
+        run_heads_x32<G, C>(smem, net, b0, batch, want_logits, policy, value, tid, wave,
+                            (net.timeline && blockIdx.x == 0 && grp == blockIdx.x) ? net.timeline + 40 : nullptr);
+        __syncthreads();
+        stamp();
+    }
+    if (ovf && overflow) atomicOr(overflow, 1);
+}
+
+template <int G>
+int launch_wsplit(tg_net *net, const float *planes, int batch, int want_logits, float *policy, float *value,
+                  int *overflow, hipStream_t stream) {
+    using C = WsCfg<G>;
+    auto kern = dualnet_fwd_wsplit_kernel<G>;
+    // (cheap, and right for every device and thread: no per-process "already configured" flag)
+    TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+    const int groups = (batch + G - 1) / G;
+    const int grid = groups < net->num_cus ? groups : net->num_cus;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTHR), C::LDS_BYTES, stream, net->dev, planes, batch, want_logits,
+                       policy, value, overflow);
+    TG_HIP(hipGetLastError());
+    return TG_OK;
+}
+
+// ---- host: tile -> lane assignment and the LDS address tables ---------------------------------------------------
+// Tile (b, ty, tx) has class h = (ty + 5 tx + b) mod 8 - the value ws_swz's g takes on its patch cell (r, s), up to a
+// constant that depends on the cell only.  A ds_read_b128 serves lanes {li 0-3, 12-15 of lane group a} + {li 4-11 of
+// lane group a ^ 1} in one LDS cycle: with the eight tiles of each of the two sets in eight different classes the
+// sixteen 16-byte chunks are distinct for every cell.  No class has more than 2 NRT tiles, so: k-th tile of class h ->
+// set k (row tile k / 2, half k % 2), lane position h inside the set.
+template <int G>
+void ws_geometry(std::vector<int> &tin, std::vector<int> &tout) {
+    using C = WsCfg<G>;
+    constexpr int NRT = C::NRT;
+    std::vector<int> slot_tile(NRT * 16, -1);
+    int cnt[8] = {};
+    for (int b = 0; b < G; ++b)
+        for (int ty = 0; ty < 5; ++ty)
+            for (int tx = 0; tx < 5; ++tx) {
+                const int h = (ty + 5 * tx + b) & 7, k = cnt[h]++;
+                const int rt = k >> 1, li = (k & 1) ? 4 + h : (h < 4 ? h : h + 8);
+                slot_tile[rt * 16 + li] = (b * 5 + ty) * 5 + tx;
+            }
+    static const int rows[4][2] = {{0, 2}, {1, 2}, {2, 1}, {1, 3}};
+    tin.assign((size_t)4 * NRT * 64 * 8, 0);
+    tout.assign((size_t)4 * NRT * 64 * 8, 0);
+    for (int w = 0; w < 4; ++w)
+        for (int rt = 0; rt < NRT; ++rt)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int li = lane & 15, lg = lane >> 4, tile = slot_tile[rt * 16 + li];
+                const int b = tile < 0 ? 0 : tile / 25, ty = tile < 0 ? 0 : (tile / 5) % 5, tx = tile < 0 ? 0 : tile % 5;
+                int *ti = &tin[(((size_t)w * NRT + rt) * 64 + lane) * 8];
+                for (int c8 = 0; c8 < 8; ++c8) {
+                    const int r = rows[w][c8 >> 2], s = c8 & 3;
+                    const int y = 2 * ty - 1 + r, x = 2 * tx - 1 + s;
+                    // chunk index of channels 8 lg .. (k-chunk 0, first half): 2 lg; the kernel XORs in 8 kc + half
+                    if (tile >= 0 && y >= 0 && y < 9 && x >= 0 && x < 9) {
+                        const int R = b * 81 + y * 9 + x;
+                        ti[c8] = R * 256 + (((lg * 2) ^ ws_swz(R)) << 4);
+                    } else {
+                        // zero row, at the chunk its natural address would have had (class of the cell: the same formula
+                        // extended beyond the board; a tile-less lane takes the class of its lane position)
+                        const int hcls = tile >= 0 ? (ty + 5 * tx + b) & 7 : (li < 4 ? li : (li < 12 ? li - 4 : li - 8));
+                        const int g = (hcls + (r >> 1) + 5 * (s >> 1)) & 7;
+                        const int sw = (g & 1) | ((g & 6) << 1);
+                        ti[c8] = C::ZERO_REL + (((lg * 2) ^ sw) << 4);
+                    }
+                }
+                // epilogue of output channels 16 w + 4 lg ..: chunk 4 w + lg.  [0..3] store addresses of outputs
+                // (2 ty + r, 2 tx + c), q = 2 r + c (outside the board: dump row); [4..7] residual read addresses (outside: zero row)
+                int *to = &tout[(((size_t)w * NRT + rt) * 64 + lane) * 8];
+                for (int q = 0; q < 4; ++q) {
+                    const int y = 2 * ty + (q >> 1), x = 2 * tx + (q & 1);
+                    if (tile >= 0 && y < 9 && x < 9) {
+                        const int R = b * 81 + y * 9 + x;
+                        to[q] = to[4 + q] = R * 256 + (((w * 4 + lg) ^ ws_swz(R)) << 4);
+                    } else {
+                        to[q] = C::DUMP_REL + lane * 16 % 256;
+                        to[4 + q] = C::ZERO_REL + lane * 16 % 256;
+                    }
+                }
+            }
+}
+
+}  // namespace
+
+namespace tg {
+
+// Winograd weight image [layer 12][wave = point row i 4][j 4][kc 2][piece 2][ct 4][lane 64][8 x f16]: U = G g G^T in
+// fp64, batch-norm scale folded in, x 2^e (largest entry of the layer into [2^9, 2^10)), pieces hi = rn16(u),
+// lo = rn16(u - hi) UNSCALED; shift table [12][64]; 2^-e [12]; the address tables of both workgroup shapes.
+// tower[l]: [64][64][3][3]; scale / shift: folded batch norm [13][64] (index 0 = stem).
+int wsplit_prepare(tg_net *net, const float *const *tower, const float *scale, const float *shift) {
+    std::vector<uint16_t> img((size_t)12 * 4 * 64 * 512, 0);
+    std::vector<float> down(12), shf(12 * 64);
+    std::vector<double> u((size_t)16 * 64 * 64);
+    for (int layer = 0; layer < 12; ++layer) {
+        const float *w = tower[layer];
+        double mx = 0.0;
+        for (int cout = 0; cout < 64; ++cout)
+            for (int cin = 0; cin < 64; ++cin) {
+                const float *g = &w[((size_t)cout * 64 + cin) * 9];
+                double gg[4][3];
+                for (int k = 0; k < 3; ++k) {
+                    gg[0][k] = g[k];
+                    gg[1][k] = 0.5 * ((double)g[k] + g[3 + k] + g[6 + k]);
+                    gg[2][k] = 0.5 * ((double)g[k] - g[3 + k] + g[6 + k]);
+                    gg[3][k] = g[6 + k];
+                }
+                const double sc = scale[(layer + 1) * 64 + cout];
+                for (int a = 0; a < 4; ++a) {
+                    const double row[4] = {gg[a][0], 0.5 * (gg[a][0] + gg[a][1] + gg[a][2]),
+                                           0.5 * (gg[a][0] - gg[a][1] + gg[a][2]), gg[a][2]};
+                    for (int bq = 0; bq < 4; ++bq) {
+                        const double v = row[bq] * sc;
+                        u[((size_t)(a * 4 + bq) * 64 + cin) * 64 + cout] = v;
+                        mx = std::fmax(mx, std::fabs(v));
+                    }
+                }
+            }
+        int e = 0;
+        if (mx > 0.0 && std::isfinite(mx)) {
+            int ex;
+            std::frexp(mx, &ex);
+            e = 10 - ex;
+        }
+        e = e > 40 ? 40 : (e < -40 ? -40 : e);
+        down[layer] = std::ldexp(1.f, -e);
+        for (int c = 0; c < 64; ++c) shf[layer * 64 + c] = shift[(layer + 1) * 64 + c];
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j)
+                for (int kc = 0; kc < 2; ++kc)
+                    for (int ct = 0; ct < 4; ++ct)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int el = 0; el < 8; ++el) {
+                                const int cout = ct * 16 + (lane & 15), cin = kc * 32 + (lane >> 4) * 8 + el;
+                                const double v = std::ldexp(u[((size_t)(i * 4 + j) * 64 + cin) * 64 + cout], e);
+                                const uint16_t h = f32_to_f16_rn((float)v);
+                                const uint16_t l = f32_to_f16_rn((float)(v - (double)f16_to_f32(h)));
+                                const size_t frag = ((((size_t)layer * 4 + i) * 4 + j) * 2 + kc) * 2;
+                                img[((frag + 0) * 4 + ct) * 512 + lane * 8 + el] = h;
+                                img[((frag + 1) * 4 + ct) * 512 + lane * 8 + el] = l;
+                            }
+    }
+    auto up = [&](const void *src, size_t bytes, const void **dst) {
+        void *d = nullptr;
+        TG_HIP(hipMalloc(&d, bytes));
+        net->allocs.push_back(d);
+        TG_HIP(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
+        *dst = d;
+        return (int)TG_OK;
+    };
+    std::vector<int> tin1, tout1, tin3, tout3;
+    ws_geometry<1>(tin1, tout1);
+    ws_geometry<3>(tin3, tout3);
+    int rc;
+    if ((rc = up(img.data(), img.size() * 2, reinterpret_cast<const void **>(&net->dev.ws_w))) ||
+        (rc = up(shf.data(), shf.size() * 4, reinterpret_cast<const void **>(&net->dev.ws_shift))) ||
+        (rc = up(down.data(), down.size() * 4, reinterpret_cast<const void **>(&net->dev.ws_down))) ||
+        (rc = up(tin1.data(), tin1.size() * 4, reinterpret_cast<const void **>(&net->dev.ws_tin[0]))) ||
+        (rc = up(tout1.data(), tout1.size() * 4, reinterpret_cast<const void **>(&net->dev.ws_tout[0]))) ||
+        (rc = up(tin3.data(), tin3.size() * 4, reinterpret_cast<const void **>(&net->dev.ws_tin[1]))) ||
+        (rc = up(tout3.data(), tout3.size() * 4, reinterpret_cast<const void **>(&net->dev.ws_tout[1]))))
+        return rc;
+    return TG_OK;
+}
+
+// group = boards per workgroup (1 or 3); 9x9 only.
+int wsplit_forward(tg_net *net, int group, const float *planes, int batch, int want_logits, float *policy,
+                   float *value, int *overflow, hipStream_t stream) {
+    if (net->board_size != 9) return tg::fail(TG_ERR_ARG, "winograd split forward: 9x9 only");
+    if (group == 3) return launch_wsplit<3>(net, planes, batch, want_logits, policy, value, overflow, stream);
+    return launch_wsplit<1>(net, planes, batch, want_logits, policy, value, overflow, stream);
+}
+
+}  // namespace tg

@@ -55,16 +55,70 @@ def next_record_dir(save_dir: str) -> int:
     return max(found) + 1
 
 
-def pin_host_threads(local_rank: int, local_world: int) -> int:
-    """Give this shard a private, contiguous slice of the host's cores: the group threads and the
-    library's random-stream generator threads of 8 shards must not pile onto the same cores
-    (host-CPU contention is the only scaling loss).  Returns the slice size."""
+def gpu_numa_cores(device_index: int):
+    """Cores of the NUMA node the GPU hangs off (/sys/class/drm/card*/device/numa_node + .../local_cpulist), or None
+    when the platform does not say (no sysfs entry, numa_node -1, single-node host)."""
+    try:
+        import torch
+        bus = torch.cuda.get_device_properties(device_index).pci_bus_id
+        dom = torch.cuda.get_device_properties(device_index).pci_domain_id
+        dev = torch.cuda.get_device_properties(device_index).pci_device_id
+        path = f"/sys/bus/pci/devices/{dom:04x}:{bus:02x}:{dev:02x}.0"
+        with open(os.path.join(path, "numa_node")) as f:
+            if int(f.read().strip()) < 0:
+                return None
+        with open(os.path.join(path, "local_cpulist")) as f:
+            return parse_cpulist(f.read())
+    except Exception:
+        return None
+
+
+def parse_cpulist(text: str):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11]"""
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def pin_host_threads(local_rank: int, local_world: int, device_index=None, numa_cores=None) -> int:
+    """Give this shard a private slice of the host's cores: the group threads and the library's random-stream
+    generator threads of 8 shards must not pile onto the same cores (host-CPU contention is the
+    only scaling loss).  The slice is taken from the cores of the NUMA node the rank's GPU hangs off when the
+    platform says which (the ranks whose GPUs share a node split that node's cores among themselves by their
+    position in local-rank order); otherwise contiguous slices of all visible cores.  Returns the slice size."""
     try:
         cores = sorted(os.sched_getaffinity(0))
     except AttributeError:
         return os.cpu_count() or 1
-    per = max(1, len(cores) // max(1, local_world))
-    mine = cores[local_rank * per:(local_rank + 1) * per] or cores
+    mine = None
+    if numa_cores is None and device_index is not None:
+        numa_cores = gpu_numa_cores(device_index)
+    if numa_cores:
+        local = [c for c in cores if c in set(numa_cores)]
+        # the other local ranks are assumed to map onto the devices the way this one does (rank r -> device r mod n):
+        # ranks on the same node = those whose device reports the same core list
+        peers = sharing = 0
+        try:
+            import torch
+            n_dev = max(1, torch.cuda.device_count())
+            for r in range(local_world):
+                same = gpu_numa_cores(r % n_dev) == numa_cores if not os.environ.get("TG_SINGLE_DEVICE") else True
+                if same:
+                    if r < local_rank:
+                        peers += 1
+                    sharing += 1
+        except Exception:
+            peers, sharing = local_rank, local_world
+        if local and sharing:
+            per = max(1, len(local) // sharing)
+            mine = local[peers * per:(peers + 1) * per]
+    if not mine:
+        per = max(1, len(cores) // max(1, local_world))
+        mine = cores[local_rank * per:(local_rank + 1) * per] or cores
     try:
         os.sched_setaffinity(0, mine)
     except OSError:
@@ -82,7 +136,7 @@ def run_shard(args, rank: int, world: int, local_rank: int, record_dir: str) -> 
     # more worker processes than GPUs (the reference's --process N puts N workers on ONE device, nn/utility.py:22):
     # the shards share the devices round-robin
     device_index = 0 if os.environ.get("TG_SINGLE_DEVICE") else local_rank % n_dev
-    cores = pin_host_threads(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+    cores = pin_host_threads(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), device_index)
     torch.cuda.set_device(device_index)
     network = load_network(model_file_path=args.model, use_gpu=args.use_gpu, board_size=args.size,
                            device_index=device_index)
