@@ -22,7 +22,8 @@ of selection / backup, same rule), `cpu_baseline` (the CPU oracle - a port of th
 Python path - timed on this host on a bounded sample of the same workload) and legs for the
 other BASELINE.json configs: at N = 1 `fp32_exact` (the same workload on the exact-fp32
 Winograd kernel), `single_tree`, `cfg3_selfplay_16_boards`, `cfg4_shard_64_boards`,
-`selfplay_1024_boards`, `cfg5_19x19`, `cfg1_cpu`; at N > 1 `cfg4_selfplay_shards` (one
+`selfplay_1024_boards`, `cfg5_19x19`, `cfg5_19x19_trees` (with its own `roofline`), `cfg1_cpu`, `cpu_selfplay` (the
+oracle's Gumbel worker as 4 / one-per-core OS processes); at N > 1 `cfg4_selfplay_shards` (one
 64-board Gumbel shard per rank, aggregate + per-rank rates + host cores per rank).
 """
 import argparse
@@ -105,6 +106,8 @@ def parse():
     ap.add_argument("--cfg4-boards", type=int, default=64, help="boards per cfg-4 shard (BASELINE.json: 64)")
     ap.add_argument("--cfg4-games", type=int, default=192, help="games each rank's cfg-4 shard plays to completion")
     ap.add_argument("--cfg4-visits", type=int, default=400)
+    ap.add_argument("--cfg5-trees", type=int, default=256, help="19x19 trees of the cfg5_19x19_trees leg")
+    ap.add_argument("--cpu-selfplay-seconds", type=float, default=6.0, help="per configuration of the cpu_selfplay leg")
     return ap.parse_args()
 
 
@@ -243,13 +246,65 @@ def extra_legs(args, net, dev, local_rank, fresh_board):
             out[key] = selfplay(boards, games)
         except Exception as exc:                          # the headline must not depend on a leg
             out[key] = {"error": repr(exc)}
+    net19 = None
     try:
         torch.manual_seed(4321)
         net19 = DualNet(dev, 19)
         out["cfg5_19x19"] = one_tree(19, net19, 1600, 64, 4)
     except Exception as exc:
         out["cfg5_19x19"] = {"error": repr(exc)}
+    # config[4] as a THROUGHPUT workload: many 19x19 trees in lock-step, with the forward kernel's own roofline
+    try:
+        out["cfg5_19x19_trees"] = trees_19(net19 if net19 is not None else DualNet(dev, 19), local_rank, args.cfg5_trees)
+    except Exception as exc:
+        out["cfg5_19x19_trees"] = {"error": repr(exc)}
     return out
+
+
+def trees_19(net19, local_rank, trees, visits=1600, batch=64, steps=2):
+    """BASELINE.json config[4] (19x19, 1600 strict visits/move, NN batch 64) for `trees` boards in lock-step: leaf-evals/s and
+    the roofline of the 19x19 forward kernel (algorithmic 322.5 MFLOP per position) from HIP events."""
+    import ctypes
+    from tamago_amd import lib as tl
+    from tamago_amd.board.go_board import GoBoard
+    from tamago_amd.mcts.engine import SearchEngine
+    lib = tl.load()
+    ev = TimedEvaluator(net19)
+    cur = torch.cuda.current_stream()
+    eng = SearchEngine(19, trees, visits + 16, batch, ev, device_index=local_rank)
+    fresh = GoBoard(19, 7.0, False)
+    for t in range(trees):
+        eng.set_root(t, fresh, 1, np.random.RandomState(50_000 + t).get_state())
+    plies = [np.zeros(trees, dtype=np.int64)]
+    run_step([(eng, cur)], plies, fresh, visits, batch)                       # warm-up move
+    ev.events.clear()
+    ev.record = True
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    leaves = sum(run_step([(eng, cur)], plies, fresh, visits, batch) for _ in range(steps))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ev.record = False
+    full_b = trees * batch
+    big = [e0.elapsed_time(e1) for e0, e1, b in ev.events if b == full_b]
+    kern_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in ev.events)
+    eng.close()
+    avg_ms = float(np.mean(big)) if big else float("nan")
+    flops_pos = lib.tg_net_flops_per_position(19)
+    peak = ctypes.c_double(0.0)
+    dtype_name = ctypes.c_char_p()
+    exec_flops = lib.tg_net_executed_flops_per_position(net19.handle, full_b, ctypes.byref(peak), ctypes.byref(dtype_name))
+    algorithmic = full_b * flops_pos / (avg_ms * 1e-3) / 1e12
+    return {"value": leaves / dt, "unit": "leaf-evals/s", "trees": trees, "steps": steps, "ms_per_step": dt / steps * 1e3,
+            "workload": f"cfg-5: {trees} lock-step 19x19 trees, PUCT, {visits} strict visits/move, NN batch {batch} per tree",
+            "roofline": {"bound": "mfma", "kernel": lib.tg_net_kernel_name(net19.handle, full_b).decode(),
+                         "achieved": algorithmic, "peak": peak.value, "unit": "TFLOP/s", "frac": algorithmic / peak.value,
+                         "algorithmic_flops_per_position": flops_pos,
+                         "mfma_issue_tflops": full_b * exec_flops / (avg_ms * 1e-3) / 1e12,
+                         "mfma_issue_frac": full_b * exec_flops / (avg_ms * 1e-3) / 1e12 / peak.value,
+                         "executed_dtype": dtype_name.value.decode() if dtype_name.value else "",
+                         "avg_launch_ms": avg_ms, "launches": len(big), "positions_per_launch": full_b,
+                         "forward_share_of_step": kern_ms * 1e-3 / dt, "traffic": None}}
 
 
 def cpu_baseline(size, visits, batch, budget_s):
@@ -286,6 +341,44 @@ def cpu_baseline(size, visits, batch, budget_s):
                       f"oracle Python tree (1 thread) + PyTorch-CPU DualNet "
                       f"({torch.get_num_threads()} threads) of {os.cpu_count()} host cores, "
                       f"{dt:.1f} s"}
+
+
+def cpu_selfplay(seconds):
+    """the CPU comparison for the self-play configs is N worker PROCESSES (selfplay_main.py:58-65; reference default
+    NUM_SELF_PLAY_WORKERS = 4, learning_param.py:43; also one per core): the oracle's Gumbel worker (oracle/cpu_selfplay.py) as
+    4 processes and as one process per core (capped at 32), at 16 and at 400 simulations per move, `seconds` each; torch
+    threads per process = cores / processes.  Leaf evaluations of all workers / the longest worker's time."""
+    import subprocess
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    out = {"kind": "port", "host_cores": cores,
+           "workload": "Gumbel sequential-halving self-play on the CPU oracle (Python tree + PyTorch-CPU DualNet), one OS process "
+                       "per worker as selfplay_main.py starts them, games to completion"}
+    env = dict(os.environ, PYTHONPATH=REPO + os.pathsep + os.environ.get("PYTHONPATH", ""), CUDA_VISIBLE_DEVICES="",
+               HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS="1")
+    for procs in sorted({4, max(1, min(cores, 32))}):
+        threads = max(1, cores // procs)
+        for visits in (16, 400):
+            env["OMP_NUM_THREADS"] = str(threads)
+            ps = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_selfplay", "--seconds", str(seconds), "--visits", str(visits),
+                                    "--seed", str(1 + i), "--threads", str(threads)], env=env, cwd=REPO,
+                                   stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for i in range(procs)]
+            rows = []
+            for pr in ps:
+                try:
+                    so, _ = pr.communicate(timeout=seconds * 4 + 240)
+                    rows.append(json.loads([ln for ln in so.splitlines() if ln.startswith("{")][-1]))
+                except Exception:
+                    pr.kill()
+            key = f"{procs}_processes_{visits}_sims"
+            if len(rows) != procs:
+                out[key] = {"error": f"{procs - len(rows)} of {procs} workers gave no result"}
+                continue
+            total = sum(r["leaf_evals"] for r in rows)
+            slowest = max(r["seconds"] for r in rows)
+            out[key] = {"value": total / slowest, "unit": "leaf-evals/s", "processes": procs, "torch_threads_per_process": threads,
+                        "cores": min(cores, procs * threads), "simulations_per_move": visits, "seconds": slowest,
+                        "moves": sum(r["moves"] for r in rows)}
+    return out
 
 
 def cfg1_cpu(budget_s):
@@ -606,6 +699,10 @@ def main():
                     result["cfg1_cpu"] = cfg1_cpu(8.0)
                 except Exception as exc:
                     result["cfg1_cpu"] = {"error": repr(exc)}
+                try:
+                    result["cpu_selfplay"] = cpu_selfplay(args.cpu_selfplay_seconds)
+                except Exception as exc:
+                    result["cpu_selfplay"] = {"error": repr(exc)}
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

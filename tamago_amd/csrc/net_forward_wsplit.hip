@@ -134,6 +134,36 @@ __device__ __forceinline__ void ws_load_w(i32x4v (&ua)[4][2][2][4], const unsign
         }
 }
 
+// The same for ONE point J of k-chunk KC (eight fragments: two asm statements), or only its channel tile ct of both pieces
+// (two fragments): the requests are placed between the instructions of the layer's last row tile.
+template <int KC, int J>
+__device__ __forceinline__ void ws_load_w_point(i32x4v (&ua)[4][2][2][4], const unsigned char *wb, int wlane, int ct = -1) {
+    if (ct < 0) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const unsigned char *base = wb + ((J * 2 + KC) * 2 + p) * 4096;
+            asm volatile("global_load_dwordx4 %0, %4, %5\n\t"
+                         "global_load_dwordx4 %1, %4, %5 offset:1024\n\t"
+                         "global_load_dwordx4 %2, %4, %5 offset:2048\n\t"
+                         "global_load_dwordx4 %3, %4, %5 offset:3072"
+                         : "=a"(ua[J][KC][p][0]), "=a"(ua[J][KC][p][1]), "=a"(ua[J][KC][p][2]), "=a"(ua[J][KC][p][3])
+                         : "v"(wlane), "s"(base)
+                         : "memory");
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c == ct) {
+                const unsigned char *base = wb + ((J * 2 + KC) * 2) * 4096 + c * 1024;
+                asm volatile("global_load_dwordx4 %0, %2, %3\n\t"
+                             "global_load_dwordx4 %1, %2, %3 offset:4096"
+                             : "=a"(ua[J][KC][0][c]), "=a"(ua[J][KC][1][c])
+                             : "v"(wlane), "s"(base)
+                             : "memory");
+            }
+    }
+}
+
 // Heads on the 16-bit matrix pipe (split_common.h: run_heads_mfma), reading the block output from the fp32 image X:
 // a B fragment (position li of a 16-row tile, channels 32 kc + 8 lg ..) is two 16-byte reads + the operand split.
 template <int G, typename C>
@@ -291,7 +321,11 @@ __device__ __forceinline__ void run_heads_x32(unsigned char *smem, const NetDev 
     }
 }
 
-template <int G>
+// PROF: s_memtime stamps of workgroup 0 / wave 0 (tg_net_profile_phases): [0] group start, [1] input staged, [2] stem done,
+// [3..14] layer done, [15] heads done; [40 + 35 (layer - 2) + 7 rt + i] for layers 2 and 3: i = 0 row tile start,
+// 1 k-chunk 0 transformed, 2 its MFMAs issued, 3 k-chunk 1 transformed, 4 its MFMAs issued + Z computed + barrier passed,
+// 5 exchange written + barrier passed, 6 epilogue stored
+template <int G, bool PROF>
 __global__ __launch_bounds__(256, 1) void dualnet_fwd_wsplit_kernel(
     NetDev net, const float *__restrict__ planes, int batch, int want_logits,
     float *__restrict__ policy, float *__restrict__ value, int *__restrict__ overflow) {
@@ -319,8 +353,14 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_wsplit_kernel(
 
     int stamp_i = 0;
     auto stamp = [&]() {
-        if (net.timeline && blockIdx.x == 0 && tid == 0 && stamp_i < 40)
-            net.timeline[stamp_i++] = (long long)__builtin_amdgcn_s_memtime();
+        if constexpr (PROF)
+            if (blockIdx.x == 0 && tid == 0 && stamp_i < 40) net.timeline[stamp_i++] = (long long)__builtin_amdgcn_s_memtime();
+    };
+    int dstamp_base = -1;                                      // detailed stamps of the current layer, or -1
+    auto dstamp = [&](int rt, int i) {
+        if constexpr (PROF)
+            if (blockIdx.x == 0 && tid == 0 && dstamp_base >= 0 && stamp_i < 40)
+                net.timeline[dstamp_base + 7 * rt + i] = (long long)__builtin_amdgcn_s_memtime();
     };
     int ovf = 0;
     const int n_groups = (batch + G - 1) / G;
@@ -346,7 +386,9 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_wsplit_kernel(
     i32x4v tb = *reinterpret_cast<const i32x4v *>(tin_w + (size_t)lane * 8 + 4);
     i32x4v to = *reinterpret_cast<const i32x4v *>(tout_w + (size_t)lane * 8);
     i32x4v tr = *reinterpret_cast<const i32x4v *>(tout_w + (size_t)lane * 8 + 4);
-    asm volatile("" :: "v"(ta), "v"(tb), "v"(to), "v"(tr));   // waited for here, before the weight requests below
+    i32x4v ta1 = *reinterpret_cast<const i32x4v *>(tin_w + ((size_t)64 + lane) * 8);      // row tile 1's (see body)
+    i32x4v tb1 = *reinterpret_cast<const i32x4v *>(tin_w + ((size_t)64 + lane) * 8 + 4);
+    asm volatile("" :: "v"(ta), "v"(tb), "v"(to), "v"(tr), "v"(ta1), "v"(tb1));   // waited for here, before the weight requests below
     // This wave's 64 weight fragments of a layer, [j 4][kc 2][piece 2][ct 4]: resident in the accumulation half of the
     // register file for the whole layer (MFMA A operands are read from there directly).  They are requested by inline
     // asm with AGPR destinations - left to the register allocator they end up in VGPRs, spilled to AGPRs and copied back
@@ -458,88 +500,127 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_wsplit_kernel(
         stamp();
 
         // ================= tower: 12 Winograd layers =================
-        // one row tile of one layer: IN / OUT = byte offsets of the input / output buffer, RES: add the residual from OUT
-        // (in place), LAST: the layer's last row tile - the weight registers of a k-chunk are dead after its MFMAs, and the
-        // next layer's fragments are requested into them right there (see load_w)
+        // A row tile is three phases (IN / OUT = byte offsets of the input / output buffer, RES: add the residual from OUT):
+        //   A  the 48 MFMAs of k-chunk 0 | input transform of k-chunk 1 (its patch cells were read a phase ago) | patch reads of
+        //      the NEXT row tile's k-chunk 0
+        //   B  the 48 MFMAs of k-chunk 1 | input transform of the next row tile's k-chunk 0 | patch reads of its k-chunk 1
+        //   C  output transform along the point row, exchange, finish this wave's channel tile, store
+        // A and B are written slice by slice - one MFMA, ~3 VALU instructions of the transform, every other slice a patch
+        // read - with a scheduling barrier behind each slice: an MFMA occupies the pipe for 16 cycles and the wave can issue
+        // two to three other instructions meanwhile (profiles/r04_microbench_wino_issue_model.txt); un-interleaved the same
+        // instructions cost their full issue time on top of the MFMAs (profiles/r04_phase_wsplit_v1.txt: 4.8 k cycles per row
+        // tile, of which MFMA 1.7 k).  The layer's last row tile has no next row tile to prepare (the next layer's input is
+        // still being written): its slices carry the REQUESTS for the next layer's weight fragments instead - a k-chunk's 32
+        // registers are dead once its MFMAs are issued -, and the next layer starts with one un-overlapped transform.
+        f32x4 dq[2][4][2];                                     // patch cells read ahead: [row a / b][column s][channel half]
+        i32x4v bh0[4], bl0[4];                                 // operand pieces of (row tile, k-chunk 0), built a phase ahead
+        // patch cells of k-chunk KC of the row tile whose table is (pa, pb) -> dq, cell c8 (c8 = 4 (row a / b) + s)
+        auto read_cell = [&](auto IN_, auto KC_, auto C8_, const i32x4v &pa, const i32x4v &pb) __attribute__((always_inline)) {
+            constexpr int IN = decltype(IN_)::value, kc = decltype(KC_)::value, c8 = decltype(C8_)::value;
+            const int a0 = (c8 < 4 ? pa[c8] : pb[c8 - 4]) ^ (kc << 7);
+            dq[c8 >> 2][c8 & 3][0] = lds_f32x4_at<IN>(a0);
+            dq[c8 >> 2][c8 & 3][1] = lds_f32x4_at<IN>(a0 ^ 16);
+        };
+        // the input transform of one k-chunk in 48 slices: 0..15 row pass t = d[ra] + sgn d[rb] (two values each), 16..47 per
+        // (point j, channel half h) four slices of three instructions: column pass, high pieces, remainders, low pieces
+        f32x4 tq[4][2];
+        float tv[8][4], trm[8][4];
+        unsigned thi[8][2];
+        auto tslice = [&](auto I_, i32x4v (&oh)[4], i32x4v (&ol)[4]) __attribute__((always_inline)) {
+            constexpr int i = decltype(I_)::value;
+            if constexpr (i < 16) {
+                constexpr int s_ = i >> 2, h = (i >> 1) & 1, e0 = (i & 1) * 2;
+                tq[s_][h][e0] = fmaf(dq[1][s_][h][e0], sgn, dq[0][s_][h][e0]);
+                tq[s_][h][e0 + 1] = fmaf(dq[1][s_][h][e0 + 1], sgn, dq[0][s_][h][e0 + 1]);
+            } else {
+                constexpr int k = (i - 16) >> 2, q = (i - 16) & 3, j = k >> 1, h = k & 1;
+                auto col = [&](int e) __attribute__((always_inline)) {
+                    return j == 0 ? tq[0][h][e] - tq[2][h][e] : (j == 1 ? tq[1][h][e] + tq[2][h][e]
+                         : (j == 2 ? tq[2][h][e] - tq[1][h][e] : tq[1][h][e] - tq[3][h][e]));
+                };
+                if constexpr (q == 0) {
+                    tv[k][0] = col(0); tv[k][1] = col(1); tv[k][2] = col(2);
+                } else if constexpr (q == 1) {
+                    tv[k][3] = col(3);
+                    thi[k][0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{tv[k][0], tv[k][1]}, f16x2));
+                    thi[k][1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{tv[k][2], tv[k][3]}, f16x2));
+                } else if constexpr (q == 2) {
+                    trm[k][0] = sub_f16_lo(tv[k][0], thi[k][0]);
+                    trm[k][1] = sub_f16_hi(tv[k][1], thi[k][0]);
+                    trm[k][2] = sub_f16_lo(tv[k][2], thi[k][1]);
+                } else {
+                    trm[k][3] = sub_f16_hi(tv[k][3], thi[k][1]);
+                    oh[j][2 * h] = (int)thi[k][0];
+                    oh[j][2 * h + 1] = (int)thi[k][1];
+                    ol[j][2 * h] = (int)__builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{trm[k][0], trm[k][1]}, f16x2));
+                    ol[j][2 * h + 1] = (int)__builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{trm[k][2], trm[k][3]}, f16x2));
+                }
+            }
+        };
+        // MFMA m of a k-chunk: point j = m / 12, product (m / 4) % 3 (cross terms first), channel tile m % 4
+        f32x4 acc[4][4];
+        auto mfma_slice = [&](auto KC_, auto M_, const i32x4v (&ph)[4], const i32x4v (&pl)[4]) __attribute__((always_inline)) {
+            constexpr int kc = decltype(KC_)::value, m = decltype(M_)::value, j = m / 12, st = (m / 4) % 3, c = m % 4;
+            if constexpr (st == 0)
+                acc[j][c] = mfma16<F>(ua[j][kc][1][c], ph[j], kc == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[j][c]);
+            else if constexpr (st == 1) acc[j][c] = mfma16<F>(ua[j][kc][0][c], pl[j], acc[j][c]);
+            else acc[j][c] = mfma16<F>(ua[j][kc][0][c], ph[j], acc[j][c]);
+        };
         auto body = [&](auto IN_, auto OUT_, auto RES_, auto LAST_, int rt, int next_layer, const f32x4 shf, const float down)
                         __attribute__((always_inline)) {
-            constexpr int IN = decltype(IN_)::value, OUT = decltype(OUT_)::value;
+            constexpr int OUT = decltype(OUT_)::value;
             constexpr bool RES = decltype(RES_)::value, LAST = decltype(LAST_)::value;
-            // address tables of the NEXT row tile (cyclic: the last row tile fetches row tile 0's for the next layer)
-            const int rn = rt + 1 < NRT ? rt + 1 : 0;
-            const i32x4v na = *reinterpret_cast<const i32x4v *>(tin_w + ((size_t)rn * 64 + lane) * 8);
-            const i32x4v nb = *reinterpret_cast<const i32x4v *>(tin_w + ((size_t)rn * 64 + lane) * 8 + 4);
-            const i32x4v no = *reinterpret_cast<const i32x4v *>(tout_w + ((size_t)rn * 64 + lane) * 8);
-            const i32x4v nr = *reinterpret_cast<const i32x4v *>(tout_w + ((size_t)rn * 64 + lane) * 8 + 4);
-            f32x4 acc[4][4];
-            static_for<2>([&](auto KC_) {
-                constexpr int kc = decltype(KC_)::value;
-                // ---- patch rows ra, rb of this wave's point row: 8 cells x 8 channels ----
-                f32x4 d[2][4][2];
-#pragma unroll
-                for (int c8 = 0; c8 < 8; ++c8) {
-                    const int a0 = (c8 < 4 ? ta[c8] : tb[c8 - 4]) ^ (kc << 7);
-                    d[c8 >> 2][c8 & 3][0] = lds_f32x4_at<IN>(a0);
-                    d[c8 >> 2][c8 & 3][1] = lds_f32x4_at<IN>(a0 ^ 16);
-                }
-                // ---- input transform: row pass t = d[ra] + sgn d[rb]; column pass; operand split ----
-                i32x4v bh[4], bl[4];
-                {
-                    f32x4 t[4][2];
-#pragma unroll
-                    for (int s = 0; s < 4; ++s)
-#pragma unroll
-                        for (int h = 0; h < 2; ++h)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) t[s][h][e] = fmaf(d[1][s][h][e], sgn, d[0][s][h][e]);
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        f32x4 v[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            v[0][e] = t[0][h][e] - t[2][h][e];
-                            v[1][e] = t[1][h][e] + t[2][h][e];
-                            v[2][e] = t[2][h][e] - t[1][h][e];
-                            v[3][e] = t[1][h][e] - t[3][h][e];
-                        }
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            unsigned hi[2], lo[2];
-                            split4_unscaled(v[j], hi, lo);
-                            bh[j][2 * h] = (int)hi[0];
-                            bh[j][2 * h + 1] = (int)hi[1];
-                            bl[j][2 * h] = (int)lo[0];
-                            bl[j][2 * h + 1] = (int)lo[1];
-                        }
-                    }
-                }
-                // the fragments of this k-chunk were requested a layer ago (kc = 0: 32 younger requests - the other k-chunk's -
-                // may still be in flight).  Only a layer's first row tile can actually wait here.
-                if constexpr (!LAST) {
-                    if constexpr (kc == 0) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                // ---- 48 MFMAs: cross terms first, one accumulator set ----
-                // (the three MFMAs of an accumulator four apart: a dependent MFMA issued back to back stalls)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        acc[j][c] = mfma16<F>(ua[j][kc][1][c], bh[j], kc == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[j][c]);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) acc[j][c] = mfma16<F>(ua[j][kc][0][c], bl[j], acc[j][c]);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) acc[j][c] = mfma16<F>(ua[j][kc][0][c], bh[j], acc[j][c]);
-                }
-                if constexpr (LAST) {
-                    if constexpr (kc == 0) asm volatile("" :: "v"(na), "v"(nb), "v"(no), "v"(nr));   // (their wait goes here)
-                    load_w(std::integral_constant<int, kc>{}, next_layer);
-                }
+            dstamp(rt, 0);
+            const unsigned char *wnext = net.ws_w + ((size_t)next_layer * 4 + wave) * 65536;
+            i32x4v bh1[4], bl1[4];
+            if constexpr (LAST) {
+                // row tile 1's patch table for the next layer, fetched (and, below, waited for) BEFORE the weight requests
+                // go out: hipcc's own counted waits know nothing of the asm requests, so a wait for any load of its own
+                // that is older than requests in flight would drain those as well
+                ta1 = *reinterpret_cast<const i32x4v *>(tin_w + ((size_t)64 + lane) * 8);
+                tb1 = *reinterpret_cast<const i32x4v *>(tin_w + ((size_t)64 + lane) * 8 + 4);
+            }
+            // ---- phase A ----
+            asm volatile("s_waitcnt vmcnt(32)" ::: "memory");     // this layer's k-chunk 0 fragments (requested a layer ago; the
+                                                                  // 32 requests behind them - k-chunk 1's - may still be in flight)
+            static_for<48>([&](auto M_) {
+                constexpr int m = decltype(M_)::value;
+                mfma_slice(std::integral_constant<int, 0>{}, M_, bh0, bl0);
+                tslice(M_, bh1, bl1);
+                if constexpr (!LAST && m >= 16 && m % 4 == 0)      // dq's old contents are dead behind slice 15
+                    read_cell(IN_, std::integral_constant<int, 0>{}, std::integral_constant<int, (m - 16) / 4>{}, ta, tb);
+                __builtin_amdgcn_sched_barrier(0);
             });
-            // ---- output transform along the point row: Z0 = m0 + m1 + m2, Z1 = m1 - m2 - m3 -> exchange ----
+            dstamp(rt, 1);
+            // ---- phase B ----
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // k-chunk 1's fragments (last row tile: ta1 / tb1)
+            if constexpr (LAST) asm volatile("" : "+v"(ta1), "+v"(tb1));
+            static_for<48>([&](auto M_) {
+                constexpr int m = decltype(M_)::value;
+                mfma_slice(std::integral_constant<int, 1>{}, M_, bh1, bl1);
+                if constexpr (!LAST) {
+                    tslice(M_, bh0, bl0);
+                    if constexpr (m >= 16 && m % 4 == 0)
+                        read_cell(IN_, std::integral_constant<int, 1>{}, std::integral_constant<int, (m - 16) / 4>{}, ta, tb);
+                } else if constexpr (m >= 12 && (m - 12) % 9 == 0 && (m - 12) / 9 < 4) {
+                    // k-chunk 0's fragments are dead: request the next layer's, point (m - 12) / 9, between the MFMAs
+                    ws_load_w_point<0, (m - 12) / 9>(ua, wnext, wlane);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            dstamp(rt, 2);
+            // next row tile's patch tables are dead now; fetch the ones after (cyclic over the row tiles - the geometry
+            // repeats in every layer)
+            if constexpr (!LAST) {
+                const int r2 = rt + 2 < NRT ? rt + 2 : rt + 2 - NRT;
+                ta = *reinterpret_cast<const i32x4v *>(tin_w + ((size_t)r2 * 64 + lane) * 8);
+                tb = *reinterpret_cast<const i32x4v *>(tin_w + ((size_t)r2 * 64 + lane) * 8 + 4);
+            }
+            // ---- phase C: output transform along the point row: Z0 = m0 + m1 + m2, Z1 = m1 - m2 - m3 -> exchange ----
             int exw = wave * 8192 + lane * 16, exr = wave * 1024 + lane * 16;     // this wave's block / its channel tile
             asm volatile("" : "+v"(exw), "+v"(exr));
             __syncthreads();                                // the previous row tile's exchange has been read
+            dstamp(rt, 3);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 f32x4 z0, z1;
@@ -550,8 +631,10 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_wsplit_kernel(
                 }
                 lds_f32x4_put<C::EX_OFF>(exw + c * 1024, z0);
                 lds_f32x4_put<C::EX_OFF + 4096>(exw + c * 1024, z1);
+                if constexpr (LAST) ws_load_w_point<1, 0>(ua, wnext, wlane, c);      // k-chunk 1's registers are dead as well
             }
             __syncthreads();
+            dstamp(rt, 4);
             // ---- sum over the point rows for output channels 16 wave + 4 lg .., shift, residual, ReLU, store ----
             {
                 f32x4 z[4][2];
@@ -565,6 +648,7 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_wsplit_kernel(
 #pragma unroll
                     for (int q = 0; q < 4; ++q) res[q] = lds_f32x4_at<OUT>(tr[q]);
                 }
+                if constexpr (LAST) ws_load_w_point<1, 1>(ua, wnext, wlane);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {               // q = 2 r + c: output (2 ty + r, 2 tx + c)
                     const int r = q >> 1, cc = q & 1;
@@ -579,18 +663,38 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_wsplit_kernel(
                     }
                     amax = fmaxf(fmaxf(amax, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
                     lds_f32x4_put<OUT>(to[q], v);
+                    if constexpr (LAST) {
+                        if (q == 1) ws_load_w_point<1, 2>(ua, wnext, wlane);
+                        if (q == 3) ws_load_w_point<1, 3>(ua, wnext, wlane);
+                    }
                 }
             }
-            ta = na; tb = nb; to = no; tr = nr;
+            dstamp(rt, 5);
+            {
+                const int r1 = rt + 1 < NRT ? rt + 1 : 0;
+                to = *reinterpret_cast<const i32x4v *>(tout_w + ((size_t)r1 * 64 + lane) * 8);
+                tr = *reinterpret_cast<const i32x4v *>(tout_w + ((size_t)r1 * 64 + lane) * 8 + 4);
+            }
         };
         auto conv = [&](auto IN_, auto OUT_, auto RES_, int layer) __attribute__((always_inline)) {
             // epilogue constants of the output channels this wave finishes: 16 wave + 4 lg ..
             const f32x4 shf = *reinterpret_cast<const f32x4 *>(net.ws_shift + layer * 64 + wave * 16 + lg * 4);
             const float down = net.ws_down[layer];
             const int next_layer = layer + 1 < kTowerLayers ? layer + 1 : 0;
+            dstamp_base = (layer == 2 || layer == 3) && grp == (int)blockIdx.x ? 40 + 35 * (layer - 2) : -1;
+            // prologue: row tile 0's k-chunk 0 transformed on its own, k-chunk 1's cells requested; then ta / tb = row tile 1's
+            static_for<8>([&](auto C8_) { read_cell(IN_, std::integral_constant<int, 0>{}, C8_, ta, tb); });
+            static_for<48>([&](auto I_) { tslice(I_, bh0, bl0); });
+            static_for<8>([&](auto C8_) { read_cell(IN_, std::integral_constant<int, 1>{}, C8_, ta, tb); });
+            ta = ta1;
+            tb = tb1;
+            // (row tile 0 peeled: inside the loop hipcc must assume that ta / tb are loads of the previous iteration and waits
+            // for them - in row tile 0 that wait would drain the weight requests still in flight)
+            body(IN_, OUT_, RES_, std::false_type{}, 0, next_layer, shf, down);
 #pragma unroll 1
-            for (int rt = 0; rt < NRT - 1; ++rt) body(IN_, OUT_, RES_, std::false_type{}, rt, next_layer, shf, down);
+            for (int rt = 1; rt < NRT - 1; ++rt) body(IN_, OUT_, RES_, std::false_type{}, rt, next_layer, shf, down);
             body(IN_, OUT_, RES_, std::true_type{}, NRT - 1, next_layer, shf, down);
+            // (ta / tb hold row tile 0's table again: the last fetch of the loop wrapped around)
             if (!(amax < (float)kWsRangeLimit)) ovf = 1;        // f16 range guard (also catches NaN)
             __syncthreads();                                    // OUT complete before the next layer reads it
             stamp();
@@ -605,19 +709,20 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_wsplit_kernel(
         }
         // next group's input planes: requested here, consumed after the heads
         fetch_planes(grp + gridDim.x);
-        run_heads_x32<G, C>(smem, net, b0, batch, want_logits, policy, value, tid, wave,
-                            (net.timeline && blockIdx.x == 0 && grp == blockIdx.x) ? net.timeline + 40 : nullptr);
+        run_heads_x32<G, C>(smem, net, b0, batch, want_logits, policy, value, tid, wave, nullptr);
         __syncthreads();
         stamp();
     }
     if (ovf && overflow) atomicOr(overflow, 1);
 }
 
-template <int G>
+template <int G, bool PROF = false>
 int launch_wsplit(tg_net *net, const float *planes, int batch, int want_logits, float *policy, float *value,
                   int *overflow, hipStream_t stream) {
     using C = WsCfg<G>;
-    auto kern = dualnet_fwd_wsplit_kernel<G>;
+    if (!PROF && net->dev.timeline)
+        return launch_wsplit<G, true>(net, planes, batch, want_logits, policy, value, overflow, stream);
+    auto kern = dualnet_fwd_wsplit_kernel<G, PROF>;
     // (cheap, and right for every device and thread: no per-process "already configured" flag)
     TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
     const int groups = (batch + G - 1) / G;

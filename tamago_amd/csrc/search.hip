@@ -1512,12 +1512,9 @@ template <int S, int NSEL, int NWRK>
 int launch_mpipe_cfg(const SearchDev &dev, int max_leaves, float *planes, hipStream_t st) {
     constexpr size_t lds = sizeof(MPipeShared<S, NSEL, NWRK>);
     static_assert(lds <= 160 * 1024, "LDS");
-    static bool configured = false;
-    if (!configured) {
-        TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&select_puct_mpipe_kernel<S, NSEL, NWRK>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = true;
-    }
+    // (unconditional: per device and thread-safe, unlike a process-wide flag)
+    TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&select_puct_mpipe_kernel<S, NSEL, NWRK>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((select_puct_mpipe_kernel<S, NSEL, NWRK>), dim3(dev.T), dim3(64 * (NSEL + NWRK)), lds, st, dev,
                        max_leaves, planes);
     return TG_OK;
@@ -1941,12 +1938,9 @@ int launch_owner_cfg(const SearchDev &dev, int max_leaves, float *planes, hipStr
     constexpr size_t lds = sizeof(OwnerShared<S, NNODE, NWRK>);
     static_assert(lds <= 160 * 1024, "LDS");
     static_assert(NNODE + NWRK + 2 <= 16, "wavefronts per workgroup");
-    static bool configured = false;
-    if (!configured) {
-        TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&select_puct_owner_kernel<S, NNODE, NWRK>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = true;
-    }
+    // (unconditional: per device and thread-safe, unlike a process-wide flag)
+    TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&select_puct_owner_kernel<S, NNODE, NWRK>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((select_puct_owner_kernel<S, NNODE, NWRK>), dim3(dev.T), dim3(64 * (NNODE + NWRK + 2)), lds, st, dev,
                        max_leaves, planes);
     return TG_OK;
@@ -2328,7 +2322,14 @@ __global__ __launch_bounds__(1024) void select_puct_split_kernel(SearchDev D, in
                         if ((v & ~2047) == tag_base && (v & 2047) != 0) { have = true; break; }
                     }
                     if (pipe_load(&sh.all_done) && x >= sh.nexp_total) break;   // every expansion has been through
-                    if (pipe_load(&sh.err) || ((spin & 63) == 63 && xw_load(&D.err[t]))) { ok = false; break; }
+                    if (pipe_load(&sh.err)) { ok = false; break; }
+                    if ((spin & 63) == 63 && xw_load(&D.err[t])) {
+                        // a worker workgroup gave up (it has reported why): stop this workgroup's owners too, instead of
+                        // letting them spin to their limits on nodes that will never be initialised
+                        if (lane == 0) pipe_store(&sh.err, 1);
+                        ok = false;
+                        break;
+                    }
                     __builtin_amdgcn_s_sleep(1);
                 }
                 if (!have) {
@@ -3599,6 +3600,8 @@ __global__ __launch_bounds__(64) void gather_roots_kernel(SearchDev D, int A, un
 struct tg_search {
     tg_search_config cfg{};
     SearchDev dev{};
+    int num_cus = 256;
+    int split_per_cu = -1;                 // resident select_puct_split_kernel workgroups per CU (queried at the first launch)
     std::vector<void *> allocs;
     int S = 0, W = 0, NC = 0, P = 0, A = 0, HMAX = 0;
     hipStream_t last_stream = nullptr;
@@ -3783,6 +3786,7 @@ int grow_fill(const GrowItem &g, size_t trees, size_t n_old, size_t n_new) {
 }  // namespace
 
 namespace {
+constexpr int kSplitNoRoom = 1;     // launch_split*: not launched - the device cannot hold all the tree's workgroups at once
 template <int S, int NNODE, int NWRK, int NSHIP = 3, int NWG = 1>
 int launch_split_cfg(tg_search *s, int max_leaves, float *planes, hipStream_t st) {
     constexpr size_t lds_a = sizeof(SplitSelShared<S, NNODE>), lds_b = sizeof(SplitWrkShared<S, NWRK>);
@@ -3805,12 +3809,18 @@ int launch_split_cfg(tg_search *s, int max_leaves, float *planes, hipStream_t st
         TG_HIP(hipMemsetAsync(s->xw_off, 0, (size_t)T * (s->xw_cap + 1) * sizeof(unsigned long long), st));
         s->xw_seq = 1;
     }
-    static bool configured = false;
-    if (!configured) {
-        TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&select_puct_split_kernel<S, NNODE, NWRK, NSHIP, NWG>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = true;
+    // (unconditional: cheap, and right for every device and host thread - a process-wide "configured" flag was neither)
+    TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&select_puct_split_kernel<S, NNODE, NWRK, NSHIP, NWG>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // The tree's workgroups wait for each other through memory: all (1 + NWG) T of them must be resident at once, which an
+    // ordinary launch does not promise.  They are one per CU (1024 threads, > 80 KB of LDS); when the device has fewer CUs
+    // than that (partitioned devices) the caller falls back to the one-workgroup kernel (kSplitNoRoom).
+    if (s->split_per_cu < 0) {                            // (once per handle: the query is not free)
+        int per_cu = 0;
+        TG_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, select_puct_split_kernel<S, NNODE, NWRK, NSHIP, NWG>, 1024, lds));
+        s->split_per_cu = per_cu;
     }
+    if ((long long)(1 + NWG) * T > (long long)s->split_per_cu * s->num_cus) return kSplitNoRoom;
     hipLaunchKernelGGL((select_puct_split_kernel<S, NNODE, NWRK, NSHIP, NWG>), dim3((1 + NWG) * T), dim3(1024), lds, st, s->dev,
                        max_leaves, planes, s->xw_job, s->xw_done, s->xw_n, s->xw_off, (int)((s->xw_seq & 0xFFFFFu) << 11), s->xw_cap);
     return TG_OK;
@@ -3849,6 +3859,10 @@ int tg_search_create(const tg_search_config *cfg, tg_search **out) {
     TG_HIP(hipSetDevice(cfg->device));
     tg_search *s = new tg_search;
     s->cfg = *cfg;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0) s->num_cus = cus;
+    }
     s->S = cfg->board_size;
     s->W = s->S + 2;
     s->NC = s->W * s->W;
@@ -4129,9 +4143,13 @@ int tg_search_select_puct(tg_search *s, int max_leaves, float *planes_dev, int32
     const bool owner = getenv("TG_SELECT_OWNER") && atoi(getenv("TG_SELECT_OWNER")) != 0;     // (read per call: tests toggle it)
     // up to kXwMaxTrees trees: a second workgroup (on another CU) for the board work of every tree (TG_SELECT_SPLIT=0: off)
     const bool split = !getenv("TG_SELECT_SPLIT") || atoi(getenv("TG_SELECT_SPLIT")) != 0;
+    int split_rc = kSplitNoRoom;
     if (pipelined && split && !s->dev.prof && s->dev.T <= kXwMaxTrees && s->dev.N <= (1 << 21)) {
-        int rc = s->S == 9 ? launch_split<9>(s, max_leaves, planes_dev, st) : launch_split<19>(s, max_leaves, planes_dev, st);
-        if (rc) return rc;
+        split_rc = s->S == 9 ? launch_split<9>(s, max_leaves, planes_dev, st) : launch_split<19>(s, max_leaves, planes_dev, st);
+        if (split_rc < 0) return split_rc;
+    }
+    if (split_rc == TG_OK) {
+        // launched
     } else if (pipelined && s->dev.T <= mpipe_max_trees && owner && s->dev.N <= (1 << 21)) {
         int rc = s->S == 9 ? launch_owner<9>(s->dev, max_leaves, planes_dev, st) : launch_owner<19>(s->dev, max_leaves, planes_dev, st);
         if (rc) return rc;

@@ -136,6 +136,10 @@ def run_shard(args, rank: int, world: int, local_rank: int, record_dir: str) -> 
     # more worker processes than GPUs (the reference's --process N puts N workers on ONE device, nn/utility.py:22):
     # the shards share the devices round-robin
     device_index = 0 if os.environ.get("TG_SINGLE_DEVICE") else local_rank % n_dev
+    if os.environ.get("TG_SINGLE_DEVICE") or world > n_dev:
+        # several shards share a device: the three-workgroups-per-tree selection kernel needs all of a tree's workgroups
+        # resident at once, which another shard's kernels can prevent - keep to the one-workgroup kernels
+        os.environ.setdefault("TG_SELECT_SPLIT", "0")
     cores = pin_host_threads(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), device_index)
     torch.cuda.set_device(device_index)
     network = load_network(model_file_path=args.model, use_gpu=args.use_gpu, board_size=args.size,
@@ -218,10 +222,14 @@ def main(argv=None) -> dict:
             print(f"Self play visits : {args.visits}")
         record_dir = os.path.join(args.save_dir, str(box[0]))
         t0 = time.perf_counter()
+        interrupted = None
         try:
             mine = run_shard(args, rank, world, local_rank, record_dir)
-        except BaseException as exc:
+        except Exception as exc:
             mine = {"error": repr(exc), "rank": rank}
+        except (KeyboardInterrupt, SystemExit) as exc:     # reported like a failure, re-raised behind the collectives
+            mine = {"error": repr(exc), "rank": rank}
+            interrupted = exc
         gathered = [mine]
         if world > 1:
             gathered = [None] * world
@@ -237,6 +245,8 @@ def main(argv=None) -> dict:
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
+        if interrupted is not None:
+            raise interrupted
         if failed:
             raise SystemExit(f"self-play shard(s) failed: {failed}")
         return result

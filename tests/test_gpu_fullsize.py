@@ -151,3 +151,25 @@ def test_bench_two_ranks_on_one_gpu():
     assert leg["shards"] == 2 and [r["rank"] for r in leg["per_rank"]] == [0, 1]
     assert all(r["games"] == 6 and r["host_cores"] >= 1 for r in leg["per_rank"])
     assert abs(leg["value"] * leg["seconds"] - sum(r["moves"] for r in leg["per_rank"]) * 33) < 1.0
+
+
+def test_bench_rank_failure_in_the_cfg4_leg_reaches_every_rank():
+    """A rank whose cfg-4 shard raises (injected: TG_BENCH_FAIL_RANK=1) still takes part in the leg's collectives: the
+    2-rank bench ends promptly - nobody waits in all_gather for the RCCL / gloo timeout -, rank 0 prints the headline line
+    with the leg reported as an error naming the rank, exit code 0."""
+    import time
+    env = dict(os.environ, TG_SINGLE_DEVICE="1", TG_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT="29587",
+               TG_BENCH_FAIL_RANK="1", PYTHONPATH=REPO + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", "29587", os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1",
+           "--warmup", "0", "--trees", "16", "--no-cpu-baseline", "--cfg4-boards", "4", "--cfg4-games", "4",
+           "--cfg4-visits", "16"]
+    t0 = time.time()
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=REPO)
+    elapsed = time.time() - t0
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert elapsed < 150, elapsed                       # (a hang would run into the 300 s / the collective's 10-minute timeout)
+    res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["n_gpus"] == 2 and res["value"] > 0
+    leg = res["cfg4_selfplay_shards"]
+    assert leg["failed_ranks"] == [1] and "injected failure on rank 1" in leg["messages"]["1"], leg
