@@ -651,6 +651,8 @@ def main():
             },
             "roofline": roof,
             "tree_kernels": tree_pmc_summary() if args.size == 9 else None,
+            # forward launches the exact-fp32 kernel had to redo (f16 range guard of the split-operand kernels): 0 = none
+            "range_fallbacks": net.range_fallbacks(),
         }
     # ---- exact-fp32 arithmetic on the same workload (N = 1): the Winograd fp32-MFMA kernel ----
     if world == 1 and not args.no_legs and args.size == 9:

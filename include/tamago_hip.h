@@ -89,6 +89,12 @@ double tg_net_flops_per_position(int board_size);
  * *dtype its name.  The roofline fraction of the forward kernel is executed FLOP/s over that peak. */
 double tg_net_executed_flops_per_position(const tg_net *net, int batch, double *peak_tflops,
                                           const char **dtype);
+/* The split-operand kernels compute in f16 pieces: a layer output beyond the f16 range raises a flag on the device and the
+ * exact-fp32 kernel queued behind every launch redoes that batch (same results, ~2.5x the time; no host round trip).
+ * *count receives the number of forward launches of this network that were redone so far - a network whose activations
+ * run hot shows up here instead of only as a slower search.  Synchronises the device.  (No reference counterpart: the
+ * reference computes in fp32 throughout, nn/network/dual_net.py:41-52.) */
+int tg_net_range_fallbacks(tg_net *net, unsigned long long *count);
 
 /* ---- featurise (nn/feature.py:10-57 + go_board.py:468-478) -------------------------- */
 /* cells_dev: uint8 [B, P] on-board cell colours, row-major from the top-left point;

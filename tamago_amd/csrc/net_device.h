@@ -63,6 +63,7 @@ struct NetDev {
     const float *ws_down;
     const int *ws_tin[2];
     const int *ws_tout[2];
+    unsigned long long *fallbacks;    // launches redone by the exact-fp32 kernel behind a raised range flag (tg_net_range_fallbacks)
     int *overflow;                    // f16 range guard: set when a layer output leaves the f16 range
     float *scratch;       // 19x19 Winograd: per workgroup two [P][64] activation images (L2-resident)
     long long *timeline;  // optional [128] s_memtime stamps of workgroup 0 (tg_net_profile_phases)

@@ -279,7 +279,10 @@ __global__ __launch_bounds__(512, 2) void dualnet_fwd_wino8_kernel(
     float *__restrict__ policy, float *__restrict__ value, const int *__restrict__ guard) {
     using C = WinoCfg<S, G, GS>;
     // fallback launch behind the split-operand kernel: runs only if that kernel raised its range flag
-    if (guard != nullptr && __builtin_nontemporal_load(guard) == 0) return;
+    if (guard != nullptr) {
+        if (__builtin_nontemporal_load(guard) == 0) return;
+        if (blockIdx.x == 0 && threadIdx.x == 0 && net.fallbacks) atomicAdd(net.fallbacks, 1ull);
+    }
     constexpr int P = C::P, M = C::M, MT = C::MT;
     constexpr int TY = C::TY, TPB = C::TPB, NT = C::NT, RT = C::RT;
     constexpr int MTH = (MT + 1) / 2;                 // stem M-tiles per half
@@ -765,6 +768,15 @@ int tg_net_create(int board_size, int device, const float *params, size_t n_para
         delete net;
         return tg::fail(TG_ERR_ARG, "tg_net_create: parameter blob not fully consumed");
     }
+    {
+        void *d = nullptr;
+        if (hipMalloc(&d, sizeof(unsigned long long)) != hipSuccess || hipMemset(d, 0, sizeof(unsigned long long)) != hipSuccess) {
+            delete net;
+            return tg::fail(TG_ERR_HIP, "tg_net_create: fallback counter");
+        }
+        net->allocs.push_back(d);
+        net->dev.fallbacks = static_cast<unsigned long long *>(d);
+    }
 
     // scratch images of the 19x19 Winograd kernel: 2 x [P][64] floats per workgroup, allocated per
     // launch stream on first use (launch_wino8)
@@ -988,6 +1000,14 @@ int tg_net_forward_dev(tg_net *net, const float *planes_dev, int batch, int want
     const int g = pick_group(9, batch, net->num_cus);
     if (g == 3) return launch<9, 3>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st);
     return launch<9, 1>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st);
+}
+
+int tg_net_range_fallbacks(tg_net *net, unsigned long long *count) {
+    if (!net || !count) return tg::fail(TG_ERR_ARG, "tg_net_range_fallbacks: null argument");
+    TG_HIP(hipSetDevice(net->device));
+    TG_HIP(hipDeviceSynchronize());
+    TG_HIP(hipMemcpy(count, net->dev.fallbacks, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return TG_OK;
 }
 
 int tg_net_profile_phases(tg_net *net, const float *planes_dev, int batch, float *policy_dev, float *value_dev,

@@ -156,9 +156,9 @@ __device__ __forceinline__ void ws_load_w_point(i32x4v (&ua)[4][2][2][4], const 
             if (c == ct) {
                 const unsigned char *base = wb + ((J * 2 + KC) * 2) * 4096 + c * 1024;
                 asm volatile("global_load_dwordx4 %0, %2, %3\n\t"
-                             "global_load_dwordx4 %1, %2, %3 offset:4096"
+                             "global_load_dwordx4 %1, %2, %4"
                              : "=a"(ua[J][KC][0][c]), "=a"(ua[J][KC][1][c])
-                             : "v"(wlane), "s"(base)
+                             : "v"(wlane), "s"(base), "s"(base + 4096)
                              : "memory");
             }
     }

@@ -55,6 +55,7 @@ _SIGNATURES = {
     "tg_net_kernel_name": (c_char_p, [c_void_p, c_int]),
     "tg_net_flops_per_position": (c_double, [c_int]),
     "tg_net_executed_flops_per_position": (c_double, [c_void_p, c_int, POINTER(c_double), POINTER(c_char_p)]),
+    "tg_net_range_fallbacks": (c_int, [c_void_p, POINTER(ctypes.c_ulonglong)]),
     "tg_featurize_dev": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                  c_void_p]),
     "tg_featurize_sym_dev": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,

@@ -127,6 +127,13 @@ class DualNet:
         return self._handle
 
     # -- inference -----------------------------------------------------------------------
+    def range_fallbacks(self) -> int:
+        """Forward launches of this network that the exact-fp32 kernel had to redo because a layer output left the f16 range
+        of the split-operand kernel (tg_net_range_fallbacks; synchronises the device).  0 for a healthy network."""
+        count = ctypes.c_ulonglong(0)
+        _lib.check(self._lib.tg_net_range_fallbacks(self._handle, ctypes.byref(count)), "tg_net_range_fallbacks")
+        return int(count.value)
+
     def _forward_host(self, input_plane: torch.Tensor, want_logits: int):
         x = input_plane.detach().to("cpu", torch.float32).contiguous()
         b, s = x.shape[0], self.board_size

@@ -71,9 +71,10 @@ def selfplay_shard(save_dir: str, network, index_list: Sequence[int], size: int,
     todo = [i for i in index_list if not os.path.isfile(os.path.join(save_dir, f"{i}.sgf"))]
     seeds = dict(zip(index_list, seeds if seeds is not None else index_list))
     flags = dict(zip(index_list, never_resign_flags)) if never_resign_flags is not None else None
-    stats = {"games": 0, "moves": 0, "leaf_evals": 0}
+    stats = {"games": 0, "moves": 0, "leaf_evals": 0, "range_fallbacks": 0}
     if not todo:
         return stats
+    fb0 = network.range_fallbacks() if hasattr(network, "range_fallbacks") else 0
     boards = min(boards, len(todo))
     if groups <= 0:
         # measured on MI355X (tools/bench_selfplay.py, 400 simulations): with the per-move bookkeeping inside the
@@ -98,6 +99,8 @@ def selfplay_shard(save_dir: str, network, index_list: Sequence[int], size: int,
 
     if groups == 1:
         _run_group(save_dir, network, size, visits, boards, seeds, device_index, next_game, stats, None, observer)
+        if hasattr(network, "range_fallbacks"):             # forward passes redone in exact fp32 (f16 range guard)
+            stats["range_fallbacks"] = network.range_fallbacks() - fb0
         return stats
 
     import torch
@@ -129,8 +132,10 @@ def selfplay_shard(save_dir: str, network, index_list: Sequence[int], size: int,
     if errors:
         raise errors[0]
     for r in results:
-        for k in stats:
+        for k in ("games", "moves", "leaf_evals"):
             stats[k] += r[k]
+    if hasattr(network, "range_fallbacks"):
+        stats["range_fallbacks"] = network.range_fallbacks() - fb0
     return stats
 
 

@@ -116,7 +116,7 @@ def test_featurize_kernel_vs_reference_golden(size):
     assert np.array_equal(out.cpu().numpy(), np.array(want))
 
 
-@pytest.mark.parametrize("size,algo", [(9, "direct"), (9, "wino"), (9, "split16"), (9, "w2"),
+@pytest.mark.parametrize("size,algo", [(9, "direct"), (9, "wino"), (9, "split16"), (9, "w2"), (9, "wsplit"),
                                        (19, "direct"), (19, "wino"), (19, "split16")])
 def test_every_tower_algorithm_matches_the_oracle(algo, size, monkeypatch):
     """Implementations of the residual tower: exact-fp32 Winograd F(2x2,3x3) kernel (TG_FWD_ALGO=wino; the
@@ -149,7 +149,7 @@ def test_split_kernels_are_fp32_class_and_fall_back_on_f16_overflow(monkeypatch)
     from oracle.net import OracleNet, make_state_dict
     fix = load_npz("net_s9.npz")
     errs = {}
-    for algo in ("wino", "direct", "split16", "w2"):
+    for algo in ("wino", "direct", "split16", "w2", "wsplit"):
         monkeypatch.setenv("TG_FWD_ALGO", algo)
         worst = 0.0
         for seed in (0, 7):
@@ -172,7 +172,14 @@ def test_split_kernels_are_fp32_class_and_fall_back_on_f16_overflow(monkeypatch)
     x = torch.from_numpy(np.random.RandomState(2).randint(-1, 2, size=(300, 6, 9, 9)).astype(np.float32))
     monkeypatch.setenv("TG_FWD_ALGO", "wino")
     want = _net(9, sd).inference_with_policy_logits(x)
-    for algo in ("split16", "w2"):
+    for algo in ("split16", "w2", "wsplit"):
         monkeypatch.setenv("TG_FWD_ALGO", algo)
-        got = _net(9, sd).inference_with_policy_logits(x)
+        hot = _net(9, sd)
+        assert hot.range_fallbacks() == 0
+        got = hot.inference_with_policy_logits(x)
         assert torch.isfinite(got[0]).all() and torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), algo
+        # ... and the host can see that it happened (tg_net_range_fallbacks): one redone launch here, none for a healthy net
+        assert hot.range_fallbacks() == 1, algo
+        healthy = _net(9, make_state_dict(9, 3, 1.4))
+        healthy.inference_with_policy_logits(x)
+        assert healthy.range_fallbacks() == 0, algo
