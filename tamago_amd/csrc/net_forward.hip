@@ -828,8 +828,9 @@ static int pick_group(int board_size, int batch, int num_cus) {
 
 static int pick_wino(int board_size, int batch, int num_cus);
 
-// 9x9 forward algorithm: TG_FWD_ALGO = split16 (f16 x 2 operand pieces on the 16-bit matrix pipe, 3 MFMAs
-// per product-sum; default) | wino (exact fp32 Winograd tower) | direct (exact fp32 direct convolution).
+// forward algorithm: TG_FWD_ALGO = wsplit (9x9 default: Winograd F(2x2,3x3) tower on f16 x 2 operand pieces) | split16 (direct
+// 3x3 convolution on f16 x 2 operand pieces, 3 MFMAs per product-sum; the 19x19 default) | w2 | wino (exact fp32 Winograd
+// tower) | direct (exact fp32 direct convolution).
 static bool pick_split() {
     const char *env = getenv("TG_FWD_ALGO");
     return !env || !strcmp(env, "split16") || !strcmp(env, "w2") || !strcmp(env, "wsplit");
@@ -838,7 +839,7 @@ static bool pick_split() {
 static bool pick_wsplit(int board_size) {
     if (board_size != 9) return false;
     const char *env = getenv("TG_FWD_ALGO");
-    return env && !strcmp(env, "wsplit");
+    return !env || !strcmp(env, "wsplit");           // the 9x9 default since round 4 (TG_FWD_ALGO=split16: the direct split kernel)
 }
 // TG_FWD_ALGO=w2: large 9x9 batches (three boards per workgroup) on the two-waves-per-SIMD kernel (net_forward_w2.hip:
 // weights through an LDS ring, batch norm folded into the weights); measured level with the one-wave-per-SIMD kernel

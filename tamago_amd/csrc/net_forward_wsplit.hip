@@ -92,27 +92,21 @@ __device__ __forceinline__ void lds_f32x4_put(int addr, f32x4 v) {
     *reinterpret_cast<lds_f32x4_t *>(static_cast<unsigned>(addr + OFF)) = v;
 }
 
-// v_fma_mix_f32: v - (f16 half of h), exact.  hipcc does not form it from C (it emits v_cvt_f32_f16 + v_sub_f32).
-__device__ __forceinline__ float sub_f16_lo(float v, unsigned h) {
-    float r;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(v));
+// Low pieces of two values whose high pieces are packed in h: f16(v0 - h.lo) | f16(v1 - h.hi) << 16, i.e. v_fma_mixlo_f16 /
+// v_fma_mixhi_f16 with the f16 halves of h as source 0, -1.0 as source 1 and the fp32 value as source 2: the difference is
+// exact in fp32 and rounded once.  (hipcc does not form these from C: it emits v_cvt_f32_f16 + v_sub_f32 + v_cvt_pk_f16_f32.)
+__device__ __forceinline__ unsigned low_pieces(float v0, float v1, unsigned h) {
+    unsigned r;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(v0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(h), "v"(v1));
     return r;
 }
-__device__ __forceinline__ float sub_f16_hi(float v, unsigned h) {
-    float r;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(v));
-    return r;
-}
-// four fp32 values -> two packed registers of high pieces, two of UNSCALED low pieces (8 VALU instructions)
+// four fp32 values -> two packed registers of high pieces, two of UNSCALED low pieces (6 VALU instructions)
 __device__ __forceinline__ void split4_unscaled(const f32x4 v, unsigned (&hi)[2], unsigned (&lo)[2]) {
-    const f16x2 h01 = __builtin_convertvector(f32x2v{v[0], v[1]}, f16x2);
-    const f16x2 h23 = __builtin_convertvector(f32x2v{v[2], v[3]}, f16x2);
-    hi[0] = __builtin_bit_cast(unsigned, h01);
-    hi[1] = __builtin_bit_cast(unsigned, h23);
-    const float r0 = sub_f16_lo(v[0], hi[0]), r1 = sub_f16_hi(v[1], hi[0]);
-    const float r2 = sub_f16_lo(v[2], hi[1]), r3 = sub_f16_hi(v[3], hi[1]);
-    lo[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{r0, r1}, f16x2));
-    lo[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{r2, r3}, f16x2));
+    hi[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{v[0], v[1]}, f16x2));
+    hi[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{v[2], v[3]}, f16x2));
+    lo[0] = low_pieces(v[0], v[1], hi[0]);
+    lo[1] = low_pieces(v[2], v[3], hi[1]);
 }
 
 // Request the 32 weight fragments of k-chunk KC of a wave's layer block wb ([j 4][kc 2][piece 2][ct 4][lane][16 B]) into
@@ -323,8 +317,7 @@ __device__ __forceinline__ void run_heads_x32(unsigned char *smem, const NetDev 
 
 // PROF: s_memtime stamps of workgroup 0 / wave 0 (tg_net_profile_phases): [0] group start, [1] input staged, [2] stem done,
 // [3..14] layer done, [15] heads done; [40 + 35 (layer - 2) + 7 rt + i] for layers 2 and 3: i = 0 row tile start,
-// 1 k-chunk 0 transformed, 2 its MFMAs issued, 3 k-chunk 1 transformed, 4 its MFMAs issued + Z computed + barrier passed,
-// 5 exchange written + barrier passed, 6 epilogue stored
+// 1 phase A done, 2 phase B done, 3 tail done + barrier passed, 4 (last row tile: own epilogue done)
 template <int G, bool PROF>
 __global__ __launch_bounds__(256, 1) void dualnet_fwd_wsplit_kernel(
     NetDev net, const float *__restrict__ planes, int batch, int want_logits,
@@ -384,8 +377,9 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_wsplit_kernel(
     // LDS address tables of the row tile about to be processed (carried across layers: the geometry repeats)
     i32x4v ta = *reinterpret_cast<const i32x4v *>(tin_w + (size_t)lane * 8);
     i32x4v tb = *reinterpret_cast<const i32x4v *>(tin_w + (size_t)lane * 8 + 4);
-    i32x4v to = *reinterpret_cast<const i32x4v *>(tout_w + (size_t)lane * 8);
+    i32x4v to = *reinterpret_cast<const i32x4v *>(tout_w + (size_t)lane * 8);          // store / residual tables: see body
     i32x4v tr = *reinterpret_cast<const i32x4v *>(tout_w + (size_t)lane * 8 + 4);
+    i32x4v to2 = to, tr2 = tr;
     i32x4v ta1 = *reinterpret_cast<const i32x4v *>(tin_w + ((size_t)64 + lane) * 8);      // row tile 1's (see body)
     i32x4v tb1 = *reinterpret_cast<const i32x4v *>(tin_w + ((size_t)64 + lane) * 8 + 4);
     asm volatile("" :: "v"(ta), "v"(tb), "v"(to), "v"(tr), "v"(ta1), "v"(tb1));   // waited for here, before the weight requests below
@@ -500,21 +494,26 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_wsplit_kernel(
         stamp();
 
         // ================= tower: 12 Winograd layers =================
-        // A row tile is three phases (IN / OUT = byte offsets of the input / output buffer, RES: add the residual from OUT):
-        //   A  the 48 MFMAs of k-chunk 0 | input transform of k-chunk 1 (its patch cells were read a phase ago) | patch reads of
-        //      the NEXT row tile's k-chunk 0
-        //   B  the 48 MFMAs of k-chunk 1 | input transform of the next row tile's k-chunk 0 | patch reads of its k-chunk 1
-        //   C  output transform along the point row, exchange, finish this wave's channel tile, store
-        // A and B are written slice by slice - one MFMA, ~3 VALU instructions of the transform, every other slice a patch
-        // read - with a scheduling barrier behind each slice: an MFMA occupies the pipe for 16 cycles and the wave can issue
-        // two to three other instructions meanwhile (profiles/r04_microbench_wino_issue_model.txt); un-interleaved the same
-        // instructions cost their full issue time on top of the MFMAs (profiles/r04_phase_wsplit_v1.txt: 4.8 k cycles per row
-        // tile, of which MFMA 1.7 k).  The layer's last row tile has no next row tile to prepare (the next layer's input is
-        // still being written): its slices carry the REQUESTS for the next layer's weight fragments instead - a k-chunk's 32
-        // registers are dead once its MFMAs are issued -, and the next layer starts with one un-overlapped transform.
+        // A row tile is two MFMA phases and a short tail (IN / OUT = byte offsets of the input / output buffer, RES: add the
+        // residual from OUT):
+        //   A  the 48 MFMAs of k-chunk 0 | input transform of k-chunk 1 (its patch cells were read a phase ago) | the
+        //      EPILOGUE OF THE PREVIOUS ROW TILE (exchange reads, sum over the point rows, shift, residual, ReLU, stores) |
+        //      patch reads of the next row tile's k-chunk 0
+        //   B  the 48 MFMAs of k-chunk 1 | input transform of the next row tile's k-chunk 0 | output transform along the point
+        //      row as far as the finished accumulators allow (Z0 complete and written behind point 2) | patch reads of the
+        //      next row tile's k-chunk 1
+        //   tail  Z1 = (m1 - m2) - m3, written; barrier
+        // A and B are written slice by slice - one MFMA and the instructions that ride along - with a scheduling barrier
+        // behind each slice: an MFMA occupies the pipe for 16 cycles and the wave issues two to three other instructions
+        // meanwhile; everything beyond that costs its issue time, but no longer its LATENCY (LDS round trips, the exchange's
+        // write bandwidth, barriers waiting for stragglers), which is what the un-overlapped version paid
+        // (profiles/r04_phase_wsplit_v1.txt: 4.8 k cycles per row tile; r04_phase_wsplit_v2_pipelined.txt: 4.3 k with the
+        // transform under the MFMAs and 2 k of those in the exchange + epilogue).  The layer's last row tile has no next
+        // row tile to prepare (the next layer's input is still being written): its slices carry the REQUESTS for the next
+        // layer's weight fragments instead - a k-chunk's 32 registers are dead once its MFMAs are issued -, its epilogue runs
+        // on its own, and the next layer starts with one un-overlapped transform.
         f32x4 dq[2][4][2];                                     // patch cells read ahead: [row a / b][column s][channel half]
         i32x4v bh0[4], bl0[4];                                 // operand pieces of (row tile, k-chunk 0), built a phase ahead
-        // patch cells of k-chunk KC of the row tile whose table is (pa, pb) -> dq, cell c8 (c8 = 4 (row a / b) + s)
         auto read_cell = [&](auto IN_, auto KC_, auto C8_, const i32x4v &pa, const i32x4v &pb) __attribute__((always_inline)) {
             constexpr int IN = decltype(IN_)::value, kc = decltype(KC_)::value, c8 = decltype(C8_)::value;
             const int a0 = (c8 < 4 ? pa[c8] : pb[c8 - 4]) ^ (kc << 7);
@@ -522,9 +521,9 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_wsplit_kernel(
             dq[c8 >> 2][c8 & 3][1] = lds_f32x4_at<IN>(a0 ^ 16);
         };
         // the input transform of one k-chunk in 48 slices: 0..15 row pass t = d[ra] + sgn d[rb] (two values each), 16..47 per
-        // (point j, channel half h) four slices of three instructions: column pass, high pieces, remainders, low pieces
+        // (point j, channel half h) four slices of two to three instructions: column pass, high pieces, low pieces
         f32x4 tq[4][2];
-        float tv[8][4], trm[8][4];
+        float tv[8][4];
         unsigned thi[8][2];
         auto tslice = [&](auto I_, i32x4v (&oh)[4], i32x4v (&ol)[4]) __attribute__((always_inline)) {
             constexpr int i = decltype(I_)::value;
@@ -545,15 +544,11 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_wsplit_kernel(
                     thi[k][0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{tv[k][0], tv[k][1]}, f16x2));
                     thi[k][1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{tv[k][2], tv[k][3]}, f16x2));
                 } else if constexpr (q == 2) {
-                    trm[k][0] = sub_f16_lo(tv[k][0], thi[k][0]);
-                    trm[k][1] = sub_f16_hi(tv[k][1], thi[k][0]);
-                    trm[k][2] = sub_f16_lo(tv[k][2], thi[k][1]);
-                } else {
-                    trm[k][3] = sub_f16_hi(tv[k][3], thi[k][1]);
                     oh[j][2 * h] = (int)thi[k][0];
+                    ol[j][2 * h] = (int)low_pieces(tv[k][0], tv[k][1], thi[k][0]);
+                } else {
                     oh[j][2 * h + 1] = (int)thi[k][1];
-                    ol[j][2 * h] = (int)__builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{trm[k][0], trm[k][1]}, f16x2));
-                    ol[j][2 * h + 1] = (int)__builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{trm[k][2], trm[k][3]}, f16x2));
+                    ol[j][2 * h + 1] = (int)low_pieces(tv[k][2], tv[k][3], thi[k][1]);
                 }
             }
         };
@@ -566,19 +561,61 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_wsplit_kernel(
             else if constexpr (st == 1) acc[j][c] = mfma16<F>(ua[j][kc][0][c], pl[j], acc[j][c]);
             else acc[j][c] = mfma16<F>(ua[j][kc][0][c], ph[j], acc[j][c]);
         };
-        auto body = [&](auto IN_, auto OUT_, auto RES_, auto LAST_, int rt, int next_layer, const f32x4 shf, const float down)
-                        __attribute__((always_inline)) {
-            constexpr int OUT = decltype(OUT_)::value;
-            constexpr bool RES = decltype(RES_)::value, LAST = decltype(LAST_)::value;
+        // The epilogue of one row tile, output q = 2 r + c at (2 ty + r, 2 tx + c), in six steps: 0 the three exchange reads
+        // (+ the residual), 1..4 one channel each (sum over the point rows, shift, residual, ReLU), 5 range check + store.
+        // Output channels 16 wave + 4 lg ..; po / pr: the row tile's store / residual address tables.
+        f32x4 ez[4][3], eres[4], ev[4];
+        auto epi_step = [&](auto OUT_, auto RES_, auto Q_, auto I_, const i32x4v &po, const i32x4v &pr, const f32x4 shf, const float down,
+                            int exr) __attribute__((always_inline)) {
+            constexpr int OUT = decltype(OUT_)::value, q = decltype(Q_)::value, i = decltype(I_)::value, r = q >> 1, cc = q & 1;
+            constexpr bool RES = decltype(RES_)::value;
+            if constexpr (i == 0) {
+                static_for<3>([&](auto U_) {                       // point rows r .. r + 2
+                    constexpr int u = decltype(U_)::value;
+                    ez[q][u] = lds_f32x4_at<((r + u) * 2 + cc) * 4096>(exr);
+                });
+                if constexpr (RES) eres[q] = lds_f32x4_at<OUT>(pr[q]);
+            } else if constexpr (i <= 4) {
+                constexpr int e = i - 1;
+                const float y = r == 0 ? (ez[q][0][e] + ez[q][1][e]) + ez[q][2][e] : (ez[q][0][e] - ez[q][1][e]) - ez[q][2][e];
+                float tt = fmaf(y, down, shf[e]);
+                if constexpr (RES) tt += eres[q][e];
+                ev[q][e] = fmaxf(tt, 0.f);
+            } else {
+                amax = fmaxf(fmaxf(amax, ev[q][0]), ev[q][1]);        // (v_max3_f32)
+                amax = fmaxf(fmaxf(amax, ev[q][2]), ev[q][3]);
+                lds_f32x4_put<OUT>(po[q], ev[q]);
+            }
+        };
+        // output transform along the point row, riding along phase B: zs01 = m0 + m1 (behind point 1), Z0 = zs01 + m2 and
+        // zd12 = m1 - m2 (behind point 2; Z0 written), Z1 = zd12 - m3 in the tail
+        f32x4 zs01[4], zd12[4];
+        auto ztail = [&](auto C_, int exw) __attribute__((always_inline)) {
+            constexpr int c = decltype(C_)::value;
+            f32x4 z1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) z1[e] = zd12[c][e] - acc[3][c][e];
+            lds_f32x4_put<4096 + c * 1024>(exw, z1);
+        };
+        auto body = [&](auto IN_, auto OUT_, auto RES_, auto FIRST_, auto LAST_, int rt, int next_layer, const f32x4 shf,
+                        const float down) __attribute__((always_inline)) {
+            constexpr bool FIRST = decltype(FIRST_)::value, LAST = decltype(LAST_)::value;
             dstamp(rt, 0);
             const unsigned char *wnext = net.ws_w + ((size_t)next_layer * 4 + wave) * 65536;
             i32x4v bh1[4], bl1[4];
+            // exchange addresses (absolute): this wave's block / its channel tile.  (The exchange lies beyond the 64 KB an
+            // LDS instruction's offset field reaches: with the base as an immediate every access cost a v_add_u32.)
+            int exw = C::EX_OFF + wave * 8192 + lane * 16, exr = C::EX_OFF + wave * 1024 + lane * 16;
+            asm volatile("" : "+v"(exw), "+v"(exr));
+            // (last row tile) the tables the code behind the weight requests needs are fetched here and waited for in slice 12
+            // of phase A, before the first request goes out: hipcc's own counted waits know nothing of the asm requests, so a
+            // wait for any load of its own that is older than requests in flight would drain those as well.  ta1 / tb1: row
+            // tile 1's patch table (next layer); to2 / tr2: this row tile's store / residual table (its epilogue runs last)
             if constexpr (LAST) {
-                // row tile 1's patch table for the next layer, fetched (and, below, waited for) BEFORE the weight requests
-                // go out: hipcc's own counted waits know nothing of the asm requests, so a wait for any load of its own
-                // that is older than requests in flight would drain those as well
                 ta1 = *reinterpret_cast<const i32x4v *>(tin_w + ((size_t)64 + lane) * 8);
                 tb1 = *reinterpret_cast<const i32x4v *>(tin_w + ((size_t)64 + lane) * 8 + 4);
+                to2 = *reinterpret_cast<const i32x4v *>(tout_w + ((size_t)(NRT - 1) * 64 + lane) * 8);
+                tr2 = *reinterpret_cast<const i32x4v *>(tout_w + ((size_t)(NRT - 1) * 64 + lane) * 8 + 4);
             }
             // ---- phase A ----
             asm volatile("s_waitcnt vmcnt(32)" ::: "memory");     // this layer's k-chunk 0 fragments (requested a layer ago; the
@@ -587,14 +624,42 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_wsplit_kernel(
                 constexpr int m = decltype(M_)::value;
                 mfma_slice(std::integral_constant<int, 0>{}, M_, bh0, bl0);
                 tslice(M_, bh1, bl1);
+                // previous row tile's epilogue: output q's exchange reads in slice 6 q, its five compute / store steps in slices
+                // 6 q + 7 .. 6 q + 11 - a whole output later, so that the LDS round trip (150+ cycles with four waves on the
+                // LDS) is over when the values are needed (next slice: +500 cycles per phase, profiles/r04_phase_wsplit_v4.txt)
+                // ... behind the previous row tile's Z1 = (m1 - m2) - m3 (slices 0 .. 3: point 3 finished with phase B's last
+                // MFMA) and the barrier that publishes the exchange (slice 5): write latency and stragglers cost MFMA slots that
+                // are filled anyway instead of a tail of their own
+                if constexpr (!FIRST && m < 4) ztail(std::integral_constant<int, m>{}, exw);
+                if constexpr (!FIRST && m == 5) __syncthreads();
+                if constexpr (!FIRST && m >= 6 && m < 30 && m % 6 == 0)
+                    epi_step(OUT_, RES_, std::integral_constant<int, m / 6 - 1>{}, std::integral_constant<int, 0>{}, to, tr, shf, down, exr);
+                if constexpr (!FIRST && m >= 13 && m < 36 && (m - 12) % 6 != 0)
+                    epi_step(OUT_, RES_, std::integral_constant<int, (m - 12) / 6>{}, std::integral_constant<int, (m - 12) % 6>{}, to, tr, shf, down, exr);
                 if constexpr (!LAST && m >= 16 && m % 4 == 0)      // dq's old contents are dead behind slice 15
                     read_cell(IN_, std::integral_constant<int, 0>{}, std::integral_constant<int, (m - 16) / 4>{}, ta, tb);
+                // last row tile: point j's k-chunk 0 fragments are dead behind slice 12 j + 11 - request the next layer's, two
+                // fragments (one channel tile) every third slice (a request costs the wave ~40 cycles of issue: the CU's
+                // address path takes 16 cycles per wave instruction and the four waves request at the same time)
+                if constexpr (LAST && m == 12) asm volatile("" : "+v"(ta1), "+v"(tb1), "+v"(to2), "+v"(tr2));
+                if constexpr (LAST && m >= 12 && m % 3 == 0)
+                    ws_load_w_point<0, (m - 12) / 12>(ua, wnext, wlane, ((m - 12) % 12) / 3);
                 __builtin_amdgcn_sched_barrier(0);
             });
             dstamp(rt, 1);
             // ---- phase B ----
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // k-chunk 1's fragments (last row tile: ta1 / tb1)
-            if constexpr (LAST) asm volatile("" : "+v"(ta1), "+v"(tb1));
+            // k-chunk 1's fragments (only a layer's first row tile can wait here; in the last one requests are in flight
+            // already, and everything it still needs has been waited for)
+            if constexpr (!LAST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // this row tile's store / residual table (the previous one's is dead), for its epilogue in the next phase A
+            if constexpr (!LAST) {
+                to = *reinterpret_cast<const i32x4v *>(tout_w + ((size_t)rt * 64 + lane) * 8);
+                tr = *reinterpret_cast<const i32x4v *>(tout_w + ((size_t)rt * 64 + lane) * 8 + 4);
+            }
+            // every wave has read the exchange (previous epilogue): a bare s_barrier - this wave's exchange reads have
+            // returned (their values were consumed slices ago), and __syncthreads() would also drain the patch reads just
+            // issued for the next row tile (s_waitcnt lgkmcnt(0): ~200 cycles per row tile)
+            __builtin_amdgcn_s_barrier();
             static_for<48>([&](auto M_) {
                 constexpr int m = decltype(M_)::value;
                 mfma_slice(std::integral_constant<int, 1>{}, M_, bh1, bl1);
@@ -602,9 +667,28 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_wsplit_kernel(
                     tslice(M_, bh0, bl0);
                     if constexpr (m >= 16 && m % 4 == 0)
                         read_cell(IN_, std::integral_constant<int, 1>{}, std::integral_constant<int, (m - 16) / 4>{}, ta, tb);
-                } else if constexpr (m >= 12 && (m - 12) % 9 == 0 && (m - 12) / 9 < 4) {
-                    // k-chunk 0's fragments are dead: request the next layer's, point (m - 12) / 9, between the MFMAs
-                    ws_load_w_point<0, (m - 12) / 9>(ua, wnext, wlane);
+                } else {
+                    // point 3's k-chunk 0 fragments (dead since phase A's last slice), then k-chunk 1's of points 0 .. 2 as
+                    // their MFMAs are done
+                    if constexpr (m < 12 && m % 3 == 0) ws_load_w_point<0, 3>(ua, wnext, wlane, m / 3);
+                    if constexpr (m >= 12 && m % 3 == 0) ws_load_w_point<1, (m - 12) / 12>(ua, wnext, wlane, ((m - 12) % 12) / 3);
+                }
+                if constexpr (m >= 26 && m < 30) {                 // points 0 and 1 are complete behind slice 23
+                    constexpr int c = m - 26;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) zs01[c][e] = acc[0][c][e] + acc[1][c][e];
+                }
+                if constexpr (m >= 38 && m < 46) {                 // point 2 behind slice 35
+                    constexpr int c = (m - 38) >> 1;
+                    if constexpr (((m - 38) & 1) == 0) {
+                        f32x4 z0;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) z0[e] = zs01[c][e] + acc[2][c][e];
+                        lds_f32x4_put<c * 1024>(exw, z0);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) zd12[c][e] = acc[1][c][e] - acc[2][c][e];
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
@@ -616,65 +700,22 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_wsplit_kernel(
                 ta = *reinterpret_cast<const i32x4v *>(tin_w + ((size_t)r2 * 64 + lane) * 8);
                 tb = *reinterpret_cast<const i32x4v *>(tin_w + ((size_t)r2 * 64 + lane) * 8 + 4);
             }
-            // ---- phase C: output transform along the point row: Z0 = m0 + m1 + m2, Z1 = m1 - m2 - m3 -> exchange ----
-            int exw = wave * 8192 + lane * 16, exr = wave * 1024 + lane * 16;     // this wave's block / its channel tile
-            asm volatile("" : "+v"(exw), "+v"(exr));
-            __syncthreads();                                // the previous row tile's exchange has been read
+            // ---- tail: Z1 = (m1 - m2) - m3 -> exchange: rides along the NEXT row tile's phase A; the last row tile's here ----
+            if constexpr (LAST) {
+                static_for<4>([&](auto C_) {
+                    ztail(C_, exw);
+                    ws_load_w_point<1, 3>(ua, wnext, wlane, decltype(C_)::value);    // point 3's k-chunk 1 registers are dead now
+                });
+                __syncthreads();
+            }
             dstamp(rt, 3);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                f32x4 z0, z1;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    z0[e] = (acc[0][c][e] + acc[1][c][e]) + acc[2][c][e];
-                    z1[e] = (acc[1][c][e] - acc[2][c][e]) - acc[3][c][e];
-                }
-                lds_f32x4_put<C::EX_OFF>(exw + c * 1024, z0);
-                lds_f32x4_put<C::EX_OFF + 4096>(exw + c * 1024, z1);
-                if constexpr (LAST) ws_load_w_point<1, 0>(ua, wnext, wlane, c);      // k-chunk 1's registers are dead as well
+            if constexpr (LAST) {
+                // ---- the last row tile's own epilogue (nothing to hide it behind), the remaining requests in between ----
+                static_for<4>([&](auto Q_) {
+                    static_for<6>([&](auto I_) { epi_step(OUT_, RES_, Q_, I_, to2, tr2, shf, down, exr); });
+                });
             }
-            __syncthreads();
             dstamp(rt, 4);
-            // ---- sum over the point rows for output channels 16 wave + 4 lg .., shift, residual, ReLU, store ----
-            {
-                f32x4 z[4][2];
-#pragma unroll
-                for (int w2 = 0; w2 < 4; ++w2)
-#pragma unroll
-                    for (int zz = 0; zz < 2; ++zz)
-                        z[w2][zz] = lds_f32x4_at<C::EX_OFF>(exr + (w2 * 2 + zz) * 4096);
-                f32x4 res[4];
-                if constexpr (RES) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) res[q] = lds_f32x4_at<OUT>(tr[q]);
-                }
-                if constexpr (LAST) ws_load_w_point<1, 1>(ua, wnext, wlane);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {               // q = 2 r + c: output (2 ty + r, 2 tx + c)
-                    const int r = q >> 1, cc = q & 1;
-                    f32x4 v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float y = r == 0 ? (z[0][cc][e] + z[1][cc][e]) + z[2][cc][e]
-                                               : (z[1][cc][e] - z[2][cc][e]) - z[3][cc][e];
-                        float tt = fmaf(y, down, shf[e]);
-                        if constexpr (RES) tt += res[q][e];
-                        v[e] = fmaxf(tt, 0.f);
-                    }
-                    amax = fmaxf(fmaxf(amax, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
-                    lds_f32x4_put<OUT>(to[q], v);
-                    if constexpr (LAST) {
-                        if (q == 1) ws_load_w_point<1, 2>(ua, wnext, wlane);
-                        if (q == 3) ws_load_w_point<1, 3>(ua, wnext, wlane);
-                    }
-                }
-            }
-            dstamp(rt, 5);
-            {
-                const int r1 = rt + 1 < NRT ? rt + 1 : 0;
-                to = *reinterpret_cast<const i32x4v *>(tout_w + ((size_t)r1 * 64 + lane) * 8);
-                tr = *reinterpret_cast<const i32x4v *>(tout_w + ((size_t)r1 * 64 + lane) * 8 + 4);
-            }
         };
         auto conv = [&](auto IN_, auto OUT_, auto RES_, int layer) __attribute__((always_inline)) {
             // epilogue constants of the output channels this wave finishes: 16 wave + 4 lg ..
@@ -690,10 +731,10 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_wsplit_kernel(
             tb = tb1;
             // (row tile 0 peeled: inside the loop hipcc must assume that ta / tb are loads of the previous iteration and waits
             // for them - in row tile 0 that wait would drain the weight requests still in flight)
-            body(IN_, OUT_, RES_, std::false_type{}, 0, next_layer, shf, down);
+            body(IN_, OUT_, RES_, std::true_type{}, std::false_type{}, 0, next_layer, shf, down);
 #pragma unroll 1
-            for (int rt = 1; rt < NRT - 1; ++rt) body(IN_, OUT_, RES_, std::false_type{}, rt, next_layer, shf, down);
-            body(IN_, OUT_, RES_, std::true_type{}, NRT - 1, next_layer, shf, down);
+            for (int rt = 1; rt < NRT - 1; ++rt) body(IN_, OUT_, RES_, std::false_type{}, std::false_type{}, rt, next_layer, shf, down);
+            body(IN_, OUT_, RES_, std::false_type{}, std::true_type{}, NRT - 1, next_layer, shf, down);
             // (ta / tb hold row tile 0's table again: the last fetch of the loop wrapped around)
             if (!(amax < (float)kWsRangeLimit)) ovf = 1;        // f16 range guard (also catches NaN)
             __syncthreads();                                    // OUT complete before the next layer reads it

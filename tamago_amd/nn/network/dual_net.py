@@ -4,6 +4,7 @@ Same constructor, ``load_state_dict`` keys (nn/utility.py:139-159) and the two i
 entry points the search uses; the arithmetic runs in the fused HIP kernel behind
 ``tg_net_forward_*`` (tamago_amd/csrc/net_forward.hip).  There is no PyTorch fallback.
 """
+import ctypes
 from typing import Dict, Tuple
 
 import numpy as np

@@ -287,3 +287,103 @@ def test_512_tree_puct_pipe_kernel_device_evaluator_replay():
         assert np.array_equal(stats["children_value_sum"][t][:n], oroot.children_value_sum[:n]), t
         assert np.array_equal(stats["children_policy"][t][:n], oroot.children_policy[:n]), t
     engine.close()
+
+
+def test_headline_launch_shape_pipe_kernel_batch_256_1000_visits_replay():
+    """The headline's exact launch shape: more than 256 trees -> select_puct_pipe_kernel + backup_kernel<9, 8>,
+    NN batch 256 per tree, 1000 strict visits (mini-batches 1 + 256 + 256 + 256 + 232).  Four of the 320 trees - first, two
+    inside, last - are replayed into CPU oracle trees from their slices of the recorded mini-batches: identical leaf planes in
+    order, identical visit counts / value sums / policies / node counts."""
+    from oracle.board import GoBoard as OBoard
+    from oracle.net import make_state_dict
+    from oracle.tree import MCTSTree as OTree, TimeManager as OTM, TimeControl as OTC
+    from tamago_amd.board.go_board import GoBoard
+    from tamago_amd.mcts.engine import SearchEngine, DeviceEvaluator
+    from tamago_amd.nn.network.dual_net import DualNet
+    from tests.helpers import load_npz
+
+    for knob in ("TG_SELECT_SERIAL", "TG_SELECT_MPIPE_TREES", "TG_MPIPE_PROF"):
+        assert not os.environ.get(knob), "the kernel choice must be the library's default"
+    size, T, K, visits = 9, 320, 256, 1000
+    watch = (0, 107, 213, 319)
+    net = DualNet(torch.device("cuda:0"), size)
+    net.load_state_dict(make_state_dict(size, 7, 1.5))
+    inner = DeviceEvaluator(net)
+    log = []                                                # per mini-batch: the watched trees' slices only (host copies)
+
+    def evaluator(planes, want_logits):
+        policy, value = inner(planes, want_logits)
+        per = planes.shape[0] // T
+        log.append((per, [(planes[t * per:(t + 1) * per].cpu(), policy[t * per:(t + 1) * per].cpu(),
+                           value[t * per:(t + 1) * per].cpu()) for t in watch]))
+        return policy, value
+
+    engine = SearchEngine(size, T, visits + 16, K, evaluator)
+    brd = load_npz("board_s9.npz")
+    roots = {}
+    for t in range(T):
+        game, plies = t % 4, 2 + (t * 7) % 40
+        board, oboard = GoBoard(size, 7.0, False), OBoard(size, 7.0, False)
+        mv, col = brd[f"g{game}_move"], brd[f"g{game}_color"]
+        plies = min(plies, len(mv) - 1)
+        for m, c in zip(mv[:plies], col[:plies]):
+            board.put_stone(int(m), int(c))
+            oboard.put_stone(int(m), int(c))
+        color = 3 - int(col[plies - 1])
+        engine.set_root(t, board, color, np.random.RandomState(7000 + t).get_state())
+        roots[t] = (oboard, color)
+    engine.root_eval(False)
+    done = 0
+    while done < visits:
+        k = min(K, visits - done)
+        engine.puct_batch(k)
+        done += k
+    stats = engine.read_root_stats()
+    nodes = engine.num_nodes()
+    assert [per for per, _ in log] == [1, 256, 256, 256, 232]
+
+    class Slice:
+        def __init__(self, w):
+            self.w, self.i = w, 0
+
+        def inference(self, planes):
+            rp, pol, val = log[self.i][1][self.w]
+            self.i += 1
+            assert torch.equal(planes, rp[:planes.shape[0]]), (watch[self.w], self.i - 1)
+            return pol[:planes.shape[0]], val[:planes.shape[0]]
+
+    for w, t in enumerate(watch):
+        oboard, color = roots[t]
+        sl = Slice(w)
+        otree = OTree(sl, size, tree_size=visits + 16, batch_size=K)
+        np.random.set_state(np.random.RandomState(7000 + t).get_state())
+        otree.search_best_move(oboard, color, OTM(OTC.STRICT_PLAYOUT, visits))
+        oroot = otree.get_root()
+        n = oroot.num_children
+        assert sl.i == len(log) and int(stats["num_children"][t]) == n and int(nodes[t]) == otree.num_nodes
+        assert np.array_equal(stats["children_visits"][t][:n], oroot.children_visits[:n]), t
+        assert np.array_equal(stats["children_value_sum"][t][:n], oroot.children_value_sum[:n]), t
+        assert np.array_equal(stats["children_policy"][t][:n], oroot.children_policy[:n]), t
+    engine.close()
+
+
+def test_forward_launch_of_524288_positions_first_middle_last_vs_oracle():
+    """The headline's forward launch is 2 048 trees x 256 leaves = 524 288 positions; the net tests stop at a few thousand.
+    One launch of that size on random planes: the first, a middle and the last 4 096 positions against the CPU oracle."""
+    from oracle.net import OracleNet, make_state_dict
+    from tamago_amd.nn.network.dual_net import DualNet
+    sd = make_state_dict(9, 7, 1.5)
+    net = DualNet(torch.device("cuda:0"), 9)
+    net.load_state_dict(sd)
+    n, w = 524288, 4096
+    g = torch.Generator(device="cuda")
+    g.manual_seed(99)
+    x = torch.randint(-1, 2, (n, 6, 9, 9), device="cuda", generator=g).float()
+    pol, val = net.forward_device(x)
+    torch.cuda.synchronize()
+    ora = OracleNet(sd)
+    for lo in (0, (n // 2 // 768) * 768 + 5, n - w):          # (the middle window straddles workgroup-round boundaries)
+        rp, rv = ora.inference(x[lo:lo + w].cpu())
+        assert float((pol[lo:lo + w].cpu() - rp).abs().max()) < TOL, lo
+        assert float((val[lo:lo + w].cpu() - rv).abs().max()) < TOL, lo
+    assert net.range_fallbacks() == 0

@@ -113,6 +113,60 @@ __global__ __launch_bounds__(512) void k_issue(float *out, int iters) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// PHASED: the body's MFMAs first (back to back), then its VALU instructions (no MFMA in between); NM = 0: VALU only.
+// MIX 0: v_add_f32, 2: v_pk_add_f32 (NV / 2 of them), 3: v_pk_fma_f32 (NV / 2)
+template <int NM, int NV, int MIX>
+__global__ __launch_bounds__(512) void k_phased(float *out, int iters) {
+    f32x4 acc[16];
+    i32x4 fa[8], fb[4];
+    float v[32];
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 pv[16];
+    for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 8; ++i) fa[i] = i32x4{0x3c003c00, 0x3c003800, 0x38003c00, 0x3c003400};
+    for (int i = 0; i < 4; ++i) fb[i] = i32x4{0x3c003800, 0x38003c00, 0x3c003c00, 0x34003c00};
+    for (int i = 0; i < 32; ++i) v[i] = threadIdx.x * 1e-3f + i;
+    for (int i = 0; i < 16; ++i) pv[i] = f32x2{threadIdx.x * 1e-3f + i, 1.f};
+#pragma unroll 1
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int m = 0; m < NM; ++m) MFMA(acc[m % 16], fa[m % 8], fb[m % 4]);
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const int d = q % 32, x = (q + 7) % 32, y = (q + 13) % 32;
+            if (MIX == 0) VADD(v[d], v[x], v[y]);
+            if (MIX == 2 && (q & 1) == 0) VPKADD(pv[d % 16], pv[x % 16], pv[y % 16]);
+            if (MIX == 3 && (q & 1) == 0)
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(pv[d % 16]) : "v"(pv[x % 16]), "v"(pv[y % 16]), "v"(pv[(d + 3) % 16]));
+        }
+    }
+    float s = 0.f;
+    for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][3] + pv[i][0] + pv[i][1];
+    for (int i = 0; i < 32; ++i) s += v[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int NM, int NV, int MIX>
+void run_phased(int threads, float *out) {
+    const int iters = 2000;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL((k_phased<NM, NV, MIX>), dim3(256), dim3(threads), 0, 0, out, iters);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((k_phased<NM, NV, MIX>), dim3(256), dim3(threads), 0, 0, out, iters);
+    hipEventRecord(e1);
+    hipDeviceSynchronize();
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const int wps = threads / 256, ninst = MIX >= 2 ? NV / 2 : NV;
+    const double cyc = ms * 1e-3 * 2.4e9 / ((double)iters * wps);
+    printf("phased  waves/SIMD=%d  %2d MFMAs then %3d x %-12s: %7.1f cycles per body; beyond the MFMAs (%d x 16.4): %6.1f = %4.1f per VALU instruction\n",
+           wps, NM, ninst, MIX == 0 ? "v_add_f32" : (MIX == 2 ? "v_pk_add_f32" : "v_pk_fma_f32"), cyc, NM, cyc - NM * 16.4,
+           (cyc - NM * 16.4) / ninst);
+}
+
 template <int NV, int NL, int MIX>
 void run(int threads, float *out) {
     const int iters = 2000;
@@ -171,6 +225,15 @@ int main() {
     // ---- 3 ----
     float *out;
     hipMalloc(&out, 1 << 22);
+    for (int threads : {256, 512}) {
+        run_phased<0, 288, 0>(threads, out);
+        run_phased<0, 288, 2>(threads, out);
+        run_phased<0, 288, 3>(threads, out);
+        run_phased<48, 288, 0>(threads, out);
+        run_phased<48, 288, 2>(threads, out);
+        run_phased<48, 288, 3>(threads, out);
+        run_phased<8, 48, 2>(threads, out);
+    }
     for (int threads : {256, 512}) {
         run<0, 0, 0>(threads, out);
         run<48, 0, 0>(threads, out);

@@ -26,13 +26,13 @@ s = st[:16] - st[0]
 print(f"group total {s[15]} ticks: staging {s[1]}, stem {s[2] - s[1]}, heads {s[15] - s[14]}")
 print("  layers:", [int(s[3 + i] - s[2 + i]) for i in range(12)])
 nrt = 5 if b > 256 else 2
-names = ["phase A (MFMA kc0 | transform kc1)", "phase B (MFMA kc1 | transform next kc0)", "barrier", "Z + exchange write + barrier", "epilogue"]
+names = ["phase A (MFMA kc0 | transform kc1 | previous tail + epilogue)", "phase B (MFMA kc1 | transform next kc0 | Z)", "tail + barrier (last row tile)", "own epilogue (last row tile)"]
 for layer in (2, 3):
     base = 40 + 35 * (layer - 2)
     print(f"layer {layer} ({'conv1' if layer % 2 == 0 else 'conv2 + residual'}), per row tile:")
     for rt in range(nrt):
         d = st[base + 7 * rt: base + 7 * rt + 7]
-        print(f"  rt {rt}: total {int(d[5] - d[0]):5d} |", " | ".join(f"{n} {int(d[i + 1] - d[i])}" for i, n in enumerate(names)))
+        print(f"  rt {rt}: total {int(d[4] - d[0]):5d} |", " | ".join(f"{n} {int(d[i + 1] - d[i])}" for i, n in enumerate(names)))
     if nrt > 1:
-        gaps = [int(st[base + 7 * (rt + 1)] - st[base + 7 * rt + 5]) for rt in range(nrt - 1)]
+        gaps = [int(st[base + 7 * (rt + 1)] - st[base + 7 * rt + 4]) for rt in range(nrt - 1)]
         print("  between row tiles:", gaps)
