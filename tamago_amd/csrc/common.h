@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <cstdarg>
 #include <cstdio>
+#include <atomic>
+#include <cstdint>
 #include <string>
 
 #include "../../include/tamago_hip.h"
@@ -19,5 +21,14 @@ int fail(int code, const char *fmt, ...);
             return tg::fail(TG_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
                             __FILE__, __LINE__);                                          \
     } while (0)
+
+// hipFuncSetAttribute costs ~20 us of host time per call (measured: the single-tree leg lost 0.19 ms per move with it in
+// front of every launch), so it is called once per kernel AND DEVICE - thread-safe, unlike a plain static flag: returns
+// true for the first caller on `device` (devices beyond 63 always return true).
+inline bool first_on_device(std::atomic<uint64_t> &mask, int device) {
+    if (device < 0 || device > 63) return true;
+    const uint64_t bit = 1ull << device;
+    return (mask.fetch_or(bit, std::memory_order_acq_rel) & bit) == 0;
+}
 
 }  // namespace tg

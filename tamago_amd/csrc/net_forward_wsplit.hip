@@ -764,8 +764,9 @@ int launch_wsplit(tg_net *net, const float *planes, int batch, int want_logits, 
     if (!PROF && net->dev.timeline)
         return launch_wsplit<G, true>(net, planes, batch, want_logits, policy, value, overflow, stream);
     auto kern = dualnet_fwd_wsplit_kernel<G, PROF>;
-    // (cheap, and right for every device and thread: no per-process "already configured" flag)
-    TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+    static std::atomic<uint64_t> configured{0};
+    if (tg::first_on_device(configured, net->device))
+        TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
     const int groups = (batch + G - 1) / G;
     const int grid = groups < net->num_cus ? groups : net->num_cus;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTHR), C::LDS_BYTES, stream, net->dev, planes, batch, want_logits,

@@ -45,6 +45,7 @@
 #include <condition_variable>
 #include <functional>
 #include <atomic>
+#include <future>
 #include <vector>
 
 namespace {
@@ -1512,9 +1513,12 @@ template <int S, int NSEL, int NWRK>
 int launch_mpipe_cfg(const SearchDev &dev, int max_leaves, float *planes, hipStream_t st) {
     constexpr size_t lds = sizeof(MPipeShared<S, NSEL, NWRK>);
     static_assert(lds <= 160 * 1024, "LDS");
-    // (unconditional: per device and thread-safe, unlike a process-wide flag)
-    TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&select_puct_mpipe_kernel<S, NSEL, NWRK>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static std::atomic<uint64_t> configured{0};          // per device, thread-safe (tg::first_on_device)
+    int devid = 0;
+    (void)hipGetDevice(&devid);
+    if (tg::first_on_device(configured, devid))
+        TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&select_puct_mpipe_kernel<S, NSEL, NWRK>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((select_puct_mpipe_kernel<S, NSEL, NWRK>), dim3(dev.T), dim3(64 * (NSEL + NWRK)), lds, st, dev,
                        max_leaves, planes);
     return TG_OK;
@@ -1938,9 +1942,12 @@ int launch_owner_cfg(const SearchDev &dev, int max_leaves, float *planes, hipStr
     constexpr size_t lds = sizeof(OwnerShared<S, NNODE, NWRK>);
     static_assert(lds <= 160 * 1024, "LDS");
     static_assert(NNODE + NWRK + 2 <= 16, "wavefronts per workgroup");
-    // (unconditional: per device and thread-safe, unlike a process-wide flag)
-    TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&select_puct_owner_kernel<S, NNODE, NWRK>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static std::atomic<uint64_t> configured{0};
+    int devid = 0;
+    (void)hipGetDevice(&devid);
+    if (tg::first_on_device(configured, devid))
+        TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&select_puct_owner_kernel<S, NNODE, NWRK>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((select_puct_owner_kernel<S, NNODE, NWRK>), dim3(dev.T), dim3(64 * (NNODE + NWRK + 2)), lds, st, dev,
                        max_leaves, planes);
     return TG_OK;
@@ -3601,6 +3608,9 @@ struct tg_search {
     tg_search_config cfg{};
     SearchDev dev{};
     int num_cus = 256;
+    // few trees: the draws of the NEXT window are generated by a background task while the GPU works on the current one
+    // (tg_search_feed_streams); everything that touches `streams` waits for it first (wait_prefill)
+    std::future<void> prefill;
     int split_per_cu = -1;                 // resident select_puct_split_kernel workgroups per CU (queried at the first launch)
     std::vector<void *> allocs;
     int S = 0, W = 0, NC = 0, P = 0, A = 0, HMAX = 0;
@@ -3809,9 +3819,10 @@ int launch_split_cfg(tg_search *s, int max_leaves, float *planes, hipStream_t st
         TG_HIP(hipMemsetAsync(s->xw_off, 0, (size_t)T * (s->xw_cap + 1) * sizeof(unsigned long long), st));
         s->xw_seq = 1;
     }
-    // (unconditional: cheap, and right for every device and host thread - a process-wide "configured" flag was neither)
-    TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&select_puct_split_kernel<S, NNODE, NWRK, NSHIP, NWG>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static std::atomic<uint64_t> configured{0};          // per device, thread-safe (a process-wide bool was neither)
+    if (tg::first_on_device(configured, s->cfg.device))
+        TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&select_puct_split_kernel<S, NNODE, NWRK, NSHIP, NWG>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // The tree's workgroups wait for each other through memory: all (1 + NWG) T of them must be resident at once, which an
     // ordinary launch does not promise.  They are one per CU (1024 threads, > 80 KB of LDS); when the device has fewer CUs
     // than that (partitioned devices) the caller falls back to the one-workgroup kernel (kSplitNoRoom).
@@ -3917,6 +3928,7 @@ int tg_search_create(const tg_search_config *cfg, tg_search **out) {
 
 int tg_search_destroy(tg_search *s) {
     if (!s) return TG_OK;
+    if (s->prefill.valid()) s->prefill.wait();          // (the background generator works on s->streams)
     (void)hipSetDevice(s->cfg.device);
     for (void *p : s->allocs) (void)hipFree(p);
     if (s->roots_dev) { (void)hipFree(s->roots_dev); (void)hipHostFree(s->roots_host); }
@@ -4237,8 +4249,13 @@ int tg_search_set_noise(tg_search *s, const double *noise_host) {
 
 // ---- library-owned legacy streams ---------------------------------------------------------
 
+static void wait_prefill(tg_search *s) {
+    if (s && s->prefill.valid()) s->prefill.get();
+}
+
 int tg_search_seed_stream(tg_search *s, int tree, const uint32_t *mt_key, int mt_pos) {
     if (!s || !mt_key) return tg::fail(TG_ERR_ARG, "tg_search_seed_stream: null argument");
+    wait_prefill(s);
     if (tree < 0 || tree >= s->dev.T) return tg::fail(TG_ERR_ARG, "tg_search_seed_stream: tree %d out of range", tree);
     if (mt_pos < 0 || mt_pos > 624) return tg::fail(TG_ERR_ARG, "tg_search_seed_stream: MT19937 position %d outside [0, 624]", mt_pos);
     if (s->streams.empty()) s->streams.resize(s->dev.T);
@@ -4249,6 +4266,7 @@ int tg_search_seed_stream(tg_search *s, int tree, const uint32_t *mt_key, int mt
 
 int tg_search_stream_state(tg_search *s, int tree, uint32_t *mt_key_out, int *mt_pos_out) {
     if (!s || !mt_key_out || !mt_pos_out) return tg::fail(TG_ERR_ARG, "tg_search_stream_state: null argument");
+    wait_prefill(s);
     if (tree < 0 || tree >= s->dev.T || s->streams.empty() || !s->streams[tree].seeded)
         return tg::fail(TG_ERR_ARG, "tg_search_stream_state: tree %d has no stream", tree);
     const tg::Mt19937 &g = s->streams[tree].state_at_position();
@@ -4261,6 +4279,7 @@ int tg_search_feed_streams(tg_search *s, size_t need, int force) {
     if (!s) return tg::fail(TG_ERR_ARG, "tg_search_feed_streams: null argument");
     const int T = s->dev.T;
     if (s->streams.size() != (size_t)T) return tg::fail(TG_ERR_ARG, "tg_search_feed_streams: streams are not seeded");
+    wait_prefill(s);
     for (int t = 0; t < T; ++t)
         if (!s->streams[t].seeded) return tg::fail(TG_ERR_ARG, "tg_search_feed_streams: tree %d has no stream", t);
     if (need == 0 || (!force && s->win_left >= (int64_t)need)) return TG_OK;
@@ -4296,6 +4315,16 @@ int tg_search_feed_streams(tg_search *s, size_t need, int force) {
     s->rng_pending_cap = (int64_t)need;
     s->win_cap = s->win_left = (int64_t)need;
     s->win_used.assign(T, 0);
+    // Few trees (a single search tree: one host thread, the GPU idle while it generates): the next window starts at most
+    // `need` draws further on, so 2 x need draws staged now = nothing left to generate when it is asked for.  Measured on
+    // the one-tree legs: the ~21 k (9x9) / 23 k (19x19) exponentials of a mini-batch window are 80 - 100 us of MT19937 +
+    // log per mini-batch on the host thread that also has to queue the next launches.
+    if (T <= 16) {
+        const size_t ahead = 2 * need;
+        s->prefill = std::async(std::launch::async, [s, T, ahead] {
+            for (int t = 0; t < T; ++t) s->streams[t].ensure(ahead);
+        });
+    }
     return TG_OK;
 }
 
@@ -4303,6 +4332,7 @@ int tg_search_advance_streams(tg_search *s, int64_t *consumed_host) {
     if (!s) return tg::fail(TG_ERR_ARG, "tg_search_advance_streams: null argument");
     const int T = s->dev.T;
     if (s->streams.size() != (size_t)T) return tg::fail(TG_ERR_ARG, "tg_search_advance_streams: streams are not seeded");
+    wait_prefill(s);
     std::vector<int64_t> used(T);
     {
         int rc = tg_search_rng_consumed(s, used.data());
@@ -4328,6 +4358,7 @@ int tg_search_draw_noise(tg_search *s, double *noise_host) {
     if (!s) return tg::fail(TG_ERR_ARG, "tg_search_draw_noise: null argument");
     const int T = s->dev.T, A = s->A;
     if (s->streams.size() != (size_t)T) return tg::fail(TG_ERR_ARG, "tg_search_draw_noise: streams are not seeded");
+    wait_prefill(s);
     std::vector<double> local;
     double *noise = noise_host;
     if (!noise) {
@@ -5143,6 +5174,7 @@ int tg_selfplay_play_move(tg_selfplay *sp, tg_net *net, float *planes_dev, float
     flush_comments(sp);
     {
         const size_t ahead = (size_t)2 * A + (size_t)sp->last_window + (size_t)8 * A;
+        wait_prefill(s);
         parallel_trees(T, [&](int t) {
             if (!sp->games[t].done && s->streams[t].seeded) s->streams[t].ensure(s->streams[t].available() < ahead ? ahead : 0);
         });
