@@ -503,7 +503,17 @@ int w2_prepare(tg_net *net, const float *conv0, const float *const *tower, const
 int w2_forward(tg_net *net, const float *planes, int batch, int want_logits, float *policy, float *value,
                int *overflow, hipStream_t stream) {
     if (net->board_size != 9) return tg::fail(TG_ERR_ARG, "w2 forward: 9x9 only");
-    if (const char *env = getenv("TG_W2_ABL")) {            // timing-only ablations (wrong results): see the kernel
+    // timing-only ablations (WRONG RESULTS: see the kernel) - only with TG_ALLOW_WRONG_RESULTS=1 next to TG_W2_ABL, and never
+    // silently: a stray environment variable must not turn the production path into a profiling experiment
+    const char *abl = getenv("TG_W2_ABL");
+    if (abl && !(getenv("TG_ALLOW_WRONG_RESULTS") && atoi(getenv("TG_ALLOW_WRONG_RESULTS")) == 1))
+        return tg::fail(TG_ERR_ARG, "TG_W2_ABL selects timing-only kernel ablations with wrong results: set TG_ALLOW_WRONG_RESULTS=1 as well, or unset it");
+    if (const char *env = abl) {
+        static bool warned = false;
+        if (!warned) {
+            fprintf(stderr, "[tamago_hip] TG_W2_ABL=%s: the w2 forward kernel runs a timing-only ablation - its results are WRONG\n", env);
+            warned = true;
+        }
         switch (atoi(env)) {
         case 1: return launch_w2<9, 3, 1>(net, planes, batch, want_logits, policy, value, overflow, stream);
         case 2: return launch_w2<9, 3, 2>(net, planes, batch, want_logits, policy, value, overflow, stream);

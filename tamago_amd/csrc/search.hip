@@ -2572,8 +2572,11 @@ __global__ __launch_bounds__(64 * NWAVE) void backup_kernel(SearchDev D, const f
                 const int entry = lane < kPathCap ? D.q_path[slot * kPathCap + lane] : 0;
                 const float *val = value + (leaf_base + k) * 3;
                 const float v0 = val[0], v1 = val[1], v2 = val[2];
+                // (a Gumbel leaf with q_node < 0 is the reference's node[-1] quirk: every such leaf writes the LAST pool slot's
+                // raw value, the last one in leaf order wins - that one write is done below by wave 0, in leaf order, instead
+                // of by whichever wave comes last here)
+                if (lane == 0 && node >= 0) D.n_raw[(size_t)t * D.N + node] = v1 * 0.5f + v2;   // tree.py:299
                 if (node < 0) node = D.N - 1;
-                if (lane == 0) D.n_raw[(size_t)t * D.N + node] = v1 * 0.5f + v2;   // tree.py:299
                 const float vleaf = v0 + v1 * 0.5f;   // tree.py:302
                 if (lane < depth) {
                     const int pn = entry >> 10, pe = entry & 1023;
@@ -2619,6 +2622,17 @@ __global__ __launch_bounds__(64 * NWAVE) void backup_kernel(SearchDev D, const f
                 r_nvsum = acc;
                 r_nvis += n;
                 r_nvl -= n;
+            }
+            // node[-1]: the last leaf (in leaf order) without a node of its own decides the last slot's raw value
+            int last = -1;
+            for (int k0 = 0; k0 < n; k0 += 64) {
+                const int kk = k0 + lane;
+                const unsigned long long m = __ballot(kk < n && D.q_node[(size_t)t * D.K + (kk < n ? kk : 0)] < 0);
+                if (m) last = k0 + 63 - __clzll((long long)m);
+            }
+            if (last >= 0 && lane == 0) {
+                const float *val = value + (leaf_base + last) * 3;
+                D.n_raw[(size_t)t * D.N + D.N - 1] = val[1] * 0.5f + val[2];
             }
         }
     } else if (wid == 0 && n > 0) {
@@ -3611,6 +3625,7 @@ struct tg_search {
     // few trees: the draws of the NEXT window are generated by a background task while the GPU works on the current one
     // (tg_search_feed_streams); everything that touches `streams` waits for it first (wait_prefill)
     std::future<void> prefill;
+    bool prefill_enabled = true;           // (the self-play path tops its streams up itself, in the shadow of the phase kernels)
     int split_per_cu = -1;                 // resident select_puct_split_kernel workgroups per CU (queried at the first launch)
     std::vector<void *> allocs;
     int S = 0, W = 0, NC = 0, P = 0, A = 0, HMAX = 0;
@@ -3655,8 +3670,22 @@ struct tg_search {
     size_t stage_cap[2] = {0, 0};
     bool stage_busy[2] = {false, false};          // ev_rng[b] guards a copy out of stage[b]
     int64_t win_cap = 0, win_left = 0;            // active / pending window: size, unread tail
+    // split upload (feed_streams_impl / feed_streams_rest): buffer, columns already up, columns still to come; the next
+    // selection launch must wait for the second part's event
+    int rng_rest_idx = 0;
+    size_t rng_rest_first = 0, rng_rest_cols = 0;
+    bool rng_rest_wait = false;
     std::vector<int64_t> win_used;                // device cursor per tree at the last advance
     std::vector<double> noise_host;               // last root Gumbel noise [T][A] (tg_search_set_noise)
+    // pinned staging rings for the small per-move uploads (root noise, chosen moves): queued on the launch stream behind
+    // the kernels that still read the old contents - the host does not wait for the stream (it used to: a pipeline drain
+    // per upload, twice per self-play move)
+    static constexpr int kPinRing = 4;
+    double *noise_pin = nullptr;
+    int32_t *moves_pin = nullptr;
+    hipEvent_t noise_ev[kPinRing] = {}, moves_ev[kPinRing] = {};
+    bool noise_ev_used[kPinRing] = {}, moves_ev_used[kPinRing] = {};
+    unsigned noise_seq = 0, moves_seq = 0;
 };
 
 namespace {
@@ -3930,6 +3959,15 @@ int tg_search_destroy(tg_search *s) {
     if (!s) return TG_OK;
     if (s->prefill.valid()) s->prefill.wait();          // (the background generator works on s->streams)
     (void)hipSetDevice(s->cfg.device);
+    if (s->last_stream) (void)hipStreamSynchronize(s->last_stream);
+    if (s->noise_pin) {
+        (void)hipHostFree(s->noise_pin);
+        for (int i = 0; i < tg_search::kPinRing; ++i) (void)hipEventDestroy(s->noise_ev[i]);
+    }
+    if (s->moves_pin) {
+        (void)hipHostFree(s->moves_pin);
+        for (int i = 0; i < tg_search::kPinRing; ++i) (void)hipEventDestroy(s->moves_ev[i]);
+    }
     for (void *p : s->allocs) (void)hipFree(p);
     if (s->roots_dev) { (void)hipFree(s->roots_dev); (void)hipHostFree(s->roots_host); }
     if (s->node_dev) { (void)hipFree(s->node_dev); (void)hipHostFree(s->node_host); }
@@ -4060,6 +4098,10 @@ static int flush_roots(tg_search *s, hipStream_t st) {
 
 // make the most recently uploaded random window the active one (stream-ordered)
 static int install_rng(tg_search *s, hipStream_t st) {
+    if (s->rng_rest_wait && s->rng_pending < 0) {   // second part of a split upload into the ACTIVE window
+        TG_HIP(hipStreamWaitEvent(st, s->ev_rng[s->rng_active], 0));
+        s->rng_rest_wait = false;
+    }
     if (s->rng_pending < 0) return TG_OK;
     s->rng_active = s->rng_pending;
     s->rng_pending = -1;
@@ -4208,8 +4250,20 @@ int tg_search_play(tg_search *s, const int32_t *moves_host, void *stream) {
     int rc = flush_roots(s, st);
     if (rc) return rc;
     if (!s->moves_dev && (rc = dev_alloc(s, &s->moves_dev, (size_t)s->dev.T))) return rc;
-    TG_HIP(hipMemcpyAsync(s->moves_dev, moves_host, (size_t)s->dev.T * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    TG_HIP(hipStreamSynchronize(st));
+    {
+        const size_t n = (size_t)s->dev.T;
+        if (!s->moves_pin) {
+            TG_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->moves_pin), tg_search::kPinRing * n * sizeof(int32_t), hipHostMallocDefault));
+            for (int i = 0; i < tg_search::kPinRing; ++i) TG_HIP(hipEventCreateWithFlags(&s->moves_ev[i], hipEventDisableTiming));
+        }
+        const int slot = (int)(s->moves_seq++ % tg_search::kPinRing);
+        if (s->moves_ev_used[slot]) TG_HIP(hipEventSynchronize(s->moves_ev[slot]));
+        int32_t *pin = s->moves_pin + (size_t)slot * n;
+        std::memcpy(pin, moves_host, n * sizeof(int32_t));
+        TG_HIP(hipMemcpyAsync(s->moves_dev, pin, n * sizeof(int32_t), hipMemcpyHostToDevice, st));   // (the caller's buffer is free)
+        TG_HIP(hipEventRecord(s->moves_ev[slot], st));
+        s->moves_ev_used[slot] = true;
+    }
     if (s->S == 9) hipLaunchKernelGGL(play_kernel<9>, dim3(s->dev.T), dim3(64), 0, st, s->dev, s->moves_dev);
     else hipLaunchKernelGGL(play_kernel<19>, dim3(s->dev.T), dim3(64), 0, st, s->dev, s->moves_dev);
     TG_HIP(hipGetLastError());
@@ -4241,9 +4295,25 @@ int tg_search_read_positions(tg_search *s, uint8_t *cells_host, int32_t *moves_h
 
 int tg_search_set_noise(tg_search *s, const double *noise_host) {
     if (!s || !noise_host) return tg::fail(TG_ERR_ARG, "tg_search_set_noise: null argument");
-    if (s->last_stream) TG_HIP(hipStreamSynchronize(s->last_stream));
-    TG_HIP(hipMemcpy(s->dev.noise, noise_host, (size_t)s->dev.T * s->A * sizeof(double), hipMemcpyHostToDevice));
-    s->noise_host.assign(noise_host, noise_host + (size_t)s->dev.T * s->A);
+    const size_t n = (size_t)s->dev.T * s->A;
+    s->noise_host.assign(noise_host, noise_host + n);
+    if (!s->last_stream) {                         // no launch stream yet: the null stream, synchronously
+        TG_HIP(hipDeviceSynchronize());
+        TG_HIP(hipMemcpy(s->dev.noise, noise_host, n * sizeof(double), hipMemcpyHostToDevice));
+        return TG_OK;
+    }
+    if (!s->noise_pin) {
+        TG_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->noise_pin), tg_search::kPinRing * n * sizeof(double), hipHostMallocDefault));
+        for (int i = 0; i < tg_search::kPinRing; ++i) TG_HIP(hipEventCreateWithFlags(&s->noise_ev[i], hipEventDisableTiming));
+    }
+    const int slot = (int)(s->noise_seq++ % tg_search::kPinRing);
+    if (s->noise_ev_used[slot]) TG_HIP(hipEventSynchronize(s->noise_ev[slot]));     // (four uploads ago: long done)
+    double *pin = s->noise_pin + (size_t)slot * n;
+    std::memcpy(pin, noise_host, n * sizeof(double));
+    // in stream order: behind the kernels that read the previous noise (the last search), ahead of the next selection
+    TG_HIP(hipMemcpyAsync(s->dev.noise, pin, n * sizeof(double), hipMemcpyHostToDevice, s->last_stream));
+    TG_HIP(hipEventRecord(s->noise_ev[slot], s->last_stream));
+    s->noise_ev_used[slot] = true;
     return TG_OK;
 }
 
@@ -4275,9 +4345,30 @@ int tg_search_stream_state(tg_search *s, int tree, uint32_t *mt_key_out, int *mt
     return TG_OK;
 }
 
-int tg_search_feed_streams(tg_search *s, size_t need, int force) {
+// Upload of a window in two parts (self-play: the window of a move's four phases is 1.7 MB at 16 boards and the GPU has
+// ~0.1 ms of root evaluation to cover its staging): feed_streams_impl(first > 0) stages and uploads the first `first`
+// draws of every tree's row only - enough for the first launch -, feed_streams_rest() the remaining columns while that
+// launch runs; the next selection launch waits for them (rng_rest_wait).
+static int feed_streams_impl(tg_search *s, size_t need, int force, size_t first);
+static int feed_streams_rest(tg_search *s);
+static void start_prefill(tg_search *s, size_t need) {
+    const int T = s->dev.T;
+    if (T > 16 || !s->prefill_enabled) return;
+    const size_t ahead = 2 * need;
+    s->prefill = std::async(std::launch::async, [s, T, ahead] {
+        for (int t = 0; t < T; ++t) s->streams[t].ensure(ahead);
+    });
+}
+
+int tg_search_feed_streams(tg_search *s, size_t need, int force) { return feed_streams_impl(s, need, force, 0); }
+
+static int feed_streams_impl(tg_search *s, size_t need, int force, size_t first) {
     if (!s) return tg::fail(TG_ERR_ARG, "tg_search_feed_streams: null argument");
     const int T = s->dev.T;
+    if (s->rng_rest_cols) {                        // (an earlier split upload was never completed: complete it first)
+        int rc = feed_streams_rest(s);
+        if (rc) return rc;
+    }
     if (s->streams.size() != (size_t)T) return tg::fail(TG_ERR_ARG, "tg_search_feed_streams: streams are not seeded");
     wait_prefill(s);
     for (int t = 0; t < T; ++t)
@@ -4303,28 +4394,65 @@ int tg_search_feed_streams(tg_search *s, size_t need, int force) {
         s->stage_cap[idx] = (size_t)T * need;
     }
     double *stage = s->stage[idx];
+    const bool split = first > 0 && first < need;
+    const size_t cols = split ? first : need;
+    static const bool feed_timing = getenv("TG_SP_TIMING") != nullptr;
+    auto clk = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tf0 = feed_timing ? clk() : 0.0;
+    size_t generated = 0;
+    for (int t = 0; t < T && feed_timing; ++t) generated += s->streams[t].available() < need ? need - s->streams[t].available() : 0;
     parallel_trees(T, [&](int t) {
         tg::LegacyStream &ls = s->streams[t];
         ls.ensure(need);
-        std::memcpy(stage + (size_t)t * need, ls.data(), need * sizeof(double));
+        std::memcpy(stage + (size_t)t * need, ls.data(), cols * sizeof(double));
     });
-    TG_HIP(hipMemcpyAsync(s->rng_buf[idx], stage, (size_t)T * need * sizeof(double), hipMemcpyHostToDevice, s->copy_stream));
+    const double tf1 = feed_timing ? clk() : 0.0;
+    if (split)
+        TG_HIP(hipMemcpy2DAsync(s->rng_buf[idx], need * sizeof(double), stage, need * sizeof(double), cols * sizeof(double), T,
+                                hipMemcpyHostToDevice, s->copy_stream));
+    else
+        TG_HIP(hipMemcpyAsync(s->rng_buf[idx], stage, (size_t)T * need * sizeof(double), hipMemcpyHostToDevice, s->copy_stream));
     TG_HIP(hipEventRecord(s->ev_rng[idx], s->copy_stream));
+    if (feed_timing) {
+        static double a_stage = 0, a_copy = 0, a_gen = 0;
+        static long calls = 0;
+        a_stage += tf1 - tf0; a_copy += clk() - tf1; a_gen += (double)generated;
+        if (++calls % 2000 == 0)
+            fprintf(stderr, "[feed timing, per call over %ld calls] generate + stage %.1f us (%.0f draws generated), enqueue copy %.1f us\n",
+                    calls, 1e6 * a_stage / calls, a_gen / calls, 1e6 * a_copy / calls);
+    }
     s->stage_busy[idx] = true;
     s->rng_pending = idx;
     s->rng_pending_cap = (int64_t)need;
     s->win_cap = s->win_left = (int64_t)need;
     s->win_used.assign(T, 0);
+    s->rng_rest_idx = idx;
+    s->rng_rest_first = cols;
+    s->rng_rest_cols = split ? need - cols : 0;
+    if (split) return TG_OK;                       // (the background generator starts behind the second part)
     // Few trees (a single search tree: one host thread, the GPU idle while it generates): the next window starts at most
     // `need` draws further on, so 2 x need draws staged now = nothing left to generate when it is asked for.  Measured on
     // the one-tree legs: the ~21 k (9x9) / 23 k (19x19) exponentials of a mini-batch window are 80 - 100 us of MT19937 +
     // log per mini-batch on the host thread that also has to queue the next launches.
-    if (T <= 16) {
-        const size_t ahead = 2 * need;
-        s->prefill = std::async(std::launch::async, [s, T, ahead] {
-            for (int t = 0; t < T; ++t) s->streams[t].ensure(ahead);
-        });
-    }
+    start_prefill(s, need);
+    return TG_OK;
+}
+
+static int feed_streams_rest(tg_search *s) {
+    if (!s->rng_rest_cols) return TG_OK;
+    const int T = s->dev.T, idx = s->rng_rest_idx;
+    const size_t need = s->rng_rest_first + s->rng_rest_cols, first = s->rng_rest_first, cols = s->rng_rest_cols;
+    s->rng_rest_cols = 0;
+    wait_prefill(s);
+    double *stage = s->stage[idx];
+    parallel_trees(T, [&](int t) {                 // (nothing was consumed in between: the rows continue where part one stopped)
+        std::memcpy(stage + (size_t)t * need + first, s->streams[t].data() + first, cols * sizeof(double));
+    });
+    TG_HIP(hipMemcpy2DAsync(s->rng_buf[idx] + first, need * sizeof(double), stage + first, need * sizeof(double), cols * sizeof(double), T,
+                            hipMemcpyHostToDevice, s->copy_stream));
+    TG_HIP(hipEventRecord(s->ev_rng[idx], s->copy_stream));     // also the new guard of the staging buffer
+    s->rng_rest_wait = true;                       // the next selection launch waits for this event
+    start_prefill(s, need);
     return TG_OK;
 }
 
@@ -5073,6 +5201,7 @@ int tg_selfplay_play_move(tg_selfplay *sp, tg_net *net, float *planes_dev, float
     tg_search *s = sp->s;
     const int T = s->dev.T, A = s->A;
     int rc;
+    s->prefill_enabled = false;
     // host-side wall clock per section (TG_SP_TIMING=1: printed every 200 moves) - where a move's time goes when
     // the GPU is not the bound
     static const bool timing = getenv("TG_SP_TIMING") != nullptr;
@@ -5130,7 +5259,7 @@ int tg_selfplay_play_move(tg_selfplay *sp, tg_net *net, float *planes_dev, float
     // read back once, behind the last phase - not a window, an upload and a host synchronisation per phase, each
     // sized as if every descent expanded (2.4x more draws).
     sp->ph_seen.assign(T, 0);
-    int64_t window = 0;
+    int64_t window = 0, first_window = 0;
     for (int ph = 0; ph < n_phases; ++ph) {
         const int32_t *nc = &sp->ph_nc[(size_t)ph * T], *mc = &sp->ph_mc[(size_t)ph * T];
         int64_t expansions = 0;
@@ -5141,9 +5270,11 @@ int tg_selfplay_play_move(tg_selfplay *sp, tg_net *net, float *planes_dev, float
             sp->ph_seen[t] = (int32_t)std::min<int64_t>(A, sp->ph_seen[t] + entered);
         }
         window += expansions * A;
+        if (ph == 0) first_window = window;
     }
     lap(3);
-    if (window > 0 && (rc = tg_search_feed_streams(s, (size_t)window, 0))) return rc;
+    // (first part: what the first phase can consume; the rest goes up while that phase runs)
+    if (window > 0 && (rc = feed_streams_impl(s, (size_t)window, 0, (size_t)first_window))) return rc;
     lap(4);
     bool any_phase = false;
     for (int ph = 0; ph < n_phases; ++ph) {
@@ -5166,14 +5297,19 @@ int tg_selfplay_play_move(tg_selfplay *sp, tg_net *net, float *planes_dev, float
             sp->observer(sp->observer_user, &ev);
         }
         leaves += total;
+        if (!any_phase && (rc = feed_streams_rest(s))) return rc;      // behind the first launched phase
         any_phase = true;
     }
+    if ((rc = feed_streams_rest(s))) return rc;                        // (no phase was launched)
     lap(3);
     // ---- host work that nobody is waiting for, while the phase kernels run: the previous move's record comments, and
     //      the draws the next move will ask for (root prior, noise, a window like this move's) generated ahead ----
     flush_comments(sp);
     {
-        const size_t ahead = (size_t)2 * A + (size_t)sp->last_window + (size_t)8 * A;
+        // (this move's window may still be consumed in full - the cursors are read back below - AND the next move asks
+        // for another one: with one window's worth ahead the next feed generated most of its window itself, 0.23 ms per
+        // move at 16 boards, with the GPU idle)
+        const size_t ahead = (size_t)2 * A + (size_t)2 * window + (size_t)8 * A;
         wait_prefill(s);
         parallel_trees(T, [&](int t) {
             if (!sp->games[t].done && s->streams[t].seeded) s->streams[t].ensure(s->streams[t].available() < ahead ? ahead : 0);
