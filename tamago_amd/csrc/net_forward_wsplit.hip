@@ -401,6 +401,19 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_wsplit_kernel(
         const int b0 = grp * G;
         stamp();
         // ================= stem: planes -> im2col'ed f16-pair images (K = 9 taps x 6 planes, padded to 64) =================
+        // (its 16 weight fragments are requested first: their L2 round trip runs under the staging pass)
+        i32x4v fa[2][2][4];                                      // [kc][piece][ct]
+        {
+            int wvg = lane * 16;
+            asm volatile("" : "+v"(wvg));
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        gmem_load_frag(fa[kc][p][c], net.wsplit + (size_t)kc * 8192, wvg + (p * 4 + c) * 1024);
+        }
         {
             float *st = reinterpret_cast<float *>(smem + C::STAGE);
             int stid = tid;
@@ -443,16 +456,6 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_wsplit_kernel(
         {
             // stem product: 2 k-chunks x 4 channel tiles x RTW row tiles x 3 f16 products (two accumulator sets, scaled
             // low pieces: the direct split kernel's image and weights), batch norm, ReLU -> X (fp32, swizzled)
-            i32x4v fa[2][2][4];                                  // [kc][piece][ct]
-            int wvg = lane * 16;
-            asm volatile("" : "+v"(wvg));
-#pragma unroll
-            for (int kc = 0; kc < 2; ++kc)
-#pragma unroll
-                for (int p = 0; p < 2; ++p)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        gmem_load_frag(fa[kc][p][c], net.wsplit + (size_t)kc * 8192, wvg + (p * 4 + c) * 1024);
 #pragma unroll
             for (int r = 0; r < RTW; ++r) {
                 int row = (wave * RTW + r) * 16 + li;

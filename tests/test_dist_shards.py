@@ -134,3 +134,41 @@ def test_launcher_rank_failure_reaches_every_rank(tmp_path):
     assert out.returncode != 0
     assert "GPU fell off the bus" in out.stderr + out.stdout
     assert "shard 0" in out.stdout and "games/hour" in out.stdout          # the surviving shard's report
+
+
+def test_numa_aware_pinning_slices_the_gpus_node():
+    """pin_host_threads takes a rank's core slice from the cores of the NUMA node its GPU hangs off (when the platform
+    says which) and falls back to contiguous slices of all visible cores otherwise."""
+    import os
+    from tamago_amd.selfplay.main import parse_cpulist, pin_host_threads
+    assert parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    assert parse_cpulist("") == []
+    saved = os.sched_getaffinity(0)
+    saved_env = os.environ.get("TG_HOST_THREADS")
+    cores = sorted(saved)
+    try:
+        if len(cores) >= 4:
+            node = cores[len(cores) // 2:]                     # pretend the GPU's node is the upper half of the cores
+            os.environ["TG_SINGLE_DEVICE"] = "1"               # (both ranks of the test "share" that node)
+            n = pin_host_threads(1, 2, device_index=None, numa_cores=node)
+            mine = sorted(os.sched_getaffinity(0))
+            assert n == len(mine) == len(node) // 2 and set(mine) <= set(node)
+            assert mine == node[len(node) // 2:][:n]           # rank 1 of 2 on that node: its second half
+            os.sched_setaffinity(0, saved)
+        # no NUMA information: contiguous slices of everything visible
+        n = pin_host_threads(0, 2)
+        assert sorted(os.sched_getaffinity(0)) == cores[:max(1, len(cores) // 2)] and n == max(1, len(cores) // 2)
+    finally:
+        os.sched_setaffinity(0, saved)
+        os.environ.pop("TG_SINGLE_DEVICE", None)
+        if saved_env is None:
+            os.environ.pop("TG_HOST_THREADS", None)
+        else:
+            os.environ["TG_HOST_THREADS"] = saved_env
+
+
+def test_cpu_selfplay_worker_counts_leaf_evaluations():
+    """oracle/cpu_selfplay.py (bench.py's cpu_selfplay leg): a 16-simulation Gumbel move is 1 + 16 leaf evaluations."""
+    from oracle.cpu_selfplay import run
+    out = run(seconds=1.5, visits=16, seed=3, threads=1)
+    assert out["moves"] >= 1 and out["leaf_evals"] == out["moves"] * 17, out
