@@ -593,6 +593,9 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_wsplit_kernel(
         // output transform along the point row, riding along phase B: zs01 = m0 + m1 (behind point 1), Z0 = zs01 + m2 and
         // zd12 = m1 - m2 (behind point 2; Z0 written), Z1 = zd12 - m3 in the tail
         f32x4 zs01[4], zd12[4];
+        constexpr bool DEFER = G == 3;                         // the last row tile's tail + epilogue ride in the next layer (see body)
+        f32x4 pshf = f32x4{0.f, 0.f, 0.f, 0.f};                // the previous layer's epilogue constants
+        float pdown = 0.f;
         auto ztail = [&](auto C_, int exw) __attribute__((always_inline)) {
             constexpr int c = decltype(C_)::value;
             f32x4 z1;
@@ -602,7 +605,7 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_wsplit_kernel(
         };
         auto body = [&](auto IN_, auto OUT_, auto RES_, auto FIRST_, auto LAST_, int rt, int next_layer, const f32x4 shf,
                         const float down) __attribute__((always_inline)) {
-            constexpr bool FIRST = decltype(FIRST_)::value, LAST = decltype(LAST_)::value;
+            constexpr bool FIRST = decltype(FIRST_)::value, LAST = decltype(LAST_)::value, RES = decltype(RES_)::value;
             dstamp(rt, 0);
             const unsigned char *wnext = net.ws_w + ((size_t)next_layer * 4 + wave) * 65536;
             i32x4v bh1[4], bl1[4];
@@ -633,12 +636,21 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_wsplit_kernel(
                 // ... behind the previous row tile's Z1 = (m1 - m2) - m3 (slices 0 .. 3: point 3 finished with phase B's last
                 // MFMA) and the barrier that publishes the exchange (slice 5): write latency and stragglers cost MFMA slots that
                 // are filled anyway instead of a tail of their own
+                // (three boards per workgroup: a layer's FIRST row tile carries the PREVIOUS LAYER's last row tile the same way -
+                // that row tile holds tiles of the third board only, row tiles 0 and 1 tiles of the first two (ws_geometry), so
+                // nothing this layer reads before the next barriers is written by it; its output buffer is this layer's
+                // input, its residual flag the opposite, its constants pshf / pdown, its tables to2 / tr2)
+                constexpr bool EPI = !FIRST || DEFER;
                 if constexpr (!FIRST && m < 4) ztail(std::integral_constant<int, m>{}, exw);
-                if constexpr (!FIRST && m == 5) __syncthreads();
-                if constexpr (!FIRST && m >= 6 && m < 30 && m % 6 == 0)
-                    epi_step(OUT_, RES_, std::integral_constant<int, m / 6 - 1>{}, std::integral_constant<int, 0>{}, to, tr, shf, down, exr);
-                if constexpr (!FIRST && m >= 13 && m < 36 && (m - 12) % 6 != 0)
-                    epi_step(OUT_, RES_, std::integral_constant<int, (m - 12) / 6>{}, std::integral_constant<int, (m - 12) % 6>{}, to, tr, shf, down, exr);
+                if constexpr (!FIRST && m == 5) __syncthreads();   // (the deferred row tile's Z1 went out before the layer's closing barrier)
+                if constexpr (EPI && m >= 6 && m < 30 && m % 6 == 0) {
+                    if constexpr (FIRST) epi_step(IN_, std::integral_constant<bool, !RES>{}, std::integral_constant<int, m / 6 - 1>{}, std::integral_constant<int, 0>{}, to2, tr2, pshf, pdown, exr);
+                    else epi_step(OUT_, RES_, std::integral_constant<int, m / 6 - 1>{}, std::integral_constant<int, 0>{}, to, tr, shf, down, exr);
+                }
+                if constexpr (EPI && m >= 13 && m < 36 && (m - 12) % 6 != 0) {
+                    if constexpr (FIRST) epi_step(IN_, std::integral_constant<bool, !RES>{}, std::integral_constant<int, (m - 12) / 6>{}, std::integral_constant<int, (m - 12) % 6>{}, to2, tr2, pshf, pdown, exr);
+                    else epi_step(OUT_, RES_, std::integral_constant<int, (m - 12) / 6>{}, std::integral_constant<int, (m - 12) % 6>{}, to, tr, shf, down, exr);
+                }
                 if constexpr (!LAST && m >= 16 && m % 4 == 0)      // dq's old contents are dead behind slice 15
                     read_cell(IN_, std::integral_constant<int, 0>{}, std::integral_constant<int, (m - 16) / 4>{}, ta, tb);
                 // last row tile: point j's k-chunk 0 fragments are dead behind slice 12 j + 11 - request the next layer's, two
@@ -709,10 +721,10 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_wsplit_kernel(
                     ztail(C_, exw);
                     ws_load_w_point<1, 3>(ua, wnext, wlane, decltype(C_)::value);    // point 3's k-chunk 1 registers are dead now
                 });
-                __syncthreads();
+                if constexpr (!DEFER) __syncthreads();
             }
             dstamp(rt, 3);
-            if constexpr (LAST) {
+            if constexpr (LAST && !DEFER) {
                 // ---- the last row tile's own epilogue (nothing to hide it behind), the remaining requests in between ----
                 static_for<4>([&](auto Q_) {
                     static_for<6>([&](auto I_) { epi_step(OUT_, RES_, Q_, I_, to2, tr2, shf, down, exr); });
@@ -739,17 +751,42 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_wsplit_kernel(
             for (int rt = 1; rt < NRT - 1; ++rt) body(IN_, OUT_, RES_, std::false_type{}, std::false_type{}, rt, next_layer, shf, down);
             body(IN_, OUT_, RES_, std::false_type{}, std::true_type{}, NRT - 1, next_layer, shf, down);
             // (ta / tb hold row tile 0's table again: the last fetch of the loop wrapped around)
+            pshf = shf;
+            pdown = down;
             if (!(amax < (float)kWsRangeLimit)) ovf = 1;        // f16 range guard (also catches NaN)
-            __syncthreads();                                    // OUT complete before the next layer reads it
+            __syncthreads();                                    // OUT complete (but a deferred last row tile) before the next layer reads it
             stamp();
         };
         using IX = std::integral_constant<int, C::X_OFF>;
         using IH = std::integral_constant<int, C::H_OFF>;
         if (!(amax < (float)kWsRangeLimit)) ovf = 1;
+        if constexpr (DEFER) {
+            // layer 0 has no previous layer: its first row tile carries a NULL epilogue - zero exchange, zero constants,
+            // every store to the dump row, every residual read from the zero row (cheaper than a third copy of the layer code)
+            for (int e = tid; e < C::EX_BYTES / 16; e += NTHR) reinterpret_cast<uint4 *>(smem + C::EX_OFF)[e] = uint4{0u, 0u, 0u, 0u};
+            pshf = f32x4{0.f, 0.f, 0.f, 0.f};
+            pdown = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                to2[q] = C::DUMP_REL + (lane * 16) % 256;
+                tr2[q] = C::ZERO_REL + (lane * 16) % 256;
+            }
+            __syncthreads();
+        }
 #pragma unroll 1
         for (int blk = 0; blk < kBlocks; ++blk) {
             conv(IX{}, IH{}, std::false_type{}, 2 * blk);
             conv(IH{}, IX{}, std::true_type{}, 2 * blk + 1);
+        }
+        if constexpr (DEFER) {
+            // the tower's last row tile (layer 11, output buffer X, residual): nothing left to hide it behind
+            int exr = C::EX_OFF + wave * 1024 + lane * 16;
+            asm volatile("" : "+v"(exr));
+            static_for<4>([&](auto Q_) {
+                static_for<6>([&](auto I_) { epi_step(IX{}, std::true_type{}, Q_, I_, to2, tr2, pshf, pdown, exr); });
+            });
+            if (!(amax < (float)kWsRangeLimit)) ovf = 1;
+            __syncthreads();
         }
         // next group's input planes: requested here, consumed after the heads
         fetch_planes(grp + gridDim.x);
