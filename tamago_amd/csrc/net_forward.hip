@@ -941,10 +941,10 @@ int tg_net_forward_dev(tg_net *net, const float *planes_dev, int batch, int want
             {
                 std::lock_guard<std::mutex> lock(net->scratch_mu);
                 int *&slot = net->flag_by_stream[st];
-                if (!slot) TG_HIP(hipMalloc(reinterpret_cast<void **>(&slot), sizeof(int)));
+                if (!slot) TG_HIP(hipMalloc(reinterpret_cast<void **>(&slot), 2 * sizeof(int)));   // [range flag, group tickets]
                 flag = slot;
             }
-            TG_HIP(hipMemsetAsync(flag, 0, sizeof(int), st));
+            TG_HIP(hipMemsetAsync(flag, 0, 2 * sizeof(int), st));
             int rc = tg::split_forward(net, 1, planes_dev, batch, want_logits, policy_dev, value_dev, flag, st);
             if (rc) return rc;
             return launch_wino8<19, 1, true>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st, flag);
@@ -980,10 +980,10 @@ int tg_net_forward_dev(tg_net *net, const float *planes_dev, int batch, int want
             {
                 std::lock_guard<std::mutex> lock(net->scratch_mu);
                 int *&slot = net->flag_by_stream[st];
-                if (!slot) TG_HIP(hipMalloc(reinterpret_cast<void **>(&slot), sizeof(int)));
+                if (!slot) TG_HIP(hipMalloc(reinterpret_cast<void **>(&slot), 2 * sizeof(int)));   // [range flag, group tickets]
                 flag = slot;
             }
-            TG_HIP(hipMemsetAsync(flag, 0, sizeof(int), st));
+            TG_HIP(hipMemsetAsync(flag, 0, 2 * sizeof(int), st));
             int rc = pick_wsplit(9)
                          ? tg::wsplit_forward(net, group, planes_dev, batch, want_logits, policy_dev, value_dev, flag, st)
                          : (pick_w2(9, batch, net->num_cus)

@@ -397,8 +397,13 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_wsplit_kernel(
     load_w(std::integral_constant<int, 0>{}, 0);
     load_w(std::integral_constant<int, 1>{}, 0);
 
-    for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    // Groups beyond a workgroup's first are handed out by a ticket counter (overflow[1], zeroed with the range flag): a
+    // workgroup that starts late - its CU was running another stream's tree kernel - takes fewer groups instead of
+    // holding the launch up with a full static share.  The ticket travels through a spare word of the bias table.
+    int *const ticket_lds = reinterpret_cast<int *>(smem + C::HB_OFF + 83 * 4);
+    for (int grp = blockIdx.x; grp < n_groups;) {
         const int b0 = grp * G;
+        if (tid == 0) *ticket_lds = overflow ? (int)gridDim.x + atomicAdd(overflow + 1, 1) : grp + (int)gridDim.x;
         stamp();
         // ================= stem: planes -> im2col'ed f16-pair images (K = 9 taps x 6 planes, padded to 64) =================
         // (its 16 weight fragments are requested first: their L2 round trip runs under the staging pass)
@@ -789,10 +794,12 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_wsplit_kernel(
             __syncthreads();
         }
         // next group's input planes: requested here, consumed after the heads
-        fetch_planes(grp + gridDim.x);
+        const int next = __builtin_amdgcn_readfirstlane(*ticket_lds);   // (written before the stem's barriers)
+        fetch_planes(next);
         run_heads_x32<G, C>(smem, net, b0, batch, want_logits, policy, value, tid, wave, nullptr);
         __syncthreads();
         stamp();
+        grp = next;
     }
     if (ovf && overflow) atomicOr(overflow, 1);
 }

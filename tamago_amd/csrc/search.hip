@@ -3618,6 +3618,78 @@ __global__ __launch_bounds__(64) void gather_roots_kernel(SearchDev D, int A, un
     }
 }
 
+// Self-play, the end of a move WITHOUT the host (tg_selfplay_play_move): the root records as above, then the move itself -
+// final root choice (tree.py:344, node.py:324-346: argmax of logit + noise + sigma(q) with the visit threshold), resign rule
+// (worker.py:59-62), two-pass / move-limit end (worker.py:44, :80) - in the arithmetic the host used to do it in
+// (float64, IEEE operations, first maximum wins), so that play_kernel and the next root expansion can follow at once.
+// state [T][4]: {bit 0: slot takes no part (parked / game just started), bit 1: never resign; passes in a row; moves
+// played; 0}.  moves_out[t]: the point played (0 = pass) or -1 (nothing to play: resigned, game over, idle slot).
+// tail [T]: {best child, kind (0 move / 1 resign / 2 second pass / 3 move limit / 4 idle), point, 0, draw cursor (int64), 0}.
+struct RootTail {
+    int32_t best, kind, pos, pad;
+    int64_t cursor, pad2;
+};
+__global__ __launch_bounds__(64) void finish_roots_kernel(SearchDev D, int A, unsigned char *out, size_t rec_bytes,
+                                                          const int32_t *state, int max_moves, int32_t *moves_out, RootTail *tail) {
+    const int t = blockIdx.x, lane = threadIdx.x;
+    const size_t ns = (size_t)t * D.N, base = ns * A;
+    unsigned char *rec = out + (size_t)t * rec_bytes;
+    int32_t *head = reinterpret_cast<int32_t *>(rec);
+    const int n = D.n_children[ns];
+    if (lane == 0) {
+        head[0] = n;
+        head[1] = D.n_visits[ns];
+        head[2] = __float_as_int(D.n_raw[ns]);
+        head[3] = D.err[t];
+    }
+    int32_t *vis = head + 4, *vl = vis + A, *act = vl + A;
+    double *vsum = reinterpret_cast<double *>(rec + 16 + (size_t)3 * A * 4 + (((size_t)3 * A * 4) % 8 ? 4 : 0));
+    double *pol = vsum + A;
+    int mc = 0;
+    for (int i = lane; i < A; i += 64) {
+        const int v = D.ch_visits[base + i];
+        vis[i] = v;
+        vl[i] = D.ch_vl[base + i];
+        act[i] = D.action[base + i];
+        vsum[i] = D.ch_vsum[base + i];
+        pol[i] = D.ch_policy[base + i];
+        if (i < n) mc = v > mc ? v : mc;
+    }
+    const int flags = state[4 * t], passes = state[4 * t + 1], played = state[4 * t + 2];
+    int best = -1, kind = 4, pos = -1, mv = -1;
+    if (!(flags & 1) && n > 0) {
+        mc = wave_max_i32(mc);
+        const double sigma_sel = (double)(50 + mc) * 1.0;
+        double bv = 0.0;
+        int bi = -1;
+        for (int i = lane; i < n; i += 64) {
+            const int v = D.ch_visits[base + i];
+            const double qi = v > 0 ? D.ch_vsum[base + i] / (double)v : 0.0;
+            const double ev = (v + D.ch_vl[base + i] >= 100) ? -10000.0
+                                                              : (D.ch_policy[base + i] + D.noise[(size_t)t * A + i]) + sigma_sel * qi;
+            if (bi < 0 || ev > bv) { bv = ev; bi = i; }
+        }
+        best = wave_argmax_first(bv, bi);
+        const int bvis = D.ch_visits[base + best];
+        const double value = bvis == 0 ? 0.5 : D.ch_vsum[base + best] / (double)bvis;
+        pos = D.action[base + best];
+        if (!(flags & 2) && value < 0.05) {
+            kind = 1;
+        } else {
+            const int p2 = pos == 0 ? passes + 1 : 0;
+            if (p2 == 2) kind = 2;
+            else if (played + 1 >= max_moves) kind = 3;
+            else { kind = 0; mv = pos; }
+        }
+    }
+    if (lane == 0) {
+        moves_out[t] = mv;
+        RootTail r{};
+        r.best = best; r.kind = kind; r.pos = pos; r.cursor = D.rng_cursor[t];
+        tail[t] = r;
+    }
+}
+
 struct tg_search {
     tg_search_config cfg{};
     SearchDev dev{};
@@ -3686,6 +3758,14 @@ struct tg_search {
     hipEvent_t noise_ev[kPinRing] = {}, moves_ev[kPinRing] = {};
     bool noise_ev_used[kPinRing] = {}, moves_ev_used[kPinRing] = {};
     unsigned noise_seq = 0, moves_seq = 0;
+    // finish_roots_kernel (self-play: the move decided on the device): per-tree state uploads, the event behind its records
+    uint8_t *roots_pin = nullptr;          // pinned mirror of st_cells / st_hist / st_meta (flush_roots)
+    hipEvent_t roots_pin_ev = nullptr;
+    bool roots_pin_used = false;
+    int32_t *state_dev = nullptr, *state_pin = nullptr;
+    hipEvent_t state_ev[kPinRing] = {}, fin_ev = nullptr;
+    bool state_ev_used[kPinRing] = {};
+    unsigned state_seq = 0;
 };
 
 namespace {
@@ -3964,6 +4044,12 @@ int tg_search_destroy(tg_search *s) {
         (void)hipHostFree(s->noise_pin);
         for (int i = 0; i < tg_search::kPinRing; ++i) (void)hipEventDestroy(s->noise_ev[i]);
     }
+    if (s->roots_pin) { (void)hipHostFree(s->roots_pin); (void)hipEventDestroy(s->roots_pin_ev); }
+    if (s->state_pin) {
+        (void)hipHostFree(s->state_pin);
+        for (int i = 0; i < tg_search::kPinRing; ++i) (void)hipEventDestroy(s->state_ev[i]);
+        (void)hipEventDestroy(s->fin_ev);
+    }
     if (s->moves_pin) {
         (void)hipHostFree(s->moves_pin);
         for (int i = 0; i < tg_search::kPinRing; ++i) (void)hipEventDestroy(s->moves_ev[i]);
@@ -4072,24 +4158,42 @@ static int flush_roots(tg_search *s, hipStream_t st) {
     const SearchDev &D = s->dev;
     size_t n_dirty = 0;
     for (uint8_t d : s->st_dirty_tree) n_dirty += d;
+    // out of a pinned mirror: a copy out of pageable memory makes the host wait for the stream (self-play queues this
+    // behind a whole move's kernels)
+    const size_t cells_b = s->st_cells.size(), hist_b = s->st_hist.size() * sizeof(uint64_t), meta_b = s->st_meta.size() * sizeof(RootMeta);
+    if (!s->roots_pin) {
+        TG_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->roots_pin), cells_b + hist_b + meta_b + 16, hipHostMallocDefault));
+        TG_HIP(hipEventCreateWithFlags(&s->roots_pin_ev, hipEventDisableTiming));
+    }
+    if (s->roots_pin_used) TG_HIP(hipEventSynchronize(s->roots_pin_ev));     // (the previous flush: long done)
+    uint8_t *pin_cells = s->roots_pin;
+    uint64_t *pin_hist = reinterpret_cast<uint64_t *>(s->roots_pin + ((cells_b + 7) & ~(size_t)7));
+    RootMeta *pin_meta = reinterpret_cast<RootMeta *>(reinterpret_cast<unsigned char *>(pin_hist) + hist_b);
     if (n_dirty == (size_t)D.T) {
-        TG_HIP(hipMemcpyAsync(D.root_cells, s->st_cells.data(), s->st_cells.size(), hipMemcpyHostToDevice, st));
-        if (D.superko)
-            TG_HIP(hipMemcpyAsync(D.root_hist, s->st_hist.data(), s->st_hist.size() * sizeof(uint64_t),
-                                  hipMemcpyHostToDevice, st));
-        TG_HIP(hipMemcpyAsync(D.meta, s->st_meta.data(), s->st_meta.size() * sizeof(RootMeta),
-                              hipMemcpyHostToDevice, st));
+        std::memcpy(pin_cells, s->st_cells.data(), cells_b);
+        std::memcpy(pin_meta, s->st_meta.data(), meta_b);
+        TG_HIP(hipMemcpyAsync(D.root_cells, pin_cells, cells_b, hipMemcpyHostToDevice, st));
+        if (D.superko) {
+            std::memcpy(pin_hist, s->st_hist.data(), hist_b);
+            TG_HIP(hipMemcpyAsync(D.root_hist, pin_hist, hist_b, hipMemcpyHostToDevice, st));
+        }
+        TG_HIP(hipMemcpyAsync(D.meta, pin_meta, meta_b, hipMemcpyHostToDevice, st));
     } else {
         for (int t = 0; t < D.T; ++t) {
             if (!s->st_dirty_tree[t]) continue;
-            TG_HIP(hipMemcpyAsync(D.root_cells + (size_t)t * s->NC, &s->st_cells[(size_t)t * s->NC], s->NC,
-                                  hipMemcpyHostToDevice, st));
-            if (D.superko)
-                TG_HIP(hipMemcpyAsync(D.root_hist + (size_t)t * s->HMAX, &s->st_hist[(size_t)t * s->HMAX],
-                                      (size_t)s->st_meta[t].hist_len * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-            TG_HIP(hipMemcpyAsync(D.meta + t, &s->st_meta[t], sizeof(RootMeta), hipMemcpyHostToDevice, st));
+            std::memcpy(pin_cells + (size_t)t * s->NC, &s->st_cells[(size_t)t * s->NC], s->NC);
+            TG_HIP(hipMemcpyAsync(D.root_cells + (size_t)t * s->NC, pin_cells + (size_t)t * s->NC, s->NC, hipMemcpyHostToDevice, st));
+            if (D.superko) {
+                const size_t hb = (size_t)s->st_meta[t].hist_len * sizeof(uint64_t);
+                std::memcpy(pin_hist + (size_t)t * s->HMAX, &s->st_hist[(size_t)t * s->HMAX], hb);
+                TG_HIP(hipMemcpyAsync(D.root_hist + (size_t)t * s->HMAX, pin_hist + (size_t)t * s->HMAX, hb, hipMemcpyHostToDevice, st));
+            }
+            pin_meta[t] = s->st_meta[t];
+            TG_HIP(hipMemcpyAsync(D.meta + t, pin_meta + t, sizeof(RootMeta), hipMemcpyHostToDevice, st));
         }
     }
+    TG_HIP(hipEventRecord(s->roots_pin_ev, st));
+    s->roots_pin_used = true;
     TG_HIP(hipMemsetAsync(D.err, 0, (size_t)D.T * sizeof(int32_t), st));
     std::fill(s->st_dirty_tree.begin(), s->st_dirty_tree.end(), 0);
     s->st_dirty = false;
@@ -4456,7 +4560,12 @@ static int feed_streams_rest(tg_search *s) {
     return TG_OK;
 }
 
-int tg_search_advance_streams(tg_search *s, int64_t *consumed_host) {
+static int advance_streams_impl(tg_search *s, int64_t *consumed_host, const uint8_t *skip);
+int tg_search_advance_streams(tg_search *s, int64_t *consumed_host) { return advance_streams_impl(s, consumed_host, nullptr); }
+
+// skip[t] != 0: tree t's stream was replaced since the window went up - what the device consumed there is not its (a
+// self-play slot whose game ended while the device had already gone on to the next root)
+static int advance_streams_impl(tg_search *s, int64_t *consumed_host, const uint8_t *skip) {
     if (!s) return tg::fail(TG_ERR_ARG, "tg_search_advance_streams: null argument");
     const int T = s->dev.T;
     if (s->streams.size() != (size_t)T) return tg::fail(TG_ERR_ARG, "tg_search_advance_streams: streams are not seeded");
@@ -4470,6 +4579,12 @@ int tg_search_advance_streams(tg_search *s, int64_t *consumed_host) {
     int64_t most = 0;
     for (int t = 0; t < T; ++t) {
         const int64_t delta = used[t] - s->win_used[t];     // the device cursor is cumulative within a window
+        if (skip && skip[t]) {
+            if (consumed_host) consumed_host[t] = 0;
+            s->win_used[t] = used[t];
+            most = std::max(most, used[t]);
+            continue;
+        }
         if (delta < 0 || (size_t)delta > s->streams[t].available())
             return tg::fail(TG_ERR_ARG, "tg_search_advance_streams: tree %d consumed %lld of %zu staged draws", t,
                             (long long)delta, s->streams[t].available());
@@ -4482,7 +4597,11 @@ int tg_search_advance_streams(tg_search *s, int64_t *consumed_host) {
     return TG_OK;
 }
 
-int tg_search_draw_noise(tg_search *s, double *noise_host) {
+static int draw_noise_impl(tg_search *s, double *noise_host, const uint8_t *skip);
+int tg_search_draw_noise(tg_search *s, double *noise_host) { return draw_noise_impl(s, noise_host, nullptr); }
+
+// skip[t] != 0: tree t draws nothing (zero noise) - its stream must not move yet
+static int draw_noise_impl(tg_search *s, double *noise_host, const uint8_t *skip) {
     if (!s) return tg::fail(TG_ERR_ARG, "tg_search_draw_noise: null argument");
     const int T = s->dev.T, A = s->A;
     if (s->streams.size() != (size_t)T) return tg::fail(TG_ERR_ARG, "tg_search_draw_noise: streams are not seeded");
@@ -4494,6 +4613,10 @@ int tg_search_draw_noise(tg_search *s, double *noise_host) {
         noise = local.data();
     }
     parallel_trees(T, [&](int t) {
+        if (skip && skip[t]) {
+            for (int i = 0; i < A; ++i) noise[(size_t)t * A + i] = 0.0;
+            return;
+        }
         tg::LegacyStream &ls = s->streams[t];
         ls.ensure((size_t)A);
         const double *e = ls.data();
@@ -4502,6 +4625,65 @@ int tg_search_draw_noise(tg_search *s, double *noise_host) {
     });
     s->win_left = 0;                               // the noise sits between two windows
     return tg_search_set_noise(s, noise);
+}
+
+// D: the engine's device view or a slice of it (sub_dev: D.T trees from some tree on); the kernel variant goes by the
+// ENGINE's tree count (how crowded the CUs are)
+static int launch_gumbel_select(tg_search *s, const SearchDev &D, const int32_t *nc_dev, const int32_t *mc_dev, const int32_t *off,
+                                int limit, float *planes_dev, hipStream_t st) {
+    const int T = D.T;
+    static const bool force_serial = getenv("TG_SELECT_SERIAL") != nullptr;
+    // workers per tree: two when the trees crowd the CUs (the three-wave workgroup fits next to a forward workgroup),
+    // six when there are CUs to spare (TG_GUMBEL_WORKERS overrides)
+    static const int workers_env = getenv("TG_GUMBEL_WORKERS") ? atoi(getenv("TG_GUMBEL_WORKERS")) : 0;
+    const int workers = workers_env ? workers_env : (s->dev.T <= 128 ? 6 : 2);
+    const bool gpipe = s->S == 9 && !force_serial && limit <= kPipeMaxK / 2 && D.N <= (1 << 21);   // (paths as node << 10 | edge)
+    if (gpipe && workers == 6)
+        hipLaunchKernelGGL((select_gumbel_pipe_kernel<9, 6>), dim3(T), dim3(64 * 7), 0, st, D, nc_dev, mc_dev, limit, off, planes_dev);
+    else if (gpipe && workers == 4)
+        hipLaunchKernelGGL((select_gumbel_pipe_kernel<9, 4>), dim3(T), dim3(64 * 5), 0, st, D, nc_dev, mc_dev, limit, off, planes_dev);
+    else if (gpipe)
+        hipLaunchKernelGGL((select_gumbel_pipe_kernel<9, 2>), dim3(T), dim3(192), 0, st, D, nc_dev, mc_dev, limit, off, planes_dev);
+    else if (s->S == 9)
+        hipLaunchKernelGGL(select_gumbel_kernel<9>, dim3(T), dim3(64), 0, st, D, nc_dev, mc_dev, limit, off, planes_dev);
+    else
+        hipLaunchKernelGGL(select_gumbel_kernel<19>, dim3(T), dim3(64), 0, st, D, nc_dev, mc_dev, limit, off, planes_dev);
+    TG_HIP(hipGetLastError());
+    return TG_OK;
+}
+
+// trees [t0, t0 + n) of the engine as a device view of their own (every per-tree array moved on; same kernels)
+static SearchDev sub_dev(const tg_search *s, int t0, int n) {
+    SearchDev D = s->dev;
+    const size_t o = (size_t)t0, N = (size_t)D.N, A = (size_t)s->A, K = (size_t)D.K;
+    D.ch_index += o * N * A; D.ch_visits += o * N * A; D.ch_vl += o * N * A;
+    D.ch_vsum += o * N * A; D.ch_policy += o * N * A; D.ch_value += o * N * A; D.action += o * N * A;
+    D.n_children += o * N; D.n_visits += o * N; D.n_vl += o * N; D.n_parent += o * N; D.n_pedge += o * N;
+    D.n_vsum += o * N; D.n_raw += o * N;
+    D.noise += o * A;
+    D.root_cells += o * s->NC; D.root_hist += o * s->HMAX; D.meta += o;
+    D.q_node += o * K; D.q_pnode += o * K; D.q_pedge += o * K; D.q_depth += o * K; D.q_path += o * K * kPathCap;
+    D.n_leaves += o;
+    D.rng += o * (size_t)D.rng_cap; D.rng_cursor += o; D.err += o;
+    D.T = n;
+    return D;
+}
+
+static int launch_backup(tg_search *s, const SearchDev &D, const float *policy_dev, const float *value_dev, int slots_per_tree,
+                         const int32_t *off, int use_logit, hipStream_t st) {
+    const bool few = s->dev.T <= 64;          // few trees: 16 waves per tree
+    const dim3 grid(D.T), block(64 * (few ? 16 : 8));
+    if (s->S == 9 && few) {
+        hipLaunchKernelGGL((backup_kernel<9, 16>), grid, block, 0, st, D, policy_dev, value_dev, slots_per_tree, off, use_logit);
+    } else if (s->S == 9) {
+        hipLaunchKernelGGL((backup_kernel<9, 8>), grid, block, 0, st, D, policy_dev, value_dev, slots_per_tree, off, use_logit);
+    } else if (few) {
+        hipLaunchKernelGGL((backup_kernel<19, 16>), grid, block, 0, st, D, policy_dev, value_dev, slots_per_tree, off, use_logit);
+    } else {
+        hipLaunchKernelGGL((backup_kernel<19, 8>), grid, block, 0, st, D, policy_dev, value_dev, slots_per_tree, off, use_logit);
+    }
+    TG_HIP(hipGetLastError());
+    return TG_OK;
 }
 
 int tg_search_select_gumbel(tg_search *s, const int32_t *num_considered_host, const int32_t *max_count_host,
@@ -4550,28 +4732,8 @@ int tg_search_select_gumbel(tg_search *s, const int32_t *num_considered_host, co
     }
     s->packed_leaves = packed;
     const int32_t *off = packed ? s->phase_dev + 2 * (size_t)T : nullptr;
-    static const bool force_serial = getenv("TG_SELECT_SERIAL") != nullptr;
-    // workers per tree: two when the trees crowd the CUs (the three-wave workgroup fits next to a forward workgroup),
-    // six when there are CUs to spare (TG_GUMBEL_WORKERS overrides)
-    static const int workers_env = getenv("TG_GUMBEL_WORKERS") ? atoi(getenv("TG_GUMBEL_WORKERS")) : 0;
-    const int workers = workers_env ? workers_env : (T <= 128 ? 6 : 2);
-    const bool gpipe = s->S == 9 && !force_serial && limit <= kPipeMaxK / 2 && s->dev.N <= (1 << 21);   // (paths as node << 10 | edge)
-    if (gpipe && workers == 6)
-        hipLaunchKernelGGL((select_gumbel_pipe_kernel<9, 6>), dim3(T), dim3(64 * 7), 0, st, s->dev, s->phase_dev,
-                           s->phase_dev + T, limit, off, planes_dev);
-    else if (gpipe && workers == 4)
-        hipLaunchKernelGGL((select_gumbel_pipe_kernel<9, 4>), dim3(T), dim3(64 * 5), 0, st, s->dev, s->phase_dev,
-                           s->phase_dev + T, limit, off, planes_dev);
-    else if (gpipe)
-        hipLaunchKernelGGL((select_gumbel_pipe_kernel<9, 2>), dim3(T), dim3(192), 0, st, s->dev, s->phase_dev,
-                           s->phase_dev + T, limit, off, planes_dev);
-    else if (s->S == 9)
-        hipLaunchKernelGGL(select_gumbel_kernel<9>, dim3(T), dim3(64), 0, st, s->dev, s->phase_dev,
-                           s->phase_dev + T, limit, off, planes_dev);
-    else
-        hipLaunchKernelGGL(select_gumbel_kernel<19>, dim3(T), dim3(64), 0, st, s->dev, s->phase_dev,
-                           s->phase_dev + T, limit, off, planes_dev);
-    TG_HIP(hipGetLastError());
+    int rc = launch_gumbel_select(s, s->dev, s->phase_dev, s->phase_dev + T, off, limit, planes_dev, st);
+    if (rc) return rc;
     return after_select(s, st);
 }
 
@@ -4586,19 +4748,7 @@ int tg_search_backup(tg_search *s, const float *policy_dev, const float *value_d
     hipStream_t st = static_cast<hipStream_t>(stream);
     s->last_stream = st;
     const int32_t *off = packed ? s->phase_dev + 2 * (size_t)s->dev.T : nullptr;
-    const bool few = s->dev.T <= 64;          // few trees: 16 waves per tree
-    const dim3 grid(s->dev.T), block(64 * (few ? 16 : 8));
-    if (s->S == 9 && few) {
-        hipLaunchKernelGGL((backup_kernel<9, 16>), grid, block, 0, st, s->dev, policy_dev, value_dev, slots_per_tree, off, use_logit);
-    } else if (s->S == 9) {
-        hipLaunchKernelGGL((backup_kernel<9, 8>), grid, block, 0, st, s->dev, policy_dev, value_dev, slots_per_tree, off, use_logit);
-    } else if (few) {
-        hipLaunchKernelGGL((backup_kernel<19, 16>), grid, block, 0, st, s->dev, policy_dev, value_dev, slots_per_tree, off, use_logit);
-    } else {
-        hipLaunchKernelGGL((backup_kernel<19, 8>), grid, block, 0, st, s->dev, policy_dev, value_dev, slots_per_tree, off, use_logit);
-    }
-    TG_HIP(hipGetLastError());
-    return TG_OK;
+    return launch_backup(s, s->dev, policy_dev, value_dev, slots_per_tree, off, use_logit, st);
 }
 
 }  // extern "C"
@@ -4609,25 +4759,79 @@ static size_t root_rec_bytes(int A) {
     if (ints % 8) ints += 4;
     return ints + (size_t)2 * A * 8;
 }
-static int gather_roots(tg_search *s) {
-    const int T = s->dev.T, A = s->A;
-    const size_t rec = root_rec_bytes(A);
-    if (!s->roots_dev) {
-        TG_HIP(hipMalloc(reinterpret_cast<void **>(&s->roots_dev), rec * T));
-        TG_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->roots_host), rec * T));
+static int alloc_root_records(tg_search *s) {                   // [T] records, then [T] RootTail
+    if (s->roots_dev) return TG_OK;
+    const size_t bytes = (root_rec_bytes(s->A) + sizeof(RootTail)) * (size_t)s->dev.T;
+    TG_HIP(hipMalloc(reinterpret_cast<void **>(&s->roots_dev), bytes));
+    TG_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->roots_host), bytes));
+    return TG_OK;
+}
+static void parse_root_records(const tg_search *s, int32_t *num_children_host, int32_t *node_visits_host, float *raw_value_host,
+                               int32_t *action_host, int32_t *visits_host, int32_t *virtual_loss_host, double *value_sum_host,
+                               double *policy_host) {
+    const size_t A = s->A, T = s->dev.T, rec = root_rec_bytes((int)A);
+    for (size_t t = 0; t < T; ++t) {
+        const unsigned char *r = s->roots_host + rec * t;
+        const int32_t *head = reinterpret_cast<const int32_t *>(r);
+        const int32_t *vis = head + 4, *vl = vis + A, *act = vl + A;
+        const double *vsum = reinterpret_cast<const double *>(r + rec - 2 * A * 8), *pol = vsum + A;
+        if (num_children_host) num_children_host[t] = head[0];
+        if (node_visits_host) node_visits_host[t] = head[1];
+        if (raw_value_host) std::memcpy(&raw_value_host[t], &head[2], 4);
+        if (visits_host) std::memcpy(visits_host + t * A, vis, A * 4);
+        if (virtual_loss_host) std::memcpy(virtual_loss_host + t * A, vl, A * 4);
+        if (action_host) std::memcpy(action_host + t * A, act, A * 4);
+        if (value_sum_host) std::memcpy(value_sum_host + t * A, vsum, A * 8);
+        if (policy_host) std::memcpy(policy_host + t * A, pol, A * 8);
     }
-    hipStream_t st = s->last_stream;
-    hipLaunchKernelGGL(gather_roots_kernel, dim3(T), dim3(64), 0, st, s->dev, A, s->roots_dev, rec);
-    TG_HIP(hipGetLastError());
-    TG_HIP(hipMemcpyAsync(s->roots_host, s->roots_dev, rec * T, hipMemcpyDeviceToHost, st));
-    TG_HIP(hipStreamSynchronize(st));
-    for (int t = 0; t < T; ++t) {
+}
+static int root_record_errors(const tg_search *s) {
+    const size_t rec = root_rec_bytes(s->A);
+    for (int t = 0; t < s->dev.T; ++t) {
         const int32_t err = reinterpret_cast<const int32_t *>(s->roots_host + rec * t)[3];
         if (err)
             return tg::fail(TG_ERR_OVERFLOW, "tree %d: %s%s", t, (err & kErrPoolFull) ? "node pool full " : "",
                             (err & kErrRngEmpty) ? "random window exhausted " : (err & kErrPipeline) ? "selection pipeline stalled or path too deep " : "");
     }
     return TG_OK;
+}
+// the records + the device's own decision (finish_roots_kernel), queued on `st`; the host waits for fin_ev, not for the stream
+static int launch_finish_roots(tg_search *s, const int32_t *state_host, int max_moves, hipStream_t st) {
+    const int T = s->dev.T, A = s->A;
+    const size_t rec = root_rec_bytes(A), n = (size_t)4 * T;
+    if (int rc = alloc_root_records(s)) return rc;
+    if (!s->moves_dev) { if (int rc = dev_alloc(s, &s->moves_dev, (size_t)T)) return rc; }
+    if (!s->state_dev) {
+        if (int rc = dev_alloc(s, &s->state_dev, n)) return rc;
+        TG_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->state_pin), tg_search::kPinRing * n * sizeof(int32_t), hipHostMallocDefault));
+        for (int i = 0; i < tg_search::kPinRing; ++i) TG_HIP(hipEventCreateWithFlags(&s->state_ev[i], hipEventDisableTiming));
+        TG_HIP(hipEventCreateWithFlags(&s->fin_ev, hipEventDisableTiming));
+    }
+    const int slot = (int)(s->state_seq++ % tg_search::kPinRing);
+    if (s->state_ev_used[slot]) TG_HIP(hipEventSynchronize(s->state_ev[slot]));
+    int32_t *pin = s->state_pin + (size_t)slot * n;
+    std::memcpy(pin, state_host, n * sizeof(int32_t));
+    TG_HIP(hipMemcpyAsync(s->state_dev, pin, n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    TG_HIP(hipEventRecord(s->state_ev[slot], st));
+    s->state_ev_used[slot] = true;
+    RootTail *tail_dev = reinterpret_cast<RootTail *>(s->roots_dev + rec * T);
+    hipLaunchKernelGGL(finish_roots_kernel, dim3(T), dim3(64), 0, st, s->dev, A, s->roots_dev, rec, s->state_dev, max_moves,
+                       s->moves_dev, tail_dev);
+    TG_HIP(hipGetLastError());
+    TG_HIP(hipMemcpyAsync(s->roots_host, s->roots_dev, (rec + sizeof(RootTail)) * T, hipMemcpyDeviceToHost, st));
+    TG_HIP(hipEventRecord(s->fin_ev, st));
+    return TG_OK;
+}
+static int gather_roots(tg_search *s) {
+    const int T = s->dev.T, A = s->A;
+    const size_t rec = root_rec_bytes(A);
+    if (int rc = alloc_root_records(s)) return rc;
+    hipStream_t st = s->last_stream;
+    hipLaunchKernelGGL(gather_roots_kernel, dim3(T), dim3(64), 0, st, s->dev, A, s->roots_dev, rec);
+    TG_HIP(hipGetLastError());
+    TG_HIP(hipMemcpyAsync(s->roots_host, s->roots_dev, rec * T, hipMemcpyDeviceToHost, st));
+    TG_HIP(hipStreamSynchronize(st));
+    return root_record_errors(s);
 }
 
 extern "C" {
@@ -4645,21 +4849,8 @@ int tg_search_read_root_stats(tg_search *s, int32_t *num_children_host, int32_t 
     if (!s) return tg::fail(TG_ERR_ARG, "tg_search_read_root_stats: null argument");
     int rc = gather_roots(s);
     if (rc) return rc;
-    const size_t A = s->A, T = s->dev.T, rec = root_rec_bytes((int)A);
-    for (size_t t = 0; t < T; ++t) {
-        const unsigned char *r = s->roots_host + rec * t;
-        const int32_t *head = reinterpret_cast<const int32_t *>(r);
-        const int32_t *vis = head + 4, *vl = vis + A, *act = vl + A;
-        const double *vsum = reinterpret_cast<const double *>(r + rec - 2 * A * 8), *pol = vsum + A;
-        if (num_children_host) num_children_host[t] = head[0];
-        if (node_visits_host) node_visits_host[t] = head[1];
-        if (raw_value_host) std::memcpy(&raw_value_host[t], &head[2], 4);
-        if (visits_host) std::memcpy(visits_host + t * A, vis, A * 4);
-        if (virtual_loss_host) std::memcpy(virtual_loss_host + t * A, vl, A * 4);
-        if (action_host) std::memcpy(action_host + t * A, act, A * 4);
-        if (value_sum_host) std::memcpy(value_sum_host + t * A, vsum, A * 8);
-        if (policy_host) std::memcpy(policy_host + t * A, pol, A * 8);
-    }
+    parse_root_records(s, num_children_host, node_visits_host, raw_value_host, action_host, visits_host, virtual_loss_host,
+                       value_sum_host, policy_host);
     return TG_OK;
 }
 
@@ -4804,6 +4995,7 @@ double host_np_sum(const double *a, int n) {        // numpy's pairwise summatio
 struct SpGame {
     int index = -1;                 // -1: slot parked
     bool never_resign = false, done = true;
+    bool fresh = false;             // started, root not expanded yet (chained moves: the slot sits out one lock-step move)
     int to_move = kBlack, pass_count = 0, moves_played = 0;
     std::string body;               // ";B[ee]C[...]" ...
 };
@@ -4878,6 +5070,22 @@ struct tg_selfplay {
     };
     std::vector<PendingComment> pending;             // [T]
     int64_t last_window = 0;                         // phase random window of the last move (draws per tree): pre-generation hint
+    // chained moves (tg_selfplay_play_move, default): the device decides the move and goes on to the next root by itself
+    bool chained = false;                            // this handle runs chained moves (set by the first tg_selfplay_play_move)
+    bool sync_started = false;                       // ... or the round-trip scheme (TG_SP_CHAIN=0)
+    bool chain_started = false;                      // a chain has run: the roots are expanded, c_phase / the cursors are valid
+    std::vector<int64_t> c_phase;                    // per tree: draw cursor behind the phases of the last move (RootTail)
+    std::vector<uint8_t> skip, skip_fresh;           // per tree: takes no part in this move / game just started
+    std::vector<int32_t> state;                      // finish_roots_kernel's per-tree state [T][4]
+    // sub-groups of a lock-step move (launch_phases_subgroups): streams 1.., events, the phase tables of a whole move
+    static constexpr int kMaxSub = 16, kMaxPhases = 16;
+    int n_sub_streams = 0;
+    hipStream_t sub_stream[kMaxSub - 1] = {};
+    hipEvent_t ev_start = nullptr, ev_first_sel[kMaxSub] = {}, ev_sub_done[kMaxSub - 1] = {};
+    int32_t *phase_all_dev = nullptr, *phase_all_pin = nullptr;      // [kMaxPhases][3 T] (pinned: a ring of two)
+    hipEvent_t phase_all_ev[2] = {};
+    bool phase_all_used[2] = {};
+    unsigned phase_all_seq = 0;
 };
 
 namespace {
@@ -5037,6 +5245,18 @@ int tg_selfplay_create(tg_search *s, const char *save_dir, int visits, double ko
 }
 
 int tg_selfplay_destroy(tg_selfplay *sp) {
+    if (!sp) return TG_OK;
+    if (sp->ev_start) {
+        (void)hipSetDevice(sp->s->cfg.device);
+        if (sp->s->last_stream) (void)hipStreamSynchronize(sp->s->last_stream);
+        for (int i = 0; i < sp->n_sub_streams; ++i) { (void)hipStreamSynchronize(sp->sub_stream[i]); (void)hipStreamDestroy(sp->sub_stream[i]); }
+        (void)hipEventDestroy(sp->ev_start);
+        for (hipEvent_t e : sp->ev_first_sel) (void)hipEventDestroy(e);
+        for (hipEvent_t e : sp->ev_sub_done) (void)hipEventDestroy(e);
+        for (hipEvent_t e : sp->phase_all_ev) (void)hipEventDestroy(e);
+        (void)hipFree(sp->phase_all_dev);
+        (void)hipHostFree(sp->phase_all_pin);
+    }
     delete sp;
     return TG_OK;
 }
@@ -5048,6 +5268,7 @@ int tg_selfplay_start_game(tg_selfplay *sp, int slot, int index, int never_resig
     g.index = index;
     g.never_resign = never_resign != 0;
     g.done = index < 0;
+    g.fresh = index >= 0;
     sp->games[slot] = g;
     if ((size_t)slot < sp->pending.size()) sp->pending[slot].valid = false;
     sp->force_feed = true;
@@ -5070,7 +5291,7 @@ int tg_selfplay_schedule(tg_selfplay *sp, int32_t *num_considered_host, int32_t 
     std::fill(max_count_host, max_count_host + (size_t)max_phases * T, 0);
     int n_phases = 0;
     for (int t = 0; t < T; ++t) {
-        if (sp->games[t].done) continue;
+        if (sp->games[t].done || (sp->chained && sp->games[t].fresh)) continue;
         const int base = sp->nc[t] < 16 ? sp->nc[t] : 16;            // MAX_CONSIDERED_NODES (mcts/constant.py)
         auto it = sp->schedule_cache.find(base);
         if (it == sp->schedule_cache.end())
@@ -5087,7 +5308,14 @@ int tg_selfplay_schedule(tg_selfplay *sp, int32_t *num_considered_host, int32_t 
     return TG_OK;
 }
 
+static int finish_move_impl(tg_selfplay *sp, int32_t *moves_host, int32_t *finished_host, int64_t *stats_host, const RootTail *tail);
 int tg_selfplay_finish_move(tg_selfplay *sp, int32_t *moves_host, int32_t *finished_host, int64_t *stats_host) {
+    return finish_move_impl(sp, moves_host, finished_host, stats_host, nullptr);
+}
+
+// tail != nullptr (chained moves): the root records are in roots_host already (launch_finish_roots, fin_ev waited for) and
+// the device has decided the moves itself - the host's own decision below, from the same statistics, must be the same
+static int finish_move_impl(tg_selfplay *sp, int32_t *moves_host, int32_t *finished_host, int64_t *stats_host, const RootTail *tail) {
     if (!sp || !moves_host || !finished_host) return tg::fail(TG_ERR_ARG, "tg_selfplay_finish_move: null argument");
     tg_search *s = sp->s;
     const SearchDev &D = s->dev;
@@ -5099,13 +5327,20 @@ int tg_selfplay_finish_move(tg_selfplay *sp, int32_t *moves_host, int32_t *finis
     sp->vsum_a.resize((size_t)T * A); sp->pol_a.resize((size_t)T * A);
     std::vector<int32_t> &act32 = sp->act32;
     act32.resize((size_t)T * A);
-    int rc = tg_search_read_root_stats(s, sp->nc.data(), sp->nv.data(), sp->raw.data(), act32.data(), sp->visits_a.data(),
+    int rc = TG_OK;
+    if (tail) {
+        if ((rc = root_record_errors(s))) return rc;
+        parse_root_records(s, sp->nc.data(), sp->nv.data(), sp->raw.data(), act32.data(), sp->visits_a.data(), sp->vl_a.data(),
+                           sp->vsum_a.data(), sp->pol_a.data());
+    } else {
+        rc = tg_search_read_root_stats(s, sp->nc.data(), sp->nv.data(), sp->raw.data(), act32.data(), sp->visits_a.data(),
                                        sp->vl_a.data(), sp->vsum_a.data(), sp->pol_a.data());
+    }
     if (rc) return rc;
     if (s->noise_host.size() != (size_t)T * A) return tg::fail(TG_ERR_STATE, "tg_selfplay_finish_move: no root noise was set");
     // the boards are only needed to score a game that ends with this move, i.e. with a second pass in a row
     bool may_end = false;
-    for (int t = 0; t < T; ++t) may_end |= !sp->games[t].done && sp->games[t].pass_count == 1;
+    for (int t = 0; t < T; ++t) may_end |= !sp->games[t].done && sp->games[t].pass_count == 1 && (!tail || tail[t].kind == 2);
     sp->cells.resize((size_t)T * s->NC);
     if (may_end) TG_HIP(hipMemcpy(sp->cells.data(), D.root_cells, sp->cells.size(), hipMemcpyDeviceToHost));
     const int max_moves = S * S * 2;                                  // worker.py:44
@@ -5115,7 +5350,7 @@ int tg_selfplay_finish_move(tg_selfplay *sp, int32_t *moves_host, int32_t *finis
         SpGame &g = sp->games[t];
         moves_host[t] = -1;
         finished_host[t] = 0;
-        if (g.done) return;
+        if (g.done || (tail && g.fresh)) return;
         const size_t o = (size_t)t * A;
         const int n = sp->nc[t];
         const int32_t *vis = &sp->visits_a[o], *vl = &sp->vl_a[o], *act = &act32[o];
@@ -5133,6 +5368,17 @@ int tg_selfplay_finish_move(tg_selfplay *sp, int32_t *moves_host, int32_t *finis
         }
         const double value = vis[best] == 0 ? 0.5 : vsum[best] / (double)vis[best];
         n_moves[t] = 1;
+        if (tail) {
+            // what the device did with the same numbers (finish_roots_kernel): anything else is a bug, not a rounding matter
+            const int p2 = act[best] == 0 ? g.pass_count + 1 : 0;
+            const int kind = (!g.never_resign && value < 0.05) ? 1 : p2 == 2 ? 2 : g.moves_played + 1 >= max_moves ? 3 : 0;
+            if (tail[t].best != best || tail[t].kind != kind || tail[t].pos != act[best]) {
+                status[t] = tg::fail(TG_ERR_STATE, "tg_selfplay_play_move: board %d: the device chose child %d (point %d, kind %d), "
+                                     "the host child %d (point %d, kind %d) from the same root statistics", t, tail[t].best,
+                                     tail[t].pos, tail[t].kind, best, act[best], kind);
+                return;
+            }
+        }
         if (!g.never_resign && value < 0.05) {                          // worker.py:59-62
             status[t] = write_sgf(sp, g, 3 - g.to_move, true, 0.0);
             g.done = true;
@@ -5194,10 +5440,300 @@ int tg_selfplay_set_observer(tg_selfplay *sp, tg_selfplay_observer fn, void *use
 // library's own network handle, backup), final choice / records / finished games, the moves played on the
 // device-resident boards.  Buffers are the caller's (device): planes [T * batch_size][6][S][S],
 // policy [T * batch_size][A], value [T * batch_size][3].
+static int play_move_sync(tg_selfplay *sp, tg_net *net, float *planes_dev, float *policy_dev, float *value_dev,
+                          void *stream, int32_t *finished_host, int64_t *stats_host);
+static int play_move_chain(tg_selfplay *sp, tg_net *net, float *planes_dev, float *policy_dev, float *value_dev,
+                           void *stream, int32_t *finished_host, int64_t *stats_host);
+
 int tg_selfplay_play_move(tg_selfplay *sp, tg_net *net, float *planes_dev, float *policy_dev, float *value_dev,
                           void *stream, int32_t *finished_host, int64_t *stats_host) {
     if (!sp || !net || !planes_dev || !policy_dev || !value_dev || !finished_host)
         return tg::fail(TG_ERR_ARG, "tg_selfplay_play_move: null argument");
+    // TG_SP_CHAIN=0: the move decided on the host, three host round trips per move (kept for comparison; a handle stays
+    // with the scheme of its first move)
+    if (!sp->chain_started && !sp->sync_started) sp->chained = !getenv("TG_SP_CHAIN") || atoi(getenv("TG_SP_CHAIN")) != 0;
+    if (sp->chained) return play_move_chain(sp, net, planes_dev, policy_dev, value_dev, stream, finished_host, stats_host);
+    sp->sync_started = true;
+    return play_move_sync(sp, net, planes_dev, policy_dev, value_dev, stream, finished_host, stats_host);
+}
+
+// Chained moves.  A call = one lock-step move of every board whose root is expanded:
+//   host   cursors of the last chain -> root child counts; Gumbel noise; halving schedule; random window (phases + next root)
+//   device the phases (selection, forward, backup); finish_roots_kernel: root records + THE MOVE (choice, resign, game end);
+//          play_kernel on the device's own moves; next root expansion, forward, backup          <- no host in between
+//   host   (while that runs) last move's record comments, draws generated ahead; then waits for the RECORDS only (fin_ev,
+//          recorded ahead of play_kernel), does the bookkeeping - checking the device's decision against its own - and returns
+//          with the device still ~0.15 ms from the end of the root evaluation the next call starts from.
+// A slot whose game has just been started (tg_selfplay_start_game) sits out one call: its root is expanded by that call's
+// chain.  The first call of a handle therefore evaluates roots only.  Games, records and draws are those of the
+// round-trip scheme (the draws of a game are consumed in the same order: root prior, noise, phases, next root prior ...).
+// The phases of a move with the boards in G sub-groups, each on a stream of its own and one selection behind the
+// previous one: a sub-group's forward pass (most of the CUs) runs while the others' tree kernels (one workgroup per
+// board) do - with ONE group the forward pass waits for the slowest board's selection and the selection for the whole
+// forward pass, every phase.  Same kernels, on slices of the engine (sub_dev); leaf slots: sub-group g owns positions
+// [first board x batch_size ...) of the caller's buffers, so sub-groups in different phases never share rows.
+static int launch_phases_subgroups(tg_selfplay *sp, tg_net *net, int n_phases, int G, float *planes_dev, float *policy_dev,
+                                   float *value_dev, hipStream_t st, int64_t &leaves, bool &any_phase) {
+    tg_search *s = sp->s;
+    const int T = s->dev.T, A = s->A, K = s->dev.K;
+    const size_t P = (size_t)s->P;
+    constexpr int kMaxPhases = tg_selfplay::kMaxPhases;
+    int rc;
+    if (!sp->ev_start) {
+        TG_HIP(hipEventCreateWithFlags(&sp->ev_start, hipEventDisableTiming));
+        for (hipEvent_t &e : sp->ev_first_sel) TG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (hipEvent_t &e : sp->ev_sub_done) TG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (hipEvent_t &e : sp->phase_all_ev) TG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        TG_HIP(hipMalloc(reinterpret_cast<void **>(&sp->phase_all_dev), (size_t)kMaxPhases * 3 * T * sizeof(int32_t)));
+        TG_HIP(hipHostMalloc(reinterpret_cast<void **>(&sp->phase_all_pin), (size_t)2 * kMaxPhases * 3 * T * sizeof(int32_t), hipHostMallocDefault));
+    }
+    while (sp->n_sub_streams < G - 1) {
+        TG_HIP(hipStreamCreateWithFlags(&sp->sub_stream[sp->n_sub_streams], hipStreamNonBlocking));
+        sp->n_sub_streams += 1;
+    }
+    int tb[tg_selfplay::kMaxSub + 1];
+    for (int g = 0; g <= G; ++g) tb[g] = (int)((int64_t)g * T / G);
+    const int ring = (int)(sp->phase_all_seq++ % 2);
+    if (sp->phase_all_used[ring]) TG_HIP(hipEventSynchronize(sp->phase_all_ev[ring]));
+    int32_t *tab = sp->phase_all_pin + (size_t)ring * kMaxPhases * 3 * T;
+    int64_t counts[kMaxPhases][tg_selfplay::kMaxSub] = {};
+    for (int ph = 0; ph < n_phases; ++ph) {
+        const int32_t *nc = &sp->ph_nc[(size_t)ph * T], *mc = &sp->ph_mc[(size_t)ph * T];
+        int32_t *row = tab + (size_t)ph * 3 * T;
+        for (int g = 0; g < G; ++g) {
+            int64_t at = (int64_t)tb[g] * K;
+            for (int t = tb[g]; t < tb[g + 1]; ++t) {
+                const int64_t n = (int64_t)nc[t] * mc[t];
+                if (nc[t] < 0 || mc[t] < 0 || n > K)
+                    return tg::fail(TG_ERR_ARG, "tg_selfplay_play_move: tree %d phase does not fit %d slots", t, K);
+                row[t] = nc[t];
+                row[T + t] = mc[t];
+                row[2 * (size_t)T + t] = (int32_t)at;
+                at += n;
+            }
+            counts[ph][g] = at - (int64_t)tb[g] * K;
+        }
+    }
+    TG_HIP(hipMemcpyAsync(sp->phase_all_dev, tab, (size_t)n_phases * 3 * T * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    TG_HIP(hipEventRecord(sp->phase_all_ev[ring], st));
+    sp->phase_all_used[ring] = true;
+    s->last_stream = st;
+    if ((rc = install_rng(s, st))) return rc;                          // (the first part of the window; the cursors back to 0)
+    s->packed_leaves = true;
+    TG_HIP(hipEventRecord(sp->ev_start, st));
+    for (int g = 1; g < G; ++g) TG_HIP(hipStreamWaitEvent(sp->sub_stream[g - 1], sp->ev_start, 0));
+    int launched[tg_selfplay::kMaxSub] = {};
+    int last_started = -1;                                              // the last sub-group whose first selection is queued
+    for (int ph = 0; ph < n_phases; ++ph) {
+        const int32_t *row = sp->phase_all_dev + (size_t)ph * 3 * T;
+        for (int g = 0; g < G; ++g) {
+            const int64_t count = counts[ph][g];
+            if (count == 0) continue;
+            hipStream_t sg = g == 0 ? st : sp->sub_stream[g - 1];
+            if (launched[g] == 0 && last_started >= 0) TG_HIP(hipStreamWaitEvent(sg, sp->ev_first_sel[last_started], 0));
+            if (launched[g] == 1 && any_phase) TG_HIP(hipStreamWaitEvent(sg, s->ev_rng[s->rng_active], 0));   // second part of the window
+            const SearchDev D = sub_dev(s, tb[g], tb[g + 1] - tb[g]);
+            const int32_t *off = row + 2 * (size_t)T + tb[g];
+            if ((rc = launch_gumbel_select(s, D, row + tb[g], row + T + tb[g], off, K, planes_dev, sg))) return rc;
+            if (launched[g] == 0) {
+                TG_HIP(hipEventRecord(sp->ev_first_sel[g], sg));
+                last_started = g;
+            }
+            const size_t o = (size_t)tb[g] * K;
+            if ((rc = tg_net_forward_dev(net, planes_dev + o * 6 * P, (int)count, 1, policy_dev + o * A, value_dev + o * 3, sg))) return rc;
+            if ((rc = launch_backup(s, D, policy_dev, value_dev, 0, off, 1, sg))) return rc;
+            leaves += count;
+            launched[g] += 1;
+            if (!any_phase) {
+                any_phase = true;
+                if ((rc = feed_streams_rest(s))) return rc;           // behind the first launched selection
+            }
+        }
+    }
+    for (int g = 1; g < G; ++g) {
+        TG_HIP(hipEventRecord(sp->ev_sub_done[g - 1], sp->sub_stream[g - 1]));
+        TG_HIP(hipStreamWaitEvent(st, sp->ev_sub_done[g - 1], 0));
+    }
+    return TG_OK;
+}
+
+static int play_move_chain(tg_selfplay *sp, tg_net *net, float *planes_dev, float *policy_dev, float *value_dev,
+                           void *stream, int32_t *finished_host, int64_t *stats_host) {
+    tg_search *s = sp->s;
+    const int T = s->dev.T, A = s->A;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int rc;
+    s->prefill_enabled = false;
+    static const bool timing = getenv("TG_SP_TIMING") != nullptr;
+    double *acc = sp->t_acc;
+    long &moves_timed = sp->moves_timed;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_last = timing ? now() : 0.0;
+    auto lap = [&](int i) { if (timing) { const double t = now(); acc[i] += t - t_last; t_last = t; } };
+    if (s->streams.size() != (size_t)T) return tg::fail(TG_ERR_ARG, "tg_selfplay_play_move: streams are not seeded");
+    sp->skip.assign(T, 0);
+    sp->skip_fresh.assign(T, 0);
+    int64_t leaves = 0;
+    for (int t = 0; t < T; ++t) {
+        const SpGame &g = sp->games[t];
+        sp->skip_fresh[t] = (!sp->chain_started || g.fresh) ? 1 : 0;          // (before the first chain no root is expanded)
+        sp->skip[t] = (g.done || sp->skip_fresh[t]) ? 1 : 0;
+        leaves += sp->skip[t] ? 0 : 1;                                        // the root evaluation this move starts from
+    }
+    // ---- the roots' child counts, off the draw cursors (a Dirichlet prior takes one draw per child) ----
+    sp->consumed.assign(T, 0);
+    sp->nc.assign(T, 0);
+    sp->c_phase.resize(T, 0);
+    if (sp->chain_started) {
+        if ((rc = advance_streams_impl(s, sp->consumed.data(), sp->skip_fresh.data()))) return rc;
+        for (int t = 0; t < T; ++t) {
+            if (sp->skip[t]) continue;
+            const int64_t n = sp->consumed[t] - sp->c_phase[t];
+            if (n < 1 || n > A)
+                return tg::fail(TG_ERR_STATE, "tg_selfplay_play_move: board %d consumed %lld draws at its root (expected 1..%d)",
+                                t, (long long)n, A);
+            sp->nc[t] = (int32_t)n;
+        }
+    }
+    sp->nc_known = true;
+    sp->nc_cursor = sp->nc;
+    lap(0);
+    if ((rc = draw_noise_impl(s, nullptr, sp->skip_fresh.data()))) return rc;
+    lap(1);
+    // ---- sequential halving (tree.py:375-384) ----
+    constexpr int kMaxPhases = tg_selfplay::kMaxPhases;
+    sp->ph_nc.resize((size_t)kMaxPhases * T);
+    sp->ph_mc.resize((size_t)kMaxPhases * T);
+    int32_t n_phases = 0;
+    if ((rc = tg_selfplay_schedule(sp, sp->ph_nc.data(), sp->ph_mc.data(), kMaxPhases, &n_phases))) return rc;
+    // one window for the phases (bound as in the round-trip scheme: DESIGN 4.2) and the next root's prior (<= A draws)
+    sp->ph_seen.assign(T, 0);
+    int64_t window = 0, first_window = 0;
+    for (int ph = 0; ph < n_phases; ++ph) {
+        const int32_t *nc = &sp->ph_nc[(size_t)ph * T], *mc = &sp->ph_mc[(size_t)ph * T];
+        int64_t expansions = 0;
+        for (int t = 0; t < T; ++t) {
+            const int64_t n = (int64_t)nc[t] * mc[t];
+            const int64_t entered = std::min<int64_t>(n, std::min<int64_t>(A, (int64_t)nc[t] + sp->ph_seen[t]));
+            expansions = entered > expansions ? entered : expansions;
+            sp->ph_seen[t] = (int32_t)std::min<int64_t>(A, sp->ph_seen[t] + entered);
+        }
+        window += expansions * A;
+        if (ph == 0) first_window = window;
+    }
+    lap(2);
+    if ((rc = feed_streams_impl(s, (size_t)(window + A), 1, window > 0 ? (size_t)first_window : 0))) return rc;
+    lap(3);
+    bool any_phase = false;
+    // sub-groups (TG_SP_SUBGROUPS overrides; 1 = the whole lock-step group at once; an observer sees whole phases)
+    const int sub_env = getenv("TG_SP_SUBGROUPS") ? atoi(getenv("TG_SP_SUBGROUPS")) : 0;       // (read per call: tests toggle it)
+    // measured (tools/bench_selfplay.py, 400 simulations, leaf evaluations/s, one group -> sub-groups): 4 boards 1.06 -> 1.20 M
+    // (2), 8: 1.71 -> 1.86 M (2), 16: 2.49 -> 2.84 M (3), 24: 3.00 -> 3.30 M (4); from 32 boards on a sub-group's forward pass
+    // needs every CU or comes in launches too small to be efficient (32 boards: 3.26 M whole, 2.95 M in six)
+    int G = sub_env > 0 ? sub_env : (T < 4 || T > 28 ? 1 : std::max(2, std::min(4, (T + 5) / 6)));
+    G = std::max(1, std::min(std::min(G, (int)tg_selfplay::kMaxSub), T));
+    if (sp->observer || n_phases == 0) G = 1;
+    if (G > 1) {
+        if ((rc = launch_phases_subgroups(sp, net, n_phases, G, planes_dev, policy_dev, value_dev, st, leaves, any_phase))) return rc;
+    }
+    for (int ph = 0; ph < n_phases && G == 1; ++ph) {
+        const int32_t *nc = &sp->ph_nc[(size_t)ph * T], *mc = &sp->ph_mc[(size_t)ph * T];
+        int64_t total = 0, slots = 0;
+        for (int t = 0; t < T; ++t) {
+            const int64_t n = (int64_t)nc[t] * mc[t];
+            total += n;
+            slots = n > slots ? n : slots;
+        }
+        if (slots == 0) continue;
+        if ((rc = tg_search_select_gumbel(s, nc, mc, 0, planes_dev, stream))) return rc;
+        if ((rc = tg_net_forward_dev(net, planes_dev, (int)total, 1, policy_dev, value_dev, stream))) return rc;
+        if ((rc = tg_search_backup(s, policy_dev, value_dev, 0, 1, stream))) return rc;
+        if (sp->observer) {
+            tg_selfplay_event ev{};
+            ev.kind = 0; ev.phase = ph; ev.trees = T; ev.positions = (int32_t)total;
+            ev.num_considered = nc; ev.max_count = mc;
+            ev.planes_dev = planes_dev; ev.policy_dev = policy_dev; ev.value_dev = value_dev; ev.stream = stream;
+            sp->observer(sp->observer_user, &ev);
+        }
+        leaves += total;
+        if (!any_phase && (rc = feed_streams_rest(s))) return rc;      // behind the first launched phase
+        any_phase = true;
+    }
+    if ((rc = feed_streams_rest(s))) return rc;                        // (no phase was launched)
+    // ---- the chain: records + decision, the moves played, the next roots expanded and evaluated ----
+    const int max_moves = s->S * s->S * 2;                             // worker.py:44
+    sp->state.assign((size_t)4 * T, 0);
+    for (int t = 0; t < T; ++t) {
+        const SpGame &g = sp->games[t];
+        sp->state[4 * (size_t)t] = (sp->skip[t] ? 1 : 0) | (g.never_resign ? 2 : 0);
+        sp->state[4 * (size_t)t + 1] = g.pass_count;
+        sp->state[4 * (size_t)t + 2] = g.moves_played;
+    }
+    s->last_stream = st;
+    if ((rc = launch_finish_roots(s, sp->state.data(), max_moves, st))) return rc;
+    if (s->S == 9) hipLaunchKernelGGL(play_kernel<9>, dim3(T), dim3(64), 0, st, s->dev, s->moves_dev);
+    else hipLaunchKernelGGL(play_kernel<19>, dim3(T), dim3(64), 0, st, s->dev, s->moves_dev);
+    TG_HIP(hipGetLastError());
+    if ((rc = tg_search_root_planes(s, planes_dev, stream))) return rc;          // (also uploads the roots of games just started)
+    if ((rc = tg_net_forward_dev(net, planes_dev, T, 1, policy_dev, value_dev, stream))) return rc;
+    if ((rc = tg_search_backup(s, policy_dev, value_dev, 1, 1, stream))) return rc;
+    lap(4);
+    // ---- host work that nobody is waiting for: the previous move's record comments, draws generated ahead ----
+    flush_comments(sp);
+    {
+        const size_t ahead = (size_t)2 * A + (size_t)2 * window + (size_t)8 * A;
+        wait_prefill(s);
+        parallel_trees(T, [&](int t) {
+            if (!sp->games[t].done && s->streams[t].seeded) s->streams[t].ensure(s->streams[t].available() < ahead ? ahead : 0);
+        });
+        sp->last_window = window;
+    }
+    lap(5);
+    // ---- the records (not the stream): bookkeeping ----
+    TG_HIP(hipEventSynchronize(s->fin_ev));
+    lap(6);
+    const RootTail *tail = reinterpret_cast<const RootTail *>(s->roots_host + root_rec_bytes(A) * (size_t)T);
+    for (int t = 0; t < T; ++t) sp->c_phase[t] = tail[t].cursor;
+    sp->mv.resize(T);
+    int64_t counts[2] = {0, 0};
+    if (any_phase || sp->chain_started) {
+        if ((rc = finish_move_impl(sp, sp->mv.data(), finished_host, counts, tail))) return rc;
+        // the roots' child counts in the records must be what the draw cursors said
+        for (int t = 0; t < T; ++t)
+            if (!sp->skip[t] && sp->nc[t] != sp->nc_cursor[t])
+                return tg::fail(TG_ERR_STATE, "tg_selfplay_play_move: board %d has %d root children but its root expansion "
+                                "consumed %d draws - the halving schedule was built from a wrong width", t, sp->nc[t], sp->nc_cursor[t]);
+        if (sp->observer) {
+            tg_selfplay_event ev{};
+            ev.kind = 1; ev.phase = n_phases; ev.trees = T;
+            ev.num_children = sp->nc.data(); ev.action = sp->act32.data(); ev.children_visits = sp->visits_a.data();
+            ev.children_value_sum = sp->vsum_a.data(); ev.moves = sp->mv.data(); ev.finished = finished_host;
+            sp->observer(sp->observer_user, &ev);
+        }
+    } else {
+        for (int t = 0; t < T; ++t) finished_host[t] = 0;
+        if ((rc = root_record_errors(s))) return rc;
+    }
+    if (sp->observer) {                                                // (the root evaluation's buffers are untouched since)
+        tg_selfplay_event ev{};
+        ev.kind = 0; ev.phase = -1; ev.trees = T; ev.positions = T;
+        ev.planes_dev = planes_dev; ev.policy_dev = policy_dev; ev.value_dev = value_dev; ev.stream = stream;
+        sp->observer(sp->observer_user, &ev);
+    }
+    for (int t = 0; t < T; ++t) sp->games[t].fresh = false;           // every root is expanded now (or about to be)
+    sp->chain_started = true;
+    lap(7);
+    if (timing && ++moves_timed % 200 == 0)
+        fprintf(stderr, "[selfplay timing (chained), ms per move over %ld moves] cursors %.3f | noise %.3f | schedule %.3f | feed %.3f | "
+                "launches %.3f | comments + draws ahead %.3f | wait for records %.3f | bookkeeping %.3f\n", moves_timed,
+                1e3 * acc[0] / moves_timed, 1e3 * acc[1] / moves_timed, 1e3 * acc[2] / moves_timed, 1e3 * acc[3] / moves_timed,
+                1e3 * acc[4] / moves_timed, 1e3 * acc[5] / moves_timed, 1e3 * acc[6] / moves_timed, 1e3 * acc[7] / moves_timed);
+    if (stats_host) { stats_host[0] = counts[0]; stats_host[1] = counts[1]; stats_host[2] = leaves; }
+    return TG_OK;
+}
+
+static int play_move_sync(tg_selfplay *sp, tg_net *net, float *planes_dev, float *policy_dev, float *value_dev,
+                          void *stream, int32_t *finished_host, int64_t *stats_host) {
     tg_search *s = sp->s;
     const int T = s->dev.T, A = s->A;
     int rc;

@@ -204,6 +204,44 @@ def _fast_vs_slow(tmp_path, boards, first_index, watch, replay_moves_at_least, c
     return a
 
 
+def test_selfplay_move_schemes_play_the_same_games(tmp_path, monkeypatch):
+    """tg_selfplay_play_move's schemes - move decided on the host with three round trips (TG_SP_CHAIN=0), decided on the
+    device with the next root chained behind it (default), the same with the boards of a lock-step move in 2 / 3 / 4
+    staggered sub-groups on their own streams (default below 29 boards) - and the phase-by-phase host path: same SGF files
+    byte for byte, same counters.  (The chained scheme itself is replayed against the oracle by the two tests below: the
+    observer they attach keeps the boards in one group.)"""
+    from oracle.net import make_state_dict
+    from tamago_amd.nn.network.dual_net import DualNet
+    from tamago_amd.selfplay.worker import selfplay_shard
+    net = DualNet(torch.device("cuda:0"), 9)
+    net.load_state_dict(make_state_dict(9, 23, 1.5))
+    idx = list(range(301, 301 + 44))
+    flags = [i % 5 != 0 for i in idx]
+    results = {}
+    for name, chain, sub in (("host decision", "0", None), ("chained", "1", "1"), ("2 sub-groups", "1", "2"),
+                             ("default", None, None), ("4 sub-groups", "1", "4")):
+        for key, val in (("TG_SP_CHAIN", chain), ("TG_SP_SUBGROUPS", sub)):
+            if val is None:
+                monkeypatch.delenv(key, raising=False)
+            else:
+                monkeypatch.setenv(key, val)
+        d = tmp_path / name.replace(" ", "_")
+        d.mkdir()
+        stats = selfplay_shard(str(d), net, idx, 9, VISITS, boards=16, never_resign_flags=flags)
+        results[name] = (stats, [open(d / f"{i}.sgf").read() for i in idx])
+    monkeypatch.delenv("TG_SP_CHAIN", raising=False)
+    monkeypatch.delenv("TG_SP_SUBGROUPS", raising=False)
+    d = tmp_path / "phases"
+    d.mkdir()
+    stats = selfplay_shard(str(d), HostOnly(net), idx[:16], 9, VISITS, boards=16, never_resign_flags=flags[:16])
+    ref = results["host decision"]
+    assert ref[0]["games"] == len(idx) and ref[0]["leaf_evals"] == ref[0]["moves"] * (VISITS + 1)
+    for name, got in results.items():
+        assert got[0] == ref[0], name
+        assert got[1] == ref[1], name
+    assert [open(d / f"{i}.sgf").read() for i in idx[:16]] == ref[1][:16]
+
+
 def test_cfg3_one_call_path_16_boards_400_sims_vs_phase_path_and_oracle(tmp_path):
     # two games replayed move for move to their end, two for their first 50 moves
     _fast_vs_slow(tmp_path, 16, 101, watch=(0, 5, 10, 15), replay_moves_at_least=160, caps=(None, 50, None, 50))
