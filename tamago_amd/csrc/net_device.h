@@ -231,6 +231,10 @@ struct tg_net {
     std::mutex host_mu;
     // 19x19 Winograd kernel: one scratch image set PER STREAM.  Launches on one stream run in order,
     // launches on different streams may overlap on the device and must not share activation images.
+    // > 0: the exact-fp32 kernel queued behind a split launch as its range guard takes at most this many workgroups.  Each
+    // needs a CU to itself even to read a clear flag: with several streams sharing the device (self-play sub-groups) a
+    // full-size guard launch waits for the other streams' forward passes to drain.  The rare real fallback is slower.
+    int guard_grid_cap = 0;
     std::mutex scratch_mu;
     std::map<hipStream_t, float *> scratch_by_stream;
     std::map<hipStream_t, int *> flag_by_stream;      // f16 split kernel: range flag per launch stream

@@ -620,7 +620,8 @@ int launch_wino8(tg_net *net, const float *planes, int batch, int want_logits, f
         attr_set[net->device & 15] = true;
     }
     const int groups = (batch + G - 1) / G;
-    const int grid = groups < net->num_cus ? groups : net->num_cus;     // one 8-wave workgroup per CU
+    int grid = groups < net->num_cus ? groups : net->num_cus;           // one 8-wave workgroup per CU
+    if (guard && net->guard_grid_cap > 0 && grid > net->guard_grid_cap) grid = net->guard_grid_cap;
     NetDev dev = net->dev;
     if (GS) {
         std::lock_guard<std::mutex> lock(net->scratch_mu);
@@ -639,6 +640,10 @@ int launch_wino8(tg_net *net, const float *planes, int batch, int want_logits, f
 }
 
 }  // namespace
+
+namespace tg {
+void net_set_guard_cap(tg_net *net, int cap) { if (net) net->guard_grid_cap = cap; }
+}  // namespace tg
 
 extern "C" {
 

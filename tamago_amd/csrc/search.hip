@@ -33,6 +33,8 @@
 #include "common.h"
 #include "legacy_stream.h"
 
+namespace tg { void net_set_guard_cap(tg_net *net, int cap); }     // net_forward.hip (tg_net::guard_grid_cap)
+
 #include <sched.h>
 
 #include <cmath>
@@ -3690,6 +3692,12 @@ __global__ __launch_bounds__(64) void finish_roots_kernel(SearchDev D, int A, un
     }
 }
 
+// the draw cursors into pinned host memory (self-play: read by the host a root evaluation later - no copy, no copy stream)
+__global__ void publish_cursors_kernel(const int64_t *cursor, int64_t *out, int T) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < T) out[t] = cursor[t];
+}
+
 struct tg_search {
     tg_search_config cfg{};
     SearchDev dev{};
@@ -3702,6 +3710,7 @@ struct tg_search {
     std::vector<void *> allocs;
     int S = 0, W = 0, NC = 0, P = 0, A = 0, HMAX = 0;
     hipStream_t last_stream = nullptr;
+    bool stream_known = false;             // a launch has named its stream (which may be the null stream: last_stream == nullptr)
     // root positions are staged on the host and uploaded in bulk by tg_search_root_planes
     std::vector<uint8_t> st_cells;
     std::vector<uint64_t> st_hist;
@@ -3759,6 +3768,8 @@ struct tg_search {
     bool noise_ev_used[kPinRing] = {}, moves_ev_used[kPinRing] = {};
     unsigned noise_seq = 0, moves_seq = 0;
     // finish_roots_kernel (self-play: the move decided on the device): per-tree state uploads, the event behind its records
+    int64_t *cur_pin = nullptr, *cur_pin_dev = nullptr;     // publish_cursors_kernel's target (pinned, mapped) + its event
+    hipEvent_t cur_ev = nullptr;
     uint8_t *roots_pin = nullptr;          // pinned mirror of st_cells / st_hist / st_meta (flush_roots)
     hipEvent_t roots_pin_ev = nullptr;
     bool roots_pin_used = false;
@@ -4039,12 +4050,13 @@ int tg_search_destroy(tg_search *s) {
     if (!s) return TG_OK;
     if (s->prefill.valid()) s->prefill.wait();          // (the background generator works on s->streams)
     (void)hipSetDevice(s->cfg.device);
-    if (s->last_stream) (void)hipStreamSynchronize(s->last_stream);
+    if (s->stream_known) (void)hipStreamSynchronize(s->last_stream);      // (nullptr: the null stream)
     if (s->noise_pin) {
         (void)hipHostFree(s->noise_pin);
         for (int i = 0; i < tg_search::kPinRing; ++i) (void)hipEventDestroy(s->noise_ev[i]);
     }
     if (s->roots_pin) { (void)hipHostFree(s->roots_pin); (void)hipEventDestroy(s->roots_pin_ev); }
+    if (s->cur_pin) { (void)hipHostFree(s->cur_pin); (void)hipEventDestroy(s->cur_ev); }
     if (s->state_pin) {
         (void)hipHostFree(s->state_pin);
         for (int i = 0; i < tg_search::kPinRing; ++i) (void)hipEventDestroy(s->state_ev[i]);
@@ -4267,6 +4279,7 @@ int tg_search_root_planes(tg_search *s, float *planes_dev, void *stream) {
     if (!s || !planes_dev) return tg::fail(TG_ERR_ARG, "tg_search_root_planes: null argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
     s->last_stream = st;
+    s->stream_known = true;
     {
         int rc = flush_roots(s, st);
         if (rc) return rc;
@@ -4284,6 +4297,7 @@ int tg_search_select_puct(tg_search *s, int max_leaves, float *planes_dev, int32
         return tg::fail(TG_ERR_ARG, "tg_search_select_puct: max_leaves %d outside [0, batch_size]", max_leaves);
     hipStream_t st = static_cast<hipStream_t>(stream);
     s->last_stream = st;
+    s->stream_known = true;
     {
         int rc = install_rng(s, st);
         if (rc) return rc;
@@ -4351,6 +4365,7 @@ int tg_search_play(tg_search *s, const int32_t *moves_host, void *stream) {
     if (!s || !moves_host) return tg::fail(TG_ERR_ARG, "tg_search_play: null argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
     s->last_stream = st;
+    s->stream_known = true;
     int rc = flush_roots(s, st);
     if (rc) return rc;
     if (!s->moves_dev && (rc = dev_alloc(s, &s->moves_dev, (size_t)s->dev.T))) return rc;
@@ -4401,7 +4416,7 @@ int tg_search_set_noise(tg_search *s, const double *noise_host) {
     if (!s || !noise_host) return tg::fail(TG_ERR_ARG, "tg_search_set_noise: null argument");
     const size_t n = (size_t)s->dev.T * s->A;
     s->noise_host.assign(noise_host, noise_host + n);
-    if (!s->last_stream) {                         // no launch stream yet: the null stream, synchronously
+    if (!s->stream_known) {                        // no launch stream yet: the null stream, synchronously
         TG_HIP(hipDeviceSynchronize());
         TG_HIP(hipMemcpy(s->dev.noise, noise_host, n * sizeof(double), hipMemcpyHostToDevice));
         return TG_OK;
@@ -4560,18 +4575,21 @@ static int feed_streams_rest(tg_search *s) {
     return TG_OK;
 }
 
-static int advance_streams_impl(tg_search *s, int64_t *consumed_host, const uint8_t *skip);
+static int advance_streams_impl(tg_search *s, int64_t *consumed_host, const uint8_t *skip, const int64_t *used_in = nullptr);
 int tg_search_advance_streams(tg_search *s, int64_t *consumed_host) { return advance_streams_impl(s, consumed_host, nullptr); }
 
 // skip[t] != 0: tree t's stream was replaced since the window went up - what the device consumed there is not its (a
 // self-play slot whose game ended while the device had already gone on to the next root)
-static int advance_streams_impl(tg_search *s, int64_t *consumed_host, const uint8_t *skip) {
+// used_in: the device cursors, if the caller has them already (publish_cursors_kernel)
+static int advance_streams_impl(tg_search *s, int64_t *consumed_host, const uint8_t *skip, const int64_t *used_in) {
     if (!s) return tg::fail(TG_ERR_ARG, "tg_search_advance_streams: null argument");
     const int T = s->dev.T;
     if (s->streams.size() != (size_t)T) return tg::fail(TG_ERR_ARG, "tg_search_advance_streams: streams are not seeded");
     wait_prefill(s);
     std::vector<int64_t> used(T);
-    {
+    if (used_in) {
+        std::memcpy(used.data(), used_in, (size_t)T * sizeof(int64_t));
+    } else {
         int rc = tg_search_rng_consumed(s, used.data());
         if (rc) return rc;
     }
@@ -4597,11 +4615,12 @@ static int advance_streams_impl(tg_search *s, int64_t *consumed_host, const uint
     return TG_OK;
 }
 
-static int draw_noise_impl(tg_search *s, double *noise_host, const uint8_t *skip);
+static int draw_noise_impl(tg_search *s, double *noise_host, const uint8_t *skip, const double *const *ready = nullptr);
 int tg_search_draw_noise(tg_search *s, double *noise_host) { return draw_noise_impl(s, noise_host, nullptr); }
 
 // skip[t] != 0: tree t draws nothing (zero noise) - its stream must not move yet
-static int draw_noise_impl(tg_search *s, double *noise_host, const uint8_t *skip) {
+// ready[t] != nullptr: the A values are there already (-log of tree t's next A draws, computed ahead): copied, the draws consumed
+static int draw_noise_impl(tg_search *s, double *noise_host, const uint8_t *skip, const double *const *ready) {
     if (!s) return tg::fail(TG_ERR_ARG, "tg_search_draw_noise: null argument");
     const int T = s->dev.T, A = s->A;
     if (s->streams.size() != (size_t)T) return tg::fail(TG_ERR_ARG, "tg_search_draw_noise: streams are not seeded");
@@ -4612,17 +4631,23 @@ static int draw_noise_impl(tg_search *s, double *noise_host, const uint8_t *skip
         local.resize((size_t)T * A);
         noise = local.data();
     }
-    parallel_trees(T, [&](int t) {
+    auto one = [&](int t) {
         if (skip && skip[t]) {
             for (int i = 0; i < A; ++i) noise[(size_t)t * A + i] = 0.0;
             return;
         }
         tg::LegacyStream &ls = s->streams[t];
         ls.ensure((size_t)A);
-        const double *e = ls.data();
-        for (int i = 0; i < A; ++i) noise[(size_t)t * A + i] = -std::log(e[i]);   // gumbel(0,1) of the same uniforms
+        if (ready && ready[t]) {
+            std::memcpy(&noise[(size_t)t * A], ready[t], (size_t)A * sizeof(double));
+        } else {
+            const double *e = ls.data();
+            for (int i = 0; i < A; ++i) noise[(size_t)t * A + i] = -std::log(e[i]);   // gumbel(0,1) of the same uniforms
+        }
         ls.consume((size_t)A);
-    });
+    };
+    if (ready && T <= 64) for (int t = 0; t < T; ++t) one(t);      // (copies: not worth waking the pool)
+    else parallel_trees(T, one);
     s->win_left = 0;                               // the noise sits between two windows
     return tg_search_set_noise(s, noise);
 }
@@ -4718,6 +4743,7 @@ int tg_search_select_gumbel(tg_search *s, const int32_t *num_considered_host, co
         return tg::fail(TG_ERR_ARG, "tg_search_select_gumbel: %lld leaves exceed T * batch_size", (long long)total);
     hipStream_t st = static_cast<hipStream_t>(stream);
     s->last_stream = st;
+    s->stream_known = true;
     if (!s->phase_dev) {
         int rc = dev_alloc(s, &s->phase_dev, (size_t)3 * T);
         if (rc) return rc;
@@ -4747,6 +4773,7 @@ int tg_search_backup(tg_search *s, const float *policy_dev, const float *value_d
         return tg::fail(TG_ERR_ARG, "tg_search_backup: slots_per_tree %d outside [1, batch_size]", slots_per_tree);
     hipStream_t st = static_cast<hipStream_t>(stream);
     s->last_stream = st;
+    s->stream_known = true;
     const int32_t *off = packed ? s->phase_dev + 2 * (size_t)s->dev.T : nullptr;
     return launch_backup(s, s->dev, policy_dev, value_dev, slots_per_tree, off, use_logit, st);
 }
@@ -5077,6 +5104,8 @@ struct tg_selfplay {
     std::vector<int64_t> c_phase;                    // per tree: draw cursor behind the phases of the last move (RootTail)
     std::vector<uint8_t> skip, skip_fresh;           // per tree: takes no part in this move / game just started
     std::vector<int32_t> state;                      // finish_roots_kernel's per-tree state [T][4]
+    std::vector<double> g2;                          // per tree: -log of the 2 A draws behind the phases (noise candidates)
+    std::vector<int64_t> g2_base;                    // ... and the cursor they start at (-1: none)
     // sub-groups of a lock-step move (launch_phases_subgroups): streams 1.., events, the phase tables of a whole move
     static constexpr int kMaxSub = 16, kMaxPhases = 16;
     int n_sub_streams = 0;
@@ -5248,7 +5277,7 @@ int tg_selfplay_destroy(tg_selfplay *sp) {
     if (!sp) return TG_OK;
     if (sp->ev_start) {
         (void)hipSetDevice(sp->s->cfg.device);
-        if (sp->s->last_stream) (void)hipStreamSynchronize(sp->s->last_stream);
+        if (sp->s->stream_known) (void)hipStreamSynchronize(sp->s->last_stream);
         for (int i = 0; i < sp->n_sub_streams; ++i) { (void)hipStreamSynchronize(sp->sub_stream[i]); (void)hipStreamDestroy(sp->sub_stream[i]); }
         (void)hipEventDestroy(sp->ev_start);
         for (hipEvent_t e : sp->ev_first_sel) (void)hipEventDestroy(e);
@@ -5346,8 +5375,21 @@ static int finish_move_impl(tg_selfplay *sp, int32_t *moves_host, int32_t *finis
     const int max_moves = S * S * 2;                                  // worker.py:44
     std::vector<int> status(T, TG_OK);
     std::vector<int64_t> n_moves(T, 0), n_games(T, 0);
+    if (tail) { sp->g2.resize((size_t)T * 2 * A); sp->g2_base.assign(T, -1); }
     parallel_trees(T, [&](int t) {
         SpGame &g = sp->games[t];
+        if (tail && !g.done && !g.fresh && s->streams[t].seeded) {
+            // the next move's Gumbel noise is -log of the A draws behind the next root's prior, i.e. behind 1..A more draws
+            // than the phases consumed (tail.cursor): every candidate's logarithm now, on the pool, while the device is
+            // busy with the root - at the next call the noise is a copy (the logarithms were 0.09 ms of its critical path)
+            tg::LegacyStream &ls = s->streams[t];
+            const size_t c = (size_t)tail[t].cursor;
+            ls.ensure(c + (size_t)2 * A);
+            const double *e = ls.data() + c;
+            double *g2 = &sp->g2[(size_t)t * 2 * A];
+            for (int i = 0; i < 2 * A; ++i) g2[i] = -std::log(e[i]);
+            sp->g2_base[t] = (int64_t)c;
+        }
         moves_host[t] = -1;
         finished_host[t] = 0;
         if (g.done || (tail && g.fresh)) return;
@@ -5518,6 +5560,7 @@ static int launch_phases_subgroups(tg_selfplay *sp, tg_net *net, int n_phases, i
     TG_HIP(hipEventRecord(sp->phase_all_ev[ring], st));
     sp->phase_all_used[ring] = true;
     s->last_stream = st;
+    s->stream_known = true;
     if ((rc = install_rng(s, st))) return rc;                          // (the first part of the window; the cursors back to 0)
     s->packed_leaves = true;
     TG_HIP(hipEventRecord(sp->ev_start, st));
@@ -5530,7 +5573,8 @@ static int launch_phases_subgroups(tg_selfplay *sp, tg_net *net, int n_phases, i
             const int64_t count = counts[ph][g];
             if (count == 0) continue;
             hipStream_t sg = g == 0 ? st : sp->sub_stream[g - 1];
-            if (launched[g] == 0 && last_started >= 0) TG_HIP(hipStreamWaitEvent(sg, sp->ev_first_sel[last_started], 0));
+            static const bool stagger = getenv("TG_SP_STAGGER") && atoi(getenv("TG_SP_STAGGER")) != 0;   // (measured: no gain at 16 boards, -3 % at 24 - the streams fall out of step by themselves)
+            if (stagger && launched[g] == 0 && last_started >= 0) TG_HIP(hipStreamWaitEvent(sg, sp->ev_first_sel[last_started], 0));
             if (launched[g] == 1 && any_phase) TG_HIP(hipStreamWaitEvent(sg, s->ev_rng[s->rng_active], 0));   // second part of the window
             const SearchDev D = sub_dev(s, tb[g], tb[g + 1] - tb[g]);
             const int32_t *off = row + 2 * (size_t)T + tb[g];
@@ -5585,7 +5629,8 @@ static int play_move_chain(tg_selfplay *sp, tg_net *net, float *planes_dev, floa
     sp->nc.assign(T, 0);
     sp->c_phase.resize(T, 0);
     if (sp->chain_started) {
-        if ((rc = advance_streams_impl(s, sp->consumed.data(), sp->skip_fresh.data()))) return rc;
+        TG_HIP(hipEventSynchronize(s->cur_ev));
+        if ((rc = advance_streams_impl(s, sp->consumed.data(), sp->skip_fresh.data(), s->cur_pin))) return rc;
         for (int t = 0; t < T; ++t) {
             if (sp->skip[t]) continue;
             const int64_t n = sp->consumed[t] - sp->c_phase[t];
@@ -5598,7 +5643,14 @@ static int play_move_chain(tg_selfplay *sp, tg_net *net, float *planes_dev, floa
     sp->nc_known = true;
     sp->nc_cursor = sp->nc;
     lap(0);
-    if ((rc = draw_noise_impl(s, nullptr, sp->skip_fresh.data()))) return rc;
+    {
+        std::vector<const double *> ready(T, nullptr);
+        for (int t = 0; t < T; ++t)
+            if (!sp->skip[t] && (size_t)t < sp->g2_base.size() && sp->g2_base[t] >= 0 && sp->g2_base[t] == sp->c_phase[t])
+                ready[t] = &sp->g2[(size_t)t * 2 * A + sp->nc[t]];
+        if ((rc = draw_noise_impl(s, nullptr, sp->skip_fresh.data(), ready.data()))) return rc;
+        sp->g2_base.assign(T, -1);
+    }
     lap(1);
     // ---- sequential halving (tree.py:375-384) ----
     constexpr int kMaxPhases = tg_selfplay::kMaxPhases;
@@ -5634,7 +5686,10 @@ static int play_move_chain(tg_selfplay *sp, tg_net *net, float *planes_dev, floa
     G = std::max(1, std::min(std::min(G, (int)tg_selfplay::kMaxSub), T));
     if (sp->observer || n_phases == 0) G = 1;
     if (G > 1) {
-        if ((rc = launch_phases_subgroups(sp, net, n_phases, G, planes_dev, policy_dev, value_dev, st, leaves, any_phase))) return rc;
+        tg::net_set_guard_cap(net, 16);                                // (see tg_net::guard_grid_cap)
+        rc = launch_phases_subgroups(sp, net, n_phases, G, planes_dev, policy_dev, value_dev, st, leaves, any_phase);
+        tg::net_set_guard_cap(net, 0);
+        if (rc) return rc;
     }
     for (int ph = 0; ph < n_phases && G == 1; ++ph) {
         const int32_t *nc = &sp->ph_nc[(size_t)ph * T], *mc = &sp->ph_mc[(size_t)ph * T];
@@ -5670,11 +5725,20 @@ static int play_move_chain(tg_selfplay *sp, tg_net *net, float *planes_dev, floa
         sp->state[4 * (size_t)t + 2] = g.moves_played;
     }
     s->last_stream = st;
+    s->stream_known = true;
     if ((rc = launch_finish_roots(s, sp->state.data(), max_moves, st))) return rc;
     if (s->S == 9) hipLaunchKernelGGL(play_kernel<9>, dim3(T), dim3(64), 0, st, s->dev, s->moves_dev);
     else hipLaunchKernelGGL(play_kernel<19>, dim3(T), dim3(64), 0, st, s->dev, s->moves_dev);
     TG_HIP(hipGetLastError());
     if ((rc = tg_search_root_planes(s, planes_dev, stream))) return rc;          // (also uploads the roots of games just started)
+    if (!s->cur_pin) {
+        TG_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->cur_pin), (size_t)T * sizeof(int64_t), hipHostMallocMapped));
+        TG_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&s->cur_pin_dev), s->cur_pin, 0));
+        TG_HIP(hipEventCreateWithFlags(&s->cur_ev, hipEventDisableTiming));
+    }
+    hipLaunchKernelGGL(publish_cursors_kernel, dim3((T + 255) / 256), dim3(256), 0, st, s->dev.rng_cursor, s->cur_pin_dev, T);
+    TG_HIP(hipGetLastError());
+    TG_HIP(hipEventRecord(s->cur_ev, st));                                      // (the host needs the cursors, not the evaluation)
     if ((rc = tg_net_forward_dev(net, planes_dev, T, 1, policy_dev, value_dev, stream))) return rc;
     if ((rc = tg_search_backup(s, policy_dev, value_dev, 1, 1, stream))) return rc;
     lap(4);
