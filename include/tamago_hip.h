@@ -300,7 +300,16 @@ int tg_selfplay_finish_move(tg_selfplay *sp, int32_t *moves_host, int32_t *finis
  * phase with its forward pass, tg_selfplay_finish_move, tg_search_play): nothing but library code runs
  * between the launches.  Caller's device buffers: planes [T*batch_size,6,S,S], policy [T*batch_size,A],
  * value [T*batch_size,3].  finished_host[T] as above; stats_host[3] = {games finished, moves decided, leaf
- * evaluations} of this move (may be NULL). */
+ * evaluations} of this move (may be NULL).
+ * Default scheme ("chained"): the device decides the move itself (final choice, resign rule, game end - the host's
+ * arithmetic, which the host repeats on the same statistics and compares), plays it and expands + evaluates the
+ * next root without the host; the call returns once the root RECORDS have arrived, with that root evaluation still
+ * running, and the next call starts from it.  Consequences a caller sees: the first call of a handle only evaluates
+ * roots (no move, nothing finished); a slot whose game was just started (tg_selfplay_start_game) sits out one call;
+ * below 225 boards the phases run in 2 - 4 sub-groups of boards on streams of the library's own (joined into
+ * `stream` before the call returns control of the buffers).  Games, records and draw order per game are the same in
+ * every scheme.  TG_SP_CHAIN=0: the move decided on the host (three round trips per move); TG_SP_SUBGROUPS=n /
+ * TG_SP_FWD_CAP=n override the grouping.  With an observer the boards stay in one group. */
 int tg_selfplay_play_move(tg_selfplay *sp, tg_net *net, float *planes_dev, float *policy_dev,
                           float *value_dev, void *stream, int32_t *finished_host, int64_t *stats_host);
 /* Audit hook of tg_selfplay_play_move (parity tests replay what the one-call path evaluated into the CPU oracle,

@@ -235,6 +235,7 @@ struct tg_net {
     // needs a CU to itself even to read a clear flag: with several streams sharing the device (self-play sub-groups) a
     // full-size guard launch waits for the other streams' forward passes to drain.  The rare real fallback is slower.
     int guard_grid_cap = 0;
+    int forward_grid_cap = 0;               // > 0: workgroups of a 9x9 split forward launch (CUs left to other streams' tree kernels)
     std::mutex scratch_mu;
     std::map<hipStream_t, float *> scratch_by_stream;
     std::map<hipStream_t, int *> flag_by_stream;      // f16 split kernel: range flag per launch stream

@@ -643,6 +643,7 @@ int launch_wino8(tg_net *net, const float *planes, int batch, int want_logits, f
 
 namespace tg {
 void net_set_guard_cap(tg_net *net, int cap) { if (net) net->guard_grid_cap = cap; }
+void net_set_forward_cap(tg_net *net, int cap) { if (net) net->forward_grid_cap = cap; }
 }  // namespace tg
 
 extern "C" {

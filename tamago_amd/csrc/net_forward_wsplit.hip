@@ -815,7 +815,8 @@ int launch_wsplit(tg_net *net, const float *planes, int batch, int want_logits, 
     if (tg::first_on_device(configured, net->device))
         TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
     const int groups = (batch + G - 1) / G;
-    const int grid = groups < net->num_cus ? groups : net->num_cus;
+    int grid = groups < net->num_cus ? groups : net->num_cus;
+    if (net->forward_grid_cap > 0 && grid > net->forward_grid_cap) grid = net->forward_grid_cap;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTHR), C::LDS_BYTES, stream, net->dev, planes, batch, want_logits,
                        policy, value, overflow);
     TG_HIP(hipGetLastError());

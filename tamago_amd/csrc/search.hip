@@ -33,7 +33,10 @@
 #include "common.h"
 #include "legacy_stream.h"
 
-namespace tg { void net_set_guard_cap(tg_net *net, int cap); }     // net_forward.hip (tg_net::guard_grid_cap)
+namespace tg {                                                        // net_forward.hip (tg_net::guard_grid_cap, forward_grid_cap)
+void net_set_guard_cap(tg_net *net, int cap);
+void net_set_forward_cap(tg_net *net, int cap);
+}
 
 #include <sched.h>
 
@@ -5682,13 +5685,24 @@ static int play_move_chain(tg_selfplay *sp, tg_net *net, float *planes_dev, floa
     // measured (tools/bench_selfplay.py, 400 simulations, leaf evaluations/s, one group -> sub-groups): 4 boards 1.06 -> 1.20 M
     // (2), 8: 1.71 -> 1.86 M (2), 16: 2.49 -> 2.84 M (3), 24: 3.00 -> 3.30 M (4); from 32 boards on a sub-group's forward pass
     // needs every CU or comes in launches too small to be efficient (32 boards: 3.26 M whole, 2.95 M in six)
-    int G = sub_env > 0 ? sub_env : (T < 4 || T > 28 ? 1 : std::max(2, std::min(4, (T + 5) / 6)));
+    // More boards: two halves (29 .. 96 boards) or four quarters (.. 224), the forward launches kept off as many CUs as the
+    // OTHER sub-groups' tree kernels need (a forward workgroup holds its CU for the whole launch - without the cap a
+    // selection waits for it to end, with 8 CUs too few the forward pass waits for the selection): 32 boards 3.33 -> 3.57 M,
+    // 48: 3.82 -> 4.16 M, 64: 4.09 -> 4.50 M, 96: 4.43 -> 4.72 M, 128: 4.62 -> 4.87 M, 192: 4.83 -> 4.97 M; 256: no gain.
+    int G = 1, fwd_cap = 0;
+    if (T >= 4 && T <= 28) G = std::max(2, std::min(4, (T + 5) / 6));
+    else if (T > 28 && T <= 96) { G = 2; fwd_cap = s->num_cus - std::max(32, T / 2); }
+    else if (T > 96 && T <= 224) { G = 4; fwd_cap = s->num_cus - 32; }
+    if (sub_env > 0) { G = sub_env; fwd_cap = 0; }
+    if (getenv("TG_SP_FWD_CAP")) fwd_cap = atoi(getenv("TG_SP_FWD_CAP"));
     G = std::max(1, std::min(std::min(G, (int)tg_selfplay::kMaxSub), T));
     if (sp->observer || n_phases == 0) G = 1;
     if (G > 1) {
         tg::net_set_guard_cap(net, 16);                                // (see tg_net::guard_grid_cap)
+        tg::net_set_forward_cap(net, fwd_cap > 0 ? fwd_cap : 0);
         rc = launch_phases_subgroups(sp, net, n_phases, G, planes_dev, policy_dev, value_dev, st, leaves, any_phase);
         tg::net_set_guard_cap(net, 0);
+        tg::net_set_forward_cap(net, 0);
         if (rc) return rc;
     }
     for (int ph = 0; ph < n_phases && G == 1; ++ph) {

@@ -59,10 +59,10 @@ def selfplay_shard(save_dir: str, network, index_list: Sequence[int], size: int,
     game a single-board worker would play with that seed.
 
     `groups` > 1 splits the boards into that many independent lock-step groups, each with its
-    own engine, HIP stream and host thread (default: 1 below 2048 boards, else 2): while one group's
-    host thread does the per-move bookkeeping (move choice, SGF comment, RNG windows) the GPU
-    runs the other group's phases, and one group's tree kernels overlap the other's forward
-    pass.  Games are independent, so the result does not depend on the grouping.
+    own engine, HIP stream and host thread (default: 1 below 2048 boards, else 2).  Games are
+    independent, so the result does not depend on the grouping.  (Inside ONE group the library
+    already overlaps the boards' tree kernels with each other's forward passes - sub-groups on
+    streams of its own, tg_selfplay_play_move in include/tamago_hip.h - without extra host threads.)
 
     `observer` (audit hook, one group only): called as observer(engine, event) from inside
     tg_selfplay_play_move for every evaluated mini-batch and every decided move
@@ -77,10 +77,9 @@ def selfplay_shard(save_dir: str, network, index_list: Sequence[int], size: int,
     fb0 = network.range_fallbacks() if hasattr(network, "range_fallbacks") else 0
     boards = min(boards, len(todo))
     if groups <= 0:
-        # measured on MI355X (tools/bench_selfplay.py, 400 simulations): with the per-move bookkeeping inside the
-        # library and three host round trips per move, ONE group is best up to 1024 boards (16 boards: 1.71 M
-        # leaf-evals/s vs 1.17 M with two groups; 64: 3.00 vs 2.45 M; 256: 4.04 vs 3.59 M; 1024: 4.67 vs 4.54 M);
-        # at 2048 boards two groups are level (4.75 vs 4.70 M)
+        # measured on MI355X (tools/bench_selfplay.py, 400 simulations): ONE group (one host thread) is best up to
+        # 1024 boards - round 4, chained moves: 16 boards 2.88 M leaf-evals/s vs 1.75 M with two groups, 64: 4.50 vs
+        # 3.33 M; at 2048 boards two groups were level in round 3 (4.75 vs 4.70 M)
         groups = 1 if boards < 2048 else 2
     groups = max(1, min(groups, boards))
     if observer is not None and groups != 1:
@@ -143,10 +142,10 @@ def _run_group(save_dir, network, size, visits, boards, seeds, device_index, nex
                observer=None):
     """One lock-step group of `boards` games on its own engine (and HIP stream, if given).
 
-    Per move the host issues a constant number of library calls, whatever the number of boards: root
-    evaluation, Gumbel noise, tg_selfplay_schedule, one selection + forward + backup per halving
-    phase, tg_selfplay_finish_move (final root choice, resign rule, improved-policy comment, two-pass
-    end + scoring, SGF file - in C++ on host threads), tg_search_play.  Python only starts games."""
+    With the library's own network the whole lock-step move is ONE library call (tg_selfplay_play_move:
+    noise, halving schedule, every phase, the move decided and played on the device, the next root
+    evaluated, records and SGF files on host threads); Python only starts games.  Any other evaluator is
+    driven phase by phase from here (tg_selfplay_schedule / tg_selfplay_finish_move / tg_search_play)."""
     import contextlib
     import ctypes
     import torch

@@ -240,6 +240,13 @@ def test_selfplay_move_schemes_play_the_same_games(tmp_path, monkeypatch):
         assert got[0] == ref[0], name
         assert got[1] == ref[1], name
     assert [open(d / f"{i}.sgf").read() for i in idx[:16]] == ref[1][:16]
+    # 40 boards at a time: two halves with the forward launches kept off 32 CUs (the default from 29 boards on) - the same
+    # games once more, whatever the grouping
+    d = tmp_path / "forty"
+    d.mkdir()
+    stats = selfplay_shard(str(d), net, idx, 9, VISITS, boards=40, never_resign_flags=flags)
+    assert stats == ref[0]
+    assert [open(d / f"{i}.sgf").read() for i in idx] == ref[1]
 
 
 def test_cfg3_one_call_path_16_boards_400_sims_vs_phase_path_and_oracle(tmp_path):
