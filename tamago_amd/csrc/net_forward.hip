@@ -276,17 +276,11 @@ struct WinoCfg {
 template <int S, int G, bool GS = false>
 __global__ __launch_bounds__(512, 2) void dualnet_fwd_wino8_kernel(
     NetDev net, const float *__restrict__ planes, int batch, int want_logits,
-    float *__restrict__ policy, float *__restrict__ value, int *guard) {
+    float *__restrict__ policy, float *__restrict__ value, const int *__restrict__ guard) {
     using C = WinoCfg<S, G, GS>;
     // fallback launch behind the split-operand kernel: runs only if that kernel raised its range flag
-    // guard[0..2] = {range flag, group tickets of the guarded launch, workgroups of THIS launch that are through}: this
-    // launch leaves all three zero for the next pair on the stream (no memset node per forward pass - 7-10 us of every
-    // self-play phase's critical path)
     if (guard != nullptr) {
-        if (__builtin_nontemporal_load(guard) == 0) {
-            if (blockIdx.x == 0 && threadIdx.x == 0) guard[1] = 0;
-            return;
-        }
+        if (__builtin_nontemporal_load(guard) == 0) return;
         if (blockIdx.x == 0 && threadIdx.x == 0 && net.fallbacks) atomicAdd(net.fallbacks, 1ull);
     }
     constexpr int P = C::P, M = C::M, MT = C::MT;
@@ -552,15 +546,6 @@ __global__ __launch_bounds__(512, 2) void dualnet_fwd_wino8_kernel(
         __syncthreads();
         stamp();                                  // 26: heads done
     }
-    if (guard != nullptr && threadIdx.x == 0) {   // (every workgroup has read the flag: the last one through clears it)
-        int *g = guard;
-        __threadfence();
-        if (atomicAdd(g + 2, 1) == (int)gridDim.x - 1) {
-            g[0] = 0;
-            g[1] = 0;
-            g[2] = 0;
-        }
-    }
 }
 
 }  // namespace
@@ -625,7 +610,7 @@ int launch(tg_net *net, const float *planes, int batch, int want_logits, float *
 
 template <int S, int G, bool GS = false>
 int launch_wino8(tg_net *net, const float *planes, int batch, int want_logits, float *policy,
-                 float *value, hipStream_t stream, int *guard = nullptr) {
+                 float *value, hipStream_t stream, const int *guard = nullptr) {
     using C = WinoCfg<S, G, GS>;
     auto kern = dualnet_fwd_wino8_kernel<S, G, GS>;
     static bool attr_set[16] = {};
@@ -962,12 +947,10 @@ int tg_net_forward_dev(tg_net *net, const float *planes_dev, int batch, int want
             {
                 std::lock_guard<std::mutex> lock(net->scratch_mu);
                 int *&slot = net->flag_by_stream[st];
-                if (!slot) {                                          // [range flag, group tickets, guard workgroups through, -]
-                    TG_HIP(hipMalloc(reinterpret_cast<void **>(&slot), 4 * sizeof(int)));
-                    TG_HIP(hipMemsetAsync(slot, 0, 4 * sizeof(int), st));     // once: the guard launch leaves them zero
-                }
+                if (!slot) TG_HIP(hipMalloc(reinterpret_cast<void **>(&slot), 2 * sizeof(int)));   // [range flag, group tickets]
                 flag = slot;
             }
+            TG_HIP(hipMemsetAsync(flag, 0, 2 * sizeof(int), st));
             int rc = tg::split_forward(net, 1, planes_dev, batch, want_logits, policy_dev, value_dev, flag, st);
             if (rc) return rc;
             return launch_wino8<19, 1, true>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st, flag);
@@ -1003,12 +986,14 @@ int tg_net_forward_dev(tg_net *net, const float *planes_dev, int batch, int want
             {
                 std::lock_guard<std::mutex> lock(net->scratch_mu);
                 int *&slot = net->flag_by_stream[st];
-                if (!slot) {                                          // [range flag, group tickets, guard workgroups through, -]
-                    TG_HIP(hipMalloc(reinterpret_cast<void **>(&slot), 4 * sizeof(int)));
-                    TG_HIP(hipMemsetAsync(slot, 0, 4 * sizeof(int), st));     // once: the guard launch leaves them zero
-                }
+                if (!slot) TG_HIP(hipMalloc(reinterpret_cast<void **>(&slot), 2 * sizeof(int)));   // [range flag, group tickets]
                 flag = slot;
             }
+            // (This memset node stays.  Twice - a ring of flags in round 3, the guard launch zeroing the words itself in
+            // round 4 - the launch went without it, and twice the 2 048-tree bench lost 20 % (5.85 -> 4.60 M leaf-evals/s):
+            // the next mini-batch's 344 MB random window, uploaded on the copy stream, is no longer hidden under the
+            // forward pass.  Self-play gained 1 % from its removal.)
+            TG_HIP(hipMemsetAsync(flag, 0, 2 * sizeof(int), st));
             int rc = pick_wsplit(9)
                          ? tg::wsplit_forward(net, group, planes_dev, batch, want_logits, policy_dev, value_dev, flag, st)
                          : (pick_w2(9, batch, net->num_cus)
