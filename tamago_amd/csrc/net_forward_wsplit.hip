@@ -374,15 +374,10 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_wsplit_kernel(
     const float sgn = wave == 1 ? 1.f : -1.f;                  // row pass of point row w: d[ra] + sgn d[rb]
     const int *const tin_w = net.ws_tin[GI] + (size_t)wave * NRT * 64 * 8;
     const int *const tout_w = net.ws_tout[GI] + (size_t)wave * NRT * 64 * 8;
-    // LDS address tables of the row tile about to be processed (carried across layers: the geometry repeats)
-    i32x4v ta = *reinterpret_cast<const i32x4v *>(tin_w + (size_t)lane * 8);
-    i32x4v tb = *reinterpret_cast<const i32x4v *>(tin_w + (size_t)lane * 8 + 4);
-    i32x4v to = *reinterpret_cast<const i32x4v *>(tout_w + (size_t)lane * 8);          // store / residual tables: see body
-    i32x4v tr = *reinterpret_cast<const i32x4v *>(tout_w + (size_t)lane * 8 + 4);
-    i32x4v to2 = to, tr2 = tr;
-    i32x4v ta1 = *reinterpret_cast<const i32x4v *>(tin_w + ((size_t)64 + lane) * 8);      // row tile 1's (see body)
-    i32x4v tb1 = *reinterpret_cast<const i32x4v *>(tin_w + ((size_t)64 + lane) * 8 + 4);
-    asm volatile("" :: "v"(ta), "v"(tb), "v"(to), "v"(tr), "v"(ta1), "v"(tb1));   // waited for here, before the weight requests below
+    // LDS address tables of the row tile about to be processed (carried across layers: the geometry repeats; fetched per
+    // group behind the stem - kept alive through stem and heads they cost 16 spilled registers, and the scratch lines, 125 us
+    // apart, came back from HBM: 3.6 KB per position of fabric traffic for nothing)
+    i32x4v ta, tb, to, tr, to2, tr2, ta1, tb1;
     // This wave's 64 weight fragments of a layer, [j 4][kc 2][piece 2][ct 4]: resident in the accumulation half of the
     // register file for the whole layer (MFMA A operands are read from there directly).  They are requested by inline
     // asm with AGPR destinations - left to the register allocator they end up in VGPRs, spilled to AGPRs and copied back
@@ -765,12 +760,26 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_wsplit_kernel(
         using IX = std::integral_constant<int, C::X_OFF>;
         using IH = std::integral_constant<int, C::H_OFF>;
         if (!(amax < (float)kWsRangeLimit)) ovf = 1;
+        ta = *reinterpret_cast<const i32x4v *>(tin_w + (size_t)lane * 8);
+        tb = *reinterpret_cast<const i32x4v *>(tin_w + (size_t)lane * 8 + 4);
+        to = *reinterpret_cast<const i32x4v *>(tout_w + (size_t)lane * 8);            // store / residual tables: see body
+        tr = *reinterpret_cast<const i32x4v *>(tout_w + (size_t)lane * 8 + 4);
+        ta1 = *reinterpret_cast<const i32x4v *>(tin_w + ((size_t)64 + lane) * 8);     // row tile 1's (see body)
+        tb1 = *reinterpret_cast<const i32x4v *>(tin_w + ((size_t)64 + lane) * 8 + 4);
+        asm volatile("" :: "v"(ta), "v"(tb), "v"(to), "v"(tr), "v"(ta1), "v"(tb1));  // waited for here (layer 0's weight requests, in flight, are needed now anyway)
+        to2 = to;
+        tr2 = tr;
         if constexpr (DEFER) {
             // layer 0 has no previous layer: its first row tile carries a NULL epilogue - zero exchange, zero constants,
             // every store to the dump row, every residual read from the zero row (cheaper than a third copy of the layer code)
-            for (int e = tid; e < C::EX_BYTES / 16; e += NTHR) reinterpret_cast<uint4 *>(smem + C::EX_OFF)[e] = uint4{0u, 0u, 0u, 0u};
-            pshf = f32x4{0.f, 0.f, 0.f, 0.f};
+            {
+                // (zeros made HERE: hipcc hoists a constant vector out of the group loop and, short of registers, spills it)
+                float z0, z1, z2, z3;
+                asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0" : "=v"(z0), "=v"(z1), "=v"(z2), "=v"(z3));
+                pshf = f32x4{z0, z1, z2, z3};
+            }
             pdown = 0.f;
+            for (int e = tid; e < C::EX_BYTES / 16; e += NTHR) reinterpret_cast<f32x4 *>(smem + C::EX_OFF)[e] = pshf;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 to2[q] = C::DUMP_REL + (lane * 16) % 256;
