@@ -58,6 +58,8 @@ struct NetDev {
     // [ct 4][lane 64][8 x f16] (batch-norm scale folded in, x 2^e, low pieces unscaled), folded shift [12][64], 2^-e [12];
     // LDS address tables of the workgroup shapes G = 1 / G = 3: patch cells [wave 4][row tile][lane 64][8], epilogue
     // (store [0..3] / residual [4..7]) [wave 4][row tile][lane 64][8]
+    const unsigned char *w1_w;        // dualnet_fwd_w1d_kernel: [layer 12][point 4][tap 3][kc 2][piece 2][ct 4][lane 64][16 B]
+    const float *w1_down;             // ... and 2^-e per layer (shift: ws_shift)
     const unsigned char *ws_w;
     const float *ws_shift;
     const float *ws_down;

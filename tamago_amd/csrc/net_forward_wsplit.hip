@@ -80,6 +80,16 @@ __host__ __device__ inline int ws_swz(int R) {
     return (g & 1) | ((g & 6) << 1);
 }
 
+// ... and of the kernel that transforms along x only (dualnet_fwd_w1d_kernel): its sixteen MFMA columns are the units
+// u = 5 board + t (outputs x = 2t, 2t + 1 of ONE board row); a unit's cells x = 2t - 1 .. 2t + 2 have (x + 1) / 2 = t or t + 1,
+// so g = (5 board + (x + 1) / 2) mod 8 is distinct over the eight units of either half of a ds_read_b128 cycle
+__host__ __device__ inline int w1_swz(int R) {
+    const int b = R >= 162 ? 2 : (R >= 81 ? 1 : 0);
+    const int p = R - 81 * b, y = (p * 57) >> 9, x = p - 9 * y;
+    const int g = (5 * b + ((x + 1) >> 1)) & 7;
+    return (g & 1) | ((g & 6) << 1);
+}
+
 // LDS accesses by ABSOLUTE LDS byte address (the kernel has no static LDS: the dynamic array starts at 0, checked at
 // kernel start).  Through `smem + addr` every access costs a v_add_u32 with the array's (relocatable) base.
 typedef __attribute__((address_space(3))) f32x4 lds_f32x4_t;
@@ -158,9 +168,24 @@ __device__ __forceinline__ void ws_load_w_point(i32x4v (&ua)[4][2][2][4], const 
     }
 }
 
+// dualnet_fwd_w1d_kernel: fragment F = 8 kc + 4 piece + ct of a tap block ([kc 2][piece 2][ct 4][lane][16 B]) into AGPR slot SLOT
+template <int SLOT, int F>
+__device__ __forceinline__ void w1_request(i32x4v (&ua)[4][2][2][4], const unsigned char *tapbase, int wlane, std::integral_constant<int, F>) {
+    constexpr int kc = F >> 3, p = (F >> 2) & 1, ct = F & 3;
+    const unsigned char *base = tapbase + kc * 8192 + p * 4096;
+    if constexpr (ct == 0) asm volatile("global_load_dwordx4 %0, %1, %2" : "=a"(ua[SLOT][kc][p][0]) : "v"(wlane), "s"(base) : "memory");
+    else if constexpr (ct == 1) asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=a"(ua[SLOT][kc][p][1]) : "v"(wlane), "s"(base) : "memory");
+    else if constexpr (ct == 2) asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=a"(ua[SLOT][kc][p][2]) : "v"(wlane), "s"(base) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=a"(ua[SLOT][kc][p][3]) : "v"(wlane), "s"(base) : "memory");
+}
+template <int SLOT>
+__device__ __forceinline__ void w1_request_tap(i32x4v (&ua)[4][2][2][4], const unsigned char *tapbase, int wlane) {
+    static_for<16>([&](auto F_) { w1_request<SLOT>(ua, tapbase, wlane, F_); });
+}
+
 // Heads on the 16-bit matrix pipe (split_common.h: run_heads_mfma), reading the block output from the fp32 image X:
 // a B fragment (position li of a 16-row tile, channels 32 kc + 8 lg ..) is two 16-byte reads + the operand split.
-template <int G, typename C>
+template <int G, typename C, int SWZ = 0>
 __device__ __forceinline__ void run_heads_x32(unsigned char *smem, const NetDev &net, int b0, int batch, int want_logits,
                                               float *__restrict__ policy, float *__restrict__ value, int tid, int wave,
                                               long long *tl) {
@@ -201,7 +226,7 @@ __device__ __forceinline__ void run_heads_x32(unsigned char *smem, const NetDev 
         const int t = wave + q * NW;
         const int row = (t < C::MT ? t : wave) * 16 + li;
         const int rr = row < M ? row : M + 1;              // zero row
-        const int sw = row < M ? ws_swz(row) : 0;
+        const int sw = row < M ? (SWZ ? w1_swz(row) : ws_swz(row)) : 0;
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc) {
             const int a0 = C::X_OFF + rr * 256 + (((kc * 8 + lg * 2) ^ sw) << 4);
@@ -813,6 +838,344 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_wsplit_kernel(
     if (ovf && overflow) atomicOr(overflow, 1);
 }
 
+// The 9x9 tower as Winograd F(2,3) along x only (TG_FWD_ALGO=w1d): 2-D Winograd (above) issues the fewest MFMAs but 5.3 VALU
+// instructions beside each and is bound by instruction issue; the direct kernel needs no transform and is bound by the matrix
+// pipe.  One transformed axis sits between: 600 MFMAs per wave and layer for three boards (2-D: 480, direct: 857), one
+// transform pass per side - 1.4 VALU instructions per MFMA, inside what an MFMA's 16 cycles hide.  Three boards per workgroup
+// only (smaller launches take dualnet_fwd_wsplit_kernel<1>).  Stem, heads, operand pieces, range guard: as above.
+// PROF: s_memtime stamps of workgroup 0 / wave 0: [0] group start, [1] input staged, [2] stem done, [3..14] layer done, [15] heads
+template <int G, bool PROF>
+__global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
+    NetDev net, const float *__restrict__ planes, int batch, int want_logits,
+    float *__restrict__ policy, float *__restrict__ value, int *__restrict__ overflow) {
+    using C = WsCfg<G>;
+    using F = FmtF16;
+    constexpr int P = C::P, M = C::M, NTHR = C::NTHR, NRT = C::NRT, RTW = C::RTW, IMG = C::IMG;
+    constexpr int GI = G == 3 ? 1 : 0;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, li = lane & 15, lg = lane >> 4;
+
+    if (static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) unsigned char *)smem)) != 0u)
+        __builtin_trap();                                      // absolute LDS addressing below
+    // ---- once per workgroup: zero + dump rows, head tables ----
+    for (int e = tid; e < 2 * 2 * 64; e += NTHR) {             // rows M, M + 1 of X and H
+        const int buf = e >> 7, r = (e >> 6) & 1, c = e & 63;
+        reinterpret_cast<float *>(smem + buf * C::BUF + (M + r) * 256)[c] = 0.f;
+    }
+    for (int e = tid; e < C::A; e += NTHR) reinterpret_cast<float *>(smem + C::HB_OFF)[e] = net.pfc_b[e];
+    for (int e = tid; e < 3 * P + 3; e += NTHR)
+        reinterpret_cast<float *>(smem + C::VW_OFF)[e] = e < 3 * P ? net.vfc_w[e] : net.vfc_b[e - 3 * P];
+    stage_head_tables<C, NTHR>(smem, net, tid);
+
+    int stamp_i = 0;
+    auto stamp = [&]() {
+        if constexpr (PROF)
+            if (blockIdx.x == 0 && tid == 0 && stamp_i < 40) net.timeline[stamp_i++] = (long long)__builtin_amdgcn_s_memtime();
+    };
+    int ovf = 0;
+    const int n_groups = (batch + G - 1) / G;
+    constexpr int NPL = (G * 6 * P + NTHR - 1) / NTHR;
+    float pre[NPL];
+    auto fetch_planes = [&](int grp2) __attribute__((always_inline)) {
+        int ft = tid;
+        asm volatile("" : "+v"(ft));
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            const int e = ft + i * NTHR;
+            const int b = grp2 * G + e / (6 * P);
+            pre[i] = (e < G * 6 * P && grp2 < n_groups && b < batch)
+                         ? __builtin_nontemporal_load(&planes[(size_t)grp2 * G * 6 * P + e]) : 0.f;
+        }
+    };
+    fetch_planes(blockIdx.x);
+    const float sgn = wave == 1 ? 1.f : -1.f;                  // row pass of point row w: d[ra] + sgn d[rb]
+    static_assert(G == 3, "dualnet_fwd_w1d_kernel: three boards per workgroup");
+    // This wave's weight fragments of a layer, [slot 4][kc 2][piece 2][ct 4]: slots 0 / 2 = taps ky 0 / 2, slots 1 and 3 take
+    // tap 1 of even / odd layers in turn (the spare one is filled for the next layer while this one runs).  AGPRs, requested
+    // by inline asm (see the kernel above): explicit waits, in-order returns.
+    i32x4v ua[4][2][2][4];
+    const int wlane = lane * 16;
+    {
+        const unsigned char *w0 = net.w1_w + (size_t)wave * 49152;
+        w1_request_tap<1>(ua, w0 + 16384, wlane);
+        w1_request_tap<2>(ua, w0 + 2 * 16384, wlane);
+        w1_request_tap<0>(ua, w0, wlane);
+    }
+
+    // Groups beyond a workgroup's first are handed out by a ticket counter (overflow[1], zeroed with the range flag): a
+    // workgroup that starts late - its CU was running another stream's tree kernel - takes fewer groups instead of
+    // holding the launch up with a full static share.  The ticket travels through a spare word of the bias table.
+    int *const ticket_lds = reinterpret_cast<int *>(smem + C::HB_OFF + 83 * 4);
+    for (int grp = blockIdx.x; grp < n_groups;) {
+        const int b0 = grp * G;
+        if (tid == 0) *ticket_lds = overflow ? (int)gridDim.x + atomicAdd(overflow + 1, 1) : grp + (int)gridDim.x;
+        stamp();
+        // ================= stem: planes -> im2col'ed f16-pair images (K = 9 taps x 6 planes, padded to 64) =================
+        // (its 16 weight fragments are requested first: their L2 round trip runs under the staging pass)
+        i32x4v fa[2][2][4];                                      // [kc][piece][ct]
+        {
+            int wvg = lane * 16;
+            asm volatile("" : "+v"(wvg));
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        gmem_load_frag(fa[kc][p][c], net.wsplit + (size_t)kc * 8192, wvg + (p * 4 + c) * 1024);
+        }
+        {
+            float *st = reinterpret_cast<float *>(smem + C::STAGE);
+            int stid = tid;
+            asm volatile("" : "+v"(stid));
+#pragma unroll
+            for (int i = 0; i < NPL; ++i)
+                if (stid + i * NTHR < G * 6 * P) st[stid + i * NTHR] = pre[i];
+            for (int e = stid; e < 4 * 64; e += NTHR)           // zero blocks of the four images
+                reinterpret_cast<unsigned *>(smem + C::SI_OFF + (e >> 6) * IMG + C::ZOFF)[e & 63] = 0u;
+            __syncthreads();
+            for (int row = stid; row < M; row += NTHR) {
+                const int bl = row / P, p = row - bl * P, y = p / 9, x = p - y * 9;
+                const float *src = st + bl * 6 * P + p;
+                const int swz = (row >> 1) & 3;
+#pragma unroll
+                for (int sl = 0; sl < 8; ++sl) {
+                    f32x4 lo, hi;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int k = sl * 8 + j, t = k / 6, c = k - t * 6;
+                        const int dy = t / 3 - 1, dx = t % 3 - 1;
+                        const bool ok = k < 54 && (unsigned)(y + dy) < 9u && (unsigned)(x + dx) < 9u;
+                        const float v = ok ? src[c * P + dy * 9 + dx] : 0.f;
+                        if (j < 4) lo[j] = v; else hi[j - 4] = v;
+                    }
+                    uint2 plo[2], phi[2];
+                    split4<F>(lo, plo);
+                    split4<F>(hi, phi);
+                    const int kc = sl >> 2, slot = (sl & 3) ^ swz;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        *reinterpret_cast<uint4 *>(smem + C::SI_OFF + (q * 2 + kc) * IMG + row * 64 + slot * 16) =
+                            uint4{plo[q].x, plo[q].y, phi[q].x, phi[q].y};
+                }
+            }
+        }
+        __syncthreads();
+        stamp();
+        float amax = 0.f;
+        {
+            // stem product: 2 k-chunks x 4 channel tiles x RTW row tiles x 3 f16 products (two accumulator sets, scaled
+            // low pieces: the direct split kernel's image and weights), batch norm, ReLU -> X (fp32, swizzled)
+#pragma unroll
+            for (int r = 0; r < RTW; ++r) {
+                int row = (wave * RTW + r) * 16 + li;
+                asm volatile("" : "+v"(row));
+                const int nat = row * 64 + ((lg ^ ((row >> 1) & 3)) << 4);
+                const int addr = C::SI_OFF + (row < M ? nat : C::ZOFF + (nat & 255));
+                i32x4v fb[2][2];                                 // [piece][kc]
+                lds_load_frag<0 * IMG>(fb[0][0], smem, addr);
+                lds_load_frag<1 * IMG>(fb[0][1], smem, addr);
+                lds_load_frag<2 * IMG>(fb[1][0], smem, addr);
+                lds_load_frag<3 * IMG>(fb[1][1], smem, addr);
+                const int orow = row < M ? row : M;
+                const int osw = row < M ? w1_swz(row) : 0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+#pragma unroll
+                    for (int kc = 0; kc < 2; ++kc) {
+                        a0 = mfma16<F>(fa[kc][0][c], fb[0][kc], a0);
+                        a1 = mfma16<F>(fa[kc][1][c], fb[0][kc], a1);
+                        a1 = mfma16<F>(fa[kc][0][c], fb[1][kc], a1);
+                    }
+                    const f32x4 sc = *reinterpret_cast<const f32x4 *>(net.sscale + c * 16 + lg * 4);
+                    const f32x4 sh = *reinterpret_cast<const f32x4 *>(net.shift + c * 16 + lg * 4);
+                    f32x4 v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float t = fmaf(a1[j], 1.f / 2048.f, a0[j]);
+                        t = fmaf(t, sc[j], sh[j]);
+                        v[j] = fmaxf(t, 0.f);
+                    }
+                    amax = fmaxf(fmaxf(amax, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+                    *reinterpret_cast<f32x4 *>(smem + C::X_OFF + orow * 256 + (((c * 4 + lg) ^ osw) << 4)) = v;
+                }
+            }
+        }
+        __syncthreads();                                        // X complete; the overlay is free again
+        if (tid < 64) reinterpret_cast<float *>(smem + C::H_OFF + (M + 1) * 256)[tid] = 0.f;   // H's zero row was under it
+        stamp();
+
+        // ================= tower: 12 layers, Winograd F(2,3) along x, the three taps along y direct =================
+        // Output row y of all three boards is one MFMA column set (unit u = 5 board + t: outputs (y, 2t), (y, 2t + 1)); wave w
+        // owns transform point w: its V_w rows (f16 hi / lo pieces, 16 registers a row) live in registers and serve three
+        // output rows each - tap ky of row y multiplies V_w[y + ky - 1] -, its 48 weight fragments of the layer in AGPRs.
+        // M_w goes through the LDS exchange; wave w' finishes output channels [16 w', 16 w' + 16): out0 = m0 + m1 + m2,
+        // out1 = m1 - m2 - m3, shift, residual, ReLU.  Everything but the MFMAs of row y rides along them: exchange + epilogue
+        // of row y - 1, input transform of row y + 2, cell reads of row y + 3, weight requests of the next layer.
+        // ---- per-lane geometry: MFMA column u = 5 board + t (15 = padding), k-group lg; wave = transform point
+        // (per group, behind the stem: kept alive through stem and heads these twelve registers spill) ----
+        const int ub = li / 5, ut = li - 5 * ub;
+        const bool uv = li < 15;
+        // the two cells of point `wave`: V = d[xa] + sgn d[xb]
+        const int xa = wave == 0 ? 2 * ut - 1 : (wave == 2 ? 2 * ut + 1 : 2 * ut);
+        const int xb = wave == 0 ? 2 * ut + 1 : (wave == 1 ? 2 * ut + 1 : (wave == 2 ? 2 * ut : 2 * ut + 2));
+        auto cell = [&](int x, int chunk, int invalid_rel, int &adr, int &str) {
+            const bool ok = uv && x >= 0 && x < 9;
+            const int R0 = 81 * ub + (ok ? x : 0);
+            adr = ok ? R0 * 256 + ((chunk ^ w1_swz(R0)) << 4) : invalid_rel + (chunk << 4);
+            str = ok ? 9 * 256 : 0;
+        };
+        int adrA, strA, adrB, strB, adrO0, strO0, adrO1, strO1, adrR0, adrR1, strR0, strR1;
+        cell(xa, lg * 2, C::ZERO_REL, adrA, strA);
+        cell(xb, lg * 2, C::ZERO_REL, adrB, strB);
+        cell(2 * ut, wave * 4 + lg, C::DUMP_REL, adrO0, strO0);        // stores of the channels 16 wave + 4 lg ..
+        cell(2 * ut + 1, wave * 4 + lg, C::DUMP_REL, adrO1, strO1);
+        cell(2 * ut, wave * 4 + lg, C::ZERO_REL, adrR0, strR0);        // residual reads (outside the board: zeros)
+        cell(2 * ut + 1, wave * 4 + lg, C::ZERO_REL, adrR1, strR1);
+        f32x4 dq[2][2][2];                                     // cells read ahead: [cell a / b][kc][channel half]
+        i32x4v vh[5][2], vl[5][2];                             // V rows: slot 4 = row 0, slot r & 3 = rows 1 .. 8; [kc]
+        f32x4 acc[2][4];                                       // [row parity][channel tile]
+        f32x4 ez[4], eres[2], ev[2];
+        float tvv[4];
+        unsigned thh[2];
+        int curA = 0, curB = 0, curO0 = 0, curO1 = 0, curR0 = 0, curR1 = 0;
+        auto vslot = [](int r) constexpr { return r == 0 ? 4 : (r & 3); };
+        auto rd = [&](auto IN_, auto I_) __attribute__((always_inline)) {          // one of the eight cell reads of the row at curA / curB
+            constexpr int IN = decltype(IN_)::value, i = decltype(I_)::value, cb = i >> 2, kc = (i >> 1) & 1, h = i & 1;
+            const int a0 = (cb ? curB : curA) ^ ((kc << 7) | (h << 4));
+            dq[cb][kc][h] = lds_f32x4_at<IN>(a0);
+            if constexpr (i == 7) { curA += strA; curB += strB; }
+        };
+        // input transform of one row in 16 slices: per (kc, half) t = d_a + sgn d_b (2 x 2 values), high pieces, low pieces
+        auto tr = [&](auto R_, auto I_) __attribute__((always_inline)) {
+            constexpr int r = decltype(R_)::value, i = decltype(I_)::value, kc = i >> 3, h = (i >> 2) & 1, q = i & 3, s = vslot(r);
+            if constexpr (q == 0) {
+                tvv[0] = fmaf(dq[1][kc][h][0], sgn, dq[0][kc][h][0]);
+                tvv[1] = fmaf(dq[1][kc][h][1], sgn, dq[0][kc][h][1]);
+            } else if constexpr (q == 1) {
+                tvv[2] = fmaf(dq[1][kc][h][2], sgn, dq[0][kc][h][2]);
+                tvv[3] = fmaf(dq[1][kc][h][3], sgn, dq[0][kc][h][3]);
+            } else if constexpr (q == 2) {
+                thh[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{tvv[0], tvv[1]}, f16x2));
+                vh[s][kc][2 * h] = (int)thh[0];
+                vl[s][kc][2 * h] = (int)low_pieces(tvv[0], tvv[1], thh[0]);
+            } else {
+                thh[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{tvv[2], tvv[3]}, f16x2));
+                vh[s][kc][2 * h + 1] = (int)thh[1];
+                vl[s][kc][2 * h + 1] = (int)low_pieces(tvv[2], tvv[3], thh[1]);
+            }
+        };
+        int ovf_layer = 0;
+        auto layer_fn = [&](auto IN_, auto OUT_, auto RES_, int layer) __attribute__((always_inline)) {
+            constexpr int IN = decltype(IN_)::value, OUT = decltype(OUT_)::value;
+            constexpr bool RES = decltype(RES_)::value;
+            constexpr int PAR = RES ? 1 : 0;                   // conv2 of a block = odd layer
+            constexpr int S1 = PAR ? 3 : 1, S1N = PAR ? 1 : 3; // AGPR slot of tap ky = 1 in this / the next layer (taps 0, 2: slots 0, 2)
+            const int next_layer = layer + 1 < kTowerLayers ? layer + 1 : 0;
+            const unsigned char *wnext = net.w1_w + ((size_t)next_layer * 4 + wave) * 49152;
+            const f32x4 shf = *reinterpret_cast<const f32x4 *>(net.ws_shift + layer * 64 + wave * 16 + lg * 4);
+            const float down = net.w1_down[layer];
+            int exw = C::EX_OFF + wave * 4096 + lane * 16, exr = C::EX_OFF + wave * 1024 + lane * 16;
+            asm volatile("" : "+v"(exw), "+v"(exr));
+            curA = adrA; curB = adrB; curO0 = adrO0; curO1 = adrO1; curR0 = adrR0; curR1 = adrR1;
+            // prologue: V rows 0 and 1, the cells of row 2 on their way
+            static_for<8>([&](auto I_) { rd(IN_, I_); });
+            static_for<16>([&](auto I_) { tr(std::integral_constant<int, 0>{}, I_); });
+            static_for<8>([&](auto I_) { rd(IN_, I_); });
+            static_for<16>([&](auto I_) { tr(std::integral_constant<int, 1>{}, I_); });
+            static_for<8>([&](auto I_) { rd(IN_, I_); });
+            // this layer's taps 1 and 2 must have arrived (requested in that order; behind them: tap 0's 16 requests, the shift)
+            asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+            // exchange + epilogue of row Y (output cells at curO0 / curO1), in slices 0 .. 26
+            auto epi = [&](auto Y_, auto I_) __attribute__((always_inline)) {
+                constexpr int y = decltype(Y_)::value, i = decltype(I_)::value, par = (y + PAR) & 1;
+                if constexpr (i < 4) {
+                    lds_f32x4_put<par * 16384 + i * 1024>(exw, acc[par][i]);
+                } else if constexpr (i == 5) {
+                    __syncthreads();
+                } else if constexpr (i == 6 || i == 7) {
+                    ez[2 * (i - 6)] = lds_f32x4_at<par * 16384 + (2 * (i - 6)) * 4096>(exr);
+                    ez[2 * (i - 6) + 1] = lds_f32x4_at<par * 16384 + (2 * (i - 6) + 1) * 4096>(exr);
+                } else if constexpr (i == 8) {
+                    if constexpr (RES) { eres[0] = lds_f32x4_at<OUT>(curR0); eres[1] = lds_f32x4_at<OUT>(curR1); curR0 += strR0; curR1 += strR1; }
+                } else if constexpr (i >= 9 && i < 25) {
+                    constexpr int k = i - 9, cc = k >> 3, e = (k >> 1) & 3, part = k & 1;
+                    if constexpr (part == 0) {
+                        ev[cc][e] = cc == 0 ? (ez[0][e] + ez[1][e]) + ez[2][e] : (ez[1][e] - ez[2][e]) - ez[3][e];
+                    } else {
+                        float tt = fmaf(ev[cc][e], down, shf[e]);
+                        if constexpr (RES) tt += eres[cc][e];
+                        ev[cc][e] = fmaxf(tt, 0.f);
+                    }
+                } else if constexpr (i == 25) {
+                    amax = fmaxf(fmaxf(amax, ev[0][0]), ev[0][1]);
+                    amax = fmaxf(fmaxf(amax, ev[0][2]), ev[0][3]);
+                    lds_f32x4_put<OUT>(curO0, ev[0]);
+                    curO0 += strO0;
+                } else if constexpr (i == 26) {
+                    amax = fmaxf(fmaxf(amax, ev[1][0]), ev[1][1]);
+                    amax = fmaxf(fmaxf(amax, ev[1][2]), ev[1][3]);
+                    lds_f32x4_put<OUT>(curO1, ev[1]);
+                    curO1 += strO1;
+                }
+            };
+            static_for<9>([&](auto Y_) {
+                constexpr int y = decltype(Y_)::value, par = (y + PAR) & 1;
+                constexpr int NT = (y == 0 || y == 8) ? 2 : 3, NM = 24 * NT, KY0 = y == 0 ? 1 : 0;
+                if constexpr (y == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // tap 0 (and the shift)
+                static_for<NM>([&](auto M_) {
+                    constexpr int m = decltype(M_)::value, ti = m / 24, q = m % 24, kc = q / 12, st = (q / 4) % 3, c = q % 4;
+                    constexpr int ky = KY0 + ti, r = y + ky - 1, s = vslot(r), slot = ky == 1 ? S1 : ky;
+                    if constexpr (st == 0)
+                        acc[par][c] = mfma16<F>(ua[slot][kc][1][c], vh[s][kc], m < 4 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[par][c]);
+                    else if constexpr (st == 1) acc[par][c] = mfma16<F>(ua[slot][kc][0][c], vl[s][kc], acc[par][c]);
+                    else acc[par][c] = mfma16<F>(ua[slot][kc][0][c], vh[s][kc], acc[par][c]);
+                    // ---- what rides along ----
+                    constexpr int E0 = y >= 1 ? 27 : 0;                                  // first slice behind the previous row's epilogue
+                    if constexpr (y >= 1 && m < 27) epi(std::integral_constant<int, y - 1>{}, M_);
+                    if constexpr (y + 2 <= 8 && m >= E0 && m < E0 + 16) tr(std::integral_constant<int, y + 2>{}, std::integral_constant<int, m - E0>{});
+                    if constexpr (y + 3 <= 8 && m >= E0 + 16 && m < E0 + 24) rd(IN_, std::integral_constant<int, m - E0 - 16>{});
+                    // next layer's weights: tap 1 into the spare slot during rows 4 .. 6, tap 2 at the start of row 8 (its last use
+                    // was row 7), tap 0 behind row 8's tap-0 MFMAs
+                    if constexpr (y >= 4 && y <= 6 && m >= 52 && m < 70 && (m - 52) % 3 == 0) {
+                        constexpr int f = (y - 4) * 6 + (m - 52) / 3;                      // 0 .. 17
+                        if constexpr (f < 16) w1_request<S1N>(ua, wnext + 16384, wlane, std::integral_constant<int, f>{});
+                    }
+                    if constexpr (y == 8 && m < 32 && m % 2 == 1)
+                        w1_request<2>(ua, wnext + 2 * 16384, wlane, std::integral_constant<int, m / 2>{});
+                    if constexpr (y == 8 && m >= 32) w1_request<0>(ua, wnext, wlane, std::integral_constant<int, m - 32>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            });
+            // row 8's exchange + epilogue on their own
+            static_for<27>([&](auto I_) { epi(std::integral_constant<int, 8>{}, I_); });
+            if (!(amax < (float)kWsRangeLimit)) ovf = 1;            // f16 range guard (also catches NaN)
+            __syncthreads();
+            stamp();
+        };
+        using IX = std::integral_constant<int, C::X_OFF>;
+        using IH = std::integral_constant<int, C::H_OFF>;
+        if (!(amax < (float)kWsRangeLimit)) ovf = 1;
+#pragma unroll 1
+        for (int blk = 0; blk < kBlocks; ++blk) {
+            layer_fn(IX{}, IH{}, std::false_type{}, 2 * blk);
+            layer_fn(IH{}, IX{}, std::true_type{}, 2 * blk + 1);
+        }
+        // next group's input planes: requested here, consumed after the heads
+        const int next = __builtin_amdgcn_readfirstlane(*ticket_lds);   // (written before the stem's barriers)
+        fetch_planes(next);
+        run_heads_x32<G, C, 1>(smem, net, b0, batch, want_logits, policy, value, tid, wave, nullptr);
+        __syncthreads();
+        stamp();
+        grp = next;
+    }
+    if (ovf && overflow) atomicOr(overflow, 1);
+}
+
 template <int G, bool PROF = false>
 int launch_wsplit(tg_net *net, const float *planes, int batch, int want_logits, float *policy, float *value,
                   int *overflow, hipStream_t stream) {
@@ -824,6 +1187,25 @@ int launch_wsplit(tg_net *net, const float *planes, int batch, int want_logits, 
     if (tg::first_on_device(configured, net->device))
         TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
     const int groups = (batch + G - 1) / G;
+    int grid = groups < net->num_cus ? groups : net->num_cus;
+    if (net->forward_grid_cap > 0 && grid > net->forward_grid_cap) grid = net->forward_grid_cap;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTHR), C::LDS_BYTES, stream, net->dev, planes, batch, want_logits,
+                       policy, value, overflow);
+    TG_HIP(hipGetLastError());
+    return TG_OK;
+}
+
+template <bool PROF = false>
+int launch_w1d(tg_net *net, const float *planes, int batch, int want_logits, float *policy, float *value,
+               int *overflow, hipStream_t stream) {
+    using C = WsCfg<3>;
+    if (!PROF && net->dev.timeline)
+        return launch_w1d<true>(net, planes, batch, want_logits, policy, value, overflow, stream);
+    auto kern = dualnet_fwd_w1d_kernel<3, PROF>;
+    static std::atomic<uint64_t> configured{0};
+    if (tg::first_on_device(configured, net->device))
+        TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+    const int groups = (batch + 2) / 3;
     int grid = groups < net->num_cus ? groups : net->num_cus;
     if (net->forward_grid_cap > 0 && grid > net->forward_grid_cap) grid = net->forward_grid_cap;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTHR), C::LDS_BYTES, stream, net->dev, planes, batch, want_logits,
@@ -973,6 +1355,74 @@ int wsplit_prepare(tg_net *net, const float *const *tower, const float *scale, c
         (rc = up(tout3.data(), tout3.size() * 4, reinterpret_cast<const void **>(&net->dev.ws_tout[1]))))
         return rc;
     return TG_OK;
+}
+
+// dualnet_fwd_w1d_kernel's weights: U_p[ky] = (G g[ky])_p along kx - p0 = g0, p1 = (g0 + g1 + g2) / 2, p2 = (g0 - g1 + g2) / 2,
+// p3 = g2 - in fp64 with the batch-norm scale folded in, x 2^e per layer, pieces as in wsplit_prepare (low pieces unscaled).
+int w1d_prepare(tg_net *net, const float *const *tower, const float *scale) {
+    if (net->board_size != 9) return TG_OK;
+    std::vector<uint16_t> img((size_t)12 * 4 * 3 * 2 * 2 * 4 * 512);
+    std::vector<float> down(12);
+    std::vector<double> u((size_t)4 * 3 * 64 * 64);
+    for (int layer = 0; layer < 12; ++layer) {
+        const float *w = tower[layer];
+        double mx = 0.0;
+        for (int cout = 0; cout < 64; ++cout)
+            for (int cin = 0; cin < 64; ++cin) {
+                const float *g = &w[((size_t)cout * 64 + cin) * 9];
+                const double sc = scale[(layer + 1) * 64 + cout];
+                for (int ky = 0; ky < 3; ++ky) {
+                    const double g0 = g[ky * 3], g1 = g[ky * 3 + 1], g2 = g[ky * 3 + 2];
+                    const double pt[4] = {g0, 0.5 * (g0 + g1 + g2), 0.5 * (g0 - g1 + g2), g2};
+                    for (int p = 0; p < 4; ++p) {
+                        const double v = pt[p] * sc;
+                        u[(((size_t)p * 3 + ky) * 64 + cin) * 64 + cout] = v;
+                        mx = std::fmax(mx, std::fabs(v));
+                    }
+                }
+            }
+        int e = 0;
+        if (mx > 0.0 && std::isfinite(mx)) {
+            int ex;
+            std::frexp(mx, &ex);
+            e = 10 - ex;
+        }
+        e = e > 40 ? 40 : (e < -40 ? -40 : e);
+        down[layer] = std::ldexp(1.f, -e);
+        for (int p = 0; p < 4; ++p)
+            for (int ky = 0; ky < 3; ++ky)
+                for (int kc = 0; kc < 2; ++kc)
+                    for (int ct = 0; ct < 4; ++ct)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int el = 0; el < 8; ++el) {
+                                const int cout = ct * 16 + (lane & 15), cin = kc * 32 + (lane >> 4) * 8 + el;
+                                const double v = std::ldexp(u[(((size_t)p * 3 + ky) * 64 + cin) * 64 + cout], e);
+                                const uint16_t h = f32_to_f16_rn((float)v);
+                                const uint16_t l = f32_to_f16_rn((float)(v - (double)f16_to_f32(h)));
+                                const size_t frag = ((((size_t)layer * 4 + p) * 3 + ky) * 2 + kc) * 2;
+                                img[((frag + 0) * 4 + ct) * 512 + lane * 8 + el] = h;
+                                img[((frag + 1) * 4 + ct) * 512 + lane * 8 + el] = l;
+                            }
+    }
+    auto up = [&](const void *src, size_t bytes, const void **dst) {
+        void *d = nullptr;
+        TG_HIP(hipMalloc(&d, bytes));
+        net->allocs.push_back(d);
+        TG_HIP(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
+        *dst = d;
+        return (int)TG_OK;
+    };
+    int rc;
+    if ((rc = up(img.data(), img.size() * 2, reinterpret_cast<const void **>(&net->dev.w1_w))) ||
+        (rc = up(down.data(), down.size() * 4, reinterpret_cast<const void **>(&net->dev.w1_down))))
+        return rc;
+    return TG_OK;
+}
+
+int w1d_forward(tg_net *net, const float *planes, int batch, int want_logits, float *policy, float *value, int *overflow,
+                hipStream_t stream) {
+    if (net->board_size != 9) return tg::fail(TG_ERR_ARG, "w1d forward: 9x9 only");
+    return launch_w1d(net, planes, batch, want_logits, policy, value, overflow, stream);
 }
 
 // group = boards per workgroup (1 or 3); 9x9 only.

@@ -15,6 +15,9 @@ from tamago_amd.nn.network.dual_net import DualNet
 from tests.helpers import load_npz
 
 
+ALGOS = ("w1d", "wsplit", "split16")      # w1d: Winograd along x only (three-board launches; smaller ones = wsplit)
+
+
 def net_for(algo, sd):
     os.environ["TG_FWD_ALGO"] = algo
     net = DualNet(torch.device("cuda:0"), 9)
@@ -32,7 +35,7 @@ def main():
         x = torch.from_numpy(rs.randint(-1, 2, size=(b, 6, 9, 9)).astype(np.float32))
         rp, rv = ora.inference(x)
         rl, _ = ora.inference_with_policy_logits(x)
-        for algo in ("wsplit", "split16"):
+        for algo in ALGOS:
             net = net_for(algo, sd)
             pol, val = net.inference(x)
             lg, _ = net.inference_with_policy_logits(x)
@@ -42,7 +45,7 @@ def main():
             ok &= not bad
             print(f"B={b:5d} {algo:8s} policy err {ep:.2e} value err {ev:.2e} logit err {el:.2e} (max |logit| {float(rl.abs().max()):.1f})"
                   + ("   <-- FAIL" if bad else ""), flush=True)
-            if bad and algo == "wsplit":
+            if bad and algo in ("wsplit", "w1d"):
                 d = (pol - rp).abs().amax(dim=1)
                 print("   boards over tolerance:", [int(i) for i in torch.nonzero(d > 1e-4).flatten()[:20]], "of", b)
     fix = load_npz("net_s9.npz")
@@ -51,7 +54,7 @@ def main():
         x = torch.from_numpy(fix[f"w{seed}_planes"].astype(np.float32))
         n = x.shape[0]
         for reps in (1, (300 + n - 1) // n):
-            for algo in ("wsplit", "split16"):
+            for algo in ALGOS:
                 lg, _ = net_for(algo, sdf).inference_with_policy_logits(x.repeat(reps, 1, 1, 1))
                 e64 = np.abs(lg[:n].numpy() - fix[f"w{seed}_logits64"]).max()
                 eref = np.abs(fix[f"w{seed}_logits"] - fix[f"w{seed}_logits64"]).max()
@@ -60,7 +63,7 @@ def main():
     # throughput, device-resident planes
     for b in ((65536,) if quick else (256, 768, 1600, 65536, 196608)):
         x = torch.from_numpy(rs.randint(-1, 2, size=(b, 6, 9, 9)).astype(np.float32)).cuda()
-        for algo in ("wsplit", "split16"):
+        for algo in ALGOS:
             net = net_for(algo, sd)
             for _ in range(3):
                 net.forward_device(x)
