@@ -838,7 +838,8 @@ static int pick_group(int board_size, int batch, int num_cus) {
 
 static int pick_wino(int board_size, int batch, int num_cus);
 
-// forward algorithm: TG_FWD_ALGO = wsplit (9x9 default: Winograd F(2x2,3x3) tower on f16 x 2 operand pieces) | split16 (direct
+// forward algorithm: TG_FWD_ALGO = w1d (9x9 default: Winograd F(2,3) along x on f16 x 2 operand pieces for launches of three-board
+// workgroups, the 2-D kernel below for smaller ones) | wsplit (Winograd F(2x2,3x3) tower on f16 x 2 operand pieces) | split16 (direct
 // 3x3 convolution on f16 x 2 operand pieces, 3 MFMAs per product-sum; the 19x19 default) | w2 | wino (exact fp32 Winograd
 // tower) | direct (exact fp32 direct convolution).
 static bool pick_split() {
@@ -850,7 +851,7 @@ static bool pick_split() {
 static bool pick_w1d(int board_size, int batch, int num_cus) {
     if (board_size != 9 || batch <= num_cus) return false;
     const char *env = getenv("TG_FWD_ALGO");
-    return env && !strcmp(env, "w1d");
+    return env && !strcmp(env, "w1d");               // (opt-in until the one-board variant exists: results must not depend on the launch size)
 }
 // TG_FWD_ALGO=wsplit: the 9x9 tower as Winograd F(2x2,3x3) on split operands (net_forward_wsplit.hip)
 static bool pick_wsplit(int board_size) {

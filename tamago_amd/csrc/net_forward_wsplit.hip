@@ -1018,8 +1018,10 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
         // of row y - 1, input transform of row y + 2, cell reads of row y + 3, weight requests of the next layer.
         // ---- per-lane geometry: MFMA column u = 5 board + t (15 = padding), k-group lg; wave = transform point
         // (per group, behind the stem: kept alive through stem and heads these twelve registers spill) ----
-        const int ub = li / 5, ut = li - 5 * ub;
-        const bool uv = li < 15;
+        int gli = li, glg = lg;
+        asm volatile("" : "+v"(gli), "+v"(glg));                  // (not to be hoisted out of the group loop)
+        const int ub = gli / 5, ut = gli - 5 * ub;
+        const bool uv = gli < 15;
         // the two cells of point `wave`: V = d[xa] + sgn d[xb]
         const int xa = wave == 0 ? 2 * ut - 1 : (wave == 2 ? 2 * ut + 1 : 2 * ut);
         const int xb = wave == 0 ? 2 * ut + 1 : (wave == 1 ? 2 * ut + 1 : (wave == 2 ? 2 * ut : 2 * ut + 2));
@@ -1029,20 +1031,19 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
             adr = ok ? R0 * 256 + ((chunk ^ w1_swz(R0)) << 4) : invalid_rel + (chunk << 4);
             str = ok ? 9 * 256 : 0;
         };
-        int adrA, strA, adrB, strB, adrO0, strO0, adrO1, strO1, adrR0, adrR1, strR0, strR1;
-        cell(xa, lg * 2, C::ZERO_REL, adrA, strA);
-        cell(xb, lg * 2, C::ZERO_REL, adrB, strB);
-        cell(2 * ut, wave * 4 + lg, C::DUMP_REL, adrO0, strO0);        // stores of the channels 16 wave + 4 lg ..
-        cell(2 * ut + 1, wave * 4 + lg, C::DUMP_REL, adrO1, strO1);
-        cell(2 * ut, wave * 4 + lg, C::ZERO_REL, adrR0, strR0);        // residual reads (outside the board: zeros)
-        cell(2 * ut + 1, wave * 4 + lg, C::ZERO_REL, adrR1, strR1);
+        int curA, strA, curB, strB, curO0, strO0, curO1, strO1, curR0, curR1, strR0, strR1;      // cursors (row 0) and row strides
+        cell(xa, glg * 2, C::ZERO_REL, curA, strA);
+        cell(xb, glg * 2, C::ZERO_REL, curB, strB);
+        cell(2 * ut, wave * 4 + glg, C::DUMP_REL, curO0, strO0);        // stores of the channels 16 wave + 4 lg ..
+        cell(2 * ut + 1, wave * 4 + glg, C::DUMP_REL, curO1, strO1);
+        cell(2 * ut, wave * 4 + glg, C::ZERO_REL, curR0, strR0);        // residual reads (outside the board: zeros)
+        cell(2 * ut + 1, wave * 4 + glg, C::ZERO_REL, curR1, strR1);
         f32x4 dq[2][2][2];                                     // cells read ahead: [cell a / b][kc][channel half]
         i32x4v vh[5][2], vl[5][2];                             // V rows: slot 4 = row 0, slot r & 3 = rows 1 .. 8; [kc]
         f32x4 acc[2][4];                                       // [row parity][channel tile]
         f32x4 ez[4], eres[2], ev[2];
         float tvv[4];
         unsigned thh[2];
-        int curA = 0, curB = 0, curO0 = 0, curO1 = 0, curR0 = 0, curR1 = 0;
         auto vslot = [](int r) constexpr { return r == 0 ? 4 : (r & 3); };
         auto rd = [&](auto IN_, auto I_) __attribute__((always_inline)) {          // one of the eight cell reads of the row at curA / curB
             constexpr int IN = decltype(IN_)::value, i = decltype(I_)::value, cb = i >> 2, kc = (i >> 1) & 1, h = i & 1;
@@ -1069,7 +1070,15 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
                 vl[s][kc][2 * h + 1] = (int)low_pieces(tvv[2], tvv[3], thh[1]);
             }
         };
-        int ovf_layer = 0;
+        f32x4 pshf = f32x4{0.f, 0.f, 0.f, 0.f};                // the previous layer's epilogue constants (its row 8 rides in this layer's row 0)
+        float pdown = 0.f;
+        int pO0 = C::DUMP_REL + (lane * 16) % 256, pO1 = pO0, pR0 = C::ZERO_REL + (lane * 16) % 256, pR1 = pR0;   // its row-8 cells (layer 0: dump / zero rows)
+        // Schedule of a row's slices (one MFMA each + what rides along):  0-15 input transform of row y + 2 | 0-3 exchange
+        // writes of row y - 1, 10 barrier, 11-12 exchange reads, 13 residual reads, 19-34 sums / shift / residual / ReLU,
+        // 35-36 stores | 37-44 cell reads of row y + 3 | from 46: weight requests.  Row 8's exchange + epilogue ride in the
+        // NEXT layer's row 0 (layer 0: a null epilogue - zero accumulators, zero constants, dump-row stores); the next layer's
+        // V rows 0 and 1 are transformed under rows 7 and 8 (its input rows 0 - 2 are complete since row 3).  No barrier at
+        // the layer boundary: between a store and any other wave's read of it lies at least one row barrier.
         auto layer_fn = [&](auto IN_, auto OUT_, auto RES_, int layer) __attribute__((always_inline)) {
             constexpr int IN = decltype(IN_)::value, OUT = decltype(OUT_)::value;
             constexpr bool RES = decltype(RES_)::value;
@@ -1081,52 +1090,67 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
             const float down = net.w1_down[layer];
             int exw = C::EX_OFF + wave * 4096 + lane * 16, exr = C::EX_OFF + wave * 1024 + lane * 16;
             asm volatile("" : "+v"(exw), "+v"(exr));
-            curA = adrA; curB = adrB; curO0 = adrO0; curO1 = adrO1; curR0 = adrR0; curR1 = adrR1;
-            // prologue: V rows 0 and 1, the cells of row 2 on their way
-            static_for<8>([&](auto I_) { rd(IN_, I_); });
-            static_for<16>([&](auto I_) { tr(std::integral_constant<int, 0>{}, I_); });
-            static_for<8>([&](auto I_) { rd(IN_, I_); });
-            static_for<16>([&](auto I_) { tr(std::integral_constant<int, 1>{}, I_); });
-            static_for<8>([&](auto I_) { rd(IN_, I_); });
+            if (layer == 0) {
+                // a group's first layer: nothing was prepared under a previous layer - V rows 0 and 1, the cells of row 2
+                // (cursors: set at the top of the group)
+                static_for<8>([&](auto I_) { rd(IN_, I_); });
+                static_for<16>([&](auto I_) { tr(std::integral_constant<int, 0>{}, I_); });
+                static_for<8>([&](auto I_) { rd(IN_, I_); });
+                static_for<16>([&](auto I_) { tr(std::integral_constant<int, 1>{}, I_); });
+                static_for<8>([&](auto I_) { rd(IN_, I_); });
+            }
             // this layer's taps 1 and 2 must have arrived (requested in that order; behind them: tap 0's 16 requests, the shift)
             asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
-            // exchange + epilogue of row Y (output cells at curO0 / curO1), in slices 0 .. 26
-            auto epi = [&](auto Y_, auto I_) __attribute__((always_inline)) {
-                constexpr int y = decltype(Y_)::value, i = decltype(I_)::value, par = (y + PAR) & 1;
+            // exchange + epilogue of a row: PREV = row 8 of the previous layer (output buffer = this layer's input, the other
+            // residual flag, constants pshf / pdown, cells at row 8), else row Y of this layer (cells at curO / curR)
+            auto epi = [&](auto PREV_, auto Y_, auto I_) __attribute__((always_inline)) {
+                constexpr bool PREV = decltype(PREV_)::value;
+                constexpr int y = decltype(Y_)::value, i = decltype(I_)::value;
+                constexpr int par = PREV ? (8 + 1 - PAR) & 1 : (y + PAR) & 1;
+                constexpr int OB = PREV ? IN : OUT;
+                constexpr bool RS = PREV ? !RES : RES;
                 if constexpr (i < 4) {
                     lds_f32x4_put<par * 16384 + i * 1024>(exw, acc[par][i]);
-                } else if constexpr (i == 5) {
+                } else if constexpr (i == 13) {
+                    if constexpr (RS) {
+                        eres[0] = lds_f32x4_at<OB>(PREV ? pR0 : curR0);
+                        eres[1] = lds_f32x4_at<OB>(PREV ? pR1 : curR1);
+                    }
+                    if constexpr (!PREV) { curR0 += strR0; curR1 += strR1; }   // (also without a residual: the next layer's deferred row needs them at row 8)
+                } else if constexpr (i == 10) {
                     __syncthreads();
-                } else if constexpr (i == 6 || i == 7) {
-                    ez[2 * (i - 6)] = lds_f32x4_at<par * 16384 + (2 * (i - 6)) * 4096>(exr);
-                    ez[2 * (i - 6) + 1] = lds_f32x4_at<par * 16384 + (2 * (i - 6) + 1) * 4096>(exr);
-                } else if constexpr (i == 8) {
-                    if constexpr (RES) { eres[0] = lds_f32x4_at<OUT>(curR0); eres[1] = lds_f32x4_at<OUT>(curR1); curR0 += strR0; curR1 += strR1; }
-                } else if constexpr (i >= 9 && i < 25) {
-                    constexpr int k = i - 9, cc = k >> 3, e = (k >> 1) & 3, part = k & 1;
+                } else if constexpr (i == 11 || i == 12) {
+                    ez[2 * (i - 11)] = lds_f32x4_at<par * 16384 + (2 * (i - 11)) * 4096>(exr);
+                    ez[2 * (i - 11) + 1] = lds_f32x4_at<par * 16384 + (2 * (i - 11) + 1) * 4096>(exr);
+                } else if constexpr (i >= 19 && i < 35) {
+                    constexpr int k = i - 19, cc = k >> 3, e = (k >> 1) & 3, part = k & 1;
                     if constexpr (part == 0) {
                         ev[cc][e] = cc == 0 ? (ez[0][e] + ez[1][e]) + ez[2][e] : (ez[1][e] - ez[2][e]) - ez[3][e];
                     } else {
-                        float tt = fmaf(ev[cc][e], down, shf[e]);
-                        if constexpr (RES) tt += eres[cc][e];
+                        float tt = fmaf(ev[cc][e], PREV ? pdown : down, PREV ? pshf[e] : shf[e]);
+                        if constexpr (RS) tt += eres[cc][e];
                         ev[cc][e] = fmaxf(tt, 0.f);
                     }
-                } else if constexpr (i == 25) {
+                } else if constexpr (i == 35) {
                     amax = fmaxf(fmaxf(amax, ev[0][0]), ev[0][1]);
                     amax = fmaxf(fmaxf(amax, ev[0][2]), ev[0][3]);
-                    lds_f32x4_put<OUT>(curO0, ev[0]);
-                    curO0 += strO0;
-                } else if constexpr (i == 26) {
+                    lds_f32x4_put<OB>(PREV ? pO0 : curO0, ev[0]);
+                    if constexpr (!PREV) curO0 += strO0;
+                } else if constexpr (i == 36) {
                     amax = fmaxf(fmaxf(amax, ev[1][0]), ev[1][1]);
                     amax = fmaxf(fmaxf(amax, ev[1][2]), ev[1][3]);
-                    lds_f32x4_put<OUT>(curO1, ev[1]);
-                    curO1 += strO1;
+                    lds_f32x4_put<OB>(PREV ? pO1 : curO1, ev[1]);
+                    if constexpr (!PREV) curO1 += strO1;
                 }
             };
             static_for<9>([&](auto Y_) {
                 constexpr int y = decltype(Y_)::value, par = (y + PAR) & 1;
                 constexpr int NT = (y == 0 || y == 8) ? 2 : 3, NM = 24 * NT, KY0 = y == 0 ? 1 : 0;
+                if constexpr (PROF)
+                    if (blockIdx.x == 0 && tid == 0 && (layer == 2 || layer == 3) && grp == (int)blockIdx.x)
+                        net.timeline[40 + 12 * (layer - 2) + y] = (long long)__builtin_amdgcn_s_memtime();
                 if constexpr (y == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // tap 0 (and the shift)
+                if constexpr (y == 6) { curA -= 9 * strA; curB -= 9 * strB; }              // from here on: the next layer's rows 0 .. 2
                 static_for<NM>([&](auto M_) {
                     constexpr int m = decltype(M_)::value, ti = m / 24, q = m % 24, kc = q / 12, st = (q / 4) % 3, c = q % 4;
                     constexpr int ky = KY0 + ti, r = y + ky - 1, s = vslot(r), slot = ky == 1 ? S1 : ky;
@@ -1135,14 +1159,22 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
                     else if constexpr (st == 1) acc[par][c] = mfma16<F>(ua[slot][kc][0][c], vl[s][kc], acc[par][c]);
                     else acc[par][c] = mfma16<F>(ua[slot][kc][0][c], vh[s][kc], acc[par][c]);
                     // ---- what rides along ----
-                    constexpr int E0 = y >= 1 ? 27 : 0;                                  // first slice behind the previous row's epilogue
-                    if constexpr (y >= 1 && m < 27) epi(std::integral_constant<int, y - 1>{}, M_);
-                    if constexpr (y + 2 <= 8 && m >= E0 && m < E0 + 16) tr(std::integral_constant<int, y + 2>{}, std::integral_constant<int, m - E0>{});
-                    if constexpr (y + 3 <= 8 && m >= E0 + 16 && m < E0 + 24) rd(IN_, std::integral_constant<int, m - E0 - 16>{});
+                    if constexpr (m < 37) {
+                        if constexpr (y == 0) epi(std::true_type{}, Y_, M_);
+                        else epi(std::false_type{}, std::integral_constant<int, y - 1>{}, M_);
+                    }
+                    if constexpr (m < 16) {
+                        if constexpr (y + 2 <= 8) tr(std::integral_constant<int, y + 2>{}, M_);
+                        else tr(std::integral_constant<int, y - 7>{}, M_);                  // rows 7 / 8: the next layer's V rows 0 / 1
+                    }
+                    if constexpr (m >= 37 && m < 45) {
+                        if constexpr (y + 3 <= 8) rd(IN_, std::integral_constant<int, m - 37>{});
+                        else rd(OUT_, std::integral_constant<int, m - 37>{});                // rows 6 .. 8: the next layer's rows 0 .. 2
+                    }
                     // next layer's weights: tap 1 into the spare slot during rows 4 .. 6, tap 2 at the start of row 8 (its last use
                     // was row 7), tap 0 behind row 8's tap-0 MFMAs
-                    if constexpr (y >= 4 && y <= 6 && m >= 52 && m < 70 && (m - 52) % 3 == 0) {
-                        constexpr int f = (y - 4) * 6 + (m - 52) / 3;                      // 0 .. 17
+                    if constexpr (y >= 4 && y <= 6 && m >= 46 && m < 64 && (m - 46) % 3 == 0) {
+                        constexpr int f = (y - 4) * 6 + (m - 46) / 3;                      // 0 .. 17
                         if constexpr (f < 16) w1_request<S1N>(ua, wnext + 16384, wlane, std::integral_constant<int, f>{});
                     }
                     if constexpr (y == 8 && m < 32 && m % 2 == 1)
@@ -1151,19 +1183,54 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
                     __builtin_amdgcn_sched_barrier(0);
                 });
             });
-            // row 8's exchange + epilogue on their own
-            static_for<27>([&](auto I_) { epi(std::integral_constant<int, 8>{}, I_); });
+            if constexpr (PROF)
+                if (blockIdx.x == 0 && tid == 0 && (layer == 2 || layer == 3) && grp == (int)blockIdx.x)
+                    net.timeline[40 + 12 * (layer - 2) + 9] = (long long)__builtin_amdgcn_s_memtime();
+            pshf = shf;
+            pdown = down;
+            // the cursors stand at row 8 (eight rows stored): that is where the deferred epilogue goes; back to row 0 for the next layer
+            pO0 = curO0; pO1 = curO1; pR0 = curR0; pR1 = curR1;
+            curO0 -= 8 * strO0; curO1 -= 8 * strO1; curR0 -= 8 * strR0; curR1 -= 8 * strR1;
             if (!(amax < (float)kWsRangeLimit)) ovf = 1;            // f16 range guard (also catches NaN)
-            __syncthreads();
             stamp();
         };
         using IX = std::integral_constant<int, C::X_OFF>;
         using IH = std::integral_constant<int, C::H_OFF>;
         if (!(amax < (float)kWsRangeLimit)) ovf = 1;
+        // row 8's cells (the deferred epilogue) and layer 0's null epilogue
+        {
+            float z0, z1, z2, z3;
+            asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0" : "=v"(z0), "=v"(z1), "=v"(z2), "=v"(z3));
+            pshf = f32x4{z0, z1, z2, z3};
+            pdown = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[1][c] = pshf;
+        }
 #pragma unroll 1
         for (int blk = 0; blk < kBlocks; ++blk) {
             layer_fn(IX{}, IH{}, std::false_type{}, 2 * blk);
             layer_fn(IH{}, IX{}, std::true_type{}, 2 * blk + 1);
+        }
+        {
+            // the tower's last row (layer 11, output X, residual): on its own
+            const int exw = C::EX_OFF + wave * 4096 + lane * 16, exr = C::EX_OFF + wave * 1024 + lane * 16;
+            constexpr int par = (8 + 1) & 1;
+            static_for<4>([&](auto I_) { lds_f32x4_put<par * 16384 + decltype(I_)::value * 1024>(exw, acc[par][decltype(I_)::value]); });
+            eres[0] = lds_f32x4_at<C::X_OFF>(pR0);
+            eres[1] = lds_f32x4_at<C::X_OFF>(pR1);
+            __syncthreads();
+            static_for<4>([&](auto I_) { ez[decltype(I_)::value] = lds_f32x4_at<par * 16384 + decltype(I_)::value * 4096>(exr); });
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float o0 = (ez[0][e] + ez[1][e]) + ez[2][e], o1 = (ez[1][e] - ez[2][e]) - ez[3][e];
+                ev[0][e] = fmaxf(fmaf(o0, pdown, pshf[e]) + eres[0][e], 0.f);
+                ev[1][e] = fmaxf(fmaf(o1, pdown, pshf[e]) + eres[1][e], 0.f);
+                amax = fmaxf(fmaxf(amax, ev[0][e]), ev[1][e]);
+            }
+            lds_f32x4_put<C::X_OFF>(pO0, ev[0]);
+            lds_f32x4_put<C::X_OFF>(pO1, ev[1]);
+            if (!(amax < (float)kWsRangeLimit)) ovf = 1;
+            __syncthreads();
         }
         // next group's input planes: requested here, consumed after the heads
         const int next = __builtin_amdgcn_readfirstlane(*ticket_lds);   // (written before the stem's barriers)

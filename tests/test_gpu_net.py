@@ -116,7 +116,7 @@ def test_featurize_kernel_vs_reference_golden(size):
     assert np.array_equal(out.cpu().numpy(), np.array(want))
 
 
-@pytest.mark.parametrize("size,algo", [(9, "direct"), (9, "wino"), (9, "split16"), (9, "w2"), (9, "wsplit"),
+@pytest.mark.parametrize("size,algo", [(9, "direct"), (9, "wino"), (9, "split16"), (9, "w2"), (9, "wsplit"), (9, "w1d"),
                                        (19, "direct"), (19, "wino"), (19, "split16")])
 def test_every_tower_algorithm_matches_the_oracle(algo, size, monkeypatch):
     """Implementations of the residual tower: exact-fp32 Winograd F(2x2,3x3) kernel (TG_FWD_ALGO=wino; the
@@ -124,7 +124,8 @@ def test_every_tower_algorithm_matches_the_oracle(algo, size, monkeypatch):
     (direct), and the split-operand kernels on the 16-bit matrix pipe (split16 = f16 x 2 pieces, one wave per SIMD,
     at both sizes; 19x19: one board per workgroup, residual image in an L2-resident scratch; w2 = the same arithmetic
     with two waves per SIMD, weights through an LDS ring and batch norm folded into the weights, for 9x9 batches
-    above the CU count).  All must agree with the oracle at every workgroup shape."""
+    above the CU count; wsplit = Winograd F(2x2,3x3) on the same operand pieces; w1d = Winograd F(2,3) along x only, the
+    default for launches of three-board workgroups).  All must agree with the oracle at every workgroup shape."""
     from oracle.net import OracleNet, make_state_dict
     monkeypatch.setenv("TG_FWD_ALGO", algo)
     sd = make_state_dict(size, 7, 1.5)
@@ -149,7 +150,7 @@ def test_split_kernels_are_fp32_class_and_fall_back_on_f16_overflow(monkeypatch)
     from oracle.net import OracleNet, make_state_dict
     fix = load_npz("net_s9.npz")
     errs = {}
-    for algo in ("wino", "direct", "split16", "w2", "wsplit"):
+    for algo in ("wino", "direct", "split16", "w2", "wsplit", "w1d"):
         monkeypatch.setenv("TG_FWD_ALGO", algo)
         worst = 0.0
         for seed in (0, 7):
@@ -172,7 +173,7 @@ def test_split_kernels_are_fp32_class_and_fall_back_on_f16_overflow(monkeypatch)
     x = torch.from_numpy(np.random.RandomState(2).randint(-1, 2, size=(300, 6, 9, 9)).astype(np.float32))
     monkeypatch.setenv("TG_FWD_ALGO", "wino")
     want = _net(9, sd).inference_with_policy_logits(x)
-    for algo in ("split16", "w2", "wsplit"):
+    for algo in ("split16", "w2", "wsplit", "w1d"):
         monkeypatch.setenv("TG_FWD_ALGO", algo)
         hot = _net(9, sd)
         assert hot.range_fallbacks() == 0
