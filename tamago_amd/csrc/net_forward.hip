@@ -34,7 +34,7 @@ int wsplit_prepare(tg_net *net, const float *const *tower, const float *scale, c
 int wsplit_forward(tg_net *net, int group, const float *planes, int batch, int want_logits, float *policy,
                    float *value, int *overflow, hipStream_t stream);
 int w1d_prepare(tg_net *net, const float *const *tower, const float *scale);
-int w1d_forward(tg_net *net, const float *planes, int batch, int want_logits, float *policy, float *value, int *overflow,
+int w1d_forward(tg_net *net, int group, const float *planes, int batch, int want_logits, float *policy, float *value, int *overflow,
                 hipStream_t stream);
 int w2_prepare(tg_net *net, const float *conv0, const float *const *tower, const float *scale, const float *shift);
 int w2_forward(tg_net *net, const float *planes, int batch, int want_logits, float *policy, float *value,
@@ -846,12 +846,12 @@ static bool pick_split() {
     const char *env = getenv("TG_FWD_ALGO");
     return !env || !strcmp(env, "split16") || !strcmp(env, "w2") || !strcmp(env, "wsplit") || !strcmp(env, "w1d");
 }
-// TG_FWD_ALGO=w1d: launches of three-board workgroups on the kernel that transforms along x only (net_forward_wsplit.hip:
-// dualnet_fwd_w1d_kernel); smaller launches on dualnet_fwd_wsplit_kernel<1>
-static bool pick_w1d(int board_size, int batch, int num_cus) {
-    if (board_size != 9 || batch <= num_cus) return false;
+// TG_FWD_ALGO=w1d (the 9x9 default): Winograd F(2,3) along x only on f16 x 2 operand pieces (net_forward_wsplit.hip:
+// dualnet_fwd_w1d_kernel<1 | 3>)
+static bool pick_w1d(int board_size, int /*batch*/, int /*num_cus*/) {
+    if (board_size != 9) return false;
     const char *env = getenv("TG_FWD_ALGO");
-    return env && !strcmp(env, "w1d");               // (opt-in until the one-board variant exists: results must not depend on the launch size)
+    return !env || !strcmp(env, "w1d");              // the 9x9 default (one- and three-board variants give the same bits; TG_FWD_ALGO=wsplit: 2-D Winograd)
 }
 // TG_FWD_ALGO=wsplit: the 9x9 tower as Winograd F(2x2,3x3) on split operands (net_forward_wsplit.hip)
 static bool pick_wsplit(int board_size) {
@@ -875,7 +875,7 @@ const char *tg_net_kernel_name(const tg_net *net, int batch) {
         return pick_wino(19, batch, net->num_cus) ? "dualnet_fwd_wino8_kernel<19, 1, global scratch>" : "dualnet_fwd_kernel<19, 1>";
     }
     if (pick_w2(9, batch, net->num_cus)) return "dualnet_fwd_w2_kernel<9, 3>";
-    if (pick_w1d(9, batch, net->num_cus)) return "dualnet_fwd_w1d_kernel<3>";
+    if (pick_w1d(9, batch, net->num_cus)) return batch > net->num_cus ? "dualnet_fwd_w1d_kernel<3>" : "dualnet_fwd_w1d_kernel<1>";
     if (pick_wsplit(9)) return batch > net->num_cus ? "dualnet_fwd_wsplit_kernel<3>" : "dualnet_fwd_wsplit_kernel<1>";
     if (pick_split()) return batch > net->num_cus ? "dualnet_fwd_split_kernel<9, 3, f16x2>" : "dualnet_fwd_split_kernel<9, 1, f16x2>";
     {
@@ -895,9 +895,11 @@ double tg_net_executed_flops_per_position(const tg_net *net, int batch, double *
     const char *name = "f32";
     double flops = 0.0;
     if (pick_w1d(S, batch, net->num_cus)) {
-        // per three-board workgroup pass: stem as below + 12 layers x 4 waves x 25 (row, tap) pairs x 4 channel tiles x 2 k-chunks x 3 products
-        const int rtw = ((3 * P + 15) / 16 + 3) / 4;
-        flops = (2.0 * 4 * 4 * rtw * 3 + 12.0 * 4 * 25 * 4 * 2 * 3) * 16384.0 / 3;
+        // per workgroup pass: stem as below + 12 layers x 4 waves x (three boards: 25 (row, tap) pairs | one board: 3 row tiles x 3
+        // taps) x 4 channel tiles x 2 k-chunks x 3 products
+        const int g = batch > net->num_cus ? 3 : 1;
+        const int rtw = ((g * P + 15) / 16 + 3) / 4;
+        flops = (2.0 * 4 * 4 * rtw * 3 + 12.0 * 4 * (g == 3 ? 25 : 9) * 4 * 2 * 3) * 16384.0 / g;
         peak = 2500.0;
         name = "f16 (2 operand pieces, Winograd F(2,3) along x, fp32 accumulate)";
     } else if (pick_wsplit(S)) {
@@ -1014,7 +1016,7 @@ int tg_net_forward_dev(tg_net *net, const float *planes_dev, int batch, int want
             // forward pass.  Self-play gained 1 % from its removal.)
             TG_HIP(hipMemsetAsync(flag, 0, 2 * sizeof(int), st));
             int rc = pick_w1d(9, batch, net->num_cus)
-                         ? tg::w1d_forward(net, planes_dev, batch, want_logits, policy_dev, value_dev, flag, st)
+                         ? tg::w1d_forward(net, group, planes_dev, batch, want_logits, policy_dev, value_dev, flag, st)
                      : pick_wsplit(9)
                          ? tg::wsplit_forward(net, group, planes_dev, batch, want_logits, policy_dev, value_dev, flag, st)
                          : (pick_w2(9, batch, net->num_cus)

@@ -90,6 +90,13 @@ __host__ __device__ inline int w1_swz(int R) {
     return (g & 1) | ((g & 6) << 1);
 }
 
+// ... one board per workgroup (units u = 5 (row mod 3) + t): g = ((x + 1) / 2 + 5 (y mod 3)) mod 8
+__host__ __device__ inline int w1g1_swz(int R) {
+    const int y = (R * 57) >> 9, x = R - 9 * y;
+    const int g = (((x + 1) >> 1) + 5 * (y % 3)) & 7;
+    return (g & 1) | ((g & 6) << 1);
+}
+
 // LDS accesses by ABSOLUTE LDS byte address (the kernel has no static LDS: the dynamic array starts at 0, checked at
 // kernel start).  Through `smem + addr` every access costs a v_add_u32 with the array's (relocatable) base.
 typedef __attribute__((address_space(3))) f32x4 lds_f32x4_t;
@@ -226,7 +233,7 @@ __device__ __forceinline__ void run_heads_x32(unsigned char *smem, const NetDev 
         const int t = wave + q * NW;
         const int row = (t < C::MT ? t : wave) * 16 + li;
         const int rr = row < M ? row : M + 1;              // zero row
-        const int sw = row < M ? (SWZ ? w1_swz(row) : ws_swz(row)) : 0;
+        const int sw = row < M ? (SWZ == 2 ? w1g1_swz(row) : (SWZ ? w1_swz(row) : ws_swz(row))) : 0;
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc) {
             const int a0 = C::X_OFF + rr * 256 + (((kc * 8 + lg * 2) ^ sw) << 4);
@@ -892,7 +899,7 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
     };
     fetch_planes(blockIdx.x);
     const float sgn = wave == 1 ? 1.f : -1.f;                  // row pass of point row w: d[ra] + sgn d[rb]
-    static_assert(G == 3, "dualnet_fwd_w1d_kernel: three boards per workgroup");
+    static_assert(G == 3 || G == 1, "dualnet_fwd_w1d_kernel: one or three boards per workgroup");
     // This wave's weight fragments of a layer, [slot 4][kc 2][piece 2][ct 4]: slots 0 / 2 = taps ky 0 / 2, slots 1 and 3 take
     // tap 1 of even / odd layers in turn (the spare one is filled for the next layer while this one runs).  AGPRs, requested
     // by inline asm (see the kernel above): explicit waits, in-order returns.
@@ -901,8 +908,13 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
     {
         const unsigned char *w0 = net.w1_w + (size_t)wave * 49152;
         w1_request_tap<1>(ua, w0 + 16384, wlane);
-        w1_request_tap<2>(ua, w0 + 2 * 16384, wlane);
-        w1_request_tap<0>(ua, w0, wlane);
+        if constexpr (G == 3) {                                  // (the order the first layer waits for them in)
+            w1_request_tap<2>(ua, w0 + 2 * 16384, wlane);
+            w1_request_tap<0>(ua, w0, wlane);
+        } else {
+            w1_request_tap<0>(ua, w0, wlane);
+            w1_request_tap<2>(ua, w0 + 2 * 16384, wlane);
+        }
     }
 
     // Groups beyond a workgroup's first are handed out by a ticket counter (overflow[1], zeroed with the range flag): a
@@ -981,7 +993,7 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
                 lds_load_frag<2 * IMG>(fb[1][0], smem, addr);
                 lds_load_frag<3 * IMG>(fb[1][1], smem, addr);
                 const int orow = row < M ? row : M;
-                const int osw = row < M ? w1_swz(row) : 0;
+                const int osw = row < M ? (G == 1 ? w1g1_swz(row) : w1_swz(row)) : 0;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
@@ -1016,226 +1028,392 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
         // M_w goes through the LDS exchange; wave w' finishes output channels [16 w', 16 w' + 16): out0 = m0 + m1 + m2,
         // out1 = m1 - m2 - m3, shift, residual, ReLU.  Everything but the MFMAs of row y rides along them: exchange + epilogue
         // of row y - 1, input transform of row y + 2, cell reads of row y + 3, weight requests of the next layer.
-        // ---- per-lane geometry: MFMA column u = 5 board + t (15 = padding), k-group lg; wave = transform point
-        // (per group, behind the stem: kept alive through stem and heads these twelve registers spill) ----
-        int gli = li, glg = lg;
-        asm volatile("" : "+v"(gli), "+v"(glg));                  // (not to be hoisted out of the group loop)
-        const int ub = gli / 5, ut = gli - 5 * ub;
-        const bool uv = gli < 15;
-        // the two cells of point `wave`: V = d[xa] + sgn d[xb]
-        const int xa = wave == 0 ? 2 * ut - 1 : (wave == 2 ? 2 * ut + 1 : 2 * ut);
-        const int xb = wave == 0 ? 2 * ut + 1 : (wave == 1 ? 2 * ut + 1 : (wave == 2 ? 2 * ut : 2 * ut + 2));
-        auto cell = [&](int x, int chunk, int invalid_rel, int &adr, int &str) {
-            const bool ok = uv && x >= 0 && x < 9;
-            const int R0 = 81 * ub + (ok ? x : 0);
-            adr = ok ? R0 * 256 + ((chunk ^ w1_swz(R0)) << 4) : invalid_rel + (chunk << 4);
-            str = ok ? 9 * 256 : 0;
-        };
-        int curA, strA, curB, strB, curO0, strO0, curO1, strO1, curR0, curR1, strR0, strR1;      // cursors (row 0) and row strides
-        cell(xa, glg * 2, C::ZERO_REL, curA, strA);
-        cell(xb, glg * 2, C::ZERO_REL, curB, strB);
-        cell(2 * ut, wave * 4 + glg, C::DUMP_REL, curO0, strO0);        // stores of the channels 16 wave + 4 lg ..
-        cell(2 * ut + 1, wave * 4 + glg, C::DUMP_REL, curO1, strO1);
-        cell(2 * ut, wave * 4 + glg, C::ZERO_REL, curR0, strR0);        // residual reads (outside the board: zeros)
-        cell(2 * ut + 1, wave * 4 + glg, C::ZERO_REL, curR1, strR1);
-        f32x4 dq[2][2][2];                                     // cells read ahead: [cell a / b][kc][channel half]
-        i32x4v vh[5][2], vl[5][2];                             // V rows: slot 4 = row 0, slot r & 3 = rows 1 .. 8; [kc]
-        f32x4 acc[2][4];                                       // [row parity][channel tile]
-        f32x4 ez[4], eres[2], ev[2];
-        float tvv[4];
-        unsigned thh[2];
-        auto vslot = [](int r) constexpr { return r == 0 ? 4 : (r & 3); };
-        auto rd = [&](auto IN_, auto I_) __attribute__((always_inline)) {          // one of the eight cell reads of the row at curA / curB
-            constexpr int IN = decltype(IN_)::value, i = decltype(I_)::value, cb = i >> 2, kc = (i >> 1) & 1, h = i & 1;
-            const int a0 = (cb ? curB : curA) ^ ((kc << 7) | (h << 4));
-            dq[cb][kc][h] = lds_f32x4_at<IN>(a0);
-            if constexpr (i == 7) { curA += strA; curB += strB; }
-        };
-        // input transform of one row in 16 slices: per (kc, half) t = d_a + sgn d_b (2 x 2 values), high pieces, low pieces
-        auto tr = [&](auto R_, auto I_) __attribute__((always_inline)) {
-            constexpr int r = decltype(R_)::value, i = decltype(I_)::value, kc = i >> 3, h = (i >> 2) & 1, q = i & 3, s = vslot(r);
-            if constexpr (q == 0) {
-                tvv[0] = fmaf(dq[1][kc][h][0], sgn, dq[0][kc][h][0]);
-                tvv[1] = fmaf(dq[1][kc][h][1], sgn, dq[0][kc][h][1]);
-            } else if constexpr (q == 1) {
-                tvv[2] = fmaf(dq[1][kc][h][2], sgn, dq[0][kc][h][2]);
-                tvv[3] = fmaf(dq[1][kc][h][3], sgn, dq[0][kc][h][3]);
-            } else if constexpr (q == 2) {
-                thh[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{tvv[0], tvv[1]}, f16x2));
-                vh[s][kc][2 * h] = (int)thh[0];
-                vl[s][kc][2 * h] = (int)low_pieces(tvv[0], tvv[1], thh[0]);
-            } else {
-                thh[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{tvv[2], tvv[3]}, f16x2));
-                vh[s][kc][2 * h + 1] = (int)thh[1];
-                vl[s][kc][2 * h + 1] = (int)low_pieces(tvv[2], tvv[3], thh[1]);
-            }
-        };
-        f32x4 pshf = f32x4{0.f, 0.f, 0.f, 0.f};                // the previous layer's epilogue constants (its row 8 rides in this layer's row 0)
-        float pdown = 0.f;
-        int pO0 = C::DUMP_REL + (lane * 16) % 256, pO1 = pO0, pR0 = C::ZERO_REL + (lane * 16) % 256, pR1 = pR0;   // its row-8 cells (layer 0: dump / zero rows)
-        // Schedule of a row's slices (one MFMA each + what rides along):  0-15 input transform of row y + 2 | 0-3 exchange
-        // writes of row y - 1, 10 barrier, 11-12 exchange reads, 13 residual reads, 19-34 sums / shift / residual / ReLU,
-        // 35-36 stores | 37-44 cell reads of row y + 3 | from 46: weight requests.  Row 8's exchange + epilogue ride in the
-        // NEXT layer's row 0 (layer 0: a null epilogue - zero accumulators, zero constants, dump-row stores); the next layer's
-        // V rows 0 and 1 are transformed under rows 7 and 8 (its input rows 0 - 2 are complete since row 3).  No barrier at
-        // the layer boundary: between a store and any other wave's read of it lies at least one row barrier.
-        auto layer_fn = [&](auto IN_, auto OUT_, auto RES_, int layer) __attribute__((always_inline)) {
-            constexpr int IN = decltype(IN_)::value, OUT = decltype(OUT_)::value;
-            constexpr bool RES = decltype(RES_)::value;
-            constexpr int PAR = RES ? 1 : 0;                   // conv2 of a block = odd layer
-            constexpr int S1 = PAR ? 3 : 1, S1N = PAR ? 1 : 3; // AGPR slot of tap ky = 1 in this / the next layer (taps 0, 2: slots 0, 2)
-            const int next_layer = layer + 1 < kTowerLayers ? layer + 1 : 0;
-            const unsigned char *wnext = net.w1_w + ((size_t)next_layer * 4 + wave) * 49152;
-            const f32x4 shf = *reinterpret_cast<const f32x4 *>(net.ws_shift + layer * 64 + wave * 16 + lg * 4);
-            const float down = net.w1_down[layer];
-            int exw = C::EX_OFF + wave * 4096 + lane * 16, exr = C::EX_OFF + wave * 1024 + lane * 16;
-            asm volatile("" : "+v"(exw), "+v"(exr));
-            if (layer == 0) {
-                // a group's first layer: nothing was prepared under a previous layer - V rows 0 and 1, the cells of row 2
-                // (cursors: set at the top of the group)
-                static_for<8>([&](auto I_) { rd(IN_, I_); });
-                static_for<16>([&](auto I_) { tr(std::integral_constant<int, 0>{}, I_); });
-                static_for<8>([&](auto I_) { rd(IN_, I_); });
-                static_for<16>([&](auto I_) { tr(std::integral_constant<int, 1>{}, I_); });
-                static_for<8>([&](auto I_) { rd(IN_, I_); });
-            }
-            // this layer's taps 1 and 2 must have arrived (requested in that order; behind them: tap 0's 16 requests, the shift)
-            asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
-            // exchange + epilogue of a row: PREV = row 8 of the previous layer (output buffer = this layer's input, the other
-            // residual flag, constants pshf / pdown, cells at row 8), else row Y of this layer (cells at curO / curR)
-            auto epi = [&](auto PREV_, auto Y_, auto I_) __attribute__((always_inline)) {
-                constexpr bool PREV = decltype(PREV_)::value;
-                constexpr int y = decltype(Y_)::value, i = decltype(I_)::value;
-                constexpr int par = PREV ? (8 + 1 - PAR) & 1 : (y + PAR) & 1;
-                constexpr int OB = PREV ? IN : OUT;
-                constexpr bool RS = PREV ? !RES : RES;
-                if constexpr (i < 4) {
-                    lds_f32x4_put<par * 16384 + i * 1024>(exw, acc[par][i]);
-                } else if constexpr (i == 13) {
-                    if constexpr (RS) {
-                        eres[0] = lds_f32x4_at<OB>(PREV ? pR0 : curR0);
-                        eres[1] = lds_f32x4_at<OB>(PREV ? pR1 : curR1);
-                    }
-                    if constexpr (!PREV) { curR0 += strR0; curR1 += strR1; }   // (also without a residual: the next layer's deferred row needs them at row 8)
-                } else if constexpr (i == 10) {
-                    __syncthreads();
-                } else if constexpr (i == 11 || i == 12) {
-                    ez[2 * (i - 11)] = lds_f32x4_at<par * 16384 + (2 * (i - 11)) * 4096>(exr);
-                    ez[2 * (i - 11) + 1] = lds_f32x4_at<par * 16384 + (2 * (i - 11) + 1) * 4096>(exr);
-                } else if constexpr (i >= 19 && i < 35) {
-                    constexpr int k = i - 19, cc = k >> 3, e = (k >> 1) & 3, part = k & 1;
-                    if constexpr (part == 0) {
-                        ev[cc][e] = cc == 0 ? (ez[0][e] + ez[1][e]) + ez[2][e] : (ez[1][e] - ez[2][e]) - ez[3][e];
-                    } else {
-                        float tt = fmaf(ev[cc][e], PREV ? pdown : down, PREV ? pshf[e] : shf[e]);
-                        if constexpr (RS) tt += eres[cc][e];
-                        ev[cc][e] = fmaxf(tt, 0.f);
-                    }
-                } else if constexpr (i == 35) {
-                    amax = fmaxf(fmaxf(amax, ev[0][0]), ev[0][1]);
-                    amax = fmaxf(fmaxf(amax, ev[0][2]), ev[0][3]);
-                    lds_f32x4_put<OB>(PREV ? pO0 : curO0, ev[0]);
-                    if constexpr (!PREV) curO0 += strO0;
-                } else if constexpr (i == 36) {
-                    amax = fmaxf(fmaxf(amax, ev[1][0]), ev[1][1]);
-                    amax = fmaxf(fmaxf(amax, ev[1][2]), ev[1][3]);
-                    lds_f32x4_put<OB>(PREV ? pO1 : curO1, ev[1]);
-                    if constexpr (!PREV) curO1 += strO1;
+        if constexpr (G == 1) {
+            // ================= one board per workgroup: MFMA column u = 5 yi + t, row tile j = output rows 3j + yi =================
+            // Same arithmetic per output as the three-board variant below, in the same order (taps ky = 0, 1, 2 - rows outside the
+            // board contribute exact zeros instead of being skipped; k-chunks; cross terms first): results do not depend on which of
+            // the two a position went through.  A row tile needs three V rows per lane (input rows 3j + yi - 1 .. + 1), none shared
+            // with the next row tile: 120 VALU of input transform per 72 MFMAs instead of 40.
+            int gli = li, glg = lg;
+            asm volatile("" : "+v"(gli), "+v"(glg));                  // (not to be hoisted out of the group loop)
+            const int uyi = gli / 5, ut = gli - 5 * uyi;
+            const bool uv = gli < 15;
+            const int xa = wave == 0 ? 2 * ut - 1 : (wave == 2 ? 2 * ut + 1 : 2 * ut);
+            const int xb = wave == 0 ? 2 * ut + 1 : (wave == 1 ? 2 * ut + 1 : (wave == 2 ? 2 * ut : 2 * ut + 2));
+            // cell (row 3j + yi + q, column x) at row tile 0: address (may lie above the image: q = -1, yi = 0 - never read), stride per row tile
+            auto cell1 = [&](int x, int q, int chunk, int invalid_rel, int &adr, int &str) {
+                const bool ok = uv && x >= 0 && x < 9;
+                const int r0 = uyi + q, rm = (r0 + 3) % 3;
+                const int g = ((((ok ? x : 0) + 1) >> 1) + 5 * rm) & 7, sw = (g & 1) | ((g & 6) << 1);
+                adr = ok ? (9 * r0 + x) * 256 + ((chunk ^ sw) << 4) : invalid_rel + (chunk << 4);
+                str = ok ? 27 * 256 : 0;
+            };
+            int cA[3], cB[3], sA, sB, sdummy, curO0, curO1, curR0, curR1, strO0, strO1, strR0, strR1;
+            cell1(xa, -1, glg * 2, C::ZERO_REL, cA[0], sA);
+            cell1(xa, 0, glg * 2, C::ZERO_REL, cA[1], sdummy);
+            cell1(xa, 1, glg * 2, C::ZERO_REL, cA[2], sdummy);
+            cell1(xb, -1, glg * 2, C::ZERO_REL, cB[0], sB);
+            cell1(xb, 0, glg * 2, C::ZERO_REL, cB[1], sdummy);
+            cell1(xb, 1, glg * 2, C::ZERO_REL, cB[2], sdummy);
+            cell1(2 * ut, 0, wave * 4 + glg, C::DUMP_REL, curO0, strO0);
+            cell1(2 * ut + 1, 0, wave * 4 + glg, C::DUMP_REL, curO1, strO1);
+            cell1(2 * ut, 0, wave * 4 + glg, C::ZERO_REL, curR0, strR0);
+            cell1(2 * ut + 1, 0, wave * 4 + glg, C::ZERO_REL, curR1, strR1);
+            const int zeroA = C::ZERO_REL + ((glg * 2) << 4);          // a cell of a row outside the board
+            f32x4 dq[2][2][2];
+            i32x4v vh[2][3][2], vl[2][3][2];                           // [row tile parity][q + 1][kc]
+            f32x4 acc[2][4];
+            f32x4 ez[4], eres[2], ev[2];
+            float tvv[4];
+            unsigned thh[2];
+            // one of the eight cell reads of (row tile J, relative row Q)
+            auto rd = [&](auto IN_, auto J_, auto Q_, auto I_) __attribute__((always_inline)) {
+                constexpr int IN = decltype(IN_)::value, j = decltype(J_)::value, qi = decltype(Q_)::value, i = decltype(I_)::value;
+                constexpr int cb = i >> 2, kc = (i >> 1) & 1, h = i & 1;
+                int a = (cb ? cB[qi] + j * sB : cA[qi] + j * sA);
+                if constexpr (j == 0 && qi == 0) a = uyi == 0 ? zeroA : a;        // row -1
+                if constexpr (j == 2 && qi == 2) a = uyi == 2 ? zeroA : a;        // row 9
+                dq[cb][kc][h] = lds_f32x4_at<IN>(a ^ ((kc << 7) | (h << 4)));
+            };
+            // sub-step I (0 .. 15) of the input transform of relative row Q into V buffer P
+            auto tr = [&](auto P_, auto Q_, auto I_) __attribute__((always_inline)) {
+                constexpr int pb = decltype(P_)::value, qi = decltype(Q_)::value, i = decltype(I_)::value, kc = i >> 3, h = (i >> 2) & 1, q = i & 3;
+                if constexpr (q == 0) {
+                    tvv[0] = fmaf(dq[1][kc][h][0], sgn, dq[0][kc][h][0]);
+                    tvv[1] = fmaf(dq[1][kc][h][1], sgn, dq[0][kc][h][1]);
+                } else if constexpr (q == 1) {
+                    tvv[2] = fmaf(dq[1][kc][h][2], sgn, dq[0][kc][h][2]);
+                    tvv[3] = fmaf(dq[1][kc][h][3], sgn, dq[0][kc][h][3]);
+                } else if constexpr (q == 2) {
+                    thh[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{tvv[0], tvv[1]}, f16x2));
+                    vh[pb][qi][kc][2 * h] = (int)thh[0];
+                    vl[pb][qi][kc][2 * h] = (int)low_pieces(tvv[0], tvv[1], thh[0]);
+                } else {
+                    thh[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{tvv[2], tvv[3]}, f16x2));
+                    vh[pb][qi][kc][2 * h + 1] = (int)thh[1];
+                    vl[pb][qi][kc][2 * h + 1] = (int)low_pieces(tvv[2], tvv[3], thh[1]);
                 }
             };
-            static_for<9>([&](auto Y_) {
-                constexpr int y = decltype(Y_)::value, par = (y + PAR) & 1;
-                constexpr int NT = (y == 0 || y == 8) ? 2 : 3, NM = 24 * NT, KY0 = y == 0 ? 1 : 0;
+            auto layer_fn = [&](auto IN_, auto OUT_, auto RES_, int layer) __attribute__((always_inline)) {
+                constexpr int OUT = decltype(OUT_)::value;
+                constexpr bool RES = decltype(RES_)::value;
+                constexpr int PAR = RES ? 1 : 0;
+                constexpr int S1 = PAR ? 3 : 1, S1N = PAR ? 1 : 3;
+                const int next_layer = layer + 1 < kTowerLayers ? layer + 1 : 0;
+                const unsigned char *wnext = net.w1_w + ((size_t)next_layer * 4 + wave) * 49152;
+                const f32x4 shf = *reinterpret_cast<const f32x4 *>(net.ws_shift + layer * 64 + wave * 16 + lg * 4);
+                const float down = net.w1_down[layer];
+                int exw = C::EX_OFF + wave * 4096 + lane * 16, exr = C::EX_OFF + wave * 1024 + lane * 16;
+                asm volatile("" : "+v"(exw), "+v"(exr));
+                // prologue: the three V rows of row tile 0, the first cells of row tile 1
+                static_for<3>([&](auto Q_) {
+                    static_for<8>([&](auto I_) { rd(IN_, std::integral_constant<int, 0>{}, Q_, I_); });
+                    static_for<16>([&](auto I_) { tr(std::integral_constant<int, PAR>{}, Q_, I_); });
+                });
+                static_for<8>([&](auto I_) { rd(IN_, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, I_); });
+                // taps 1 and 0 must have arrived (requested in that order; behind them tap 2's 16 requests and the shift)
+                asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+                auto epi = [&](auto J_, auto I_) __attribute__((always_inline)) {          // exchange + epilogue of row tile J
+                    constexpr int j = decltype(J_)::value, i = decltype(I_)::value, par = (j + PAR) & 1;
+                    if constexpr (i < 4) {
+                        lds_f32x4_put<par * 16384 + i * 1024>(exw, acc[par][i]);
+                    } else if constexpr (i == 10) {
+                        __syncthreads();
+                    } else if constexpr (i == 11 || i == 12) {
+                        ez[2 * (i - 11)] = lds_f32x4_at<par * 16384 + (2 * (i - 11)) * 4096>(exr);
+                        ez[2 * (i - 11) + 1] = lds_f32x4_at<par * 16384 + (2 * (i - 11) + 1) * 4096>(exr);
+                    } else if constexpr (i == 13) {
+                        if constexpr (RES) {
+                            eres[0] = lds_f32x4_at<OUT>(curR0 + j * strR0);
+                            eres[1] = lds_f32x4_at<OUT>(curR1 + j * strR1);
+                        }
+                    } else if constexpr (i >= 19 && i < 35) {
+                        constexpr int k = i - 19, cc = k >> 3, e = (k >> 1) & 3, part = k & 1;
+                        if constexpr (part == 0) {
+                            ev[cc][e] = cc == 0 ? (ez[0][e] + ez[1][e]) + ez[2][e] : (ez[1][e] - ez[2][e]) - ez[3][e];
+                        } else {
+                            float tt = fmaf(ev[cc][e], down, shf[e]);
+                            if constexpr (RES) tt += eres[cc][e];
+                            ev[cc][e] = fmaxf(tt, 0.f);
+                        }
+                    } else if constexpr (i == 35) {
+                        amax = fmaxf(fmaxf(amax, ev[0][0]), ev[0][1]);
+                        amax = fmaxf(fmaxf(amax, ev[0][2]), ev[0][3]);
+                        lds_f32x4_put<OUT>(curO0 + j * strO0, ev[0]);
+                    } else if constexpr (i == 36) {
+                        amax = fmaxf(fmaxf(amax, ev[1][0]), ev[1][1]);
+                        amax = fmaxf(fmaxf(amax, ev[1][2]), ev[1][3]);
+                        lds_f32x4_put<OUT>(curO1 + j * strO1, ev[1]);
+                    }
+                };
+                static_for<3>([&](auto J_) {
+                    constexpr int j = decltype(J_)::value, par = (j + PAR) & 1, nb = 1 - par;
+                    static_for<72>([&](auto M_) {
+                        constexpr int m = decltype(M_)::value, ky = m / 24, q = m % 24, kc = q / 12, st = (q / 4) % 3, c = q % 4;
+                        constexpr int slot = ky == 1 ? S1 : ky;
+                        if constexpr (j == 0 && m == 48) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tap 2 (and the shift)
+                        if constexpr (st == 0)
+                            acc[par][c] = mfma16<F>(ua[slot][kc][1][c], vh[par][ky][kc], m < 4 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[par][c]);
+                        else if constexpr (st == 1) acc[par][c] = mfma16<F>(ua[slot][kc][0][c], vl[par][ky][kc], acc[par][c]);
+                        else acc[par][c] = mfma16<F>(ua[slot][kc][0][c], vh[par][ky][kc], acc[par][c]);
+                        // ---- what rides along: epilogue of the previous row tile, V rows of the next one ----
+                        if constexpr (j >= 1 && m < 37) epi(std::integral_constant<int, j - 1>{}, M_);
+                        if constexpr (j <= 1) {
+                            using JN = std::integral_constant<int, j + 1>;
+                            using NB = std::integral_constant<int, nb>;
+                            if constexpr (m < 8) { tr(NB{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 2 * m>{}); tr(NB{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 2 * m + 1>{}); }
+                            if constexpr (m >= 10 && m < 18) rd(IN_, JN{}, std::integral_constant<int, 1>{}, std::integral_constant<int, m - 10>{});
+                            if constexpr (m >= 24 && m < 32) { tr(NB{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 2 * (m - 24)>{}); tr(NB{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 2 * (m - 24) + 1>{}); }
+                            if constexpr (m >= 34 && m < 42) rd(IN_, JN{}, std::integral_constant<int, 2>{}, std::integral_constant<int, m - 34>{});
+                            if constexpr (m >= 48 && m < 56) { tr(NB{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 2 * (m - 48)>{}); tr(NB{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 2 * (m - 48) + 1>{}); }
+                            if constexpr (j == 0 && m >= 58 && m < 66) rd(IN_, std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, m - 58>{});
+                        }
+                        // next layer's weights: tap 1 into the spare slot under row tiles 0 and 1, tap 0 behind row tile 2's tap-0 MFMAs
+                        if constexpr (j <= 1 && m >= 44 && m < 68 && (m - 44) % 3 == 0) {
+                            constexpr int f = j * 8 + (m - 44) / 3;
+                            w1_request<S1N>(ua, wnext + 16384, wlane, std::integral_constant<int, f>{});
+                        }
+                        if constexpr (j == 2 && m >= 40 && m < 72 && m % 2 == 0) w1_request<0>(ua, wnext, wlane, std::integral_constant<int, (m - 40) / 2>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                });
+                // ... tap 2 behind the last MFMA; row tile 2's exchange + epilogue on their own
+                w1_request_tap<2>(ua, wnext + 2 * 16384, wlane);
+                static_for<37>([&](auto I_) { epi(std::integral_constant<int, 2>{}, I_); });
+                if (!(amax < (float)kWsRangeLimit)) ovf = 1;
+                __syncthreads();
+                stamp();
+            };
+            using IX = std::integral_constant<int, C::X_OFF>;
+            using IH = std::integral_constant<int, C::H_OFF>;
+            if (!(amax < (float)kWsRangeLimit)) ovf = 1;
+#pragma unroll 1
+            for (int blk = 0; blk < kBlocks; ++blk) {
+                layer_fn(IX{}, IH{}, std::false_type{}, 2 * blk);
+                layer_fn(IH{}, IX{}, std::true_type{}, 2 * blk + 1);
+            }
+        } else {
+            // ---- per-lane geometry: MFMA column u = 5 board + t (15 = padding), k-group lg; wave = transform point
+            // (per group, behind the stem: kept alive through stem and heads these twelve registers spill) ----
+            int gli = li, glg = lg;
+            asm volatile("" : "+v"(gli), "+v"(glg));                  // (not to be hoisted out of the group loop)
+            const int ub = gli / 5, ut = gli - 5 * ub;
+            const bool uv = gli < 15;
+            // the two cells of point `wave`: V = d[xa] + sgn d[xb]
+            const int xa = wave == 0 ? 2 * ut - 1 : (wave == 2 ? 2 * ut + 1 : 2 * ut);
+            const int xb = wave == 0 ? 2 * ut + 1 : (wave == 1 ? 2 * ut + 1 : (wave == 2 ? 2 * ut : 2 * ut + 2));
+            auto cell = [&](int x, int chunk, int invalid_rel, int &adr, int &str) {
+                const bool ok = uv && x >= 0 && x < 9;
+                const int R0 = 81 * ub + (ok ? x : 0);
+                adr = ok ? R0 * 256 + ((chunk ^ w1_swz(R0)) << 4) : invalid_rel + (chunk << 4);
+                str = ok ? 9 * 256 : 0;
+            };
+            int curA, strA, curB, strB, curO0, strO0, curO1, strO1, curR0, curR1, strR0, strR1;      // cursors (row 0) and row strides
+            cell(xa, glg * 2, C::ZERO_REL, curA, strA);
+            cell(xb, glg * 2, C::ZERO_REL, curB, strB);
+            cell(2 * ut, wave * 4 + glg, C::DUMP_REL, curO0, strO0);        // stores of the channels 16 wave + 4 lg ..
+            cell(2 * ut + 1, wave * 4 + glg, C::DUMP_REL, curO1, strO1);
+            cell(2 * ut, wave * 4 + glg, C::ZERO_REL, curR0, strR0);        // residual reads (outside the board: zeros)
+            cell(2 * ut + 1, wave * 4 + glg, C::ZERO_REL, curR1, strR1);
+            f32x4 dq[2][2][2];                                     // cells read ahead: [cell a / b][kc][channel half]
+            i32x4v vh[5][2], vl[5][2];                             // V rows: slot 4 = row 0, slot r & 3 = rows 1 .. 8; [kc]
+            f32x4 acc[2][4];                                       // [row parity][channel tile]
+            f32x4 ez[4], eres[2], ev[2];
+            float tvv[4];
+            unsigned thh[2];
+            auto vslot = [](int r) constexpr { return r == 0 ? 4 : (r & 3); };
+            auto rd = [&](auto IN_, auto I_) __attribute__((always_inline)) {          // one of the eight cell reads of the row at curA / curB
+                constexpr int IN = decltype(IN_)::value, i = decltype(I_)::value, cb = i >> 2, kc = (i >> 1) & 1, h = i & 1;
+                const int a0 = (cb ? curB : curA) ^ ((kc << 7) | (h << 4));
+                dq[cb][kc][h] = lds_f32x4_at<IN>(a0);
+                if constexpr (i == 7) { curA += strA; curB += strB; }
+            };
+            // input transform of one row in 16 slices: per (kc, half) t = d_a + sgn d_b (2 x 2 values), high pieces, low pieces
+            auto tr = [&](auto R_, auto I_) __attribute__((always_inline)) {
+                constexpr int r = decltype(R_)::value, i = decltype(I_)::value, kc = i >> 3, h = (i >> 2) & 1, q = i & 3, s = vslot(r);
+                if constexpr (q == 0) {
+                    tvv[0] = fmaf(dq[1][kc][h][0], sgn, dq[0][kc][h][0]);
+                    tvv[1] = fmaf(dq[1][kc][h][1], sgn, dq[0][kc][h][1]);
+                } else if constexpr (q == 1) {
+                    tvv[2] = fmaf(dq[1][kc][h][2], sgn, dq[0][kc][h][2]);
+                    tvv[3] = fmaf(dq[1][kc][h][3], sgn, dq[0][kc][h][3]);
+                } else if constexpr (q == 2) {
+                    thh[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{tvv[0], tvv[1]}, f16x2));
+                    vh[s][kc][2 * h] = (int)thh[0];
+                    vl[s][kc][2 * h] = (int)low_pieces(tvv[0], tvv[1], thh[0]);
+                } else {
+                    thh[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{tvv[2], tvv[3]}, f16x2));
+                    vh[s][kc][2 * h + 1] = (int)thh[1];
+                    vl[s][kc][2 * h + 1] = (int)low_pieces(tvv[2], tvv[3], thh[1]);
+                }
+            };
+            f32x4 pshf = f32x4{0.f, 0.f, 0.f, 0.f};                // the previous layer's epilogue constants (its row 8 rides in this layer's row 0)
+            float pdown = 0.f;
+            int pO0 = C::DUMP_REL + (lane * 16) % 256, pO1 = pO0, pR0 = C::ZERO_REL + (lane * 16) % 256, pR1 = pR0;   // its row-8 cells (layer 0: dump / zero rows)
+            // Schedule of a row's slices (one MFMA each + what rides along):  0-15 input transform of row y + 2 | 0-3 exchange
+            // writes of row y - 1, 10 barrier, 11-12 exchange reads, 13 residual reads, 19-34 sums / shift / residual / ReLU,
+            // 35-36 stores | 37-44 cell reads of row y + 3 | from 46: weight requests.  Row 8's exchange + epilogue ride in the
+            // NEXT layer's row 0 (layer 0: a null epilogue - zero accumulators, zero constants, dump-row stores); the next layer's
+            // V rows 0 and 1 are transformed under rows 7 and 8 (its input rows 0 - 2 are complete since row 3).  No barrier at
+            // the layer boundary: between a store and any other wave's read of it lies at least one row barrier.
+            auto layer_fn = [&](auto IN_, auto OUT_, auto RES_, int layer) __attribute__((always_inline)) {
+                constexpr int IN = decltype(IN_)::value, OUT = decltype(OUT_)::value;
+                constexpr bool RES = decltype(RES_)::value;
+                constexpr int PAR = RES ? 1 : 0;                   // conv2 of a block = odd layer
+                constexpr int S1 = PAR ? 3 : 1, S1N = PAR ? 1 : 3; // AGPR slot of tap ky = 1 in this / the next layer (taps 0, 2: slots 0, 2)
+                const int next_layer = layer + 1 < kTowerLayers ? layer + 1 : 0;
+                const unsigned char *wnext = net.w1_w + ((size_t)next_layer * 4 + wave) * 49152;
+                const f32x4 shf = *reinterpret_cast<const f32x4 *>(net.ws_shift + layer * 64 + wave * 16 + lg * 4);
+                const float down = net.w1_down[layer];
+                int exw = C::EX_OFF + wave * 4096 + lane * 16, exr = C::EX_OFF + wave * 1024 + lane * 16;
+                asm volatile("" : "+v"(exw), "+v"(exr));
+                if (layer == 0) {
+                    // a group's first layer: nothing was prepared under a previous layer - V rows 0 and 1, the cells of row 2
+                    // (cursors: set at the top of the group)
+                    static_for<8>([&](auto I_) { rd(IN_, I_); });
+                    static_for<16>([&](auto I_) { tr(std::integral_constant<int, 0>{}, I_); });
+                    static_for<8>([&](auto I_) { rd(IN_, I_); });
+                    static_for<16>([&](auto I_) { tr(std::integral_constant<int, 1>{}, I_); });
+                    static_for<8>([&](auto I_) { rd(IN_, I_); });
+                }
+                // this layer's taps 1 and 2 must have arrived (requested in that order; behind them: tap 0's 16 requests, the shift)
+                asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+                // exchange + epilogue of a row: PREV = row 8 of the previous layer (output buffer = this layer's input, the other
+                // residual flag, constants pshf / pdown, cells at row 8), else row Y of this layer (cells at curO / curR)
+                auto epi = [&](auto PREV_, auto Y_, auto I_) __attribute__((always_inline)) {
+                    constexpr bool PREV = decltype(PREV_)::value;
+                    constexpr int y = decltype(Y_)::value, i = decltype(I_)::value;
+                    constexpr int par = PREV ? (8 + 1 - PAR) & 1 : (y + PAR) & 1;
+                    constexpr int OB = PREV ? IN : OUT;
+                    constexpr bool RS = PREV ? !RES : RES;
+                    if constexpr (i < 4) {
+                        lds_f32x4_put<par * 16384 + i * 1024>(exw, acc[par][i]);
+                    } else if constexpr (i == 13) {
+                        if constexpr (RS) {
+                            eres[0] = lds_f32x4_at<OB>(PREV ? pR0 : curR0);
+                            eres[1] = lds_f32x4_at<OB>(PREV ? pR1 : curR1);
+                        }
+                        if constexpr (!PREV) { curR0 += strR0; curR1 += strR1; }   // (also without a residual: the next layer's deferred row needs them at row 8)
+                    } else if constexpr (i == 10) {
+                        __syncthreads();
+                    } else if constexpr (i == 11 || i == 12) {
+                        ez[2 * (i - 11)] = lds_f32x4_at<par * 16384 + (2 * (i - 11)) * 4096>(exr);
+                        ez[2 * (i - 11) + 1] = lds_f32x4_at<par * 16384 + (2 * (i - 11) + 1) * 4096>(exr);
+                    } else if constexpr (i >= 19 && i < 35) {
+                        constexpr int k = i - 19, cc = k >> 3, e = (k >> 1) & 3, part = k & 1;
+                        if constexpr (part == 0) {
+                            ev[cc][e] = cc == 0 ? (ez[0][e] + ez[1][e]) + ez[2][e] : (ez[1][e] - ez[2][e]) - ez[3][e];
+                        } else {
+                            float tt = fmaf(ev[cc][e], PREV ? pdown : down, PREV ? pshf[e] : shf[e]);
+                            if constexpr (RS) tt += eres[cc][e];
+                            ev[cc][e] = fmaxf(tt, 0.f);
+                        }
+                    } else if constexpr (i == 35) {
+                        amax = fmaxf(fmaxf(amax, ev[0][0]), ev[0][1]);
+                        amax = fmaxf(fmaxf(amax, ev[0][2]), ev[0][3]);
+                        lds_f32x4_put<OB>(PREV ? pO0 : curO0, ev[0]);
+                        if constexpr (!PREV) curO0 += strO0;
+                    } else if constexpr (i == 36) {
+                        amax = fmaxf(fmaxf(amax, ev[1][0]), ev[1][1]);
+                        amax = fmaxf(fmaxf(amax, ev[1][2]), ev[1][3]);
+                        lds_f32x4_put<OB>(PREV ? pO1 : curO1, ev[1]);
+                        if constexpr (!PREV) curO1 += strO1;
+                    }
+                };
+                static_for<9>([&](auto Y_) {
+                    constexpr int y = decltype(Y_)::value, par = (y + PAR) & 1;
+                    constexpr int NT = (y == 0 || y == 8) ? 2 : 3, NM = 24 * NT, KY0 = y == 0 ? 1 : 0;
+                    if constexpr (PROF)
+                        if (blockIdx.x == 0 && tid == 0 && (layer == 2 || layer == 3) && grp == (int)blockIdx.x)
+                            net.timeline[40 + 12 * (layer - 2) + y] = (long long)__builtin_amdgcn_s_memtime();
+                    if constexpr (y == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // tap 0 (and the shift)
+                    if constexpr (y == 6) { curA -= 9 * strA; curB -= 9 * strB; }              // from here on: the next layer's rows 0 .. 2
+                    static_for<NM>([&](auto M_) {
+                        constexpr int m = decltype(M_)::value, ti = m / 24, q = m % 24, kc = q / 12, st = (q / 4) % 3, c = q % 4;
+                        constexpr int ky = KY0 + ti, r = y + ky - 1, s = vslot(r), slot = ky == 1 ? S1 : ky;
+                        if constexpr (st == 0)
+                            acc[par][c] = mfma16<F>(ua[slot][kc][1][c], vh[s][kc], m < 4 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[par][c]);
+                        else if constexpr (st == 1) acc[par][c] = mfma16<F>(ua[slot][kc][0][c], vl[s][kc], acc[par][c]);
+                        else acc[par][c] = mfma16<F>(ua[slot][kc][0][c], vh[s][kc], acc[par][c]);
+                        // ---- what rides along ----
+                        if constexpr (m < 37) {
+                            if constexpr (y == 0) epi(std::true_type{}, Y_, M_);
+                            else epi(std::false_type{}, std::integral_constant<int, y - 1>{}, M_);
+                        }
+                        if constexpr (m < 16) {
+                            if constexpr (y + 2 <= 8) tr(std::integral_constant<int, y + 2>{}, M_);
+                            else tr(std::integral_constant<int, y - 7>{}, M_);                  // rows 7 / 8: the next layer's V rows 0 / 1
+                        }
+                        if constexpr (m >= 37 && m < 45) {
+                            if constexpr (y + 3 <= 8) rd(IN_, std::integral_constant<int, m - 37>{});
+                            else rd(OUT_, std::integral_constant<int, m - 37>{});                // rows 6 .. 8: the next layer's rows 0 .. 2
+                        }
+                        // next layer's weights: tap 1 into the spare slot during rows 4 .. 6, tap 2 at the start of row 8 (its last use
+                        // was row 7), tap 0 behind row 8's tap-0 MFMAs
+                        if constexpr (y >= 4 && y <= 6 && m >= 46 && m < 64 && (m - 46) % 3 == 0) {
+                            constexpr int f = (y - 4) * 6 + (m - 46) / 3;                      // 0 .. 17
+                            if constexpr (f < 16) w1_request<S1N>(ua, wnext + 16384, wlane, std::integral_constant<int, f>{});
+                        }
+                        if constexpr (y == 8 && m < 32 && m % 2 == 1)
+                            w1_request<2>(ua, wnext + 2 * 16384, wlane, std::integral_constant<int, m / 2>{});
+                        if constexpr (y == 8 && m >= 32) w1_request<0>(ua, wnext, wlane, std::integral_constant<int, m - 32>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                });
                 if constexpr (PROF)
                     if (blockIdx.x == 0 && tid == 0 && (layer == 2 || layer == 3) && grp == (int)blockIdx.x)
-                        net.timeline[40 + 12 * (layer - 2) + y] = (long long)__builtin_amdgcn_s_memtime();
-                if constexpr (y == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // tap 0 (and the shift)
-                if constexpr (y == 6) { curA -= 9 * strA; curB -= 9 * strB; }              // from here on: the next layer's rows 0 .. 2
-                static_for<NM>([&](auto M_) {
-                    constexpr int m = decltype(M_)::value, ti = m / 24, q = m % 24, kc = q / 12, st = (q / 4) % 3, c = q % 4;
-                    constexpr int ky = KY0 + ti, r = y + ky - 1, s = vslot(r), slot = ky == 1 ? S1 : ky;
-                    if constexpr (st == 0)
-                        acc[par][c] = mfma16<F>(ua[slot][kc][1][c], vh[s][kc], m < 4 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[par][c]);
-                    else if constexpr (st == 1) acc[par][c] = mfma16<F>(ua[slot][kc][0][c], vl[s][kc], acc[par][c]);
-                    else acc[par][c] = mfma16<F>(ua[slot][kc][0][c], vh[s][kc], acc[par][c]);
-                    // ---- what rides along ----
-                    if constexpr (m < 37) {
-                        if constexpr (y == 0) epi(std::true_type{}, Y_, M_);
-                        else epi(std::false_type{}, std::integral_constant<int, y - 1>{}, M_);
-                    }
-                    if constexpr (m < 16) {
-                        if constexpr (y + 2 <= 8) tr(std::integral_constant<int, y + 2>{}, M_);
-                        else tr(std::integral_constant<int, y - 7>{}, M_);                  // rows 7 / 8: the next layer's V rows 0 / 1
-                    }
-                    if constexpr (m >= 37 && m < 45) {
-                        if constexpr (y + 3 <= 8) rd(IN_, std::integral_constant<int, m - 37>{});
-                        else rd(OUT_, std::integral_constant<int, m - 37>{});                // rows 6 .. 8: the next layer's rows 0 .. 2
-                    }
-                    // next layer's weights: tap 1 into the spare slot during rows 4 .. 6, tap 2 at the start of row 8 (its last use
-                    // was row 7), tap 0 behind row 8's tap-0 MFMAs
-                    if constexpr (y >= 4 && y <= 6 && m >= 46 && m < 64 && (m - 46) % 3 == 0) {
-                        constexpr int f = (y - 4) * 6 + (m - 46) / 3;                      // 0 .. 17
-                        if constexpr (f < 16) w1_request<S1N>(ua, wnext + 16384, wlane, std::integral_constant<int, f>{});
-                    }
-                    if constexpr (y == 8 && m < 32 && m % 2 == 1)
-                        w1_request<2>(ua, wnext + 2 * 16384, wlane, std::integral_constant<int, m / 2>{});
-                    if constexpr (y == 8 && m >= 32) w1_request<0>(ua, wnext, wlane, std::integral_constant<int, m - 32>{});
-                    __builtin_amdgcn_sched_barrier(0);
-                });
-            });
-            if constexpr (PROF)
-                if (blockIdx.x == 0 && tid == 0 && (layer == 2 || layer == 3) && grp == (int)blockIdx.x)
-                    net.timeline[40 + 12 * (layer - 2) + 9] = (long long)__builtin_amdgcn_s_memtime();
-            pshf = shf;
-            pdown = down;
-            // the cursors stand at row 8 (eight rows stored): that is where the deferred epilogue goes; back to row 0 for the next layer
-            pO0 = curO0; pO1 = curO1; pR0 = curR0; pR1 = curR1;
-            curO0 -= 8 * strO0; curO1 -= 8 * strO1; curR0 -= 8 * strR0; curR1 -= 8 * strR1;
-            if (!(amax < (float)kWsRangeLimit)) ovf = 1;            // f16 range guard (also catches NaN)
-            stamp();
-        };
-        using IX = std::integral_constant<int, C::X_OFF>;
-        using IH = std::integral_constant<int, C::H_OFF>;
-        if (!(amax < (float)kWsRangeLimit)) ovf = 1;
-        // row 8's cells (the deferred epilogue) and layer 0's null epilogue
-        {
-            float z0, z1, z2, z3;
-            asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0" : "=v"(z0), "=v"(z1), "=v"(z2), "=v"(z3));
-            pshf = f32x4{z0, z1, z2, z3};
-            pdown = 0.f;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[1][c] = pshf;
-        }
-#pragma unroll 1
-        for (int blk = 0; blk < kBlocks; ++blk) {
-            layer_fn(IX{}, IH{}, std::false_type{}, 2 * blk);
-            layer_fn(IH{}, IX{}, std::true_type{}, 2 * blk + 1);
-        }
-        {
-            // the tower's last row (layer 11, output X, residual): on its own
-            const int exw = C::EX_OFF + wave * 4096 + lane * 16, exr = C::EX_OFF + wave * 1024 + lane * 16;
-            constexpr int par = (8 + 1) & 1;
-            static_for<4>([&](auto I_) { lds_f32x4_put<par * 16384 + decltype(I_)::value * 1024>(exw, acc[par][decltype(I_)::value]); });
-            eres[0] = lds_f32x4_at<C::X_OFF>(pR0);
-            eres[1] = lds_f32x4_at<C::X_OFF>(pR1);
-            __syncthreads();
-            static_for<4>([&](auto I_) { ez[decltype(I_)::value] = lds_f32x4_at<par * 16384 + decltype(I_)::value * 4096>(exr); });
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float o0 = (ez[0][e] + ez[1][e]) + ez[2][e], o1 = (ez[1][e] - ez[2][e]) - ez[3][e];
-                ev[0][e] = fmaxf(fmaf(o0, pdown, pshf[e]) + eres[0][e], 0.f);
-                ev[1][e] = fmaxf(fmaf(o1, pdown, pshf[e]) + eres[1][e], 0.f);
-                amax = fmaxf(fmaxf(amax, ev[0][e]), ev[1][e]);
-            }
-            lds_f32x4_put<C::X_OFF>(pO0, ev[0]);
-            lds_f32x4_put<C::X_OFF>(pO1, ev[1]);
+                        net.timeline[40 + 12 * (layer - 2) + 9] = (long long)__builtin_amdgcn_s_memtime();
+                pshf = shf;
+                pdown = down;
+                // the cursors stand at row 8 (eight rows stored): that is where the deferred epilogue goes; back to row 0 for the next layer
+                pO0 = curO0; pO1 = curO1; pR0 = curR0; pR1 = curR1;
+                curO0 -= 8 * strO0; curO1 -= 8 * strO1; curR0 -= 8 * strR0; curR1 -= 8 * strR1;
+                if (!(amax < (float)kWsRangeLimit)) ovf = 1;            // f16 range guard (also catches NaN)
+                stamp();
+            };
+            using IX = std::integral_constant<int, C::X_OFF>;
+            using IH = std::integral_constant<int, C::H_OFF>;
             if (!(amax < (float)kWsRangeLimit)) ovf = 1;
-            __syncthreads();
+            // row 8's cells (the deferred epilogue) and layer 0's null epilogue
+            {
+                float z0, z1, z2, z3;
+                asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0" : "=v"(z0), "=v"(z1), "=v"(z2), "=v"(z3));
+                pshf = f32x4{z0, z1, z2, z3};
+                pdown = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[1][c] = pshf;
+            }
+#pragma unroll 1
+            for (int blk = 0; blk < kBlocks; ++blk) {
+                layer_fn(IX{}, IH{}, std::false_type{}, 2 * blk);
+                layer_fn(IH{}, IX{}, std::true_type{}, 2 * blk + 1);
+            }
+            {
+                // the tower's last row (layer 11, output X, residual): on its own
+                const int exw = C::EX_OFF + wave * 4096 + lane * 16, exr = C::EX_OFF + wave * 1024 + lane * 16;
+                constexpr int par = (8 + 1) & 1;
+                static_for<4>([&](auto I_) { lds_f32x4_put<par * 16384 + decltype(I_)::value * 1024>(exw, acc[par][decltype(I_)::value]); });
+                eres[0] = lds_f32x4_at<C::X_OFF>(pR0);
+                eres[1] = lds_f32x4_at<C::X_OFF>(pR1);
+                __syncthreads();
+                static_for<4>([&](auto I_) { ez[decltype(I_)::value] = lds_f32x4_at<par * 16384 + decltype(I_)::value * 4096>(exr); });
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float o0 = (ez[0][e] + ez[1][e]) + ez[2][e], o1 = (ez[1][e] - ez[2][e]) - ez[3][e];
+                    ev[0][e] = fmaxf(fmaf(o0, pdown, pshf[e]) + eres[0][e], 0.f);
+                    ev[1][e] = fmaxf(fmaf(o1, pdown, pshf[e]) + eres[1][e], 0.f);
+                    amax = fmaxf(fmaxf(amax, ev[0][e]), ev[1][e]);
+                }
+                lds_f32x4_put<C::X_OFF>(pO0, ev[0]);
+                lds_f32x4_put<C::X_OFF>(pO1, ev[1]);
+                if (!(amax < (float)kWsRangeLimit)) ovf = 1;
+                __syncthreads();
+            }
         }
         // next group's input planes: requested here, consumed after the heads
         const int next = __builtin_amdgcn_readfirstlane(*ticket_lds);   // (written before the stem's barriers)
         fetch_planes(next);
-        run_heads_x32<G, C, 1>(smem, net, b0, batch, want_logits, policy, value, tid, wave, nullptr);
+        run_heads_x32<G, C, (G == 1 ? 2 : 1)>(smem, net, b0, batch, want_logits, policy, value, tid, wave, nullptr);
         __syncthreads();
         stamp();
         grp = next;
@@ -1262,17 +1440,17 @@ int launch_wsplit(tg_net *net, const float *planes, int batch, int want_logits, 
     return TG_OK;
 }
 
-template <bool PROF = false>
+template <int G, bool PROF = false>
 int launch_w1d(tg_net *net, const float *planes, int batch, int want_logits, float *policy, float *value,
                int *overflow, hipStream_t stream) {
-    using C = WsCfg<3>;
+    using C = WsCfg<G>;
     if (!PROF && net->dev.timeline)
-        return launch_w1d<true>(net, planes, batch, want_logits, policy, value, overflow, stream);
-    auto kern = dualnet_fwd_w1d_kernel<3, PROF>;
+        return launch_w1d<G, true>(net, planes, batch, want_logits, policy, value, overflow, stream);
+    auto kern = dualnet_fwd_w1d_kernel<G, PROF>;
     static std::atomic<uint64_t> configured{0};
     if (tg::first_on_device(configured, net->device))
         TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-    const int groups = (batch + 2) / 3;
+    const int groups = (batch + G - 1) / G;
     int grid = groups < net->num_cus ? groups : net->num_cus;
     if (net->forward_grid_cap > 0 && grid > net->forward_grid_cap) grid = net->forward_grid_cap;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTHR), C::LDS_BYTES, stream, net->dev, planes, batch, want_logits,
@@ -1486,10 +1664,11 @@ int w1d_prepare(tg_net *net, const float *const *tower, const float *scale) {
     return TG_OK;
 }
 
-int w1d_forward(tg_net *net, const float *planes, int batch, int want_logits, float *policy, float *value, int *overflow,
+int w1d_forward(tg_net *net, int group, const float *planes, int batch, int want_logits, float *policy, float *value, int *overflow,
                 hipStream_t stream) {
     if (net->board_size != 9) return tg::fail(TG_ERR_ARG, "w1d forward: 9x9 only");
-    return launch_w1d(net, planes, batch, want_logits, policy, value, overflow, stream);
+    if (group == 3) return launch_w1d<3>(net, planes, batch, want_logits, policy, value, overflow, stream);
+    return launch_w1d<1>(net, planes, batch, want_logits, policy, value, overflow, stream);
 }
 
 // group = boards per workgroup (1 or 3); 9x9 only.

@@ -48,6 +48,16 @@ def main():
             if bad and algo in ("wsplit", "w1d"):
                 d = (pol - rp).abs().amax(dim=1)
                 print("   boards over tolerance:", [int(i) for i in torch.nonzero(d > 1e-4).flatten()[:20]], "of", b)
+    # results must not depend on the launch size: the one-board and the three-board variants of a kernel family, bit for bit
+    x = torch.from_numpy(rs.randint(-1, 2, size=(600, 6, 9, 9)).astype(np.float32))
+    for algo in ALGOS:
+        net = net_for(algo, sd)
+        big = net.inference_with_policy_logits(x)
+        small = net.inference_with_policy_logits(x[:100])
+        one = net.inference_with_policy_logits(x[7:8])
+        same = torch.equal(big[0][:100], small[0]) and torch.equal(big[1][:100], small[1]) and torch.equal(big[0][7:8], one[0]) and torch.equal(big[1][7:8], one[1])
+        ok &= same
+        print(f"{algo:8s} 600-position launch vs 100 / 1 of the same positions: {'bit-identical' if same else 'DIFFERENT   <-- FAIL'}", flush=True)
     fix = load_npz("net_s9.npz")
     for seed in (0, 7):
         sdf = make_state_dict(9, seed, float(fix[f"w{seed}_gain"]))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-4 counter evidence, one call on the GPU box:  bash tools/pmc_r04.sh
-#   1. forward kernel (tools/bench_net.py 9 65536): SQ / LDS / L2 / HBM counters in separate --pmc passes
+#   1. forward kernels (tools/bench_net.py 9 65536; default = w1d, then wsplit / split16 / wino): SQ / LDS / L2 / HBM counters in separate --pmc passes
 #   2. tree kernels (bench.py --trees 2048, 3 steps): HBM-side and L2 bytes of select / backup / root / play
 #   3. stand-alone featurise kernel (tools/bench_featurize.py)
 #   4. kernel trace of the headline bench (--stats)
@@ -21,6 +21,16 @@ pass fwd_c "$FWD" FETCH_SIZE
 pass fwd_d "$FWD" WRITE_SIZE
 pass fwd_e "$FWD" TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_READ_sum
 pass fwd_f "$FWD" TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_BUSY_avr
+# the 2-D Winograd split kernel (TG_FWD_ALGO=wsplit: the 9x9 default of the first half of round 4) on the same batch
+export TG_FWD_ALGO=wsplit
+pass ws_a "$FWD" SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE
+pass ws_b "$FWD" SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
+pass ws_g "$FWD" SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU
+pass ws_c "$FWD" FETCH_SIZE
+pass ws_d "$FWD" WRITE_SIZE
+pass ws_e "$FWD" TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_READ_sum
+pass ws_f "$FWD" TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_BUSY_avr
+unset TG_FWD_ALGO
 # the direct split kernel (TG_FWD_ALGO=split16, the 9x9 default up to round 3) on the same batch
 export TG_FWD_ALGO=split16
 pass w2_a "$FWD" SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE

@@ -58,6 +58,9 @@ def main(out):
     per2, times2 = counters(out, ["w2_a", "w2_b", "w2_c", "w2_d", "w2_e", "w2_f"], ["dualnet_fwd_split_kernel<9"])
     per.update(per2)
     times.update(times2)
+    per4, times4 = counters(out, ["ws_a", "ws_b", "ws_c", "ws_d", "ws_e", "ws_f", "ws_g"], ["dualnet_fwd_wsplit"])
+    per.update(per4)
+    times.update(times4)
     per3, times3 = counters(out, ["wn_a", "wn_b", "wn_c", "wn_d", "wn_e", "wn_f"], ["dualnet_fwd_wino8"])
     per.update(per3)
     times.update(times3)
@@ -107,7 +110,7 @@ def main(out):
                 "tcc_busy_fraction": c.get("TCC_BUSY_avr", 0) / max(1.0, c["GRBM_GUI_ACTIVE"] / 8),
             },
         }
-        tag = "wsplit" if "wsplit" in kname else ("w2" if "w2" in kname else ("split" if "split" in kname else ("wino" if "wino" in kname else "direct")))
+        tag = "w1d" if "w1d" in kname else "wsplit" if "wsplit" in kname else ("w2" if "w2" in kname else ("split" if "split" in kname else ("wino" if "wino" in kname else "direct")))
         if "SQ_INSTS_VALU" in c:      # instruction mix per wave: the kernel is issue-bound
             waves = 4 * 256 * (positions // 3 // 256 + 1) * 0 + 1
             summary["derived"]["instructions_per_launch"] = {k: c[k] for k in c if k.startswith("SQ_INSTS_")}
