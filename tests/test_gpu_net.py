@@ -141,6 +141,22 @@ def test_every_tower_algorithm_matches_the_oracle(algo, size, monkeypatch):
         assert np.abs(val.numpy() - rv.numpy()).max() < TOL, (algo, b)
 
 
+@pytest.mark.parametrize("algo", ["w1d", "wsplit", "split16"])
+def test_results_do_not_depend_on_the_launch_size(algo, monkeypatch):
+    """A position's policy and value must come out the same bits whether it is evaluated alone, in a mini-batch of one-board
+    workgroups or deep inside a launch of three-board workgroups: self-play games would otherwise depend on how the boards
+    of a lock-step move are grouped (tests/test_gpu_fastpath.py::test_selfplay_move_schemes_play_the_same_games).  The one-
+    and three-board variants of each kernel family do the same arithmetic in the same order."""
+    from oracle.net import make_state_dict
+    monkeypatch.setenv("TG_FWD_ALGO", algo)
+    net = _net(9, make_state_dict(9, 5, 1.5))
+    x = torch.from_numpy(np.random.RandomState(3).randint(-1, 2, size=(1000, 6, 9, 9)).astype(np.float32))
+    big = net.inference_with_policy_logits(x)
+    for lo, hi in ((0, 100), (7, 8), (500, 756), (997, 1000)):
+        part = net.inference_with_policy_logits(x[lo:hi])
+        assert torch.equal(part[0], big[0][lo:hi]) and torch.equal(part[1], big[1][lo:hi]), (algo, lo, hi)
+
+
 def test_split_kernels_are_fp32_class_and_fall_back_on_f16_overflow(monkeypatch):
     """Accuracy of every 9x9 kernel against the reference's own fp64 forward (tests/golden/net_s9.npz):
     the split-operand kernels must be as close to fp64 as the reference's fp32 CPU path is (same
