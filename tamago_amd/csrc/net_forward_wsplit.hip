@@ -1044,8 +1044,8 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
             auto cell1 = [&](int x, int q, int chunk, int invalid_rel, int &adr, int &str) {
                 const bool ok = uv && x >= 0 && x < 9;
                 const int r0 = uyi + q, rm = (r0 + 3) % 3;
-                const int g = ((((ok ? x : 0) + 1) >> 1) + 5 * rm) & 7, sw = (g & 1) | ((g & 6) << 1);
-                adr = ok ? (9 * r0 + x) * 256 + ((chunk ^ sw) << 4) : invalid_rel + (chunk << 4);
+                const int g = (((x + 1) >> 1) + 5 * rm) & 7, sw = (g & 1) | ((g & 6) << 1);
+                adr = (ok ? (9 * r0 + x) * 256 : invalid_rel) + ((chunk ^ sw) << 4);
                 str = ok ? 27 * 256 : 0;
             };
             int cA[3], cB[3], sA, sB, sdummy, curO0, curO1, curR0, curR1, strO0, strO1, strR0, strR1;
@@ -1059,7 +1059,6 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
             cell1(2 * ut + 1, 0, wave * 4 + glg, C::DUMP_REL, curO1, strO1);
             cell1(2 * ut, 0, wave * 4 + glg, C::ZERO_REL, curR0, strR0);
             cell1(2 * ut + 1, 0, wave * 4 + glg, C::ZERO_REL, curR1, strR1);
-            const int zeroA = C::ZERO_REL + ((glg * 2) << 4);          // a cell of a row outside the board
             f32x4 dq[2][2][2];
             i32x4v vh[2][3][2], vl[2][3][2];                           // [row tile parity][q + 1][kc]
             f32x4 acc[2][4];
@@ -1071,8 +1070,9 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
                 constexpr int IN = decltype(IN_)::value, j = decltype(J_)::value, qi = decltype(Q_)::value, i = decltype(I_)::value;
                 constexpr int cb = i >> 2, kc = (i >> 1) & 1, h = i & 1;
                 int a = (cb ? cB[qi] + j * sB : cA[qi] + j * sA);
-                if constexpr (j == 0 && qi == 0) a = uyi == 0 ? zeroA : a;        // row -1
-                if constexpr (j == 2 && qi == 2) a = uyi == 2 ? zeroA : a;        // row 9
+                // rows -1 / 9: the zero row, same chunk (the low byte of the address: rows are 256 bytes)
+                if constexpr (j == 0 && qi == 0) a = uyi == 0 ? C::ZERO_REL + (a & 255) : a;
+                if constexpr (j == 2 && qi == 2) a = uyi == 2 ? C::ZERO_REL + (a & 255) : a;
                 dq[cb][kc][h] = lds_f32x4_at<IN>(a ^ ((kc << 7) | (h << 4)));
             };
             // sub-step I (0 .. 15) of the input transform of relative row Q into V buffer P
@@ -1204,8 +1204,10 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
             const int xb = wave == 0 ? 2 * ut + 1 : (wave == 1 ? 2 * ut + 1 : (wave == 2 ? 2 * ut : 2 * ut + 2));
             auto cell = [&](int x, int chunk, int invalid_rel, int &adr, int &str) {
                 const bool ok = uv && x >= 0 && x < 9;
-                const int R0 = 81 * ub + (ok ? x : 0);
-                adr = ok ? R0 * 256 + ((chunk ^ w1_swz(R0)) << 4) : invalid_rel + (chunk << 4);
+                // (cells outside the board - and the padding column - keep the chunk their class would give them: the reads of a
+                // ds_read_b128 cycle stay on sixteen distinct chunks, zero row included)
+                const int g = (5 * ub + ((x + 1) >> 1)) & 7, sw = (g & 1) | ((g & 6) << 1);
+                adr = (ok ? (81 * ub + x) * 256 : invalid_rel) + ((chunk ^ sw) << 4);
                 str = ok ? 9 * 256 : 0;
             };
             int curA, strA, curB, strB, curO0, strO0, curO1, strO1, curR0, curR1, strR0, strR1;      // cursors (row 0) and row strides
