@@ -306,7 +306,7 @@ int tg_selfplay_finish_move(tg_selfplay *sp, int32_t *moves_host, int32_t *finis
  * next root without the host; the call returns once the root RECORDS have arrived, with that root evaluation still
  * running, and the next call starts from it.  Consequences a caller sees: the first call of a handle only evaluates
  * roots (no move, nothing finished); a slot whose game was just started (tg_selfplay_start_game) sits out one call;
- * below 225 boards the phases run in 2 - 4 sub-groups of boards on streams of the library's own (joined into
+ * below 385 boards the phases run in 2 - 4 sub-groups of boards on streams of the library's own (joined into
  * `stream` before the call returns control of the buffers).  Games, records and draw order per game are the same in
  * every scheme.  TG_SP_CHAIN=0: the move decided on the host (three round trips per move); TG_SP_SUBGROUPS=n /
  * TG_SP_FWD_CAP=n override the grouping.  With an observer the boards stay in one group. */

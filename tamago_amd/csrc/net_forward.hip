@@ -868,8 +868,22 @@ static bool pick_w2(int board_size, int batch, int num_cus) {
     return env && !strcmp(env, "w2");
 }
 
+// The ragged-tail rule of tg_net_forward_dev (9x9 split-operand kernels): positions of `batch` that go through a second launch of
+// one-board workgroups (0: a single launch)
+static int tail_positions(const tg_net *net, int batch) {
+    if (!net || net->board_size != 9 || !pick_split() || getenv("TG_FWD_NO_TAIL")) return 0;
+    const int round = 3 * net->num_cus, rem = batch % round;
+    return (batch > round && rem > 0 && rem <= net->num_cus) ? rem : 0;
+}
+
 const char *tg_net_kernel_name(const tg_net *net, int batch) {
     if (!net) return "";
+    if (tail_positions(net, batch) > 0) {              // two launches: name both
+        if (pick_w2(9, batch, net->num_cus)) return "dualnet_fwd_w2_kernel<9, 3> + dualnet_fwd_split_kernel<9, 1, f16x2> (ragged tail)";
+        if (pick_w1d(9, batch, net->num_cus)) return "dualnet_fwd_w1d_kernel<3> + dualnet_fwd_w1d_kernel<1> (ragged tail)";
+        if (pick_wsplit(9)) return "dualnet_fwd_wsplit_kernel<3> + dualnet_fwd_wsplit_kernel<1> (ragged tail)";
+        return "dualnet_fwd_split_kernel<9, 3, f16x2> + dualnet_fwd_split_kernel<9, 1, f16x2> (ragged tail)";
+    }
     if (net->board_size == 19) {
         if (pick_split()) return "dualnet_fwd_split_kernel<19, 1, f16x2>";
         return pick_wino(19, batch, net->num_cus) ? "dualnet_fwd_wino8_kernel<19, 1, global scratch>" : "dualnet_fwd_kernel<19, 1>";
@@ -890,6 +904,11 @@ const char *tg_net_kernel_name(const tg_net *net, int batch) {
 
 double tg_net_executed_flops_per_position(const tg_net *net, int batch, double *peak_tflops, const char **dtype) {
     if (!net) return 0.0;
+    if (const int tail = tail_positions(net, batch)) {  // two launches: the positions' weighted mean
+        const double head = tg_net_executed_flops_per_position(net, batch - tail, peak_tflops, dtype);
+        const double rest = tg_net_executed_flops_per_position(net, tail, nullptr, nullptr);
+        return (head * (batch - tail) + rest * tail) / batch;
+    }
     const int S = net->board_size, P = S * S;
     double peak = 157.3;
     const char *name = "f32";

@@ -5693,6 +5693,7 @@ static int play_move_chain(tg_selfplay *sp, tg_net *net, float *planes_dev, floa
     if (T >= 4 && T <= 28) G = std::max(2, std::min(4, (T + 5) / 6));
     else if (T > 28 && T <= 96) { G = 2; fwd_cap = s->num_cus - std::max(32, T / 2); }
     else if (T > 96 && T <= 224) { G = 4; fwd_cap = s->num_cus - 32; }
+    else if (T > 224 && T <= 384) { G = 2; fwd_cap = s->num_cus - 32; }     // (256 boards, one-axis forward kernel: 6.07 -> 6.30 M; 512: level)
     if (sub_env > 0) { G = sub_env; fwd_cap = 0; }
     if (getenv("TG_SP_FWD_CAP")) fwd_cap = atoi(getenv("TG_SP_FWD_CAP"));
     G = std::max(1, std::min(std::min(G, (int)tg_selfplay::kMaxSub), T));

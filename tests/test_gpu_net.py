@@ -157,6 +157,28 @@ def test_results_do_not_depend_on_the_launch_size(algo, monkeypatch):
         assert torch.equal(part[0], big[0][lo:hi]) and torch.equal(part[1], big[1][lo:hi]), (algo, lo, hi)
 
 
+def test_kernel_name_and_executed_flops_know_the_ragged_tail_split(monkeypatch):
+    """A 9x9 launch whose remainder beyond whole rounds of three-board workgroups is at most one workgroup per CU goes out as TWO
+    launches (three-board head + one-board tail): the name and the issued-FLOP figure bench.py prices the matrix pipe with
+    must say so."""
+    import ctypes
+    from oracle.net import make_state_dict
+    from tamago_amd import lib as tl
+    monkeypatch.delenv("TG_FWD_ALGO", raising=False)
+    net = _net(9, make_state_dict(9, 5, 1.5))
+    lib = tl.load()
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+
+    def flops(b):
+        return lib.tg_net_executed_flops_per_position(net.handle, b, None, None)
+    whole, ragged, small = 6 * cus, 6 * cus + 64, 64
+    assert b"ragged tail" not in lib.tg_net_kernel_name(net.handle, whole)
+    name = lib.tg_net_kernel_name(net.handle, ragged)
+    assert b"ragged tail" in name and b"<3>" in name and b"<1>" in name
+    want = (flops(whole) * whole + flops(small) * small) / ragged
+    assert abs(flops(ragged) - want) < 1e-6 * want and flops(small) > flops(whole)
+
+
 def test_split_kernels_are_fp32_class_and_fall_back_on_f16_overflow(monkeypatch):
     """Accuracy of every 9x9 kernel against the reference's own fp64 forward (tests/golden/net_s9.npz):
     the split-operand kernels must be as close to fp64 as the reference's fp32 CPU path is (same

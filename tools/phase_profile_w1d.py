@@ -13,7 +13,8 @@ from tamago_amd import lib as tl
 lib = tl.load()
 net = DualNet(torch.device("cuda:0"), 9)
 b = int(sys.argv[1]) if len(sys.argv) > 1 else 65280
-b -= b % 768
+if b > 768:
+    b -= b % 768
 x = torch.randint(-1, 2, (b, 6, 9, 9), device="cuda").float()
 pol = torch.empty((b, 82), device="cuda")
 val = torch.empty((b, 3), device="cuda")
