@@ -63,10 +63,11 @@ struct WsCfg {
     static constexpr int SI_OFF = H_OFF;
     static constexpr int STAGE = SI_OFF + 4 * IMG;
     static constexpr int RTW = (MT + NW - 1) / NW;        // stem: row tiles per wave
+    static constexpr int SS_OFF = (STAGE + G * 6 * P * 4 + 15) & ~15;   // stem batch-norm scale [64] + shift [64] (w1d kernel)
     // head overlay (over H): policy features as f16 pairs 12 KB, scratch
     static constexpr int HQ_OFF = H_OFF;
     static constexpr int AUX = H_OFF + 12288;
-    static_assert(STAGE + G * 6 * P * 4 <= EX_OFF + EX_BYTES, "stem overlay");
+    static_assert(SS_OFF + 512 <= EX_OFF + EX_BYTES, "stem overlay");
     static_assert(AUX + G * (P + 96 + 4) * 4 <= H_OFF + M * 256, "head overlay");
     static_assert(LDS_BYTES <= 163840, "LDS");
 };
@@ -107,6 +108,22 @@ __device__ __forceinline__ f32x4 lds_f32x4_at(int addr) {
 template <int OFF>
 __device__ __forceinline__ void lds_f32x4_put(int addr, f32x4 v) {
     *reinterpret_cast<lds_f32x4_t *>(static_cast<unsigned>(addr + OFF)) = v;
+}
+
+// The lane id, computed where it is asked for: hipcc treats the mbcnt pair as a pure value, computes it once at the top of a
+// persistent kernel and - with the register file full of weight fragments - keeps it in scratch, one exposed reload per use.
+// A volatile asm is neither hoisted nor merged: two instructions per phase instead.
+__device__ __forceinline__ int fresh_lane() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
+// "These values are used here": hipcc waits for a load it tracks where the value is first used, and with vmcnt(0) - it does
+// not see the weight requests of the inline asm, so the wait must sit where none of them is in flight.  (A free function:
+// clang rejects asm operands that name captured variables inside a generic lambda.)
+__device__ __forceinline__ void use_here(f32x4 &v, float &s) {
+    asm volatile("" : "+v"(v), "+v"(s));
 }
 
 // Low pieces of two values whose high pieces are packed in h: f16(v0 - h.lo) | f16(v1 - h.hi) << 16, i.e. v_fma_mixlo_f16 /
@@ -202,9 +219,14 @@ __device__ __forceinline__ void run_heads_x32(unsigned char *smem, const NetDev 
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63, li = lane & 15, lg = lane >> 4;
     auto stamp = [&](int i) { if (tl && tid == 0) tl[i] = (long long)__builtin_amdgcn_s_memtime(); };
+    // (__shfl_xor derives its addresses from a lane id that hipcc computes once per kernel and keeps in scratch)
+    auto lane_xor = [&](float v, int o) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ o) << 2, __builtin_bit_cast(int, v)));
+    };
     float *hval = reinterpret_cast<float *>(smem + C::AUX);   // [G][P]
     float *plog = hval + G * P;                               // [G][NT * 16]
     float *vlog = plog + G * NT * 16;                         // [G][4]
+    const float down2 = net.pfc_tab[0], down2x = down2 * (1.f / 2048.f);   // (requested here: behind the barrier its L2 round trip is exposed)
     i32x4v fw[NTW][KS][2];
 #pragma unroll
     for (int u = 0; u < NTW; ++u) {
@@ -277,7 +299,6 @@ __device__ __forceinline__ void run_heads_x32(unsigned char *smem, const NetDev 
     stamp(0);
     __syncthreads();
     stamp(1);
-    const float down2 = net.pfc_tab[0], down2x = down2 * (1.f / 2048.f);
 #pragma unroll
     for (int u = 0; u < NTW; ++u) {
         const int nt = wave + u * NW;
@@ -313,10 +334,10 @@ __device__ __forceinline__ void run_heads_x32(unsigned char *smem, const NetDev 
             const int j = part + i * 16;
             if (j < P) sv = fmaf(h[j], wv[j], sv);
         }
-        sv += __shfl_xor(sv, 8);
-        sv += __shfl_xor(sv, 4);
-        sv += __shfl_xor(sv, 2);
-        sv += __shfl_xor(sv, 1);
+        sv += lane_xor(sv, 8);
+        sv += lane_xor(sv, 4);
+        sv += lane_xor(sv, 2);
+        sv += lane_xor(sv, 1);
         if (part == 0) vlog[bl * 4 + c] = sv + reinterpret_cast<const float *>(smem + C::VW_OFF)[3 * P + c];
     }
     stamp(2);
@@ -328,11 +349,11 @@ __device__ __forceinline__ void run_heads_x32(unsigned char *smem, const NetDev 
         const float l1 = lane + 64 < A ? plog[bl * NT * 16 + lane + 64] : -INFINITY;
         float m = fmaxf(l0, l1);
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, lane_xor(m, o));
         const float e0 = expf(l0 - m), e1 = lane + 64 < A ? expf(l1 - m) : 0.f;
         float sum = e0 + e1;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        for (int o = 32; o > 0; o >>= 1) sum += lane_xor(sum, o);
         const float inv = 1.f / sum;
         __builtin_nontemporal_store(want_logits ? l0 : e0 * inv, &policy[(size_t)b * A + lane]);
         if (lane + 64 < A) __builtin_nontemporal_store(want_logits ? l1 : e1 * inv, &policy[(size_t)b * A + lane + 64]);
@@ -880,15 +901,16 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
     int stamp_i = 0;
     auto stamp = [&]() {
         if constexpr (PROF)
-            if (blockIdx.x == 0 && tid == 0 && stamp_i < 40) net.timeline[stamp_i++] = (long long)__builtin_amdgcn_s_memtime();
+            if (blockIdx.x == 0 && wave == 0 && stamp_i < 40 && fresh_lane() == 0) net.timeline[stamp_i++] = (long long)__builtin_amdgcn_s_memtime();
     };
     int ovf = 0;
     const int n_groups = (batch + G - 1) / G;
     constexpr int NPL = (G * 6 * P + NTHR - 1) / NTHR;
     float pre[NPL];
+    float ssv;                                                 // the stem's batch-norm scale (threads 0 .. 63) / shift (64 .. 127): travels with the planes
     auto fetch_planes = [&](int grp2) __attribute__((always_inline)) {
-        int ft = tid;
-        asm volatile("" : "+v"(ft));
+        const int ft = wave * 64 + fresh_lane();
+        ssv = ft < 64 ? net.sscale[ft] : (ft < 128 ? net.shift[ft - 64] : 0.f);
 #pragma unroll
         for (int i = 0; i < NPL; ++i) {
             const int e = ft + i * NTHR;
@@ -923,14 +945,13 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
     int *const ticket_lds = reinterpret_cast<int *>(smem + C::HB_OFF + 83 * 4);
     for (int grp = blockIdx.x; grp < n_groups;) {
         const int b0 = grp * G;
-        if (tid == 0) *ticket_lds = overflow ? (int)gridDim.x + atomicAdd(overflow + 1, 1) : grp + (int)gridDim.x;
+        if (wave == 0 && fresh_lane() == 0) *ticket_lds = overflow ? (int)gridDim.x + atomicAdd(overflow + 1, 1) : grp + (int)gridDim.x;
         stamp();
         // ================= stem: planes -> im2col'ed f16-pair images (K = 9 taps x 6 planes, padded to 64) =================
         // (its 16 weight fragments are requested first: their L2 round trip runs under the staging pass)
         i32x4v fa[2][2][4];                                      // [kc][piece][ct]
         {
-            int wvg = lane * 16;
-            asm volatile("" : "+v"(wvg));
+            const int wvg = fresh_lane() * 16;
 #pragma unroll
             for (int kc = 0; kc < 2; ++kc)
 #pragma unroll
@@ -941,13 +962,14 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
         }
         {
             float *st = reinterpret_cast<float *>(smem + C::STAGE);
-            int stid = tid;
-            asm volatile("" : "+v"(stid));
+            const int stid = wave * 64 + fresh_lane();
 #pragma unroll
             for (int i = 0; i < NPL; ++i)
                 if (stid + i * NTHR < G * 6 * P) st[stid + i * NTHR] = pre[i];
             for (int e = stid; e < 4 * 64; e += NTHR)           // zero blocks of the four images
                 reinterpret_cast<unsigned *>(smem + C::SI_OFF + (e >> 6) * IMG + C::ZOFF)[e & 63] = 0u;
+            // (scale / shift through the overlay: sixteen exposed L2 round trips per group when the stem's epilogue fetched them itself)
+            if (stid < 128) reinterpret_cast<float *>(smem + C::SS_OFF)[stid] = ssv;
             __syncthreads();
             for (int row = stid; row < M; row += NTHR) {
                 const int bl = row / P, p = row - bl * P, y = p / 9, x = p - y * 9;
@@ -981,11 +1003,13 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
         {
             // stem product: 2 k-chunks x 4 channel tiles x RTW row tiles x 3 f16 products (two accumulator sets, scaled
             // low pieces: the direct split kernel's image and weights), batch norm, ReLU -> X (fp32, swizzled)
+            const int slane = fresh_lane();                      // (per group: what hangs off the lane id is recomputed, not spilled)
+            const int sli = slane & 15, slg = slane >> 4;
 #pragma unroll
             for (int r = 0; r < RTW; ++r) {
-                int row = (wave * RTW + r) * 16 + li;
+                int row = (wave * RTW + r) * 16 + sli;
                 asm volatile("" : "+v"(row));
-                const int nat = row * 64 + ((lg ^ ((row >> 1) & 3)) << 4);
+                const int nat = row * 64 + ((slg ^ ((row >> 1) & 3)) << 4);
                 const int addr = C::SI_OFF + (row < M ? nat : C::ZOFF + (nat & 255));
                 i32x4v fb[2][2];                                 // [piece][kc]
                 lds_load_frag<0 * IMG>(fb[0][0], smem, addr);
@@ -1003,8 +1027,8 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
                         a1 = mfma16<F>(fa[kc][1][c], fb[0][kc], a1);
                         a1 = mfma16<F>(fa[kc][0][c], fb[1][kc], a1);
                     }
-                    const f32x4 sc = *reinterpret_cast<const f32x4 *>(net.sscale + c * 16 + lg * 4);
-                    const f32x4 sh = *reinterpret_cast<const f32x4 *>(net.shift + c * 16 + lg * 4);
+                    const f32x4 sc = *reinterpret_cast<const f32x4 *>(smem + C::SS_OFF + (c * 16 + slg * 4) * 4);
+                    const f32x4 sh = *reinterpret_cast<const f32x4 *>(smem + C::SS_OFF + 256 + (c * 16 + slg * 4) * 4);
                     f32x4 v;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -1013,12 +1037,12 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
                         v[j] = fmaxf(t, 0.f);
                     }
                     amax = fmaxf(fmaxf(amax, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
-                    *reinterpret_cast<f32x4 *>(smem + C::X_OFF + orow * 256 + (((c * 4 + lg) ^ osw) << 4)) = v;
+                    *reinterpret_cast<f32x4 *>(smem + C::X_OFF + orow * 256 + (((c * 4 + slg) ^ osw) << 4)) = v;
                 }
             }
         }
         __syncthreads();                                        // X complete; the overlay is free again
-        if (tid < 64) reinterpret_cast<float *>(smem + C::H_OFF + (M + 1) * 256)[tid] = 0.f;   // H's zero row was under it
+        if (wave == 0) reinterpret_cast<float *>(smem + C::H_OFF + (M + 1) * 256)[fresh_lane()] = 0.f;   // H's zero row was under it
         stamp();
 
         // ================= tower: 12 layers, Winograd F(2,3) along x, the three taps along y direct =================
@@ -1034,8 +1058,7 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
             // board contribute exact zeros instead of being skipped; k-chunks; cross terms first): results do not depend on which of
             // the two a position went through.  A row tile needs three V rows per lane (input rows 3j + yi - 1 .. + 1), none shared
             // with the next row tile: 120 VALU of input transform per 72 MFMAs instead of 40.
-            int gli = li, glg = lg;
-            asm volatile("" : "+v"(gli), "+v"(glg));                  // (not to be hoisted out of the group loop)
+            const int glane = fresh_lane(), gli = glane & 15, glg = glane >> 4, wlane = glane * 16;   // (per group: not to be hoisted out of the group loop)
             const int uyi = gli / 5, ut = gli - 5 * uyi;
             const bool uv = gli < 15;
             const int xa = wave == 0 ? 2 * ut - 1 : (wave == 2 ? 2 * ut + 1 : 2 * ut);
@@ -1101,9 +1124,9 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
                 constexpr int S1 = PAR ? 3 : 1, S1N = PAR ? 1 : 3;
                 const int next_layer = layer + 1 < kTowerLayers ? layer + 1 : 0;
                 const unsigned char *wnext = net.w1_w + ((size_t)next_layer * 4 + wave) * 49152;
-                const f32x4 shf = *reinterpret_cast<const f32x4 *>(net.ws_shift + layer * 64 + wave * 16 + lg * 4);
-                const float down = net.w1_down[layer];
-                int exw = C::EX_OFF + wave * 4096 + lane * 16, exr = C::EX_OFF + wave * 1024 + lane * 16;
+                f32x4 shf = *reinterpret_cast<const f32x4 *>(net.ws_shift + layer * 64 + wave * 16 + glg * 4);
+                float down = net.w1_down[layer];
+                int exw = C::EX_OFF + wave * 4096 + glane * 16, exr = C::EX_OFF + wave * 1024 + glane * 16;
                 asm volatile("" : "+v"(exw), "+v"(exr));
                 // prologue: the three V rows of row tile 0, the first cells of row tile 1
                 static_for<3>([&](auto Q_) {
@@ -1151,7 +1174,11 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
                     static_for<72>([&](auto M_) {
                         constexpr int m = decltype(M_)::value, ky = m / 24, q = m % 24, kc = q / 12, st = (q / 4) % 3, c = q % 4;
                         constexpr int slot = ky == 1 ? S1 : ky;
-                        if constexpr (j == 0 && m == 48) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tap 2 (and the shift)
+                        // tap 2, the shift and the scale (the next layer's requests start behind this wait: it would wait for them too)
+                        if constexpr (j == 0 && m == 48) {
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            use_here(shf, down);
+                        }
                         if constexpr (st == 0)
                             acc[par][c] = mfma16<F>(ua[slot][kc][1][c], vh[par][ky][kc], m < 4 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[par][c]);
                         else if constexpr (st == 1) acc[par][c] = mfma16<F>(ua[slot][kc][0][c], vl[par][ky][kc], acc[par][c]);
@@ -1169,8 +1196,8 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
                             if constexpr (j == 0 && m >= 58 && m < 66) rd(IN_, std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, m - 58>{});
                         }
                         // next layer's weights: tap 1 into the spare slot under row tiles 0 and 1, tap 0 behind row tile 2's tap-0 MFMAs
-                        if constexpr (j <= 1 && m >= 44 && m < 68 && (m - 44) % 3 == 0) {
-                            constexpr int f = j * 8 + (m - 44) / 3;
+                        if constexpr (j <= 1 && m >= 50 && m < 72 && (m - 50) % 3 == 0) {
+                            constexpr int f = j * 8 + (m - 50) / 3;
                             w1_request<S1N>(ua, wnext + 16384, wlane, std::integral_constant<int, f>{});
                         }
                         if constexpr (j == 2 && m >= 40 && m < 72 && m % 2 == 0) w1_request<0>(ua, wnext, wlane, std::integral_constant<int, (m - 40) / 2>{});
@@ -1195,8 +1222,7 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
         } else {
             // ---- per-lane geometry: MFMA column u = 5 board + t (15 = padding), k-group lg; wave = transform point
             // (per group, behind the stem: kept alive through stem and heads these twelve registers spill) ----
-            int gli = li, glg = lg;
-            asm volatile("" : "+v"(gli), "+v"(glg));                  // (not to be hoisted out of the group loop)
+            const int glane = fresh_lane(), gli = glane & 15, glg = glane >> 4, wlane = glane * 16;   // (per group: not to be hoisted out of the group loop)
             const int ub = gli / 5, ut = gli - 5 * ub;
             const bool uv = gli < 15;
             // the two cells of point `wave`: V = d[xa] + sgn d[xb]
@@ -1251,7 +1277,7 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
             };
             f32x4 pshf = f32x4{0.f, 0.f, 0.f, 0.f};                // the previous layer's epilogue constants (its row 8 rides in this layer's row 0)
             float pdown = 0.f;
-            int pO0 = C::DUMP_REL + (lane * 16) % 256, pO1 = pO0, pR0 = C::ZERO_REL + (lane * 16) % 256, pR1 = pR0;   // its row-8 cells (layer 0: dump / zero rows)
+            int pO0 = C::DUMP_REL + (glane * 16) % 256, pO1 = pO0, pR0 = C::ZERO_REL + (glane * 16) % 256, pR1 = pR0;   // its row-8 cells (layer 0: dump / zero rows)
             // Schedule of a row's slices (one MFMA each + what rides along):  0-15 input transform of row y + 2 | 0-3 exchange
             // writes of row y - 1, 10 barrier, 11-12 exchange reads, 13 residual reads, 19-34 sums / shift / residual / ReLU,
             // 35-36 stores | 37-44 cell reads of row y + 3 | from 46: weight requests.  Row 8's exchange + epilogue ride in the
@@ -1265,9 +1291,9 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
                 constexpr int S1 = PAR ? 3 : 1, S1N = PAR ? 1 : 3; // AGPR slot of tap ky = 1 in this / the next layer (taps 0, 2: slots 0, 2)
                 const int next_layer = layer + 1 < kTowerLayers ? layer + 1 : 0;
                 const unsigned char *wnext = net.w1_w + ((size_t)next_layer * 4 + wave) * 49152;
-                const f32x4 shf = *reinterpret_cast<const f32x4 *>(net.ws_shift + layer * 64 + wave * 16 + lg * 4);
+                const f32x4 shf = *reinterpret_cast<const f32x4 *>(net.ws_shift + layer * 64 + wave * 16 + glg * 4);
                 const float down = net.w1_down[layer];
-                int exw = C::EX_OFF + wave * 4096 + lane * 16, exr = C::EX_OFF + wave * 1024 + lane * 16;
+                int exw = C::EX_OFF + wave * 4096 + glane * 16, exr = C::EX_OFF + wave * 1024 + glane * 16;
                 asm volatile("" : "+v"(exw), "+v"(exr));
                 if (layer == 0) {
                     // a group's first layer: nothing was prepared under a previous layer - V rows 0 and 1, the cells of row 2
@@ -1326,9 +1352,11 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
                     constexpr int y = decltype(Y_)::value, par = (y + PAR) & 1;
                     constexpr int NT = (y == 0 || y == 8) ? 2 : 3, NM = 24 * NT, KY0 = y == 0 ? 1 : 0;
                     if constexpr (PROF)
-                        if (blockIdx.x == 0 && tid == 0 && (layer == 2 || layer == 3) && grp == (int)blockIdx.x)
+                        if (blockIdx.x == 0 && wave == 0 && glane == 0 && (layer == 2 || layer == 3) && grp == (int)blockIdx.x)
                             net.timeline[40 + 12 * (layer - 2) + y] = (long long)__builtin_amdgcn_s_memtime();
-                    if constexpr (y == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // tap 0 (and the shift)
+                    // tap 0; behind it the layer's shift and scale (requested at the layer top, 48 MFMAs ago: hipcc waits for them
+                    // where the epilogue first uses them, 19 slices on)
+                    if constexpr (y == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
                     if constexpr (y == 6) { curA -= 9 * strA; curB -= 9 * strB; }              // from here on: the next layer's rows 0 .. 2
                     static_for<NM>([&](auto M_) {
                         constexpr int m = decltype(M_)::value, ti = m / 24, q = m % 24, kc = q / 12, st = (q / 4) % 3, c = q % 4;
@@ -1363,7 +1391,7 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
                     });
                 });
                 if constexpr (PROF)
-                    if (blockIdx.x == 0 && tid == 0 && (layer == 2 || layer == 3) && grp == (int)blockIdx.x)
+                    if (blockIdx.x == 0 && wave == 0 && glane == 0 && (layer == 2 || layer == 3) && grp == (int)blockIdx.x)
                         net.timeline[40 + 12 * (layer - 2) + 9] = (long long)__builtin_amdgcn_s_memtime();
                 pshf = shf;
                 pdown = down;
@@ -1392,7 +1420,7 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
             }
             {
                 // the tower's last row (layer 11, output X, residual): on its own
-                const int exw = C::EX_OFF + wave * 4096 + lane * 16, exr = C::EX_OFF + wave * 1024 + lane * 16;
+                const int exw = C::EX_OFF + wave * 4096 + glane * 16, exr = C::EX_OFF + wave * 1024 + glane * 16;
                 constexpr int par = (8 + 1) & 1;
                 static_for<4>([&](auto I_) { lds_f32x4_put<par * 16384 + decltype(I_)::value * 1024>(exw, acc[par][decltype(I_)::value]); });
                 eres[0] = lds_f32x4_at<C::X_OFF>(pR0);
@@ -1415,7 +1443,7 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
         // next group's input planes: requested here, consumed after the heads
         const int next = __builtin_amdgcn_readfirstlane(*ticket_lds);   // (written before the stem's barriers)
         fetch_planes(next);
-        run_heads_x32<G, C, (G == 1 ? 2 : 1)>(smem, net, b0, batch, want_logits, policy, value, tid, wave, nullptr);
+        run_heads_x32<G, C, (G == 1 ? 2 : 1)>(smem, net, b0, batch, want_logits, policy, value, wave * 64 + fresh_lane(), wave, nullptr);
         __syncthreads();
         stamp();
         grp = next;
