@@ -871,7 +871,7 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_wsplit_kernel(
 // pipe.  One transformed axis sits between: 600 MFMAs per wave and layer for three boards (2-D: 480, direct: 857), one
 // transform pass per side - 1.4 VALU instructions per MFMA, inside what an MFMA's 16 cycles hide.  Three boards per workgroup
 // only (smaller launches take dualnet_fwd_wsplit_kernel<1>).  Stem, heads, operand pieces, range guard: as above.
-// PROF: s_memtime stamps of workgroup 0 / wave 0: [0] group start, [1] input staged, [2] stem done, [3..14] layer done, [15] heads
+// PROF: s_memtime stamps of workgroup 0 / wave 0: [0] group start, [1] input staged, [2] stem done, [3..14] layer done, [15] heads done, [64..66] inside the heads: 1x1 convolutions done, barrier passed, FCs done
 template <int G, bool PROF>
 __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
     NetDev net, const float *__restrict__ planes, int batch, int want_logits,
@@ -1443,7 +1443,8 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
         // next group's input planes: requested here, consumed after the heads
         const int next = __builtin_amdgcn_readfirstlane(*ticket_lds);   // (written before the stem's barriers)
         fetch_planes(next);
-        run_heads_x32<G, C, (G == 1 ? 2 : 1)>(smem, net, b0, batch, want_logits, policy, value, wave * 64 + fresh_lane(), wave, nullptr);
+        run_heads_x32<G, C, (G == 1 ? 2 : 1)>(smem, net, b0, batch, want_logits, policy, value, wave * 64 + fresh_lane(), wave,
+                                              PROF && blockIdx.x == 0 && grp == (int)blockIdx.x ? net.timeline + 64 : nullptr);   // [64..66]: 1x1 convolutions done, barrier passed, FCs done
         __syncthreads();
         stamp();
         grp = next;

@@ -24,6 +24,7 @@ for _ in range(2):
 print("kernel:", lib.tg_net_kernel_name(net.handle, b).decode(), " batch", b)
 s = st[:16] - st[0]
 print(f"group total {s[15]} ticks: staging {s[1]}, stem {s[2] - s[1]}, heads {s[15] - s[14]}")
+print(f"  heads: 1x1 convolutions + features {st[64] - st[14]}, barrier {st[65] - st[64]}, policy / value FC {st[66] - st[65]}, softmax + stores {st[15] - st[66]}")
 print("  layers:", [int(s[3 + i] - s[2 + i]) for i in range(12)])
 for layer in (2, 3):
     d = st[40 + 12 * (layer - 2): 40 + 12 * (layer - 2) + 10]
