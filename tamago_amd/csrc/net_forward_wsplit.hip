@@ -1117,8 +1117,19 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
                     vl[pb][qi][kc][2 * h + 1] = (int)low_pieces(tvv[2], tvv[3], thh[1]);
                 }
             };
+            f32x4 pshf;                                            // the previous layer's epilogue constants (its row tile 2 rides in this layer's row tile 0)
+            float pdown;
+            // Schedule of a row tile's 72 slices (one MFMA each + what rides along):  0-3 exchange writes of the PREVIOUS row tile
+            // (row tile 0: of the previous LAYER's row tile 2 - output buffer = this layer's input, the other residual flag, constants
+            // pshf / pdown; a group's first layer: a null epilogue - zero accumulators and constants, zero-row reads, dump-row stores),
+            // 10 barrier, 11-12 exchange reads, 13 residual reads, 19-34 sums / shift / residual / ReLU, 35-36 stores | 11-18 cell
+            // reads and 19-26 transform of this row tile's OWN third V row (input rows 3j + yi + 1: the last of them was stored
+            // under the previous row tile and is visible behind this row tile's barrier) | 27-34 / 35-50 and 51-58 / 59-71 cell reads
+            // and transforms of the NEXT row tile's first two V rows (row tile 2: of the next layer's row tile 0, from this layer's
+            // output rows -1 .. 2, complete since row tile 1) | weight requests.  No barrier and no prologue at the layer boundary:
+            // between a store and any other wave's read of it lies at least one row-tile barrier.
             auto layer_fn = [&](auto IN_, auto OUT_, auto RES_, int layer) __attribute__((always_inline)) {
-                constexpr int OUT = decltype(OUT_)::value;
+                constexpr int IN = decltype(IN_)::value, OUT = decltype(OUT_)::value;
                 constexpr bool RES = decltype(RES_)::value;
                 constexpr int PAR = RES ? 1 : 0;
                 constexpr int S1 = PAR ? 3 : 1, S1N = PAR ? 1 : 3;
@@ -1128,16 +1139,25 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
                 float down = net.w1_down[layer];
                 int exw = C::EX_OFF + wave * 4096 + glane * 16, exr = C::EX_OFF + wave * 1024 + glane * 16;
                 asm volatile("" : "+v"(exw), "+v"(exr));
-                // prologue: the three V rows of row tile 0, the first cells of row tile 1
-                static_for<3>([&](auto Q_) {
-                    static_for<8>([&](auto I_) { rd(IN_, std::integral_constant<int, 0>{}, Q_, I_); });
-                    static_for<16>([&](auto I_) { tr(std::integral_constant<int, PAR>{}, Q_, I_); });
-                });
-                static_for<8>([&](auto I_) { rd(IN_, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, I_); });
-                // taps 1 and 0 must have arrived (requested in that order; behind them tap 2's 16 requests and the shift)
+                if constexpr (!RES) {
+                    if (layer == 0) {
+                        // a group's first layer: nothing was prepared under a previous layer - the first two V rows of row tile 0
+                        static_for<2>([&](auto Q_) {
+                            static_for<8>([&](auto I_) { rd(IN_, std::integral_constant<int, 0>{}, Q_, I_); });
+                            static_for<16>([&](auto I_) { tr(std::integral_constant<int, PAR>{}, Q_, I_); });
+                        });
+                    }
+                }
+                // taps 1 and 0 must have arrived (requested in that order; behind them tap 2's 16 requests, the shift and the scale)
                 asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
-                auto epi = [&](auto J_, auto I_) __attribute__((always_inline)) {          // exchange + epilogue of row tile J
-                    constexpr int j = decltype(J_)::value, i = decltype(I_)::value, par = (j + PAR) & 1;
+                // exchange + epilogue of a row tile: PREV = row tile 2 of the previous layer, else row tile J of this one
+                auto epi = [&](auto PREV_, auto J_, auto I_) __attribute__((always_inline)) {
+                    constexpr bool PREV = decltype(PREV_)::value;
+                    constexpr int j = PREV ? 2 : decltype(J_)::value, i = decltype(I_)::value;
+                    constexpr int par = PREV ? 1 - PAR : (j + PAR) & 1;
+                    constexpr int OB = PREV ? IN : OUT;
+                    constexpr bool RS = PREV ? !RES : RES;
+                    const bool null_epi = PREV && layer == 0;
                     if constexpr (i < 4) {
                         lds_f32x4_put<par * 16384 + i * 1024>(exw, acc[par][i]);
                     } else if constexpr (i == 10) {
@@ -1146,31 +1166,37 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
                         ez[2 * (i - 11)] = lds_f32x4_at<par * 16384 + (2 * (i - 11)) * 4096>(exr);
                         ez[2 * (i - 11) + 1] = lds_f32x4_at<par * 16384 + (2 * (i - 11) + 1) * 4096>(exr);
                     } else if constexpr (i == 13) {
-                        if constexpr (RES) {
-                            eres[0] = lds_f32x4_at<OUT>(curR0 + j * strR0);
-                            eres[1] = lds_f32x4_at<OUT>(curR1 + j * strR1);
+                        if constexpr (RS) {
+                            const int zr = C::ZERO_REL + (glane * 16) % 256;
+                            eres[0] = lds_f32x4_at<OB>(null_epi ? zr : curR0 + j * strR0);
+                            eres[1] = lds_f32x4_at<OB>(null_epi ? zr : curR1 + j * strR1);
                         }
                     } else if constexpr (i >= 19 && i < 35) {
                         constexpr int k = i - 19, cc = k >> 3, e = (k >> 1) & 3, part = k & 1;
                         if constexpr (part == 0) {
                             ev[cc][e] = cc == 0 ? (ez[0][e] + ez[1][e]) + ez[2][e] : (ez[1][e] - ez[2][e]) - ez[3][e];
                         } else {
-                            float tt = fmaf(ev[cc][e], down, shf[e]);
-                            if constexpr (RES) tt += eres[cc][e];
+                            float tt = fmaf(ev[cc][e], PREV ? pdown : down, PREV ? pshf[e] : shf[e]);
+                            if constexpr (RS) tt += eres[cc][e];
                             ev[cc][e] = fmaxf(tt, 0.f);
                         }
                     } else if constexpr (i == 35) {
                         amax = fmaxf(fmaxf(amax, ev[0][0]), ev[0][1]);
                         amax = fmaxf(fmaxf(amax, ev[0][2]), ev[0][3]);
-                        lds_f32x4_put<OUT>(curO0 + j * strO0, ev[0]);
+                        lds_f32x4_put<OB>(null_epi ? C::DUMP_REL + (glane * 16) % 256 : curO0 + j * strO0, ev[0]);
                     } else if constexpr (i == 36) {
                         amax = fmaxf(fmaxf(amax, ev[1][0]), ev[1][1]);
                         amax = fmaxf(fmaxf(amax, ev[1][2]), ev[1][3]);
-                        lds_f32x4_put<OUT>(curO1 + j * strO1, ev[1]);
+                        lds_f32x4_put<OB>(null_epi ? C::DUMP_REL + (glane * 16) % 256 : curO1 + j * strO1, ev[1]);
                     }
                 };
                 static_for<3>([&](auto J_) {
                     constexpr int j = decltype(J_)::value, par = (j + PAR) & 1, nb = 1 - par;
+                    using PB = std::integral_constant<int, par>;
+                    using NB = std::integral_constant<int, nb>;
+                    using Q0 = std::integral_constant<int, 0>;
+                    using Q1 = std::integral_constant<int, 1>;
+                    using Q2 = std::integral_constant<int, 2>;
                     static_for<72>([&](auto M_) {
                         constexpr int m = decltype(M_)::value, ky = m / 24, q = m % 24, kc = q / 12, st = (q / 4) % 3, c = q % 4;
                         constexpr int slot = ky == 1 ? S1 : ky;
@@ -1183,41 +1209,79 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
                             acc[par][c] = mfma16<F>(ua[slot][kc][1][c], vh[par][ky][kc], m < 4 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[par][c]);
                         else if constexpr (st == 1) acc[par][c] = mfma16<F>(ua[slot][kc][0][c], vl[par][ky][kc], acc[par][c]);
                         else acc[par][c] = mfma16<F>(ua[slot][kc][0][c], vh[par][ky][kc], acc[par][c]);
-                        // ---- what rides along: epilogue of the previous row tile, V rows of the next one ----
-                        if constexpr (j >= 1 && m < 37) epi(std::integral_constant<int, j - 1>{}, M_);
-                        if constexpr (j <= 1) {
-                            using JN = std::integral_constant<int, j + 1>;
-                            using NB = std::integral_constant<int, nb>;
-                            if constexpr (m < 8) { tr(NB{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 2 * m>{}); tr(NB{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 2 * m + 1>{}); }
-                            if constexpr (m >= 10 && m < 18) rd(IN_, JN{}, std::integral_constant<int, 1>{}, std::integral_constant<int, m - 10>{});
-                            if constexpr (m >= 24 && m < 32) { tr(NB{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 2 * (m - 24)>{}); tr(NB{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 2 * (m - 24) + 1>{}); }
-                            if constexpr (m >= 34 && m < 42) rd(IN_, JN{}, std::integral_constant<int, 2>{}, std::integral_constant<int, m - 34>{});
-                            if constexpr (m >= 48 && m < 56) { tr(NB{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 2 * (m - 48)>{}); tr(NB{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 2 * (m - 48) + 1>{}); }
-                            if constexpr (j == 0 && m >= 58 && m < 66) rd(IN_, std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, m - 58>{});
+                        // ---- what rides along ----
+                        if constexpr (m < 37) {
+                            if constexpr (j == 0) epi(std::true_type{}, J_, M_);
+                            else epi(std::false_type{}, std::integral_constant<int, j - 1>{}, M_);
                         }
-                        // next layer's weights: tap 1 into the spare slot under row tiles 0 and 1, tap 0 behind row tile 2's tap-0 MFMAs
+                        // this row tile's own third V row
+                        if constexpr (m >= 11 && m < 19) rd(IN_, J_, Q2{}, std::integral_constant<int, m - 11>{});
+                        if constexpr (m >= 19 && m < 27) { tr(PB{}, Q2{}, std::integral_constant<int, 2 * (m - 19)>{}); tr(PB{}, Q2{}, std::integral_constant<int, 2 * (m - 19) + 1>{}); }
+                        // the next row tile's first two V rows (row tile 2: the next layer's row tile 0, from this layer's output)
+                        if constexpr (m >= 27 && m < 35) {
+                            if constexpr (j <= 1) rd(IN_, std::integral_constant<int, j + 1>{}, Q0{}, std::integral_constant<int, m - 27>{});
+                            else rd(OUT_, Q0{}, Q0{}, std::integral_constant<int, m - 27>{});
+                        }
+                        if constexpr (m >= 35 && m < 51) tr(NB{}, Q0{}, std::integral_constant<int, m - 35>{});
+                        if constexpr (m >= 51 && m < 59) {
+                            if constexpr (j <= 1) rd(IN_, std::integral_constant<int, j + 1>{}, Q1{}, std::integral_constant<int, m - 51>{});
+                            else rd(OUT_, Q0{}, Q1{}, std::integral_constant<int, m - 51>{});
+                        }
+                        if constexpr (m >= 59 && m < 62) { tr(NB{}, Q1{}, std::integral_constant<int, 2 * (m - 59)>{}); tr(NB{}, Q1{}, std::integral_constant<int, 2 * (m - 59) + 1>{}); }
+                        if constexpr (m >= 62) tr(NB{}, Q1{}, std::integral_constant<int, m - 56>{});
+                        // next layer's weights: tap 1 into the spare slot under row tiles 0 and 1, tap 0 right behind row tile 2's
+                        // tap-0 MFMAs (the next layer needs it first), tap 2 behind the last MFMA
                         if constexpr (j <= 1 && m >= 50 && m < 72 && (m - 50) % 3 == 0) {
                             constexpr int f = j * 8 + (m - 50) / 3;
                             w1_request<S1N>(ua, wnext + 16384, wlane, std::integral_constant<int, f>{});
                         }
-                        if constexpr (j == 2 && m >= 40 && m < 72 && m % 2 == 0) w1_request<0>(ua, wnext, wlane, std::integral_constant<int, (m - 40) / 2>{});
+                        if constexpr (j == 2 && m >= 24 && m < 40) w1_request<0>(ua, wnext, wlane, std::integral_constant<int, m - 24>{});
                         __builtin_amdgcn_sched_barrier(0);
                     });
                 });
-                // ... tap 2 behind the last MFMA; row tile 2's exchange + epilogue on their own
                 w1_request_tap<2>(ua, wnext + 2 * 16384, wlane);
-                static_for<37>([&](auto I_) { epi(std::integral_constant<int, 2>{}, I_); });
-                if (!(amax < (float)kWsRangeLimit)) ovf = 1;
-                __syncthreads();
+                pshf = shf;
+                pdown = down;
+                if (!(amax < (float)kWsRangeLimit)) ovf = 1;            // f16 range guard (also catches NaN)
                 stamp();
             };
             using IX = std::integral_constant<int, C::X_OFF>;
             using IH = std::integral_constant<int, C::H_OFF>;
             if (!(amax < (float)kWsRangeLimit)) ovf = 1;
+            {
+                // layer 0's null epilogue
+                float z0, z1, z2, z3;
+                asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0" : "=v"(z0), "=v"(z1), "=v"(z2), "=v"(z3));
+                pshf = f32x4{z0, z1, z2, z3};
+                pdown = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[1][c] = pshf;
+            }
 #pragma unroll 1
             for (int blk = 0; blk < kBlocks; ++blk) {
                 layer_fn(IX{}, IH{}, std::false_type{}, 2 * blk);
                 layer_fn(IH{}, IX{}, std::true_type{}, 2 * blk + 1);
+            }
+            {
+                // the tower's last row tile (layer 11, output X, residual): on its own
+                const int exw = C::EX_OFF + wave * 4096 + glane * 16, exr = C::EX_OFF + wave * 1024 + glane * 16;
+                constexpr int par = (2 + 1) & 1;
+                static_for<4>([&](auto I_) { lds_f32x4_put<par * 16384 + decltype(I_)::value * 1024>(exw, acc[par][decltype(I_)::value]); });
+                eres[0] = lds_f32x4_at<C::X_OFF>(curR0 + 2 * strR0);
+                eres[1] = lds_f32x4_at<C::X_OFF>(curR1 + 2 * strR1);
+                __syncthreads();
+                static_for<4>([&](auto I_) { ez[decltype(I_)::value] = lds_f32x4_at<par * 16384 + decltype(I_)::value * 4096>(exr); });
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float o0 = (ez[0][e] + ez[1][e]) + ez[2][e], o1 = (ez[1][e] - ez[2][e]) - ez[3][e];
+                    ev[0][e] = fmaxf(fmaf(o0, pdown, pshf[e]) + eres[0][e], 0.f);
+                    ev[1][e] = fmaxf(fmaf(o1, pdown, pshf[e]) + eres[1][e], 0.f);
+                    amax = fmaxf(fmaxf(amax, ev[0][e]), ev[1][e]);
+                }
+                lds_f32x4_put<C::X_OFF>(curO0 + 2 * strO0, ev[0]);
+                lds_f32x4_put<C::X_OFF>(curO1 + 2 * strO1, ev[1]);
+                if (!(amax < (float)kWsRangeLimit)) ovf = 1;
+                __syncthreads();
             }
         } else {
             // ---- per-lane geometry: MFMA column u = 5 board + t (15 = padding), k-group lg; wave = transform point
