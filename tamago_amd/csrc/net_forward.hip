@@ -39,9 +39,15 @@ int w1d_forward(tg_net *net, int group, const float *planes, int batch, int want
 int w2_prepare(tg_net *net, const float *conv0, const float *const *tower, const float *scale, const float *shift);
 int w2_forward(tg_net *net, const float *planes, int batch, int want_logits, float *policy, float *value,
                 int *overflow, hipStream_t stream);
+// net_forward_band.hip: a 19x19 board spread over 2 / 4 workgroups (small launches)
+int band_count(const tg_net *net, int batch);
+int band_forward(tg_net *net, int bands, const float *planes, int batch, int want_logits, float *policy, float *value,
+                 int *overflow, int *flags, hipStream_t stream);
 }  // namespace tg
 
 namespace {
+
+constexpr int kBandFlagInts = 2 * 512;                     // (two per workgroup of a banded launch, at most num_cus workgroups)
 
 template <int S, int G>
 __global__ __launch_bounds__(256, (FwdCfg<S, G>::WAVES_PER_SIMD)) void dualnet_fwd_kernel(
@@ -885,7 +891,10 @@ const char *tg_net_kernel_name(const tg_net *net, int batch) {
         return "dualnet_fwd_split_kernel<9, 3, f16x2> + dualnet_fwd_split_kernel<9, 1, f16x2> (ragged tail)";
     }
     if (net->board_size == 19) {
-        if (pick_split()) return "dualnet_fwd_split_kernel<19, 1, f16x2>";
+        if (pick_split()) {
+            const int nb = tg::band_count(net, batch);
+            return nb == 4 ? "dualnet_fwd_band_kernel<4>" : (nb == 2 ? "dualnet_fwd_band_kernel<2>" : "dualnet_fwd_split_kernel<19, 1, f16x2>");
+        }
         return pick_wino(19, batch, net->num_cus) ? "dualnet_fwd_wino8_kernel<19, 1, global scratch>" : "dualnet_fwd_kernel<19, 1>";
     }
     if (pick_w2(9, batch, net->num_cus)) return "dualnet_fwd_w2_kernel<9, 3>";
@@ -987,11 +996,14 @@ int tg_net_forward_dev(tg_net *net, const float *planes_dev, int batch, int want
             {
                 std::lock_guard<std::mutex> lock(net->scratch_mu);
                 int *&slot = net->flag_by_stream[st];
-                if (!slot) TG_HIP(hipMalloc(reinterpret_cast<void **>(&slot), 2 * sizeof(int)));   // [range flag, group tickets]
+                // [range flag, group tickets, sequence numbers of the banded kernel: exchange + gather, one per workgroup each]
+                if (!slot) TG_HIP(hipMalloc(reinterpret_cast<void **>(&slot), (2 + kBandFlagInts) * sizeof(int)));
                 flag = slot;
             }
-            TG_HIP(hipMemsetAsync(flag, 0, 2 * sizeof(int), st));
-            int rc = tg::split_forward(net, 1, planes_dev, batch, want_logits, policy_dev, value_dev, flag, st);
+            const int bands = tg::band_count(net, batch);
+            TG_HIP(hipMemsetAsync(flag, 0, (bands ? 2 + kBandFlagInts : 2) * sizeof(int), st));
+            int rc = bands ? tg::band_forward(net, bands, planes_dev, batch, want_logits, policy_dev, value_dev, flag, flag + 2, st)
+                           : tg::split_forward(net, 1, planes_dev, batch, want_logits, policy_dev, value_dev, flag, st);
             if (rc) return rc;
             return launch_wino8<19, 1, true>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st, flag);
         }

@@ -390,7 +390,9 @@ __global__ __launch_bounds__((SplitCfg<S, G, F>::NTHR), 1) void dualnet_fwd_spli
                             if constexpr (add_res) t += xres[c][r][j];
                             v[j] = fmaxf(t, 0.f);
                         }
-                        amax = fmaxf(fmaxf(amax, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+                        // (rows beyond the board do not count: at 19x19 their "residual" is row 0 of the global scratch image, which
+                        // nobody writes - fresh from hipMalloc it could hold anything, and the first launch on a stream fell back)
+                        if (brow[r] < M) amax = fmaxf(fmaxf(amax, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
                         const int row = wrow[r];
                         if constexpr (last) {
                             const int hrow = brow[r] < M ? brow[r] : M;

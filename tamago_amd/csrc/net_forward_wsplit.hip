@@ -679,6 +679,7 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_wsplit_kernel(
             // ---- phase A ----
             asm volatile("s_waitcnt vmcnt(32)" ::: "memory");     // this layer's k-chunk 0 fragments (requested a layer ago; the
                                                                   // 32 requests behind them - k-chunk 1's - may still be in flight)
+            __builtin_amdgcn_sched_barrier(0);                    // (an MFMA is no memory operation: nothing else keeps it behind the wait)
             static_for<48>([&](auto M_) {
                 constexpr int m = decltype(M_)::value;
                 mfma_slice(std::integral_constant<int, 0>{}, M_, bh0, bl0);
@@ -718,7 +719,10 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_wsplit_kernel(
             // ---- phase B ----
             // k-chunk 1's fragments (only a layer's first row tile can wait here; in the last one requests are in flight
             // already, and everything it still needs has been waited for)
-            if constexpr (!LAST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (!LAST) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
             // this row tile's store / residual table (the previous one's is dead), for its epilogue in the next phase A
             if constexpr (!LAST) {
                 to = *reinterpret_cast<const i32x4v *>(tout_w + ((size_t)rt * 64 + lane) * 8);
@@ -1150,6 +1154,7 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
                 }
                 // taps 1 and 0 must have arrived (requested in that order; behind them tap 2's 16 requests, the shift and the scale)
                 asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);                 // (an MFMA is no memory operation: nothing else keeps it behind the wait)
                 // exchange + epilogue of a row tile: PREV = row tile 2 of the previous layer, else row tile J of this one
                 auto epi = [&](auto PREV_, auto J_, auto I_) __attribute__((always_inline)) {
                     constexpr bool PREV = decltype(PREV_)::value;
@@ -1204,6 +1209,7 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
                         if constexpr (j == 0 && m == 48) {
                             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                             use_here(shf, down);
+                            __builtin_amdgcn_sched_barrier(0);      // (hipcc had moved the first tap-2 MFMA in front of the wait: an MFMA is no memory operation)
                         }
                         if constexpr (st == 0)
                             acc[par][c] = mfma16<F>(ua[slot][kc][1][c], vh[par][ky][kc], m < 4 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[par][c]);
@@ -1370,6 +1376,7 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
                 }
                 // this layer's taps 1 and 2 must have arrived (requested in that order; behind them: tap 0's 16 requests, the shift)
                 asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);                 // (an MFMA is no memory operation: nothing else keeps it behind the wait)
                 // exchange + epilogue of a row: PREV = row 8 of the previous layer (output buffer = this layer's input, the other
                 // residual flag, constants pshf / pdown, cells at row 8), else row Y of this layer (cells at curO / curR)
                 auto epi = [&](auto PREV_, auto Y_, auto I_) __attribute__((always_inline)) {
@@ -1420,7 +1427,10 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
                             net.timeline[40 + 12 * (layer - 2) + y] = (long long)__builtin_amdgcn_s_memtime();
                     // tap 0; behind it the layer's shift and scale (requested at the layer top, 48 MFMAs ago: hipcc waits for them
                     // where the epilogue first uses them, 19 slices on)
-                    if constexpr (y == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    if constexpr (y == 1) {
+                        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                     if constexpr (y == 6) { curA -= 9 * strA; curB -= 9 * strB; }              // from here on: the next layer's rows 0 .. 2
                     static_for<NM>([&](auto M_) {
                         constexpr int m = decltype(M_)::value, ti = m / 24, q = m % 24, kc = q / 12, st = (q / 4) % 3, c = q % 4;

@@ -157,6 +157,67 @@ def test_results_do_not_depend_on_the_launch_size(algo, monkeypatch):
         assert torch.equal(part[0], big[0][lo:hi]) and torch.equal(part[1], big[1][lo:hi]), (algo, lo, hi)
 
 
+def test_results_do_not_depend_on_what_another_stream_is_doing():
+    """Two streams forward their own ragged batches (three-board groups + a tail of one-board workgroups) at the same time,
+    over and over: every result equals the single-stream one bit for bit.  (Found with this: hipcc had moved the first
+    MFMA that reads a layer's tap-2 fragments in front of the s_waitcnt that guards them - an MFMA is no memory operation,
+    only a sched_barrier keeps it behind an inline-asm wait - and under another stream's memory traffic the fragments
+    were late: tests/test_gpu_fastpath.py::test_selfplay_move_schemes_play_the_same_games turned flaky.)"""
+    from oracle.net import make_state_dict
+    net = _net(9, make_state_dict(9, 23, 1.5))
+    x = torch.from_numpy(np.random.RandomState(11).randint(-1, 2, size=(1200, 6, 9, 9)).astype(np.float32)).cuda()
+    xa, xb = x[:864], x[300:300 + 808].contiguous()
+    ra, rb = net.forward_device(xa), net.forward_device(xb)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs_a, outs_b = [], []
+    for _ in range(40):
+        with torch.cuda.stream(s1):
+            outs_a.append(net.forward_device(xa))
+        with torch.cuda.stream(s2):
+            outs_b.append(net.forward_device(xb))
+            outs_b.append(net.forward_device(xb[:40]))
+    torch.cuda.synchronize()
+    assert all(torch.equal(p, ra[0]) and torch.equal(v, ra[1]) for p, v in outs_a)
+    assert all(torch.equal(p, rb[0][:p.shape[0]]) and torch.equal(v, rb[1][:p.shape[0]]) for p, v in outs_b)
+
+
+def test_banded_19x19_kernel_equals_the_one_workgroup_kernel(monkeypatch):
+    """Small 19x19 launches spread a board over 4 (up to 64 boards) or 2 (up to 128) workgroups with halo rows exchanged
+    through L2 (csrc/net_forward_band.hip): same arithmetic per output in the same order, so the same bits as the
+    one-workgroup kernel that larger launches (and TG_FWD_BANDS=0) take - and the oracle's values within the tolerance."""
+    from oracle.net import OracleNet, make_state_dict
+    from tamago_amd import lib as tl
+    lib = tl.load()
+    sd = make_state_dict(19, 3, 1.4)
+    net = _net(19, sd)
+    x = torch.from_numpy(np.random.RandomState(8).randint(-1, 2, size=(140, 6, 19, 19)).astype(np.float32))
+    assert lib.tg_net_kernel_name(net.handle, 64).decode() == "dualnet_fwd_band_kernel<4>"
+    assert lib.tg_net_kernel_name(net.handle, 100).decode() == "dualnet_fwd_band_kernel<2>"
+    assert lib.tg_net_kernel_name(net.handle, 140).decode() == "dualnet_fwd_split_kernel<19, 1, f16x2>"
+    whole = net.inference_with_policy_logits(x)                      # 140 boards: one workgroup per board
+    four = net.inference_with_policy_logits(x[:64])
+    two = net.inference_with_policy_logits(x[30:130])
+    one = net.inference_with_policy_logits(x[139:140])
+    assert torch.equal(four[0], whole[0][:64]) and torch.equal(four[1], whole[1][:64])
+    assert torch.equal(two[0], whole[0][30:130]) and torch.equal(two[1], whole[1][30:130])
+    assert torch.equal(one[0], whole[0][139:140]) and torch.equal(one[1], whole[1][139:140])
+    for _ in range(5):                                               # the same launch again: nothing left behind in the flags
+        again = net.inference_with_policy_logits(x[:64])
+        assert torch.equal(again[0], four[0]) and torch.equal(again[1], four[1])
+    monkeypatch.setenv("TG_FWD_BANDS", "0")
+    assert lib.tg_net_kernel_name(net.handle, 64).decode() == "dualnet_fwd_split_kernel<19, 1, f16x2>"
+    plain = net.inference_with_policy_logits(x[:64])
+    assert torch.equal(plain[0], four[0]) and torch.equal(plain[1], four[1])
+    monkeypatch.delenv("TG_FWD_BANDS")
+    rp, rv = OracleNet(sd).inference(x[:8])
+    pol, val = net.inference(x[:8])
+    assert np.abs(pol.numpy() - rp.numpy()).max() < TOL and np.abs(val.numpy() - rv.numpy()).max() < TOL
+    # no launch above was redone by the exact kernel (a band that waits too long for its neighbour raises the range flag; the
+    # one-workgroup kernel used to raise it on a stream's first launch: rows beyond the board read an unwritten scratch row)
+    assert net.range_fallbacks() == 0
+
+
 def test_kernel_name_and_executed_flops_know_the_ragged_tail_split(monkeypatch):
     """A 9x9 launch whose remainder beyond whole rounds of three-board workgroups is at most one workgroup per CU goes out as TWO
     launches (three-board head + one-board tail): the name and the issued-FLOP figure bench.py prices the matrix pipe with
