@@ -60,6 +60,14 @@ pass f19_c "$F19" FETCH_SIZE
 pass f19_d "$F19" WRITE_SIZE
 pass f19_e "$F19" TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_READ_sum
 fi
+if [ "$PMC_ONLY" != "tree" ]; then
+# banded 19x19 kernel: one tree's mini-batch (64 positions over 256 workgroups)
+B19="python $R/tools/bench_net.py 19 64"
+pass b19_a "$B19" SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE
+pass b19_c "$B19" FETCH_SIZE
+pass b19_d "$B19" WRITE_SIZE
+pass b19_e "$B19" TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_READ_sum
+fi
 TREE="python $R/bench.py --steps 2 --warmup 1 --trees 2048 --no-cpu-baseline --no-legs"
 pass tree_c "$TREE" FETCH_SIZE
 pass tree_d "$TREE" WRITE_SIZE
@@ -69,4 +77,10 @@ pass feat_c "$FEAT" FETCH_SIZE
 pass feat_d "$FEAT" WRITE_SIZE
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python $R/bench.py --steps 3 --warmup 1 --trees 2048 --no-cpu-baseline --no-legs > $OUT/trace.log 2>&1
 echo "trace: rc=$?"
+# kernel traces of the single-tree legs (9x9 and 19x19 through the API)
+for leg in single_tree_9x9:bench_api_latency.py single_tree_19x19:bench_api_latency_19.py; do
+  name=${leg%%:*}; script=${leg##*:}; rm -rf /tmp/lt
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/lt -o t -- python $R/tools/$script > $OUT/$name.log 2>&1
+  f=$(find /tmp/lt -name t_kernel_stats.csv | head -1); [ -n "$f" ] && cp $f $OUT/r04_${name}_kernel_stats.csv; grep -E "MCTSTree|19x19 search|per move" $OUT/$name.log | tail -1
+done
 python3 $R/tools/pmc_r04_summary.py $OUT

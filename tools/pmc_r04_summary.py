@@ -82,6 +82,25 @@ def main(out):
         with open(path, "w") as f:
             json.dump(summary, f, indent=1)
         print(path, json.dumps(summary["derived"], indent=1))
+    # the banded 19x19 kernel (a board over four workgroups) on one tree's mini-batch of 64 positions
+    perb, timesb = counters(out, ["b19_a", "b19_c", "b19_d", "b19_e"], ["dualnet_fwd_band_kernel"])
+    for kname, c in perb.items():
+        if "GRBM_GUI_ACTIVE" not in c:
+            continue
+        launches, dur_ns = timesb[kname]
+        positions = 64
+        hbm = (2 * c.get("FETCH_SIZE", 0) + c.get("WRITE_SIZE", 0)) * 1024
+        summary = {"kernel": kname, "csrc_digest": digest, "positions_per_launch": positions, "workgroups": 256,
+                   "avg_duration_us_profiled": dur_ns / 1e3, "counters_per_launch": c,
+                   "derived": {"shader_clock_GHz": c["GRBM_GUI_ACTIVE"] / 8 / dur_ns,
+                               "mfma_busy_fraction_of_simd_cycles": c["SQ_VALU_MFMA_BUSY_CYCLES"] / (256 * 4 * c["GRBM_GUI_ACTIVE"] / 8),
+                               "hbm_bytes_per_position": hbm / positions, "algorithmic_io_bytes_per_position": 6 * 361 * 4 + 362 * 4 + 12,
+                               "l2_request_bytes_per_position": c.get("TCC_REQ_sum", 0) * 128 / positions,
+                               "l2_hit_rate": c.get("TCC_HIT_sum", 0) / max(1.0, c.get("TCC_REQ_sum", 0))}}
+        path = f"{out}/r04_pmc_forward_band_19x19_b64.json"
+        with open(path, "w") as f:
+            json.dump(summary, f, indent=1)
+        print(path, json.dumps(summary["derived"], indent=1))
     for kname, c in per.items():
         if "GRBM_GUI_ACTIVE" not in c or times[kname][1] < 1e5:      # (the guarded fp32 fallback launch exits in microseconds)
             continue
