@@ -38,7 +38,7 @@ def sources():
                   if f.endswith(".hip") or f.endswith(".cpp"))
 
 
-FORWARD_SOURCES = ("net_forward.hip", "net_forward_split.hip", "net_forward_w2.hip", "net_forward_wsplit.hip", "split_common.h", "net_device.h",
+FORWARD_SOURCES = ("net_forward.hip", "net_forward_split.hip", "net_forward_band.hip", "net_forward_w2.hip", "net_forward_wsplit.hip", "split_common.h", "net_device.h",
                    "common.h")
 
 

@@ -241,6 +241,11 @@ struct tg_net {
     std::mutex scratch_mu;
     std::map<hipStream_t, float *> scratch_by_stream;
     std::map<hipStream_t, int *> flag_by_stream;      // f16 split kernel: range flag per launch stream
+    // banded 19x19 kernel: its launches follow each other even across streams (two of them half-resident on the device would
+    // hold each other's missing bands off the CUs until the bounded waits give up) - the last launch's completion event
+    hipEvent_t band_done = nullptr;
+    hipStream_t band_stream = nullptr;
+    bool band_recorded = false;
     size_t scratch_floats = 0;
 };
 

@@ -824,6 +824,7 @@ int tg_net_destroy(tg_net *net) {
     for (void *p : net->allocs) (void)hipFree(p);
     for (auto &kv : net->scratch_by_stream) (void)hipFree(kv.second);
     for (auto &kv : net->flag_by_stream) (void)hipFree(kv.second);
+    if (net->band_done) (void)hipEventDestroy(net->band_done);
     if (net->st_planes) (void)hipFree(net->st_planes);
     if (net->st_policy) (void)hipFree(net->st_policy);
     if (net->st_value) (void)hipFree(net->st_value);

@@ -18,7 +18,9 @@
 // All workgroups of a launch must be resident at once (grid = NB x boards <= CUs, one workgroup per CU by LDS): the
 // launcher only takes this kernel for such batches.  Waits are bounded: a band whose neighbour does not show up (CUs held
 // by another stream's kernels for longer than the limit) raises the range flag - the exact-fp32 kernel queued behind
-// every split launch then redoes the batch - and stops waiting; no launch can hang.
+// every split launch then redoes the batch - and stops waiting; no launch can hang.  A network's banded launches follow each
+// other even when they come from different streams (an event per network): two of them half-resident would wait for bands
+// that the other one keeps off the CUs.
 // Reference: nn/network/dual_net.py:41-52, nn/network/res_block.py:8-38 at BOARD_SIZE = 19 (board/constant.py:4).
 #include "split_common.h"
 
@@ -484,10 +486,16 @@ int launch_band(tg_net *net, const float *planes, int batch, int want_logits, fl
             slot = static_cast<float *>(d);
         }
         dev.scratch = slot;
+        // one banded launch at a time on the device: a launch on another stream waits for the previous one's end
+        if (!net->band_done) TG_HIP(hipEventCreateWithFlags(&net->band_done, hipEventDisableTiming));
+        if (net->band_recorded && net->band_stream != stream) TG_HIP(hipStreamWaitEvent(stream, net->band_done, 0));
+        hipLaunchKernelGGL(kern, dim3(batch * NB), dim3(C::NTHR), C::LDS_BYTES, stream, dev, planes, batch, want_logits,
+                           policy, value, overflow, flags);
+        TG_HIP(hipGetLastError());
+        TG_HIP(hipEventRecord(net->band_done, stream));
+        net->band_stream = stream;
+        net->band_recorded = true;
     }
-    hipLaunchKernelGGL(kern, dim3(batch * NB), dim3(C::NTHR), C::LDS_BYTES, stream, dev, planes, batch, want_logits,
-                       policy, value, overflow, flags);
-    TG_HIP(hipGetLastError());
     return TG_OK;
 }
 
@@ -502,9 +510,10 @@ int band_count(const tg_net *net, int batch) {
     const int forced = env ? atoi(env) : -1;
     if (net->board_size != 19 || forced == 0) return 0;
     if (net->forward_grid_cap > 0) return 0;               // CUs are held back for other streams' kernels
-    // Two banded launches on two streams whose workgroups do not all fit on the device can hold each other's missing bands off
-    // the CUs until the bounded waits give up (correct results - the exact kernel redoes both - but 0.1 s late): with the
-    // sub-group streams of a self-play move in flight (guard_grid_cap is set exactly then) a launch takes a quarter of the CUs.
+    // (Two banded launches whose workgroups do not all fit on the device could hold each other's missing bands off the CUs until
+    // the bounded waits give up: launch_band lets a network's banded launches follow each other across streams.)  With the
+    // sub-group streams of a self-play move in flight (guard_grid_cap is set exactly then) a launch takes a quarter of the CUs
+    // and leaves the rest to the other sub-groups' tree kernels.
     const int cus = net->guard_grid_cap > 0 ? net->num_cus / 4 : net->num_cus;
     if ((forced == 4 || forced < 0) && batch * 4 <= cus) return 4;
     if ((forced == 2 || forced == 4 || forced < 0) && batch * 2 <= cus) return 2;
