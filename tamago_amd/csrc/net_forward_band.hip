@@ -486,13 +486,18 @@ int launch_band(tg_net *net, const float *planes, int batch, int want_logits, fl
             slot = static_cast<float *>(d);
         }
         dev.scratch = slot;
-        // one banded launch at a time on the device: a launch on another stream waits for the previous one's end
-        if (!net->band_done) TG_HIP(hipEventCreateWithFlags(&net->band_done, hipEventDisableTiming));
-        if (net->band_recorded && net->band_stream != stream) TG_HIP(hipStreamWaitEvent(stream, net->band_done, 0));
+        // one banded launch at a time on the device: when the launch stream changes, the new stream waits for what the previous
+        // one has queued (an event recorded there now: launches that stay on one stream - a search - pay nothing)
+        if (net->band_recorded && net->band_stream != stream) {
+            if (!net->band_done) TG_HIP(hipEventCreateWithFlags(&net->band_done, hipEventDisableTiming));
+            if (hipEventRecord(net->band_done, net->band_stream) == hipSuccess)
+                TG_HIP(hipStreamWaitEvent(stream, net->band_done, 0));
+            else
+                (void)hipGetLastError();                     // (the previous stream is gone: nothing of it can be in flight)
+        }
         hipLaunchKernelGGL(kern, dim3(batch * NB), dim3(C::NTHR), C::LDS_BYTES, stream, dev, planes, batch, want_logits,
                            policy, value, overflow, flags);
         TG_HIP(hipGetLastError());
-        TG_HIP(hipEventRecord(net->band_done, stream));
         net->band_stream = stream;
         net->band_recorded = true;
     }
