@@ -218,6 +218,31 @@ def test_banded_19x19_kernel_equals_the_one_workgroup_kernel(monkeypatch):
     assert net.range_fallbacks() == 0
 
 
+def test_banded_kernel_cannot_hang_a_silent_band_ends_in_the_exact_fallback(monkeypatch):
+    """A band whose neighbour never shows up (here: band 1 keeps its sequence numbers to itself, TG_BAND_TEST_MUTE) gives up
+    after the bounded wait, raises the range flag, and the exact-fp32 kernel queued behind the launch redoes the batch: the
+    call returns within seconds, the result is the exact kernel's (oracle tolerance), the fallback is counted."""
+    import time
+    from oracle.net import OracleNet, make_state_dict
+    sd = make_state_dict(19, 4, 1.2)
+    net = _net(19, sd)
+    x = torch.from_numpy(np.random.RandomState(9).randint(-1, 2, size=(4, 6, 19, 19)).astype(np.float32))
+    good = net.inference(x)
+    assert net.range_fallbacks() == 0
+    monkeypatch.setenv("TG_BAND_TEST_MUTE", "1")
+    t0 = time.perf_counter()
+    pol, val = net.inference(x)
+    dt = time.perf_counter() - t0
+    monkeypatch.delenv("TG_BAND_TEST_MUTE")
+    assert dt < 20.0, dt
+    assert net.range_fallbacks() == 1
+    rp, rv = OracleNet(sd).inference(x)
+    assert np.abs(pol.numpy() - rp.numpy()).max() < TOL and np.abs(val.numpy() - rv.numpy()).max() < TOL
+    assert np.abs(pol.numpy() - good[0].numpy()).max() < TOL
+    again = net.inference(x)                                         # and the next launch is an ordinary one
+    assert torch.equal(again[0], good[0]) and torch.equal(again[1], good[1]) and net.range_fallbacks() == 1
+
+
 def test_kernel_name_and_executed_flops_know_the_ragged_tail_split(monkeypatch):
     """A 9x9 launch whose remainder beyond whole rounds of three-board workgroups is at most one workgroup per CU goes out as TWO
     launches (three-board head + one-board tail): the name and the issued-FLOP figure bench.py prices the matrix pipe with
