@@ -199,6 +199,7 @@ def extra_legs(args, net, dev, local_rank, fresh_board):
     from tamago_amd.mcts.engine import SearchEngine
     from tamago_amd.nn.network.dual_net import DualNet
     from tamago_amd.selfplay.worker import selfplay_shard
+    from tamago_amd import lib as _lib
     out = {}
     cur = torch.cuda.current_stream(dev)
 
@@ -215,7 +216,8 @@ def extra_legs(args, net, dev, local_rank, fresh_board):
         dt1 = time.perf_counter() - t1
         one.close()
         return {"value": n1 / dt1, "unit": "leaf-evals/s", "ms_per_move": dt1 / moves * 1e3, "moves": moves,
-                "workload": f"ONE search tree, {size}x{size}, {visits} strict visits/move, NN batch {batch}"}
+                "workload": f"ONE search tree, {size}x{size}, {visits} strict visits/move, NN batch {batch}",
+                "forward_kernel": _lib.load().tg_net_kernel_name(network.handle, batch).decode()}
 
     # strict single-tree reading of config[1] (latency-bound: descent k+1 depends on the virtual loss of k)
     try:
