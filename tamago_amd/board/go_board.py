@@ -58,6 +58,7 @@ class GoBoard:
         self.rec_color = [0] * self.max_records
         self.rec_pos = [PASS] * self.max_records
         self.rec_hash = np.zeros(self.max_records, dtype=np.uint64)
+        self.handicap_pos: List[int] = []
 
     def get_board_size(self) -> int:
         return self.board_size
@@ -120,6 +121,34 @@ class GoBoard:
                 self.ko_pos = libs[0]
         self._save(color, pos)
         self.moves += 1
+
+    def put_handicap_stone(self, pos: int, color) -> None:
+        """board/go_board.py:187-235: a stone like any other (captures, prisoners, ko, positional hash) that is no MOVE -
+        the move counter and the move record stay as they are, the point goes to the handicap list."""
+        color = color_value(color)
+        other = 3 - color
+        self.cells[pos] = color
+        self.hash ^= int(self.zobrist[color][pos])
+        captured = 0
+        for n in self.get_neighbor4(pos):
+            if self.cells[n] == other:
+                stones, libs = self._string(n)
+                if not libs:
+                    for p in stones:
+                        self.cells[p] = EMPTY
+                        self.hash ^= int(self.zobrist[other][p])
+                    captured += len(stones)
+        self.prisoner[color - 1] += captured
+        if captured == 1 and all(self.cells[n] != color for n in self.get_neighbor4(pos)):
+            libs = [n for n in self.get_neighbor4(pos) if self.cells[n] == EMPTY]
+            if len(libs) == 1:
+                self.ko_move = self.moves
+                self.ko_pos = libs[0]
+        self.handicap_pos.append(pos)
+
+    def get_handicap_history(self) -> List[int]:
+        """board/go_board.py:546-552."""
+        return self.handicap_pos[:]
 
     def is_legal(self, pos: int, color) -> bool:
         """board/go_board.py:260-304."""
@@ -207,3 +236,4 @@ def copy_board(dst: GoBoard, src: GoBoard) -> None:
     dst.rec_color = src.rec_color[:]
     dst.rec_pos = src.rec_pos[:]
     dst.rec_hash = src.rec_hash.copy()
+    dst.handicap_pos = src.handicap_pos[:]

@@ -2,8 +2,9 @@
 command set and the response texts of gtp/client.py:31-600 that reach the hot path):
 genmove / lz-genmove_analyze / cgos-genmove_analyze -> MCTSTree.search_best_move (or the
 Gumbel search), lz-analyze / cgos-analyze -> MCTSTree.ponder, plus the board bookkeeping
-commands a GTP controller needs around them.  Not carried over: gogui colour maps, handicap
-tables, tree dump, animation."""
+commands a GTP controller needs around them (incl. fixed_handicap).  Not carried over: gogui colour
+maps, tree dump, animation.  tests/test_gpu_gtp.py replays a session recorded from the reference's
+command loop byte for byte."""
 import sys
 from typing import Callable, Dict, List
 
@@ -47,7 +48,8 @@ class GtpClient:
             "version": lambda a: self._ok(VERSION),
             "protocol_version": lambda a: self._ok(PROTOCOL_VERSION),
             "name": lambda a: self._ok(PROGRAM_NAME),
-            "known_command": lambda a: self._ok("true" if a and a[0] in self.commands else "false"),
+            # (gtp/client.py:116-125: an unknown command is a FAILURE "unknown command", not "= false")
+            "known_command": lambda a: self._ok("true") if a and a[0] in self.commands else self._fail("unknown command"),
             "list_commands": lambda a: self._ok("\n".join(self.commands)),
             "komi": self._komi,
             "get_komi": lambda a: self._ok(str(self.board.get_komi())),
@@ -58,6 +60,7 @@ class GtpClient:
             "clear_board": self._clear_board,
             "time_settings": self._time_settings,
             "time_left": self._time_left,
+            "fixed_handicap": self._fixed_handicap,
             "showboard": self._showboard,
             "loadsgf": self._loadsgf,
             "final_score": lambda a: self._ok("?"),
@@ -108,16 +111,31 @@ class GtpClient:
         self._put(pos, color)
         self._ok("")
 
-    def _rebuild(self, history):
+    def _rebuild(self, history, handicaps=()):
         self.board = GoBoard(board_size=self.board.get_board_size(), komi=self.komi, check_superko=self.superko)
         self.history = []
+        for pos in handicaps:                         # go_board.py:554-560: handicap stones first, then the moves
+            self.board.put_handicap_stone(pos, Stone.BLACK)
         for pos, color in history:
             self._put(pos, color)
+
+    def _fixed_handicap(self, args):
+        """gtp/client.py:342-366."""
+        if self.board.moves > 1 or len(self.board.get_handicap_history()) > 1:
+            return self._fail("board not empty")
+        from tamago_amd.board.handicap import get_handicap_coordinates
+        size = self.board.get_board_size()
+        points = get_handicap_coordinates(size, int(args[0]))
+        if points is None:
+            return self._fail(f"size {size}, handicaps {args[0]} is not supported")
+        for point in points:
+            self.board.put_handicap_stone(self.coordinate.convert_from_gtp_format(point), Stone.BLACK)
+        self._ok(" ".join(points))
 
     def _undo(self, args):
         if not self.history:
             return self._fail("cannot undo")
-        self._rebuild(self.history[:-1])
+        self._rebuild(self.history[:-1], self.board.get_handicap_history())
         self._ok("")
 
     def _boardsize(self, args):
@@ -142,8 +160,8 @@ class GtpClient:
         self._ok("")
 
     def _time_settings(self, args):
+        # gtp/client.py:255-265: the main time only; the time-control MODE stays what the client was started with
         try:
-            self.time_manager.set_mode(TimeControl.TIME_CONTROL)
             for color in (Stone.BLACK, Stone.WHITE):
                 self.time_manager.set_remaining_time(color, float(args[0]))
         except (IndexError, ValueError):

@@ -152,10 +152,19 @@ class MCTSTree:
         engine = _engine or self._engine_for(board)
         threshold = time_manager.get_num_visits_threshold(color)
         done = 0
+        # tree.py:168-174 prints the final analysis (interval 0) at the end of search() - BEFORE search_best_move flushes the
+        # last, partial mini-batch (tree.py:84-85): its leaves are selected (virtual losses in place) but not yet evaluated
+        # or backed up, and the printed visit counts do not include them
+        late_analysis = bool(analysis_query) and analysis_query.get("interval", 0) == 0
+        pending = False
         while done < threshold:
             leaves = min(self.batch_size, threshold - done)
             engine.ensure_capacity(leaves)
-            engine.puct_batch(leaves)
+            if late_analysis and leaves < self.batch_size and done + leaves == threshold:
+                engine.puct_select(leaves)
+                pending = True
+            else:
+                engine.puct_batch(leaves)
             done += leaves
             if leaves == self.batch_size and done < threshold:
                 if time_manager.is_time_over():
@@ -169,6 +178,8 @@ class MCTSTree:
             sys.stdout.write(engine.read_node(0, 0).get_analysis(board, analysis_query.get("mode", "lz"),
                                                                  self.get_pv_lists))
             sys.stdout.flush()
+        if pending:
+            engine.puct_flush()
 
     def ponder(self, board: GoBoard, color, analysis_query: Dict[str, Any]):
         """mcts/tree.py:108-127: search without a visit limit until input arrives on stdin

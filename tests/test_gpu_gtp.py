@@ -1,9 +1,9 @@
 """GTP front end (next row 8(f).2) on the device search: a command script end to end; genmove
 equals MCTSTree.search_best_move on the same position and random state.
 
-This file compares the product WITH ITSELF (command loop vs direct search).  What pins the GTP row to the
-reference are the lz- / cgos-analysis strings and PV lines (byte-identical to reference-recorded goldens,
-tests/test_gpu_search.py) and the search itself (tree fixtures); the command loop has no reference recording."""
+The first test compares the product WITH ITSELF (command loop vs direct search); the last one replays a session the
+REFERENCE's command loop recorded (tests/golden/gtp_session.json, tools/gen_golden_gtp.py) byte for byte.  The lz- /
+cgos-analysis strings and PV lines are also pinned by reference-recorded goldens in tests/test_gpu_search.py."""
 import io
 import sys
 
@@ -40,7 +40,7 @@ def test_gtp_session_matches_direct_search(tmp_path):
                              "boardsize 9\nclear_board\nkomi 6.5\nget_komi\nplay b E5\nplay w C3\n"
                              "7 genmove b\nundo\nbogus\nquit\n")
     blocks = out.split("\n\n")
-    assert blocks[0] == "=1 2" and blocks[1] == "= TamaGo" and blocks[2] == "= true" and blocks[3] == "= false"
+    assert blocks[0] == "=1 2" and blocks[1] == "= TamaGo" and blocks[2] == "= true" and blocks[3] == "? unknown command"
     assert blocks[7] == "= 6.5"
     assert blocks[10].startswith("=7 ")
     move = blocks[10][3:]
@@ -66,3 +66,22 @@ def test_gtp_session_matches_direct_search(tmp_path):
     out = run_script(client, f"loadsgf {path} 11\nlz-analyze w nonsense\nquit\n")
     assert out.split("\n\n")[0] == "= " and out.split("\n\n")[1].startswith("? lz-analyze")
     assert len(client.history) == 10 and client.board.moves == 11
+
+
+def test_gtp_session_equals_the_reference_recording():
+    """The command loop against the REFERENCE's own: tools/gen_golden_gtp.py ran /root/reference/gtp/client.py on a scripted
+    session (protocol commands, play / genmove / undo, an illegal move, handicap, time settings, lz- and cgos-genmove_analyze)
+    with the deterministic stub network and recorded its stdout; the same script, seeds and network here must print the
+    same bytes."""
+    import random
+    from oracle.stubnet import StubNet
+    from tamago_amd.gtp.client import GtpClient
+    from tamago_amd.mcts.time_manager import TimeControl
+    from tests.helpers import load_json
+    gold = load_json("gtp_session.json")
+    client = GtpClient(9, True, StubNet(8), komi=7.0, visits=gold["visits"], batch_size=gold["batch_size"],
+                       tree_size=gold["tree_size"], mode=TimeControl.STRICT_PLAYOUT)
+    np.random.seed(gold["seed"])
+    random.seed(gold["seed"])
+    out = run_script(client, gold["script"])
+    assert out == gold["stdout"]

@@ -62,3 +62,33 @@ def test_time_manager_modes():
     assert not TimeManager(TimeControl.STRICT_PLAYOUT, 80).is_move_decided(root, 80)
     tm = TimeManager(TimeControl.CONSTANT_TIME, constant_time=2.0)
     assert tm.get_num_visits_threshold(1) == 40    # 20 visits/s default speed
+
+
+def test_handicap_points_equal_the_reference_table():
+    """board/handicap.py: the rule that produces the points against every entry (and every refusal) of the reference's table
+    (tests/golden/handicap.json, written by tools/gen_golden_gtp.py from the imported reference)."""
+    from tamago_amd.board.handicap import get_handicap_coordinates
+    from tests.helpers import load_json
+    table = load_json("handicap.json")
+    assert len(table) == 17 * 12
+    for key, want in table.items():
+        size, n = (int(v) for v in key.split(","))
+        assert get_handicap_coordinates(size, n) == want, key
+
+
+def test_handicap_stones_are_stones_but_no_moves():
+    from tamago_amd.board.go_board import GoBoard, copy_board
+    from tamago_amd.board.stone import Stone
+    board = GoBoard(9, 7.0, True)
+    pos = [board.coordinate.convert_from_gtp_format(p) for p in ("G7", "C3")]
+    for p in pos:
+        board.put_handicap_stone(p, Stone.BLACK)
+    assert board.moves == 1 and board.get_handicap_history() == pos
+    data = board.get_board_data()
+    assert sum(1 for v in data if v == 1) == 2 and sum(1 for v in data if v == 2) == 0
+    assert not board.is_legal(pos[0], Stone.WHITE)
+    other = GoBoard(9, 7.0, True)
+    copy_board(other, board)
+    assert other.get_handicap_history() == pos and other.get_board_data() == data
+    board.clear()
+    assert board.get_handicap_history() == [] and other.get_handicap_history() == pos
