@@ -38,11 +38,17 @@ import torch
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
+# TG_BENCH_DRY_RUN=1 (tests/test_dist_shards.py): the N-rank PLUMBING of this file - process group, barriers, max-over-ranks
+# clock, sum-over-ranks count, the cfg-4 gather with its failure path, the one JSON line - on CPU ranks (gloo) with a stub in
+# place of the GPU workload, so that the 8-rank code path has run before an 8-GPU node shows up.  Its numbers mean nothing
+# and the line says so ("data": "DRY RUN ...").
+DRY = os.environ.get("TG_BENCH_DRY_RUN") == "1"
+
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix (= fp32 vector) peak
 PROFILES = os.path.join(REPO, "profiles")
 
 
-def pmc_summary(kernel_name):
+def pmc_summary(kernel_name, size=9):
     """The rocprofv3 PMC summary (tools/pmc_r02.sh -> profiles/r02_pmc_forward_*.json) measured on THESE
     kernel sources for THIS kernel: HBM-side bytes per position (FETCH_SIZE doubled + WRITE_SIZE, separate
     passes, as MI355X_MICROARCH.md section HBM prescribes), matrix-pipe busy fraction, L2 request bytes.
@@ -54,7 +60,8 @@ def pmc_summary(kernel_name):
     for path in sorted(glob.glob(os.path.join(PROFILES, "r0[0-9]_pmc_forward_*.json")), reverse=True):
         with open(path) as f:
             d = json.load(f)
-        if d.get("csrc_digest") == digest and kernel_name.split("<")[0] in d.get("kernel", ""):
+        if d.get("csrc_digest") == digest and kernel_name.split("<")[0] in d.get("kernel", "") and \
+                f"_{size}x{size}_" in os.path.basename(path):
             d["file"] = os.path.relpath(path, REPO)
             return d
     sys.stderr.write(f"bench.py: no PMC summary in profiles/ for kernel {kernel_name!r} at csrc digest {digest} - "
@@ -297,16 +304,24 @@ def trees_19(net19, local_rank, trees, visits=1600, batch=64, steps=2):
     dtype_name = ctypes.c_char_p()
     exec_flops = lib.tg_net_executed_flops_per_position(net19.handle, full_b, ctypes.byref(peak), ctypes.byref(dtype_name))
     algorithmic = full_b * flops_pos / (avg_ms * 1e-3) / 1e12
+    kname19 = lib.tg_net_kernel_name(net19.handle, full_b).decode()
+    pmc = pmc_summary(kname19, 19)
     return {"value": leaves / dt, "unit": "leaf-evals/s", "trees": trees, "steps": steps, "ms_per_step": dt / steps * 1e3,
             "workload": f"cfg-5: {trees} lock-step 19x19 trees, PUCT, {visits} strict visits/move, NN batch {batch} per tree",
-            "roofline": {"bound": "mfma", "kernel": lib.tg_net_kernel_name(net19.handle, full_b).decode(),
+            "roofline": {"bound": "mfma", "kernel": kname19,
                          "achieved": algorithmic, "peak": peak.value, "unit": "TFLOP/s", "frac": algorithmic / peak.value,
                          "algorithmic_flops_per_position": flops_pos,
                          "mfma_issue_tflops": full_b * exec_flops / (avg_ms * 1e-3) / 1e12,
                          "mfma_issue_frac": full_b * exec_flops / (avg_ms * 1e-3) / 1e12 / peak.value,
                          "executed_dtype": dtype_name.value.decode() if dtype_name.value else "",
                          "avg_launch_ms": avg_ms, "launches": len(big), "positions_per_launch": full_b,
-                         "forward_share_of_step": kern_ms * 1e-3 / dt, "traffic": None}}
+                         "forward_share_of_step": kern_ms * 1e-3 / dt,
+                         "traffic": pmc["derived"]["hbm_bytes_per_position"] * full_b if pmc else None,
+                         "traffic_unit": "HBM-side bytes per launch: rocprofv3 PMC FETCH_SIZE x 2 + WRITE_SIZE (separate passes) "
+                                         "per position x positions of this launch",
+                         "traffic_source": pmc["file"] if pmc else None,
+                         "algorithmic_io_bytes": full_b * (6 * 361 * 4 + (361 + 4) * 4),
+                         "mfma_busy_frac_pmc": pmc["derived"].get("mfma_busy_fraction_of_simd_cycles") if pmc else None}}
 
 
 def cpu_baseline(size, visits, batch, budget_s):
@@ -432,10 +447,12 @@ def cfg4_leg(args, net, local_rank, rank, world, dist, red_dev):
     games = args.cfg4_games
     first = 1 + rank * games
     tmp = tempfile.mkdtemp(prefix=f"tg_cfg4_r{rank}_")
-    torch.cuda.synchronize()
+    if not DRY:
+        torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
+    cpu0 = time.process_time()                              # CPU seconds of ALL threads of this rank (group threads, the library's random-stream generators)
     # A rank whose shard fails still takes part in every collective below: it contributes an error row (the other
     # ranks would otherwise wait in all_gather until the RCCL timeout).  TG_BENCH_FAIL_RANK=r injects such a failure (tests).
     err = None
@@ -443,16 +460,21 @@ def cfg4_leg(args, net, local_rank, rank, world, dist, red_dev):
     try:
         if os.environ.get("TG_BENCH_FAIL_RANK") == str(rank):
             raise RuntimeError(f"injected failure on rank {rank} (TG_BENCH_FAIL_RANK)")
-        st = selfplay_shard(tmp, net, list(range(first, first + games)), 9, args.cfg4_visits, boards=args.cfg4_boards,
-                            never_resign_flags=[True] * games, device_index=local_rank)
-        torch.cuda.synchronize()
+        if DRY:
+            time.sleep(0.05 * (1 + rank % 3))
+            st = {"leaf_evals": (args.cfg4_visits + 1) * 60 * games, "games": games, "moves": 60 * games}
+        else:
+            st = selfplay_shard(tmp, net, list(range(first, first + games)), 9, args.cfg4_visits, boards=args.cfg4_boards,
+                                never_resign_flags=[True] * games, device_index=local_rank)
+            torch.cuda.synchronize()
     except Exception as exc:                                # (KeyboardInterrupt / SystemExit end the process: torchrun
         err = repr(exc)                                     #  then tears the other ranks down)
         sys.stderr.write(f"bench.py rank {rank}: cfg-4 shard failed: {err}\n")
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     dt = time.perf_counter() - t0
-    mine = torch.tensor([st["leaf_evals"], dt, st["games"], st["moves"], len(os.sched_getaffinity(0)), 1.0 if err else 0.0],
+    cpu_s = time.process_time() - cpu0
+    mine = torch.tensor([st["leaf_evals"], dt, st["games"], st["moves"], len(os.sched_getaffinity(0)), 1.0 if err else 0.0, cpu_s],
                         dtype=torch.float64, device=red_dev)
     if world > 1:
         allr = [torch.zeros_like(mine) for _ in range(world)]
@@ -475,10 +497,85 @@ def cfg4_leg(args, net, local_rank, rank, world, dist, red_dev):
     return {"value": total / slowest, "unit": "leaf-evals/s", "shards": world, "boards_per_shard": args.cfg4_boards,
             "games_per_shard": games, "simulations_per_move": args.cfg4_visits, "seconds": slowest,
             "games_per_hour": sum(r[2] for r in rows) / slowest * 3600,
+            # host cost of a shard: CPU seconds of all its threads per 10^6 leaf evaluations, and how many cores that keeps
+            # busy while the shard runs - host contention is the only thing that can bend the 1 -> 8 GPU curve
+            "host_cpu_s_per_1e6_leaf_evals": sum(r[6] for r in rows) / max(total, 1.0) * 1e6,
             "per_rank": [{"rank": i, "leaf_evals_per_s": r[0] / r[1], "seconds": r[1], "games": int(r[2]), "moves": int(r[3]),
-                          "host_cores": int(r[4])} for i, r in enumerate(rows)],
+                          "host_cores": int(r[4]), "host_cpu_s": r[6], "host_cores_busy": r[6] / r[1]} for i, r in enumerate(rows)],
             "workload": f"cfg-4: {world} shard(s) x {args.cfg4_boards} lock-step boards, Gumbel sequential halving, "
                         f"{args.cfg4_visits} simulations/move, games to completion, SGF records written, one shard per rank / GPU"}
+
+
+def dry_main(args, rank, local_rank, world):
+    """TG_BENCH_DRY_RUN=1: main()'s rank plumbing with a stub workload on CPU ranks (gloo).  Same collectives in the same
+    order as the GPU path: barrier / timed steps / barrier, MAX over ranks of the clock, SUM of the counts, the host-cost
+    gather, the cfg-4 leg's gather with its failure path, one JSON line from rank 0, barrier, teardown."""
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        try:
+            from tamago_amd.selfplay.main import pin_host_threads
+            pin_host_threads(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), None)
+        except Exception as exc:
+            sys.stderr.write(f"bench.py: host-thread pinning skipped ({exc})\n")
+    red_dev = torch.device("cpu")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def step():
+        time.sleep(0.01 * (1 + rank % 3))                      # ranks finish at different times: the clock is the slowest one's
+        return args.trees * (args.visits + 1)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    cpu0 = time.process_time()
+    leaves = 0
+    for _ in range(args.steps):
+        leaves += step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    row = [time.process_time() - cpu0, elapsed, float(leaves), float(len(os.sched_getaffinity(0)))]
+    rows = [row]
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        tot = torch.tensor([leaves], dtype=torch.float64)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        leaves = float(tot.item())
+        mine_h = torch.tensor(row, dtype=torch.float64)
+        all_h = [torch.zeros_like(mine_h) for _ in range(world)]
+        dist.all_gather(all_h, mine_h)
+        rows = [[float(v) for v in t] for t in all_h]
+    result = None
+    if rank == 0:
+        result = {"metric": "MCTS leaf-evals/sec (9x9, batch 256)", "value": leaves / elapsed, "unit": "leaf-evals/s",
+                  "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                  "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none",
+                  "data": "DRY RUN (TG_BENCH_DRY_RUN=1): no GPU, stub workload - rank plumbing only, the numbers mean nothing",
+                  "config": {"workload": "stub", "trees_per_gpu": args.trees,
+                             "leaf_evals_per_step_per_gpu": args.trees * (args.visits + 1),
+                             "parallelism": f"{world} x independent board shards (no collective)"},
+                  "host": {"per_rank": [{"rank": i, "cpu_s": r[0], "cores_busy": r[0] / r[1], "cores_pinned": int(r[3])}
+                                        for i, r in enumerate(rows)]}}
+    if world > 1 and not args.no_legs:
+        try:
+            leg = cfg4_leg(args, None, local_rank, rank, world, dist, red_dev)
+        except Exception as exc:
+            leg = {"error": repr(exc)}
+        if rank == 0:
+            result["cfg4_selfplay_shards"] = leg
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -488,6 +585,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if os.environ.get("TG_SINGLE_DEVICE"):                     # N ranks on one GPU (tests only)
         local_rank = 0
+    if DRY:
+        return dry_main(args, rank, local_rank, world)
     torch.cuda.set_device(local_rank)                          # before any collective is set up
     dev = torch.device("cuda", local_rank)
     backend = os.environ.get("TG_DIST_BACKEND", "nccl")        # nccl == RCCL on ROCm
@@ -545,6 +644,8 @@ def main():
     full_b = sizes[0] * args.batch
     flops_pos = lib.tg_net_flops_per_position(args.size)
 
+    host_cpu = []                                             # (CPU seconds of all threads, wall seconds, leaves) of this rank's timed regions
+
     def timed_region(steps, warmup):
         """W untimed + K timed steps (barrier + synchronise on both sides); returns leaf evaluations, seconds (max over
         ranks), and the forward launches' HIP-event times (all: ms sum; full-size launches: list)."""
@@ -555,11 +656,13 @@ def main():
         evaluator.record = True
         barrier()
         t0 = time.perf_counter()
+        cpu0 = time.process_time()
         leaves = 0
         for _ in range(steps):
             leaves += run_step(engines, plies_list, fresh_board, args.visits, args.batch)
         barrier()
         elapsed = time.perf_counter() - t0
+        host_cpu.append((time.process_time() - cpu0, elapsed, leaves))
         evaluator.record = False
         kern_ms, big = 0.0, []
         for e0, e1, b in evaluator.events:
@@ -625,6 +728,15 @@ def main():
         }
 
     leaves, elapsed, kern_ms, big = timed_region(args.steps, args.warmup)
+    # host cost of the headline loop, every rank's: CPU seconds of all its threads (this driver thread + the library's
+    # random-stream generator threads) per 10^6 leaf evaluations, cores kept busy
+    cpu_s, wall_s, my_leaves = host_cpu[0]
+    host_rows = [[cpu_s, wall_s, float(my_leaves), float(len(os.sched_getaffinity(0)))]]
+    if world > 1:
+        mine_h = torch.tensor(host_rows[0], dtype=torch.float64, device=red_dev)
+        all_h = [torch.zeros_like(mine_h) for _ in range(world)]
+        dist.all_gather(all_h, mine_h)
+        host_rows = [[float(v) for v in t.cpu()] for t in all_h]
 
     result = None
     if rank == 0:
@@ -652,6 +764,11 @@ def main():
                 "parallelism": f"{world} x independent board shards (no collective)",
             },
             "roofline": roof,
+            "host": {"cpu_s_per_1e6_leaf_evals": sum(r[0] for r in host_rows) / max(sum(r[2] for r in host_rows), 1.0) * 1e6,
+                     "per_rank": [{"rank": i, "cpu_s": r[0], "cores_busy": r[0] / r[1], "cores_pinned": int(r[3])}
+                                  for i, r in enumerate(host_rows)],
+                     "note": "time.process_time() of each rank over its timed region: all threads of the process (driver "
+                             "thread, library random-stream generators); cores_busy = CPU seconds / wall seconds"},
             "tree_kernels": tree_pmc_summary() if args.size == 9 else None,
             # forward launches the exact-fp32 kernel had to redo (f16 range guard of the split-operand kernels): 0 = none
             "range_fallbacks": net.range_fallbacks(),

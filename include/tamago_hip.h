@@ -95,6 +95,15 @@ double tg_net_executed_flops_per_position(const tg_net *net, int batch, double *
  * run hot shows up here instead of only as a slower search.  Synchronises the device.  (No reference counterpart: the
  * reference computes in fp32 throughout, nn/network/dual_net.py:41-52.) */
 int tg_net_range_fallbacks(tg_net *net, unsigned long long *count);
+/* 19x19: launches of up to 128 boards spread a board over 2 / 4 workgroups that exchange halo rows through L2 with BOUNDED
+ * waits.  *count receives how many of those waits gave up so far (each ends in the exact-fp32 redo above, so it is also
+ * part of tg_net_range_fallbacks' count - this one tells the two causes apart).  After the first one the network keeps to
+ * the one-workgroup kernel: somebody else's kernels hold this GPU's compute units.  Synchronises the device. */
+int tg_net_band_timeouts(tg_net *net, unsigned long long *count);
+/* shared != 0: other PROCESSES drive this GPU too (the reference's `--process N` on one device, nn/utility.py:22,
+ * selfplay_main.py:44-65 with more workers than GPUs).  Kernels that need several workgroups of one launch resident at the
+ * same time (the banded 19x19 forward) are not chosen then.  Results do not depend on this switch. */
+int tg_net_set_shared_device(tg_net *net, int shared);
 
 /* ---- featurise (nn/feature.py:10-57 + go_board.py:468-478) -------------------------- */
 /* cells_dev: uint8 [B, P] on-board cell colours, row-major from the top-left point;

@@ -20,10 +20,11 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-
          "-ffp-contract=off"]
 
 
-# per-source flags.  net_forward_wsplit.hip: MFMA results in VGPRs (the accumulation half of the register file holds the
+# per-source flags.  net_forward_w1d.hip / net_forward_w1dband.hip: MFMA results in VGPRs (the accumulation half of the register file holds the
 # layer's weight fragments), and no SLP vectorisation (v_pk_add_f32 / v_pk_fma_f32 beside an MFMA stream cost ~12 cycles
 # each against ~3.4 for two plain instructions: profiles/r04_microbench_wino_issue_model.txt)
-EXTRA_FLAGS = {"net_forward_wsplit.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+_W1D_FLAGS = ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+EXTRA_FLAGS = {"net_forward_w1d.hip": _W1D_FLAGS, "net_forward_w1dband.hip": _W1D_FLAGS}
 
 
 def _hipcc() -> str:
@@ -38,8 +39,9 @@ def sources():
                   if f.endswith(".hip") or f.endswith(".cpp"))
 
 
-FORWARD_SOURCES = ("net_forward.hip", "net_forward_split.hip", "net_forward_band.hip", "net_forward_w2.hip", "net_forward_wsplit.hip", "split_common.h", "net_device.h",
-                   "common.h")
+FORWARD_SOURCES = tuple(f for f in ("net_forward.hip", "net_forward_split.hip", "net_forward_band.hip", "net_forward_w1d.hip",
+                                     "net_forward_w1dband.hip", "w1d_common.h", "split_common.h", "net_device.h", "common.h")
+                        if os.path.exists(os.path.join(CSRC, f)))
 
 
 def source_digest(names=None) -> str:
@@ -70,18 +72,25 @@ def build(force: bool = False, verbose: bool = True) -> str:
     headers.append(os.path.join(REPO, "include", "tamago_hip.h"))
     newest_header = max(os.path.getmtime(h) for h in headers)
     objs = []
-    rebuilt = False
+    jobs = []
     for src in sources():
         obj = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
         objs.append(obj)
         stale = force or not os.path.exists(obj) or \
             os.path.getmtime(obj) < max(os.path.getmtime(src), newest_header)
         if stale:
-            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-x", "hip", "-c", src, "-o", obj]
+            jobs.append([hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-x", "hip", "-c", src, "-o", obj])
+    rebuilt = bool(jobs)
+    if jobs:
+        # the translation units are independent: compile them side by side (search.hip alone takes over a minute)
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
             if verbose:
                 print("[tamago_amd.build]", " ".join(cmd), flush=True)
             subprocess.check_call(cmd)
-            rebuilt = True
+        with ThreadPoolExecutor(max_workers=min(len(jobs), max(1, (os.cpu_count() or 2) // 2), 8)) as pool:
+            list(pool.map(run, jobs))
     if rebuilt or not os.path.exists(LIB):
         cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
         if verbose:

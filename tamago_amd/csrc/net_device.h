@@ -3,6 +3,7 @@
 #pragma once
 #include "common.h"
 
+#include <atomic>
 #include <cmath>
 #include <map>
 #include <mutex>
@@ -40,12 +41,6 @@ struct NetDev {
     // 1 + 9*layer + tap for the tower) an LDS-ready image [k-chunk 2][piece][cout tile 4][lane 64][8 x 16 bit]
     const unsigned char *wsplit;      // f16 x 2 pieces
     const float *sscale;              // [13][64] folded BN scale incl. the per-layer weight scaling 2^-e
-    // two-waves-per-SIMD kernel (net_forward_w2.hip): [k-chunk][chh 2][piece 2][ct 2][lane 64][8 x f16],
-    // batch-norm scale folded into the weights; accumulator start values [13][64] (folded shift x weight scaling);
-    // per-layer factor 2^-e [13]
-    const unsigned char *ww2;
-    const float *w2_init;
-    const float *w2_down;
     // head phase on the 16-bit matrix pipe (split_common.h run_heads_mfma): the three 1x1-convolution channels
     // (policy 0, policy 1, value; batch norm folded) as A fragments [k-chunk 2][piece 2][lane 64][8 x f16], their
     // accumulator start values [16] + 2^-e at [16]; the policy FC as A fragments
@@ -54,18 +49,14 @@ struct NetDev {
     const float *hd1_tab;
     const unsigned char *pfc_img;
     const float *pfc_tab;
-    // Winograd tower on split operands (net_forward_wsplit.hip): weight image [layer 12][point row 4][j 4][kc 2][piece 2]
-    // [ct 4][lane 64][8 x f16] (batch-norm scale folded in, x 2^e, low pieces unscaled), folded shift [12][64], 2^-e [12];
-    // LDS address tables of the workgroup shapes G = 1 / G = 3: patch cells [wave 4][row tile][lane 64][8], epilogue
-    // (store [0..3] / residual [4..7]) [wave 4][row tile][lane 64][8]
-    const unsigned char *w1_w;        // dualnet_fwd_w1d_kernel: [layer 12][point 4][tap 3][kc 2][piece 2][ct 4][lane 64][16 B]
-    const float *w1_down;             // ... and 2^-e per layer (shift: ws_shift)
-    const unsigned char *ws_w;
-    const float *ws_shift;
-    const float *ws_down;
-    const int *ws_tin[2];
-    const int *ws_tout[2];
+    // Winograd F(2,3) along x on split operands (net_forward_w1d.hip, net_forward_w1dband.hip): weight image
+    // [layer 12][point 4][tap ky 3][kc 2][piece 2][ct 4][lane 64][16 B] (batch-norm scale folded in, x 2^e, low pieces
+    // unscaled), folded shift [12][64], 2^-e [12] - independent of the board size
+    const unsigned char *w1_w;
+    const float *w1_shift;
+    const float *w1_down;
     unsigned long long *fallbacks;    // launches redone by the exact-fp32 kernel behind a raised range flag (tg_net_range_fallbacks)
+    unsigned int *band_timeouts;      // banded 19x19 kernels: bounded waits that gave up (host-mapped: band_count reads it without a sync)
     int *overflow;                    // f16 range guard: set when a layer output leaves the f16 range
     float *scratch;       // 19x19 Winograd: per workgroup two [P][64] activation images (L2-resident)
     long long *timeline;  // optional [128] s_memtime stamps of workgroup 0 (tg_net_profile_phases)
@@ -236,8 +227,11 @@ struct tg_net {
     // > 0: the exact-fp32 kernel queued behind a split launch as its range guard takes at most this many workgroups.  Each
     // needs a CU to itself even to read a clear flag: with several streams sharing the device (self-play sub-groups) a
     // full-size guard launch waits for the other streams' forward passes to drain.  The rare real fallback is slower.
-    int guard_grid_cap = 0;
-    int forward_grid_cap = 0;               // > 0: workgroups of a 9x9 split forward launch (CUs left to other streams' tree kernels)
+    // (Both are set around a self-play move's sub-group launches - search.hip play_move_chain - by host threads that may SHARE
+    // this handle: atomics, and a user count so that one thread's release does not zero them under another's launches.)
+    std::atomic<int> guard_grid_cap{0};
+    std::atomic<int> forward_grid_cap{0};   // > 0: workgroups of a 9x9 split forward launch (CUs left to other streams' tree kernels)
+    std::atomic<int> cap_users{0};
     std::mutex scratch_mu;
     std::map<hipStream_t, float *> scratch_by_stream;
     std::map<hipStream_t, int *> flag_by_stream;      // f16 split kernel: range flag per launch stream
@@ -246,6 +240,10 @@ struct tg_net {
     hipEvent_t band_done = nullptr;
     hipStream_t band_stream = nullptr;
     bool band_recorded = false;
+    // the host's view of dev.band_timeouts (pinned, mapped): once a banded launch has run into its bounded wait - the device is
+    // shared with somebody whose kernels keep bands off the CUs - this network stays on the one-workgroup kernels
+    volatile unsigned int *band_timeouts_host = nullptr;
+    bool shared_device = false;             // tg_net_set_shared_device: several processes drive this GPU
     size_t scratch_floats = 0;
 };
 

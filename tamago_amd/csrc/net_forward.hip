@@ -30,15 +30,10 @@ int split_prepare(tg_net *net, const float *conv0, const float *const *tower, co
 int split_forward(tg_net *net, int group, const float *planes, int batch, int want_logits, float *policy,
                   float *value, int *overflow, hipStream_t stream);
 int heads_prepare(tg_net *net, const float *hp_w, const float *hv_w, const float *head_ss, const float *pfc_w, int P);
-int wsplit_prepare(tg_net *net, const float *const *tower, const float *scale, const float *shift);
-int wsplit_forward(tg_net *net, int group, const float *planes, int batch, int want_logits, float *policy,
-                   float *value, int *overflow, hipStream_t stream);
-int w1d_prepare(tg_net *net, const float *const *tower, const float *scale);
+// net_forward_w1d.hip: the tower as Winograd F(2,3) along x on split operands (the 9x9 default)
+int w1d_prepare(tg_net *net, const float *const *tower, const float *scale, const float *shift);
 int w1d_forward(tg_net *net, int group, const float *planes, int batch, int want_logits, float *policy, float *value, int *overflow,
                 hipStream_t stream);
-int w2_prepare(tg_net *net, const float *conv0, const float *const *tower, const float *scale, const float *shift);
-int w2_forward(tg_net *net, const float *planes, int batch, int want_logits, float *policy, float *value,
-                int *overflow, hipStream_t stream);
 // net_forward_band.hip: a 19x19 board spread over 2 / 4 workgroups (small launches)
 int band_count(const tg_net *net, int batch);
 int band_forward(tg_net *net, int bands, const float *planes, int batch, int want_logits, float *policy, float *value,
@@ -630,7 +625,7 @@ int launch_wino8(tg_net *net, const float *planes, int batch, int want_logits, f
     }
     const int groups = (batch + G - 1) / G;
     int grid = groups < net->num_cus ? groups : net->num_cus;           // one 8-wave workgroup per CU
-    if (guard && net->guard_grid_cap > 0 && grid > net->guard_grid_cap) grid = net->guard_grid_cap;
+    if (const int cap = net->guard_grid_cap.load(); guard && cap > 0 && grid > cap) grid = cap;
     NetDev dev = net->dev;
     if (GS) {
         std::lock_guard<std::mutex> lock(net->scratch_mu);
@@ -651,8 +646,24 @@ int launch_wino8(tg_net *net, const float *planes, int batch, int want_logits, f
 }  // namespace
 
 namespace tg {
-void net_set_guard_cap(tg_net *net, int cap) { if (net) net->guard_grid_cap = cap; }
-void net_set_forward_cap(tg_net *net, int cap) { if (net) net->forward_grid_cap = cap; }
+// Grid caps around a self-play move's sub-group launches.  Several host threads (groups of one shard) may share the handle:
+// the caps stay up while ANY of them is between acquire and release; concurrent users' forward caps differ only when
+// their board counts do - the last acquire wins, any value is correct (the kernels take groups by ticket).
+void net_caps_acquire(tg_net *net, int guard_cap, int forward_cap) {
+    if (!net) return;
+    std::lock_guard<std::mutex> lock(net->scratch_mu);
+    net->cap_users.fetch_add(1);
+    net->guard_grid_cap.store(guard_cap);
+    net->forward_grid_cap.store(forward_cap);
+}
+void net_caps_release(tg_net *net) {
+    if (!net) return;
+    std::lock_guard<std::mutex> lock(net->scratch_mu);
+    if (net->cap_users.fetch_sub(1) == 1) {
+        net->guard_grid_cap.store(0);
+        net->forward_grid_cap.store(0);
+    }
+}
 }  // namespace tg
 
 extern "C" {
@@ -792,6 +803,20 @@ int tg_net_create(int board_size, int device, const float *params, size_t n_para
         net->allocs.push_back(d);
         net->dev.fallbacks = static_cast<unsigned long long *>(d);
     }
+    if (board_size == 19) {
+        // bounded waits of the banded kernels that gave up: pinned host memory mapped into the device, so that the choice of
+        // the next launch's kernel (band_count) sees it without a synchronisation
+        void *h = nullptr, *d = nullptr;
+        if (hipHostMalloc(&h, sizeof(unsigned int), hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+            if (h) (void)hipHostFree(h);
+            tg_net_destroy(net);
+            return tg::fail(TG_ERR_HIP, "tg_net_create: band-timeout counter");
+        }
+        *static_cast<unsigned int *>(h) = 0u;
+        net->band_timeouts_host = static_cast<volatile unsigned int *>(h);
+        net->dev.band_timeouts = static_cast<unsigned int *>(d);
+    }
 
     // scratch images of the 19x19 Winograd kernel: 2 x [P][64] floats per workgroup, allocated per
     // launch stream on first use (launch_wino8)
@@ -808,9 +833,7 @@ int tg_net_create(int board_size, int device, const float *params, size_t n_para
     }
     if ((board_size == 9 && (rc = tg::heads_prepare(net, hp_w.data(), hv_w.data(), head_ss.data(), pfc_raw, P))) ||
         (rc = tg::split_prepare(net, conv0_raw, tower_raw, scale.data())) ||
-        (board_size == 9 && (rc = tg::w2_prepare(net, conv0_raw, tower_raw, scale.data(), shift.data()))) ||
-        (board_size == 9 && (rc = tg::wsplit_prepare(net, tower_raw, scale.data(), shift.data()))) ||
-        (board_size == 9 && (rc = tg::w1d_prepare(net, tower_raw, scale.data())))) {
+        (rc = tg::w1d_prepare(net, tower_raw, scale.data(), shift.data()))) {
         tg_net_destroy(net);
         return rc;
     }
@@ -825,6 +848,7 @@ int tg_net_destroy(tg_net *net) {
     for (auto &kv : net->scratch_by_stream) (void)hipFree(kv.second);
     for (auto &kv : net->flag_by_stream) (void)hipFree(kv.second);
     if (net->band_done) (void)hipEventDestroy(net->band_done);
+    if (net->band_timeouts_host) (void)hipHostFree(const_cast<unsigned int *>(net->band_timeouts_host));
     if (net->st_planes) (void)hipFree(net->st_planes);
     if (net->st_policy) (void)hipFree(net->st_policy);
     if (net->st_value) (void)hipFree(net->st_value);
@@ -845,40 +869,31 @@ static int pick_group(int board_size, int batch, int num_cus) {
 
 static int pick_wino(int board_size, int batch, int num_cus);
 
-// forward algorithm: TG_FWD_ALGO = w1d (9x9 default: Winograd F(2,3) along x on f16 x 2 operand pieces for launches of three-board
-// workgroups, the 2-D kernel below for smaller ones) | wsplit (Winograd F(2x2,3x3) tower on f16 x 2 operand pieces) | split16 (direct
-// 3x3 convolution on f16 x 2 operand pieces, 3 MFMAs per product-sum; the 19x19 default) | w2 | wino (exact fp32 Winograd
-// tower) | direct (exact fp32 direct convolution).
+// forward algorithm: TG_FWD_ALGO = w1d (the 9x9 default: Winograd F(2,3) along x on f16 x 2 operand pieces, net_forward_w1d.hip:
+// dualnet_fwd_w1d_kernel<3> for launches above the CU count, <1> - one board per workgroup, same bits - below) | split16 (direct
+// 3x3 convolution on f16 x 2 operand pieces, 3 MFMAs per product-sum; the 19x19 default) | wino (exact fp32 Winograd tower,
+// also the fallback behind the f16 range guard) | direct (exact fp32 direct convolution).  (The 2-D Winograd and the
+// two-waves-per-SIMD kernels of rounds 3 / 4 were measured slower and live, unbuilt, under tools/experiments/kernels/.)
 static bool pick_split() {
     const char *env = getenv("TG_FWD_ALGO");
-    return !env || !strcmp(env, "split16") || !strcmp(env, "w2") || !strcmp(env, "wsplit") || !strcmp(env, "w1d");
+    return !env || !strcmp(env, "split16") || !strcmp(env, "w1d");
 }
-// TG_FWD_ALGO=w1d (the 9x9 default): Winograd F(2,3) along x only on f16 x 2 operand pieces (net_forward_wsplit.hip:
-// dualnet_fwd_w1d_kernel<1 | 3>)
 static bool pick_w1d(int board_size, int /*batch*/, int /*num_cus*/) {
     if (board_size != 9) return false;
     const char *env = getenv("TG_FWD_ALGO");
-    return !env || !strcmp(env, "w1d");              // the 9x9 default (one- and three-board variants give the same bits; TG_FWD_ALGO=wsplit: 2-D Winograd)
+    return !env || !strcmp(env, "w1d");
 }
-// TG_FWD_ALGO=wsplit: the 9x9 tower as Winograd F(2x2,3x3) on split operands (net_forward_wsplit.hip)
-static bool pick_wsplit(int board_size) {
-    if (board_size != 9) return false;
-    const char *env = getenv("TG_FWD_ALGO");
-    return !env || !strcmp(env, "wsplit") || !strcmp(env, "w1d");   // the 9x9 default since round 4 (TG_FWD_ALGO=split16: the direct split kernel)
-}
-// TG_FWD_ALGO=w2: large 9x9 batches (three boards per workgroup) on the two-waves-per-SIMD kernel (net_forward_w2.hip:
-// weights through an LDS ring, batch norm folded into the weights); measured level with the one-wave-per-SIMD kernel
-// (net_forward_split.hip, the default), DESIGN.md 4.1d
-static bool pick_w2(int board_size, int batch, int num_cus) {
-    if (board_size != 9 || batch <= num_cus) return false;
-    const char *env = getenv("TG_FWD_ALGO");
-    return env && !strcmp(env, "w2");
+// TG_FWD_NO_TAIL (tuning knob): no second launch for a ragged tail.  Read ONCE per process - the launch path and the
+// name / FLOP queries below must agree on it.
+static bool no_tail_split() {
+    static const bool v = getenv("TG_FWD_NO_TAIL") != nullptr;
+    return v;
 }
 
 // The ragged-tail rule of tg_net_forward_dev (9x9 split-operand kernels): positions of `batch` that go through a second launch of
 // one-board workgroups (0: a single launch)
 static int tail_positions(const tg_net *net, int batch) {
-    if (!net || net->board_size != 9 || !pick_split() || getenv("TG_FWD_NO_TAIL")) return 0;
+    if (!net || net->board_size != 9 || !pick_split() || no_tail_split()) return 0;
     const int round = 3 * net->num_cus, rem = batch % round;
     return (batch > round && rem > 0 && rem <= net->num_cus) ? rem : 0;
 }
@@ -886,9 +901,7 @@ static int tail_positions(const tg_net *net, int batch) {
 const char *tg_net_kernel_name(const tg_net *net, int batch) {
     if (!net) return "";
     if (tail_positions(net, batch) > 0) {              // two launches: name both
-        if (pick_w2(9, batch, net->num_cus)) return "dualnet_fwd_w2_kernel<9, 3> + dualnet_fwd_split_kernel<9, 1, f16x2> (ragged tail)";
         if (pick_w1d(9, batch, net->num_cus)) return "dualnet_fwd_w1d_kernel<3> + dualnet_fwd_w1d_kernel<1> (ragged tail)";
-        if (pick_wsplit(9)) return "dualnet_fwd_wsplit_kernel<3> + dualnet_fwd_wsplit_kernel<1> (ragged tail)";
         return "dualnet_fwd_split_kernel<9, 3, f16x2> + dualnet_fwd_split_kernel<9, 1, f16x2> (ragged tail)";
     }
     if (net->board_size == 19) {
@@ -898,9 +911,7 @@ const char *tg_net_kernel_name(const tg_net *net, int batch) {
         }
         return pick_wino(19, batch, net->num_cus) ? "dualnet_fwd_wino8_kernel<19, 1, global scratch>" : "dualnet_fwd_kernel<19, 1>";
     }
-    if (pick_w2(9, batch, net->num_cus)) return "dualnet_fwd_w2_kernel<9, 3>";
     if (pick_w1d(9, batch, net->num_cus)) return batch > net->num_cus ? "dualnet_fwd_w1d_kernel<3>" : "dualnet_fwd_w1d_kernel<1>";
-    if (pick_wsplit(9)) return batch > net->num_cus ? "dualnet_fwd_wsplit_kernel<3>" : "dualnet_fwd_wsplit_kernel<1>";
     if (pick_split()) return batch > net->num_cus ? "dualnet_fwd_split_kernel<9, 3, f16x2>" : "dualnet_fwd_split_kernel<9, 1, f16x2>";
     {
         const int wg = pick_wino(9, batch, net->num_cus);
@@ -931,18 +942,9 @@ double tg_net_executed_flops_per_position(const tg_net *net, int batch, double *
         flops = (2.0 * 4 * 4 * rtw * 3 + 12.0 * 4 * (g == 3 ? 25 : 9) * 4 * 2 * 3) * 16384.0 / g;
         peak = 2500.0;
         name = "f16 (2 operand pieces, Winograd F(2,3) along x, fp32 accumulate)";
-    } else if (pick_wsplit(S)) {
-        // per workgroup pass: stem (2 k-chunks x 4 channel tiles x 4 waves x RTW row tiles x 3 products) + 12 layers x
-        // (16 points x NRT row tiles x 4 channel tiles x 2 k-chunks x 3 products) of v_mfma_f32_16x16x32_f16
-        const int g = batch > net->num_cus ? 3 : 1;
-        const int nrt = (g * 25 + 15) / 16, rtw = ((g * P + 15) / 16 + 3) / 4;
-        flops = (2.0 * 4 * 4 * rtw * 3 + 12.0 * 16 * nrt * 4 * 2 * 3) * 16384.0 / g;
-        peak = 2500.0;
-        name = "f16 (2 operand pieces, Winograd F(2x2,3x3), fp32 accumulate)";
     } else if ((S == 9 || S == 19) && pick_split()) {
         // per workgroup pass: (2 stem + 12 * 18) k-chunks x (4 cout tiles x row tiles) x 3 products of
         // v_mfma_f32_16x16x32_f16 (16 384 FLOP each)
-        // (the two-waves-per-SIMD kernel issues the same MFMAs: 8 waves x 24 per chunk = 16 row tiles x 4 x 3)
         const int g = S == 19 ? 1 : (batch > net->num_cus ? 3 : 1);
         const int row_tiles = S == 19 ? 24 : (g == 3 ? 16 : 6);   // 4 waves x 6 | 4 waves x 4 | 3 waves x 2
         flops = (2.0 + 12.0 * 18.0) * 4.0 * row_tiles * 3.0 * 16384.0 / g;
@@ -1021,8 +1023,7 @@ int tg_net_forward_dev(tg_net *net, const float *planes_dev, int batch, int want
             {
                 const int round = 3 * net->num_cus;
                 const int rem = batch % round;
-                static const bool no_tail = getenv("TG_FWD_NO_TAIL") != nullptr;
-                if (!no_tail && batch > round && rem > 0 && rem <= net->num_cus) {
+                if (!no_tail_split() && batch > round && rem > 0 && rem <= net->num_cus) {
                     const int head = batch - rem;
                     const size_t P = 81, A = 82;
                     int rc = tg_net_forward_dev(net, planes_dev, head, want_logits, policy_dev, value_dev, stream);
@@ -1049,11 +1050,7 @@ int tg_net_forward_dev(tg_net *net, const float *planes_dev, int batch, int want
             TG_HIP(hipMemsetAsync(flag, 0, 2 * sizeof(int), st));
             int rc = pick_w1d(9, batch, net->num_cus)
                          ? tg::w1d_forward(net, group, planes_dev, batch, want_logits, policy_dev, value_dev, flag, st)
-                     : pick_wsplit(9)
-                         ? tg::wsplit_forward(net, group, planes_dev, batch, want_logits, policy_dev, value_dev, flag, st)
-                         : (pick_w2(9, batch, net->num_cus)
-                                ? tg::w2_forward(net, planes_dev, batch, want_logits, policy_dev, value_dev, flag, st)
-                                : tg::split_forward(net, group, planes_dev, batch, want_logits, policy_dev, value_dev, flag, st));
+                         : tg::split_forward(net, group, planes_dev, batch, want_logits, policy_dev, value_dev, flag, st);
             if (rc) return rc;
             if (group == 3) return launch_wino8<9, 3>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st, flag);
             return launch_wino8<9, 1>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st, flag);
@@ -1073,6 +1070,20 @@ int tg_net_range_fallbacks(tg_net *net, unsigned long long *count) {
     TG_HIP(hipSetDevice(net->device));
     TG_HIP(hipDeviceSynchronize());
     TG_HIP(hipMemcpy(count, net->dev.fallbacks, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return TG_OK;
+}
+
+int tg_net_band_timeouts(tg_net *net, unsigned long long *count) {
+    if (!net || !count) return tg::fail(TG_ERR_ARG, "tg_net_band_timeouts: null argument");
+    TG_HIP(hipSetDevice(net->device));
+    TG_HIP(hipDeviceSynchronize());
+    *count = net->band_timeouts_host ? *net->band_timeouts_host : 0ull;
+    return TG_OK;
+}
+
+int tg_net_set_shared_device(tg_net *net, int shared) {
+    if (!net) return tg::fail(TG_ERR_ARG, "tg_net_set_shared_device: null argument");
+    net->shared_device = shared != 0;
     return TG_OK;
 }
 

@@ -176,6 +176,7 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_band_kernel(
             __builtin_amdgcn_s_sleep(2);
             if (++n > kBandSpinLimit) {
                 *reinterpret_cast<volatile int *>(dead) = 1;
+                if (net.band_timeouts) atomicAdd(net.band_timeouts, 1u);   // (host-mapped: tg_net_band_timeouts, band_count)
                 break;
             }
         }
@@ -520,6 +521,11 @@ int band_count(const tg_net *net, int batch) {
     const int forced = env ? atoi(env) : -1;
     if (net->board_size != 19 || forced == 0) return 0;
     if (net->forward_grid_cap > 0) return 0;               // CUs are held back for other streams' kernels
+    // A device shared with other PROCESSES (more self-play shards than GPUs, TG_SINGLE_DEVICE): their kernels can keep bands
+    // off the CUs for longer than the bounded waits - results stay right (the exact kernel redoes the batch) but every such
+    // launch costs 0.1 s.  Announced (tg_net_set_shared_device) or found out (a first bounded wait gave up): stay on the
+    // one-workgroup kernel.  A forced TG_FWD_BANDS still wins (tests).
+    if (forced < 0 && (net->shared_device || (net->band_timeouts_host && *net->band_timeouts_host > 0))) return 0;
     // (Two banded launches whose workgroups do not all fit on the device could hold each other's missing bands off the CUs until
     // the bounded waits give up: launch_band lets a network's banded launches follow each other across streams.)  With the
     // sub-group streams of a self-play move in flight (guard_grid_cap is set exactly then) a launch takes a quarter of the CUs

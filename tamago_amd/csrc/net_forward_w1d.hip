@@ -1,35 +1,25 @@
-// DualNet forward for gfx950, 9x9: Winograd F(2x2,3x3) residual tower ON SPLIT OPERANDS (round 4).
+// DualNet forward for gfx950: the residual tower as Winograd F(2,3) along ONE axis on split operands (round 4; its own file
+// since round 5 - the 2-D Winograd tower it grew out of is kept, unbuilt, under tools/experiments/kernels/).
 //
-// net_forward_split.hip runs the fp32 3x3 convolutions on the 16-bit matrix pipe as three f16 products per fp32
-// product (a = ah + al, w = wh + wl:  a w ~ ah wh + ah wl + al wh) - and is bound by the MFMA count: the pipe is
-// power- and issue-capped, and 228.6 MFLOP of MFMAs are issued per position for 72.3 MFLOP of
-// algorithm.  This kernel cuts the count: per 2x2 output tile Y = A^T [ (G g G^T) . (B^T d B) ] A, i.e. 16
-// transform points x (25 tiles per board) instead of 9 taps x 81 positions = 1.82x fewer MFMA rows; 127.9 MFLOP
-// issued per position.  What makes it work (measured first: tools/microbench/wino_issue_model.hip,
-// profiles/r04_microbench_wino_issue_model.txt; tools/experiments/winograd_split_accuracy.py):
-//   * V = B^T d B is computed in fp32 (adds only, exact inputs) and split AFTERWARDS into two f16 pieces; the weights
-//     U = G g G^T are computed in fp64 on the host with the batch-norm scale folded in, scaled by a power of two per
-//     layer and split there.  Logit error against the reference's fp64 forward: the same class as the direct split
-//     kernel and the reference's own fp32 path.
-//   * the LOW pieces are kept UNSCALED (al = rn16(a - ah), no 2^11): v_mfma_f32_16x16x32_f16 keeps f16 subnormals
-//     (probe in the micro-benchmark), so the cross terms have the right magnitude by themselves and ONE accumulator
-//     set takes all three products (K = 64 per Winograd point: six MFMAs per accumulator).
-//   * a Winograd point's GEMM is tiny (tiles x 64 x 64), so the operands decide the structure: wave w of the four
-//     owns POINT ROW w (four points, all 64 output channels, all tiles).  Its 64 weight fragments (64 KB) are
-//     loaded once per layer and stay in registers; it computes only its own row of the input transform (no wave
-//     repeats another's VALU work - the loop is VALU-bound: beside an MFMA stream every VALU instruction beyond
-//     two per MFMA costs ~3.4 cycles); the transform along the point row's own axis is done in registers, and the
-//     sum over the four point rows goes through a 32 KB LDS exchange: Z = M A (two values per row instead of
-//     four), then wave w' finishes output channels [16 w', 16 w' + 16): folded shift, residual, ReLU, store.
-//   * activations stay in LDS as fp32 [position][64 channels] (two buffers: block input X - also the residual -
-//     and the intermediate H), 16-byte chunk index XOR-swizzled by a function of the position under which the
-//     4 x 4 patch reads of sixteen tiles are conflict-free for every patch cell; the tiles are assigned to lanes
-//     so that this holds (host: ws_geometry).  All per-lane LDS addresses of a row tile come from two small
-//     tables in global memory (the geometry is the same for every layer and workgroup): no address arithmetic in
-//     the loop.
-// Stem (6 -> 64 channels) and heads are the direct split kernel's (im2col'ed K = 64 product; 1x1 convolutions and
-// policy FC on the 16-bit pipe), reading / writing the fp32 images.  f16 range guard as there: |V| <= 4 |d| must stay
-// below 65504, so a layer output beyond 16000 raises the flag and the exact-fp32 kernel redoes the batch.
+// net_forward_split.hip runs the fp32 3x3 convolutions on the 16-bit matrix pipe as three f16 products per fp32 product
+// (a = ah + al, w = wh + wl:  a w ~ ah wh + ah wl + al wh) and is bound by the MFMA count (857 per wave and layer for three
+// boards); 2-D Winograd F(2x2,3x3) issues 480 but 5.3 VALU instructions beside each and is bound by instruction issue.
+// Transforming along x only sits between: 600 MFMAs per wave and layer, one transform pass per side - 1.3 VALU instructions
+// per MFMA, inside what an MFMA's 16 cycles hide.  Shared with the kernels of this family:
+//   * V = B^T d is computed in fp32 (one add per value, exact inputs) and split AFTERWARDS into two f16 pieces; the weights
+//     U = G g are computed in fp64 on the host with the batch-norm scale folded in, scaled by a power of two per layer and
+//     split there.  Logit error against the reference's fp64 forward: the class of the reference's own fp32 path.
+//   * the LOW pieces are kept UNSCALED (al = rn16(a - ah), no 2^11): v_mfma_f32_16x16x32_f16 keeps f16 subnormals, so the
+//     cross terms have the right magnitude by themselves and ONE accumulator set takes all three products.
+//   * wave w of the four owns transform POINT w: its weight fragments of a layer stay in registers (AGPRs, requested by
+//     inline asm with explicit waits - tests/test_isa_waits.py checks the emitted code), the sum over the points goes
+//     through a 32 KB LDS exchange, wave w' finishes output channels [16 w', 16 w' + 16).
+//   * activations stay in LDS as fp32 [position][64 channels] (block input X - also the residual - and the intermediate
+//     H), 16-byte chunk index XOR-swizzled by a function of the position under which the reads of sixteen units are
+//     conflict-free for every cell.
+// Stem (6 -> 64 channels) and heads are the direct split kernel's (im2col'ed K = 64 product; 1x1 convolutions and policy
+// FC on the 16-bit pipe), reading / writing the fp32 images.  f16 range guard as there: |V| <= 2 |d| must stay below 65504,
+// so a layer output beyond 16000 raises the flag and the exact-fp32 kernel redoes the batch.
 // Reference: nn/network/res_block.py:8-38, nn/network/dual_net.py:41-52.
 #include "split_common.h"
 
@@ -72,16 +62,8 @@ struct WsCfg {
     static_assert(LDS_BYTES <= 163840, "LDS");
 };
 
-// 16-byte chunk XOR of activation row R (position 81 b + 9 y + x): g = ((y + 1) / 2 + 5 ((x + 1) / 2) + b) mod 8, spread
-// over chunk-index bits 0, 2, 3 (bit 1 is the one in which the two lane groups of a ds_read_b128 cycle differ)
-__host__ __device__ inline int ws_swz(int R) {
-    const int b = R >= 162 ? 2 : (R >= 81 ? 1 : 0);
-    const int p = R - 81 * b, y = (p * 57) >> 9, x = p - 9 * y;
-    const int g = (((y + 1) >> 1) + 5 * ((x + 1) >> 1) + b) & 7;
-    return (g & 1) | ((g & 6) << 1);
-}
-
-// ... and of the kernel that transforms along x only (dualnet_fwd_w1d_kernel): its sixteen MFMA columns are the units
+// 16-byte chunk XOR of activation row R (position 81 b + 9 y + x), spread over chunk-index bits 0, 2, 3 (bit 1 is the one in
+// which the two lane groups of a ds_read_b128 cycle differ).  The kernel's sixteen MFMA columns are the units
 // u = 5 board + t (outputs x = 2t, 2t + 1 of ONE board row); a unit's cells x = 2t - 1 .. 2t + 2 have (x + 1) / 2 = t or t + 1,
 // so g = (5 board + (x + 1) / 2) mod 8 is distinct over the eight units of either half of a ds_read_b128 cycle
 __host__ __device__ inline int w1_swz(int R) {
@@ -143,55 +125,6 @@ __device__ __forceinline__ void split4_unscaled(const f32x4 v, unsigned (&hi)[2]
     lo[1] = low_pieces(v[2], v[3], hi[1]);
 }
 
-// Request the 32 weight fragments of k-chunk KC of a wave's layer block wb ([j 4][kc 2][piece 2][ct 4][lane][16 B]) into
-// AGPRs.  (A free function: clang rejects asm operands that name captured variables inside a generic lambda.)
-template <int KC>
-__device__ __forceinline__ void ws_load_w(i32x4v (&ua)[4][2][2][4], const unsigned char *wb, int wlane) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const unsigned char *base = wb + ((j * 2 + KC) * 2 + p) * 4096;
-            asm volatile("global_load_dwordx4 %0, %4, %5\n\t"
-                         "global_load_dwordx4 %1, %4, %5 offset:1024\n\t"
-                         "global_load_dwordx4 %2, %4, %5 offset:2048\n\t"
-                         "global_load_dwordx4 %3, %4, %5 offset:3072"
-                         : "=a"(ua[j][KC][p][0]), "=a"(ua[j][KC][p][1]), "=a"(ua[j][KC][p][2]), "=a"(ua[j][KC][p][3])
-                         : "v"(wlane), "s"(base)
-                         : "memory");
-        }
-}
-
-// The same for ONE point J of k-chunk KC (eight fragments: two asm statements), or only its channel tile ct of both pieces
-// (two fragments): the requests are placed between the instructions of the layer's last row tile.
-template <int KC, int J>
-__device__ __forceinline__ void ws_load_w_point(i32x4v (&ua)[4][2][2][4], const unsigned char *wb, int wlane, int ct = -1) {
-    if (ct < 0) {
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const unsigned char *base = wb + ((J * 2 + KC) * 2 + p) * 4096;
-            asm volatile("global_load_dwordx4 %0, %4, %5\n\t"
-                         "global_load_dwordx4 %1, %4, %5 offset:1024\n\t"
-                         "global_load_dwordx4 %2, %4, %5 offset:2048\n\t"
-                         "global_load_dwordx4 %3, %4, %5 offset:3072"
-                         : "=a"(ua[J][KC][p][0]), "=a"(ua[J][KC][p][1]), "=a"(ua[J][KC][p][2]), "=a"(ua[J][KC][p][3])
-                         : "v"(wlane), "s"(base)
-                         : "memory");
-        }
-    } else {
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (c == ct) {
-                const unsigned char *base = wb + ((J * 2 + KC) * 2) * 4096 + c * 1024;
-                asm volatile("global_load_dwordx4 %0, %2, %3\n\t"
-                             "global_load_dwordx4 %1, %2, %4"
-                             : "=a"(ua[J][KC][0][c]), "=a"(ua[J][KC][1][c])
-                             : "v"(wlane), "s"(base), "s"(base + 4096)
-                             : "memory");
-            }
-    }
-}
-
 // dualnet_fwd_w1d_kernel: fragment F = 8 kc + 4 piece + ct of a tap block ([kc 2][piece 2][ct 4][lane][16 B]) into AGPR slot SLOT
 template <int SLOT, int F>
 __device__ __forceinline__ void w1_request(i32x4v (&ua)[4][2][2][4], const unsigned char *tapbase, int wlane, std::integral_constant<int, F>) {
@@ -207,9 +140,9 @@ __device__ __forceinline__ void w1_request_tap(i32x4v (&ua)[4][2][2][4], const u
     static_for<16>([&](auto F_) { w1_request<SLOT>(ua, tapbase, wlane, F_); });
 }
 
-// Heads on the 16-bit matrix pipe (split_common.h: run_heads_mfma), reading the block output from the fp32 image X:
+// Heads on the 16-bit matrix pipe (as split_common.h: run_heads_mfma), reading the block output from the fp32 image X:
 // a B fragment (position li of a 16-row tile, channels 32 kc + 8 lg ..) is two 16-byte reads + the operand split.
-template <int G, typename C, int SWZ = 0>
+template <int G, typename C, int SWZ>
 __device__ __forceinline__ void run_heads_x32(unsigned char *smem, const NetDev &net, int b0, int batch, int want_logits,
                                               float *__restrict__ policy, float *__restrict__ value, int tid, int wave,
                                               long long *tl) {
@@ -255,7 +188,7 @@ __device__ __forceinline__ void run_heads_x32(unsigned char *smem, const NetDev 
         const int t = wave + q * NW;
         const int row = (t < C::MT ? t : wave) * 16 + li;
         const int rr = row < M ? row : M + 1;              // zero row
-        const int sw = row < M ? (SWZ == 2 ? w1g1_swz(row) : (SWZ ? w1_swz(row) : ws_swz(row))) : 0;
+        const int sw = row < M ? (SWZ == 2 ? w1g1_swz(row) : w1_swz(row)) : 0;
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc) {
             const int a0 = C::X_OFF + rr * 256 + (((kc * 8 + lg * 2) ^ sw) << 4);
@@ -368,513 +301,9 @@ __device__ __forceinline__ void run_heads_x32(unsigned char *smem, const NetDev 
     }
 }
 
-// PROF: s_memtime stamps of workgroup 0 / wave 0 (tg_net_profile_phases): [0] group start, [1] input staged, [2] stem done,
-// [3..14] layer done, [15] heads done; [40 + 35 (layer - 2) + 7 rt + i] for layers 2 and 3: i = 0 row tile start,
-// 1 phase A done, 2 phase B done, 3 tail done + barrier passed, 4 (last row tile: own epilogue done)
-template <int G, bool PROF>
-__global__ __launch_bounds__(256, 1) void dualnet_fwd_wsplit_kernel(
-    NetDev net, const float *__restrict__ planes, int batch, int want_logits,
-    float *__restrict__ policy, float *__restrict__ value, int *__restrict__ overflow) {
-    using C = WsCfg<G>;
-    using F = FmtF16;
-    constexpr int P = C::P, M = C::M, NTHR = C::NTHR, NRT = C::NRT, RTW = C::RTW, IMG = C::IMG;
-    constexpr int GI = G == 3 ? 1 : 0;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63, li = lane & 15, lg = lane >> 4;
-
-    if (static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) unsigned char *)smem)) != 0u)
-        __builtin_trap();                                      // absolute LDS addressing below
-    // ---- once per workgroup: zero + dump rows, head tables ----
-    for (int e = tid; e < 2 * 2 * 64; e += NTHR) {             // rows M, M + 1 of X and H
-        const int buf = e >> 7, r = (e >> 6) & 1, c = e & 63;
-        reinterpret_cast<float *>(smem + buf * C::BUF + (M + r) * 256)[c] = 0.f;
-    }
-    for (int e = tid; e < C::A; e += NTHR) reinterpret_cast<float *>(smem + C::HB_OFF)[e] = net.pfc_b[e];
-    for (int e = tid; e < 3 * P + 3; e += NTHR)
-        reinterpret_cast<float *>(smem + C::VW_OFF)[e] = e < 3 * P ? net.vfc_w[e] : net.vfc_b[e - 3 * P];
-    stage_head_tables<C, NTHR>(smem, net, tid);
-
-    int stamp_i = 0;
-    auto stamp = [&]() {
-        if constexpr (PROF)
-            if (blockIdx.x == 0 && tid == 0 && stamp_i < 40) net.timeline[stamp_i++] = (long long)__builtin_amdgcn_s_memtime();
-    };
-    int dstamp_base = -1;                                      // detailed stamps of the current layer, or -1
-    auto dstamp = [&](int rt, int i) {
-        if constexpr (PROF)
-            if (blockIdx.x == 0 && tid == 0 && dstamp_base >= 0 && stamp_i < 40)
-                net.timeline[dstamp_base + 7 * rt + i] = (long long)__builtin_amdgcn_s_memtime();
-    };
-    int ovf = 0;
-    const int n_groups = (batch + G - 1) / G;
-    constexpr int NPL = (G * 6 * P + NTHR - 1) / NTHR;
-    float pre[NPL];
-    auto fetch_planes = [&](int grp2) __attribute__((always_inline)) {
-        int ft = tid;
-        asm volatile("" : "+v"(ft));
-#pragma unroll
-        for (int i = 0; i < NPL; ++i) {
-            const int e = ft + i * NTHR;
-            const int b = grp2 * G + e / (6 * P);
-            pre[i] = (e < G * 6 * P && grp2 < n_groups && b < batch)
-                         ? __builtin_nontemporal_load(&planes[(size_t)grp2 * G * 6 * P + e]) : 0.f;
-        }
-    };
-    fetch_planes(blockIdx.x);
-    const float sgn = wave == 1 ? 1.f : -1.f;                  // row pass of point row w: d[ra] + sgn d[rb]
-    const int *const tin_w = net.ws_tin[GI] + (size_t)wave * NRT * 64 * 8;
-    const int *const tout_w = net.ws_tout[GI] + (size_t)wave * NRT * 64 * 8;
-    // LDS address tables of the row tile about to be processed (carried across layers: the geometry repeats; fetched per
-    // group behind the stem - kept alive through stem and heads they cost 16 spilled registers, and the scratch lines, 125 us
-    // apart, came back from HBM: 3.6 KB per position of fabric traffic for nothing)
-    i32x4v ta, tb, to, tr, to2, tr2, ta1, tb1;
-    // This wave's 64 weight fragments of a layer, [j 4][kc 2][piece 2][ct 4]: resident in the accumulation half of the
-    // register file for the whole layer (MFMA A operands are read from there directly).  They are requested by inline
-    // asm with AGPR destinations - left to the register allocator they end up in VGPRs, spilled to AGPRs and copied back
-    // before every use - so hipcc does not track them: the waits are explicit (body) and nothing may copy these registers
-    // between a request and its wait (checked in the ISA).  All requests of a k-chunk go out in the layer BEFORE, in its
-    // last row tile, as soon as the chunk's own MFMAs are done; layer 0's at kernel start and in layer 11's last row tile.
-    i32x4v ua[4][2][2][4];
-    const int wlane = lane * 16;
-    auto load_w = [&](auto KC_, int layer) __attribute__((always_inline)) {
-        ws_load_w<decltype(KC_)::value>(ua, net.ws_w + ((size_t)layer * 4 + wave) * 65536, wlane);
-    };
-    load_w(std::integral_constant<int, 0>{}, 0);
-    load_w(std::integral_constant<int, 1>{}, 0);
-
-    // Groups beyond a workgroup's first are handed out by a ticket counter (overflow[1], zeroed with the range flag): a
-    // workgroup that starts late - its CU was running another stream's tree kernel - takes fewer groups instead of
-    // holding the launch up with a full static share.  The ticket travels through a spare word of the bias table.
-    int *const ticket_lds = reinterpret_cast<int *>(smem + C::HB_OFF + 83 * 4);
-    for (int grp = blockIdx.x; grp < n_groups;) {
-        const int b0 = grp * G;
-        if (tid == 0) *ticket_lds = overflow ? (int)gridDim.x + atomicAdd(overflow + 1, 1) : grp + (int)gridDim.x;
-        stamp();
-        // ================= stem: planes -> im2col'ed f16-pair images (K = 9 taps x 6 planes, padded to 64) =================
-        // (its 16 weight fragments are requested first: their L2 round trip runs under the staging pass)
-        i32x4v fa[2][2][4];                                      // [kc][piece][ct]
-        {
-            int wvg = lane * 16;
-            asm volatile("" : "+v"(wvg));
-#pragma unroll
-            for (int kc = 0; kc < 2; ++kc)
-#pragma unroll
-                for (int p = 0; p < 2; ++p)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        gmem_load_frag(fa[kc][p][c], net.wsplit + (size_t)kc * 8192, wvg + (p * 4 + c) * 1024);
-        }
-        {
-            float *st = reinterpret_cast<float *>(smem + C::STAGE);
-            int stid = tid;
-            asm volatile("" : "+v"(stid));
-#pragma unroll
-            for (int i = 0; i < NPL; ++i)
-                if (stid + i * NTHR < G * 6 * P) st[stid + i * NTHR] = pre[i];
-            for (int e = stid; e < 4 * 64; e += NTHR)           // zero blocks of the four images
-                reinterpret_cast<unsigned *>(smem + C::SI_OFF + (e >> 6) * IMG + C::ZOFF)[e & 63] = 0u;
-            __syncthreads();
-            for (int row = stid; row < M; row += NTHR) {
-                const int bl = row / P, p = row - bl * P, y = p / 9, x = p - y * 9;
-                const float *src = st + bl * 6 * P + p;
-                const int swz = (row >> 1) & 3;
-#pragma unroll
-                for (int sl = 0; sl < 8; ++sl) {
-                    f32x4 lo, hi;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int k = sl * 8 + j, t = k / 6, c = k - t * 6;
-                        const int dy = t / 3 - 1, dx = t % 3 - 1;
-                        const bool ok = k < 54 && (unsigned)(y + dy) < 9u && (unsigned)(x + dx) < 9u;
-                        const float v = ok ? src[c * P + dy * 9 + dx] : 0.f;
-                        if (j < 4) lo[j] = v; else hi[j - 4] = v;
-                    }
-                    uint2 plo[2], phi[2];
-                    split4<F>(lo, plo);
-                    split4<F>(hi, phi);
-                    const int kc = sl >> 2, slot = (sl & 3) ^ swz;
-#pragma unroll
-                    for (int q = 0; q < 2; ++q)
-                        *reinterpret_cast<uint4 *>(smem + C::SI_OFF + (q * 2 + kc) * IMG + row * 64 + slot * 16) =
-                            uint4{plo[q].x, plo[q].y, phi[q].x, phi[q].y};
-                }
-            }
-        }
-        __syncthreads();
-        stamp();
-        float amax = 0.f;
-        {
-            // stem product: 2 k-chunks x 4 channel tiles x RTW row tiles x 3 f16 products (two accumulator sets, scaled
-            // low pieces: the direct split kernel's image and weights), batch norm, ReLU -> X (fp32, swizzled)
-#pragma unroll
-            for (int r = 0; r < RTW; ++r) {
-                int row = (wave * RTW + r) * 16 + li;
-                asm volatile("" : "+v"(row));
-                const int nat = row * 64 + ((lg ^ ((row >> 1) & 3)) << 4);
-                const int addr = C::SI_OFF + (row < M ? nat : C::ZOFF + (nat & 255));
-                i32x4v fb[2][2];                                 // [piece][kc]
-                lds_load_frag<0 * IMG>(fb[0][0], smem, addr);
-                lds_load_frag<1 * IMG>(fb[0][1], smem, addr);
-                lds_load_frag<2 * IMG>(fb[1][0], smem, addr);
-                lds_load_frag<3 * IMG>(fb[1][1], smem, addr);
-                const int orow = row < M ? row : M;
-                const int osw = row < M ? ws_swz(row) : 0;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
-#pragma unroll
-                    for (int kc = 0; kc < 2; ++kc) {
-                        a0 = mfma16<F>(fa[kc][0][c], fb[0][kc], a0);
-                        a1 = mfma16<F>(fa[kc][1][c], fb[0][kc], a1);
-                        a1 = mfma16<F>(fa[kc][0][c], fb[1][kc], a1);
-                    }
-                    const f32x4 sc = *reinterpret_cast<const f32x4 *>(net.sscale + c * 16 + lg * 4);
-                    const f32x4 sh = *reinterpret_cast<const f32x4 *>(net.shift + c * 16 + lg * 4);
-                    f32x4 v;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float t = fmaf(a1[j], 1.f / 2048.f, a0[j]);
-                        t = fmaf(t, sc[j], sh[j]);
-                        v[j] = fmaxf(t, 0.f);
-                    }
-                    amax = fmaxf(fmaxf(amax, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
-                    *reinterpret_cast<f32x4 *>(smem + C::X_OFF + orow * 256 + (((c * 4 + lg) ^ osw) << 4)) = v;
-                }
-            }
-        }
-        __syncthreads();                                        // X complete; the overlay is free again
-        if (tid < 64) reinterpret_cast<float *>(smem + C::H_OFF + (M + 1) * 256)[tid] = 0.f;   // H's zero row was under it
-        stamp();
-
-        // ================= tower: 12 Winograd layers =================
-        // A row tile is two MFMA phases and a short tail (IN / OUT = byte offsets of the input / output buffer, RES: add the
-        // residual from OUT):
-        //   A  the 48 MFMAs of k-chunk 0 | input transform of k-chunk 1 (its patch cells were read a phase ago) | the
-        //      EPILOGUE OF THE PREVIOUS ROW TILE (exchange reads, sum over the point rows, shift, residual, ReLU, stores) |
-        //      patch reads of the next row tile's k-chunk 0
-        //   B  the 48 MFMAs of k-chunk 1 | input transform of the next row tile's k-chunk 0 | output transform along the point
-        //      row as far as the finished accumulators allow (Z0 complete and written behind point 2) | patch reads of the
-        //      next row tile's k-chunk 1
-        //   tail  Z1 = (m1 - m2) - m3, written; barrier
-        // A and B are written slice by slice - one MFMA and the instructions that ride along - with a scheduling barrier
-        // behind each slice: an MFMA occupies the pipe for 16 cycles and the wave issues two to three other instructions
-        // meanwhile; everything beyond that costs its issue time, but no longer its LATENCY (LDS round trips, the exchange's
-        // write bandwidth, barriers waiting for stragglers), which is what the un-overlapped version paid
-        // (profiles/r04_phase_wsplit_v1.txt: 4.8 k cycles per row tile; r04_phase_wsplit_v2_pipelined.txt: 4.3 k with the
-        // transform under the MFMAs and 2 k of those in the exchange + epilogue).  The layer's last row tile has no next
-        // row tile to prepare (the next layer's input is still being written): its slices carry the REQUESTS for the next
-        // layer's weight fragments instead - a k-chunk's 32 registers are dead once its MFMAs are issued -, its epilogue runs
-        // on its own, and the next layer starts with one un-overlapped transform.
-        f32x4 dq[2][4][2];                                     // patch cells read ahead: [row a / b][column s][channel half]
-        i32x4v bh0[4], bl0[4];                                 // operand pieces of (row tile, k-chunk 0), built a phase ahead
-        auto read_cell = [&](auto IN_, auto KC_, auto C8_, const i32x4v &pa, const i32x4v &pb) __attribute__((always_inline)) {
-            constexpr int IN = decltype(IN_)::value, kc = decltype(KC_)::value, c8 = decltype(C8_)::value;
-            const int a0 = (c8 < 4 ? pa[c8] : pb[c8 - 4]) ^ (kc << 7);
-            dq[c8 >> 2][c8 & 3][0] = lds_f32x4_at<IN>(a0);
-            dq[c8 >> 2][c8 & 3][1] = lds_f32x4_at<IN>(a0 ^ 16);
-        };
-        // the input transform of one k-chunk in 48 slices: 0..15 row pass t = d[ra] + sgn d[rb] (two values each), 16..47 per
-        // (point j, channel half h) four slices of two to three instructions: column pass, high pieces, low pieces
-        f32x4 tq[4][2];
-        float tv[8][4];
-        unsigned thi[8][2];
-        auto tslice = [&](auto I_, i32x4v (&oh)[4], i32x4v (&ol)[4]) __attribute__((always_inline)) {
-            constexpr int i = decltype(I_)::value;
-            if constexpr (i < 16) {
-                constexpr int s_ = i >> 2, h = (i >> 1) & 1, e0 = (i & 1) * 2;
-                tq[s_][h][e0] = fmaf(dq[1][s_][h][e0], sgn, dq[0][s_][h][e0]);
-                tq[s_][h][e0 + 1] = fmaf(dq[1][s_][h][e0 + 1], sgn, dq[0][s_][h][e0 + 1]);
-            } else {
-                constexpr int k = (i - 16) >> 2, q = (i - 16) & 3, j = k >> 1, h = k & 1;
-                auto col = [&](int e) __attribute__((always_inline)) {
-                    return j == 0 ? tq[0][h][e] - tq[2][h][e] : (j == 1 ? tq[1][h][e] + tq[2][h][e]
-                         : (j == 2 ? tq[2][h][e] - tq[1][h][e] : tq[1][h][e] - tq[3][h][e]));
-                };
-                if constexpr (q == 0) {
-                    tv[k][0] = col(0); tv[k][1] = col(1); tv[k][2] = col(2);
-                } else if constexpr (q == 1) {
-                    tv[k][3] = col(3);
-                    thi[k][0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{tv[k][0], tv[k][1]}, f16x2));
-                    thi[k][1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{tv[k][2], tv[k][3]}, f16x2));
-                } else if constexpr (q == 2) {
-                    oh[j][2 * h] = (int)thi[k][0];
-                    ol[j][2 * h] = (int)low_pieces(tv[k][0], tv[k][1], thi[k][0]);
-                } else {
-                    oh[j][2 * h + 1] = (int)thi[k][1];
-                    ol[j][2 * h + 1] = (int)low_pieces(tv[k][2], tv[k][3], thi[k][1]);
-                }
-            }
-        };
-        // MFMA m of a k-chunk: point j = m / 12, product (m / 4) % 3 (cross terms first), channel tile m % 4
-        f32x4 acc[4][4];
-        auto mfma_slice = [&](auto KC_, auto M_, const i32x4v (&ph)[4], const i32x4v (&pl)[4]) __attribute__((always_inline)) {
-            constexpr int kc = decltype(KC_)::value, m = decltype(M_)::value, j = m / 12, st = (m / 4) % 3, c = m % 4;
-            if constexpr (st == 0)
-                acc[j][c] = mfma16<F>(ua[j][kc][1][c], ph[j], kc == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[j][c]);
-            else if constexpr (st == 1) acc[j][c] = mfma16<F>(ua[j][kc][0][c], pl[j], acc[j][c]);
-            else acc[j][c] = mfma16<F>(ua[j][kc][0][c], ph[j], acc[j][c]);
-        };
-        // The epilogue of one row tile, output q = 2 r + c at (2 ty + r, 2 tx + c), in six steps: 0 the three exchange reads
-        // (+ the residual), 1..4 one channel each (sum over the point rows, shift, residual, ReLU), 5 range check + store.
-        // Output channels 16 wave + 4 lg ..; po / pr: the row tile's store / residual address tables.
-        f32x4 ez[4][3], eres[4], ev[4];
-        auto epi_step = [&](auto OUT_, auto RES_, auto Q_, auto I_, const i32x4v &po, const i32x4v &pr, const f32x4 shf, const float down,
-                            int exr) __attribute__((always_inline)) {
-            constexpr int OUT = decltype(OUT_)::value, q = decltype(Q_)::value, i = decltype(I_)::value, r = q >> 1, cc = q & 1;
-            constexpr bool RES = decltype(RES_)::value;
-            if constexpr (i == 0) {
-                static_for<3>([&](auto U_) {                       // point rows r .. r + 2
-                    constexpr int u = decltype(U_)::value;
-                    ez[q][u] = lds_f32x4_at<((r + u) * 2 + cc) * 4096>(exr);
-                });
-                if constexpr (RES) eres[q] = lds_f32x4_at<OUT>(pr[q]);
-            } else if constexpr (i <= 4) {
-                constexpr int e = i - 1;
-                const float y = r == 0 ? (ez[q][0][e] + ez[q][1][e]) + ez[q][2][e] : (ez[q][0][e] - ez[q][1][e]) - ez[q][2][e];
-                float tt = fmaf(y, down, shf[e]);
-                if constexpr (RES) tt += eres[q][e];
-                ev[q][e] = fmaxf(tt, 0.f);
-            } else {
-                amax = fmaxf(fmaxf(amax, ev[q][0]), ev[q][1]);        // (v_max3_f32)
-                amax = fmaxf(fmaxf(amax, ev[q][2]), ev[q][3]);
-                lds_f32x4_put<OUT>(po[q], ev[q]);
-            }
-        };
-        // output transform along the point row, riding along phase B: zs01 = m0 + m1 (behind point 1), Z0 = zs01 + m2 and
-        // zd12 = m1 - m2 (behind point 2; Z0 written), Z1 = zd12 - m3 in the tail
-        f32x4 zs01[4], zd12[4];
-        constexpr bool DEFER = G == 3;                         // the last row tile's tail + epilogue ride in the next layer (see body)
-        f32x4 pshf = f32x4{0.f, 0.f, 0.f, 0.f};                // the previous layer's epilogue constants
-        float pdown = 0.f;
-        auto ztail = [&](auto C_, int exw) __attribute__((always_inline)) {
-            constexpr int c = decltype(C_)::value;
-            f32x4 z1;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) z1[e] = zd12[c][e] - acc[3][c][e];
-            lds_f32x4_put<4096 + c * 1024>(exw, z1);
-        };
-        auto body = [&](auto IN_, auto OUT_, auto RES_, auto FIRST_, auto LAST_, int rt, int next_layer, const f32x4 shf,
-                        const float down) __attribute__((always_inline)) {
-            constexpr bool FIRST = decltype(FIRST_)::value, LAST = decltype(LAST_)::value, RES = decltype(RES_)::value;
-            dstamp(rt, 0);
-            const unsigned char *wnext = net.ws_w + ((size_t)next_layer * 4 + wave) * 65536;
-            i32x4v bh1[4], bl1[4];
-            // exchange addresses (absolute): this wave's block / its channel tile.  (The exchange lies beyond the 64 KB an
-            // LDS instruction's offset field reaches: with the base as an immediate every access cost a v_add_u32.)
-            int exw = C::EX_OFF + wave * 8192 + lane * 16, exr = C::EX_OFF + wave * 1024 + lane * 16;
-            asm volatile("" : "+v"(exw), "+v"(exr));
-            // (last row tile) the tables the code behind the weight requests needs are fetched here and waited for in slice 12
-            // of phase A, before the first request goes out: hipcc's own counted waits know nothing of the asm requests, so a
-            // wait for any load of its own that is older than requests in flight would drain those as well.  ta1 / tb1: row
-            // tile 1's patch table (next layer); to2 / tr2: this row tile's store / residual table (its epilogue runs last)
-            if constexpr (LAST) {
-                ta1 = *reinterpret_cast<const i32x4v *>(tin_w + ((size_t)64 + lane) * 8);
-                tb1 = *reinterpret_cast<const i32x4v *>(tin_w + ((size_t)64 + lane) * 8 + 4);
-                to2 = *reinterpret_cast<const i32x4v *>(tout_w + ((size_t)(NRT - 1) * 64 + lane) * 8);
-                tr2 = *reinterpret_cast<const i32x4v *>(tout_w + ((size_t)(NRT - 1) * 64 + lane) * 8 + 4);
-            }
-            // ---- phase A ----
-            asm volatile("s_waitcnt vmcnt(32)" ::: "memory");     // this layer's k-chunk 0 fragments (requested a layer ago; the
-                                                                  // 32 requests behind them - k-chunk 1's - may still be in flight)
-            __builtin_amdgcn_sched_barrier(0);                    // (an MFMA is no memory operation: nothing else keeps it behind the wait)
-            static_for<48>([&](auto M_) {
-                constexpr int m = decltype(M_)::value;
-                mfma_slice(std::integral_constant<int, 0>{}, M_, bh0, bl0);
-                tslice(M_, bh1, bl1);
-                // previous row tile's epilogue: output q's exchange reads in slice 6 q, its five compute / store steps in slices
-                // 6 q + 7 .. 6 q + 11 - a whole output later, so that the LDS round trip (150+ cycles with four waves on the
-                // LDS) is over when the values are needed (next slice: +500 cycles per phase, profiles/r04_phase_wsplit_v4.txt)
-                // ... behind the previous row tile's Z1 = (m1 - m2) - m3 (slices 0 .. 3: point 3 finished with phase B's last
-                // MFMA) and the barrier that publishes the exchange (slice 5): write latency and stragglers cost MFMA slots that
-                // are filled anyway instead of a tail of their own
-                // (three boards per workgroup: a layer's FIRST row tile carries the PREVIOUS LAYER's last row tile the same way -
-                // that row tile holds tiles of the third board only, row tiles 0 and 1 tiles of the first two (ws_geometry), so
-                // nothing this layer reads before the next barriers is written by it; its output buffer is this layer's
-                // input, its residual flag the opposite, its constants pshf / pdown, its tables to2 / tr2)
-                constexpr bool EPI = !FIRST || DEFER;
-                if constexpr (!FIRST && m < 4) ztail(std::integral_constant<int, m>{}, exw);
-                if constexpr (!FIRST && m == 5) __syncthreads();   // (the deferred row tile's Z1 went out before the layer's closing barrier)
-                if constexpr (EPI && m >= 6 && m < 30 && m % 6 == 0) {
-                    if constexpr (FIRST) epi_step(IN_, std::integral_constant<bool, !RES>{}, std::integral_constant<int, m / 6 - 1>{}, std::integral_constant<int, 0>{}, to2, tr2, pshf, pdown, exr);
-                    else epi_step(OUT_, RES_, std::integral_constant<int, m / 6 - 1>{}, std::integral_constant<int, 0>{}, to, tr, shf, down, exr);
-                }
-                if constexpr (EPI && m >= 13 && m < 36 && (m - 12) % 6 != 0) {
-                    if constexpr (FIRST) epi_step(IN_, std::integral_constant<bool, !RES>{}, std::integral_constant<int, (m - 12) / 6>{}, std::integral_constant<int, (m - 12) % 6>{}, to2, tr2, pshf, pdown, exr);
-                    else epi_step(OUT_, RES_, std::integral_constant<int, (m - 12) / 6>{}, std::integral_constant<int, (m - 12) % 6>{}, to, tr, shf, down, exr);
-                }
-                if constexpr (!LAST && m >= 16 && m % 4 == 0)      // dq's old contents are dead behind slice 15
-                    read_cell(IN_, std::integral_constant<int, 0>{}, std::integral_constant<int, (m - 16) / 4>{}, ta, tb);
-                // last row tile: point j's k-chunk 0 fragments are dead behind slice 12 j + 11 - request the next layer's, two
-                // fragments (one channel tile) every third slice (a request costs the wave ~40 cycles of issue: the CU's
-                // address path takes 16 cycles per wave instruction and the four waves request at the same time)
-                if constexpr (LAST && m == 12) asm volatile("" : "+v"(ta1), "+v"(tb1), "+v"(to2), "+v"(tr2));
-                if constexpr (LAST && m >= 12 && m % 3 == 0)
-                    ws_load_w_point<0, (m - 12) / 12>(ua, wnext, wlane, ((m - 12) % 12) / 3);
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            dstamp(rt, 1);
-            // ---- phase B ----
-            // k-chunk 1's fragments (only a layer's first row tile can wait here; in the last one requests are in flight
-            // already, and everything it still needs has been waited for)
-            if constexpr (!LAST) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // this row tile's store / residual table (the previous one's is dead), for its epilogue in the next phase A
-            if constexpr (!LAST) {
-                to = *reinterpret_cast<const i32x4v *>(tout_w + ((size_t)rt * 64 + lane) * 8);
-                tr = *reinterpret_cast<const i32x4v *>(tout_w + ((size_t)rt * 64 + lane) * 8 + 4);
-            }
-            // every wave has read the exchange (previous epilogue): a bare s_barrier - this wave's exchange reads have
-            // returned (their values were consumed slices ago), and __syncthreads() would also drain the patch reads just
-            // issued for the next row tile (s_waitcnt lgkmcnt(0): ~200 cycles per row tile)
-            __builtin_amdgcn_s_barrier();
-            static_for<48>([&](auto M_) {
-                constexpr int m = decltype(M_)::value;
-                mfma_slice(std::integral_constant<int, 1>{}, M_, bh1, bl1);
-                if constexpr (!LAST) {
-                    tslice(M_, bh0, bl0);
-                    if constexpr (m >= 16 && m % 4 == 0)
-                        read_cell(IN_, std::integral_constant<int, 1>{}, std::integral_constant<int, (m - 16) / 4>{}, ta, tb);
-                } else {
-                    // point 3's k-chunk 0 fragments (dead since phase A's last slice), then k-chunk 1's of points 0 .. 2 as
-                    // their MFMAs are done
-                    if constexpr (m < 12 && m % 3 == 0) ws_load_w_point<0, 3>(ua, wnext, wlane, m / 3);
-                    if constexpr (m >= 12 && m % 3 == 0) ws_load_w_point<1, (m - 12) / 12>(ua, wnext, wlane, ((m - 12) % 12) / 3);
-                }
-                if constexpr (m >= 26 && m < 30) {                 // points 0 and 1 are complete behind slice 23
-                    constexpr int c = m - 26;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) zs01[c][e] = acc[0][c][e] + acc[1][c][e];
-                }
-                if constexpr (m >= 38 && m < 46) {                 // point 2 behind slice 35
-                    constexpr int c = (m - 38) >> 1;
-                    if constexpr (((m - 38) & 1) == 0) {
-                        f32x4 z0;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) z0[e] = zs01[c][e] + acc[2][c][e];
-                        lds_f32x4_put<c * 1024>(exw, z0);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) zd12[c][e] = acc[1][c][e] - acc[2][c][e];
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            dstamp(rt, 2);
-            // next row tile's patch tables are dead now; fetch the ones after (cyclic over the row tiles - the geometry
-            // repeats in every layer)
-            if constexpr (!LAST) {
-                const int r2 = rt + 2 < NRT ? rt + 2 : rt + 2 - NRT;
-                ta = *reinterpret_cast<const i32x4v *>(tin_w + ((size_t)r2 * 64 + lane) * 8);
-                tb = *reinterpret_cast<const i32x4v *>(tin_w + ((size_t)r2 * 64 + lane) * 8 + 4);
-            }
-            // ---- tail: Z1 = (m1 - m2) - m3 -> exchange: rides along the NEXT row tile's phase A; the last row tile's here ----
-            if constexpr (LAST) {
-                static_for<4>([&](auto C_) {
-                    ztail(C_, exw);
-                    ws_load_w_point<1, 3>(ua, wnext, wlane, decltype(C_)::value);    // point 3's k-chunk 1 registers are dead now
-                });
-                if constexpr (!DEFER) __syncthreads();
-            }
-            dstamp(rt, 3);
-            if constexpr (LAST && !DEFER) {
-                // ---- the last row tile's own epilogue (nothing to hide it behind), the remaining requests in between ----
-                static_for<4>([&](auto Q_) {
-                    static_for<6>([&](auto I_) { epi_step(OUT_, RES_, Q_, I_, to2, tr2, shf, down, exr); });
-                });
-            }
-            dstamp(rt, 4);
-        };
-        auto conv = [&](auto IN_, auto OUT_, auto RES_, int layer) __attribute__((always_inline)) {
-            // epilogue constants of the output channels this wave finishes: 16 wave + 4 lg ..
-            const f32x4 shf = *reinterpret_cast<const f32x4 *>(net.ws_shift + layer * 64 + wave * 16 + lg * 4);
-            const float down = net.ws_down[layer];
-            const int next_layer = layer + 1 < kTowerLayers ? layer + 1 : 0;
-            dstamp_base = (layer == 2 || layer == 3) && grp == (int)blockIdx.x ? 40 + 35 * (layer - 2) : -1;
-            // prologue: row tile 0's k-chunk 0 transformed on its own, k-chunk 1's cells requested; then ta / tb = row tile 1's
-            static_for<8>([&](auto C8_) { read_cell(IN_, std::integral_constant<int, 0>{}, C8_, ta, tb); });
-            static_for<48>([&](auto I_) { tslice(I_, bh0, bl0); });
-            static_for<8>([&](auto C8_) { read_cell(IN_, std::integral_constant<int, 1>{}, C8_, ta, tb); });
-            ta = ta1;
-            tb = tb1;
-            // (row tile 0 peeled: inside the loop hipcc must assume that ta / tb are loads of the previous iteration and waits
-            // for them - in row tile 0 that wait would drain the weight requests still in flight)
-            body(IN_, OUT_, RES_, std::true_type{}, std::false_type{}, 0, next_layer, shf, down);
-#pragma unroll 1
-            for (int rt = 1; rt < NRT - 1; ++rt) body(IN_, OUT_, RES_, std::false_type{}, std::false_type{}, rt, next_layer, shf, down);
-            body(IN_, OUT_, RES_, std::false_type{}, std::true_type{}, NRT - 1, next_layer, shf, down);
-            // (ta / tb hold row tile 0's table again: the last fetch of the loop wrapped around)
-            pshf = shf;
-            pdown = down;
-            if (!(amax < (float)kWsRangeLimit)) ovf = 1;        // f16 range guard (also catches NaN)
-            __syncthreads();                                    // OUT complete (but a deferred last row tile) before the next layer reads it
-            stamp();
-        };
-        using IX = std::integral_constant<int, C::X_OFF>;
-        using IH = std::integral_constant<int, C::H_OFF>;
-        if (!(amax < (float)kWsRangeLimit)) ovf = 1;
-        ta = *reinterpret_cast<const i32x4v *>(tin_w + (size_t)lane * 8);
-        tb = *reinterpret_cast<const i32x4v *>(tin_w + (size_t)lane * 8 + 4);
-        to = *reinterpret_cast<const i32x4v *>(tout_w + (size_t)lane * 8);            // store / residual tables: see body
-        tr = *reinterpret_cast<const i32x4v *>(tout_w + (size_t)lane * 8 + 4);
-        ta1 = *reinterpret_cast<const i32x4v *>(tin_w + ((size_t)64 + lane) * 8);     // row tile 1's (see body)
-        tb1 = *reinterpret_cast<const i32x4v *>(tin_w + ((size_t)64 + lane) * 8 + 4);
-        asm volatile("" :: "v"(ta), "v"(tb), "v"(to), "v"(tr), "v"(ta1), "v"(tb1));  // waited for here (layer 0's weight requests, in flight, are needed now anyway)
-        to2 = to;
-        tr2 = tr;
-        if constexpr (DEFER) {
-            // layer 0 has no previous layer: its first row tile carries a NULL epilogue - zero exchange, zero constants,
-            // every store to the dump row, every residual read from the zero row (cheaper than a third copy of the layer code)
-            {
-                // (zeros made HERE: hipcc hoists a constant vector out of the group loop and, short of registers, spills it)
-                float z0, z1, z2, z3;
-                asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0" : "=v"(z0), "=v"(z1), "=v"(z2), "=v"(z3));
-                pshf = f32x4{z0, z1, z2, z3};
-            }
-            pdown = 0.f;
-            for (int e = tid; e < C::EX_BYTES / 16; e += NTHR) reinterpret_cast<f32x4 *>(smem + C::EX_OFF)[e] = pshf;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                to2[q] = C::DUMP_REL + (lane * 16) % 256;
-                tr2[q] = C::ZERO_REL + (lane * 16) % 256;
-            }
-            __syncthreads();
-        }
-#pragma unroll 1
-        for (int blk = 0; blk < kBlocks; ++blk) {
-            conv(IX{}, IH{}, std::false_type{}, 2 * blk);
-            conv(IH{}, IX{}, std::true_type{}, 2 * blk + 1);
-        }
-        if constexpr (DEFER) {
-            // the tower's last row tile (layer 11, output buffer X, residual): nothing left to hide it behind
-            int exr = C::EX_OFF + wave * 1024 + lane * 16;
-            asm volatile("" : "+v"(exr));
-            static_for<4>([&](auto Q_) {
-                static_for<6>([&](auto I_) { epi_step(IX{}, std::true_type{}, Q_, I_, to2, tr2, pshf, pdown, exr); });
-            });
-            if (!(amax < (float)kWsRangeLimit)) ovf = 1;
-            __syncthreads();
-        }
-        // next group's input planes: requested here, consumed after the heads
-        const int next = __builtin_amdgcn_readfirstlane(*ticket_lds);   // (written before the stem's barriers)
-        fetch_planes(next);
-        run_heads_x32<G, C>(smem, net, b0, batch, want_logits, policy, value, tid, wave, nullptr);
-        __syncthreads();
-        stamp();
-        grp = next;
-    }
-    if (ovf && overflow) atomicOr(overflow, 1);
-}
-
-// The 9x9 tower as Winograd F(2,3) along x only (TG_FWD_ALGO=w1d): 2-D Winograd (above) issues the fewest MFMAs but 5.3 VALU
-// instructions beside each and is bound by instruction issue; the direct kernel needs no transform and is bound by the matrix
-// pipe.  One transformed axis sits between: 600 MFMAs per wave and layer for three boards (2-D: 480, direct: 857), one
-// transform pass per side - 1.4 VALU instructions per MFMA, inside what an MFMA's 16 cycles hide.  Three boards per workgroup
-// only (smaller launches take dualnet_fwd_wsplit_kernel<1>).  Stem, heads, operand pieces, range guard: as above.
+// The 9x9 tower as Winograd F(2,3) along x only (the 9x9 default; TG_FWD_ALGO=w1d): 600 MFMAs per wave and layer for three
+// boards (2-D Winograd: 480, direct: 857), one transform pass per side.  G = 3 boards per workgroup for throughput launches,
+// G = 1 for launches up to the CU count - same bits either way.
 // PROF: s_memtime stamps of workgroup 0 / wave 0: [0] group start, [1] input staged, [2] stem done, [3..14] layer done, [15] heads done, [64..66] inside the heads: 1x1 convolutions done, barrier passed, FCs done
 template <int G, bool PROF>
 __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
@@ -882,13 +311,12 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
     float *__restrict__ policy, float *__restrict__ value, int *__restrict__ overflow) {
     using C = WsCfg<G>;
     using F = FmtF16;
-    constexpr int P = C::P, M = C::M, NTHR = C::NTHR, NRT = C::NRT, RTW = C::RTW, IMG = C::IMG;
-    constexpr int GI = G == 3 ? 1 : 0;
+    constexpr int P = C::P, M = C::M, NTHR = C::NTHR, RTW = C::RTW, IMG = C::IMG;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63, li = lane & 15, lg = lane >> 4;
+    const int lane = tid & 63;
 
     if (static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) unsigned char *)smem)) != 0u)
         __builtin_trap();                                      // absolute LDS addressing below
@@ -1139,7 +567,7 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
                 constexpr int S1 = PAR ? 3 : 1, S1N = PAR ? 1 : 3;
                 const int next_layer = layer + 1 < kTowerLayers ? layer + 1 : 0;
                 const unsigned char *wnext = net.w1_w + ((size_t)next_layer * 4 + wave) * 49152;
-                f32x4 shf = *reinterpret_cast<const f32x4 *>(net.ws_shift + layer * 64 + wave * 16 + glg * 4);
+                f32x4 shf = *reinterpret_cast<const f32x4 *>(net.w1_shift + layer * 64 + wave * 16 + glg * 4);
                 float down = net.w1_down[layer];
                 int exw = C::EX_OFF + wave * 4096 + glane * 16, exr = C::EX_OFF + wave * 1024 + glane * 16;
                 asm volatile("" : "+v"(exw), "+v"(exr));
@@ -1361,7 +789,7 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
                 constexpr int S1 = PAR ? 3 : 1, S1N = PAR ? 1 : 3; // AGPR slot of tap ky = 1 in this / the next layer (taps 0, 2: slots 0, 2)
                 const int next_layer = layer + 1 < kTowerLayers ? layer + 1 : 0;
                 const unsigned char *wnext = net.w1_w + ((size_t)next_layer * 4 + wave) * 49152;
-                const f32x4 shf = *reinterpret_cast<const f32x4 *>(net.ws_shift + layer * 64 + wave * 16 + glg * 4);
+                const f32x4 shf = *reinterpret_cast<const f32x4 *>(net.w1_shift + layer * 64 + wave * 16 + glg * 4);
                 const float down = net.w1_down[layer];
                 int exw = C::EX_OFF + wave * 4096 + glane * 16, exr = C::EX_OFF + wave * 1024 + glane * 16;
                 asm volatile("" : "+v"(exw), "+v"(exr));
@@ -1527,25 +955,6 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
 }
 
 template <int G, bool PROF = false>
-int launch_wsplit(tg_net *net, const float *planes, int batch, int want_logits, float *policy, float *value,
-                  int *overflow, hipStream_t stream) {
-    using C = WsCfg<G>;
-    if (!PROF && net->dev.timeline)
-        return launch_wsplit<G, true>(net, planes, batch, want_logits, policy, value, overflow, stream);
-    auto kern = dualnet_fwd_wsplit_kernel<G, PROF>;
-    static std::atomic<uint64_t> configured{0};
-    if (tg::first_on_device(configured, net->device))
-        TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-    const int groups = (batch + G - 1) / G;
-    int grid = groups < net->num_cus ? groups : net->num_cus;
-    if (net->forward_grid_cap > 0 && grid > net->forward_grid_cap) grid = net->forward_grid_cap;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTHR), C::LDS_BYTES, stream, net->dev, planes, batch, want_logits,
-                       policy, value, overflow);
-    TG_HIP(hipGetLastError());
-    return TG_OK;
-}
-
-template <int G, bool PROF = false>
 int launch_w1d(tg_net *net, const float *planes, int batch, int want_logits, float *policy, float *value,
                int *overflow, hipStream_t stream) {
     using C = WsCfg<G>;
@@ -1557,162 +966,24 @@ int launch_w1d(tg_net *net, const float *planes, int batch, int want_logits, flo
         TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
     const int groups = (batch + G - 1) / G;
     int grid = groups < net->num_cus ? groups : net->num_cus;
-    if (net->forward_grid_cap > 0 && grid > net->forward_grid_cap) grid = net->forward_grid_cap;
+    if (const int cap = net->forward_grid_cap.load(); cap > 0 && grid > cap) grid = cap;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTHR), C::LDS_BYTES, stream, net->dev, planes, batch, want_logits,
                        policy, value, overflow);
     TG_HIP(hipGetLastError());
     return TG_OK;
 }
 
-// ---- host: tile -> lane assignment and the LDS address tables ---------------------------------------------------
-// Tile (b, ty, tx) has class h = (ty + 5 tx + b) mod 8 - the value ws_swz's g takes on its patch cell (r, s), up to a
-// constant that depends on the cell only.  A ds_read_b128 serves lanes {li 0-3, 12-15 of lane group a} + {li 4-11 of
-// lane group a ^ 1} in one LDS cycle: with the eight tiles of each of the two sets in eight different classes the
-// sixteen 16-byte chunks are distinct for every cell.  No class has more than 2 NRT tiles, so: k-th tile of class h ->
-// set k (row tile k / 2, half k % 2), lane position h inside the set.
-template <int G>
-void ws_geometry(std::vector<int> &tin, std::vector<int> &tout) {
-    using C = WsCfg<G>;
-    constexpr int NRT = C::NRT;
-    std::vector<int> slot_tile(NRT * 16, -1);
-    int cnt[8] = {};
-    for (int b = 0; b < G; ++b)
-        for (int ty = 0; ty < 5; ++ty)
-            for (int tx = 0; tx < 5; ++tx) {
-                const int h = (ty + 5 * tx + b) & 7, k = cnt[h]++;
-                const int rt = k >> 1, li = (k & 1) ? 4 + h : (h < 4 ? h : h + 8);
-                slot_tile[rt * 16 + li] = (b * 5 + ty) * 5 + tx;
-            }
-    static const int rows[4][2] = {{0, 2}, {1, 2}, {2, 1}, {1, 3}};
-    tin.assign((size_t)4 * NRT * 64 * 8, 0);
-    tout.assign((size_t)4 * NRT * 64 * 8, 0);
-    for (int w = 0; w < 4; ++w)
-        for (int rt = 0; rt < NRT; ++rt)
-            for (int lane = 0; lane < 64; ++lane) {
-                const int li = lane & 15, lg = lane >> 4, tile = slot_tile[rt * 16 + li];
-                const int b = tile < 0 ? 0 : tile / 25, ty = tile < 0 ? 0 : (tile / 5) % 5, tx = tile < 0 ? 0 : tile % 5;
-                int *ti = &tin[(((size_t)w * NRT + rt) * 64 + lane) * 8];
-                for (int c8 = 0; c8 < 8; ++c8) {
-                    const int r = rows[w][c8 >> 2], s = c8 & 3;
-                    const int y = 2 * ty - 1 + r, x = 2 * tx - 1 + s;
-                    // chunk index of channels 8 lg .. (k-chunk 0, first half): 2 lg; the kernel XORs in 8 kc + half
-                    if (tile >= 0 && y >= 0 && y < 9 && x >= 0 && x < 9) {
-                        const int R = b * 81 + y * 9 + x;
-                        ti[c8] = R * 256 + (((lg * 2) ^ ws_swz(R)) << 4);
-                    } else {
-                        // zero row, at the chunk its natural address would have had (class of the cell: the same formula
-                        // extended beyond the board; a tile-less lane takes the class of its lane position)
-                        const int hcls = tile >= 0 ? (ty + 5 * tx + b) & 7 : (li < 4 ? li : (li < 12 ? li - 4 : li - 8));
-                        const int g = (hcls + (r >> 1) + 5 * (s >> 1)) & 7;
-                        const int sw = (g & 1) | ((g & 6) << 1);
-                        ti[c8] = C::ZERO_REL + (((lg * 2) ^ sw) << 4);
-                    }
-                }
-                // epilogue of output channels 16 w + 4 lg ..: chunk 4 w + lg.  [0..3] store addresses of outputs
-                // (2 ty + r, 2 tx + c), q = 2 r + c (outside the board: dump row); [4..7] residual read addresses (outside: zero row)
-                int *to = &tout[(((size_t)w * NRT + rt) * 64 + lane) * 8];
-                for (int q = 0; q < 4; ++q) {
-                    const int y = 2 * ty + (q >> 1), x = 2 * tx + (q & 1);
-                    if (tile >= 0 && y < 9 && x < 9) {
-                        const int R = b * 81 + y * 9 + x;
-                        to[q] = to[4 + q] = R * 256 + (((w * 4 + lg) ^ ws_swz(R)) << 4);
-                    } else {
-                        to[q] = C::DUMP_REL + lane * 16 % 256;
-                        to[4 + q] = C::ZERO_REL + lane * 16 % 256;
-                    }
-                }
-            }
-}
-
 }  // namespace
 
 namespace tg {
 
-// Winograd weight image [layer 12][wave = point row i 4][j 4][kc 2][piece 2][ct 4][lane 64][8 x f16]: U = G g G^T in
-// fp64, batch-norm scale folded in, x 2^e (largest entry of the layer into [2^9, 2^10)), pieces hi = rn16(u),
-// lo = rn16(u - hi) UNSCALED; shift table [12][64]; 2^-e [12]; the address tables of both workgroup shapes.
-// tower[l]: [64][64][3][3]; scale / shift: folded batch norm [13][64] (index 0 = stem).
-int wsplit_prepare(tg_net *net, const float *const *tower, const float *scale, const float *shift) {
-    std::vector<uint16_t> img((size_t)12 * 4 * 64 * 512, 0);
-    std::vector<float> down(12), shf(12 * 64);
-    std::vector<double> u((size_t)16 * 64 * 64);
-    for (int layer = 0; layer < 12; ++layer) {
-        const float *w = tower[layer];
-        double mx = 0.0;
-        for (int cout = 0; cout < 64; ++cout)
-            for (int cin = 0; cin < 64; ++cin) {
-                const float *g = &w[((size_t)cout * 64 + cin) * 9];
-                double gg[4][3];
-                for (int k = 0; k < 3; ++k) {
-                    gg[0][k] = g[k];
-                    gg[1][k] = 0.5 * ((double)g[k] + g[3 + k] + g[6 + k]);
-                    gg[2][k] = 0.5 * ((double)g[k] - g[3 + k] + g[6 + k]);
-                    gg[3][k] = g[6 + k];
-                }
-                const double sc = scale[(layer + 1) * 64 + cout];
-                for (int a = 0; a < 4; ++a) {
-                    const double row[4] = {gg[a][0], 0.5 * (gg[a][0] + gg[a][1] + gg[a][2]),
-                                           0.5 * (gg[a][0] - gg[a][1] + gg[a][2]), gg[a][2]};
-                    for (int bq = 0; bq < 4; ++bq) {
-                        const double v = row[bq] * sc;
-                        u[((size_t)(a * 4 + bq) * 64 + cin) * 64 + cout] = v;
-                        mx = std::fmax(mx, std::fabs(v));
-                    }
-                }
-            }
-        int e = 0;
-        if (mx > 0.0 && std::isfinite(mx)) {
-            int ex;
-            std::frexp(mx, &ex);
-            e = 10 - ex;
-        }
-        e = e > 40 ? 40 : (e < -40 ? -40 : e);
-        down[layer] = std::ldexp(1.f, -e);
-        for (int c = 0; c < 64; ++c) shf[layer * 64 + c] = shift[(layer + 1) * 64 + c];
-        for (int i = 0; i < 4; ++i)
-            for (int j = 0; j < 4; ++j)
-                for (int kc = 0; kc < 2; ++kc)
-                    for (int ct = 0; ct < 4; ++ct)
-                        for (int lane = 0; lane < 64; ++lane)
-                            for (int el = 0; el < 8; ++el) {
-                                const int cout = ct * 16 + (lane & 15), cin = kc * 32 + (lane >> 4) * 8 + el;
-                                const double v = std::ldexp(u[((size_t)(i * 4 + j) * 64 + cin) * 64 + cout], e);
-                                const uint16_t h = f32_to_f16_rn((float)v);
-                                const uint16_t l = f32_to_f16_rn((float)(v - (double)f16_to_f32(h)));
-                                const size_t frag = ((((size_t)layer * 4 + i) * 4 + j) * 2 + kc) * 2;
-                                img[((frag + 0) * 4 + ct) * 512 + lane * 8 + el] = h;
-                                img[((frag + 1) * 4 + ct) * 512 + lane * 8 + el] = l;
-                            }
-    }
-    auto up = [&](const void *src, size_t bytes, const void **dst) {
-        void *d = nullptr;
-        TG_HIP(hipMalloc(&d, bytes));
-        net->allocs.push_back(d);
-        TG_HIP(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
-        *dst = d;
-        return (int)TG_OK;
-    };
-    std::vector<int> tin1, tout1, tin3, tout3;
-    ws_geometry<1>(tin1, tout1);
-    ws_geometry<3>(tin3, tout3);
-    int rc;
-    if ((rc = up(img.data(), img.size() * 2, reinterpret_cast<const void **>(&net->dev.ws_w))) ||
-        (rc = up(shf.data(), shf.size() * 4, reinterpret_cast<const void **>(&net->dev.ws_shift))) ||
-        (rc = up(down.data(), down.size() * 4, reinterpret_cast<const void **>(&net->dev.ws_down))) ||
-        (rc = up(tin1.data(), tin1.size() * 4, reinterpret_cast<const void **>(&net->dev.ws_tin[0]))) ||
-        (rc = up(tout1.data(), tout1.size() * 4, reinterpret_cast<const void **>(&net->dev.ws_tout[0]))) ||
-        (rc = up(tin3.data(), tin3.size() * 4, reinterpret_cast<const void **>(&net->dev.ws_tin[1]))) ||
-        (rc = up(tout3.data(), tout3.size() * 4, reinterpret_cast<const void **>(&net->dev.ws_tout[1]))))
-        return rc;
-    return TG_OK;
-}
-
 // dualnet_fwd_w1d_kernel's weights: U_p[ky] = (G g[ky])_p along kx - p0 = g0, p1 = (g0 + g1 + g2) / 2, p2 = (g0 - g1 + g2) / 2,
-// p3 = g2 - in fp64 with the batch-norm scale folded in, x 2^e per layer, pieces as in wsplit_prepare (low pieces unscaled).
-int w1d_prepare(tg_net *net, const float *const *tower, const float *scale) {
-    if (net->board_size != 9) return TG_OK;
+// p3 = g2 - in fp64 with the batch-norm scale folded in, x 2^e per layer (largest entry into [2^9, 2^10)), pieces hi = rn16(u),
+// lo = rn16(u - hi) UNSCALED; folded shift [12][64]; 2^-e [12].  tower[l]: [64][64][3][3]; scale / shift: folded batch norm
+// [13][64] (index 0 = stem).  The image does not depend on the board size.
+int w1d_prepare(tg_net *net, const float *const *tower, const float *scale, const float *shift) {
     std::vector<uint16_t> img((size_t)12 * 4 * 3 * 2 * 2 * 4 * 512);
-    std::vector<float> down(12);
+    std::vector<float> down(12), shf(12 * 64);
     std::vector<double> u((size_t)4 * 3 * 64 * 64);
     for (int layer = 0; layer < 12; ++layer) {
         const float *w = tower[layer];
@@ -1739,6 +1010,7 @@ int w1d_prepare(tg_net *net, const float *const *tower, const float *scale) {
         }
         e = e > 40 ? 40 : (e < -40 ? -40 : e);
         down[layer] = std::ldexp(1.f, -e);
+        for (int c = 0; c < 64; ++c) shf[layer * 64 + c] = shift[(layer + 1) * 64 + c];
         for (int p = 0; p < 4; ++p)
             for (int ky = 0; ky < 3; ++ky)
                 for (int kc = 0; kc < 2; ++kc)
@@ -1764,6 +1036,7 @@ int w1d_prepare(tg_net *net, const float *const *tower, const float *scale) {
     };
     int rc;
     if ((rc = up(img.data(), img.size() * 2, reinterpret_cast<const void **>(&net->dev.w1_w))) ||
+        (rc = up(shf.data(), shf.size() * 4, reinterpret_cast<const void **>(&net->dev.w1_shift))) ||
         (rc = up(down.data(), down.size() * 4, reinterpret_cast<const void **>(&net->dev.w1_down))))
         return rc;
     return TG_OK;
@@ -1774,14 +1047,6 @@ int w1d_forward(tg_net *net, int group, const float *planes, int batch, int want
     if (net->board_size != 9) return tg::fail(TG_ERR_ARG, "w1d forward: 9x9 only");
     if (group == 3) return launch_w1d<3>(net, planes, batch, want_logits, policy, value, overflow, stream);
     return launch_w1d<1>(net, planes, batch, want_logits, policy, value, overflow, stream);
-}
-
-// group = boards per workgroup (1 or 3); 9x9 only.
-int wsplit_forward(tg_net *net, int group, const float *planes, int batch, int want_logits, float *policy,
-                   float *value, int *overflow, hipStream_t stream) {
-    if (net->board_size != 9) return tg::fail(TG_ERR_ARG, "winograd split forward: 9x9 only");
-    if (group == 3) return launch_wsplit<3>(net, planes, batch, want_logits, policy, value, overflow, stream);
-    return launch_wsplit<1>(net, planes, batch, want_logits, policy, value, overflow, stream);
 }
 
 }  // namespace tg

@@ -34,8 +34,8 @@
 #include "legacy_stream.h"
 
 namespace tg {                                                        // net_forward.hip (tg_net::guard_grid_cap, forward_grid_cap)
-void net_set_guard_cap(tg_net *net, int cap);
-void net_set_forward_cap(tg_net *net, int cap);
+void net_caps_acquire(tg_net *net, int guard_cap, int forward_cap);
+void net_caps_release(tg_net *net);
 }
 
 #include <sched.h>
@@ -1547,56 +1547,7 @@ int launch_mpipe(const SearchDev &dev, int max_leaves, float *planes, hipStream_
     }
 }
 
-// ---- PUCT selection with every NODE owned by one wavefront -----------------------------------------------------
-// The multi-selector kernel above gives each DESCENT to a wavefront; a descent then has to wait at every node for the
-// earlier descents still inside it, and to make its virtual loss visible to the others (global stores, a wait for
-// them to land, a flag) before it moves on: 24 k cycles of wavefront time per descent, 40 % of it waiting.  Here
-// the NODES have owners instead.  A descent is a token that travels from wavefront to wavefront:
-//   * wave 0 owns the ROOT: it takes the root steps of all descents one after the other out of registers (statistics,
-//     virtual losses, quotient cache) - the chain every launch is bounded by, now without a single wait for another
-//     wavefront inside it;
-//   * waves 1..NNODE own the nodes below: a node at depth d under root edge e belongs to wave 1 + (d + e) % NNODE.
-//     Wide trees spread over the root edges, deep narrow ones over the levels.  All visits to a node are made by one
-//     wavefront in descent order (a node's visitors all come from its parent's owner, which hands them on in the
-//     order it made them - by induction from the root), so the owner reads and writes the node's virtual losses with
-//     plain loads and stores: nobody else looks at them before the launch ends;
-//   * one wave is the ALLOCATOR: every descent ends in exactly one leaf; leaves report to it and it takes them in
-//     descent order - node numbers, random draws (xseq) and job slots are handed out exactly as by the serial loop;
-//   * NWRK workers replay paths, expand and featurise as before.
-// A descent's state sits in an LDS slot (slot = k mod kSlots; at most kSlots descents are in flight: the root waits
-// for the worker of descent k - kSlots), the hand-over is one LDS word per slot (`mail`: descent, addressee) that every
-// owner polls with one load per lane.  An owner takes the LOWEST descent addressed to it whose node is ready (child
-// index assigned by the allocator, arrays initialised by the worker): never blocking on a descent keeps the allocator
-// - which needs ALL earlier leaves - from waiting for a descent queued behind one that waits for the allocator.
-// An edge expanded earlier in the same launch is recognised by its owner (child index still "not expanded" although
-// the edge has been visited) and resolved through the expanding descent (exp_key / alloc_child).
-// Same trees bit for bit (tests/test_gpu_search.py, test_gpu_end_to_end.py).
-template <int S, int NNODE, int NWRK>
-struct OwnerShared {
-    static constexpr int kSlots = (S == 9 ? 5 : 4) * NWRK;       // descents in flight; a multiple of the worker count
-    static_assert(kSlots <= 64, "one mail word per lane");
-    Lds<S, false> board[NWRK];
-    PipeJob job[kSlots];
-    int16_t moves[kSlots][kPathMax<S>];
-    int qpath[kSlots][kPathCap];      // (node << 10 | edge) of the first kPathCap levels
-    int job_seq[kSlots];              // k + 1 once job k sits in its slot
-    int slot_done[kSlots];            // jobs finished in this slot so far
-    int mail[64];                     // (k + 1) << 8 | wave that takes descent k next; 0: nobody
-    int st_node[kSlots];              // its node; <= -2: the child that descent (-2 - v) is having allocated
-    int st_depth[kSlots], st_prev[kSlots], st_redge[kSlots];
-    int lm_parent[kSlots], lm_edge[kSlots], lm_child[kSlots], lm_depth[kSlots];   // leaf report to the allocator
-    int leaf_ready[kSlots];           // k + 1
-    int done[kPipeMaxK];              // job k finished (node initialised, planes written)
-    int alloc_child[kPipeMaxK];       // node of descent k's leaf once the allocator has taken it (kOwnNotYet before)
-    int exp_key[kPipeMaxK];           // (parent << 10 | edge) if descent k's leaf needs a new node, else -1
-    int16_t jobof[kPipeMaxK];         // node (n0 + i) is being created by job jobof[i]
-    int num_nodes;
-    int cursor_seq;
-    long long cursor_val;
-    int all_done;                     // the allocator has handed out the last leaf
-    int err;
-};
-constexpr int kOwnNotYet = -3;
+constexpr int kOwnNotYet = -3;        // alloc_child of a descent whose leaf the allocator has not taken yet
 
 __device__ __forceinline__ int wave_min_i32(int v) {
     v = min(v, lane_partner_i32<0>(v));
@@ -1607,377 +1558,10 @@ __device__ __forceinline__ int wave_min_i32(int v) {
                min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
-template <int S, int NNODE, int NWRK>
-__global__ __launch_bounds__(64 * (NNODE + NWRK + 2)) void select_puct_owner_kernel(SearchDev D, int max_leaves, float *planes) {
-    using G = Geo<S>;
-    using Shared = OwnerShared<S, NNODE, NWRK>;
-    constexpr int A = G::A;
-    constexpr int R = (A + 63) / 64;
-    constexpr int NTHR = 64 * (NNODE + NWRK + 2);
-    constexpr int kSlots = Shared::kSlots;
-    extern __shared__ __attribute__((aligned(16))) unsigned char own_smem[];
-    Shared &sh = *reinterpret_cast<Shared *>(own_smem);
-    const int t = blockIdx.x;
-    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const RootMeta meta = D.meta[t];
-    const int n0 = meta.num_nodes;
-    const size_t root_ns = (size_t)t * D.N, root_base = root_ns * A;
-    const bool active = D.err[t] == 0 && n0 > 0;
-    if (threadIdx.x < kSlots) {
-        sh.job_seq[threadIdx.x] = 0;
-        sh.slot_done[threadIdx.x] = 0;
-        sh.leaf_ready[threadIdx.x] = 0;
-    }
-    if (threadIdx.x < 64) sh.mail[threadIdx.x] = 0;
-    for (int i = threadIdx.x; i < kPipeMaxK; i += NTHR) { sh.done[i] = 0; sh.alloc_child[i] = kOwnNotYet; sh.exp_key[i] = -1; }
-    if (threadIdx.x == 0) {
-        sh.cursor_seq = 0;
-        sh.cursor_val = D.rng_cursor[t];
-        sh.num_nodes = n0;
-        sh.all_done = 0;
-        sh.err = 0;
-    }
-    __syncthreads();
-    // s_memtime accumulators of tree 0 (tg_search_profile with TG_MPIPE_PROF=1; tools/profile_owner.py)
-    const bool prof = D.prof && t == 0;
-    const long long t_begin = prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
-    long long tp = t_begin, pc_busy = 0, pc_wait = 0, pc_items = 0;
-    auto lap = [&](long long &acc) {
-        if (prof) { const long long now = (long long)__builtin_amdgcn_s_memtime(); acc += now - tp; tp = now; }
-    };
-    auto fail = [&](int code, int site = 0) {                       // wave-uniform call; reported once
-        if (lane == 0 && !pipe_load(&sh.err)) {
-            atomicOr(&D.err[t], code | (site << 8));
-            pipe_store(&sh.err, 1);
-        }
-    };
-
-    if (wid == 0) {
-        // ---- the root's owner ------------------------------------------------------------------------
-        __builtin_amdgcn_s_setprio(3);
-        if (active) {
-            int r_vis[R], r_act[R], r_idx[R], r_kref[R], c_vl[R];
-            double r_vsum[R], r_pol[R], c_q[R];
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int i = lane + 64 * r, ii = i < A ? i : A - 1;
-                r_vis[r] = D.ch_visits[root_base + ii];
-                r_act[r] = D.action[root_base + ii];
-                r_idx[r] = D.ch_index[root_base + ii];
-                r_vsum[r] = D.ch_vsum[root_base + ii];
-                r_pol[r] = D.ch_policy[root_base + ii];
-                c_vl[r] = D.ch_vl[root_base + ii];
-                r_kref[r] = -1;
-                const int cnt = r_vis[r] + c_vl[r];
-                c_q[r] = cnt != 0 ? r_vsum[r] / (double)cnt : 0.0;
-            }
-            const int root_nc = D.n_children[root_ns];
-            const int root_total0 = D.n_visits[root_ns] + D.n_vl[root_ns];
-            bool ok = true;
-            int k = 0;
-            for (; k < max_leaves; ++k) {
-                const int slot = k % kSlots;
-                lap(pc_busy);
-                ok = mp_wait_ge(sh, &sh.slot_done[slot], k / kSlots);                 // the slot's last descent is through
-                lap(pc_wait);
-                if (!ok) break;
-                // pucb.py:8-29 with the quotients of the unchanged children remembered (node.py:141-157); every
-                // descent before this one has added one virtual loss to the root (node.py:76-83)
-                const double sq = __dsqrt_rn((double)(root_total0 + k + 1));
-                double best = 0.0;
-                int best_i = -1;
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int i = lane + 64 * r;
-                    if (i < root_nc) {
-                        double v = c_q[r] + (r_pol[r] * sq) / (double)(r_vis[r] + c_vl[r] + 1);
-                        if (D.cgos && i == root_nc - 1) v -= 0.1;
-                        if (best_i < 0 || v > best) { best = v; best_i = i; }
-                    }
-                }
-                best_i = wave_argmax_first(best, best_i);
-                const int owner = best_i & 63, oslot = best_i >> 6;
-                int my_move = 0, my_child = 0, my_cnt = 0, my_kref = -1;
-#pragma unroll
-                for (int r = 0; r < R; ++r)
-                    if (r == oslot) { my_move = r_act[r]; my_child = r_idx[r]; my_cnt = r_vis[r] + c_vl[r]; my_kref = r_kref[r]; }
-                const int src = __builtin_amdgcn_readfirstlane(owner);
-                const int e = best_i;
-                const int mv = __builtin_amdgcn_readlane(my_move, src);
-                int child = __builtin_amdgcn_readlane(my_child, src);
-                const int count = __builtin_amdgcn_readlane(my_cnt, src);
-                const int kref = __builtin_amdgcn_readlane(my_kref, src);
-                // two consecutive passes: never descend below (tree.py:224-229)
-                const bool two_pass = meta.moves + 1 > 2 && mv == 0 && meta.prev == 0;
-                const int threshold = two_pass ? 10000000 : 1;
-                const bool leaf = count + 1 < threshold + 1;
-                if (child == kNotExpanded && kref >= 0) child = -2 - kref;           // being allocated by descent kref
-                const bool expands = leaf && child == kNotExpanded;
-                if (!leaf && child == kNotExpanded) { ok = false; break; }           // visited but without a node: never
-                // the virtual loss of this descent, and the quotient it changes
-#pragma unroll
-                for (int r = 0; r < R; ++r)
-                    if (r == oslot) {
-                        if (lane == owner) {
-                            c_vl[r] += 1;
-                            if (expands) r_kref[r] = k;
-                        }
-                        const int cnt = r_vis[r] + c_vl[r];
-                        const double q = cnt != 0 ? r_vsum[r] / (double)cnt : 0.0;
-                        if (lane == owner) c_q[r] = q;
-                    }
-                if (lane == 0) {
-                    sh.moves[slot][0] = (int16_t)mv;
-                    sh.qpath[slot][0] = e;                                           // node 0
-                    if (leaf) {
-                        sh.lm_parent[slot] = 0; sh.lm_edge[slot] = e; sh.lm_child[slot] = child; sh.lm_depth[slot] = 1;
-                        mp_publish(&sh.leaf_ready[slot], k + 1);
-                    } else {
-                        sh.st_node[slot] = child; sh.st_depth[slot] = 1; sh.st_prev[slot] = mv; sh.st_redge[slot] = e;
-                        mp_publish(&sh.mail[slot], ((k + 1) << 8) | (1 + (1 + e) % NNODE));
-                    }
-                }
-            }
-            lap(pc_busy);
-            if (prof && lane == 0) { atomicAdd((unsigned long long *)D.prof + 0, (unsigned long long)pc_busy); atomicAdd((unsigned long long *)D.prof + 1, (unsigned long long)pc_wait); }
-            if (!ok) fail(kErrPipeline, 1);
-            if (ok) {
-                // the root's virtual losses (max_leaves descents, one each) reach the pool here
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int i = lane + 64 * r;
-                    if (i < A) D.ch_vl[root_base + i] = c_vl[r];
-                }
-                if (lane == 0) D.n_vl[root_ns] += max_leaves;
-            }
-        }
-    } else if (wid <= NNODE) {
-        // ---- owners of the nodes below the root --------------------------------------------------------
-        __builtin_amdgcn_s_setprio(2);
-        const int me = wid;
-        int idle = 0;
-        int unf0 = -1, unf1 = -1, unf2 = -1, unf3 = -1, n_unf = 0;   // nodes with stores of this wave possibly still in flight
-        while (active) {
-            // the lowest descent addressed to this wave whose node is ready
-            lap(pc_busy);
-            // Readiness (child index assigned by the allocator, arrays initialised by the worker) is evaluated by all
-            // lanes at once, lane = slot: two descents waiting for the same node read the same flags with the same
-            // instructions - one after the other, the later descent could find ready what the earlier one had just
-            // found pending, and overtake it.
-            const int w = lane < kSlots ? pipe_load(&sh.mail[lane]) : 0;
-            const bool mine = (w & 255) == me;
-            int nd = mine ? sh.st_node[lane] : 0;
-            bool ready = mine;
-            {
-                const bool pending = mine && nd <= -2;
-                const int c = pipe_load(&sh.alloc_child[pending ? -2 - nd : 0]);
-                if (pending) {
-                    if (c == kOwnNotYet) ready = false;
-                    else nd = c;
-                }
-                const bool fresh = ready && nd >= n0;                                 // created in this launch
-                const int dn = pipe_load(&sh.done[fresh ? (int)sh.jobof[nd - n0] : 0]);
-                if (fresh && dn == 0) ready = false;                                  // expansion in flight
-            }
-            const int kmin = wave_min_i32(ready ? (w >> 8) - 1 : 0x7fffffff);
-            const int k = kmin == 0x7fffffff ? -1 : kmin;
-            const int slot = k >= 0 ? k % kSlots : 0;
-            const int node = __builtin_amdgcn_readlane(nd, slot);
-            if (k < 0) {
-                if (pipe_load(&sh.all_done) || pipe_load(&sh.err)) break;
-                if (++idle > kPipeSpinLimit) { fail(kErrPipeline, 2); break; }
-                __builtin_amdgcn_s_sleep(1);
-                continue;
-            }
-            idle = 0;
-            lap(pc_wait);
-            pc_items += 1;
-            const int depth = sh.st_depth[slot], prev = sh.st_prev[slot], redge = sh.st_redge[slot];
-            if (depth >= kPathMax<S>) { fail(kErrPipeline, 3); break; }
-            // This wave's earlier virtual-loss stores have to have landed if they concern this very node (and none of
-            // the loads below may be issued before they have): the nodes written since the last such wait are
-            // remembered - a wait on every visit cost ~1 k cycles of the ~6 k a visit took.
-            if (node == unf0 || node == unf1 || node == unf2 || node == unf3 || n_unf >= 4) {
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                unf0 = unf1 = unf2 = unf3 = -1;
-                n_unf = 0;
-            } else {
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            }
-            if (n_unf == 0) unf0 = node;
-            else if (n_unf == 1) unf1 = node;
-            else if (n_unf == 2) unf2 = node;
-            else unf3 = node;
-            ++n_unf;
-            const EdgePick pick = select_puct<S>(D, t, node, lane);
-            const int e = pick.edge, mv = pick.move;
-            const size_t ns = (size_t)t * D.N + node, base = ns * A;
-            const bool two_pass = meta.moves + depth + 1 > 2 && mv == 0 && prev == 0;   // tree.py:224-229
-            const int threshold = two_pass ? 10000000 : 1;
-            const bool leaf = pick.count + 1 < threshold + 1;
-            int child = pick.child;
-            const int key = (node << 10) | e;
-            if (child == kNotExpanded && pick.count >= 1) {
-                // visited, yet without a node: an earlier descent of this launch is having it allocated
-                int kref = -1;
-                for (int b0 = 0; b0 < k && kref < 0; b0 += 64) {
-                    const unsigned long long hit = __ballot(b0 + lane < k && sh.exp_key[b0 + lane] == key);
-                    if (hit) kref = b0 + __ffsll((long long)hit) - 1;
-                }
-                if (kref < 0) { fail(kErrPipeline, 4); break; }
-                child = -2 - kref;
-            }
-            if (lane == 0) {
-                D.n_vl[ns] = pick.node_vl + 1;                                       // node.py:76-83
-                D.ch_vl[base + e] = pick.edge_vl + 1;
-                sh.moves[slot][depth] = (int16_t)mv;
-                if (depth < kPathCap) sh.qpath[slot][depth] = key;
-                if (leaf) {
-                    if (child == kNotExpanded) sh.exp_key[k] = key;
-                    sh.lm_parent[slot] = node; sh.lm_edge[slot] = e; sh.lm_child[slot] = child; sh.lm_depth[slot] = depth + 1;
-                    sh.mail[slot] = 0;
-                    mp_publish(&sh.leaf_ready[slot], k + 1);
-                } else {
-                    sh.st_node[slot] = child; sh.st_depth[slot] = depth + 1; sh.st_prev[slot] = mv;
-                    mp_publish(&sh.mail[slot], ((k + 1) << 8) | (1 + (depth + 1 + redge) % NNODE));
-                }
-            }
-            wave_sync();
-        }
-        if (prof && lane == 0) {
-            atomicAdd((unsigned long long *)D.prof + 2, (unsigned long long)pc_busy);
-            atomicAdd((unsigned long long *)D.prof + 3, (unsigned long long)pc_wait);
-            atomicAdd((unsigned long long *)D.prof + 4, (unsigned long long)pc_items);
-        }
-    } else if (wid == NNODE + 1) {
-        // ---- the allocator: leaves in descent order ----------------------------------------------------
-        int num_nodes = n0, nexp = 0;
-        bool ok = active;
-        for (int k = 0; ok && k < max_leaves; ++k) {
-            const int slot = k % kSlots;
-            lap(pc_busy);
-            ok = mp_wait_ge(sh, &sh.leaf_ready[slot], k + 1);
-            lap(pc_wait);
-            if (!ok) { fail(kErrPipeline, 5); break; }
-            const int parent = sh.lm_parent[slot], e = sh.lm_edge[slot], depth = sh.lm_depth[slot];
-            int child = sh.lm_child[slot];
-            if (child <= -2) child = sh.alloc_child[-2 - child];                     // an earlier leaf: taken already
-            const int expand = child == kNotExpanded;
-            int xseq = 0;
-            if (expand) {
-                if (num_nodes >= D.N || num_nodes - n0 >= kPipeMaxK) { fail(kErrPoolFull, 6); ok = false; break; }
-                child = num_nodes++;
-                xseq = nexp++;
-            }
-            if (lane == 0) {
-                if (expand) sh.jobof[child - n0] = (int16_t)k;
-                PipeJob &j = sh.job[slot];
-                j.k = k; j.parent = parent; j.edge = e; j.child = child;
-                j.expand = expand; j.xseq = xseq; j.depth = depth;
-                mp_publish(&sh.alloc_child[k], child);
-                mp_publish(&sh.job_seq[slot], k + 1);
-                if (expand) {
-                    __builtin_amdgcn_s_waitcnt(0xC07F);                              // lgkmcnt(0): jobof is in LDS before ...
-                    D.ch_index[((size_t)t * D.N + parent) * A + e] = child;          // ... anybody can find the node here
-                }
-            }
-        }
-        lap(pc_busy);
-        if (lane == 0) {
-            sh.num_nodes = num_nodes;
-            if (ok) mp_publish(&sh.all_done, 1);
-            if (prof) { atomicAdd((unsigned long long *)D.prof + 5, (unsigned long long)pc_busy); atomicAdd((unsigned long long *)D.prof + 6, (unsigned long long)pc_wait); }
-        }
-    } else {
-        // ---- workers: job k on wave k % NWRK ------------------------------------------------------------
-        const int w = wid - NNODE - 2;
-        Lds<S, false> &L = sh.board[w];
-        BoardScalars rootb;
-        int root_to_move;
-        load_root<S>(L, rootb, root_to_move, D, t, lane);
-        for (int k = w; active && k < max_leaves; k += NWRK) {
-            const int slot = k % kSlots;
-            lap(pc_busy);
-            const bool have = mp_wait_ge(sh, &sh.job_seq[slot], k + 1);
-            lap(pc_wait);
-            if (!have) { fail(kErrPipeline, 7); break; }
-            const PipeJob j = sh.job[slot];
-            {
-                // queue entry of leaf k (what the backup reads)
-                const size_t qs = (size_t)t * D.K + k;
-                const int npath = j.depth < kPathCap ? j.depth : kPathCap;
-                if (lane < npath) D.q_path[qs * kPathCap + lane] = sh.qpath[slot][lane];
-                if (lane == 0) {
-                    D.q_node[qs] = j.child;
-                    D.q_pnode[qs] = j.parent;
-                    D.q_pedge[qs] = j.edge;
-                    D.q_depth[qs] = (j.depth <= kPathCap && D.N <= (1 << 21)) ? j.depth : 0;
-                }
-            }
-            reset_work<S>(L, lane);
-            BoardScalars b = rootb;
-            int c = root_to_move;
-            for (int i = 0; i < j.depth; ++i) {
-                put_stone<S>(L, b, sh.moves[slot][i], c, D.zob, lane);
-                c = 3 - c;
-            }
-            if (j.expand) expand_node_pipe<S>(L, b, c, D, t, j.child, j.parent, j.edge, j.xseq, sh, lane);
-            write_planes<S>(L, b, c, planes + ((size_t)t * max_leaves + k) * 6 * G::P, lane);
-            wave_sync();
-            if (lane == 0) {
-                pipe_store(&sh.done[k], 1);                                          // releases the node arrays
-                pipe_store(&sh.slot_done[slot], k / kSlots + 1);
-            }
-        }
-        lap(pc_busy);
-        if (prof && lane == 0) { atomicAdd((unsigned long long *)D.prof + 7, (unsigned long long)pc_busy); atomicAdd((unsigned long long *)D.prof + 8, (unsigned long long)pc_wait); }
-    }
-    __syncthreads();
-    if (prof && threadIdx.x == 0) D.prof[15] += (long long)__builtin_amdgcn_s_memtime() - t_begin;
-    const bool good = active && !sh.err;
-    if (threadIdx.x == 0) {
-        D.meta[t].num_nodes = sh.num_nodes;
-        D.n_leaves[t] = good ? max_leaves : 0;
-        D.rng_cursor[t] = sh.cursor_val;
-    }
-}
-
-template <int S, int NNODE, int NWRK>
-int launch_owner_cfg(const SearchDev &dev, int max_leaves, float *planes, hipStream_t st) {
-    constexpr size_t lds = sizeof(OwnerShared<S, NNODE, NWRK>);
-    static_assert(lds <= 160 * 1024, "LDS");
-    static_assert(NNODE + NWRK + 2 <= 16, "wavefronts per workgroup");
-    static std::atomic<uint64_t> configured{0};
-    int devid = 0;
-    (void)hipGetDevice(&devid);
-    if (tg::first_on_device(configured, devid))
-        TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&select_puct_owner_kernel<S, NNODE, NWRK>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((select_puct_owner_kernel<S, NNODE, NWRK>), dim3(dev.T), dim3(64 * (NNODE + NWRK + 2)), lds, st, dev,
-                       max_leaves, planes);
-    return TG_OK;
-}
-
-template <int S>
-int launch_owner(const SearchDev &dev, int max_leaves, float *planes, hipStream_t st) {
-    // node owners * 100 + workers (TG_OWNER_CFG: tuning knob)
-    static const int cfg = getenv("TG_OWNER_CFG") ? atoi(getenv("TG_OWNER_CFG")) : 0;
-    if constexpr (S == 9) {
-        if (cfg == 608) return launch_owner_cfg<S, 6, 8>(dev, max_leaves, planes, st);
-        if (cfg == 410) return launch_owner_cfg<S, 4, 10>(dev, max_leaves, planes, st);
-        if (cfg == 311) return launch_owner_cfg<S, 3, 11>(dev, max_leaves, planes, st);
-        return launch_owner_cfg<S, 5, 9>(dev, max_leaves, planes, st);
-    } else {
-        if (cfg == 406) return launch_owner_cfg<S, 4, 6>(dev, max_leaves, planes, st);
-        if (cfg == 704) return launch_owner_cfg<S, 7, 4>(dev, max_leaves, planes, st);
-        return launch_owner_cfg<S, 5, 5>(dev, max_leaves, planes, st);
-    }
-}
-
 // ---- PUCT selection of one tree on SEVERAL compute units -----------------------------------------------------------
 // Both kernels above keep ~40 k wave-cycles of work per descent on the 16 waves a workgroup can have - on ONE CU -
 // and 25 k of it is the workers' board work (path replay, candidates, priors, planes), which needs nothing from the
-// selectors but the job.  Here a tree gets 1 + NWG workgroups: the first is the owner kernel's selecting half (root
+// selectors but the job.  Here a tree gets 1 + NWG workgroups: the first is the selecting half of the node-owner design (root
 // owner, node owners, allocator, plus "shippers" and the draw cursor), the others are nothing but workers, on other
 // CUs (consecutive workgroups go to different XCDs).  What crosses between them goes through memory with agent-coherent
 // accesses (relaxed agent-scope atomics: sc1 loads and stores, served at the coherence point, no cache maintenance):
@@ -2073,7 +1657,7 @@ __global__ __launch_bounds__(1024) void select_puct_split_kernel(SearchDev D, in
             }
         };
         if (wid == 0) {
-            // ---- the root's owner (as in select_puct_owner_kernel) ---------------------------------------
+            // ---- the root's owner (the node-owner design: tools/experiments/kernels/select_puct_owner.hip.inc) ---------------------------------------
             __builtin_amdgcn_s_setprio(3);
             if (active) {
                 int r_vis[R], r_act[R], r_idx[R], r_kref[R], c_vl[R];
@@ -3675,6 +3259,7 @@ __global__ __launch_bounds__(64) void finish_roots_kernel(SearchDev D, int A, un
             if (bi < 0 || ev > bv) { bv = ev; bi = i; }
         }
         best = wave_argmax_first(bv, bi);
+        if (best < 0) best = 0;                            // every evaluation NaN (a diverged network): the host's rule "i == 0 || ev > best" keeps child 0
         const int bvis = D.ch_visits[base + best];
         const double value = bvis == 0 ? 0.5 : D.ch_vsum[base + best] / (double)bvis;
         pos = D.action[base + best];
@@ -4314,8 +3899,6 @@ int tg_search_select_puct(tg_search *s, int max_leaves, float *planes_dev, int32
     // few trees: the descents themselves are pipelined over four selector waves (+ four workers); with many
     // trees per CU the three-wave kernel keeps more trees resident
     static const int mpipe_max_trees = getenv("TG_SELECT_MPIPE_TREES") ? atoi(getenv("TG_SELECT_MPIPE_TREES")) : 256;
-    // ... or, TG_SELECT_OWNER=1, nodes owned by wavefronts and descents travelling between them
-    const bool owner = getenv("TG_SELECT_OWNER") && atoi(getenv("TG_SELECT_OWNER")) != 0;     // (read per call: tests toggle it)
     // up to kXwMaxTrees trees: a second workgroup (on another CU) for the board work of every tree (TG_SELECT_SPLIT=0: off)
     const bool split = !getenv("TG_SELECT_SPLIT") || atoi(getenv("TG_SELECT_SPLIT")) != 0;
     int split_rc = kSplitNoRoom;
@@ -4325,9 +3908,6 @@ int tg_search_select_puct(tg_search *s, int max_leaves, float *planes_dev, int32
     }
     if (split_rc == TG_OK) {
         // launched
-    } else if (pipelined && s->dev.T <= mpipe_max_trees && owner && s->dev.N <= (1 << 21)) {
-        int rc = s->S == 9 ? launch_owner<9>(s->dev, max_leaves, planes_dev, st) : launch_owner<19>(s->dev, max_leaves, planes_dev, st);
-        if (rc) return rc;
     } else if (pipelined && s->dev.T <= mpipe_max_trees) {
         int rc = s->S == 9 ? launch_mpipe<9>(s->dev, max_leaves, planes_dev, st) : launch_mpipe<19>(s->dev, max_leaves, planes_dev, st);
         if (rc) return rc;
@@ -5699,11 +5279,9 @@ static int play_move_chain(tg_selfplay *sp, tg_net *net, float *planes_dev, floa
     G = std::max(1, std::min(std::min(G, (int)tg_selfplay::kMaxSub), T));
     if (sp->observer || n_phases == 0) G = 1;
     if (G > 1) {
-        tg::net_set_guard_cap(net, 16);                                // (see tg_net::guard_grid_cap)
-        tg::net_set_forward_cap(net, fwd_cap > 0 ? fwd_cap : 0);
+        tg::net_caps_acquire(net, 16, fwd_cap > 0 ? fwd_cap : 0);      // (see tg_net::guard_grid_cap; the handle may be shared by group threads)
         rc = launch_phases_subgroups(sp, net, n_phases, G, planes_dev, policy_dev, value_dev, st, leaves, any_phase);
-        tg::net_set_guard_cap(net, 0);
-        tg::net_set_forward_cap(net, 0);
+        tg::net_caps_release(net);
         if (rc) return rc;
     }
     for (int ph = 0; ph < n_phases && G == 1; ++ph) {

@@ -1,16 +1,15 @@
-"""Training step for the DualNet the search evaluates (nn/learn.py:318-403,
+"""Training step for the DualNet the search evaluates (nn/learn.py:318-403, 126-232,
 nn/loss.py:33-55).
 
 The loop, the losses, the optimiser and the file formats interchange with the reference
 (``model/rl-model.bin`` is the same ``state_dict``, ``model/rl-state.ckpt`` holds a
-``torch.optim.SGD`` state over the parameters in the same order).  The mini-batch step itself
-exists twice: ``HipTrainer`` = this repo's HIP kernels (tamago_amd/csrc/train.hip behind
-``tg_trainer_*``: forward with batch statistics, backward, SGD-Nesterov, running statistics;
-the default for 9x9), and ``rl_train_step`` / ``sl_train_step`` / ``GraphedStep`` = torch autograd
-over ATen / MIOpen ops, kept as the fp32 reference the kernels are tested against and for other
-board sizes.  The arithmetic is fp32 throughout (the reference runs this step under fp16
-autocast with a GradScaler, learn.py:342,371 - fp32 is the stricter of the two, and what its
-CPU trainer does).
+``torch.optim.SGD`` state over the parameters in the same order).  The mini-batch step is ``HipTrainer`` = this repo's HIP
+kernels (tamago_amd/csrc/train.hip behind ``tg_trainer_*``: forward with batch statistics, backward, SGD-Nesterov, running
+statistics) - the ONLY step implementation in the package: a board size the kernels are not built for (anything but 9x9
+today) is refused with an error, not handed to a library.  The torch-autograd restatement the kernels are tested against
+lives with the other checkers in ``oracle/train_ref.py``.  The arithmetic is fp32 throughout (the reference runs this step
+under fp16 autocast with a GradScaler on the GPU, learn.py:342,371, and in fp32 on the CPU - fp32 is the stricter of the
+two; mixed precision stays optional and unbuilt).
 
 The network is held as a flat table of tensors keyed like the state_dict (no module tree):
 the same table feeds ``DualNet.load_state_dict`` of the inference side after a step.
@@ -63,10 +62,10 @@ def calculate_value_loss(output: torch.Tensor, target: torch.Tensor) -> torch.Te
 
 
 # -------------------------------------------------------------------------------- the table
-class TrainableDualNet:
-    """Parameters and batch-norm statistics of one DualNet on the device, as leaves of an
-    autograd graph.  ``parameters()`` yields them in the reference module's order, so an
-    optimiser state written by either side loads into the other."""
+class ParamTable:
+    """Parameters and batch-norm statistics of one DualNet as a flat table of tensors keyed like the reference's
+    state_dict (no module tree, no forward pass).  ``parameters()`` yields the trainable ones in the reference module's
+    order: a ``torch.optim.SGD`` built over them has the state layout of the reference's ``model/rl-state.ckpt``."""
 
     def __init__(self, device: torch.device, board_size: int = 9,
                  state: Dict[str, torch.Tensor] = None):
@@ -104,168 +103,19 @@ class TrainableDualNet:
     def parameters(self):
         return [v for v in self.t.values() if v.requires_grad]
 
-    def train(self):
-        self.training = True
-        return self
 
-    def eval(self):
-        self.training = False
-        return self
-
-    def zero_grad(self):
-        for p in self.parameters():
-            p.grad = None
-
-    # ---- forward (dual_net.py:41-52, res_block.py:27-40, head/*.py) -------------------------
-    def _bn(self, x, prefix, cfg):
-        eps, momentum = cfg
-        t = self.t
-        return F.batch_norm(x, t[prefix + ".running_mean"], t[prefix + ".running_var"],
-                            t[prefix + ".weight"], t[prefix + ".bias"],
-                            training=self.training, momentum=momentum, eps=eps)
-
-    def forward(self, planes: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        """Policy logits [B, S*S+1] and value logits [B, 3]."""
-        t = self.t
-        self.batches_tracked += int(self.training)
-        x = F.relu(self._bn(F.conv2d(planes, t["conv_layer.weight"], padding=1),
-                            "bn_layer", _STEM_BN))
-        for b in range(BLOCKS):
-            pre = f"blocks.{b}"
-            h = F.relu(self._bn(F.conv2d(x, t[pre + ".conv1.weight"], padding=1),
-                                pre + ".bn1", _BODY_BN))
-            h = self._bn(F.conv2d(h, t[pre + ".conv2.weight"], padding=1), pre + ".bn2", _BODY_BN)
-            x = F.relu(x + h)
-        heads = []
-        for name in ("policy_head", "value_head"):
-            h = F.relu(self._bn(F.conv2d(x, t[name + ".conv_layer.weight"]),
-                                name + ".bn_layer", _BODY_BN))
-            heads.append(F.linear(h.flatten(1), t[name + ".fc_layer.weight"],
-                                  t[name + ".fc_layer.bias"]))
-        return heads[0], heads[1]
-
-
-def make_optimizer(net: TrainableDualNet, lr: float) -> torch.optim.SGD:
-    """learn.py:333-337: SGD, Nesterov momentum 0.9, weight decay 1e-4 on every parameter."""
+def make_optimizer(net: ParamTable, lr: float) -> torch.optim.SGD:
+    """learn.py:333-337: SGD, Nesterov momentum 0.9, weight decay 1e-4 on every parameter.  (The product path uses it for
+    the optimiser-state FILE only - the update itself is train.hip's sgd kernels.)"""
     return torch.optim.SGD(net.parameters(), lr=lr, momentum=MOMENTUM,
                            weight_decay=WEIGHT_DECAY, nesterov=True)
-
-
-def rl_train_step(net: TrainableDualNet, optimizer, plane, policy, value) -> Dict[str, float]:
-    """One mini-batch of learn.py:360-376 (KLD policy loss + value cross entropy)."""
-    with torch.enable_grad():
-        policy_predict, value_predict = net.forward(plane)
-        net.zero_grad()
-        policy_loss = calculate_policy_kld_loss(policy_predict, policy)
-        value_loss = calculate_value_loss(value_predict, value)
-        loss = (policy_loss + RL_VALUE_WEIGHT * value_loss).mean()
-        loss.backward()
-    optimizer.step()
-    return {"loss": loss.item(), "policy": policy_loss.mean().item(),
-            "value": value_loss.mean().item()}
-
-
-def sl_train_step(net: TrainableDualNet, optimizer, plane, policy, value) -> Dict[str, float]:
-    """One mini-batch of the supervised trainer (learn.py:150-180): the policy target is a
-    distribution scored against the softmax output, value weight 0.02."""
-    with torch.enable_grad():
-        policy_predict, value_predict = net.forward(plane)
-        net.zero_grad()
-        policy_loss = calculate_policy_loss(F.softmax(policy_predict, dim=1), policy)
-        value_loss = calculate_value_loss(value_predict, value)
-        loss = (policy_loss + SL_VALUE_WEIGHT * value_loss).mean()
-        loss.backward()
-    optimizer.step()
-    return {"loss": loss.item(), "policy": policy_loss.mean().item(),
-            "value": value_loss.mean().item()}
-
-
-class GraphedStep:
-    """One mini-batch step captured in a hipGraph (torch.cuda.CUDAGraph) and replayed: the
-    eager step is launch-bound (a few hundred small kernels for 2.7 ms of a 256-position
-    batch), a replay is one submission.  Inputs are copied into static buffers, the three
-    loss values are accumulated on the device (no host read per step).  The operator sequence
-    is the eager step's; results agree with it to summation-order noise."""
-
-    def __init__(self, net: TrainableDualNet, optimizer, batch_size: int, mode: str = "rl"):
-        dev, s = net.device, net.board_size
-        self.net, self.optimizer = net, optimizer
-        self.plane = torch.zeros((batch_size, 6, s, s), device=dev)
-        self.policy = torch.full((batch_size, s * s + 1), 1.0 / (s * s + 1), device=dev)
-        self.value = torch.zeros((batch_size,), dtype=torch.int64, device=dev)
-        self.sums = torch.zeros(3, dtype=torch.float64, device=dev)
-        self.steps = 0
-        body = self._rl if mode == "rl" else self._sl
-        # warm-up on a side stream (library workspaces, algorithm choice), then put every
-        # tensor the warm-up touched back: parameters, statistics, momentum buffers
-        params = [p.detach().clone() for p in net.parameters()]
-        stats = {k: v.clone() for k, v in net.t.items() if not v.requires_grad}
-        had = {id(p): optimizer.state[p]["momentum_buffer"].clone()
-               for p in net.parameters() if "momentum_buffer" in optimizer.state.get(p, {})}
-        tracked = net.batches_tracked
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side), torch.enable_grad():
-            for _ in range(3):
-                optimizer.zero_grad(set_to_none=True)
-                body()
-        torch.cuda.current_stream(dev).wait_stream(side)
-        self._restore(params, stats, had)
-        self.graph = torch.cuda.CUDAGraph()
-        optimizer.zero_grad(set_to_none=True)
-        with torch.enable_grad(), torch.cuda.graph(self.graph):
-            body()
-        self._restore(params, stats, had)     # the capture pass does not execute, but be exact
-        self.sums.zero_()
-        net.batches_tracked = tracked
-
-    def _restore(self, params, stats, had):
-        with torch.no_grad():
-            for p, saved in zip(self.net.parameters(), params):
-                p.copy_(saved)
-                buf = self.optimizer.state[p].get("momentum_buffer")
-                if buf is not None:           # zeros == "no buffer yet": first step sets buf = grad
-                    buf.copy_(had[id(p)]) if id(p) in had else buf.zero_()
-            for k, saved in stats.items():
-                self.net.t[k].copy_(saved)
-
-    def _losses(self, policy_loss, value_loss, weight):
-        loss = (policy_loss + weight * value_loss).mean()
-        loss.backward()
-        self.optimizer.step()
-        self.sums += torch.stack([loss.detach(), policy_loss.detach().mean(),
-                                  value_loss.detach().mean()]).double()
-
-    def _rl(self):
-        p, v = self.net.forward(self.plane)
-        self._losses(calculate_policy_kld_loss(p, self.policy),
-                     calculate_value_loss(v, self.value), RL_VALUE_WEIGHT)
-
-    def _sl(self):
-        p, v = self.net.forward(self.plane)
-        self._losses(calculate_policy_loss(F.softmax(p, dim=1), self.policy),
-                     calculate_value_loss(v, self.value), SL_VALUE_WEIGHT)
-
-    def __call__(self, plane, policy, value):
-        self.plane.copy_(plane, non_blocking=True)
-        self.policy.copy_(policy, non_blocking=True)
-        self.value.copy_(value, non_blocking=True)
-        self.graph.replay()
-        self.steps += 1
-        self.net.batches_tracked += 1
-
-    def take_losses(self) -> Dict[str, float]:
-        """Summed losses since the last call (one host read)."""
-        total = self.sums.tolist()
-        self.sums.zero_()
-        return {"loss": total[0], "policy": total[1], "value": total[2]}
 
 
 class HipTrainer:
     """The training step as this repo's HIP kernels (tamago_amd/csrc/train.hip behind tg_trainer_*): forward with
     batch statistics, backward, SGD-Nesterov + weight decay, batch-norm running statistics - no autograd, no
-    library kernel.  Same table / state_dict / optimiser-state layout as TrainableDualNet + make_optimizer, so
-    the two interchange (and with the reference's modules).  9x9, fp32."""
+    library kernel.  Same table / state_dict / optimiser-state layout as ParamTable + make_optimizer (and as the
+    reference's modules).  fp32; built for 9x9 - any other board size raises (there is no second backend to fall to)."""
 
     def __init__(self, device: torch.device, board_size: int = 9, batch_size: int = 256,
                  state: Dict[str, torch.Tensor] = None):
@@ -276,6 +126,10 @@ class HipTrainer:
         self.device = torch.device(device)
         if self.device.type == "cuda" and self.device.index is None:
             self.device = torch.device("cuda", 0)           # (tg_trainer_create below uses index 0 as well)
+        if board_size != 9:
+            raise ValueError(f"HipTrainer: the HIP training step (tamago_amd/csrc/train.hip) is built for 9x9 boards; "
+                             f"board size {board_size} is not served (the reference's own trainer, nn/learn.py, is the "
+                             f"tool for it)")
         self.board_size = board_size
         self.batch_size = batch_size
         self.keys = state_dict_keys(board_size)
@@ -400,7 +254,7 @@ def train_with_gumbel_alphazero_on_gpu(program_dir: str, board_size: int, batch_
     device = torch.device("cuda", device_index)
     torch.cuda.set_device(device)             # graph capture and side streams run on the CURRENT device
     data_set = sorted(glob.glob(os.path.join(program_dir, "data", "rl_data_*.npz")))
-    net = TrainableDualNet(device, board_size)
+    net = ParamTable(device, board_size)
     model_file_path = os.path.join(program_dir, "model", "rl-model.bin")
     if os.path.exists(model_file_path):
         print(f"load {model_file_path}")
@@ -421,23 +275,10 @@ def train_with_gumbel_alphazero_on_gpu(program_dir: str, board_size: int, batch_
         print(f"num_trained_batches : {num_trained_batches}")
 
     train_loss = {"loss": 0.0, "policy": 0.0, "value": 0.0}
-    # Step implementation: this repo's HIP kernels (tg_trainer_*, 9x9) unless TG_TRAIN_BACKEND says otherwise
-    # ("autograd" = torch autograd replayed as a hipGraph, "eager" = the same, launch by launch; other board sizes
-    # use autograd).  All three read and write the same model / optimiser-state files.
-    backend = os.environ.get("TG_TRAIN_BACKEND", "hip" if board_size == 9 else "autograd")
-    if os.environ.get("TG_TRAIN_EAGER", "0") == "1":
-        backend = "eager"
-    if backend not in ("hip", "autograd", "eager"):
-        # (a typo used to fall through to the eager loop silently)
-        raise ValueError(f"TG_TRAIN_BACKEND={backend!r}: expected 'hip', 'autograd' or 'eager'")
-    graphed = hip = None
-    if backend == "hip":
-        hip = HipTrainer(device, board_size, batch_size, net.state_dict())
-        buffers = [optimizer.state[p].get("momentum_buffer") for p in net.parameters()]
-        if all(b is not None for b in buffers):
-            hip.load_momentum_buffers(buffers)
-    elif backend == "autograd":
-        graphed = GraphedStep(net.train(), optimizer, batch_size, "rl")
+    hip = HipTrainer(device, board_size, batch_size, net.state_dict())      # (refuses sizes train.hip is not built for)
+    buffers = [optimizer.state[p].get("momentum_buffer") for p in net.parameters()]
+    if all(b is not None for b in buffers):
+        hip.load_momentum_buffers(buffers)
     for data_index, path in enumerate(data_set):
         plane_data, policy_data, value_data = load_data_set(path)
         planes = torch.from_numpy(plane_data).to(device, torch.float32)   # chunk resident in HBM
@@ -445,36 +286,24 @@ def train_with_gumbel_alphazero_on_gpu(program_dir: str, board_size: int, batch_
         values = torch.from_numpy(value_data).to(device)
         train_loss = {"loss": 0.0, "policy": 0.0, "value": 0.0}
         iteration = 0
-        net.train()
         started = time.time()
         for i in range(0, len(value_data) - batch_size + 1, batch_size):
-            batch = (planes[i:i + batch_size], policies[i:i + batch_size], values[i:i + batch_size])
-            if hip is not None:
-                hip.step(*batch, mode="rl", lr=RL_LEARNING_RATE)
-            elif graphed is not None:
-                graphed(*batch)
-            else:
-                part = rl_train_step(net, optimizer, *batch)
-                for k in train_loss:
-                    train_loss[k] += part[k]
+            hip.step(planes[i:i + batch_size], policies[i:i + batch_size], values[i:i + batch_size],
+                     mode="rl", lr=RL_LEARNING_RATE)
             num_trained_batches += 1
             iteration += 1
-        if hip is not None:
-            train_loss = hip.take_losses()
-        elif graphed is not None:
-            train_loss = graphed.take_losses()
+        train_loss = hip.take_losses()
         print_learning_process(train_loss, 0, data_index, iteration, started)
 
-    if hip is not None:
-        # back into the table / torch.optim.SGD layout the files are written from
-        net.load_state_dict(hip.state_dict())
-        fresh = make_optimizer(net, RL_LEARNING_RATE)        # (load_state_dict made new parameter tensors)
-        had_momentum = any("momentum_buffer" in st for st in optimizer.state.values())
-        if hip.steps or had_momentum:
-            for p, buf in zip(net.parameters(), hip.momentum_buffers()):
-                fresh.state[p]["momentum_buffer"] = buf.to(device)
-        optimizer = fresh
-        hip.close()
+    # back into the table / torch.optim.SGD layout the files are written from
+    net.load_state_dict(hip.state_dict())
+    fresh = make_optimizer(net, RL_LEARNING_RATE)            # (load_state_dict made new parameter tensors)
+    had_momentum = any("momentum_buffer" in st for st in optimizer.state.values())
+    if hip.steps or had_momentum:
+        for p, buf in zip(net.parameters(), hip.momentum_buffers()):
+            fresh.state[p]["momentum_buffer"] = buf.to(device)
+    optimizer = fresh
+    hip.close()
     os.makedirs(os.path.dirname(model_file_path), exist_ok=True)
     torch.save(net.state_dict(), model_file_path)
     torch.save({"num_trained_batches": num_trained_batches,
@@ -503,55 +332,48 @@ def train_on_gpu(program_dir: str, board_size: int, batch_size: int, epochs: int
     """Supervised trainer, learn.py:126-232: `epochs` passes over the training chunks of
     ``data/sl_data_*.npz``, after each one the test chunks in eval mode, then the learning
     rate schedule; writes ``model/sl-model.bin`` relative to the working directory, as the
-    reference does (learn.py:232).  Returns the last test-loss sums."""
+    reference does (learn.py:232).  Returns the last test-loss sums.
+
+    Training steps: ``HipTrainer`` (mode "sl": cross entropy of the softmax output against the move distribution, value
+    weight 0.02; the learning rate is an argument of every step, so the schedule needs no re-capture).  Test pass: the
+    trained table goes into the INFERENCE network (``DualNet``: batch norm folded from the running statistics = eval
+    mode) and the losses are taken from its policy / value probabilities."""
     if not torch.cuda.is_available():
         raise RuntimeError("tamago_amd trains on the GPU only")
+    from tamago_amd.nn.network.dual_net import DualNet
     device = torch.device("cuda", device_index)
-    torch.cuda.set_device(device)             # graph capture and side streams run on the CURRENT device
+    torch.cuda.set_device(device)
     data_set = sorted(glob.glob(os.path.join(program_dir, "data", "sl_data_*.npz")))
     train_files, test_files = split_train_test_set(data_set, 0.8)
-    net = TrainableDualNet(device, board_size)
-    optimizer = make_optimizer(net, SL_LEARNING_RATE)
+    hip = HipTrainer(device, board_size, batch_size, random_state_dict(board_size))
+    evaluator = DualNet(device, board_size)
     current_lr = SL_LEARNING_RATE
-    eager = os.environ.get("TG_TRAIN_EAGER", "0") == "1"
-    graphed = None
     test_loss = {"loss": 0.0, "policy": 0.0, "value": 0.0}
     for epoch in range(epochs):
         for data_index, path in enumerate(train_files):
             planes, policies, values = _chunk_on_device(path, device)
-            net.train()
-            if graphed is None and not eager:     # (re)captured after a learning-rate change:
-                graphed = GraphedStep(net, optimizer, batch_size, "sl")   # lr is baked into the graph
-            train_loss = {"loss": 0.0, "policy": 0.0, "value": 0.0}
             iteration = 0
             started = time.time()
             for i in range(0, len(values) - batch_size + 1, batch_size):
-                batch = (planes[i:i + batch_size], policies[i:i + batch_size], values[i:i + batch_size])
-                if eager:
-                    part = sl_train_step(net, optimizer, *batch)
-                    for k in train_loss:
-                        train_loss[k] += part[k]
-                else:
-                    graphed(*batch)
+                hip.step(planes[i:i + batch_size], policies[i:i + batch_size], values[i:i + batch_size],
+                         mode="sl", lr=current_lr)
                 iteration += 1
-            if not eager:
-                train_loss = graphed.take_losses()
-            print_learning_process(train_loss, epoch, data_index, iteration, started)
+            print_learning_process(hip.take_losses(), epoch, data_index, iteration, started)
 
-        sums = torch.zeros(3, dtype=torch.float64, device=device)
+        sums = torch.zeros(3, dtype=torch.float64)
         test_iteration = 0
         started = time.time()
-        net.eval()
+        evaluator.load_state_dict(hip.state_dict())
         for path in test_files:
             planes, policies, values = _chunk_on_device(path, device)
-            with torch.no_grad():
-                for i in range(0, len(values) - batch_size + 1, batch_size):
-                    p, v = net.forward(planes[i:i + batch_size])
-                    policy_loss = calculate_policy_loss(F.softmax(p, dim=1), policies[i:i + batch_size])
-                    value_loss = calculate_value_loss(v, values[i:i + batch_size])
-                    loss = (policy_loss + SL_VALUE_WEIGHT * value_loss).mean()
-                    sums += torch.stack([loss, policy_loss.mean(), value_loss.mean()]).double()
-                    test_iteration += 1
+            for i in range(0, len(values) - batch_size + 1, batch_size):
+                prob, vprob = evaluator.forward_device(planes[i:i + batch_size].contiguous())
+                policy_loss = calculate_policy_loss(prob, policies[i:i + batch_size])
+                target = values[i:i + batch_size].long()
+                value_loss = -torch.log(vprob.gather(1, target[:, None])[:, 0])      # = cross entropy of the value logits
+                loss = (policy_loss + SL_VALUE_WEIGHT * value_loss).mean()
+                sums += torch.stack([loss, policy_loss.mean(), value_loss.mean()]).double().cpu()
+                test_iteration += 1
         total = sums.tolist()
         test_loss = {"loss": total[0], "policy": total[1], "value": total[2]}
         n = max(test_iteration, 1)
@@ -562,11 +384,9 @@ def train_on_gpu(program_dir: str, board_size: int, batch_size: int, epochs: int
 
         if epoch in LEARNING_SCHEDULE["learning_rate"]:
             previous_lr, current_lr = current_lr, LEARNING_SCHEDULE["learning_rate"][epoch]
-            for group in optimizer.param_groups:
-                group["lr"] = current_lr
-            graphed = None
             print(f"Epoch {epoch}, learning rate has changed {previous_lr} -> {current_lr}")
 
     os.makedirs("model", exist_ok=True)
-    torch.save(net.state_dict(), os.path.join("model", "sl-model.bin"))
+    torch.save(hip.state_dict(), os.path.join("model", "sl-model.bin"))
+    hip.close()
     return test_loss

@@ -135,6 +135,18 @@ class DualNet:
         _lib.check(self._lib.tg_net_range_fallbacks(self._handle, ctypes.byref(count)), "tg_net_range_fallbacks")
         return int(count.value)
 
+    def band_timeouts(self) -> int:
+        """19x19: bounded waits of the banded forward kernels that gave up (tg_net_band_timeouts; synchronises the device).
+        Each one is also a range fallback; after the first the network keeps to the one-workgroup kernel."""
+        count = ctypes.c_ulonglong(0)
+        _lib.check(self._lib.tg_net_band_timeouts(self._handle, ctypes.byref(count)), "tg_net_band_timeouts")
+        return int(count.value)
+
+    def set_shared_device(self, shared: bool = True) -> None:
+        """Other processes drive this GPU too (more self-play shards than GPUs): kernels that need several workgroups of one
+        launch resident at once are not chosen (tg_net_set_shared_device).  Results do not change."""
+        _lib.check(self._lib.tg_net_set_shared_device(self._handle, 1 if shared else 0), "tg_net_set_shared_device")
+
     def _forward_host(self, input_plane: torch.Tensor, want_logits: int):
         x = input_plane.detach().to("cpu", torch.float32).contiguous()
         b, s = x.shape[0], self.board_size

@@ -102,18 +102,21 @@ def pin_host_threads(local_rank: int, local_world: int, device_index=None, numa_
         # the other local ranks are assumed to map onto the devices the way this one does (rank r -> device r mod n):
         # ranks on the same node = those whose device reports the same core list
         peers = sharing = 0
-        try:
+        all_known = True                                 # NUMA slices or contiguous slices: the same rule for every local rank,
+        try:                                             # or a rank without NUMA information lands on another's slice
             import torch
             n_dev = max(1, torch.cuda.device_count())
             for r in range(local_world):
-                same = gpu_numa_cores(r % n_dev) == numa_cores if not os.environ.get("TG_SINGLE_DEVICE") else True
-                if same:
+                theirs = numa_cores if os.environ.get("TG_SINGLE_DEVICE") else gpu_numa_cores(r % n_dev)
+                if theirs is None:
+                    all_known = False
+                if theirs == numa_cores:
                     if r < local_rank:
                         peers += 1
                     sharing += 1
         except Exception:
             peers, sharing = local_rank, local_world
-        if local and sharing:
+        if local and sharing and all_known:
             per = max(1, len(local) // sharing)
             mine = local[peers * per:(peers + 1) * per]
     if not mine:
@@ -136,14 +139,19 @@ def run_shard(args, rank: int, world: int, local_rank: int, record_dir: str) -> 
     # more worker processes than GPUs (the reference's --process N puts N workers on ONE device, nn/utility.py:22):
     # the shards share the devices round-robin
     device_index = 0 if os.environ.get("TG_SINGLE_DEVICE") else local_rank % n_dev
-    if os.environ.get("TG_SINGLE_DEVICE") or world > n_dev:
+    # ranks of THIS node against the GPUs of this node (a 16-rank job on two 8-GPU nodes shares nothing)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    shared = bool(os.environ.get("TG_SINGLE_DEVICE")) or local_world > n_dev
+    if shared:
         # several shards share a device: the three-workgroups-per-tree selection kernel needs all of a tree's workgroups
         # resident at once, which another shard's kernels can prevent - keep to the one-workgroup kernels
         os.environ.setdefault("TG_SELECT_SPLIT", "0")
-    cores = pin_host_threads(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), device_index)
+    cores = pin_host_threads(local_rank, local_world, device_index)
     torch.cuda.set_device(device_index)
     network = load_network(model_file_path=args.model, use_gpu=args.use_gpu, board_size=args.size,
                            device_index=device_index)
+    if shared and hasattr(network, "set_shared_device"):
+        network.set_shared_device(True)                    # ... and so does the banded 19x19 forward (net_forward_band.hip)
     mine = shard_indices(list(range(1, args.num_data + 1)), world, rank)
     flags = [True] * len(mine) if args.never_resign else None
     t0 = time.perf_counter()

@@ -1,6 +1,6 @@
 """Multi-GPU path on CPU: self-play shards are independent (no data-path collective); the
-only distributed step is the barrier + reduction bench.py uses for timing.  world_size 2,
-gloo backend."""
+only distributed step is the barrier + reduction bench.py uses for timing.  world sizes 2
+and 8 (the reference's selfplay_main.py:44-65 runs 8 worker shards), gloo backend."""
 import os
 import subprocess
 import sys
@@ -134,6 +134,101 @@ def test_launcher_rank_failure_reaches_every_rank(tmp_path):
     assert out.returncode != 0
     assert "GPU fell off the bus" in out.stderr + out.stdout
     assert "shard 0" in out.stdout and "games/hour" in out.stdout          # the surviving shard's report
+
+
+def _torchrun(nproc, port, script_args, env, timeout=600):
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+                           "--master-addr", "127.0.0.1", "--master-port", str(port)] + script_args,
+                          env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_rank_plumbing_at_world_size_8(tmp_path):
+    """bench.py's N-rank code path at N = 8, before an 8-GPU node shows up: TG_BENCH_DRY_RUN=1 keeps the collectives of the
+    GPU path in their order (barrier / timed steps / barrier, MAX of the clock, SUM of the counts, the host-cost gather, the
+    cfg-4 gather) and swaps the workload for a stub.  Rank 0 prints ONE line: the aggregate is the sum over eight ranks over
+    the slowest rank's clock; a failure injected into a MIDDLE rank's cfg-4 shard reaches rank 0 as an error row instead of
+    stranding seven ranks in a collective."""
+    import json
+    env = dict(os.environ, TG_BENCH_DRY_RUN="1", MASTER_ADDR="127.0.0.1")
+    env.pop("TG_BENCH_FAIL_RANK", None)
+    bench = os.path.join(REPO, "bench.py")
+    out = _torchrun(8, 29581, [bench, "--gpus", "8", "--steps", "3", "--warmup", "1", "--trees", "64", "--cfg4-games", "4"], env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 only
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["steps"] == 3 and line["scaling"] == "weak" and "DRY RUN" in line["data"]
+    per_step = 64 * 1001
+    # whole-job aggregate: eight ranks' units over the max-over-ranks time (every stub step sleeps 10 - 30 ms)
+    assert abs(line["value"] * line["ms_per_step"] * 1e-3 - 8 * per_step) < 1e-6 * 8 * per_step
+    assert line["ms_per_step"] >= 30.0
+    assert [r["rank"] for r in line["host"]["per_rank"]] == list(range(8))
+    leg = line["cfg4_selfplay_shards"]
+    assert leg["shards"] == 8 and [r["rank"] for r in leg["per_rank"]] == list(range(8))
+    assert leg["seconds"] >= 0.15 and "host_cpu_s_per_1e6_leaf_evals" in leg
+    assert abs(leg["value"] * leg["seconds"] - 8 * 401 * 60 * 4) < 1e-6 * 8 * 401 * 60 * 4
+    # a middle rank's shard fails
+    env["TG_BENCH_FAIL_RANK"] = "3"
+    out = _torchrun(8, 29583, [bench, "--gpus", "8", "--steps", "1", "--warmup", "0", "--trees", "8", "--cfg4-games", "2"], env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    leg = line["cfg4_selfplay_shards"]
+    assert leg["failed_ranks"] == [3] and "injected failure on rank 3" in leg["messages"]["3"]
+    assert line["value"] > 0                                 # the headline of the same run stands
+
+
+LAUNCHER8 = r'''
+import json, os, sys
+sys.path.insert(0, os.environ["TG_REPO"])
+from tamago_amd.selfplay import main as launcher
+from tamago_amd.selfplay.worker import shard_indices
+
+def fake_shard(args, rank, world, local_rank, record_dir):
+    assert os.path.isdir(record_dir) and world == 8
+    if os.environ.get("TG_FAIL_RANK") == str(rank):
+        raise RuntimeError(f"shard {rank}: GPU fell off the bus")
+    mine = shard_indices(list(range(1, args.num_data + 1)), world, rank)
+    open(os.path.join(record_dir, f"rank{rank}.txt"), "w").write(" ".join(map(str, mine)))
+    return {"games": len(mine), "moves": 10 * len(mine), "leaf_evals": 401 * 10 * len(mine), "seconds": 0.1 * (1 + rank % 4),
+            "rank": rank, "device": local_rank, "host_cores": launcher.pin_host_threads(local_rank, world),
+            "first": mine[0], "last": mine[-1]}
+
+launcher.run_shard = fake_shard
+result = launcher.main(["--save-dir", os.environ["TG_SAVE"], "--num-data", "67", "--visits", "400", "--boards", "64",
+                        "--size", "9", "--json"])
+if int(os.environ["RANK"]) == 0:
+    assert result["shards"] == 8 and result["games"] == 67 and result["leaf_evals"] == 401 * 670
+    assert result["seconds"] >= 0.4                      # slowest rank
+    assert sorted(s["rank"] for s in result["per_shard"]) == list(range(8))
+    print("LAUNCH8-OK")
+'''
+
+
+def test_selfplay_launcher_eight_ranks_gloo(tmp_path):
+    """BASELINE.json config[3]'s launcher at its real world size (selfplay_main.py:44-65: 8 worker shards): one record
+    directory chosen by rank 0, eight disjoint contiguous game blocks covering 1 .. 67 in rank order, the aggregate over
+    eight ranks on the slowest rank's clock; then the same launch with a MIDDLE rank (5) raising: every rank exits
+    non-zero, the error text and the surviving shards' report reach the output."""
+    script = tmp_path / "launch8.py"
+    script.write_text(LAUNCHER8)
+    save = tmp_path / "archive"
+    save.mkdir()
+    env = dict(os.environ, TG_REPO=REPO, TG_SAVE=str(save), MASTER_ADDR="127.0.0.1")
+    env.pop("TG_FAIL_RANK", None)
+    out = _torchrun(8, 29585, [str(script)], env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "LAUNCH8-OK" in out.stdout
+    games = []
+    for r in range(8):
+        mine = [int(g) for g in (save / "1" / f"rank{r}.txt").read_text().split()]
+        assert mine == list(range(mine[0], mine[0] + len(mine))) and 8 <= len(mine) <= 9
+        games += mine
+    assert games == list(range(1, 68))
+    env["TG_FAIL_RANK"] = "5"
+    out = _torchrun(8, 29587, [str(script)], env, timeout=180)
+    assert out.returncode != 0
+    assert "shard 5: GPU fell off the bus" in out.stderr + out.stdout
+    assert "shard 0" in out.stdout and "shard 7" in out.stdout and "games/hour" in out.stdout
 
 
 def test_numa_aware_pinning_slices_the_gpus_node():

@@ -116,16 +116,15 @@ def test_featurize_kernel_vs_reference_golden(size):
     assert np.array_equal(out.cpu().numpy(), np.array(want))
 
 
-@pytest.mark.parametrize("size,algo", [(9, "direct"), (9, "wino"), (9, "split16"), (9, "w2"), (9, "wsplit"), (9, "w1d"),
+@pytest.mark.parametrize("size,algo", [(9, "direct"), (9, "wino"), (9, "split16"), (9, "w1d"),
                                        (19, "direct"), (19, "wino"), (19, "split16")])
 def test_every_tower_algorithm_matches_the_oracle(algo, size, monkeypatch):
     """Implementations of the residual tower: exact-fp32 Winograd F(2x2,3x3) kernel (TG_FWD_ALGO=wino; the
     layer outputs of a 19x19 board passing through a global scratch image), exact-fp32 direct implicit GEMM
     (direct), and the split-operand kernels on the 16-bit matrix pipe (split16 = f16 x 2 pieces, one wave per SIMD,
-    at both sizes; 19x19: one board per workgroup, residual image in an L2-resident scratch; w2 = the same arithmetic
-    with two waves per SIMD, weights through an LDS ring and batch norm folded into the weights, for 9x9 batches
-    above the CU count; wsplit = Winograd F(2x2,3x3) on the same operand pieces; w1d = Winograd F(2,3) along x only, the
-    default for launches of three-board workgroups).  All must agree with the oracle at every workgroup shape."""
+    at both sizes; 19x19: one board per workgroup, residual image in an L2-resident scratch; w1d = Winograd F(2,3) along
+    x only on the same operand pieces, the 9x9 default).  All must agree with the oracle at every workgroup shape.
+    (Round 5: the two-waves-per-SIMD and 2-D Winograd kernels, measured slower, left the library - tools/experiments/kernels/.)"""
     from oracle.net import OracleNet, make_state_dict
     monkeypatch.setenv("TG_FWD_ALGO", algo)
     sd = make_state_dict(size, 7, 1.5)
@@ -141,7 +140,7 @@ def test_every_tower_algorithm_matches_the_oracle(algo, size, monkeypatch):
         assert np.abs(val.numpy() - rv.numpy()).max() < TOL, (algo, b)
 
 
-@pytest.mark.parametrize("algo", ["w1d", "wsplit", "split16"])
+@pytest.mark.parametrize("algo", ["w1d", "split16"])
 def test_results_do_not_depend_on_the_launch_size(algo, monkeypatch):
     """A position's policy and value must come out the same bits whether it is evaluated alone, in a mini-batch of one-board
     workgroups or deep inside a launch of three-board workgroups: self-play games would otherwise depend on how the boards
@@ -236,11 +235,34 @@ def test_banded_kernel_cannot_hang_a_silent_band_ends_in_the_exact_fallback(monk
     monkeypatch.delenv("TG_BAND_TEST_MUTE")
     assert dt < 20.0, dt
     assert net.range_fallbacks() == 1
+    assert net.band_timeouts() >= 1                                  # ... told apart from an f16-range fallback
     rp, rv = OracleNet(sd).inference(x)
     assert np.abs(pol.numpy() - rp.numpy()).max() < TOL and np.abs(val.numpy() - rv.numpy()).max() < TOL
     assert np.abs(pol.numpy() - good[0].numpy()).max() < TOL
-    again = net.inference(x)                                         # and the next launch is an ordinary one
+    # the next launch is an ordinary one - and, the device having shown that it cannot keep a board's bands resident, on the
+    # one-workgroup kernel from now on (same bits)
+    from tamago_amd import lib as tl
+    assert b"band" not in tl.load().tg_net_kernel_name(net.handle, 4)
+    again = net.inference(x)
     assert torch.equal(again[0], good[0]) and torch.equal(again[1], good[1]) and net.range_fallbacks() == 1
+
+
+def test_a_shared_device_keeps_19x19_launches_on_the_one_workgroup_kernel(monkeypatch):
+    """More shard processes than GPUs (selfplay/main.py, TG_SINGLE_DEVICE): another process's kernels can keep a board's bands
+    off the CUs, so the banded kernel is not chosen (tg_net_set_shared_device) - same results, no 0.1 s bounded waits."""
+    from oracle.net import make_state_dict
+    from tamago_amd import lib as tl
+    monkeypatch.delenv("TG_FWD_BANDS", raising=False)
+    net = _net(19, make_state_dict(19, 4, 1.2))
+    lib = tl.load()
+    x = torch.from_numpy(np.random.RandomState(10).randint(-1, 2, size=(16, 6, 19, 19)).astype(np.float32))
+    assert b"band" in lib.tg_net_kernel_name(net.handle, 16)
+    banded = net.inference(x)
+    net.set_shared_device(True)
+    assert b"band" not in lib.tg_net_kernel_name(net.handle, 16)
+    alone = net.inference(x)
+    assert torch.equal(alone[0], banded[0]) and torch.equal(alone[1], banded[1])
+    assert net.band_timeouts() == 0 and net.range_fallbacks() == 0
 
 
 def test_kernel_name_and_executed_flops_know_the_ragged_tail_split(monkeypatch):
@@ -274,7 +296,7 @@ def test_split_kernels_are_fp32_class_and_fall_back_on_f16_overflow(monkeypatch)
     from oracle.net import OracleNet, make_state_dict
     fix = load_npz("net_s9.npz")
     errs = {}
-    for algo in ("wino", "direct", "split16", "w2", "wsplit", "w1d"):
+    for algo in ("wino", "direct", "split16", "w1d"):
         monkeypatch.setenv("TG_FWD_ALGO", algo)
         worst = 0.0
         for seed in (0, 7):
@@ -297,7 +319,7 @@ def test_split_kernels_are_fp32_class_and_fall_back_on_f16_overflow(monkeypatch)
     x = torch.from_numpy(np.random.RandomState(2).randint(-1, 2, size=(300, 6, 9, 9)).astype(np.float32))
     monkeypatch.setenv("TG_FWD_ALGO", "wino")
     want = _net(9, sd).inference_with_policy_logits(x)
-    for algo in ("split16", "w2", "wsplit", "w1d"):
+    for algo in ("split16", "w1d"):
         monkeypatch.setenv("TG_FWD_ALGO", algo)
         hot = _net(9, sd)
         assert hot.range_fallbacks() == 0

@@ -331,11 +331,10 @@ def test_pipelined_selection_equals_serial(cfg):
     import sys
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_select_digest.py")
     outs = []
-    for variant in ("serial", "mpipe", "mpipe", "pipe", "owner", "owner", "split", "split", "split1"):
+    for variant in ("serial", "mpipe", "mpipe", "pipe", "split", "split", "split1"):
         env = dict(os.environ)
         env.pop("TG_SELECT_SERIAL", None)
         env.pop("TG_SELECT_MPIPE_TREES", None)
-        env.pop("TG_SELECT_OWNER", None)
         env.pop("TG_SPLIT_CFG", None)
         # select_puct_split_kernel (<= 16 trees): one selecting workgroup + two of workers per tree; "split1": one of workers
         env["TG_SELECT_SPLIT"] = "1" if variant.startswith("split") else "0"
@@ -345,8 +344,6 @@ def test_pipelined_selection_equals_serial(cfg):
             env["TG_SELECT_SERIAL"] = "1"
         elif variant == "pipe":
             env["TG_SELECT_MPIPE_TREES"] = "0"
-        elif variant == "owner":          # select_puct_owner_kernel: nodes owned by wavefronts (opt-in)
-            env["TG_SELECT_OWNER"] = "1"
         res = subprocess.run([sys.executable, script] + cfg.split(), env=env, capture_output=True, text=True, timeout=600)
         assert res.returncode == 0, res.stderr[-2000:]
         outs.append(res.stdout.strip().splitlines()[-1])

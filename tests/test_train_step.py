@@ -16,6 +16,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 from gen_golden_train import make_case, sample_of  # noqa: E402  (seeded inputs only)
 
 from tamago_amd.nn import learn  # noqa: E402
+from oracle import train_ref  # noqa: E402   (the torch-autograd checker: never imported by the package)
 from tamago_amd.nn.network.dual_net import state_dict_keys  # noqa: E402
 
 GOLD = np.load(os.path.join(ROOT, "tests", "golden", "train_s9.npz"))
@@ -34,12 +35,12 @@ TOL = {
 
 def run_and_check(mode, device, tol):
     state, batches = make_case()
-    net = learn.TrainableDualNet(device, 9, state)
+    net = train_ref.TrainableDualNet(device, 9, state)
     net.train()
     opt = learn.make_optimizer(net, 0.01)
     group = opt.param_groups[0]
     assert (group["momentum"], group["weight_decay"], group["nesterov"]) == (0.9, 1e-4, True)
-    step = learn.rl_train_step if mode == "rl" else learn.sl_train_step
+    step = train_ref.rl_train_step if mode == "rl" else train_ref.sl_train_step
     moved = 0.0
     for k, (planes, pol, val) in enumerate(batches):
         part = step(net, opt, torch.from_numpy(planes).to(device),
@@ -166,7 +167,7 @@ def test_hip_training_step_tensor_by_tensor_vs_autograd():
         tl.check(lib.tg_trainer_debug_read(hip.handle, which, idx, out.ctypes.data))
         return torch.from_numpy(out).permute(0, 2, 1).reshape(bsz, 64, 9, 9).to(dev)
 
-    net = learn.TrainableDualNet(dev, 9, state).train()
+    net = train_ref.TrainableDualNet(dev, 9, state).train()
     opt = learn.make_optimizer(net, 0.01)
     t = net.t
     zs, outs, ys = [], [], []
@@ -224,15 +225,15 @@ def test_graphed_step_equals_eager(mode):
     dev = torch.device("cuda", 0)
     state, batches = make_case()
     dev_batches = [tuple(torch.from_numpy(a).to(dev) for a in b) for b in batches]
-    step = learn.rl_train_step if mode == "rl" else learn.sl_train_step
-    eager = learn.TrainableDualNet(dev, 9, state).train()
+    step = train_ref.rl_train_step if mode == "rl" else train_ref.sl_train_step
+    eager = train_ref.TrainableDualNet(dev, 9, state).train()
     opt_e = learn.make_optimizer(eager, 0.01)
     step(eager, opt_e, *dev_batches[0])
     second = step(eager, opt_e, *dev_batches[1])
-    graphed_net = learn.TrainableDualNet(dev, 9, state).train()
+    graphed_net = train_ref.TrainableDualNet(dev, 9, state).train()
     opt_g = learn.make_optimizer(graphed_net, 0.01)
     step(graphed_net, opt_g, *dev_batches[0])                 # momentum buffers exist before capture
-    run = learn.GraphedStep(graphed_net, opt_g, 32, mode)
+    run = train_ref.GraphedStep(graphed_net, opt_g, 32, mode)
     run(*dev_batches[1])
     got = run.take_losses()
     np.testing.assert_allclose([got["loss"], got["policy"], got["value"]],
@@ -275,9 +276,9 @@ def test_rl_training_loop_files(tmp_path):
 
 @pytest.mark.gpu
 def test_sl_trainer_files(tmp_path, monkeypatch):
-    """sl_data chunks -> epochs with the test split and the learning-rate schedule ->
-    model/sl-model.bin; the hipGraph path (re-captured at the rate change) and the eager
-    path reach the same test loss."""
+    """sl_data chunks -> epochs with the test split and the learning-rate schedule -> model/sl-model.bin: the product
+    loop (HipTrainer steps, test pass on the HIP inference network) reaches the test loss of the torch-autograd
+    restatement of the reference's loop (oracle/train_ref.py: hipGraph'd MIOpen / ATen steps, module forward in eval mode)."""
     state, batches = make_case()
     os.makedirs(tmp_path / "data")
     for c in range(5):                       # 4 training chunks, 1 test chunk
@@ -288,20 +289,41 @@ def test_sl_trainer_files(tmp_path, monkeypatch):
         np.savez_compressed(tmp_path / "data" / f"sl_data_{c}.npz", input=planes, policy=pol,
                             value=rng.randint(0, 3, 64).astype(np.int32), kifu_count=4)
     monkeypatch.setattr(learn, "LEARNING_SCHEDULE", {"learning_rate": {0: 0.001}})
+    monkeypatch.setattr(train_ref, "LEARNING_SCHEDULE", {"learning_rate": {0: 0.001}})
     results = {}
-    for leg, eager in (("graph", "0"), ("eager", "1")):
+    for leg, run in (("hip", learn.train_on_gpu), ("reference", train_ref.train_on_gpu_reference)):
         work = tmp_path / leg
         os.makedirs(work)
         monkeypatch.chdir(work)
-        monkeypatch.setenv("TG_TRAIN_EAGER", eager)
-        torch.manual_seed(5)
+        torch.manual_seed(5)                 # (both legs start from the same random table)
         np.random.seed(5)
-        test_loss = learn.train_on_gpu(str(tmp_path), 9, 32, 2)
+        test_loss = run(str(tmp_path), 9, 32, 2)
         saved = torch.load(work / "model" / "sl-model.bin", map_location="cpu")
         assert int(saved["bn_layer.num_batches_tracked"]) == 2 * 4 * 2
         results[leg] = (test_loss, saved)
     # sixteen steps apart the two legs are separate fp32 trajectories (see TOL): compare the
     # test-set losses they reach, not parameters
     for k in ("loss", "policy", "value"):
-        g, e = results["graph"][0][k], results["eager"][0][k]
-        assert np.isfinite(g) and np.isfinite(e) and abs(g - e) < 0.02 * abs(e)
+        g, e = results["hip"][0][k], results["reference"][0][k]
+        assert np.isfinite(g) and np.isfinite(e) and abs(g - e) < 0.02 * abs(e), (k, g, e)
+
+
+@pytest.mark.gpu
+def test_other_board_sizes_are_refused_not_handed_to_a_library(tmp_path):
+    """One backend: the package has no torch-autograd step to fall back to - a size train.hip is not built for raises."""
+    with pytest.raises(ValueError, match="9x9"):
+        learn.HipTrainer(torch.device("cuda", 0), 19, 32)
+    os.makedirs(tmp_path / "data")
+    with pytest.raises(ValueError, match="9x9"):
+        learn.train_with_gumbel_alphazero_on_gpu(str(tmp_path), 19, 32)
+
+
+def test_the_package_has_one_training_backend():
+    """CPU check of the same: nothing under tamago_amd/ builds an autograd graph or imports the checker."""
+    import re
+    pkg = os.path.join(ROOT, "tamago_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"\.backward\(|optimizer\.step\(|enable_grad|CUDAGraph|^\s*(from|import) oracle", text, re.M), os.path.join(dirpath, f)

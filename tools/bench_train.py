@@ -9,6 +9,7 @@ import torch
 
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from tamago_amd.nn import learn  # noqa: E402
+from oracle import train_ref  # noqa: E402   (torch-autograd comparison legs)
 
 dev = torch.device("cuda", 0)
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 9
@@ -31,22 +32,22 @@ for batch in batches:
         dh = (time.time() - t0) / 30
         print(f"train step 9x9 batch {batch}: HIP kernels (tg_trainer_step) {dh * 1e3:.2f} ms -> {batch / dh:,.0f} positions/s")
         continue
-    net = learn.TrainableDualNet(dev, size)
+    net = train_ref.TrainableDualNet(dev, size)
     opt = learn.make_optimizer(net, 0.01)
     rng = np.random.RandomState(1)
     planes = torch.from_numpy((rng.uniform(size=(batch, 6, size, size)) < 0.3).astype(np.float32)).to(dev)
     pol = torch.softmax(torch.randn(batch, size * size + 1, device=dev), 1)
     val = torch.randint(0, 3, (batch,), device=dev)
     for _ in range(5):
-        learn.rl_train_step(net, opt, planes, pol, val)
+        train_ref.rl_train_step(net, opt, planes, pol, val)
     torch.cuda.synchronize()
     n = 30
     t0 = time.time()
     for _ in range(n):
-        learn.rl_train_step(net, opt, planes, pol, val)
+        train_ref.rl_train_step(net, opt, planes, pol, val)
     torch.cuda.synchronize()
     dt = (time.time() - t0) / n
-    run = learn.GraphedStep(net, opt, batch, "rl")
+    run = train_ref.GraphedStep(net, opt, batch, "rl")
     for _ in range(3):
         run(planes, pol, val)
     torch.cuda.synchronize()

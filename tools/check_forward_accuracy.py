@@ -8,7 +8,7 @@ from tests.helpers import load_npz
 from oracle.net import OracleNet, make_state_dict
 from tamago_amd.nn.network.dual_net import DualNet
 fix = load_npz("net_s9.npz")
-for algo in ("wino", "direct", "split16", "w2"):
+for algo in ("wino", "direct", "split16", "w1d"):
     os.environ["TG_FWD_ALGO"] = algo
     for seed in (0, 7):
         sd = make_state_dict(9, seed, float(fix[f"w{seed}_gain"]))
