@@ -135,6 +135,57 @@ __device__ __forceinline__ void w1_request(i32x4v (&ua)[4][2][2][4], const unsig
     else if constexpr (ct == 2) asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=a"(ua[SLOT][kc][p][2]) : "v"(wlane), "s"(base) : "memory");
     else asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=a"(ua[SLOT][kc][p][3]) : "v"(wlane), "s"(base) : "memory");
 }
+// ... the same fragment into a VGPR destination (the three-board variant keeps tap 2 / k-chunk 1 of odd layers there)
+template <int F>
+__device__ __forceinline__ void w1_request_v(i32x4v &dst, const unsigned char *tapbase, int wlane, std::integral_constant<int, F>) {
+    constexpr int kc = F >> 3, p = (F >> 2) & 1, ct = F & 3;
+    const unsigned char *base = tapbase + kc * 8192 + p * 4096;
+    if constexpr (ct == 0) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(wlane), "s"(base) : "memory");
+    else if constexpr (ct == 1) asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(dst) : "v"(wlane), "s"(base) : "memory");
+    else if constexpr (ct == 2) asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(dst) : "v"(wlane), "s"(base) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=v"(dst) : "v"(wlane), "s"(base) : "memory");
+}
+
+// Request schedule of the three-board variant (round 5).  A wave's 48 fragments of a layer are 48 KB; four waves' requests
+// pass through the CU's vector L1 at 64 B per clock, i.e. 16 clocks - one MFMA - per request and wave.  Round 4 issued 32 of
+// the 48 inside row 8 (768 clocks of MFMAs, 2 048 of L1): row 8 took 2 200 - 2 700 ticks, row 0 and row 1 waited for what
+// was still in flight.  A fragment can only be requested once its register is free, so the schedule follows the uses:
+//   kind 0: tap 1 of the next layer -> the spare slot S1N (free all layer): rows 1 - 6, 3 / 3 / 3 / 3 / 2 / 2
+//   kind 1: tap 2, k-chunk 1 of the next layer -> its OTHER buffer (ua[2][1] for even layers, the VGPR fragments ux for odd
+//           ones: double-buffered since round 5, 32 VGPRs): rows 5 - 6, in the order the next layer's row 0 uses them
+//   kind 2: tap 2, k-chunk 0 of the next layer -> ua[2][0], freed by row 7's last MFMAs: row 7 from slice 53, row 8's first
+//   kind 3: tap 0 of the next layer -> ua[0], freed by row 8's first 24 MFMAs: row 8 from slice 13 (12 fragments)
+//   kind 4: tap 0 / k-chunk 1 / high pieces of THIS layer (the four fragments row 8 of the previous layer freed last): row 0
+// -> -1, or 16 kind + fragment (8 kc + 4 piece + ct).  Issue order = wait order (w1_wait_* below).
+constexpr int w1_sched(int y, int m) {
+    if (y >= 1 && y <= 4 && (m == 46 || m == 52 || m == 58)) return 3 * (y - 1) + (m - 46) / 6;
+    if ((y == 5 || y == 6) && (m == 46 || m == 52)) return 12 + 2 * (y - 5) + (m - 46) / 6;
+    if ((y == 5 || y == 6) && (m == 49 || m == 55 || m == 61 || m == 67)) {
+        const int i = 4 * (y - 5) + (m - 49) / 6;              // 0 .. 3: low pieces (used first), 4 .. 7: high pieces
+        return 16 + (i < 4 ? 12 + i : 8 + (i - 4));
+    }
+    if (y == 7 && m >= 53 && m <= 69 && (m - 53) % 4 == 0) { const int i = (m - 53) / 4; return 32 + (i < 4 ? 4 + i : 0); }
+    if (y == 8 && (m == 1 || m == 5 || m == 9)) return 32 + 1 + (m - 1) / 4;
+    if (y == 8 && m >= 13 && m <= 46 && (m - 13) % 3 == 0) {
+        const int i = (m - 13) / 3;                            // 0 .. 11: (kc 0, low), (kc 0, high), (kc 1, low)
+        return 48 + (i < 4 ? 4 + i : (i < 8 ? i - 4 : 12 + (i - 8)));
+    }
+    if (y == 0 && (m == 1 || m == 4 || m == 7 || m == 10)) return 64 + 8 + (m - 1) / 3;
+    return -1;
+}
+// Requests behind the last one a wait is for (in issue order): the layer top needs tap 1 (last: row 6, slice 52), row 0's
+// slice 24 needs tap 2 (last: row 8, slice 9), row 1 needs tap 0 (last: row 0, slice 10: nothing behind it)
+constexpr int w1_count_from(int y0, int m0) {                  // scheduled requests strictly behind (y0, m0), up to the end of row 8
+    int n = 0;
+    for (int y = y0; y <= 8; ++y)
+        for (int m = (y == y0 ? m0 + 1 : 0); m < 72; ++m)
+            if (y != 0 && w1_sched(y, m) >= 0) ++n;
+    return n;
+}
+constexpr int kW1WaitTop = w1_count_from(6, 52);               // 23: tap 1 has arrived
+constexpr int kW1WaitTap2 = w1_count_from(8, 9) + 2 + 4;       // 18: + the layer's shift and scale, + row 0's four requests
+static_assert(kW1WaitTop == 23 && kW1WaitTap2 == 18, "request schedule and wait counts");
+
 template <int SLOT>
 __device__ __forceinline__ void w1_request_tap(i32x4v (&ua)[4][2][2][4], const unsigned char *tapbase, int wlane) {
     static_for<16>([&](auto F_) { w1_request<SLOT>(ua, tapbase, wlane, F_); });
@@ -362,9 +413,12 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
     {
         const unsigned char *w0 = net.w1_w + (size_t)wave * 49152;
         w1_request_tap<1>(ua, w0 + 16384, wlane);
-        if constexpr (G == 3) {                                  // (the order the first layer waits for them in)
-            w1_request_tap<2>(ua, w0 + 2 * 16384, wlane);
-            w1_request_tap<0>(ua, w0, wlane);
+        if constexpr (G == 3) {
+            // (the order the first layer waits for them in - that of the steady-state schedule w1_sched: tap 2 with k-chunk 1
+            // first, tap 0 without the four fragments row 0 of every layer requests itself)
+            static_for<8>([&](auto I_) { constexpr int i = decltype(I_)::value; w1_request<2>(ua, w0 + 2 * 16384, wlane, std::integral_constant<int, (i < 4 ? 12 + i : 8 + (i - 4))>{}); });
+            static_for<8>([&](auto I_) { constexpr int i = decltype(I_)::value; w1_request<2>(ua, w0 + 2 * 16384, wlane, std::integral_constant<int, (i < 4 ? 4 + i : i - 4)>{}); });
+            static_for<12>([&](auto I_) { constexpr int i = decltype(I_)::value; w1_request<0>(ua, w0, wlane, std::integral_constant<int, (i < 4 ? 4 + i : (i < 8 ? i - 4 : 12 + (i - 8)))>{}); });
         } else {
             w1_request_tap<0>(ua, w0, wlane);
             w1_request_tap<2>(ua, w0 + 2 * 16384, wlane);
@@ -747,6 +801,7 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
             f32x4 ez[4], eres[2], ev[2];
             float tvv[4];
             unsigned thh[2];
+            i32x4v ux[2][4];                                       // tap 2 / k-chunk 1 of ODD layers, [piece][ct] (even layers: ua[2][1]; see w1_sched)
             auto vslot = [](int r) constexpr { return r == 0 ? 4 : (r & 3); };
             auto rd = [&](auto IN_, auto I_) __attribute__((always_inline)) {          // one of the eight cell reads of the row at curA / curB
                 constexpr int IN = decltype(IN_)::value, i = decltype(I_)::value, cb = i >> 2, kc = (i >> 1) & 1, h = i & 1;
@@ -789,8 +844,7 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
                 constexpr int S1 = PAR ? 3 : 1, S1N = PAR ? 1 : 3; // AGPR slot of tap ky = 1 in this / the next layer (taps 0, 2: slots 0, 2)
                 const int next_layer = layer + 1 < kTowerLayers ? layer + 1 : 0;
                 const unsigned char *wnext = net.w1_w + ((size_t)next_layer * 4 + wave) * 49152;
-                const f32x4 shf = *reinterpret_cast<const f32x4 *>(net.w1_shift + layer * 64 + wave * 16 + glg * 4);
-                const float down = net.w1_down[layer];
+                const unsigned char *wcur = net.w1_w + ((size_t)layer * 4 + wave) * 49152;
                 int exw = C::EX_OFF + wave * 4096 + glane * 16, exr = C::EX_OFF + wave * 1024 + glane * 16;
                 asm volatile("" : "+v"(exw), "+v"(exr));
                 if (layer == 0) {
@@ -802,9 +856,19 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
                     static_for<16>([&](auto I_) { tr(std::integral_constant<int, 1>{}, I_); });
                     static_for<8>([&](auto I_) { rd(IN_, I_); });
                 }
-                // this layer's taps 1 and 2 must have arrived (requested in that order; behind them: tap 0's 16 requests, the shift)
-                asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+                // this layer's tap 1 must have arrived (behind its last request: the 23 of rows 6 - 8, w1_sched)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kW1WaitTop) : "memory");
                 __builtin_amdgcn_sched_barrier(0);                 // (an MFMA is no memory operation: nothing else keeps it behind the wait)
+                // shift and scale of this layer: requested HERE (two vector loads the wait counts below include), first used
+                // by row 0's epilogue of row 1, i.e. behind the vmcnt(0) at the top of row 1
+                const f32x4 shf = *reinterpret_cast<const f32x4 *>(net.w1_shift + layer * 64 + wave * 16 + glg * 4);
+                float down;
+                {
+                    const float *dp = net.w1_down + layer;
+                    int zoff = 0;
+                    asm volatile("" : "+v"(zoff));                 // a VECTOR load whatever hipcc proves about the address: the count must not depend on it
+                    asm volatile("global_load_dword %0, %1, %2" : "=v"(down) : "v"(zoff), "s"(dp) : "memory");
+                }
                 // exchange + epilogue of a row: PREV = row 8 of the previous layer (output buffer = this layer's input, the other
                 // residual flag, constants pshf / pdown, cells at row 8), else row Y of this layer (cells at curO / curR)
                 auto epi = [&](auto PREV_, auto Y_, auto I_) __attribute__((always_inline)) {
@@ -853,20 +917,25 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
                     if constexpr (PROF)
                         if (blockIdx.x == 0 && wave == 0 && glane == 0 && (layer == 2 || layer == 3) && grp == (int)blockIdx.x)
                             net.timeline[40 + 12 * (layer - 2) + y] = (long long)__builtin_amdgcn_s_memtime();
-                    // tap 0; behind it the layer's shift and scale (requested at the layer top, 48 MFMAs ago: hipcc waits for them
-                    // where the epilogue first uses them, 19 slices on)
+                    // tap 0 - its last four fragments were requested in row 0 - and with it the layer's shift and scale
                     if constexpr (y == 1) {
-                        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     if constexpr (y == 6) { curA -= 9 * strA; curB -= 9 * strB; }              // from here on: the next layer's rows 0 .. 2
                     static_for<NM>([&](auto M_) {
                         constexpr int m = decltype(M_)::value, ti = m / 24, q = m % 24, kc = q / 12, st = (q / 4) % 3, c = q % 4;
                         constexpr int ky = KY0 + ti, r = y + ky - 1, s = vslot(r), slot = ky == 1 ? S1 : ky;
+                        constexpr bool UX = PAR == 1 && ky == 2 && kc == 1;      // odd layers: tap 2 / k-chunk 1 from the VGPR fragments
+                        // tap 2 (row 0: the second tap): its last request was row 8's slice 9 of the previous layer
+                        if constexpr (y == 0 && m == 24) {
+                            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kW1WaitTap2) : "memory");
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                         if constexpr (st == 0)
-                            acc[par][c] = mfma16<F>(ua[slot][kc][1][c], vh[s][kc], m < 4 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[par][c]);
-                        else if constexpr (st == 1) acc[par][c] = mfma16<F>(ua[slot][kc][0][c], vl[s][kc], acc[par][c]);
-                        else acc[par][c] = mfma16<F>(ua[slot][kc][0][c], vh[s][kc], acc[par][c]);
+                            acc[par][c] = mfma16<F>(UX ? ux[1][c] : ua[slot][kc][1][c], vh[s][kc], m < 4 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[par][c]);
+                        else if constexpr (st == 1) acc[par][c] = mfma16<F>(UX ? ux[0][c] : ua[slot][kc][0][c], vl[s][kc], acc[par][c]);
+                        else acc[par][c] = mfma16<F>(UX ? ux[0][c] : ua[slot][kc][0][c], vh[s][kc], acc[par][c]);
                         // ---- what rides along ----
                         if constexpr (m < 37) {
                             if constexpr (y == 0) epi(std::true_type{}, Y_, M_);
@@ -880,15 +949,21 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
                             if constexpr (y + 3 <= 8) rd(IN_, std::integral_constant<int, m - 37>{});
                             else rd(OUT_, std::integral_constant<int, m - 37>{});                // rows 6 .. 8: the next layer's rows 0 .. 2
                         }
-                        // next layer's weights: tap 1 into the spare slot during rows 4 .. 6, tap 2 at the start of row 8 (its last use
-                        // was row 7), tap 0 behind row 8's tap-0 MFMAs
-                        if constexpr (y >= 4 && y <= 6 && m >= 46 && m < 64 && (m - 46) % 3 == 0) {
-                            constexpr int f = (y - 4) * 6 + (m - 46) / 3;                      // 0 .. 17
-                            if constexpr (f < 16) w1_request<S1N>(ua, wnext + 16384, wlane, std::integral_constant<int, f>{});
+                        // weight requests (w1_sched): each behind the last use of the register it goes to
+                        {
+                            constexpr int code = w1_sched(y, m), kind = code >> 4;
+                            using FR = std::integral_constant<int, (code & 15)>;
+                            if constexpr (code >= 0) {
+                                if constexpr (kind == 0) w1_request<S1N>(ua, wnext + 16384, wlane, FR{});
+                                else if constexpr (kind == 1) {
+                                    // (the next layer is odd when this one is even: its tap 2 / k-chunk 1 goes to the VGPR fragments)
+                                    if constexpr (PAR == 0) w1_request_v(ux[(FR::value >> 2) & 1][FR::value & 3], wnext + 2 * 16384, wlane, FR{});
+                                    else w1_request<2>(ua, wnext + 2 * 16384, wlane, FR{});
+                                } else if constexpr (kind == 2) w1_request<2>(ua, wnext + 2 * 16384, wlane, FR{});
+                                else if constexpr (kind == 3) w1_request<0>(ua, wnext, wlane, FR{});
+                                else w1_request<0>(ua, wcur, wlane, FR{});
+                            }
                         }
-                        if constexpr (y == 8 && m < 32 && m % 2 == 1)
-                            w1_request<2>(ua, wnext + 2 * 16384, wlane, std::integral_constant<int, m / 2>{});
-                        if constexpr (y == 8 && m >= 32) w1_request<0>(ua, wnext, wlane, std::integral_constant<int, m - 32>{});
                         __builtin_amdgcn_sched_barrier(0);
                     });
                 });
