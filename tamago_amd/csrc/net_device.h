@@ -235,6 +235,9 @@ struct tg_net {
     std::mutex scratch_mu;
     std::map<hipStream_t, float *> scratch_by_stream;
     std::map<hipStream_t, int *> flag_by_stream;      // f16 split kernel: range flag per launch stream
+    // 19x19 one-axis Winograd kernel (net_forward_w1dband.hip): per stream the pairs' exchange rows + the feature image
+    struct WbScratch { float *mem = nullptr; int cap = 0; };
+    std::map<hipStream_t, WbScratch> wb_by_stream;
     // banded 19x19 kernel: its launches follow each other even across streams (two of them half-resident on the device would
     // hold each other's missing bands off the CUs until the bounded waits give up) - the last launch's completion event
     hipEvent_t band_done = nullptr;

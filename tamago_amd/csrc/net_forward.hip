@@ -34,6 +34,9 @@ int heads_prepare(tg_net *net, const float *hp_w, const float *hv_w, const float
 int w1d_prepare(tg_net *net, const float *const *tower, const float *scale, const float *shift);
 int w1d_forward(tg_net *net, int group, const float *planes, int batch, int want_logits, float *policy, float *value, int *overflow,
                 hipStream_t stream);
+// net_forward_w1dband.hip: 19x19, one-axis Winograd tower, a board over two workgroups + the batched heads kernel
+int w1dband_forward(tg_net *net, const float *planes, int batch, int want_logits, float *policy, float *value, int *overflow,
+                    hipStream_t stream);
 // net_forward_band.hip: a 19x19 board spread over 2 / 4 workgroups (small launches)
 int band_count(const tg_net *net, int batch);
 int band_forward(tg_net *net, int bands, const float *planes, int batch, int want_logits, float *policy, float *value,
@@ -847,6 +850,7 @@ int tg_net_destroy(tg_net *net) {
     for (void *p : net->allocs) (void)hipFree(p);
     for (auto &kv : net->scratch_by_stream) (void)hipFree(kv.second);
     for (auto &kv : net->flag_by_stream) (void)hipFree(kv.second);
+    for (auto &kv : net->wb_by_stream) if (kv.second.mem) (void)hipFree(kv.second.mem);
     if (net->band_done) (void)hipEventDestroy(net->band_done);
     if (net->band_timeouts_host) (void)hipHostFree(const_cast<unsigned int *>(net->band_timeouts_host));
     if (net->st_planes) (void)hipFree(net->st_planes);
@@ -876,7 +880,17 @@ static int pick_wino(int board_size, int batch, int num_cus);
 // two-waves-per-SIMD kernels of rounds 3 / 4 were measured slower and live, unbuilt, under tools/experiments/kernels/.)
 static bool pick_split() {
     const char *env = getenv("TG_FWD_ALGO");
-    return !env || !strcmp(env, "split16") || !strcmp(env, "w1d");
+    return !env || !strcmp(env, "split16") || !strcmp(env, "w1d") || !strcmp(env, "w1dband");
+}
+// 19x19: the one-axis Winograd tower over two workgroups per board (net_forward_w1dband.hip).  Needs both workgroups of a pair
+// resident: not on a device shared with other processes, not while a self-play move's sub-group streams hold CUs back.
+static bool pick_w1dband(const tg_net *net) {
+    if (net->board_size != 19) return false;
+    const char *env = getenv("TG_FWD_ALGO");
+    if (env) return !strcmp(env, "w1dband");
+    if (net->shared_device || net->forward_grid_cap.load() > 0 || net->guard_grid_cap.load() > 0) return false;
+    if (net->band_timeouts_host && *net->band_timeouts_host > 0) return false;
+    return getenv("TG_FWD_W1DBAND") != nullptr;            // (opt-in until it has been measured)
 }
 static bool pick_w1d(int board_size, int /*batch*/, int /*num_cus*/) {
     if (board_size != 9) return false;
@@ -905,6 +919,7 @@ const char *tg_net_kernel_name(const tg_net *net, int batch) {
         return "dualnet_fwd_split_kernel<9, 3, f16x2> + dualnet_fwd_split_kernel<9, 1, f16x2> (ragged tail)";
     }
     if (net->board_size == 19) {
+        if (pick_w1dband(net)) return "dualnet_fwd_w1dband_kernel + dualnet_heads19_kernel";
         if (pick_split()) {
             const int nb = tg::band_count(net, batch);
             return nb == 4 ? "dualnet_fwd_band_kernel<4>" : (nb == 2 ? "dualnet_fwd_band_kernel<2>" : "dualnet_fwd_split_kernel<19, 1, f16x2>");
@@ -934,7 +949,12 @@ double tg_net_executed_flops_per_position(const tg_net *net, int batch, double *
     double peak = 157.3;
     const char *name = "f32";
     double flops = 0.0;
-    if (pick_w1d(S, batch, net->num_cus)) {
+    if (S == 19 && pick_w1dband(net)) {
+        // per board and layer: band 0 = 6 stages x 72 + 48 MFMAs per wave, band 1 = 6 x 72; stem: 2 x 16 row tiles x 4 x 2 x 3
+        flops = (12.0 * 4 * (480 + 432) + 2.0 * 16 * 4 * 2 * 3) * 16384.0;
+        peak = 2500.0;
+        name = "f16 (2 operand pieces, Winograd F(2,3) along x, fp32 accumulate)";
+    } else if (pick_w1d(S, batch, net->num_cus)) {
         // per workgroup pass: stem as below + 12 layers x 4 waves x (three boards: 25 (row, tap) pairs | one board: 3 row tiles x 3
         // taps) x 4 channel tiles x 2 k-chunks x 3 products
         const int g = batch > net->num_cus ? 3 : 1;
@@ -1002,6 +1022,12 @@ int tg_net_forward_dev(tg_net *net, const float *planes_dev, int batch, int want
                 // [range flag, group tickets, sequence numbers of the banded kernel: exchange + gather, one per workgroup each]
                 if (!slot) TG_HIP(hipMalloc(reinterpret_cast<void **>(&slot), (2 + kBandFlagInts) * sizeof(int)));
                 flag = slot;
+            }
+            if (pick_w1dband(net)) {
+                TG_HIP(hipMemsetAsync(flag, 0, 2 * sizeof(int), st));
+                int rc = tg::w1dband_forward(net, planes_dev, batch, want_logits, policy_dev, value_dev, flag, st);
+                if (rc) return rc;
+                return launch_wino8<19, 1, true>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st, flag);
             }
             const int bands = tg::band_count(net, batch);
             TG_HIP(hipMemsetAsync(flag, 0, (bands ? 2 + kBandFlagInts : 2) * sizeof(int), st));
