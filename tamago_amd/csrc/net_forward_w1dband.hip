@@ -49,7 +49,9 @@ struct WbCfg {
     static constexpr int HW_OFF = EX_OFF + EX_BYTES;       // head 1x1 weights [64][4] (policy 0, policy 1, value, 0)
     static constexpr int HS_OFF = HW_OFF + 64 * 4 * 4;     // head batch norm: scale / shift x 3
     static constexpr int MISC = HS_OFF + 32;               // [0] the partner did not show up
-    static constexpr int LDS_BYTES = MISC + 16;
+    static constexpr int SH_OFF = MISC + 16;               // the tower's folded shifts [12][64] + 2^-e [12] (+ padding)
+    static constexpr int PROF_OFF = SH_OFF + 12 * 64 * 4 + 64;   // 32 s_memtime stamps (profiling builds)
+    static constexpr int LDS_BYTES = PROF_OFF + 512;
     // stem overlay (over H and the exchange): im2col'ed input of the band's cells as f16-pair images + the board's planes
     static constexpr int MT = (CELLS + 15) / 16;           // 14 row tiles
     static constexpr int RTW = (MT + NW - 1) / NW;         // 4 per wave
@@ -78,7 +80,7 @@ __host__ __device__ inline int wb_swz(int l, int x) {
 // What rides along the MFMAs of the stages of a layer (n = 0 .. 6: S, 2A, 2B, 1A, 1B, 0A, 0B).
 struct WbStage {
     int k, h;            // step (3: row 9's stage), half
-    int ord;             // tap order: 0 = (-1, 0, +1), 1 = (+1, 0, -1)
+    int ord;             // tap order: 0 = (-1, 0, +1), 1 = (+1, 0, -1), 2 = (0, +1, -1)
     // transform jobs: code = 100 + 10 * (s + 1) + half for V_half[s] of the regular mapping (s = -1 .. 3), 200 + r for row r = 8 / 9 of
     // row 9's mapping; + 1000 when the source is this layer's OUTPUT (a V row of the next layer); 0 = none
     int early, after, late;
@@ -87,49 +89,68 @@ constexpr WbStage wb_stage(int n) {
     switch (n) {
     case 0: return {3, 0, 0, 100 + 30 + 0, 100 + 20 + 0, 0};                         // S:  V_A[2], V_A[1]
     case 1: return {2, 0, 0, 100 + 20 + 1, 100 + 40 + 0, 100 + 30 + 1};              // 2A: V_B[1], V_A[3] (rows 3 / 6: stored by S, behind the barrier), V_B[2]
-    case 2: return {2, 1, 0, 0, 100 + 40 + 1, 100 + 10 + 0};                         // 2B: V_B[3], V_A[0]
-    case 3: return {1, 0, 0, 0, 0, 100 + 10 + 1};                                    // 1A: V_B[0]
+    case 2: return {2, 1, 0, 0, 100 + 40 + 1, 0};                                    // 2B: V_B[3]
+    case 3: return {1, 0, 1, 0, 100 + 10 + 0, 100 + 10 + 1};                         // 1A: V_A[0] (used last: taps +1, 0, -1), V_B[0]
     case 4: return {1, 1, 0, 0, 0, 0};                                               // 1B: (the halo copy)
     case 5: return {0, 0, 1, 0, 100 + 0 + 0, 1200 + 8};                              // 0A: V_A[-1] (the halo row: behind the barrier), the next layer's row 8
-    default: return {0, 1, 1, 0, 100 + 0 + 1, 1200 + 9};                             // 0B: V_B[-1], the next layer's row 9
+    default: return {0, 1, 2, 0, 100 + 0 + 1, 1200 + 9};                             // 0B: V_B[-1], the next layer's row 9 (tap 0 first: its fragments are the next to be needed)
     }
 }
-// Every job writes a slot whose previous row has seen its last MFMA, and reads rows a barrier has published:
-//   * slot (s + 1) mod 3 of a half: V[2] replaces V[-1] (last used 0x, slices 48-71), V[3] the row-9 stage's row (S), V[0]
-//     replaces V[3] (2x, 48-71), V[-1] replaces V[2] (1x, 48-71), the row-9 rows replace V[0] (0x, 24-47), V[1] itself (0x, 0-23);
-//   * a layer's input rows 0 / 3 / 6 are its predecessor's last outputs (0A -> stored under 0B, 0B -> stored under S): jobs that
-//     read them (V[0] of classes 1 / 2, V[3] of classes 0 / 1) start behind 2A's barrier; row 9 is stored under 2A.
+// FIVE register slots (16 registers each: two k-chunks of f16 high / low pieces) hold the V rows of both halves and of row 9's
+// stage; a row is written where the row before it in that slot has seen its last MFMA (slices of the stages in brackets):
+//   P0: row 8 [S 0-23] -> V_A[3] (2A behind the barrier) [2A 48-71] -> V_B[3] (2B) [2B 48-71] -> V_A[0] (1A) [1A 48-71, 0A 24-47] -> row 8 (0A late)
+//   P1: row 9 [S 24-47] -> V_B[2] (2A late) [2B, 1B] -> V_A[-1] (0A) [0A 48-71] -> row 9 (0B late)
+//   P2: V_A[2] (S early) [2A, 1A 0-23] -> V_B[0] (1A late) [1B, 0B 0-23] -> V_A[2] ...
+//   P3: V_A[1] (S behind its barrier) [2A, 1A, 0A 0-23] -> V_B[-1] (0B) [0B 48-71] -> V_A[1] ...
+//   P4: V_B[1] (2A early) [2B, 1B, 0B 24-47] -> V_B[1] ...
+// and every job reads rows a barrier has published: a layer's input rows 0 / 3 / 6 are its predecessor's last outputs (0A ->
+// stored under 0B, 0B -> stored under S): the jobs that read them (V[0], V[3]) start behind 2A's barrier; row 9 is stored under 2A.
+constexpr int wb_slot(int job) {                           // job code (without the + 1000 source flag) -> slot
+    const int j = job % 1000;
+    if (j >= 200) return j - 208;                          // rows 8, 9 -> P0, P1
+    const int sr = (j - 100) / 10 - 1, h = (j - 100) % 10;
+    constexpr int A[5] = {1, 0, 3, 2, 0}, B[5] = {3, 2, 4, 1, 0};
+    return h == 0 ? A[sr + 1] : B[sr + 1];
+}
 
-// Weight requests (next layer's unless noted), code = 16 kind + fragment:
-//   kind 0: tap -1 -> the spare slot (double-buffered by layer parity), four a stage in 2B .. 0A
-//   kind 1: tap 0, behind its last uses in 0B (taps in the order +1, 0, -1 there)
-//   kind 2: tap +1, free since 0B's slice 24: four in 0B, twelve in the next layer's S (THIS layer's fragments there)
+// Weight requests, code = 16 kind + fragment (8 kc + 4 piece + ct).  A wave's request is 1 KB; the CU's vector L1 passes 64 B a
+// clock, so four waves asking more often than every fourth slice (one MFMA = 16 clocks) fill the request queue and the
+// MFMAs behind it wait (first version: twenty requests in 0B at every second slice - 0B took 2.5 x a stage).
+//   kind 0: tap -1 of the NEXT layer -> the spare slot (double-buffered by layer parity), four a stage in 2B .. 0A
+//   kind 1: tap 0 of the next layer, behind its last uses in 0B (taps in the order 0, +1, -1 there: free from slice 24; first
+//           used at S's slice 24 - sixteen requests take the L1 1 024 clocks)
+//   kind 2: tap +1 of THIS layer (free since the previous layer's 0B, first used at 2A's slice 48): twelve in S, four in 2A
+constexpr int kWbTap0Order[16] = {4, 5, 6, 7, 0, 1, 2, 3, 12, 13, 14, 15, 8, 9, 10, 11};
+constexpr int kWbTap0Slice0B[16] = {25, 28, 31, 34, 37, 40, 43, 46, 49, 52, 55, 58, 61, 64, 67, 70};
 constexpr int wb_wreq(int n, int m) {
     if (n >= 2 && n <= 5 && (m == 50 || m == 56 || m == 62 || m == 68)) return 4 * (n - 2) + (m - 50) / 6;
-    if (n == 6 && m >= 30 && m <= 60 && m % 2 == 0) {
-        const int i = (m - 30) / 2;                        // (kc 0, low), (kc 0, high), (kc 1, low), (kc 1, high)
-        return 16 + (i < 4 ? 4 + i : (i < 8 ? i - 4 : (i < 12 ? 12 + (i - 8) : 8 + (i - 12))));
-    }
-    if (n == 6 && (m == 62 || m == 65 || m == 68 || m == 71)) return 32 + 4 + (m - 62) / 3;
-    if (n == 0 && m >= 1 && m <= 45 && (m - 1) % 4 == 0) {
-        const int i = (m - 1) / 4;                         // 0 .. 11: (kc 0, high), (kc 1, low), (kc 1, high)
-        return 32 + (i < 4 ? i : (i < 8 ? 12 + (i - 4) : 8 + (i - 8)));
-    }
+    if (n == 6)
+        for (int i = 0; i < 16; ++i)
+            if (m == kWbTap0Slice0B[i]) return 16 + kWbTap0Order[i];
+    if (n == 0 && m >= 1 && m <= 34 && (m - 1) % 3 == 0) return 32 + kWbTap0Order[(m - 1) / 3];
+    if (n == 1 && m >= 1 && m <= 10 && (m - 1) % 3 == 0) return 32 + kWbTap0Order[12 + (m - 1) / 3];
     return -1;
 }
-constexpr int wb_count(int n0, int m0, int n1, int m1) {   // requests strictly behind (n0, m0) up to and including (n1, m1 - 1) of the NEXT pass through the stages
+constexpr int wb_count(int n0, int m0, int n1, int m1) {   // requests strictly behind (n0, m0) and before (n1, m1), going round the stages
     int cnt = 0;
-    for (int n = n0, first = 1;; n = (n + 1) % 7, first = 0) {
-        const int lo = first ? m0 + 1 : 0, hi = (n == n1 && !first) ? m1 : 72;
-        for (int m = lo; m < hi; ++m)
-            if (wb_wreq(n, m) >= 0) ++cnt;
-        if (n == n1 && !first) break;
+    if (n0 == n1 && m1 > m0) {
+        for (int m = m0 + 1; m < m1; ++m)
+            if (wb_wreq(n0, m) >= 0) ++cnt;
+        return cnt;
     }
+    for (int m = m0 + 1; m < 72; ++m)
+        if (wb_wreq(n0, m) >= 0) ++cnt;
+    for (int n = (n0 + 1) % 7; n != n1; n = (n + 1) % 7)
+        for (int m = 0; m < 72; ++m)
+            if (wb_wreq(n, m) >= 0) ++cnt;
+    for (int m = 0; m < m1; ++m)
+        if (wb_wreq(n1, m) >= 0) ++cnt;
     return cnt;
 }
-constexpr int kWbWaitTop = wb_count(5, 68, 0, 0);          // S, slice 0: tap -1 (last request 0A / 68) - behind it 0B's twenty
-constexpr int kWbWaitTap0 = wb_count(6, 60, 0, 24);        // S, slice 24: tap 0 (last request 0B / 60)
-static_assert(kWbWaitTop == 20 && kWbWaitTap0 == 10, "request schedule and wait counts");
+constexpr int kWbWaitTop = wb_count(5, 68, 0, 0);          // S, slice 0: tap -1 (last request 0A / 68) - behind it 0B's sixteen
+constexpr int kWbWaitTap0 = wb_count(6, 70, 0, 24);        // S, slice 24: tap 0 (last request 0B / 70) - behind it eight of tap +1
+constexpr int kWbWaitTapP = wb_count(1, 10, 1, 48);        // 2A, slice 48: tap +1 (last request 2A / 10) - nothing behind it
+static_assert(kWbWaitTop == 16 && kWbWaitTap0 == 8 && kWbWaitTapP == 0, "request schedule and wait counts");
 
 template <bool PROF>
 __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1dband_kernel(
@@ -148,6 +169,7 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1dband_kernel(
     const int pair = (int)blockIdx.x - band * n_pairs;
     const int lmax = band == 0 ? 9 : 8;                    // rows l = 0 .. lmax exist (band 1: nine rows)
     float *const pmem = xmem + (size_t)pair * C::PAIR_FLOATS;
+    // sequence numbers: one per WAVE of a band ([band][4], 64 bytes apart): a wave publishes as soon as ITS stores have landed
     int *const seq_mine = reinterpret_cast<int *>(pmem + 4 * C::XROW_FLOATS) + band * 16;
     int *const seq_theirs = reinterpret_cast<int *>(pmem + 4 * C::XROW_FLOATS) + (1 - band) * 16;
     int *const dead = reinterpret_cast<int *>(smem + C::MISC);
@@ -164,8 +186,21 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1dband_kernel(
         reinterpret_cast<float *>(smem + C::HW_OFF)[e] = c == 0 ? net.hp_w[k] : (c == 1 ? net.hp_w[64 + k] : (c == 2 ? net.hv_w[k] : 0.f));
     }
     if (tid < 6) reinterpret_cast<float *>(smem + C::HS_OFF)[tid] = net.head_ss[tid];
+    for (int e = tid; e < 12 * 64 + 12; e += NTHR)
+        reinterpret_cast<float *>(smem + C::SH_OFF)[e] = e < 12 * 64 ? net.w1_shift[e] : net.w1_down[e - 12 * 64];
     if (tid == 0) *dead = 0;
 
+    // PROF: s_memtime stamps of pair 0's first board (band 0: timeline[0 ..], band 1: timeline[64 ..]): [0] start, [1] stem done,
+    // [2 + L] layer L done, [14] head convolutions done, [16 + n] stage n of layers 2 / 3 starts ([16 .. 22], [24 .. 30]), [23] / [31] their ends
+    // (every workgroup stamps into its own LDS, wave 0 only - one s_memtime + one LDS store, no condition on registers the tower
+    // would have to keep; pair 0 copies its stamps out after its first board)
+    auto stamp = [&](int i) {
+        if constexpr (PROF)
+            if (wave == 0) {
+                const long long t = (long long)__builtin_amdgcn_s_memtime();
+                asm volatile("ds_write_b64 %0, %1" ::"v"(C::PROF_OFF + 8 * i), "v"(t) : "memory");
+            }
+    };
     int ovf = 0;
     constexpr int NPL = (6 * P + NTHR - 1) / NTHR;
     float pre[NPL];
@@ -189,15 +224,13 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1dband_kernel(
         const int wlane0 = (tid & 63) * 16;
         const unsigned char *w0 = net.w1_w + (size_t)wave * 49152;
         w1_request_tap<1>(ua, w0 + ky_m * 16384, wlane0);
-        static_for<16>([&](auto I_) {
-            constexpr int i = decltype(I_)::value;
-            w1_request<0>(ua, w0 + 16384, wlane0, std::integral_constant<int, (i < 4 ? 4 + i : (i < 8 ? i - 4 : (i < 12 ? 12 + (i - 8) : 8 + (i - 12))))>{});
-        });
-        static_for<4>([&](auto I_) { w1_request<2>(ua, w0 + ky_p * 16384, wlane0, std::integral_constant<int, 4 + decltype(I_)::value>{}); });
+        static_for<16>([&](auto I_) { w1_request<0>(ua, w0 + 16384, wlane0, std::integral_constant<int, kWbTap0Order[decltype(I_)::value]>{}); });
+        // (tap +1: the layer's own stages S and 2A ask for it)
     }
 
     int kiter = 0;
     for (int b = pair; b < batch; b += n_pairs, ++kiter) {
+        stamp(0);
         // ================= stem: planes -> im2col'ed f16-pair images of the band's cells (halo row included) -> X =================
         i32x4v fa[2][2][4];
         {
@@ -296,6 +329,7 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1dband_kernel(
             reinterpret_cast<float *>(smem + C::H_OFF + C::ZERO_REL)[fresh_lane()] = 0.f;
         }
         if (!(amax < (float)kWsRangeLimit)) ovf = 1;
+        stamp(1);
 
         // ================= tower =================
         {
@@ -304,119 +338,125 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1dband_kernel(
             const bool uv = gli < 15;
             const int xa0 = wave == 0 ? 2 * ut - 1 : (wave == 2 ? 2 * ut + 1 : 2 * ut);
             const int xb0 = wave == 0 ? 2 * ut + 1 : (wave == 1 ? 2 * ut + 1 : (wave == 2 ? 2 * ut : 2 * ut + 2));
-            // byte address of cell (l, x), 16-byte chunk `chunk` (before the k-chunk / half XOR), or of its class's chunk in the
-            // zero / dump row
-            auto cell = [&](int l, int x, int chunk, int invalid_rel, bool on) {
-                const bool ok = on && x >= 0 && x < S && l >= -1 && l <= lmax;
-                return (ok ? ((l + 1) * S + x) * 256 : invalid_rel) + ((chunk ^ wb_swz(l, x)) << 4);
-            };
-            // V-row reads of the regular stages: cell columns a / b of half h at row class base (s = 0); rows s = -1 and s = 3
-            // have their own addresses (another swizzle class; s = -1 of class 0 is the halo row, s = 3 of class 2 is row 9)
-            int rA[2][3], rB[2][3];                                // [half][0: s = -1, 1: s = 0 (+ s * ROWB for s = 1, 2), 2: s = 3]
+            // Per-lane addressing with few registers (the kernel is written against the whole register file): the swizzle of a
+            // cell a lane touches is always that of class g = (gli + K) mod 8 with a compile-time K (wb_swz: g = 5 floor(l / 3) +
+            // (x + 1) / 2, l = 3 c + s, x = 2 (t' + 5 half) + e) - `pk` holds the eight 4-bit XOR values of g = gli .. gli + 7.
+            unsigned pk = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int g = (gli + j) & 7;
+                pk |= (unsigned)((g & 1) | ((g & 6) << 1)) << (4 * j);
+            }
+            asm volatile("" : "+v"(pk));
+            auto swz_k = [&](int K) { return (int)((pk >> (4 * (K & 7))) & 15u); };   // K: compile-time at every use
+            // V-row reads of the regular stages: UNswizzled address of cell (3 c, xa / xb + 10 half), chunk 2 glg - or of the zero row
+            // with stride 0 (a column outside the board, lane 15); row s adds s * stride, the swizzle K = 5 fd(s) + 5 half + (e + 1) / 2
+            int uA[2], uB[2], stA[2], stB[2];
+            const int eA = wave == 0 ? -1 : (wave == 2 ? 1 : 0), eB = wave == 0 ? 1 : (wave == 1 ? 1 : (wave == 2 ? 0 : 2));
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                rA[h][0] = cell(3 * uc - 1, xa0 + 10 * h, glg * 2, C::ZERO_REL, uv);
-                rA[h][1] = cell(3 * uc, xa0 + 10 * h, glg * 2, C::ZERO_REL, uv);
-                rA[h][2] = cell(3 * uc + 3, xa0 + 10 * h, glg * 2, C::ZERO_REL, uv);
-                rB[h][0] = cell(3 * uc - 1, xb0 + 10 * h, glg * 2, C::ZERO_REL, uv);
-                rB[h][1] = cell(3 * uc, xb0 + 10 * h, glg * 2, C::ZERO_REL, uv);
-                rB[h][2] = cell(3 * uc + 3, xb0 + 10 * h, glg * 2, C::ZERO_REL, uv);
+                const int xa = xa0 + 10 * h, xb = xb0 + 10 * h;
+                const bool oka = uv && xa >= 0 && xa < S, okb = uv && xb >= 0 && xb < S;
+                uA[h] = (oka ? ((3 * uc + 1) * S + xa) * 256 : C::ZERO_REL) + (glg << 5);
+                uB[h] = (okb ? ((3 * uc + 1) * S + xb) * 256 : C::ZERO_REL) + (glg << 5);
+                stA[h] = oka ? ROWB : 0;
+                stB[h] = okb ? ROWB : 0;
             }
-            // (rows s = 1, 2 of an invalid column must not step out of the zero row)
-            int rAs[2], rBs[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const bool oka = uv && xa0 + 10 * h >= 0 && xa0 + 10 * h < S, okb = uv && xb0 + 10 * h >= 0 && xb0 + 10 * h < S;
-                rAs[h] = oka ? ROWB : 0;
-                rBs[h] = okb ? ROWB : 0;
-            }
-            // outputs of a regular stage: cells (3 c + k, 2 t) and (.., 2 t + 1), channels 16 wave + 4 glg ..: stores (outside: dump
-            // row) and residual reads (outside: zero row)
-            int oS[2][2], oR[2][2], oStr[2][2];
+            // outputs of a regular stage: cells (3 c + k, 2 t + e), channels 16 wave + 4 glg .. (swizzled: the class does not depend on
+            // k); outside the board: dump row, stride 0.  Residual reads: the same cell, or the zero row (= dump row + 256).
+            int oS[2][2], oSt[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const int x = 2 * (ut + 5 * h) + e;
-                    oS[h][e] = cell(3 * uc, x, wave * 4 + glg, C::DUMP_REL, uv);
-                    oR[h][e] = cell(3 * uc, x, wave * 4 + glg, C::ZERO_REL, uv);
-                    oStr[h][e] = (uv && x < S) ? ROWB : 0;
+                    const bool ok = uv && x < S;
+                    oS[h][e] = (ok ? ((3 * uc + 1) * S + x) * 256 : C::DUMP_REL) + (((wave * 4 + glg) ^ swz_k(5 * h + ((e + 1) >> 1))) << 4);
                 }
-            // row 9's stage: li = tile (10 .. 15: no unit)
+            oSt[0] = uv ? ROWB : 0;                                // (half 0, and e = 0 of half 1)
+            oSt[1] = (uv && 2 * (ut + 5) + 1 < S) ? ROWB : 0;      // (half 1, e = 1: x = 19 for the last tile)
+            // row 9's stage (li = tile, 10 .. 15: no unit): addresses made where they are used (three times a layer)
             const bool sv = gli < 10;
-            const int sxa = wave == 0 ? 2 * gli - 1 : (wave == 2 ? 2 * gli + 1 : 2 * gli);
-            const int sxb = wave == 0 ? 2 * gli + 1 : (wave == 1 ? 2 * gli + 1 : (wave == 2 ? 2 * gli : 2 * gli + 2));
-            int sA[2], sB[2], sO[2];
-            sA[0] = cell(8, sxa, glg * 2, C::ZERO_REL, sv);
-            sA[1] = cell(9, sxa, glg * 2, C::ZERO_REL, sv);
-            sB[0] = cell(8, sxb, glg * 2, C::ZERO_REL, sv);
-            sB[1] = cell(9, sxb, glg * 2, C::ZERO_REL, sv);
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                sO[e] = cell(9, 2 * gli + e, wave * 4 + glg, C::DUMP_REL, sv);   // (its residual: the same cell, or the zero row = dump row + 256)
-            }
             // edge row l = 0 as the PARTNER's halo row l = -1 (its LDS layout): bytes into an exchange row, or -1
+            // (class 0 lanes: gli = t', so the halo row's class is g = gli + K, K = -5 + 5 h + (e + 1) / 2; through pk: not hoisted)
             auto x_off = [&](int h, int e) {
                 const int x = 2 * (ut + 5 * h) + e;
-                return (uv && uc == 0 && x < S) ? x * 256 + (((wave * 4 + glg) ^ wb_swz(-1, x)) << 4) : -1;
+                return (uv && uc == 0 && x < S) ? x * 256 + (((wave * 4 + glg) ^ swz_k(11 + 5 * h + ((e + 1) >> 1))) << 4) : -1;
             };
 
-            f32x4 dq[2][2][2];
-            i32x4v vh[2][3][2], vl[2][3][2];                       // [half][slot (s + 1) mod 3][kc]
+            f32x4 dq[2][2];                                        // cell reads in flight: [(kc, channel half) group parity][cell a / b]
+            i32x4v vh[5][2], vl[5][2];                             // [slot (wb_slot)][kc]
             f32x4 acc[1][4];                                       // (one set: slice i stores the previous stage's acc[i] to the exchange before its MFMA restarts it)
             f32x4 ez[4], eres[2], ev[2];
             float tvv[4];
             unsigned thh[2];
-            f32x4 pshf, nshf;
-            float pdown, ndown;
-            int flag_seen = 0;
+            i32x4v flag_seen = i32x4v{0, 0, 0, 0};
             // ---- cell reads and transforms of a job ----
+            // address of cell column a / b (CB) of a job's row, chunk 2 glg (the k-chunk / channel-half bits are XORed in by rd)
             auto job_addr = [&](auto IN_, auto OUT_, auto JOB_, auto CB_) __attribute__((always_inline)) {
                 constexpr int job = decltype(JOB_)::value, j = job % 1000, cb = decltype(CB_)::value;
                 constexpr int base = job >= 1000 ? decltype(OUT_)::value : decltype(IN_)::value;
-                int a;
                 if constexpr (j >= 200) {
-                    constexpr int r = j - 200 - 8;
-                    a = cb ? sB[r] : sA[r];
+                    // row 9's mapping: cell (r, 2 li + e), class g = 5 floor(r / 3) + li + (e + 1) / 2
+                    constexpr int r = j - 200;
+                    const int e = cb ? eB : eA, x = 2 * gli + e;
+                    const bool ok = sv && x >= 0 && x < S && r <= lmax;
+                    const int K = 5 * (r / 3) + ((e + 1) >> 1);        // (e: wave-uniform, so is the shift below)
+                    return base + (ok ? ((r + 1) * S + x) * 256 : C::ZERO_REL) + (((glg * 2) ^ (int)((pk >> (4 * (K & 7))) & 15u)) << 4);
                 } else {
-                    constexpr int s = (j - 100) / 10 - 1, h = (j - 100) % 10;
-                    if constexpr (s == -1) a = cb ? rB[h][0] : rA[h][0];
-                    else if constexpr (s == 3) a = cb ? rB[h][2] : rA[h][2];
-                    else a = (cb ? rB[h][1] : rA[h][1]) + s * (cb ? rBs[h] : rAs[h]);
+                    constexpr int sr = (j - 100) / 10 - 1, h = (j - 100) % 10;
+                    constexpr int fd = sr < 0 ? -1 : sr / 3;
+                    const int e = cb ? eB : eA;
+                    const int K = 5 * fd + 5 * h + ((e + 1) >> 1) + 16;
+                    int a = (cb ? uB[h] : uA[h]) + sr * (cb ? stB[h] : stA[h]);
+                    if constexpr (sr == 3) {
+                        // row 3 c + 3 of class 2 is row 9: beyond the board for band 1
+                        if (band == 1 && uc == 2) a = C::ZERO_REL + (glg << 5);
+                    }
+                    return base + (a ^ ((int)((pk >> (4 * (K & 7))) & 15u) << 4));
                 }
-                return a + base;
             };
-            // read I (0 .. 7) of a job, in the order (a, b) x (kc 0 h 0), (kc 0 h 1), (kc 1 h 0), (kc 1 h 1)
+            // read I (0 .. 7) of a job: group (kc, channel half) = I >> 1 in the order (0, 0), (0, 1), (1, 0), (1, 1), cell a / b = I & 1
             auto rd = [&](auto IN_, auto OUT_, auto JOB_, auto I_) __attribute__((always_inline)) {
-                constexpr int i = decltype(I_)::value, cb = i & 1, kc = i >> 2, hh = (i >> 1) & 1;
+                constexpr int i = decltype(I_)::value, cb = i & 1, g = i >> 1, kc = g >> 1, hh = g & 1;
                 const int a = job_addr(IN_, OUT_, JOB_, std::integral_constant<int, cb>{});
-                dq[cb][kc][hh] = lds_f32x4_at<0>(a ^ ((kc << 7) | (hh << 4)));
+                dq[g & 1][cb] = lds_f32x4_at<0>(a ^ ((kc << 7) | (hh << 4)));
             };
             auto tr = [&](auto JOB_, auto I_) __attribute__((always_inline)) {
-                constexpr int job = decltype(JOB_)::value, j = job % 1000, i = decltype(I_)::value, kc = i >> 3, hh = (i >> 2) & 1, q = i & 3;
-                // destination: regular V_half[s] -> slot (s + 1) mod 3 of the half; row 9's stage: row 8 -> half A's slot 1, row 9 -> half B's
-                constexpr int h = j >= 200 ? (j - 200 - 8) : (j - 100) % 10;
-                constexpr int sl = j >= 200 ? 1 : (((j - 100) / 10 - 1) + 1) % 3;
+                constexpr int job = decltype(JOB_)::value, j = job % 1000, i = decltype(I_)::value, g = i >> 2, kc = g >> 1, hh = g & 1, q = i & 3;
+                constexpr int sl = wb_slot(j);
                 if constexpr (q == 0) {
-                    tvv[0] = fmaf(dq[1][kc][hh][0], sgn, dq[0][kc][hh][0]);
-                    tvv[1] = fmaf(dq[1][kc][hh][1], sgn, dq[0][kc][hh][1]);
+                    tvv[0] = fmaf(dq[g & 1][1][0], sgn, dq[g & 1][0][0]);
+                    tvv[1] = fmaf(dq[g & 1][1][1], sgn, dq[g & 1][0][1]);
                 } else if constexpr (q == 1) {
-                    tvv[2] = fmaf(dq[1][kc][hh][2], sgn, dq[0][kc][hh][2]);
-                    tvv[3] = fmaf(dq[1][kc][hh][3], sgn, dq[0][kc][hh][3]);
+                    tvv[2] = fmaf(dq[g & 1][1][2], sgn, dq[g & 1][0][2]);
+                    tvv[3] = fmaf(dq[g & 1][1][3], sgn, dq[g & 1][0][3]);
                 } else if constexpr (q == 2) {
                     thh[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{tvv[0], tvv[1]}, f16x2));
-                    vh[h][sl][kc][2 * hh] = (int)thh[0];
-                    vl[h][sl][kc][2 * hh] = (int)low_pieces(tvv[0], tvv[1], thh[0]);
+                    vh[sl][kc][2 * hh] = (int)thh[0];
+                    vl[sl][kc][2 * hh] = (int)low_pieces(tvv[0], tvv[1], thh[0]);
                 } else {
                     thh[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2v{tvv[2], tvv[3]}, f16x2));
-                    vh[h][sl][kc][2 * hh + 1] = (int)thh[1];
-                    vl[h][sl][kc][2 * hh + 1] = (int)low_pieces(tvv[2], tvv[3], thh[1]);
+                    vh[sl][kc][2 * hh + 1] = (int)thh[1];
+                    vl[sl][kc][2 * hh + 1] = (int)low_pieces(tvv[2], tvv[3], thh[1]);
+                }
+            };
+            // A job in the slices of a stage, T0 = its first slice (early 0, behind-the-barrier 24, late 48): reads of group g at
+            // T0 + {0, 2, 8, 12} (+ 1 for cell b), transform sub-steps of group g at T0 + {6, 10, 14, 18} + 0 .. 3 - a group's two
+            // registers are read again only when the group two before it has been consumed
+            auto job_slice = [&](auto IN_, auto OUT_, auto JOB_, auto T0_, auto M_) __attribute__((always_inline)) {
+                constexpr int t = decltype(M_)::value - decltype(T0_)::value;
+                if constexpr (decltype(JOB_)::value != 0 && t >= 0 && t < 22) {
+                    if constexpr (t == 0 || t == 1) rd(IN_, OUT_, JOB_, std::integral_constant<int, t>{});
+                    if constexpr (t == 2 || t == 3) rd(IN_, OUT_, JOB_, std::integral_constant<int, t>{});
+                    if constexpr (t == 8 || t == 9) rd(IN_, OUT_, JOB_, std::integral_constant<int, t - 4>{});
+                    if constexpr (t == 12 || t == 13) rd(IN_, OUT_, JOB_, std::integral_constant<int, t - 6>{});
+                    if constexpr (t >= 6) tr(JOB_, std::integral_constant<int, t - 6>{});
                 }
             };
             // a whole job at once (a group's first layer: nothing was prepared under a previous one)
             auto job_now = [&](auto IN_, auto OUT_, auto JOB_) __attribute__((always_inline)) {
-                static_for<8>([&](auto I_) { rd(IN_, OUT_, JOB_, I_); });
-                static_for<16>([&](auto I_) { tr(JOB_, I_); });
+                static_for<22>([&](auto M_) { job_slice(IN_, OUT_, JOB_, std::integral_constant<int, 0>{}, M_); });
             };
 
             // One layer.  PAR = layer parity (conv2 of a block = odd = the residual); layer instantiations alternate, so every
@@ -431,26 +471,26 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1dband_kernel(
                 const unsigned char *wcur = net.w1_w + ((size_t)layer * 4 + wave) * 49152;
                 int exw = C::EX_OFF + wave * 4096 + glane * 16, exr = C::EX_OFF + wave * 1024 + glane * 16;
                 asm volatile("" : "+v"(exw), "+v"(exr));
+                // (hipcc hoists what is invariant across the block loop - some fifty cell addresses - out of it and spills it: the
+                // values they derive from are made opaque per layer, the addresses cheap recomputations)
+                asm volatile("" : "+v"(pk), "+v"(uA[0]), "+v"(uA[1]), "+v"(uB[0]), "+v"(uB[1]));
+                asm volatile("" : "+v"(oS[0][0]), "+v"(oS[0][1]), "+v"(oS[1][0]), "+v"(oS[1][1]));
                 // sequence number of the edge row the PREVIOUS layer published (this one consumes it), and its buffer parity
                 const int pub = kiter * 11 + layer;                // number of edge rows published before this layer's
-                f32x4 shf;
-                float down;
+                // this layer's folded shift (channels 16 wave + 4 glg ..) and 2^-e, the previous layer's for the epilogue stage S carries
+                const int prev_layer = layer > 0 ? layer - 1 : 0;
+                const f32x4 shf = *reinterpret_cast<const f32x4 *>(smem + C::SH_OFF + (layer * 64 + wave * 16 + glg * 4) * 4);
+                const float down = reinterpret_cast<const float *>(smem + C::SH_OFF)[12 * 64 + layer];
+                const float pdown = layer > 0 ? reinterpret_cast<const float *>(smem + C::SH_OFF)[12 * 64 + prev_layer] : 0.f;
+                f32x4 pshf;
                 if (layer == 0) {
-                    // a group's first layer: its V rows of stages S and 2A / 2B that a previous layer would have made, its shift
-                    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(nshf) : "v"(glg * 16 + wave * 64), "s"(net.w1_shift) : "memory");
-                    {
-                        int zoff = 0;
-                        asm volatile("" : "+v"(zoff));
-                        asm volatile("global_load_dword %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=v"(ndown) : "v"(zoff), "s"(net.w1_down) : "memory");
-                    }
+                    // a group's first layer: the row-9 stage's V rows, which the previous layer's 0A / 0B would have made
                     job_now(IN_, OUT_, std::integral_constant<int, 200 + 8>{});
                     job_now(IN_, OUT_, std::integral_constant<int, 200 + 9>{});
                 }
                 // tap -1 of this layer has arrived (and with it everything requested before 0B: the next shift / scale, the halo copy)
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kWbWaitTop) : "memory");
                 __builtin_amdgcn_sched_barrier(0);
-                shf = nshf;
-                down = ndown;
 
                 // exchange + epilogue of the PREVIOUS stage, sub-step I (the slices of the stage they ride in)
                 auto epi = [&](auto N_, auto I_) __attribute__((always_inline)) {
@@ -464,7 +504,18 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1dband_kernel(
                     const bool null_epi = PREV && layer == 0;
                     constexpr int pk = ps.k, ph = ps.h;
                     // (output cells of the stage the epilogue belongs to: row 9's mapping, or cells (3 c + k, 2 t + e) of half ph)
-#define WB_OADDR(e, store) (pk == 3 ? ((store) ? sO[e] : (sO[e] >= C::DUMP_REL ? sO[e] + 256 : sO[e])) : ((store) ? oS[ph & 1][e] : oR[ph & 1][e]) + (pk % 3) * oStr[ph & 1][e])
+                    // (output cell e of the stage the epilogue belongs to: row 9's mapping - cell (9, 2 li + e) - or cell (3 c + k, 2 t + e) of
+                    // half ph; the residual comes from the same cell, or from the zero row = dump row + 256)
+                    auto out_addr = [&](int e) {
+                        if constexpr (pk == 3) {
+                            const int x = 2 * gli + e;
+                            const bool ok = sv && x < S && lmax == 9;
+                            return (ok ? (10 * S + x) * 256 : C::DUMP_REL) + (((wave * 4 + glg) ^ swz_k(15 + ((e + 1) >> 1))) << 4);
+                        } else {
+                            return oS[ph & 1][e] + (pk % 3) * ((ph == 1 && e == 1) ? oSt[1] : oSt[0]);
+                        }
+                    };
+#define WB_OADDR(e, store) ((store) ? out_addr(e) : (out_addr(e) >= C::DUMP_REL ? out_addr(e) + 256 : out_addr(e)))
                     if constexpr (i < 4) {
                         lds_f32x4_put<par * 16384 + i * 1024>(exw, acc[0][i]);
                     } else if constexpr (i == 10) {
@@ -473,6 +524,10 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1dband_kernel(
                         ez[2 * (i - 11)] = lds_f32x4_at<par * 16384 + (2 * (i - 11)) * 4096>(exr);
                         ez[2 * (i - 11) + 1] = lds_f32x4_at<par * 16384 + (2 * (i - 11) + 1) * 4096>(exr);
                     } else if constexpr (i == 13) {
+                        if constexpr (PREV) {
+                            pshf = *reinterpret_cast<const f32x4 *>(smem + C::SH_OFF + (prev_layer * 64 + wave * 16 + glg * 4) * 4);
+                            if (layer == 0) pshf = f32x4{0.f, 0.f, 0.f, 0.f};
+                        }
                         if constexpr (RS) {
                             const int zr = C::ZERO_REL + (glane * 16) % 256;
                             eres[0] = lds_f32x4_at<OB>(null_epi ? zr : WB_OADDR(0, false));
@@ -483,7 +538,7 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1dband_kernel(
                         if constexpr (part == 0) {
                             ev[cc][e] = cc == 0 ? (ez[0][e] + ez[1][e]) + ez[2][e] : (ez[1][e] - ez[2][e]) - ez[3][e];
                         } else {
-                            float tt = fmaf(ev[cc][e], PREV ? pdown : down, PREV ? pshf[e] : shf[e]);
+                            float tt = fmaf(ev[cc][e], PREV ? pdown : down, PREV ? pshf[e] : shf[e]);   // (pshf: read where stage S's epilogue starts)
                             if constexpr (RS) tt += eres[cc][e];
                             ev[cc][e] = fmaxf(tt, 0.f);
                         }
@@ -492,18 +547,6 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1dband_kernel(
                         amax = fmaxf(fmaxf(amax, ev[e][0]), ev[e][1]);
                         amax = fmaxf(fmaxf(amax, ev[e][2]), ev[e][3]);
                         lds_f32x4_put<OB>(null_epi ? C::DUMP_REL + (glane * 16) % 256 : WB_OADDR(e, true), ev[e]);
-                    } else if constexpr (i == 37 || i == 38) {
-                        // the edge row l = 0 (step 0 of row class 0) also goes to the partner: layers 0 .. 10 (PREV: the previous layer's)
-                        if constexpr (pk == 0) {
-                            constexpr int e = i - 37;
-                            const int lay = PREV ? layer - 1 : layer;
-                            const int xo = x_off(ph, e);
-                            if (lay >= 0 && lay < kTowerLayers - 1 && xo >= 0) {
-                                float *dst = pmem + (size_t)(band * 2 + ((kiter * 11 + lay) & 1)) * C::XROW_FLOATS;
-                                const float *p = reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(dst) + xo);
-                                asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(ev[e]) : "memory");
-                            }
-                        }
                     }
 #undef WB_OADDR
                 };
@@ -511,56 +554,36 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1dband_kernel(
                 static_for<7>([&](auto N_) {
                     constexpr int n = decltype(N_)::value;
                     constexpr WbStage st = wb_stage(n);
-                    constexpr int par = (PAR + n) & 1;
                     using JE = std::integral_constant<int, st.early>;
                     using JA = std::integral_constant<int, st.after>;
                     using JL = std::integral_constant<int, st.late>;
                     // ---- before the stage ----
-                    if constexpr (n == 4) {
-                        // 1B: the partner's edge row of the previous layer must have been published (asked for in 1A)
-                        if (layer > 0) {
-                            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // (1A's four weight requests lie behind the question)
-                            __builtin_amdgcn_sched_barrier(0);
-                            int seen = __builtin_amdgcn_readfirstlane(flag_seen);
-                            int spins = 0;
-                            while (seen < pub) {
-                                if (*reinterpret_cast<volatile int *>(dead)) break;
-                                __builtin_amdgcn_s_sleep(2);
-                                seen = __hip_atomic_load(seq_theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                if (++spins > kWbSpinLimit) {
-                                    *reinterpret_cast<volatile int *>(dead) = 1;
-                                    if (net.band_timeouts && glane == 0 && wave == 0) atomicAdd(net.band_timeouts, 1u);
-                                    break;
-                                }
-                            }
-                            // copy it into the halo row of this layer's INPUT buffer: 19 x 256 B = 4 x 1 KB + 768 B, LDS-DMA, sc1
-                            const float *src = pmem + (size_t)((1 - band) * 2 + ((pub - 1) & 1)) * C::XROW_FLOATS;
-                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const unsigned char *>(src) + wave * 1024 + glane * 16),
-                                                             (__attribute__((address_space(3))) void *)(smem + IN + wave * 1024), 16, 0, 16);
-                            if (wave == 0 && glane < 48)
-                                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const unsigned char *>(src) + 4096 + glane * 16),
-                                                                 (__attribute__((address_space(3))) void *)(smem + IN + 4096), 16, 0, 16);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    }
+                    if constexpr (PROF) stamp(16 + 8 * PAR + n);       // (every layer overwrites: the last conv1 / conv2 layers' stay)
                     static_for<72>([&](auto M_) {
                         constexpr int m = decltype(M_)::value;
                         constexpr int NT = st.k == 3 ? 2 : 3;
+                        if constexpr (PROF && PAR == 1 && n <= 1 && (m == 0 || m == 11 || m == 24 || m == 37 || m == 44 || m == 48 || m == 60 || m == 71)) {
+                            constexpr int si = m == 0 ? 0 : (m == 11 ? 1 : (m == 24 ? 2 : (m == 37 ? 3 : (m == 44 ? 4 : (m == 48 ? 5 : (m == 60 ? 6 : 7))))));
+                            stamp(32 + 8 * n + si);
+                        }
                         if constexpr (m < 4) epi(N_, M_);           // (exchange write of acc[m]: in front of the MFMA that restarts it)
                         if constexpr (m < 24 * NT) {
                             constexpr int ti = m / 24, q = m % 24, kc = q / 12, pr = (q / 4) % 3, c = q % 4;
                             // row 9's stage: taps -1 (row 8: half A's slot 1), 0 (row 9: half B's slot 1); regular: ord 0 = (-1, 0, +1), 1 = (+1, 0, -1)
-                            constexpr int d = st.k == 3 ? ti - 1 : (st.ord == 0 ? ti - 1 : 1 - ti);
+                            constexpr int d = st.k == 3 ? ti - 1 : (st.ord == 0 ? ti - 1 : (st.ord == 1 ? 1 - ti : (ti == 0 ? 0 : (ti == 1 ? 1 : -1))));
                             constexpr int slot = d == -1 ? S1 : (d == 0 ? 0 : 2);
-                            constexpr int vhf = st.k == 3 ? ti : st.h, vsl = st.k == 3 ? 1 : (st.k + d + 1) % 3;
+                            constexpr int vsl = st.k == 3 ? ti : wb_slot(100 + 10 * (st.k + d + 1) + st.h);
                             // waits for the fragments (see wb_wreq)
                             if constexpr (n == 0 && m == 24) {
                                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kWbWaitTap0) : "memory");
                                 __builtin_amdgcn_sched_barrier(0);
                             }
                             if constexpr (n == 1 && m == 48) {
-                                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tap +1; also: every edge store of the previous layer has landed
+                                static_assert(kWbWaitTapP == 0, "tap +1 wait");
+                                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tap +1; also: the edge stores of stage S (slices 39-42) have landed
                                 __builtin_amdgcn_sched_barrier(0);
+                                // ... so this wave's part of the previous layer's edge row is in memory: say so (the partner waits for all four waves)
+                                if (layer > 0 && glane == 0) __hip_atomic_store(seq_mine + wave, pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             }
                             bool run = true;
                             if constexpr (st.k == 3) run = band == 0;             // (uniform: band 1 has no row 9)
@@ -569,25 +592,34 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1dband_kernel(
                             }
                             if (run) {
                                 if constexpr (pr == 0)
-                                    acc[0][c] = mfma16<F>(ua[slot][kc][1][c], vh[vhf][vsl][kc], q < 4 && ti == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[0][c]);
-                                else if constexpr (pr == 1) acc[0][c] = mfma16<F>(ua[slot][kc][0][c], vl[vhf][vsl][kc], acc[0][c]);
-                                else acc[0][c] = mfma16<F>(ua[slot][kc][0][c], vh[vhf][vsl][kc], acc[0][c]);
+                                    acc[0][c] = mfma16<F>(ua[slot][kc][1][c], vh[vsl][kc], q < 4 && ti == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[0][c]);
+                                else if constexpr (pr == 1) acc[0][c] = mfma16<F>(ua[slot][kc][0][c], vl[vsl][kc], acc[0][c]);
+                                else acc[0][c] = mfma16<F>(ua[slot][kc][0][c], vh[vsl][kc], acc[0][c]);
                             }
                         }
                         // ---- what rides along ----
-                        if constexpr (m >= 4 && m < 39) epi(N_, M_);
-                        if constexpr (st.early != 0) {
-                            if constexpr (m < 8) rd(IN_, OUT_, JE{}, M_);
-                            if constexpr (m >= 8 && m < 24) tr(JE{}, std::integral_constant<int, m - 8>{});
+                        if constexpr (m >= 4 && m < 37) epi(N_, M_);
+                        if constexpr (n == 0 && m >= 39 && m < 43) {
+                            // The previous layer's edge row l = 0 (layers 0 .. 10) goes to the partner, in ITS halo row's layout: half A's cells were
+                            // stored to LDS by this lane under 0B (read back: its own writes), half B's are the epilogue values of this stage.  HERE
+                            // because a store's acknowledgement takes ~1 us and every counted wait behind it waits for it: the next one is 2A's slice 48.
+                            constexpr int hx = (m - 39) >> 1, e = (m - 39) & 1;
+                            const int xo = x_off(hx, e);
+#ifndef WB_EXP
+#define WB_EXP 0
+#endif
+                            if (layer > 0 && xo >= 0 && WB_EXP != 2) {
+                                f32x4 v = ev[e];
+                                if constexpr (hx == 0 && WB_EXP != 3) v = lds_f32x4_at<IN>(oS[0][e]);
+                                float *dst = pmem + (size_t)(band * 2 + ((pub - 1) & 1)) * C::XROW_FLOATS;
+                                const float *pp = reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(dst) + xo);
+                                if constexpr (WB_EXP == 1) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(pp), "v"(v) : "memory");
+                                else asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(pp), "v"(v) : "memory");
+                            }
                         }
-                        if constexpr (st.after != 0) {
-                            if constexpr (m >= 24 && m < 32) rd(IN_, OUT_, JA{}, std::integral_constant<int, m - 24>{});
-                            if constexpr (m >= 32 && m < 48) tr(JA{}, std::integral_constant<int, m - 32>{});
-                        }
-                        if constexpr (st.late != 0) {
-                            if constexpr (m >= 46 && m < 54) rd(IN_, OUT_, JL{}, std::integral_constant<int, m - 46>{});
-                            if constexpr (m >= 56) tr(JL{}, std::integral_constant<int, m - 56>{});
-                        }
+                        job_slice(IN_, OUT_, JE{}, std::integral_constant<int, 0>{}, M_);
+                        job_slice(IN_, OUT_, JA{}, std::integral_constant<int, 24>{}, M_);
+                        job_slice(IN_, OUT_, JL{}, std::integral_constant<int, 48>{}, M_);
                         // weight requests
                         {
                             constexpr int code = wb_wreq(n, m), kind = code >> 4;
@@ -595,49 +627,69 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1dband_kernel(
                             if constexpr (code >= 0) {
                                 if constexpr (kind == 0) w1_request<S1N>(ua, wnext + ky_m * 16384, wlane, FR{});
                                 else if constexpr (kind == 1) w1_request<0>(ua, wnext + 16384, wlane, FR{});
-                                else w1_request<2>(ua, (n == 0 ? wcur : wnext) + ky_p * 16384, wlane, FR{});
+                                else w1_request<2>(ua, wcur + ky_p * 16384, wlane, FR{});
                             }
                         }
                         // hand-off riders
-                        if constexpr (n == 2 && m == 11) {
-                            // 2B, behind its barrier: every wave has passed 2A's vmcnt(0) - the previous layer's edge row is in memory
-                            if (layer > 0 && wave == 0 && glane == 0) __hip_atomic_store(seq_mine, pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                        if constexpr (n == 3 && m == 4) {
-                            // 1A: ask for the partner's sequence number (looked at in front of 1B)
+                        if constexpr (n == 3 && m == 40) {
+                            // 1A: ask for the partner's four sequence numbers (looked at under 1B)
                             if (layer > 0) {
                                 int zoff = 0;
                                 asm volatile("" : "+v"(zoff));
-                                asm volatile("global_load_dword %0, %1, %2 sc1" : "=v"(flag_seen) : "v"(zoff), "s"(seq_theirs) : "memory");
+                                asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(flag_seen) : "v"(zoff), "s"(seq_theirs) : "memory");
                             }
                         }
-                        if constexpr (n == 4 && m == 20) {
-                            // 1B: shift and scale of the next layer
-                            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(nshf) : "v"(glg * 16 + wave * 64), "s"(net.w1_shift + next_layer * 64) : "memory");
-                            int zoff = 0;
-                            asm volatile("" : "+v"(zoff));
-                            asm volatile("global_load_dword %0, %1, %2" : "=v"(ndown) : "v"(zoff), "s"(net.w1_down + next_layer) : "memory");
+                        if constexpr (n == 4 && m == 16) {
+                            // 1B: the partner's edge row of the previous layer must have been published by all of its waves ...
+                            if (layer > 0) {
+                                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // (1A's four weight requests lie behind the question)
+                                __builtin_amdgcn_sched_barrier(0);
+                                int seen = min(min(flag_seen[0], flag_seen[1]), min(flag_seen[2], flag_seen[3]));
+                                seen = __builtin_amdgcn_readfirstlane(seen);
+                                int spins = 0;
+                                while (seen < pub) {
+                                    if (*reinterpret_cast<volatile int *>(dead)) break;
+                                    __builtin_amdgcn_s_sleep(2);
+                                    seen = __hip_atomic_load(seq_theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                                    for (int w = 1; w < 4; ++w) seen = min(seen, __hip_atomic_load(seq_theirs + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                                    if (++spins > kWbSpinLimit) {
+                                        *reinterpret_cast<volatile int *>(dead) = 1;
+                                        if (net.band_timeouts && glane == 0 && wave == 0) atomicAdd(net.band_timeouts, 1u);
+                                        break;
+                                    }
+                                }
+                                // ... then it is copied into the halo row of this layer's INPUT buffer: 19 x 256 B = 4 x 1 KB + 768 B, LDS-DMA, sc1
+                                const float *src = pmem + (size_t)((1 - band) * 2 + ((pub - 1) & 1)) * C::XROW_FLOATS;
+                                int dl = glane * 16;
+                                asm volatile("" : "+v"(dl));                      // (per layer: a 64-bit per-lane pointer kept across the block loop is two spilled registers)
+                                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const unsigned char *>(src) + wave * 1024 + dl),
+                                                                 (__attribute__((address_space(3))) void *)(smem + IN + wave * 1024), 16, 0, 16);
+                                if (wave == 0 && dl < 48 * 16)
+                                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const unsigned char *>(src) + 4096 + dl),
+                                                                     (__attribute__((address_space(3))) void *)(smem + IN + 4096), 16, 0, 16);
+                            }
                         }
                         if constexpr (n == 5 && m == 9) {
-                            // 0A, in front of its barrier: this wave's share of the halo copy has landed (behind it: 1B's two loads and four requests)
-                            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                            // 0A, in front of its barrier: this wave's share of the halo copy has landed (behind it: 1B's four weight requests)
+                            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     });
                 });
-                pshf = shf;
-                pdown = down;
                 if (!(amax < (float)kWsRangeLimit)) ovf = 1;
+                if constexpr (PROF) {
+                    stamp(2 + layer);
+                    stamp(16 + 8 * PAR + 7);
+                }
             };
             using IX = std::integral_constant<int, C::X_OFF>;
             using IH = std::integral_constant<int, C::H_OFF>;
             {
                 float z0, z1, z2, z3;
                 asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0" : "=v"(z0), "=v"(z1), "=v"(z2), "=v"(z3));
-                pshf = f32x4{z0, z1, z2, z3};
-                pdown = 0.f;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) acc[0][c] = pshf;      // (layer 0's stage S carries a null epilogue)
+                for (int c = 0; c < 4; ++c) acc[0][c] = f32x4{z0, z1, z2, z3};      // (layer 0's stage S carries a null epilogue)
             }
 #pragma unroll 1
             for (int blk = 0; blk < kBlocks; ++blk) {
@@ -649,8 +701,11 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1dband_kernel(
                 const int exw = C::EX_OFF + wave * 4096 + glane * 16, exr = C::EX_OFF + wave * 1024 + glane * 16;
                 constexpr int par = (1 + 6) & 1;
                 static_for<4>([&](auto I_) { lds_f32x4_put<par * 16384 + decltype(I_)::value * 1024>(exw, acc[0][decltype(I_)::value]); });
-                eres[0] = lds_f32x4_at<C::X_OFF>(oR[1][0]);
-                eres[1] = lds_f32x4_at<C::X_OFF>(oR[1][1]);
+                const f32x4 pshf = *reinterpret_cast<const f32x4 *>(smem + C::SH_OFF + (11 * 64 + wave * 16 + glg * 4) * 4);
+                const float pdown = reinterpret_cast<const float *>(smem + C::SH_OFF)[12 * 64 + 11];
+                const int o0 = oS[1][0], o1 = oS[1][1];
+                eres[0] = lds_f32x4_at<C::X_OFF>(o0 >= C::DUMP_REL ? o0 + 256 : o0);
+                eres[1] = lds_f32x4_at<C::X_OFF>(o1 >= C::DUMP_REL ? o1 + 256 : o1);
                 __syncthreads();
                 static_for<4>([&](auto I_) { ez[decltype(I_)::value] = lds_f32x4_at<par * 16384 + decltype(I_)::value * 4096>(exr); });
 #pragma unroll
@@ -660,8 +715,8 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1dband_kernel(
                     ev[1][e] = fmaxf(fmaf(o1, pdown, pshf[e]) + eres[1][e], 0.f);
                     amax = fmaxf(fmaxf(amax, ev[0][e]), ev[1][e]);
                 }
-                lds_f32x4_put<C::X_OFF>(oS[1][0], ev[0]);
-                lds_f32x4_put<C::X_OFF>(oS[1][1], ev[1]);
+                lds_f32x4_put<C::X_OFF>(o0, ev[0]);
+                lds_f32x4_put<C::X_OFF>(o1, ev[1]);
                 if (!(amax < (float)kWsRangeLimit)) ovf = 1;
                 __syncthreads();
             }
@@ -697,14 +752,88 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1dband_kernel(
             }
         }
         __syncthreads();
+        stamp(14);
+        if constexpr (PROF) {
+            __syncthreads();
+            // (the SECOND board of pair 0 when there is one: steady state, the partner is neither ahead nor behind by a launch skew)
+            if (pair == 0 && kiter == (batch > n_pairs ? 1 : 0) && tid < 64)
+                net.timeline[band * 64 + tid] = reinterpret_cast<volatile long long *>(smem + C::PROF_OFF)[tid];
+        }
     }
     if (ovf && overflow) atomicOr(overflow, 1);
 }
 
-// The two fully connected layers + softmaxes of a 19x19 launch: policy FC 722 -> 362 and value FC 361 -> 3 on the features
-// dualnet_fwd_w1dband_kernel left in global memory ([board][policy 0 | policy 1 | value][361]).  TB boards per workgroup:
-// thread a (0 .. 361) owns policy output a of all TB boards - the FC matrix (transposed, [722][362] fp32, 1 MB) is read once
-// per workgroup, coalesced over a, the features come from LDS as broadcasts.  Plain fp32 FMAs (the reference's arithmetic).
+// The two fully connected layers + softmaxes of a 19x19 launch, on the features dualnet_fwd_w1dband_kernel left in global memory
+// ([board][policy 0 | policy 1 | value][361]): policy FC 722 -> 362, value FC 361 -> 3.  Plain fp32 FMAs (the reference's arithmetic) in
+// ONE summation order whatever the launch size: the 722 inputs in four quarters (181, 181, 180, 180), each a sequential FMA chain
+// from zero, logit = ((q0 + q1) + (q2 + q3)) + bias.  The FC matrix (transposed, [722][362] fp32, 1 MB) is the cost: a CU's L1
+// passes it in 7.5 us, so
+//   * small launches (one tree's mini-batch): dualnet_heads19_part_kernel - one workgroup per (board, quarter), partial sums to
+//     global memory - then dualnet_heads19_fin_kernel per board (sum, bias, softmaxes, value FC);
+//   * large launches: dualnet_heads19_kernel<16> - sixteen boards per workgroup share one pass over the matrix.
+__global__ __launch_bounds__(384) void dualnet_heads19_part_kernel(NetDev net, const float *__restrict__ feat, float *__restrict__ part) {
+    constexpr int P = 361, A = 362;
+    __shared__ float f[184];
+    const int b = blockIdx.x >> 2, q = blockIdx.x & 3, tid = threadIdx.x;
+    const int j0 = q < 2 ? q * 181 : 362 + (q - 2) * 180, n = q < 2 ? 181 : 180;
+    if (tid < n) f[tid] = feat[(size_t)b * 3 * P + j0 + tid];
+    __syncthreads();
+    if (tid < A) {
+        const float *wT = net.pfc_wT + (size_t)j0 * A + tid;
+        float s = 0.f;
+#pragma unroll 4
+        for (int j = 0; j < n; ++j) s = fmaf(f[j], wT[(size_t)j * A], s);
+        part[((size_t)b * 4 + q) * 384 + tid] = s;
+    }
+}
+
+__global__ __launch_bounds__(128) void dualnet_heads19_fin_kernel(NetDev net, const float *__restrict__ feat, const float *__restrict__ part, int want_logits,
+                                                                  float *__restrict__ policy, float *__restrict__ value) {
+    constexpr int P = 361, A = 362;
+    __shared__ float lg[A + 6];
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float m = -INFINITY;
+    for (int a = tid; a < A; a += 128) {
+        const float *p = part + (size_t)b * 4 * 384 + a;
+        const float v = ((p[0] + p[384]) + (p[768] + p[1152])) + net.pfc_b[a];
+        lg[a] = v;
+        m = fmaxf(m, v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(red[0], red[1]);
+    float sum = 0.f;
+    for (int a = tid; a < A; a += 128) sum += expf(lg[a] - m);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if (lane == 0) red[2 + wave] = sum;
+    __syncthreads();
+    const float inv = 1.f / (red[2] + red[3]);
+    for (int a = tid; a < A; a += 128) __builtin_nontemporal_store(want_logits ? lg[a] : expf(lg[a] - m) * inv, &policy[(size_t)b * A + a]);
+    // value FC: wave 0, lanes 0 .. 47 = 3 outputs x 16 parts, 23 inputs each in sequence, the parts summed in a fixed (butterfly) order
+    if (wave == 0) {
+        const int c = lane >> 4, part_i = lane & 15;
+        float sv = 0.f;
+        if (c < 3) {
+            const float *h = feat + (size_t)b * 3 * P + 2 * P, *wv = net.vfc_w + c * P;
+            for (int j = part_i * 23; j < (part_i + 1) * 23 && j < P; ++j) sv = fmaf(h[j], wv[j], sv);
+        }
+        sv += __shfl_xor(sv, 8);
+        sv += __shfl_xor(sv, 4);
+        sv += __shfl_xor(sv, 2);
+        sv += __shfl_xor(sv, 1);
+        const float v0 = __shfl(sv, 0) + net.vfc_b[0], v1 = __shfl(sv, 16) + net.vfc_b[1], v2 = __shfl(sv, 32) + net.vfc_b[2];
+        if (lane < 3) {
+            const float vm = fmaxf(v0, fmaxf(v1, v2));
+            const float e0 = expf(v0 - vm), e1 = expf(v1 - vm), e2 = expf(v2 - vm);
+            value[(size_t)b * 3 + lane] = (lane == 0 ? e0 : (lane == 1 ? e1 : e2)) / (e0 + e1 + e2);
+        }
+    }
+}
+
 template <int TB>
 __global__ __launch_bounds__(384) void dualnet_heads19_kernel(NetDev net, const float *__restrict__ feat, int batch, int want_logits,
                                                               float *__restrict__ policy, float *__restrict__ value) {
@@ -719,31 +848,32 @@ __global__ __launch_bounds__(384) void dualnet_heads19_kernel(NetDev net, const 
     }
     __syncthreads();
     if (tid < A) {
-        float s[TB][2];
-#pragma unroll
-        for (int bl = 0; bl < TB; ++bl) { s[bl][0] = net.pfc_b[tid]; s[bl][1] = 0.f; }
+        // (the four quarters of dualnet_heads19_part_kernel, in its order)
+        float s[TB], t[TB];
         const float *wT = net.pfc_wT + tid;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j0 = q < 2 ? q * 181 : 362 + (q - 2) * 180, n = q < 2 ? 181 : 180;
+            float r[TB];
+#pragma unroll
+            for (int bl = 0; bl < TB; ++bl) r[bl] = 0.f;
 #pragma unroll 2
-        for (int j = 0; j < 2 * P; j += 2) {
-            const float w0 = wT[(size_t)j * A], w1 = wT[(size_t)(j + 1) * A];
+            for (int j = 0; j < n; ++j) {
+                const float w = wT[(size_t)(j0 + j) * A];
+#pragma unroll
+                for (int bl = 0; bl < TB; ++bl) r[bl] = fmaf(f[bl][j0 + j], w, r[bl]);
+            }
 #pragma unroll
             for (int bl = 0; bl < TB; ++bl) {
-                s[bl][0] = fmaf(f[bl][j], w0, s[bl][0]);
-                s[bl][1] = fmaf(f[bl][j + 1], w1, s[bl][1]);
+                if (q == 0) s[bl] = r[bl];
+                else if (q == 1) s[bl] = s[bl] + r[bl];
+                else if (q == 2) t[bl] = r[bl];
+                else t[bl] = t[bl] + r[bl];
             }
         }
+        const float bias = net.pfc_b[tid];
 #pragma unroll
-        for (int bl = 0; bl < TB; ++bl) lg[bl][tid] = s[bl][0] + s[bl][1];
-    } else if (tid < A + 3 * TB && tid - A < 3 * TB) {
-        const int q = tid - A, bl = q / 3, c = q - bl * 3;
-        const float *wv = net.vfc_w + c * P;
-        float s0 = net.vfc_b[c], s1 = 0.f;
-        for (int j = 0; j + 1 < P; j += 2) {
-            s0 = fmaf(f[bl][2 * P + j], wv[j], s0);
-            s1 = fmaf(f[bl][2 * P + j + 1], wv[j + 1], s1);
-        }
-        s0 = fmaf(f[bl][2 * P + P - 1], wv[P - 1], s0);
-        vl[bl][c] = s0 + s1;
+        for (int bl = 0; bl < TB; ++bl) lg[bl][tid] = (s[bl] + t[bl]) + bias;
     }
     __syncthreads();
     const int wave = tid >> 6, lane = tid & 63;
@@ -754,23 +884,36 @@ __global__ __launch_bounds__(384) void dualnet_heads19_kernel(NetDev net, const 
         for (int a = lane; a < A; a += 64) m = fmaxf(m, lg[bl][a]);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-        float sum = 0.f;
-        for (int a = lane; a < A; a += 64) sum += expf(lg[bl][a] - m);
+        // (the same two-wave split of the sums as dualnet_heads19_fin_kernel: a = tid, tid + 128, .. per thread of a 128-thread block)
+        float sum0 = 0.f, sum1 = 0.f;
+        for (int a = lane; a < A; a += 128) sum0 += expf(lg[bl][a] - m);
+        for (int a = lane + 64; a < A; a += 128) sum1 += expf(lg[bl][a] - m);
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-        const float inv = 1.f / sum;
+        for (int o = 32; o > 0; o >>= 1) { sum0 += __shfl_xor(sum0, o); sum1 += __shfl_xor(sum1, o); }
+        const float inv = 1.f / (sum0 + sum1);
         for (int a = lane; a < A; a += 64) {
             const float v = lg[bl][a];
             __builtin_nontemporal_store(want_logits ? v : expf(v - m) * inv, &policy[(size_t)b * A + a]);
         }
+        // value FC as in the small-launch kernel: 3 outputs x 16 parts of 23 inputs
+        const int c = lane >> 4, part_i = lane & 15;
+        float sv = 0.f;
+        if (c < 3) {
+            const float *h = &f[bl][2 * P], *wv = net.vfc_w + c * P;
+            for (int j = part_i * 23; j < (part_i + 1) * 23 && j < P; ++j) sv = fmaf(h[j], wv[j], sv);
+        }
+        sv += __shfl_xor(sv, 8);
+        sv += __shfl_xor(sv, 4);
+        sv += __shfl_xor(sv, 2);
+        sv += __shfl_xor(sv, 1);
+        const float v0 = __shfl(sv, 0) + net.vfc_b[0], v1 = __shfl(sv, 16) + net.vfc_b[1], v2 = __shfl(sv, 32) + net.vfc_b[2];
         if (lane < 3) {
-            const float v0 = vl[bl][0], v1 = vl[bl][1], v2 = vl[bl][2];
             const float vm = fmaxf(v0, fmaxf(v1, v2));
             const float e0 = expf(v0 - vm), e1 = expf(v1 - vm), e2 = expf(v2 - vm);
-            const float es = e0 + e1 + e2;
-            value[(size_t)b * 3 + lane] = (lane == 0 ? e0 : (lane == 1 ? e1 : e2)) / es;
+            value[(size_t)b * 3 + lane] = (lane == 0 ? e0 : (lane == 1 ? e1 : e2)) / (e0 + e1 + e2);
         }
     }
+    (void)vl;
 }
 
 }  // namespace
@@ -791,10 +934,12 @@ int w1dband_forward(tg_net *net, const float *planes, int batch, int want_logits
                     hipStream_t stream) {
     using C = WbCfg;
     if (net->board_size != 19) return tg::fail(TG_ERR_ARG, "w1dband forward: 19x19 only");
-    auto kern = dualnet_fwd_w1dband_kernel<false>;
+    auto kern = net->dev.timeline ? dualnet_fwd_w1dband_kernel<true> : dualnet_fwd_w1dband_kernel<false>;
     static std::atomic<uint64_t> configured{0};
-    if (tg::first_on_device(configured, net->device))
-        TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+    if (tg::first_on_device(configured, net->device)) {
+        TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(dualnet_fwd_w1dband_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+        TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(dualnet_fwd_w1dband_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+    }
     const int pairs = w1dband_pairs(net, batch);
     const size_t xfloats = (size_t)(net->num_cus / 2) * C::PAIR_FLOATS;
     float *xmem = nullptr, *feat = nullptr;
@@ -807,7 +952,7 @@ int w1dband_forward(tg_net *net, const float *planes, int batch, int want_logits
             slot.cap = 0;
             void *d = nullptr;
             const int cap = batch < 1024 ? 1024 : batch;
-            TG_HIP(hipMalloc(&d, (xfloats + (size_t)cap * 3 * C::P) * sizeof(float)));
+            TG_HIP(hipMalloc(&d, (xfloats + (size_t)cap * 3 * C::P + (size_t)512 * 4 * 384) * sizeof(float)));
             slot.mem = static_cast<float *>(d);
             slot.cap = cap;
         }
@@ -818,8 +963,11 @@ int w1dband_forward(tg_net *net, const float *planes, int batch, int want_logits
     TG_HIP(hipMemsetAsync(xmem, 0, xfloats * sizeof(float), stream));
     hipLaunchKernelGGL(kern, dim3(2 * pairs), dim3(C::NTHR), C::LDS_BYTES, stream, net->dev, planes, batch, feat, xmem, overflow);
     TG_HIP(hipGetLastError());
-    if (batch <= 256) {
-        hipLaunchKernelGGL(dualnet_heads19_kernel<2>, dim3((batch + 1) / 2), dim3(384), 0, stream, net->dev, feat, batch, want_logits, policy, value);
+    if (batch <= 512) {
+        // partial sums [batch][4][384] behind the feature image
+        float *part = feat + (size_t)batch * 3 * C::P;
+        hipLaunchKernelGGL(dualnet_heads19_part_kernel, dim3(batch * 4), dim3(384), 0, stream, net->dev, feat, part);
+        hipLaunchKernelGGL(dualnet_heads19_fin_kernel, dim3(batch), dim3(128), 0, stream, net->dev, feat, part, want_logits, policy, value);
     } else {
         hipLaunchKernelGGL(dualnet_heads19_kernel<16>, dim3((batch + 15) / 16), dim3(384), 0, stream, net->dev, feat, batch, want_logits, policy, value);
     }
