@@ -95,6 +95,11 @@ double tg_net_executed_flops_per_position(const tg_net *net, int batch, double *
  * run hot shows up here instead of only as a slower search.  Synchronises the device.  (No reference counterpart: the
  * reference computes in fp32 throughout, nn/network/dual_net.py:41-52.) */
 int tg_net_range_fallbacks(tg_net *net, unsigned long long *count);
+/* ... and how many POSITIONS the exact-fp32 kernel redid in those launches.  The one-axis Winograd kernels (the defaults at both
+ * board sizes) mark the workgroup passes - 3 boards (1 in small launches) at 9x9, one board at 19x19 - whose activations left
+ * the f16 range, and the exact kernel redoes those only: one hot position in a launch of half a million costs three positions'
+ * redo, not the launch's.  (The direct split kernels and a band's time-out redo the whole launch.)  Synchronises the device. */
+int tg_net_range_fallback_positions(tg_net *net, unsigned long long *count);
 /* 19x19: launches of up to 128 boards spread a board over 2 / 4 workgroups that exchange halo rows through L2 with BOUNDED
  * waits.  *count receives how many of those waits gave up so far (each ends in the exact-fp32 redo above, so it is also
  * part of tg_net_range_fallbacks' count - this one tells the two causes apart).  After the first one the network keeps to

@@ -55,7 +55,7 @@ struct NetDev {
     const unsigned char *w1_w;
     const float *w1_shift;
     const float *w1_down;
-    unsigned long long *fallbacks;    // launches redone by the exact-fp32 kernel behind a raised range flag (tg_net_range_fallbacks)
+    unsigned long long *fallbacks;    // [0] launches (partly) redone by the exact-fp32 kernel behind a raised range flag (tg_net_range_fallbacks), [1] positions redone (tg_net_range_fallback_positions)
     unsigned int *band_timeouts;      // banded 19x19 kernels: bounded waits that gave up (host-mapped: band_count reads it without a sync)
     int *overflow;                    // f16 range guard: set when a layer output leaves the f16 range
     float *scratch;       // 19x19 Winograd: per workgroup two [P][64] activation images (L2-resident)
@@ -235,6 +235,10 @@ struct tg_net {
     std::mutex scratch_mu;
     std::map<hipStream_t, float *> scratch_by_stream;
     std::map<hipStream_t, int *> flag_by_stream;      // f16 split kernel: range flag per launch stream
+    // ... and which GROUPS (workgroup passes: 3 / 1 boards at 9x9, a board at 19x19) raised it: one bit per group, all zero between
+    // launches (the exact kernel clears the bits it consumes), so that it redoes those groups only
+    struct GroupBits { int *mem = nullptr; int words = 0; };
+    std::map<hipStream_t, GroupBits> bits_by_stream;
     // 19x19 one-axis Winograd kernel (net_forward_w1dband.hip): per stream the pairs' exchange rows + the feature image
     struct WbScratch { float *mem = nullptr; int cap = 0; };
     std::map<hipStream_t, WbScratch> wb_by_stream;

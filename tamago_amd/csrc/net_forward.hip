@@ -33,10 +33,10 @@ int heads_prepare(tg_net *net, const float *hp_w, const float *hv_w, const float
 // net_forward_w1d.hip: the tower as Winograd F(2,3) along x on split operands (the 9x9 default)
 int w1d_prepare(tg_net *net, const float *const *tower, const float *scale, const float *shift);
 int w1d_forward(tg_net *net, int group, const float *planes, int batch, int want_logits, float *policy, float *value, int *overflow,
-                hipStream_t stream);
+                int *group_bits, hipStream_t stream);
 // net_forward_w1dband.hip: 19x19, one-axis Winograd tower, a board over two workgroups + the batched heads kernel
 int w1dband_forward(tg_net *net, const float *planes, int batch, int want_logits, float *policy, float *value, int *overflow,
-                    hipStream_t stream);
+                    int *group_bits, hipStream_t stream);
 // net_forward_band.hip: a 19x19 board spread over 2 / 4 workgroups (small launches)
 int band_count(const tg_net *net, int batch);
 int band_forward(tg_net *net, int bands, const float *planes, int batch, int want_logits, float *policy, float *value,
@@ -283,11 +283,16 @@ struct WinoCfg {
 template <int S, int G, bool GS = false>
 __global__ __launch_bounds__(512, 2) void dualnet_fwd_wino8_kernel(
     NetDev net, const float *__restrict__ planes, int batch, int want_logits,
-    float *__restrict__ policy, float *__restrict__ value, const int *__restrict__ guard) {
+    float *__restrict__ policy, float *__restrict__ value, const int *__restrict__ guard, int *__restrict__ group_bits) {
     using C = WinoCfg<S, G, GS>;
-    // fallback launch behind the split-operand kernel: runs only if that kernel raised its range flag
+    // fallback launch behind the split-operand kernel: runs only if that kernel raised its range flag - and, when that kernel
+    // says WHICH groups left the f16 range (bit 0 of the flag + one bit per group in group_bits; bit 1 of the flag = redo
+    // everything: a band gave up waiting), only over those groups: a single hot position costs one group's redo, not the batch's
+    bool only_marked = false;
     if (guard != nullptr) {
-        if (__builtin_nontemporal_load(guard) == 0) return;
+        const int gf = __builtin_nontemporal_load(guard);
+        if (gf == 0) return;
+        only_marked = group_bits != nullptr && !(gf & 2);
         if (blockIdx.x == 0 && threadIdx.x == 0 && net.fallbacks) atomicAdd(net.fallbacks, 1ull);
     }
     constexpr int P = C::P, M = C::M, MT = C::MT;
@@ -349,6 +354,18 @@ __global__ __launch_bounds__(512, 2) void dualnet_fwd_wino8_kernel(
     const int n_groups = (batch + G - 1) / G;
     for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
         const int b0 = grp * G;
+        if (guard != nullptr) {
+            // (uniform: every thread reads the same word; the owner of the group - this workgroup - clears the bit behind the
+            // barrier, so the bitmap is all zero again when the launch ends)
+            int marked = 1;
+            if (group_bits != nullptr) {
+                marked = (__builtin_nontemporal_load(group_bits + (grp >> 5)) >> (grp & 31)) & 1;
+                __syncthreads();
+                if (marked && tid == 0) atomicAnd(group_bits + (grp >> 5), ~(1 << (grp & 31)));
+            }
+            if (only_marked && !marked) continue;
+            if (tid == 0 && net.fallbacks) atomicAdd(net.fallbacks + 1, (unsigned long long)(batch - b0 < G ? batch - b0 : G));
+        }
         stamp();                                  // 0: group start
         stage_planes<S, G, C, 512>(smem, planes, b0, batch, tid);
         __syncthreads();
@@ -617,7 +634,7 @@ int launch(tg_net *net, const float *planes, int batch, int want_logits, float *
 
 template <int S, int G, bool GS = false>
 int launch_wino8(tg_net *net, const float *planes, int batch, int want_logits, float *policy,
-                 float *value, hipStream_t stream, const int *guard = nullptr) {
+                 float *value, hipStream_t stream, const int *guard = nullptr, int *group_bits = nullptr) {
     using C = WinoCfg<S, G, GS>;
     auto kern = dualnet_fwd_wino8_kernel<S, G, GS>;
     static bool attr_set[16] = {};
@@ -641,7 +658,7 @@ int launch_wino8(tg_net *net, const float *planes, int batch, int want_logits, f
         dev.scratch = slot;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), C::LDS_BYTES, stream, dev, planes, batch,
-                       want_logits, policy, value, guard);
+                       want_logits, policy, value, guard, group_bits);
     TG_HIP(hipGetLastError());
     return TG_OK;
 }
@@ -799,7 +816,7 @@ int tg_net_create(int board_size, int device, const float *params, size_t n_para
     }
     {
         void *d = nullptr;
-        if (hipMalloc(&d, sizeof(unsigned long long)) != hipSuccess || hipMemset(d, 0, sizeof(unsigned long long)) != hipSuccess) {
+        if (hipMalloc(&d, 2 * sizeof(unsigned long long)) != hipSuccess || hipMemset(d, 0, 2 * sizeof(unsigned long long)) != hipSuccess) {
             delete net;
             return tg::fail(TG_ERR_HIP, "tg_net_create: fallback counter");
         }
@@ -850,6 +867,7 @@ int tg_net_destroy(tg_net *net) {
     for (void *p : net->allocs) (void)hipFree(p);
     for (auto &kv : net->scratch_by_stream) (void)hipFree(kv.second);
     for (auto &kv : net->flag_by_stream) (void)hipFree(kv.second);
+    for (auto &kv : net->bits_by_stream) if (kv.second.mem) (void)hipFree(kv.second.mem);
     for (auto &kv : net->wb_by_stream) if (kv.second.mem) (void)hipFree(kv.second.mem);
     if (net->band_done) (void)hipEventDestroy(net->band_done);
     if (net->band_timeouts_host) (void)hipHostFree(const_cast<unsigned int *>(net->band_timeouts_host));
@@ -857,6 +875,27 @@ int tg_net_destroy(tg_net *net) {
     if (net->st_policy) (void)hipFree(net->st_policy);
     if (net->st_value) (void)hipFree(net->st_value);
     delete net;
+    return TG_OK;
+}
+
+// The per-stream group bitmap of the f16 kernels' range guard, at least `groups` bits, all zero (allocated zeroed; every
+// consumer clears what it read).  Growing it frees the old one: hipFree waits for the device, nothing can still be using it.
+static int group_bits_for(tg_net *net, hipStream_t st, int groups, int **out) {
+    std::lock_guard<std::mutex> lock(net->scratch_mu);
+    auto &slot = net->bits_by_stream[st];
+    const int words = (groups + 31) / 32;
+    if (slot.words < words) {
+        if (slot.mem) TG_HIP(hipFree(slot.mem));
+        slot.mem = nullptr;
+        slot.words = 0;
+        const int cap = words < 2048 ? 2048 : words;
+        void *d = nullptr;
+        TG_HIP(hipMalloc(&d, (size_t)cap * sizeof(int)));
+        TG_HIP(hipMemset(d, 0, (size_t)cap * sizeof(int)));
+        slot.mem = static_cast<int *>(d);
+        slot.words = cap;
+    }
+    *out = slot.mem;
     return TG_OK;
 }
 
@@ -882,15 +921,20 @@ static bool pick_split() {
     const char *env = getenv("TG_FWD_ALGO");
     return !env || !strcmp(env, "split16") || !strcmp(env, "w1d") || !strcmp(env, "w1dband");
 }
-// 19x19: the one-axis Winograd tower over two workgroups per board (net_forward_w1dband.hip).  Needs both workgroups of a pair
-// resident: not on a device shared with other processes, not while a self-play move's sub-group streams hold CUs back.
+// 19x19: the one-axis Winograd tower over two workgroups per board (net_forward_w1dband.hip), the 19x19 default since round 5
+// (1.15x the direct split kernel at 4 096 boards, 1.15x the banded one at 64).  Needs both workgroups of a pair resident: not on a
+// device shared with other processes, not after a bounded wait gave up once.  The choice must NOT depend on what a self-play move
+// is doing (sub-group streams, grid caps): the Winograd and the direct kernels round differently, and a game must not depend on
+// how its boards were grouped (tests/test_gpu_debts.py::test_19x19_selfplay_groups_equal_single_group) - the launch honours the
+// forward cap instead (w1dband_pairs), and a network's pair launches follow each other across streams (w1dband_forward).
 static bool pick_w1dband(const tg_net *net) {
     if (net->board_size != 19) return false;
     const char *env = getenv("TG_FWD_ALGO");
     if (env) return !strcmp(env, "w1dband");
-    if (net->shared_device || net->forward_grid_cap.load() > 0 || net->guard_grid_cap.load() > 0) return false;
+    if (getenv("TG_FWD_BANDS")) return false;              // (the banded direct kernel was asked for by name: tests, comparisons)
+    if (net->shared_device) return false;
     if (net->band_timeouts_host && *net->band_timeouts_host > 0) return false;
-    return getenv("TG_FWD_W1DBAND") != nullptr;            // (opt-in until it has been measured)
+    return true;
 }
 static bool pick_w1d(int board_size, int /*batch*/, int /*num_cus*/) {
     if (board_size != 9) return false;
@@ -950,8 +994,8 @@ double tg_net_executed_flops_per_position(const tg_net *net, int batch, double *
     const char *name = "f32";
     double flops = 0.0;
     if (S == 19 && pick_w1dband(net)) {
-        // per board and layer: band 0 = 6 stages x 72 + 48 MFMAs per wave, band 1 = 6 x 72; stem: 2 x 16 row tiles x 4 x 2 x 3
-        flops = (12.0 * 4 * (480 + 432) + 2.0 * 16 * 4 * 2 * 3) * 16384.0;
+        // per board and layer: 6 stages x 72 + 48 MFMAs per wave in either band (band 1's row-9 stage runs on the zero row); stem: 2 x 16 row tiles x 4 x 2 x 3
+        flops = (12.0 * 4 * (480 + 480) + 2.0 * 16 * 4 * 2 * 3) * 16384.0;
         peak = 2500.0;
         name = "f16 (2 operand pieces, Winograd F(2,3) along x, fp32 accumulate)";
     } else if (pick_w1d(S, batch, net->num_cus)) {
@@ -1024,10 +1068,12 @@ int tg_net_forward_dev(tg_net *net, const float *planes_dev, int batch, int want
                 flag = slot;
             }
             if (pick_w1dband(net)) {
+                int *bits = nullptr;
+                if (int rc = group_bits_for(net, st, batch, &bits)) return rc;
                 TG_HIP(hipMemsetAsync(flag, 0, 2 * sizeof(int), st));
-                int rc = tg::w1dband_forward(net, planes_dev, batch, want_logits, policy_dev, value_dev, flag, st);
+                int rc = tg::w1dband_forward(net, planes_dev, batch, want_logits, policy_dev, value_dev, flag, bits, st);
                 if (rc) return rc;
-                return launch_wino8<19, 1, true>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st, flag);
+                return launch_wino8<19, 1, true>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st, flag, bits);
             }
             const int bands = tg::band_count(net, batch);
             TG_HIP(hipMemsetAsync(flag, 0, (bands ? 2 + kBandFlagInts : 2) * sizeof(int), st));
@@ -1074,12 +1120,17 @@ int tg_net_forward_dev(tg_net *net, const float *planes_dev, int batch, int want
             // the next mini-batch's 344 MB random window, uploaded on the copy stream, is no longer hidden under the
             // forward pass.  Self-play gained 1 % from its removal.)
             TG_HIP(hipMemsetAsync(flag, 0, 2 * sizeof(int), st));
-            int rc = pick_w1d(9, batch, net->num_cus)
-                         ? tg::w1d_forward(net, group, planes_dev, batch, want_logits, policy_dev, value_dev, flag, st)
+            // (the one-axis kernel marks the groups that left the range: the exact kernel redoes those only; the direct split
+            // kernel raises the flag alone: the whole batch)
+            int *bits = nullptr;
+            const bool w1d = pick_w1d(9, batch, net->num_cus);
+            if (w1d)
+                if (int rc = group_bits_for(net, st, (batch + group - 1) / group, &bits)) return rc;
+            int rc = w1d ? tg::w1d_forward(net, group, planes_dev, batch, want_logits, policy_dev, value_dev, flag, bits, st)
                          : tg::split_forward(net, group, planes_dev, batch, want_logits, policy_dev, value_dev, flag, st);
             if (rc) return rc;
-            if (group == 3) return launch_wino8<9, 3>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st, flag);
-            return launch_wino8<9, 1>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st, flag);
+            if (group == 3) return launch_wino8<9, 3>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st, flag, bits);
+            return launch_wino8<9, 1>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st, flag, bits);
         }
         const int wg = pick_wino(9, batch, net->num_cus);
         if (wg == 1) return launch_wino8<9, 1>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st);
@@ -1096,6 +1147,14 @@ int tg_net_range_fallbacks(tg_net *net, unsigned long long *count) {
     TG_HIP(hipSetDevice(net->device));
     TG_HIP(hipDeviceSynchronize());
     TG_HIP(hipMemcpy(count, net->dev.fallbacks, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return TG_OK;
+}
+
+int tg_net_range_fallback_positions(tg_net *net, unsigned long long *count) {
+    if (!net || !count) return tg::fail(TG_ERR_ARG, "tg_net_range_fallback_positions: null argument");
+    TG_HIP(hipSetDevice(net->device));
+    TG_HIP(hipDeviceSynchronize());
+    TG_HIP(hipMemcpy(count, net->dev.fallbacks + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return TG_OK;
 }
 

@@ -23,6 +23,13 @@
 // Reference: nn/network/res_block.py:8-38, nn/network/dual_net.py:41-52.
 #include "w1d_common.h"
 
+// W1_ABL (experiments only, tools/experiments/wb_ablation.sh: results are wrong, the timing says what a class of riders costs in the
+// three-board variant): 1 no weight requests, 2 no input transforms, 4 no cell reads, 8 no epilogue arithmetic, 16 no exchange
+// traffic, 32 no row barrier, 128 no MFMAs, 256 no heads, 512 no stem
+#ifndef W1_ABL
+#define W1_ABL 0
+#endif
+
 namespace {
 
 
@@ -287,7 +294,7 @@ __device__ __forceinline__ void run_heads_x32(unsigned char *smem, const NetDev 
 template <int G, bool PROF>
 __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
     NetDev net, const float *__restrict__ planes, int batch, int want_logits,
-    float *__restrict__ policy, float *__restrict__ value, int *__restrict__ overflow) {
+    float *__restrict__ policy, float *__restrict__ value, int *__restrict__ overflow, int *__restrict__ group_bits) {
     using C = WsCfg<G>;
     using F = FmtF16;
     constexpr int P = C::P, M = C::M, NTHR = C::NTHR, RTW = C::RTW, IMG = C::IMG;
@@ -734,13 +741,14 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
             auto rd = [&](auto IN_, auto I_) __attribute__((always_inline)) {          // one of the eight cell reads of the row at curA / curB
                 constexpr int IN = decltype(IN_)::value, i = decltype(I_)::value, cb = i >> 2, kc = (i >> 1) & 1, h = i & 1;
                 const int a0 = (cb ? curB : curA) ^ ((kc << 7) | (h << 4));
-                dq[cb][kc][h] = lds_f32x4_at<IN>(a0);
+                if constexpr (!(W1_ABL & 4)) dq[cb][kc][h] = lds_f32x4_at<IN>(a0);
                 if constexpr (i == 7) { curA += strA; curB += strB; }
             };
             // input transform of one row in 16 slices: per (kc, half) t = d_a + sgn d_b (2 x 2 values), high pieces, low pieces
             auto tr = [&](auto R_, auto I_) __attribute__((always_inline)) {
                 constexpr int r = decltype(R_)::value, i = decltype(I_)::value, kc = i >> 3, h = (i >> 2) & 1, q = i & 3, s = vslot(r);
-                if constexpr (q == 0) {
+                if constexpr (W1_ABL & 2) {
+                } else if constexpr (q == 0) {
                     tvv[0] = fmaf(dq[1][kc][h][0], sgn, dq[0][kc][h][0]);
                     tvv[1] = fmaf(dq[1][kc][h][1], sgn, dq[0][kc][h][1]);
                 } else if constexpr (q == 1) {
@@ -806,7 +814,7 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
                     constexpr int OB = PREV ? IN : OUT;
                     constexpr bool RS = PREV ? !RES : RES;
                     if constexpr (i < 4) {
-                        lds_f32x4_put<par * 16384 + i * 1024>(exw, acc[par][i]);
+                        if constexpr (!(W1_ABL & 16)) lds_f32x4_put<par * 16384 + i * 1024>(exw, acc[par][i]);
                     } else if constexpr (i == 13) {
                         if constexpr (RS) {
                             eres[0] = lds_f32x4_at<OB>(PREV ? pR0 : curR0);
@@ -814,13 +822,16 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
                         }
                         if constexpr (!PREV) { curR0 += strR0; curR1 += strR1; }   // (also without a residual: the next layer's deferred row needs them at row 8)
                     } else if constexpr (i == 10) {
-                        __syncthreads();
+                        if constexpr (!(W1_ABL & 32)) __syncthreads();
                     } else if constexpr (i == 11 || i == 12) {
+                        if constexpr (!(W1_ABL & 16)) {
                         ez[2 * (i - 11)] = lds_f32x4_at<par * 16384 + (2 * (i - 11)) * 4096>(exr);
                         ez[2 * (i - 11) + 1] = lds_f32x4_at<par * 16384 + (2 * (i - 11) + 1) * 4096>(exr);
+                        }
                     } else if constexpr (i >= 19 && i < 35) {
                         constexpr int k = i - 19, cc = k >> 3, e = (k >> 1) & 3, part = k & 1;
-                        if constexpr (part == 0) {
+                        if constexpr (W1_ABL & 8) {
+                        } else if constexpr (part == 0) {
                             ev[cc][e] = cc == 0 ? (ez[0][e] + ez[1][e]) + ez[2][e] : (ez[1][e] - ez[2][e]) - ez[3][e];
                         } else {
                             float tt = fmaf(ev[cc][e], PREV ? pdown : down, PREV ? pshf[e] : shf[e]);
@@ -860,7 +871,8 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
                             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kW1WaitTap2) : "memory");
                             __builtin_amdgcn_sched_barrier(0);
                         }
-                        if constexpr (st == 0)
+                        if constexpr (W1_ABL & 128) {
+                        } else if constexpr (st == 0)
                             acc[par][c] = mfma16<F>(UX ? ux[1][c] : ua[slot][kc][1][c], vh[s][kc], m < 4 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[par][c]);
                         else if constexpr (st == 1) acc[par][c] = mfma16<F>(UX ? ux[0][c] : ua[slot][kc][0][c], vl[s][kc], acc[par][c]);
                         else acc[par][c] = mfma16<F>(UX ? ux[0][c] : ua[slot][kc][0][c], vh[s][kc], acc[par][c]);
@@ -881,7 +893,7 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
                         {
                             constexpr int code = w1_sched(y, m), kind = code >> 4;
                             using FR = std::integral_constant<int, (code & 15)>;
-                            if constexpr (code >= 0) {
+                            if constexpr (code >= 0 && !(W1_ABL & 1)) {
                                 if constexpr (kind == 0) w1_request<S1N>(ua, wnext + 16384, wlane, FR{});
                                 else if constexpr (kind == 1) {
                                     // (the next layer is odd when this one is even: its tap 2 / k-chunk 1 goes to the VGPR fragments)
@@ -945,9 +957,12 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
                 __syncthreads();
             }
         }
+        // a group that left the f16 range says so: the exact kernel behind this launch redoes the marked groups only
+        if (group_bits && !(amax < (float)kWsRangeLimit)) atomicOr(group_bits + (grp >> 5), 1 << (grp & 31));
         // next group's input planes: requested here, consumed after the heads
         const int next = __builtin_amdgcn_readfirstlane(*ticket_lds);   // (written before the stem's barriers)
         fetch_planes(next);
+        if constexpr (!(W1_ABL & 256))
         run_heads_x32<G, C, (G == 1 ? 2 : 1)>(smem, net, b0, batch, want_logits, policy, value, wave * 64 + fresh_lane(), wave,
                                               PROF && blockIdx.x == 0 && grp == (int)blockIdx.x ? net.timeline + 64 : nullptr);   // [64..66]: 1x1 convolutions done, barrier passed, FCs done
         __syncthreads();
@@ -959,10 +974,10 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1d_kernel(
 
 template <int G, bool PROF = false>
 int launch_w1d(tg_net *net, const float *planes, int batch, int want_logits, float *policy, float *value,
-               int *overflow, hipStream_t stream) {
+               int *overflow, int *group_bits, hipStream_t stream) {
     using C = WsCfg<G>;
     if (!PROF && net->dev.timeline)
-        return launch_w1d<G, true>(net, planes, batch, want_logits, policy, value, overflow, stream);
+        return launch_w1d<G, true>(net, planes, batch, want_logits, policy, value, overflow, group_bits, stream);
     auto kern = dualnet_fwd_w1d_kernel<G, PROF>;
     static std::atomic<uint64_t> configured{0};
     if (tg::first_on_device(configured, net->device))
@@ -971,7 +986,7 @@ int launch_w1d(tg_net *net, const float *planes, int batch, int want_logits, flo
     int grid = groups < net->num_cus ? groups : net->num_cus;
     if (const int cap = net->forward_grid_cap.load(); cap > 0 && grid > cap) grid = cap;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTHR), C::LDS_BYTES, stream, net->dev, planes, batch, want_logits,
-                       policy, value, overflow);
+                       policy, value, overflow, group_bits);
     TG_HIP(hipGetLastError());
     return TG_OK;
 }
@@ -1046,10 +1061,10 @@ int w1d_prepare(tg_net *net, const float *const *tower, const float *scale, cons
 }
 
 int w1d_forward(tg_net *net, int group, const float *planes, int batch, int want_logits, float *policy, float *value, int *overflow,
-                hipStream_t stream) {
+                int *group_bits, hipStream_t stream) {
     if (net->board_size != 9) return tg::fail(TG_ERR_ARG, "w1d forward: 9x9 only");
-    if (group == 3) return launch_w1d<3>(net, planes, batch, want_logits, policy, value, overflow, stream);
-    return launch_w1d<1>(net, planes, batch, want_logits, policy, value, overflow, stream);
+    if (group == 3) return launch_w1d<3>(net, planes, batch, want_logits, policy, value, overflow, group_bits, stream);
+    return launch_w1d<1>(net, planes, batch, want_logits, policy, value, overflow, group_bits, stream);
 }
 
 }  // namespace tg

@@ -33,6 +33,13 @@
 // Reference: nn/network/dual_net.py:41-106, nn/network/res_block.py:8-38 at BOARD_SIZE = 19 (board/constant.py:4).
 #include "w1d_common.h"
 
+// WB_ABL (experiments only, tools/experiments/wb_ablation.sh: results are wrong, the timing says what a class of riders costs):
+// 1 no weight requests, 2 no input transforms (and their cell reads), 4 no cell reads, 8 no epilogue arithmetic, 16 no exchange
+// traffic, 32 no stage barrier, 64 no hand-off between the bands, 128 no MFMAs
+#ifndef WB_ABL
+#define WB_ABL 0
+#endif
+
 namespace {
 
 constexpr int kWbSpinLimit = 1 << 17;                      // polls of the partner's sequence number (~ 0.1 s) before giving up
@@ -155,7 +162,7 @@ static_assert(kWbWaitTop == 16 && kWbWaitTap0 == 8 && kWbWaitTapP == 0, "request
 template <bool PROF>
 __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1dband_kernel(
     NetDev net, const float *__restrict__ planes, int batch, float *__restrict__ feat, float *__restrict__ xmem,
-    int *__restrict__ overflow) {
+    int *__restrict__ overflow, int *__restrict__ group_bits) {
     using C = WbCfg;
     using F = FmtF16;
     constexpr int S = C::S, P = C::P, NTHR = C::NTHR, RTW = C::RTW, IMG = C::IMG, ROWB = C::ROWB;
@@ -173,6 +180,9 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1dband_kernel(
     int *const seq_mine = reinterpret_cast<int *>(pmem + 4 * C::XROW_FLOATS) + band * 16;
     int *const seq_theirs = reinterpret_cast<int *>(pmem + 4 * C::XROW_FLOATS) + (1 - band) * 16;
     int *const dead = reinterpret_cast<int *>(smem + C::MISC);
+    // test hook (TG_WB_TEST_MUTE, through the launch's second flag word): band 1 keeps its sequence numbers to itself - band 0 runs
+    // into the bounded wait, the exact kernel redoes the batch
+    const bool mute = overflow && __builtin_amdgcn_readfirstlane(overflow[1]) != 0 && band == 1;
 
     if (static_cast<unsigned>(reinterpret_cast<size_t>((__attribute__((address_space(3))) unsigned char *)smem)) != 0u)
         __builtin_trap();                                  // absolute LDS addressing below
@@ -328,7 +338,7 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1dband_kernel(
             reinterpret_cast<float *>(smem + C::H_OFF + C::DUMP_REL)[fresh_lane()] = 0.f;
             reinterpret_cast<float *>(smem + C::H_OFF + C::ZERO_REL)[fresh_lane()] = 0.f;
         }
-        if (!(amax < (float)kWsRangeLimit)) ovf = 1;
+        if (!(amax < (float)kWsRangeLimit)) ovf |= 1;
         stamp(1);
 
         // ================= tower =================
@@ -419,12 +429,14 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1dband_kernel(
             // read I (0 .. 7) of a job: group (kc, channel half) = I >> 1 in the order (0, 0), (0, 1), (1, 0), (1, 1), cell a / b = I & 1
             auto rd = [&](auto IN_, auto OUT_, auto JOB_, auto I_) __attribute__((always_inline)) {
                 constexpr int i = decltype(I_)::value, cb = i & 1, g = i >> 1, kc = g >> 1, hh = g & 1;
+                if constexpr (WB_ABL & 4) return;
                 const int a = job_addr(IN_, OUT_, JOB_, std::integral_constant<int, cb>{});
                 dq[g & 1][cb] = lds_f32x4_at<0>(a ^ ((kc << 7) | (hh << 4)));
             };
             auto tr = [&](auto JOB_, auto I_) __attribute__((always_inline)) {
                 constexpr int job = decltype(JOB_)::value, j = job % 1000, i = decltype(I_)::value, g = i >> 2, kc = g >> 1, hh = g & 1, q = i & 3;
                 constexpr int sl = wb_slot(j);
+                if constexpr (WB_ABL & 2) return;
                 if constexpr (q == 0) {
                     tvv[0] = fmaf(dq[g & 1][1][0], sgn, dq[g & 1][0][0]);
                     tvv[1] = fmaf(dq[g & 1][1][1], sgn, dq[g & 1][0][1]);
@@ -517,12 +529,14 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1dband_kernel(
                     };
 #define WB_OADDR(e, store) ((store) ? out_addr(e) : (out_addr(e) >= C::DUMP_REL ? out_addr(e) + 256 : out_addr(e)))
                     if constexpr (i < 4) {
-                        lds_f32x4_put<par * 16384 + i * 1024>(exw, acc[0][i]);
+                        if constexpr (!(WB_ABL & 16)) lds_f32x4_put<par * 16384 + i * 1024>(exw, acc[0][i]);
                     } else if constexpr (i == 10) {
-                        __syncthreads();
+                        if constexpr (!(WB_ABL & 32)) __syncthreads();
                     } else if constexpr (i == 11 || i == 12) {
+                        if constexpr (!(WB_ABL & 16)) {
                         ez[2 * (i - 11)] = lds_f32x4_at<par * 16384 + (2 * (i - 11)) * 4096>(exr);
                         ez[2 * (i - 11) + 1] = lds_f32x4_at<par * 16384 + (2 * (i - 11) + 1) * 4096>(exr);
+                        }
                     } else if constexpr (i == 13) {
                         if constexpr (PREV) {
                             pshf = *reinterpret_cast<const f32x4 *>(smem + C::SH_OFF + (prev_layer * 64 + wave * 16 + glg * 4) * 4);
@@ -535,7 +549,8 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1dband_kernel(
                         }
                     } else if constexpr (i >= 19 && i < 35) {
                         constexpr int kk = i - 19, cc = kk >> 3, e = (kk >> 1) & 3, part = kk & 1;
-                        if constexpr (part == 0) {
+                        if constexpr (WB_ABL & 8) {
+                        } else if constexpr (part == 0) {
                             ev[cc][e] = cc == 0 ? (ez[0][e] + ez[1][e]) + ez[2][e] : (ez[1][e] - ez[2][e]) - ez[3][e];
                         } else {
                             float tt = fmaf(ev[cc][e], PREV ? pdown : down, PREV ? pshf[e] : shf[e]);   // (pshf: read where stage S's epilogue starts)
@@ -558,7 +573,11 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1dband_kernel(
                     using JA = std::integral_constant<int, st.after>;
                     using JL = std::integral_constant<int, st.late>;
                     // ---- before the stage ----
+#ifdef WB_PROF_FIRST
+                    if constexpr (PROF) { if (layer < 2) stamp(16 + 8 * PAR + n); }   // (experiments: the stages of a board's FIRST two layers)
+#else
                     if constexpr (PROF) stamp(16 + 8 * PAR + n);       // (every layer overwrites: the last conv1 / conv2 layers' stay)
+#endif
                     static_for<72>([&](auto M_) {
                         constexpr int m = decltype(M_)::value;
                         constexpr int NT = st.k == 3 ? 2 : 3;
@@ -583,14 +602,12 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1dband_kernel(
                                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tap +1; also: the edge stores of stage S (slices 39-42) have landed
                                 __builtin_amdgcn_sched_barrier(0);
                                 // ... so this wave's part of the previous layer's edge row is in memory: say so (the partner waits for all four waves)
-                                if (layer > 0 && glane == 0) __hip_atomic_store(seq_mine + wave, pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (layer > 0 && glane == 0 && !mute) __hip_atomic_store(seq_mine + wave, pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             }
-                            bool run = true;
-                            if constexpr (st.k == 3) run = band == 0;             // (uniform: band 1 has no row 9)
-                            if constexpr (st.k == 3 && q < 4 && ti == 0) {
-                                if (!run) acc[0][c] = f32x4{0.f, 0.f, 0.f, 0.f};    // (its null epilogue must not see a stale accumulator)
-                            }
-                            if (run) {
+                            // (Band 1 has no row 9: its stage S multiplies the zero row - the jobs of rows beyond lmax read it - and stores to
+                            // the dump row.  A uniform `if (band == 0)` around these 48 MFMAs cost a compare and a branch per MFMA in BOTH
+                            // bands, and band 1 gained nothing from skipping them: it waits for band 0's edge row a few stages later anyway.)
+                            if constexpr (!(WB_ABL & 128)) {
                                 if constexpr (pr == 0)
                                     acc[0][c] = mfma16<F>(ua[slot][kc][1][c], vh[vsl][kc], q < 4 && ti == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[0][c]);
                                 else if constexpr (pr == 1) acc[0][c] = mfma16<F>(ua[slot][kc][0][c], vl[vsl][kc], acc[0][c]);
@@ -608,7 +625,7 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1dband_kernel(
 #ifndef WB_EXP
 #define WB_EXP 0
 #endif
-                            if (layer > 0 && xo >= 0 && WB_EXP != 2) {
+                            if (layer > 0 && xo >= 0 && WB_EXP != 2 && !(WB_ABL & 64)) {
                                 f32x4 v = ev[e];
                                 if constexpr (hx == 0 && WB_EXP != 3) v = lds_f32x4_at<IN>(oS[0][e]);
                                 float *dst = pmem + (size_t)(band * 2 + ((pub - 1) & 1)) * C::XROW_FLOATS;
@@ -624,7 +641,7 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1dband_kernel(
                         {
                             constexpr int code = wb_wreq(n, m), kind = code >> 4;
                             using FR = std::integral_constant<int, (code & 15)>;
-                            if constexpr (code >= 0) {
+                            if constexpr (code >= 0 && !(WB_ABL & 1)) {
                                 if constexpr (kind == 0) w1_request<S1N>(ua, wnext + ky_m * 16384, wlane, FR{});
                                 else if constexpr (kind == 1) w1_request<0>(ua, wnext + 16384, wlane, FR{});
                                 else w1_request<2>(ua, wcur + ky_p * 16384, wlane, FR{});
@@ -633,7 +650,7 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1dband_kernel(
                         // hand-off riders
                         if constexpr (n == 3 && m == 40) {
                             // 1A: ask for the partner's four sequence numbers (looked at under 1B)
-                            if (layer > 0) {
+                            if (layer > 0 && !(WB_ABL & 64)) {
                                 int zoff = 0;
                                 asm volatile("" : "+v"(zoff));
                                 asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(flag_seen) : "v"(zoff), "s"(seq_theirs) : "memory");
@@ -641,7 +658,7 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1dband_kernel(
                         }
                         if constexpr (n == 4 && m == 16) {
                             // 1B: the partner's edge row of the previous layer must have been published by all of its waves ...
-                            if (layer > 0) {
+                            if (layer > 0 && !(WB_ABL & 64)) {
                                 asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // (1A's four weight requests lie behind the question)
                                 __builtin_amdgcn_sched_barrier(0);
                                 int seen = min(min(flag_seen[0], flag_seen[1]), min(flag_seen[2], flag_seen[3]));
@@ -677,10 +694,14 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1dband_kernel(
                         __builtin_amdgcn_sched_barrier(0);
                     });
                 });
-                if (!(amax < (float)kWsRangeLimit)) ovf = 1;
+                if (!(amax < (float)kWsRangeLimit)) ovf |= 1;
                 if constexpr (PROF) {
                     stamp(2 + layer);
+#ifdef WB_PROF_FIRST
+                    if (layer < 2) stamp(16 + 8 * PAR + 7);
+#else
                     stamp(16 + 8 * PAR + 7);
+#endif
                 }
             };
             using IX = std::integral_constant<int, C::X_OFF>;
@@ -717,11 +738,13 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1dband_kernel(
                 }
                 lds_f32x4_put<C::X_OFF>(o0, ev[0]);
                 lds_f32x4_put<C::X_OFF>(o1, ev[1]);
-                if (!(amax < (float)kWsRangeLimit)) ovf = 1;
+                if (!(amax < (float)kWsRangeLimit)) ovf |= 1;
                 __syncthreads();
             }
         }
-        if (*reinterpret_cast<volatile int *>(dead)) ovf = 1;
+        if (*reinterpret_cast<volatile int *>(dead)) ovf |= 2;   // (a partner that did not show up: the exact kernel redoes the whole batch)
+        // a board that left the f16 range says so: the exact kernel behind this launch redoes the marked boards only
+        if (group_bits && !(amax < (float)kWsRangeLimit)) atomicOr(group_bits + (b >> 5), 1 << (b & 31));
         // next board's planes: requested here, consumed after the head convolutions
         fetch_planes(b + n_pairs);
         // ================= heads, first part: the three 1x1 convolutions of the band's cells (fp32), batch norm, ReLU -> feat =================
@@ -760,7 +783,7 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1dband_kernel(
                 net.timeline[band * 64 + tid] = reinterpret_cast<volatile long long *>(smem + C::PROF_OFF)[tid];
         }
     }
-    if (ovf && overflow) atomicOr(overflow, 1);
+    if (ovf && overflow) atomicOr(overflow, ovf);
 }
 
 // The two fully connected layers + softmaxes of a 19x19 launch, on the features dualnet_fwd_w1dband_kernel left in global memory
@@ -922,7 +945,9 @@ namespace tg {
 
 // pairs of workgroups a launch of `batch` boards would use (0: TG_FWD_ALGO / a shared device keep it off - see w1dband_wanted)
 int w1dband_pairs(const tg_net *net, int batch) {
-    const int cap = net->num_cus / 2;
+    int cus = net->num_cus;
+    if (const int fc = net->forward_grid_cap.load(); fc > 0 && fc < cus) cus = fc;   // (a self-play move's sub-groups: CUs left to the other streams' tree kernels)
+    const int cap = cus / 2;
     int pairs = batch < cap ? batch : cap;
     if (pairs >= 8) pairs &= ~7;                           // partners on the same XCD (consecutive workgroups go round the eight)
     return pairs;
@@ -931,7 +956,7 @@ int w1dband_pairs(const tg_net *net, int batch) {
 // scratch: per pair the exchange rows and sequence numbers (zeroed once: the numbers only grow within a launch and every
 // launch zeroes them again - memset node in front of the kernel), then the feature image [batch][3][361]
 int w1dband_forward(tg_net *net, const float *planes, int batch, int want_logits, float *policy, float *value, int *overflow,
-                    hipStream_t stream) {
+                    int *group_bits, hipStream_t stream) {
     using C = WbCfg;
     if (net->board_size != 19) return tg::fail(TG_ERR_ARG, "w1dband forward: 19x19 only");
     auto kern = net->dev.timeline ? dualnet_fwd_w1dband_kernel<true> : dualnet_fwd_w1dband_kernel<false>;
@@ -958,10 +983,23 @@ int w1dband_forward(tg_net *net, const float *planes, int batch, int want_logits
         }
         xmem = slot.mem;
         feat = slot.mem + xfloats;
+        // one cross-workgroup launch at a time on the device (as launch_band does, and sharing its state): two launches that each
+        // got half of their workgroups onto the CUs would hold each other's partner bands off until the bounded waits give up.
+        // When the launch stream changes, the new stream waits for what the previous one has queued.
+        if (net->band_recorded && net->band_stream != stream) {
+            if (!net->band_done) TG_HIP(hipEventCreateWithFlags(&net->band_done, hipEventDisableTiming));
+            if (hipEventRecord(net->band_done, net->band_stream) == hipSuccess)
+                TG_HIP(hipStreamWaitEvent(stream, net->band_done, 0));
+            else
+                (void)hipGetLastError();                   // (the previous stream is gone: nothing of it can be in flight)
+        }
+        net->band_stream = stream;
+        net->band_recorded = true;
     }
     // the sequence numbers start from zero in every launch
     TG_HIP(hipMemsetAsync(xmem, 0, xfloats * sizeof(float), stream));
-    hipLaunchKernelGGL(kern, dim3(2 * pairs), dim3(C::NTHR), C::LDS_BYTES, stream, net->dev, planes, batch, feat, xmem, overflow);
+    if (getenv("TG_WB_TEST_MUTE")) TG_HIP(hipMemsetAsync(overflow + 1, 1, 1, stream));      // (tests: a non-zero second flag word mutes band 1)
+    hipLaunchKernelGGL(kern, dim3(2 * pairs), dim3(C::NTHR), C::LDS_BYTES, stream, net->dev, planes, batch, feat, xmem, overflow, group_bits);
     TG_HIP(hipGetLastError());
     if (batch <= 512) {
         // partial sums [batch][4][384] behind the feature image

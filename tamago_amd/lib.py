@@ -56,6 +56,7 @@ _SIGNATURES = {
     "tg_net_flops_per_position": (c_double, [c_int]),
     "tg_net_executed_flops_per_position": (c_double, [c_void_p, c_int, POINTER(c_double), POINTER(c_char_p)]),
     "tg_net_range_fallbacks": (c_int, [c_void_p, POINTER(ctypes.c_ulonglong)]),
+    "tg_net_range_fallback_positions": (c_int, [c_void_p, POINTER(ctypes.c_ulonglong)]),
     "tg_net_band_timeouts": (c_int, [c_void_p, POINTER(ctypes.c_ulonglong)]),
     "tg_net_set_shared_device": (c_int, [c_void_p, c_int]),
     "tg_featurize_dev": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,

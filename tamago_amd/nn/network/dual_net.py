@@ -135,6 +135,13 @@ class DualNet:
         _lib.check(self._lib.tg_net_range_fallbacks(self._handle, ctypes.byref(count)), "tg_net_range_fallbacks")
         return int(count.value)
 
+    def range_fallback_positions(self) -> int:
+        """Positions the exact-fp32 kernel redid in those launches (tg_net_range_fallback_positions): the one-axis Winograd kernels
+        mark the workgroup passes that left the range, only those are redone."""
+        count = ctypes.c_ulonglong(0)
+        _lib.check(self._lib.tg_net_range_fallback_positions(self._handle, ctypes.byref(count)), "tg_net_range_fallback_positions")
+        return int(count.value)
+
     def band_timeouts(self) -> int:
         """19x19: bounded waits of the banded forward kernels that gave up (tg_net_band_timeouts; synchronises the device).
         Each one is also a range fallback; after the first the network keeps to the one-workgroup kernel."""

@@ -117,13 +117,14 @@ def test_featurize_kernel_vs_reference_golden(size):
 
 
 @pytest.mark.parametrize("size,algo", [(9, "direct"), (9, "wino"), (9, "split16"), (9, "w1d"),
-                                       (19, "direct"), (19, "wino"), (19, "split16")])
+                                       (19, "direct"), (19, "wino"), (19, "split16"), (19, "w1dband")])
 def test_every_tower_algorithm_matches_the_oracle(algo, size, monkeypatch):
     """Implementations of the residual tower: exact-fp32 Winograd F(2x2,3x3) kernel (TG_FWD_ALGO=wino; the
     layer outputs of a 19x19 board passing through a global scratch image), exact-fp32 direct implicit GEMM
     (direct), and the split-operand kernels on the 16-bit matrix pipe (split16 = f16 x 2 pieces, one wave per SIMD,
     at both sizes; 19x19: one board per workgroup, residual image in an L2-resident scratch; w1d = Winograd F(2,3) along
-    x only on the same operand pieces, the 9x9 default).  All must agree with the oracle at every workgroup shape.
+    x only on the same operand pieces, the 9x9 default; w1dband = the same tower at 19x19, a board over two workgroups, the
+    19x19 default since round 5).  All must agree with the oracle at every workgroup shape.
     (Round 5: the two-waves-per-SIMD and 2-D Winograd kernels, measured slower, left the library - tools/experiments/kernels/.)"""
     from oracle.net import OracleNet, make_state_dict
     monkeypatch.setenv("TG_FWD_ALGO", algo)
@@ -191,6 +192,7 @@ def test_banded_19x19_kernel_equals_the_one_workgroup_kernel(monkeypatch):
     sd = make_state_dict(19, 3, 1.4)
     net = _net(19, sd)
     x = torch.from_numpy(np.random.RandomState(8).randint(-1, 2, size=(140, 6, 19, 19)).astype(np.float32))
+    monkeypatch.setenv("TG_FWD_ALGO", "split16")                   # (the default is the one-axis Winograd pair kernel, below)
     assert lib.tg_net_kernel_name(net.handle, 64).decode() == "dualnet_fwd_band_kernel<4>"
     assert lib.tg_net_kernel_name(net.handle, 100).decode() == "dualnet_fwd_band_kernel<2>"
     assert lib.tg_net_kernel_name(net.handle, 140).decode() == "dualnet_fwd_split_kernel<19, 1, f16x2>"
@@ -209,6 +211,7 @@ def test_banded_19x19_kernel_equals_the_one_workgroup_kernel(monkeypatch):
     plain = net.inference_with_policy_logits(x[:64])
     assert torch.equal(plain[0], four[0]) and torch.equal(plain[1], four[1])
     monkeypatch.delenv("TG_FWD_BANDS")
+    monkeypatch.setenv("TG_FWD_ALGO", "split16")
     rp, rv = OracleNet(sd).inference(x[:8])
     pol, val = net.inference(x[:8])
     assert np.abs(pol.numpy() - rp.numpy()).max() < TOL and np.abs(val.numpy() - rv.numpy()).max() < TOL
@@ -226,6 +229,7 @@ def test_banded_kernel_cannot_hang_a_silent_band_ends_in_the_exact_fallback(monk
     sd = make_state_dict(19, 4, 1.2)
     net = _net(19, sd)
     x = torch.from_numpy(np.random.RandomState(9).randint(-1, 2, size=(4, 6, 19, 19)).astype(np.float32))
+    monkeypatch.setenv("TG_FWD_ALGO", "split16")
     good = net.inference(x)
     assert net.range_fallbacks() == 0
     monkeypatch.setenv("TG_BAND_TEST_MUTE", "1")
@@ -253,16 +257,61 @@ def test_a_shared_device_keeps_19x19_launches_on_the_one_workgroup_kernel(monkey
     from oracle.net import make_state_dict
     from tamago_amd import lib as tl
     monkeypatch.delenv("TG_FWD_BANDS", raising=False)
-    net = _net(19, make_state_dict(19, 4, 1.2))
-    lib = tl.load()
     x = torch.from_numpy(np.random.RandomState(10).randint(-1, 2, size=(16, 6, 19, 19)).astype(np.float32))
-    assert b"band" in lib.tg_net_kernel_name(net.handle, 16)
-    banded = net.inference(x)
-    net.set_shared_device(True)
-    assert b"band" not in lib.tg_net_kernel_name(net.handle, 16)
-    alone = net.inference(x)
-    assert torch.equal(alone[0], banded[0]) and torch.equal(alone[1], banded[1])
-    assert net.band_timeouts() == 0 and net.range_fallbacks() == 0
+    lib = tl.load()
+    for algo in ("split16", None):                                   # the banded direct kernel by name, the pair kernel by default
+        if algo:
+            monkeypatch.setenv("TG_FWD_ALGO", algo)
+        else:
+            monkeypatch.delenv("TG_FWD_ALGO")
+        net = _net(19, make_state_dict(19, 4, 1.2))
+        assert b"band" in lib.tg_net_kernel_name(net.handle, 16)
+        banded = net.inference(x)
+        net.set_shared_device(True)
+        assert lib.tg_net_kernel_name(net.handle, 16).decode() == "dualnet_fwd_split_kernel<19, 1, f16x2>"
+        alone = net.inference(x)
+        if algo:                                                     # (same arithmetic in the same order: same bits)
+            assert torch.equal(alone[0], banded[0]) and torch.equal(alone[1], banded[1])
+        else:                                                        # (Winograd vs direct: the tolerance)
+            assert (alone[0] - banded[0]).abs().max() < TOL and (alone[1] - banded[1]).abs().max() < TOL
+        assert net.band_timeouts() == 0 and net.range_fallbacks() == 0
+
+
+def test_pair_kernel_19x19_launch_sizes_repeats_and_the_bounded_wait(monkeypatch):
+    """dualnet_fwd_w1dband_kernel (the 19x19 default): a position's bits do not depend on the launch it is part of (1 board, fewer
+    boards than pairs of CUs, several boards per pair), repeats leave nothing behind in the sequence numbers, and a partner
+    band that never publishes (TG_WB_TEST_MUTE) ends in the bounded wait -> exact fallback, counted as a band time-out, after
+    which the network stays on the one-workgroup kernel."""
+    import time
+    from oracle.net import OracleNet, make_state_dict
+    from tamago_amd import lib as tl
+    lib = tl.load()
+    monkeypatch.delenv("TG_FWD_ALGO", raising=False)
+    monkeypatch.delenv("TG_FWD_BANDS", raising=False)
+    sd = make_state_dict(19, 6, 1.3)
+    net = _net(19, sd)
+    assert lib.tg_net_kernel_name(net.handle, 64).decode() == "dualnet_fwd_w1dband_kernel + dualnet_heads19_kernel"
+    x = torch.from_numpy(np.random.RandomState(12).randint(-1, 2, size=(600, 6, 19, 19)).astype(np.float32))
+    big = net.inference_with_policy_logits(x)
+    for lo, hi in ((0, 40), (77, 78), (300, 500), (597, 600)):
+        for _ in range(2):
+            part = net.inference_with_policy_logits(x[lo:hi])
+            assert torch.equal(part[0], big[0][lo:hi]) and torch.equal(part[1], big[1][lo:hi]), (lo, hi)
+    rp, rv = OracleNet(sd).inference(x[:6])
+    pol, val = net.inference(x[:6])
+    assert np.abs(pol.numpy() - rp.numpy()).max() < TOL and np.abs(val.numpy() - rv.numpy()).max() < TOL
+    assert net.range_fallbacks() == 0 and net.band_timeouts() == 0
+    monkeypatch.setenv("TG_WB_TEST_MUTE", "1")
+    t0 = time.perf_counter()
+    pol2, val2 = net.inference(x[:6])
+    dt = time.perf_counter() - t0
+    monkeypatch.delenv("TG_WB_TEST_MUTE")
+    assert dt < 20.0, dt
+    assert net.range_fallbacks() == 1 and net.band_timeouts() >= 1
+    assert np.abs(pol2.numpy() - rp.numpy()).max() < TOL and np.abs(val2.numpy() - rv.numpy()).max() < TOL
+    assert b"band" not in lib.tg_net_kernel_name(net.handle, 6)
+    net.inference(x[:6])
+    assert net.range_fallbacks() == 1
 
 
 def test_kernel_name_and_executed_flops_know_the_ragged_tail_split(monkeypatch):
@@ -330,3 +379,35 @@ def test_split_kernels_are_fp32_class_and_fall_back_on_f16_overflow(monkeypatch)
         healthy = _net(9, make_state_dict(9, 3, 1.4))
         healthy.inference_with_policy_logits(x)
         assert healthy.range_fallbacks() == 0, algo
+
+
+def test_one_hot_position_costs_one_groups_redo(monkeypatch):
+    """The f16 range guard at group granularity (round 5): the one-axis Winograd kernels mark the workgroup passes whose activations
+    left the f16 range, and the exact-fp32 kernel queued behind the launch redoes THOSE - three positions (a 9x9 group) or one
+    board (19x19), not the launch.  Every other position keeps the bits of an undisturbed launch; the hot position gets the
+    exact kernel's result; the counters say so (tg_net_range_fallbacks / tg_net_range_fallback_positions)."""
+    from oracle.net import make_state_dict
+    monkeypatch.delenv("TG_FWD_ALGO", raising=False)
+    for size, n, hot in ((9, 1000, 77), (9, 200, 140), (19, 40, 5)):      # three-board groups; one-board workgroups; a 19x19 board
+        sd = make_state_dict(size, 9, 1.4)
+        x = torch.from_numpy(np.random.RandomState(21).randint(-1, 2, size=(n, 6, size, size)).astype(np.float32))
+        net = _net(size, sd)
+        clean = net.inference_with_policy_logits(x)
+        assert net.range_fallbacks() == 0 and net.range_fallback_positions() == 0
+        xh = x.clone()
+        xh[hot] *= 3.0e4                                                  # stem output ~1e5: beyond the guard's 16 000
+        got = net.inference_with_policy_logits(xh)
+        group = 3 if (size == 9 and n > 256) else 1
+        lo = hot - hot % group
+        assert net.range_fallbacks() == 1 and net.range_fallback_positions() == group, (size, n)
+        keep = torch.ones(n, dtype=torch.bool)
+        keep[lo:lo + group] = False
+        assert torch.equal(got[0][keep], clean[0][keep]) and torch.equal(got[1][keep], clean[1][keep])
+        monkeypatch.setenv("TG_FWD_ALGO", "wino")
+        exact = _net(size, sd).inference_with_policy_logits(xh[lo:lo + group])
+        monkeypatch.delenv("TG_FWD_ALGO")
+        assert torch.isfinite(got[0]).all()
+        assert torch.equal(got[0][lo:lo + group], exact[0]) and torch.equal(got[1][lo:lo + group], exact[1])
+        # the bitmap is clean again: the next launch redoes nothing
+        again = net.inference_with_policy_logits(x)
+        assert torch.equal(again[0], clean[0]) and net.range_fallbacks() == 1 and net.range_fallback_positions() == group

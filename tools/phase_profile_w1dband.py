@@ -9,6 +9,8 @@ import numpy as np
 import torch
 from tamago_amd.nn.network.dual_net import DualNet
 from tamago_amd import lib as tl
+if os.environ.get("TG_EXP_LIB"):                            # an alternative build (tools/experiments/_bin/libtamago_exp<N>.so)
+    tl.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "experiments", "_bin", f"libtamago_exp{os.environ['TG_EXP_LIB']}.so")
 
 lib = tl.load()
 net = DualNet(torch.device("cuda:0"), 19)
