@@ -225,6 +225,16 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1dband_kernel(
         }
     };
     fetch_planes(pair);
+    // Which way the edge rows travel.  HIP promises nothing about where a workgroup runs (observed: workgroup b on XCD b mod 8 - the
+    // launch numbers partners eight apart for that), so the two bands TELL each other: each publishes its XCD (agent scope), reads
+    // the partner's behind the first board's stem, and both take the L2 path - plain stores, reads past the vector L1 - only when
+    // the numbers agree; a partner that is not there yet when asked, or anywhere else, means agent scope (correct everywhere).
+    int my_xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
+    my_xcc = (my_xcc & 15) + 1;
+    int *const xcc_slot = reinterpret_cast<int *>(pmem + 4 * C::XROW_FLOATS) + 32;   // [band 2], behind the sequence numbers ([band][16])
+    if (tid == 0) __hip_atomic_store(xcc_slot + band, my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int l2x = 0;
     const float sgn = wave == 1 ? 1.f : -1.f;
     // taps along y in local order d = -1, 0, +1 (input row l + d): band 1 runs down the board (ky = 1 + d), band 0 up (ky = 1 - d)
     const int ky_m = band == 1 ? 0 : 2, ky_p = band == 1 ? 2 : 0;
@@ -339,6 +349,20 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1dband_kernel(
             reinterpret_cast<float *>(smem + C::H_OFF + C::ZERO_REL)[fresh_lane()] = 0.f;
         }
         if (!(amax < (float)kWsRangeLimit)) ovf |= 1;
+        if (kiter == 0) {
+            // (both bands ask at the same point of their first board and both have published before their stem: they read the same two
+            // numbers unless one of them started more than a stem late - then BOTH must fall back, so the late one's own answer does not
+            // count either: a band takes the L2 path only if the partner's number was there within the bounded look AND the partner
+            // says the same about ours - it publishes its verdict, we read it before the first row travels (layer 1))
+            int theirs = 0;
+            for (int spin = 0; spin < 4096 && theirs == 0; ++spin) {
+                theirs = __hip_atomic_load(xcc_slot + (1 - band), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (theirs == 0) __builtin_amdgcn_s_sleep(2);
+            }
+            theirs = __builtin_amdgcn_readfirstlane(theirs);
+            l2x = theirs == my_xcc ? 1 : 0;
+            if (tid == 0) __hip_atomic_store(xcc_slot + 2 + band, l2x ? 2 : 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         stamp(1);
 
         // ================= tower =================
@@ -500,6 +524,23 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1dband_kernel(
                     job_now(IN_, OUT_, std::integral_constant<int, 200 + 8>{});
                     job_now(IN_, OUT_, std::integral_constant<int, 200 + 9>{});
                 }
+                if (layer == 1 && kiter == 0) {
+                    // the first edge row is about to travel: the partner's verdict on the L2 path (published behind its first stem, a
+                    // layer ago).  Both verdicts must be "yes"; one that does not come at all is a partner that is not there - the
+                    // bounded wait of the hand-off would find that out a few stages later anyway.
+                    int theirs = 0, spins = 0;
+                    while (theirs == 0) {
+                        theirs = __hip_atomic_load(xcc_slot + 2 + (1 - band), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (theirs == 0) {
+                            __builtin_amdgcn_s_sleep(2);
+                            if (++spins > kWbSpinLimit) {
+                                *reinterpret_cast<volatile int *>(dead) = 1;
+                                break;
+                            }
+                        }
+                    }
+                    if (__builtin_amdgcn_readfirstlane(theirs) != 2) l2x = 0;
+                }
                 // tap -1 of this layer has arrived (and with it everything requested before 0B: the next shift / scale, the halo copy)
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kWbWaitTop) : "memory");
                 __builtin_amdgcn_sched_barrier(0);
@@ -622,15 +663,14 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1dband_kernel(
                             // because a store's acknowledgement takes ~1 us and every counted wait behind it waits for it: the next one is 2A's slice 48.
                             constexpr int hx = (m - 39) >> 1, e = (m - 39) & 1;
                             const int xo = x_off(hx, e);
-#ifndef WB_EXP
-#define WB_EXP 0
-#endif
-                            if (layer > 0 && xo >= 0 && WB_EXP != 2 && !(WB_ABL & 64)) {
+                            if (layer > 0 && xo >= 0 && !(WB_ABL & 64)) {
                                 f32x4 v = ev[e];
-                                if constexpr (hx == 0 && WB_EXP != 3) v = lds_f32x4_at<IN>(oS[0][e]);
+                                if constexpr (hx == 0) v = lds_f32x4_at<IN>(oS[0][e]);
                                 float *dst = pmem + (size_t)(band * 2 + ((pub - 1) & 1)) * C::XROW_FLOATS;
                                 const float *pp = reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(dst) + xo);
-                                if constexpr (WB_EXP == 1) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(pp), "v"(v) : "memory");
+                                // (partner on this XCD: a plain store - the vector L1 writes through to the shared L2 and the row stays there;
+                                // otherwise agent scope: written through to the fabric)
+                                if (l2x) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(pp), "v"(v) : "memory");
                                 else asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(pp), "v"(v) : "memory");
                             }
                         }
@@ -680,11 +720,20 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1dband_kernel(
                                 const float *src = pmem + (size_t)((1 - band) * 2 + ((pub - 1) & 1)) * C::XROW_FLOATS;
                                 int dl = glane * 16;
                                 asm volatile("" : "+v"(dl));                      // (per layer: a 64-bit per-lane pointer kept across the block loop is two spilled registers)
-                                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const unsigned char *>(src) + wave * 1024 + dl),
-                                                                 (__attribute__((address_space(3))) void *)(smem + IN + wave * 1024), 16, 0, 16);
-                                if (wave == 0 && dl < 48 * 16)
-                                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const unsigned char *>(src) + 4096 + dl),
-                                                                     (__attribute__((address_space(3))) void *)(smem + IN + 4096), 16, 0, 16);
+                                // (aux 16 = sc1: agent scope; aux 2 = nt: past this CU's vector L1, from the XCD's L2 - tools/microbench/xwg_pingpong.hip variant 1)
+                                if (l2x) {
+                                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const unsigned char *>(src) + wave * 1024 + dl),
+                                                                     (__attribute__((address_space(3))) void *)(smem + IN + wave * 1024), 16, 0, 2);
+                                    if (wave == 0 && dl < 48 * 16)
+                                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const unsigned char *>(src) + 4096 + dl),
+                                                                         (__attribute__((address_space(3))) void *)(smem + IN + 4096), 16, 0, 2);
+                                } else {
+                                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const unsigned char *>(src) + wave * 1024 + dl),
+                                                                     (__attribute__((address_space(3))) void *)(smem + IN + wave * 1024), 16, 0, 16);
+                                    if (wave == 0 && dl < 48 * 16)
+                                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const unsigned char *>(src) + 4096 + dl),
+                                                                         (__attribute__((address_space(3))) void *)(smem + IN + 4096), 16, 0, 16);
+                                }
                             }
                         }
                         if constexpr (n == 5 && m == 9) {
