@@ -184,6 +184,14 @@ int tg_search_rng_consumed(tg_search *s, int64_t *consumed_host);
  * queued per tree (== max_leaves unless the tree hit an error). */
 int tg_search_select_puct(tg_search *s, int max_leaves, float *planes_dev, int32_t *n_leaves_dev,
                           void *stream);
+/* n_batches PUCT mini-batches (leaves_host[b] descents per tree each) queued back to back on `stream`: one random window from the
+ * library's streams for all of them (tg_search_feed_streams semantics, force_window as its `force`), then per mini-batch
+ * tg_search_select_puct, tg_net_forward_dev (want_logits 0) and tg_search_backup - the launches of the per-mini-batch calls
+ * without the host round trip between them.  For searches whose course does not depend on what a mini-batch found (the
+ * reference's STRICT_PLAYOUT: no early stop, mcts/time_manager.py:160-161; mcts/tree.py:146-152).  policy_dev [T * batch_size, A],
+ * value_dev [T * batch_size, 3] and planes_dev are reused by every mini-batch.  Afterwards: tg_search_advance_streams. */
+int tg_search_puct_chain(tg_search *s, tg_net *net, const int32_t *leaves_host, int n_batches, int force_window,
+                         float *planes_dev, float *policy_dev, float *value_dev, void *stream);
 /* Reset every tree to its root position, expand the root (consumes the root's Dirichlet
  * draw) and write the root planes [T,6,S,S] (tree.py:49-53); one leaf per tree is queued. */
 int tg_search_root_planes(tg_search *s, float *planes_dev, void *stream);

@@ -910,7 +910,7 @@ template <int TB>
 __global__ __launch_bounds__(384) void dualnet_heads19_kernel(NetDev net, const float *__restrict__ feat, int batch, int want_logits,
                                                               float *__restrict__ policy, float *__restrict__ value) {
     constexpr int P = 361, A = 362;
-    __shared__ float f[TB][3 * P + 1];
+    __shared__ __attribute__((aligned(16))) float f[TB][3 * P + 1];     // (row stride 1 084 floats: a multiple of four)
     __shared__ float lg[TB][A + 2];
     __shared__ float vl[TB][4];
     const int tid = threadIdx.x, b0 = blockIdx.x * TB;
@@ -929,12 +929,30 @@ __global__ __launch_bounds__(384) void dualnet_heads19_kernel(NetDev net, const 
             float r[TB];
 #pragma unroll
             for (int bl = 0; bl < TB; ++bl) r[bl] = 0.f;
-#pragma unroll 2
-            for (int j = 0; j < n; ++j) {
-                const float w = wT[(size_t)(j0 + j) * A];
+            // (the same chain of FMAs per board, inputs in ascending order; the features of four inputs come with ONE 16-byte LDS
+            // read per board - sixteen broadcast ds_read_b32 per input were what this loop issued, 63 % of its time waiting -
+            // and four matrix rows are in flight at a time)
+            auto one = [&](int jj) {
+                const float w = wT[(size_t)jj * A];
 #pragma unroll
-                for (int bl = 0; bl < TB; ++bl) r[bl] = fmaf(f[bl][j0 + j], w, r[bl]);
+                for (int bl = 0; bl < TB; ++bl) r[bl] = fmaf(f[bl][jj], w, r[bl]);
+            };
+            int j = j0;
+            const int jend = j0 + n;
+            for (; j < jend && (j & 3); ++j) one(j);
+#pragma unroll 2
+            for (; j + 4 <= jend; j += 4) {
+                const float w0 = wT[(size_t)j * A], w1 = wT[(size_t)(j + 1) * A], w2 = wT[(size_t)(j + 2) * A], w3 = wT[(size_t)(j + 3) * A];
+#pragma unroll
+                for (int bl = 0; bl < TB; ++bl) {
+                    const f32x4 fv = *reinterpret_cast<const f32x4 *>(&f[bl][j]);
+                    r[bl] = fmaf(fv[0], w0, r[bl]);
+                    r[bl] = fmaf(fv[1], w1, r[bl]);
+                    r[bl] = fmaf(fv[2], w2, r[bl]);
+                    r[bl] = fmaf(fv[3], w3, r[bl]);
+                }
             }
+            for (; j < jend; ++j) one(j);
 #pragma unroll
             for (int bl = 0; bl < TB; ++bl) {
                 if (q == 0) s[bl] = r[bl];

@@ -4103,9 +4103,12 @@ static int feed_streams_impl(tg_search *s, size_t need, int force, size_t first)
     const double tf0 = feed_timing ? clk() : 0.0;
     size_t generated = 0;
     for (int t = 0; t < T && feed_timing; ++t) generated += s->streams[t].available() < need ? need - s->streams[t].available() : 0;
+    // (a split upload generates only what its first part carries: a stream that was re-seeded for this search - search_best_move
+    // hands numpy's state over per move, mcts/tree.py:49 - has nothing staged, and the draws of a whole search, ~80 k exponentials
+    // at 9x9, are 0.4 ms of MT19937 + log that the first selection launch need not wait for: feed_streams_rest generates the rest)
     parallel_trees(T, [&](int t) {
         tg::LegacyStream &ls = s->streams[t];
-        ls.ensure(need);
+        ls.ensure(cols);
         std::memcpy(stage + (size_t)t * need, ls.data(), cols * sizeof(double));
     });
     const double tf1 = feed_timing ? clk() : 0.0;
@@ -4148,6 +4151,7 @@ static int feed_streams_rest(tg_search *s) {
     wait_prefill(s);
     double *stage = s->stage[idx];
     parallel_trees(T, [&](int t) {                 // (nothing was consumed in between: the rows continue where part one stopped)
+        s->streams[t].ensure(need);
         std::memcpy(stage + (size_t)t * need + first, s->streams[t].data() + first, cols * sizeof(double));
     });
     TG_HIP(hipMemcpy2DAsync(s->rng_buf[idx] + first, need * sizeof(double), stage + first, need * sizeof(double), cols * sizeof(double), T,
@@ -4155,6 +4159,31 @@ static int feed_streams_rest(tg_search *s) {
     TG_HIP(hipEventRecord(s->ev_rng[idx], s->copy_stream));     // also the new guard of the staging buffer
     s->rng_rest_wait = true;                       // the next selection launch waits for this event
     start_prefill(s, need);
+    return TG_OK;
+}
+
+// A split upload continued piece by piece (tg_search_puct_chain): the columns up to `upto` of the window whose first part
+// feed_streams_impl sent - generated now -, and `st` waits for them.  The device cursor of a tree never passes the columns its
+// launched selections may consume (leaves x A each), so a launch only needs the pieces up to its own.
+static int feed_streams_part(tg_search *s, size_t upto, hipStream_t st) {
+    if (!s->rng_rest_cols) return TG_OK;
+    const int T = s->dev.T, idx = s->rng_rest_idx;
+    const size_t need = s->rng_rest_first + s->rng_rest_cols, first = s->rng_rest_first;
+    if (upto > need) upto = need;
+    if (upto <= first) return TG_OK;
+    const size_t cols = upto - first;
+    wait_prefill(s);
+    double *stage = s->stage[idx];
+    parallel_trees(T, [&](int t) {
+        s->streams[t].ensure(upto);
+        std::memcpy(stage + (size_t)t * need + first, s->streams[t].data() + first, cols * sizeof(double));
+    });
+    TG_HIP(hipMemcpy2DAsync(s->rng_buf[idx] + first, need * sizeof(double), stage + first, need * sizeof(double), cols * sizeof(double), T,
+                            hipMemcpyHostToDevice, s->copy_stream));
+    TG_HIP(hipEventRecord(s->ev_rng[idx], s->copy_stream));     // also the new guard of the staging buffer
+    TG_HIP(hipStreamWaitEvent(st, s->ev_rng[idx], 0));
+    s->rng_rest_first = upto;
+    s->rng_rest_cols = need - upto;
     return TG_OK;
 }
 
@@ -5069,6 +5098,43 @@ static int play_move_sync(tg_selfplay *sp, tg_net *net, float *planes_dev, float
                           void *stream, int32_t *finished_host, int64_t *stats_host);
 static int play_move_chain(tg_selfplay *sp, tg_net *net, float *planes_dev, float *policy_dev, float *value_dev,
                            void *stream, int32_t *finished_host, int64_t *stats_host);
+
+// PUCT mini-batches queued back to back (mcts/tree.py:146-152 with process_mini_batch, :273-315): ONE random window for all of them
+// - uploaded in two parts, the first mini-batch's share in front of its selection launch, the rest behind it -, then per mini-batch
+// selection, forward pass, backup on `stream`, with no host round trip in between.  The same launches on the same data as the
+// per-mini-batch calls; for searches whose course does not depend on a mini-batch's outcome (STRICT_PLAYOUT, time_manager.py:160-161).
+// The caller reads the cursors back afterwards (tg_search_advance_streams), as after a single mini-batch.
+int tg_search_puct_chain(tg_search *s, tg_net *net, const int32_t *leaves_host, int n_batches, int force_window,
+                         float *planes_dev, float *policy_dev, float *value_dev, void *stream) {
+    if (!s || !net || !leaves_host || !planes_dev || !policy_dev || !value_dev)
+        return tg::fail(TG_ERR_ARG, "tg_search_puct_chain: null argument");
+    if (n_batches < 1) return tg::fail(TG_ERR_ARG, "tg_search_puct_chain: no mini-batch");
+    if (tg_net_board_size(net) != s->S) return tg::fail(TG_ERR_ARG, "tg_search_puct_chain: network and search differ in board size");
+    size_t total = 0;
+    for (int b = 0; b < n_batches; ++b) {
+        if (leaves_host[b] < 1 || leaves_host[b] > s->dev.K)
+            return tg::fail(TG_ERR_ARG, "tg_search_puct_chain: mini-batch %d of %d leaves outside [1, batch_size]", b, leaves_host[b]);
+        total += (size_t)leaves_host[b];
+    }
+    const size_t A = (size_t)s->A;
+    // The window goes up one mini-batch's share at a time, each generated (MT19937 + log on this thread: ~90 us per 21 k draws)
+    // and uploaded while the launches of the mini-batch before it run (select + forward + backup: 0.3 - 0.45 ms): a search that
+    // starts from a freshly seeded stream - search_best_move hands numpy's state over per move - has nothing staged.
+    int rc = feed_streams_impl(s, total * A, force_window, n_batches > 1 ? (size_t)leaves_host[0] * A : 0);
+    if (rc) return rc;
+    const bool pieces = s->rng_rest_cols > 0;                            // (a new window was started and split)
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    size_t upto = 0;
+    for (int b = 0; b < n_batches; ++b) {
+        const int k = leaves_host[b];
+        upto += (size_t)k * A;
+        if (b > 0 && pieces && (rc = feed_streams_part(s, upto, st))) return rc;
+        if ((rc = tg_search_select_puct(s, k, planes_dev, nullptr, stream))) return rc;
+        if ((rc = tg_net_forward_dev(net, planes_dev, s->dev.T * k, 0, policy_dev, value_dev, stream))) return rc;
+        if ((rc = tg_search_backup(s, policy_dev, value_dev, k, 0, stream))) return rc;
+    }
+    return feed_streams_rest(s);                                          // (nothing left unless the window was an older, larger one)
+}
 
 int tg_selfplay_play_move(tg_selfplay *sp, tg_net *net, float *planes_dev, float *policy_dev, float *value_dev,
                           void *stream, int32_t *finished_host, int64_t *stats_host) {

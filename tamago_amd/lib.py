@@ -70,6 +70,7 @@ _SIGNATURES = {
     "tg_search_set_rng": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t]),
     "tg_search_rng_consumed": (c_int, [c_void_p, c_void_p]),
     "tg_search_select_puct": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "tg_search_puct_chain": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "tg_search_read_root_stats": (c_int, [c_void_p] + [c_void_p] * 8),
     "tg_search_profile": (c_int, [c_void_p, c_int, c_void_p]),
     "tg_search_play": (c_int, [c_void_p, c_void_p, c_void_p]),

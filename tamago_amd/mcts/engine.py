@@ -281,6 +281,33 @@ class SearchEngine:
         self._evaluate_and_backup(leaves, False)
         self._collect_rng()
 
+    def puct_chain(self, batches):
+        """Several mini-batches queued in one go: ONE random window for all of them (the device cursor runs on from launch to
+        launch), every selection / forward / backup launch enqueued back to back, one cursor read-back at the end - for searches
+        whose course does not depend on what a mini-batch found (STRICT_PLAYOUT: no early stop, time_manager.py:160-161).  Same
+        launches on the same data as puct_batch called once per mini-batch; what goes is the host's round trip between them
+        (the selection launch of mini-batch k + 1 used to be queued only after the cursor of mini-batch k had been read back)."""
+        arr = np.ascontiguousarray(batches, dtype=np.int32)
+        total, kmax = int(arr.sum()), int(arr.max())
+        self.node_bound += total
+        self._queue_stride = int(arr[-1])
+        policy = torch.empty((self.T * kmax, self.A), dtype=torch.float32, device=self.device)
+        value = torch.empty((self.T * kmax, 3), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.tg_search_puct_chain(self.handle, self.evaluator.network.handle, arr.ctypes.data, len(arr),
+                                                 int(self._window_left == 0), self.planes.data_ptr(), policy.data_ptr(),
+                                                 value.data_ptr(), self._stream()), "tg_search_puct_chain")
+        self._window_left = -1                       # the library tracks the window from here on
+        self.evaluator.batches.extend(int(self.T * k) for k in arr)
+        self._keep = (policy, value)                 # keep alive until the stream has consumed them
+        self._collect_rng()
+
+    def can_chain(self, total_leaves: int) -> bool:
+        """puct_chain needs the library's streams (one window for the whole search), the device evaluator (the forward pass is
+        queued by the library) and a pool that holds the whole search without growing (the reference doubles its node list
+        between mini-batches, mcts/tree.py:254-258: that stays there)."""
+        return (not self.host_streams) and isinstance(self.evaluator, DeviceEvaluator) and \
+            self.node_bound + total_leaves <= self.N
+
     def puct_select(self, leaves: int):
         """The selection half of puct_batch: afterwards the device queue holds `leaves` leaves per
         tree (read_queue) until puct_flush() evaluates and backs them up."""
