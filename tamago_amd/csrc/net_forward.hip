@@ -950,10 +950,16 @@ static bool no_tail_split() {
 
 // The ragged-tail rule of tg_net_forward_dev (9x9 split-operand kernels): positions of `batch` that go through a second launch of
 // one-board workgroups (0: a single launch)
+// (Round 5: with the workgroups a launch may take - a self-play move's sub-groups cap the forward grid, forward_grid_cap - instead of
+// the CU count.  A 64-board shard's phase is 3 200 positions on 224 workgroups: the rule on 256 split 128 positions off into a
+// one-board launch that found only the 32 spare CUs free - 170 - 280 us each, 15 % of the shard's time - while the head still
+// needed five rounds.)
 static int tail_positions(const tg_net *net, int batch) {
     if (!net || net->board_size != 9 || !pick_split() || no_tail_split()) return 0;
-    const int round = 3 * net->num_cus, rem = batch % round;
-    return (batch > round && rem > 0 && rem <= net->num_cus) ? rem : 0;
+    int grid = net->num_cus;
+    if (const int cap = net->forward_grid_cap.load(); cap > 0 && cap < grid) grid = cap;
+    const int round = 3 * grid, rem = batch % round;
+    return (batch > round && rem > 0 && rem <= grid) ? rem : 0;
 }
 
 const char *tg_net_kernel_name(const tg_net *net, int batch) {
@@ -1093,9 +1099,8 @@ int tg_net_forward_dev(tg_net *net, const float *planes_dev, int batch, int want
             // one more, mostly empty round of 3-board workgroups - the two launches follow each other on the stream.
             // (Self-play phases: 16 boards x 100 / 108 leaves = 2 rounds + 64 / 192 positions.)
             {
-                const int round = 3 * net->num_cus;
-                const int rem = batch % round;
-                if (!no_tail_split() && batch > round && rem > 0 && rem <= net->num_cus) {
+                const int rem = tail_positions(net, batch);
+                if (rem > 0) {
                     const int head = batch - rem;
                     const size_t P = 81, A = 82;
                     int rc = tg_net_forward_dev(net, planes_dev, head, want_logits, policy_dev, value_dev, stream);
