@@ -57,13 +57,27 @@ def pmc_summary(kernel_name, size=9):
     from tamago_amd.build import FORWARD_SOURCES, source_digest
     digest = source_digest(FORWARD_SOURCES)
     import glob
+    # ("a + b": a forward pass of two kernels - the 19x19 tower + its batched heads kernel: the first one's summary, with the
+    # HBM-side bytes of the others added)
+    names = [n.split("<")[0].strip() for n in kernel_name.split(" + ")]
+    found = {}
     for path in sorted(glob.glob(os.path.join(PROFILES, "r0[0-9]_pmc_forward_*.json")), reverse=True):
         with open(path) as f:
             d = json.load(f)
-        if d.get("csrc_digest") == digest and kernel_name.split("<")[0] in d.get("kernel", "") and \
-                f"_{size}x{size}_" in os.path.basename(path):
-            d["file"] = os.path.relpath(path, REPO)
-            return d
+        if d.get("csrc_digest") != digest or f"_{size}x{size}_" not in os.path.basename(path):
+            continue
+        for n in names:
+            # (a launch-size family: the largest profiled launch of the kernel stands for the throughput legs)
+            if n in d.get("kernel", "") and (n not in found or d.get("positions_per_launch", 0) > found[n].get("positions_per_launch", 0)):
+                d["file"] = os.path.relpath(path, REPO)
+                found[n] = d
+    if names[0] in found:
+        d = found[names[0]]
+        extra = [found[n] for n in names[1:] if n in found]
+        if extra:
+            d["derived"]["hbm_bytes_per_position"] += sum(e["derived"]["hbm_bytes_per_position"] for e in extra)
+            d["file"] += " + " + " + ".join(e["file"] for e in extra)
+        return d
     sys.stderr.write(f"bench.py: no PMC summary in profiles/ for kernel {kernel_name!r} at csrc digest {digest} - "
                      "roofline.traffic is null (run tools/pmc_r03.sh on the GPU box and commit the summary)\n")
     return None

@@ -95,7 +95,7 @@ def main(out):
     digest_all = source_digest()
     for prefix, match, positions, size in (("fwd", ["dualnet_fwd"], 65536, 9), ("wn", ["dualnet_fwd_wino8"], 65536, 9),
                                            ("f19", ["dualnet_fwd", "dualnet_heads19"], 4096, 19), ("b19", ["dualnet_fwd", "dualnet_heads19"], 64, 19)):
-        for kname, summary in forward_summary(out, prefix, match, positions, size, digest, 1e5 if positions > 64 else 2e4).items():
+        for kname, summary in forward_summary(out, prefix, match, positions, size, digest, 1e5 if size == 9 else 2e4).items():
             path = f"{out}/r05_pmc_forward_{tag_of(kname)}_{size}x{size}_b{positions}.json"
             with open(path, "w") as f:
                 json.dump(summary, f, indent=1)
