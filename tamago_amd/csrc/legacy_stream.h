@@ -16,6 +16,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 namespace tg {
@@ -64,6 +65,13 @@ struct LegacyStream {
     std::vector<double> buf;     // buf[head..] = e at positions base, base + 1, ...
     size_t head = 0;
     bool seeded = false;
+    // Snapshots of `ahead` every kSnapEvery generated draws (round 5): handing the state at the logical position back to numpy
+    // (search_best_move does, per move: mcts/tree.py leaves np.random where the search left it) used to replay every consumed
+    // draw through `behind` - 0.2 ms per 9x9 move, 1.5 ms per 19x19 move (half a million draws).  From the nearest snapshot it
+    // is at most kSnapEvery draws.  generated / consumed count draws since seed(); snapshots older than the position are dropped.
+    static constexpr size_t kSnapEvery = 2048;
+    size_t generated = 0, consumed = 0;
+    std::vector<std::pair<size_t, Mt19937>> snaps;
 
     void seed(const uint32_t *key624, int pos) {
         std::memcpy(ahead.key, key624, sizeof(ahead.key));
@@ -72,6 +80,8 @@ struct LegacyStream {
         lag = 0;
         buf.clear();
         head = 0;
+        generated = consumed = 0;
+        snaps.clear();
         seeded = true;
     }
     size_t available() const { return buf.size() - head; }
@@ -84,14 +94,27 @@ struct LegacyStream {
         }
         const size_t have = buf.size();
         buf.resize(need);
-        for (size_t i = have; i < need; ++i) buf[i] = -std::log(1.0 - ahead.next_double());
+        for (size_t i = have; i < need; ++i) {
+            if (generated % kSnapEvery == 0 && generated > 0) snaps.emplace_back(generated, ahead);
+            buf[i] = -std::log(1.0 - ahead.next_double());
+            ++generated;
+        }
     }
     void consume(size_t n) {     // n <= available()
         head += n;
         lag += n;
+        consumed += n;
+        // keep the last snapshot at or before the position, drop the ones before it
+        size_t keep = 0;
+        while (keep + 1 < snaps.size() && snaps[keep + 1].first <= consumed) ++keep;
+        if (keep > 0) snaps.erase(snaps.begin(), snaps.begin() + (std::ptrdiff_t)keep);
     }
-    // generator state at the logical position (next unconsumed draw); O(draws since the last call)
+    // generator state at the logical position (next unconsumed draw); at most kSnapEvery draws of replay
     const Mt19937 &state_at_position() {
+        if (lag > kSnapEvery && !snaps.empty() && snaps.front().first <= consumed && consumed - snaps.front().first < lag) {
+            behind = snaps.front().second;
+            lag = consumed - snaps.front().first;
+        }
         for (; lag; --lag) (void)behind.next_double();
         return behind;
     }
