@@ -239,6 +239,11 @@ int tg_search_draw_noise(tg_search *s, double *noise_host);
 /* Host-only helper (no device needed): the next n legacy standard_exponential draws of the
  * generator (mt_key, *mt_pos), updated in place - the arithmetic the streams above use. */
 int tg_legacy_exponentials(uint32_t *mt_key, int *mt_pos, size_t n, double *out);
+/* Host-only: what a search does to a library-owned stream - per step stage steps[i] + slack draws, consume steps[i] - and the
+ * generator state at the logical position afterwards (what tg_search_stream_state hands back to numpy after a search:
+ * mcts/tree.py leaves np.random where the search left it), plus the next n_next staged draws.  For tests. */
+int tg_legacy_stream_walk(const uint32_t *mt_key, int mt_pos, const int64_t *steps, int n_steps, int64_t slack,
+                          uint32_t *mt_key_out, int *mt_pos_out, double *next_draws_out, int n_next);
 /* Gumbel root noise, float64 [T][A] (node.py:275-278 set_gumbel_noise), to be set after the
  * root evaluation of a Gumbel move. */
 int tg_search_set_noise(tg_search *s, const double *noise_host);

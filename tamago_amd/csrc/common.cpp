@@ -53,3 +53,29 @@ extern "C" int tg_legacy_exponentials(uint32_t *mt_key, int *mt_pos, size_t n, d
     *mt_pos = g.pos;
     return TG_OK;
 }
+
+// Host-only walk of a LegacyStream (what a search does to it): per step a window is staged (the step's draws + `slack`) and the
+// step's draws are consumed; afterwards the generator state at the logical position is handed back - from the nearest snapshot,
+// which is what this entry point lets the CPU tests check against numpy (tests/test_host_rng.py).
+extern "C" int tg_legacy_stream_walk(const uint32_t *mt_key, int mt_pos, const int64_t *steps, int n_steps, int64_t slack,
+                                     uint32_t *mt_key_out, int *mt_pos_out, double *next_draws_out, int n_next) {
+    if (!mt_key || !steps || !mt_key_out || !mt_pos_out || n_steps < 0 || slack < 0 || (n_next > 0 && !next_draws_out))
+        return tg::fail(TG_ERR_ARG, "tg_legacy_stream_walk: bad argument");
+    if (mt_pos < 0 || mt_pos > 624) return tg::fail(TG_ERR_ARG, "tg_legacy_stream_walk: MT19937 position outside [0, 624]");
+    tg::LegacyStream ls;
+    ls.seed(mt_key, mt_pos);
+    for (int i = 0; i < n_steps; ++i) {
+        if (steps[i] < 0) return tg::fail(TG_ERR_ARG, "tg_legacy_stream_walk: negative step");
+        ls.ensure((size_t)(steps[i] + slack));
+        ls.consume((size_t)steps[i]);
+    }
+    const tg::Mt19937 &g = ls.state_at_position();
+    std::memcpy(mt_key_out, g.key, sizeof(g.key));
+    *mt_pos_out = g.pos;
+    if (n_next > 0) {                                   // the staged draws at the position (what the device would be sent next)
+        ls.ensure((size_t)n_next);
+        std::memcpy(next_draws_out, ls.data(), (size_t)n_next * sizeof(double));
+    }
+    return TG_OK;
+}
+

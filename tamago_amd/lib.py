@@ -91,6 +91,7 @@ _SIGNATURES = {
     "tg_search_advance_streams": (c_int, [c_void_p, c_void_p]),
     "tg_search_draw_noise": (c_int, [c_void_p, c_void_p]),
     "tg_legacy_exponentials": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "tg_legacy_stream_walk": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_int]),
     "tg_trainer_create": (c_int, [c_int, c_int, c_int, c_void_p, c_size_t, POINTER(c_void_p)]),
     "tg_trainer_destroy": (c_int, [c_void_p]),
     "tg_trainer_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p]),
