@@ -16,8 +16,8 @@
 //                      sum / sum of squares (the batch statistics) by atomics
 //   conv_kernel<DGRAD> the same loop on rotated / transposed weights over dZ; epilogue: + skip gradient,
 //                      ReLU mask, D of the layer below + its two batch-norm-backward sums
-//   wgrad_kernel       dW[co][tap][ci] = sum_rows dZ[row][co] * A[row + tap][ci] per board, accumulated over a
-//                      workgroup's boards in registers, one partial image per workgroup
+//   wgrad_kernel       dW[tap][co][ci] = sum_rows dZ[row][co] * A[row + tap][ci]; a workgroup owns 16 output channels for a
+//                      chunk of boards (accumulated in registers, staged through two LDS buffers), one partial image per chunk
 //   head_* kernels     1x1 convolutions, their batch norms, both fully connected layers, the losses and all
 //                      of their gradients
 //   sgd_kernel         reduces the partial images, adds weight decay, momentum / Nesterov, updates; batch-norm
@@ -78,14 +78,14 @@ struct TrainDev {
                                     // double: var = E[z^2] - mean^2 cancels, and the stem's gradient sees 13 layers of it.
                                     // kRep replicas (workgroup w adds to replica w % kRep): 256 same-address atomics
                                     // per channel serialise in L2 and cost more than the convolution itself
-    float *partial;                 // [13][NWG][9][64][64] weight-gradient partial images
+    float *partial;                 // [13][WCH][9][64][64] weight-gradient partial images, one per chunk of boards
     float *hz, *hD;                 // head conv outputs / their D: [B][81][4] (2 policy, 1 value, 1 pad)
     double *hstat;                  // [kRep][4][4]: sum, sumsq, S1, S2 for the 3 head channels
     float *hact;                    // [B][3*81] ReLU(BN(hz)) flattened: policy c*81+p (162), value (81)
     float *dlog;                    // [B][A + 3] dL/dlogits
     double *loss;                   // [kRep][4] accumulated: total, policy, value
     Layout L;
-    int B, NWG;
+    int B, NWG, WCH;                // batch, workgroups of the per-board kernels, board chunks of wgrad_kernel
 };
 
 struct TrainDev;
@@ -118,6 +118,15 @@ __device__ __forceinline__ void bn_consts(const TrainDev &T, int l, int c, float
 
 enum ConvMode { FWD = 0, DGRAD = 1 };
 
+// -DTG_TRAIN_PROF (tools/experiments/train_prof.sh): workgroup 0 stamps the 100 MHz clock at the phase boundaries of four launches
+// of a step (slot 0: conv FWD of layer 5, 1: conv DGRAD of layer 5, 2: wgrad of layer 5, 3: head_loss); tg_trainer_debug_read(3)
+#ifdef TG_TRAIN_PROF
+__device__ unsigned long long g_prof[4 * 16];
+#define TG_PROF(slot, k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_prof[(slot) * 16 + (k)] = wall_clock64(); } while (0)
+#else
+#define TG_PROF(slot, k) do { } while (0)
+#endif
+
 // ---- 3x3 convolution, forward and data gradient ----------------------------------------------------------
 // layer l (0 = stem).  FWD: input = activation feeding conv l, output Z_l + statistics.
 // DGRAD (l >= 1): input dZ_l (batch-norm backward of D_l, rebuilt on load), output D_{l-1} + its sums.
@@ -147,6 +156,33 @@ __global__ __launch_bounds__(256) void conv_kernel(TrainDev T, const float *__re
         }
         mask[mt] = m;
     }
+    // ---- the board's global loads are requested before the per-channel tables are made: the tables cost a round trip to the
+    //      statistics + fp64 division and square root, the board a round trip of its own (1.5 us per launch when one followed
+    //      the other; a 256-position batch is ONE board per workgroup) ----
+    constexpr int NV = (P * C / 4 + NT - 1) / NT;          // float4 per thread
+    const size_t bstride = (size_t)P * C;
+    const bool fwd = MODE == FWD;
+    const bool conv1 = (l & 1) != 0;
+    const int yb = (l - 1) / 2;
+    const bool staged = !(MODE == FWD && l == 0);
+    const bool has_second = fwd ? (conv1 && yb >= 1) : true;
+    f32x4 zv[NV], sv[NV];
+    auto request = [&](int b) {
+        // FWD: z = Z_{l-1}; conv1 also adds the previous block output and materialises Y.  DGRAD: d = D_l, z = Z_l.
+        const float *zsrc = T.Z + ((size_t)(fwd ? l - 1 : l) * T.B + b) * bstride;
+        const float *second = !has_second ? zsrc : fwd ? T.Y + ((size_t)(yb - 1) * T.B + b) * bstride : T.D + ((size_t)l * T.B + b) * bstride;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = tid + i * NT;
+            if (e < P * C / 4) {
+                zv[i] = *reinterpret_cast<const f32x4 *>(zsrc + e * 4);
+                if (has_second) sv[i] = *reinterpret_cast<const f32x4 *>(second + e * 4);
+            }
+        }
+    };
+    const int pslot = l == 5 ? MODE : -1;
+    if (pslot >= 0) TG_PROF(pslot, 0);
+    if (staged && (int)blockIdx.x < T.B) request(blockIdx.x);
     // ---- per-channel tables -------------------------------------------------------------------------
     // FWD: tab[0] = scale, tab[1] = shift of the PRODUCER's batch norm (layer l - 1)
     // DGRAD: tab[0] = gamma*rstd of layer l, tab[1] = mean, tab[2] = rstd, tab[3] unused; m1/m2 in tab[4..5]
@@ -179,37 +215,19 @@ __global__ __launch_bounds__(256) void conv_kernel(TrainDev T, const float *__re
         }
     }
     __syncthreads();
+    if (pslot >= 0) TG_PROF(pslot, 1);
     const float *wfrag = (MODE == FWD ? T.wf : T.wb) + (size_t)l * 4 * 9 * 4 * 64 * 4;
     const f32x4 *wl = reinterpret_cast<const f32x4 *>(wfrag) + (size_t)wave * 9 * 4 * 64 + lane;
-    const size_t bstride = (size_t)P * C;
     float s_sum[4] = {0.f, 0.f, 0.f, 0.f}, s_sq[4] = {0.f, 0.f, 0.f, 0.f};
     for (int b = blockIdx.x; b < T.B; b += gridDim.x) {
-        // ---- stage the board: LDS act[row][c].  All global loads of a thread first, then the arithmetic: the board
-        //      is 1296 float4 = 5.06 per thread, and a load-use-store loop would pay the memory latency five times ----
-        constexpr int NV = (P * C / 4 + NT - 1) / NT;          // float4 per thread
+        // ---- stage the board: LDS act[row][c] from the registers requested above / at the end of the board before ----
         if (MODE == FWD && l == 0) {
             for (int e = tid; e < P * C; e += NT) {
                 const int row = e >> 6, c = e & 63;
                 act[row * kRow + c] = c < 6 ? planes[((size_t)b * 6 + c) * P + row] : 0.f;
             }
         } else {
-            const bool fwd = MODE == FWD;
-            const bool conv1 = (l & 1) != 0;
-            // FWD: z = Z_{l-1}; conv1 also adds the previous block output and materialises Y.  DGRAD: d = D_l, z = Z_l.
-            const float *zsrc = T.Z + ((size_t)(fwd ? l - 1 : l) * T.B + b) * bstride;
-            const int yb = (l - 1) / 2;
-            const float *second = fwd ? (conv1 && yb >= 1 ? T.Y + ((size_t)(yb - 1) * T.B + b) * bstride : nullptr)
-                                      : T.D + ((size_t)l * T.B + b) * bstride;
             float *yout = fwd && conv1 ? T.Y + ((size_t)yb * T.B + b) * bstride : nullptr;
-            f32x4 zv[NV], sv[NV];
-#pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                const int e = tid + i * NT;
-                if (e < P * C / 4) {
-                    zv[i] = *reinterpret_cast<const f32x4 *>(zsrc + e * 4);
-                    if (second) sv[i] = *reinterpret_cast<const f32x4 *>(second + e * 4);
-                }
-            }
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 const int e = tid + i * NT;
@@ -219,7 +237,7 @@ __global__ __launch_bounds__(256) void conv_kernel(TrainDev T, const float *__re
                     if (fwd) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] = fmaf(zv[i][j], tab[c + j], tab[64 + c + j]);
-                        if (second) v += sv[i];
+                        if (has_second) v += sv[i];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
                         if (yout) *reinterpret_cast<f32x4 *>(yout + e * 4) = v;
@@ -236,6 +254,7 @@ __global__ __launch_bounds__(256) void conv_kernel(TrainDev T, const float *__re
             }
         }
         __syncthreads();
+        if (pslot >= 0) TG_PROF(pslot, 2);
         // ---- implicit GEMM: acc[mt] (16 couts x 16 rows) over 9 taps x 16 k-groups of 4 channels ----
         f32x4 acc[HMT];
 #pragma unroll
@@ -287,6 +306,7 @@ __global__ __launch_bounds__(256) void conv_kernel(TrainDev T, const float *__re
             __builtin_amdgcn_sched_barrier(0);
         });
         // ---- epilogue ----
+        if (pslot >= 0) TG_PROF(pslot, 3);
         const int c0 = wave * 16 + lg * 4;
         if (MODE == FWD) {
             float *z = T.Z + ((size_t)l * T.B + b) * bstride;
@@ -320,7 +340,9 @@ __global__ __launch_bounds__(256) void conv_kernel(TrainDev T, const float *__re
                 }
             }
         }
+        if (staged && b + (int)gridDim.x < T.B) request(b + gridDim.x);
         __syncthreads();
+        if (pslot >= 0) TG_PROF(pslot, 4);
     }
     // per-channel sums: reduce over the 16 lanes that share lg, one atomic per channel and workgroup-wave
 #pragma unroll
@@ -337,107 +359,162 @@ __global__ __launch_bounds__(256) void conv_kernel(TrainDev T, const float *__re
             atomicAdd(&T.stat[base + 64 + j], (double)s_sq[j]);
         }
     }
+    if (pslot >= 0) TG_PROF(pslot, 5);
 }
 
-// ---- weight gradient: partial[wg][tap][co][ci] = sum over the workgroup's boards and rows of dZ[row][co] * A[row+tap][ci] ----
+// ---- weight gradient ---------------------------------------------------------------------------------------
+// dW[tap][co][ci] = sum over boards and rows of dZ[row][co] * A[row + tap][ci].  Workgroup (q, chunk) owns the output channels
+// [16q, 16q+16) of every tap and input channel for the boards chunk, chunk + chunks, ...: 36 MFMA tiles (9 taps x 4 ci tiles)
+// shared out over 8 waves (wave w: ci tile w & 3, taps (w >> 2) + 2i - five on waves 0-3, four on waves 4-7, nine per SIMD).
+// One partial image per CHUNK (64 of them at batch >= 64: 9.4 MB per layer; one image per workgroup and board was 37.7 MB
+// written and read again, 491 MB per step).  A board's dZ slice (16 channels) and activations (all 64) are staged into one of
+// two LDS buffers while the MFMAs of the board before run on the other: activations on an 11 x 11 padded board whose border
+// stays zero, so that a tap is a constant address offset (no validity test per MFMA), cells 80 floats apart (the four rows x 16
+// channels of a ds_read_b32 hit 32 distinct banks twice).
+constexpr int kWRow = 80, kWCells = 121, kWAct = kWCells * kWRow, kWBuf = kWAct + 84 * 16;
+constexpr int kWgradLdsFloats = 2 * kWBuf + 5 * 16 + 2 * 64;
+
 __global__ __launch_bounds__(512) void wgrad_kernel(TrainDev T, const float *__restrict__ planes, int l) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *act = smem;                         // A_{l-1}: [81][72] + zero row
-    float *zrow = smem + P * kRow;
-    float *dzt = zrow + kRow;                  // dZ_l: [84 rows][72]
-    float *tab = dzt + 84 * kRow;
-    // 8 waves: wave (w, half) owns output channels [16w, 16w+16) for taps {0..4} (half 0) / {5..8} (half 1)
+    float *tab = smem + 2 * kWBuf;             // [5][16]: gamma*rstd, mean, rstd, m1, m2 of the slice; [2][64]: scale / shift of layer l - 1
     constexpr int NT = 512;
-    const int tid = threadIdx.x, wave = (tid >> 6) & 3, half = tid >> 8, lane = tid & 63, li = lane & 15, lg = lane >> 4;
-    const int tap0 = half ? 5 : 0, ntap = half ? 4 : 5;
+    const int tid = threadIdx.x, wave = tid >> 6, ct = wave & 3, tpar = wave >> 2, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+    const int q = blockIdx.x & 3, chunk = blockIdx.x >> 2, chunks = gridDim.x >> 2;
     const float eps_l = 2e-5f;
-    for (int e = tid; e < kRow; e += NT) zrow[e] = 0.f;
-    for (int e = tid; e < 3 * kRow; e += NT) dzt[P * kRow + e] = 0.f;     // rows 81..83: zero
-    if (tid < 64) {
+    const bool rebuild = l >= 2 && (l & 1) == 0;          // conv2: its input h = relu(bn(Z_{l-1})) is rebuilt
+    for (int e = tid; e < 2 * kWBuf / 4; e += NT) reinterpret_cast<f32x4 *>(smem)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tid < 16) {
+        const int c = q * 16 + tid;
         float mean, rstd;
-        bn_consts(T, l, tid, l == 0 ? 1e-5f : eps_l, mean, rstd);
+        bn_consts(T, l, c, l == 0 ? 1e-5f : eps_l, mean, rstd);
         const double n = (double)(T.B * P);
-        tab[tid] = T.param[T.L.bn_w[l] + tid] * rstd;
-        tab[64 + tid] = mean;
-        tab[128 + tid] = rstd;
-        tab[192 + tid] = (float)(stat_sum(T.stat + (size_t)l * kRep * 256 + 128 + tid, 256) / n);
-        tab[256 + tid] = (float)(stat_sum(T.stat + (size_t)l * kRep * 256 + 192 + tid, 256) / n);
-        if (l >= 1 && (l & 1) == 0) {          // conv2: its input h = relu(bn(Z_{l-1})) is rebuilt
-            float mean2, rstd2;
-            bn_consts(T, l - 1, tid, eps_l, mean2, rstd2);
-            const float sc2 = T.param[T.L.bn_w[l - 1] + tid] * rstd2;
-            tab[320 + tid] = sc2;
-            tab[384 + tid] = T.param[T.L.bn_b[l - 1] + tid] - mean2 * sc2;
-        }
+        tab[tid] = T.param[T.L.bn_w[l] + c] * rstd;
+        tab[16 + tid] = mean;
+        tab[32 + tid] = rstd;
+        tab[48 + tid] = (float)(stat_sum(T.stat + (size_t)l * kRep * 256 + 128 + c, 256) / n);
+        tab[64 + tid] = (float)(stat_sum(T.stat + (size_t)l * kRep * 256 + 192 + c, 256) / n);
+    } else if (rebuild && tid >= 64 && tid < 128) {
+        const int c = tid - 64;
+        float mean2, rstd2;
+        bn_consts(T, l - 1, c, eps_l, mean2, rstd2);
+        const float sc2 = T.param[T.L.bn_w[l - 1] + c] * rstd2;
+        tab[80 + c] = sc2;
+        tab[144 + c] = T.param[T.L.bn_b[l - 1] + c] - mean2 * sc2;
     }
-    __syncthreads();
     const size_t bstride = (size_t)P * C;
-    f32x4 acc[20];                              // [tap - tap0][ci tile]
+    const float *asrc = l == 0 ? nullptr : (l & 1) ? T.Y + (size_t)((l - 1) / 2) * T.B * bstride : T.Z + (size_t)(l - 1) * T.B * bstride;
+    constexpr int NV = (P * C / 4 + NT - 1) / NT;          // float4 of activations per thread
+    f32x4 ra[NV], rd, rz;
+    auto request = [&](int b) {
 #pragma unroll
-    for (int i = 0; i < 20; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int b = blockIdx.x; b < T.B; b += gridDim.x) {
-        const float *d = T.D + ((size_t)l * T.B + b) * bstride;
-        const float *z = T.Z + ((size_t)l * T.B + b) * bstride;
-        for (int e = tid; e < P * C / 4; e += NT) {
-            const int row = e >> 4, c = (e & 15) * 4;
-            const f32x4 dv = *reinterpret_cast<const f32x4 *>(d + row * C + c);
-            const f32x4 zv = *reinterpret_cast<const f32x4 *>(z + row * C + c);
-            f32x4 v, a;
+        for (int i = 0; i < NV; ++i) {
+            const int e = tid + i * NT;
+            if (e < P * C / 4) {
+                if (l == 0) {
+                    const int row = e >> 4, c = (e & 15) * 4;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ra[i][j] = c + j < 6 ? planes[((size_t)b * 6 + c + j) * P + row] : 0.f;
+                } else {
+                    ra[i] = *reinterpret_cast<const f32x4 *>(asrc + (size_t)b * bstride + e * 4);
+                }
+            }
+        }
+        if (tid < P * 4) {
+            const size_t off = ((size_t)l * T.B + b) * bstride + (tid >> 2) * C + q * 16 + (tid & 3) * 4;
+            rd = *reinterpret_cast<const f32x4 *>(T.D + off);
+            rz = *reinterpret_cast<const f32x4 *>(T.Z + off);
+        }
+    };
+    auto deposit = [&](float *buf) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = tid + i * NT;
+            if (e < P * C / 4) {
+                const int row = e >> 4, c = (e & 15) * 4, y = row / S, cell = (y + 1) * 11 + (row - y * S) + 1;
+                f32x4 a = ra[i];
+                if (rebuild) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a[j] = fmaxf(fmaf(a[j], tab[80 + c + j], tab[144 + c + j]), 0.f);
+                }
+                *reinterpret_cast<f32x4 *>(buf + cell * kWRow + c) = a;
+            }
+        }
+        if (tid < P * 4) {
+            const int c = (tid & 3) * 4;
+            f32x4 v;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float xh = (zv[j] - tab[64 + c + j]) * tab[128 + c + j];
-                v[j] = tab[c + j] * (dv[j] - tab[192 + c + j] - xh * tab[256 + c + j]);
+                const float xh = (rz[j] - tab[16 + c + j]) * tab[32 + c + j];
+                v[j] = tab[c + j] * (rd[j] - tab[48 + c + j] - xh * tab[64 + c + j]);
             }
-            *reinterpret_cast<f32x4 *>(dzt + row * kRow + c) = v;
-            if (l == 0) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) a[j] = c + j < 6 ? planes[((size_t)b * 6 + c + j) * P + row] : 0.f;
-            } else if (l & 1) {
-                a = *reinterpret_cast<const f32x4 *>(T.Y + ((size_t)((l - 1) / 2) * T.B + b) * bstride + row * C + c);
-            } else {
-                const f32x4 zp = *reinterpret_cast<const f32x4 *>(T.Z + ((size_t)(l - 1) * T.B + b) * bstride + row * C + c);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) a[j] = fmaxf(fmaf(zp[j], tab[320 + c + j], tab[384 + c + j]), 0.f);
-            }
-            *reinterpret_cast<f32x4 *>(act + row * kRow + c) = a;
+            *reinterpret_cast<f32x4 *>(buf + kWAct + (tid >> 2) * 16 + c) = v;
         }
-        __syncthreads();
-        // D[co][ci] += sum_k dZ^T[co][k = row] * A[row + tap][ci]: MFMA A operand = dZ^T (lane: co = li, k = lg),
-        // B operand = shifted activations (lane: ci = li, k = lg)
-#pragma unroll 1
-        for (int ks = 0; ks < 21; ++ks) {
-            const int row = ks * 4 + lg;
-            const float dzv = dzt[row * kRow + wave * 16 + li];
-            const int y = row / S, x = row - y * S;
+    };
+    // lane's activation address per k-step (rows ks * 4 + lg), relative to the cell one row and one column up-left of it, so
+    // that every tap is a non-negative constant; rows 81..83 (dZ is zero there) read a cell of finite values
+    int aoff[21];
 #pragma unroll
-            for (int tt = 0; tt < 5; ++tt) {
-                const int tap = tap0 + tt;
-                const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-                const bool ok = tt < ntap && row < P && (unsigned)(y + dy) < (unsigned)S && (unsigned)(x + dx) < (unsigned)S;
-                const float *ap = ok ? act + (row + dy * S + dx) * kRow + li : zrow + li;
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct)
-                    acc[tt * 4 + ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(dzv, ap[ct * 16], acc[tt * 4 + ct], 0, 0, 0);
-            }
-        }
-        __syncthreads();
+    for (int ks = 0; ks < 21; ++ks) {
+        const int row = ks * 4 + lg, r2 = row < P ? row : 0, y = r2 / S;
+        aoff[ks] = (y * 11 + (r2 - y * S)) * kWRow + ct * 16 + li;
     }
-    // partial image: [wg][tap][co][ci]; lane holds co = 16 wave + 4 lg + j, ci = 16 ct + li
-    float *out = T.partial + ((size_t)l * T.NWG + blockIdx.x) * 9 * 64 * 64;
+    f32x4 acc[5];
 #pragma unroll
-    for (int tt = 0; tt < 5; ++tt)
-        if (tt < ntap)
+    for (int i = 0; i < 5; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int b = chunk;
+    if (l == 5) TG_PROF(2, 0);
+    if (b < T.B) request(b);
+    __syncthreads();                                       // tables and the zeroed buffers
+    if (l == 5) TG_PROF(2, 1);
+    for (int it = 0; b < T.B; b += chunks, ++it) {
+        float *buf = smem + (it & 1) * kWBuf;
+        deposit(buf);
+        __syncthreads();
+        if (l == 5 && it < 4) TG_PROF(2, 2 + it);
+        if (b + chunks < T.B) request(b + chunks);
+        const float *dz = buf + kWAct + lg * 16 + li;
+        auto run = [&](auto TP_) {
+            constexpr int TP = decltype(TP_)::value;
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct)
+            for (int ks = 0; ks < 21; ++ks) {
+                const float dzv = dz[ks * 64];
+                const float *ap = buf + aoff[ks];
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    out[((tap0 + tt) * 64 + wave * 16 + lg * 4 + j) * 64 + ct * 16 + li] = acc[tt * 4 + ct][j];
+                for (int i = 0; i < 5; ++i) {
+                    const int tap = TP + 2 * i;
+                    if (tap < 9) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(dzv, ap[((tap / 3) * 11 + tap % 3) * kWRow], acc[i], 0, 0, 0);
+                }
+            }
+        };
+        if (tpar == 0) run(std::integral_constant<int, 0>{});
+        else run(std::integral_constant<int, 1>{});
+    }
+    if (l == 5) TG_PROF(2, 6);
+    // partial image of the chunk: [chunk][tap][co][ci]; lane holds co = 16 q + 4 lg + j, ci = 16 ct + li
+    float *out = T.partial + ((size_t)l * chunks + chunk) * 9 * 64 * 64;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int tap = tpar + 2 * i;
+        if (tap < 9)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out[(tap * 64 + q * 16 + lg * 4 + j) * 64 + ct * 16 + li] = acc[i][j];
+    }
+    if (l == 5) TG_PROF(2, 7);
 }
 
 // ---- weight fragments from the master weights (they change every step) ---------------------------------
 __global__ void repack_kernel(TrainDev T) {
     const int l = blockIdx.y;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;          // fragment element index
+    // first launch of a step: the accumulators of the step are cleared here (four memset launches of ~5 us each before)
+    {
+        const int g = l * (int)(gridDim.x * blockDim.x) + e;
+        constexpr int n_stat = kLayers * kRep * 256, n_h = kRep * 16;
+        if (g < n_stat) T.stat[g] = 0.0;
+        else if (g < n_stat + n_h) T.hstat[g - n_stat] = 0.0;
+        else if (g < n_stat + n_h + 128) T.grad[T.L.p_conv + (g - n_stat - n_h)] = 0.f;
+        else if (g < n_stat + n_h + 192) T.grad[T.L.v_conv + (g - n_stat - n_h - 128)] = 0.f;
+    }
     if (e >= 4 * 9 * 4 * 64 * 4) return;
     const int j = e & 3, lane = (e >> 2) & 63, s = (e >> 8) & 3, tap = (e >> 10) % 9, wv = e / (9 * 1024);
     const int n = lane & 15, g = lane >> 4;
@@ -455,50 +532,91 @@ __global__ void repack_kernel(TrainDev T) {
 }
 
 // ---- heads -----------------------------------------------------------------------------------------------
-// 1. per board: Y_6 = relu(Y_5 + bn(Z_12)) (materialised), head 1x1 convolutions -> hz[b][p][3], statistics
-__global__ __launch_bounds__(128) void head_conv_kernel(TrainDev T) {
+// 1. per board: Y_6 = relu(Y_5 + bn(Z_12)) (materialised), head 1x1 convolutions -> hz[b][p][3], statistics.
+//    Thread (row group r = tid / 16, channel quad c = 4 (tid % 16)): a row is one coalesced 256-byte read by 16 lanes, the three
+//    dot products are finished by a butterfly over those lanes (a thread per ROW read 64 scattered lines per instruction).
+__global__ __launch_bounds__(256) void head_conv_kernel(TrainDev T) {
+    __shared__ float red[4][6];
     __shared__ float tab[128];
-    __shared__ float red[6];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, c = (tid & 15) * 4, r0 = tid >> 4;
+    const size_t bstride = (size_t)P * C;
+    constexpr int NR = (P + 15) / 16;
+    f32x4 zv[NR], yv[NR];
+    auto request = [&](int b) {
+        const float *z = T.Z + ((size_t)12 * T.B + b) * bstride;
+        const float *yp = T.Y + ((size_t)5 * T.B + b) * bstride;
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int row = r0 + 16 * k;
+            if (row < P) {
+                zv[k] = *reinterpret_cast<const f32x4 *>(z + row * C + c);
+                yv[k] = *reinterpret_cast<const f32x4 *>(yp + row * C + c);
+            }
+        }
+    };
+    if ((int)blockIdx.x < T.B) request(blockIdx.x);       // in flight while the batch-norm constants are made
     if (tid < 64) {
         float mean, rstd;
         bn_consts(T, 12, tid, 2e-5f, mean, rstd);
-        const float sc = T.param[T.L.bn_w[12] + tid] * rstd;
-        tab[tid] = sc;
-        tab[64 + tid] = T.param[T.L.bn_b[12] + tid] - mean * sc;
+        const float sc1 = T.param[T.L.bn_w[12] + tid] * rstd;
+        tab[tid] = sc1;
+        tab[64 + tid] = T.param[T.L.bn_b[12] + tid] - mean * sc1;
     }
-    if (tid < 6) red[tid] = 0.f;
+    float w0[4], w1[4], w2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        w0[j] = T.param[T.L.p_conv + c + j];
+        w1[j] = T.param[T.L.p_conv + 64 + c + j];
+        w2[j] = T.param[T.L.v_conv + c + j];
+    }
     __syncthreads();
-    const size_t bstride = (size_t)P * C;
+    float sc[4], sh[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sc[j] = tab[c + j]; sh[j] = tab[64 + c + j]; }
     float s[3] = {0.f, 0.f, 0.f}, q[3] = {0.f, 0.f, 0.f};
     for (int b = blockIdx.x; b < T.B; b += gridDim.x) {
-        const float *z = T.Z + ((size_t)12 * T.B + b) * bstride;
-        const float *yp = T.Y + ((size_t)5 * T.B + b) * bstride;
         float *yo = T.Y + ((size_t)6 * T.B + b) * bstride;
-        for (int row = tid; row < P; row += 128) {
-            float d0 = 0.f, d1 = 0.f, d2 = 0.f;
-            for (int c = 0; c < C; c += 4) {
-                const f32x4 zv = *reinterpret_cast<const f32x4 *>(z + row * C + c);
-                f32x4 v = *reinterpret_cast<const f32x4 *>(yp + row * C + c);
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int row = r0 + 16 * k;            // uniform over the 16 lanes of a row: the butterfly below stays inside them
+            if (row < P) {
+                f32x4 v = yv[k];
+                float d0 = 0.f, d1 = 0.f, d2 = 0.f;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    v[j] = fmaxf(v[j] + fmaf(zv[j], tab[c + j], tab[64 + c + j]), 0.f);
-                    d0 = fmaf(v[j], T.param[T.L.p_conv + c + j], d0);
-                    d1 = fmaf(v[j], T.param[T.L.p_conv + 64 + c + j], d1);
-                    d2 = fmaf(v[j], T.param[T.L.v_conv + c + j], d2);
+                    v[j] = fmaxf(v[j] + fmaf(zv[k][j], sc[j], sh[j]), 0.f);
+                    d0 = fmaf(v[j], w0[j], d0);
+                    d1 = fmaf(v[j], w1[j], d1);
+                    d2 = fmaf(v[j], w2[j], d2);
                 }
                 *reinterpret_cast<f32x4 *>(yo + row * C + c) = v;
-            }
-            *reinterpret_cast<f32x4 *>(T.hz + ((size_t)b * P + row) * 4) = f32x4{d0, d1, d2, 0.f};
-            s[0] += d0; s[1] += d1; s[2] += d2;
-            q[0] = fmaf(d0, d0, q[0]); q[1] = fmaf(d1, d1, q[1]); q[2] = fmaf(d2, d2, q[2]);
-        }
-    }
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { atomicAdd(&red[k], s[k]); atomicAdd(&red[3 + k], q[k]); }
+                for (int o = 8; o > 0; o >>= 1) { d0 += __shfl_xor(d0, o); d1 += __shfl_xor(d1, o); d2 += __shfl_xor(d2, o); }
+                if ((tid & 15) == 0) {
+                    *reinterpret_cast<f32x4 *>(T.hz + ((size_t)b * P + row) * 4) = f32x4{d0, d1, d2, 0.f};
+                    s[0] += d0; s[1] += d1; s[2] += d2;
+                    q[0] = fmaf(d0, d0, q[0]); q[1] = fmaf(d1, d1, q[1]); q[2] = fmaf(d2, d2, q[2]);
+                }
+            }
+        }
+        if (b + (int)gridDim.x < T.B) request(b + gridDim.x);
+    }
+    // lanes 0, 16, 32, 48 of a wave hold sums: one more butterfly, then wave -> workgroup through LDS, one atomic per statistic
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        s[k] += __shfl_xor(s[k], 16); s[k] += __shfl_xor(s[k], 32);
+        q[k] += __shfl_xor(q[k], 16); q[k] += __shfl_xor(q[k], 32);
+    }
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { red[tid >> 6][k] = s[k]; red[tid >> 6][3 + k] = q[k]; }
+    }
     __syncthreads();
     double *hs = T.hstat + (blockIdx.x % kRep) * 16;
-    if (tid < 3) { atomicAdd(&hs[tid], (double)red[tid]); atomicAdd(&hs[4 + tid], (double)red[3 + tid]); }
+    if (tid < 6) {
+        const float v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+        atomicAdd(&hs[tid < 3 ? tid : 4 + tid - 3], (double)v);
+    }
 }
 
 // 2. per board: batch norm + ReLU of the head convolutions, both FC layers, losses, dL/dlogits, gradient back to the
@@ -509,8 +627,9 @@ __global__ __launch_bounds__(256) void head_loss_kernel(TrainDev T, const float 
     __shared__ float h[3 * P];            // [162 policy | 81 value]
     __shared__ float logit[A + 3], dl[A + 3];
     __shared__ float hc[12];              // head bn: scale[3], shift[3], mean[3], rstd[3]
-    __shared__ float red[8];
+    __shared__ float wred[4][6];
     const int tid = threadIdx.x;
+    TG_PROF(3, 0);
     if (tid < 3) {
         const double n = (double)(T.B * P);
         const double dmean = stat_sum(T.hstat + tid, 16) / n;
@@ -523,8 +642,8 @@ __global__ __launch_bounds__(256) void head_loss_kernel(TrainDev T, const float 
         hc[6 + tid] = mean;
         hc[9 + tid] = rstd;
     }
-    if (tid < 8) red[tid] = 0.f;
     __syncthreads();
+    TG_PROF(3, 1);
     float lp = 0.f, lv = 0.f, s1[3] = {0.f, 0.f, 0.f}, s2[3] = {0.f, 0.f, 0.f};
     for (int b = blockIdx.x; b < T.B; b += gridDim.x) {
         for (int e = tid; e < 3 * P; e += 256) {
@@ -534,85 +653,142 @@ __global__ __launch_bounds__(256) void head_loss_kernel(TrainDev T, const float 
             T.hact[(size_t)b * 3 * P + e] = v;
         }
         __syncthreads();
-        if (tid < A) {
-            const float *w = T.param + T.L.p_fc_w + (size_t)tid * 2 * P;
-            float acc = T.param[T.L.p_fc_b + tid];
-            for (int j = 0; j < 2 * P; ++j) acc = fmaf(h[j], w[j], acc);
-            logit[tid] = acc;
-        } else if (tid < A + 3) {
-            const float *w = T.param + T.L.v_fc_w + (size_t)(tid - A) * P;
-            float acc = T.param[T.L.v_fc_b + tid - A];
-            for (int j = 0; j < P; ++j) acc = fmaf(h[2 * P + j], w[j], acc);
-            logit[tid] = acc;
+        TG_PROF(3, 2);
+        {
+            // both FC layers: wave w takes the outputs w, w + 4, ... (82 policy logits, 3 value logits), its lanes the inputs
+            // (coalesced weight rows; a thread per OUTPUT read 64 scattered lines per instruction), butterfly per output
+            const int wv = tid >> 6, ln = tid & 63;
+            const float h0 = h[ln], h1 = h[64 + ln], h2 = ln < 2 * P - 128 ? h[128 + ln] : 0.f;
+            const float v0 = h[2 * P + ln], v1 = ln < P - 64 ? h[2 * P + 64 + ln] : 0.f;
+            // in phases over all 22 outputs of the wave - every load first, then the products, then the butterflies level by
+            // level - so that the chains overlap (written output by output hipcc keeps them in program order: 15 us)
+            constexpr int NO = (A + 3 + 3) / 4;
+            float wa[NO], wb[NO], wc[NO], bias[NO], acc[NO];
+#pragma unroll
+            for (int i = 0; i < NO; ++i) {
+                const int a = wv + 4 * i, a2 = a < A + 3 ? a : A + 2;
+                const bool pol = a2 < A;
+                const float *w = pol ? T.param + T.L.p_fc_w + (size_t)a2 * 2 * P : T.param + T.L.v_fc_w + (size_t)(a2 - A) * P;
+                const int n = pol ? 2 * P : P;
+                wa[i] = w[ln];
+                wb[i] = w[64 + ln < n ? 64 + ln : 0];
+                wc[i] = w[128 + ln < n ? 128 + ln : 0];
+                bias[i] = pol ? T.param[T.L.p_fc_b + a2] : T.param[T.L.v_fc_b + a2 - A];
+            }
+#pragma unroll
+            for (int i = 0; i < NO; ++i) {
+                const int a = wv + 4 * i;
+                const bool pol = a < A;
+                const int n = pol ? 2 * P : P;
+                const float x0 = pol ? h0 : v0, x1 = 64 + ln < n ? (pol ? h1 : v1) : 0.f, x2 = 128 + ln < n ? h2 : 0.f;
+                acc[i] = fmaf(x2, wc[i], fmaf(x1, wb[i], x0 * wa[i]));
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                float t[NO];
+#pragma unroll
+                for (int i = 0; i < NO; ++i) t[i] = __shfl_xor(acc[i], o);
+#pragma unroll
+                for (int i = 0; i < NO; ++i) acc[i] += t[i];
+            }
+            if (ln == 0) {
+#pragma unroll
+                for (int i = 0; i < NO; ++i)
+                    if (wv + 4 * i < A + 3) logit[wv + 4 * i] = acc[i] + bias[i];
+            }
         }
         __syncthreads();
-        if (tid == 0) {
-            // policy: log-softmax, loss, dL/dlogit
-            float m = -INFINITY;
-            for (int a = 0; a < A; ++a) m = fmaxf(m, logit[a]);
-            float se = 0.f;
-            for (int a = 0; a < A; ++a) se += expf(logit[a] - m);
+        TG_PROF(3, 3);
+        if (tid < 64) {
+            // policy: log-softmax, loss, dL/dlogit - lane a takes actions a and a + 64, sums by butterfly over the wave
+            // (one lane walking the 82 actions three times was 22 of this kernel's 44 us)
+            auto wsum = [](float v) {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+                return v;
+            };
+            const int a0 = tid, a1 = tid + 64;
+            const bool two = a1 < A;
+            const float l0 = logit[a0], l1 = two ? logit[a1] : -INFINITY;
+            float m = fmaxf(l0, l1);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+            const float se = wsum(expf(l0 - m) + (two ? expf(l1 - m) : 0.f));
             const float lse = m + logf(se);
             const float *tp = target_policy + (size_t)b * A;
+            const float t0 = tp[a0], t1 = two ? tp[a1] : 0.f;
             const float invb = 1.f / (float)T.B;
-            float loss = 0.f;
+            float part = 0.f;
             if (!sl_mode) {
                 // kl_div(logp, t, batchmean): sum t * (log t - logp) / B (0 where t == 0); gradient (p * sum t - t) / B
-                float st = 0.f;
-                for (int a = 0; a < A; ++a) st += tp[a];
-                for (int a = 0; a < A; ++a) {
-                    const float logp = logit[a] - lse, t = tp[a];
-                    if (t > 0.f) loss += t * (logf(t) - logp);
-                    dl[a] = (expf(logp) * st - t) * invb;
-                }
+                const float st = wsum(t0 + t1);
+                const float lp0 = l0 - lse, lp1 = l1 - lse;
+                if (t0 > 0.f) part += t0 * (logf(t0) - lp0);
+                if (two && t1 > 0.f) part += t1 * (logf(t1) - lp1);
+                dl[a0] = (expf(lp0) * st - t0) * invb;
+                if (two) dl[a1] = (expf(lp1) * st - t1) * invb;
             } else {
                 // -sum t * log(softmax + 1e-8) per sample, mean over the batch
-                float dot = 0.f;
-                for (int a = 0; a < A; ++a) {
-                    const float p = expf(logit[a] - lse), t = tp[a];
-                    loss -= t * logf(p + 1e-8f);
-                    dot += t * p / (p + 1e-8f);
-                }
-                for (int a = 0; a < A; ++a) {
-                    const float p = expf(logit[a] - lse), t = tp[a];
-                    dl[a] = (p * dot - t * p / (p + 1e-8f)) * invb;
-                }
+                const float p0 = expf(l0 - lse), p1 = two ? expf(l1 - lse) : 0.f;
+                part = -(t0 * logf(p0 + 1e-8f)) - (two ? t1 * logf(p1 + 1e-8f) : 0.f);
+                const float dot = wsum(t0 * p0 / (p0 + 1e-8f) + (two ? t1 * p1 / (p1 + 1e-8f) : 0.f));
+                dl[a0] = (p0 * dot - t0 * p0 / (p0 + 1e-8f)) * invb;
+                if (two) dl[a1] = (p1 * dot - t1 * p1 / (p1 + 1e-8f)) * invb;
             }
-            lp += loss;
-            // value: cross entropy against the class
-            float vm = fmaxf(logit[A], fmaxf(logit[A + 1], logit[A + 2]));
-            float ve = expf(logit[A] - vm) + expf(logit[A + 1] - vm) + expf(logit[A + 2] - vm);
-            const float vlse = vm + logf(ve);
-            const int cls = (int)target_value[b];
-            lv += vlse - logit[A + cls];
-            for (int k = 0; k < 3; ++k)
-                dl[A + k] = value_weight * (expf(logit[A + k] - vlse) - (k == cls ? 1.f : 0.f)) * invb;
+            const float loss = wsum(part);
+            if (tid == 0) {
+                lp += loss;
+                // value: cross entropy against the class
+                float vm = fmaxf(logit[A], fmaxf(logit[A + 1], logit[A + 2]));
+                float ve = expf(logit[A] - vm) + expf(logit[A + 1] - vm) + expf(logit[A + 2] - vm);
+                const float vlse = vm + logf(ve);
+                const int cls = (int)target_value[b];
+                lv += vlse - logit[A + cls];
+                for (int k = 0; k < 3; ++k)
+                    dl[A + k] = value_weight * (expf(logit[A + k] - vlse) - (k == cls ? 1.f : 0.f)) * invb;
+            }
         }
         __syncthreads();
+        TG_PROF(3, 4);
         if (tid < A + 3) T.dlog[(size_t)b * (A + 3) + tid] = dl[tid];
         // back through the FC layers to the head activations, ReLU mask, D + sums
         for (int e = tid; e < 3 * P; e += 256) {
             const int k = e / P, p = e - k * P;
+            const float hzv = T.hz[((size_t)b * P + p) * 4 + k];
             float g = 0.f;
             if (k < 2) {
-                for (int a = 0; a < A; ++a) g = fmaf(dl[a], T.param[T.L.p_fc_w + (size_t)a * 2 * P + e], g);
+#pragma unroll
+                for (int a = 0; a < A; ++a) g = fmaf(dl[a], T.param[T.L.p_fc_w + (size_t)a * 2 * P + e], g);   // all 82 loads in flight
             } else {
                 for (int c = 0; c < 3; ++c) g = fmaf(dl[A + c], T.param[T.L.v_fc_w + (size_t)c * P + p], g);
             }
             g = h[e] > 0.f ? g : 0.f;
             T.hD[((size_t)b * P + p) * 4 + k] = g;
-            const float xh = (T.hz[((size_t)b * P + p) * 4 + k] - hc[6 + k]) * hc[9 + k];
+            const float xh = (hzv - hc[6 + k]) * hc[9 + k];
             s1[k] += g;
             s2[k] = fmaf(g, xh, s2[k]);
         }
         __syncthreads();
     }
-    // every thread contributes to every k (its elements may span channels)
+    TG_PROF(3, 5);
+    // every thread contributes to every k (its elements may span channels): butterfly over the wave, the four waves through LDS
+    // (256 x 6 same-address LDS atomics serialised)
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { atomicAdd(&red[k], s1[k]); atomicAdd(&red[3 + k], s2[k]); }
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s1[k] += __shfl_xor(s1[k], o); s2[k] += __shfl_xor(s2[k], o); }
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { wred[tid >> 6][k] = s1[k]; wred[tid >> 6][3 + k] = s2[k]; }
+    }
     __syncthreads();
     double *hs = T.hstat + (blockIdx.x % kRep) * 16;
-    if (tid < 3) { atomicAdd(&hs[8 + tid], (double)red[tid]); atomicAdd(&hs[12 + tid], (double)red[3 + tid]); }
+    if (tid < 6) {
+        const float v = (wred[0][tid] + wred[1][tid]) + (wred[2][tid] + wred[3][tid]);
+        atomicAdd(&hs[tid < 3 ? 8 + tid : 12 + tid - 3], (double)v);
+    }
     if (tid == 0) {
         const double pol = (double)lp / T.B, val = (double)lv / T.B;      // this workgroup's share of the batch means
         double *ls = T.loss + (blockIdx.x % kRep) * 4;
@@ -620,26 +796,36 @@ __global__ __launch_bounds__(256) void head_loss_kernel(TrainDev T, const float 
         atomicAdd(&ls[2], val);
         atomicAdd(&ls[0], pol + (double)value_weight * val);
     }
+    TG_PROF(3, 6);
 }
 
 // 3. FC weight / bias gradients: dW[a][j] = sum_b dlog[b][a] * hact[b][j] (policy: j < 162; value rows a >= A: the last
-//    81 of hact).  One workgroup per output a, thread j: hact reads coalesced over j, dlog[b][a] a broadcast.
-__global__ __launch_bounds__(192) void head_fc_grad_kernel(TrainDev T) {
-    const int a = blockIdx.x, j = threadIdx.x;
+//    81 of hact).  One workgroup per output a, thread (j, y): hact reads coalesced over j, dlog[b][a] a broadcast; the four y
+//    take a quarter of the batch each, sixteen loads in flight (one thread walking the batch four loads at a time was 20 us of
+//    memory latency), summed in y order through LDS.
+__global__ __launch_bounds__(768) void head_fc_grad_kernel(TrainDev T) {
+    __shared__ float part[4][192], partb[4];
+    const int a = blockIdx.x, j = threadIdx.x, y = threadIdx.y;
     const bool pol = a < A;
     const int nj = pol ? 2 * P : P;
     float g = 0.f, gb = 0.f;
     if (j < nj) {
         const float *h = T.hact + (pol ? j : 2 * P + j);
         const float *d = T.dlog + a;
-#pragma unroll 4
-        for (int b = 0; b < T.B; ++b) {
+        const int per = (T.B + 3) / 4, b0 = y * per, b1 = b0 + per < T.B ? b0 + per : T.B;
+#pragma unroll 16
+        for (int b = b0; b < b1; ++b) {
             const float dv = d[(size_t)b * (A + 3)];
             g = fmaf(dv, h[(size_t)b * 3 * P], g);
             gb += dv;
         }
-        T.grad[(pol ? T.L.p_fc_w + (size_t)a * 2 * P : T.L.v_fc_w + (size_t)(a - A) * P) + j] = g;
-        if (j == 0) T.grad[pol ? T.L.p_fc_b + a : T.L.v_fc_b + a - A] = gb;
+    }
+    part[y][j] = g;
+    if (j == 0) partb[y] = gb;
+    __syncthreads();
+    if (y == 0 && j < nj) {
+        T.grad[(pol ? T.L.p_fc_w + (size_t)a * 2 * P : T.L.v_fc_w + (size_t)(a - A) * P) + j] = (part[0][j] + part[1][j]) + (part[2][j] + part[3][j]);
+        if (j == 0) T.grad[pol ? T.L.p_fc_b + a : T.L.v_fc_b + a - A] = (partb[0] + partb[1]) + (partb[2] + partb[3]);
     }
 }
 
@@ -719,6 +905,8 @@ __global__ void sgd_kernel(TrainDev T, SgdArgs a) {
     float g;
     bool is_stat = false;
     int l = -1, kind = -1;       // kind 0 conv weight, 1 bn weight, 2 bn bias, 3 running mean, 4 running var
+    // 96 % of the elements are convolution weights of the blocks (sgd_conv_kernel's): periodic layout, rejected without the walk
+    if (i >= L.conv[1] && i < L.p_conv && (i - L.conv[1]) % (2 * (size_t)kConvW + 512) < 2 * (size_t)kConvW) return;
     for (int k = 0; k < kLayers; ++k) {
         const size_t wn = k == 0 ? 64 * 6 * 9 : kConvW;
         if (i >= L.conv[k] && i < L.conv[k] + wn) { l = k; kind = 0; break; }
@@ -779,9 +967,10 @@ __global__ void sgd_conv_kernel(TrainDev T, SgdArgs a) {
     if (e >= 36864) return;
     const int ci = e & 63, co = (e >> 6) & 63, tap = e >> 12;
     if (l == 0 && ci >= 6) return;
-    const float *p = T.partial + (size_t)l * T.NWG * 36864 + e;
+    const float *p = T.partial + (size_t)l * T.WCH * 36864 + e;
     float g = 0.f;
-    for (int w = 0; w < T.NWG; ++w) g += p[(size_t)w * 36864];
+#pragma unroll 8
+    for (int w = 0; w < T.WCH; ++w) g += p[(size_t)w * 36864];
     const size_t i = T.L.conv[l] + (l == 0 ? (size_t)(co * 6 + ci) * 9 + tap : (size_t)(co * 64 + ci) * 9 + tap);
     const float w0 = T.param[i];
     g = fmaf(a.weight_decay, w0, g);
@@ -810,7 +999,7 @@ int talloc(tg_trainer *t, T **out, size_t count) {
     return TG_OK;
 }
 constexpr int kConvLds = (P * kRow + kRow + 9 * 64) * 4;
-constexpr int kWgradLds = (P * kRow + kRow + 84 * kRow + 7 * 64) * 4;
+constexpr int kWgradLds = kWgradLdsFloats * 4;
 }  // namespace
 
 extern "C" {
@@ -829,12 +1018,13 @@ int tg_trainer_create(int board_size, int device, int batch, const float *params
     D.L = L;
     D.B = batch;
     D.NWG = batch < 256 ? batch : 256;
+    D.WCH = batch < 64 ? batch : 64;
     const size_t act = (size_t)batch * P * C;
     int rc = TG_OK;
     if ((rc = talloc(t, &D.param, L.total)) || (rc = talloc(t, &D.grad, L.total)) || (rc = talloc(t, &D.mom, L.total)) ||
         (rc = talloc(t, &D.wf, (size_t)kLayers * 36864)) || (rc = talloc(t, &D.wb, (size_t)kLayers * 36864)) ||
         (rc = talloc(t, &D.Z, kLayers * act)) || (rc = talloc(t, &D.Y, 7 * act)) || (rc = talloc(t, &D.D, kLayers * act)) ||
-        (rc = talloc(t, &D.stat, (size_t)kLayers * kRep * 256)) || (rc = talloc(t, &D.partial, (size_t)kLayers * D.NWG * 36864)) ||
+        (rc = talloc(t, &D.stat, (size_t)kLayers * kRep * 256)) || (rc = talloc(t, &D.partial, (size_t)kLayers * D.WCH * 36864)) ||
         (rc = talloc(t, &D.hz, (size_t)batch * P * 4)) || (rc = talloc(t, &D.hD, (size_t)batch * P * 4)) ||
         (rc = talloc(t, &D.hstat, (size_t)kRep * 16)) || (rc = talloc(t, &D.hact, (size_t)batch * 3 * P)) ||
         (rc = talloc(t, &D.dlog, (size_t)batch * (A + 3))) || (rc = talloc(t, &D.loss, (size_t)kRep * 4))) {
@@ -865,19 +1055,15 @@ int tg_trainer_step(tg_trainer *t, const float *planes_dev, const float *policy_
     hipStream_t st = static_cast<hipStream_t>(stream);
     TrainDev &D = t->dev;
     const int grid = D.NWG;
-    TG_HIP(hipMemsetAsync(D.stat, 0, (size_t)kLayers * kRep * 256 * sizeof(double), st));
-    TG_HIP(hipMemsetAsync(D.hstat, 0, (size_t)kRep * 16 * sizeof(double), st));
-    TG_HIP(hipMemsetAsync(D.grad + D.L.p_conv, 0, 128 * sizeof(float), st));
-    TG_HIP(hipMemsetAsync(D.grad + D.L.v_conv, 0, 64 * sizeof(float), st));
     hipLaunchKernelGGL(repack_kernel, dim3(36864 / 256, kLayers), dim3(256), 0, st, D);
     for (int l = 0; l < kLayers; ++l)
         hipLaunchKernelGGL(conv_kernel<FWD>, dim3(grid), dim3(256), kConvLds, st, D, planes_dev, l);
-    hipLaunchKernelGGL(head_conv_kernel, dim3(grid), dim3(128), 0, st, D);
+    hipLaunchKernelGGL(head_conv_kernel, dim3(grid), dim3(256), 0, st, D);
     hipLaunchKernelGGL(head_loss_kernel, dim3(grid), dim3(256), 0, st, D, policy_dev, value_dev, sl_mode, value_weight);
-    hipLaunchKernelGGL(head_fc_grad_kernel, dim3(A + 3), dim3(192), 0, st, D);
+    hipLaunchKernelGGL(head_fc_grad_kernel, dim3(A + 3), dim3(192, 4), 0, st, D);
     hipLaunchKernelGGL(head_back_kernel, dim3(grid), dim3(256), 0, st, D);
     for (int l = kLayers - 1; l >= 0; --l) {
-        hipLaunchKernelGGL(wgrad_kernel, dim3(grid), dim3(512), kWgradLds, st, D, planes_dev, l);
+        hipLaunchKernelGGL(wgrad_kernel, dim3(4 * D.WCH), dim3(512), kWgradLds, st, D, planes_dev, l);
         if (l >= 1) hipLaunchKernelGGL(conv_kernel<DGRAD>, dim3(grid), dim3(256), kConvLds, st, D, planes_dev, l);
     }
     SgdArgs a{lr, 0.9f, 1e-4f, t->first_step ? 1 : 0};
@@ -918,6 +1104,12 @@ int tg_trainer_debug_read(tg_trainer *t, int which, int index, float *out_host) 
     TG_HIP(hipDeviceSynchronize());
     const TrainDev &D = t->dev;
     const size_t act = (size_t)D.B * P * C;
+#ifdef TG_TRAIN_PROF
+    if (which == 3) {
+        TG_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 64));
+        return TG_OK;
+    }
+#endif
     const float *src = which == 0 ? D.Z + index * act : which == 1 ? D.Y + index * act : which == 2 ? D.D + index * act : nullptr;
     if (!src) return tg::fail(TG_ERR_ARG, "tg_trainer_debug_read: which must be 0 (Z), 1 (Y) or 2 (D)");
     TG_HIP(hipMemcpy(out_host, src, act * sizeof(float), hipMemcpyDeviceToHost));

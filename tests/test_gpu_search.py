@@ -348,3 +348,47 @@ def test_pipelined_selection_equals_serial(cfg):
         assert res.returncode == 0, res.stderr[-2000:]
         outs.append(res.stdout.strip().splitlines()[-1])
     assert len(set(outs)) == 1, outs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size,trees,batches", [(9, 1, [256, 256, 256, 232]), (9, 3, [32, 32, 7]), (19, 1, [64] * 5 + [13])])
+def test_chained_mini_batches_equal_the_per_mini_batch_loop(size, trees, batches):
+    """tg_search_puct_chain (all mini-batches of a STRICT_PLAYOUT search queued in one call, the random window sent in pieces) against
+    puct_batch called once per mini-batch, on freshly seeded streams as search_best_move starts them: same root statistics, same
+    node counts, same generator state afterwards - and MCTSTree.search takes the chained path exactly when nothing between the
+    mini-batches depends on their results."""
+    import torch
+    from oracle.net import make_state_dict
+    from tamago_amd.board.go_board import GoBoard
+    from tamago_amd.mcts.engine import SearchEngine, DeviceEvaluator
+    from tamago_amd.nn.network.dual_net import DualNet
+    net = DualNet(torch.device("cuda:0"), size)
+    net.load_state_dict(make_state_dict(size, 3, 1.3))
+
+    def run(chain):
+        eng = SearchEngine(size, trees, sum(batches) + 64, max(batches), DeviceEvaluator(net))
+        for t in range(trees):
+            eng.set_root(t, GoBoard(size), 1, np.random.RandomState(70 + t).get_state())
+        eng.root_eval(False)
+        assert eng.can_chain(sum(batches))
+        if chain:
+            eng.puct_chain(batches)
+        else:
+            for k in batches:
+                eng.puct_batch(k)
+        stats = eng.read_root_stats()
+        nodes = eng.num_nodes().copy()
+        states = [eng.streams[t].final_state() for t in range(trees)]
+        sizes = list(eng.evaluator.batches)
+        eng.close()
+        return stats, nodes, states, sizes
+
+    a, b = run(False), run(True)
+    for key in a[0]:
+        assert np.array_equal(a[0][key], b[0][key]), key
+    assert np.array_equal(a[1], b[1]) and a[3] == b[3]
+    for sa, sb in zip(a[2], b[2]):
+        ga, gb = np.random.RandomState(), np.random.RandomState()
+        ga.set_state(sa)
+        gb.set_state(sb)
+        assert np.array_equal(ga.random_sample(8), gb.random_sample(8))
