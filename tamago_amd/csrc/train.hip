@@ -37,6 +37,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int S = 9, P = 81, A = 82, C = 64;
 constexpr int kLayers = 13;                       // conv layers: stem + 12
 constexpr int kRow = 72;                          // LDS row stride in floats (conflict-free ds_read_b128)
+constexpr int kCells = 121;                       // 11 x 11 padded board of the convolution kernels
 constexpr int kMT = 6;                            // 16-row tiles per board (96 >= 81)
 constexpr int kConvW = 64 * 64 * 9;
 constexpr int kRep = 16;                          // replicas of every atomically accumulated statistic
@@ -136,26 +137,12 @@ __device__ unsigned long long g_prof[4 * 16];
 template <int MODE>
 __global__ __launch_bounds__(256) void conv_kernel(TrainDev T, const float *__restrict__ planes, int l) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *act = smem;                       // [81][72] + zero row
-    float *zrow = smem + P * kRow;
-    float *tab = zrow + kRow;                // per-channel constants [4][64]
+    float *act = smem;                       // [121 cells of the 11 x 11 padded board][72]: the border stays zero, a tap is a constant offset
+    float *tab = smem + kCells * kRow;       // per-channel constants [9][64]
     constexpr int NT = 256, HMT = kMT;                     // row tiles per wave
     const int tid = threadIdx.x, wave = tid >> 6, half = 0, lane = tid & 63, li = lane & 15, lg = lane >> 4;
     const float eps_l = 2e-5f;
-    for (int e = tid; e < kRow; e += NT) zrow[e] = 0.f;
-    // tap validity of row (half * HMT + mt) * 16 + li
-    unsigned mask[HMT];
-#pragma unroll
-    for (int mt = 0; mt < HMT; ++mt) {
-        const int r = (half * HMT + mt) * 16 + li, y = r / S, x = r - y * S;
-        unsigned m = 0;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-            if (r < P && yy >= 0 && yy < S && xx >= 0 && xx < S) m |= 1u << t;
-        }
-        mask[mt] = m;
-    }
+    for (int e = tid; e < kCells * kRow / 4; e += NT) reinterpret_cast<f32x4 *>(act)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
     // ---- the board's global loads are requested before the per-channel tables are made: the tables cost a round trip to the
     //      statistics + fp64 division and square root, the board a round trip of its own (1.5 us per launch when one followed
     //      the other; a 256-position batch is ONE board per workgroup) ----
@@ -223,8 +210,8 @@ __global__ __launch_bounds__(256) void conv_kernel(TrainDev T, const float *__re
         // ---- stage the board: LDS act[row][c] from the registers requested above / at the end of the board before ----
         if (MODE == FWD && l == 0) {
             for (int e = tid; e < P * C; e += NT) {
-                const int row = e >> 6, c = e & 63;
-                act[row * kRow + c] = c < 6 ? planes[((size_t)b * 6 + c) * P + row] : 0.f;
+                const int row = e >> 6, c = e & 63, y = row / S;
+                act[((y + 1) * 11 + row - y * S + 1) * kRow + c] = c < 6 ? planes[((size_t)b * 6 + c) * P + row] : 0.f;
             }
         } else {
             float *yout = fwd && conv1 ? T.Y + ((size_t)yb * T.B + b) * bstride : nullptr;
@@ -232,7 +219,7 @@ __global__ __launch_bounds__(256) void conv_kernel(TrainDev T, const float *__re
             for (int i = 0; i < NV; ++i) {
                 const int e = tid + i * NT;
                 if (e < P * C / 4) {
-                    const int row = e >> 4, c = (e & 15) * 4;
+                    const int row = e >> 4, c = (e & 15) * 4, y = row / S, cell = (y + 1) * 11 + row - y * S + 1;
                     f32x4 v;
                     if (fwd) {
 #pragma unroll
@@ -249,7 +236,7 @@ __global__ __launch_bounds__(256) void conv_kernel(TrainDev T, const float *__re
                             v[j] = tab[c + j] * (sv[i][j] - tab[192 + c + j] - xh * tab[256 + c + j]);
                         }
                     }
-                    *reinterpret_cast<f32x4 *>(act + row * kRow + c) = v;
+                    *reinterpret_cast<f32x4 *>(act + cell * kRow + c) = v;
                 }
             }
         }
@@ -277,25 +264,27 @@ __global__ __launch_bounds__(256) void conv_kernel(TrainDev T, const float *__re
                 }
             }
         }
-        // per row tile: base pointer of the lane's row (channel sub-group lg), per tap: shifted or the zero row
+
+        // per row tile: the lane's row on the padded board, one cell up-left (tap (0, 0)); rows beyond the board (tile 5) read
+        // row 0's cells - their products are never stored
         const float *rowp[HMT];
 #pragma unroll
-        for (int mt = 0; mt < HMT; ++mt) rowp[mt] = act + ((half * HMT + mt) * 16 + li) * kRow + lg * 4;
-        const float *zp = zrow + lg * 4;
+        for (int mt = 0; mt < HMT; ++mt) {
+            const int r = (half * HMT + mt) * 16 + li, r2 = r < P ? r : 0, y = r2 / S;
+            rowp[mt] = act + (y * 11 + r2 - y * S) * kRow + lg * 4;
+        }
         f32x4 wq[3], av[2][HMT];
         wq[0] = wl[0];
         wq[1] = wl[64];
 #pragma unroll
-        for (int mt = 0; mt < HMT; ++mt)
-            av[0][mt] = lds4((((mask[mt] >> 0) & 1u) ? rowp[mt] + (-S - 1) * kRow : zp));
+        for (int mt = 0; mt < HMT; ++mt) av[0][mt] = lds4(rowp[mt]);
         static_for<36>([&](auto ST_) {
             constexpr int st = decltype(ST_)::value, nx = st + 1, tapn = nx / 4, sn = nx % 4;
-            constexpr int toffn = ((tapn / 3 - 1) * S + (tapn % 3 - 1)) * kRow;
+            constexpr int toffn = ((tapn / 3) * 11 + tapn % 3) * kRow;
             wq[(st + 2) % 3] = wl[(st + 2 < 36 ? st + 2 : 35) * 64];
             if constexpr (nx < 36) {
 #pragma unroll
-                for (int mt = 0; mt < HMT; ++mt)
-                    av[nx & 1][mt] = lds4((((mask[mt] >> tapn) & 1u) ? rowp[mt] + toffn : zp) + sn * 16);
+                for (int mt = 0; mt < HMT; ++mt) av[nx & 1][mt] = lds4(rowp[mt] + toffn + sn * 16);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -998,7 +987,7 @@ int talloc(tg_trainer *t, T **out, size_t count) {
     *out = static_cast<T *>(p);
     return TG_OK;
 }
-constexpr int kConvLds = (P * kRow + kRow + 9 * 64) * 4;
+constexpr int kConvLds = (kCells * kRow + 9 * 64) * 4;
 constexpr int kWgradLds = kWgradLdsFloats * 4;
 }  // namespace
 
@@ -1062,6 +1051,9 @@ int tg_trainer_step(tg_trainer *t, const float *planes_dev, const float *policy_
     hipLaunchKernelGGL(head_loss_kernel, dim3(grid), dim3(256), 0, st, D, policy_dev, value_dev, sl_mode, value_weight);
     hipLaunchKernelGGL(head_fc_grad_kernel, dim3(A + 3), dim3(192, 4), 0, st, D);
     hipLaunchKernelGGL(head_back_kernel, dim3(grid), dim3(256), 0, st, D);
+    // backward.  (Measured and dropped: wgrad of layer l on a second stream beside the data-gradient chain - the two kernels do
+    // run side by side, 34 + 32 us overlapping into 41 instead of 24 + 20 one after the other, but the event between two
+    // launches of the chain costs 8 us on its stream: 0.91 against 0.93 ms per step.)
     for (int l = kLayers - 1; l >= 0; --l) {
         hipLaunchKernelGGL(wgrad_kernel, dim3(4 * D.WCH), dim3(512), kWgradLds, st, D, planes_dev, l);
         if (l >= 1) hipLaunchKernelGGL(conv_kernel<DGRAD>, dim3(grid), dim3(256), kConvLds, st, D, planes_dev, l);
