@@ -197,10 +197,9 @@ def run_step(engines, plies_list, fresh_board, visits, batch):
             # window for the next search, generated while this search's last forward pass runs
             engine.prefetch_rng(first)
             leaves += engine.T * (1 + visits)
-            nc, action, visits_arr = engine.read_roots()
-            cols = np.arange(engine.A)[None, :]
-            masked = np.where(cols < nc[:, None], visits_arr, -1)
-            moves = action[np.arange(engine.T), np.argmax(masked, axis=1)].astype(np.int32)
+            # -2: the most visited root child's move (get_best_move_index), chosen by the play kernel - the driver only
+            # advances the positions and needs no read-back between two searches
+            moves = np.full(engine.T, -2, dtype=np.int32)
             plies += 1
             over = plies > 2 * engine.P - 8
             moves[over] = -1

@@ -207,9 +207,10 @@ int tg_search_read_root_stats(tg_search *s, int32_t *num_children_host, int32_t 
  * expansion detail: candidates / Dirichlet sum / node init); the call returns the counters
  * accumulated so far (cycles_host [16], may be NULL) and clears them. */
 int tg_search_profile(tg_search *s, int enable, long long *cycles_host);
-/* Play moves_host[t] (padded coordinate, 0 = PASS, < 0 = leave the tree alone) on the ROOT
- * position of every tree on the device (GoBoard.put_stone, go_board.py:131-185) and flip the
- * side to move: self-play boards stay resident between searches. */
+/* Play moves_host[t] (padded coordinate, 0 = PASS, -1 = leave the tree alone, -2 = the move of the most
+ * visited child of the tree's root, node.py:167-175 get_best_move_index, chosen on the device: no
+ * read-back between two searches) on the ROOT position of every tree on the device (GoBoard.put_stone,
+ * go_board.py:131-185) and flip the side to move: self-play boards stay resident between searches. */
 int tg_search_play(tg_search *s, const int32_t *moves_host, void *stream);
 /* Current root positions: cells uint8 [T][(S+2)^2], GoBoard.moves [T], side to move [T]
  * (any pointer may be NULL). Synchronises. */

@@ -188,13 +188,15 @@ __device__ __forceinline__ double read_lane_f64(double v, int src_lane) {
 // way.  ~40 instructions and no branches; the compare-and-swap butterfly above costs ~150 with its exec-mask
 // juggling.  Returns the wave-uniform winner (-1: no candidate).  All 64 lanes must be active.
 __device__ __forceinline__ int wave_argmax_first(double val, int idx) {
+    // (compare + select, not fmax: fmax quiets signalling NaNs first - a v_max_f64 x, x in front of every step; the scores
+    // compared here are never NaN unless the network has diverged, and then any deterministic answer will do)
+    auto mx2 = [](double a, double b) { return b > a ? b : a; };
     double m = idx >= 0 ? val : -__builtin_inf();
-    m = __builtin_fmax(m, lane_partner_f64<0>(m));
-    m = __builtin_fmax(m, lane_partner_f64<1>(m));
-    m = __builtin_fmax(m, lane_partner_f64<2>(m));
-    m = __builtin_fmax(m, lane_partner_f64<3>(m));
-    const double mx = __builtin_fmax(__builtin_fmax(read_lane_f64(m, 0), read_lane_f64(m, 16)),
-                                     __builtin_fmax(read_lane_f64(m, 32), read_lane_f64(m, 48)));
+    m = mx2(m, lane_partner_f64<0>(m));
+    m = mx2(m, lane_partner_f64<1>(m));
+    m = mx2(m, lane_partner_f64<2>(m));
+    m = mx2(m, lane_partner_f64<3>(m));
+    const double mx = mx2(mx2(read_lane_f64(m, 0), read_lane_f64(m, 16)), mx2(read_lane_f64(m, 32), read_lane_f64(m, 48)));
     int c = (idx >= 0 && val == mx) ? idx : 0x7fffffff;
     c = min(c, lane_partner_i32<0>(c));
     c = min(c, lane_partner_i32<1>(c));
@@ -638,6 +640,18 @@ __device__ void write_planes(const LT &L, const BoardScalars &b, int to_move, fl
     }
 }
 
+constexpr int kRcpN = 2048;
+
+// a / b for an integer-valued b whose reciprocal y = RN(1 / b) is at hand: q0 = RN(a y) is within an ulp of the quotient, the
+// remainder r = a - b q0 is exact in one FMA, and RN(q0 + r y) is the correctly rounded quotient (Markstein; b's significand
+// is never all ones here: b < 2^31) - the bits of the IEEE division in four instructions instead of the ~25 of v_div_*.
+// Checked against exact rational arithmetic for 300 000 (a, b <= 4096) on the CPU and by every tree digest of the GPU suite.
+__device__ __forceinline__ double div_by_count(double a, double b, double y) {
+    const double q0 = a * y;
+    const double r = __builtin_fma(-q0, b, a);
+    return __builtin_fma(r, y, q0);
+}
+
 // node.py:141-157 + pucb.py:8-29.  Everything the descent step needs from the node is loaded
 // in ONE round trip (the loads are independent): the three node scalars and, per lane, the
 // child arrays of its (up to ceil(A/64)) slots incl. action and child index; the winner's
@@ -648,11 +662,14 @@ struct EdgePick {
 
 // pucb.py:8-29 on a node's statistics held in registers (lane i + 64 r: child i + 64 r); `total` = visits + virtual
 // losses of the node.  The arithmetic of select_puct, shared with the kernels that load the statistics themselves.
+// `rcp` (optional, LDS): rcp[n] = RN(1 / n) for n < kRcpN - both quotients then cost four instructions each instead of the
+// ~25 of the division sequence (div_by_count: the same bits).
 template <int S>
 __device__ __forceinline__ EdgePick score_puct(const SearchDev &D, const int (&vis)[(Geo<S>::A + 63) / 64],
                                                const int (&vl)[(Geo<S>::A + 63) / 64], const int (&idx)[(Geo<S>::A + 63) / 64],
                                                const int (&act)[(Geo<S>::A + 63) / 64], const double (&vsum)[(Geo<S>::A + 63) / 64],
-                                               const double (&pol)[(Geo<S>::A + 63) / 64], int nc, int total, int node_vl, int lane) {
+                                               const double (&pol)[(Geo<S>::A + 63) / 64], int nc, int total, int node_vl, int lane,
+                                               const double *rcp = nullptr) {
     constexpr int R = (Geo<S>::A + 63) / 64;
     const double sq = __dsqrt_rn((double)(total + 1));
     double best = 0.0;
@@ -664,7 +681,16 @@ __device__ __forceinline__ EdgePick score_puct(const SearchDev &D, const int (&v
         // A group of 64 children none of which has been tried needs no division: q = 0 and u = (p sqrt) / 1, and
         // 0.0 + x / 1.0 is x bit for bit.  Most groups of most nodes are like that.
         if (__any(i < nc && cnt != 0)) {
-            if (i < nc) {
+            if (rcp && !__any(i < nc && cnt + 1 >= kRcpN)) {
+                if (i < nc) {
+                    const int c1 = cnt != 0 ? cnt : 1;
+                    const double q = cnt != 0 ? div_by_count(vsum[r], (double)c1, rcp[c1]) : 0.0;
+                    const double u = div_by_count(pol[r] * sq, (double)(cnt + 1), rcp[cnt + 1]);
+                    double sc = q + u;
+                    if (D.cgos && i == nc - 1) sc -= 0.1;
+                    if (best_i < 0 || sc > best) { best = sc; best_i = i; }
+                }
+            } else if (i < nc) {
                 const double q = cnt != 0 ? vsum[r] / (double)cnt : 0.0;
                 const double u = (pol[r] * sq) / (double)(cnt + 1);
                 double sc = q + u;
@@ -695,7 +721,7 @@ __device__ __forceinline__ EdgePick score_puct(const SearchDev &D, const int (&v
 }
 
 template <int S>
-__device__ EdgePick select_puct(const SearchDev &D, int t, int node, int lane) {
+__device__ EdgePick select_puct(const SearchDev &D, int t, int node, int lane, const double *rcp = nullptr) {
     constexpr int A = Geo<S>::A;
     constexpr int R = (A + 63) / 64;
     const size_t ns = (size_t)t * D.N + node;
@@ -716,7 +742,7 @@ __device__ EdgePick select_puct(const SearchDev &D, int t, int node, int lane) {
     const int nc = D.n_children[ns];
     const int node_vl = D.n_vl[ns];
     const int total = D.n_visits[ns] + node_vl;
-    return score_puct<S>(D, vis, vl, idx, act, vsum, pol, nc, total, node_vl, lane);
+    return score_puct<S>(D, vis, vl, idx, act, vsum, pol, nc, total, node_vl, lane, rcp);
 }
 
 template <int S, typename LT>
@@ -1576,6 +1602,17 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 //   * the random-draw cursor: inside ONE workgroup of workers a chain through LDS (NWG = 1); with more, counts in and
 //     offsets out through a wave of the selecting half (see the kernel).
 // Bounded spins everywhere (a stall is an error, never a hang).  Same trees bit for bit.
+// -DTG_SPLIT_PROF (tools/experiments/split_prof.sh): s_memtime accumulators of tree 0 in D.prof - who waits for whom in a launch
+// (0 root loop, 1 root's wait for a free slot, 2 allocator loop, 3 allocator's wait, 4 node owner 1 busy, 5 its steps, 6 shipper 0
+// loop, 7-10 worker (1, 0): wait for a job / replay / expansion / planes, 12 start of the selecting half (absolute), 13 latest end
+// of a worker (absolute), 15 selecting half start to end)
+#ifdef TG_SPLIT_PROF
+#define SP_NOW() ((long long)__builtin_amdgcn_s_memtime())
+#define SP_ON(D, t) ((D).prof != nullptr && (t) == 0)
+#else
+#define SP_NOW() 0LL
+#define SP_ON(D, t) false
+#endif
 constexpr int kXwHeader = 8;                                   // words: tag, parent, edge, child, expand, xseq, depth, k
 template <int S>
 constexpr int kXwEntryWords = kXwHeader + kPathCap + kPathMax<S> / 2;
@@ -1603,6 +1640,10 @@ struct SplitSelShared {
     int nexp_total;                   // expansions of the launch (once all_done)
     int all_done;
     int err;
+    // the root owner's step is the chain a launch hangs on: sqrt(N + k + 1) of every descent and the correctly rounded
+    // reciprocals of the counts a child can reach are made by the whole workgroup before the chain starts
+    double sq[kPipeMaxK];
+    double rcp[kRcpN];
 };
 template <int S, int NWRK>
 struct SplitWrkShared {
@@ -1640,15 +1681,23 @@ __global__ __launch_bounds__(1024) void select_puct_split_kernel(SearchDev D, in
     unsigned long long *const xoff = xw_off + (size_t)t * (cap + 1);          // draws before expansion x (tagged)
     const long long cursor0 = D.rng_cursor[t];
 
+    const bool sp = SP_ON(D, t) && lane == 0;
+    const long long sp_t0 = SP_NOW();
     if (selecting) {
         using Shared = SplitSelShared<S, NNODE>;
         constexpr int kSlots = Shared::kSlots;
         Shared &sh = *reinterpret_cast<Shared *>(xw_smem);
+        if (sp && threadIdx.x == 0) D.prof[12] = sp_t0;
         if (threadIdx.x < kSlots) {
             sh.slot_free[threadIdx.x] = 0; sh.leaf_ready[threadIdx.x] = 0; sh.ship_ready[threadIdx.x] = 0; sh.mail[threadIdx.x] = 0;
         }
         for (int i = threadIdx.x; i < kPipeMaxK; i += 1024) { sh.alloc_child[i] = kOwnNotYet; sh.exp_key[i] = -1; }
         if (threadIdx.x == 0) { sh.num_nodes = n0; sh.all_done = 0; sh.err = 0; }
+        {
+            const int total0 = D.n_visits[root_ns] + D.n_vl[root_ns];
+            for (int i = threadIdx.x; i < max_leaves; i += 1024) sh.sq[i] = __dsqrt_rn((double)(total0 + i + 1));
+            for (int i = threadIdx.x; i < kRcpN; i += 1024) sh.rcp[i] = 1.0 / (double)(i ? i : 1);
+        }
         __syncthreads();
         auto fail = [&](int code, int site) {
             if (lane == 0 && !pipe_load(&sh.err)) {
@@ -1661,7 +1710,7 @@ __global__ __launch_bounds__(1024) void select_puct_split_kernel(SearchDev D, in
             __builtin_amdgcn_s_setprio(3);
             if (active) {
                 int r_vis[R], r_act[R], r_idx[R], r_kref[R], c_vl[R];
-                double r_vsum[R], r_pol[R], c_q[R];
+                double r_vsum[R], r_pol[R], c_q[R], c_den[R], c_rcp[R];
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const int i = lane + 64 * r, ii = i < A ? i : A - 1;
@@ -1674,27 +1723,35 @@ __global__ __launch_bounds__(1024) void select_puct_split_kernel(SearchDev D, in
                     r_kref[r] = -1;
                     const int cnt = r_vis[r] + c_vl[r];
                     c_q[r] = cnt != 0 ? r_vsum[r] / (double)cnt : 0.0;
+                    c_den[r] = (double)(cnt + 1);
+                    if (__any(cnt + 1 >= kRcpN)) c_rcp[r] = 1.0 / c_den[r];     // wave-uniform: the division is not even issued otherwise
+                    else c_rcp[r] = sh.rcp[cnt + 1];
                 }
                 const int root_nc = D.n_children[root_ns];
-                const int root_total0 = D.n_visits[root_ns] + D.n_vl[root_ns];
                 bool ok = true;
+                long long sp_acc = 0, sp_seg[4] = {0, 0, 0, 0};
                 for (int k = 0; k < max_leaves; ++k) {
                     const int slot = k % kSlots;
+                    const long long sp_w = SP_NOW();
                     ok = mp_wait_ge(sh, &sh.slot_free[slot], k / kSlots);
+                    long long sp_x = SP_NOW();
+                    sp_acc += sp_x - sp_w;
                     if (!ok) break;
-                    const double sq = __dsqrt_rn((double)(root_total0 + k + 1));
+                    const double sq = sh.sq[k];
                     double best = 0.0;
                     int best_i = -1;
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         const int i = lane + 64 * r;
                         if (i < root_nc) {
-                            double v = c_q[r] + (r_pol[r] * sq) / (double)(r_vis[r] + c_vl[r] + 1);
+                            double v = c_q[r] + div_by_count(r_pol[r] * sq, c_den[r], c_rcp[r]);
                             if (D.cgos && i == root_nc - 1) v -= 0.1;
                             if (best_i < 0 || v > best) { best = v; best_i = i; }
                         }
                     }
+                    { const long long n = SP_NOW(); sp_seg[0] += n - sp_x; sp_x = n; }
                     best_i = wave_argmax_first(best, best_i);
+                    { const long long n = SP_NOW(); sp_seg[1] += n - sp_x; sp_x = n; }
                     const int owner = best_i & 63, oslot = best_i >> 6;
                     int my_move = 0, my_child = 0, my_cnt = 0, my_kref = -1;
 #pragma unroll
@@ -1719,10 +1776,16 @@ __global__ __launch_bounds__(1024) void select_puct_split_kernel(SearchDev D, in
                                 c_vl[r] += 1;
                                 if (expands) r_kref[r] = k;
                             }
+                            // the owner's new count is its old denominator: q = value sum / count by the reciprocal it holds
                             const int cnt = r_vis[r] + c_vl[r];
-                            const double q = cnt != 0 ? r_vsum[r] / (double)cnt : 0.0;
-                            if (lane == owner) c_q[r] = q;
+                            const double q = div_by_count(r_vsum[r], c_den[r], c_rcp[r]);
+                            const double den = (double)(cnt + 1);
+                            double rcp;
+                            if (__any(lane == owner && cnt + 1 >= kRcpN)) rcp = 1.0 / den;
+                            else rcp = sh.rcp[cnt + 1 < kRcpN ? cnt + 1 : 0];
+                            if (lane == owner) { c_q[r] = q; c_den[r] = den; c_rcp[r] = rcp; }
                         }
+                    { const long long n = SP_NOW(); sp_seg[2] += n - sp_x; sp_x = n; }
                     if (lane == 0) {
                         sh.moves[slot][0] = (int16_t)mv;
                         sh.qpath[slot][0] = e;
@@ -1734,7 +1797,12 @@ __global__ __launch_bounds__(1024) void select_puct_split_kernel(SearchDev D, in
                             mp_publish(&sh.mail[slot], ((k + 1) << 8) | (1 + (1 + e) % NNODE));
                         }
                     }
+                    sp_seg[3] += SP_NOW() - sp_x;
                 }
+                if (sp) { D.prof[0] += SP_NOW() - sp_t0; D.prof[1] += sp_acc; }
+#ifdef TG_SPLIT_PROF_ROOT      // the root step by segment instead of the worker's phases: 7 scores, 8 arg-max, 9 winner + update, 10 job hand-off
+                if (sp) { D.prof[7] += sp_seg[0]; D.prof[8] += sp_seg[1]; D.prof[9] += sp_seg[2]; D.prof[10] += sp_seg[3]; }
+#endif
                 if (!ok) fail(kErrPipeline, 1);
                 if (ok) {
 #pragma unroll
@@ -1751,6 +1819,7 @@ __global__ __launch_bounds__(1024) void select_puct_split_kernel(SearchDev D, in
             const int me = wid;
             int idle = 0;
             int unf0 = -1, unf1 = -1, unf2 = -1, unf3 = -1, n_unf = 0;
+            long long sp_busy = 0, sp_steps = 0;
             while (active) {
                 const int w = lane < kSlots ? pipe_load(&sh.mail[lane]) : 0;
                 const bool mine = (w & 255) == me;
@@ -1784,6 +1853,7 @@ __global__ __launch_bounds__(1024) void select_puct_split_kernel(SearchDev D, in
                     continue;
                 }
                 idle = 0;
+                const long long sp_b = SP_NOW();
                 const int depth = sh.st_depth[slot], prev = sh.st_prev[slot], redge = sh.st_redge[slot];
                 if (depth >= kPathMax<S>) { fail(kErrPipeline, 3); break; }
                 if (was_fresh) {
@@ -1802,7 +1872,7 @@ __global__ __launch_bounds__(1024) void select_puct_split_kernel(SearchDev D, in
                 else if (n_unf == 2) unf2 = node;
                 else unf3 = node;
                 ++n_unf;
-                const EdgePick pick = select_puct<S>(D, t, node, lane);
+                const EdgePick pick = select_puct<S>(D, t, node, lane, sh.rcp);
                 const int e = pick.edge, mv = pick.move;
                 const size_t ns = (size_t)t * D.N + node, base = ns * A;
                 const bool two_pass = meta.moves + depth + 1 > 2 && mv == 0 && prev == 0;   // tree.py:224-229
@@ -1835,14 +1905,22 @@ __global__ __launch_bounds__(1024) void select_puct_split_kernel(SearchDev D, in
                     }
                 }
                 wave_sync();
+                sp_busy += SP_NOW() - sp_b;
+                sp_steps += 1;
             }
+#ifndef TG_BACKUP_PROF
+            if (sp && me == 1) { D.prof[4] += sp_busy; D.prof[5] += sp_steps; }
+#endif
         } else if (wid == NNODE + 1) {
             // ---- the allocator: leaves in descent order (LDS only: what later descents may be waiting for) ----
             int num_nodes = n0, nexp = 0;
             bool ok = active;
+            long long sp_acc = 0;
             for (int k = 0; ok && k < max_leaves; ++k) {
                 const int slot = k % kSlots;
+                const long long sp_w = SP_NOW();
                 ok = mp_wait_ge(sh, &sh.leaf_ready[slot], k + 1);
+                sp_acc += SP_NOW() - sp_w;
                 if (!ok) { fail(kErrPipeline, 5); break; }
                 const int parent = sh.lm_parent[slot], e = sh.lm_edge[slot];
                 int child = sh.lm_child[slot];
@@ -1870,6 +1948,9 @@ __global__ __launch_bounds__(1024) void select_puct_split_kernel(SearchDev D, in
                 sh.nexp_total = nexp;
                 if (ok) mp_publish(&sh.all_done, 1);
             }
+#ifndef TG_BACKUP_PROF
+            if (sp) { D.prof[2] += SP_NOW() - sp_t0; D.prof[3] += sp_acc; }
+#endif
         } else if (wid < NNODE + 2 + NSHIP) {
             // ---- shippers: job k to the workers' workgroup, on wave k % NSHIP (a store to the coherence point takes
             //      longer than the root takes for a descent: several jobs are under way at a time) ----
@@ -1903,6 +1984,7 @@ __global__ __launch_bounds__(1024) void select_puct_split_kernel(SearchDev D, in
                     mp_publish(&sh.slot_free[slot], k / kSlots + 1);
                 }
             }
+            if (sp && j == 0) D.prof[6] += SP_NOW() - sp_t0;
         }
         if (NWG > 1 && wid == NNODE + 2 + NSHIP && active) {
             // ---- the draw cursor: counts in, offsets out, in expansion order ----
@@ -1943,6 +2025,7 @@ __global__ __launch_bounds__(1024) void select_puct_split_kernel(SearchDev D, in
         if (threadIdx.x == 0) {
             D.meta[t].num_nodes = sh.num_nodes;
             D.n_leaves[t] = good ? max_leaves : 0;
+            if (sp) D.prof[15] += SP_NOW() - sp_t0;
         }
     } else {
         // ---- the workers' workgroup: job k on wave k % NWRK ----------------------------------------------------
@@ -1956,9 +2039,11 @@ __global__ __launch_bounds__(1024) void select_puct_split_kernel(SearchDev D, in
             BoardScalars rootb;
             int root_to_move;
             load_root<S>(L, rootb, root_to_move, D, t, lane);
+            long long sp_a[4] = {0, 0, 0, 0};
             for (int k = (role - 1) * NWRK + w; active && k < max_leaves; k += NWG * NWRK) {
                 const int *const entry = jobs + (size_t)k * EW;
                 bool have = false;
+                long long sp_x = SP_NOW();
                 for (int spin = 0; spin < kPipeSpinLimit / 16; ++spin) {
                     if (xw_load(&entry[0]) == (tag_base | (k + 1))) { have = true; break; }
                     if ((spin & 63) == 63 && (xw_load(&D.err[t]) || pipe_load(&sh.err))) break;   // the other half gave up
@@ -1969,6 +2054,7 @@ __global__ __launch_bounds__(1024) void select_puct_split_kernel(SearchDev D, in
                     if (lane == 0) pipe_store(&sh.err, 1);
                     break;
                 }
+                { const long long n = SP_NOW(); sp_a[0] += n - sp_x; sp_x = n; }
                 const int hw = lane < kXwHeader + kPathCap ? xw_load(&entry[lane]) : 0;
                 const int parent = __builtin_amdgcn_readlane(hw, 1), edge = __builtin_amdgcn_readlane(hw, 2);
                 const int child = __builtin_amdgcn_readlane(hw, 3), expand = __builtin_amdgcn_readlane(hw, 4);
@@ -1998,6 +2084,7 @@ __global__ __launch_bounds__(1024) void select_puct_split_kernel(SearchDev D, in
                     put_stone<S>(L, b, sh.moves[w][i], c, D.zob, lane);
                     c = 3 - c;
                 }
+                { const long long n = SP_NOW(); sp_a[1] += n - sp_x; sp_x = n; }
                 if constexpr (NWG == 1) {
                     if (expand) expand_node_pipe<S>(L, b, c, D, t, child, parent, edge, xseq, sh, lane);
                     write_planes<S>(L, b, c, planes + ((size_t)t * max_leaves + k) * 6 * G::P, lane);
@@ -2007,7 +2094,9 @@ __global__ __launch_bounds__(1024) void select_puct_split_kernel(SearchDev D, in
                         n = gen_candidates<S>(L, b, c, D, lane);
                         if (lane == 0) xw_store(&xn[xseq], tag_base | (n + 1));
                     }
+                    { const long long n = SP_NOW(); sp_a[2] += n - sp_x; sp_x = n; }
                     write_planes<S>(L, b, c, planes + ((size_t)t * max_leaves + k) * 6 * G::P, lane);
+                    { const long long n = SP_NOW(); sp_a[3] += n - sp_x; sp_x = n; }
                     if (expand) {
                         unsigned long long ov = 0;
                         bool got = false;
@@ -2035,7 +2124,12 @@ __global__ __launch_bounds__(1024) void select_puct_split_kernel(SearchDev D, in
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                     if (lane == 0) xw_store(&done[k], tag_base | (k + 1));
                 }
+                { const long long n = SP_NOW(); sp_a[2] += n - sp_x; sp_x = n; }
             }
+#ifndef TG_SPLIT_PROF_ROOT
+            if (sp && role == 1 && w == 0) { D.prof[7] += sp_a[0]; D.prof[8] += sp_a[1]; D.prof[9] += sp_a[2]; D.prof[10] += sp_a[3]; }
+#endif
+            if (sp) atomicMax(reinterpret_cast<unsigned long long *>(D.prof + 13), (unsigned long long)SP_NOW());
         }
         __syncthreads();
         if (NWG == 1 && threadIdx.x == 0) D.rng_cursor[t] = sh.cursor_val;
@@ -2072,7 +2166,17 @@ __global__ __launch_bounds__(64 * NWAVE) void backup_kernel(SearchDev D, const f
     __shared__ int r_nvis, r_nvl;
     __shared__ uint16_t leaf_edge[kBackupCap];     // root edge of leaf k; | 0x8000 once backed up WITHOUT a parent (nothing for the root)
     __shared__ float rootv[kBackupCap];            // its value at the root's level
+    __shared__ uint8_t leaf_neg[kBackupCap];       // leaf k names the reference's node[-1] (q_node < 0)
     const size_t rbase = (size_t)t * D.N * A;                     // root = node 0
+#ifdef TG_BACKUP_PROF       // tools/experiments/split_prof.sh: D.prof 2 set-up, 3 policies (slowest wave), 4 values (slowest wave), 5 whole kernel
+    const bool bp = D.prof != nullptr && t == 0 && lane == 0;
+    const long long bp_t0 = (long long)__builtin_amdgcn_s_memtime();
+    __shared__ unsigned long long bp_max[2];
+    if (threadIdx.x < 2) bp_max[threadIdx.x] = 0;
+#define BP_MARK(i) do { if (bp) atomicMax(&bp_max[i], (unsigned long long)__builtin_amdgcn_s_memtime()); } while (0)
+#else
+#define BP_MARK(i) do { } while (0)
+#endif
     bool part = n > 0 && n <= kBackupCap;
     if (n > 0) {
         for (int i = threadIdx.x; i < A; i += NTHR) {
@@ -2088,20 +2192,27 @@ __global__ __launch_bounds__(64 * NWAVE) void backup_kernel(SearchDev D, const f
         if (part)
             for (int k = threadIdx.x; k < n; k += NTHR) {
                 const size_t slot = (size_t)t * D.K + k;
+                leaf_neg[k] = D.q_node[slot] < 0;
                 if (D.q_depth[slot] > 0 && D.q_pnode[slot] >= 0) leaf_edge[k] = (uint16_t)(D.q_path[slot * kPathCap] & 1023);
                 else part = false;
             }
     }
     part = __syncthreads_and(part) != 0;      // (also: every wave has read the leaf count before anybody resets it)
+#ifdef TG_BACKUP_PROF
+    const long long bp_t1 = (long long)__builtin_amdgcn_s_memtime();
+#endif
     {
         // policies.  Each leaf is a chain of four dependent loads (queue entry, child count, actions, policy values).
         // (Gumbel leaves all name the reference's node[-1], tree.py:412-416: the last pool slot, which has no children
         // unless the pool is full - an error - so nothing is written for them and their order is immaterial.)
         // Four leaves of a wave at a time, every stage of the chain for all four before the next stage: the round
         // trips of the four overlap (one leaf after the other: 32 leaves x 4 round trips = 80 us of a 256-leaf launch).
-        constexpr int U = 4, RP = (A + 63) / 64;
+        // Round 5: all leaves of a wave at once where the registers allow (16 at 9x9, 6 at 19x19 instead of four), and the
+        // child count and the actions - both indexed by the node - in ONE stage: three round trips per pass, and a
+        // 256-leaf launch of one tree is a single pass (25 -> 8 us).
+        constexpr int RP = (A + 63) / 64, U = RP <= 2 ? 16 : 6;
         for (int k0 = wid; k0 < n; k0 += U * NWAVE) {
-            int node[U], nc[U];
+            int node[U];
             bool live[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -2109,25 +2220,24 @@ __global__ __launch_bounds__(64 * NWAVE) void backup_kernel(SearchDev D, const f
                 live[u] = k < n;
                 node[u] = live[u] ? D.q_node[(size_t)t * D.K + k] : 0;
             }
+            int nc[U], pos[U][RP];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (node[u] < 0) node[u] = D.N - 1;
                 nc[u] = live[u] ? D.n_children[(size_t)t * D.N + node[u]] : 0;
-            }
-            int pos[U][RP];
-#pragma unroll
-            for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int r = 0; r < RP; ++r) {
                     const int i = lane + 64 * r;
-                    pos[u][r] = i < nc[u] ? (int)D.action[((size_t)t * D.N + node[u]) * A + i] : -1;
+                    pos[u][r] = live[u] && i < A ? (int)D.action[((size_t)t * D.N + node[u]) * A + i] : -1;
                 }
+            }
             float pv[U][RP];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const float *pol = policy + (leaf_base + k0 + u * NWAVE) * A;
 #pragma unroll
                 for (int r = 0; r < RP; ++r) {
+                    if (lane + 64 * r >= nc[u]) pos[u][r] = -1;
                     const int ps = pos[u][r];
                     pv[u][r] = 0.f;
                     if (ps == 0) {
@@ -2145,58 +2255,118 @@ __global__ __launch_bounds__(64 * NWAVE) void backup_kernel(SearchDev D, const f
                     if (pos[u][r] >= 0) D.ch_policy[((size_t)t * D.N + node[u]) * A + lane + 64 * r] = (double)pv[u][r];
         }
     }
+    BP_MARK(0);
     if (part) {
         // values, leaves shared out by root edge.  Lane i handles level i of a leaf's recorded path (all loads of all
         // levels are independent: one memory round trip per leaf); the value at level j above the leaf edge is the
         // reference's iterated float32 `value = 1.0 - value`.
-        for (int k0 = 0; k0 < n; k0 += 64) {
-            const int kk = k0 + lane;
-            unsigned long long todo = __ballot(kk < n && (int)(leaf_edge[kk < n ? kk : 0] % NWAVE) == wid);
-            while (todo) {
-                const int k = k0 + __ffsll((long long)todo) - 1;
-                todo &= todo - 1;
-                const size_t slot = (size_t)t * D.K + k;
-                int node = D.q_node[slot];
-                const int depth = D.q_depth[slot];
-                const int entry = lane < kPathCap ? D.q_path[slot * kPathCap + lane] : 0;
-                const float *val = value + (leaf_base + k) * 3;
-                const float v0 = val[0], v1 = val[1], v2 = val[2];
-                // (a Gumbel leaf with q_node < 0 is the reference's node[-1] quirk: every such leaf writes the LAST pool slot's
-                // raw value, the last one in leaf order wins - that one write is done below by wave 0, in leaf order, instead
-                // of by whichever wave comes last here)
-                if (lane == 0 && node >= 0) D.n_raw[(size_t)t * D.N + node] = v1 * 0.5f + v2;   // tree.py:299
-                if (node < 0) node = D.N - 1;
-                const float vleaf = v0 + v1 * 0.5f;   // tree.py:302
-                if (lane < depth) {
-                    const int pn = entry >> 10, pe = entry & 1023;
-                    float v = vleaf;
-                    for (int q = depth - 1 - lane; q > 0; --q) v = 1.0f - v;
-                    const size_t cs = (size_t)t * D.N + pn;
-                    const size_t ce = cs * A + pe;
-                    if (lane == depth - 1) D.ch_value[ce] = (double)vleaf;   // set_leaf_value
-                    if (lane == 0) {                                         // level 0 is the root: LDS copy
-                        r_vsum[pe] = (double)((float)r_vsum[pe] + v);
-                        r_vis[pe] += 1;
-                        r_vl[pe] -= 1;
-                        rootv[k] = v;
-                    } else {
-                        const double vs = D.ch_vsum[ce];
-                        const int cv = D.ch_visits[ce], cl = D.ch_vl[ce];
-                        const float ns_ = D.n_vsum[cs];
-                        const int nv = D.n_visits[cs], nl = D.n_vl[cs];
-                        D.ch_vsum[ce] = (double)((float)vs + v);         // float32 accumulation (file header)
-                        D.ch_visits[ce] = cv + 1;
-                        D.ch_vl[ce] = cl - 1;
-                        D.n_vsum[cs] = ns_ + v;
-                        D.n_visits[cs] = nv + 1;
-                        D.n_vl[cs] = nl - 1;
-                    }
+        // A wave's leaves are a three-stage pipeline (round 5: one leaf after the other was two dependent round trips each -
+        // 60-80 us per 256-leaf launch of one tree, most of whose leaves hang below one root child, i.e. on one wave):
+        //   M  queue entry, path and network value of the leaf four places ahead are requested,
+        //   S  the statistics of the leaf two places ahead (its metadata has arrived) are requested,
+        //   U  the leaf in front is applied and stored.
+        // The statistics of stage S were requested BEFORE the two leaves in front of it were applied: a lane that meets the
+        // same edge (node) again takes the values it has just computed instead of the loaded ones - a node always sits at
+        // the same level, i.e. in the same lane, so the lane's own last two updates are all that can be stale (its older
+        // stores precede the loads in program order).  Same additions in the same order on every (node, edge).
+        {
+            struct Meta { int k, node, depth, entry; float v0, v1, v2; };
+            struct Stats { double vs; int cv, cl; float ns; int nv, nl; };
+            struct Fwd { long long ekey; int nkey; double vs; int cv, cl; float ns; int nv, nl; };
+            int blk = 0;
+            unsigned long long todo = 0;
+            auto next_k = [&]() -> int {                 // this wave's leaves in leaf order, -1 when there are no more
+                while (!todo) {
+                    if (blk >= n) return -1;
+                    const int kk = blk + lane;
+                    todo = __ballot(kk < n && (int)(leaf_edge[kk < n ? kk : 0] % NWAVE) == wid);
+                    blk += 64;
                 }
-                // (the next leaf of this wave may pass through the same nodes: a node always sits at the same level, i.e.
-                // in the same lane, so its loads follow these stores in that lane's program order)
+                const int k = blk - 64 + __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                return k;
+            };
+            auto fetch = [&](int k) {
+                Meta m;
+                m.k = k;
+                if (k >= 0) {
+                    const size_t slot = (size_t)t * D.K + k;
+                    m.node = D.q_node[slot];
+                    m.depth = D.q_depth[slot];
+                    m.entry = lane < kPathCap ? D.q_path[slot * kPathCap + lane] : 0;
+                    const float *val = value + (leaf_base + k) * 3;
+                    m.v0 = val[0]; m.v1 = val[1]; m.v2 = val[2];
+                } else {
+                    m.node = 0; m.depth = 0; m.entry = 0; m.v0 = m.v1 = m.v2 = 0.f;
+                }
+                return m;
+            };
+            auto request = [&](const Meta &m) {
+                Stats st{0.0, 0, 0, 0.f, 0, 0};
+                if (m.k >= 0 && lane >= 1 && lane < m.depth) {
+                    const size_t cs = (size_t)t * D.N + (m.entry >> 10), ce = cs * A + (m.entry & 1023);
+                    st.vs = D.ch_vsum[ce]; st.cv = D.ch_visits[ce]; st.cl = D.ch_vl[ce];
+                    st.ns = D.n_vsum[cs]; st.nv = D.n_visits[cs]; st.nl = D.n_vl[cs];
+                }
+                return st;
+            };
+            Fwd f1{-1, -1, 0.0, 0, 0, 0.f, 0, 0}, f2 = f1;              // this lane's last and last-but-one update
+            Meta m0 = fetch(next_k()), m1 = fetch(next_k()), m2 = fetch(next_k()), m3 = fetch(next_k());
+            Stats s0 = request(m0), s1 = request(m1);
+            while (m0.k >= 0) {
+                const Meta m4 = fetch(next_k());                                    // M
+                const Stats s2 = request(m2);                                       // S
+                {                                                                   // U
+                    const int k = m0.k, depth = m0.depth;
+                    // (a Gumbel leaf with q_node < 0 is the reference's node[-1] quirk: every such leaf writes the LAST pool slot's
+                    // raw value, the last one in leaf order wins - that one write is done below by wave 0, in leaf order, instead
+                    // of by whichever wave comes last here)
+                    if (lane == 0 && m0.node >= 0) D.n_raw[(size_t)t * D.N + m0.node] = m0.v1 * 0.5f + m0.v2;   // tree.py:299
+                    const float vleaf = m0.v0 + m0.v1 * 0.5f;   // tree.py:302
+                    Fwd nf{-1, -1, 0.0, 0, 0, 0.f, 0, 0};
+                    if (lane < depth) {
+                        const int pn = m0.entry >> 10, pe = m0.entry & 1023;
+                        float v = vleaf;
+                        for (int q = depth - 1 - lane; q > 0; --q) v = 1.0f - v;
+                        const size_t cs = (size_t)t * D.N + pn;
+                        const size_t ce = cs * A + pe;
+                        if (lane == depth - 1) D.ch_value[ce] = (double)vleaf;   // set_leaf_value
+                        if (lane == 0) {                                         // level 0 is the root: LDS copy
+                            r_vsum[pe] = (double)((float)r_vsum[pe] + v);
+                            r_vis[pe] += 1;
+                            r_vl[pe] -= 1;
+                            rootv[k] = v;
+                        } else {
+                            double vs = s0.vs;
+                            int cv = s0.cv, cl = s0.cl;
+                            float ns_ = s0.ns;
+                            int nv = s0.nv, nl = s0.nl;
+                            const long long ekey = (long long)ce;
+                            if (f1.ekey == ekey) { vs = f1.vs; cv = f1.cv; cl = f1.cl; }
+                            else if (f2.ekey == ekey) { vs = f2.vs; cv = f2.cv; cl = f2.cl; }
+                            if (f1.nkey == pn) { ns_ = f1.ns; nv = f1.nv; nl = f1.nl; }
+                            else if (f2.nkey == pn) { ns_ = f2.ns; nv = f2.nv; nl = f2.nl; }
+                            nf.ekey = ekey; nf.nkey = pn;
+                            nf.vs = (double)((float)vs + v);                     // float32 accumulation (file header)
+                            nf.cv = cv + 1; nf.cl = cl - 1;
+                            nf.ns = ns_ + v; nf.nv = nv + 1; nf.nl = nl - 1;
+                            D.ch_vsum[ce] = nf.vs;
+                            D.ch_visits[ce] = nf.cv;
+                            D.ch_vl[ce] = nf.cl;
+                            D.n_vsum[cs] = nf.ns;
+                            D.n_visits[cs] = nf.nv;
+                            D.n_vl[cs] = nf.nl;
+                        }
+                    }
+                    f2 = f1;
+                    f1 = nf;
+                }
+                m0 = m1; m1 = m2; m2 = m3; m3 = m4;
+                s0 = s1; s1 = s2;
                 wave_sync();
             }
         }
+        BP_MARK(1);
         __syncthreads();
         if (wid == 0) {
             // the root node's float32 value sum: every leaf's root-level value, in leaf order
@@ -2216,7 +2386,7 @@ __global__ __launch_bounds__(64 * NWAVE) void backup_kernel(SearchDev D, const f
             int last = -1;
             for (int k0 = 0; k0 < n; k0 += 64) {
                 const int kk = k0 + lane;
-                const unsigned long long m = __ballot(kk < n && D.q_node[(size_t)t * D.K + (kk < n ? kk : 0)] < 0);
+                const unsigned long long m = __ballot(kk < n && leaf_neg[kk < n ? kk : 0] != 0);      // (from the set-up pass: no round trip per 64 leaves here)
                 if (m) last = k0 + 63 - __clzll((long long)m);
             }
             if (last >= 0 && lane == 0) {
@@ -2326,6 +2496,14 @@ __global__ __launch_bounds__(64 * NWAVE) void backup_kernel(SearchDev D, const f
         }
     }
     if (threadIdx.x == 0) D.n_leaves[t] = 0;
+#ifdef TG_BACKUP_PROF
+    if (bp && threadIdx.x == 0) {
+        D.prof[2] += bp_t1 - bp_t0;
+        D.prof[3] += (long long)bp_max[0] - bp_t1;
+        D.prof[4] += (long long)bp_max[1] - (long long)bp_max[0];
+        D.prof[5] += (long long)__builtin_amdgcn_s_memtime() - bp_t0;
+    }
+#endif
 }
 
 
@@ -3120,7 +3298,26 @@ __global__ __launch_bounds__(64) void play_kernel(SearchDev D, const int32_t *mo
     using G = Geo<S>;
     __shared__ Lds<S> L;
     const int t = blockIdx.x, lane = threadIdx.x;
-    const int mv = moves[t];
+    int mv = moves[t];
+    if (mv == -2) {
+        // the move of the most visited root child (node.py:167-175 get_best_move_index: np.argmax, first index on ties),
+        // chosen here so that a driver that only advances its positions needs no read-back between two searches
+        constexpr int R = (G::A + 63) / 64;
+        const size_t rbase = (size_t)t * D.N * G::A;
+        const int nc = D.meta[t].num_nodes > 0 ? D.n_children[(size_t)t * D.N] : 0;
+        double best = 0.0;
+        int best_i = -1;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = lane + 64 * r;
+            if (i < nc) {
+                const double v = (double)D.ch_visits[rbase + i];
+                if (best_i < 0 || v > best) { best = v; best_i = i; }
+            }
+        }
+        best_i = wave_argmax_first(best, best_i);
+        mv = best_i >= 0 ? (int)D.action[rbase + best_i] : -1;
+    }
     if (mv < 0) return;                                 // RESIGN / idle tree
     BoardScalars b;
     int to_move;
@@ -3902,7 +4099,12 @@ int tg_search_select_puct(tg_search *s, int max_leaves, float *planes_dev, int32
     // up to kXwMaxTrees trees: a second workgroup (on another CU) for the board work of every tree (TG_SELECT_SPLIT=0: off)
     const bool split = !getenv("TG_SELECT_SPLIT") || atoi(getenv("TG_SELECT_SPLIT")) != 0;
     int split_rc = kSplitNoRoom;
-    if (pipelined && split && !s->dev.prof && s->dev.T <= kXwMaxTrees && s->dev.N <= (1 << 21)) {
+#ifdef TG_SPLIT_PROF
+    const bool split_prof_ok = true;
+#else
+    const bool split_prof_ok = !s->dev.prof;
+#endif
+    if (pipelined && split && split_prof_ok && s->dev.T <= kXwMaxTrees && s->dev.N <= (1 << 21)) {
         split_rc = s->S == 9 ? launch_split<9>(s, max_leaves, planes_dev, st) : launch_split<19>(s, max_leaves, planes_dev, st);
         if (split_rc < 0) return split_rc;
     }

@@ -358,7 +358,8 @@ class SearchEngine:
         return queue
 
     def play(self, moves):
-        """Play one move per tree on the device-resident root positions (< 0 = skip)."""
+        """Play one move per tree on the device-resident root positions (-1 = skip, -2 = the most visited root child's
+        move, chosen on the device)."""
         mv = np.ascontiguousarray(moves, dtype=np.int32)
         assert mv.shape == (self.T,)
         _lib.check(self.lib.tg_search_play(self.handle, mv.ctypes.data, self._stream()), "tg_search_play")

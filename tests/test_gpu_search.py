@@ -392,3 +392,39 @@ def test_chained_mini_batches_equal_the_per_mini_batch_loop(size, trees, batches
         ga.set_state(sa)
         gb.set_state(sb)
         assert np.array_equal(ga.random_sample(8), gb.random_sample(8))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size,trees", [(9, 3), (19, 1)])
+def test_play_of_the_most_visited_child_on_the_device_equals_the_host_choice(size, trees):
+    """tg_search_play with -2 (the play kernel takes np.argmax(children_visits[:num_children]) itself, node.py:167-175) leaves the
+    same root positions as reading the roots back, choosing on the host and playing that move."""
+    import torch
+    from oracle.net import make_state_dict
+    from tamago_amd.board.go_board import GoBoard
+    from tamago_amd.mcts.engine import SearchEngine, DeviceEvaluator
+    from tamago_amd.nn.network.dual_net import DualNet
+    net = DualNet(torch.device("cuda:0"), size)
+    net.load_state_dict(make_state_dict(size, 5, 1.3))
+
+    def run(on_device):
+        eng = SearchEngine(size, trees, 200, 32, DeviceEvaluator(net))
+        for t in range(trees):
+            eng.set_root(t, GoBoard(size), 1, np.random.RandomState(11 + t).get_state())
+        out = []
+        for _ in range(3):
+            eng.root_eval(False)
+            for _ in range(3):
+                eng.puct_batch(32)
+            if on_device:
+                eng.play(np.full(trees, -2, dtype=np.int32))
+            else:
+                nc, action, visits = eng.read_roots()
+                masked = np.where(np.arange(eng.A)[None, :] < nc[:, None], visits, -1)
+                eng.play(action[np.arange(trees), np.argmax(masked, axis=1)].astype(np.int32))
+            out.append(eng.read_positions())
+        eng.close()
+        return out
+
+    for (ca, ma, ta), (cb, mb, tb) in zip(run(False), run(True)):
+        assert np.array_equal(ca, cb) and np.array_equal(ma, mb) and np.array_equal(ta, tb)
