@@ -1819,7 +1819,8 @@ __global__ __launch_bounds__(1024) void select_puct_split_kernel(SearchDev D, in
             const int me = wid;
             int idle = 0;
             int unf0 = -1, unf1 = -1, unf2 = -1, unf3 = -1, n_unf = 0;
-            long long sp_busy = 0, sp_steps = 0;
+            long long sp_busy = 0, sp_steps = 0, sp_hits = 0;
+            int sp_last = -1;
             while (active) {
                 const int w = lane < kSlots ? pipe_load(&sh.mail[lane]) : 0;
                 const bool mine = (w & 255) == me;
@@ -1907,9 +1908,14 @@ __global__ __launch_bounds__(1024) void select_puct_split_kernel(SearchDev D, in
                 wave_sync();
                 sp_busy += SP_NOW() - sp_b;
                 sp_steps += 1;
+                sp_hits += (node == sp_last && !was_fresh);
+                sp_last = node;
             }
 #ifndef TG_BACKUP_PROF
             if (sp && me == 1) { D.prof[4] += sp_busy; D.prof[5] += sp_steps; }
+#ifdef TG_SPLIT_PROF_HITS      // all owners: steps in slot 11, steps on the node the owner handled last in slot 14
+            if (sp) { atomicAdd(reinterpret_cast<unsigned long long *>(D.prof + 11), (unsigned long long)sp_steps); atomicAdd(reinterpret_cast<unsigned long long *>(D.prof + 14), (unsigned long long)sp_hits); }
+#endif
 #endif
         } else if (wid == NNODE + 1) {
             // ---- the allocator: leaves in descent order (LDS only: what later descents may be waiting for) ----

@@ -327,3 +327,35 @@ def test_the_package_has_one_training_backend():
             if f.endswith(".py"):
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"\.backward\(|optimizer\.step\(|enable_grad|CUDAGraph|^\s*(from|import) oracle", text, re.M), os.path.join(dirpath, f)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bsz,mode", [(256, "rl"), (100, "sl"), (70, "rl")])
+def test_hip_training_step_at_the_batch_sizes_the_weight_gradient_chunks_differently(bsz, mode):
+    """wgrad_kernel shares a batch out over min(64, B) chunks of boards: at 256 (learning_param.py BATCH_SIZE, the size the
+    bench quotes) a workgroup walks four boards through its two LDS buffers, at 100 and 70 the chunks are ragged (some walk two
+    boards, some one).  One step against torch autograd + torch.optim.SGD on the same batch: losses, every parameter, the
+    batch-norm statistics and the momentum buffers (the golden-vector tests above run at batch 32: one board per chunk)."""
+    dev = torch.device("cuda", 0)
+    state, _ = make_case()
+    rng = np.random.RandomState(700 + bsz)
+    planes = torch.from_numpy(rng.uniform(size=(bsz, 6, 9, 9)).astype(np.float32)).to(dev)
+    pol = rng.gamma(0.3, size=(bsz, 82))
+    pol = torch.from_numpy((pol / pol.sum(1, keepdims=True)).astype(np.float32)).to(dev)
+    val = torch.from_numpy(rng.randint(0, 3, size=bsz).astype(np.int64)).to(dev)
+    hip = learn.HipTrainer(dev, 9, bsz, state)
+    hip.step(planes, pol, val, mode=mode, lr=0.01)
+    got = hip.take_losses()
+    net = train_ref.TrainableDualNet(dev, 9, state).train()
+    opt = learn.make_optimizer(net, 0.01)
+    want = (train_ref.rl_train_step if mode == "rl" else train_ref.sl_train_step)(net, opt, planes, pol, val)
+    np.testing.assert_allclose([got["loss"], got["policy"], got["value"]], [want["loss"], want["policy"], want["value"]],
+                               rtol=0, atol=2e-5)
+    now, ref = hip.state_dict(), net.state_dict()
+    moved = 0.0
+    for key, _ in state_dict_keys(9):
+        np.testing.assert_allclose(now[key].numpy(), ref[key].cpu().numpy(), rtol=0, atol=3e-5, err_msg=key)
+        moved = max(moved, float((ref[key].cpu() - state[key]).abs().max()))
+    assert moved > 1e-3
+    for g, p in zip(hip.momentum_buffers(), net.parameters()):
+        np.testing.assert_allclose(g.numpy(), opt.state[p]["momentum_buffer"].cpu().numpy(), rtol=0, atol=2e-3)

@@ -31,5 +31,7 @@ for it in range(n):
     last_worker = int(cyc[13] - cyc[12])
     if it in (0, 1, n // 2, n - 1):
         print(f"launch {it}: last worker done {last_worker / 100:.1f} us after the selecting half started; selecting half {cyc[15] / 100:.1f} us")
+        if cyc[11]:
+            print(f"    node owners: {cyc[11]} steps, {cyc[14]} on the node the owner handled last ({100 * cyc[14] / cyc[11]:.0f} %)")
         for i in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10):
             print(f"    {names[i]:48s} {cyc[i] / (1 if i == 5 else 100):9.1f}" + ("" if i == 5 else " us"))
