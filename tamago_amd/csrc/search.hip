@@ -1229,6 +1229,22 @@ template <typename Sh>
 __device__ __forceinline__ bool mp_wait_ge(const Sh &sh, const int *p, int want) {
     return mp_wait_val(sh, p, want) >= 0;
 }
+// ... and a word the writer stored BEFORE the flag, read in the same round trip: LDS operations of a wave are carried out in issue
+// order on both sides (flag read first here, data written first there), so `data` is valid whenever the flag read says so
+template <typename Sh>
+__device__ __forceinline__ bool mp_wait_with(const Sh &sh, const int *flag, int want, const int *data, int &out) {
+    for (int spin = 0; spin < kPipeSpinLimit; ++spin) {
+        const int f = *reinterpret_cast<const volatile int *>(flag);
+        const int d = *reinterpret_cast<const volatile int *>(data);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (f >= want) { out = d; return true; }
+        if (spin >= 32) {
+            if (pipe_load(&sh.err)) return false;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    return false;
+}
 
 // flag store behind plain LDS stores of the same lane: LDS operations of a wave complete in order, the fence
 // only keeps the compiler from reordering them
@@ -1644,6 +1660,7 @@ struct SplitSelShared {
     // reciprocals of the counts a child can reach are made by the whole workgroup before the chain starts
     double sq[kPipeMaxK];
     double rcp[kRcpN];
+    int choice[kPipeMaxK];            // root edge of descent k + 1 (0: not chosen yet): the chooser's only product, the clerk's input
 };
 template <int S, int NWRK>
 struct SplitWrkShared {
@@ -1691,7 +1708,7 @@ __global__ __launch_bounds__(1024) void select_puct_split_kernel(SearchDev D, in
         if (threadIdx.x < kSlots) {
             sh.slot_free[threadIdx.x] = 0; sh.leaf_ready[threadIdx.x] = 0; sh.ship_ready[threadIdx.x] = 0; sh.mail[threadIdx.x] = 0;
         }
-        for (int i = threadIdx.x; i < kPipeMaxK; i += 1024) { sh.alloc_child[i] = kOwnNotYet; sh.exp_key[i] = -1; }
+        for (int i = threadIdx.x; i < kPipeMaxK; i += 1024) { sh.alloc_child[i] = kOwnNotYet; sh.exp_key[i] = -1; sh.choice[i] = 0; }
         if (threadIdx.x == 0) { sh.num_nodes = n0; sh.all_done = 0; sh.err = 0; }
         {
             const int total0 = D.n_visits[root_ns] + D.n_vl[root_ns];
@@ -1705,113 +1722,181 @@ __global__ __launch_bounds__(1024) void select_puct_split_kernel(SearchDev D, in
                 pipe_store(&sh.err, 1);
             }
         };
-        if (wid == 0) {
-            // ---- the root's owner (the node-owner design: tools/experiments/kernels/select_puct_owner.hip.inc) ---------------------------------------
-            __builtin_amdgcn_s_setprio(3);
-            if (active) {
-                int r_vis[R], r_act[R], r_idx[R], r_kref[R], c_vl[R];
-                double r_vsum[R], r_pol[R], c_q[R], c_den[R], c_rcp[R];
+        // ---- the root.  Every descent passes it, so its step is the chain a launch hangs on.  Two halves:
+        //  * the CHOICE - scores of all children for sqrt(N + k + 1), arg-max, one more virtual loss on the winner - is all that is
+        //    serial;
+        //  * what a choice entails (move, child, leaf or step, the job for the owners / the allocator, slots) is clerical.
+        // DUAL (9x9): wave 0 only chooses and leaves the edge in sh.choice[k]; the clerk (wave kClerk, on another SIMD) follows the
+        // ring: one wave doing both took ~1 700 cycles per descent = 96 % of a launch, the chooser alone takes ~1 050.  At 19x19 the
+        // sixteenth wave is worth more as a tenth node owner (deep trees: the launches hang on the owners): wave 0 does both there.
+        constexpr bool DUAL = S == 9;
+        constexpr int kClerk = DUAL ? NNODE + 2 + NSHIP + (NWG > 1 ? 1 : 0) : -1;
+        int r_vis[R], r_act[R], r_idx[R], r_kref[R], c_vl[R], c_cnt[R], root_nc = 0;
+        double r_vsum[R], r_pol[R], c_q[R], c_rcp[R], c_rcpn[R];
+        auto chooser_init = [&]() {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int i = lane + 64 * r, ii = i < A ? i : A - 1;
+                r_vsum[r] = D.ch_vsum[root_base + ii];
+                r_pol[r] = D.ch_policy[root_base + ii];
+                c_cnt[r] = D.ch_visits[root_base + ii] + D.ch_vl[root_base + ii];
+                c_q[r] = c_cnt[r] != 0 ? r_vsum[r] / (double)c_cnt[r] : 0.0;
+                // reciprocals of count + 1 (this step's denominator) and count + 2 (the next one, should this child be chosen:
+                // requested a step ahead, so that no LDS round trip sits between two choices)
+                if (__any(c_cnt[r] + 2 >= kRcpN)) { c_rcp[r] = 1.0 / (double)(c_cnt[r] + 1); c_rcpn[r] = 1.0 / (double)(c_cnt[r] + 2); }
+                else { c_rcp[r] = sh.rcp[c_cnt[r] + 1]; c_rcpn[r] = sh.rcp[c_cnt[r] + 2]; }
+            }
+            root_nc = D.n_children[root_ns];
+        };
+        auto choose = [&](double sq) -> int {
+            double best = 0.0;
+            int best_i = -1;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int i = lane + 64 * r;
+                if (i < root_nc) {
+                    double v = c_q[r] + div_by_count(r_pol[r] * sq, (double)(c_cnt[r] + 1), c_rcp[r]);
+                    if (D.cgos && i == root_nc - 1) v -= 0.1;
+                    if (best_i < 0 || v > best) { best = v; best_i = i; }
+                }
+            }
+            best_i = wave_argmax_first(best, best_i);
+            if (best_i < 0) best_i = 0;                                      // (a diverged network: every score NaN)
+            return best_i;
+        };
+        auto chosen = [&](int best_i) {                                      // one more virtual loss on the winner
+            const int owner = best_i & 63, oslot = best_i >> 6;
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (r == oslot) {
+                    // the winner's new count is its old denominator: q = value sum / count by the reciprocal it holds
+                    const double q = div_by_count(r_vsum[r], (double)(c_cnt[r] + 1), c_rcp[r]);
+                    double nn;
+                    if (__any(lane == owner && c_cnt[r] + 3 >= kRcpN)) nn = 1.0 / (double)(c_cnt[r] + 3);
+                    else nn = sh.rcp[c_cnt[r] + 3 < kRcpN ? c_cnt[r] + 3 : 0];
+                    if (lane == owner) { c_q[r] = q; c_cnt[r] += 1; c_rcp[r] = c_rcpn[r]; c_rcpn[r] = nn; }
+                }
+        };
+        auto clerk_init = [&]() {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int i = lane + 64 * r, ii = i < A ? i : A - 1;
+                r_vis[r] = D.ch_visits[root_base + ii];
+                r_act[r] = D.action[root_base + ii];
+                r_idx[r] = D.ch_index[root_base + ii];
+                c_vl[r] = D.ch_vl[root_base + ii];
+                r_kref[r] = -1;
+            }
+        };
+        auto clerk_step = [&](int k, int slot, int best_i) -> bool {
+            const int owner = best_i & 63, oslot = best_i >> 6;
+            int my_move = 0, my_child = 0, my_cnt = 0, my_kref = -1;
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (r == oslot) { my_move = r_act[r]; my_child = r_idx[r]; my_cnt = r_vis[r] + c_vl[r]; my_kref = r_kref[r]; }
+            const int src = __builtin_amdgcn_readfirstlane(owner);
+            const int e = best_i;
+            const int mv = __builtin_amdgcn_readlane(my_move, src);
+            int child = __builtin_amdgcn_readlane(my_child, src);
+            const int count = __builtin_amdgcn_readlane(my_cnt, src);
+            const int kref = __builtin_amdgcn_readlane(my_kref, src);
+            const bool two_pass = meta.moves + 1 > 2 && mv == 0 && meta.prev == 0;   // tree.py:224-229
+            const int threshold = two_pass ? 10000000 : 1;
+            const bool leaf = count + 1 < threshold + 1;
+            if (child == kNotExpanded && kref >= 0) child = -2 - kref;
+            const bool expands = leaf && child == kNotExpanded;
+            if (!leaf && child == kNotExpanded) return false;
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (r == oslot && lane == owner) {
+                    c_vl[r] += 1;
+                    if (expands) r_kref[r] = k;
+                }
+            if (lane == 0) {
+                sh.moves[slot][0] = (int16_t)mv;
+                sh.qpath[slot][0] = e;
+                if (leaf) {
+                    sh.lm_parent[slot] = 0; sh.lm_edge[slot] = e; sh.lm_child[slot] = child; sh.lm_depth[slot] = 1;
+                    mp_publish(&sh.leaf_ready[slot], k + 1);
+                } else {
+                    sh.st_node[slot] = child; sh.st_depth[slot] = 1; sh.st_prev[slot] = mv; sh.st_redge[slot] = e;
+                    mp_publish(&sh.mail[slot], ((k + 1) << 8) | (1 + (1 + e) % NNODE));
+                }
+            }
+            return true;
+        };
+        auto clerk_done = [&](bool ok) {
+            if (!ok) fail(kErrPipeline, 1);
+            if (ok) {
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    const int i = lane + 64 * r, ii = i < A ? i : A - 1;
-                    r_vis[r] = D.ch_visits[root_base + ii];
-                    r_act[r] = D.action[root_base + ii];
-                    r_idx[r] = D.ch_index[root_base + ii];
-                    r_vsum[r] = D.ch_vsum[root_base + ii];
-                    r_pol[r] = D.ch_policy[root_base + ii];
-                    c_vl[r] = D.ch_vl[root_base + ii];
-                    r_kref[r] = -1;
-                    const int cnt = r_vis[r] + c_vl[r];
-                    c_q[r] = cnt != 0 ? r_vsum[r] / (double)cnt : 0.0;
-                    c_den[r] = (double)(cnt + 1);
-                    if (__any(cnt + 1 >= kRcpN)) c_rcp[r] = 1.0 / c_den[r];     // wave-uniform: the division is not even issued otherwise
-                    else c_rcp[r] = sh.rcp[cnt + 1];
+                    const int i = lane + 64 * r;
+                    if (i < A) D.ch_vl[root_base + i] = c_vl[r];
                 }
-                const int root_nc = D.n_children[root_ns];
+                if (lane == 0) D.n_vl[root_ns] += max_leaves;
+            }
+        };
+        if (wid == 0) {
+            __builtin_amdgcn_s_setprio(3);
+            if (active) {
+                chooser_init();
+                if constexpr (!DUAL) clerk_init();
+                double sq = sh.sq[0];
                 bool ok = true;
-                long long sp_acc = 0, sp_seg[4] = {0, 0, 0, 0};
+                long long sp_acc = 0;
+                for (int k = 0; k < max_leaves; ++k) {
+                    const double sqn = sh.sq[k + 1 < max_leaves ? k + 1 : k];      // (used by the next step)
+                    if constexpr (!DUAL) {
+                        const long long sp_w = SP_NOW();
+                        ok = mp_wait_ge(sh, &sh.slot_free[k % kSlots], k / kSlots);
+                        sp_acc += SP_NOW() - sp_w;
+                        if (!ok) break;
+                    }
+                    const int best_i = choose(sq);
+                    if constexpr (DUAL) {
+                        if (lane == 0) pipe_store(&sh.choice[k], best_i + 1);
+                    } else {
+                        ok = clerk_step(k, k % kSlots, best_i);
+                        if (!ok) break;
+                    }
+                    chosen(best_i);
+                    sq = sqn;
+                }
+                if (sp) D.prof[14] += SP_NOW() - sp_t0;
+                if constexpr (!DUAL) {
+                    if (sp) { D.prof[0] += SP_NOW() - sp_t0; D.prof[1] += sp_acc; }
+                    clerk_done(ok);
+                }
+            }
+        } else if (DUAL && wid == kClerk) {
+            __builtin_amdgcn_s_setprio(3);
+            if (active) {
+                clerk_init();
+                bool ok = true;
+                long long sp_acc = 0;
                 for (int k = 0; k < max_leaves; ++k) {
                     const int slot = k % kSlots;
+                    // the choice and the slot's release in one round trip
                     const long long sp_w = SP_NOW();
-                    ok = mp_wait_ge(sh, &sh.slot_free[slot], k / kSlots);
-                    long long sp_x = SP_NOW();
-                    sp_acc += sp_x - sp_w;
+                    int ch = 0;
+                    ok = false;
+                    for (int spin = 0; spin < kPipeSpinLimit; ++spin) {
+                        ch = *reinterpret_cast<const volatile int *>(&sh.choice[k]);
+                        const int fr = *reinterpret_cast<const volatile int *>(&sh.slot_free[slot]);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        if (ch >= 1 && fr >= k / kSlots) { ok = true; break; }
+                        if (spin >= 32) {
+                            if (pipe_load(&sh.err)) break;
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                    }
+                    sp_acc += SP_NOW() - sp_w;
                     if (!ok) break;
-                    const double sq = sh.sq[k];
-                    double best = 0.0;
-                    int best_i = -1;
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const int i = lane + 64 * r;
-                        if (i < root_nc) {
-                            double v = c_q[r] + div_by_count(r_pol[r] * sq, c_den[r], c_rcp[r]);
-                            if (D.cgos && i == root_nc - 1) v -= 0.1;
-                            if (best_i < 0 || v > best) { best = v; best_i = i; }
-                        }
-                    }
-                    { const long long n = SP_NOW(); sp_seg[0] += n - sp_x; sp_x = n; }
-                    best_i = wave_argmax_first(best, best_i);
-                    { const long long n = SP_NOW(); sp_seg[1] += n - sp_x; sp_x = n; }
-                    const int owner = best_i & 63, oslot = best_i >> 6;
-                    int my_move = 0, my_child = 0, my_cnt = 0, my_kref = -1;
-#pragma unroll
-                    for (int r = 0; r < R; ++r)
-                        if (r == oslot) { my_move = r_act[r]; my_child = r_idx[r]; my_cnt = r_vis[r] + c_vl[r]; my_kref = r_kref[r]; }
-                    const int src = __builtin_amdgcn_readfirstlane(owner);
-                    const int e = best_i;
-                    const int mv = __builtin_amdgcn_readlane(my_move, src);
-                    int child = __builtin_amdgcn_readlane(my_child, src);
-                    const int count = __builtin_amdgcn_readlane(my_cnt, src);
-                    const int kref = __builtin_amdgcn_readlane(my_kref, src);
-                    const bool two_pass = meta.moves + 1 > 2 && mv == 0 && meta.prev == 0;   // tree.py:224-229
-                    const int threshold = two_pass ? 10000000 : 1;
-                    const bool leaf = count + 1 < threshold + 1;
-                    if (child == kNotExpanded && kref >= 0) child = -2 - kref;
-                    const bool expands = leaf && child == kNotExpanded;
-                    if (!leaf && child == kNotExpanded) { ok = false; break; }
-#pragma unroll
-                    for (int r = 0; r < R; ++r)
-                        if (r == oslot) {
-                            if (lane == owner) {
-                                c_vl[r] += 1;
-                                if (expands) r_kref[r] = k;
-                            }
-                            // the owner's new count is its old denominator: q = value sum / count by the reciprocal it holds
-                            const int cnt = r_vis[r] + c_vl[r];
-                            const double q = div_by_count(r_vsum[r], c_den[r], c_rcp[r]);
-                            const double den = (double)(cnt + 1);
-                            double rcp;
-                            if (__any(lane == owner && cnt + 1 >= kRcpN)) rcp = 1.0 / den;
-                            else rcp = sh.rcp[cnt + 1 < kRcpN ? cnt + 1 : 0];
-                            if (lane == owner) { c_q[r] = q; c_den[r] = den; c_rcp[r] = rcp; }
-                        }
-                    { const long long n = SP_NOW(); sp_seg[2] += n - sp_x; sp_x = n; }
-                    if (lane == 0) {
-                        sh.moves[slot][0] = (int16_t)mv;
-                        sh.qpath[slot][0] = e;
-                        if (leaf) {
-                            sh.lm_parent[slot] = 0; sh.lm_edge[slot] = e; sh.lm_child[slot] = child; sh.lm_depth[slot] = 1;
-                            mp_publish(&sh.leaf_ready[slot], k + 1);
-                        } else {
-                            sh.st_node[slot] = child; sh.st_depth[slot] = 1; sh.st_prev[slot] = mv; sh.st_redge[slot] = e;
-                            mp_publish(&sh.mail[slot], ((k + 1) << 8) | (1 + (1 + e) % NNODE));
-                        }
-                    }
-                    sp_seg[3] += SP_NOW() - sp_x;
+                    ok = clerk_step(k, slot, ch - 1);
+                    if (!ok) break;
                 }
                 if (sp) { D.prof[0] += SP_NOW() - sp_t0; D.prof[1] += sp_acc; }
-#ifdef TG_SPLIT_PROF_ROOT      // the root step by segment instead of the worker's phases: 7 scores, 8 arg-max, 9 winner + update, 10 job hand-off
-                if (sp) { D.prof[7] += sp_seg[0]; D.prof[8] += sp_seg[1]; D.prof[9] += sp_seg[2]; D.prof[10] += sp_seg[3]; }
-#endif
-                if (!ok) fail(kErrPipeline, 1);
-                if (ok) {
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const int i = lane + 64 * r;
-                        if (i < A) D.ch_vl[root_base + i] = c_vl[r];
-                    }
-                    if (lane == 0) D.n_vl[root_ns] += max_leaves;
-                }
+                clerk_done(ok);
             }
         } else if (wid <= NNODE) {
             // ---- owners of the nodes below the root ----------------------------------------------------
@@ -1925,11 +2010,10 @@ __global__ __launch_bounds__(1024) void select_puct_split_kernel(SearchDev D, in
             for (int k = 0; ok && k < max_leaves; ++k) {
                 const int slot = k % kSlots;
                 const long long sp_w = SP_NOW();
-                ok = mp_wait_ge(sh, &sh.leaf_ready[slot], k + 1);
+                int child = 0;
+                ok = mp_wait_with(sh, &sh.leaf_ready[slot], k + 1, &sh.lm_child[slot], child);
                 sp_acc += SP_NOW() - sp_w;
                 if (!ok) { fail(kErrPipeline, 5); break; }
-                const int parent = sh.lm_parent[slot], e = sh.lm_edge[slot];
-                int child = sh.lm_child[slot];
                 if (child <= -2) child = sh.alloc_child[-2 - child];
                 const int expand = child == kNotExpanded;
                 int xseq = 0;
@@ -1938,15 +2022,12 @@ __global__ __launch_bounds__(1024) void select_puct_split_kernel(SearchDev D, in
                     child = num_nodes++;
                     xseq = nexp++;
                 }
+                // (the parent's child index in memory is the shipper's store: behind ship_ready, i.e. behind jobof)
                 if (lane == 0) {
                     if (expand) sh.jobof[child - n0] = (int16_t)k;
                     sh.sp_child[slot] = child; sh.sp_expand[slot] = expand; sh.sp_xseq[slot] = xseq;
                     mp_publish(&sh.alloc_child[k], child);
                     mp_publish(&sh.ship_ready[slot], k + 1);
-                    if (expand) {
-                        __builtin_amdgcn_s_waitcnt(0xC07F);                          // lgkmcnt(0): jobof is in LDS before ...
-                        D.ch_index[((size_t)t * D.N + parent) * A + e] = child;      // ... anybody can find the node here
-                    }
                 }
             }
             if (lane == 0) {
@@ -1978,6 +2059,8 @@ __global__ __launch_bounds__(1024) void select_puct_split_kernel(SearchDev D, in
                     else if (lane == 7) word = k;
                     else if (lane >= kXwHeader && lane < kXwHeader + kPathCap) word = sh.qpath[slot][lane - kXwHeader];
                     if (lane >= 1 && lane < kXwHeader + kPathCap) xw_store(&entry[lane], word);
+                    // a new node becomes findable from its parent (jobof has been in LDS since before ship_ready)
+                    if (lane == 4 && word) D.ch_index[((size_t)t * D.N + sh.lm_parent[slot]) * A + sh.lm_edge[slot]] = sh.sp_child[slot];
                     for (int jj = lane; 2 * jj < depth; jj += 64) {
                         const int lo = (unsigned short)sh.moves[slot][2 * jj];
                         const int hi = 2 * jj + 1 < depth ? (unsigned short)sh.moves[slot][2 * jj + 1] : 0;
@@ -2132,9 +2215,7 @@ __global__ __launch_bounds__(1024) void select_puct_split_kernel(SearchDev D, in
                 }
                 { const long long n = SP_NOW(); sp_a[2] += n - sp_x; sp_x = n; }
             }
-#ifndef TG_SPLIT_PROF_ROOT
             if (sp && role == 1 && w == 0) { D.prof[7] += sp_a[0]; D.prof[8] += sp_a[1]; D.prof[9] += sp_a[2]; D.prof[10] += sp_a[3]; }
-#endif
             if (sp) atomicMax(reinterpret_cast<unsigned long long *>(D.prof + 13), (unsigned long long)SP_NOW());
         }
         __syncthreads();
@@ -3713,7 +3794,7 @@ int launch_split_cfg(tg_search *s, int max_leaves, float *planes, hipStream_t st
     constexpr size_t lds_a = sizeof(SplitSelShared<S, NNODE>), lds_b = sizeof(SplitWrkShared<S, NWRK>);
     constexpr size_t lds = lds_a > lds_b ? lds_a : lds_b;
     static_assert(lds <= 160 * 1024, "LDS");
-    static_assert(NNODE + 2 + NSHIP + (NWG > 1 ? 1 : 0) <= 16 && NWRK <= 16, "wavefronts per workgroup");
+    static_assert(NNODE + 2 + NSHIP + (NWG > 1 ? 1 : 0) + (S == 9 ? 1 : 0) <= 16 && NWRK <= 16, "wavefronts per workgroup");
     const int T = s->dev.T;
     if (!s->xw_job) {
         s->xw_cap = s->dev.K < kPipeMaxK ? s->dev.K : kPipeMaxK;
@@ -3753,13 +3834,14 @@ int launch_split(tg_search *s, int max_leaves, float *planes, hipStream_t st) {
     // node owners * 100 + workers (TG_SPLIT_CFG: tuning knob)
     static const int cfg = getenv("TG_SPLIT_CFG") ? atoi(getenv("TG_SPLIT_CFG")) : 0;
     if constexpr (S == 9) {
+        // (16 waves: chooser + clerk + owners + allocator + shippers + the draw cursor when there are several worker workgroups)
         if (cfg == 616) return launch_split_cfg<S, 6, 16>(s, max_leaves, planes, st);
         if (cfg == 816) return launch_split_cfg<S, 8, 16>(s, max_leaves, planes, st);
-        if (cfg == 1216) return launch_split_cfg<S, 12, 16, 2>(s, max_leaves, planes, st);
-        if (cfg == 1012) return launch_split_cfg<S, 10, 12>(s, max_leaves, planes, st);
+        if (cfg == 1016) return launch_split_cfg<S, 10, 16, 2>(s, max_leaves, planes, st);          // two shippers
+        if (cfg == 912) return launch_split_cfg<S, 9, 12>(s, max_leaves, planes, st);
         if (cfg == 11016) return launch_split_cfg<S, 10, 16, 3, 1>(s, max_leaves, planes, st);    // one workgroup of workers
-        if (cfg == 31016) return launch_split_cfg<S, 10, 16, 3, 3>(s, max_leaves, planes, st);
-        return launch_split_cfg<S, 10, 16, 3, 2>(s, max_leaves, planes, st);
+        if (cfg == 30916) return launch_split_cfg<S, 9, 16, 3, 3>(s, max_leaves, planes, st);
+        return launch_split_cfg<S, 9, 16, 3, 2>(s, max_leaves, planes, st);
     } else {
         if (cfg == 607) return launch_split_cfg<S, 6, 7>(s, max_leaves, planes, st);
         if (cfg == 1207) return launch_split_cfg<S, 12, 7, 2>(s, max_leaves, planes, st);

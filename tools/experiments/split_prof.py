@@ -20,7 +20,7 @@ eng.set_root(0, GoBoard(size), 1, np.random.RandomState(0).get_state())
 lib = tl.load()
 eng.root_eval(False)
 tl.check(lib.tg_search_profile(eng.handle, 1, None))
-names = ["root owner: loop", "root owner: wait for a free slot", "allocator: loop", "allocator: wait for the next leaf",
+names = ["clerk: loop", "clerk: wait for a free slot", "allocator: loop", "allocator: wait for the next leaf",
          "node owner 1: busy", "node owner 1: steps", "shipper 0: loop", "worker (1,0): wait for a job", "worker (1,0): header + reset + replay",
          "worker (1,0): candidates / prior / done tag", "worker (1,0): planes", "-", "-", "-", "-", "selecting half: start to end"]
 print(f"{size}x{size}, {batch} descents per launch; ticks of s_memtime (100 MHz: 1 tick = 10 ns)")
@@ -31,6 +31,7 @@ for it in range(n):
     last_worker = int(cyc[13] - cyc[12])
     if it in (0, 1, n // 2, n - 1):
         print(f"launch {it}: last worker done {last_worker / 100:.1f} us after the selecting half started; selecting half {cyc[15] / 100:.1f} us")
+        print(f"    {'chooser: loop':48s} {cyc[14] / 100:9.1f} us")
         if cyc[11]:
             print(f"    node owners: {cyc[11]} steps, {cyc[14]} on the node the owner handled last ({100 * cyc[14] / cyc[11]:.0f} %)")
         for i in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10):
