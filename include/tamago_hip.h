@@ -369,7 +369,7 @@ int tg_selfplay_set_observer(tg_selfplay *sp, tg_selfplay_observer fn, void *use
  * backward, torch.optim.SGD(momentum 0.9, weight_decay 1e-4, nesterov=True) update, batch-norm running
  * statistics), fp32.  The trainer owns a device copy of the parameters in the tg_net_create blob order
  * (running_mean / running_var included; num_batches_tracked is the caller's counter) and a momentum blob of
- * the same layout.  9x9; batch = positions per step (>= 2).
+ * the same layout.  board_size 9 or 19 (other sizes: TG_ERR_ARG); batch = positions per step (>= 2).
  *   tg_trainer_step: planes [B,6,9,9] fp32, policy targets [B,82] fp32, value classes [B] int64, all device
  *     memory; sl_mode 0 = RL objective (KL(target || softmax) batch mean + value_weight * cross entropy,
  *     learn.py:360-376), 1 = supervised (-sum t log(softmax + 1e-8), learn.py:150-180); ENQUEUES the step.

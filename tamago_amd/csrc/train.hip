@@ -5,7 +5,10 @@
 // torch.optim.SGD(momentum 0.9, weight decay 1e-4, nesterov) - in fp32 (the reference runs it under fp16
 // autocast; fp32 is what its CPU trainer does and the stricter of the two).
 //
-// Data layout (HBM): activations are NHWC fp32 [B][81][64].  Kept per step: Z_l = convolution output before
+// Board sizes: 9x9 (the size the reference trains at; every tuning decision below was made for it) and 19x19 (the same kernels
+// instantiated for S = 19: a board in four staging passes and four passes of the MFMA loop, one LDS buffer in the weight
+// gradient, FC layers by groups of outputs).
+// Data layout (HBM): activations are NHWC fp32 [B][P][64] (P = S * S positions).  Kept per step: Z_l = convolution output before
 // its batch norm (13 layers), Y_b = block outputs after ReLU (stem + 6 blocks), D_l = dL/d(batch-norm output
 // of layer l, ReLU mask applied).  Nothing else is materialised: every kernel rebuilds the tensor it needs
 // while staging a board into LDS (batch norm + ReLU of the producer's Z, batch-norm backward of D), so a
@@ -34,11 +37,13 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int S = 9, P = 81, A = 82, C = 64;
+constexpr int C = 64;
 constexpr int kLayers = 13;                       // conv layers: stem + 12
 constexpr int kRow = 72;                          // LDS row stride in floats (conflict-free ds_read_b128)
-constexpr int kCells = 121;                       // 11 x 11 padded board of the convolution kernels
-constexpr int kMT = 6;                            // 16-row tiles per board (96 >= 81)
+// Board geometry of a kernel instantiated for board size S (9: the size the reference trains at and every tuning decision
+// here was made for; 19: the same kernels walking the board in more passes): positions, actions, padded width / cells, 16-row tiles
+#define TG_GEO(S) constexpr int P = (S) * (S), A = P + 1, W = (S) + 2, kCells = W * W, kMT = (P + 15) / 16; \
+    (void)A; (void)W; (void)kCells; (void)kMT
 constexpr int kConvW = 64 * 64 * 9;
 constexpr int kRep = 16;                          // replicas of every atomically accumulated statistic
 
@@ -49,7 +54,8 @@ struct Layout {
     size_t v_conv, v_bn_w, v_bn_b, v_bn_m, v_bn_v, v_fc_w, v_fc_b;
     size_t total;
 };
-Layout make_layout() {
+Layout make_layout(int S) {
+    const int P = S * S, A = P + 1;
     Layout L{};
     size_t o = 0;
     auto take = [&](size_t n) { size_t r = o; o += n; return r; };
@@ -86,7 +92,7 @@ struct TrainDev {
     float *dlog;                    // [B][A + 3] dL/dlogits
     double *loss;                   // [kRep][4] accumulated: total, policy, value
     Layout L;
-    int B, NWG, WCH;                // batch, workgroups of the per-board kernels, board chunks of wgrad_kernel
+    int B, NWG, WCH, P;             // batch, workgroups of the per-board kernels, board chunks of wgrad_kernel, positions per board
 };
 
 struct TrainDev;
@@ -110,7 +116,7 @@ __device__ __forceinline__ void static_for(Fn &&fn) {
 
 // batch-norm constants of layer `l` from its statistics: scale = gamma * rstd, shift = beta - mean * scale
 __device__ __forceinline__ void bn_consts(const TrainDev &T, int l, int c, float eps, float &mean, float &rstd) {
-    const double n = (double)(T.B * P);
+    const double n = (double)(T.B * T.P);
     const double m = stat_sum(T.stat + (size_t)l * kRep * 256 + c, 256) / n;
     const double var = fmax(stat_sum(T.stat + (size_t)l * kRep * 256 + 64 + c, 256) / n - m * m, 0.0);
     mean = (float)m;
@@ -134,33 +140,35 @@ __device__ unsigned long long g_prof[4 * 16];
 // 4 waves: wave w owns output channels [16w, 16w+16) of all six row tiles.  A 256-position batch is one board per CU
 // = one wave per SIMD, so the loop hides its own latencies: weight fragments (L2) are requested two (tap, channel
 // group) steps ahead, activation fragments (LDS) one step ahead, positions pinned with sched_barrier.
-template <int MODE>
+template <int MODE, int S>
 __global__ __launch_bounds__(256) void conv_kernel(TrainDev T, const float *__restrict__ planes, int l) {
+    TG_GEO(S);
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *act = smem;                       // [121 cells of the 11 x 11 padded board][72]: the border stays zero, a tap is a constant offset
+    float *act = smem;                       // [cells of the (S + 2)^2 padded board][72]: the border stays zero, a tap is a constant offset
     float *tab = smem + kCells * kRow;       // per-channel constants [9][64]
-    constexpr int NT = 256, HMT = kMT;                     // row tiles per wave
-    const int tid = threadIdx.x, wave = tid >> 6, half = 0, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+    constexpr int NT = 256, HMT = 6;                       // row tiles per pass of the MFMA loop (9x9: all six of the board)
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lg = lane >> 4;
     const float eps_l = 2e-5f;
     for (int e = tid; e < kCells * kRow / 4; e += NT) reinterpret_cast<f32x4 *>(act)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
     // ---- the board's global loads are requested before the per-channel tables are made: the tables cost a round trip to the
     //      statistics + fp64 division and square root, the board a round trip of its own (1.5 us per launch when one followed
-    //      the other; a 256-position batch is ONE board per workgroup) ----
-    constexpr int NV = (P * C / 4 + NT - 1) / NT;          // float4 per thread
+    //      the other; a 256-position batch is ONE board per workgroup).  A thread stages six float4 per pass: the whole 9x9
+    //      board in one pass, a 19x19 board in four ----
+    constexpr int NV = (P * C / 4 + NT - 1) / NT, NVP = 6;  // float4 per thread: of the board, of a pass
     const size_t bstride = (size_t)P * C;
     const bool fwd = MODE == FWD;
     const bool conv1 = (l & 1) != 0;
     const int yb = (l - 1) / 2;
     const bool staged = !(MODE == FWD && l == 0);
     const bool has_second = fwd ? (conv1 && yb >= 1) : true;
-    f32x4 zv[NV], sv[NV];
-    auto request = [&](int b) {
+    f32x4 zv[NVP], sv[NVP];
+    auto request = [&](int b, int i0) {
         // FWD: z = Z_{l-1}; conv1 also adds the previous block output and materialises Y.  DGRAD: d = D_l, z = Z_l.
         const float *zsrc = T.Z + ((size_t)(fwd ? l - 1 : l) * T.B + b) * bstride;
         const float *second = !has_second ? zsrc : fwd ? T.Y + ((size_t)(yb - 1) * T.B + b) * bstride : T.D + ((size_t)l * T.B + b) * bstride;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int e = tid + i * NT;
+        for (int i = 0; i < NVP; ++i) {
+            const int e = tid + (i0 + i) * NT;
             if (e < P * C / 4) {
                 zv[i] = *reinterpret_cast<const f32x4 *>(zsrc + e * 4);
                 if (has_second) sv[i] = *reinterpret_cast<const f32x4 *>(second + e * 4);
@@ -169,7 +177,7 @@ __global__ __launch_bounds__(256) void conv_kernel(TrainDev T, const float *__re
     };
     const int pslot = l == 5 ? MODE : -1;
     if (pslot >= 0) TG_PROF(pslot, 0);
-    if (staged && (int)blockIdx.x < T.B) request(blockIdx.x);
+    if (staged && (int)blockIdx.x < T.B) request(blockIdx.x, 0);
     // ---- per-channel tables -------------------------------------------------------------------------
     // FWD: tab[0] = scale, tab[1] = shift of the PRODUCER's batch norm (layer l - 1)
     // DGRAD: tab[0] = gamma*rstd of layer l, tab[1] = mean, tab[2] = rstd, tab[3] unused; m1/m2 in tab[4..5]
@@ -185,7 +193,7 @@ __global__ __launch_bounds__(256) void conv_kernel(TrainDev T, const float *__re
         } else {
             float mean, rstd;
             bn_consts(T, l, tid, eps_l, mean, rstd);
-            const double n = (double)(T.B * P);
+            const double n = (double)(T.B * T.P);
             tab[tid] = T.param[T.L.bn_w[l] + tid] * rstd;
             tab[64 + tid] = mean;
             tab[128 + tid] = rstd;
@@ -207,129 +215,132 @@ __global__ __launch_bounds__(256) void conv_kernel(TrainDev T, const float *__re
     const f32x4 *wl = reinterpret_cast<const f32x4 *>(wfrag) + (size_t)wave * 9 * 4 * 64 + lane;
     float s_sum[4] = {0.f, 0.f, 0.f, 0.f}, s_sq[4] = {0.f, 0.f, 0.f, 0.f};
     for (int b = blockIdx.x; b < T.B; b += gridDim.x) {
-        // ---- stage the board: LDS act[row][c] from the registers requested above / at the end of the board before ----
+        // ---- stage the board: LDS act[cell][c] from the registers requested above / at the end of the board before ----
         if (MODE == FWD && l == 0) {
             for (int e = tid; e < P * C; e += NT) {
                 const int row = e >> 6, c = e & 63, y = row / S;
-                act[((y + 1) * 11 + row - y * S + 1) * kRow + c] = c < 6 ? planes[((size_t)b * 6 + c) * P + row] : 0.f;
+                act[((y + 1) * W + row - y * S + 1) * kRow + c] = c < 6 ? planes[((size_t)b * 6 + c) * P + row] : 0.f;
             }
         } else {
             float *yout = fwd && conv1 ? T.Y + ((size_t)yb * T.B + b) * bstride : nullptr;
+            for (int i0 = 0; i0 < NV; i0 += NVP) {
+                if (i0 > 0) request(b, i0);
 #pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                const int e = tid + i * NT;
-                if (e < P * C / 4) {
-                    const int row = e >> 4, c = (e & 15) * 4, y = row / S, cell = (y + 1) * 11 + row - y * S + 1;
-                    f32x4 v;
-                    if (fwd) {
+                for (int i = 0; i < NVP; ++i) {
+                    const int e = tid + (i0 + i) * NT;
+                    if (e < P * C / 4) {
+                        const int row = e >> 4, c = (e & 15) * 4, y = row / S, cell = (y + 1) * W + row - y * S + 1;
+                        f32x4 v;
+                        if (fwd) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = fmaf(zv[i][j], tab[c + j], tab[64 + c + j]);
-                        if (has_second) v += sv[i];
+                            for (int j = 0; j < 4; ++j) v[j] = fmaf(zv[i][j], tab[c + j], tab[64 + c + j]);
+                            if (has_second) v += sv[i];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-                        if (yout) *reinterpret_cast<f32x4 *>(yout + e * 4) = v;
-                    } else {
-                        // dZ_l = gamma*rstd * (D - m1 - xhat * m2), xhat = (Z - mean) * rstd
+                            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                            if (yout) *reinterpret_cast<f32x4 *>(yout + e * 4) = v;
+                        } else {
+                            // dZ_l = gamma*rstd * (D - m1 - xhat * m2), xhat = (Z - mean) * rstd
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float xh = (zv[i][j] - tab[64 + c + j]) * tab[128 + c + j];
-                            v[j] = tab[c + j] * (sv[i][j] - tab[192 + c + j] - xh * tab[256 + c + j]);
+                            for (int j = 0; j < 4; ++j) {
+                                const float xh = (zv[i][j] - tab[64 + c + j]) * tab[128 + c + j];
+                                v[j] = tab[c + j] * (sv[i][j] - tab[192 + c + j] - xh * tab[256 + c + j]);
+                            }
                         }
+                        *reinterpret_cast<f32x4 *>(act + cell * kRow + c) = v;
                     }
-                    *reinterpret_cast<f32x4 *>(act + cell * kRow + c) = v;
                 }
             }
         }
         __syncthreads();
         if (pslot >= 0) TG_PROF(pslot, 2);
-        // ---- implicit GEMM: acc[mt] (16 couts x 16 rows) over 9 taps x 16 k-groups of 4 channels ----
-        f32x4 acc[HMT];
-#pragma unroll
-        for (int mt = 0; mt < HMT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // DGRAD: the epilogue's operands (Z, Y of the layer below, the skip gradient) are requested now, behind the loop
         const bool ep_conv1 = MODE == DGRAD && (l & 1) != 0;   // input of conv1 = block output Y_{(l-1)/2}; the skip carries D_{l+1}
-        f32x4 ep_z[HMT], ep_y[HMT], ep_s[HMT];
-        if (MODE == DGRAD) {
-            const float *zb = T.Z + ((size_t)(l - 1) * T.B + b) * bstride;
-            const float *yb2 = T.Y + ((size_t)((l - 1) / 2) * T.B + b) * bstride;
-            const float *dskip = T.D + ((size_t)(l + 1 < kLayers ? l + 1 : l) * T.B + b) * bstride;
-            const int cc = wave * 16 + lg * 4;
-#pragma unroll
-            for (int mt = 0; mt < HMT; ++mt) {
-                const int row = (half * HMT + mt) * 16 + li, r2 = row < P ? row : 0;
-                ep_z[mt] = *reinterpret_cast<const f32x4 *>(zb + r2 * C + cc);
-                if (ep_conv1) {
-                    ep_y[mt] = *reinterpret_cast<const f32x4 *>(yb2 + r2 * C + cc);
-                    ep_s[mt] = *reinterpret_cast<const f32x4 *>(dskip + r2 * C + cc);
-                }
-            }
-        }
-
-        // per row tile: the lane's row on the padded board, one cell up-left (tap (0, 0)); rows beyond the board (tile 5) read
-        // row 0's cells - their products are never stored
-        const float *rowp[HMT];
-#pragma unroll
-        for (int mt = 0; mt < HMT; ++mt) {
-            const int r = (half * HMT + mt) * 16 + li, r2 = r < P ? r : 0, y = r2 / S;
-            rowp[mt] = act + (y * 11 + r2 - y * S) * kRow + lg * 4;
-        }
-        f32x4 wq[3], av[2][HMT];
-        wq[0] = wl[0];
-        wq[1] = wl[64];
-#pragma unroll
-        for (int mt = 0; mt < HMT; ++mt) av[0][mt] = lds4(rowp[mt]);
-        static_for<36>([&](auto ST_) {
-            constexpr int st = decltype(ST_)::value, nx = st + 1, tapn = nx / 4, sn = nx % 4;
-            constexpr int toffn = ((tapn / 3) * 11 + tapn % 3) * kRow;
-            wq[(st + 2) % 3] = wl[(st + 2 < 36 ? st + 2 : 35) * 64];
-            if constexpr (nx < 36) {
-#pragma unroll
-                for (int mt = 0; mt < HMT; ++mt) av[nx & 1][mt] = lds4(rowp[mt] + toffn + sn * 16);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int mt = 0; mt < HMT; ++mt)
-                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[st % 3][j], av[st & 1][mt][j], acc[mt], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        // ---- epilogue ----
-        if (pslot >= 0) TG_PROF(pslot, 3);
         const int c0 = wave * 16 + lg * 4;
-        if (MODE == FWD) {
-            float *z = T.Z + ((size_t)l * T.B + b) * bstride;
+        // ---- implicit GEMM: acc[mt] (16 couts x 16 rows) over 9 taps x 16 k-groups of 4 channels, HMT row tiles per pass ----
+        for (int mt0 = 0; mt0 < kMT; mt0 += HMT) {
+            f32x4 acc[HMT];
 #pragma unroll
-            for (int mt = 0; mt < HMT; ++mt) {
-                const int row = (half * HMT + mt) * 16 + li;
-                if (row < P) {
-                    *reinterpret_cast<f32x4 *>(z + row * C + c0) = acc[mt];
+            for (int mt = 0; mt < HMT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // DGRAD: the epilogue's operands (Z, Y of the layer below, the skip gradient) are requested now, behind the loop
+            f32x4 ep_z[HMT], ep_y[HMT], ep_s[HMT];
+            if (MODE == DGRAD) {
+                const float *zb = T.Z + ((size_t)(l - 1) * T.B + b) * bstride;
+                const float *yb2 = T.Y + ((size_t)((l - 1) / 2) * T.B + b) * bstride;
+                const float *dskip = T.D + ((size_t)(l + 1 < kLayers ? l + 1 : l) * T.B + b) * bstride;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { s_sum[j] += acc[mt][j]; s_sq[j] = fmaf(acc[mt][j], acc[mt][j], s_sq[j]); }
+                for (int mt = 0; mt < HMT; ++mt) {
+                    const int row = (mt0 + mt) * 16 + li, r2 = row < P ? row : 0;
+                    ep_z[mt] = *reinterpret_cast<const f32x4 *>(zb + r2 * C + c0);
+                    if (ep_conv1) {
+                        ep_y[mt] = *reinterpret_cast<const f32x4 *>(yb2 + r2 * C + c0);
+                        ep_s[mt] = *reinterpret_cast<const f32x4 *>(dskip + r2 * C + c0);
+                    }
                 }
             }
-        } else {
-            // D_{l-1} = (dA + skip) * [A_{l-1} > 0]; sums S1 = sum D, S2 = sum D * xhat_{l-1}
-            float *dout = T.D + ((size_t)(l - 1) * T.B + b) * bstride;
+            // per row tile: the lane's row on the padded board, one cell up-left (tap (0, 0)); rows beyond the board (the last
+            // tile) read row 0's cells - their products are never stored
+            const float *rowp[HMT];
 #pragma unroll
             for (int mt = 0; mt < HMT; ++mt) {
-                const int row = (half * HMT + mt) * 16 + li;
-                if (row < P) {
-                    f32x4 g = acc[mt];
-                    if (ep_conv1) g += ep_s[mt];
+                const int r = (mt0 + mt) * 16 + li, r2 = r < P ? r : 0, y = r2 / S;
+                rowp[mt] = act + (y * W + r2 - y * S) * kRow + lg * 4;
+            }
+            f32x4 wq[3], av[2][HMT];
+            wq[0] = wl[0];
+            wq[1] = wl[64];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float pre = ep_conv1 ? ep_y[mt][j] : fmaf(ep_z[mt][j], tab[320 + c0 + j], tab[384 + c0 + j]);
-                        g[j] = pre > 0.f ? g[j] : 0.f;
-                        const float xh = (ep_z[mt][j] - tab[448 + c0 + j]) * tab[512 + c0 + j];
-                        s_sum[j] += g[j];
-                        s_sq[j] = fmaf(g[j], xh, s_sq[j]);
+            for (int mt = 0; mt < HMT; ++mt) av[0][mt] = lds4(rowp[mt]);
+            static_for<36>([&](auto ST_) {
+                constexpr int st = decltype(ST_)::value, nx = st + 1, tapn = nx / 4, sn = nx % 4;
+                constexpr int toffn = ((tapn / 3) * W + tapn % 3) * kRow;
+                wq[(st + 2) % 3] = wl[(st + 2 < 36 ? st + 2 : 35) * 64];
+                if constexpr (nx < 36) {
+#pragma unroll
+                    for (int mt = 0; mt < HMT; ++mt) av[nx & 1][mt] = lds4(rowp[mt] + toffn + sn * 16);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int mt = 0; mt < HMT; ++mt)
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[st % 3][j], av[st & 1][mt][j], acc[mt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            // ---- epilogue ----
+            if (pslot >= 0) TG_PROF(pslot, 3);
+            if (MODE == FWD) {
+                float *z = T.Z + ((size_t)l * T.B + b) * bstride;
+#pragma unroll
+                for (int mt = 0; mt < HMT; ++mt) {
+                    const int row = (mt0 + mt) * 16 + li;
+                    if (row < P) {
+                        *reinterpret_cast<f32x4 *>(z + row * C + c0) = acc[mt];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { s_sum[j] += acc[mt][j]; s_sq[j] = fmaf(acc[mt][j], acc[mt][j], s_sq[j]); }
                     }
-                    *reinterpret_cast<f32x4 *>(dout + row * C + c0) = g;
+                }
+            } else {
+                // D_{l-1} = (dA + skip) * [A_{l-1} > 0]; sums S1 = sum D, S2 = sum D * xhat_{l-1}
+                float *dout = T.D + ((size_t)(l - 1) * T.B + b) * bstride;
+#pragma unroll
+                for (int mt = 0; mt < HMT; ++mt) {
+                    const int row = (mt0 + mt) * 16 + li;
+                    if (row < P) {
+                        f32x4 g = acc[mt];
+                        if (ep_conv1) g += ep_s[mt];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float pre = ep_conv1 ? ep_y[mt][j] : fmaf(ep_z[mt][j], tab[320 + c0 + j], tab[384 + c0 + j]);
+                            g[j] = pre > 0.f ? g[j] : 0.f;
+                            const float xh = (ep_z[mt][j] - tab[448 + c0 + j]) * tab[512 + c0 + j];
+                            s_sum[j] += g[j];
+                            s_sq[j] = fmaf(g[j], xh, s_sq[j]);
+                        }
+                        *reinterpret_cast<f32x4 *>(dout + row * C + c0) = g;
+                    }
                 }
             }
         }
-        if (staged && b + (int)gridDim.x < T.B) request(b + gridDim.x);
+        if (staged && b + (int)gridDim.x < T.B) request(b + gridDim.x, 0);
         __syncthreads();
         if (pslot >= 0) TG_PROF(pslot, 4);
     }
@@ -360,23 +371,33 @@ __global__ __launch_bounds__(256) void conv_kernel(TrainDev T, const float *__re
 // two LDS buffers while the MFMAs of the board before run on the other: activations on an 11 x 11 padded board whose border
 // stays zero, so that a tap is a constant address offset (no validity test per MFMA), cells 80 floats apart (the four rows x 16
 // channels of a ds_read_b32 hit 32 distinct banks twice).
-constexpr int kWRow = 80, kWCells = 121, kWAct = kWCells * kWRow, kWBuf = kWAct + 84 * 16;
-constexpr int kWgradLdsFloats = 2 * kWBuf + 5 * 16 + 2 * 64;
+// 19x19: the padded board alone is 127 KB at 72 floats per cell - one buffer (the staging of the next board's registers still
+// runs under the MFMAs, its deposit does not), lane addresses computed per k-step instead of kept in 91 registers.
+template <int S>
+struct WGeo {
+    static constexpr int P = S * S, W = S + 2, KS = (P + 3) / 4;                 // k-steps of four rows
+    static constexpr int kWRow = S == 9 ? 80 : 72, NBUF = S == 9 ? 2 : 1;
+    static constexpr int kWAct = W * W * kWRow, kWBuf = kWAct + KS * 4 * 16;
+    static constexpr int kLdsFloats = NBUF * kWBuf + 5 * 16 + 2 * 64;
+};
 
+template <int S>
 __global__ __launch_bounds__(512) void wgrad_kernel(TrainDev T, const float *__restrict__ planes, int l) {
+    using G = WGeo<S>;
+    constexpr int P = G::P, W = G::W, KS = G::KS, kWRow = G::kWRow, NBUF = G::NBUF, kWAct = G::kWAct, kWBuf = G::kWBuf;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *tab = smem + 2 * kWBuf;             // [5][16]: gamma*rstd, mean, rstd, m1, m2 of the slice; [2][64]: scale / shift of layer l - 1
+    float *tab = smem + NBUF * kWBuf;          // [5][16]: gamma*rstd, mean, rstd, m1, m2 of the slice; [2][64]: scale / shift of layer l - 1
     constexpr int NT = 512;
     const int tid = threadIdx.x, wave = tid >> 6, ct = wave & 3, tpar = wave >> 2, lane = tid & 63, li = lane & 15, lg = lane >> 4;
     const int q = blockIdx.x & 3, chunk = blockIdx.x >> 2, chunks = gridDim.x >> 2;
     const float eps_l = 2e-5f;
     const bool rebuild = l >= 2 && (l & 1) == 0;          // conv2: its input h = relu(bn(Z_{l-1})) is rebuilt
-    for (int e = tid; e < 2 * kWBuf / 4; e += NT) reinterpret_cast<f32x4 *>(smem)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int e = tid; e < NBUF * kWBuf / 4; e += NT) reinterpret_cast<f32x4 *>(smem)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (tid < 16) {
         const int c = q * 16 + tid;
         float mean, rstd;
         bn_consts(T, l, c, l == 0 ? 1e-5f : eps_l, mean, rstd);
-        const double n = (double)(T.B * P);
+        const double n = (double)(T.B * T.P);
         tab[tid] = T.param[T.L.bn_w[l] + c] * rstd;
         tab[16 + tid] = mean;
         tab[32 + tid] = rstd;
@@ -393,7 +414,8 @@ __global__ __launch_bounds__(512) void wgrad_kernel(TrainDev T, const float *__r
     const size_t bstride = (size_t)P * C;
     const float *asrc = l == 0 ? nullptr : (l & 1) ? T.Y + (size_t)((l - 1) / 2) * T.B * bstride : T.Z + (size_t)(l - 1) * T.B * bstride;
     constexpr int NV = (P * C / 4 + NT - 1) / NT;          // float4 of activations per thread
-    f32x4 ra[NV], rd, rz;
+    constexpr int ND = (P * 4 + NT - 1) / NT;              // float4 of the dZ slice per thread
+    f32x4 ra[NV], rd[ND], rz[ND];
     auto request = [&](int b) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -408,10 +430,14 @@ __global__ __launch_bounds__(512) void wgrad_kernel(TrainDev T, const float *__r
                 }
             }
         }
-        if (tid < P * 4) {
-            const size_t off = ((size_t)l * T.B + b) * bstride + (tid >> 2) * C + q * 16 + (tid & 3) * 4;
-            rd = *reinterpret_cast<const f32x4 *>(T.D + off);
-            rz = *reinterpret_cast<const f32x4 *>(T.Z + off);
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int e = tid + i * NT;
+            if (e < P * 4) {
+                const size_t off = ((size_t)l * T.B + b) * bstride + (e >> 2) * C + q * 16 + (e & 3) * 4;
+                rd[i] = *reinterpret_cast<const f32x4 *>(T.D + off);
+                rz[i] = *reinterpret_cast<const f32x4 *>(T.Z + off);
+            }
         }
     };
     auto deposit = [&](float *buf) {
@@ -419,7 +445,7 @@ __global__ __launch_bounds__(512) void wgrad_kernel(TrainDev T, const float *__r
         for (int i = 0; i < NV; ++i) {
             const int e = tid + i * NT;
             if (e < P * C / 4) {
-                const int row = e >> 4, c = (e & 15) * 4, y = row / S, cell = (y + 1) * 11 + (row - y * S) + 1;
+                const int row = e >> 4, c = (e & 15) * 4, y = row / S, cell = (y + 1) * W + (row - y * S) + 1;
                 f32x4 a = ra[i];
                 if (rebuild) {
 #pragma unroll
@@ -428,24 +454,31 @@ __global__ __launch_bounds__(512) void wgrad_kernel(TrainDev T, const float *__r
                 *reinterpret_cast<f32x4 *>(buf + cell * kWRow + c) = a;
             }
         }
-        if (tid < P * 4) {
-            const int c = (tid & 3) * 4;
-            f32x4 v;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float xh = (rz[j] - tab[16 + c + j]) * tab[32 + c + j];
-                v[j] = tab[c + j] * (rd[j] - tab[48 + c + j] - xh * tab[64 + c + j]);
+        for (int i = 0; i < ND; ++i) {
+            const int e = tid + i * NT;
+            if (e < P * 4) {
+                const int c = (e & 3) * 4;
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float xh = (rz[i][j] - tab[16 + c + j]) * tab[32 + c + j];
+                    v[j] = tab[c + j] * (rd[i][j] - tab[48 + c + j] - xh * tab[64 + c + j]);
+                }
+                *reinterpret_cast<f32x4 *>(buf + kWAct + (e >> 2) * 16 + c) = v;
             }
-            *reinterpret_cast<f32x4 *>(buf + kWAct + (tid >> 2) * 16 + c) = v;
         }
     };
-    // lane's activation address per k-step (rows ks * 4 + lg), relative to the cell one row and one column up-left of it, so
-    // that every tap is a non-negative constant; rows 81..83 (dZ is zero there) read a cell of finite values
-    int aoff[21];
-#pragma unroll
-    for (int ks = 0; ks < 21; ++ks) {
+    // lane's activation address of k-step ks (rows ks * 4 + lg), relative to the cell one row and one column up-left of it, so
+    // that every tap is a non-negative constant; rows beyond the board (dZ is zero there) read a cell of finite values
+    auto aoff_of = [&](int ks) {
         const int row = ks * 4 + lg, r2 = row < P ? row : 0, y = r2 / S;
-        aoff[ks] = (y * 11 + (r2 - y * S)) * kWRow + ct * 16 + li;
+        return (y * W + (r2 - y * S)) * kWRow + ct * 16 + li;
+    };
+    int aoff[S == 9 ? KS : 1];
+    if constexpr (S == 9) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) aoff[ks] = aoff_of(ks);
     }
     f32x4 acc[5];
 #pragma unroll
@@ -456,7 +489,7 @@ __global__ __launch_bounds__(512) void wgrad_kernel(TrainDev T, const float *__r
     __syncthreads();                                       // tables and the zeroed buffers
     if (l == 5) TG_PROF(2, 1);
     for (int it = 0; b < T.B; b += chunks, ++it) {
-        float *buf = smem + (it & 1) * kWBuf;
+        float *buf = smem + (NBUF == 2 ? (it & 1) : 0) * kWBuf;
         deposit(buf);
         __syncthreads();
         if (l == 5 && it < 4) TG_PROF(2, 2 + it);
@@ -464,19 +497,26 @@ __global__ __launch_bounds__(512) void wgrad_kernel(TrainDev T, const float *__r
         const float *dz = buf + kWAct + lg * 16 + li;
         auto run = [&](auto TP_) {
             constexpr int TP = decltype(TP_)::value;
-#pragma unroll
-            for (int ks = 0; ks < 21; ++ks) {
+            auto step = [&](int ks, int ao) {
                 const float dzv = dz[ks * 64];
-                const float *ap = buf + aoff[ks];
+                const float *ap = buf + ao;
 #pragma unroll
                 for (int i = 0; i < 5; ++i) {
                     const int tap = TP + 2 * i;
-                    if (tap < 9) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(dzv, ap[((tap / 3) * 11 + tap % 3) * kWRow], acc[i], 0, 0, 0);
+                    if (tap < 9) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(dzv, ap[((tap / 3) * W + tap % 3) * kWRow], acc[i], 0, 0, 0);
                 }
+            };
+            if constexpr (S == 9) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) step(ks, aoff[ks]);
+            } else {
+#pragma unroll 7
+                for (int ks = 0; ks < KS; ++ks) step(ks, aoff_of(ks));
             }
         };
         if (tpar == 0) run(std::integral_constant<int, 0>{});
         else run(std::integral_constant<int, 1>{});
+        if constexpr (NBUF == 1) __syncthreads();          // the one buffer is free for the next board's deposit
     }
     if (l == 5) TG_PROF(2, 6);
     // partial image of the chunk: [chunk][tap][co][ci]; lane holds co = 16 q + 4 lg + j, ci = 16 ct + li
@@ -524,26 +564,28 @@ __global__ void repack_kernel(TrainDev T) {
 // 1. per board: Y_6 = relu(Y_5 + bn(Z_12)) (materialised), head 1x1 convolutions -> hz[b][p][3], statistics.
 //    Thread (row group r = tid / 16, channel quad c = 4 (tid % 16)): a row is one coalesced 256-byte read by 16 lanes, the three
 //    dot products are finished by a butterfly over those lanes (a thread per ROW read 64 scattered lines per instruction).
+template <int S>
 __global__ __launch_bounds__(256) void head_conv_kernel(TrainDev T) {
+    TG_GEO(S);
     __shared__ float red[4][6];
     __shared__ float tab[128];
     const int tid = threadIdx.x, c = (tid & 15) * 4, r0 = tid >> 4;
     const size_t bstride = (size_t)P * C;
-    constexpr int NR = (P + 15) / 16;
-    f32x4 zv[NR], yv[NR];
-    auto request = [&](int b) {
+    constexpr int NR = (P + 15) / 16, NRP = 6;             // rows per thread: of the board, of a pass (9x9: one pass)
+    f32x4 zv[NRP], yv[NRP];
+    auto request = [&](int b, int k0) {
         const float *z = T.Z + ((size_t)12 * T.B + b) * bstride;
         const float *yp = T.Y + ((size_t)5 * T.B + b) * bstride;
 #pragma unroll
-        for (int k = 0; k < NR; ++k) {
-            const int row = r0 + 16 * k;
+        for (int k = 0; k < NRP; ++k) {
+            const int row = r0 + 16 * (k0 + k);
             if (row < P) {
                 zv[k] = *reinterpret_cast<const f32x4 *>(z + row * C + c);
                 yv[k] = *reinterpret_cast<const f32x4 *>(yp + row * C + c);
             }
         }
     };
-    if ((int)blockIdx.x < T.B) request(blockIdx.x);       // in flight while the batch-norm constants are made
+    if ((int)blockIdx.x < T.B) request(blockIdx.x, 0);    // in flight while the batch-norm constants are made
     if (tid < 64) {
         float mean, rstd;
         bn_consts(T, 12, tid, 2e-5f, mean, rstd);
@@ -565,30 +607,33 @@ __global__ __launch_bounds__(256) void head_conv_kernel(TrainDev T) {
     float s[3] = {0.f, 0.f, 0.f}, q[3] = {0.f, 0.f, 0.f};
     for (int b = blockIdx.x; b < T.B; b += gridDim.x) {
         float *yo = T.Y + ((size_t)6 * T.B + b) * bstride;
+        for (int k0 = 0; k0 < NR; k0 += NRP) {
+            if (k0 > 0) request(b, k0);
 #pragma unroll
-        for (int k = 0; k < NR; ++k) {
-            const int row = r0 + 16 * k;            // uniform over the 16 lanes of a row: the butterfly below stays inside them
-            if (row < P) {
-                f32x4 v = yv[k];
-                float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+            for (int k = 0; k < NRP; ++k) {
+                const int row = r0 + 16 * (k0 + k);       // uniform over the 16 lanes of a row: the butterfly below stays inside them
+                if (row < P) {
+                    f32x4 v = yv[k];
+                    float d0 = 0.f, d1 = 0.f, d2 = 0.f;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    v[j] = fmaxf(v[j] + fmaf(zv[k][j], sc[j], sh[j]), 0.f);
-                    d0 = fmaf(v[j], w0[j], d0);
-                    d1 = fmaf(v[j], w1[j], d1);
-                    d2 = fmaf(v[j], w2[j], d2);
-                }
-                *reinterpret_cast<f32x4 *>(yo + row * C + c) = v;
+                    for (int j = 0; j < 4; ++j) {
+                        v[j] = fmaxf(v[j] + fmaf(zv[k][j], sc[j], sh[j]), 0.f);
+                        d0 = fmaf(v[j], w0[j], d0);
+                        d1 = fmaf(v[j], w1[j], d1);
+                        d2 = fmaf(v[j], w2[j], d2);
+                    }
+                    *reinterpret_cast<f32x4 *>(yo + row * C + c) = v;
 #pragma unroll
-                for (int o = 8; o > 0; o >>= 1) { d0 += __shfl_xor(d0, o); d1 += __shfl_xor(d1, o); d2 += __shfl_xor(d2, o); }
-                if ((tid & 15) == 0) {
-                    *reinterpret_cast<f32x4 *>(T.hz + ((size_t)b * P + row) * 4) = f32x4{d0, d1, d2, 0.f};
-                    s[0] += d0; s[1] += d1; s[2] += d2;
-                    q[0] = fmaf(d0, d0, q[0]); q[1] = fmaf(d1, d1, q[1]); q[2] = fmaf(d2, d2, q[2]);
+                    for (int o = 8; o > 0; o >>= 1) { d0 += __shfl_xor(d0, o); d1 += __shfl_xor(d1, o); d2 += __shfl_xor(d2, o); }
+                    if ((tid & 15) == 0) {
+                        *reinterpret_cast<f32x4 *>(T.hz + ((size_t)b * P + row) * 4) = f32x4{d0, d1, d2, 0.f};
+                        s[0] += d0; s[1] += d1; s[2] += d2;
+                        q[0] = fmaf(d0, d0, q[0]); q[1] = fmaf(d1, d1, q[1]); q[2] = fmaf(d2, d2, q[2]);
+                    }
                 }
             }
         }
-        if (b + (int)gridDim.x < T.B) request(b + gridDim.x);
+        if (b + (int)gridDim.x < T.B) request(b + gridDim.x, 0);
     }
     // lanes 0, 16, 32, 48 of a wave hold sums: one more butterfly, then wave -> workgroup through LDS, one atomic per statistic
 #pragma unroll
@@ -610,17 +655,19 @@ __global__ __launch_bounds__(256) void head_conv_kernel(TrainDev T) {
 
 // 2. per board: batch norm + ReLU of the head convolutions, both FC layers, losses, dL/dlogits, gradient back to the
 //    head activations (hD = dL/d(bn output), ReLU mask applied) and its batch-norm-backward sums
+template <int S>
 __global__ __launch_bounds__(256) void head_loss_kernel(TrainDev T, const float *__restrict__ target_policy,
                                                          const long long *__restrict__ target_value, int sl_mode,
                                                          float value_weight) {
-    __shared__ float h[3 * P];            // [162 policy | 81 value]
+    TG_GEO(S);
+    __shared__ float h[3 * P];            // [2 P policy | P value]
     __shared__ float logit[A + 3], dl[A + 3];
     __shared__ float hc[12];              // head bn: scale[3], shift[3], mean[3], rstd[3]
     __shared__ float wred[4][6];
     const int tid = threadIdx.x;
     TG_PROF(3, 0);
     if (tid < 3) {
-        const double n = (double)(T.B * P);
+        const double n = (double)(T.B * T.P);
         const double dmean = stat_sum(T.hstat + tid, 16) / n;
         const float mean = (float)dmean;
         const float rstd = (float)(1.0 / sqrt(fmax(stat_sum(T.hstat + 4 + tid, 16) / n - dmean * dmean, 0.0) + 2e-5));
@@ -647,82 +694,117 @@ __global__ __launch_bounds__(256) void head_loss_kernel(TrainDev T, const float 
             // both FC layers: wave w takes the outputs w, w + 4, ... (82 policy logits, 3 value logits), its lanes the inputs
             // (coalesced weight rows; a thread per OUTPUT read 64 scattered lines per instruction), butterfly per output
             const int wv = tid >> 6, ln = tid & 63;
-            const float h0 = h[ln], h1 = h[64 + ln], h2 = ln < 2 * P - 128 ? h[128 + ln] : 0.f;
-            const float v0 = h[2 * P + ln], v1 = ln < P - 64 ? h[2 * P + 64 + ln] : 0.f;
-            // in phases over all 22 outputs of the wave - every load first, then the products, then the butterflies level by
-            // level - so that the chains overlap (written output by output hipcc keeps them in program order: 15 us)
-            constexpr int NO = (A + 3 + 3) / 4;
-            float wa[NO], wb[NO], wc[NO], bias[NO], acc[NO];
+            // in phases over a group of the wave's outputs - every load first, then the products, then the butterflies level by
+            // level - so that the chains overlap (written output by output hipcc keeps them in program order: 15 us).  9x9: all
+            // 22 outputs of a wave in one group, three weights per lane and output; 19x19: groups of 6, twelve weights
+            constexpr int NJ = (2 * P + 63) / 64;                       // inputs per lane (policy rows are the longer ones)
+            constexpr int NOW = (A + 3 + 3) / 4;                        // outputs per wave
+            constexpr int NO = S == 9 ? NOW : 6;                        // ... per group
+            float hp[NJ], hv[NJ];
 #pragma unroll
-            for (int i = 0; i < NO; ++i) {
-                const int a = wv + 4 * i, a2 = a < A + 3 ? a : A + 2;
-                const bool pol = a2 < A;
-                const float *w = pol ? T.param + T.L.p_fc_w + (size_t)a2 * 2 * P : T.param + T.L.v_fc_w + (size_t)(a2 - A) * P;
-                const int n = pol ? 2 * P : P;
-                wa[i] = w[ln];
-                wb[i] = w[64 + ln < n ? 64 + ln : 0];
-                wc[i] = w[128 + ln < n ? 128 + ln : 0];
-                bias[i] = pol ? T.param[T.L.p_fc_b + a2] : T.param[T.L.v_fc_b + a2 - A];
+            for (int jj = 0; jj < NJ; ++jj) {
+                const int j = 64 * jj + ln;
+                hp[jj] = j < 2 * P ? h[j] : 0.f;
+                hv[jj] = j < P ? h[2 * P + j] : 0.f;
             }
+            for (int g0 = 0; g0 < NOW; g0 += NO) {
+                float wgt[NO][NJ], bias[NO], acc[NO];
 #pragma unroll
-            for (int i = 0; i < NO; ++i) {
-                const int a = wv + 4 * i;
-                const bool pol = a < A;
-                const int n = pol ? 2 * P : P;
-                const float x0 = pol ? h0 : v0, x1 = 64 + ln < n ? (pol ? h1 : v1) : 0.f, x2 = 128 + ln < n ? h2 : 0.f;
-                acc[i] = fmaf(x2, wc[i], fmaf(x1, wb[i], x0 * wa[i]));
-            }
+                for (int i = 0; i < NO; ++i) {
+                    const int a = wv + 4 * (g0 + i), a2 = a < A + 3 ? a : A + 2;
+                    const bool pol = a2 < A;
+                    const float *w = pol ? T.param + T.L.p_fc_w + (size_t)a2 * 2 * P : T.param + T.L.v_fc_w + (size_t)(a2 - A) * P;
+                    const int n = pol ? 2 * P : P;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                float t[NO];
+                    for (int jj = 0; jj < NJ; ++jj) wgt[i][jj] = w[64 * jj + ln < n ? 64 * jj + ln : 0];
+                    bias[i] = pol ? T.param[T.L.p_fc_b + a2] : T.param[T.L.v_fc_b + a2 - A];
+                }
 #pragma unroll
-                for (int i = 0; i < NO; ++i) t[i] = __shfl_xor(acc[i], o);
+                for (int i = 0; i < NO; ++i) {
+                    const bool pol = wv + 4 * (g0 + i) < A;
+                    const int n = pol ? 2 * P : P;
+                    float sacc = 0.f;
 #pragma unroll
-                for (int i = 0; i < NO; ++i) acc[i] += t[i];
-            }
-            if (ln == 0) {
+                    for (int jj = 0; jj < NJ; ++jj) {
+                        const float x = 64 * jj + ln < n ? (pol ? hp[jj] : hv[jj]) : 0.f;
+                        sacc = jj == 0 ? x * wgt[i][0] : fmaf(x, wgt[i][jj], sacc);
+                    }
+                    acc[i] = sacc;
+                }
 #pragma unroll
-                for (int i = 0; i < NO; ++i)
-                    if (wv + 4 * i < A + 3) logit[wv + 4 * i] = acc[i] + bias[i];
+                for (int o = 32; o > 0; o >>= 1) {
+                    float t[NO];
+#pragma unroll
+                    for (int i = 0; i < NO; ++i) t[i] = __shfl_xor(acc[i], o);
+#pragma unroll
+                    for (int i = 0; i < NO; ++i) acc[i] += t[i];
+                }
+                if (ln == 0) {
+#pragma unroll
+                    for (int i = 0; i < NO; ++i)
+                        if (wv + 4 * (g0 + i) < A + 3) logit[wv + 4 * (g0 + i)] = acc[i] + bias[i];
+                }
             }
         }
         __syncthreads();
         TG_PROF(3, 3);
         if (tid < 64) {
-            // policy: log-softmax, loss, dL/dlogit - lane a takes actions a and a + 64, sums by butterfly over the wave
+            // policy: log-softmax, loss, dL/dlogit - lane a takes actions a, a + 64, ..., sums by butterfly over the wave
             // (one lane walking the 82 actions three times was 22 of this kernel's 44 us)
             auto wsum = [](float v) {
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
                 return v;
             };
-            const int a0 = tid, a1 = tid + 64;
-            const bool two = a1 < A;
-            const float l0 = logit[a0], l1 = two ? logit[a1] : -INFINITY;
-            float m = fmaxf(l0, l1);
+            constexpr int RA = (A + 63) / 64;                            // actions per lane: a = lane + 64 r
+            float lg_[RA], tg_[RA];
+            const float *tp = target_policy + (size_t)b * A;
+            float m = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < RA; ++r) {
+                const int a = tid + 64 * r;
+                lg_[r] = a < A ? logit[a] : -INFINITY;
+                tg_[r] = a < A ? tp[a] : 0.f;
+                m = fmaxf(m, lg_[r]);
+            }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-            const float se = wsum(expf(l0 - m) + (two ? expf(l1 - m) : 0.f));
-            const float lse = m + logf(se);
-            const float *tp = target_policy + (size_t)b * A;
-            const float t0 = tp[a0], t1 = two ? tp[a1] : 0.f;
+            float se_l = 0.f;
+#pragma unroll
+            for (int r = 0; r < RA; ++r) se_l += tid + 64 * r < A ? expf(lg_[r] - m) : 0.f;
+            const float lse = m + logf(wsum(se_l));
             const float invb = 1.f / (float)T.B;
             float part = 0.f;
             if (!sl_mode) {
                 // kl_div(logp, t, batchmean): sum t * (log t - logp) / B (0 where t == 0); gradient (p * sum t - t) / B
-                const float st = wsum(t0 + t1);
-                const float lp0 = l0 - lse, lp1 = l1 - lse;
-                if (t0 > 0.f) part += t0 * (logf(t0) - lp0);
-                if (two && t1 > 0.f) part += t1 * (logf(t1) - lp1);
-                dl[a0] = (expf(lp0) * st - t0) * invb;
-                if (two) dl[a1] = (expf(lp1) * st - t1) * invb;
+                float st_l = 0.f;
+#pragma unroll
+                for (int r = 0; r < RA; ++r) st_l += tg_[r];
+                const float st = wsum(st_l);
+#pragma unroll
+                for (int r = 0; r < RA; ++r) {
+                    const int a = tid + 64 * r;
+                    if (a < A) {
+                        const float lpr = lg_[r] - lse;
+                        if (tg_[r] > 0.f) part += tg_[r] * (logf(tg_[r]) - lpr);
+                        dl[a] = (expf(lpr) * st - tg_[r]) * invb;
+                    }
+                }
             } else {
                 // -sum t * log(softmax + 1e-8) per sample, mean over the batch
-                const float p0 = expf(l0 - lse), p1 = two ? expf(l1 - lse) : 0.f;
-                part = -(t0 * logf(p0 + 1e-8f)) - (two ? t1 * logf(p1 + 1e-8f) : 0.f);
-                const float dot = wsum(t0 * p0 / (p0 + 1e-8f) + (two ? t1 * p1 / (p1 + 1e-8f) : 0.f));
-                dl[a0] = (p0 * dot - t0 * p0 / (p0 + 1e-8f)) * invb;
-                if (two) dl[a1] = (p1 * dot - t1 * p1 / (p1 + 1e-8f)) * invb;
+                float pr[RA], dot_l = 0.f;
+#pragma unroll
+                for (int r = 0; r < RA; ++r) {
+                    pr[r] = tid + 64 * r < A ? expf(lg_[r] - lse) : 0.f;
+                    if (tid + 64 * r < A) {
+                        part -= tg_[r] * logf(pr[r] + 1e-8f);
+                        dot_l += tg_[r] * pr[r] / (pr[r] + 1e-8f);
+                    }
+                }
+                const float dot = wsum(dot_l);
+#pragma unroll
+                for (int r = 0; r < RA; ++r)
+                    if (tid + 64 * r < A) dl[tid + 64 * r] = (pr[r] * dot - tg_[r] * pr[r] / (pr[r] + 1e-8f)) * invb;
             }
             const float loss = wsum(part);
             if (tid == 0) {
@@ -739,15 +821,16 @@ __global__ __launch_bounds__(256) void head_loss_kernel(TrainDev T, const float 
         }
         __syncthreads();
         TG_PROF(3, 4);
-        if (tid < A + 3) T.dlog[(size_t)b * (A + 3) + tid] = dl[tid];
+        for (int a = tid; a < A + 3; a += 256) T.dlog[(size_t)b * (A + 3) + a] = dl[a];
         // back through the FC layers to the head activations, ReLU mask, D + sums
         for (int e = tid; e < 3 * P; e += 256) {
             const int k = e / P, p = e - k * P;
             const float hzv = T.hz[((size_t)b * P + p) * 4 + k];
             float g = 0.f;
             if (k < 2) {
-#pragma unroll
-                for (int a = 0; a < A; ++a) g = fmaf(dl[a], T.param[T.L.p_fc_w + (size_t)a * 2 * P + e], g);   // all 82 loads in flight
+                constexpr int kUnroll = S == 9 ? A : 16;           // 9x9: all 82 loads in flight
+#pragma unroll kUnroll
+                for (int a = 0; a < A; ++a) g = fmaf(dl[a], T.param[T.L.p_fc_w + (size_t)a * 2 * P + e], g);
             } else {
                 for (int c = 0; c < 3; ++c) g = fmaf(dl[A + c], T.param[T.L.v_fc_w + (size_t)c * P + p], g);
             }
@@ -792,41 +875,51 @@ __global__ __launch_bounds__(256) void head_loss_kernel(TrainDev T, const float 
 //    81 of hact).  One workgroup per output a, thread (j, y): hact reads coalesced over j, dlog[b][a] a broadcast; the four y
 //    take a quarter of the batch each, sixteen loads in flight (one thread walking the batch four loads at a time was 20 us of
 //    memory latency), summed in y order through LDS.
+template <int S>
 __global__ __launch_bounds__(768) void head_fc_grad_kernel(TrainDev T) {
-    __shared__ float part[4][192], partb[4];
-    const int a = blockIdx.x, j = threadIdx.x, y = threadIdx.y;
+    TG_GEO(S);
+    constexpr int NX = 192;                                  // blockDim.x; a policy row has 2 P inputs: 162 (one pass) / 722 (four)
+    __shared__ float part[4][NX], partb[4];
+    const int a = blockIdx.x, y = threadIdx.y;
     const bool pol = a < A;
     const int nj = pol ? 2 * P : P;
-    float g = 0.f, gb = 0.f;
-    if (j < nj) {
-        const float *h = T.hact + (pol ? j : 2 * P + j);
-        const float *d = T.dlog + a;
-        const int per = (T.B + 3) / 4, b0 = y * per, b1 = b0 + per < T.B ? b0 + per : T.B;
+    const int per = (T.B + 3) / 4, b0 = y * per, b1 = b0 + per < T.B ? b0 + per : T.B;
+    for (int j0 = 0; j0 < nj; j0 += NX) {
+        const int j = j0 + threadIdx.x;
+        float g = 0.f, gb = 0.f;
+        if (j < nj) {
+            const float *h = T.hact + (pol ? j : 2 * P + j);
+            const float *d = T.dlog + a;
 #pragma unroll 16
-        for (int b = b0; b < b1; ++b) {
-            const float dv = d[(size_t)b * (A + 3)];
-            g = fmaf(dv, h[(size_t)b * 3 * P], g);
-            gb += dv;
+            for (int b = b0; b < b1; ++b) {
+                const float dv = d[(size_t)b * (A + 3)];
+                g = fmaf(dv, h[(size_t)b * 3 * P], g);
+                gb += dv;
+            }
         }
-    }
-    part[y][j] = g;
-    if (j == 0) partb[y] = gb;
-    __syncthreads();
-    if (y == 0 && j < nj) {
-        T.grad[(pol ? T.L.p_fc_w + (size_t)a * 2 * P : T.L.v_fc_w + (size_t)(a - A) * P) + j] = (part[0][j] + part[1][j]) + (part[2][j] + part[3][j]);
-        if (j == 0) T.grad[pol ? T.L.p_fc_b + a : T.L.v_fc_b + a - A] = (partb[0] + partb[1]) + (partb[2] + partb[3]);
+        __syncthreads();                                     // (the pass before has been read)
+        part[y][threadIdx.x] = g;
+        if (j == 0) partb[y] = gb;
+        __syncthreads();
+        if (y == 0 && j < nj) {
+            T.grad[(pol ? T.L.p_fc_w + (size_t)a * 2 * P : T.L.v_fc_w + (size_t)(a - A) * P) + j] =
+                (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+            if (j == 0) T.grad[pol ? T.L.p_fc_b + a : T.L.v_fc_b + a - A] = (partb[0] + partb[1]) + (partb[2] + partb[3]);
+        }
     }
 }
 
 // 4. per board: batch-norm backward of the head convolutions, their weight gradients, gradient into Y_6,
 //    ReLU mask -> D_12 and its sums.  Thread (row group g, channel c): coalesced over c, sums in registers.
+template <int S>
 __global__ __launch_bounds__(256) void head_back_kernel(TrainDev T) {
+    TG_GEO(S);
     __shared__ float hc[15];              // gamma*rstd[3], mean[3], rstd[3], m1[3], m2[3]
     __shared__ float dzs[P * 4];          // dZ of the three head channels, per row
     __shared__ float red[4][5][64];       // per row group: S1, S2, three weight-gradient rows
     const int tid = threadIdx.x, c = tid & 63, g = tid >> 6;
     if (tid < 3) {
-        const double n = (double)(T.B * P);
+        const double n = (double)(T.B * T.P);
         const double dmean = stat_sum(T.hstat + tid, 16) / n;
         const float mean = (float)dmean;
         const float rstd = (float)(1.0 / sqrt(fmax(stat_sum(T.hstat + 4 + tid, 16) / n - dmean * dmean, 0.0) + 2e-5));
@@ -904,7 +997,7 @@ __global__ void sgd_kernel(TrainDev T, SgdArgs a) {
         if (i >= L.bn_m[k] && i < L.bn_m[k] + 64) { l = k; kind = 3; break; }
         if (i >= L.bn_v[k] && i < L.bn_v[k] + 64) { l = k; kind = 4; break; }
     }
-    const double n = (double)(T.B * P);
+    const double n = (double)(T.B * T.P);
     if (kind == 0) {
         return;                                                       // convolution weights: sgd_conv_kernel
     } else if (kind == 1) {
@@ -971,7 +1064,7 @@ __global__ void sgd_conv_kernel(TrainDev T, SgdArgs a) {
 }  // namespace
 
 struct tg_trainer {
-    int device = 0, batch = 0;
+    int device = 0, batch = 0, size = 9;
     TrainDev dev{};
     std::vector<void *> allocs;
     bool first_step = true;
@@ -987,25 +1080,66 @@ int talloc(tg_trainer *t, T **out, size_t count) {
     *out = static_cast<T *>(p);
     return TG_OK;
 }
-constexpr int kConvLds = (kCells * kRow + 9 * 64) * 4;
-constexpr int kWgradLds = kWgradLdsFloats * 4;
+template <int S> constexpr int kConvLds = ((S + 2) * (S + 2) * kRow + 9 * 64) * 4;
+template <int S> constexpr int kWgradLds = WGeo<S>::kLdsFloats * 4;
+
+template <int S>
+int configure_kernels() {
+    static_assert(kConvLds<S> <= 160 * 1024 && kWgradLds<S> <= 160 * 1024, "LDS");
+    TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_kernel<FWD, S>), hipFuncAttributeMaxDynamicSharedMemorySize, kConvLds<S>));
+    TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_kernel<DGRAD, S>), hipFuncAttributeMaxDynamicSharedMemorySize, kConvLds<S>));
+    TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, kWgradLds<S>));
+    return TG_OK;
+}
+
+// one mini-batch: ~45 launches on the caller's stream
+template <int S>
+int launch_step(tg_trainer *t, const float *planes_dev, const float *policy_dev, const long long *value_dev, int sl_mode,
+                float value_weight, float lr, hipStream_t st) {
+    TrainDev &D = t->dev;
+    const int grid = D.NWG, A = S * S + 1;
+    hipLaunchKernelGGL(repack_kernel, dim3(36864 / 256, kLayers), dim3(256), 0, st, D);
+    for (int l = 0; l < kLayers; ++l)
+        hipLaunchKernelGGL((conv_kernel<FWD, S>), dim3(grid), dim3(256), kConvLds<S>, st, D, planes_dev, l);
+    hipLaunchKernelGGL(head_conv_kernel<S>, dim3(grid), dim3(256), 0, st, D);
+    hipLaunchKernelGGL(head_loss_kernel<S>, dim3(grid), dim3(256), 0, st, D, policy_dev, value_dev, sl_mode, value_weight);
+    hipLaunchKernelGGL(head_fc_grad_kernel<S>, dim3(A + 3), dim3(192, 4), 0, st, D);
+    hipLaunchKernelGGL(head_back_kernel<S>, dim3(grid), dim3(256), 0, st, D);
+    // backward.  (Measured and dropped: wgrad of layer l on a second stream beside the data-gradient chain - the two kernels do
+    // run side by side, 34 + 32 us overlapping into 41 instead of 24 + 20 one after the other, but the event between two
+    // launches of the chain costs 8 us on its stream: 0.91 against 0.93 ms per step.)
+    for (int l = kLayers - 1; l >= 0; --l) {
+        hipLaunchKernelGGL(wgrad_kernel<S>, dim3(4 * D.WCH), dim3(512), kWgradLds<S>, st, D, planes_dev, l);
+        if (l >= 1) hipLaunchKernelGGL((conv_kernel<DGRAD, S>), dim3(grid), dim3(256), kConvLds<S>, st, D, planes_dev, l);
+    }
+    SgdArgs a{lr, 0.9f, 1e-4f, t->first_step ? 1 : 0};
+    hipLaunchKernelGGL(sgd_conv_kernel, dim3(36864 / 256, kLayers), dim3(256), 0, st, D, a);
+    hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)((D.L.total + 255) / 256)), dim3(256), 0, st, D, a);
+    TG_HIP(hipGetLastError());
+    t->first_step = false;
+    return TG_OK;
+}
 }  // namespace
 
 extern "C" {
 
 int tg_trainer_create(int board_size, int device, int batch, const float *params_host, size_t n_params, tg_trainer **out) {
     if (!params_host || !out) return tg::fail(TG_ERR_ARG, "tg_trainer_create: null argument");
-    if (board_size != 9) return tg::fail(TG_ERR_ARG, "tg_trainer_create: the HIP training step is built for 9x9");
+    if (board_size != 9 && board_size != 19)
+        return tg::fail(TG_ERR_ARG, "tg_trainer_create: the HIP training step is built for 9x9 and 19x19 boards, not %d", board_size);
     if (batch < 2) return tg::fail(TG_ERR_ARG, "tg_trainer_create: batch must be >= 2 (batch statistics)");
-    const Layout L = make_layout();
+    const Layout L = make_layout(board_size);
+    const int P = board_size * board_size, A = P + 1;
     if (n_params != L.total) return tg::fail(TG_ERR_ARG, "tg_trainer_create: expected %zu parameters, got %zu", L.total, n_params);
     TG_HIP(hipSetDevice(device));
     tg_trainer *t = new tg_trainer;
     t->device = device;
     t->batch = batch;
+    t->size = board_size;
     TrainDev &D = t->dev;
     D.L = L;
     D.B = batch;
+    D.P = P;
     D.NWG = batch < 256 ? batch : 256;
     D.WCH = batch < 64 ? batch : 64;
     const size_t act = (size_t)batch * P * C;
@@ -1022,9 +1156,11 @@ int tg_trainer_create(int board_size, int device, int batch, const float *params
         return rc;
     }
     TG_HIP(hipMemcpy(D.param, params_host, L.total * sizeof(float), hipMemcpyHostToDevice));
-    TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_kernel<FWD>), hipFuncAttributeMaxDynamicSharedMemorySize, kConvLds));
-    TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_kernel<DGRAD>), hipFuncAttributeMaxDynamicSharedMemorySize, kConvLds));
-    TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kWgradLds));
+    if ((rc = board_size == 9 ? configure_kernels<9>() : configure_kernels<19>())) {
+        for (void *p : t->allocs) (void)hipFree(p);
+        delete t;
+        return rc;
+    }
     *out = t;
     return TG_OK;
 }
@@ -1042,28 +1178,8 @@ int tg_trainer_step(tg_trainer *t, const float *planes_dev, const float *policy_
     if (!t || !planes_dev || !policy_dev || !value_dev) return tg::fail(TG_ERR_ARG, "tg_trainer_step: null argument");
     TG_HIP(hipSetDevice(t->device));          // the launches below belong to the trainer's device whatever the caller's is
     hipStream_t st = static_cast<hipStream_t>(stream);
-    TrainDev &D = t->dev;
-    const int grid = D.NWG;
-    hipLaunchKernelGGL(repack_kernel, dim3(36864 / 256, kLayers), dim3(256), 0, st, D);
-    for (int l = 0; l < kLayers; ++l)
-        hipLaunchKernelGGL(conv_kernel<FWD>, dim3(grid), dim3(256), kConvLds, st, D, planes_dev, l);
-    hipLaunchKernelGGL(head_conv_kernel, dim3(grid), dim3(256), 0, st, D);
-    hipLaunchKernelGGL(head_loss_kernel, dim3(grid), dim3(256), 0, st, D, policy_dev, value_dev, sl_mode, value_weight);
-    hipLaunchKernelGGL(head_fc_grad_kernel, dim3(A + 3), dim3(192, 4), 0, st, D);
-    hipLaunchKernelGGL(head_back_kernel, dim3(grid), dim3(256), 0, st, D);
-    // backward.  (Measured and dropped: wgrad of layer l on a second stream beside the data-gradient chain - the two kernels do
-    // run side by side, 34 + 32 us overlapping into 41 instead of 24 + 20 one after the other, but the event between two
-    // launches of the chain costs 8 us on its stream: 0.91 against 0.93 ms per step.)
-    for (int l = kLayers - 1; l >= 0; --l) {
-        hipLaunchKernelGGL(wgrad_kernel, dim3(4 * D.WCH), dim3(512), kWgradLds, st, D, planes_dev, l);
-        if (l >= 1) hipLaunchKernelGGL(conv_kernel<DGRAD>, dim3(grid), dim3(256), kConvLds, st, D, planes_dev, l);
-    }
-    SgdArgs a{lr, 0.9f, 1e-4f, t->first_step ? 1 : 0};
-    hipLaunchKernelGGL(sgd_conv_kernel, dim3(36864 / 256, kLayers), dim3(256), 0, st, D, a);
-    hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)((D.L.total + 255) / 256)), dim3(256), 0, st, D, a);
-    TG_HIP(hipGetLastError());
-    t->first_step = false;
-    return TG_OK;
+    return t->size == 9 ? launch_step<9>(t, planes_dev, policy_dev, value_dev, sl_mode, value_weight, lr, st)
+                        : launch_step<19>(t, planes_dev, policy_dev, value_dev, sl_mode, value_weight, lr, st);
 }
 
 int tg_trainer_read_losses(tg_trainer *t, double *sums_host, int reset) {
@@ -1095,7 +1211,7 @@ int tg_trainer_debug_read(tg_trainer *t, int which, int index, float *out_host) 
     TG_HIP(hipSetDevice(t->device));
     TG_HIP(hipDeviceSynchronize());
     const TrainDev &D = t->dev;
-    const size_t act = (size_t)D.B * P * C;
+    const size_t act = (size_t)D.B * D.P * C;
 #ifdef TG_TRAIN_PROF
     if (which == 3) {
         TG_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 64));

@@ -6,7 +6,7 @@ The loop, the losses, the optimiser and the file formats interchange with the re
 ``torch.optim.SGD`` state over the parameters in the same order).  The mini-batch step is ``HipTrainer`` = this repo's HIP
 kernels (tamago_amd/csrc/train.hip behind ``tg_trainer_*``: forward with batch statistics, backward, SGD-Nesterov, running
 statistics) - the ONLY step implementation in the package: a board size the kernels are not built for (anything but 9x9
-today) is refused with an error, not handed to a library.  The torch-autograd restatement the kernels are tested against
+and 19x19) is refused with an error, not handed to a library.  The torch-autograd restatement the kernels are tested against
 lives with the other checkers in ``oracle/train_ref.py``.  The arithmetic is fp32 throughout (the reference runs this step
 under fp16 autocast with a GradScaler on the GPU, learn.py:342,371, and in fp32 on the CPU - fp32 is the stricter of the
 two; mixed precision stays optional and unbuilt).
@@ -115,7 +115,8 @@ class HipTrainer:
     """The training step as this repo's HIP kernels (tamago_amd/csrc/train.hip behind tg_trainer_*): forward with
     batch statistics, backward, SGD-Nesterov + weight decay, batch-norm running statistics - no autograd, no
     library kernel.  Same table / state_dict / optimiser-state layout as ParamTable + make_optimizer (and as the
-    reference's modules).  fp32; built for 9x9 - any other board size raises (there is no second backend to fall to)."""
+    reference's modules).  fp32; built for 9x9 (the size every tuning decision was made at) and 19x19 (the same kernels walking
+    the board in more passes) - any other board size raises (there is no second backend to fall to)."""
 
     def __init__(self, device: torch.device, board_size: int = 9, batch_size: int = 256,
                  state: Dict[str, torch.Tensor] = None):
@@ -126,8 +127,8 @@ class HipTrainer:
         self.device = torch.device(device)
         if self.device.type == "cuda" and self.device.index is None:
             self.device = torch.device("cuda", 0)           # (tg_trainer_create below uses index 0 as well)
-        if board_size != 9:
-            raise ValueError(f"HipTrainer: the HIP training step (tamago_amd/csrc/train.hip) is built for 9x9 boards; "
+        if board_size not in (9, 19):
+            raise ValueError(f"HipTrainer: the HIP training step (tamago_amd/csrc/train.hip) is built for 9x9 and 19x19 boards; "
                              f"board size {board_size} is not served (the reference's own trainer, nn/learn.py, is the "
                              f"tool for it)")
         self.board_size = board_size

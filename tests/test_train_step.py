@@ -311,11 +311,11 @@ def test_sl_trainer_files(tmp_path, monkeypatch):
 @pytest.mark.gpu
 def test_other_board_sizes_are_refused_not_handed_to_a_library(tmp_path):
     """One backend: the package has no torch-autograd step to fall back to - a size train.hip is not built for raises."""
-    with pytest.raises(ValueError, match="9x9"):
-        learn.HipTrainer(torch.device("cuda", 0), 19, 32)
+    with pytest.raises(ValueError, match="9x9 and 19x19"):
+        learn.HipTrainer(torch.device("cuda", 0), 13, 32)
     os.makedirs(tmp_path / "data")
-    with pytest.raises(ValueError, match="9x9"):
-        learn.train_with_gumbel_alphazero_on_gpu(str(tmp_path), 19, 32)
+    with pytest.raises(ValueError, match="9x9 and 19x19"):
+        learn.train_with_gumbel_alphazero_on_gpu(str(tmp_path), 13, 32)
 
 
 def test_the_package_has_one_training_backend():
@@ -327,6 +327,70 @@ def test_the_package_has_one_training_backend():
             if f.endswith(".py"):
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"\.backward\(|optimizer\.step\(|enable_grad|CUDAGraph|^\s*(from|import) oracle", text, re.M), os.path.join(dirpath, f)
+
+
+def random_state(size, seed):
+    """make_case's parameter distributions at another board size."""
+    rng = np.random.RandomState(seed)
+    state = {}
+    for key, shape in state_dict_keys(size):
+        if key.endswith("running_mean"):
+            v = rng.normal(0, 0.05, shape)
+        elif key.endswith("running_var"):
+            v = rng.uniform(0.8, 1.2, shape)
+        elif ".bn" in key or key.startswith("bn_layer"):
+            v = rng.uniform(0.7, 1.3, shape) if key.endswith("weight") else rng.normal(0, 0.1, shape)
+        else:
+            fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else 64
+            v = rng.uniform(-1, 1, shape) / np.sqrt(fan_in)
+        state[key] = torch.from_numpy(np.asarray(v, np.float32))
+    return state
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bsz,mode", [(32, "rl"), (70, "sl"), (256, "rl")])
+def test_hip_training_step_19x19_vs_autograd(bsz, mode):
+    """The same kernels instantiated for 19x19 (a board in four staging passes and four passes of the MFMA loop, one LDS buffer in
+    the weight gradient, FC layers in groups of outputs): one step against torch autograd + torch.optim.SGD on the same batch -
+    losses, every parameter, batch-norm statistics, momentum buffers - and the saved Z / Y / D tensors of three layers."""
+    import torch.nn.functional as F
+    from tamago_amd import lib as tl
+    dev = torch.device("cuda", 0)
+    size, P = 19, 361
+    state = random_state(size, 4100 + bsz)
+    rng = np.random.RandomState(900 + bsz)
+    planes = torch.from_numpy(rng.uniform(size=(bsz, 6, size, size)).astype(np.float32)).to(dev)
+    pol = rng.gamma(0.3, size=(bsz, P + 1))
+    pol = torch.from_numpy((pol / pol.sum(1, keepdims=True)).astype(np.float32)).to(dev)
+    val = torch.from_numpy(rng.randint(0, 3, size=bsz).astype(np.int64)).to(dev)
+    hip = learn.HipTrainer(dev, size, bsz, state)
+    hip.step(planes, pol, val, mode=mode, lr=0.01)
+    got = hip.take_losses()
+    lib = tl.load()
+
+    def saved(which, idx):
+        out = np.zeros((bsz, P, 64), dtype=np.float32)
+        tl.check(lib.tg_trainer_debug_read(hip.handle, which, idx, out.ctypes.data))
+        return torch.from_numpy(out).permute(0, 2, 1).reshape(bsz, 64, size, size).to(dev)
+
+    net = train_ref.TrainableDualNet(dev, size, state).train()
+    # forward tensors of the stem and the first block from the checker's own modules
+    t = net.t
+    with torch.no_grad():
+        z0 = F.conv2d(planes, t["conv_layer.weight"], padding=1)
+        assert float((saved(0, 0) - z0).abs().max()) < 1e-5 * max(1.0, float(z0.abs().max()))
+    opt = learn.make_optimizer(net, 0.01)
+    want = (train_ref.rl_train_step if mode == "rl" else train_ref.sl_train_step)(net, opt, planes, pol, val)
+    np.testing.assert_allclose([got["loss"], got["policy"], got["value"]], [want["loss"], want["policy"], want["value"]],
+                               rtol=0, atol=5e-5)
+    now, ref = hip.state_dict(), net.state_dict()
+    moved = 0.0
+    for key, _ in state_dict_keys(size):
+        np.testing.assert_allclose(now[key].numpy(), ref[key].cpu().numpy(), rtol=0, atol=5e-5, err_msg=key)
+        moved = max(moved, float((ref[key].cpu() - state[key]).abs().max()))
+    assert moved > 1e-3
+    for g, p in zip(hip.momentum_buffers(), net.parameters()):
+        np.testing.assert_allclose(g.numpy(), opt.state[p]["momentum_buffer"].cpu().numpy(), rtol=0, atol=4e-3)
 
 
 @pytest.mark.gpu

@@ -21,7 +21,7 @@ for batch in batches:
         planes = torch.from_numpy((rng.uniform(size=(batch, 6, size, size)) < 0.3).astype(np.float32)).to(dev)
         pol = torch.softmax(torch.randn(batch, size * size + 1, device=dev), 1)
         val = torch.randint(0, 3, (batch,), device=dev)
-        hip = learn.HipTrainer(dev, 9, batch)
+        hip = learn.HipTrainer(dev, size, batch)
         for _ in range(3):
             hip.step(planes, pol, val)
         torch.cuda.synchronize()
@@ -30,7 +30,7 @@ for batch in batches:
             hip.step(planes, pol, val)
         torch.cuda.synchronize()
         dh = (time.time() - t0) / 30
-        print(f"train step 9x9 batch {batch}: HIP kernels (tg_trainer_step) {dh * 1e3:.2f} ms -> {batch / dh:,.0f} positions/s")
+        print(f"train step {size}x{size} batch {batch}: HIP kernels (tg_trainer_step) {dh * 1e3:.2f} ms -> {batch / dh:,.0f} positions/s")
         continue
     net = train_ref.TrainableDualNet(dev, size)
     opt = learn.make_optimizer(net, 0.01)
@@ -58,8 +58,8 @@ for batch in batches:
     dg = (time.time() - t0) / n
     line = (f"train step {size}x{size} batch {batch}: autograd eager {dt * 1e3:.2f} ms -> {batch / dt:,.0f} positions/s; "
             f"autograd hipGraph {dg * 1e3:.2f} ms -> {batch / dg:,.0f} positions/s")
-    if size == 9:
-        hip = learn.HipTrainer(dev, 9, batch)
+    if size in (9, 19):
+        hip = learn.HipTrainer(dev, size, batch)
         for _ in range(3):
             hip.step(planes, pol, val)
         torch.cuda.synchronize()
