@@ -423,3 +423,34 @@ def test_hip_training_step_at_the_batch_sizes_the_weight_gradient_chunks_differe
     assert moved > 1e-3
     for g, p in zip(hip.momentum_buffers(), net.parameters()):
         np.testing.assert_allclose(g.numpy(), opt.state[p]["momentum_buffer"].cpu().numpy(), rtol=0, atol=2e-3)
+
+
+@pytest.mark.gpu
+def test_rl_training_loop_files_19x19(tmp_path):
+    """The file-level loop at the other board size the step is built for: data/rl_data_*.npz (19x19 planes, 362-way policies) ->
+    model/rl-model.bin + rl-state.ckpt, a resumed second pass over the same file trains further, and the trained table loads into
+    the 19x19 inference network."""
+    size, P, bsz = 19, 361, 16
+    rng = np.random.RandomState(77)
+    state = random_state(size, 5)
+    planes = rng.uniform(size=(3 * bsz, 6, size, size)).astype(np.float32)
+    pol = rng.gamma(0.3, size=(3 * bsz, P + 1))
+    pol = (pol / pol.sum(1, keepdims=True)).astype(np.float32)
+    val = rng.randint(0, 3, size=3 * bsz).astype(np.int32)
+    os.makedirs(tmp_path / "data")
+    np.savez_compressed(tmp_path / "data" / "rl_data_0.npz", input=planes, policy=pol, value=val, kifu_count=3)
+    os.makedirs(tmp_path / "model")
+    torch.save(state, tmp_path / "model" / "rl-model.bin")
+    np.random.seed(3)
+    first = learn.train_with_gumbel_alphazero_on_gpu(str(tmp_path), size, bsz)
+    ck = torch.load(tmp_path / "model" / "rl-state.ckpt", map_location="cpu")
+    assert ck["num_trained_batches"] == 3
+    np.random.seed(3)
+    second = learn.train_with_gumbel_alphazero_on_gpu(str(tmp_path), size, bsz)
+    assert torch.load(tmp_path / "model" / "rl-state.ckpt", map_location="cpu")["num_trained_batches"] == 6
+    assert np.isfinite(first["loss"]) and second["loss"] < first["loss"]
+    from tamago_amd.nn.network.dual_net import DualNet
+    net = DualNet(torch.device("cuda", 0), size)
+    net.load_state_dict(torch.load(tmp_path / "model" / "rl-model.bin", map_location="cpu"))
+    policy, value = net.inference(torch.from_numpy(planes[:4]))
+    assert policy.shape == (4, P + 1) and torch.isfinite(policy).all() and torch.isfinite(value).all()
