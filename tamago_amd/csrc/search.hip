@@ -106,7 +106,7 @@ struct SearchDev {
     int32_t T, N, K, cgos, superko;
 };
 
-constexpr int kPathCap = 24;
+constexpr int kPathCap = 48;      // (24 until round 5: the last mini-batches of a 1 600-visit 19x19 search walk 25 levels and fell to the one-wave backup, 560 us instead of 30)
 enum : int32_t { kErrPoolFull = 1, kErrRngEmpty = 2, kErrPipeline = 4 };
 
 template <int S>
