@@ -56,8 +56,31 @@ for batch in batches:
         run(planes, pol, val)
     torch.cuda.synchronize()
     dg = (time.time() - t0) / n
+    # the reference's own GPU mode: the same step under fp16 autocast with a GradScaler (learn.py:342,371), eager as it runs it
+    amp_net = train_ref.TrainableDualNet(dev, size)
+    amp_opt = learn.make_optimizer(amp_net, 0.01)
+    scaler = torch.amp.GradScaler("cuda")
+
+    def amp_step():
+        with torch.enable_grad():
+            with torch.autocast(device_type="cuda", dtype=torch.float16):
+                pp, vp = amp_net.forward(planes)
+                loss = (learn.calculate_policy_kld_loss(pp, pol) + learn.RL_VALUE_WEIGHT * learn.calculate_value_loss(vp, val)).mean()
+            amp_net.zero_grad()
+            scaler.scale(loss).backward()
+        scaler.step(amp_opt)
+        scaler.update()
+    for _ in range(5):
+        amp_step()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(n):
+        amp_step()
+    torch.cuda.synchronize()
+    da = (time.time() - t0) / n
     line = (f"train step {size}x{size} batch {batch}: autograd eager {dt * 1e3:.2f} ms -> {batch / dt:,.0f} positions/s; "
-            f"autograd hipGraph {dg * 1e3:.2f} ms -> {batch / dg:,.0f} positions/s")
+            f"autograd hipGraph {dg * 1e3:.2f} ms -> {batch / dg:,.0f} positions/s; "
+            f"autograd fp16 autocast + GradScaler, eager (the reference's GPU mode) {da * 1e3:.2f} ms")
     if size in (9, 19):
         hip = learn.HipTrainer(dev, size, batch)
         for _ in range(3):
