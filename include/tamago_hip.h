@@ -382,9 +382,9 @@ int tg_trainer_destroy(tg_trainer *t);
 int tg_trainer_step(tg_trainer *t, const float *planes_dev, const float *policy_dev,
                     const long long *value_dev, int sl_mode, float value_weight, float lr, void *stream);
 int tg_trainer_read_losses(tg_trainer *t, double *sums_host /* [3] */, int reset);
-/* parameters (and, unless NULL, the momentum buffers) back to the host; n = tg_net_param_count(9) */
+/* parameters (and, unless NULL, the momentum buffers) back to the host; n = tg_net_param_count(board_size) */
 int tg_trainer_get_params(tg_trainer *t, float *params_host, float *momentum_host, size_t n);
-/* test aid: one saved tensor of the last step, NHWC fp32 [B][81][64]: which 0 = Z_index (convolution output
+/* test aid: one saved tensor of the last step, NHWC fp32 [B][board_size^2][64]: which 0 = Z_index (convolution output
  * before its batch norm, index 0..12), 1 = Y_index (block output, 0..6), 2 = D_index (dL/d batch-norm output) */
 int tg_trainer_debug_read(tg_trainer *t, int which, int index, float *out_host);
 /* resume: momentum buffers of a loaded optimiser state (the next step is then not a "first" step) */
