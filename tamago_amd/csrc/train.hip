@@ -181,32 +181,36 @@ __global__ __launch_bounds__(256) void conv_kernel(TrainDev T, const float *__re
     // ---- per-channel tables -------------------------------------------------------------------------
     // FWD: tab[0] = scale, tab[1] = shift of the PRODUCER's batch norm (layer l - 1)
     // DGRAD: tab[0] = gamma*rstd of layer l, tab[1] = mean, tab[2] = rstd, tab[3] unused; m1/m2 in tab[4..5]
-    if (tid < 64) {
-        if (MODE == FWD) {
-            if (l >= 1) {
-                float mean, rstd;
-                bn_consts(T, l - 1, tid, l - 1 == 0 ? 1e-5f : eps_l, mean, rstd);
-                const float sc = T.param[T.L.bn_w[l - 1] + tid] * rstd;
-                tab[tid] = sc;
-                tab[64 + tid] = T.param[T.L.bn_b[l - 1] + tid] - mean * sc;
-            }
-        } else {
+    if (MODE == FWD) {
+        if (tid < 64 && l >= 1) {
             float mean, rstd;
-            bn_consts(T, l, tid, eps_l, mean, rstd);
+            bn_consts(T, l - 1, tid, l - 1 == 0 ? 1e-5f : eps_l, mean, rstd);
+            const float sc = T.param[T.L.bn_w[l - 1] + tid] * rstd;
+            tab[tid] = sc;
+            tab[64 + tid] = T.param[T.L.bn_b[l - 1] + tid] - mean * sc;
+        }
+    } else {
+        // three waves, a third of the constants each (one wave making all of them: 3.1 us of statistics round trip + fp64 chain)
+        const int c = tid & 63, part = tid >> 6;
+        if (part == 0) {
+            float mean, rstd;
+            bn_consts(T, l, c, eps_l, mean, rstd);
+            tab[c] = T.param[T.L.bn_w[l] + c] * rstd;
+            tab[64 + c] = mean;
+            tab[128 + c] = rstd;
+        } else if (part == 1) {
             const double n = (double)(T.B * T.P);
-            tab[tid] = T.param[T.L.bn_w[l] + tid] * rstd;
-            tab[64 + tid] = mean;
-            tab[128 + tid] = rstd;
-            tab[192 + tid] = (float)(stat_sum(T.stat + (size_t)l * kRep * 256 + 128 + tid, 256) / n);      // m1 = mean(D)
-            tab[256 + tid] = (float)(stat_sum(T.stat + (size_t)l * kRep * 256 + 192 + tid, 256) / n);      // m2 = mean(D * xhat)
+            tab[192 + c] = (float)(stat_sum(T.stat + (size_t)l * kRep * 256 + 128 + c, 256) / n);      // m1 = mean(D)
+            tab[256 + c] = (float)(stat_sum(T.stat + (size_t)l * kRep * 256 + 192 + c, 256) / n);      // m2 = mean(D * xhat)
+        } else if (part == 2) {
             // constants of the layer BELOW (mask / xhat of D_{l-1})
             float mean2, rstd2;
-            bn_consts(T, l - 1, tid, l - 1 == 0 ? 1e-5f : eps_l, mean2, rstd2);
-            const float sc2 = T.param[T.L.bn_w[l - 1] + tid] * rstd2;
-            tab[320 + tid] = sc2;
-            tab[384 + tid] = T.param[T.L.bn_b[l - 1] + tid] - mean2 * sc2;
-            tab[448 + tid] = mean2;
-            tab[512 + tid] = rstd2;
+            bn_consts(T, l - 1, c, l - 1 == 0 ? 1e-5f : eps_l, mean2, rstd2);
+            const float sc2 = T.param[T.L.bn_w[l - 1] + c] * rstd2;
+            tab[320 + c] = sc2;
+            tab[384 + c] = T.param[T.L.bn_b[l - 1] + c] - mean2 * sc2;
+            tab[448 + c] = mean2;
+            tab[512 + c] = rstd2;
         }
     }
     __syncthreads();
@@ -979,16 +983,20 @@ __global__ __launch_bounds__(256) void head_back_kernel(TrainDev T) {
 // ---- optimiser: torch.optim.SGD(momentum, weight_decay, nesterov) over every parameter, running statistics ------
 struct SgdArgs { float lr, momentum, weight_decay; int first_step; };
 
+// number of parameters that are NOT convolution weights (those are sgd_conv_kernel's): the stem's batch norm, two batch norms per
+// block, everything from the head convolutions on - 4 % of the blob; the kernel is launched over these only
+__host__ __device__ inline size_t sgd_small_count(const Layout &L) { return 256 + 6 * 512 + (L.total - L.p_conv); }
+
 __global__ void sgd_kernel(TrainDev T, SgdArgs a) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= T.L.total) return;
     const Layout &L = T.L;
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= sgd_small_count(L)) return;
+    // k-th non-convolution element -> its place in the blob
+    const size_t i = k < 256 ? L.bn_w[0] + k : k < 256 + 6 * 512 ? L.bn_w[1 + 2 * ((k - 256) / 512)] + (k - 256) % 512 : L.p_conv + (k - 256 - 6 * 512);
     // which tensor is element i in?
     float g;
     bool is_stat = false;
     int l = -1, kind = -1;       // kind 0 conv weight, 1 bn weight, 2 bn bias, 3 running mean, 4 running var
-    // 96 % of the elements are convolution weights of the blocks (sgd_conv_kernel's): periodic layout, rejected without the walk
-    if (i >= L.conv[1] && i < L.p_conv && (i - L.conv[1]) % (2 * (size_t)kConvW + 512) < 2 * (size_t)kConvW) return;
     for (int k = 0; k < kLayers; ++k) {
         const size_t wn = k == 0 ? 64 * 6 * 9 : kConvW;
         if (i >= L.conv[k] && i < L.conv[k] + wn) { l = k; kind = 0; break; }
@@ -1114,7 +1122,7 @@ int launch_step(tg_trainer *t, const float *planes_dev, const float *policy_dev,
     }
     SgdArgs a{lr, 0.9f, 1e-4f, t->first_step ? 1 : 0};
     hipLaunchKernelGGL(sgd_conv_kernel, dim3(36864 / 256, kLayers), dim3(256), 0, st, D, a);
-    hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)((D.L.total + 255) / 256)), dim3(256), 0, st, D, a);
+    hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)((sgd_small_count(D.L) + 255) / 256)), dim3(256), 0, st, D, a);
     TG_HIP(hipGetLastError());
     t->first_step = false;
     return TG_OK;
