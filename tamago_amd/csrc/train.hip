@@ -140,9 +140,13 @@ __device__ unsigned long long g_prof[4 * 16];
 // 4 waves: wave w owns output channels [16w, 16w+16) of all six row tiles.  A 256-position batch is one board per CU
 // = one wave per SIMD, so the loop hides its own latencies: weight fragments (L2) are requested two (tap, channel
 // group) steps ahead, activation fragments (LDS) one step ahead, positions pinned with sched_barrier.
+// `per_board` workgroups share a board (1, or - 19x19 batches below the CU count - one per pass of the MFMA loop: each stages the
+// board and computes six of its row tiles; a 64-position 19x19 batch on 64 CUs was slower than the library).
 template <int MODE, int S>
-__global__ __launch_bounds__(256) void conv_kernel(TrainDev T, const float *__restrict__ planes, int l) {
+__global__ __launch_bounds__(256) void conv_kernel(TrainDev T, const float *__restrict__ planes, int l, int per_board) {
     TG_GEO(S);
+    const int pb = kMT > 6 ? per_board : 1;              // (9x9: one pass, a constant)
+    const int wg = blockIdx.x / pb, part = blockIdx.x - wg * pb, nwg = gridDim.x / pb;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *act = smem;                       // [cells of the (S + 2)^2 padded board][72]: the border stays zero, a tap is a constant offset
     float *tab = smem + kCells * kRow;       // per-channel constants [9][64]
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(256) void conv_kernel(TrainDev T, const float *__re
     };
     const int pslot = l == 5 ? MODE : -1;
     if (pslot >= 0) TG_PROF(pslot, 0);
-    if (staged && (int)blockIdx.x < T.B) request(blockIdx.x, 0);
+    if (staged && wg < T.B) request(wg, 0);
     // ---- per-channel tables -------------------------------------------------------------------------
     // FWD: tab[0] = scale, tab[1] = shift of the PRODUCER's batch norm (layer l - 1)
     // DGRAD: tab[0] = gamma*rstd of layer l, tab[1] = mean, tab[2] = rstd, tab[3] unused; m1/m2 in tab[4..5]
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(256) void conv_kernel(TrainDev T, const float *__re
     const float *wfrag = (MODE == FWD ? T.wf : T.wb) + (size_t)l * 4 * 9 * 4 * 64 * 4;
     const f32x4 *wl = reinterpret_cast<const f32x4 *>(wfrag) + (size_t)wave * 9 * 4 * 64 + lane;
     float s_sum[4] = {0.f, 0.f, 0.f, 0.f}, s_sq[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int b = blockIdx.x; b < T.B; b += gridDim.x) {
+    for (int b = wg; b < T.B; b += nwg) {
         // ---- stage the board: LDS act[cell][c] from the registers requested above / at the end of the board before ----
         if (MODE == FWD && l == 0) {
             for (int e = tid; e < P * C; e += NT) {
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(256) void conv_kernel(TrainDev T, const float *__re
                 act[((y + 1) * W + row - y * S + 1) * kRow + c] = c < 6 ? planes[((size_t)b * 6 + c) * P + row] : 0.f;
             }
         } else {
-            float *yout = fwd && conv1 ? T.Y + ((size_t)yb * T.B + b) * bstride : nullptr;
+            float *yout = fwd && conv1 && part == 0 ? T.Y + ((size_t)yb * T.B + b) * bstride : nullptr;
             for (int i0 = 0; i0 < NV; i0 += NVP) {
                 if (i0 > 0) request(b, i0);
 #pragma unroll
@@ -260,7 +264,7 @@ __global__ __launch_bounds__(256) void conv_kernel(TrainDev T, const float *__re
         const bool ep_conv1 = MODE == DGRAD && (l & 1) != 0;   // input of conv1 = block output Y_{(l-1)/2}; the skip carries D_{l+1}
         const int c0 = wave * 16 + lg * 4;
         // ---- implicit GEMM: acc[mt] (16 couts x 16 rows) over 9 taps x 16 k-groups of 4 channels, HMT row tiles per pass ----
-        for (int mt0 = 0; mt0 < kMT; mt0 += HMT) {
+        for (int mt0 = pb > 1 ? part * HMT : 0; mt0 < (pb > 1 ? (part + 1) * HMT : kMT); mt0 += HMT) {
             f32x4 acc[HMT];
 #pragma unroll
             for (int mt = 0; mt < HMT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -344,7 +348,7 @@ __global__ __launch_bounds__(256) void conv_kernel(TrainDev T, const float *__re
                 }
             }
         }
-        if (staged && b + (int)gridDim.x < T.B) request(b + gridDim.x, 0);
+        if (staged && b + nwg < T.B) request(b + nwg, 0);
         __syncthreads();
         if (pslot >= 0) TG_PROF(pslot, 4);
     }
@@ -1106,9 +1110,12 @@ int launch_step(tg_trainer *t, const float *planes_dev, const float *policy_dev,
                 float value_weight, float lr, hipStream_t st) {
     TrainDev &D = t->dev;
     const int grid = D.NWG, A = S * S + 1;
+    // 19x19 below the CU count: a board's four passes of the MFMA loop on four workgroups
+    constexpr int kPasses = ((S * S + 15) / 16 + 5) / 6;
+    const int per_board = kPasses > 1 && D.B * kPasses <= 256 ? kPasses : 1;
     hipLaunchKernelGGL(repack_kernel, dim3(36864 / 256, kLayers), dim3(256), 0, st, D);
     for (int l = 0; l < kLayers; ++l)
-        hipLaunchKernelGGL((conv_kernel<FWD, S>), dim3(grid), dim3(256), kConvLds<S>, st, D, planes_dev, l);
+        hipLaunchKernelGGL((conv_kernel<FWD, S>), dim3(grid * per_board), dim3(256), kConvLds<S>, st, D, planes_dev, l, per_board);
     hipLaunchKernelGGL(head_conv_kernel<S>, dim3(grid), dim3(256), 0, st, D);
     hipLaunchKernelGGL(head_loss_kernel<S>, dim3(grid), dim3(256), 0, st, D, policy_dev, value_dev, sl_mode, value_weight);
     hipLaunchKernelGGL(head_fc_grad_kernel<S>, dim3(A + 3), dim3(192, 4), 0, st, D);
@@ -1118,7 +1125,7 @@ int launch_step(tg_trainer *t, const float *planes_dev, const float *policy_dev,
     // launches of the chain costs 8 us on its stream: 0.91 against 0.93 ms per step.)
     for (int l = kLayers - 1; l >= 0; --l) {
         hipLaunchKernelGGL(wgrad_kernel<S>, dim3(4 * D.WCH), dim3(512), kWgradLds<S>, st, D, planes_dev, l);
-        if (l >= 1) hipLaunchKernelGGL((conv_kernel<DGRAD, S>), dim3(grid), dim3(256), kConvLds<S>, st, D, planes_dev, l);
+        if (l >= 1) hipLaunchKernelGGL((conv_kernel<DGRAD, S>), dim3(grid * per_board), dim3(256), kConvLds<S>, st, D, planes_dev, l, per_board);
     }
     SgdArgs a{lr, 0.9f, 1e-4f, t->first_step ? 1 : 0};
     hipLaunchKernelGGL(sgd_conv_kernel, dim3(36864 / 256, kLayers), dim3(256), 0, st, D, a);
