@@ -853,7 +853,7 @@ __global__ __launch_bounds__(384) void dualnet_heads19_part_kernel(NetDev net, c
     if (tid < A) {
         const float *wT = net.pfc_wT + (size_t)j0 * A + tid;
         float s = 0.f;
-#pragma unroll 4
+#pragma unroll 16
         for (int j = 0; j < n; ++j) s = fmaf(f[j], wT[(size_t)j * A], s);
         part[((size_t)b * 4 + q) * 384 + tid] = s;
     }
