@@ -303,7 +303,11 @@ def worker(size: int):
                         (7, 50, 148, True)]
     else:
         puct_cases = [(0, 64, 200, "STRICT", False, 0, False),
-                      (1, 64, 200, "STRICT", False, 200, True)]
+                      (1, 64, 200, "STRICT", False, 200, True),
+                      # round 6: BASELINE config[4] at full size (1 600 strict visits, NN batch 64) and a CONSTANT-mode
+                      # search (early stop after every descent, mcts/time_manager.py) on a mid-game position
+                      (2, 64, 1600, "STRICT", False, 0, False),
+                      (3, 64, 400, "CONSTANT", False, 100, True)]
         gumbel_cases = [(1, 16, 0, True), (2, 100, 150, True)]
 
     for seed, batch, visits, mode, cgos, ply, superko in puct_cases:

@@ -2,7 +2,10 @@
 modules on the CPU in fp32: nn/network/dual_net.py + nn/loss.py + torch.optim.SGD as
 nn/learn.py:333-376 wires them (without autocast - the CPU has no fp16 path).
 
-    python tools/gen_golden_train.py        # needs /root/reference; writes tests/golden/train_s9.npz
+    python tools/gen_golden_train.py        # needs /root/reference; writes tests/golden/train_s9.npz and train_s19.npz
+
+The reference's DualNet takes the board size as a constructor argument (nn/network/dual_net.py:17), so 19x19 needs no
+scratch copy of the reference here (batch 16 at 19x19: the fixture stays small, the step is the same code).
 
 Inputs are rebuilt from seeds by `make_case` (numpy RandomState, portable), so the fixture holds
 outputs only: per-step losses, a 48-value sample of every parameter after every step, and the
@@ -19,10 +22,12 @@ sys.path.insert(0, ROOT)
 from tamago_amd.nn.network.dual_net import state_dict_keys  # noqa: E402
 
 STEPS, BATCH, SIZE = 3, 32, 9
+BATCH_BY_SIZE = {9: BATCH, 19: 16}
 
 
-def make_case(seed=20240):
-    rng = np.random.RandomState(seed)
+def make_case(seed=20240, SIZE=SIZE):
+    rng = np.random.RandomState(seed + (0 if SIZE == 9 else SIZE))
+    BATCH = BATCH_BY_SIZE[SIZE]
     state = {}
     for key, shape in state_dict_keys(SIZE):
         if key.endswith("running_mean"):
@@ -57,13 +62,18 @@ def sample_of(t):
 
 
 def main():
+    for size in (9, 19):
+        generate(size)
+
+
+def generate(SIZE):
     sys.path.insert(0, "/root/reference")
     from nn.network.dual_net import DualNet
     from nn.loss import calculate_policy_kld_loss, calculate_value_loss, calculate_policy_loss
     torch.set_num_threads(4)
     out = {}
     for mode in ("rl", "sl"):
-        state, batches = make_case()
+        state, batches = make_case(SIZE=SIZE)
         net = DualNet(torch.device("cpu"), SIZE)
         full = dict(net.state_dict())
         full.update(state)
@@ -104,7 +114,7 @@ def main():
             pe, ve = net.forward(torch.tensor(batches[0][0]))
         out[f"{mode}_eval_policy"] = pe.numpy()
         out[f"{mode}_eval_value"] = ve.numpy()
-    path = os.path.join(ROOT, "tests", "golden", "train_s9.npz")
+    path = os.path.join(ROOT, "tests", "golden", f"train_s{SIZE}.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes", out["rl_losses"], out["sl_losses"])
 
