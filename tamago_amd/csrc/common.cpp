@@ -1,6 +1,8 @@
 // Library-level entry points of libtamago_hip.so: error reporting and device queries.
 #include "common.h"
 
+#include <cstdlib>
+
 namespace tg {
 
 std::string &last_error() {
@@ -16,6 +18,14 @@ int fail(int code, const char *fmt, ...) {
     va_end(ap);
     last_error() = buf;
     return code;
+}
+
+const char *knob(const char *name) {
+    static const bool enabled = [] {
+        const char *v = getenv("TG_DEBUG_KNOBS");
+        return v && atoi(v) != 0;
+    }();
+    return enabled ? getenv(name) : nullptr;
 }
 
 }  // namespace tg

@@ -14,6 +14,12 @@ namespace tg {
 std::string &last_error();
 int fail(int code, const char *fmt, ...);
 
+// Debug / experiment knobs (kernel-variant selectors, forced groupings, test hooks - INTEGRATION.md 2.6) are read through knob():
+// it returns the variable's value only when TG_DEBUG_KNOBS=1 is set in the process environment, nullptr otherwise, so a product
+// process ignores them (round 6).  The knobs a deployment may set - TG_FWD_ALGO, TG_HOST_THREADS, TG_SHARED_DEVICE,
+// TG_SP_TIMING - are read with getenv directly.
+const char *knob(const char *name);
+
 #define TG_HIP(expr)                                                                      \
     do {                                                                                  \
         hipError_t _e = (expr);                                                           \

@@ -227,11 +227,8 @@ struct tg_net {
     // > 0: the exact-fp32 kernel queued behind a split launch as its range guard takes at most this many workgroups.  Each
     // needs a CU to itself even to read a clear flag: with several streams sharing the device (self-play sub-groups) a
     // full-size guard launch waits for the other streams' forward passes to drain.  The rare real fallback is slower.
-    // (Both are set around a self-play move's sub-group launches - search.hip play_move_chain - by host threads that may SHARE
-    // this handle: atomics, and a user count so that one thread's release does not zero them under another's launches.)
-    std::atomic<int> guard_grid_cap{0};
-    std::atomic<int> forward_grid_cap{0};   // > 0: workgroups of a 9x9 split forward launch (CUs left to other streams' tree kernels)
-    std::atomic<int> cap_users{0};
+    // (Round 6: these caps are a property of the LAUNCH, not of the network - tg::launch_caps() below, set by the launching
+    // thread around a self-play move's sub-group launches; a handle shared by group threads carries no such state any more.)
     std::mutex scratch_mu;
     std::map<hipStream_t, float *> scratch_by_stream;
     std::map<hipStream_t, int *> flag_by_stream;      // f16 split kernel: range flag per launch stream
@@ -254,3 +251,18 @@ struct tg_net {
     size_t scratch_floats = 0;
 };
 
+namespace tg {
+// Per-launch grid caps of the forward family, owned by the launching THREAD (search.hip's play_move_chain scopes them around the
+// sub-group launches of one self-play move):
+//   guard   > 0: the exact-fp32 kernel queued behind a split launch as its range guard takes at most this many workgroups
+//   forward > 0: workgroups a forward launch may take (CUs left to other streams' tree kernels)
+struct LaunchCaps { int guard = 0, forward = 0; };
+LaunchCaps &launch_caps();
+struct LaunchCapsScope {
+    LaunchCaps saved;
+    LaunchCapsScope(int guard, int forward) : saved(launch_caps()) { launch_caps() = LaunchCaps{guard, forward}; }
+    ~LaunchCapsScope() { launch_caps() = saved; }
+    LaunchCapsScope(const LaunchCapsScope &) = delete;
+    LaunchCapsScope &operator=(const LaunchCapsScope &) = delete;
+};
+}  // namespace tg

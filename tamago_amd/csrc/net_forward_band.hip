@@ -480,7 +480,7 @@ int launch_band(tg_net *net, const float *planes, int batch, int want_logits, fl
     NetDev dev = net->dev;
     // TG_BAND_TEST_MUTE=b: band b keeps its sequence number to itself (tests/test_gpu_net.py: the bounded waits end the launch,
     // the exact kernel redoes the batch)
-    const char *mute_env = getenv("TG_BAND_TEST_MUTE");
+    const char *mute_env = tg::knob("TG_BAND_TEST_MUTE");
     const int mute_band = mute_env ? atoi(mute_env) : -1;
     {
         static_assert((size_t)C::SLOT_FLOATS == (size_t)2 * C::P * 64, "one slot = one workgroup's share of the scratch");
@@ -517,10 +517,10 @@ namespace tg {
 // bands per board the banded kernel would use for this batch (0: the batch is too large for it - every workgroup of a
 // launch must be resident at once - or TG_FWD_BANDS=0 switches it off; TG_FWD_BANDS=2 / 4 force a split)
 int band_count(const tg_net *net, int batch) {
-    const char *env = getenv("TG_FWD_BANDS");
+    const char *env = tg::knob("TG_FWD_BANDS");
     const int forced = env ? atoi(env) : -1;
     if (net->board_size != 19 || forced == 0) return 0;
-    if (net->forward_grid_cap > 0) return 0;               // CUs are held back for other streams' kernels
+    if (tg::launch_caps().forward > 0) return 0;               // CUs are held back for other streams' kernels
     // A device shared with other PROCESSES (more self-play shards than GPUs, TG_SINGLE_DEVICE): their kernels can keep bands
     // off the CUs for longer than the bounded waits - results stay right (the exact kernel redoes the batch) but every such
     // launch costs 0.1 s.  Announced (tg_net_set_shared_device) or found out (a first bounded wait gave up): stay on the
@@ -528,9 +528,9 @@ int band_count(const tg_net *net, int batch) {
     if (forced < 0 && (net->shared_device || (net->band_timeouts_host && *net->band_timeouts_host > 0))) return 0;
     // (Two banded launches whose workgroups do not all fit on the device could hold each other's missing bands off the CUs until
     // the bounded waits give up: launch_band lets a network's banded launches follow each other across streams.)  With the
-    // sub-group streams of a self-play move in flight (guard_grid_cap is set exactly then) a launch takes a quarter of the CUs
+    // sub-group streams of a self-play move in flight (tg::launch_caps().guard is set exactly then) a launch takes a quarter of the CUs
     // and leaves the rest to the other sub-groups' tree kernels.
-    const int cus = net->guard_grid_cap > 0 ? net->num_cus / 4 : net->num_cus;
+    const int cus = tg::launch_caps().guard > 0 ? net->num_cus / 4 : net->num_cus;
     if ((forced == 4 || forced < 0) && batch * 4 <= cus) return 4;
     if ((forced == 2 || forced == 4 || forced < 0) && batch * 2 <= cus) return 2;
     return 0;

@@ -466,7 +466,7 @@ int launch_split(tg_net *net, const float *planes, int batch, int want_logits, f
     const int groups = (batch + G - 1) / G;
     // TG_FWD_CUS=n: at most n workgroups (CUs) for the forward pass - leaves CUs to the tree kernels of another lock-step
     // group running on a second stream (the persistent workgroups of a full-width launch own every CU's LDS and registers)
-    static const int cu_cap = getenv("TG_FWD_CUS") ? atoi(getenv("TG_FWD_CUS")) : 0;
+    static const int cu_cap = tg::knob("TG_FWD_CUS") ? atoi(tg::knob("TG_FWD_CUS")) : 0;
     const int cus = cu_cap > 0 && cu_cap < net->num_cus ? cu_cap : net->num_cus;
     const int grid = groups < cus ? groups : cus;
     NetDev dev = net->dev;
@@ -632,7 +632,7 @@ int split_forward(tg_net *net, int group, const float *planes, int batch, int wa
     if (net->board_size == 19) return launch_split<19, 1, FmtF16>(net, planes, batch, want_logits, policy, value, overflow, stream);
     if (net->board_size != 9) return tg::fail(TG_ERR_ARG, "split forward: 9x9 and 19x19 only");
     if (group == 3) {
-        if (const char *env = getenv("TG_SPLIT_SPAN")) {              // tuning knob
+        if (const char *env = tg::knob("TG_SPLIT_SPAN")) {              // tuning knob
             const int q = atoi(env);
             if (q == 2) return launch_split<9, 3, FmtF16, 2>(net, planes, batch, want_logits, policy, value, overflow, stream);
             if (q == 3) return launch_split<9, 3, FmtF16, 3>(net, planes, batch, want_logits, policy, value, overflow, stream);

@@ -1,5 +1,5 @@
 // DualNet forward for gfx950: the residual tower as Winograd F(2,3) along ONE axis on split operands (round 4; its own file
-// since round 5 - the 2-D Winograd tower it grew out of is kept, unbuilt, under tools/experiments/kernels/).
+// since round 5 - the 2-D Winograd tower it grew out of is in the git history: commit 04640d1, tools/experiments/kernels/).
 //
 // net_forward_split.hip runs the fp32 3x3 convolutions on the 16-bit matrix pipe as three f16 products per fp32 product
 // (a = ah + al, w = wh + wl:  a w ~ ah wh + ah wl + al wh) and is bound by the MFMA count (857 per wave and layer for three
@@ -984,7 +984,7 @@ int launch_w1d(tg_net *net, const float *planes, int batch, int want_logits, flo
         TG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
     const int groups = (batch + G - 1) / G;
     int grid = groups < net->num_cus ? groups : net->num_cus;
-    if (const int cap = net->forward_grid_cap.load(); cap > 0 && grid > cap) grid = cap;
+    if (const int cap = tg::launch_caps().forward; cap > 0 && grid > cap) grid = cap;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTHR), C::LDS_BYTES, stream, net->dev, planes, batch, want_logits,
                        policy, value, overflow, group_bits);
     TG_HIP(hipGetLastError());

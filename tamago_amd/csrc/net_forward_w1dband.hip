@@ -1013,7 +1013,7 @@ namespace tg {
 // pairs of workgroups a launch of `batch` boards would use (0: TG_FWD_ALGO / a shared device keep it off - see w1dband_wanted)
 int w1dband_pairs(const tg_net *net, int batch) {
     int cus = net->num_cus;
-    if (const int fc = net->forward_grid_cap.load(); fc > 0 && fc < cus) cus = fc;   // (a self-play move's sub-groups: CUs left to the other streams' tree kernels)
+    if (const int fc = tg::launch_caps().forward; fc > 0 && fc < cus) cus = fc;   // (a self-play move's sub-groups: CUs left to the other streams' tree kernels)
     const int cap = cus / 2;
     int pairs = batch < cap ? batch : cap;
     if (pairs >= 8) pairs &= ~7;                           // partners on the same XCD (consecutive workgroups go round the eight)
@@ -1065,7 +1065,7 @@ int w1dband_forward(tg_net *net, const float *planes, int batch, int want_logits
     }
     // the sequence numbers start from zero in every launch
     TG_HIP(hipMemsetAsync(xmem, 0, xfloats * sizeof(float), stream));
-    if (getenv("TG_WB_TEST_MUTE")) TG_HIP(hipMemsetAsync(overflow + 1, 1, 1, stream));      // (tests: a non-zero second flag word mutes band 1)
+    if (tg::knob("TG_WB_TEST_MUTE")) TG_HIP(hipMemsetAsync(overflow + 1, 1, 1, stream));      // (tests: a non-zero second flag word mutes band 1)
     hipLaunchKernelGGL(kern, dim3(2 * pairs), dim3(C::NTHR), C::LDS_BYTES, stream, net->dev, planes, batch, feat, xmem, overflow, group_bits);
     TG_HIP(hipGetLastError());
     if (batch <= 512) {

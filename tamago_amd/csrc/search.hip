@@ -33,9 +33,9 @@
 #include "common.h"
 #include "legacy_stream.h"
 
-namespace tg {                                                        // net_forward.hip (tg_net::guard_grid_cap, forward_grid_cap)
-void net_caps_acquire(tg_net *net, int guard_cap, int forward_cap);
-void net_caps_release(tg_net *net);
+namespace tg {                                                        // net_forward.hip: per-thread grid caps of the forward launches
+struct LaunchCaps { int guard = 0, forward = 0; };
+LaunchCaps &launch_caps();
 }
 
 #include <sched.h>
@@ -1574,7 +1574,7 @@ int launch_mpipe_cfg(const SearchDev &dev, int max_leaves, float *planes, hipStr
 template <int S>
 int launch_mpipe(const SearchDev &dev, int max_leaves, float *planes, hipStream_t st) {
     // selectors * 100 + workers (TG_MPIPE_CFG: tuning knob).  9x9: 16 wavefronts; 19x19: a worker's board is 25 KB of LDS
-    static const int cfg = getenv("TG_MPIPE_CFG") ? atoi(getenv("TG_MPIPE_CFG")) : 0;
+    static const int cfg = tg::knob("TG_MPIPE_CFG") ? atoi(tg::knob("TG_MPIPE_CFG")) : 0;
     if constexpr (S == 9) {
         if (cfg == 404) return launch_mpipe_cfg<S, 4, 4>(dev, max_leaves, planes, st);
         if (cfg == 408) return launch_mpipe_cfg<S, 4, 8>(dev, max_leaves, planes, st);
@@ -3832,7 +3832,7 @@ int launch_split_cfg(tg_search *s, int max_leaves, float *planes, hipStream_t st
 template <int S>
 int launch_split(tg_search *s, int max_leaves, float *planes, hipStream_t st) {
     // node owners * 100 + workers (TG_SPLIT_CFG: tuning knob)
-    static const int cfg = getenv("TG_SPLIT_CFG") ? atoi(getenv("TG_SPLIT_CFG")) : 0;
+    static const int cfg = tg::knob("TG_SPLIT_CFG") ? atoi(tg::knob("TG_SPLIT_CFG")) : 0;
     if constexpr (S == 9) {
         // (16 waves: chooser + clerk + owners + allocator + shippers + the draw cursor when there are several worker workgroups)
         if (cfg == 616) return launch_split_cfg<S, 6, 16>(s, max_leaves, planes, st);
@@ -4178,14 +4178,16 @@ int tg_search_select_puct(tg_search *s, int max_leaves, float *planes_dev, int32
     // three wavefronts per tree (selector + two workers) cut the serial chain of a mini-batch:
     // 1.8x for one tree, still +0.4 % with 2048 trees per GPU (measured); TG_SELECT_SERIAL=1 keeps
     // the one-wavefront kernel (also used while the per-phase profile counters are on)
-    static const bool force_serial = getenv("TG_SELECT_SERIAL") != nullptr;
-    static const bool mpipe_prof = getenv("TG_MPIPE_PROF") != nullptr;     // phase counters of the multi-selector kernel
+    static const bool force_serial = tg::knob("TG_SELECT_SERIAL") != nullptr;
+    static const bool mpipe_prof = tg::knob("TG_MPIPE_PROF") != nullptr;     // phase counters of the multi-selector kernel
     const bool pipelined = !force_serial && (!s->dev.prof || mpipe_prof) && max_leaves <= kPipeMaxK;
     // few trees: the descents themselves are pipelined over four selector waves (+ four workers); with many
     // trees per CU the three-wave kernel keeps more trees resident
-    static const int mpipe_max_trees = getenv("TG_SELECT_MPIPE_TREES") ? atoi(getenv("TG_SELECT_MPIPE_TREES")) : 256;
+    static const int mpipe_max_trees = tg::knob("TG_SELECT_MPIPE_TREES") ? atoi(tg::knob("TG_SELECT_MPIPE_TREES")) : 256;
     // up to kXwMaxTrees trees: a second workgroup (on another CU) for the board work of every tree (TG_SELECT_SPLIT=0: off)
-    const bool split = !getenv("TG_SELECT_SPLIT") || atoi(getenv("TG_SELECT_SPLIT")) != 0;
+    // (TG_SHARED_DEVICE=1 - several processes on this GPU: a tree's three workgroups may not get resident together - turns it off, too)
+    static const bool shared_device = getenv("TG_SHARED_DEVICE") && atoi(getenv("TG_SHARED_DEVICE")) != 0;
+    const bool split = !shared_device && (!tg::knob("TG_SELECT_SPLIT") || atoi(tg::knob("TG_SELECT_SPLIT")) != 0);
     int split_rc = kSplitNoRoom;
 #ifdef TG_SPLIT_PROF
     const bool split_prof_ok = true;
@@ -4559,10 +4561,10 @@ static int draw_noise_impl(tg_search *s, double *noise_host, const uint8_t *skip
 static int launch_gumbel_select(tg_search *s, const SearchDev &D, const int32_t *nc_dev, const int32_t *mc_dev, const int32_t *off,
                                 int limit, float *planes_dev, hipStream_t st) {
     const int T = D.T;
-    static const bool force_serial = getenv("TG_SELECT_SERIAL") != nullptr;
+    static const bool force_serial = tg::knob("TG_SELECT_SERIAL") != nullptr;
     // workers per tree: two when the trees crowd the CUs (the three-wave workgroup fits next to a forward workgroup),
     // six when there are CUs to spare (TG_GUMBEL_WORKERS overrides)
-    static const int workers_env = getenv("TG_GUMBEL_WORKERS") ? atoi(getenv("TG_GUMBEL_WORKERS")) : 0;
+    static const int workers_env = tg::knob("TG_GUMBEL_WORKERS") ? atoi(tg::knob("TG_GUMBEL_WORKERS")) : 0;
     const int workers = workers_env ? workers_env : (s->dev.T <= 128 ? 6 : 2);
     const bool gpipe = s->S == 9 && !force_serial && limit <= kPipeMaxK / 2 && D.N <= (1 << 21);   // (paths as node << 10 | edge)
     if (gpipe && workers == 6)
@@ -5432,7 +5434,7 @@ int tg_selfplay_play_move(tg_selfplay *sp, tg_net *net, float *planes_dev, float
         return tg::fail(TG_ERR_ARG, "tg_selfplay_play_move: null argument");
     // TG_SP_CHAIN=0: the move decided on the host, three host round trips per move (kept for comparison; a handle stays
     // with the scheme of its first move)
-    if (!sp->chain_started && !sp->sync_started) sp->chained = !getenv("TG_SP_CHAIN") || atoi(getenv("TG_SP_CHAIN")) != 0;
+    if (!sp->chain_started && !sp->sync_started) sp->chained = !tg::knob("TG_SP_CHAIN") || atoi(tg::knob("TG_SP_CHAIN")) != 0;
     if (sp->chained) return play_move_chain(sp, net, planes_dev, policy_dev, value_dev, stream, finished_host, stats_host);
     sp->sync_started = true;
     return play_move_sync(sp, net, planes_dev, policy_dev, value_dev, stream, finished_host, stats_host);
@@ -5512,7 +5514,7 @@ static int launch_phases_subgroups(tg_selfplay *sp, tg_net *net, int n_phases, i
             const int64_t count = counts[ph][g];
             if (count == 0) continue;
             hipStream_t sg = g == 0 ? st : sp->sub_stream[g - 1];
-            static const bool stagger = getenv("TG_SP_STAGGER") && atoi(getenv("TG_SP_STAGGER")) != 0;   // (measured: no gain at 16 boards, -3 % at 24 - the streams fall out of step by themselves)
+            static const bool stagger = tg::knob("TG_SP_STAGGER") && atoi(tg::knob("TG_SP_STAGGER")) != 0;   // (measured: no gain at 16 boards, -3 % at 24 - the streams fall out of step by themselves)
             if (stagger && launched[g] == 0 && last_started >= 0) TG_HIP(hipStreamWaitEvent(sg, sp->ev_first_sel[last_started], 0));
             if (launched[g] == 1 && any_phase) TG_HIP(hipStreamWaitEvent(sg, s->ev_rng[s->rng_active], 0));   // second part of the window
             const SearchDev D = sub_dev(s, tb[g], tb[g + 1] - tb[g]);
@@ -5617,7 +5619,7 @@ static int play_move_chain(tg_selfplay *sp, tg_net *net, float *planes_dev, floa
     lap(3);
     bool any_phase = false;
     // sub-groups (TG_SP_SUBGROUPS overrides; 1 = the whole lock-step group at once; an observer sees whole phases)
-    const int sub_env = getenv("TG_SP_SUBGROUPS") ? atoi(getenv("TG_SP_SUBGROUPS")) : 0;       // (read per call: tests toggle it)
+    const int sub_env = tg::knob("TG_SP_SUBGROUPS") ? atoi(tg::knob("TG_SP_SUBGROUPS")) : 0;       // (read per call: tests toggle it)
     // measured (tools/bench_selfplay.py, 400 simulations, leaf evaluations/s, one group -> sub-groups): 4 boards 1.06 -> 1.20 M
     // (2), 8: 1.71 -> 1.86 M (2), 16: 2.49 -> 2.84 M (3), 24: 3.00 -> 3.30 M (4); from 32 boards on a sub-group's forward pass
     // needs every CU or comes in launches too small to be efficient (32 boards: 3.26 M whole, 2.95 M in six)
@@ -5631,13 +5633,14 @@ static int play_move_chain(tg_selfplay *sp, tg_net *net, float *planes_dev, floa
     else if (T > 96 && T <= 224) { G = 4; fwd_cap = s->num_cus - 32; }
     else if (T > 224 && T <= 384) { G = 2; fwd_cap = s->num_cus - 32; }     // (256 boards, one-axis forward kernel: 6.07 -> 6.30 M; 512: level)
     if (sub_env > 0) { G = sub_env; fwd_cap = 0; }
-    if (getenv("TG_SP_FWD_CAP")) fwd_cap = atoi(getenv("TG_SP_FWD_CAP"));
+    if (tg::knob("TG_SP_FWD_CAP")) fwd_cap = atoi(tg::knob("TG_SP_FWD_CAP"));
     G = std::max(1, std::min(std::min(G, (int)tg_selfplay::kMaxSub), T));
     if (sp->observer || n_phases == 0) G = 1;
     if (G > 1) {
-        tg::net_caps_acquire(net, 16, fwd_cap > 0 ? fwd_cap : 0);      // (see tg_net::guard_grid_cap; the handle may be shared by group threads)
+        const tg::LaunchCaps saved = tg::launch_caps();                // (caps belong to this thread's launches, net_device.h)
+        tg::launch_caps() = tg::LaunchCaps{16, fwd_cap > 0 ? fwd_cap : 0};
         rc = launch_phases_subgroups(sp, net, n_phases, G, planes_dev, policy_dev, value_dev, st, leaves, any_phase);
-        tg::net_caps_release(net);
+        tg::launch_caps() = saved;
         if (rc) return rc;
     }
     for (int ph = 0; ph < n_phases && G == 1; ++ph) {

@@ -305,8 +305,10 @@ class SearchEngine:
         """puct_chain needs the library's streams (one window for the whole search), the device evaluator (the forward pass is
         queued by the library) and a pool that holds the whole search without growing (the reference doubles its node list
         between mini-batches, mcts/tree.py:254-258: that stays there)."""
-        return (not self.host_streams) and isinstance(self.evaluator, DeviceEvaluator) and \
-            self.node_bound + total_leaves <= self.N
+        # (exactly DeviceEvaluator: the chained forward passes are launched by the library on the network handle and never go
+        # through evaluator.__call__ - a subclass that wraps the forward pass keeps the per-mini-batch loop)
+        return total_leaves > 0 and (not self.host_streams) and type(self.evaluator) is DeviceEvaluator and \
+            hasattr(self.evaluator.network, "handle") and self.node_bound + total_leaves <= self.N
 
     def puct_select(self, leaves: int):
         """The selection half of puct_batch: afterwards the device queue holds `leaves` leaves per

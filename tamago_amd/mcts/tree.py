@@ -157,7 +157,7 @@ class MCTSTree:
         # or backed up, and the printed visit counts do not include them
         late_analysis = bool(analysis_query) and analysis_query.get("interval", 0) == 0
         pending = False
-        if time_manager.mode == TimeControl.STRICT_PLAYOUT and not analysis_query and engine.can_chain(threshold):
+        if threshold > 0 and time_manager.mode == TimeControl.STRICT_PLAYOUT and not analysis_query and engine.can_chain(threshold):
             # nothing between the mini-batches depends on their results (no early stop, the 10 000 s limit never ends it): queue them all
             batches = [self.batch_size] * (threshold // self.batch_size)
             if threshold % self.batch_size:

@@ -361,7 +361,7 @@ def train_on_gpu(program_dir: str, board_size: int, batch_size: int, epochs: int
                 iteration += 1
             print_learning_process(hip.take_losses(), epoch, data_index, iteration, started)
 
-        sums = torch.zeros(3, dtype=torch.float64)
+        sums = torch.zeros(3, dtype=torch.float64, device=device)       # accumulated on the device, read once per epoch
         test_iteration = 0
         started = time.time()
         evaluator.load_state_dict(hip.state_dict())
@@ -371,11 +371,12 @@ def train_on_gpu(program_dir: str, board_size: int, batch_size: int, epochs: int
                 prob, vprob = evaluator.forward_device(planes[i:i + batch_size].contiguous())
                 policy_loss = calculate_policy_loss(prob, policies[i:i + batch_size])
                 target = values[i:i + batch_size].long()
-                value_loss = -torch.log(vprob.gather(1, target[:, None])[:, 0])      # = cross entropy of the value logits
+                # = cross entropy of the value logits; a probability that underflowed to 0 must not turn the epoch's sum into inf
+                value_loss = -torch.log(vprob.gather(1, target[:, None])[:, 0].clamp_min(1e-38))
                 loss = (policy_loss + SL_VALUE_WEIGHT * value_loss).mean()
-                sums += torch.stack([loss, policy_loss.mean(), value_loss.mean()]).double().cpu()
+                sums += torch.stack([loss, policy_loss.mean(), value_loss.mean()]).double()
                 test_iteration += 1
-        total = sums.tolist()
+        total = sums.cpu().tolist()
         test_loss = {"loss": total[0], "policy": total[1], "value": total[2]}
         n = max(test_iteration, 1)
         print(f"Test {epoch} : loss = {total[0] / n:6f}, time = {time.time() - started:3f} seconds.",

@@ -145,7 +145,8 @@ def run_shard(args, rank: int, world: int, local_rank: int, record_dir: str) -> 
     if shared:
         # several shards share a device: the three-workgroups-per-tree selection kernel needs all of a tree's workgroups
         # resident at once, which another shard's kernels can prevent - keep to the one-workgroup kernels
-        os.environ.setdefault("TG_SELECT_SPLIT", "0")
+        # (TG_SHARED_DEVICE is the product switch for both this and the 19x19 pair kernel; read when the handles are created)
+        os.environ.setdefault("TG_SHARED_DEVICE", "1")
     cores = pin_host_threads(local_rank, local_world, device_index)
     torch.cuda.set_device(device_index)
     network = load_network(model_file_path=args.model, use_gpu=args.use_gpu, board_size=args.size,

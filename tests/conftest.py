@@ -9,6 +9,10 @@ if REPO not in sys.path:
 
 GOLDEN = os.path.join(REPO, "tests", "golden")
 
+# the library reads its kernel-variant / grouping / test-hook knobs (TG_SELECT_*, TG_SP_*, TG_FWD_BANDS, TG_*_TEST_MUTE ...) only
+# in a process that asks for them (csrc/common.h tg::knob); the tests compare those variants, so they do
+os.environ.setdefault("TG_DEBUG_KNOBS", "1")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

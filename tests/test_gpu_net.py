@@ -125,7 +125,7 @@ def test_every_tower_algorithm_matches_the_oracle(algo, size, monkeypatch):
     at both sizes; 19x19: one board per workgroup, residual image in an L2-resident scratch; w1d = Winograd F(2,3) along
     x only on the same operand pieces, the 9x9 default; w1dband = the same tower at 19x19, a board over two workgroups, the
     19x19 default since round 5).  All must agree with the oracle at every workgroup shape.
-    (Round 5: the two-waves-per-SIMD and 2-D Winograd kernels, measured slower, left the library - tools/experiments/kernels/.)"""
+    (Round 5: the two-waves-per-SIMD and 2-D Winograd kernels, measured slower, left the library; git history, commit 04640d1.)"""
     from oracle.net import OracleNet, make_state_dict
     monkeypatch.setenv("TG_FWD_ALGO", algo)
     sd = make_state_dict(size, 7, 1.5)
