@@ -226,25 +226,30 @@ int tg_search_read_positions(tg_search *s, uint8_t *cells_host, int32_t *moves_h
  * stream_state: generator state after everything the tree has consumed so far (hand it back with
  *   np.random.set_state(('MT19937', key, pos, 0, 0.0))).
  * feed_streams: make `need` draws per tree available to the next root / select launch (no-op
- *   while the uploaded window still covers `need` for every tree, unless force != 0); staging is
- *   pinned and the upload overlaps running kernels.
+ *   while the generated window still covers `need` for every tree, unless force != 0); the window is
+ *   generated by a kernel on a stream of the library's own and overlaps running kernels.
  * advance_streams: after a root / select launch - wait for it, move every stream by what its tree
  *   consumed (optionally reported in consumed_host [T]).
- * draw_noise: set_gumbel_noise for every root from the next A draws of each stream (uploaded
- *   like tg_search_set_noise; copy returned in noise_host [T][A] unless NULL). */
+ * draw_noise: set_gumbel_noise for every root from the next A draws of each stream (generated on the
+ *   device, ordered like tg_search_set_noise's upload; copy returned in noise_host [T][A] unless NULL). */
 int tg_search_seed_stream(tg_search *s, int tree, const uint32_t *mt_key, int mt_pos);
 int tg_search_stream_state(tg_search *s, int tree, uint32_t *mt_key_out, int *mt_pos_out);
 int tg_search_feed_streams(tg_search *s, size_t need, int force);
 int tg_search_advance_streams(tg_search *s, int64_t *consumed_host);
 int tg_search_draw_noise(tg_search *s, double *noise_host);
-/* Host-only helper (no device needed): the next n legacy standard_exponential draws of the
- * generator (mt_key, *mt_pos), updated in place - the arithmetic the streams above use. */
+/* Since round 6 the streams live ON THE DEVICE (csrc/legacy_rng_device.h: MT19937, random_sample and glibc's table-driven
+ * double-precision log - the build numpy's legacy distributions reach through libm on an FMA-capable x86-64 - restated
+ * operation by operation): windows and noise are generated there, the host only counts what was consumed.
+ * Host-only helpers (no device needed) that run the SAME restated arithmetic on the host, for the CPU tests:
+ *   tg_legacy_exponentials: the next n legacy standard_exponential draws of the generator (mt_key, *mt_pos), updated in place;
+ *   tg_glibc_log: out[i] = log(x[i]) (positive normal arguments) - held against Python's math.log (= libm) bit for bit. */
 int tg_legacy_exponentials(uint32_t *mt_key, int *mt_pos, size_t n, double *out);
-/* Host-only: what a search does to a library-owned stream - per step stage steps[i] + slack draws, consume steps[i] - and the
- * generator state at the logical position afterwards (what tg_search_stream_state hands back to numpy after a search:
- * mcts/tree.py leaves np.random where the search left it), plus the next n_next staged draws.  For tests. */
-int tg_legacy_stream_walk(const uint32_t *mt_key, int mt_pos, const int64_t *steps, int n_steps, int64_t slack,
-                          uint32_t *mt_key_out, int *mt_pos_out, double *next_draws_out, int n_next);
+int tg_glibc_log(const double *x, size_t n, double *out);
+/* Test hooks of the device streams (tests/test_gpu_rng.py): read columns [first, first + count) of tree `tree`'s row of the
+ * most recently generated window; walk the streams as a search would - per step a window of steps[i] + slack draws, whole
+ * (part 0) or in pieces of `part` draws, steps[i] of which count as consumed - without running a search. */
+int tg_search_debug_read_window(tg_search *s, int tree, size_t first, size_t count, double *out_host);
+int tg_search_debug_stream_walk(tg_search *s, const int64_t *steps, int n_steps, int64_t slack, int64_t part);
 /* Gumbel root noise, float64 [T][A] (node.py:275-278 set_gumbel_noise), to be set after the
  * root evaluation of a Gumbel move. */
 int tg_search_set_noise(tg_search *s, const double *noise_host);
@@ -340,6 +345,15 @@ int tg_selfplay_finish_move(tg_selfplay *sp, int32_t *moves_host, int32_t *finis
  * TG_SP_FWD_CAP=n override the grouping.  With an observer the boards stay in one group. */
 int tg_selfplay_play_move(tg_selfplay *sp, tg_net *net, float *planes_dev, float *policy_dev,
                           float *value_dev, void *stream, int32_t *finished_host, int64_t *stats_host);
+/* The two halves of a chained tg_selfplay_play_move, for a caller that keeps several handles (lanes of one shard: each its own
+ * tg_search, buffers and stream) in flight from one host thread - selfplay/worker.py:46-90 plays its games one after the other;
+ * games are independent, so lanes need not be on the same move.  `begin` queues the whole move (phases, decision, the moves
+ * played, next root evaluation) on `stream` and returns; `end` waits for that move's root records, does the bookkeeping
+ * (records, finished games, SGF) and fills finished_host[T] / stats_host[3] as tg_selfplay_play_move does.  Between a handle's
+ * `begin` and `end` only other handles may be driven; slots are refilled (tg_selfplay_start_game) after `end`.  The buffers
+ * belong to the library until `end` returns.  Not with an observer or TG_SP_CHAIN=0 (TG_ERR_STATE). */
+int tg_selfplay_move_begin(tg_selfplay *sp, tg_net *net, float *planes_dev, float *policy_dev, float *value_dev, void *stream);
+int tg_selfplay_move_end(tg_selfplay *sp, int32_t *finished_host, int64_t *stats_host);
 /* Audit hook of tg_selfplay_play_move (parity tests replay what the one-call path evaluated into the CPU oracle,
  * mini-batch by mini-batch: mcts/tree.py:273-315 process_mini_batch is where the reference would be tapped).
  * The observer is called on the calling thread

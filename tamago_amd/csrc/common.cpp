@@ -51,41 +51,25 @@ int tg_device_count(int *count) {
 }  // extern "C"
 
 #include "legacy_stream.h"
+#include "legacy_rng_device.h"
 
+// The arithmetic of the device-resident legacy streams on the HOST (same functions: MT19937, random_sample, the restated glibc
+// log), so that the CPU tests can hold it against numpy and the reference-recorded draws without a GPU.
 extern "C" int tg_legacy_exponentials(uint32_t *mt_key, int *mt_pos, size_t n, double *out) {
     if (!mt_key || !mt_pos || (!out && n)) return tg::fail(TG_ERR_ARG, "tg_legacy_exponentials: null argument");
     if (*mt_pos < 0 || *mt_pos > 624) return tg::fail(TG_ERR_ARG, "tg_legacy_exponentials: MT19937 position outside [0, 624]");
     tg::Mt19937 g;
     std::memcpy(g.key, mt_key, sizeof(g.key));
     g.pos = *mt_pos;
-    for (size_t i = 0; i < n; ++i) out[i] = -std::log(1.0 - g.next_double());
+    for (size_t i = 0; i < n; ++i) out[i] = -tg_rng::glibc_log(1.0 - g.next_double(), tg_rng::kLogTabHost);
     std::memcpy(mt_key, g.key, sizeof(g.key));
     *mt_pos = g.pos;
     return TG_OK;
 }
 
-// Host-only walk of a LegacyStream (what a search does to it): per step a window is staged (the step's draws + `slack`) and the
-// step's draws are consumed; afterwards the generator state at the logical position is handed back - from the nearest snapshot,
-// which is what this entry point lets the CPU tests check against numpy (tests/test_host_rng.py).
-extern "C" int tg_legacy_stream_walk(const uint32_t *mt_key, int mt_pos, const int64_t *steps, int n_steps, int64_t slack,
-                                     uint32_t *mt_key_out, int *mt_pos_out, double *next_draws_out, int n_next) {
-    if (!mt_key || !steps || !mt_key_out || !mt_pos_out || n_steps < 0 || slack < 0 || (n_next > 0 && !next_draws_out))
-        return tg::fail(TG_ERR_ARG, "tg_legacy_stream_walk: bad argument");
-    if (mt_pos < 0 || mt_pos > 624) return tg::fail(TG_ERR_ARG, "tg_legacy_stream_walk: MT19937 position outside [0, 624]");
-    tg::LegacyStream ls;
-    ls.seed(mt_key, mt_pos);
-    for (int i = 0; i < n_steps; ++i) {
-        if (steps[i] < 0) return tg::fail(TG_ERR_ARG, "tg_legacy_stream_walk: negative step");
-        ls.ensure((size_t)(steps[i] + slack));
-        ls.consume((size_t)steps[i]);
-    }
-    const tg::Mt19937 &g = ls.state_at_position();
-    std::memcpy(mt_key_out, g.key, sizeof(g.key));
-    *mt_pos_out = g.pos;
-    if (n_next > 0) {                                   // the staged draws at the position (what the device would be sent next)
-        ls.ensure((size_t)n_next);
-        std::memcpy(next_draws_out, ls.data(), (size_t)n_next * sizeof(double));
-    }
+// out[i] = the restated glibc log of x[i] (positive, normal arguments - what the streams feed it)
+extern "C" int tg_glibc_log(const double *x, size_t n, double *out) {
+    if ((!x || !out) && n) return tg::fail(TG_ERR_ARG, "tg_glibc_log: null argument");
+    for (size_t i = 0; i < n; ++i) out[i] = tg_rng::glibc_log(x[i], tg_rng::kLogTabHost);
     return TG_OK;
 }
-

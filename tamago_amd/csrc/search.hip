@@ -28,10 +28,10 @@
 //     mcts/tree.py:297-313);
 //   * PUCB is float64 with IEEE division and sqrt; this file is compiled with
 //     -ffp-contract=off so no FMA is formed behind the source's back;
-//   * the random draws come from the host side of the library (libm log; csrc/legacy_stream.h) or from the
-//     caller through tg_search_set_rng.
+//   * the random draws are generated on the device (csrc/legacy_rng_device.h: MT19937 + glibc's log restated) or come from
+//     the caller through tg_search_set_rng.
 #include "common.h"
-#include "legacy_stream.h"
+#include "legacy_rng_device.h"
 
 namespace tg {                                                        // net_forward.hip: per-thread grid caps of the forward launches
 struct LaunchCaps { int guard = 0, forward = 0; };
@@ -3574,10 +3574,7 @@ struct tg_search {
     tg_search_config cfg{};
     SearchDev dev{};
     int num_cus = 256;
-    // few trees: the draws of the NEXT window are generated by a background task while the GPU works on the current one
-    // (tg_search_feed_streams); everything that touches `streams` waits for it first (wait_prefill)
-    std::future<void> prefill;
-    bool prefill_enabled = true;           // (the self-play path tops its streams up itself, in the shadow of the phase kernels)
+    bool prefill_enabled = true;           // (unused since the streams live on the device; kept for the callers that set it)
     int split_per_cu = -1;                 // resident select_puct_split_kernel workgroups per CU (queried at the first launch)
     std::vector<void *> allocs;
     int S = 0, W = 0, NC = 0, P = 0, A = 0, HMAX = 0;
@@ -3616,12 +3613,32 @@ struct tg_search {
     int rng_active = 0, rng_pending = -1;
     int64_t rng_pending_cap = 0;
     bool sel_recorded = false;
-    // library-owned legacy streams (tg_search_seed_stream): one per tree, windows are generated,
-    // staged in pinned memory and uploaded without any host-language involvement
-    std::vector<tg::LegacyStream> streams;
-    double *stage[2] = {nullptr, nullptr};        // pinned, paired with rng_buf[]
-    size_t stage_cap[2] = {0, 0};
-    bool stage_busy[2] = {false, false};          // ev_rng[b] guards a copy out of stage[b]
+    // Library-owned legacy streams (tg_search_seed_stream), device-resident since round 6 (csrc/legacy_rng_device.h): per tree
+    // the MT19937 state at the stream's logical position (`mt_base`) and behind the last generated piece of a window
+    // (`mt_cont`), [T][625] words each; windows and Gumbel noise are GENERATED by rng_fill_kernel on `copy_stream`.  The host
+    // keeps, per tree, only what it was seeded with until that is uploaded and the draws consumed since the device state was
+    // last brought up to date (`lag`, from the cursor read-backs) - handed to the next generation launch through a ring of
+    // host-mapped arrays.
+    struct DevStream {
+        bool seeded = false, dirty = false;
+        uint32_t key[624];
+        int pos = 624;
+        int64_t lag = 0;
+    };
+    std::vector<DevStream> streams;
+    uint32_t *mt_base = nullptr, *mt_cont = nullptr;
+    uint32_t *seed_pin = nullptr;                 // pinned [T][625]: seeds on their way up, one state on its way down
+    hipEvent_t seed_ev = nullptr;
+    bool seed_ev_used = false;
+    static constexpr int kLagRing = 8;
+    long long *lag_pin = nullptr, *lag_pin_dev = nullptr;          // host-mapped [kLagRing][T]
+    unsigned char *skip_pin = nullptr, *skip_pin_dev = nullptr;    // host-mapped [kLagRing][T]
+    hipEvent_t lag_ev[kLagRing] = {};
+    bool lag_ev_used[kLagRing] = {};
+    unsigned lag_seq = 0;
+    double *noise_back = nullptr;                 // pinned [T][A]: the device-drawn root noise on its way to noise_host
+    hipEvent_t noise_back_ev = nullptr, noise_order_ev = nullptr;
+    bool noise_back_pending = false;
     int64_t win_cap = 0, win_left = 0;            // active / pending window: size, unread tail
     // split upload (feed_streams_impl / feed_streams_rest): buffer, columns already up, columns still to come; the next
     // selection launch must wait for the second part's event
@@ -3921,7 +3938,6 @@ int tg_search_create(const tg_search_config *cfg, tg_search **out) {
 
 int tg_search_destroy(tg_search *s) {
     if (!s) return TG_OK;
-    if (s->prefill.valid()) s->prefill.wait();          // (the background generator works on s->streams)
     (void)hipSetDevice(s->cfg.device);
     if (s->stream_known) (void)hipStreamSynchronize(s->last_stream);      // (nullptr: the null stream)
     if (s->noise_pin) {
@@ -3952,8 +3968,16 @@ int tg_search_destroy(tg_search *s) {
     }
     if (s->ev_sel) (void)hipEventDestroy(s->ev_sel);
     if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
-    for (int b = 0; b < 2; ++b)
-        if (s->stage[b]) (void)hipHostFree(s->stage[b]);
+    if (s->mt_base) (void)hipFree(s->mt_base);
+    if (s->mt_cont) (void)hipFree(s->mt_cont);
+    if (s->seed_pin) (void)hipHostFree(s->seed_pin);
+    if (s->seed_ev) (void)hipEventDestroy(s->seed_ev);
+    if (s->lag_pin) (void)hipHostFree(s->lag_pin);
+    if (s->skip_pin) (void)hipHostFree(s->skip_pin);
+    for (hipEvent_t e : s->lag_ev) if (e) (void)hipEventDestroy(e);
+    if (s->noise_back) (void)hipHostFree(s->noise_back);
+    if (s->noise_back_ev) (void)hipEventDestroy(s->noise_back_ev);
+    if (s->noise_order_ev) (void)hipEventDestroy(s->noise_order_ev);
     delete s;
     return TG_OK;
 }
@@ -4291,6 +4315,7 @@ int tg_search_set_noise(tg_search *s, const double *noise_host) {
     if (!s || !noise_host) return tg::fail(TG_ERR_ARG, "tg_search_set_noise: null argument");
     const size_t n = (size_t)s->dev.T * s->A;
     s->noise_host.assign(noise_host, noise_host + n);
+    s->noise_back_pending = false;                 // (a device-drawn noise still on its way back is superseded)
     if (!s->stream_known) {                        // no launch stream yet: the null stream, synchronously
         TG_HIP(hipDeviceSynchronize());
         TG_HIP(hipMemcpy(s->dev.noise, noise_host, n * sizeof(double), hipMemcpyHostToDevice));
@@ -4311,60 +4336,150 @@ int tg_search_set_noise(tg_search *s, const double *noise_host) {
     return TG_OK;
 }
 
-// ---- library-owned legacy streams ---------------------------------------------------------
+// ---- library-owned legacy streams, device-resident (csrc/legacy_rng_device.h) ---------------
 
-static void wait_prefill(tg_search *s) {
-    if (s && s->prefill.valid()) s->prefill.get();
+static void wait_prefill(tg_search *) {}          // (round 5's host-side background generator: nothing to wait for any more)
+
+static int rng_alloc(tg_search *s) {
+    if (s->mt_base) return TG_OK;
+    const size_t T = (size_t)s->dev.T, words = T * tg_rng::kStateWords;
+    TG_HIP(hipMalloc(reinterpret_cast<void **>(&s->mt_base), words * sizeof(uint32_t)));
+    TG_HIP(hipMalloc(reinterpret_cast<void **>(&s->mt_cont), words * sizeof(uint32_t)));
+    TG_HIP(hipMemset(s->mt_base, 0, words * sizeof(uint32_t)));
+    TG_HIP(hipMemset(s->mt_cont, 0, words * sizeof(uint32_t)));
+    TG_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->seed_pin), words * sizeof(uint32_t), hipHostMallocDefault));
+    TG_HIP(hipEventCreateWithFlags(&s->seed_ev, hipEventDisableTiming));
+    TG_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->lag_pin), tg_search::kLagRing * T * sizeof(long long), hipHostMallocMapped));
+    TG_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&s->lag_pin_dev), s->lag_pin, 0));
+    TG_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->skip_pin), tg_search::kLagRing * T, hipHostMallocMapped));
+    TG_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&s->skip_pin_dev), s->skip_pin, 0));
+    for (hipEvent_t &e : s->lag_ev) TG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    TG_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->noise_back), T * (size_t)s->A * sizeof(double), hipHostMallocDefault));
+    TG_HIP(hipEventCreateWithFlags(&s->noise_back_ev, hipEventDisableTiming));
+    TG_HIP(hipEventCreateWithFlags(&s->noise_order_ev, hipEventDisableTiming));
+    return TG_OK;
+}
+
+// seeds that have not gone up yet: staged in pinned memory, copied on the generation stream ahead of the launch that needs them
+static int rng_sync_seeds(tg_search *s) {
+    const int T = s->dev.T;
+    bool any = false;
+    for (int t = 0; t < T && !any; ++t) any = s->streams[t].dirty;
+    if (!any) return TG_OK;
+    if (s->seed_ev_used) TG_HIP(hipEventSynchronize(s->seed_ev));           // (the previous use of the staging rows)
+    int t = 0;
+    while (t < T) {
+        if (!s->streams[t].dirty) { ++t; continue; }
+        int t1 = t;
+        for (; t1 < T && s->streams[t1].dirty; ++t1) {
+            uint32_t *row = s->seed_pin + (size_t)t1 * tg_rng::kStateWords;
+            std::memcpy(row, s->streams[t1].key, sizeof(s->streams[t1].key));
+            row[tg_rng::kMtN] = (uint32_t)s->streams[t1].pos;
+            s->streams[t1].dirty = false;
+        }
+        const size_t o = (size_t)t * tg_rng::kStateWords, n = (size_t)(t1 - t) * tg_rng::kStateWords;
+        TG_HIP(hipMemcpyAsync(s->mt_base + o, s->seed_pin + o, n * sizeof(uint32_t), hipMemcpyHostToDevice, s->copy_stream));
+        t = t1;
+    }
+    TG_HIP(hipEventRecord(s->seed_ev, s->copy_stream));
+    s->seed_ev_used = true;
+    return TG_OK;
+}
+
+// The draws consumed since the device states were brought up to date, handed to the next generation launch: a slot of the
+// host-mapped ring (the launch reads it over the bus: T x 8 bytes).  skip[t] != 0: that tree takes no part (its lag stays here).
+static int rng_take_lag(tg_search *s, const uint8_t *skip, int *slot_out) {
+    const int T = s->dev.T;
+    const int slot = (int)(s->lag_seq++ % tg_search::kLagRing);
+    if (s->lag_ev_used[slot]) TG_HIP(hipEventSynchronize(s->lag_ev[slot]));     // (eight launches ago: long done)
+    long long *lag = s->lag_pin + (size_t)slot * T;
+    unsigned char *sk = s->skip_pin + (size_t)slot * T;
+    for (int t = 0; t < T; ++t) {
+        const bool out = skip && skip[t];
+        sk[t] = out ? 1 : 0;
+        lag[t] = out ? 0 : (long long)s->streams[t].lag;
+        if (!out) s->streams[t].lag = 0;
+    }
+    *slot_out = slot;
+    return TG_OK;
+}
+
+static int rng_launch(tg_search *s, const tg_rng::FillArgs &a, int slot) {
+    const int T = s->dev.T;
+    const long long blocks = a.count / 312 + 2;
+    int nw = T >= 512 ? 1 : T >= 64 ? 4 : 16;
+    if (blocks <= 3) nw = 1;
+    else if (blocks <= 10 && nw > 4) nw = 4;
+    if (nw == 1) hipLaunchKernelGGL(tg_rng::rng_fill_kernel<1>, dim3(T), dim3(64), 0, s->copy_stream, a);
+    else if (nw == 4) hipLaunchKernelGGL(tg_rng::rng_fill_kernel<4>, dim3(T), dim3(256), 0, s->copy_stream, a);
+    else hipLaunchKernelGGL(tg_rng::rng_fill_kernel<16>, dim3(T), dim3(1024), 0, s->copy_stream, a);
+    TG_HIP(hipGetLastError());
+    if (slot >= 0) {
+        TG_HIP(hipEventRecord(s->lag_ev[slot], s->copy_stream));
+        s->lag_ev_used[slot] = true;
+    }
+    return TG_OK;
 }
 
 int tg_search_seed_stream(tg_search *s, int tree, const uint32_t *mt_key, int mt_pos) {
     if (!s || !mt_key) return tg::fail(TG_ERR_ARG, "tg_search_seed_stream: null argument");
-    wait_prefill(s);
     if (tree < 0 || tree >= s->dev.T) return tg::fail(TG_ERR_ARG, "tg_search_seed_stream: tree %d out of range", tree);
     if (mt_pos < 0 || mt_pos > 624) return tg::fail(TG_ERR_ARG, "tg_search_seed_stream: MT19937 position %d outside [0, 624]", mt_pos);
+    TG_HIP(hipSetDevice(s->cfg.device));
+    if (int rc = rng_alloc(s)) return rc;
     if (s->streams.empty()) s->streams.resize(s->dev.T);
-    s->streams[tree].seed(mt_key, mt_pos);
-    s->win_left = 0;                               // the uploaded window belongs to the old stream
+    tg_search::DevStream &ds = s->streams[tree];
+    std::memcpy(ds.key, mt_key, sizeof(ds.key));
+    ds.pos = mt_pos;
+    ds.lag = 0;
+    ds.seeded = ds.dirty = true;
+    s->win_left = 0;                               // the generated window belongs to the old stream
     return TG_OK;
 }
 
 int tg_search_stream_state(tg_search *s, int tree, uint32_t *mt_key_out, int *mt_pos_out) {
     if (!s || !mt_key_out || !mt_pos_out) return tg::fail(TG_ERR_ARG, "tg_search_stream_state: null argument");
-    wait_prefill(s);
     if (tree < 0 || tree >= s->dev.T || s->streams.empty() || !s->streams[tree].seeded)
         return tg::fail(TG_ERR_ARG, "tg_search_stream_state: tree %d has no stream", tree);
-    const tg::Mt19937 &g = s->streams[tree].state_at_position();
-    std::memcpy(mt_key_out, g.key, 624 * sizeof(uint32_t));
-    *mt_pos_out = g.pos;
+    tg_search::DevStream &ds = s->streams[tree];
+    if (ds.dirty && ds.lag == 0) {                 // never used since it was seeded
+        std::memcpy(mt_key_out, ds.key, sizeof(ds.key));
+        *mt_pos_out = ds.pos;
+        return TG_OK;
+    }
+    // bring the device states up to date (a generation launch of zero draws commits the consumed ones), then read this tree's
+    int rc, slot = -1;
+    if ((rc = rng_sync_seeds(s)) || (rc = rng_take_lag(s, nullptr, &slot))) return rc;
+    tg_rng::FillArgs a{};
+    a.base = s->mt_base; a.cont = s->mt_cont; a.lag = s->lag_pin_dev + (size_t)slot * s->dev.T;
+    if ((rc = rng_launch(s, a, slot))) return rc;
+    if (s->seed_ev_used) TG_HIP(hipEventSynchronize(s->seed_ev));
+    uint32_t *row = s->seed_pin + (size_t)tree * tg_rng::kStateWords;
+    TG_HIP(hipMemcpyAsync(row, s->mt_base + (size_t)tree * tg_rng::kStateWords, tg_rng::kStateWords * sizeof(uint32_t),
+                          hipMemcpyDeviceToHost, s->copy_stream));
+    TG_HIP(hipStreamSynchronize(s->copy_stream));
+    std::memcpy(mt_key_out, row, 624 * sizeof(uint32_t));
+    *mt_pos_out = (int)row[tg_rng::kMtN];
     return TG_OK;
 }
 
-// Upload of a window in two parts (self-play: the window of a move's four phases is 1.7 MB at 16 boards and the GPU has
-// ~0.1 ms of root evaluation to cover its staging): feed_streams_impl(first > 0) stages and uploads the first `first`
-// draws of every tree's row only - enough for the first launch -, feed_streams_rest() the remaining columns while that
-// launch runs; the next selection launch waits for them (rng_rest_wait).
+// A window in parts (self-play: the window of a move's four phases is 1.7 MB at 16 boards; a chained PUCT search: one window
+// for all its mini-batches): feed_streams_impl(first > 0) generates the first `first` draws of every tree's row only - enough
+// for the first launch -, feed_streams_rest() / feed_streams_part() the remaining columns while that launch runs, each piece
+// going on from the generator state the piece before it left (`mt_cont`); the launches that need them wait for the event.
 static int feed_streams_impl(tg_search *s, size_t need, int force, size_t first);
 static int feed_streams_rest(tg_search *s);
-static void start_prefill(tg_search *s, size_t need) {
-    const int T = s->dev.T;
-    if (T > 16 || !s->prefill_enabled) return;
-    const size_t ahead = 2 * need;
-    s->prefill = std::async(std::launch::async, [s, T, ahead] {
-        for (int t = 0; t < T; ++t) s->streams[t].ensure(ahead);
-    });
-}
 
 int tg_search_feed_streams(tg_search *s, size_t need, int force) { return feed_streams_impl(s, need, force, 0); }
 
 static int feed_streams_impl(tg_search *s, size_t need, int force, size_t first) {
     if (!s) return tg::fail(TG_ERR_ARG, "tg_search_feed_streams: null argument");
     const int T = s->dev.T;
-    if (s->rng_rest_cols) {                        // (an earlier split upload was never completed: complete it first)
+    if (s->rng_rest_cols) {                        // (an earlier window in parts was never completed: complete it first)
         int rc = feed_streams_rest(s);
         if (rc) return rc;
     }
     if (s->streams.size() != (size_t)T) return tg::fail(TG_ERR_ARG, "tg_search_feed_streams: streams are not seeded");
-    wait_prefill(s);
     for (int t = 0; t < T; ++t)
         if (!s->streams[t].seeded) return tg::fail(TG_ERR_ARG, "tg_search_feed_streams: tree %d has no stream", t);
     if (need == 0 || (!force && s->win_left >= (int64_t)need)) return TG_OK;
@@ -4376,49 +4491,15 @@ static int feed_streams_impl(tg_search *s, size_t need, int force, size_t first)
         TG_HIP(hipMalloc(reinterpret_cast<void **>(&s->rng_buf[idx]), (size_t)T * need * sizeof(double)));
         s->rng_buf_cap[idx] = (int64_t)need;
     }
-    if (s->stage_busy[idx]) {                       // an earlier upload may still read this staging buffer
-        TG_HIP(hipEventSynchronize(s->ev_rng[idx]));
-        s->stage_busy[idx] = false;
-    }
-    if ((size_t)T * need > s->stage_cap[idx]) {
-        if (s->stage[idx]) (void)hipHostFree(s->stage[idx]);
-        s->stage[idx] = nullptr;
-        s->stage_cap[idx] = 0;
-        TG_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->stage[idx]), (size_t)T * need * sizeof(double), hipHostMallocDefault));
-        s->stage_cap[idx] = (size_t)T * need;
-    }
-    double *stage = s->stage[idx];
     const bool split = first > 0 && first < need;
     const size_t cols = split ? first : need;
-    static const bool feed_timing = getenv("TG_SP_TIMING") != nullptr;
-    auto clk = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double tf0 = feed_timing ? clk() : 0.0;
-    size_t generated = 0;
-    for (int t = 0; t < T && feed_timing; ++t) generated += s->streams[t].available() < need ? need - s->streams[t].available() : 0;
-    // (a split upload generates only what its first part carries: a stream that was re-seeded for this search - search_best_move
-    // hands numpy's state over per move, mcts/tree.py:49 - has nothing staged, and the draws of a whole search, ~80 k exponentials
-    // at 9x9, are 0.4 ms of MT19937 + log that the first selection launch need not wait for: feed_streams_rest generates the rest)
-    parallel_trees(T, [&](int t) {
-        tg::LegacyStream &ls = s->streams[t];
-        ls.ensure(cols);
-        std::memcpy(stage + (size_t)t * need, ls.data(), cols * sizeof(double));
-    });
-    const double tf1 = feed_timing ? clk() : 0.0;
-    if (split)
-        TG_HIP(hipMemcpy2DAsync(s->rng_buf[idx], need * sizeof(double), stage, need * sizeof(double), cols * sizeof(double), T,
-                                hipMemcpyHostToDevice, s->copy_stream));
-    else
-        TG_HIP(hipMemcpyAsync(s->rng_buf[idx], stage, (size_t)T * need * sizeof(double), hipMemcpyHostToDevice, s->copy_stream));
+    int rc, slot = -1;
+    if ((rc = rng_sync_seeds(s)) || (rc = rng_take_lag(s, nullptr, &slot))) return rc;
+    tg_rng::FillArgs a{};
+    a.base = s->mt_base; a.cont = s->mt_cont; a.lag = s->lag_pin_dev + (size_t)slot * T;
+    a.out = s->rng_buf[idx]; a.pitch = (long long)need; a.first = 0; a.count = (long long)cols;
+    if ((rc = rng_launch(s, a, slot))) return rc;
     TG_HIP(hipEventRecord(s->ev_rng[idx], s->copy_stream));
-    if (feed_timing) {
-        static double a_stage = 0, a_copy = 0, a_gen = 0;
-        static long calls = 0;
-        a_stage += tf1 - tf0; a_copy += clk() - tf1; a_gen += (double)generated;
-        if (++calls % 2000 == 0)
-            fprintf(stderr, "[feed timing, per call over %ld calls] generate + stage %.1f us (%.0f draws generated), enqueue copy %.1f us\n",
-                    calls, 1e6 * a_stage / calls, a_gen / calls, 1e6 * a_copy / calls);
-    }
-    s->stage_busy[idx] = true;
     s->rng_pending = idx;
     s->rng_pending_cap = (int64_t)need;
     s->win_cap = s->win_left = (int64_t)need;
@@ -4426,70 +4507,54 @@ static int feed_streams_impl(tg_search *s, size_t need, int force, size_t first)
     s->rng_rest_idx = idx;
     s->rng_rest_first = cols;
     s->rng_rest_cols = split ? need - cols : 0;
-    if (split) return TG_OK;                       // (the background generator starts behind the second part)
-    // Few trees (a single search tree: one host thread, the GPU idle while it generates): the next window starts at most
-    // `need` draws further on, so 2 x need draws staged now = nothing left to generate when it is asked for.  Measured on
-    // the one-tree legs: the ~21 k (9x9) / 23 k (19x19) exponentials of a mini-batch window are 80 - 100 us of MT19937 +
-    // log per mini-batch on the host thread that also has to queue the next launches.
-    start_prefill(s, need);
+    return TG_OK;
+}
+
+// columns [first, upto) of the window in parts, behind the piece before them
+static int feed_streams_piece(tg_search *s, size_t upto) {
+    const int idx = s->rng_rest_idx;
+    const size_t need = s->rng_rest_first + s->rng_rest_cols, first = s->rng_rest_first;
+    tg_rng::FillArgs a{};
+    a.base = s->mt_base; a.cont = s->mt_cont; a.from_cont = 1;
+    a.out = s->rng_buf[idx]; a.pitch = (long long)need; a.first = (long long)first; a.count = (long long)(upto - first);
+    if (int rc = rng_launch(s, a, -1)) return rc;
+    TG_HIP(hipEventRecord(s->ev_rng[idx], s->copy_stream));
+    s->rng_rest_first = upto;
+    s->rng_rest_cols = need - upto;
     return TG_OK;
 }
 
 static int feed_streams_rest(tg_search *s) {
     if (!s->rng_rest_cols) return TG_OK;
-    const int T = s->dev.T, idx = s->rng_rest_idx;
-    const size_t need = s->rng_rest_first + s->rng_rest_cols, first = s->rng_rest_first, cols = s->rng_rest_cols;
-    s->rng_rest_cols = 0;
-    wait_prefill(s);
-    double *stage = s->stage[idx];
-    parallel_trees(T, [&](int t) {                 // (nothing was consumed in between: the rows continue where part one stopped)
-        s->streams[t].ensure(need);
-        std::memcpy(stage + (size_t)t * need + first, s->streams[t].data() + first, cols * sizeof(double));
-    });
-    TG_HIP(hipMemcpy2DAsync(s->rng_buf[idx] + first, need * sizeof(double), stage + first, need * sizeof(double), cols * sizeof(double), T,
-                            hipMemcpyHostToDevice, s->copy_stream));
-    TG_HIP(hipEventRecord(s->ev_rng[idx], s->copy_stream));     // also the new guard of the staging buffer
+    if (int rc = feed_streams_piece(s, s->rng_rest_first + s->rng_rest_cols)) return rc;
     s->rng_rest_wait = true;                       // the next selection launch waits for this event
-    start_prefill(s, need);
     return TG_OK;
 }
 
-// A split upload continued piece by piece (tg_search_puct_chain): the columns up to `upto` of the window whose first part
-// feed_streams_impl sent - generated now -, and `st` waits for them.  The device cursor of a tree never passes the columns its
-// launched selections may consume (leaves x A each), so a launch only needs the pieces up to its own.
+// A window in parts continued piece by piece (tg_search_puct_chain): the columns up to `upto`, and `st` waits for them.  The
+// device cursor of a tree never passes the columns its launched selections may consume (leaves x A each), so a launch only
+// needs the pieces up to its own.
 static int feed_streams_part(tg_search *s, size_t upto, hipStream_t st) {
     if (!s->rng_rest_cols) return TG_OK;
-    const int T = s->dev.T, idx = s->rng_rest_idx;
-    const size_t need = s->rng_rest_first + s->rng_rest_cols, first = s->rng_rest_first;
+    const size_t need = s->rng_rest_first + s->rng_rest_cols;
     if (upto > need) upto = need;
-    if (upto <= first) return TG_OK;
-    const size_t cols = upto - first;
-    wait_prefill(s);
-    double *stage = s->stage[idx];
-    parallel_trees(T, [&](int t) {
-        s->streams[t].ensure(upto);
-        std::memcpy(stage + (size_t)t * need + first, s->streams[t].data() + first, cols * sizeof(double));
-    });
-    TG_HIP(hipMemcpy2DAsync(s->rng_buf[idx] + first, need * sizeof(double), stage + first, need * sizeof(double), cols * sizeof(double), T,
-                            hipMemcpyHostToDevice, s->copy_stream));
-    TG_HIP(hipEventRecord(s->ev_rng[idx], s->copy_stream));     // also the new guard of the staging buffer
+    if (upto <= s->rng_rest_first) return TG_OK;
+    const int idx = s->rng_rest_idx;
+    if (int rc = feed_streams_piece(s, upto)) return rc;
     TG_HIP(hipStreamWaitEvent(st, s->ev_rng[idx], 0));
-    s->rng_rest_first = upto;
-    s->rng_rest_cols = need - upto;
     return TG_OK;
 }
 
 static int advance_streams_impl(tg_search *s, int64_t *consumed_host, const uint8_t *skip, const int64_t *used_in = nullptr);
 int tg_search_advance_streams(tg_search *s, int64_t *consumed_host) { return advance_streams_impl(s, consumed_host, nullptr); }
 
-// skip[t] != 0: tree t's stream was replaced since the window went up - what the device consumed there is not its (a
+// skip[t] != 0: tree t's stream was replaced since the window was generated - what the device consumed there is not its (a
 // self-play slot whose game ended while the device had already gone on to the next root)
 // used_in: the device cursors, if the caller has them already (publish_cursors_kernel)
 static int advance_streams_impl(tg_search *s, int64_t *consumed_host, const uint8_t *skip, const int64_t *used_in) {
     if (!s) return tg::fail(TG_ERR_ARG, "tg_search_advance_streams: null argument");
     const int T = s->dev.T;
     if (s->streams.size() != (size_t)T) return tg::fail(TG_ERR_ARG, "tg_search_advance_streams: streams are not seeded");
-    wait_prefill(s);
     std::vector<int64_t> used(T);
     if (used_in) {
         std::memcpy(used.data(), used_in, (size_t)T * sizeof(int64_t));
@@ -4507,10 +4572,10 @@ static int advance_streams_impl(tg_search *s, int64_t *consumed_host, const uint
             most = std::max(most, used[t]);
             continue;
         }
-        if (delta < 0 || (size_t)delta > s->streams[t].available())
-            return tg::fail(TG_ERR_ARG, "tg_search_advance_streams: tree %d consumed %lld of %zu staged draws", t,
-                            (long long)delta, s->streams[t].available());
-        s->streams[t].consume((size_t)delta);
+        if (delta < 0 || used[t] > s->win_cap)
+            return tg::fail(TG_ERR_ARG, "tg_search_advance_streams: tree %d consumed %lld draws, cursor %lld of a window of %lld", t,
+                            (long long)delta, (long long)used[t], (long long)s->win_cap);
+        s->streams[t].lag += delta;
         if (consumed_host) consumed_host[t] = delta;
         s->win_used[t] = used[t];
         most = std::max(most, used[t]);
@@ -4519,41 +4584,89 @@ static int advance_streams_impl(tg_search *s, int64_t *consumed_host, const uint
     return TG_OK;
 }
 
-static int draw_noise_impl(tg_search *s, double *noise_host, const uint8_t *skip, const double *const *ready = nullptr);
+// the device-drawn noise of the last tg_search_draw_noise, on the host (finish_move's own arithmetic, callers that ask for it)
+static int noise_host_sync(tg_search *s) {
+    if (!s->noise_back_pending) return TG_OK;
+    TG_HIP(hipEventSynchronize(s->noise_back_ev));
+    const size_t n = (size_t)s->dev.T * s->A;
+    s->noise_host.assign(s->noise_back, s->noise_back + n);
+    s->noise_back_pending = false;
+    return TG_OK;
+}
+
+static int draw_noise_impl(tg_search *s, double *noise_host, const uint8_t *skip);
 int tg_search_draw_noise(tg_search *s, double *noise_host) { return draw_noise_impl(s, noise_host, nullptr); }
 
-// skip[t] != 0: tree t draws nothing (zero noise) - its stream must not move yet
-// ready[t] != nullptr: the A values are there already (-log of tree t's next A draws, computed ahead): copied, the draws consumed
-static int draw_noise_impl(tg_search *s, double *noise_host, const uint8_t *skip, const double *const *ready) {
+// node.py:275-278 for every root: A draws of each tree's stream as Gumbel(0, 1) = -log(-log(1 - u)), generated on the device
+// straight into the root noise rows, in stream order behind the kernels that read the previous noise and ahead of the next
+// selection.  skip[t] != 0: tree t draws nothing (zero noise) - its stream must not move yet.
+static int draw_noise_impl(tg_search *s, double *noise_host, const uint8_t *skip) {
     if (!s) return tg::fail(TG_ERR_ARG, "tg_search_draw_noise: null argument");
     const int T = s->dev.T, A = s->A;
     if (s->streams.size() != (size_t)T) return tg::fail(TG_ERR_ARG, "tg_search_draw_noise: streams are not seeded");
-    wait_prefill(s);
-    std::vector<double> local;
-    double *noise = noise_host;
-    if (!noise) {
-        local.resize((size_t)T * A);
-        noise = local.data();
+    for (int t = 0; t < T; ++t)
+        if (!(skip && skip[t]) && !s->streams[t].seeded) return tg::fail(TG_ERR_ARG, "tg_search_draw_noise: tree %d has no stream", t);
+    int rc, slot = -1;
+    if ((rc = noise_host_sync(s))) return rc;                       // (the staging rows are about to be rewritten)
+    if ((rc = rng_sync_seeds(s)) || (rc = rng_take_lag(s, skip, &slot))) return rc;
+    if (s->stream_known) {
+        TG_HIP(hipEventRecord(s->noise_order_ev, s->last_stream));
+        TG_HIP(hipStreamWaitEvent(s->copy_stream, s->noise_order_ev, 0));
+    } else {
+        TG_HIP(hipDeviceSynchronize());
     }
-    auto one = [&](int t) {
-        if (skip && skip[t]) {
-            for (int i = 0; i < A; ++i) noise[(size_t)t * A + i] = 0.0;
-            return;
-        }
-        tg::LegacyStream &ls = s->streams[t];
-        ls.ensure((size_t)A);
-        if (ready && ready[t]) {
-            std::memcpy(&noise[(size_t)t * A], ready[t], (size_t)A * sizeof(double));
-        } else {
-            const double *e = ls.data();
-            for (int i = 0; i < A; ++i) noise[(size_t)t * A + i] = -std::log(e[i]);   // gumbel(0,1) of the same uniforms
-        }
-        ls.consume((size_t)A);
-    };
-    if (ready && T <= 64) for (int t = 0; t < T; ++t) one(t);      // (copies: not worth waking the pool)
-    else parallel_trees(T, one);
+    tg_rng::FillArgs a{};
+    a.base = s->mt_base; a.cont = s->mt_cont; a.lag = s->lag_pin_dev + (size_t)slot * T;
+    a.skip = s->skip_pin_dev + (size_t)slot * T;
+    a.count = A; a.noise = s->dev.noise;
+    if ((rc = rng_launch(s, a, slot))) return rc;
+    TG_HIP(hipMemcpyAsync(s->noise_back, s->dev.noise, (size_t)T * A * sizeof(double), hipMemcpyDeviceToHost, s->copy_stream));
+    TG_HIP(hipEventRecord(s->noise_back_ev, s->copy_stream));
+    s->noise_back_pending = true;
+    if (s->stream_known) TG_HIP(hipStreamWaitEvent(s->last_stream, s->noise_back_ev, 0));
+    else TG_HIP(hipStreamSynchronize(s->copy_stream));
     s->win_left = 0;                               // the noise sits between two windows
-    return tg_search_set_noise(s, noise);
+    if (noise_host) {
+        if ((rc = noise_host_sync(s))) return rc;
+        std::memcpy(noise_host, s->noise_host.data(), (size_t)T * A * sizeof(double));
+    }
+    return TG_OK;
+}
+
+// ---- test hooks of the device streams (tests/test_gpu_rng.py) ----
+// columns [first, first + count) of tree `tree`'s row of the most recently generated window
+int tg_search_debug_read_window(tg_search *s, int tree, size_t first, size_t count, double *out_host) {
+    if (!s || (!out_host && count)) return tg::fail(TG_ERR_ARG, "tg_search_debug_read_window: null argument");
+    const int idx = s->rng_pending >= 0 ? s->rng_pending : s->rng_active;
+    const int64_t pitch = s->rng_pending >= 0 ? s->rng_pending_cap : s->dev.rng_cap;
+    if (tree < 0 || tree >= s->dev.T || !s->rng_buf[idx] || (int64_t)(first + count) > pitch)
+        return tg::fail(TG_ERR_ARG, "tg_search_debug_read_window: outside the window (%lld draws per tree)", (long long)pitch);
+    TG_HIP(hipStreamSynchronize(s->copy_stream));
+    TG_HIP(hipMemcpy(out_host, s->rng_buf[idx] + (size_t)tree * pitch + first, count * sizeof(double), hipMemcpyDeviceToHost));
+    return TG_OK;
+}
+
+// What a search does to the streams, without a search: per step a window of steps[i] + slack draws is generated - whole
+// (part == 0) or in parts of `part` draws (first part, continued pieces, the rest: feed_streams_impl / _part / _rest) - and
+// steps[i] draws of every tree count as consumed.
+int tg_search_debug_stream_walk(tg_search *s, const int64_t *steps, int n_steps, int64_t slack, int64_t part) {
+    if (!s || !steps || n_steps < 0 || slack < 0 || part < 0) return tg::fail(TG_ERR_ARG, "tg_search_debug_stream_walk: bad argument");
+    int rc;
+    for (int i = 0; i < n_steps; ++i) {
+        if (steps[i] < 0) return tg::fail(TG_ERR_ARG, "tg_search_debug_stream_walk: negative step");
+        const size_t need = (size_t)(steps[i] + slack);
+        if (need == 0) continue;
+        if ((rc = feed_streams_impl(s, need, 1, part > 0 ? (size_t)part : 0))) return rc;
+        if (part > 0) {
+            for (size_t upto = (size_t)(2 * part); upto + (size_t)part < need; upto += (size_t)part)
+                if ((rc = feed_streams_part(s, upto, s->copy_stream))) return rc;
+            if ((rc = feed_streams_rest(s))) return rc;
+            s->rng_rest_wait = false;
+        }
+        for (int t = 0; t < s->dev.T; ++t) s->streams[t].lag += steps[i];
+        s->win_left = 0;
+    }
+    return TG_OK;
 }
 
 // D: the engine's device view or a slice of it (sub_dev: D.T trees from some tree on); the kernel variant goes by the
@@ -5008,8 +5121,6 @@ struct tg_selfplay {
     std::vector<int64_t> c_phase;                    // per tree: draw cursor behind the phases of the last move (RootTail)
     std::vector<uint8_t> skip, skip_fresh;           // per tree: takes no part in this move / game just started
     std::vector<int32_t> state;                      // finish_roots_kernel's per-tree state [T][4]
-    std::vector<double> g2;                          // per tree: -log of the 2 A draws behind the phases (noise candidates)
-    std::vector<int64_t> g2_base;                    // ... and the cursor they start at (-1: none)
     // sub-groups of a lock-step move (launch_phases_subgroups): streams 1.., events, the phase tables of a whole move
     static constexpr int kMaxSub = 16, kMaxPhases = 16;
     int n_sub_streams = 0;
@@ -5019,6 +5130,18 @@ struct tg_selfplay {
     hipEvent_t phase_all_ev[2] = {};
     bool phase_all_used[2] = {};
     unsigned phase_all_seq = 0;
+    // A chained move between tg_selfplay_move_begin (everything queued) and tg_selfplay_move_end (records awaited, bookkeeping):
+    // what the second half needs from the first.  Several handles (lanes of one shard, each with its own engine and stream) are
+    // kept in this state at once by ONE host thread, so that the device always has other lanes' moves queued while the host
+    // waits for one lane's records - boards of different lanes are on different moves (round 6).
+    struct PendingMove {
+        bool active = false, any_phase = false;
+        int64_t leaves = 0;
+        int32_t n_phases = 0;
+        float *planes = nullptr, *policy = nullptr, *value = nullptr;
+        void *stream = nullptr;
+        double t_last = 0.0;
+    } pend;
 };
 
 namespace {
@@ -5270,6 +5393,7 @@ static int finish_move_impl(tg_selfplay *sp, int32_t *moves_host, int32_t *finis
                                        sp->vl_a.data(), sp->vsum_a.data(), sp->pol_a.data());
     }
     if (rc) return rc;
+    if (int nrc = noise_host_sync(s)) return nrc;                    // (the device-drawn noise has long arrived)
     if (s->noise_host.size() != (size_t)T * A) return tg::fail(TG_ERR_STATE, "tg_selfplay_finish_move: no root noise was set");
     // the boards are only needed to score a game that ends with this move, i.e. with a second pass in a row
     bool may_end = false;
@@ -5279,21 +5403,8 @@ static int finish_move_impl(tg_selfplay *sp, int32_t *moves_host, int32_t *finis
     const int max_moves = S * S * 2;                                  // worker.py:44
     std::vector<int> status(T, TG_OK);
     std::vector<int64_t> n_moves(T, 0), n_games(T, 0);
-    if (tail) { sp->g2.resize((size_t)T * 2 * A); sp->g2_base.assign(T, -1); }
     parallel_trees(T, [&](int t) {
         SpGame &g = sp->games[t];
-        if (tail && !g.done && !g.fresh && s->streams[t].seeded) {
-            // the next move's Gumbel noise is -log of the A draws behind the next root's prior, i.e. behind 1..A more draws
-            // than the phases consumed (tail.cursor): every candidate's logarithm now, on the pool, while the device is
-            // busy with the root - at the next call the noise is a copy (the logarithms were 0.09 ms of its critical path)
-            tg::LegacyStream &ls = s->streams[t];
-            const size_t c = (size_t)tail[t].cursor;
-            ls.ensure(c + (size_t)2 * A);
-            const double *e = ls.data() + c;
-            double *g2 = &sp->g2[(size_t)t * 2 * A];
-            for (int i = 0; i < 2 * A; ++i) g2[i] = -std::log(e[i]);
-            sp->g2_base[t] = (int64_t)c;
-        }
         moves_host[t] = -1;
         finished_host[t] = 0;
         if (g.done || (tail && g.fresh)) return;
@@ -5390,6 +5501,8 @@ static int play_move_sync(tg_selfplay *sp, tg_net *net, float *planes_dev, float
                           void *stream, int32_t *finished_host, int64_t *stats_host);
 static int play_move_chain(tg_selfplay *sp, tg_net *net, float *planes_dev, float *policy_dev, float *value_dev,
                            void *stream, int32_t *finished_host, int64_t *stats_host);
+static int chain_begin(tg_selfplay *sp, tg_net *net, float *planes_dev, float *policy_dev, float *value_dev, void *stream);
+static int chain_end(tg_selfplay *sp, int32_t *finished_host, int64_t *stats_host);
 
 // PUCT mini-batches queued back to back (mcts/tree.py:146-152 with process_mini_batch, :273-315): ONE random window for all of them
 // - uploaded in two parts, the first mini-batch's share in front of its selection launch, the rest behind it -, then per mini-batch
@@ -5438,6 +5551,24 @@ int tg_selfplay_play_move(tg_selfplay *sp, tg_net *net, float *planes_dev, float
     if (sp->chained) return play_move_chain(sp, net, planes_dev, policy_dev, value_dev, stream, finished_host, stats_host);
     sp->sync_started = true;
     return play_move_sync(sp, net, planes_dev, policy_dev, value_dev, stream, finished_host, stats_host);
+}
+
+// The two halves of a chained tg_selfplay_play_move (see PendingMove): `begin` queues the whole move on `stream` and returns with
+// the device working; `end` waits for that move's records, does the bookkeeping and reports finished games.  Between the two
+// the caller may run other handles' halves; slots are refilled (tg_selfplay_start_game) between an `end` and the next `begin`.
+int tg_selfplay_move_begin(tg_selfplay *sp, tg_net *net, float *planes_dev, float *policy_dev, float *value_dev, void *stream) {
+    if (!sp || !net || !planes_dev || !policy_dev || !value_dev) return tg::fail(TG_ERR_ARG, "tg_selfplay_move_begin: null argument");
+    if (sp->sync_started || sp->observer)
+        return tg::fail(TG_ERR_STATE, "tg_selfplay_move_begin: this handle runs the round-trip scheme / has an observer (whole moves only)");
+    if (sp->pend.active) return tg::fail(TG_ERR_STATE, "tg_selfplay_move_begin: the previous move has not been ended");
+    sp->chained = true;
+    return chain_begin(sp, net, planes_dev, policy_dev, value_dev, stream);
+}
+
+int tg_selfplay_move_end(tg_selfplay *sp, int32_t *finished_host, int64_t *stats_host) {
+    if (!sp || !finished_host) return tg::fail(TG_ERR_ARG, "tg_selfplay_move_end: null argument");
+    if (!sp->pend.active) return tg::fail(TG_ERR_STATE, "tg_selfplay_move_end: no move has been begun");
+    return chain_end(sp, finished_host, stats_host);
 }
 
 // Chained moves.  A call = one lock-step move of every board whose root is expanded:
@@ -5544,6 +5675,14 @@ static int launch_phases_subgroups(tg_selfplay *sp, tg_net *net, int n_phases, i
 
 static int play_move_chain(tg_selfplay *sp, tg_net *net, float *planes_dev, float *policy_dev, float *value_dev,
                            void *stream, int32_t *finished_host, int64_t *stats_host) {
+    if (sp->pend.active) return tg::fail(TG_ERR_STATE, "tg_selfplay_play_move: a move begun with tg_selfplay_move_begin has not been ended");
+    if (int rc = chain_begin(sp, net, planes_dev, policy_dev, value_dev, stream)) return rc;
+    return chain_end(sp, finished_host, stats_host);
+}
+
+static inline double sp_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+static int chain_begin(tg_selfplay *sp, tg_net *net, float *planes_dev, float *policy_dev, float *value_dev, void *stream) {
     tg_search *s = sp->s;
     const int T = s->dev.T, A = s->A;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -5551,10 +5690,8 @@ static int play_move_chain(tg_selfplay *sp, tg_net *net, float *planes_dev, floa
     s->prefill_enabled = false;
     static const bool timing = getenv("TG_SP_TIMING") != nullptr;
     double *acc = sp->t_acc;
-    long &moves_timed = sp->moves_timed;
-    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double t_last = timing ? now() : 0.0;
-    auto lap = [&](int i) { if (timing) { const double t = now(); acc[i] += t - t_last; t_last = t; } };
+    double t_last = timing ? sp_now() : 0.0;
+    auto lap = [&](int i) { if (timing) { const double t = sp_now(); acc[i] += t - t_last; t_last = t; } };
     if (s->streams.size() != (size_t)T) return tg::fail(TG_ERR_ARG, "tg_selfplay_play_move: streams are not seeded");
     sp->skip.assign(T, 0);
     sp->skip_fresh.assign(T, 0);
@@ -5584,14 +5721,7 @@ static int play_move_chain(tg_selfplay *sp, tg_net *net, float *planes_dev, floa
     sp->nc_known = true;
     sp->nc_cursor = sp->nc;
     lap(0);
-    {
-        std::vector<const double *> ready(T, nullptr);
-        for (int t = 0; t < T; ++t)
-            if (!sp->skip[t] && (size_t)t < sp->g2_base.size() && sp->g2_base[t] >= 0 && sp->g2_base[t] == sp->c_phase[t])
-                ready[t] = &sp->g2[(size_t)t * 2 * A + sp->nc[t]];
-        if ((rc = draw_noise_impl(s, nullptr, sp->skip_fresh.data(), ready.data()))) return rc;
-        sp->g2_base.assign(T, -1);
-    }
+    if ((rc = draw_noise_impl(s, nullptr, sp->skip_fresh.data()))) return rc;      // (generated on the device, legacy_rng_device.h)
     lap(1);
     // ---- sequential halving (tree.py:375-384) ----
     constexpr int kMaxPhases = tg_selfplay::kMaxPhases;
@@ -5696,15 +5826,27 @@ static int play_move_chain(tg_selfplay *sp, tg_net *net, float *planes_dev, floa
     lap(4);
     // ---- host work that nobody is waiting for: the previous move's record comments, draws generated ahead ----
     flush_comments(sp);
-    {
-        const size_t ahead = (size_t)2 * A + (size_t)2 * window + (size_t)8 * A;
-        wait_prefill(s);
-        parallel_trees(T, [&](int t) {
-            if (!sp->games[t].done && s->streams[t].seeded) s->streams[t].ensure(s->streams[t].available() < ahead ? ahead : 0);
-        });
-        sp->last_window = window;
-    }
+    sp->last_window = window;            // (draws are no longer generated ahead on the host: the device produces them)
     lap(5);
+    sp->pend = tg_selfplay::PendingMove{true, any_phase, leaves, n_phases, planes_dev, policy_dev, value_dev, stream, 0.0};
+    return TG_OK;
+}
+
+static int chain_end(tg_selfplay *sp, int32_t *finished_host, int64_t *stats_host) {
+    tg_search *s = sp->s;
+    const int T = s->dev.T, A = s->A;
+    int rc;
+    static const bool timing = getenv("TG_SP_TIMING") != nullptr;
+    double *acc = sp->t_acc;
+    long &moves_timed = sp->moves_timed;
+    double t_last = timing ? sp_now() : 0.0;
+    auto lap = [&](int i) { if (timing) { const double t = sp_now(); acc[i] += t - t_last; t_last = t; } };
+    const bool any_phase = sp->pend.any_phase;
+    const int64_t leaves = sp->pend.leaves;
+    const int32_t n_phases = sp->pend.n_phases;
+    float *planes_dev = sp->pend.planes, *policy_dev = sp->pend.policy, *value_dev = sp->pend.value;
+    void *stream = sp->pend.stream;
+    sp->pend.active = false;
     // ---- the records (not the stream): bookkeeping ----
     TG_HIP(hipEventSynchronize(s->fin_ev));
     lap(6);
@@ -5857,17 +5999,7 @@ static int play_move_sync(tg_selfplay *sp, tg_net *net, float *planes_dev, float
     // ---- host work that nobody is waiting for, while the phase kernels run: the previous move's record comments, and
     //      the draws the next move will ask for (root prior, noise, a window like this move's) generated ahead ----
     flush_comments(sp);
-    {
-        // (this move's window may still be consumed in full - the cursors are read back below - AND the next move asks
-        // for another one: with one window's worth ahead the next feed generated most of its window itself, 0.23 ms per
-        // move at 16 boards, with the GPU idle)
-        const size_t ahead = (size_t)2 * A + (size_t)2 * window + (size_t)8 * A;
-        wait_prefill(s);
-        parallel_trees(T, [&](int t) {
-            if (!sp->games[t].done && s->streams[t].seeded) s->streams[t].ensure(s->streams[t].available() < ahead ? ahead : 0);
-        });
-        sp->last_window = window;
-    }
+    sp->last_window = window;
     lap(4);
     if (any_phase && (rc = tg_search_advance_streams(s, nullptr))) return rc;
     lap(5);

@@ -91,7 +91,9 @@ _SIGNATURES = {
     "tg_search_advance_streams": (c_int, [c_void_p, c_void_p]),
     "tg_search_draw_noise": (c_int, [c_void_p, c_void_p]),
     "tg_legacy_exponentials": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
-    "tg_legacy_stream_walk": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_int]),
+    "tg_glibc_log": (c_int, [c_void_p, c_size_t, c_void_p]),
+    "tg_search_debug_read_window": (c_int, [c_void_p, c_int, c_size_t, c_size_t, c_void_p]),
+    "tg_search_debug_stream_walk": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64]),
     "tg_trainer_create": (c_int, [c_int, c_int, c_int, c_void_p, c_size_t, POINTER(c_void_p)]),
     "tg_trainer_destroy": (c_int, [c_void_p]),
     "tg_trainer_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p]),
@@ -106,6 +108,8 @@ _SIGNATURES = {
     "tg_selfplay_finish_move": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "tg_selfplay_set_observer": (c_int, [c_void_p, SELFPLAY_OBSERVER, c_void_p]),
     "tg_selfplay_play_move": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "tg_selfplay_move_begin": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "tg_selfplay_move_end": (c_int, [c_void_p, c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -53,7 +53,7 @@ def _finish(game: _Game, winner, is_resign: bool, score: float):
 
 def selfplay_shard(save_dir: str, network, index_list: Sequence[int], size: int, visits: int,
                    boards: int = 16, seeds: Sequence[int] = None, device_index: int = 0,
-                   never_resign_flags: Sequence[bool] = None, groups: int = 0, observer=None) -> dict:
+                   never_resign_flags: Sequence[bool] = None, groups: int = 0, observer=None, lanes: int = 0) -> dict:
     """Play the games of `index_list`, `boards` at a time.  Game i draws from its own legacy
     stream seeded with seeds[i] (default: its index), so every game equals the reference
     game a single-board worker would play with that seed.
@@ -63,6 +63,13 @@ def selfplay_shard(save_dir: str, network, index_list: Sequence[int], size: int,
     independent, so the result does not depend on the grouping.  (Inside ONE group the library
     already overlaps the boards' tree kernels with each other's forward passes - sub-groups on
     streams of its own, tg_selfplay_play_move in include/tamago_hip.h - without extra host threads.)
+
+    `lanes` (DualNet evaluator, no observer): the boards of a group are split into that many LANES - each its own engine,
+    selfplay handle, buffers and HIP stream - all driven by the group's ONE host thread through the two halves of a chained
+    move (tg_selfplay_move_begin / _end): while the host waits for one lane's records and queues its next move, the other lanes'
+    moves are running, so boards of different lanes are on different moves and a lane's select / backup kernels always have
+    another lane's forward pass to hide under.  0 = auto (measured table in _auto_lanes), 1 = one lock-step group as before.
+    Games are independent: the result does not depend on the lanes (tests/test_gpu_fastpath.py).
 
     `observer` (audit hook, one group only): called as observer(engine, event) from inside
     tg_selfplay_play_move for every evaluated mini-batch and every decided move
@@ -97,7 +104,7 @@ def selfplay_shard(save_dir: str, network, index_list: Sequence[int], size: int,
             return index, nr
 
     if groups == 1:
-        _run_group(save_dir, network, size, visits, boards, seeds, device_index, next_game, stats, None, observer)
+        _run_group(save_dir, network, size, visits, boards, seeds, device_index, next_game, stats, None, observer, lanes)
         if hasattr(network, "range_fallbacks"):             # forward passes redone in exact fp32 (f16 range guard)
             stats["range_fallbacks"] = network.range_fallbacks() - fb0
         return stats
@@ -111,7 +118,7 @@ def selfplay_shard(save_dir: str, network, index_list: Sequence[int], size: int,
         try:
             stream = torch.cuda.Stream(device=torch.device("cuda", device_index))
             _run_group(save_dir, network, size, visits, sizes[g], seeds, device_index, next_game,
-                       results[g], stream)
+                       results[g], stream, None, lanes)
         except BaseException as exc:          # surfaced in the caller's thread
             errors.append(exc)
 
@@ -138,8 +145,124 @@ def selfplay_shard(save_dir: str, network, index_list: Sequence[int], size: int,
     return stats
 
 
+def _auto_lanes(boards: int, size: int) -> int:
+    """Lanes of a group of `boards` boards (measured on MI355X, tools/bench_selfplay.py, 400 simulations; docs/DESIGN_HISTORY.md 12)."""
+    env = os.environ.get("TG_SP_LANES")
+    if env:
+        return max(1, min(int(env), boards))
+    if size != 9:
+        return 1
+    if boards < 8:
+        return 1
+    if boards <= 32:
+        return 4
+    if boards <= 512:
+        return 4
+    return 2
+
+
+def _run_lanes(save_dir, network, size, visits, lane_sizes, seeds, device_index, next_game, stats):
+    """A group's boards as independent lanes on one host thread (selfplay_shard's `lanes`)."""
+    import ctypes
+    import time as _time
+    from collections import deque
+    import torch
+    from tamago_amd import lib as _lib
+    device = torch.device("cuda", device_index)
+    start_board = GoBoard(board_size=size, komi=7.0, check_superko=True)
+    komi = float(start_board.get_komi())
+    a = size * size + 1
+
+    class Lane:
+        pass
+
+    lanes = []
+    timing = os.environ.get("TG_SP_TIMING") is not None
+    t_end = t_begin = t_refill = 0.0
+    n_moves = 0
+    try:
+        for n in lane_sizes:
+            ln = Lane()
+            ln.boards = n
+            ln.stream = torch.cuda.Stream(device=device)
+            with torch.cuda.stream(ln.stream):
+                ln.engine = SearchEngine(size, n, max(SELF_PLAY_VISITS * 10, visits + 8), max(visits, 1),
+                                         DeviceEvaluator(network), check_superko=True, device_index=device_index)
+                ln.policy = torch.empty((n * ln.engine.K, a), dtype=torch.float32, device=device)
+                ln.value = torch.empty((n * ln.engine.K, 3), dtype=torch.float32, device=device)
+            ln.handle = ctypes.c_void_p()
+            ln.sp_open = False
+            lanes.append(ln)
+            lib = ln.engine.lib
+            _lib.check(lib.tg_selfplay_create(ln.engine.handle, os.fsencode(save_dir), visits, komi, repr(komi).encode(),
+                                              ctypes.byref(ln.handle)), "tg_selfplay_create")
+            ln.sp_open = True
+            ln.finished = np.zeros(n, dtype=np.int32)
+            ln.counts = np.zeros(3, dtype=np.int64)
+            ln.live = 0
+        lib = lanes[0].engine.lib
+
+        def start(ln, slot: int) -> bool:
+            nxt = next_game()
+            if nxt is None:
+                _lib.check(lib.tg_selfplay_start_game(ln.handle, slot, -1, 0), "tg_selfplay_start_game")
+                return False
+            index, never_resign = nxt
+            ln.engine.streams[slot] = None
+            ln.engine.set_root(slot, start_board, Stone.BLACK, np.random.RandomState(seeds[index]).get_state())
+            _lib.check(lib.tg_selfplay_start_game(ln.handle, slot, index, int(never_resign)), "tg_selfplay_start_game")
+            return True
+
+        def begin(ln):
+            _lib.check(lib.tg_selfplay_move_begin(ln.handle, network.handle, ln.engine.planes.data_ptr(), ln.policy.data_ptr(),
+                                                  ln.value.data_ptr(), ln.stream.cuda_stream), "tg_selfplay_move_begin")
+
+        # slots are handed out lane by lane in board order - with one lane that is the order of the lock-step group
+        for ln in lanes:
+            for slot in range(ln.boards):
+                if start(ln, slot):
+                    ln.live += 1
+                else:
+                    ln.engine.set_root(slot, start_board, Stone.BLACK, np.random.RandomState(0).get_state())
+        ring = deque()
+        for ln in lanes:
+            if ln.live > 0:
+                begin(ln)
+                ring.append(ln)
+        while ring:
+            ln = ring.popleft()
+            t0 = _time.perf_counter()
+            _lib.check(lib.tg_selfplay_move_end(ln.handle, ln.finished.ctypes.data, ln.counts.ctypes.data), "tg_selfplay_move_end")
+            t1 = _time.perf_counter()
+            stats["games"] += int(ln.counts[0])
+            stats["moves"] += int(ln.counts[1])
+            stats["leaf_evals"] += int(ln.counts[2])
+            for slot in np.nonzero(ln.finished)[0]:
+                if not start(ln, int(slot)):
+                    ln.live -= 1
+            t2 = _time.perf_counter()
+            if ln.live > 0:
+                begin(ln)
+                ring.append(ln)
+            t3 = _time.perf_counter()
+            t_end += t1 - t0
+            t_refill += t2 - t1
+            t_begin += t3 - t2
+            n_moves += 1
+        if timing:
+            import sys
+            sys.stderr.write(f"[selfplay timing] {len(lanes)} lanes, {n_moves} lane-moves: move_end {1e3 * t_end / max(n_moves, 1):.3f} ms, "
+                             f"slot refill {1e3 * t_refill / max(n_moves, 1):.3f} ms, move_begin {1e3 * t_begin / max(n_moves, 1):.3f} ms per lane-move\n")
+    finally:
+        for ln in lanes:
+            if getattr(ln, "sp_open", False):
+                ln.engine.lib.tg_selfplay_destroy(ln.handle)
+            if getattr(ln, "engine", None) is not None:
+                ln.engine.close()
+
+
 def _run_group(save_dir, network, size, visits, boards, seeds, device_index, next_game, stats, stream,
-               observer=None):
+               observer=None, lanes=0):
     """One lock-step group of `boards` games on its own engine (and HIP stream, if given).
 
     With the library's own network the whole lock-step move is ONE library call (tg_selfplay_play_move:
@@ -151,6 +274,13 @@ def _run_group(save_dir, network, size, visits, boards, seeds, device_index, nex
     import torch
     from tamago_amd import lib as _lib
     from tamago_amd.nn.network.dual_net import DualNet
+    if isinstance(network, DualNet) and observer is None:
+        n_lanes = lanes if lanes > 0 else _auto_lanes(boards, size)
+        n_lanes = max(1, min(n_lanes, boards))
+        if n_lanes > 1 and (os.environ.get("TG_SP_CHAIN", "1") != "0"):
+            sizes = [boards // n_lanes + (1 if g < boards % n_lanes else 0) for g in range(n_lanes)]
+            _run_lanes(save_dir, network, size, visits, sizes, seeds, device_index, next_game, stats)
+            return
     ctx = torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
     with ctx:
         evaluator = DeviceEvaluator(network) if isinstance(network, DualNet) \

@@ -218,8 +218,11 @@ def test_selfplay_move_schemes_play_the_same_games(tmp_path, monkeypatch):
     idx = list(range(301, 301 + 44))
     flags = [i % 5 != 0 for i in idx]
     results = {}
-    for name, chain, sub in (("host decision", "0", None), ("chained", "1", "1"), ("2 sub-groups", "1", "2"),
-                             ("default", None, None), ("4 sub-groups", "1", "4")):
+    # round 6: lanes - the boards as independent engines on their own streams, driven by one host thread through
+    # tg_selfplay_move_begin / _end, each lane on a move of its own (the default from 8 boards on)
+    for name, chain, sub, lanes in (("host decision", "0", None, 1), ("chained", "1", "1", 1), ("2 sub-groups", "1", "2", 1),
+                                    ("default", None, None, 0), ("4 sub-groups", "1", "4", 1), ("3 lanes", None, None, 3),
+                                    ("8 lanes of one group", "1", "1", 8)):
         for key, val in (("TG_SP_CHAIN", chain), ("TG_SP_SUBGROUPS", sub)):
             if val is None:
                 monkeypatch.delenv(key, raising=False)
@@ -227,7 +230,7 @@ def test_selfplay_move_schemes_play_the_same_games(tmp_path, monkeypatch):
                 monkeypatch.setenv(key, val)
         d = tmp_path / name.replace(" ", "_")
         d.mkdir()
-        stats = selfplay_shard(str(d), net, idx, 9, VISITS, boards=16, never_resign_flags=flags)
+        stats = selfplay_shard(str(d), net, idx, 9, VISITS, boards=16, never_resign_flags=flags, lanes=lanes)
         results[name] = (stats, [open(d / f"{i}.sgf").read() for i in idx])
     monkeypatch.delenv("TG_SP_CHAIN", raising=False)
     monkeypatch.delenv("TG_SP_SUBGROUPS", raising=False)

@@ -1,5 +1,5 @@
-"""ExpStream (host side of the device RNG feed) vs numpy's legacy generator and the
-reference-recorded draws - CPU only."""
+"""The legacy random stream's arithmetic on the host - ExpStream (the numpy-side feed) and the library's restatement of MT19937 +
+glibc's log (what the device streams compute) - vs numpy's legacy generator, libm and the reference-recorded draws.  CPU only."""
 import numpy as np
 
 from tests.helpers import load_npz
@@ -66,35 +66,25 @@ def test_library_legacy_stream_equals_numpy():
         assert np.array_equal(np.array([-math.log(v) for v in e]), fix[f"seed{seed}_gum82"])   # libm log, not numpy's SIMD log
 
 
-def test_stream_state_after_long_consumption_comes_from_snapshots():
-    """After a search the library hands numpy's generator back at the position the search left it (tg_search_stream_state ->
-    np.random.set_state; mcts/tree.py draws from the process-global generator).  The state is rebuilt from snapshots taken every
-    2 048 generated draws (csrc/legacy_stream.h) instead of replaying every consumed draw: whatever the pattern of windows and
-    consumption - fewer draws than a snapshot interval, many intervals, windows far larger than what is consumed - the state
-    must be numpy's after the same number of standard_exponential draws, and the staged draws must continue the stream."""
+def test_restated_glibc_log_equals_libm():
+    """tg_glibc_log = csrc/legacy_rng_device.h's glibc_log on the host: the function the DEVICE streams compute their
+    exponentials (-log(1 - u)) and Gumbel noise (-log of those) with, restated from glibc's FMA build.  Against Python's math.log
+    (a plain call of libm's log; numpy's own np.log is a SIMD routine that rounds differently) bit for bit, on the argument classes
+    the streams produce - 1 - u, the exponentials, the neighbourhood of 1 with its separate polynomial - and on wide-range values.
+    (numpy's legacy generators call the same libm: the next test holds the whole chain against RandomState.)"""
+    import math
     from tamago_amd import lib as tl
     lib = tl.load()
-    patterns = [([5], 100), ([2047, 1, 1], 0), ([2048], 0), ([2049], 7000), ([82] * 300, 21000), ([70000], 1000),
-                ([1000, 0, 50000, 3, 2048 * 7], 5000), ([600000], 23000)]
-    for seed in (3, 2**31 - 9):
-        for steps, slack in patterns:
-            ref = np.random.RandomState(seed)
-            ref.random_sample(11)                                 # (a mid-state start position)
-            state = ref.get_state()
-            key = np.ascontiguousarray(state[1], dtype=np.uint32).copy()
-            arr = np.ascontiguousarray(steps, dtype=np.int64)
-            key_out = np.zeros(624, dtype=np.uint32)
-            pos_out = tl.ctypes.c_int(0)
-            nxt = np.empty(9, dtype=np.float64)
-            tl.check(lib.tg_legacy_stream_walk(key.ctypes.data, int(state[2]), arr.ctypes.data, len(arr), slack,
-                                               key_out.ctypes.data, tl.ctypes.byref(pos_out), nxt.ctypes.data, len(nxt)),
-                     "tg_legacy_stream_walk")
-            ref.standard_exponential(int(arr.sum()))
-            want = ref.get_state()
-            got = np.random.RandomState()
-            got.set_state(("MT19937", key_out, int(pos_out.value), 0, 0.0))
-            chk = np.random.RandomState()
-            chk.set_state(want)
-            assert np.array_equal(got.random_sample(6), chk.random_sample(6)), (seed, steps)
-            chk.set_state(want)
-            assert np.array_equal(nxt, chk.standard_exponential(9)), (seed, steps)
+    rs = np.random.RandomState(77)
+    u = rs.random_sample(200_000)
+    one_minus = 1.0 - u
+    expo = np.array([-math.log(v) for v in one_minus[:100_000]])
+    near_one = 0.93 + 0.14 * rs.random_sample(100_000)
+    edges = np.array([1.0, 1.0 - 2.0 ** -53, 1.0 + 2.0 ** -52, 1.0 - 2.0 ** -4, 1.0 + float.fromhex("0x1.09p-4"), float.fromhex("0x1.6p-1"), 2.0 ** -53, 36.7, 745.0])
+    wide = np.ldexp(0.5 + rs.random_sample(100_000), rs.randint(-60, 60, 100_000))
+    x = np.ascontiguousarray(np.concatenate([one_minus, expo[expo > 0], near_one, edges, wide]))
+    out = np.empty_like(x)
+    tl.check(lib.tg_glibc_log(x.ctypes.data, x.size, out.ctypes.data), "tg_glibc_log")
+    want = np.array([math.log(v) for v in x])
+    bad = np.nonzero(out.view(np.uint64) != want.view(np.uint64))[0]
+    assert bad.size == 0, (x[bad[:4]], out[bad[:4]], want[bad[:4]])

@@ -31,4 +31,8 @@ t0 = int(rows[lo]["Start_Timestamp"])
 for r in rows[lo:lo + show]:
     q = qs.setdefault(r.get("Queue_Id", "?"), len(qs))
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    print(f"{(s - t0)/1e3:9.1f} us  +{(e - s)/1e3:7.1f} us  q{q}  {'    ' * q}{short(r['Kernel_Name'])}")
+    try:
+        wgs = int(r.get("Grid_Size", r.get("Grid_Size_X", 0))) // max(1, int(r.get("Workgroup_Size", r.get("Workgroup_Size_X", 1))))
+    except Exception:
+        wgs = -1
+    print(f"{(s - t0)/1e3:9.1f} us  +{(e - s)/1e3:7.1f} us  q{q:<2d} wg{wgs:<5d} {'  ' * q}{short(r['Kernel_Name'])}")
