@@ -664,6 +664,22 @@ def main():
     flops_pos = lib.tg_net_flops_per_position(args.size)
 
     host_cpu = []                                             # (CPU seconds of all threads, wall seconds, leaves) of this rank's timed regions
+    host_threads = []                                         # per timed region: [(thread name, CPU seconds)] of the busiest threads
+
+    def thread_cpu():
+        """{tid: (comm, CPU seconds)} of this process's threads (/proc/self/task/*/stat: utime + stime)."""
+        out = {}
+        tick = os.sysconf("SC_CLK_TCK")
+        try:
+            for tid in os.listdir("/proc/self/task"):
+                with open(f"/proc/self/task/{tid}/stat") as f:
+                    text = f.read()
+                comm = text[text.index("(") + 1:text.rindex(")")]
+                rest = text[text.rindex(")") + 2:].split()
+                out[tid] = (comm, (int(rest[11]) + int(rest[12])) / tick)
+        except OSError:
+            pass
+        return out
 
     def timed_region(steps, warmup):
         """W untimed + K timed steps (barrier + synchronise on both sides); returns leaf evaluations, seconds (max over
@@ -676,12 +692,16 @@ def main():
         barrier()
         t0 = time.perf_counter()
         cpu0 = time.process_time()
+        thr0 = thread_cpu()
         leaves = 0
         for _ in range(steps):
             leaves += run_step(engines, plies_list, fresh_board, args.visits, args.batch)
         barrier()
         elapsed = time.perf_counter() - t0
         host_cpu.append((time.process_time() - cpu0, elapsed, leaves))
+        thr1 = thread_cpu()
+        busy = sorted(((c, s1 - thr0.get(tid, (c, 0.0))[1]) for tid, (c, s1) in thr1.items()), key=lambda kv: -kv[1])
+        host_threads.append([(c, round(v, 3)) for c, v in busy[:6] if v > 0.0])
         evaluator.record = False
         kern_ms, big = 0.0, []
         for e0, e1, b in evaluator.events:
@@ -786,8 +806,10 @@ def main():
             "host": {"cpu_s_per_1e6_leaf_evals": sum(r[0] for r in host_rows) / max(sum(r[2] for r in host_rows), 1.0) * 1e6,
                      "per_rank": [{"rank": i, "cpu_s": r[0], "cores_busy": r[0] / r[1], "cores_pinned": int(r[3])}
                                   for i, r in enumerate(host_rows)],
-                     "note": "time.process_time() of each rank over its timed region: all threads of the process (driver "
-                             "thread, library random-stream generators); cores_busy = CPU seconds / wall seconds"},
+                     "busiest_threads_cpu_s": host_threads[0] if host_threads else None,
+                     "note": "time.process_time() of each rank over its timed region: all threads of the process; cores_busy = "
+                             "CPU seconds / wall seconds.  Since round 6 the random streams are generated on the device (no "
+                             "generator threads); busiest_threads_cpu_s = rank 0's threads by CPU seconds (/proc/self/task)"},
             "tree_kernels": tree_pmc_summary() if args.size == 9 else None,
             # forward launches the exact-fp32 kernel had to redo (f16 range guard of the split-operand kernels): 0 = none
             "range_fallbacks": net.range_fallbacks(),

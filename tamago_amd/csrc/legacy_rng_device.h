@@ -75,6 +75,7 @@ __host__ __device__ __forceinline__ double glibc_log(double x, const double *tab
     return y + hi;
 }
 
+#ifdef TG_RNG_DEVICE_KERNELS      // (search.hip: the translation unit that launches them; common.cpp takes glibc_log only)
 __device__ __forceinline__ void rng_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -93,28 +94,70 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
     return y;
 }
 
-// One regeneration of the 624-word state in LDS by ONE wavefront (legacy_stream.h Mt19937::regenerate): word i needs the OLD
-// words i, i + 1 and - below 227 - the old word i + 397, from 227 on the NEW word i - 227.  Passes of 64 words in rising order:
-// a pass reads before it writes (one instruction stream), and i - 227 always lies in an earlier pass.
-__device__ __forceinline__ void mt_twist(uint32_t *key, int lane) {
-    for (int base = 0; base < kMtN - 1; base += 64) {
-        const int i = base + lane;
-        const bool on = i < kMtN - 1;
-        uint32_t v = 0;
-        if (on) v = (i < kMtN - kMtM ? key[i + kMtM] : key[i - (kMtN - kMtM)]) ^ mt_mix(key[i], key[i + 1]);
-        rng_wave_sync();
-        if (on) key[i] = v;
-        rng_wave_sync();
+// The 624-word state of ONE wavefront in registers: lane l holds words l, l + 64, ..., l + 576 (k[9]: lanes 0..47).
+// One regeneration (legacy_stream.h Mt19937::regenerate): word i needs the OLD words i, i + 1 and - below 227 - the old word
+// i + 397, from 227 on the NEW word i - 227.  Register by register in rising order: i + 1 is the neighbouring lane (lane 0 of
+// the next register for lane 63), i + 397 = lane + 13 of register r + 6 / r + 7, i - 227 = lane - 35 of register r - 3 / r - 4
+// (already new) - cross-lane reads (ds_bpermute), no memory.  (The LDS version of round 6's first cut took ~1 600 cycles per
+// regeneration - ten dependent read / write passes -, this one ~400; a window's cost is mostly regenerations.)
+struct MtRegs {
+    uint32_t k[10];
+};
+
+__device__ __forceinline__ void mt_load(MtRegs &m, const uint32_t *src, int lane) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) m.k[r] = (r < 9 || lane < 48) ? src[lane + 64 * r] : 0u;
+}
+__device__ __forceinline__ void mt_store(const MtRegs &m, uint32_t *dst, int lane) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r)
+        if (r < 9 || lane < 48) dst[lane + 64 * r] = m.k[r];
+}
+
+__device__ __forceinline__ void mt_twist(MtRegs &m, int lane) {
+    const int up13 = (lane + 13) & 63, dn35 = (lane + 29) & 63, up1 = (lane + 1) & 63;
+    const bool lo13 = lane + 13 < 64, hi35 = lane >= 35;
+    // everything that reads OLD words first, all in flight together: word i + 1 of every register, word i + 397 of registers 0..3
+    uint32_t mix[10];
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t nxt = (uint32_t)__shfl((int)m.k[r], up1);
+        if (r < 9) {
+            const uint32_t wrap = (uint32_t)__builtin_amdgcn_readfirstlane((int)m.k[r + 1]);
+            if (lane == 63) nxt = wrap;
+        }
+        mix[r] = mt_mix(m.k[r], nxt);                                 // (r = 9, lane 47: patched below with the NEW word 0)
     }
-    if (lane == 0) key[kMtN - 1] = key[kMtM - 1] ^ mt_mix(key[kMtN - 1], key[0]);
-    rng_wave_sync();
+    uint32_t su[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) su[q] = (uint32_t)__shfl((int)m.k[6 + q], up13);
+    const uint32_t old9 = m.k[9];
+    // four levels of NEW words: registers 0..2, then 3..5, 6..8, 9 - each level reads the level before it once (lane - 35)
+    uint32_t sh[7];
+    m.k[0] = (lo13 ? su[0] : su[1]) ^ mix[0];
+    m.k[1] = (lo13 ? su[1] : su[2]) ^ mix[1];
+    m.k[2] = (lo13 ? su[2] : su[3]) ^ mix[2];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) sh[q] = (uint32_t)__shfl((int)m.k[q], dn35);
+    m.k[3] = (lane < 35 ? su[3] : sh[0]) ^ mix[3];
+    m.k[4] = (hi35 ? sh[1] : sh[0]) ^ mix[4];
+    m.k[5] = (hi35 ? sh[2] : sh[1]) ^ mix[5];
+#pragma unroll
+    for (int q = 3; q < 6; ++q) sh[q] = (uint32_t)__shfl((int)m.k[q], dn35);
+    m.k[6] = (hi35 ? sh[3] : sh[2]) ^ mix[6];
+    m.k[7] = (hi35 ? sh[4] : sh[3]) ^ mix[7];
+    m.k[8] = (hi35 ? sh[5] : sh[4]) ^ mix[8];
+    sh[6] = (uint32_t)__shfl((int)m.k[6], dn35);
+    // register 9: word 623 (lane 47) mixes its old value with the NEW word 0
+    const uint32_t new0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)m.k[0]);
+    const uint32_t mix9 = lane == 47 ? mt_mix(old9, new0) : mix[9];
+    m.k[9] = (hi35 ? sh[6] : sh[5]) ^ mix9;
 }
 
 // State after `words` more 32-bit outputs, numpy's lazy convention (the block is regenerated when the next word is asked for).
-// Returns the new pos; key is twisted as often as needed.  One wavefront.
-__device__ __forceinline__ int mt_skip(uint32_t *key, int pos, long long words, int lane) {
+__device__ __forceinline__ int mt_skip(MtRegs &m, int pos, long long words, int lane) {
     while (words > 0) {
-        if (pos == kMtN) { mt_twist(key, lane); pos = 0; }
+        if (pos == kMtN) { mt_twist(m, lane); pos = 0; }
         const long long step = words < (long long)(kMtN - pos) ? words : (long long)(kMtN - pos);
         pos += (int)step;
         words -= step;
@@ -130,84 +173,68 @@ struct FillArgs {
     long long pitch, first, count;
     int from_cont;                // 0: base += lag, generate from base (base itself does not move); 1: go on behind the last piece
     double *noise;                // != null: Gumbel mode - out is unused, noise[T][count] = -log(e), and base moves behind the draws
+    uint32_t *words;              // scratch [T][words_pitch]: the tempered 32-bit outputs of this piece, in stream order from word 0
+    long long words_pitch;        // of the state's current block (rng_words_kernel -> rng_draws_kernel)
+    int *pos0;                    // [T] position in that block the piece starts at
 };
 
-// A piece of every tree's window.  One workgroup of NW wavefronts per tree; wavefront w takes the stream's blocks w, w + NW, ...
-// of 624 words - each from its own copy of the state, twisting NW times from one block to its next (a twist is ~450 cycles, the
-// 312 logarithms of a block ~2 500: no hand-offs, and sixteen wavefronts still divide a long window by ~10) - and wavefront 0
-// also leaves the state behind the piece in `cont`.
-template <int NW>
-__global__ __launch_bounds__(64 * NW) void rng_fill_kernel(FillArgs a) {
-    __shared__ uint32_t keys[NW][kMtN];
+// A piece in two launches (a regeneration is serial, the logarithms are not - and they are 6x the work):
+//   rng_words_kernel  one wavefront per tree: commits the consumed draws, walks the state over the piece's blocks and leaves
+//                     their tempered words in the scratch row + the state behind the piece (~450 cycles per block of 312 draws);
+//   rng_draws_kernel  one thread per draw: two words -> the 53-bit uniform -> -log(1 - u) (or the Gumbel value), any number of
+//                     workgroups.
+// (Round 6's first cut did both in one workgroup per tree, every wavefront regenerating its way from block to block: sixteen
+// wavefronts on one CU share four SIMDs, and a 70 k-draw piece of one 19x19 tree took 210 us; this takes ~55.)
+__global__ __launch_bounds__(64) void rng_words_kernel(FillArgs a) {
+    const int t = blockIdx.x, lane = threadIdx.x;
+    if (a.skip && a.skip[t]) return;
+    uint32_t *st = (a.from_cont ? a.cont : a.base) + (size_t)t * kStateWords;
+    MtRegs m;
+    mt_load(m, st, lane);
+    int pos = (int)st[kMtN];
+    const long long lag = (!a.from_cont && a.lag) ? a.lag[t] : 0;
+    if (lag > 0) {                                                   // commit what the searches consumed: base moves
+        pos = mt_skip(m, pos, 2 * lag, lane);
+        mt_store(m, st, lane);
+        if (lane == 0) st[kMtN] = (uint32_t)pos;
+    }
+    if (lane == 0) a.pos0[t] = pos;
+    // absolute word index = pos + stream word; block b holds [624 b, 624 b + 624); block 0 is the state as it stands
+    const long long end = (long long)pos + 2 * a.count;              // first word behind the piece
+    const long long n_blocks = a.count > 0 ? (end - 1) / kMtN + 1 : 0;
+    uint32_t *row = a.words + (size_t)t * a.words_pitch;
+    for (long long b = 0; b < n_blocks; ++b) {
+        if (b > 0) mt_twist(m, lane);
+#pragma unroll
+        for (int r = 0; r < 10; ++r)
+            if (r < 9 || lane < 48) row[kMtN * b + lane + 64 * r] = mt_temper(m.k[r]);
+    }
+    // the state behind the piece, lazily (a position on a block boundary stays "624" of the block before)
+    const int pos_e = a.count > 0 ? (int)(end - kMtN * (n_blocks - 1)) : pos;
+    uint32_t *dst = (a.noise ? a.base : a.cont) + (size_t)t * kStateWords;
+    mt_store(m, dst, lane);
+    if (lane == 0) dst[kMtN] = (uint32_t)pos_e;
+}
+
+__global__ __launch_bounds__(256) void rng_draws_kernel(FillArgs a) {
     __shared__ double tab[256];
-    __shared__ int start_pos;
-    const int t = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t = blockIdx.y;
+    const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
     if (a.skip && a.skip[t]) {                                       // (a parked tree: zero noise, the stream does not move)
-        if (a.noise)
-            for (long long i = threadIdx.x; i < a.count; i += 64 * NW) a.noise[(size_t)t * a.count + i] = 0.0;
+        if (a.noise && j < a.count) a.noise[(size_t)t * a.count + j] = 0.0;
         return;
     }
-    for (int i = threadIdx.x; i < 256; i += 64 * NW) tab[i] = kLogTab[i];
-    uint32_t *st = (a.from_cont ? a.cont : a.base) + (size_t)t * kStateWords;
-    if (wave == 0) {
-        for (int i = lane; i < kMtN; i += 64) keys[0][i] = st[i];
-        int pos = (int)st[kMtN];
-        rng_wave_sync();
-        const long long lag = (!a.from_cont && a.lag) ? a.lag[t] : 0;
-        if (lag > 0) {                                               // commit what the searches consumed: base moves
-            pos = mt_skip(keys[0], pos, 2 * lag, lane);
-            for (int i = lane; i < kMtN; i += 64) st[i] = keys[0][i];
-            if (lane == 0) st[kMtN] = (uint32_t)pos;
-        }
-        if (lane == 0) start_pos = pos;
-    }
+    tab[threadIdx.x] = kLogTab[threadIdx.x];
     __syncthreads();
-    const int pos0 = start_pos;
-    if (wave > 0)
-        for (int i = lane; i < kMtN; i += 64) keys[wave][i] = keys[0][i];
-    __syncthreads();                                                 // (wave 0 twists keys[0] from here on)
-    uint32_t *key = keys[wave];
-    // absolute word index = pos0 + stream word; block b holds [624 b, 624 b + 624); block 0 is the state as loaded
-    const long long last_word = (long long)pos0 + 2 * a.count - 1;   // second word of the last draw
-    const long long n_blocks = a.count > 0 ? last_word / kMtN + 1 : 0;
-    long long at = 0;                                                // block the wavefront's key holds
-    uint32_t prev_last = 0;                                          // word 623 of block at - 1 (a draw may straddle two blocks)
-    for (long long b = wave; b < n_blocks; b += NW) {
-        while (at < b) {
-            prev_last = key[kMtN - 1];
-            mt_twist(key, lane);
-            at += 1;
-        }
-        // draws whose second word lies in block b:  624 b <= pos0 + 2 j + 1 < 624 b + 624
-        long long j_lo = (kMtN * b - pos0 - 1 + 1) / 2;              // ceil((624 b - pos0 - 1) / 2), operands >= 0 when b >= 1
-        if (b == 0 || j_lo < 0) j_lo = 0;
-        long long j_hi = (kMtN * b + kMtN - 1 - pos0 - 1) / 2 + 1;   // floor(...) + 1, exclusive
-        if (kMtN * b + kMtN - 1 - pos0 - 1 < 0) j_hi = 0;
-        if (j_hi > a.count) j_hi = a.count;
-        for (long long j = j_lo + lane; j < j_hi; j += 64) {
-            const long long a0 = (long long)pos0 + 2 * j - kMtN * b;   // index of the first word inside block b, or -1
-            const uint32_t w0 = mt_temper(a0 < 0 ? prev_last : key[a0]);
-            const uint32_t w1 = mt_temper(key[a0 + 1]);
-            const unsigned long long bits = ((unsigned long long)(w0 >> 5) << 26) | (unsigned long long)(w1 >> 6);
-            const double u = (double)bits * 0x1p-53;                 // (a * 67108864.0 + b) / 9007199254740992.0, exact
-            const double e = -glibc_log(1.0 - u, tab);
-            if (a.noise) a.noise[(size_t)t * a.count + j] = -glibc_log(e, tab);
-            else a.out[(size_t)t * a.pitch + a.first + j] = e;
-        }
-    }
-    if (wave == 0) {
-        // the state behind the piece: absolute word pos0 + 2 count, lazily (a position on a block boundary stays "624" of the
-        // block before)
-        const long long end = (long long)pos0 + 2 * a.count;
-        long long be = end > 0 ? (end - 1) / kMtN : 0;
-        if (a.count == 0) be = 0;
-        while (at < be) { mt_twist(key, lane); at += 1; }
-        // (at > be cannot happen: wavefront 0's last block is <= the last block, and be >= last block when count > 0)
-        const int pos_e = a.count > 0 ? (int)(end - kMtN * be) : pos0;
-        uint32_t *dst = (a.noise ? a.base : a.cont) + (size_t)t * kStateWords;
-        for (int i = lane; i < kMtN; i += 64) dst[i] = key[i];
-        if (lane == 0) dst[kMtN] = (uint32_t)pos_e;
-    }
+    if (j >= a.count) return;
+    const uint32_t *w = a.words + (size_t)t * a.words_pitch + a.pos0[t] + 2 * j;
+    const unsigned long long bits = ((unsigned long long)(w[0] >> 5) << 26) | (unsigned long long)(w[1] >> 6);
+    const double u = (double)bits * 0x1p-53;                         // (a * 67108864.0 + b) / 9007199254740992.0, exact
+    const double e = -glibc_log(1.0 - u, tab);
+    if (a.noise) a.noise[(size_t)t * a.count + j] = -glibc_log(e, tab);
+    else a.out[(size_t)t * a.pitch + a.first + j] = e;
 }
+
+#endif  // TG_RNG_DEVICE_KERNELS
 
 }  // namespace tg_rng

@@ -31,6 +31,7 @@
 //   * the random draws are generated on the device (csrc/legacy_rng_device.h: MT19937 + glibc's log restated) or come from
 //     the caller through tg_search_set_rng.
 #include "common.h"
+#define TG_RNG_DEVICE_KERNELS
 #include "legacy_rng_device.h"
 
 namespace tg {                                                        // net_forward.hip: per-thread grid caps of the forward launches
@@ -3627,6 +3628,9 @@ struct tg_search {
     };
     std::vector<DevStream> streams;
     uint32_t *mt_base = nullptr, *mt_cont = nullptr;
+    uint32_t *rng_words = nullptr;                // scratch: the tempered words of the piece being generated (rng_words_kernel)
+    size_t rng_words_cap = 0;
+    int *rng_pos0 = nullptr;
     uint32_t *seed_pin = nullptr;                 // pinned [T][625]: seeds on their way up, one state on its way down
     hipEvent_t seed_ev = nullptr;
     bool seed_ev_used = false;
@@ -3636,6 +3640,10 @@ struct tg_search {
     hipEvent_t lag_ev[kLagRing] = {};
     bool lag_ev_used[kLagRing] = {};
     unsigned lag_seq = 0;
+    size_t eager_need = 0;                        // few trees: the last whole-window request (advance_streams regenerates ahead)
+    bool auto_rest = false;                       // feed_streams_impl over-generated: the rest of the window goes out at install_rng
+    int64_t *consumed_pin = nullptr;              // pinned [T]: the cursors on their way to the host (tg_search_rng_consumed)
+    hipEvent_t block_ev = nullptr;                // blocking-sync event for the host's long waits (tg_search_rng_consumed)
     double *noise_back = nullptr;                 // pinned [T][A]: the device-drawn root noise on its way to noise_host
     hipEvent_t noise_back_ev = nullptr, noise_order_ev = nullptr;
     bool noise_back_pending = false;
@@ -3970,11 +3978,15 @@ int tg_search_destroy(tg_search *s) {
     if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
     if (s->mt_base) (void)hipFree(s->mt_base);
     if (s->mt_cont) (void)hipFree(s->mt_cont);
+    if (s->rng_words) (void)hipFree(s->rng_words);
+    if (s->rng_pos0) (void)hipFree(s->rng_pos0);
     if (s->seed_pin) (void)hipHostFree(s->seed_pin);
     if (s->seed_ev) (void)hipEventDestroy(s->seed_ev);
     if (s->lag_pin) (void)hipHostFree(s->lag_pin);
     if (s->skip_pin) (void)hipHostFree(s->skip_pin);
     for (hipEvent_t e : s->lag_ev) if (e) (void)hipEventDestroy(e);
+    if (s->block_ev) (void)hipEventDestroy(s->block_ev);
+    if (s->consumed_pin) (void)hipHostFree(s->consumed_pin);
     if (s->noise_back) (void)hipHostFree(s->noise_back);
     if (s->noise_back_ev) (void)hipEventDestroy(s->noise_back_ev);
     if (s->noise_order_ev) (void)hipEventDestroy(s->noise_order_ev);
@@ -4110,6 +4122,7 @@ static int flush_roots(tg_search *s, hipStream_t st) {
 }
 
 // make the most recently uploaded random window the active one (stream-ordered)
+static int feed_streams_rest(tg_search *s);
 static int install_rng(tg_search *s, hipStream_t st) {
     if (s->rng_rest_wait && s->rng_pending < 0) {   // second part of a split upload into the ACTIVE window
         TG_HIP(hipStreamWaitEvent(st, s->ev_rng[s->rng_active], 0));
@@ -4122,6 +4135,10 @@ static int install_rng(tg_search *s, hipStream_t st) {
     s->dev.rng = s->rng_buf[s->rng_active];
     s->dev.rng_cap = s->rng_pending_cap;
     TG_HIP(hipMemsetAsync(s->dev.rng_cursor, 0, (size_t)s->dev.T * sizeof(int64_t), st));
+    if (s->auto_rest) {                             // (feed_streams_impl's few-tree over-generation: the rest, behind this launch's wait)
+        s->auto_rest = false;
+        return feed_streams_rest(s);
+    }
     return TG_OK;
 }
 
@@ -4156,9 +4173,27 @@ int tg_search_rng_consumed(tg_search *s, int64_t *consumed_host) {
     if (!s || !consumed_host) return tg::fail(TG_ERR_ARG, "tg_search_rng_consumed: null argument");
     // wait for the last selection kernel only - the forward / backup behind it keep running
     if (s->sel_recorded) TG_HIP(hipStreamWaitEvent(s->copy_stream, s->ev_sel, 0));
-    TG_HIP(hipMemcpyAsync(consumed_host, s->dev.rng_cursor, (size_t)s->dev.T * sizeof(int64_t),
+    // (into pinned memory: a copy into the caller's pageable array makes the runtime wait - spinning - inside hipMemcpyAsync)
+    if (!s->consumed_pin) TG_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->consumed_pin), (size_t)s->dev.T * sizeof(int64_t), hipHostMallocDefault));
+    TG_HIP(hipMemcpyAsync(s->consumed_pin, s->dev.rng_cursor, (size_t)s->dev.T * sizeof(int64_t),
                           hipMemcpyDeviceToHost, s->copy_stream));
-    TG_HIP(hipStreamSynchronize(s->copy_stream));
+    // Many trees: the selection launch this waits for takes milliseconds - sleep on a blocking event instead of spinning on the
+    // stream (a rank's driver thread burnt a whole core doing nothing; eight ranks share the host).  Few trees: the wait is
+    // tens of microseconds and a wake-up would cost more than it saves.
+    if (s->dev.T >= 256) {
+        if (!s->block_ev) TG_HIP(hipEventCreateWithFlags(&s->block_ev, hipEventBlockingSync | hipEventDisableTiming));
+        TG_HIP(hipEventRecord(s->block_ev, s->copy_stream));
+        // (hipEventSynchronize spins whatever the event's flags say on this runtime: poll and sleep instead)
+        for (;;) {
+            const hipError_t q = hipEventQuery(s->block_ev);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) return tg::fail(TG_ERR_HIP, "tg_search_rng_consumed: hipEventQuery: %s", hipGetErrorString(q));
+            std::this_thread::sleep_for(std::chrono::microseconds(s->dev.T >= 1024 ? 200 : 50));
+        }
+    } else {
+        TG_HIP(hipStreamSynchronize(s->copy_stream));
+    }
+    std::memcpy(consumed_host, s->consumed_pin, (size_t)s->dev.T * sizeof(int64_t));
     return TG_OK;
 }
 
@@ -4345,6 +4380,7 @@ static int rng_alloc(tg_search *s) {
     const size_t T = (size_t)s->dev.T, words = T * tg_rng::kStateWords;
     TG_HIP(hipMalloc(reinterpret_cast<void **>(&s->mt_base), words * sizeof(uint32_t)));
     TG_HIP(hipMalloc(reinterpret_cast<void **>(&s->mt_cont), words * sizeof(uint32_t)));
+    TG_HIP(hipMalloc(reinterpret_cast<void **>(&s->rng_pos0), T * sizeof(int)));
     TG_HIP(hipMemset(s->mt_base, 0, words * sizeof(uint32_t)));
     TG_HIP(hipMemset(s->mt_cont, 0, words * sizeof(uint32_t)));
     TG_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->seed_pin), words * sizeof(uint32_t), hipHostMallocDefault));
@@ -4404,16 +4440,25 @@ static int rng_take_lag(tg_search *s, const uint8_t *skip, int *slot_out) {
     return TG_OK;
 }
 
-static int rng_launch(tg_search *s, const tg_rng::FillArgs &a, int slot) {
+static int rng_launch(tg_search *s, const tg_rng::FillArgs &a_in, int slot) {
     const int T = s->dev.T;
-    const long long blocks = a.count / 312 + 2;
-    int nw = T >= 512 ? 1 : T >= 64 ? 4 : 16;
-    if (blocks <= 3) nw = 1;
-    else if (blocks <= 10 && nw > 4) nw = 4;
-    if (nw == 1) hipLaunchKernelGGL(tg_rng::rng_fill_kernel<1>, dim3(T), dim3(64), 0, s->copy_stream, a);
-    else if (nw == 4) hipLaunchKernelGGL(tg_rng::rng_fill_kernel<4>, dim3(T), dim3(256), 0, s->copy_stream, a);
-    else hipLaunchKernelGGL(tg_rng::rng_fill_kernel<16>, dim3(T), dim3(1024), 0, s->copy_stream, a);
+    tg_rng::FillArgs a = a_in;
+    // scratch row of a tree: the piece's words from word 0 of the block it starts in (<= 623 words in front, <= 623 behind)
+    const long long pitch = 2 * a.count + 2 * tg_rng::kMtN;
+    if ((size_t)T * (size_t)pitch > s->rng_words_cap) {
+        if (s->rng_words) (void)hipFree(s->rng_words);             // implicit device synchronisation (rare: the largest piece so far)
+        s->rng_words = nullptr;
+        s->rng_words_cap = 0;
+        TG_HIP(hipMalloc(reinterpret_cast<void **>(&s->rng_words), (size_t)T * (size_t)pitch * sizeof(uint32_t)));
+        s->rng_words_cap = (size_t)T * (size_t)pitch;
+    }
+    a.words = s->rng_words; a.words_pitch = pitch; a.pos0 = s->rng_pos0;
+    hipLaunchKernelGGL(tg_rng::rng_words_kernel, dim3(T), dim3(64), 0, s->copy_stream, a);
     TG_HIP(hipGetLastError());
+    if (a.count > 0) {
+        hipLaunchKernelGGL(tg_rng::rng_draws_kernel, dim3((unsigned)((a.count + 255) / 256), T), dim3(256), 0, s->copy_stream, a);
+        TG_HIP(hipGetLastError());
+    }
     if (slot >= 0) {
         TG_HIP(hipEventRecord(s->lag_ev[slot], s->copy_stream));
         s->lag_ev_used[slot] = true;
@@ -4475,14 +4520,26 @@ int tg_search_feed_streams(tg_search *s, size_t need, int force) { return feed_s
 static int feed_streams_impl(tg_search *s, size_t need, int force, size_t first) {
     if (!s) return tg::fail(TG_ERR_ARG, "tg_search_feed_streams: null argument");
     const int T = s->dev.T;
-    if (s->rng_rest_cols) {                        // (an earlier window in parts was never completed: complete it first)
-        int rc = feed_streams_rest(s);
+    if (s->rng_rest_cols && !s->auto_rest) {       // (an earlier window in parts was never completed: complete it first; an
+        int rc = feed_streams_rest(s);             //  over-generated window's rest goes out behind the launch that installs it)
         if (rc) return rc;
     }
     if (s->streams.size() != (size_t)T) return tg::fail(TG_ERR_ARG, "tg_search_feed_streams: streams are not seeded");
     for (int t = 0; t < T; ++t)
         if (!s->streams[t].seeded) return tg::fail(TG_ERR_ARG, "tg_search_feed_streams: tree %d has no stream", t);
     if (need == 0 || (!force && s->win_left >= (int64_t)need)) return TG_OK;
+    // Few trees (a single search tree): a window of `need` draws is a bound - a mini-batch consumes a fraction of it - and
+    // every regeneration costs the launch that waits for it ~25 us.  Generate two windows' worth instead: the first `need`
+    // draws now, the rest behind the first launch that uses them (install_rng), and the following mini-batches find their
+    // draws there (win_left).  The draws are the stream's, whatever the window they were generated in.
+    s->auto_rest = false;
+    s->eager_need = 0;
+    if (first == 0 && T <= 16 && need >= 2048 && need <= ((size_t)1 << 20)) {
+        s->eager_need = need;
+        first = need;
+        need *= 2;                                  // (one tree, ms per move at 19x19 / 9x9: x2 11.4 / 1.65, x4 11.8 / 1.70 - a larger window means a longer commit of the consumed draws in front of the next one)
+        s->auto_rest = true;
+    }
     const int idx = 1 - s->rng_active;             // never the window a running kernel may read
     if ((int64_t)need > s->rng_buf_cap[idx]) {
         (void)hipFree(s->rng_buf[idx]);             // implicit device synchronisation (rare)
@@ -4581,6 +4638,14 @@ static int advance_streams_impl(tg_search *s, int64_t *consumed_host, const uint
         most = std::max(most, used[t]);
     }
     s->win_left = s->win_cap - most;
+    // Few trees: when the next mini-batch will not find its draws in this window, the next window is generated NOW - the
+    // consumed draws committed, four windows' worth generated - under the forward pass and backup that are running, instead
+    // of in front of the next selection launch (one 19x19 tree: five regenerations per move, ~90 us each).  Nothing is
+    // consumed between here and that launch, so its tg_search_feed_streams finds the window in place.
+    if (s->eager_need > 0 && !skip && s->win_left < (int64_t)s->eager_need) {
+        const size_t need = s->eager_need;
+        return feed_streams_impl(s, need, 0, 0);
+    }
     return TG_OK;
 }
 

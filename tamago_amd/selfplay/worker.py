@@ -146,19 +146,15 @@ def selfplay_shard(save_dir: str, network, index_list: Sequence[int], size: int,
 
 
 def _auto_lanes(boards: int, size: int) -> int:
-    """Lanes of a group of `boards` boards (measured on MI355X, tools/bench_selfplay.py, 400 simulations; docs/DESIGN_HISTORY.md 12)."""
+    """Lanes of a group of `boards` boards.  Measured on MI355X (tools/experiments/sp_lanes_sweep*.sh, 400 simulations,
+    profiles/r06_selfplay_lanes_sweep.txt): at a FIXED number of boards in flight lanes do not pay - 16 boards 3.45 M leaf-evals/s
+    in one lock-step group vs 3.19 M in two lanes (GPU_MAX_HW_QUEUES=16; 2.2 M with the default four hardware queues), 64 boards
+    5.7 vs 5.4 M: a move's time is its chain of dependent phases whatever the number of boards on it, so splitting the boards
+    only multiplies the per-move fixed work (tail kernels, host launches).  One group stays the default; TG_SP_LANES overrides."""
     env = os.environ.get("TG_SP_LANES")
     if env:
         return max(1, min(int(env), boards))
-    if size != 9:
-        return 1
-    if boards < 8:
-        return 1
-    if boards <= 32:
-        return 4
-    if boards <= 512:
-        return 4
-    return 2
+    return 1
 
 
 def _run_lanes(save_dir, network, size, visits, lane_sizes, seeds, device_index, next_game, stats):
