@@ -824,7 +824,14 @@ def main():
             result["fp32_exact"] = {"value": l2 / e2, "unit": "leaf-evals/s", "dtype": "f32", "steps": 2, "warmup": 1,
                                     "ms_per_step": e2 / 2 * 1e3, "workload": result["config"]["workload"] +
                                     f", {args.trees} trees, TG_FWD_ALGO=wino (exact fp32 operands on the fp32 MFMA)",
-                                    "roofline": roof2}
+                                    "roofline": roof2,
+                                    "note": "fallback path only (the exact redo behind the f16 range guard; rare: range_fallbacks), "
+                                            "not tuned: its HBM-side traffic is ~24x the algorithmic bytes and half of its LDS-active "
+                                            "cycles are bank conflicts (profiles/r05_pmc_forward_wino_9x9_b65536.json).  Its "
+                                            "roofline.frac divides the DIRECT-convolution FLOP count (72.28 MFLOP per position) by the "
+                                            "fp32 matrix peak although the kernel is a Winograd F(2x2,3x3) tower that issues 2.25x fewer "
+                                            "products - a frac above 1 is therefore possible and says nothing about utilisation; "
+                                            "mfma_issue_frac (issued MFMA FLOPs over the same peak) is the utilisation figure"}
         except Exception as exc:                          # the headline must not depend on a leg
             result["fp32_exact"] = {"error": repr(exc)}
         finally:

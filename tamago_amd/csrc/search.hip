@@ -1679,7 +1679,7 @@ struct SplitWrkShared {
 template <int S, int NNODE, int NWRK, int NSHIP, int NWG>
 __global__ __launch_bounds__(1024) void select_puct_split_kernel(SearchDev D, int max_leaves, float *planes, int *xw_job,
                                                                    int *xw_done, int *xw_n, unsigned long long *xw_off,
-                                                                   int tag_base, int cap) {
+                                                                   int tag_base, int cap, int test_mute) {
     using G = Geo<S>;
     constexpr int A = G::A;
     constexpr int R = (A + 63) / 64;
@@ -1688,6 +1688,9 @@ __global__ __launch_bounds__(1024) void select_puct_split_kernel(SearchDev D, in
     const int t = blockIdx.x / (1 + NWG);
     const int role = blockIdx.x % (1 + NWG);          // 0: selecting half, 1 .. NWG: workers
     const bool selecting = role == 0;
+    // test hook (TG_SPLIT_TEST_MUTE): the worker workgroups of a tree never show up - the selecting half must run into its
+    // bounded waits and report a stalled pipeline (kErrPipeline), not hang (tests/test_gpu_search.py)
+    if (test_mute && !selecting) return;
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const RootMeta meta = D.meta[t];
     const int n0 = meta.num_nodes;
@@ -3850,7 +3853,8 @@ int launch_split_cfg(tg_search *s, int max_leaves, float *planes, hipStream_t st
     }
     if ((long long)(1 + NWG) * T > (long long)s->split_per_cu * s->num_cus) return kSplitNoRoom;
     hipLaunchKernelGGL((select_puct_split_kernel<S, NNODE, NWRK, NSHIP, NWG>), dim3((1 + NWG) * T), dim3(1024), lds, st, s->dev,
-                       max_leaves, planes, s->xw_job, s->xw_done, s->xw_n, s->xw_off, (int)((s->xw_seq & 0xFFFFFu) << 11), s->xw_cap);
+                       max_leaves, planes, s->xw_job, s->xw_done, s->xw_n, s->xw_off, (int)((s->xw_seq & 0xFFFFFu) << 11), s->xw_cap,
+                       tg::knob("TG_SPLIT_TEST_MUTE") ? 1 : 0);
     return TG_OK;
 }
 
@@ -4659,13 +4663,16 @@ static int noise_host_sync(tg_search *s) {
     return TG_OK;
 }
 
-static int draw_noise_impl(tg_search *s, double *noise_host, const uint8_t *skip);
+static int draw_noise_impl(tg_search *s, double *noise_host, const uint8_t *skip, hipEvent_t order_after = nullptr);
 int tg_search_draw_noise(tg_search *s, double *noise_host) { return draw_noise_impl(s, noise_host, nullptr); }
 
 // node.py:275-278 for every root: A draws of each tree's stream as Gumbel(0, 1) = -log(-log(1 - u)), generated on the device
 // straight into the root noise rows, in stream order behind the kernels that read the previous noise and ahead of the next
 // selection.  skip[t] != 0: tree t draws nothing (zero noise) - its stream must not move yet.
-static int draw_noise_impl(tg_search *s, double *noise_host, const uint8_t *skip) {
+// order_after: an event the caller knows to lie behind every reader of the previous noise (self-play's chained moves: the
+// cursor event, recorded right behind the root expansion - the noise is then generated UNDER the root's forward pass and
+// backup instead of behind them); null: behind everything queued on the launch stream so far.
+static int draw_noise_impl(tg_search *s, double *noise_host, const uint8_t *skip, hipEvent_t order_after) {
     if (!s) return tg::fail(TG_ERR_ARG, "tg_search_draw_noise: null argument");
     const int T = s->dev.T, A = s->A;
     if (s->streams.size() != (size_t)T) return tg::fail(TG_ERR_ARG, "tg_search_draw_noise: streams are not seeded");
@@ -4674,7 +4681,9 @@ static int draw_noise_impl(tg_search *s, double *noise_host, const uint8_t *skip
     int rc, slot = -1;
     if ((rc = noise_host_sync(s))) return rc;                       // (the staging rows are about to be rewritten)
     if ((rc = rng_sync_seeds(s)) || (rc = rng_take_lag(s, skip, &slot))) return rc;
-    if (s->stream_known) {
+    if (order_after) {
+        TG_HIP(hipStreamWaitEvent(s->copy_stream, order_after, 0));
+    } else if (s->stream_known) {
         TG_HIP(hipEventRecord(s->noise_order_ev, s->last_stream));
         TG_HIP(hipStreamWaitEvent(s->copy_stream, s->noise_order_ev, 0));
     } else {
@@ -4745,7 +4754,11 @@ static int launch_gumbel_select(tg_search *s, const SearchDev &D, const int32_t 
     static const int workers_env = tg::knob("TG_GUMBEL_WORKERS") ? atoi(tg::knob("TG_GUMBEL_WORKERS")) : 0;
     const int workers = workers_env ? workers_env : (s->dev.T <= 128 ? 6 : 2);
     const bool gpipe = s->S == 9 && !force_serial && limit <= kPipeMaxK / 2 && D.N <= (1 << 21);   // (paths as node << 10 | edge)
-    if (gpipe && workers == 6)
+    if (gpipe && workers == 15)
+        hipLaunchKernelGGL((select_gumbel_pipe_kernel<9, 15>), dim3(T), dim3(64 * 16), 0, st, D, nc_dev, mc_dev, limit, off, planes_dev);
+    else if (gpipe && workers == 10)
+        hipLaunchKernelGGL((select_gumbel_pipe_kernel<9, 10>), dim3(T), dim3(64 * 11), 0, st, D, nc_dev, mc_dev, limit, off, planes_dev);
+    else if (gpipe && workers == 6)
         hipLaunchKernelGGL((select_gumbel_pipe_kernel<9, 6>), dim3(T), dim3(64 * 7), 0, st, D, nc_dev, mc_dev, limit, off, planes_dev);
     else if (gpipe && workers == 4)
         hipLaunchKernelGGL((select_gumbel_pipe_kernel<9, 4>), dim3(T), dim3(64 * 5), 0, st, D, nc_dev, mc_dev, limit, off, planes_dev);
@@ -5786,7 +5799,8 @@ static int chain_begin(tg_selfplay *sp, tg_net *net, float *planes_dev, float *p
     sp->nc_known = true;
     sp->nc_cursor = sp->nc;
     lap(0);
-    if ((rc = draw_noise_impl(s, nullptr, sp->skip_fresh.data()))) return rc;      // (generated on the device, legacy_rng_device.h)
+    // (generated on the device, legacy_rng_device.h; the readers of the last noise - phases, finish_roots_kernel - lie before cur_ev)
+    if ((rc = draw_noise_impl(s, nullptr, sp->skip_fresh.data(), sp->chain_started ? s->cur_ev : nullptr))) return rc;
     lap(1);
     // ---- sequential halving (tree.py:375-384) ----
     constexpr int kMaxPhases = tg_selfplay::kMaxPhases;

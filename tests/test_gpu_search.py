@@ -428,3 +428,45 @@ def test_play_of_the_most_visited_child_on_the_device_equals_the_host_choice(siz
 
     for (ca, ma, ta), (cb, mb, tb) in zip(run(False), run(True)):
         assert np.array_equal(ca, cb) and np.array_equal(ma, mb) and np.array_equal(ta, tb)
+
+
+def test_split_selector_with_a_muted_worker_workgroup_reports_a_stall_instead_of_hanging():
+    """select_puct_split_kernel spans three workgroups per tree that hand work to each other through memory (tagged job
+    entries, agent scope) - correct only while all of them are resident.  Every wait is bounded: with the worker workgroups
+    muted (TG_SPLIT_TEST_MUTE: they exit at once, as if they had never been scheduled) the selecting half runs into its limits,
+    the launch ENDS, and the next read reports a stalled pipeline for the tree - the library's answer to a device that cannot
+    hold a tree's workgroups together (a shared device takes the one-workgroup kernels from the start, TG_SHARED_DEVICE).  A
+    fresh search in the same process, hook off, is unaffected.  (Subprocess: the hook is read once per launch from the
+    environment, the error is sticky per tree.)"""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import sys, time, numpy as np, torch
+sys.path.insert(0, %r)
+from oracle.stubnet import StubNet
+from tamago_amd.board.go_board import GoBoard
+from tamago_amd.mcts.engine import SearchEngine, HostEvaluator
+from tamago_amd.lib import TamagoHipError
+dev = torch.device("cuda", 0)
+eng = SearchEngine(9, 2, 600, 64, HostEvaluator(StubNet(salt=5), dev))
+board = GoBoard(9, 7.0, False)
+for t in range(2):
+    eng.set_root(t, board, 1, np.random.RandomState(t).get_state())
+eng.root_eval(False, first_batch=64)
+t0 = time.time()
+try:
+    eng.puct_batch(64)
+    eng.read_root_stats()
+    print("NO ERROR")
+except TamagoHipError as exc:
+    print("ERROR after %%.1f s: %%s" %% (time.time() - t0, exc))
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TG_DEBUG_KNOBS="1", TG_SPLIT_TEST_MUTE="1", TG_SELECT_SPLIT="1")
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    last = res.stdout.strip().splitlines()[-1]
+    assert last.startswith("ERROR after") and "pipeline stalled" in last, res.stdout[-1000:] + res.stderr[-1000:]
+    env.pop("TG_SPLIT_TEST_MUTE")
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and res.stdout.strip().splitlines()[-1] == "NO ERROR", res.stdout[-1000:] + res.stderr[-1000:]
