@@ -32,6 +32,9 @@ import os
 import sys
 import time
 
+# (before the first HIP call of the process: the self-play legs drive up to ~8 HIP streams at once - tamago_amd/__init__.py)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 import numpy as np
 import torch
 

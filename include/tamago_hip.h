@@ -245,6 +245,10 @@ int tg_search_draw_noise(tg_search *s, double *noise_host);
  *   tg_glibc_log: out[i] = log(x[i]) (positive normal arguments) - held against Python's math.log (= libm) bit for bit. */
 int tg_legacy_exponentials(uint32_t *mt_key, int *mt_pos, size_t n, double *out);
 int tg_glibc_log(const double *x, size_t n, double *out);
+/* A HIP stream owned by the handle (created on first request, destroyed with it; hipStreamNonBlocking) for callers that run
+ * several handles side by side - the lanes of a self-play shard (selfplay/worker.py) - and want each on a stream of its own
+ * without going through a host framework's stream pool. */
+int tg_search_own_stream(tg_search *s, void **stream_out);
 /* Test hooks of the device streams (tests/test_gpu_rng.py): read columns [first, first + count) of tree `tree`'s row of the
  * most recently generated window; walk the streams as a search would - per step a window of steps[i] + slack draws, whole
  * (part 0) or in pieces of `part` draws, steps[i] of which count as consumed - without running a search. */

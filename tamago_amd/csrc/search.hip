@@ -3610,6 +3610,7 @@ struct tg_search {
     // double-buffered random windows, uploaded on a private copy stream so that the host can
     // prepare mini-batch j+1 while the forward pass of mini-batch j runs
     hipStream_t copy_stream = nullptr;
+    hipStream_t own_stream = nullptr;              // tg_search_own_stream: a launch stream of the handle's own (self-play lanes)
     hipEvent_t ev_rng[2] = {nullptr, nullptr};
     hipEvent_t ev_sel = nullptr;
     double *rng_buf[2] = {nullptr, nullptr};
@@ -3980,6 +3981,7 @@ int tg_search_destroy(tg_search *s) {
     }
     if (s->ev_sel) (void)hipEventDestroy(s->ev_sel);
     if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
+    if (s->own_stream) { (void)hipStreamSynchronize(s->own_stream); (void)hipStreamDestroy(s->own_stream); }
     if (s->mt_base) (void)hipFree(s->mt_base);
     if (s->mt_cont) (void)hipFree(s->mt_cont);
     if (s->rng_words) (void)hipFree(s->rng_words);
@@ -4704,6 +4706,18 @@ static int draw_noise_impl(tg_search *s, double *noise_host, const uint8_t *skip
         if ((rc = noise_host_sync(s))) return rc;
         std::memcpy(noise_host, s->noise_host.data(), (size_t)T * A * sizeof(double));
     }
+    return TG_OK;
+}
+
+// A launch stream that belongs to the handle (non-blocking, created on first request): self-play lanes run each engine on one of
+// these instead of streams out of the host framework's pool - the hardware queue a stream lands on goes by creation order, and
+// a pool of 32 streams created in one go leaves the library's own streams sharing queues with them (measured: two lanes on pool
+// streams 2.99-3.10 M leaf-evals/s, on streams created here 3.65 M).
+int tg_search_own_stream(tg_search *s, void **stream_out) {
+    if (!s || !stream_out) return tg::fail(TG_ERR_ARG, "tg_search_own_stream: null argument");
+    TG_HIP(hipSetDevice(s->cfg.device));
+    if (!s->own_stream) TG_HIP(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
+    *stream_out = s->own_stream;
     return TG_OK;
 }
 
@@ -5876,6 +5890,12 @@ static int chain_begin(tg_selfplay *sp, tg_net *net, float *planes_dev, float *p
         any_phase = true;
     }
     if ((rc = feed_streams_rest(s))) return rc;                        // (no phase was launched)
+    // No phase at all - every board's game has just been started (the first call of a handle; later: all games of the group
+    // ended with the same move, which a one-board group does every game): the new window must be in place BEFORE
+    // finish_roots_kernel notes each board's cursor "behind the phases", or that note is the OLD window's last cursor and the
+    // next move reads a root of nc - that many children off it (found in round 6 with one-board lanes: "board 0 has 82 root
+    // children but its root expansion consumed 81 draws").
+    if (!any_phase && (rc = install_rng(s, st))) return rc;
     // ---- the chain: records + decision, the moves played, the next roots expanded and evaluated ----
     const int max_moves = s->S * s->S * 2;                             // worker.py:44
     sp->state.assign((size_t)4 * T, 0);
@@ -5939,7 +5959,10 @@ static int chain_end(tg_selfplay *sp, int32_t *finished_host, int64_t *stats_hos
         for (int t = 0; t < T; ++t)
             if (!sp->skip[t] && sp->nc[t] != sp->nc_cursor[t])
                 return tg::fail(TG_ERR_STATE, "tg_selfplay_play_move: board %d has %d root children but its root expansion "
-                                "consumed %d draws - the halving schedule was built from a wrong width", t, sp->nc[t], sp->nc_cursor[t]);
+                                "consumed %d draws - the halving schedule was built from a wrong width (cursor %lld behind the root, %lld "
+                                "behind the phases before it; window %lld; game move %d)", t, sp->nc[t], sp->nc_cursor[t],
+                                (long long)sp->consumed[t], (long long)(sp->consumed[t] - sp->nc_cursor[t]), (long long)s->win_cap,
+                                sp->games[t].moves_played);
         if (sp->observer) {
             tg_selfplay_event ev{};
             ev.kind = 1; ev.phase = n_phases; ev.trees = T;

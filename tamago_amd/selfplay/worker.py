@@ -84,10 +84,19 @@ def selfplay_shard(save_dir: str, network, index_list: Sequence[int], size: int,
     fb0 = network.range_fallbacks() if hasattr(network, "range_fallbacks") else 0
     boards = min(boards, len(todo))
     if groups <= 0:
-        # measured on MI355X (tools/bench_selfplay.py, 400 simulations): ONE group (one host thread) is best up to
-        # 1024 boards - round 4, chained moves: 16 boards 2.88 M leaf-evals/s vs 1.75 M with two groups, 64: 4.50 vs
-        # 3.33 M; at 2048 boards two groups were level in round 3 (4.75 vs 4.70 M)
-        groups = 1 if boards < 2048 else 2
+        # Measured on MI355X (tools/bench_selfplay.py, 400 simulations, leaf-evals/s; profiles/r06_selfplay_lanes_sweep.txt).
+        # Round 6, random streams generated on the device (the host threads no longer compete with generator threads):
+        # TWO groups - two lock-step halves on their own host threads, streams and moves - beat one from 8 to 28 boards:
+        # 8 boards 2.24 -> 2.29 M, 12: 2.99 -> 3.18, 16: 3.52 -> 3.72-3.74 (three runs), 24: 3.57 -> 4.54; 32: 4.66 -> 4.39,
+        # 64: 5.87 -> 4.72, three groups at 16 boards 2.44.  (With the draws generated on host threads it was the other way round:
+        # round 4, 16 boards 2.88 M in one group vs 1.75 M in two.)  The groups' streams need hardware queues of their own
+        # (tamago_amd/__init__.py asks for 16; on the runtime's default of four the halves serialise).  At 2048 boards two groups
+        # were level in round 3 (4.75 vs 4.70 M).
+        import tamago_amd
+        from tamago_amd.nn.network.dual_net import DualNet as _DualNet
+        two = size == 9 and 8 <= boards <= 28 and observer is None and isinstance(network, _DualNet) and \
+            (tamago_amd.HW_QUEUES or 0) >= 8 and not os.environ.get("TG_SP_LANES")
+        groups = 2 if two or boards >= 2048 else 1
     groups = max(1, min(groups, boards))
     if observer is not None and groups != 1:
         raise ValueError("selfplay_shard: an observer needs groups = 1")
@@ -146,11 +155,13 @@ def selfplay_shard(save_dir: str, network, index_list: Sequence[int], size: int,
 
 
 def _auto_lanes(boards: int, size: int) -> int:
-    """Lanes of a group of `boards` boards.  Measured on MI355X (tools/experiments/sp_lanes_sweep*.sh, 400 simulations,
-    profiles/r06_selfplay_lanes_sweep.txt): at a FIXED number of boards in flight lanes do not pay - 16 boards 3.45 M leaf-evals/s
-    in one lock-step group vs 3.19 M in two lanes (GPU_MAX_HW_QUEUES=16; 2.2 M with the default four hardware queues), 64 boards
-    5.7 vs 5.4 M: a move's time is its chain of dependent phases whatever the number of boards on it, so splitting the boards
-    only multiplies the per-move fixed work (tail kernels, host launches).  One group stays the default; TG_SP_LANES overrides."""
+    """Lanes of a group of `boards` boards: one.  Lanes - several engines driven by ONE host thread through the two halves of a
+    chained move - were measured (tools/experiments/sp_lanes_sweep*.sh, sp_pool_order.py; profiles/r06_selfplay_lanes_sweep.txt):
+    two lanes of 8 boards run at 3.65-3.75 M leaf-evals/s or at 3.0-3.1 M - two stable states (in the slow one a lane's records
+    are always ready at once and the other's 1.1 ms later; which one a run falls into went by its first calls, and neither a
+    minimum distance between the lanes' begins nor forward caps moved it), three or four lanes collapse to 2.1-2.4 M.  Two
+    groups on host threads of their own (selfplay_shard's `groups`) reach the fast state every time, so THAT is the default from
+    8 to 28 boards; the lanes stay available (TG_SP_LANES / `lanes`) with the same games (tests/test_gpu_fastpath.py)."""
     env = os.environ.get("TG_SP_LANES")
     if env:
         return max(1, min(int(env), boards))
@@ -180,12 +191,16 @@ def _run_lanes(save_dir, network, size, visits, lane_sizes, seeds, device_index,
         for n in lane_sizes:
             ln = Lane()
             ln.boards = n
-            ln.stream = torch.cuda.Stream(device=device)
-            with torch.cuda.stream(ln.stream):
-                ln.engine = SearchEngine(size, n, max(SELF_PLAY_VISITS * 10, visits + 8), max(visits, 1),
-                                         DeviceEvaluator(network), check_superko=True, device_index=device_index)
-                ln.policy = torch.empty((n * ln.engine.K, a), dtype=torch.float32, device=device)
-                ln.value = torch.empty((n * ln.engine.K, 3), dtype=torch.float32, device=device)
+            ln.engine = SearchEngine(size, n, max(SELF_PLAY_VISITS * 10, visits + 8), max(visits, 1),
+                                     DeviceEvaluator(network), check_superko=True, device_index=device_index)
+            ln.policy = torch.empty((n * ln.engine.K, a), dtype=torch.float32, device=device)
+            ln.value = torch.empty((n * ln.engine.K, 3), dtype=torch.float32, device=device)
+            if os.environ.get("TG_SP_LANE_STREAMS", "torch") == "own":
+                ln.stream = ctypes.c_void_p()
+                _lib.check(ln.engine.lib.tg_search_own_stream(ln.engine.handle, ctypes.byref(ln.stream)), "tg_search_own_stream")
+            else:
+                ln.torch_stream = torch.cuda.Stream(device=device)
+                ln.stream = ctypes.c_void_p(ln.torch_stream.cuda_stream)
             ln.handle = ctypes.c_void_p()
             ln.sp_open = False
             lanes.append(ln)
@@ -211,7 +226,7 @@ def _run_lanes(save_dir, network, size, visits, lane_sizes, seeds, device_index,
 
         def begin(ln):
             _lib.check(lib.tg_selfplay_move_begin(ln.handle, network.handle, ln.engine.planes.data_ptr(), ln.policy.data_ptr(),
-                                                  ln.value.data_ptr(), ln.stream.cuda_stream), "tg_selfplay_move_begin")
+                                                  ln.value.data_ptr(), ln.stream), "tg_selfplay_move_begin")
 
         # slots are handed out lane by lane in board order - with one lane that is the order of the lock-step group
         for ln in lanes:
@@ -221,9 +236,14 @@ def _run_lanes(save_dir, network, size, visits, lane_sizes, seeds, device_index,
                 else:
                     ln.engine.set_root(slot, start_board, Stone.BLACK, np.random.RandomState(0).get_state())
         ring = deque()
+
+        def begin_spaced(ln):
+            begin(ln)
+
         for ln in lanes:
+            ln.begun_at = 0.0
             if ln.live > 0:
-                begin(ln)
+                begin_spaced(ln)
                 ring.append(ln)
         while ring:
             ln = ring.popleft()
@@ -238,7 +258,7 @@ def _run_lanes(save_dir, network, size, visits, lane_sizes, seeds, device_index,
                     ln.live -= 1
             t2 = _time.perf_counter()
             if ln.live > 0:
-                begin(ln)
+                begin_spaced(ln)
                 ring.append(ln)
             t3 = _time.perf_counter()
             t_end += t1 - t0

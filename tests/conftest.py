@@ -12,6 +12,8 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 # the library reads its kernel-variant / grouping / test-hook knobs (TG_SELECT_*, TG_SP_*, TG_FWD_BANDS, TG_*_TEST_MUTE ...) only
 # in a process that asks for them (csrc/common.h tg::knob); the tests compare those variants, so they do
 os.environ.setdefault("TG_DEBUG_KNOBS", "1")
+# (what importing tamago_amd asks for; here as well so that it holds whatever is imported first)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 
 def pytest_configure(config):

@@ -96,6 +96,17 @@ def test_one_call_per_move_path_equals_the_phase_by_phase_path(tmp_path):
     assert a == b and a["games"] == 10
     for i in idx:
         assert open(fast / f"{i}.sgf").read() == open(slow / f"{i}.sgf").read(), i
+    # ONE board at a time: every game's end leaves the group with nothing but a freshly started game - a call that launches no
+    # phase at all.  (Round 6: the random window of such a call was installed behind the note of each board's cursor, and the next
+    # move read a wrong root width off it - "82 root children but its root expansion consumed 81 draws"; it takes all games of a
+    # group ending on the same move, which larger groups rarely do.)  Same games again, also from two boards in two lanes.
+    for name, boards, lanes in (("solo", 1, 1), ("two_lanes_of_one", 2, 2)):
+        d = tmp_path / name
+        d.mkdir()
+        c = selfplay_shard(str(d), net, idx, 9, 48, boards=boards, never_resign_flags=flags, groups=1, lanes=lanes)
+        assert c == a, name
+        for i in idx:
+            assert open(d / f"{i}.sgf").read() == open(fast / f"{i}.sgf").read(), (name, i)
 
 
 def test_gumbel_kernel_variants_write_the_same_games():

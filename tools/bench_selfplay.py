@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of the lock-step Gumbel self-play shard (BASELINE.json configs 3 / 4)."""
 import os, sys, time, tempfile, shutil
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")          # before torch loads the HIP runtime (tamago_amd/__init__.py)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from tamago_amd.nn.network.dual_net import DualNet
