@@ -82,7 +82,7 @@ def pmc_summary(kernel_name, size=9):
             d["file"] += " + " + " + ".join(e["file"] for e in extra)
         return d
     sys.stderr.write(f"bench.py: no PMC summary in profiles/ for kernel {kernel_name!r} at csrc digest {digest} - "
-                     "roofline.traffic is null (run tools/pmc_r03.sh on the GPU box and commit the summary)\n")
+                     "roofline.traffic is null (run tools/pmc_r06.sh on the GPU box and commit the summary)\n")
     return None
 
 
@@ -104,7 +104,7 @@ def tree_pmc_summary():
                                  "avg_duration_us": k["avg_duration_us"]}
             return out
     sys.stderr.write(f"bench.py: no tree-kernel PMC summary in profiles/ at csrc digest {digest} - tree_kernels is null "
-                     "(run tools/pmc_r03.sh on the GPU box and commit the summary)\n")
+                     "(run tools/pmc_r06.sh on the GPU box and commit the summary)\n")
     return None
 
 

@@ -103,6 +103,9 @@ extern "C" int tg_featurize_sym_dev(int board_size, const uint8_t *cells_dev, co
     if (board_size == 9)
         hipLaunchKernelGGL(featurize_kernel<9>, grid, block, 0, st, cells_dev, to_move_dev,
                            prev_move_dev, moves_dev, sym_dev, batch, planes_dev);
+    else if (board_size == 13)
+        hipLaunchKernelGGL(featurize_kernel<13>, grid, block, 0, st, cells_dev, to_move_dev,
+                           prev_move_dev, moves_dev, sym_dev, batch, planes_dev);
     else if (board_size == 19)
         hipLaunchKernelGGL(featurize_kernel<19>, grid, block, 0, st, cells_dev, to_move_dev,
                            prev_move_dev, moves_dev, sym_dev, batch, planes_dev);

@@ -696,8 +696,10 @@ int tg_net_board_size(const tg_net *net) { return net ? net->board_size : 0; }
 
 int tg_net_create(int board_size, int device, const float *params, size_t n_params, tg_net **out) {
     if (!out || !params) return tg::fail(TG_ERR_ARG, "tg_net_create: null argument");
-    if (board_size != 9 && board_size != 19)
-        return tg::fail(TG_ERR_ARG, "tg_net_create: board size %d not built (9 and 19 are)", board_size);
+    // 9 and 19 have the f16-pipe towers; 13 runs on the exact-fp32 direct kernel (dualnet_fwd_kernel<13, 1>: generic in the
+    // board size, fp32 MFMA) - the reference's results within the same 1e-4, a fraction of the speed
+    if (board_size != 9 && board_size != 19 && board_size != 13)
+        return tg::fail(TG_ERR_ARG, "tg_net_create: board size %d not built (9, 13 and 19 are)", board_size);
     if (n_params != tg_net_param_count(board_size))
         return tg::fail(TG_ERR_ARG, "tg_net_create: expected %zu parameters, got %zu",
                         tg_net_param_count(board_size), n_params);
@@ -963,6 +965,7 @@ static int tail_positions(const tg_net *net, int batch) {
 
 const char *tg_net_kernel_name(const tg_net *net, int batch) {
     if (!net) return "";
+    if (net->board_size == 13) return "dualnet_fwd_kernel<13, 1>";
     if (tail_positions(net, batch) > 0) {              // two launches: name both
         if (pick_w1d(9, batch, net->num_cus)) return "dualnet_fwd_w1d_kernel<3> + dualnet_fwd_w1d_kernel<1> (ragged tail)";
         return "dualnet_fwd_split_kernel<9, 3, f16x2> + dualnet_fwd_split_kernel<9, 1, f16x2> (ragged tail)";
@@ -1025,7 +1028,7 @@ double tg_net_executed_flops_per_position(const tg_net *net, int batch, double *
         const int tiles = g * ((S + 1) / 2) * ((S + 1) / 2), rt = (tiles + 15) / 16, mt = (g * P + 15) / 16;
         flops = (12.0 * 16 * 4 * rt * 16 + 9.0 * 2 * 4 * mt) * 2048.0 / g;
     } else {
-        const int g = pick_group(S, batch, net->num_cus), mt = (g * P + 15) / 16;
+        const int g = S == 13 ? 1 : pick_group(S, batch, net->num_cus), mt = (g * P + 15) / 16;
         flops = (12.0 * 9 * 16 * 4 * mt + 9.0 * 2 * 4 * mt) * 2048.0 / g;
     }
     if (peak_tflops) *peak_tflops = peak;
@@ -1141,6 +1144,7 @@ int tg_net_forward_dev(tg_net *net, const float *planes_dev, int batch, int want
         if (wg == 2) return launch_wino8<9, 2>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st);
         if (wg == 3) return launch_wino8<9, 3>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st);
     }
+    if (net->board_size == 13) return launch<13, 1>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st);
     const int g = pick_group(9, batch, net->num_cus);
     if (g == 3) return launch<9, 3>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st);
     return launch<9, 1>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st);

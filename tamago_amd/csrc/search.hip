@@ -3886,8 +3886,11 @@ extern "C" {
 
 int tg_search_create(const tg_search_config *cfg, tg_search **out) {
     if (!cfg || !out) return tg::fail(TG_ERR_ARG, "tg_search_create: null argument");
-    if (cfg->board_size != 9 && cfg->board_size != 19)
-        return tg::fail(TG_ERR_ARG, "tg_search_create: board size %d not built (9 and 19 are)", cfg->board_size);
+    // 9 and 19 have the tuned kernels; 13 (the third size TamaGo is played at: board/constant.py:4 BOARD_SIZE is a free
+    // constant, main.py --size) runs on the board-size-generic ones (one wavefront per tree for selection, the 19x19 backup) -
+    // same trees, no pipelining.  Other sizes: instantiate them below (kGenericSize) and rebuild.
+    if (cfg->board_size != 9 && cfg->board_size != 19 && cfg->board_size != 13)
+        return tg::fail(TG_ERR_ARG, "tg_search_create: board size %d not built (9, 13 and 19 are)", cfg->board_size);
     if (cfg->num_trees < 1 || cfg->tree_size < 2 || cfg->batch_size < 1)
         return tg::fail(TG_ERR_ARG, "tg_search_create: num_trees/tree_size/batch_size out of range");
     TG_HIP(hipSetDevice(cfg->device));
@@ -4224,6 +4227,7 @@ int tg_search_root_planes(tg_search *s, float *planes_dev, void *stream) {
         if ((rc = install_rng(s, st))) return rc;
     }
     if (s->S == 9) hipLaunchKernelGGL(root_kernel<9>, dim3(s->dev.T), dim3(64), 0, st, s->dev, planes_dev);
+    else if (s->S == 13) hipLaunchKernelGGL(root_kernel<13>, dim3(s->dev.T), dim3(64), 0, st, s->dev, planes_dev);
     else hipLaunchKernelGGL(root_kernel<19>, dim3(s->dev.T), dim3(64), 0, st, s->dev, planes_dev);
     TG_HIP(hipGetLastError());
     return after_select(s, st);
@@ -4245,7 +4249,7 @@ int tg_search_select_puct(tg_search *s, int max_leaves, float *planes_dev, int32
     // the one-wavefront kernel (also used while the per-phase profile counters are on)
     static const bool force_serial = tg::knob("TG_SELECT_SERIAL") != nullptr;
     static const bool mpipe_prof = tg::knob("TG_MPIPE_PROF") != nullptr;     // phase counters of the multi-selector kernel
-    const bool pipelined = !force_serial && (!s->dev.prof || mpipe_prof) && max_leaves <= kPipeMaxK;
+    const bool pipelined = !force_serial && (!s->dev.prof || mpipe_prof) && max_leaves <= kPipeMaxK && s->S != 13;   // (13x13: the generic kernel)
     // few trees: the descents themselves are pipelined over four selector waves (+ four workers); with many
     // trees per CU the three-wave kernel keeps more trees resident
     static const int mpipe_max_trees = tg::knob("TG_SELECT_MPIPE_TREES") ? atoi(tg::knob("TG_SELECT_MPIPE_TREES")) : 256;
@@ -4275,6 +4279,8 @@ int tg_search_select_puct(tg_search *s, int max_leaves, float *planes_dev, int32
             hipLaunchKernelGGL(select_puct_pipe_kernel<19>, dim3(s->dev.T), dim3(192), 0, st, s->dev, max_leaves, planes_dev);
     } else if (s->S == 9)
         hipLaunchKernelGGL(select_puct_kernel<9>, dim3(s->dev.T), dim3(64), 0, st, s->dev, max_leaves, planes_dev);
+    else if (s->S == 13)
+        hipLaunchKernelGGL(select_puct_kernel<13>, dim3(s->dev.T), dim3(64), 0, st, s->dev, max_leaves, planes_dev);
     else
         hipLaunchKernelGGL(select_puct_kernel<19>, dim3(s->dev.T), dim3(64), 0, st, s->dev, max_leaves, planes_dev);
     TG_HIP(hipGetLastError());
@@ -4324,6 +4330,7 @@ int tg_search_play(tg_search *s, const int32_t *moves_host, void *stream) {
         s->moves_ev_used[slot] = true;
     }
     if (s->S == 9) hipLaunchKernelGGL(play_kernel<9>, dim3(s->dev.T), dim3(64), 0, st, s->dev, s->moves_dev);
+    else if (s->S == 13) hipLaunchKernelGGL(play_kernel<13>, dim3(s->dev.T), dim3(64), 0, st, s->dev, s->moves_dev);
     else hipLaunchKernelGGL(play_kernel<19>, dim3(s->dev.T), dim3(64), 0, st, s->dev, s->moves_dev);
     TG_HIP(hipGetLastError());
     return TG_OK;
@@ -4780,6 +4787,8 @@ static int launch_gumbel_select(tg_search *s, const SearchDev &D, const int32_t 
         hipLaunchKernelGGL((select_gumbel_pipe_kernel<9, 2>), dim3(T), dim3(192), 0, st, D, nc_dev, mc_dev, limit, off, planes_dev);
     else if (s->S == 9)
         hipLaunchKernelGGL(select_gumbel_kernel<9>, dim3(T), dim3(64), 0, st, D, nc_dev, mc_dev, limit, off, planes_dev);
+    else if (s->S == 13)
+        hipLaunchKernelGGL(select_gumbel_kernel<13>, dim3(T), dim3(64), 0, st, D, nc_dev, mc_dev, limit, off, planes_dev);
     else
         hipLaunchKernelGGL(select_gumbel_kernel<19>, dim3(T), dim3(64), 0, st, D, nc_dev, mc_dev, limit, off, planes_dev);
     TG_HIP(hipGetLastError());
@@ -4807,7 +4816,9 @@ static int launch_backup(tg_search *s, const SearchDev &D, const float *policy_d
                          const int32_t *off, int use_logit, hipStream_t st) {
     const bool few = s->dev.T <= 64;          // few trees: 16 waves per tree
     const dim3 grid(D.T), block(64 * (few ? 16 : 8));
-    if (s->S == 9 && few) {
+    if (s->S == 13) {
+        hipLaunchKernelGGL((backup_kernel<13, 8>), grid, dim3(64 * 8), 0, st, D, policy_dev, value_dev, slots_per_tree, off, use_logit);
+    } else if (s->S == 9 && few) {
         hipLaunchKernelGGL((backup_kernel<9, 16>), grid, block, 0, st, D, policy_dev, value_dev, slots_per_tree, off, use_logit);
     } else if (s->S == 9) {
         hipLaunchKernelGGL((backup_kernel<9, 8>), grid, block, 0, st, D, policy_dev, value_dev, slots_per_tree, off, use_logit);
@@ -5909,6 +5920,7 @@ static int chain_begin(tg_selfplay *sp, tg_net *net, float *planes_dev, float *p
     s->stream_known = true;
     if ((rc = launch_finish_roots(s, sp->state.data(), max_moves, st))) return rc;
     if (s->S == 9) hipLaunchKernelGGL(play_kernel<9>, dim3(T), dim3(64), 0, st, s->dev, s->moves_dev);
+    else if (s->S == 13) hipLaunchKernelGGL(play_kernel<13>, dim3(T), dim3(64), 0, st, s->dev, s->moves_dev);
     else hipLaunchKernelGGL(play_kernel<19>, dim3(T), dim3(64), 0, st, s->dev, s->moves_dev);
     TG_HIP(hipGetLastError());
     if ((rc = tg_search_root_planes(s, planes_dev, stream))) return rc;          // (also uploads the roots of games just started)

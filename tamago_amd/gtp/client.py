@@ -144,7 +144,7 @@ class GtpClient:
         except (IndexError, ValueError):
             return self._fail("boardsize int")
         net_size = getattr(self.mcts.network, "board_size", None)
-        if size not in (9, 19) or (net_size is not None and net_size != size):
+        if size not in (9, 13, 19) or (net_size is not None and net_size != size):
             # the reference answers an out-of-range size with "?"; here the size must also be the
             # one the resident network was built for (a [B,82] policy cannot serve a 19x19 tree)
             return self._fail("unacceptable size")

@@ -6,7 +6,7 @@ import pytest
 from tests.helpers import load_json, load_npz, oracle_replay
 
 
-@pytest.mark.parametrize("size", [9, 19])
+@pytest.mark.parametrize("size", [9, 13, 19])
 def test_oracle_symmetric_planes(size):
     from oracle.feature import generate_input_planes
     fix = load_npz(f"feat_s{size}.npz")
@@ -38,7 +38,7 @@ def test_policy_targets_host_logic():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("size", [9, 19])
+@pytest.mark.parametrize("size", [9, 13, 19])
 def test_symmetric_featurize_kernel(size):
     from tamago_amd.nn.feature import featurize_batch, generate_input_planes
     from tamago_amd.board.go_board import GoBoard

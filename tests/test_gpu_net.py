@@ -19,7 +19,7 @@ def _net(size, sd):
     return net
 
 
-@pytest.mark.parametrize("size", [9, 19])
+@pytest.mark.parametrize("size", [9, 13, 19])
 def test_forward_vs_reference_golden(size):
     from oracle.net import make_state_dict
     fix = load_npz(f"net_s{size}.npz")
@@ -41,7 +41,7 @@ def test_forward_vs_reference_golden(size):
         assert err_hip < 4 * err_ref + 1e-6
 
 
-@pytest.mark.parametrize("size,batches", [(9, [1, 2, 7, 256, 257, 770, 1539, 1600]), (19, [1, 3, 64])])
+@pytest.mark.parametrize("size,batches", [(9, [1, 2, 7, 256, 257, 770, 1539, 1600]), (13, [1, 5, 300]), (19, [1, 3, 64])])
 def test_forward_vs_oracle_random_planes(size, batches):
     from oracle.net import OracleNet, make_state_dict
     sd = make_state_dict(size, 3, 1.4)
@@ -77,7 +77,7 @@ def test_forward_empty_and_errors():
         DualNet(torch.device("cpu"), 9)
 
 
-@pytest.mark.parametrize("size", [9, 19])
+@pytest.mark.parametrize("size", [9, 13, 19])
 def test_featurize_kernel_vs_reference_golden(size):
     """tg_featurize_dev against planes recorded from nn/feature.py in the reference."""
     from oracle.board import GoBoard

@@ -55,7 +55,7 @@ def check_root(tree, mv, rec, digest=True):
         assert product_digest(tree, tree.num_nodes) == rec["digest"]
 
 
-@pytest.mark.parametrize("size", [9, 19])
+@pytest.mark.parametrize("size", [9, 13, 19])
 def test_puct_vs_reference_golden(size):
     from oracle.stubnet import StubNet
     from tamago_amd.mcts.tree import MCTSTree
@@ -79,7 +79,7 @@ def test_puct_vs_reference_golden(size):
         assert root.get_analysis(board, "cgos", tree.get_pv_lists) == rec["analysis_cgos"]
 
 
-@pytest.mark.parametrize("size", [9, 19])
+@pytest.mark.parametrize("size", [9, 13, 19])
 def test_gumbel_vs_reference_golden(size):
     from oracle.stubnet import StubNet
     from tamago_amd.mcts.tree import MCTSTree

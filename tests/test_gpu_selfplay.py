@@ -129,3 +129,38 @@ def test_gumbel_kernel_variants_write_the_same_games():
         assert res.returncode == 0, res.stderr[-2000:]
         outs.append(res.stdout.strip().splitlines()[-1])
     assert len(set(outs)) == 1, outs
+
+
+def test_13x13_selfplay_one_call_path_equals_the_phase_by_phase_path(tmp_path):
+    """BOARD_SIZE = 13 (board/constant.py:4; built in round 6: board-size-generic tree kernels, the exact-fp32 forward kernel):
+    a shard's games through the one-call chained path and through the phase-by-phase host path are the same files, and a game
+    played alone equals its copy in the shard."""
+    import torch
+    from tamago_amd.nn.network.dual_net import DualNet
+    from tamago_amd.selfplay.worker import selfplay_shard
+
+    class HostOnly:
+        def __init__(self, net):
+            self.net = net
+
+        def inference(self, planes):
+            return self.net.inference(planes)
+
+        def inference_with_policy_logits(self, planes):
+            return self.net.inference_with_policy_logits(planes)
+
+    torch.manual_seed(22)
+    net = DualNet(torch.device("cuda:0"), 13)
+    idx = list(range(1, 6))
+    flags = [i % 2 == 0 for i in idx]
+    fast, slow, solo = tmp_path / "fast", tmp_path / "slow", tmp_path / "solo"
+    fast.mkdir(), slow.mkdir(), solo.mkdir()
+    a = selfplay_shard(str(fast), net, idx, 13, 24, boards=3, never_resign_flags=flags)
+    b = selfplay_shard(str(slow), HostOnly(net), idx, 13, 24, boards=3, never_resign_flags=flags)
+    assert a == b and a["games"] == 5
+    for i in idx:
+        text = open(fast / f"{i}.sgf").read()
+        assert text == open(slow / f"{i}.sgf").read(), i
+        assert "SZ[13]" in text
+    selfplay_shard(str(solo), net, idx[:1], 13, 24, boards=1, never_resign_flags=flags[:1])
+    assert open(solo / "1.sgf").read() == open(fast / "1.sgf").read()

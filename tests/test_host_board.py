@@ -10,7 +10,7 @@ def _lst(arr):
     return [int(v) for v in arr if v >= 0]
 
 
-@pytest.mark.parametrize("size,n_games", [(9, 6), (19, 2)])
+@pytest.mark.parametrize("size,n_games", [(9, 6), (13, 2), (19, 2)])
 def test_product_goboard_playouts(size, n_games):
     from tamago_amd.board.go_board import GoBoard, copy_board
     from tamago_amd.board.stone import Stone

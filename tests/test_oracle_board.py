@@ -20,7 +20,7 @@ def _cands(arr):
     return [int(v) for v in arr if v >= 0]
 
 
-@pytest.mark.parametrize("size,n_games", [(9, 6), (19, 2)])
+@pytest.mark.parametrize("size,n_games", [(9, 6), (13, 2), (19, 2)])
 def test_playouts(size, n_games):
     fix = load_npz(f"board_s{size}.npz")
     for g in range(n_games):

@@ -9,7 +9,7 @@ from oracle.net import OracleNet, make_state_dict, forward_logits
 from tests.helpers import load_npz, oracle_replay
 
 
-@pytest.mark.parametrize("size", [9, 19])
+@pytest.mark.parametrize("size", [9, 13, 19])
 def test_feature_planes(size):
     fix = load_npz(f"feat_s{size}.npz")
     brd = load_npz(f"board_s{size}.npz")
@@ -30,7 +30,7 @@ def test_feature_planes(size):
         assert np.array_equal(planes, fix["planes"][i].astype(np.float32)), i
 
 
-@pytest.mark.parametrize("size", [9, 19])
+@pytest.mark.parametrize("size", [9, 13, 19])
 def test_dualnet_forward(size):
     fix = load_npz(f"net_s{size}.npz")
     for seed in (0, 7):

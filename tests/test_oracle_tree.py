@@ -56,7 +56,7 @@ def test_halving_schedule():
         assert [[k, c] for k, c in candidates_and_visit_pairs(n0, v).items()] == pairs
 
 
-@pytest.mark.parametrize("size", [9, 19])
+@pytest.mark.parametrize("size", [9, 13, 19])
 def test_puct(size):
     brd = load_npz(f"board_s{size}.npz")
     for rec in cases(size, "puct"):
@@ -71,7 +71,7 @@ def test_puct(size):
         assert float(np.random.random_sample()) == float.fromhex(rec["rng_after"])
 
 
-@pytest.mark.parametrize("size", [9, 19])
+@pytest.mark.parametrize("size", [9, 13, 19])
 def test_gumbel(size):
     brd = load_npz(f"board_s{size}.npz")
     for rec in cases(size, "gumbel"):

@@ -33,18 +33,19 @@ def orchestrate():
     env["PYTHONPATH"] = REF + os.pathsep + REPO
     subprocess.check_call([sys.executable, os.path.abspath(__file__), "--size", "9"], env=env,
                           cwd="/tmp")
-    scratch = tempfile.mkdtemp(prefix="ref19_")
-    try:
-        tree = os.path.join(scratch, "ref")
-        shutil.copytree(REF, tree, ignore=shutil.ignore_patterns(".git", "__pycache__"))
-        path = os.path.join(tree, "board", "constant.py")
-        text = open(path, encoding="utf-8").read().replace("BOARD_SIZE = 9", "BOARD_SIZE = 19")
-        open(path, "w", encoding="utf-8").write(text)
-        env["PYTHONPATH"] = tree + os.pathsep + REPO
-        subprocess.check_call([sys.executable, os.path.abspath(__file__), "--size", "19"],
-                              env=env, cwd="/tmp")
-    finally:
-        shutil.rmtree(scratch, ignore_errors=True)
+    for size in (19, 13):                  # (13: round 6 - the third size the library is built for)
+        scratch = tempfile.mkdtemp(prefix=f"ref{size}_")
+        try:
+            tree = os.path.join(scratch, "ref")
+            shutil.copytree(REF, tree, ignore=shutil.ignore_patterns(".git", "__pycache__"))
+            path = os.path.join(tree, "board", "constant.py")
+            text = open(path, encoding="utf-8").read().replace("BOARD_SIZE = 9", f"BOARD_SIZE = {size}")
+            open(path, "w", encoding="utf-8").write(text)
+            env["PYTHONPATH"] = tree + os.pathsep + REPO
+            subprocess.check_call([sys.executable, os.path.abspath(__file__), "--size", str(size)],
+                                  env=env, cwd="/tmp")
+        finally:
+            shutil.rmtree(scratch, ignore_errors=True)
     return 0
 
 
@@ -148,7 +149,7 @@ def worker(size: int):
         return board, {k: np.array(v) for k, v in rec.items()}
 
     n_games = 6 if size == 9 else 2
-    plies = 150 if size == 9 else 420
+    plies = 150 if size == 9 else (240 if size == 13 else 420)
     board_fix = {}
     feat_boards = []
     for g in range(n_games):
@@ -167,7 +168,7 @@ def worker(size: int):
         return board
 
     feat = {"game": [], "ply": [], "color": [], "planes": []}
-    picks = [0, 1, 2, 3, 10, 25, 40, 60, 80, 100, 120, 140] if size == 9 else [0, 1, 50, 200, 400]
+    picks = [0, 1, 2, 3, 10, 25, 40, 60, 80, 100, 120, 140] if size == 9 else ([0, 1, 30, 120, 230] if size == 13 else [0, 1, 50, 200, 400])
     for g in range(min(n_games, 3)):
         moves = board_fix[f"g{g}_move"]
         colors = board_fix[f"g{g}_color"]
@@ -301,6 +302,11 @@ def worker(size: int):
         gumbel_cases = [(1, 16, 0, True), (2, 100, 0, True), (3, 400, 0, True),
                         (4, 16, 50, True), (5, 100, 100, False), (6, 400, 120, True),
                         (7, 50, 148, True)]
+    elif size == 13:
+        puct_cases = [(0, 64, 200, "STRICT", False, 0, False),
+                      (1, 32, 150, "CONSTANT", False, 100, True),
+                      (2, 8, 60, "STRICT", True, 180, False)]
+        gumbel_cases = [(1, 16, 0, True), (2, 100, 80, True)]
     else:
         puct_cases = [(0, 64, 200, "STRICT", False, 0, False),
                       (1, 64, 200, "STRICT", False, 200, True),
