@@ -13,3 +13,8 @@ trace single_tree_9x9 python $R/tools/bench_single_tree.py 9 8
 trace single_tree_19x19 python $R/tools/bench_single_tree.py 19 4
 trace selfplay_64_boards python $R/tools/bench_selfplay.py 64 400 128 1
 echo done
+# (round 6) the 16-board shard - two host-thread groups by default - with its concurrency picture
+trace selfplay_16_boards python $R/tools/bench_selfplay.py 16 400 96
+rm -rf /tmp/lt2; timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/lt2 -o t -- python $R/tools/bench_selfplay.py 16 400 64 > $OUT/sp16_trace.log 2>&1
+f=$(find /tmp/lt2 -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python $R/tools/experiments/sp_timeline.py $f 220 > $OUT/r06_selfplay_16_boards_two_groups_timeline.txt
+echo done16
