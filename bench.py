@@ -52,7 +52,7 @@ PROFILES = os.path.join(REPO, "profiles")
 
 
 def pmc_summary(kernel_name, size=9):
-    """The rocprofv3 PMC summary (tools/pmc_r02.sh -> profiles/r02_pmc_forward_*.json) measured on THESE
+    """The rocprofv3 PMC summary (tools/pmc_r06.sh -> profiles/r06_pmc_forward_*.json; the scripts of earlier rounds are in the git history) measured on THESE
     kernel sources for THIS kernel: HBM-side bytes per position (FETCH_SIZE doubled + WRITE_SIZE, separate
     passes, as MI355X_MICROARCH.md section HBM prescribes), matrix-pipe busy fraction, L2 request bytes.
     A summary taken on other sources (csrc digest differs) or another kernel is NOT quoted: returns None and
@@ -87,7 +87,7 @@ def pmc_summary(kernel_name, size=9):
 
 
 def tree_pmc_summary():
-    """HBM-side traffic of the tree kernels (selection, backup; rocprofv3 PMC, tools/pmc_r03.sh) - quoted only when the
+    """HBM-side traffic of the tree kernels (selection, backup; rocprofv3 PMC, tools/pmc_r06.sh) - quoted only when the
     summary was measured on THESE sources (digest over all of csrc/ + the ABI header), else None + a warning."""
     import glob
     from tamago_amd.build import source_digest
