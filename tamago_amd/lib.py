@@ -9,7 +9,8 @@ from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_in
                     c_size_t, c_uint64, c_void_p)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libtamago_hip.so")
+# (TAMAGO_HIP_LIB: another build of the library - kernel experiments under tools/experiments/_bin/; default: the in-tree build)
+LIB_PATH = os.environ.get("TAMAGO_HIP_LIB") or os.path.join(HERE, "libtamago_hip.so")
 
 
 class TamagoHipError(RuntimeError):
