@@ -95,7 +95,8 @@ def selfplay_shard(save_dir: str, network, index_list: Sequence[int], size: int,
         import tamago_amd
         from tamago_amd.nn.network.dual_net import DualNet as _DualNet
         two = size == 9 and 8 <= boards <= 28 and observer is None and isinstance(network, _DualNet) and \
-            (tamago_amd.HW_QUEUES or 0) >= 8 and not os.environ.get("TG_SP_LANES")
+            (tamago_amd.HW_QUEUES or 0) >= 8 and not os.environ.get("TG_SP_LANES") and \
+            os.environ.get("TG_SHARED_DEVICE", "0") in ("", "0")          # (several shard processes on one GPU: one group each)
         groups = 2 if two or boards >= 2048 else 1
     groups = max(1, min(groups, boards))
     if observer is not None and groups != 1:
