@@ -100,12 +100,19 @@ struct SearchDev {
     // random stream
     const double *rng;          // [T][rng_cap]  e_i = -log(1-u_i)
     int64_t *rng_cursor;        // [T]
+    int64_t *cursor_pub;        // [T] host-mapped mirror of rng_cursor (written with it: the host reads the cursors behind the
+                                // selection launch's event without a copy kernel, which would queue for a CU behind the forward pass)
     int64_t rng_cap;
     const uint64_t *zob;        // [4][NC]
     int32_t *err;               // [T] sticky error flags
     long long *prof;            // optional [16] s_memtime cycle accumulators of tree 0 (tg_search_profile)
     int32_t T, N, K, cgos, superko;
 };
+
+__device__ __forceinline__ void set_cursor(const SearchDev &D, int t, long long v) {
+    D.rng_cursor[t] = v;
+    if (D.cursor_pub) D.cursor_pub[t] = v;
+}
 
 constexpr int kPathCap = 48;      // (24 until round 5: the last mini-batches of a 1 600-visit 19x19 search walk 25 levels and fell to the one-wave backup, 560 us instead of 30)
 enum : int32_t { kErrPoolFull = 1, kErrRngEmpty = 2, kErrPipeline = 4 };
@@ -613,7 +620,7 @@ __device__ int expand_node(LT &L, const BoardScalars &b, int to_move, const Sear
         D.n_raw[ns] = 0.f;
         D.n_parent[ns] = parent;
         D.n_pedge[ns] = pedge;
-        D.rng_cursor[t] = cur + n;
+        set_cursor(D, t, cur + n);
     }
     num_nodes += 1;
     wave_sync();
@@ -1165,7 +1172,7 @@ __global__ __launch_bounds__(192) void select_puct_pipe_kernel(SearchDev D, int 
     if (threadIdx.x == 0) {
         D.meta[t].num_nodes = num_nodes;
         D.n_leaves[t] = queued;
-        D.rng_cursor[t] = sh.cursor_val;
+        set_cursor(D, t, sh.cursor_val);
     }
 }
 
@@ -1553,7 +1560,7 @@ __global__ __launch_bounds__(64 * (NSEL + NWRK)) void select_puct_mpipe_kernel(S
     if (threadIdx.x == 0) {
         D.meta[t].num_nodes = sh.num_nodes;
         D.n_leaves[t] = good ? max_leaves : 0;
-        D.rng_cursor[t] = sh.cursor_val;
+        set_cursor(D, t, sh.cursor_val);
     }
 }
 
@@ -2111,7 +2118,7 @@ __global__ __launch_bounds__(1024) void select_puct_split_kernel(SearchDev D, in
                 if (lane == 0 && x + 1 <= cap)
                     __hip_atomic_store(&xoff[x + 1], ((unsigned long long)(unsigned)tag_base << 32) | off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if (ok && lane == 0) D.rng_cursor[t] = cursor0 + (long long)off;
+            if (ok && lane == 0) set_cursor(D, t, cursor0 + (long long)off);
         }
         __syncthreads();
         const bool good = active && !sh.err;
@@ -2223,7 +2230,7 @@ __global__ __launch_bounds__(1024) void select_puct_split_kernel(SearchDev D, in
             if (sp) atomicMax(reinterpret_cast<unsigned long long *>(D.prof + 13), (unsigned long long)SP_NOW());
         }
         __syncthreads();
-        if (NWG == 1 && threadIdx.x == 0) D.rng_cursor[t] = sh.cursor_val;
+        if (NWG == 1 && threadIdx.x == 0) set_cursor(D, t, sh.cursor_val);
     }
 }
 
@@ -3309,7 +3316,7 @@ __global__ __launch_bounds__(64 * (1 + NW)) void select_gumbel_pipe_kernel(Searc
     if (threadIdx.x == 0) {
         D.meta[t].num_nodes = num_nodes;
         D.n_leaves[t] = queued;
-        D.rng_cursor[t] = sh.cursor_val;
+        set_cursor(D, t, sh.cursor_val);
     }
 }
 
@@ -3646,8 +3653,7 @@ struct tg_search {
     unsigned lag_seq = 0;
     size_t eager_need = 0;                        // few trees: the last whole-window request (advance_streams regenerates ahead)
     bool auto_rest = false;                       // feed_streams_impl over-generated: the rest of the window goes out at install_rng
-    int64_t *consumed_pin = nullptr;              // pinned [T]: the cursors on their way to the host (tg_search_rng_consumed)
-    hipEvent_t block_ev = nullptr;                // blocking-sync event for the host's long waits (tg_search_rng_consumed)
+    int64_t *consumed_pin = nullptr;              // host-mapped [T]: the kernels' mirror of the cursors (SearchDev::cursor_pub)
     double *noise_back = nullptr;                 // pinned [T][A]: the device-drawn root noise on its way to noise_host
     hipEvent_t noise_back_ev = nullptr, noise_order_ev = nullptr;
     bool noise_back_pending = false;
@@ -3934,6 +3940,17 @@ int tg_search_create(const tg_search_config *cfg, tg_search **out) {
     }
     D.rng = s->rng_buf[0];
     D.rng_cap = 0;              // nothing installed yet
+    {
+        // the cursors' host-mapped mirror (tg_search_rng_consumed)
+        void *dp = nullptr;
+        if (hipHostMalloc(reinterpret_cast<void **>(&s->consumed_pin), T * sizeof(int64_t), hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer(&dp, s->consumed_pin, 0) != hipSuccess) {
+            tg_search_destroy(s);
+            return tg::fail(TG_ERR_HIP, "tg_search_create: cursor mirror");
+        }
+        std::memset(s->consumed_pin, 0, T * sizeof(int64_t));
+        D.cursor_pub = static_cast<int64_t *>(dp);
+    }
     if (hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&s->ev_rng[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&s->ev_rng[1], hipEventDisableTiming) != hipSuccess ||
@@ -3994,7 +4011,6 @@ int tg_search_destroy(tg_search *s) {
     if (s->lag_pin) (void)hipHostFree(s->lag_pin);
     if (s->skip_pin) (void)hipHostFree(s->skip_pin);
     for (hipEvent_t e : s->lag_ev) if (e) (void)hipEventDestroy(e);
-    if (s->block_ev) (void)hipEventDestroy(s->block_ev);
     if (s->consumed_pin) (void)hipHostFree(s->consumed_pin);
     if (s->noise_back) (void)hipHostFree(s->noise_back);
     if (s->noise_back_ev) (void)hipEventDestroy(s->noise_back_ev);
@@ -4144,6 +4160,7 @@ static int install_rng(tg_search *s, hipStream_t st) {
     s->dev.rng = s->rng_buf[s->rng_active];
     s->dev.rng_cap = s->rng_pending_cap;
     TG_HIP(hipMemsetAsync(s->dev.rng_cursor, 0, (size_t)s->dev.T * sizeof(int64_t), st));
+    if (s->dev.cursor_pub) TG_HIP(hipMemsetAsync(s->dev.cursor_pub, 0, (size_t)s->dev.T * sizeof(int64_t), st));
     if (s->auto_rest) {                             // (feed_streams_impl's few-tree over-generation: the rest, behind this launch's wait)
         s->auto_rest = false;
         return feed_streams_rest(s);
@@ -4180,27 +4197,23 @@ int tg_search_set_rng(tg_search *s, const double *exp_stream_host, size_t stride
 
 int tg_search_rng_consumed(tg_search *s, int64_t *consumed_host) {
     if (!s || !consumed_host) return tg::fail(TG_ERR_ARG, "tg_search_rng_consumed: null argument");
-    // wait for the last selection kernel only - the forward / backup behind it keep running
-    if (s->sel_recorded) TG_HIP(hipStreamWaitEvent(s->copy_stream, s->ev_sel, 0));
-    // (into pinned memory: a copy into the caller's pageable array makes the runtime wait - spinning - inside hipMemcpyAsync)
-    if (!s->consumed_pin) TG_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->consumed_pin), (size_t)s->dev.T * sizeof(int64_t), hipHostMallocDefault));
-    TG_HIP(hipMemcpyAsync(s->consumed_pin, s->dev.rng_cursor, (size_t)s->dev.T * sizeof(int64_t),
-                          hipMemcpyDeviceToHost, s->copy_stream));
-    // Many trees: the selection launch this waits for takes milliseconds - sleep on a blocking event instead of spinning on the
-    // stream (a rank's driver thread burnt a whole core doing nothing; eight ranks share the host).  Few trees: the wait is
-    // tens of microseconds and a wake-up would cost more than it saves.
-    if (s->dev.T >= 256) {
-        if (!s->block_ev) TG_HIP(hipEventCreateWithFlags(&s->block_ev, hipEventBlockingSync | hipEventDisableTiming));
-        TG_HIP(hipEventRecord(s->block_ev, s->copy_stream));
-        // (hipEventSynchronize spins whatever the event's flags say on this runtime: poll and sleep instead)
+    // The kernels that move a cursor mirror it into host-mapped memory (SearchDev::cursor_pub); the host waits for the last
+    // selection launch's event only - the forward pass / backup behind it keep running - and reads the mirror.  (Until round 6
+    // a copy on the side stream: for a few trees that copy is a one-workgroup kernel, and it queued for a CU behind the forward
+    // pass's 256 workgroups - the cursors, and with them the generation of the next random window, arrived ~57 us late.)
+    if (!s->sel_recorded) {
+        TG_HIP(hipDeviceSynchronize());
+    } else if (s->dev.T >= 256) {
+        // Many trees: the selection launch takes milliseconds - sleep instead of spinning (a rank's driver thread burnt a whole
+        // core doing nothing; eight ranks share the host; hipEventSynchronize spins whatever the event's flags say here).
         for (;;) {
-            const hipError_t q = hipEventQuery(s->block_ev);
+            const hipError_t q = hipEventQuery(s->ev_sel);
             if (q == hipSuccess) break;
             if (q != hipErrorNotReady) return tg::fail(TG_ERR_HIP, "tg_search_rng_consumed: hipEventQuery: %s", hipGetErrorString(q));
             std::this_thread::sleep_for(std::chrono::microseconds(s->dev.T >= 1024 ? 200 : 50));
         }
     } else {
-        TG_HIP(hipStreamSynchronize(s->copy_stream));
+        TG_HIP(hipEventSynchronize(s->ev_sel));
     }
     std::memcpy(consumed_host, s->consumed_pin, (size_t)s->dev.T * sizeof(int64_t));
     return TG_OK;
@@ -4808,6 +4821,7 @@ static SearchDev sub_dev(const tg_search *s, int t0, int n) {
     D.q_node += o * K; D.q_pnode += o * K; D.q_pedge += o * K; D.q_depth += o * K; D.q_path += o * K * kPathCap;
     D.n_leaves += o;
     D.rng += o * (size_t)D.rng_cap; D.rng_cursor += o; D.err += o;
+    if (D.cursor_pub) D.cursor_pub += o;
     D.T = n;
     return D;
 }
