@@ -123,7 +123,10 @@ def selfplay_shard(save_dir: str, network, index_list: Sequence[int], size: int,
     sizes = [boards // groups + (1 if g < boards % groups else 0) for g in range(groups)]
     results = [dict(games=0, moves=0, leaf_evals=0) for _ in range(groups)]
     errors = []
-
+    # (Round 6 tried to make the two groups pace each other - a group's move begun at a fixed offset into its partner's, or pushed
+    # out of the offsets measured slow (0 and 0.5 of a move: 2.9-3.1 M leaf-evals/s at 16 boards against 3.6-3.7 M at 0.3 / 0.7):
+    # forcing ANY offset cost more than it gave (3.5-3.6 M typical, the slow runs still there).  Left alone two groups run at
+    # 3.7 M in ten runs of thirteen, 3.4-3.5 M in two, 3.2 M in one; one group: 3.45-3.5 M every time.)
     def work(g):
         try:
             stream = torch.cuda.Stream(device=torch.device("cuda", device_index))
