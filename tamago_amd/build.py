@@ -83,14 +83,27 @@ def build(force: bool = False, verbose: bool = True) -> str:
     rebuilt = bool(jobs)
     if jobs:
         # the translation units are independent: compile them side by side (search.hip alone takes over a minute)
-        from concurrent.futures import ThreadPoolExecutor
+        from concurrent.futures import ThreadPoolExecutor, as_completed
 
         def run(cmd):
+            name = os.path.basename(cmd[-3])
             if verbose:
                 print("[tamago_amd.build]", " ".join(cmd), flush=True)
-            subprocess.check_call(cmd)
+            # (output collected per source and printed under its name: the jobs run side by side)
+            res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            if res.stdout.strip():
+                print("".join(f"[{name}] {line}\n" for line in res.stdout.splitlines()), end="", flush=True)
+            if res.returncode != 0:
+                raise subprocess.CalledProcessError(res.returncode, cmd)
         with ThreadPoolExecutor(max_workers=min(len(jobs), max(1, (os.cpu_count() or 2) // 2), 8)) as pool:
-            list(pool.map(run, jobs))
+            futures = [pool.submit(run, cmd) for cmd in jobs]
+            try:
+                for fut in as_completed(futures):
+                    fut.result()
+            except BaseException:
+                for fut in futures:                  # the first failure ends the build: jobs not yet started are dropped
+                    fut.cancel()
+                raise
     if rebuilt or not os.path.exists(LIB):
         cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
         if verbose:
