@@ -84,20 +84,17 @@ def selfplay_shard(save_dir: str, network, index_list: Sequence[int], size: int,
     fb0 = network.range_fallbacks() if hasattr(network, "range_fallbacks") else 0
     boards = min(boards, len(todo))
     if groups <= 0:
-        # Measured on MI355X (tools/bench_selfplay.py, 400 simulations, leaf-evals/s; profiles/r06_selfplay_lanes_sweep.txt).
-        # Round 6, random streams generated on the device (the host threads no longer compete with generator threads):
-        # TWO groups - two lock-step halves on their own host threads, streams and moves - beat one from 8 to 28 boards:
-        # 8 boards 2.24 -> 2.29 M, 12: 2.99 -> 3.18, 16: 3.52 -> 3.72-3.74 (three runs), 24: 3.57 -> 4.54; 32: 4.66 -> 4.39,
-        # 64: 5.87 -> 4.72, three groups at 16 boards 2.44.  (With the draws generated on host threads it was the other way round:
-        # round 4, 16 boards 2.88 M in one group vs 1.75 M in two.)  The groups' streams need hardware queues of their own
-        # (tamago_amd/__init__.py asks for 16; on the runtime's default of four the halves serialise).  At 2048 boards two groups
-        # were level in round 3 (4.75 vs 4.70 M).
-        import tamago_amd
-        from tamago_amd.nn.network.dual_net import DualNet as _DualNet
-        two = size == 9 and 8 <= boards <= 28 and observer is None and isinstance(network, _DualNet) and \
-            (tamago_amd.HW_QUEUES or 0) >= 8 and not os.environ.get("TG_SP_LANES") and \
-            os.environ.get("TG_SHARED_DEVICE", "0") in ("", "0")          # (several shard processes on one GPU: one group each)
-        groups = 2 if two or boards >= 2048 else 1
+        # ONE group below 2048 boards.  Measured on MI355X (400 simulations, leaf-evals/s; profiles/r06_selfplay_lanes_sweep.txt,
+        # tools/experiments/sp_bench_context.py).  Round 6, random streams generated on the device: two groups - two lock-step
+        # halves on their own host threads, streams and moves - reach 3.7 M at 16 boards (one group: 3.45-3.57 M) and 4.5 M at 24
+        # (3.6 M) in a fresh process most of the time, but the same call repeated inside one process gives 3.20 / 3.12 / 3.19 /
+        # 3.81 / 3.39 / 3.52 M where one group gives 3.54-3.57 M six times out of six, the bench's own leg landed on 3.79 / 3.16 /
+        # 3.16 M, and a one-group run AFTER two-group runs in the same process dropped to 2.7 M.  Pacing the groups against each
+        # other did not tame it.  The mean is below one group's: not the default.  (`groups=2` remains for callers that measure it
+        # on their own workload; from 32 boards on it loses outright: 32: 4.66 -> 4.39 M, 64: 5.87 -> 4.72 M; with the draws
+        # generated on host threads it lost everywhere: round 4, 16 boards 2.88 M vs 1.75 M.  At 2048 boards two groups were level
+        # in round 3: 4.75 vs 4.70 M.)
+        groups = 1 if boards < 2048 else 2
     groups = max(1, min(groups, boards))
     if observer is not None and groups != 1:
         raise ValueError("selfplay_shard: an observer needs groups = 1")
@@ -123,10 +120,6 @@ def selfplay_shard(save_dir: str, network, index_list: Sequence[int], size: int,
     sizes = [boards // groups + (1 if g < boards % groups else 0) for g in range(groups)]
     results = [dict(games=0, moves=0, leaf_evals=0) for _ in range(groups)]
     errors = []
-    # (Round 6 tried to make the two groups pace each other - a group's move begun at a fixed offset into its partner's, or pushed
-    # out of the offsets measured slow (0 and 0.5 of a move: 2.9-3.1 M leaf-evals/s at 16 boards against 3.6-3.7 M at 0.3 / 0.7):
-    # forcing ANY offset cost more than it gave (3.5-3.6 M typical, the slow runs still there).  Left alone two groups run at
-    # 3.7 M in ten runs of thirteen, 3.4-3.5 M in two, 3.2 M in one; one group: 3.45-3.5 M every time.)
     def work(g):
         try:
             stream = torch.cuda.Stream(device=torch.device("cuda", device_index))
