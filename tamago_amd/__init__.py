@@ -6,7 +6,7 @@ moves, the random-stream generator), and streams that share a hardware queue ser
 2.66 M leaf-evals/s on 8 queues, 3.65 M on 16 (profiles/r06_selfplay_lanes_sweep.txt).  The runtime reads the variable when it
 loads (measured: setting it after `import torch` has no effect), so it has to be in the environment before torch is imported:
 HW_QUEUES records what this process will get - the variable's value, 16 if the package could still set it (torch not imported
-yet), None if that is not knowable - and a shard takes two lanes only with 16 or more (selfplay/worker.py _auto_lanes).
+yet), None if that is not knowable (callers that split a shard into groups or lanes can look at it).
 bench.py, tests/conftest.py and the self-play launcher set it first thing.
 """
 import os as _os

@@ -219,7 +219,7 @@ def test_selfplay_move_schemes_play_the_same_games(tmp_path, monkeypatch):
     flags = [i % 5 != 0 for i in idx]
     results = {}
     # round 6: lanes - the boards as independent engines on their own streams, driven by one host thread through
-    # tg_selfplay_move_begin / _end, each lane on a move of its own (the default from 8 boards on)
+    # tg_selfplay_move_begin / _end, each lane on a move of its own (an option; one lock-step group is the default)
     for name, chain, sub, lanes in (("host decision", "0", None, 1), ("chained", "1", "1", 1), ("2 sub-groups", "1", "2", 1),
                                     ("default", None, None, 0), ("4 sub-groups", "1", "4", 1), ("3 lanes", None, None, 3),
                                     ("8 lanes of one group", "1", "1", 8)):
