@@ -117,20 +117,25 @@ __device__ __forceinline__ void mt_store(const MtRegs &m, uint32_t *dst, int lan
 __device__ __forceinline__ void mt_twist(MtRegs &m, int lane) {
     const int up13 = (lane + 13) & 63, dn35 = (lane + 29) & 63, up1 = (lane + 1) & 63;
     const bool lo13 = lane + 13 < 64, hi35 = lane >= 35;
-    // everything that reads OLD words first, all in flight together: word i + 1 of every register, word i + 397 of registers 0..3
+    // everything that reads OLD words first, ALL in flight together (fourteen cross-lane reads, then one wait): word i + 1 of every
+    // register, word i + 397 of registers 0..3.  (Written as "all reads, fence, all uses": with a read next to its use the
+    // compiler waited for each one in turn - ten round trips of ~100 cycles in a row, most of a regeneration.)
+    uint32_t nx[10], su[4];
+#pragma unroll
+    for (int r = 0; r < 10; ++r) nx[r] = (uint32_t)__shfl((int)m.k[r], up1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) su[q] = (uint32_t)__shfl((int)m.k[6 + q], up13);
+    __builtin_amdgcn_sched_barrier(0);
     uint32_t mix[10];
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        uint32_t nxt = (uint32_t)__shfl((int)m.k[r], up1);
+        uint32_t nxt = nx[r];
         if (r < 9) {
             const uint32_t wrap = (uint32_t)__builtin_amdgcn_readfirstlane((int)m.k[r + 1]);
             if (lane == 63) nxt = wrap;
         }
         mix[r] = mt_mix(m.k[r], nxt);                                 // (r = 9, lane 47: patched below with the NEW word 0)
     }
-    uint32_t su[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) su[q] = (uint32_t)__shfl((int)m.k[6 + q], up13);
     const uint32_t old9 = m.k[9];
     // four levels of NEW words: registers 0..2, then 3..5, 6..8, 9 - each level reads the level before it once (lane - 35)
     uint32_t sh[7];
