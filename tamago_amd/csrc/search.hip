@@ -78,14 +78,21 @@ struct RootMeta {
     int32_t hist_len;   // number of valid history slots (== moves, clamped)
 };
 
+struct NodeRec {
+    int32_t visits, vl;         // node_visits, virtual_loss
+    float vsum, raw;            // node_value_sum (float32 like the reference's np.float32 accumulator), raw_value
+    int32_t children, parent, pedge, pad;
+};
+static_assert(sizeof(NodeRec) == 32, "two node records per 64-byte line");
+
 struct SearchDev {
     // node pool, [T][N][A]
     int32_t *ch_index, *ch_visits, *ch_vl;
     double *ch_vsum, *ch_policy, *ch_value;
     int16_t *action;
-    // node scalars, [T][N]
-    int32_t *n_children, *n_visits, *n_vl, *n_parent, *n_pedge;
-    float *n_vsum, *n_raw;
+    // node scalars, [T][N]: ONE 32-byte record per node (round 6; seven separate arrays until then - a path level of the backup
+    // touched three 64-byte lines for visits / virtual loss / value sum, a selection step three for children / visits / virtual loss)
+    NodeRec *node;
     double *noise;              // [T][A]   root Gumbel noise (0 for PUCT)
     // root position, per tree
     uint8_t *root_cells;        // [T][NC]
@@ -613,13 +620,13 @@ __device__ int expand_node(LT &L, const BoardScalars &b, int to_move, const Sear
     }
     if (lane == 0) {
         const size_t ns = (size_t)t * D.N + node;
-        D.n_children[ns] = n;
-        D.n_visits[ns] = 0;
-        D.n_vl[ns] = 0;
-        D.n_vsum[ns] = 0.f;
-        D.n_raw[ns] = 0.f;
-        D.n_parent[ns] = parent;
-        D.n_pedge[ns] = pedge;
+        D.node[ns].children = n;
+        D.node[ns].visits = 0;
+        D.node[ns].vl = 0;
+        D.node[ns].vsum = 0.f;
+        D.node[ns].raw = 0.f;
+        D.node[ns].parent = parent;
+        D.node[ns].pedge = pedge;
         set_cursor(D, t, cur + n);
     }
     num_nodes += 1;
@@ -747,9 +754,9 @@ __device__ EdgePick select_puct(const SearchDev &D, int t, int node, int lane, c
         idx[r] = D.ch_index[base + ii];
         act[r] = D.action[base + ii];
     }
-    const int nc = D.n_children[ns];
-    const int node_vl = D.n_vl[ns];
-    const int total = D.n_visits[ns] + node_vl;
+    const int nc = D.node[ns].children;
+    const int node_vl = D.node[ns].vl;
+    const int total = D.node[ns].visits + node_vl;
     return score_puct<S>(D, vis, vl, idx, act, vsum, pol, nc, total, node_vl, lane, rcp);
 }
 
@@ -840,7 +847,7 @@ __global__ __launch_bounds__(64) void select_puct_kernel(SearchDev D, int max_le
                 const int edge_cnt = pick.count + 1;                  // after the virtual loss
                 int child = pick.child;
                 if (lane == 0) {                                      // node.py:76-83
-                    D.n_vl[ns] = pick.node_vl + 1;
+                    D.node[ns].vl = pick.node_vl + 1;
                     D.ch_vl[base + e] = pick.edge_vl + 1;
                 }
                 // two consecutive passes: never descend below (tree.py:224-229)
@@ -1022,13 +1029,13 @@ __device__ void expand_fill(LT &L, const SearchDev &D, int t, int node, int pare
     }
     if (lane == 0) {
         const size_t ns = (size_t)t * D.N + node;
-        D.n_children[ns] = n;
-        D.n_visits[ns] = 0;
-        D.n_vl[ns] = 0;
-        D.n_vsum[ns] = 0.f;
-        D.n_raw[ns] = 0.f;
-        D.n_parent[ns] = parent;
-        D.n_pedge[ns] = pedge;
+        D.node[ns].children = n;
+        D.node[ns].visits = 0;
+        D.node[ns].vl = 0;
+        D.node[ns].vsum = 0.f;
+        D.node[ns].raw = 0.f;
+        D.node[ns].parent = parent;
+        D.node[ns].pedge = pedge;
     }
     wave_sync();
 }
@@ -1078,7 +1085,7 @@ __global__ __launch_bounds__(192) void select_puct_pipe_kernel(SearchDev D, int 
                 if (depth >= kPathMax<S>) { ok = false; break; }
                 if (lane == 0) {
                     sh.moves[slot][depth] = (int16_t)mv;
-                    D.n_vl[ns] = pick.node_vl + 1;                             // node.py:76-83
+                    D.node[ns].vl = pick.node_vl + 1;                             // node.py:76-83
                     D.ch_vl[base + e] = pick.edge_vl + 1;
                     if (depth < kPathCap) D.q_path[((size_t)t * D.K + k) * kPathCap + depth] = (node << 10) | e;
                 }
@@ -1324,8 +1331,8 @@ __global__ __launch_bounds__(64 * (NSEL + NWRK)) void select_puct_mpipe_kernel(S
                 const int cnt = r_vis[r] + c_vl[r];
                 c_q[r] = cnt != 0 ? r_vsum[r] / (double)cnt : 0.0;
             }
-            root_nc = D.n_children[root_ns];
-            root_total0 = D.n_visits[root_ns] + D.n_vl[root_ns];
+            root_nc = D.node[root_ns].children;
+            root_total0 = D.node[root_ns].visits + D.node[root_ns].vl;
         }
         for (int k = wid; active && k < max_leaves; k += NSEL) {
             if (pipe_load(&sh.err)) break;
@@ -1438,7 +1445,7 @@ __global__ __launch_bounds__(64 * (NSEL + NWRK)) void select_puct_mpipe_kernel(S
                     if (depth == 0) {
                         sh.root_vl[e] = pick.edge_vl + 1;
                     } else {
-                        D.n_vl[ns] = pick.node_vl + 1;                             // node.py:76-83
+                        D.node[ns].vl = pick.node_vl + 1;                             // node.py:76-83
                         D.ch_vl[base + e] = pick.edge_vl + 1;
                     }
                     // the successors may have this node as soon as the virtual loss is in place (a descent that ends
@@ -1554,7 +1561,7 @@ __global__ __launch_bounds__(64 * (NSEL + NWRK)) void select_puct_mpipe_kernel(S
     if (good) {
         // the root's virtual losses (max_leaves descents, one each) reach the pool here
         for (int i = threadIdx.x; i < A; i += NTHR) D.ch_vl[root_base + i] = sh.root_vl[i];
-        if (threadIdx.x == 0) D.n_vl[root_ns] += max_leaves;
+        if (threadIdx.x == 0) D.node[root_ns].vl += max_leaves;
     }
     if (prof && threadIdx.x == 0) D.prof[15] += (long long)__builtin_amdgcn_s_memtime() - t_begin;
     if (threadIdx.x == 0) {
@@ -1722,7 +1729,7 @@ __global__ __launch_bounds__(1024) void select_puct_split_kernel(SearchDev D, in
         for (int i = threadIdx.x; i < kPipeMaxK; i += 1024) { sh.alloc_child[i] = kOwnNotYet; sh.exp_key[i] = -1; sh.choice[i] = 0; }
         if (threadIdx.x == 0) { sh.num_nodes = n0; sh.all_done = 0; sh.err = 0; }
         {
-            const int total0 = D.n_visits[root_ns] + D.n_vl[root_ns];
+            const int total0 = D.node[root_ns].visits + D.node[root_ns].vl;
             for (int i = threadIdx.x; i < max_leaves; i += 1024) sh.sq[i] = __dsqrt_rn((double)(total0 + i + 1));
             for (int i = threadIdx.x; i < kRcpN; i += 1024) sh.rcp[i] = 1.0 / (double)(i ? i : 1);
         }
@@ -1757,7 +1764,7 @@ __global__ __launch_bounds__(1024) void select_puct_split_kernel(SearchDev D, in
                 if (__any(c_cnt[r] + 2 >= kRcpN)) { c_rcp[r] = 1.0 / (double)(c_cnt[r] + 1); c_rcpn[r] = 1.0 / (double)(c_cnt[r] + 2); }
                 else { c_rcp[r] = sh.rcp[c_cnt[r] + 1]; c_rcpn[r] = sh.rcp[c_cnt[r] + 2]; }
             }
-            root_nc = D.n_children[root_ns];
+            root_nc = D.node[root_ns].children;
         };
         auto choose = [&](double sq) -> int {
             double best = 0.0;
@@ -1844,7 +1851,7 @@ __global__ __launch_bounds__(1024) void select_puct_split_kernel(SearchDev D, in
                     const int i = lane + 64 * r;
                     if (i < A) D.ch_vl[root_base + i] = c_vl[r];
                 }
-                if (lane == 0) D.n_vl[root_ns] += max_leaves;
+                if (lane == 0) D.node[root_ns].vl += max_leaves;
             }
         };
         if (wid == 0) {
@@ -1987,7 +1994,7 @@ __global__ __launch_bounds__(1024) void select_puct_split_kernel(SearchDev D, in
                     child = -2 - kref;
                 }
                 if (lane == 0) {
-                    D.n_vl[ns] = pick.node_vl + 1;                                   // node.py:76-83
+                    D.node[ns].vl = pick.node_vl + 1;                                   // node.py:76-83
                     D.ch_vl[base + e] = pick.edge_vl + 1;
                     sh.moves[slot][depth] = (int16_t)mv;
                     if (depth < kPathCap) sh.qpath[slot][depth] = key;
@@ -2283,9 +2290,9 @@ __global__ __launch_bounds__(64 * NWAVE) void backup_kernel(SearchDev D, const f
             r_vl[i] = D.ch_vl[rbase + i];
         }
         if (threadIdx.x == 0) {
-            r_nvsum = D.n_vsum[(size_t)t * D.N];
-            r_nvis = D.n_visits[(size_t)t * D.N];
-            r_nvl = D.n_vl[(size_t)t * D.N];
+            r_nvsum = D.node[(size_t)t * D.N].vsum;
+            r_nvis = D.node[(size_t)t * D.N].visits;
+            r_nvl = D.node[(size_t)t * D.N].vl;
         }
         if (part)
             for (int k = threadIdx.x; k < n; k += NTHR) {
@@ -2322,7 +2329,7 @@ __global__ __launch_bounds__(64 * NWAVE) void backup_kernel(SearchDev D, const f
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (node[u] < 0) node[u] = D.N - 1;
-                nc[u] = live[u] ? D.n_children[(size_t)t * D.N + node[u]] : 0;
+                nc[u] = live[u] ? D.node[(size_t)t * D.N + node[u]].children : 0;
 #pragma unroll
                 for (int r = 0; r < RP; ++r) {
                     const int i = lane + 64 * r;
@@ -2404,7 +2411,7 @@ __global__ __launch_bounds__(64 * NWAVE) void backup_kernel(SearchDev D, const f
                 if (m.k >= 0 && lane >= 1 && lane < m.depth) {
                     const size_t cs = (size_t)t * D.N + (m.entry >> 10), ce = cs * A + (m.entry & 1023);
                     st.vs = D.ch_vsum[ce]; st.cv = D.ch_visits[ce]; st.cl = D.ch_vl[ce];
-                    st.ns = D.n_vsum[cs]; st.nv = D.n_visits[cs]; st.nl = D.n_vl[cs];
+                    st.ns = D.node[cs].vsum; st.nv = D.node[cs].visits; st.nl = D.node[cs].vl;
                 }
                 return st;
             };
@@ -2419,7 +2426,7 @@ __global__ __launch_bounds__(64 * NWAVE) void backup_kernel(SearchDev D, const f
                     // (a Gumbel leaf with q_node < 0 is the reference's node[-1] quirk: every such leaf writes the LAST pool slot's
                     // raw value, the last one in leaf order wins - that one write is done below by wave 0, in leaf order, instead
                     // of by whichever wave comes last here)
-                    if (lane == 0 && m0.node >= 0) D.n_raw[(size_t)t * D.N + m0.node] = m0.v1 * 0.5f + m0.v2;   // tree.py:299
+                    if (lane == 0 && m0.node >= 0) D.node[(size_t)t * D.N + m0.node].raw = m0.v1 * 0.5f + m0.v2;   // tree.py:299
                     const float vleaf = m0.v0 + m0.v1 * 0.5f;   // tree.py:302
                     Fwd nf{-1, -1, 0.0, 0, 0, 0.f, 0, 0};
                     if (lane < depth) {
@@ -2451,9 +2458,9 @@ __global__ __launch_bounds__(64 * NWAVE) void backup_kernel(SearchDev D, const f
                             D.ch_vsum[ce] = nf.vs;
                             D.ch_visits[ce] = nf.cv;
                             D.ch_vl[ce] = nf.cl;
-                            D.n_vsum[cs] = nf.ns;
-                            D.n_visits[cs] = nf.nv;
-                            D.n_vl[cs] = nf.nl;
+                            D.node[cs].vsum = nf.ns;
+                            D.node[cs].visits = nf.nv;
+                            D.node[cs].vl = nf.nl;
                         }
                     }
                     f2 = f1;
@@ -2489,7 +2496,7 @@ __global__ __launch_bounds__(64 * NWAVE) void backup_kernel(SearchDev D, const f
             }
             if (last >= 0 && lane == 0) {
                 const float *val = value + (leaf_base + last) * 3;
-                D.n_raw[(size_t)t * D.N + D.N - 1] = val[1] * 0.5f + val[2];
+                D.node[(size_t)t * D.N + D.N - 1].raw = val[1] * 0.5f + val[2];
             }
         }
     } else if (wid == 0 && n > 0) {
@@ -2512,7 +2519,7 @@ __global__ __launch_bounds__(64 * NWAVE) void backup_kernel(SearchDev D, const f
             const float *val_n = value + (leaf_base + kn) * 3;
             const float v0_n = val_n[0], v1_n = val_n[1], v2_n = val_n[2];
             if (node < 0) node = D.N - 1;
-            if (lane == 0) D.n_raw[(size_t)t * D.N + node] = v1 * 0.5f + v2;   // tree.py:299
+            if (lane == 0) D.node[(size_t)t * D.N + node].raw = v1 * 0.5f + v2;   // tree.py:299
             if (cur >= 0) {
                 const float vleaf = v0 + v1 * 0.5f;   // tree.py:302
                 if (depth > 0) {
@@ -2533,14 +2540,14 @@ __global__ __launch_bounds__(64 * NWAVE) void backup_kernel(SearchDev D, const f
                         } else {
                             const double vs = D.ch_vsum[ce];
                             const int cv = D.ch_visits[ce], cl = D.ch_vl[ce];
-                            const float ns_ = D.n_vsum[cs];
-                            const int nv = D.n_visits[cs], nl = D.n_vl[cs];
+                            const float ns_ = D.node[cs].vsum;
+                            const int nv = D.node[cs].visits, nl = D.node[cs].vl;
                             D.ch_vsum[ce] = (double)((float)vs + v);         // float32 accumulation (file header)
                             D.ch_visits[ce] = cv + 1;
                             D.ch_vl[ce] = cl - 1;
-                            D.n_vsum[cs] = ns_ + v;
-                            D.n_visits[cs] = nv + 1;
-                            D.n_vl[cs] = nl - 1;
+                            D.node[cs].vsum = ns_ + v;
+                            D.node[cs].visits = nv + 1;
+                            D.node[cs].vl = nl - 1;
                         }
                     }
                 } else if (lane == 0) {
@@ -2552,15 +2559,15 @@ __global__ __launch_bounds__(64 * NWAVE) void backup_kernel(SearchDev D, const f
                         // all loads of a level first (independent, one round trip), then the stores
                         const double vs = D.ch_vsum[ce];
                         const int cv = D.ch_visits[ce], cl = D.ch_vl[ce];
-                        const float ns_ = D.n_vsum[cs];
-                        const int nv = D.n_visits[cs], nl = D.n_vl[cs];
-                        const int pe = D.n_pedge[cs], pn = D.n_parent[cs];
+                        const float ns_ = D.node[cs].vsum;
+                        const int nv = D.node[cs].visits, nl = D.node[cs].vl;
+                        const int pe = D.node[cs].pedge, pn = D.node[cs].parent;
                         D.ch_vsum[ce] = (double)((float)vs + v);
                         D.ch_visits[ce] = cv + 1;
                         D.ch_vl[ce] = cl - 1;
-                        D.n_vsum[cs] = ns_ + v;
-                        D.n_visits[cs] = nv + 1;
-                        D.n_vl[cs] = nl - 1;
+                        D.node[cs].vsum = ns_ + v;
+                        D.node[cs].visits = nv + 1;
+                        D.node[cs].vl = nl - 1;
                         v = 1.0f - v;
                         e = pe;
                         cur = pn;
@@ -2588,9 +2595,9 @@ __global__ __launch_bounds__(64 * NWAVE) void backup_kernel(SearchDev D, const f
             D.ch_vl[rbase + i] = r_vl[i];
         }
         if (threadIdx.x == 0) {
-            D.n_vsum[(size_t)t * D.N] = r_nvsum;
-            D.n_visits[(size_t)t * D.N] = r_nvis;
-            D.n_vl[(size_t)t * D.N] = r_nvl;
+            D.node[(size_t)t * D.N].vsum = r_nvsum;
+            D.node[(size_t)t * D.N].visits = r_nvis;
+            D.node[(size_t)t * D.N].vl = r_nvl;
         }
     }
     if (threadIdx.x == 0) D.n_leaves[t] = 0;
@@ -2681,7 +2688,7 @@ __device__ int select_root_halving(const SearchDev &D, int t, int node, int coun
         vsum[r] = D.ch_vsum[base + ii];
         logit[r] = D.ch_policy[base + ii] + D.noise[(size_t)t * A + ii];
     }
-    const int nc = D.n_children[ns];
+    const int nc = D.node[ns].children;
     int mx = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -2711,9 +2718,9 @@ __device__ int select_node_halving(Scratch &L, const SearchDev &D, int t, int no
     constexpr int R = (A + 63) / 64;
     const size_t ns = (size_t)t * D.N + node;
     const size_t base = ns * A;
-    const int nc = D.n_children[ns];
-    const int nv = D.n_visits[ns];
-    const double raw = (double)D.n_raw[ns];
+    const int nc = D.node[ns].children;
+    const int nv = D.node[ns].visits;
+    const double raw = (double)D.node[ns].raw;
     double logit[R], q[R];
     int vis[R];
     double mx = -INFINITY;
@@ -2883,7 +2890,7 @@ __global__ __launch_bounds__(64 * (1 + NW)) void select_gumbel_pipe_kernel(Searc
         if (active) {
             const size_t base = (size_t)t * D.N * A;
             double vsum[R];
-            r_nc = D.n_children[(size_t)t * D.N];
+            r_nc = D.node[(size_t)t * D.N].children;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int i = lane + 64 * r, ii = i < A ? i : A - 1;
@@ -3197,7 +3204,7 @@ __global__ __launch_bounds__(64 * (1 + NW)) void select_gumbel_pipe_kernel(Searc
                 const int i = lane + 64 * r;
                 if (i < r_nc) D.ch_vl[base + r_edge[r]] = r_cnt[r] - r_vis[r];       // rank order -> child index
             }
-            if (lane == 0) D.n_vl[(size_t)t * D.N] += r_added;
+            if (lane == 0) D.node[(size_t)t * D.N].vl += r_added;
         }
         if (active && !ok && lane == 0) {
             if (!(D.err[t] & (kErrPoolFull | kErrRngEmpty))) atomicOr(&D.err[t], kErrPipeline);
@@ -3249,7 +3256,7 @@ __global__ __launch_bounds__(64 * (1 + NW)) void select_gumbel_pipe_kernel(Searc
                     if (i < kPathCap) D.q_path[qs * kPathCap + i] = entry;
                     if (i >= 1) {
                         const size_t ns = (size_t)t * D.N + (entry >> 10);
-                        atomicAdd(&D.n_vl[ns], 1);
+                        atomicAdd(&D.node[ns].vl, 1);
                         atomicAdd(&D.ch_vl[ns * A + (entry & 1023)], 1);
                     }
                 }
@@ -3299,7 +3306,7 @@ __global__ __launch_bounds__(64 * (1 + NW)) void select_gumbel_pipe_kernel(Searc
                 if (lane < kPathCap) D.q_path[qs * kPathCap + lane] = entry;
                 if (lane >= 1) {                                                   // node.py:76-83 below the root
                     const size_t ns = (size_t)t * D.N + (entry >> 10);
-                    atomicAdd(&D.n_vl[ns], 1);
+                    atomicAdd(&D.node[ns].vl, 1);
                     atomicAdd(&D.ch_vl[ns * A + (entry & 1023)], 1);
                 }
             }
@@ -3357,7 +3364,7 @@ __global__ __launch_bounds__(64) void select_gumbel_kernel(SearchDev D, const in
                 int child = D.ch_index[base + e];
                 wave_sync();
                 if (lane == 0) {
-                    D.n_vl[ns] += 1;
+                    D.node[ns].vl += 1;
                     D.ch_vl[base + e] += 1;
                 }
                 if (visits < 1) {                                     // tree.py:412-416
@@ -3402,7 +3409,7 @@ __global__ __launch_bounds__(64) void play_kernel(SearchDev D, const int32_t *mo
         // chosen here so that a driver that only advances its positions needs no read-back between two searches
         constexpr int R = (G::A + 63) / 64;
         const size_t rbase = (size_t)t * D.N * G::A;
-        const int nc = D.meta[t].num_nodes > 0 ? D.n_children[(size_t)t * D.N] : 0;
+        const int nc = D.meta[t].num_nodes > 0 ? D.node[(size_t)t * D.N].children : 0;
         double best = 0.0;
         int best_i = -1;
 #pragma unroll
@@ -3454,11 +3461,11 @@ __global__ __launch_bounds__(64) void gather_node_kernel(SearchDev D, int A, int
     const size_t ns = (size_t)tree * D.N + node, base = ns * A;
     int32_t *head = reinterpret_cast<int32_t *>(out);
     if (lane == 0) {
-        head[0] = D.n_children[ns];
-        head[1] = D.n_visits[ns];
-        head[2] = D.n_vl[ns];
-        head[3] = __float_as_int(D.n_vsum[ns]);
-        head[4] = __float_as_int(D.n_raw[ns]);
+        head[0] = D.node[ns].children;
+        head[1] = D.node[ns].visits;
+        head[2] = D.node[ns].vl;
+        head[3] = __float_as_int(D.node[ns].vsum);
+        head[4] = __float_as_int(D.node[ns].raw);
         head[5] = D.err[tree];
         head[6] = head[7] = 0;
     }
@@ -3485,9 +3492,9 @@ __global__ __launch_bounds__(64) void gather_roots_kernel(SearchDev D, int A, un
     unsigned char *rec = out + (size_t)t * rec_bytes;
     int32_t *head = reinterpret_cast<int32_t *>(rec);
     if (lane == 0) {
-        head[0] = D.n_children[ns];
-        head[1] = D.n_visits[ns];
-        head[2] = __float_as_int(D.n_raw[ns]);
+        head[0] = D.node[ns].children;
+        head[1] = D.node[ns].visits;
+        head[2] = __float_as_int(D.node[ns].raw);
         head[3] = D.err[t];
     }
     int32_t *vis = head + 4, *vl = vis + A, *act = vl + A;
@@ -3519,11 +3526,11 @@ __global__ __launch_bounds__(64) void finish_roots_kernel(SearchDev D, int A, un
     const size_t ns = (size_t)t * D.N, base = ns * A;
     unsigned char *rec = out + (size_t)t * rec_bytes;
     int32_t *head = reinterpret_cast<int32_t *>(rec);
-    const int n = D.n_children[ns];
+    const int n = D.node[ns].children;
     if (lane == 0) {
         head[0] = n;
-        head[1] = D.n_visits[ns];
-        head[2] = __float_as_int(D.n_raw[ns]);
+        head[1] = D.node[ns].visits;
+        head[2] = __float_as_int(D.node[ns].raw);
         head[3] = D.err[t];
     }
     int32_t *vis = head + 4, *vl = vis + A, *act = vl + A;
@@ -3924,8 +3931,7 @@ int tg_search_create(const tg_search_config *cfg, tg_search **out) {
     ALLOC(ch_index, T * N * A) ALLOC(ch_visits, T * N * A) ALLOC(ch_vl, T * N * A)
     ALLOC(ch_vsum, T * N * A) ALLOC(ch_policy, T * N * A) ALLOC(ch_value, T * N * A)
     ALLOC(action, T * N * A)
-    ALLOC(n_children, T * N) ALLOC(n_visits, T * N) ALLOC(n_vl, T * N) ALLOC(n_parent, T * N)
-    ALLOC(n_pedge, T * N) ALLOC(n_vsum, T * N) ALLOC(n_raw, T * N)
+    ALLOC(node, T * N)
     ALLOC(noise, T * A)
     ALLOC(root_cells, T * s->NC) ALLOC(root_hist, T * s->HMAX) ALLOC(meta, T)
     ALLOC(q_node, T * K) ALLOC(q_pnode, T * K) ALLOC(q_pedge, T * K) ALLOC(n_leaves, T)
@@ -4030,8 +4036,7 @@ int tg_search_grow(tg_search *s, int new_tree_size) {
 #define GROW(field, per) items.push_back(GrowItem{reinterpret_cast<void **>(&D.field), sizeof(*D.field), (size_t)(per)});
     GROW(ch_index, A) GROW(ch_visits, A) GROW(ch_vl, A) GROW(ch_vsum, A) GROW(ch_policy, A) GROW(ch_value, A)
     GROW(action, A)
-    GROW(n_children, 1) GROW(n_visits, 1) GROW(n_vl, 1) GROW(n_parent, 1) GROW(n_pedge, 1) GROW(n_vsum, 1)
-    GROW(n_raw, 1)
+    GROW(node, 1)
 #undef GROW
     // phase 1: every new array allocated and filled; on any failure the new arrays are released and nothing changed
     int rc = TG_OK;
@@ -4814,8 +4819,7 @@ static SearchDev sub_dev(const tg_search *s, int t0, int n) {
     const size_t o = (size_t)t0, N = (size_t)D.N, A = (size_t)s->A, K = (size_t)D.K;
     D.ch_index += o * N * A; D.ch_visits += o * N * A; D.ch_vl += o * N * A;
     D.ch_vsum += o * N * A; D.ch_policy += o * N * A; D.ch_value += o * N * A; D.action += o * N * A;
-    D.n_children += o * N; D.n_visits += o * N; D.n_vl += o * N; D.n_parent += o * N; D.n_pedge += o * N;
-    D.n_vsum += o * N; D.n_raw += o * N;
+    D.node += o * N;
     D.noise += o * A;
     D.root_cells += o * s->NC; D.root_hist += o * s->HMAX; D.meta += o;
     D.q_node += o * K; D.q_pnode += o * K; D.q_pedge += o * K; D.q_depth += o * K; D.q_path += o * K * kPathCap;
@@ -5035,8 +5039,10 @@ int tg_search_read_path(tg_search *s, int tree, int slot, int32_t *nodes_host, i
         nodes.push_back(cur);
         edges.push_back(e);
         const size_t cs = (size_t)tree * D.N + cur;
-        TG_HIP(hipMemcpy(&e, D.n_pedge + cs, sizeof(int32_t), hipMemcpyDeviceToHost));
-        TG_HIP(hipMemcpy(&cur, D.n_parent + cs, sizeof(int32_t), hipMemcpyDeviceToHost));
+        NodeRec rec;
+        TG_HIP(hipMemcpy(&rec, D.node + cs, sizeof(NodeRec), hipMemcpyDeviceToHost));
+        e = rec.pedge;
+        cur = rec.parent;
         if ((int)nodes.size() > D.N) return tg::fail(TG_ERR_HIP, "tg_search_read_path: parent chain does not end");
     }
     *length_host = (int32_t)nodes.size();
