@@ -181,7 +181,14 @@ struct FillArgs {
     uint32_t *words;              // scratch [T][words_pitch]: the tempered 32-bit outputs of this piece, in stream order from word 0
     long long words_pitch;        // of the state's current block (rng_words_kernel -> rng_draws_kernel)
     int *pos0;                    // [T] position in that block the piece starts at
+    // Snapshots (few trees): the raw state every kSnapEvery blocks behind `base`, so that committing a whole search's consumption
+    // (one 19x19 tree: ~1 500 regenerations = 0.6-0.8 ms in front of tg_search_stream_state) starts from the nearest one.
+    uint32_t *snap;               // [T][snap_cap][624] or null
+    int snap_cap;
+    int *snap_n;                  // [T] valid snapshots of the CURRENT base (snapshot i = the state (i + 1) * kSnapEvery blocks on)
+    long long *cont_blk;          // [T] how many blocks behind `base` the state in `cont` is
 };
+constexpr int kSnapEvery = 32;
 
 // A piece in two launches (a regeneration is serial, the logarithms are not - and they are 6x the work):
 //   rng_words_kernel  one wavefront per tree: commits the consumed draws, walks the state over the piece's blocks and leaves
@@ -197,11 +204,26 @@ __global__ __launch_bounds__(64) void rng_words_kernel(FillArgs a) {
     MtRegs m;
     mt_load(m, st, lane);
     int pos = (int)st[kMtN];
+    long long abs0 = (a.from_cont && a.cont_blk) ? a.cont_blk[t] : 0;     // blocks behind `base` of the state in hand
+    int n_snap = a.snap ? a.snap_n[t] : 0;
     const long long lag = (!a.from_cont && a.lag) ? a.lag[t] : 0;
     if (lag > 0) {                                                   // commit what the searches consumed: base moves
-        pos = mt_skip(m, pos, 2 * lag, lane);
+        const long long end = (long long)pos + 2 * lag;              // first unconsumed word, counted from word 0 of block 0
+        const long long be = (end - 1) / kMtN;                       // its block, lazily (a boundary stays with the block before)
+        long long at = 0;
+        if (a.snap) {
+            long long k = be / kSnapEvery;
+            if (k > n_snap) k = n_snap;
+            if (k > 0) {
+                mt_load(m, a.snap + ((size_t)t * a.snap_cap + (size_t)(k - 1)) * kMtN, lane);
+                at = k * kSnapEvery;
+            }
+        }
+        for (; at < be; ++at) mt_twist(m, lane);
+        pos = (int)(end - kMtN * be);
         mt_store(m, st, lane);
         if (lane == 0) st[kMtN] = (uint32_t)pos;
+        n_snap = 0;                                                  // (they belonged to the old base)
     }
     if (lane == 0) a.pos0[t] = pos;
     // absolute word index = pos + stream word; block b holds [624 b, 624 b + 624); block 0 is the state as it stands
@@ -209,7 +231,17 @@ __global__ __launch_bounds__(64) void rng_words_kernel(FillArgs a) {
     const long long n_blocks = a.count > 0 ? (end - 1) / kMtN + 1 : 0;
     uint32_t *row = a.words + (size_t)t * a.words_pitch;
     for (long long b = 0; b < n_blocks; ++b) {
-        if (b > 0) mt_twist(m, lane);
+        if (b > 0) {
+            mt_twist(m, lane);
+            const long long abs_b = abs0 + b;
+            if (a.snap && !a.noise && abs_b % kSnapEvery == 0) {
+                const long long idx = abs_b / kSnapEvery - 1;
+                if (idx < a.snap_cap) {
+                    mt_store(m, a.snap + ((size_t)t * a.snap_cap + (size_t)idx) * kMtN, lane);
+                    if (idx + 1 > n_snap) n_snap = (int)(idx + 1);
+                }
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 10; ++r)
             if (r < 9 || lane < 48) row[kMtN * b + lane + 64 * r] = mt_temper(m.k[r]);
@@ -218,7 +250,12 @@ __global__ __launch_bounds__(64) void rng_words_kernel(FillArgs a) {
     const int pos_e = a.count > 0 ? (int)(end - kMtN * (n_blocks - 1)) : pos;
     uint32_t *dst = (a.noise ? a.base : a.cont) + (size_t)t * kStateWords;
     mt_store(m, dst, lane);
-    if (lane == 0) dst[kMtN] = (uint32_t)pos_e;
+    if (lane == 0) {
+        dst[kMtN] = (uint32_t)pos_e;
+        if (a.noise) n_snap = 0;                                     // (base moved behind the noise draws)
+        if (a.snap) a.snap_n[t] = n_snap;
+        if (a.cont_blk && !a.noise) a.cont_blk[t] = abs0 + (n_blocks > 0 ? n_blocks - 1 : 0);
+    }
 }
 
 __global__ __launch_bounds__(256) void rng_draws_kernel(FillArgs a) {

@@ -3649,6 +3649,10 @@ struct tg_search {
     uint32_t *rng_words = nullptr;                // scratch: the tempered words of the piece being generated (rng_words_kernel)
     size_t rng_words_cap = 0;
     int *rng_pos0 = nullptr;
+    uint32_t *rng_snap = nullptr;                 // [T][rng_snap_cap][624]: state snapshots behind mt_base (T <= 64)
+    int rng_snap_cap = 0;
+    int *rng_snap_n = nullptr;
+    long long *rng_cont_blk = nullptr;
     uint32_t *seed_pin = nullptr;                 // pinned [T][625]: seeds on their way up, one state on its way down
     hipEvent_t seed_ev = nullptr;
     bool seed_ev_used = false;
@@ -4012,6 +4016,9 @@ int tg_search_destroy(tg_search *s) {
     if (s->mt_cont) (void)hipFree(s->mt_cont);
     if (s->rng_words) (void)hipFree(s->rng_words);
     if (s->rng_pos0) (void)hipFree(s->rng_pos0);
+    if (s->rng_snap) (void)hipFree(s->rng_snap);
+    if (s->rng_snap_n) (void)hipFree(s->rng_snap_n);
+    if (s->rng_cont_blk) (void)hipFree(s->rng_cont_blk);
     if (s->seed_pin) (void)hipHostFree(s->seed_pin);
     if (s->seed_ev) (void)hipEventDestroy(s->seed_ev);
     if (s->lag_pin) (void)hipHostFree(s->lag_pin);
@@ -4412,6 +4419,10 @@ static int rng_alloc(tg_search *s) {
     TG_HIP(hipMalloc(reinterpret_cast<void **>(&s->mt_base), words * sizeof(uint32_t)));
     TG_HIP(hipMalloc(reinterpret_cast<void **>(&s->mt_cont), words * sizeof(uint32_t)));
     TG_HIP(hipMalloc(reinterpret_cast<void **>(&s->rng_pos0), T * sizeof(int)));
+    TG_HIP(hipMalloc(reinterpret_cast<void **>(&s->rng_snap_n), T * sizeof(int)));
+    TG_HIP(hipMalloc(reinterpret_cast<void **>(&s->rng_cont_blk), T * sizeof(long long)));
+    TG_HIP(hipMemset(s->rng_snap_n, 0, T * sizeof(int)));
+    TG_HIP(hipMemset(s->rng_cont_blk, 0, T * sizeof(long long)));
     TG_HIP(hipMemset(s->mt_base, 0, words * sizeof(uint32_t)));
     TG_HIP(hipMemset(s->mt_cont, 0, words * sizeof(uint32_t)));
     TG_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->seed_pin), words * sizeof(uint32_t), hipHostMallocDefault));
@@ -4446,6 +4457,7 @@ static int rng_sync_seeds(tg_search *s) {
         }
         const size_t o = (size_t)t * tg_rng::kStateWords, n = (size_t)(t1 - t) * tg_rng::kStateWords;
         TG_HIP(hipMemcpyAsync(s->mt_base + o, s->seed_pin + o, n * sizeof(uint32_t), hipMemcpyHostToDevice, s->copy_stream));
+        TG_HIP(hipMemsetAsync(s->rng_snap_n + t, 0, (size_t)(t1 - t) * sizeof(int), s->copy_stream));   // (snapshots of the old stream)
         t = t1;
     }
     TG_HIP(hipEventRecord(s->seed_ev, s->copy_stream));
@@ -4484,6 +4496,22 @@ static int rng_launch(tg_search *s, const tg_rng::FillArgs &a_in, int slot) {
         s->rng_words_cap = (size_t)T * (size_t)pitch;
     }
     a.words = s->rng_words; a.words_pitch = pitch; a.pos0 = s->rng_pos0;
+    if (T <= 64) {
+        // state snapshots every kSnapEvery blocks of the whole window (legacy_rng_device.h): a later commit of the consumed draws
+        // starts from the nearest one
+        const long long window = a.noise ? 0 : (a.pitch > a.count ? a.pitch : a.count);
+        const int want = (int)((2 * window / tg_rng::kMtN + 2) / tg_rng::kSnapEvery + 1);
+        if (want > s->rng_snap_cap) {
+            if (s->rng_snap) (void)hipFree(s->rng_snap);           // implicit device synchronisation (rare: the largest window so far)
+            s->rng_snap = nullptr;
+            s->rng_snap_cap = 0;
+            TG_HIP(hipMalloc(reinterpret_cast<void **>(&s->rng_snap), (size_t)T * want * tg_rng::kMtN * sizeof(uint32_t)));
+            s->rng_snap_cap = want;
+            TG_HIP(hipMemsetAsync(s->rng_snap_n, 0, (size_t)T * sizeof(int), s->copy_stream));
+        }
+        a.snap = s->rng_snap; a.snap_cap = s->rng_snap_cap; a.snap_n = s->rng_snap_n;
+    }
+    a.cont_blk = s->rng_cont_blk;
     hipLaunchKernelGGL(tg_rng::rng_words_kernel, dim3(T), dim3(64), 0, s->copy_stream, a);
     TG_HIP(hipGetLastError());
     if (a.count > 0) {
