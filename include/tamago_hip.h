@@ -301,6 +301,8 @@ int tg_search_read_node(tg_search *s, int tree, int node, int32_t *num_children,
                         int32_t *children_visits, int32_t *children_virtual_loss,
                         double *children_value_sum, double *children_policy,
                         double *children_value, float *node_value_sum, float *raw_value);
+/* num_nodes of the tree that tg_search_read_node read last, as of that read (same record, no device access). */
+int tg_search_node_record_num_nodes(tg_search *s, int32_t *num_nodes_host);
 int tg_search_num_nodes(tg_search *s, int32_t *num_nodes_host /* [T] */);
 /* Root statistics of all trees in one call: num_children [T], action [T][A],
  * children_visits [T][A] (what get_best_move reads, node.py:169-184). Synchronises. */

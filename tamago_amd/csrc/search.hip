@@ -3467,7 +3467,8 @@ __global__ __launch_bounds__(64) void gather_node_kernel(SearchDev D, int A, int
         head[3] = __float_as_int(D.node[ns].vsum);
         head[4] = __float_as_int(D.node[ns].raw);
         head[5] = D.err[tree];
-        head[6] = head[7] = 0;
+        head[6] = D.meta[tree].num_nodes;          // (tg_search_node_record_num_nodes: no second read after a search)
+        head[7] = 0;
     }
     int32_t *idx = head + 8, *vis = idx + A, *vl = vis + A, *act = vl + A;
     double *vsum = reinterpret_cast<double *>(out + 32 + (((size_t)4 * A * 4 + 7) & ~(size_t)7));
@@ -5149,6 +5150,15 @@ int tg_search_read_node(tg_search *s, int tree, int node, int32_t *num_children,
     if (children_value_sum) std::memcpy(children_value_sum, vsum, A * 8);
     if (children_policy) std::memcpy(children_policy, pol, A * 8);
     if (children_value) std::memcpy(children_value, val, A * 8);
+    return TG_OK;
+}
+
+// num_nodes of the tree the last tg_search_read_node read, as of that read (it travels in the same record: a search's caller
+// wants both - mcts/tree.py:57-105 reads the root and tree.num_nodes - and a second call would be a second host round trip)
+int tg_search_node_record_num_nodes(tg_search *s, int32_t *num_nodes_host) {
+    if (!s || !num_nodes_host) return tg::fail(TG_ERR_ARG, "tg_search_node_record_num_nodes: null argument");
+    if (!s->node_host) return tg::fail(TG_ERR_STATE, "tg_search_node_record_num_nodes: no node has been read");
+    *num_nodes_host = reinterpret_cast<const int32_t *>(s->node_host)[6];
     return TG_OK;
 }
 

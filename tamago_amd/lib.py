@@ -93,6 +93,7 @@ _SIGNATURES = {
     "tg_search_draw_noise": (c_int, [c_void_p, c_void_p]),
     "tg_legacy_exponentials": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "tg_glibc_log": (c_int, [c_void_p, c_size_t, c_void_p]),
+    "tg_search_node_record_num_nodes": (c_int, [c_void_p, POINTER(c_int32)]),
     "tg_search_own_stream": (c_int, [c_void_p, POINTER(c_void_p)]),
     "tg_search_debug_read_window": (c_int, [c_void_p, c_int, c_size_t, c_size_t, c_void_p]),
     "tg_search_debug_stream_walk": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64]),

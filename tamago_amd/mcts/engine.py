@@ -256,7 +256,9 @@ class SearchEngine:
         self._feed_rng(self.A * (1 + first_batch))
         _lib.check(self.lib.tg_search_root_planes(self.handle, self.planes.data_ptr(),
                                                   self._stream()), "tg_search_root_planes")
-        self._collect_rng()
+        # a Dirichlet prior takes one draw per child (mcts/tree.py:509-519): what the root expansion consumed IS the roots'
+        # child counts - known as soon as the expansion kernel is done, without waiting for the root's forward pass and backup
+        self.root_children = np.asarray(self._collect_rng(), dtype=np.int64).copy()
         self._evaluate_and_backup(1, use_logit)
 
     def prefetch_rng(self, leaves: int):
@@ -492,4 +494,7 @@ class SearchEngine:
         view.node_value_sum = np.float32(nvs.value)
         view.raw_value = np.float32(raw.value)
         view.action = [int(v) for v in action]
+        n = ctypes.c_int32(0)
+        _lib.check(self.lib.tg_search_node_record_num_nodes(self.handle, ctypes.byref(n)), "tg_search_node_record_num_nodes")
+        view.tree_num_nodes = int(n.value)           # num_nodes of the tree, read with the node
         return view

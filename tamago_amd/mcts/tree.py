@@ -127,13 +127,13 @@ class MCTSTree:
         engine.set_root(0, board, color, np.random.get_state())
         engine.root_eval(use_logit=False)                              # _initialize_search
         time_manager.start_timer()
-        if int(engine.read_roots()[0][0]) == 1:                            # tree.py:76-77
+        if int(engine.root_children[0]) == 1:                              # tree.py:76-77 (the root's child count off the draw cursor)
             self.num_nodes = int(engine.num_nodes()[0])
             self._commit_rng(engine)
             return PASS
         self.search(board, color, time_manager, analysis_query or {}, _engine=engine)
         root = engine.read_node(0, 0)
-        self.num_nodes = int(engine.num_nodes()[0])
+        self.num_nodes = root.tree_num_nodes
         self._sync_size(engine)
         self._commit_rng(engine)
         search_time = time_manager.calculate_consumption_time()
@@ -288,13 +288,13 @@ class MCTSTree:
         engine.set_root(0, board, color, np.random.get_state())
         engine.root_eval(use_logit=True)
         engine.set_gumbel_noise()
-        nc, _, _ = engine.read_roots()
+        nc = engine.root_children                  # (child count off the draw cursor: no read-back behind the root evaluation)
         base = int(nc[0]) if nc[0] < MAX_CONSIDERED_NODES else MAX_CONSIDERED_NODES
         for num_considered, max_count in get_candidates_and_visit_pairs(base, visits).items():
             engine.ensure_capacity(num_considered * max_count)
             engine.gumbel_phase([num_considered], [max_count])
         root = self.get_root()
-        self.num_nodes = int(engine.num_nodes()[0])
+        self.num_nodes = root.tree_num_nodes
         self._commit_rng(engine)
         next_index = root.select_move_by_sequential_halving_for_root(PLAYOUTS)
         value = root.calculate_value_evaluation(next_index)
