@@ -4597,7 +4597,9 @@ static int feed_streams_impl(tg_search *s, size_t need, int force, size_t first)
     if (first == 0 && T <= 16 && need >= 2048 && need <= ((size_t)1 << 20)) {
         s->eager_need = need;
         first = need;
-        need *= 2;                                  // (one tree, ms per move at 19x19 / 9x9: x2 11.4 / 1.65, x4 11.8 / 1.70 - a larger window means a longer commit of the consumed draws in front of the next one)
+        // (one tree, ms per move at 9x9 / 19x19 with state snapshots: x2 1.475 / 10.94, x3 1.483 / 10.92, x4 1.464 / 10.91, x8 1.595 / 10.97)
+        static const int overgen = tg::knob("TG_RNG_OVERGEN") ? std::max(1, atoi(tg::knob("TG_RNG_OVERGEN"))) : 2;
+        need *= (size_t)overgen;
         s->auto_rest = true;
     }
     const int idx = 1 - s->rng_active;             // never the window a running kernel may read
