@@ -232,6 +232,7 @@ struct tg_net {
     std::mutex scratch_mu;
     std::map<hipStream_t, float *> scratch_by_stream;
     std::map<hipStream_t, int *> flag_by_stream;      // f16 split kernel: range flag per launch stream
+    std::map<hipStream_t, unsigned> flag_seq_by_stream;   // 9x9: launches so far on the stream (which of its two flag sets is next)
     // ... and which GROUPS (workgroup passes: 3 / 1 boards at 9x9, a board at 19x19) raised it: one bit per group, all zero between
     // launches (the exact kernel clears the bits it consumes), so that it redoes those groups only
     struct GroupBits { int *mem = nullptr; int words = 0; };

@@ -283,8 +283,12 @@ struct WinoCfg {
 template <int S, int G, bool GS = false>
 __global__ __launch_bounds__(512, 2) void dualnet_fwd_wino8_kernel(
     NetDev net, const float *__restrict__ planes, int batch, int want_logits,
-    float *__restrict__ policy, float *__restrict__ value, const int *__restrict__ guard, int *__restrict__ group_bits) {
+    float *__restrict__ policy, float *__restrict__ value, const int *__restrict__ guard, int *__restrict__ group_bits,
+    int *__restrict__ clear_next) {
     using C = WinoCfg<S, G, GS>;
+    // (guard launches of the 9x9 f16 kernels: the flag words of the stream's NEXT launch are cleared here - two sets alternate -
+    // instead of by a 5 us memset node in front of every forward pass; nobody reads that set during this launch)
+    if (clear_next != nullptr && blockIdx.x == 0 && threadIdx.x < 2) clear_next[threadIdx.x] = 0;
     // fallback launch behind the split-operand kernel: runs only if that kernel raised its range flag - and, when that kernel
     // says WHICH groups left the f16 range (bit 0 of the flag + one bit per group in group_bits; bit 1 of the flag = redo
     // everything: a band gave up waiting), only over those groups: a single hot position costs one group's redo, not the batch's
@@ -634,7 +638,7 @@ int launch(tg_net *net, const float *planes, int batch, int want_logits, float *
 
 template <int S, int G, bool GS = false>
 int launch_wino8(tg_net *net, const float *planes, int batch, int want_logits, float *policy,
-                 float *value, hipStream_t stream, const int *guard = nullptr, int *group_bits = nullptr) {
+                 float *value, hipStream_t stream, const int *guard = nullptr, int *group_bits = nullptr, int *clear_next = nullptr) {
     using C = WinoCfg<S, G, GS>;
     auto kern = dualnet_fwd_wino8_kernel<S, G, GS>;
     static bool attr_set[16] = {};
@@ -658,7 +662,7 @@ int launch_wino8(tg_net *net, const float *planes, int batch, int want_logits, f
         dev.scratch = slot;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), C::LDS_BYTES, stream, dev, planes, batch,
-                       want_logits, policy, value, guard, group_bits);
+                       want_logits, policy, value, guard, group_bits, clear_next);
     TG_HIP(hipGetLastError());
     return TG_OK;
 }
@@ -1115,18 +1119,28 @@ int tg_net_forward_dev(tg_net *net, const float *planes_dev, int batch, int want
             // makes the exact-fp32 Winograd kernel, queued right behind, redo the batch if a layer output
             // left the f16 range; with the flag clear that launch exits at once.
             const int group = batch > net->num_cus ? 3 : 1;
-            int *flag = nullptr;
+            // [range flag, group tickets] x 2: a stream's launches alternate between the two sets, and the guard launch behind
+            // launch k clears the set of launch k + 1 (no memset node in front of a forward pass: ~8 us per launch with its gap -
+            // five per single-tree move, a dozen per self-play move).  Rounds 3 and 4 took the memset out twice and put it back
+            // twice: the 2 048-tree bench lost 20 % without it, because the node happened to let the next mini-batch's 344 MB
+            // random window - then uploaded from the host - slip under the forward pass.  That upload is gone (round 6).
+            int *flag = nullptr, *flag_next = nullptr;
             {
                 std::lock_guard<std::mutex> lock(net->scratch_mu);
                 int *&slot = net->flag_by_stream[st];
-                if (!slot) TG_HIP(hipMalloc(reinterpret_cast<void **>(&slot), 2 * sizeof(int)));   // [range flag, group tickets]
-                flag = slot;
+                if (!slot) {
+                    TG_HIP(hipMalloc(reinterpret_cast<void **>(&slot), 4 * sizeof(int)));
+                    TG_HIP(hipMemset(slot, 0, 4 * sizeof(int)));
+                }
+                const unsigned seq = net->flag_seq_by_stream[st]++;
+                flag = slot + 2 * (seq & 1u);
+                flag_next = slot + 2 * ((seq + 1u) & 1u);
             }
-            // (This memset node stays.  Twice - a ring of flags in round 3, the guard launch zeroing the words itself in
-            // round 4 - the launch went without it, and twice the 2 048-tree bench lost 20 % (5.85 -> 4.60 M leaf-evals/s):
-            // the next mini-batch's 344 MB random window, uploaded on the copy stream, is no longer hidden under the
-            // forward pass.  Self-play gained 1 % from its removal.)
-            TG_HIP(hipMemsetAsync(flag, 0, 2 * sizeof(int), st));
+            // (A self-play move's sub-group launches - several streams at once, grid caps set - keep the memset: without it the
+            // shard faulted, with kernels serialised it did not; a two-stream replay of plain forward launches,
+            // tools/experiments/fwd_two_streams.py, is clean - the race was not found, so the launches that showed it keep the
+            // node that hides it.)
+            if (tg::launch_caps().guard > 0 || tg::knob("TG_FWD_FLAG_MEMSET")) TG_HIP(hipMemsetAsync(flag, 0, 2 * sizeof(int), st));
             // (the one-axis kernel marks the groups that left the range: the exact kernel redoes those only; the direct split
             // kernel raises the flag alone: the whole batch)
             int *bits = nullptr;
@@ -1136,8 +1150,8 @@ int tg_net_forward_dev(tg_net *net, const float *planes_dev, int batch, int want
             int rc = w1d ? tg::w1d_forward(net, group, planes_dev, batch, want_logits, policy_dev, value_dev, flag, bits, st)
                          : tg::split_forward(net, group, planes_dev, batch, want_logits, policy_dev, value_dev, flag, st);
             if (rc) return rc;
-            if (group == 3) return launch_wino8<9, 3>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st, flag, bits);
-            return launch_wino8<9, 1>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st, flag, bits);
+            if (group == 3) return launch_wino8<9, 3>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st, flag, bits, flag_next);
+            return launch_wino8<9, 1>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st, flag, bits, flag_next);
         }
         const int wg = pick_wino(9, batch, net->num_cus);
         if (wg == 1) return launch_wino8<9, 1>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st);

@@ -4497,7 +4497,7 @@ static int rng_launch(tg_search *s, const tg_rng::FillArgs &a_in, int slot) {
         s->rng_words_cap = (size_t)T * (size_t)pitch;
     }
     a.words = s->rng_words; a.words_pitch = pitch; a.pos0 = s->rng_pos0;
-    if (T <= 64) {
+    if (T <= 64 && !tg::knob("TG_RNG_NO_SNAP")) {
         // state snapshots every kSnapEvery blocks of the whole window (legacy_rng_device.h): a later commit of the consumed draws
         // starts from the nearest one
         const long long window = a.noise ? 0 : (a.pitch > a.count ? a.pitch : a.count);
