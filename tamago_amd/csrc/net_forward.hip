@@ -673,7 +673,11 @@ namespace tg {
 // Grid caps of the launches a thread queues (net_device.h): per launching thread, so a network handle shared by several group
 // threads of a shard carries no launch state (round 6; until then two atomics on the handle, last writer wins).
 LaunchCaps &launch_caps() {
-    static thread_local LaunchCaps caps;
+    static thread_local LaunchCaps caps = [] {
+        LaunchCaps c;
+        if (const char *env = tg::knob("TG_FWD_TEST_GUARD_CAP")) c.guard = atoi(env);      // (experiments: caps outside a self-play move)
+        return c;
+    }();
     return caps;
 }
 }  // namespace tg
@@ -1140,7 +1144,8 @@ int tg_net_forward_dev(tg_net *net, const float *planes_dev, int batch, int want
             // shard faulted, with kernels serialised it did not; a two-stream replay of plain forward launches,
             // tools/experiments/fwd_two_streams.py, is clean - the race was not found, so the launches that showed it keep the
             // node that hides it.)
-            if (tg::launch_caps().guard > 0 || tg::knob("TG_FWD_FLAG_MEMSET")) TG_HIP(hipMemsetAsync(flag, 0, 2 * sizeof(int), st));
+            if ((tg::launch_caps().guard > 0 && !tg::knob("TG_FWD_FLAG_PINGPONG")) || tg::knob("TG_FWD_FLAG_MEMSET"))
+                TG_HIP(hipMemsetAsync(flag, 0, 2 * sizeof(int), st));
             // (the one-axis kernel marks the groups that left the range: the exact kernel redoes those only; the direct split
             // kernel raises the flag alone: the whole batch)
             int *bits = nullptr;
