@@ -814,7 +814,8 @@ int tg_net_create(int board_size, int device, const float *params, size_t n_para
     }
     {
         void *d = nullptr;
-        if (hipMalloc(&d, 2 * sizeof(unsigned long long)) != hipSuccess || hipMemset(d, 0, 2 * sizeof(unsigned long long)) != hipSuccess) {
+        if (hipMalloc(&d, 2 * sizeof(unsigned long long)) != hipSuccess || hipMemset(d, 0, 2 * sizeof(unsigned long long)) != hipSuccess ||
+            hipStreamSynchronize(nullptr) != hipSuccess) {
             delete net;
             return tg::fail(TG_ERR_HIP, "tg_net_create: fallback counter");
         }
@@ -891,7 +892,7 @@ static int group_bits_for(tg_net *net, hipStream_t st, int groups, int **out) {
         const int cap = words < 2048 ? 2048 : words;
         void *d = nullptr;
         TG_HIP(hipMalloc(&d, (size_t)cap * sizeof(int)));
-        TG_HIP(hipMemset(d, 0, (size_t)cap * sizeof(int)));
+        TG_HIP(hipMemsetAsync(d, 0, (size_t)cap * sizeof(int), st));   // (in the launching stream's order: see the flag words)
         slot.mem = static_cast<int *>(d);
         slot.words = cap;
     }
@@ -1134,18 +1135,16 @@ int tg_net_forward_dev(tg_net *net, const float *planes_dev, int batch, int want
                 int *&slot = net->flag_by_stream[st];
                 if (!slot) {
                     TG_HIP(hipMalloc(reinterpret_cast<void **>(&slot), 4 * sizeof(int)));
-                    TG_HIP(hipMemset(slot, 0, 4 * sizeof(int)));
+                    // (cleared in the launching stream's order: hipMemset on device memory returns before the fill has run, and
+                    // the null stream it runs on does not order a non-blocking stream - a first launch there took its group
+                    // tickets from whatever the allocation held)
+                    TG_HIP(hipMemsetAsync(slot, 0, 4 * sizeof(int), st));
                 }
                 const unsigned seq = net->flag_seq_by_stream[st]++;
                 flag = slot + 2 * (seq & 1u);
                 flag_next = slot + 2 * ((seq + 1u) & 1u);
             }
-            // (A self-play move's sub-group launches - several streams at once, grid caps set - keep the memset: without it the
-            // shard faulted, with kernels serialised it did not; a two-stream replay of plain forward launches,
-            // tools/experiments/fwd_two_streams.py, is clean - the race was not found, so the launches that showed it keep the
-            // node that hides it.)
-            if ((tg::launch_caps().guard > 0 && !tg::knob("TG_FWD_FLAG_PINGPONG")) || tg::knob("TG_FWD_FLAG_MEMSET"))
-                TG_HIP(hipMemsetAsync(flag, 0, 2 * sizeof(int), st));
+            if (tg::knob("TG_FWD_FLAG_MEMSET")) TG_HIP(hipMemsetAsync(flag, 0, 2 * sizeof(int), st));   // (experiments: the node back)
             // (the one-axis kernel marks the groups that left the range: the exact kernel redoes those only; the direct split
             // kernel raises the flag alone: the whole batch)
             int *bits = nullptr;

@@ -4426,6 +4426,7 @@ static int rng_alloc(tg_search *s) {
     TG_HIP(hipMemset(s->rng_cont_blk, 0, T * sizeof(long long)));
     TG_HIP(hipMemset(s->mt_base, 0, words * sizeof(uint32_t)));
     TG_HIP(hipMemset(s->mt_cont, 0, words * sizeof(uint32_t)));
+    TG_HIP(hipStreamSynchronize(nullptr));               // (the fills above: not ordered before a non-blocking stream otherwise)
     TG_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->seed_pin), words * sizeof(uint32_t), hipHostMallocDefault));
     TG_HIP(hipEventCreateWithFlags(&s->seed_ev, hipEventDisableTiming));
     TG_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->lag_pin), tg_search::kLagRing * T * sizeof(long long), hipHostMallocMapped));
