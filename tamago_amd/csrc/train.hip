@@ -1088,6 +1088,7 @@ int talloc(tg_trainer *t, T **out, size_t count) {
     void *p = nullptr;
     TG_HIP(hipMalloc(&p, count * sizeof(T)));
     TG_HIP(hipMemset(p, 0, count * sizeof(T)));
+    TG_HIP(hipStreamSynchronize(nullptr));      // (the fill is queued on the null stream: not ordered before a non-blocking stream's step)
     t->allocs.push_back(p);
     *out = static_cast<T *>(p);
     return TG_OK;
@@ -1207,7 +1208,10 @@ int tg_trainer_read_losses(tg_trainer *t, double *sums_host, int reset) {
         sums_host[k] = 0.0;
         for (int r = 0; r < kRep; ++r) sums_host[k] += rep[r * 4 + k];
     }
-    if (reset) TG_HIP(hipMemset(t->dev.loss, 0, sizeof(rep)));
+    if (reset) {
+        TG_HIP(hipMemset(t->dev.loss, 0, sizeof(rep)));
+        TG_HIP(hipStreamSynchronize(nullptr));  // (done before the caller queues the next step on whatever stream)
+    }
     return TG_OK;
 }
 
