@@ -2842,6 +2842,16 @@ __global__ __launch_bounds__(64 * (1 + NW)) void select_gumbel_pipe_kernel(Searc
     __shared__ int rm_path[kRootMemo][kRootPath];
     __shared__ int8_t sched[kPipeMaxK / 2];
     __shared__ int bulk_n;
+    // The look-ahead walks (below: "Expansions first") of a phase's root children are independent of each other - disjoint
+    // subtrees, statistics that do not move - and the workers have nothing to do until the first job is queued: every wave of
+    // the workgroup walks its share (entry f on wave f mod (1 + NW), its own softmax scratch), the selector then hands out node
+    // numbers, draws and jobs in entry order as before.  (The walks were 112 k of the selector's 194 k cycles per phase.)
+    __shared__ HalvingScratch<S> hsw[NW];
+    __shared__ int la_ready, la_done, la_n;
+    __shared__ int la_mv[kRootMemo], la_vis[kRootMemo], la_child[kRootMemo], la_e[kRootMemo];       // entry f at the root
+    __shared__ int la_res[kRootMemo], la_node[kRootMemo], la_edge[kRootMemo], la_chd[kRootMemo], la_depth[kRootMemo];   // where its walk ended
+    __shared__ int16_t la_moves[kRootMemo][kRootPath];
+    constexpr int kWalkLeaf = 1, kWalkExpand = 2, kWalkDeep = 3, kWalkPoolFull = 4;
     const int t = blockIdx.x;
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const RootMeta meta = D.meta[t];
@@ -2852,6 +2862,7 @@ __global__ __launch_bounds__(64 * (1 + NW)) void select_gumbel_pipe_kernel(Searc
     }
     for (int i = threadIdx.x; i < kPipeMaxK / 32; i += NTHR) sh.done_bits[i] = 0u;
     if (threadIdx.x == 0) {
+        la_ready = 0; la_done = 0; la_n = 0;
         sh.cursor_seq = 0;
         sh.cursor_val = D.rng_cursor[t];
         sh.final_count = -1;
@@ -2865,13 +2876,34 @@ __global__ __launch_bounds__(64 * (1 + NW)) void select_gumbel_pipe_kernel(Searc
     int queued = 0;
 
     // s_memtime accumulators of tree 0's selector (tg_search_profile; tools/profile_gumbel.py): 0 set-up (root into
-    // registers, ranking), 1 look-ahead for expansions, 2 descents that walk, 3 descents answered by the root memo,
-    // 4 waiting for a free job slot (inside 1..3), 5 write-back, 6 / 7 descents that walked / did not
+    // registers, ranking), 1 the phase's root choices, 8 nodes and EXPAND jobs handed out, 7 this wave's share of the entries'
+    // walks, 3 waiting for the other waves' shares, 2 first descents, 4 waiting for a free job slot (inside 1..2), 5 write-back,
+    // 6 first descents (count)
     const bool prof = D.prof && t == 0;
     const long long t_begin = prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
-    long long tp = t_begin, pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tp = t_begin, pc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     auto lap = [&](int i) {
         if (prof) { const long long now = (long long)__builtin_amdgcn_s_memtime(); pc[i] += now - tp; tp = now; }
+    };
+    // entry f's walk from its root child down to where the first descent will end - a leaf, or the point of expansion - without
+    // side effects; paths longer than the per-entry buffers are left to the selector's one-by-one code (kWalkDeep)
+    auto walk = [&](int f, HalvingScratch<S> &scratch) {
+        int node = 0, depth = 0, res = kWalkDeep;
+        int mv = la_mv[f], visits = la_vis[f], child = la_child[f], e = la_e[f];
+        while (depth < kRootPath - 2) {
+            if (lane == 0) { la_moves[f][depth] = (int16_t)mv; rm_path[f][depth] = (node << 10) | e; }
+            ++depth;
+            if (visits < 1) { res = kWalkLeaf; break; }
+            if (child == kNotExpanded) { res = kWalkExpand; break; }
+            if (child >= n0) break;                                       // (created in this launch: cannot happen, subtrees are disjoint)
+            node = child;
+            e = select_node_halving<S>(scratch, D, t, node, lane);
+            const size_t nb = ((size_t)t * D.N + node) * A;
+            mv = D.action[nb + e];
+            visits = D.ch_visits[nb + e];
+            child = D.ch_index[nb + e];
+        }
+        if (lane == 0) { la_res[f] = res; la_node[f] = node; la_edge[f] = e; la_chd[f] = child; la_depth[f] = depth; }
     };
     if (wid == 0) {
         // ---- selector -------------------------------------------------------------------
@@ -2967,16 +2999,18 @@ __global__ __launch_bounds__(64 * (1 + NW)) void select_gumbel_pipe_kernel(Searc
         __shared__ int memo_tag[kMemo], memo_edge[kMemo], memo_move[kMemo], memo_vis[kMemo], memo_child[kMemo];
         for (int i = lane; i < kMemo; i += 64) memo_tag[i] = -1;
         // (leaves by root child: rm_* / sched above.  The network still evaluates every queued leaf.)
-        int n_first = 0, my_first_pos = -1, n_desc = 0;      // entries so far; lane f: entry f's root child; descents so far
+        int n_first = 0, n_desc = 0, n_iter = 0;             // entries so far; descents so far; threshold levels walked one by one
         wave_sync();
         auto publish = [&](int plane_slot, int parent, int edge, int child, int expand, int xseq, int depth, int src,
-                           const int *path_src = nullptr) -> bool {
+                           const int *path_src = nullptr, const int16_t *moves_src = nullptr) -> bool {
             if (jid >= kPipeMaxK) return false;
             const int slot = jid % kPipeSlots;
             const long long w0 = prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
             if (!pipe_wait_ge(&sh.slot_done[slot], jid / kPipeSlots)) return false;
             if (prof) pc[4] += (long long)__builtin_amdgcn_s_memtime() - w0;
-            if (path_src) {                                      // COPY job: the worker needs the path only
+            if (path_src && moves_src) {                         // an entry's recorded walk
+                for (int i = lane; i < depth; i += 64) { sh.moves[slot][i] = moves_src[i]; sh.paths[slot][i] = path_src[i]; }
+            } else if (path_src) {                               // COPY job: the worker needs the path only
                 for (int i = lane; i < depth; i += 64) sh.paths[slot][i] = path_src[i];
             } else {
                 for (int i = lane; i < depth; i += 64) { sh.moves[slot][i] = sel_moves[i]; sh.paths[slot][i] = sel_path[i]; }
@@ -3002,88 +3036,131 @@ __global__ __launch_bounds__(64 * (1 + NW)) void select_gumbel_pipe_kernel(Searc
         // allocated and wait, if at all, for a job that is about to finish.  Subtrees of different root children are
         // disjoint and statistics are constant within a phase, so every choice is what the one-by-one order makes.
         lap(0);
+        // ---- the root choices of the phase, simulated on a copy of the counters: entries (first appearances) and the schedule ----
+        // A choice is "the first child in rank order whose count is under the threshold, child 0 if there is none" and adds one to
+        // that child's count: a threshold level hands its `width` descents out greedily in rank order - child i takes
+        // min(th - count_i, what is left), whatever remains goes to child 0 - so a level is a prefix sum over the wave, not
+        // `width` ballots in a row (one by one: 58 k of the selector's 156 k cycles per phase).
         if (ok) {
-            int s_cnt[R];
-            unsigned long long seen[R];
+            int s_cnt[R], f_of[R];
 #pragma unroll
-            for (int r = 0; r < R; ++r) { s_cnt[r] = r_cnt[r]; seen[r] = 0ull; }
+            for (int r = 0; r < R; ++r) { s_cnt[r] = r_cnt[r]; f_of[r] = -1; }
+            const int owner0 = pos0 & 63, rr0 = pos0 >> 6;
             for (int th = 1; ok && th <= levels; ++th) {
-                for (int j = 0; ok && j < width; ++j) {
-                    int pos = -1;
+                const int qbase = n_desc;
+                ++n_iter;
+                int need[R], pre[R], take[R];
+                int running = 0;
+                bool multi = false;                                       // a child more than one descent under the threshold
+                const unsigned long long below = (1ull << lane) - 1ull;
+                int under_before = 0;
 #pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const unsigned long long under = __ballot(lane + 64 * r < r_nc && s_cnt[r] < th);
-                        if (pos < 0 && under) pos = 64 * r + __ffsll((long long)under) - 1;
+                for (int r = 0; r < R; ++r) {
+                    need[r] = (lane + 64 * r < r_nc && s_cnt[r] < th) ? th - s_cnt[r] : 0;
+                    // (every child under the threshold takes at least one descent: only the first `width` of them can take any -
+                    // the never-visited children further down the ranking, `th` under it, stay out of the sums)
+                    const unsigned long long under = __ballot(need[r] > 0);
+                    if (under_before + __popcll(under & below) >= width) need[r] = 0;
+                    under_before += __popcll(under);
+                    multi = multi || __ballot(need[r] > 1) != 0ull;
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if (!multi) {                                         // (the usual level: the prefix sum is a bit count)
+                        const unsigned long long m = __ballot(need[r] == 1);
+                        pre[r] = running + __popcll(m & below);
+                        running += __popcll(m);
+                    } else {
+                        int incl = need[r];
+#pragma unroll
+                        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+                        pre[r] = running + incl - need[r];
+                        running += __builtin_amdgcn_readlane(incl, 63);
                     }
-                    if (pos < 0) pos = pos0;
-                    const int owner = pos & 63, rr = pos >> 6;
-                    int m_mv = 0, m_vis = 0, m_idx = 0, m_e = 0;
-                    bool first = false;
+                }
+                const int given = running < width ? running : width;
+                const int leftover = width - given;                       // descents that find no child under the threshold: child 0
+                int max_take = 0;
+                unsigned long long fresh[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int room = width - pre[r];
+                    take[r] = room <= 0 ? 0 : (need[r] < room ? need[r] : room);
+                    s_cnt[r] += take[r];
+                    max_take = max(max_take, take[r]);
+                    fresh[r] = __ballot(take[r] > 0 && f_of[r] < 0);
+                }
+                max_take = multi ? wave_max_i32(max_take) : (given > 0 ? 1 : 0);
+                // entries: the children that appear for the first time, in the order of their first descents
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const bool mine = take[r] > 0 && f_of[r] < 0;
+                    if (mine) f_of[r] = n_first + __popcll(fresh[r] & below);
+                    n_first += __popcll(fresh[r]);
+                    if (mine && f_of[r] < kRootMemo) {
+                        const int f = f_of[r];
+                        rm_pos[f] = lane + 64 * r; rm_slot[f] = qbase + pre[r];
+                        la_mv[f] = r_act[r]; la_vis[f] = r_vis[r]; la_child[f] = r_idx[r]; la_e[f] = r_edge[r];
+                    }
+                }
+                if (leftover > 0) {
+                    int f0 = -1;
 #pragma unroll
                     for (int r = 0; r < R; ++r)
-                        if (r == rr) {
-                            m_mv = r_act[r]; m_vis = r_vis[r]; m_idx = r_idx[r]; m_e = r_edge[r];
-                            first = !((seen[r] >> owner) & 1ull);            // wave-uniform bookkeeping
-                            seen[r] |= 1ull << owner;
-                            if (lane == owner) s_cnt[r] += 1;
-                        }
-                    const int q = n_desc++;                               // this descent's leaf slot
-                    if (!first) {
-                        const unsigned long long rh = __ballot(lane < n_first && my_first_pos == pos);
-                        if (lane == 0) sched[q] = (int8_t)(__ffsll((long long)rh) - 1);
-                        continue;
-                    }
-                    if (n_first >= kRootMemo) { ok = false; break; }      // (never: <= 17 root children per phase)
-                    if (lane == n_first) my_first_pos = pos;
-                    if (lane == 0) { rm_pos[n_first] = pos; rm_slot[n_first] = q; sched[q] = (int8_t)-1; }
-                    ++n_first;
-                    int node = 0, depth = 0;
-                    int mv = __builtin_amdgcn_readlane(m_mv, owner);
-                    int visits = __builtin_amdgcn_readlane(m_vis, owner);
-                    int child = __builtin_amdgcn_readlane(m_idx, owner);
-                    int e = __builtin_amdgcn_readlane(m_e, owner);
-                    while (ok) {
-                        if (depth >= kPathMax<S>) break;                  // the descent proper reports it
-                        if (lane == 0) { sel_moves[depth] = (int16_t)mv; sel_path[depth] = (node << 10) | e; }
-                        ++depth;
-                        wave_sync();
-                        if (visits < 1) break;                            // ends on a leaf: nothing to expand
-                        if (child == kNotExpanded) {
-                            if (num_nodes >= D.N || num_nodes - n0 >= kPipeMaxK) break;   // reported by the descent proper
-                            child = num_nodes++;
-                            if (node == 0) {
+                        if (r == rr0) f0 = __builtin_amdgcn_readlane(f_of[r], owner0);
+                    const bool fresh0 = f0 < 0;
+                    if (fresh0) f0 = n_first++;
 #pragma unroll
-                                for (int r = 0; r < R; ++r)
-                                    if (r == rr && lane == owner) r_idx[r] = child;
-                            } else if (lane == 0) {
-                                memo_child[node & (kMemo - 1)] = child;
+                    for (int r = 0; r < R; ++r)
+                        if (r == rr0 && lane == owner0) {
+                            s_cnt[r] += leftover;
+                            f_of[r] = f0;
+                            if (fresh0 && f0 < kRootMemo) {
+                                rm_pos[f0] = pos0; rm_slot[f0] = qbase + given;
+                                la_mv[f0] = r_act[r]; la_vis[f0] = r_vis[r]; la_child[f0] = r_idx[r]; la_e[f0] = r_edge[r];
                             }
-                            if (lane == 0) {
-                                D.ch_index[((size_t)t * D.N + node) * A + e] = child;
-                                sh.jobof[child - n0] = (int16_t)jid;
-                            }
-                            wave_sync();
-                            ok = publish(-1, node, e, child, 1, nexp++, depth, -1);
-                            break;                                        // its children are unvisited: a leaf follows
                         }
-                        node = child;
-                        if (node >= n0) break;                            // (created in this launch: cannot happen, subtrees are disjoint)
-                        const int slot = node & (kMemo - 1);
-                        if (memo_tag[slot] != node) {
-                            e = select_node_halving<S>(hs, D, t, node, lane);
-                            const size_t nb = ((size_t)t * D.N + node) * A;
-                            mv = D.action[nb + e];
-                            visits = D.ch_visits[nb + e];
-                            child = D.ch_index[nb + e];
-                            wave_sync();
-                            if (lane == 0) {
-                                memo_tag[slot] = node; memo_edge[slot] = e; memo_move[slot] = mv;
-                                memo_vis[slot] = visits; memo_child[slot] = child;
+                    for (int k = lane; k < leftover; k += 64) sched[qbase + given + k] = (int8_t)((fresh0 && k == 0) ? -1 : f0);
+                }
+                if (n_first > kRootMemo) { ok = false; break; }          // (never: <= 17 root children per phase)
+                // the schedule: descent q repeats the leaf of entry sched[q] (-1: it IS the entry's first descent)
+                for (int k = 0; k < max_take; ++k)
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        if (k < take[r]) sched[qbase + pre[r] + k] = (int8_t)((k == 0 && ((fresh[r] >> lane) & 1ull)) ? -1 : f_of[r]);
+                n_desc += width;
+                // Steady state: `width` children stand exactly at the threshold and nothing ranked before the last of them can
+                // come under a later one - every remaining level gives each of them one descent, in the same order.
+                if (leftover == 0 && th < levels) {
+                    unsigned long long tk[R];
+                    int last = -1, ntk = 0;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        tk[r] = __ballot(take[r] > 0);
+                        if (tk[r]) last = 64 * r + 63 - __clzll((long long)tk[r]);
+                        ntk += __popcll(tk[r]);
+                    }
+                    bool steady = ntk == width;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const int i = lane + 64 * r;
+                        const bool fine = i > last || i >= r_nc || (take[r] > 0 ? s_cnt[r] == th : s_cnt[r] >= levels);
+                        steady = steady && __ballot(!fine) == 0ull;
+                    }
+                    if (steady) {
+                        const int rem = levels - th;
+                        int before = 0;
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            if (take[r] > 0) {
+                                const int ord = before + __popcll(tk[r] & below);
+                                for (int l = 0; l < rem; ++l) sched[n_desc + l * width + ord] = (int8_t)f_of[r];
+                                s_cnt[r] += rem;
                             }
-                            wave_sync();
-                        } else {
-                            e = memo_edge[slot]; mv = memo_move[slot]; visits = memo_vis[slot]; child = memo_child[slot];
+                            before += __popcll(tk[r]);
                         }
+                        n_desc += rem * width;
+                        break;
                     }
                 }
             }
@@ -3094,10 +3171,107 @@ __global__ __launch_bounds__(64 * (1 + NW)) void select_gumbel_pipe_kernel(Searc
         }
         wave_sync();
         lap(1);
-        // the first descents proper, in descent order
+        // ---- the entries' walks, shared out over the workgroup's waves (this one takes its share) ----
+        if (active) {
+            const int n_walk = ok ? n_first : 0;
+            if (lane == 0) { la_n = n_walk; pipe_store(&la_ready, 1); }
+            for (int f = 0; f < n_walk; f += 1 + NW) walk(f, hs);
+            wave_sync();
+            if (lane == 0) __hip_atomic_fetch_add(&la_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            lap(7);
+            if (!pipe_wait_ge(&la_done, 1 + NW)) ok = false;
+        }
+        lap(3);
+        // One entry, one by one (paths longer than the per-entry buffers): walked down WITHOUT side effects to the point of
+        // expansion, the node allocated and its EXPAND job queued.
+        auto lookahead_serial = [&](int f) {
+            const int pos = rm_pos[f];
+            const int owner = pos & 63, rr = pos >> 6;
+            int node = 0, depth = 0;
+            int mv = la_mv[f], visits = la_vis[f], child = la_child[f], e = la_e[f];
+            while (ok) {
+                if (depth >= kPathMax<S>) break;                  // the descent proper reports it
+                if (lane == 0) { sel_moves[depth] = (int16_t)mv; sel_path[depth] = (node << 10) | e; }
+                ++depth;
+                wave_sync();
+                if (visits < 1) break;                            // ends on a leaf: nothing to expand
+                if (child == kNotExpanded) {
+                    if (num_nodes >= D.N || num_nodes - n0 >= kPipeMaxK) break;   // reported by the descent proper
+                    child = num_nodes++;
+                    if (node == 0) {
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+                            if (r == rr && lane == owner) r_idx[r] = child;
+                    } else if (lane == 0) {
+                        memo_child[node & (kMemo - 1)] = child;
+                    }
+                    if (lane == 0) {
+                        D.ch_index[((size_t)t * D.N + node) * A + e] = child;
+                        sh.jobof[child - n0] = (int16_t)jid;
+                    }
+                    wave_sync();
+                    ok = publish(-1, node, e, child, 1, nexp++, depth, -1);
+                    break;                                        // its children are unvisited: a leaf follows
+                }
+                node = child;
+                if (node >= n0) break;                            // (created in this launch: cannot happen, subtrees are disjoint)
+                const int slot = node & (kMemo - 1);
+                if (memo_tag[slot] != node) {
+                    e = select_node_halving<S>(hs, D, t, node, lane);
+                    const size_t nb = ((size_t)t * D.N + node) * A;
+                    mv = D.action[nb + e];
+                    visits = D.ch_visits[nb + e];
+                    child = D.ch_index[nb + e];
+                    wave_sync();
+                    if (lane == 0) {
+                        memo_tag[slot] = node; memo_edge[slot] = e; memo_move[slot] = mv;
+                        memo_vis[slot] = visits; memo_child[slot] = child;
+                    }
+                    wave_sync();
+                } else {
+                    e = memo_edge[slot]; mv = memo_move[slot]; visits = memo_vis[slot]; child = memo_child[slot];
+                }
+            }
+        };
+        // Expansions first.  Every root child is entered several times in a phase, and only its FIRST descent can meet
+        // a node that has to be expanded (the later ones find it there; the new node's children are unvisited, so
+        // the descent ends right below it).  Waiting for each of those expansions in turn (replay + candidates +
+        // prior: ~5 us) was a third of a launch.  So every entry has been walked down to its point of expansion (above):
+        // here the nodes are allocated and the EXPAND jobs queued - node numbers and draws in descent order, exactly as the
+        // one-by-one order makes them - and nobody waits.  The descents proper then find the children allocated and wait, if
+        // at all, for a job that is about to finish.  Subtrees of different root children are disjoint and statistics are
+        // constant within a phase, so every choice is what the one-by-one order makes.
         for (int f = 0; ok && f < n_first; ++f) {
+            const int res = la_res[f];
+            if (res == kWalkDeep) { lookahead_serial(f); continue; }
+            if (res != kWalkExpand) continue;
+            if (num_nodes >= D.N || num_nodes - n0 >= kPipeMaxK) {        // reported by the descent proper
+                if (lane == 0) la_res[f] = kWalkPoolFull;
+                wave_sync();
+                continue;
+            }
+            const int node = la_node[f], e = la_edge[f];
+            const int child = num_nodes++;
+            if (node == 0) {
+                const int pos = rm_pos[f];
+                const int owner = pos & 63, rr = pos >> 6;
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if (r == rr && lane == owner) r_idx[r] = child;
+            }
+            if (lane == 0) {
+                la_chd[f] = child;
+                D.ch_index[((size_t)t * D.N + node) * A + e] = child;
+                sh.jobof[child - n0] = (int16_t)jid;
+            }
+            wave_sync();
+            ok = publish(-1, node, e, child, 1, nexp++, la_depth[f], -1, rm_path[f], la_moves[f]);
+        }
+        wave_sync();
+        lap(8);
+        // One entry's first descent, one by one (see lookahead_serial).
+        auto descend_serial = [&](int f) {
             {
-                if (pipe_load(&sh.err)) { ok = false; break; }
                 const int my_q = rm_slot[f];
                 int node = 0, depth = 0, root_pos = 0;
                 while (ok) {
@@ -3195,6 +3369,41 @@ __global__ __launch_bounds__(64 * (1 + NW)) void select_gumbel_pipe_kernel(Searc
                     node = child;
                 }
             }
+        };
+        // the first descents proper, in descent order: where the walk ended, one step into the node just made if it ended on
+        // an expansion (the step waits for that job), the LEAF job
+        for (int f = 0; ok && f < n_first; ++f) {
+            if (pipe_load(&sh.err)) { ok = false; break; }
+            const int res = la_res[f];
+            if (res == kWalkDeep) { descend_serial(f); continue; }
+            if (res == kWalkPoolFull) {                                   // tree.py:418-420
+                if (lane == 0) atomicOr(&D.err[t], kErrPoolFull);
+                ok = false;
+                break;
+            }
+            int node = la_node[f], e = la_edge[f], child = la_chd[f], depth = la_depth[f];
+            if (res == kWalkExpand) {
+                node = child;
+                ok = pipe_wait_done(sh, sh.jobof[node - n0]);             // expansion in flight?
+                if (!ok) break;
+                const size_t base = ((size_t)t * D.N + node) * A;
+                e = select_node_halving<S>(hs, D, t, node, lane);
+                const int mv = D.action[base + e];
+                const int visits = D.ch_visits[base + e];
+                child = D.ch_index[base + e];
+                wave_sync();
+                if (lane == 0) { la_moves[f][depth] = (int16_t)mv; rm_path[f][depth] = (node << 10) | e; }
+                ++depth;
+                if (visits >= 1) { ok = false; break; }                   // (a node made in this launch has no visited child)
+            }
+            // tree.py:412-416: the queue entry of this leaf (node to evaluate - still NOT_EXPANDED: node[-1] -, parent, edge,
+            // path) is written by the worker that takes the job; the later descents through this root child: left to the
+            // workers (sched)
+            if (lane == 0) { rm_parent[f] = node; rm_edge[f] = e; rm_child[f] = child; rm_job[f] = jid; rm_depth[f] = depth; }
+            wave_sync();
+            ok = publish(rm_slot[f], node, e, child, 0, 0, depth, -1, rm_path[f], la_moves[f]);
+            lap(2);
+            if (prof) pc[6] += 1;
         }
         if (active) {
             // the root's virtual losses back to the pool
@@ -3217,7 +3426,8 @@ __global__ __launch_bounds__(64 * (1 + NW)) void select_gumbel_pipe_kernel(Searc
         }
         lap(5);
         if (prof && lane == 0) {
-            for (int i = 0; i < 8; ++i) D.prof[i] += pc[i];
+            for (int i = 0; i < 10; ++i) D.prof[i] += pc[i];
+            D.prof[12] += 1; D.prof[13] += levels; D.prof[14] += width; D.prof[11] += n_iter;
             D.prof[15] += (long long)__builtin_amdgcn_s_memtime() - t_begin;
         }
     } else {
@@ -3226,6 +3436,18 @@ __global__ __launch_bounds__(64 * (1 + NW)) void select_gumbel_pipe_kernel(Searc
         BoardScalars rootb;
         int root_to_move;
         load_root<S>(L, rootb, root_to_move, D, t, lane);
+        if (active) {
+            // this wave's share of the entries' walks (see `walk`): nothing else to do until the first job is queued
+            if (pipe_wait_ge(&la_ready, 1)) {
+                const int n_walk = la_n;
+                for (int f = wid; f < n_walk; f += 1 + NW) walk(f, hsw[wid - 1]);
+            } else if (lane == 0) {
+                atomicOr(&D.err[t], kErrPipeline);
+                pipe_store(&sh.err, 1);
+            }
+            wave_sync();
+            if (lane == 0) __hip_atomic_fetch_add(&la_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
         for (int k = wid - 1; active; k += NW) {
             const int slot = k % kPipeSlots;
             bool have = false, stalled = true;

@@ -27,9 +27,11 @@ for m in range(moves):
     board.put_stone(mv, color); color = 3 - color
 tl.check(lib.tg_search_profile(tree._engine.handle, 0, cyc.ctypes.data))
 ph = 4 * n
-names = {0: "set-up (root into registers, ranking)", 1: "schedule of the phase + look-ahead for expansions", 2: "first descents (walk, LEAF job)",
+names = {0: "set-up (root into registers, ranking)", 1: "root choices of the phase (entries, schedule)",
+         7: "its share of the entries' walks", 3: "waiting for the other waves' shares", 8: "nodes / EXPAND jobs handed out", 2: "first descents (step into the new node, LEAF job)",
          4: "(waiting for a free job slot, inside the above)", 5: "write-back"}
 print(f"selector wave, ticks per phase over {ph} phases ({cyc[6]/ph:.1f} first descents per phase; the repeats are the workers')")
 for i, nm in names.items():
     print(f"  {nm:50s} {cyc[i]/ph:9.0f}")
+print(f"  {cyc[12]} launches: threshold levels per launch {cyc[13]/max(cyc[12],1):.1f}, walked one by one {cyc[11]/max(cyc[12],1):.1f}; width {cyc[14]/max(cyc[12],1):.1f}")
 print(f"  per first descent {cyc[2]/max(cyc[6],1):.0f}; selector done after {cyc[15]/ph:.0f} ticks per phase")
