@@ -114,6 +114,7 @@ struct SearchDev {
     int32_t *err;               // [T] sticky error flags
     long long *prof;            // optional [16] s_memtime cycle accumulators of tree 0 (tg_search_profile)
     int32_t T, N, K, cgos, superko;
+    int32_t gumbel_one_by_one;  // test hook (TG_GUMBEL_ONE_BY_ONE): select_gumbel_pipe_kernel takes every entry through its job ring, as a phase with a long path does
 };
 
 __device__ __forceinline__ void set_cursor(const SearchDev &D, int t, long long v) {
@@ -154,6 +155,16 @@ __device__ __forceinline__ double lane_partner_f64(double v) {
     const int lo = lane_partner_i32<STEP>((int)(unsigned)bits);
     const int hi = lane_partner_i32<STEP>((int)(unsigned)((unsigned long long)bits >> 32));
     return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+// inclusive prefix sum over the wave's lanes: four row shifts, two row broadcasts (no LDS crossbar round trips)
+__device__ __forceinline__ int wave_scan_add_i32(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);     // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);     // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);     // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);     // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);     // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);     // row_bcast:31 into rows 2 and 3
+    return v;
 }
 __device__ __forceinline__ int wave_sum(int v) {
     v += lane_partner_i32<0>(v);
@@ -2851,6 +2862,11 @@ __global__ __launch_bounds__(64 * (1 + NW)) void select_gumbel_pipe_kernel(Searc
     __shared__ int la_mv[kRootMemo], la_vis[kRootMemo], la_child[kRootMemo], la_e[kRootMemo];       // entry f at the root
     __shared__ int la_res[kRootMemo], la_node[kRootMemo], la_edge[kRootMemo], la_chd[kRootMemo], la_depth[kRootMemo];   // where its walk ended
     __shared__ int16_t la_moves[kRootMemo][kRootPath];
+    // ... and the first descents themselves are the workers' too: entry f - its expansion (node number and place in the draw
+    // order given by the selector), the step into the node just made, the leaf's queue entry, virtual losses and planes - is one
+    // piece of work on one board replay, entry f on worker f mod NW; the selector queues nothing.  (One by one through the job
+    // ring - EXPAND job, wait, step, LEAF job - the first descents were 60 k of the selector's 123 k cycles per phase.)
+    __shared__ int la_go, la_fast, la_ndesc, la_xseq[kRootMemo];
     constexpr int kWalkLeaf = 1, kWalkExpand = 2, kWalkDeep = 3, kWalkPoolFull = 4;
     const int t = blockIdx.x;
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -2862,7 +2878,7 @@ __global__ __launch_bounds__(64 * (1 + NW)) void select_gumbel_pipe_kernel(Searc
     }
     for (int i = threadIdx.x; i < kPipeMaxK / 32; i += NTHR) sh.done_bits[i] = 0u;
     if (threadIdx.x == 0) {
-        la_ready = 0; la_done = 0; la_n = 0;
+        la_ready = 0; la_done = 0; la_n = 0; la_go = 0; la_fast = 0;
         sh.cursor_seq = 0;
         sh.cursor_val = D.rng_cursor[t];
         sh.final_count = -1;
@@ -2890,7 +2906,7 @@ __global__ __launch_bounds__(64 * (1 + NW)) void select_gumbel_pipe_kernel(Searc
     auto walk = [&](int f, HalvingScratch<S> &scratch) {
         int node = 0, depth = 0, res = kWalkDeep;
         int mv = la_mv[f], visits = la_vis[f], child = la_child[f], e = la_e[f];
-        while (depth < kRootPath - 2) {
+        while (depth < (D.gumbel_one_by_one ? 0 : kRootPath - 2)) {
             if (lane == 0) { la_moves[f][depth] = (int16_t)mv; rm_path[f][depth] = (node << 10) | e; }
             ++depth;
             if (visits < 1) { res = kWalkLeaf; break; }
@@ -3071,9 +3087,7 @@ __global__ __launch_bounds__(64 * (1 + NW)) void select_gumbel_pipe_kernel(Searc
                         pre[r] = running + __popcll(m & below);
                         running += __popcll(m);
                     } else {
-                        int incl = need[r];
-#pragma unroll
-                        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+                        const int incl = wave_scan_add_i32(need[r]);
                         pre[r] = running + incl - need[r];
                         running += __builtin_amdgcn_readlane(incl, 63);
                     }
@@ -3182,6 +3196,16 @@ __global__ __launch_bounds__(64 * (1 + NW)) void select_gumbel_pipe_kernel(Searc
             if (!pipe_wait_ge(&la_done, 1 + NW)) ok = false;
         }
         lap(3);
+        // (a path longer than the per-entry buffers anywhere in the phase: every entry goes the one-by-one way through the job
+        // ring - expansions of both kinds in one phase would wait for each other's place in the draw order across the two queues)
+        bool fast = ok;
+        if (ok) {
+            if (__ballot(lane < n_first && la_res[lane] == kWalkDeep)) {
+                fast = false;
+                if (lane < n_first) la_res[lane] = kWalkDeep;
+                wave_sync();
+            }
+        }
         // One entry, one by one (paths longer than the per-entry buffers): walked down WITHOUT side effects to the point of
         // expansion, the node allocated and its EXPAND job queued.
         auto lookahead_serial = [&](int f) {
@@ -3241,33 +3265,33 @@ __global__ __launch_bounds__(64 * (1 + NW)) void select_gumbel_pipe_kernel(Searc
         // one-by-one order makes them - and nobody waits.  The descents proper then find the children allocated and wait, if
         // at all, for a job that is about to finish.  Subtrees of different root children are disjoint and statistics are
         // constant within a phase, so every choice is what the one-by-one order makes.
-        for (int f = 0; ok && f < n_first; ++f) {
-            const int res = la_res[f];
-            if (res == kWalkDeep) { lookahead_serial(f); continue; }
-            if (res != kWalkExpand) continue;
-            if (num_nodes >= D.N || num_nodes - n0 >= kPipeMaxK) {        // reported by the descent proper
-                if (lane == 0) la_res[f] = kWalkPoolFull;
-                wave_sync();
-                continue;
+        if (active && !fast && lane == 0) { la_fast = 0; pipe_store(&la_go, 1); }      // (the workers: straight to the job ring)
+        if (!fast) {
+            for (int f = 0; ok && f < n_first; ++f) lookahead_serial(f);
+        } else {
+            // lane f: entry f.  Node numbers and places in the draw order go to the entries that expand, in entry order; when
+            // the pool runs out the rest are marked (reported where the one-by-one order reports them).
+            const int res = lane < n_first ? la_res[lane] : 0;
+            const unsigned long long xm = __ballot(res == kWalkExpand);
+            const int ord = __popcll(xm & ((1ull << lane) - 1ull));
+            const int room_pool = D.N - num_nodes, room_launch = kPipeMaxK - (num_nodes - n0);
+            const int room = max(0, min(room_pool, room_launch));
+            if (res == kWalkExpand) {
+                if (ord >= room) {
+                    la_res[lane] = kWalkPoolFull;
+                } else {
+                    const int child = num_nodes + ord;
+                    la_chd[lane] = child;
+                    la_xseq[lane] = nexp + ord;
+                    D.ch_index[((size_t)t * D.N + la_node[lane]) * A + la_edge[lane]] = child;
+                }
             }
-            const int node = la_node[f], e = la_edge[f];
-            const int child = num_nodes++;
-            if (node == 0) {
-                const int pos = rm_pos[f];
-                const int owner = pos & 63, rr = pos >> 6;
-#pragma unroll
-                for (int r = 0; r < R; ++r)
-                    if (r == rr && lane == owner) r_idx[r] = child;
-            }
-            if (lane == 0) {
-                la_chd[f] = child;
-                D.ch_index[((size_t)t * D.N + node) * A + e] = child;
-                sh.jobof[child - n0] = (int16_t)jid;
-            }
-            wave_sync();
-            ok = publish(-1, node, e, child, 1, nexp++, la_depth[f], -1, rm_path[f], la_moves[f]);
+            const int granted = min(__popcll(xm), room);
+            num_nodes += granted;
+            nexp += granted;
         }
         wave_sync();
+        if (active && fast && lane == 0) { la_fast = ok ? 1 : 0; la_ndesc = n_desc; pipe_store(&la_go, 1); }
         lap(8);
         // One entry's first descent, one by one (see lookahead_serial).
         auto descend_serial = [&](int f) {
@@ -3370,8 +3394,8 @@ __global__ __launch_bounds__(64 * (1 + NW)) void select_gumbel_pipe_kernel(Searc
                 }
             }
         };
-        // the first descents proper, in descent order: where the walk ended, one step into the node just made if it ended on
-        // an expansion (the step waits for that job), the LEAF job
+        // the first descents: the workers' (see la_go) - here only what the one-by-one order reports at this point, and the
+        // one-by-one descents of a phase with a long path
         for (int f = 0; ok && f < n_first; ++f) {
             if (pipe_load(&sh.err)) { ok = false; break; }
             const int res = la_res[f];
@@ -3381,30 +3405,9 @@ __global__ __launch_bounds__(64 * (1 + NW)) void select_gumbel_pipe_kernel(Searc
                 ok = false;
                 break;
             }
-            int node = la_node[f], e = la_edge[f], child = la_chd[f], depth = la_depth[f];
-            if (res == kWalkExpand) {
-                node = child;
-                ok = pipe_wait_done(sh, sh.jobof[node - n0]);             // expansion in flight?
-                if (!ok) break;
-                const size_t base = ((size_t)t * D.N + node) * A;
-                e = select_node_halving<S>(hs, D, t, node, lane);
-                const int mv = D.action[base + e];
-                const int visits = D.ch_visits[base + e];
-                child = D.ch_index[base + e];
-                wave_sync();
-                if (lane == 0) { la_moves[f][depth] = (int16_t)mv; rm_path[f][depth] = (node << 10) | e; }
-                ++depth;
-                if (visits >= 1) { ok = false; break; }                   // (a node made in this launch has no visited child)
-            }
-            // tree.py:412-416: the queue entry of this leaf (node to evaluate - still NOT_EXPANDED: node[-1] -, parent, edge,
-            // path) is written by the worker that takes the job; the later descents through this root child: left to the
-            // workers (sched)
-            if (lane == 0) { rm_parent[f] = node; rm_edge[f] = e; rm_child[f] = child; rm_job[f] = jid; rm_depth[f] = depth; }
-            wave_sync();
-            ok = publish(rm_slot[f], node, e, child, 0, 0, depth, -1, rm_path[f], la_moves[f]);
-            lap(2);
             if (prof) pc[6] += 1;
         }
+        lap(2);
         if (active) {
             // the root's virtual losses back to the pool
             const size_t base = (size_t)t * D.N * A;
@@ -3426,8 +3429,8 @@ __global__ __launch_bounds__(64 * (1 + NW)) void select_gumbel_pipe_kernel(Searc
         }
         lap(5);
         if (prof && lane == 0) {
-            for (int i = 0; i < 10; ++i) D.prof[i] += pc[i];
-            D.prof[12] += 1; D.prof[13] += levels; D.prof[14] += width; D.prof[11] += n_iter;
+            for (int i = 0; i < 9; ++i) D.prof[i] += pc[i];
+            D.prof[12] += 1; D.prof[14] += n_iter;
             D.prof[15] += (long long)__builtin_amdgcn_s_memtime() - t_begin;
         }
     } else {
@@ -3436,6 +3439,10 @@ __global__ __launch_bounds__(64 * (1 + NW)) void select_gumbel_pipe_kernel(Searc
         BoardScalars rootb;
         int root_to_move;
         load_root<S>(L, rootb, root_to_move, D, t, lane);
+        // (s_memtime accumulators of tree 0's first worker: 9 waiting for the selector's go, 10 its entries, 11 the scheduled copies,
+        // 13 start of the kernel to its end)
+        const bool wprof = prof && wid == 1 && lane == 0;
+        long long wt1 = 0, wt2 = 0, wt3 = 0, wt4 = 0;
         if (active) {
             // this wave's share of the entries' walks (see `walk`): nothing else to do until the first job is queued
             if (pipe_wait_ge(&la_ready, 1)) {
@@ -3447,6 +3454,92 @@ __global__ __launch_bounds__(64 * (1 + NW)) void select_gumbel_pipe_kernel(Searc
             }
             wave_sync();
             if (lane == 0) __hip_atomic_fetch_add(&la_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (wprof) wt1 = (long long)__builtin_amdgcn_s_memtime();
+            // this wave's share of the first descents (see la_go): expansions reserve their draws in entry order (xseq), an
+            // entry waits only for entries before it - each on a worker that takes its entries in ascending order
+            if (!pipe_wait_ge(&la_go, 1)) {
+                if (lane == 0) { atomicOr(&D.err[t], kErrPipeline); pipe_store(&sh.err, 1); }
+            } else if (la_fast) {
+                if (wprof) wt2 = (long long)__builtin_amdgcn_s_memtime();
+                const int n_ent = la_n;
+                for (int f = wid - 1; f < n_ent; f += NW) {
+                    const int res = la_res[f];
+                    if (res != kWalkLeaf && res != kWalkExpand) continue;      // (pool full: reported by the selector)
+                    if (pipe_load(&sh.err)) break;
+                    int depth = la_depth[f], parent = la_node[f], edge = la_edge[f], child = la_chd[f];
+                    reset_work<S>(L, lane);
+                    BoardScalars b = rootb;
+                    int c = root_to_move;
+                    for (int i = 0; i < depth; ++i) {
+                        put_stone<S>(L, b, la_moves[f][i], c, D.zob, lane);
+                        c = 3 - c;
+                    }
+                    if (res == kWalkExpand) {
+                        if (!expand_node_pipe<S>(L, b, c, D, t, child, parent, edge, la_xseq[f], sh, lane)) break;
+                        // node.py:349-361 at the node just made (its arrays were written by this wave's lanes)
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        const int node = child;
+                        const size_t nb = ((size_t)t * D.N + node) * A;
+                        const int e2 = select_node_halving<S>(hsw[wid - 1], D, t, node, lane);
+                        const int mv2 = D.action[nb + e2];
+                        const int visits2 = D.ch_visits[nb + e2];
+                        child = D.ch_index[nb + e2];
+                        if (visits2 >= 1) {                                    // (a node made in this launch has no visited child)
+                            if (lane == 0) { atomicOr(&D.err[t], kErrPipeline); pipe_store(&sh.err, 1); }
+                            break;
+                        }
+                        if (lane == 0) { la_moves[f][depth] = (int16_t)mv2; rm_path[f][depth] = (node << 10) | e2; }
+                        put_stone<S>(L, b, mv2, c, D.zob, lane);
+                        c = 3 - c;
+                        parent = node; edge = e2; depth += 1;
+                        wave_sync();
+                    }
+                    // tree.py:412-416: the leaf's queue entry (node to evaluate - still NOT_EXPANDED: node[-1] -, parent, edge,
+                    // path), the virtual losses of its path below the root (node.py:76-83), its planes
+                    const int q = rm_slot[f];
+                    const size_t qs = (size_t)t * D.K + q;
+                    if (lane == 0) {
+                        D.q_node[qs] = child;
+                        D.q_pnode[qs] = parent;
+                        D.q_pedge[qs] = edge;
+                        D.q_depth[qs] = (depth <= kPathCap && D.N <= (1 << 21)) ? depth : 0;
+                    }
+                    const int my_entry = lane < depth ? rm_path[f][lane] : 0;
+                    if (lane < depth && lane < kPathCap) D.q_path[qs * kPathCap + lane] = my_entry;
+                    write_planes<S>(L, b, c, planes + (leaf_base + q) * 6 * G::P, lane);
+                    int n_through = 1;                                         // descents of the phase that end on this leaf
+                    // the later descents through this root child end on the same leaf (see `sched`): their queue entries,
+                    // virtual losses and planes right here, off the board this wave holds - stores only (as copies of the first
+                    // leaf's planes, shared out over the workers afterwards, they were a load round trip each and waited for the
+                    // slowest entry: 65 k cycles of a 160 k launch)
+                    const int n_all = la_ndesc;
+                    for (int q0 = 0; q0 < n_all; q0 += 64) {
+                        unsigned long long m = __ballot(q0 + lane < n_all && sched[q0 + lane] == f);
+                        while (m) {
+                            const int q2 = q0 + __ffsll((long long)m) - 1;
+                            m &= m - 1;
+                            const size_t qs2 = (size_t)t * D.K + q2;
+                            if (lane == 0) {
+                                D.q_node[qs2] = child;
+                                D.q_pnode[qs2] = parent;
+                                D.q_pedge[qs2] = edge;
+                                D.q_depth[qs2] = (depth <= kPathCap && D.N <= (1 << 21)) ? depth : 0;
+                            }
+                            if (lane < depth && lane < kPathCap) D.q_path[qs2 * kPathCap + lane] = my_entry;
+                            write_planes<S>(L, b, c, planes + (leaf_base + q2) * 6 * G::P, lane);
+                            ++n_through;
+                        }
+                    }
+                    // node.py:76-83 below the root: one virtual loss per descent on every node and edge of the path - added once
+                    if (lane >= 1 && lane < depth) {
+                        const size_t ns = (size_t)t * D.N + (my_entry >> 10);
+                        atomicAdd(&D.node[ns].vl, n_through);
+                        atomicAdd(&D.ch_vl[ns * A + (my_entry & 1023)], n_through);
+                    }
+                }
+                if (wprof) wt3 = (long long)__builtin_amdgcn_s_memtime();
+            }
         }
         for (int k = wid - 1; active; k += NW) {
             const int slot = k % kPipeSlots;
@@ -3511,7 +3604,8 @@ __global__ __launch_bounds__(64 * (1 + NW)) void select_gumbel_pipe_kernel(Searc
             }
         }
         // the scheduled leaves (see `sched`): leaf slot q of this tree repeats the leaf of root-child entry f
-        const int nq = (active && pipe_load(&sh.final_count) >= 0 && !pipe_load(&sh.err)) ? bulk_n : 0;
+        if (wprof) wt4 = (long long)__builtin_amdgcn_s_memtime();
+        const int nq = (active && !la_fast && pipe_load(&sh.final_count) >= 0 && !pipe_load(&sh.err)) ? bulk_n : 0;
         for (int q = wid - 1; q < nq; q += NW) {
             const int f = sched[q];
             if (f < 0) continue;
@@ -3539,6 +3633,10 @@ __global__ __launch_bounds__(64 * (1 + NW)) void select_gumbel_pipe_kernel(Searc
             const float2 *src = reinterpret_cast<const float2 *>(planes + (leaf_base + rm_slot[f]) * 6 * G::P);
             float2 *dst = reinterpret_cast<float2 *>(planes + (leaf_base + q) * 6 * G::P);
             for (int i = lane; i < 3 * G::P; i += 64) dst[i] = src[i];
+        }
+        if (wprof) {
+            const long long wt5 = (long long)__builtin_amdgcn_s_memtime();
+            D.prof[9] += wt2 - wt1; D.prof[10] += wt3 - wt2; D.prof[11] += wt5 - wt4; D.prof[13] += wt5 - t_begin;
         }
     }
     __syncthreads();
@@ -5042,27 +5140,30 @@ static int launch_gumbel_select(tg_search *s, const SearchDev &D, const int32_t 
                                 int limit, float *planes_dev, hipStream_t st) {
     const int T = D.T;
     static const bool force_serial = tg::knob("TG_SELECT_SERIAL") != nullptr;
-    // workers per tree: two when the trees crowd the CUs (the three-wave workgroup fits next to a forward workgroup),
-    // six when there are CUs to spare (TG_GUMBEL_WORKERS overrides)
+    // workers per tree: two when the trees crowd the CUs, six when there are CUs to spare, ten for a handful of trees - a phase's
+    // dozen entries (expansion + leaf, see the kernel) then take two rounds instead of three: one tree 0.53 -> 0.55 M, 4 boards
+    // 1.55 -> 1.60 M, 16 boards 3.60 -> 3.65 M leaf evaluations/s; fifteen: no better (TG_GUMBEL_WORKERS overrides)
     static const int workers_env = tg::knob("TG_GUMBEL_WORKERS") ? atoi(tg::knob("TG_GUMBEL_WORKERS")) : 0;
-    const int workers = workers_env ? workers_env : (s->dev.T <= 128 ? 6 : 2);
+    const int workers = workers_env ? workers_env : (s->dev.T <= 28 ? 10 : (s->dev.T <= 128 ? 6 : 2));
     const bool gpipe = s->S == 9 && !force_serial && limit <= kPipeMaxK / 2 && D.N <= (1 << 21);   // (paths as node << 10 | edge)
+    SearchDev Dk = D;
+    Dk.gumbel_one_by_one = tg::knob("TG_GUMBEL_ONE_BY_ONE") ? 1 : 0;           // (read per call: a test toggles it)
     if (gpipe && workers == 15)
-        hipLaunchKernelGGL((select_gumbel_pipe_kernel<9, 15>), dim3(T), dim3(64 * 16), 0, st, D, nc_dev, mc_dev, limit, off, planes_dev);
+        hipLaunchKernelGGL((select_gumbel_pipe_kernel<9, 15>), dim3(T), dim3(64 * 16), 0, st, Dk, nc_dev, mc_dev, limit, off, planes_dev);
     else if (gpipe && workers == 10)
-        hipLaunchKernelGGL((select_gumbel_pipe_kernel<9, 10>), dim3(T), dim3(64 * 11), 0, st, D, nc_dev, mc_dev, limit, off, planes_dev);
+        hipLaunchKernelGGL((select_gumbel_pipe_kernel<9, 10>), dim3(T), dim3(64 * 11), 0, st, Dk, nc_dev, mc_dev, limit, off, planes_dev);
     else if (gpipe && workers == 6)
-        hipLaunchKernelGGL((select_gumbel_pipe_kernel<9, 6>), dim3(T), dim3(64 * 7), 0, st, D, nc_dev, mc_dev, limit, off, planes_dev);
+        hipLaunchKernelGGL((select_gumbel_pipe_kernel<9, 6>), dim3(T), dim3(64 * 7), 0, st, Dk, nc_dev, mc_dev, limit, off, planes_dev);
     else if (gpipe && workers == 4)
-        hipLaunchKernelGGL((select_gumbel_pipe_kernel<9, 4>), dim3(T), dim3(64 * 5), 0, st, D, nc_dev, mc_dev, limit, off, planes_dev);
+        hipLaunchKernelGGL((select_gumbel_pipe_kernel<9, 4>), dim3(T), dim3(64 * 5), 0, st, Dk, nc_dev, mc_dev, limit, off, planes_dev);
     else if (gpipe)
-        hipLaunchKernelGGL((select_gumbel_pipe_kernel<9, 2>), dim3(T), dim3(192), 0, st, D, nc_dev, mc_dev, limit, off, planes_dev);
+        hipLaunchKernelGGL((select_gumbel_pipe_kernel<9, 2>), dim3(T), dim3(192), 0, st, Dk, nc_dev, mc_dev, limit, off, planes_dev);
     else if (s->S == 9)
-        hipLaunchKernelGGL(select_gumbel_kernel<9>, dim3(T), dim3(64), 0, st, D, nc_dev, mc_dev, limit, off, planes_dev);
+        hipLaunchKernelGGL(select_gumbel_kernel<9>, dim3(T), dim3(64), 0, st, Dk, nc_dev, mc_dev, limit, off, planes_dev);
     else if (s->S == 13)
-        hipLaunchKernelGGL(select_gumbel_kernel<13>, dim3(T), dim3(64), 0, st, D, nc_dev, mc_dev, limit, off, planes_dev);
+        hipLaunchKernelGGL(select_gumbel_kernel<13>, dim3(T), dim3(64), 0, st, Dk, nc_dev, mc_dev, limit, off, planes_dev);
     else
-        hipLaunchKernelGGL(select_gumbel_kernel<19>, dim3(T), dim3(64), 0, st, D, nc_dev, mc_dev, limit, off, planes_dev);
+        hipLaunchKernelGGL(select_gumbel_kernel<19>, dim3(T), dim3(64), 0, st, Dk, nc_dev, mc_dev, limit, off, planes_dev);
     TG_HIP(hipGetLastError());
     return TG_OK;
 }

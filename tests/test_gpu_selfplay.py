@@ -110,23 +110,29 @@ def test_one_call_per_move_path_equals_the_phase_by_phase_path(tmp_path):
 
 
 def test_gumbel_kernel_variants_write_the_same_games():
-    """select_gumbel_pipe_kernel with two, four and six workers per tree (six is the default up to 128 trees; the
-    repeated descents of a phase are shared out among the workers) and the one-wavefront kernel
+    """select_gumbel_pipe_kernel with two, four, six and ten workers per tree (ten is the default up to 28 trees, six up to
+    128; every wave walks its share of a phase's root children, a worker takes whole entries: expansion, the step into the new
+    node, the leaf and its repeats), the same kernel with every entry sent one by one through its job ring - what a phase with
+    a path longer than the per-entry buffers does (TG_GUMBEL_ONE_BY_ONE=1) - and the one-wavefront kernel
     (TG_SELECT_SERIAL=1) play byte-identical games: 8 lock-step boards, 64 simulations per move."""
     import subprocess
     import sys
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_gumbel_games.py")
     outs = []
-    for variant in ("serial", "2", "4", "6"):
+    for variant in ("serial", "2", "4", "6", "10", "one-by-one", "one-by-one 2"):
         env = dict(os.environ)
-        env.pop("TG_SELECT_SERIAL", None)
-        env.pop("TG_GUMBEL_WORKERS", None)
+        for k in ("TG_SELECT_SERIAL", "TG_GUMBEL_WORKERS", "TG_GUMBEL_ONE_BY_ONE"):
+            env.pop(k, None)
         if variant == "serial":
             env["TG_SELECT_SERIAL"] = "1"
+        elif variant.startswith("one-by-one"):
+            env["TG_GUMBEL_ONE_BY_ONE"] = "1"
+            if variant.endswith(" 2"):
+                env["TG_GUMBEL_WORKERS"] = "2"
         else:
             env["TG_GUMBEL_WORKERS"] = variant
         res = subprocess.run([sys.executable, script, "8", "12", "64"], env=env, capture_output=True, text=True, timeout=900)
-        assert res.returncode == 0, res.stderr[-2000:]
+        assert res.returncode == 0, (variant, res.stderr[-2000:])
         outs.append(res.stdout.strip().splitlines()[-1])
     assert len(set(outs)) == 1, outs
 

@@ -33,5 +33,7 @@ names = {0: "set-up (root into registers, ranking)", 1: "root choices of the pha
 print(f"selector wave, ticks per phase over {ph} phases ({cyc[6]/ph:.1f} first descents per phase; the repeats are the workers')")
 for i, nm in names.items():
     print(f"  {nm:50s} {cyc[i]/ph:9.0f}")
-print(f"  {cyc[12]} launches: threshold levels per launch {cyc[13]/max(cyc[12],1):.1f}, walked one by one {cyc[11]/max(cyc[12],1):.1f}; width {cyc[14]/max(cyc[12],1):.1f}")
+L = max(cyc[12], 1)
+print(f"  {cyc[12]} launches, {cyc[14]/L:.1f} threshold levels walked one by one per launch")
+print(f"first worker wave, ticks per launch: waiting for the selector's go {cyc[9]/L:.0f}, its entries {cyc[10]/L:.0f}, scheduled copies {cyc[11]/L:.0f}; kernel start to its end {cyc[13]/L:.0f}")
 print(f"  per first descent {cyc[2]/max(cyc[6],1):.0f}; selector done after {cyc[15]/ph:.0f} ticks per phase")
