@@ -6246,7 +6246,11 @@ static int chain_begin(tg_selfplay *sp, tg_net *net, float *planes_dev, float *p
     // selection waits for it to end, with 8 CUs too few the forward pass waits for the selection): 32 boards 3.33 -> 3.57 M,
     // 48: 3.82 -> 4.16 M, 64: 4.09 -> 4.50 M, 96: 4.43 -> 4.72 M, 128: 4.62 -> 4.87 M, 192: 4.83 -> 4.97 M; 256: no gain.
     int G = 1, fwd_cap = 0;
-    if (T >= 4 && T <= 28) G = std::max(2, std::min(4, (T + 5) / 6));
+    // (re-measured when the selection launch got shorter - the workers take whole entries, round 6 -: three sub-groups beat four
+    // from 13 boards on - 20 boards 3.50 -> 4.01 M, 24: 3.95 -> 4.11 M, 28: 4.22 -> 4.41 M - and a forward cap pays from 24 boards:
+    // 24: 4.17 -> 4.25 M, 28: 4.46 -> 4.62 M; 8 / 12 boards: two sub-groups as before)
+    if (T >= 4 && T <= 12) G = 2;
+    else if (T > 12 && T <= 28) { G = 3; if (T >= 24) fwd_cap = s->num_cus - 32; }
     else if (T > 28 && T <= 96) { G = 2; fwd_cap = s->num_cus - std::max(32, T / 2); }
     else if (T > 96 && T <= 224) { G = 4; fwd_cap = s->num_cus - 32; }
     else if (T > 224 && T <= 384) { G = 2; fwd_cap = s->num_cus - 32; }     // (256 boards, one-axis forward kernel: 6.07 -> 6.30 M; 512: level)
