@@ -1076,21 +1076,28 @@ int tg_net_forward_dev(tg_net *net, const float *planes_dev, int batch, int want
         if (pick_split()) {
             // split-operand kernel (one board per workgroup, residual image in the per-stream scratch), the exact
             // fp32 Winograd kernel behind it as the range-guard fallback - as at 9x9 below
-            int *flag = nullptr;
+            int *flag = nullptr, *flag_next = nullptr;
             {
                 std::lock_guard<std::mutex> lock(net->scratch_mu);
                 int *&slot = net->flag_by_stream[st];
-                // [range flag, group tickets, sequence numbers of the banded kernel: exchange + gather, one per workgroup each]
-                if (!slot) TG_HIP(hipMalloc(reinterpret_cast<void **>(&slot), (2 + kBandFlagInts) * sizeof(int)));
-                flag = slot;
+                // [range flag, second word] x 2 (the pair kernel's launches alternate between the two sets, as at 9x9 below), then
+                // [range flag, -, sequence numbers of the banded direct kernel: exchange + gather, one per workgroup each]
+                if (!slot) {
+                    TG_HIP(hipMalloc(reinterpret_cast<void **>(&slot), (4 + 2 + kBandFlagInts) * sizeof(int)));
+                    TG_HIP(hipMemsetAsync(slot, 0, (4 + 2 + kBandFlagInts) * sizeof(int), st));
+                }
+                const unsigned seq = net->flag_seq_by_stream[st]++;
+                flag = slot + 2 * (seq & 1u);
+                flag_next = slot + 2 * ((seq + 1u) & 1u);
+                if (!pick_w1dband(net)) flag = slot + 4;
             }
             if (pick_w1dband(net)) {
                 int *bits = nullptr;
                 if (int rc = group_bits_for(net, st, batch, &bits)) return rc;
-                TG_HIP(hipMemsetAsync(flag, 0, 2 * sizeof(int), st));
+                if (tg::knob("TG_FWD_FLAG_MEMSET")) TG_HIP(hipMemsetAsync(flag, 0, 2 * sizeof(int), st));   // (experiments: the node back)
                 int rc = tg::w1dband_forward(net, planes_dev, batch, want_logits, policy_dev, value_dev, flag, bits, st);
                 if (rc) return rc;
-                return launch_wino8<19, 1, true>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st, flag, bits);
+                return launch_wino8<19, 1, true>(net, planes_dev, batch, want_logits, policy_dev, value_dev, st, flag, bits, flag_next);
             }
             const int bands = tg::band_count(net, batch);
             TG_HIP(hipMemsetAsync(flag, 0, (bands ? 2 + kBandFlagInts : 2) * sizeof(int), st));

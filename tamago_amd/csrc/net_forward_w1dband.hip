@@ -843,6 +843,15 @@ __global__ __launch_bounds__(256, 1) void dualnet_fwd_w1dband_kernel(
 //   * small launches (one tree's mini-batch): dualnet_heads19_part_kernel - one workgroup per (board, quarter), partial sums to
 //     global memory - then dualnet_heads19_fin_kernel per board (sum, bias, softmaxes, value FC);
 //   * large launches: dualnet_heads19_kernel<16> - sixteen boards per workgroup share one pass over the matrix.
+// The band kernel's sequence numbers ([pair][band 2][16] ints behind each pair's exchange rows) must read zero when a launch
+// starts: the heads kernel queued behind a band launch - the band kernel is done with them by then - clears them for the stream's
+// NEXT launch (until round 6 a memset node over the whole 2.5 MB exchange area in front of every launch: 5 us + its gap, a
+// twentieth of a 64-board launch).
+__device__ __forceinline__ void wb_clear_seq(int *seq, int n_pairs, int block, int blocks, int tid) {
+    if (seq == nullptr || tid >= 32) return;
+    for (int p = block; p < n_pairs; p += blocks) seq[(size_t)p * WbCfg::PAIR_FLOATS + tid] = 0;
+}
+
 __global__ __launch_bounds__(384) void dualnet_heads19_part_kernel(NetDev net, const float *__restrict__ feat, float *__restrict__ part) {
     constexpr int P = 361, A = 362;
     __shared__ float f[184];
@@ -860,11 +869,12 @@ __global__ __launch_bounds__(384) void dualnet_heads19_part_kernel(NetDev net, c
 }
 
 __global__ __launch_bounds__(128) void dualnet_heads19_fin_kernel(NetDev net, const float *__restrict__ feat, const float *__restrict__ part, int want_logits,
-                                                                  float *__restrict__ policy, float *__restrict__ value) {
+                                                                  float *__restrict__ policy, float *__restrict__ value, int *__restrict__ seq, int n_seq) {
     constexpr int P = 361, A = 362;
     __shared__ float lg[A + 6];
     __shared__ float red[4];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    wb_clear_seq(seq, n_seq, blockIdx.x, gridDim.x, tid);
     float m = -INFINITY;
     for (int a = tid; a < A; a += 128) {
         const float *p = part + (size_t)b * 4 * 384 + a;
@@ -908,12 +918,13 @@ __global__ __launch_bounds__(128) void dualnet_heads19_fin_kernel(NetDev net, co
 
 template <int TB>
 __global__ __launch_bounds__(384) void dualnet_heads19_kernel(NetDev net, const float *__restrict__ feat, int batch, int want_logits,
-                                                              float *__restrict__ policy, float *__restrict__ value) {
+                                                              float *__restrict__ policy, float *__restrict__ value, int *__restrict__ seq, int n_seq) {
     constexpr int P = 361, A = 362;
     __shared__ __attribute__((aligned(16))) float f[TB][3 * P + 1];     // (row stride 1 084 floats: a multiple of four)
     __shared__ float lg[TB][A + 2];
     __shared__ float vl[TB][4];
     const int tid = threadIdx.x, b0 = blockIdx.x * TB;
+    wb_clear_seq(seq, n_seq, blockIdx.x, gridDim.x, tid);
     for (int e = tid; e < TB * 3 * P; e += 384) {
         const int bl = e / (3 * P), j = e - bl * 3 * P;
         f[bl][j] = b0 + bl < batch ? feat[(size_t)(b0 + bl) * 3 * P + j] : 0.f;
@@ -1045,6 +1056,7 @@ int w1dband_forward(tg_net *net, const float *planes, int batch, int want_logits
             void *d = nullptr;
             const int cap = batch < 1024 ? 1024 : batch;
             TG_HIP(hipMalloc(&d, (xfloats + (size_t)cap * 3 * C::P + (size_t)512 * 4 * 384) * sizeof(float)));
+            TG_HIP(hipMemsetAsync(d, 0, xfloats * sizeof(float), stream));      // (in the launching stream's order; from then on the heads kernels keep the sequence numbers at zero between launches)
             slot.mem = static_cast<float *>(d);
             slot.cap = cap;
         }
@@ -1063,8 +1075,9 @@ int w1dband_forward(tg_net *net, const float *planes, int batch, int want_logits
         net->band_stream = stream;
         net->band_recorded = true;
     }
-    // the sequence numbers start from zero in every launch
-    TG_HIP(hipMemsetAsync(xmem, 0, xfloats * sizeof(float), stream));
+    // (the sequence numbers start from zero in every launch: wb_clear_seq)
+    int *const seq = reinterpret_cast<int *>(xmem + 4 * C::XROW_FLOATS);
+    const int n_seq = net->num_cus / 2;
     if (tg::knob("TG_WB_TEST_MUTE")) TG_HIP(hipMemsetAsync(overflow + 1, 1, 1, stream));      // (tests: a non-zero second flag word mutes band 1)
     hipLaunchKernelGGL(kern, dim3(2 * pairs), dim3(C::NTHR), C::LDS_BYTES, stream, net->dev, planes, batch, feat, xmem, overflow, group_bits);
     TG_HIP(hipGetLastError());
@@ -1072,9 +1085,9 @@ int w1dband_forward(tg_net *net, const float *planes, int batch, int want_logits
         // partial sums [batch][4][384] behind the feature image
         float *part = feat + (size_t)batch * 3 * C::P;
         hipLaunchKernelGGL(dualnet_heads19_part_kernel, dim3(batch * 4), dim3(384), 0, stream, net->dev, feat, part);
-        hipLaunchKernelGGL(dualnet_heads19_fin_kernel, dim3(batch), dim3(128), 0, stream, net->dev, feat, part, want_logits, policy, value);
+        hipLaunchKernelGGL(dualnet_heads19_fin_kernel, dim3(batch), dim3(128), 0, stream, net->dev, feat, part, want_logits, policy, value, seq, n_seq);
     } else {
-        hipLaunchKernelGGL(dualnet_heads19_kernel<16>, dim3((batch + 15) / 16), dim3(384), 0, stream, net->dev, feat, batch, want_logits, policy, value);
+        hipLaunchKernelGGL(dualnet_heads19_kernel<16>, dim3((batch + 15) / 16), dim3(384), 0, stream, net->dev, feat, batch, want_logits, policy, value, seq, n_seq);
     }
     TG_HIP(hipGetLastError());
     return TG_OK;
