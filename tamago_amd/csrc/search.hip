@@ -2816,11 +2816,16 @@ __device__ int select_node_halving(Scratch &L, const SearchDev &D, int t, int no
     return best_i;
 }
 
-// ---- Gumbel / sequential-halving selection, pipelined like select_puct_pipe_kernel -----------
-// The selector walks (root: node.py:324-346, below: :349-361) and queues two kinds of jobs for
-// the workers: LEAF (replay the path, write the planes of leaf `plane_slot`) and EXPAND (replay,
-// expand the child it is about to enter - the selector then waits for exactly that job, because
-// it continues INTO the new node).  9x9 only (three LDS boards of 19x19 exceed the static limit).
+// ---- Gumbel / sequential-halving selection: one workgroup per tree, a selector wave + NW workers -----------
+// (root: node.py:324-346, below: :349-361).  Two modes inside one kernel:
+//  * the usual one (round 6; `la_*` below): the selector ranks the root and works out which root children the phase enters
+//    ("entries") and which descents repeat them; every wave walks its share of the entries; the selector numbers the new nodes;
+//    a worker takes whole entries - expansion, the step into the new node, the leaf and its repeats - off one board replay;
+//  * one by one, through the job ring of select_puct_pipe_kernel (any path longer than the per-entry buffers, or the test hook
+//    SearchDev::gumbel_one_by_one): the selector walks and queues LEAF (replay the path, write the planes of leaf `plane_slot`)
+//    and EXPAND jobs (replay, expand the child it is about to enter - it then waits for exactly that job, because it continues
+//    INTO the new node), the workers share the repeats out afterwards as plane copies.
+// 9x9 only (sized for 81-point boards; 13x13 / 19x19 run select_gumbel_kernel, one wavefront per tree).
 template <int S>
 struct HalvingScratch {
     double w1[Geo<S>::A + 7];
@@ -2842,11 +2847,11 @@ __global__ __launch_bounds__(64 * (1 + NW)) void select_gumbel_pipe_kernel(Searc
     // Leaves by root child.  ~100 descents of a phase go to 2..16 root children and all descents through one root
     // child end on the same leaf (nothing moves within a phase).  The root choices of the whole phase are simulated up
     // front (ballots on a copy of the counters): a root child's FIRST descent gets an entry f (rm_pos = its root child,
-    // rm_slot = its leaf slot), every later descent only `sched[leaf slot] = f`.  The selector then walks the first
-    // descents alone (LEAF jobs; rm_* completed: leaf, path, job).  When the ring has drained, the workers share
-    // the scheduled leaves out among themselves: queue entry, virtual losses of the path, planes copied from the
-    // first leaf's slot - no per-leaf work of the selector, which was the slowest wave of a phase (2.2 k cycles
-    // per repeated descent, 87 of 100).
+    // rm_slot = its leaf slot), every later descent only `sched[leaf slot] = f`.  Only the first descents are walked
+    // (rm_* completed: leaf, path); the scheduled leaves are written by the worker that holds the entry's board (one-by-one
+    // mode: shared out among the workers when the ring has drained - queue entry, virtual losses of the path, planes copied
+    // from the first leaf's slot) - no per-leaf work of the selector, which was the slowest wave of a phase (2.2 k cycles per
+    // repeated descent, 87 of 100).
     constexpr int kRootMemo = 24, kRootPath = 32;        // (a phase enters at most 16 + 1 root children)
     __shared__ int rm_pos[kRootMemo], rm_parent[kRootMemo], rm_edge[kRootMemo], rm_child[kRootMemo], rm_job[kRootMemo],
         rm_slot[kRootMemo], rm_depth[kRootMemo];
