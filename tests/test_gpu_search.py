@@ -218,6 +218,49 @@ def test_gumbel_packed_leaf_layout_equals_strided():
     assert a["children_visits"][0].sum() == 8 * 3 + 4 * 5 and a["children_visits"][2].sum() == 40
 
 
+@pytest.mark.parametrize("one_by_one", [False, True])
+def test_gumbel_phase_reports_a_full_node_pool(one_by_one, monkeypatch):
+    """A halving phase whose entries need more nodes than the pool has: the nodes that fit are handed out in entry order, the
+    launch reports "node pool full" (tree.py:418-420's "Tree is full" path is the caller's: grow and search again) - in the usual
+    mode (node numbers handed out by lanes) and one by one through the job ring (TG_GUMBEL_ONE_BY_ONE); a pool that fits gives
+    the same tree in both modes."""
+    import torch
+    from oracle.stubnet import StubNet
+    from tamago_amd.board.go_board import GoBoard
+    from tamago_amd.lib import TamagoHipError
+    from tamago_amd.mcts.engine import SearchEngine, HostEvaluator
+    if one_by_one:
+        monkeypatch.setenv("TG_GUMBEL_ONE_BY_ONE", "1")
+    else:
+        monkeypatch.delenv("TG_GUMBEL_ONE_BY_ONE", raising=False)
+
+    def run(tree_size):
+        eng = SearchEngine(9, 2, tree_size, 48, HostEvaluator(StubNet(6), torch.device("cuda:0")))
+        for t in range(2):
+            eng.set_root(t, GoBoard(9), 1, np.random.RandomState(70 + t).get_state())
+        eng.root_eval(use_logit=True)
+        eng.set_gumbel_noise()
+        eng.gumbel_phase([16, 8], [1, 2])
+        eng.gumbel_phase([8, 8], [3, 4])
+        stats = eng.read_root_stats()
+        nodes = eng.num_nodes()
+        eng.close()
+        return stats, nodes
+
+    stats, nodes = run(64)
+    assert nodes[0] == 1 + 8 and nodes[1] == 1 + 8           # a root child's node is made by the first descent that finds it visited
+    assert stats["children_visits"][0].sum() == 16 + 24 and stats["children_visits"][1].sum() == 16 + 32
+    if one_by_one:
+        monkeypatch.delenv("TG_GUMBEL_ONE_BY_ONE")
+        usual, usual_nodes = run(64)
+        assert np.array_equal(nodes, usual_nodes)
+        for key in stats:
+            assert np.array_equal(stats[key], usual[key]), key
+        monkeypatch.setenv("TG_GUMBEL_ONE_BY_ONE", "1")
+    with pytest.raises(TamagoHipError, match="node pool full"):
+        run(6)                                                   # either tree wants 9 nodes
+
+
 def test_library_streams_equal_host_streams():
     """The library-owned legacy streams (tg_search_seed_stream / feed / advance / draw_noise) and
     the numpy-side feed (ExpStream + tg_search_set_rng / rng_consumed / set_noise) give the same
