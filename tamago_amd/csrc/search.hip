@@ -2825,7 +2825,8 @@ __device__ int select_node_halving(Scratch &L, const SearchDev &D, int t, int no
 //    SearchDev::gumbel_one_by_one): the selector walks and queues LEAF (replay the path, write the planes of leaf `plane_slot`)
 //    and EXPAND jobs (replay, expand the child it is about to enter - it then waits for exactly that job, because it continues
 //    INTO the new node), the workers share the repeats out afterwards as plane copies.
-// 9x9 only (sized for 81-point boards; 13x13 / 19x19 run select_gumbel_kernel, one wavefront per tree).
+// 9x9 (2 / 6 / 10 workers) and 19x19 (2 / 4: a worker's board is 19 KB there); 13x13 runs select_gumbel_kernel, one wavefront
+// per tree.
 template <int S>
 struct HalvingScratch {
     double w1[Geo<S>::A + 7];
@@ -5151,6 +5152,7 @@ static int launch_gumbel_select(tg_search *s, const SearchDev &D, const int32_t 
     static const int workers_env = tg::knob("TG_GUMBEL_WORKERS") ? atoi(tg::knob("TG_GUMBEL_WORKERS")) : 0;
     const int workers = workers_env ? workers_env : (s->dev.T <= 28 ? 10 : (s->dev.T <= 128 ? 6 : 2));
     const bool gpipe = s->S == 9 && !force_serial && limit <= kPipeMaxK / 2 && D.N <= (1 << 21);   // (paths as node << 10 | edge)
+    const bool gpipe19 = s->S == 19 && !force_serial && limit <= kPipeMaxK / 2 && D.N <= (1 << 21);
     SearchDev Dk = D;
     Dk.gumbel_one_by_one = tg::knob("TG_GUMBEL_ONE_BY_ONE") ? 1 : 0;           // (read per call: a test toggles it)
     if (gpipe && workers == 15)
@@ -5163,6 +5165,10 @@ static int launch_gumbel_select(tg_search *s, const SearchDev &D, const int32_t 
         hipLaunchKernelGGL((select_gumbel_pipe_kernel<9, 4>), dim3(T), dim3(64 * 5), 0, st, Dk, nc_dev, mc_dev, limit, off, planes_dev);
     else if (gpipe)
         hipLaunchKernelGGL((select_gumbel_pipe_kernel<9, 2>), dim3(T), dim3(192), 0, st, Dk, nc_dev, mc_dev, limit, off, planes_dev);
+    else if (gpipe19 && workers >= 4)
+        hipLaunchKernelGGL((select_gumbel_pipe_kernel<19, 4>), dim3(T), dim3(64 * 5), 0, st, Dk, nc_dev, mc_dev, limit, off, planes_dev);
+    else if (gpipe19)
+        hipLaunchKernelGGL((select_gumbel_pipe_kernel<19, 2>), dim3(T), dim3(192), 0, st, Dk, nc_dev, mc_dev, limit, off, planes_dev);
     else if (s->S == 9)
         hipLaunchKernelGGL(select_gumbel_kernel<9>, dim3(T), dim3(64), 0, st, Dk, nc_dev, mc_dev, limit, off, planes_dev);
     else if (s->S == 13)
@@ -6259,6 +6265,9 @@ static int chain_begin(tg_selfplay *sp, tg_net *net, float *planes_dev, float *p
     else if (T > 28 && T <= 96) { G = 2; fwd_cap = s->num_cus - std::max(32, T / 2); }
     else if (T > 96 && T <= 224) { G = 4; fwd_cap = s->num_cus - 32; }
     else if (T > 224 && T <= 384) { G = 2; fwd_cap = s->num_cus - 32; }     // (256 boards, one-axis forward kernel: 6.07 -> 6.30 M; 512: level)
+    // (19x19: the pair kernel's launches follow each other across streams, net_device.h band_done - sub-groups only add launches:
+    // 16 boards x 100 simulations 0.53 -> 0.55 M, 64 boards 0.86 -> 0.91 M leaf evaluations/s as one group)
+    if (s->S == 19) { G = 1; fwd_cap = 0; }
     if (sub_env > 0) { G = sub_env; fwd_cap = 0; }
     if (tg::knob("TG_SP_FWD_CAP")) fwd_cap = atoi(tg::knob("TG_SP_FWD_CAP"));
     G = std::max(1, std::min(std::min(G, (int)tg_selfplay::kMaxSub), T));

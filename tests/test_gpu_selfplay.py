@@ -137,6 +137,30 @@ def test_gumbel_kernel_variants_write_the_same_games():
     assert len(set(outs)) == 1, outs
 
 
+def test_gumbel_kernel_variants_write_the_same_games_19x19():
+    """BOARD_SIZE = 19: select_gumbel_pipe_kernel<19> with four workers per tree (the default up to 128 trees) and two, the same
+    kernel one by one through its job ring, and the one-wavefront kernel play byte-identical games: 4 lock-step boards, 24
+    simulations per move."""
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_gumbel_games.py")
+    outs = []
+    for variant in ("serial", "4", "2", "one-by-one"):
+        env = dict(os.environ)
+        for k in ("TG_SELECT_SERIAL", "TG_GUMBEL_WORKERS", "TG_GUMBEL_ONE_BY_ONE"):
+            env.pop(k, None)
+        if variant == "serial":
+            env["TG_SELECT_SERIAL"] = "1"
+        elif variant == "one-by-one":
+            env["TG_GUMBEL_ONE_BY_ONE"] = "1"
+        else:
+            env["TG_GUMBEL_WORKERS"] = variant
+        res = subprocess.run([sys.executable, script, "4", "4", "24", "19"], env=env, capture_output=True, text=True, timeout=900)
+        assert res.returncode == 0, (variant, res.stderr[-2000:])
+        outs.append(res.stdout.strip().splitlines()[-1])
+    assert len(set(outs)) == 1, outs
+
+
 def test_13x13_selfplay_one_call_path_equals_the_phase_by_phase_path(tmp_path):
     """BOARD_SIZE = 13 (board/constant.py:4; built in round 6: board-size-generic tree kernels, the exact-fp32 forward kernel):
     a shard's games through the one-call chained path and through the phase-by-phase host path are the same files, and a game
