@@ -2825,8 +2825,7 @@ __device__ int select_node_halving(Scratch &L, const SearchDev &D, int t, int no
 //    SearchDev::gumbel_one_by_one): the selector walks and queues LEAF (replay the path, write the planes of leaf `plane_slot`)
 //    and EXPAND jobs (replay, expand the child it is about to enter - it then waits for exactly that job, because it continues
 //    INTO the new node), the workers share the repeats out afterwards as plane copies.
-// 9x9 (2 / 6 / 10 workers) and 19x19 (2 / 4: a worker's board is 19 KB there); 13x13 runs select_gumbel_kernel, one wavefront
-// per tree.
+// 9x9 (2 / 6 / 10 workers), 13x13 (2 / 6) and 19x19 (2 / 4: a worker's board is 19 KB there).
 template <int S>
 struct HalvingScratch {
     double w1[Geo<S>::A + 7];
@@ -4601,7 +4600,7 @@ int tg_search_select_puct(tg_search *s, int max_leaves, float *planes_dev, int32
     // the one-wavefront kernel (also used while the per-phase profile counters are on)
     static const bool force_serial = tg::knob("TG_SELECT_SERIAL") != nullptr;
     static const bool mpipe_prof = tg::knob("TG_MPIPE_PROF") != nullptr;     // phase counters of the multi-selector kernel
-    const bool pipelined = !force_serial && (!s->dev.prof || mpipe_prof) && max_leaves <= kPipeMaxK && s->S != 13;   // (13x13: the generic kernel)
+    const bool pipelined = !force_serial && (!s->dev.prof || mpipe_prof) && max_leaves <= kPipeMaxK;
     // few trees: the descents themselves are pipelined over four selector waves (+ four workers); with many
     // trees per CU the three-wave kernel keeps more trees resident
     static const int mpipe_max_trees = tg::knob("TG_SELECT_MPIPE_TREES") ? atoi(tg::knob("TG_SELECT_MPIPE_TREES")) : 256;
@@ -4615,18 +4614,21 @@ int tg_search_select_puct(tg_search *s, int max_leaves, float *planes_dev, int32
 #else
     const bool split_prof_ok = !s->dev.prof;
 #endif
-    if (pipelined && split && split_prof_ok && s->dev.T <= kXwMaxTrees && s->dev.N <= (1 << 21)) {
+    if (pipelined && split && split_prof_ok && s->S != 13 && s->dev.T <= kXwMaxTrees && s->dev.N <= (1 << 21)) {   // (13x13: no split instantiation)
         split_rc = s->S == 9 ? launch_split<9>(s, max_leaves, planes_dev, st) : launch_split<19>(s, max_leaves, planes_dev, st);
         if (split_rc < 0) return split_rc;
     }
     if (split_rc == TG_OK) {
         // launched
     } else if (pipelined && s->dev.T <= mpipe_max_trees) {
-        int rc = s->S == 9 ? launch_mpipe<9>(s->dev, max_leaves, planes_dev, st) : launch_mpipe<19>(s->dev, max_leaves, planes_dev, st);
+        int rc = s->S == 9 ? launch_mpipe<9>(s->dev, max_leaves, planes_dev, st)
+                           : (s->S == 13 ? launch_mpipe<13>(s->dev, max_leaves, planes_dev, st) : launch_mpipe<19>(s->dev, max_leaves, planes_dev, st));
         if (rc) return rc;
     } else if (pipelined) {
         if (s->S == 9)
             hipLaunchKernelGGL(select_puct_pipe_kernel<9>, dim3(s->dev.T), dim3(192), 0, st, s->dev, max_leaves, planes_dev);
+        else if (s->S == 13)
+            hipLaunchKernelGGL(select_puct_pipe_kernel<13>, dim3(s->dev.T), dim3(192), 0, st, s->dev, max_leaves, planes_dev);
         else
             hipLaunchKernelGGL(select_puct_pipe_kernel<19>, dim3(s->dev.T), dim3(192), 0, st, s->dev, max_leaves, planes_dev);
     } else if (s->S == 9)
@@ -5165,6 +5167,10 @@ static int launch_gumbel_select(tg_search *s, const SearchDev &D, const int32_t 
         hipLaunchKernelGGL((select_gumbel_pipe_kernel<9, 4>), dim3(T), dim3(64 * 5), 0, st, Dk, nc_dev, mc_dev, limit, off, planes_dev);
     else if (gpipe)
         hipLaunchKernelGGL((select_gumbel_pipe_kernel<9, 2>), dim3(T), dim3(192), 0, st, Dk, nc_dev, mc_dev, limit, off, planes_dev);
+    else if (s->S == 13 && !force_serial && limit <= kPipeMaxK / 2 && D.N <= (1 << 21) && workers >= 6)
+        hipLaunchKernelGGL((select_gumbel_pipe_kernel<13, 6>), dim3(T), dim3(64 * 7), 0, st, Dk, nc_dev, mc_dev, limit, off, planes_dev);
+    else if (s->S == 13 && !force_serial && limit <= kPipeMaxK / 2 && D.N <= (1 << 21))
+        hipLaunchKernelGGL((select_gumbel_pipe_kernel<13, 2>), dim3(T), dim3(192), 0, st, Dk, nc_dev, mc_dev, limit, off, planes_dev);
     else if (gpipe19 && workers >= 4)
         hipLaunchKernelGGL((select_gumbel_pipe_kernel<19, 4>), dim3(T), dim3(64 * 5), 0, st, Dk, nc_dev, mc_dev, limit, off, planes_dev);
     else if (gpipe19)

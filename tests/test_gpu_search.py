@@ -363,12 +363,13 @@ def test_search_with_callback_and_ponder():
     assert text.startswith("info move ") and text.endswith("\n")
 
 
-@pytest.mark.parametrize("cfg", ["9 24 64 4", "9 1 256 4", "19 6 32 4", "9 16 64 5"])
+@pytest.mark.parametrize("cfg", ["9 24 64 4", "9 1 256 4", "19 6 32 4", "9 16 64 5", "13 6 48 4"])
 def test_pipelined_selection_equals_serial(cfg):
     """The pipelined PUCT selection kernels - select_puct_mpipe_kernel (descents pipelined over several selector
     waves + board workers, the default up to 256 trees) and select_puct_pipe_kernel (selector + two workers per
     tree, for more trees; forced here with TG_SELECT_MPIPE_TREES=0) - build exactly the trees of the one-wavefront
-    kernel (TG_SELECT_SERIAL=1): ragged roots, superko, several mini-batches with a short last one."""
+    kernel (TG_SELECT_SERIAL=1): ragged roots, superko, several mini-batches with a short last one.  (13x13 has the two
+    pipelined kernels, no split instantiation: the "split" variants run the default there.)"""
     import os
     import subprocess
     import sys

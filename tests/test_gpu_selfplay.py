@@ -137,15 +137,16 @@ def test_gumbel_kernel_variants_write_the_same_games():
     assert len(set(outs)) == 1, outs
 
 
-def test_gumbel_kernel_variants_write_the_same_games_19x19():
-    """BOARD_SIZE = 19: select_gumbel_pipe_kernel<19> with four workers per tree (the default up to 128 trees) and two, the same
-    kernel one by one through its job ring, and the one-wavefront kernel play byte-identical games: 4 lock-step boards, 24
-    simulations per move."""
+@pytest.mark.parametrize("size,workers", [(13, ("6", "2")), (19, ("4", "2"))])
+def test_gumbel_kernel_variants_write_the_same_games_on_larger_boards(size, workers):
+    """BOARD_SIZE = 13 / 19: select_gumbel_pipe_kernel with its two worker counts per tree (six / four are the defaults up to
+    128 trees), the same kernel one by one through its job ring, and the one-wavefront kernel play byte-identical games: 4
+    lock-step boards, 24 simulations per move."""
     import subprocess
     import sys
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_gumbel_games.py")
     outs = []
-    for variant in ("serial", "4", "2", "one-by-one"):
+    for variant in ("serial",) + workers + ("one-by-one",):
         env = dict(os.environ)
         for k in ("TG_SELECT_SERIAL", "TG_GUMBEL_WORKERS", "TG_GUMBEL_ONE_BY_ONE"):
             env.pop(k, None)
@@ -155,7 +156,7 @@ def test_gumbel_kernel_variants_write_the_same_games_19x19():
             env["TG_GUMBEL_ONE_BY_ONE"] = "1"
         else:
             env["TG_GUMBEL_WORKERS"] = variant
-        res = subprocess.run([sys.executable, script, "4", "4", "24", "19"], env=env, capture_output=True, text=True, timeout=900)
+        res = subprocess.run([sys.executable, script, "4", "4", "24", str(size)], env=env, capture_output=True, text=True, timeout=900)
         assert res.returncode == 0, (variant, res.stderr[-2000:])
         outs.append(res.stdout.strip().splitlines()[-1])
     assert len(set(outs)) == 1, outs
