@@ -5171,7 +5171,7 @@ static int launch_gumbel_select(tg_search *s, const SearchDev &D, const int32_t 
         hipLaunchKernelGGL((select_gumbel_pipe_kernel<13, 6>), dim3(T), dim3(64 * 7), 0, st, Dk, nc_dev, mc_dev, limit, off, planes_dev);
     else if (s->S == 13 && !force_serial && limit <= kPipeMaxK / 2 && D.N <= (1 << 21))
         hipLaunchKernelGGL((select_gumbel_pipe_kernel<13, 2>), dim3(T), dim3(192), 0, st, Dk, nc_dev, mc_dev, limit, off, planes_dev);
-    else if (gpipe19 && workers >= 4)
+    else if (gpipe19 && (workers >= 4 || !workers_env))           // (a 19x19 workgroup has its CU to itself with two workers as well: 256 boards 1.12 -> 1.17 M with four)
         hipLaunchKernelGGL((select_gumbel_pipe_kernel<19, 4>), dim3(T), dim3(64 * 5), 0, st, Dk, nc_dev, mc_dev, limit, off, planes_dev);
     else if (gpipe19)
         hipLaunchKernelGGL((select_gumbel_pipe_kernel<19, 2>), dim3(T), dim3(192), 0, st, Dk, nc_dev, mc_dev, limit, off, planes_dev);
