@@ -2872,6 +2872,11 @@ __global__ __launch_bounds__(64 * (1 + NW)) void select_gumbel_pipe_kernel(Searc
     // piece of work on one board replay, entry f on worker f mod NW; the selector queues nothing.  (One by one through the job
     // ring - EXPAND job, wait, step, LEAF job - the first descents were 60 k of the selector's 123 k cycles per phase.)
     __shared__ int la_go, la_fast, la_ndesc, la_xseq[kRootMemo];
+    // an entry's leaf position for its repeats, one byte per point (colour as the side to move sees it | 4: the previous move) +
+    // (pass plane, side): the repeats are shared out over ALL workers once their entry's leaf stands (the best root child's ~50
+    // repeats of a late phase were one worker's: 25 k of its 46 k cycles)
+    __shared__ uint8_t ent_code[kRootMemo][(G::P + 3) & ~3];
+    __shared__ int ent_meta[kRootMemo], ent_done[kRootMemo];
     constexpr int kWalkLeaf = 1, kWalkExpand = 2, kWalkDeep = 3, kWalkPoolFull = 4;
     const int t = blockIdx.x;
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -2882,6 +2887,7 @@ __global__ __launch_bounds__(64 * (1 + NW)) void select_gumbel_pipe_kernel(Searc
         sh.slot_done[threadIdx.x] = 0;
     }
     for (int i = threadIdx.x; i < kPipeMaxK / 32; i += NTHR) sh.done_bits[i] = 0u;
+    if (threadIdx.x < kRootMemo) ent_done[threadIdx.x] = 0;
     if (threadIdx.x == 0) {
         la_ready = 0; la_done = 0; la_n = 0; la_go = 0; la_fast = 0;
         sh.cursor_seq = 0;
@@ -3513,34 +3519,70 @@ __global__ __launch_bounds__(64 * (1 + NW)) void select_gumbel_pipe_kernel(Searc
                     const int my_entry = lane < depth ? rm_path[f][lane] : 0;
                     if (lane < depth && lane < kPathCap) D.q_path[qs * kPathCap + lane] = my_entry;
                     write_planes<S>(L, b, c, planes + (leaf_base + q) * 6 * G::P, lane);
-                    int n_through = 1;                                         // descents of the phase that end on this leaf
-                    // the later descents through this root child end on the same leaf (see `sched`): their queue entries,
-                    // virtual losses and planes right here, off the board this wave holds - stores only (as copies of the first
-                    // leaf's planes, shared out over the workers afterwards, they were a load round trip each and waited for the
-                    // slowest entry: 65 k cycles of a 160 k launch)
+                    // the later descents through this root child end on the same leaf (see `sched`): how many, for the virtual
+                    // losses (node.py:76-83 below the root: one per descent on every node and edge of the path - added once); the
+                    // position for whoever writes their queue entries and planes (below)
                     const int n_all = la_ndesc;
-                    for (int q0 = 0; q0 < n_all; q0 += 64) {
-                        unsigned long long m = __ballot(q0 + lane < n_all && sched[q0 + lane] == f);
-                        while (m) {
-                            const int q2 = q0 + __ffsll((long long)m) - 1;
-                            m &= m - 1;
-                            const size_t qs2 = (size_t)t * D.K + q2;
-                            if (lane == 0) {
-                                D.q_node[qs2] = child;
-                                D.q_pnode[qs2] = parent;
-                                D.q_pedge[qs2] = edge;
-                                D.q_depth[qs2] = (depth <= kPathCap && D.N <= (1 << 21)) ? depth : 0;
-                            }
-                            if (lane < depth && lane < kPathCap) D.q_path[qs2 * kPathCap + lane] = my_entry;
-                            write_planes<S>(L, b, c, planes + (leaf_base + q2) * 6 * G::P, lane);
-                            ++n_through;
-                        }
-                    }
-                    // node.py:76-83 below the root: one virtual loss per descent on every node and edge of the path - added once
+                    int n_through = 1;
+                    for (int q0 = 0; q0 < n_all; q0 += 64)
+                        n_through += __popcll(__ballot(q0 + lane < n_all && sched[q0 + lane] == f));
                     if (lane >= 1 && lane < depth) {
                         const size_t ns = (size_t)t * D.N + (my_entry >> 10);
                         atomicAdd(&D.node[ns].vl, n_through);
                         atomicAdd(&D.ch_vl[ns * A + (my_entry & 1023)], n_through);
+                    }
+                    {
+                        const bool pass_plane = b.moves > 1 && b.prev == 0;
+                        for (int pt = lane; pt < G::P; pt += 64) {
+                            const int p = (pt / S + 1) * G::W + (pt % S) + 1;
+                            int col = L.color[p];
+                            if (c == kWhite && col != 0) col = 3 - col;
+                            ent_code[f][pt] = (uint8_t)(col | ((!pass_plane && p == b.prev) ? 4 : 0));
+                        }
+                        if (lane == 0) {
+                            ent_meta[f] = (pass_plane ? 1 : 0) | (c == kWhite ? 2 : 0);
+                            rm_parent[f] = parent; rm_edge[f] = edge; rm_child[f] = child; rm_job[f] = -1; rm_depth[f] = depth;
+                        }
+                    }
+                    wave_sync();
+                    if (lane == 0) pipe_store(&ent_done[f], 1);
+                }
+                // the repeats, shared out over the workers: queue entry, path and planes of leaf slot q = those of its entry
+                const int n_rep = la_ndesc;
+                for (int q = wid - 1; q < n_rep; q += NW) {
+                    const int f = sched[q];
+                    if (f < 0) continue;
+                    if (la_res[f] != kWalkLeaf && la_res[f] != kWalkExpand) continue;
+                    bool there = false;
+                    for (int spin = 0; spin < kPipeSpinLimit; ++spin) {
+                        if (pipe_load(&ent_done[f])) { there = true; break; }
+                        if (pipe_load(&sh.err)) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    if (!there) {
+                        if (lane == 0) { atomicOr(&D.err[t], kErrPipeline); pipe_store(&sh.err, 1); }
+                        break;
+                    }
+                    const int depth = rm_depth[f];
+                    const size_t qs = (size_t)t * D.K + q;
+                    if (lane == 0) {
+                        D.q_node[qs] = rm_child[f];
+                        D.q_pnode[qs] = rm_parent[f];
+                        D.q_pedge[qs] = rm_edge[f];
+                        D.q_depth[qs] = (depth <= kPathCap && D.N <= (1 << 21)) ? depth : 0;
+                    }
+                    if (lane < depth && lane < kPathCap) D.q_path[qs * kPathCap + lane] = rm_path[f][lane];
+                    const int meta_f = ent_meta[f];
+                    const float pass_f = (meta_f & 1) ? 1.f : 0.f, side_f = (meta_f & 2) ? -1.f : 1.f;
+                    float *dst = planes + (leaf_base + q) * 6 * G::P;
+                    for (int pt = lane; pt < G::P; pt += 64) {
+                        const int code = ent_code[f][pt], col = code & 3;
+                        dst[pt] = col == 0 ? 1.f : 0.f;
+                        dst[G::P + pt] = col == 1 ? 1.f : 0.f;
+                        dst[2 * G::P + pt] = col == 2 ? 1.f : 0.f;
+                        dst[3 * G::P + pt] = (code & 4) ? 1.f : 0.f;
+                        dst[4 * G::P + pt] = pass_f;
+                        dst[5 * G::P + pt] = side_f;
                     }
                 }
                 if (wprof) wt3 = (long long)__builtin_amdgcn_s_memtime();
