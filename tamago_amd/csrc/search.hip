@@ -2820,7 +2820,8 @@ __device__ int select_node_halving(Scratch &L, const SearchDev &D, int t, int no
 // (root: node.py:324-346, below: :349-361).  Two modes inside one kernel:
 //  * the usual one (round 6; `la_*` below): the selector ranks the root and works out which root children the phase enters
 //    ("entries") and which descents repeat them; every wave walks its share of the entries; the selector numbers the new nodes;
-//    a worker takes whole entries - expansion, the step into the new node, the leaf and its repeats - off one board replay;
+//    a worker takes whole entries - expansion, the step into the new node, the leaf - off one board replay; the repeats of all
+//    entries are shared out over the workers;
 //  * one by one, through the job ring of select_puct_pipe_kernel (any path longer than the per-entry buffers, or the test hook
 //    SearchDev::gumbel_one_by_one): the selector walks and queues LEAF (replay the path, write the planes of leaf `plane_slot`)
 //    and EXPAND jobs (replay, expand the child it is about to enter - it then waits for exactly that job, because it continues
@@ -2848,8 +2849,8 @@ __global__ __launch_bounds__(64 * (1 + NW)) void select_gumbel_pipe_kernel(Searc
     // child end on the same leaf (nothing moves within a phase).  The root choices of the whole phase are simulated up
     // front (ballots on a copy of the counters): a root child's FIRST descent gets an entry f (rm_pos = its root child,
     // rm_slot = its leaf slot), every later descent only `sched[leaf slot] = f`.  Only the first descents are walked
-    // (rm_* completed: leaf, path); the scheduled leaves are written by the worker that holds the entry's board (one-by-one
-    // mode: shared out among the workers when the ring has drained - queue entry, virtual losses of the path, planes copied
+    // (rm_* completed: leaf, path); the scheduled leaves are shared out among the workers - queue entry, path, planes written
+    // from the entry's position code in LDS (one-by-one mode: when the ring has drained, virtual losses per leaf, planes copied
     // from the first leaf's slot) - no per-leaf work of the selector, which was the slowest wave of a phase (2.2 k cycles per
     // repeated descent, 87 of 100).
     constexpr int kRootMemo = 24, kRootPath = 32;        // (a phase enters at most 16 + 1 root children)
