@@ -5187,8 +5187,11 @@ int tg_search_debug_stream_walk(tg_search *s, const int64_t *steps, int n_steps,
 
 // D: the engine's device view or a slice of it (sub_dev: D.T trees from some tree on); the kernel variant goes by the
 // ENGINE's tree count (how crowded the CUs are)
+// `limit`: leaf slots per tree (the stride of the strided layout); `max_n`: the most descents any tree of this launch makes - what the
+// pipelined kernel's per-phase tables are sized against (until the end of round 6 `limit` stood in for it: a shard at 800
+// simulations per move - 800 slots, phases of ~200 descents - fell to the one-wavefront kernel, 0.96 instead of 3.4 M at 16 boards)
 static int launch_gumbel_select(tg_search *s, const SearchDev &D, const int32_t *nc_dev, const int32_t *mc_dev, const int32_t *off,
-                                int limit, float *planes_dev, hipStream_t st) {
+                                int limit, int max_n, float *planes_dev, hipStream_t st) {
     const int T = D.T;
     static const bool force_serial = tg::knob("TG_SELECT_SERIAL") != nullptr;
     // workers per tree: two when the trees crowd the CUs, six when there are CUs to spare, ten for a handful of trees - a phase's
@@ -5196,8 +5199,8 @@ static int launch_gumbel_select(tg_search *s, const SearchDev &D, const int32_t 
     // 1.55 -> 1.60 M, 16 boards 3.60 -> 3.65 M leaf evaluations/s; fifteen: no better (TG_GUMBEL_WORKERS overrides)
     static const int workers_env = tg::knob("TG_GUMBEL_WORKERS") ? atoi(tg::knob("TG_GUMBEL_WORKERS")) : 0;
     const int workers = workers_env ? workers_env : (s->dev.T <= 28 ? 10 : (s->dev.T <= 128 ? 6 : 2));
-    const bool gpipe = s->S == 9 && !force_serial && limit <= kPipeMaxK / 2 && D.N <= (1 << 21);   // (paths as node << 10 | edge)
-    const bool gpipe19 = s->S == 19 && !force_serial && limit <= kPipeMaxK / 2 && D.N <= (1 << 21);
+    const bool gpipe = s->S == 9 && !force_serial && max_n <= kPipeMaxK / 2 && D.N <= (1 << 21);   // (paths as node << 10 | edge)
+    const bool gpipe19 = s->S == 19 && !force_serial && max_n <= kPipeMaxK / 2 && D.N <= (1 << 21);
     SearchDev Dk = D;
     Dk.gumbel_one_by_one = tg::knob("TG_GUMBEL_ONE_BY_ONE") ? 1 : 0;           // (read per call: a test toggles it)
     if (gpipe && workers == 15)
@@ -5210,9 +5213,9 @@ static int launch_gumbel_select(tg_search *s, const SearchDev &D, const int32_t 
         hipLaunchKernelGGL((select_gumbel_pipe_kernel<9, 4>), dim3(T), dim3(64 * 5), 0, st, Dk, nc_dev, mc_dev, limit, off, planes_dev);
     else if (gpipe)
         hipLaunchKernelGGL((select_gumbel_pipe_kernel<9, 2>), dim3(T), dim3(192), 0, st, Dk, nc_dev, mc_dev, limit, off, planes_dev);
-    else if (s->S == 13 && !force_serial && limit <= kPipeMaxK / 2 && D.N <= (1 << 21) && workers >= 6)
+    else if (s->S == 13 && !force_serial && max_n <= kPipeMaxK / 2 && D.N <= (1 << 21) && workers >= 6)
         hipLaunchKernelGGL((select_gumbel_pipe_kernel<13, 6>), dim3(T), dim3(64 * 7), 0, st, Dk, nc_dev, mc_dev, limit, off, planes_dev);
-    else if (s->S == 13 && !force_serial && limit <= kPipeMaxK / 2 && D.N <= (1 << 21))
+    else if (s->S == 13 && !force_serial && max_n <= kPipeMaxK / 2 && D.N <= (1 << 21))
         hipLaunchKernelGGL((select_gumbel_pipe_kernel<13, 2>), dim3(T), dim3(192), 0, st, Dk, nc_dev, mc_dev, limit, off, planes_dev);
     else if (gpipe19 && (workers >= 4 || !workers_env))           // (a 19x19 workgroup has its CU to itself with two workers as well: 256 boards 1.12 -> 1.17 M with four)
         hipLaunchKernelGGL((select_gumbel_pipe_kernel<19, 4>), dim3(T), dim3(64 * 5), 0, st, Dk, nc_dev, mc_dev, limit, off, planes_dev);
@@ -5282,11 +5285,12 @@ int tg_search_select_gumbel(tg_search *s, const int32_t *num_considered_host, co
     const int ring = (int)(s->phase_seq % tg_search::kPhaseRing);
     if (s->phase_ev_used[ring]) TG_HIP(hipEventSynchronize(s->phase_ev[ring]));
     int32_t *phase_host = s->phase_pin + (size_t)ring * 3 * T;
-    int64_t total = 0;
+    int64_t total = 0, max_n = 0;
     for (int t = 0; t < T; ++t) {
         const int64_t n = (int64_t)num_considered_host[t] * max_count_host[t];
         if (num_considered_host[t] < 0 || max_count_host[t] < 0 || n > limit)
             return tg::fail(TG_ERR_ARG, "tg_search_select_gumbel: tree %d phase does not fit %d slots", t, limit);
+        max_n = n > max_n ? n : max_n;
         phase_host[t] = num_considered_host[t];
         phase_host[T + t] = max_count_host[t];
         phase_host[2 * (size_t)T + t] = (int32_t)total;
@@ -5311,7 +5315,7 @@ int tg_search_select_gumbel(tg_search *s, const int32_t *num_considered_host, co
     }
     s->packed_leaves = packed;
     const int32_t *off = packed ? s->phase_dev + 2 * (size_t)T : nullptr;
-    int rc = launch_gumbel_select(s, s->dev, s->phase_dev, s->phase_dev + T, off, limit, planes_dev, st);
+    int rc = launch_gumbel_select(s, s->dev, s->phase_dev, s->phase_dev + T, off, limit, (int)max_n, planes_dev, st);
     if (rc) return rc;
     return after_select(s, st);
 }
@@ -6158,6 +6162,7 @@ static int launch_phases_subgroups(tg_selfplay *sp, tg_net *net, int n_phases, i
     if (sp->phase_all_used[ring]) TG_HIP(hipEventSynchronize(sp->phase_all_ev[ring]));
     int32_t *tab = sp->phase_all_pin + (size_t)ring * kMaxPhases * 3 * T;
     int64_t counts[kMaxPhases][tg_selfplay::kMaxSub] = {};
+    int32_t most[kMaxPhases][tg_selfplay::kMaxSub] = {};               // the most descents a tree of the sub-group makes in the phase
     for (int ph = 0; ph < n_phases; ++ph) {
         const int32_t *nc = &sp->ph_nc[(size_t)ph * T], *mc = &sp->ph_mc[(size_t)ph * T];
         int32_t *row = tab + (size_t)ph * 3 * T;
@@ -6171,6 +6176,7 @@ static int launch_phases_subgroups(tg_selfplay *sp, tg_net *net, int n_phases, i
                 row[T + t] = mc[t];
                 row[2 * (size_t)T + t] = (int32_t)at;
                 at += n;
+                most[ph][g] = n > most[ph][g] ? (int32_t)n : most[ph][g];
             }
             counts[ph][g] = at - (int64_t)tb[g] * K;
         }
@@ -6197,7 +6203,7 @@ static int launch_phases_subgroups(tg_selfplay *sp, tg_net *net, int n_phases, i
             if (launched[g] == 1 && any_phase) TG_HIP(hipStreamWaitEvent(sg, s->ev_rng[s->rng_active], 0));   // second part of the window
             const SearchDev D = sub_dev(s, tb[g], tb[g + 1] - tb[g]);
             const int32_t *off = row + 2 * (size_t)T + tb[g];
-            if ((rc = launch_gumbel_select(s, D, row + tb[g], row + T + tb[g], off, K, planes_dev, sg))) return rc;
+            if ((rc = launch_gumbel_select(s, D, row + tb[g], row + T + tb[g], off, K, most[ph][g], planes_dev, sg))) return rc;
             if (launched[g] == 0) {
                 TG_HIP(hipEventRecord(sp->ev_first_sel[g], sg));
                 last_started = g;

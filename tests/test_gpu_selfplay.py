@@ -137,6 +137,26 @@ def test_gumbel_kernel_variants_write_the_same_games():
     assert len(set(outs)) == 1, outs
 
 
+def test_gumbel_kernels_agree_at_800_simulations():
+    """More than 512 leaf slots per tree (800 simulations per move) with phases of ~200 descents: the pipelined kernel is chosen
+    by the phases' sizes, not by the slot count (until the end of round 6 such a shard ran on the one-wavefront kernel), and
+    plays the one-wavefront kernel's games."""
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_gumbel_games.py")
+    outs = []
+    for variant in ("serial", "default"):
+        env = dict(os.environ)
+        for k in ("TG_SELECT_SERIAL", "TG_GUMBEL_WORKERS", "TG_GUMBEL_ONE_BY_ONE"):
+            env.pop(k, None)
+        if variant == "serial":
+            env["TG_SELECT_SERIAL"] = "1"
+        res = subprocess.run([sys.executable, script, "3", "3", "800"], env=env, capture_output=True, text=True, timeout=900)
+        assert res.returncode == 0, (variant, res.stderr[-2000:])
+        outs.append(res.stdout.strip().splitlines()[-1])
+    assert len(set(outs)) == 1, outs
+
+
 @pytest.mark.parametrize("size,workers", [(13, ("6", "2")), (19, ("4", "2"))])
 def test_gumbel_kernel_variants_write_the_same_games_on_larger_boards(size, workers):
     """BOARD_SIZE = 13 / 19: select_gumbel_pipe_kernel with its two worker counts per tree (six / four are the defaults up to
