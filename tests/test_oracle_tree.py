@@ -137,3 +137,70 @@ def test_random_draws_of_a_gumbel_phase_stay_inside_the_provisioned_window(visit
         np.random.seed(77 + game)
         tree = Counting(StubNet(3 + game), 9, tree_size=visits * 10 + 16, batch_size=max(visits, 1))
         tree.generate_move_with_sequential_halving(board, color, TimeManager(TimeControl.CONSTANT_PLAYOUT, visits), True)
+
+
+def test_root_choices_of_a_halving_phase_as_prefix_sums():
+    """What select_gumbel_pipe_kernel's selector relies on (csrc/search.hip, "the root choices of the phase"): node.py:324-346 picks,
+    for each of `width` descents of a threshold level, the first child in score order whose visits + virtual losses are under
+    the threshold (child 0 if none) - the scores do not move within a phase.  A level therefore hands its descents out greedily
+    in rank order: only the first `width` children under the threshold can take any, child i takes min(threshold - count_i,
+    what is left), the rest go to child 0; and once `width` children stand exactly at the threshold with nothing ranked before
+    the last of them able to come under a later one, every remaining level repeats itself.  One choice at a time against
+    that, on random counters."""
+    rs = np.random.RandomState(11)
+
+    def one_by_one(cnt, rank, width, levels):
+        cnt = cnt.copy()
+        picks = []
+        for th in range(1, levels + 1):
+            for _ in range(width):
+                under = [c for c in rank if cnt[c] < th]
+                c = under[0] if under else 0            # every score -10000: np.argmax returns child 0
+                cnt[c] += 1
+                picks.append(c)
+        return picks, cnt
+
+    def by_levels(cnt, rank, width, levels):
+        cnt = cnt.copy()
+        picks = []
+        th = 1
+        while th <= levels:
+            need = {c: max(0, th - cnt[c]) for c in rank}
+            under = [c for c in rank if need[c] > 0][:width]     # every child under takes at least one
+            left = width
+            takers = []
+            for c in under:
+                take = min(need[c], left)
+                if take <= 0:
+                    break
+                picks += [c] * take
+                cnt[c] += take
+                left -= take
+                takers.append(c)
+            picks += [0] * left
+            cnt[0] += left
+            th += 1
+            # steady state: `width` takers at the threshold, nothing ranked before the last of them can come under later
+            if left == 0 and len(takers) == width and th <= levels:
+                last = max(rank.index(c) for c in takers)
+                if all((cnt[c] == th - 1) if c in takers else (cnt[c] >= levels) for c in rank[:last + 1]):
+                    for _ in range(th, levels + 1):
+                        picks += takers
+                    for c in takers:
+                        cnt[c] += levels - th + 1
+                    break
+        return picks, cnt
+
+    for _ in range(400):
+        n = int(rs.randint(1, 83))
+        width = int(rs.randint(1, 17))
+        levels = int(rs.randint(1, 40))
+        rank = list(rs.permutation(n))
+        shape = rs.randint(0, 3)
+        cnt = (rs.randint(0, levels + 4, size=n) if shape == 0 else
+               rs.randint(0, 3, size=n) if shape == 1 else
+               np.where(rs.rand(n) < 0.2, rs.randint(0, levels + 1, size=n), levels + 5))
+        a, ca = one_by_one(cnt, rank, width, levels)
+        b, cb = by_levels(cnt, rank, width, levels)
+        assert a == b, (n, width, levels)
+        assert np.array_equal(ca, cb)
